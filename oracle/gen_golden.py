@@ -152,6 +152,8 @@ def _record_per_trace(name, capacity, alpha, beta_initial, beta_steps, has_dupli
             final_max_priority=np.float64(mem.max_priority),
             final_size=np.int64(mem.size),
             final_write=np.int64(mem.tree.write),
+            final_next_random=np.float64(random.random()),
+            script_uses_random=np.int64(name.startswith('speedtest')),
         )
         print(f"per_trace_{name}: {len(op_code)} ops, {len(pool_u)} uniforms, root={mem.tree.total():.6f}")
     finally:

@@ -1,0 +1,9 @@
+"""simple_distributed_rl_amd -- MI355X (gfx950) native actor-learner data path behind the
+SRL (pocokhc/simple_distributed_rl) Runner / Config / Worker / Trainer / Memory plugin surface.
+
+The compute path is hand-written HIP behind the C ABI of include/srlx.h (libsrlx.so); this
+package is the Python host that mirrors the reference's plugin interfaces.  There is no CPU
+fallback: using a device-backed class without the built library raises.
+"""
+
+__version__ = "0.1.0"

@@ -1,0 +1,113 @@
+"""ctypes binding of libsrlx.so (C ABI declared in include/srlx.h).
+
+The library is built in-tree by `python __graft_entry__.py` / `make -C simple_distributed_rl_amd/csrc`
+and is the ONLY implementation of the device path: a missing library is an error, never a fallback.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrlx.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNIFORMS_EXHAUSTED, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+PRIO_NONE, PRIO_F64, PRIO_F32, PRIO_RAW = 0, 1, 2, 3
+
+c_i64 = ctypes.c_int64
+c_f64 = ctypes.c_double
+c_int = ctypes.c_int
+c_p = ctypes.c_void_p
+
+
+class SrlxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"libsrlx error {status}: {message}")
+        self.status = status
+
+
+class UniformsExhausted(SrlxError):
+    pass
+
+
+# name -> (restype, argtypes); mirrors include/srlx.h one to one (tests/test_abi.py checks the set)
+SIGNATURES = {
+    "srlx_last_error": (ctypes.c_char_p, []),
+    "srlx_version": (c_int, []),
+    "srlx_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "srlx_device_info": (c_int, [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_i64)]),
+    "srlx_per_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_f64, c_f64, c_f64, c_int, c_f64, c_int]),
+    "srlx_per_destroy": (c_int, [c_p]),
+    "srlx_per_clear": (c_int, [c_p, c_p]),
+    "srlx_per_length": (c_i64, [c_p]),
+    "srlx_per_capacity": (c_i64, [c_p]),
+    "srlx_per_add": (c_int, [c_p, c_i64, c_p, c_int, c_int, c_p]),
+    "srlx_per_sample": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_int, c_p]),
+    "srlx_per_update": (c_int, [c_p, c_i64, c_p, c_p, c_int, c_int, c_p]),
+    "srlx_per_backup": (c_int, [c_p, ctypes.POINTER(c_f64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_p]),
+    "srlx_per_restore": (c_int, [c_p, c_f64, c_i64, c_i64, c_p]),
+    "srlx_per_restore_resized": (c_int, [c_p, c_i64, c_i64, c_p]),
+    "srlx_per_tree_ptr": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i64)]),
+    "srlx_per_state_ptr": (c_int, [c_p, ctypes.POINTER(c_p)]),
+    "srlx_per_refresh": (c_int, [c_p, c_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Loads libsrlx.so once.  Raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C simple_distributed_rl_amd/csrc`). "
+                "simple_distributed_rl_amd has no CPU fallback for the device path."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+        return L
+
+
+def check(status):
+    if status == OK:
+        return
+    msg = lib().srlx_last_error().decode("utf-8", "replace")
+    if status == ERR_UNIFORMS_EXHAUSTED:
+        raise UniformsExhausted(status, msg)
+    raise SrlxError(status, msg)
+
+
+def device_count():
+    n = c_int(0)
+    check(lib().srlx_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_info(device=0):
+    name = ctypes.create_string_buffer(64)
+    cu = c_int(0)
+    mem = c_i64(0)
+    check(lib().srlx_device_info(device, name, 64, ctypes.byref(cu), ctypes.byref(mem)))
+    return dict(arch=name.value.decode(), cu_count=cu.value, hbm_bytes=mem.value)
+
+
+def np_ptr(a):
+    return a.ctypes.data_as(c_p)
+
+
+def torch_stream_ptr():
+    """hipStream_t of torch's current stream (so srlx kernels order with torch ops)."""
+    import torch
+
+    return c_p(torch.cuda.current_stream().cuda_stream)

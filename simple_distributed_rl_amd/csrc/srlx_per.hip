@@ -1,0 +1,948 @@
+// srlx_per.hip -- GPU-resident proportional prioritized replay (sum-tree) for gfx950.
+//
+// Replaces srl/rl/memories/priority_memories/proportional_memory.py:13-205 (and its pybind11
+// twin cpp_module/src/proportional_memory.cpp) behind the C ABI of include/srlx.h.
+//
+// Data layout in HBM (one handle):
+//   buf   : (2N) float64, tree = buf + 1.  The reference's implicit heap (node i has children
+//           2i+1 / 2i+2, leaf slot j is node j+N-1).  The one-element offset makes every sibling
+//           pair (2i+1, 2i+2) one 16-byte aligned granule, so a descent step is ONE
+//           global_load_dwordx4 and the leaf priority comes with the last pair for free.
+//   state : { float64 max_priority; int64 size; int64 write; } -- lives on the device so that
+//           add/sample/update are HIP-graph capturable (no host-side scalars frozen at capture).
+//
+// Bit-exactness contract (SURVEY.md section 7 "hard parts"): the reference propagates fp64
+// deltas leaf->root per update, in call order (proportional_memory.py:49-54,81-86).  fp64 adds
+// do not re-associate, so every kernel below applies, for every tree node, exactly the
+// reference's sequence of `tree[node] += change_i` in list order i.  Parallelism comes from
+// processing different NODES concurrently, never from re-ordering one node's additions.
+// Compile with -ffp-contract=off (see Makefile): a fused multiply-add would change roundings.
+//
+// Kernels and their bounds (algorithmic bytes per unit; DESIGN.md has the derivation):
+//   per_sample : (depth+1)*8 B tree reads + 8 B uniform + 16 B out per draw  -> HBM/L2 bound
+//   per_update : 16 B leaf R/W + depth*16 B ancestor RMW per index           -> latency bound at B=32
+//   per_add    : same as update + 8 B priority                               -> root chain (n fp64 adds)
+#include <new>
+
+#include "srlx_common.h"
+
+namespace {
+
+using i64 = int64_t;
+using u64 = unsigned long long;
+
+struct PerState {
+    double max_priority;
+    i64 size;
+    i64 write;
+    i64 pad;
+};
+
+constexpr int kWgSample = 256;       // threads of the single-workgroup sample kernel
+constexpr i64 kSmallSampleMax = 8192;  // uniforms handled by the single-workgroup path
+constexpr int kWgUpdate = 256;
+constexpr int kUpdateChunk = 1024;   // indices per general-update launch (LDS resident)
+constexpr int kWgAdd = 256;
+constexpr i64 kSmallAddMax = 1024;   // adds handled by the single-workgroup path
+constexpr int kTopLevels = 13;       // levels of the tree staged in LDS by the bulk descent (8191 nodes, 64 KiB)
+
+__device__ __forceinline__ int node_depth(i64 x) { return 63 - __clzll((u64)(x + 1)); }
+
+// (|x|+eps)^alpha.  kind F64: numpy float64 semantics (sqrt fast path at 0.5 like np.power);
+// kind F32: the expression evaluated in float32 (numpy keeps a float32 array in float32,
+// proportional_memory.py:172), correctly rounded, then widened.
+__device__ __forceinline__ double transform_f64(double v, double eps, double alpha) {
+    double x = fabs(v) + eps;
+    if (alpha == 0.5) return __dsqrt_rn(x);
+    if (alpha == 1.0) return x;
+    return pow(x, alpha);
+}
+__device__ __forceinline__ double transform_f32(float v, double eps, double alpha) {
+    float x = fabsf(v) + (float)eps;
+    float a = (float)alpha;
+    if (a == 0.5f) return (double)__fsqrt_rn(x);
+    if (a == 1.0f) return (double)x;
+    return (double)(float)pow((double)x, (double)a);
+}
+__device__ __forceinline__ double load_prio(const void *prio, int kind, i64 i, double eps, double alpha,
+                                            double max_priority) {
+    switch (kind) {
+        case SRLX_PRIO_NONE: return max_priority;
+        case SRLX_PRIO_F64: return transform_f64(((const double *)prio)[i], eps, alpha);
+        case SRLX_PRIO_F32: return transform_f32(((const float *)prio)[i], eps, alpha);
+        default: return ((const double *)prio)[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// descent: proportional_memory.py:56-66 (_retrieve) + :88-92 (get)
+// `top` (LDS copy of tree[0..top_n)) may be null.  Sibling pairs are 16-byte aligned.
+// ------------------------------------------------------------------------------------------
+template <bool USE_TOP>
+__device__ __forceinline__ void descend(const double *__restrict__ tree, i64 tree_len, const double *top, i64 top_n,
+                                        double val, i64 &out_idx, double &out_p) {
+    i64 idx = 0;
+    double p = tree_len == 1 ? tree[0] : 0.0;
+    for (;;) {
+        i64 left = 2 * idx + 1;
+        if (left >= tree_len) break;
+        double l, r;
+        if (USE_TOP && left + 1 < top_n) {
+            l = top[left];
+            r = top[left + 1];
+        } else {
+            const double2 v = *reinterpret_cast<const double2 *>(tree + left);
+            l = v.x;
+            r = v.y;
+        }
+        if (val <= l) {
+            idx = left;
+            p = l;
+        } else {
+            val -= l;
+            idx = left + 1;
+            p = r;
+        }
+    }
+    out_idx = idx;
+    out_p = p;
+}
+
+__device__ __forceinline__ double beta_of(double beta_initial, double beta_steps, i64 step) {
+    // proportional_memory.py:138-140
+    double beta = beta_initial + ((1.0 - beta_initial) * (double)step) / beta_steps;
+    return beta > 1.0 ? 1.0 : beta;
+}
+
+// block-wide max of one double per thread (blockDim.x <= 1024, power of two)
+__device__ __forceinline__ double block_max(double v, double *red) {
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (t < s) red[t] = fmax(red[t], red[t + s]);
+        __syncthreads();
+    }
+    double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// block-wide exclusive scan of one int per thread; returns exclusive prefix, *total = sum
+__device__ __forceinline__ int block_exscan(int v, int *buf, int *total) {
+    const int t = threadIdx.x;
+    const int n = blockDim.x;
+    buf[t] = v;
+    __syncthreads();
+    for (int off = 1; off < n; off <<= 1) {
+        int add = (t >= off) ? buf[t - off] : 0;
+        __syncthreads();
+        buf[t] += add;
+        __syncthreads();
+    }
+    int incl = buf[t];
+    *total = buf[n - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+struct SampleArgs {
+    const double *tree;
+    i64 tree_len;
+    const PerState *state;
+    double beta_initial, beta_steps;
+    i64 step;
+    const i64 *d_step;
+    int has_duplicate;
+    const double *uniforms;
+    i64 n_uniforms;
+    i64 batch;
+    // scratch
+    i64 *cand_idx;
+    double *cand_p;
+    i64 *map;
+    double *wtmp;
+    // outputs
+    i64 *out_idx;
+    double *out_w;
+    float *out_w32;
+    i64 *out_used;
+};
+
+// ------------------------------------------------------------------------------------------
+// per_sample, single workgroup (the B=32/64 learner call): descent of every supplied uniform,
+// in-order acceptance (zero-priority and duplicate rejects consume a uniform each, :146-157),
+// prefix-sum compaction, IS weights and max-normalisation (:163-167) in ONE launch.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);                 // blockDim doubles
+    int *ibuf = reinterpret_cast<int *>(red + blockDim.x);          // blockDim ints
+    unsigned char *flags = reinterpret_cast<unsigned char *>(ibuf + blockDim.x);  // n_uniforms bytes
+
+    const int t = threadIdx.x, T = blockDim.x;
+    const i64 M = a.n_uniforms, B = a.batch;
+    const double total = a.tree[0];  // :135
+
+    // phase 1: one descent per uniform (coalesced uniform reads, strided assignment)
+    for (i64 j = t; j < M; j += T) {
+        i64 idx;
+        double p;
+        descend<false>(a.tree, a.tree_len, nullptr, 0, a.uniforms[j] * total, idx, p);  // :147-148
+        a.cand_idx[j] = idx;
+        a.cand_p[j] = p;
+    }
+    __syncthreads();
+
+    // phase 2: acceptance.  A draw is rejected if its leaf priority is 0 (:150-152) or, without
+    // duplicates, if an earlier non-zero draw already produced the same leaf (:155-156).
+    for (i64 j = t; j < M; j += T) {
+        bool ok = a.cand_p[j] != 0.0;
+        if (ok && !a.has_duplicate) {
+            const i64 me = a.cand_idx[j];
+            for (i64 k = 0; k < j; k++)
+                if (a.cand_idx[k] == me && a.cand_p[k] != 0.0) {
+                    ok = false;
+                    break;
+                }
+        }
+        flags[j] = ok ? 1 : 0;
+    }
+    __syncthreads();
+
+    // phase 3: ordered compaction.  Thread t owns the contiguous chunk [t*c, (t+1)*c).
+    const i64 c = (M + T - 1) / T;
+    const i64 lo = (i64)t * c, hi = (lo + c < M) ? lo + c : M;
+    int cnt = 0;
+    for (i64 j = lo; j < hi; j++) cnt += flags[j];
+    int total_ok;
+    int pos = block_exscan(cnt, ibuf, &total_ok);
+    for (i64 j = lo; j < hi; j++) {
+        if (flags[j]) {
+            if (pos < B) a.map[pos] = j;
+            if (pos == B - 1) *a.out_used = j + 1;  // uniforms consumed = index of the B-th accept + 1
+            pos++;
+        }
+    }
+    if (t == 0 && total_ok < B) *a.out_used = -1;
+    __syncthreads();
+    if (total_ok < B) return;
+
+    // phase 4: importance weights (:163-167)
+    const i64 step = a.d_step ? *a.d_step : a.step;
+    const double beta = beta_of(a.beta_initial, a.beta_steps, step);
+    const double size = (double)a.state->size;
+    double wmax_local = 0.0;
+    for (i64 i = t; i < B; i += T) {
+        const i64 j = a.map[i];
+        const double prob = a.cand_p[j] / total;
+        const double w = pow(size * prob, -beta);
+        a.wtmp[i] = w;
+        a.out_idx[i] = a.cand_idx[j];
+        wmax_local = fmax(wmax_local, w);
+    }
+    const double wmax = block_max(wmax_local, red);
+    for (i64 i = t; i < B; i += T) {
+        const double w = a.wtmp[i] / wmax;
+        if (a.out_w) a.out_w[i] = w;
+        if (a.out_w32) a.out_w32[i] = (float)w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per_sample, bulk path (thousands..millions of draws per launch: prefetching learners, the
+// PER micro-benchmark).  The top kTopLevels levels (64 KiB) are staged in LDS per workgroup;
+// the remaining levels are 16-byte pair loads.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_descend_bulk(SampleArgs a, u64 *zero_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *top = reinterpret_cast<double *>(smem);
+    const i64 top_cap = ((i64)1 << kTopLevels) - 1;
+    const i64 top_n = a.tree_len < top_cap ? a.tree_len : top_cap;
+    for (i64 k = threadIdx.x; k < top_n; k += blockDim.x) top[k] = a.tree[k];
+    __syncthreads();
+    const double total = top[0];
+    const i64 M = a.n_uniforms;
+    unsigned zeros = 0;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (i64)gridDim.x * blockDim.x) {
+        i64 idx;
+        double p;
+        descend<true>(a.tree, a.tree_len, top, top_n, a.uniforms[j] * total, idx, p);
+        a.cand_idx[j] = idx;
+        a.cand_p[j] = p;
+        zeros += (p == 0.0);
+    }
+    if (zeros) atomicAdd(zero_count, (u64)zeros);
+}
+
+// single workgroup: ordered compaction of the accepted draws.  Fast exit when nothing was rejected.
+__global__ void __launch_bounds__(1024) k_compact_bulk(SampleArgs a, const u64 *zero_count, int *identity) {
+    __shared__ int ibuf[1024];
+    const i64 M = a.n_uniforms, B = a.batch;
+    const int t = threadIdx.x, T = blockDim.x;
+    if (*zero_count == 0) {
+        if (t == 0) {
+            *identity = 1;
+            *a.out_used = (M >= B) ? B : -1;
+        }
+        return;
+    }
+    if (t == 0) *identity = 0;
+    i64 base = 0;
+    bool done = false;
+    for (i64 tile = 0; tile < M && !done; tile += T) {
+        const i64 j = tile + t;
+        const int ok = (j < M && a.cand_p[j] != 0.0) ? 1 : 0;
+        int tot;
+        const i64 pos = base + block_exscan(ok, ibuf, &tot);
+        if (ok && pos < B) {
+            a.map[pos] = j;
+            if (pos == B - 1) *a.out_used = j + 1;
+        }
+        base += tot;
+        done = base >= B;
+    }
+    if (t == 0 && base < B) *a.out_used = -1;
+}
+
+__global__ void __launch_bounds__(256) k_weights_bulk(SampleArgs a, const int *identity, u64 *wmax_bits) {
+    __shared__ double red[256];
+    const i64 B = a.batch;
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const double total = a.tree[0];
+    const i64 step = a.d_step ? *a.d_step : a.step;
+    const double beta = beta_of(a.beta_initial, a.beta_steps, step);
+    const double size = (double)a.state->size;
+    double w = 0.0;
+    if (i < B && *a.out_used >= 0) {
+        const i64 j = *identity ? i : a.map[i];
+        w = pow(size * (a.cand_p[j] / total), -beta);
+        a.wtmp[i] = w;
+        a.out_idx[i] = a.cand_idx[j];
+    }
+    const double m = block_max(w, red);
+    // positive doubles order like their bit patterns
+    if (threadIdx.x == 0 && m > 0.0) atomicMax(wmax_bits, (u64)__double_as_longlong(m));
+}
+
+__global__ void __launch_bounds__(256) k_normalise_bulk(SampleArgs a, const u64 *wmax_bits) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.batch || *a.out_used < 0) return;
+    const double wmax = __longlong_as_double((long long)*wmax_bits);
+    const double w = a.wtmp[i] / wmax;
+    if (a.out_w) a.out_w[i] = w;
+    if (a.out_w32) a.out_w32[i] = (float)w;
+}
+
+// ------------------------------------------------------------------------------------------
+// per_update, general indices (proportional_memory.py:171-177), one workgroup, n <= kUpdateChunk.
+//   1. p_i = transform(priority_i); change_i = p_i - (value the leaf holds when step i runs)
+//      -- a repeated index sees the earlier write of the same call (:173-175)
+//   2. the last occurrence of each leaf stores p_i
+//   3. every touched ancestor is owned by ONE thread which replays `node += change_i` for the
+//      contributing i in list order (the reference's _propagate order for that node)
+//   4. max_priority = max(max_priority, max_i p_i)  (:176-177)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_ancestor(i64 a, int da, i64 x, int dx) {
+    return dx > da && (((x + 1) >> (dx - da)) == a + 1);
+}
+
+__global__ void __launch_bounds__(kWgUpdate) k_update_wg(double *tree, i64 tree_len, PerState *state, i64 n,
+                                                          const i64 *indices, const void *prio, int kind, double eps,
+                                                          double alpha, int *err_flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *s_p = reinterpret_cast<double *>(smem);
+    double *s_chg = s_p + n;
+    double *red = s_chg + n;                                    // blockDim doubles
+    i64 *s_idx = reinterpret_cast<i64 *>(red + blockDim.x);     // n
+    int *s_dep = reinterpret_cast<int *>(s_idx + n);            // n
+    const int t = threadIdx.x, T = blockDim.x;
+    const double maxp0 = state->max_priority;
+
+    double pmax = 0.0;
+    for (i64 i = t; i < n; i += T) {
+        i64 x = indices[i];
+        if (x < 0 || x >= tree_len) {  // the reference would raise IndexError; flag and neutralise
+            *err_flag = 1;
+            x = 0;
+        }
+        const double p = load_prio(prio, kind, i, eps, alpha, maxp0);
+        s_p[i] = p;
+        s_idx[i] = x;
+        s_dep[i] = node_depth(x);
+        pmax = fmax(pmax, p);
+    }
+    __syncthreads();
+
+    bool last_me[ (kUpdateChunk + kWgUpdate - 1) / kWgUpdate ];
+    int q = 0;
+    for (i64 i = t; i < n; i += T, q++) {
+        const i64 x = s_idx[i];
+        i64 prev = -1;
+        for (i64 j = 0; j < i; j++)
+            if (s_idx[j] == x) prev = j;
+        bool last = true;
+        for (i64 j = i + 1; j < n; j++)
+            if (s_idx[j] == x) {
+                last = false;
+                break;
+            }
+        const double before = prev >= 0 ? s_p[prev] : tree[x];
+        s_chg[i] = s_p[i] - before;  // :83
+        last_me[q] = last;
+    }
+    __syncthreads();  // every old leaf value has been read
+    q = 0;
+    for (i64 i = t; i < n; i += T, q++)
+        if (last_me[q]) tree[s_idx[i]] = s_p[i];  // :85
+
+    // ancestors (:49-54).  task (i, k): the k-th ancestor of index i; the first i that reaches a
+    // node owns it.
+    int maxd = node_depth(tree_len - 1);
+    const i64 tasks = n * (i64)maxd;
+    for (i64 task = t; task < tasks; task += T) {
+        const i64 i = task / maxd;
+        const int k = (int)(task % maxd) + 1;
+        const int dx = s_dep[i];
+        if (k > dx) continue;
+        const int da = dx - k;
+        const i64 a = ((s_idx[i] + 1) >> k) - 1;
+        bool owner = true;
+        for (i64 j = 0; j < i; j++)
+            if (is_ancestor(a, da, s_idx[j], s_dep[j])) {
+                owner = false;
+                break;
+            }
+        if (!owner) continue;
+        double v = tree[a];
+        v += s_chg[i];
+        for (i64 j = i + 1; j < n; j++)
+            if (is_ancestor(a, da, s_idx[j], s_dep[j])) v += s_chg[j];
+        tree[a] = v;
+    }
+
+    const double m = block_max(pmax, red);
+    if (t == 0 && kind != SRLX_PRIO_NONE && maxp0 < m) state->max_priority = m;
+}
+
+// ------------------------------------------------------------------------------------------
+// per_add of n consecutive ring slots (proportional_memory.py:120-129, :71-79).
+// The batch covers at most 3 runs of tree nodes that are contiguous AND on one tree depth
+// (ring wrap-around x the two leaf depths of a non-power-of-two capacity).  Within a run the
+// leaves under an ancestor are a contiguous slice of the batch, so each ancestor is owned by
+// one thread that adds that slice in order; runs are processed in batch order.
+// ------------------------------------------------------------------------------------------
+struct Run {
+    i64 i_lo, i_hi;  // batch positions [i_lo, i_hi)
+    i64 x_lo;        // tree node of batch position i_lo
+    int dl;          // depth of the run's leaves
+};
+
+__device__ __forceinline__ int make_runs(i64 cap, i64 write, i64 n, Run runs[4]) {
+    const i64 tree_len = 2 * cap - 1;
+    const int D = node_depth(tree_len - 1);
+    const i64 first_deep = ((i64)1 << D) - 1;  // first node on the deepest level
+    const i64 sb = first_deep - (cap - 1);     // slots [0,sb) are one level up, [sb,cap) on level D
+    int nr = 0;
+    i64 done = 0;
+    // ring pieces in batch order: [write, min(write+n,cap)) then [0, write+n-cap)
+    for (int piece = 0; piece < 2; piece++) {
+        i64 s_lo = piece == 0 ? write : 0;
+        i64 s_hi = piece == 0 ? (write + n < cap ? write + n : cap) : (write + n - cap);
+        if (piece == 1 && write + n <= cap) break;
+        // split at sb
+        i64 cuts[3] = {s_lo, (sb > s_lo && sb < s_hi) ? sb : s_lo, s_hi};
+        for (int c = 0; c < 2; c++) {
+            const i64 a = cuts[c], b = cuts[c + 1];
+            if (b <= a) continue;
+            runs[nr].i_lo = done;
+            runs[nr].i_hi = done + (b - a);
+            runs[nr].x_lo = a + cap - 1;
+            runs[nr].dl = (a < sb) ? D - 1 : D;
+            done += b - a;
+            nr++;
+        }
+    }
+    return nr;
+}
+
+// number of ancestor nodes of a run
+__device__ __forceinline__ i64 run_tasks(const Run &r) {
+    const i64 x_hi = r.x_lo + (r.i_hi - r.i_lo) - 1;
+    i64 tot = 0;
+    for (int d = r.dl - 1; d >= 0; d--) tot += (((x_hi + 1) >> (r.dl - d)) - ((r.x_lo + 1) >> (r.dl - d))) + 1;
+    return tot;
+}
+
+// thread `tid` of `nthreads` processes its share of a run's ancestor nodes
+__device__ __forceinline__ void run_ancestors(double *tree, const double *chg, const Run &r, i64 tid, i64 nthreads) {
+    const i64 cnt = r.i_hi - r.i_lo;
+    const i64 x_hi = r.x_lo + cnt - 1;
+    const i64 tasks = run_tasks(r);
+    for (i64 task = tid; task < tasks; task += nthreads) {
+        i64 rem = task;
+        int d = r.dl - 1;
+        i64 a = 0;
+        for (; d >= 0; d--) {
+            const i64 a_lo = ((r.x_lo + 1) >> (r.dl - d)) - 1;
+            const i64 a_hi = ((x_hi + 1) >> (r.dl - d)) - 1;
+            const i64 c = a_hi - a_lo + 1;
+            if (rem < c) {
+                a = a_lo + rem;
+                break;
+            }
+            rem -= c;
+        }
+        const int s = r.dl - d;
+        i64 first = ((a + 1) << s) - 1, last = ((a + 2) << s) - 2;
+        if (first < r.x_lo) first = r.x_lo;
+        if (last > x_hi) last = x_hi;
+        const double *c0 = chg + r.i_lo + (first - r.x_lo);
+        const i64 m = last - first + 1;
+        double v = tree[a];
+        for (i64 k = 0; k < m; k++) v += c0[k];  // list order: the reference's propagate order
+        tree[a] = v;
+    }
+}
+
+struct AddArgs {
+    double *tree;
+    i64 cap;
+    PerState *state;
+    i64 n;
+    const void *prio;
+    int kind;
+    double eps, alpha;
+    double *chg;  // scratch, n doubles
+};
+
+__device__ __forceinline__ void add_leaf(const AddArgs &a, i64 i, i64 write, double maxp) {
+    i64 slot = write + i;
+    if (slot >= a.cap) slot -= a.cap;
+    const i64 x = slot + a.cap - 1;
+    const double p = load_prio(a.prio, a.kind, i, a.eps, a.alpha, maxp);
+    a.chg[i] = p - a.tree[x];
+    a.tree[x] = p;
+}
+
+__device__ __forceinline__ void add_commit(const AddArgs &a) {
+    PerState *s = a.state;
+    i64 w = s->write + a.n;
+    if (w >= a.cap) w -= a.cap;
+    s->write = w;
+    i64 z = s->size + a.n;
+    s->size = z > a.cap ? a.cap : z;
+}
+
+// n <= kSmallAddMax: everything in one launch
+__global__ void __launch_bounds__(kWgAdd) k_add_wg(AddArgs a) {
+    const int t = threadIdx.x, T = blockDim.x;
+    const i64 write = a.state->write;
+    const double maxp = a.state->max_priority;
+    for (i64 i = t; i < a.n; i += T) add_leaf(a, i, write, maxp);
+    __syncthreads();
+    Run runs[4];
+    const int nr = make_runs(a.cap, write, a.n, runs);
+    for (int r = 0; r < nr; r++) {
+        run_ancestors(a.tree, a.chg, runs[r], t, T);
+        __syncthreads();
+    }
+    if (t == 0) add_commit(a);
+}
+
+// bulk: leaf pass, then one ancestor launch per run (empty runs exit), then commit
+__global__ void __launch_bounds__(256) k_add_leaf_bulk(AddArgs a) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) add_leaf(a, i, a.state->write, a.state->max_priority);
+}
+__global__ void __launch_bounds__(256) k_add_anc_bulk(AddArgs a, int r) {
+    Run runs[4];
+    const int nr = make_runs(a.cap, a.state->write, a.n, runs);
+    if (r >= nr) return;
+    run_ancestors(a.tree, a.chg, runs[r], (i64)blockIdx.x * blockDim.x + threadIdx.x, (i64)gridDim.x * blockDim.x);
+}
+__global__ void k_add_commit(AddArgs a) { add_commit(a); }
+
+__global__ void k_state_init(PerState *s) {
+    s->max_priority = 1.0;
+    s->size = 0;
+    s->write = 0;
+    s->pad = 0;
+}
+__global__ void k_state_set(PerState *s, double mp, i64 size, i64 write) {
+    s->max_priority = mp;
+    s->size = size;
+    s->write = write;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// host side
+// ==========================================================================================
+struct srlx_per {
+    int device;
+    i64 capacity, tree_len;
+    double alpha, beta_initial, beta_steps, epsilon;
+    int has_duplicate;
+    double *d_buf;
+    double *d_tree;
+    PerState *d_state;
+    int *d_err;
+    hipStream_t stream;
+    i64 size, write;  // host mirror
+    srlx::Arena scratch;  // device
+    srlx::Arena staging;  // device copies of host-mode arguments / results
+    srlx::Arena pinned;   // pinned host
+};
+
+namespace {
+
+hipStream_t pick_stream(srlx_per *h, void *stream) { return stream ? (hipStream_t)stream : h->stream; }
+
+size_t prio_elem_bytes(int kind) { return kind == SRLX_PRIO_F32 ? 4 : 8; }
+
+int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st) {
+    SRLX_TRY(h->scratch.reserve(srlx::Carver::padded((size_t)n * 8)));
+    AddArgs a{h->d_tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr};
+    if (n <= kSmallAddMax) {
+        hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(kWgAdd), 0, st, a);
+    } else {
+        const int blocks = (int)((n + 255) / 256);
+        hipLaunchKernelGGL(k_add_leaf_bulk, dim3(blocks), dim3(256), 0, st, a);
+        // ~2n ancestor nodes; the root owner walks all n changes, so more threads do not help it
+        i64 anc_threads = 2 * n + 64;
+        int anc_blocks = (int)((anc_threads + 255) / 256);
+        if (anc_blocks > 2048) anc_blocks = 2048;
+        for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_add_anc_bulk, dim3(anc_blocks), dim3(256), 0, st, a, r);
+        hipLaunchKernelGGL(k_add_commit, dim3(1), dim3(1), 0, st, a);
+    }
+    SRLX_HIP(hipGetLastError());
+    // host mirror
+    h->write = (h->write + n) % h->capacity;
+    h->size = (h->size + n > h->capacity) ? h->capacity : h->size + n;
+    return SRLX_OK;
+}
+
+int launch_update(srlx_per *h, i64 n, const i64 *d_idx, const void *d_prio, int kind, hipStream_t st) {
+    const size_t eb = prio_elem_bytes(kind);
+    for (i64 off = 0; off < n; off += kUpdateChunk) {
+        const i64 m = (n - off < kUpdateChunk) ? n - off : kUpdateChunk;
+        const size_t lds = (size_t)m * (8 + 8 + 8 + 4) + (size_t)kWgUpdate * 8 + 16;
+        hipLaunchKernelGGL(k_update_wg, dim3(1), dim3(kWgUpdate), lds, st, h->d_tree, h->tree_len, h->d_state, m,
+                           d_idx + off, (const void *)((const char *)d_prio + (size_t)off * eb), kind, h->epsilon,
+                           h->alpha, h->d_err);
+    }
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+// scratch layout for sample
+struct SampleScratch {
+    i64 *cand_idx;
+    double *cand_p;
+    i64 *map;
+    double *wtmp;
+    u64 *counters;  // [0] zero_count, [1] wmax_bits, [2] identity (int)
+    static size_t bytes(i64 M, i64 B) {
+        using C = srlx::Carver;
+        return C::padded((size_t)M * 8) * 2 + C::padded((size_t)B * 8) * 2 + C::padded(64);
+    }
+};
+
+int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double *d_u, i64 M, i64 *d_idx, double *d_w,
+                  float *d_w32, i64 *d_used, hipStream_t st) {
+    SRLX_TRY(h->scratch.reserve(SampleScratch::bytes(M, B)));
+    srlx::Carver cv(h->scratch.ptr);
+    SampleArgs a{};
+    a.tree = h->d_tree;
+    a.tree_len = h->tree_len;
+    a.state = h->d_state;
+    a.beta_initial = h->beta_initial;
+    a.beta_steps = h->beta_steps;
+    a.step = step;
+    a.d_step = d_step;
+    a.has_duplicate = h->has_duplicate;
+    a.uniforms = d_u;
+    a.n_uniforms = M;
+    a.batch = B;
+    a.cand_idx = cv.take<i64>(M);
+    a.cand_p = cv.take<double>(M);
+    a.map = cv.take<i64>(B);
+    a.wtmp = cv.take<double>(B);
+    u64 *counters = cv.take<u64>(8);
+    a.out_idx = d_idx;
+    a.out_w = d_w;
+    a.out_w32 = d_w32;
+    a.out_used = d_used;
+
+    if (M <= kSmallSampleMax) {
+        const size_t lds = (size_t)kWgSample * (8 + 4) + (size_t)M + 16;
+        hipLaunchKernelGGL(k_sample_wg, dim3(1), dim3(kWgSample), lds, st, a);
+    } else {
+        if (!h->has_duplicate) {
+            srlx::set_error("per_sample: has_duplicate=False is limited to %lld uniforms per call", (long long)kSmallSampleMax);
+            return SRLX_ERR_UNSUPPORTED;
+        }
+        SRLX_HIP(hipMemsetAsync(counters, 0, 64, st));
+        int cu = 256;
+        i64 want = (M + 255) / 256;
+        int blocks = (int)(want < (i64)cu * 2 ? want : (i64)cu * 2);  // 64 KiB LDS each -> 2 per CU
+        const size_t lds = (size_t)(((i64)1 << kTopLevels) - 1) * 8 + 8;
+        hipLaunchKernelGGL(k_descend_bulk, dim3(blocks), dim3(256), lds, st, a, counters);
+        hipLaunchKernelGGL(k_compact_bulk, dim3(1), dim3(1024), 0, st, a, counters, (int *)(counters + 2));
+        const int wb = (int)((B + 255) / 256);
+        hipLaunchKernelGGL(k_weights_bulk, dim3(wb), dim3(256), 0, st, a, (const int *)(counters + 2), counters + 1);
+        hipLaunchKernelGGL(k_normalise_bulk, dim3(wb), dim3(256), 0, st, a, counters + 1);
+    }
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double beta_initial, double beta_steps,
+                    int has_duplicate, double epsilon, int device) {
+    SRLX_REQUIRE(out != nullptr, "per_create: out is NULL");
+    SRLX_REQUIRE(capacity > 0 && capacity <= ((i64)1 << 30), "per_create: capacity %lld out of range", (long long)capacity);
+    SRLX_REQUIRE(beta_steps != 0.0, "per_create: beta_steps must be non-zero");
+    int ndev = 0;
+    SRLX_HIP(hipGetDeviceCount(&ndev));
+    SRLX_REQUIRE(device >= 0 && device < ndev, "per_create: device %d not present (%d devices)", device, ndev);
+    srlx::DeviceGuard guard(device);
+    srlx_per *h = new (std::nothrow) srlx_per();
+    if (!h) return SRLX_ERR_NOMEM;
+    h->device = device;
+    h->capacity = capacity;
+    h->tree_len = 2 * capacity - 1;
+    h->alpha = alpha;
+    h->beta_initial = beta_initial;
+    h->beta_steps = beta_steps;
+    h->epsilon = epsilon;
+    h->has_duplicate = has_duplicate ? 1 : 0;
+    h->pinned.pinned_host = true;
+    h->size = h->write = 0;
+    h->d_buf = nullptr;
+    h->d_state = nullptr;
+    h->d_err = nullptr;
+    h->stream = nullptr;
+    hipError_t e = hipMalloc((void **)&h->d_buf, sizeof(double) * (size_t)(h->tree_len + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_state, sizeof(PerState));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_err, sizeof(int));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        srlx::set_error("per_create: %s", hipGetErrorString(e));
+        srlx_per_destroy(h);
+        return e == hipErrorOutOfMemory ? SRLX_ERR_NOMEM : SRLX_ERR_HIP;
+    }
+    h->d_tree = h->d_buf + 1;
+    *out = h;
+    int s = srlx_per_clear(h, nullptr);
+    if (s == SRLX_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SRLX_ERR_HIP;
+    if (s != SRLX_OK) {
+        srlx_per_destroy(h);
+        *out = nullptr;
+    }
+    return s;
+}
+
+int srlx_per_destroy(srlx_per_t *h) {
+    if (!h) return SRLX_OK;
+    srlx::DeviceGuard guard(h->device);
+    (void)hipDeviceSynchronize();
+    if (h->d_buf) (void)hipFree(h->d_buf);
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->d_err) (void)hipFree(h->d_err);
+    h->scratch.release();
+    h->staging.release();
+    h->pinned.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return SRLX_OK;
+}
+
+int srlx_per_clear(srlx_per_t *h, void *stream) {
+    SRLX_REQUIRE(h, "per_clear: NULL handle");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick_stream(h, stream);
+    SRLX_HIP(hipMemsetAsync(h->d_buf, 0, sizeof(double) * (size_t)(h->tree_len + 1), st));
+    SRLX_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, st, h->d_state);
+    SRLX_HIP(hipGetLastError());
+    h->size = h->write = 0;
+    return SRLX_OK;
+}
+
+int64_t srlx_per_length(const srlx_per_t *h) { return h ? h->size : -1; }
+int64_t srlx_per_capacity(const srlx_per_t *h) { return h ? h->capacity : -1; }
+
+int srlx_per_add(srlx_per_t *h, int64_t n, const void *prio, int prio_kind, int on_device, void *stream) {
+    SRLX_REQUIRE(h, "per_add: NULL handle");
+    SRLX_REQUIRE(n >= 0 && n <= h->capacity, "per_add: n=%lld must be in [0, capacity=%lld]", (long long)n,
+                 (long long)h->capacity);
+    SRLX_REQUIRE(prio_kind >= SRLX_PRIO_NONE && prio_kind <= SRLX_PRIO_RAW, "per_add: bad prio_kind %d", prio_kind);
+    SRLX_REQUIRE(prio_kind == SRLX_PRIO_NONE || prio != nullptr, "per_add: prio is NULL");
+    if (n == 0) return SRLX_OK;
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick_stream(h, stream);
+    if (on_device || prio_kind == SRLX_PRIO_NONE) return launch_add(h, n, prio, prio_kind, st);
+    const size_t bytes = (size_t)n * prio_elem_bytes(prio_kind);
+    SRLX_TRY(h->pinned.reserve(bytes));
+    SRLX_TRY(h->staging.reserve(bytes));
+    memcpy(h->pinned.ptr, prio, bytes);
+    SRLX_HIP(hipMemcpyAsync(h->staging.ptr, h->pinned.ptr, bytes, hipMemcpyHostToDevice, st));
+    SRLX_TRY(launch_add(h, n, h->staging.ptr, prio_kind, st));
+    SRLX_HIP(hipStreamSynchronize(st));
+    return SRLX_OK;
+}
+
+int srlx_per_sample(srlx_per_t *h, int64_t batch_size, int64_t step, const int64_t *d_step, const double *uniforms,
+                    int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used,
+                    int on_device, void *stream) {
+    SRLX_REQUIRE(h, "per_sample: NULL handle");
+    SRLX_REQUIRE(batch_size > 0, "per_sample: batch_size must be positive");
+    SRLX_REQUIRE(uniforms && n_uniforms >= batch_size, "per_sample: need at least batch_size uniforms (%lld < %lld)",
+                 (long long)n_uniforms, (long long)batch_size);
+    SRLX_REQUIRE(out_idx && out_used, "per_sample: out_idx/out_used are NULL");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick_stream(h, stream);
+    if (on_device)
+        return launch_sample(h, batch_size, step, d_step, uniforms, n_uniforms, out_idx, out_w, out_w32, out_used, st);
+
+    SRLX_REQUIRE(d_step == nullptr, "per_sample: d_step needs on_device=1");
+    using C = srlx::Carver;
+    const size_t in_bytes = C::padded((size_t)n_uniforms * 8);
+    const size_t out_bytes = C::padded((size_t)batch_size * 8) * 2 + C::padded((size_t)batch_size * 4) + C::padded(8);
+    SRLX_TRY(h->pinned.reserve(in_bytes + out_bytes));
+    SRLX_TRY(h->staging.reserve(in_bytes + out_bytes));
+    C hp(h->pinned.ptr), dp(h->staging.ptr);
+    double *h_u = hp.take<double>(n_uniforms);
+    double *d_u = dp.take<double>(n_uniforms);
+    i64 *h_idx = hp.take<i64>(batch_size), *d_idx = dp.take<i64>(batch_size);
+    double *h_w = hp.take<double>(batch_size), *d_w = dp.take<double>(batch_size);
+    float *h_w32 = hp.take<float>(batch_size), *d_w32 = dp.take<float>(batch_size);
+    i64 *h_used = hp.take<i64>(1), *d_used = dp.take<i64>(1);
+    memcpy(h_u, uniforms, (size_t)n_uniforms * 8);
+    SRLX_HIP(hipMemcpyAsync(d_u, h_u, (size_t)n_uniforms * 8, hipMemcpyHostToDevice, st));
+    SRLX_TRY(launch_sample(h, batch_size, step, nullptr, d_u, n_uniforms, d_idx, d_w, d_w32, d_used, st));
+    // results sit contiguously after the uniforms: one copy back
+    SRLX_HIP(hipMemcpyAsync(h_idx, d_idx, out_bytes, hipMemcpyDeviceToHost, st));
+    SRLX_HIP(hipStreamSynchronize(st));
+    *out_used = *h_used;
+    if (*h_used < 0) {
+        srlx::set_error("per_sample: %lld uniforms were not enough for %lld accepted draws", (long long)n_uniforms,
+                        (long long)batch_size);
+        return SRLX_ERR_UNIFORMS_EXHAUSTED;
+    }
+    memcpy(out_idx, h_idx, (size_t)batch_size * 8);
+    if (out_w) memcpy(out_w, h_w, (size_t)batch_size * 8);
+    if (out_w32) memcpy(out_w32, h_w32, (size_t)batch_size * 4);
+    return SRLX_OK;
+}
+
+int srlx_per_update(srlx_per_t *h, int64_t n, const int64_t *indices, const void *prio, int prio_kind, int on_device,
+                    void *stream) {
+    SRLX_REQUIRE(h, "per_update: NULL handle");
+    SRLX_REQUIRE(n >= 0, "per_update: negative n");
+    SRLX_REQUIRE(prio_kind >= SRLX_PRIO_F64 && prio_kind <= SRLX_PRIO_RAW, "per_update: bad prio_kind %d", prio_kind);
+    if (n == 0) return SRLX_OK;
+    SRLX_REQUIRE(indices && prio, "per_update: NULL array");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick_stream(h, stream);
+    if (on_device) return launch_update(h, n, indices, prio, prio_kind, st);
+
+    for (i64 i = 0; i < n; i++)
+        SRLX_REQUIRE(indices[i] >= 0 && indices[i] < h->tree_len, "per_update: index %lld out of range [0,%lld)",
+                     (long long)indices[i], (long long)h->tree_len);
+    using C = srlx::Carver;
+    const size_t ib = C::padded((size_t)n * 8), pb = C::padded((size_t)n * prio_elem_bytes(prio_kind));
+    SRLX_TRY(h->pinned.reserve(ib + pb));
+    SRLX_TRY(h->staging.reserve(ib + pb));
+    C hp(h->pinned.ptr), dp(h->staging.ptr);
+    i64 *h_i = hp.take<i64>(n), *d_i = dp.take<i64>(n);
+    char *h_p = (char *)h->pinned.ptr + ib, *d_p = (char *)h->staging.ptr + ib;
+    memcpy(h_i, indices, (size_t)n * 8);
+    memcpy(h_p, prio, (size_t)n * prio_elem_bytes(prio_kind));
+    SRLX_HIP(hipMemcpyAsync(d_i, h_i, ib + (size_t)n * prio_elem_bytes(prio_kind), hipMemcpyHostToDevice, st));
+    SRLX_TRY(launch_update(h, n, d_i, d_p, prio_kind, st));
+    SRLX_HIP(hipStreamSynchronize(st));
+    return SRLX_OK;
+}
+
+int srlx_per_backup(srlx_per_t *h, double *max_priority, int64_t *size, int64_t *write, double *tree_host) {
+    SRLX_REQUIRE(h && max_priority && size && write, "per_backup: NULL argument");
+    srlx::DeviceGuard guard(h->device);
+    SRLX_HIP(hipDeviceSynchronize());
+    PerState s;
+    SRLX_HIP(hipMemcpy(&s, h->d_state, sizeof(s), hipMemcpyDeviceToHost));
+    *max_priority = s.max_priority;
+    *size = s.size;
+    *write = s.write;
+    h->size = s.size;
+    h->write = s.write;
+    if (tree_host) SRLX_HIP(hipMemcpy(tree_host, h->d_tree, sizeof(double) * (size_t)h->tree_len, hipMemcpyDeviceToHost));
+    int err = 0;
+    SRLX_HIP(hipMemcpy(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) {
+        srlx::set_error("per: an earlier on-device update() received an out-of-range tree index");
+        return SRLX_ERR_INVALID;
+    }
+    return SRLX_OK;
+}
+
+int srlx_per_restore(srlx_per_t *h, double max_priority, int64_t size, int64_t write, const double *tree_host) {
+    SRLX_REQUIRE(h && tree_host, "per_restore: NULL argument");
+    SRLX_REQUIRE(size >= 0 && size <= h->capacity && write >= 0 && write < h->capacity, "per_restore: bad size/write");
+    srlx::DeviceGuard guard(h->device);
+    SRLX_HIP(hipDeviceSynchronize());
+    SRLX_HIP(hipMemcpy(h->d_tree, tree_host, sizeof(double) * (size_t)h->tree_len, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_state_set, dim3(1), dim3(1), 0, h->stream, h->d_state, max_priority, (i64)size, (i64)write);
+    SRLX_HIP(hipGetLastError());
+    SRLX_HIP(hipStreamSynchronize(h->stream));
+    h->size = size;
+    h->write = write;
+    return SRLX_OK;
+}
+
+int srlx_per_restore_resized(srlx_per_t *h, int64_t old_capacity, int64_t old_size, const double *old_tree_host) {
+    SRLX_REQUIRE(h && old_tree_host, "per_restore_resized: NULL argument");
+    SRLX_REQUIRE(old_capacity > 0 && old_size >= 0 && old_size <= old_capacity, "per_restore_resized: bad sizes");
+    SRLX_TRY(srlx_per_clear(h, nullptr));
+    const double *leaves = old_tree_host + (old_capacity - 1);
+    for (i64 off = 0; off < old_size; off += h->capacity) {
+        const i64 m = (old_size - off < h->capacity) ? old_size - off : h->capacity;
+        SRLX_TRY(srlx_per_add(h, m, leaves + off, SRLX_PRIO_RAW, 0, nullptr));
+    }
+    SRLX_HIP(hipStreamSynchronize(h->stream));
+    return SRLX_OK;
+}
+
+int srlx_per_tree_ptr(srlx_per_t *h, void **d_tree, int64_t *tree_len) {
+    SRLX_REQUIRE(h && d_tree, "per_tree_ptr: NULL argument");
+    *d_tree = h->d_tree;
+    if (tree_len) *tree_len = h->tree_len;
+    return SRLX_OK;
+}
+
+int srlx_per_state_ptr(srlx_per_t *h, void **d_state) {
+    SRLX_REQUIRE(h && d_state, "per_state_ptr: NULL argument");
+    *d_state = h->d_state;
+    return SRLX_OK;
+}
+
+int srlx_per_refresh(srlx_per_t *h, void *stream) {
+    SRLX_REQUIRE(h, "per_refresh: NULL handle");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick_stream(h, stream);
+    SRLX_TRY(h->pinned.reserve(sizeof(PerState)));
+    SRLX_HIP(hipMemcpyAsync(h->pinned.ptr, h->d_state, sizeof(PerState), hipMemcpyDeviceToHost, st));
+    SRLX_HIP(hipStreamSynchronize(st));
+    const PerState *s = (const PerState *)h->pinned.ptr;
+    h->size = s->size;
+    h->write = s->write;
+    return SRLX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+"""ProportionalMemory on the MI355X: the sum-tree lives in HBM behind libsrlx.so.
+
+Drop-in for the reference's srl/rl/memories/priority_memories/proportional_memory.py:95-205
+(`ProportionalMemory`) and for its pybind11 twin (cpp_module/src/proportional_memory.cpp:250-275):
+same constructor arguments, same `clear/length/add/sample/update/backup/restore`, same return
+values (`sample` -> (batches, float64 weights, list of TREE indices)).  Selectable from an
+unmodified reference config through
+    cfg.memory.set_custom("simple_distributed_rl_amd.rl.memories.priority_memories.proportional_memory:ProportionalMemory", {...})
+(srl/rl/memories/priority_replay_buffer.py:111-117,149-152).
+
+Like the C++ twin, the opaque `batch` objects stay on the host in a list; the device owns the
+priorities.  Random numbers: the reference calls `random.random()` once per descent attempt
+(:147); this class draws the same stream from Python's `random` and leaves the generator in
+exactly the state the reference would (rejected draws included), so a seeded run interleaves
+with other `random` users identically.
+"""
+import ctypes
+import random
+import threading
+from typing import Any, List, Optional
+
+import numpy as np
+
+from simple_distributed_rl_amd import _native as N
+
+from .imemory import IPriorityMemory
+
+
+class ProportionalMemory(IPriorityMemory):
+    def __init__(
+        self,
+        capacity: int,
+        alpha: float = 0.6,
+        beta_initial: float = 0.4,
+        beta_steps: int = 1_000_000,
+        has_duplicate: bool = True,
+        epsilon: float = 0.0001,
+        device: int = 0,
+        host_transform: bool = True,
+    ):
+        """host_transform=True evaluates (|p|+eps)**alpha with the host's Python/numpy exactly as
+        proportional_memory.py:124,172 does (so the tree is bit-identical to the reference run on
+        this host); False ships raw priorities and lets the kernel transform them."""
+        self.capacity = int(capacity)
+        self.alpha = alpha
+        self.beta_initial = beta_initial
+        self.beta_steps = beta_steps
+        self.has_duplicate = has_duplicate
+        self.epsilon = epsilon
+        self.device = int(device)
+        self.host_transform = host_transform
+        self._lock = threading.Lock()  # play_mp.py:248-286 calls add() and sample() from two threads
+        self._lib = N.lib()
+        h = N.c_p()
+        N.check(
+            self._lib.srlx_per_create(
+                ctypes.byref(h),
+                self.capacity,
+                float(alpha),
+                float(beta_initial),
+                float(beta_steps),
+                int(bool(has_duplicate)),
+                float(epsilon),
+                self.device,
+            )
+        )
+        self._h = h
+        self.data: List[Any] = [None] * self.capacity
+        self._write = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.srlx_per_destroy(h)
+            self._h = None
+
+    # ---- IPriorityMemory -----------------------------------------------------------------
+    def clear(self) -> None:
+        with self._lock:
+            N.check(self._lib.srlx_per_clear(self._h, None))
+            self.data = [None] * self.capacity
+            self._write = 0
+
+    def length(self) -> int:
+        return int(self._lib.srlx_per_length(self._h))
+
+    def add(self, batch: Any, priority: Optional[float] = None, _restore_skip: bool = False) -> None:
+        with self._lock:
+            self.data[self._write] = batch
+            self._write = (self._write + 1) % self.capacity
+            if priority is None:
+                N.check(self._lib.srlx_per_add(self._h, 1, None, N.PRIO_NONE, 0, None))
+                return
+            priority = float(priority)  # see oracle/gen_golden.py trace (4): numpy scalars are widened
+            if _restore_skip:
+                kind = N.PRIO_RAW
+            elif self.host_transform:
+                priority = (abs(priority) + self.epsilon) ** self.alpha  # proportional_memory.py:124
+                kind = N.PRIO_RAW
+            else:
+                kind = N.PRIO_F64
+            v = N.c_f64(priority)
+            N.check(self._lib.srlx_per_add(self._h, 1, ctypes.byref(v), kind, 0, None))
+
+    def sample(self, batch_size: int, step: int):
+        batch_size = int(batch_size)
+        idx = np.empty(batch_size, np.int64)
+        w = np.empty(batch_size, np.float64)
+        used = N.c_i64(0)
+        with self._lock:
+            state = random.getstate()
+            m = batch_size if self.has_duplicate else 4 * batch_size
+            while True:
+                u = np.fromiter((random.random() for _ in range(m)), np.float64, m)
+                st = self._lib.srlx_per_sample(
+                    self._h, batch_size, int(step), None, N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), 0, None
+                )
+                if st == N.ERR_UNIFORMS_EXHAUSTED and m < 9999 * batch_size:  # :146 "for safety" bound
+                    random.setstate(state)
+                    m = 2 * m + 16
+                    continue
+                N.check(st)
+                break
+            if used.value != m:  # rejected draws: leave `random` where the reference would
+                random.setstate(state)
+                for _ in range(used.value):
+                    random.random()
+            cap1 = self.capacity - 1
+            indices = idx.tolist()
+            batches = [self.data[i - cap1] for i in indices]
+        return batches, w, indices
+
+    def update(self, indices: List[Any], priorities: np.ndarray) -> None:
+        n = len(indices)
+        if n == 0:
+            return
+        idx = np.ascontiguousarray(indices, dtype=np.int64)
+        pr = np.asarray(priorities)
+        if self.host_transform:
+            pr = np.ascontiguousarray((np.abs(pr) + self.epsilon) ** self.alpha, dtype=np.float64)  # :172
+            kind = N.PRIO_RAW
+        elif pr.dtype == np.float32:
+            pr = np.ascontiguousarray(pr)
+            kind = N.PRIO_F32
+        else:
+            pr = np.ascontiguousarray(pr, dtype=np.float64)
+            kind = N.PRIO_F64
+        if pr.shape[0] < n:
+            raise IndexError("priorities shorter than indices")
+        with self._lock:
+            N.check(self._lib.srlx_per_update(self._h, n, N.np_ptr(idx), N.np_ptr(pr), kind, 0, None))
+
+    def backup(self):
+        """Same list layout as proportional_memory.py:179-187."""
+        with self._lock:
+            mp, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+            tree = np.empty(2 * self.capacity - 1, np.float64)
+            N.check(self._lib.srlx_per_backup(self._h, ctypes.byref(mp), ctypes.byref(size), ctypes.byref(write), N.np_ptr(tree)))
+            return [self.capacity, mp.value, size.value, write.value, tree.tolist(), self.data[:]]
+
+    def restore(self, data) -> None:
+        with self._lock:
+            if self.capacity == data[0]:  # :190-194
+                tree = np.ascontiguousarray(data[4], dtype=np.float64)
+                N.check(self._lib.srlx_per_restore(self._h, float(data[1]), int(data[2]), int(data[3]), N.np_ptr(tree)))
+                self.data = list(data[5][:])
+                self._write = int(data[3])
+            else:  # :195-205 -- clear, then re-add the first `size` leaves with _restore_skip
+                old_cap, old_size = int(data[0]), int(data[2])
+                tree = np.ascontiguousarray(data[4], dtype=np.float64)
+                N.check(self._lib.srlx_per_restore_resized(self._h, old_cap, old_size, N.np_ptr(tree)))
+                self.data = [None] * self.capacity
+                self._write = 0
+                for i in range(old_size):
+                    self.data[self._write] = data[5][i]
+                    self._write = (self._write + 1) % self.capacity
+
+    # ---- extras (not in the reference interface) --------------------------------------------
+    @property
+    def max_priority(self) -> float:
+        mp, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+        N.check(self._lib.srlx_per_backup(self._h, ctypes.byref(mp), ctypes.byref(size), ctypes.byref(write), None))
+        return mp.value
+
+    def tree_array(self) -> np.ndarray:
+        return np.asarray(self.backup()[4])

@@ -1,0 +1,369 @@
+"""GPU parity tests of the sum-tree kernels, through the C ABI (libsrlx.so), against
+(1) golden traces recorded from the imported reference and (2) the CPU oracle on seeded inputs.
+Bar: tree indices / tree contents / uniform consumption bit-exact; IS weights rel 1e-13 (the
+device and glibc `pow` may differ in the last ulp); transformed priorities <= 1 ulp (exact at alpha=0.5)."""
+import ctypes
+import glob
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle_bindings import OraclePER, iter_trace
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TRACES = sorted(glob.glob(os.path.join(GOLDEN, "per_trace_*.npz")))
+IDS = [os.path.basename(p)[10:-4] for p in TRACES]
+W_RTOL = 1e-13
+
+
+def _N():
+    from simple_distributed_rl_amd import _native as N
+
+    return N
+
+
+class AbiPER:
+    """Minimal direct caller of the C ABI with host arrays (no Python shim logic)."""
+
+    def __init__(self, capacity, alpha, beta_initial, beta_steps, has_duplicate, epsilon):
+        N = _N()
+        self.N, self.lib = N, N.lib()
+        self.capacity = int(capacity)
+        h = N.c_p()
+        N.check(self.lib.srlx_per_create(ctypes.byref(h), self.capacity, alpha, beta_initial, beta_steps, int(has_duplicate), epsilon, 0))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.srlx_per_destroy(self.h)
+            self.h = None
+
+    def add(self, values=None, kind=None, n=None):
+        N = self.N
+        if values is None:
+            N.check(self.lib.srlx_per_add(self.h, int(n or 1), None, N.PRIO_NONE, 0, None))
+        else:
+            v = np.ascontiguousarray(values)
+            N.check(self.lib.srlx_per_add(self.h, v.size, N.np_ptr(v), kind, 0, None))
+
+    def sample(self, B, step, uniforms):
+        N = self.N
+        u = np.ascontiguousarray(uniforms, np.float64)
+        idx = np.empty(B, np.int64)
+        w = np.empty(B, np.float64)
+        w32 = np.empty(B, np.float32)
+        used = N.c_i64(0)
+        st = self.lib.srlx_per_sample(self.h, B, int(step), None, N.np_ptr(u), u.size, N.np_ptr(idx), N.np_ptr(w), N.np_ptr(w32), ctypes.byref(used), 0, None)
+        return st, used.value, idx, w, w32
+
+    def update(self, indices, pri, kind):
+        N = self.N
+        i = np.ascontiguousarray(indices, np.int64)
+        p = np.ascontiguousarray(pri)
+        N.check(self.lib.srlx_per_update(self.h, i.size, N.np_ptr(i), N.np_ptr(p), kind, 0, None))
+
+    def state(self):
+        N = self.N
+        mp, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+        tree = np.empty(2 * self.capacity - 1, np.float64)
+        N.check(self.lib.srlx_per_backup(self.h, ctypes.byref(mp), ctypes.byref(size), ctypes.byref(write), N.np_ptr(tree)))
+        return mp.value, size.value, write.value, tree
+
+
+def _mk(cls, z):
+    return cls(int(z["capacity"]), float(z["alpha"]), float(z["beta_initial"]), float(z["beta_steps"]), bool(z["has_duplicate"]), float(z["epsilon"]))
+
+
+@pytest.mark.parametrize("path", TRACES, ids=IDS)
+def test_abi_replays_reference_trace_bit_exact(path):
+    """Golden traces from the imported reference through the C ABI: indices, number of consumed
+    uniforms (retries included) and the final tree are bit-equal."""
+    N = _N()
+    z = np.load(path)
+    m = _mk(AbiPER, z)
+    eps, alpha = float(z["epsilon"]), float(z["alpha"])
+    slack = np.random.default_rng(0).random(5)
+    for kind, p in iter_trace(z):
+        if kind == "add":
+            if p["priority"] is None:
+                m.add(None)
+            else:
+                m.add(np.array([(abs(p["priority"]) + eps) ** alpha]), N.PRIO_RAW)  # proportional_memory.py:124 on the host
+        elif kind == "sample":
+            u = np.concatenate([p["uniforms"], slack])  # extra uniforms must NOT be consumed
+            st, used, idx, w, w32 = m.sample(p["batch_size"], p["step"], u)
+            assert st == 0
+            assert used == p["uniforms"].size
+            np.testing.assert_array_equal(idx, p["indices"])
+            np.testing.assert_allclose(w, p["weights"], rtol=W_RTOL, atol=0)
+            np.testing.assert_array_equal(w32, w.astype(np.float32))
+            if used > p["batch_size"]:  # with one uniform too few the call must report exhaustion
+                st2, used2, *_ = m.sample(p["batch_size"], p["step"], p["uniforms"][:-1])
+                assert st2 == N.ERR_UNIFORMS_EXHAUSTED and used2 == -1
+        else:
+            m.update(p["indices"], p["transformed"], N.PRIO_RAW)
+    mp, size, write, tree = m.state()
+    assert (size, write) == (int(z["final_size"]), int(z["final_write"]))
+    assert mp == float(z["final_max_priority"])
+    np.testing.assert_array_equal(tree, z["final_tree"])
+
+
+@pytest.mark.parametrize("path", [p for p in TRACES if "speedtest" not in p], ids=[i for i in IDS if "speedtest" not in i])
+def test_shim_lockstep_with_python_random(path):
+    """The Python shim (IPriorityMemory) under random.seed(s): same indices as the reference and the
+    `random` generator ends in the same state (rejected draws consume a value each, :146-157)."""
+    from simple_distributed_rl_amd.rl.memories.priority_memories.proportional_memory import ProportionalMemory
+
+    z = np.load(path)
+    m = _mk(ProportionalMemory, z)
+    random.seed(int(z["seed"]))
+    item = 0
+    for kind, p in iter_trace(z):
+        if kind == "add":
+            m.add(item, p["priority"])
+            item += 1
+        elif kind == "sample":
+            batches, w, idx = m.sample(p["batch_size"], p["step"])
+            assert idx == p["indices"].tolist()
+            assert isinstance(w, np.ndarray) and w.dtype == np.float64
+            np.testing.assert_allclose(w, p["weights"], rtol=W_RTOL, atol=0)
+            cap = int(z["capacity"])
+            assert all(b is not None for b in batches)
+            assert len(batches) == p["batch_size"]
+        else:
+            m.update(p["indices"].tolist(), p["priorities"])
+    assert random.random() == float(z["final_next_random"])
+    np.testing.assert_array_equal(m.tree_array(), z["final_tree"])
+    assert m.length() == int(z["final_size"])
+
+
+@pytest.mark.parametrize("alpha", [0.5, 0.6, 1.0, 0.0])
+@pytest.mark.parametrize("kind_name", ["f32", "f64"])
+def test_device_transform_matches_oracle(alpha, kind_name):
+    """Device-side (|p|+eps)^alpha (SRLX_PRIO_F32 / _F64) vs the oracle: exact for alpha in {0, .5, 1},
+    <= 1 ulp of the priority dtype otherwise."""
+    N = _N()
+    cap = 777
+    rng = np.random.default_rng(3)
+    pri = (rng.standard_normal(cap) * 2).astype(np.float32 if kind_name == "f32" else np.float64)
+    g = AbiPER(cap, alpha, 0.4, 1000, True, 1e-4)
+    o = OraclePER(cap, alpha, 0.4, 1000, True, 1e-4)
+    g.add(None, n=cap)
+    for _ in range(cap):
+        o.add(None)
+    leaves = np.arange(cap, dtype=np.int64) + cap - 1
+    g.update(leaves, pri, N.PRIO_F32 if kind_name == "f32" else N.PRIO_F64)
+    o.update(leaves, pri)
+    got, want = g.state()[3][leaves], o.tree()[leaves]
+    if alpha in (0.0, 0.5, 1.0):
+        np.testing.assert_array_equal(got, want)
+    else:
+        ulp = np.spacing(want.astype(np.float32)).astype(np.float64) if kind_name == "f32" else np.spacing(want)
+        assert np.all(np.abs(got - want) <= ulp)
+    assert g.state()[0] == pytest.approx(o.max_priority, rel=1e-15)
+
+
+@pytest.mark.parametrize("capacity", [1, 2, 3, 5, 64, 1000, 4097])
+def test_random_op_mix_vs_oracle(capacity):
+    """Seeded add/sample/update mixes (ring wrap-around, both leaf depths, partially filled tree,
+    bulk adds, duplicate indices) against the oracle: everything bit-exact (alpha=0.5 path)."""
+    N = _N()
+    rng = np.random.default_rng(capacity)
+    g = AbiPER(capacity, 0.5, 0.4, 5000, True, 1e-4)
+    o = OraclePER(capacity, 0.5, 0.4, 5000, True, 1e-4)
+    step = 0
+    for it in range(60):
+        n = int(rng.integers(1, max(2, min(capacity, 300) + 1)))
+        n = min(n, capacity)
+        mode = it % 3
+        if mode == 0:
+            g.add(None, n=n)
+            for _ in range(n):
+                o.add(None)
+        else:
+            v = rng.random(n) * 3
+            g.add(v, N.PRIO_F64)
+            for x in v:
+                o.add(float(np.sqrt(abs(x) + 1e-4)), mode=2)  # numpy-f64 semantics: sqrt at alpha=.5
+        B = int(rng.integers(1, 70))
+        u = rng.random(B + 40)
+        st, used, idx, w, _ = g.sample(B, step, u)
+        oused, oidx, ow, _ = o.sample(B, step, u)
+        assert st == 0 and used == oused
+        np.testing.assert_array_equal(idx, oidx)
+        np.testing.assert_allclose(w, ow, rtol=W_RTOL, atol=0)
+        upd = np.concatenate([idx, idx[: B // 3]])
+        pri = np.abs(rng.standard_normal(upd.size)).astype(np.float32)
+        g.update(upd, pri, N.PRIO_F32)
+        o.update(upd, pri)
+        step += 37
+    mp, size, write, tree = g.state()
+    omp, osize, owrite, otree = o.get_state()
+    np.testing.assert_array_equal(tree, otree)
+    assert (mp, size, write) == (omp, osize, owrite)
+
+
+def test_full_size_1M_bulk_paths():
+    """BASELINE size: capacity 1,000,000 (tree 16 MB).  Bulk add of 1M priorities, bulk sample of
+    200k draws (LDS-staged multi-workgroup path), chunked update of 5000 indices, all vs the oracle."""
+    N = _N()
+    cap = 1_000_000
+    rng = np.random.default_rng(0)
+    g = AbiPER(cap, 0.5, 0.4, 1_000_000, True, 1e-4)
+    o = OraclePER(cap, 0.5, 0.4, 1_000_000, True, 1e-4)
+    pri = rng.random(cap)  # |delta| ~ U(0,1) like speedtest.py:40-41
+    tx = np.sqrt(np.abs(pri) + 1e-4)
+    g.add(pri[:600_000], N.PRIO_F64)
+    g.add(pri[600_000:], N.PRIO_F64)
+    for x in tx:
+        o.add(float(x), mode=2)
+    np.testing.assert_array_equal(g.state()[3], o.tree())
+    # wrap-around bulk add with priority=None
+    g.add(None, n=123_457)
+    for _ in range(123_457):
+        o.add(None)
+    np.testing.assert_array_equal(g.state()[3], o.tree())
+    B = 200_000
+    u = rng.random(B)
+    st, used, idx, w, w32 = g.sample(B, 250_000, u)
+    oused, oidx, ow, _ = o.sample(B, 250_000, u)
+    assert st == 0 and used == oused == B
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_allclose(w, ow, rtol=W_RTOL, atol=0)
+    # size-independent properties: indices are leaves; weights in (0,1], max == 1
+    assert idx.min() >= cap - 1 and idx.max() <= 2 * cap - 2
+    assert w.max() == 1.0 and w.min() > 0
+    upd = idx[:5000]
+    p32 = np.abs(rng.standard_normal(5000)).astype(np.float32)
+    g.update(upd, p32, N.PRIO_F32)
+    o.update(upd, p32)
+    mp, size, write, tree = g.state()
+    np.testing.assert_array_equal(tree, o.tree())
+    assert mp == o.max_priority and size == cap and write == o.write
+    # root == what the reference's delta propagation gives, and close to the exact leaf sum
+    assert abs(tree[0] - tree[cap - 1 :].sum()) / tree[0] < 1e-9
+
+
+def test_on_device_pointers_with_torch():
+    """on_device=1: device pointers (torch tensors), work enqueued on torch's current stream,
+    step read from a device scalar -- same results as the host-pointer path."""
+    import torch
+
+    N = _N()
+    cap = 5000
+    rng = np.random.default_rng(5)
+    g = AbiPER(cap, 0.5, 0.4, 10_000, True, 1e-4)
+    o = OraclePER(cap, 0.5, 0.4, 10_000, True, 1e-4)
+    dev = torch.device("cuda:0")
+    st = N.torch_stream_ptr()
+    pri = torch.tensor(rng.random(cap), dtype=torch.float64, device=dev)
+    N.check(g.lib.srlx_per_add(g.h, cap, N.c_p(pri.data_ptr()), N.PRIO_F64, 1, st))
+    for x in np.sqrt(pri.cpu().numpy() + 1e-4):
+        o.add(float(x), mode=2)
+    B = 64
+    u_np = rng.random(B + 8)
+    u = torch.tensor(u_np, device=dev)
+    idx = torch.empty(B, dtype=torch.int64, device=dev)
+    w = torch.empty(B, dtype=torch.float64, device=dev)
+    w32 = torch.empty(B, dtype=torch.float32, device=dev)
+    used = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_step = torch.tensor([1234], dtype=torch.int64, device=dev)
+    N.check(
+        g.lib.srlx_per_sample(g.h, B, 0, N.c_p(d_step.data_ptr()), N.c_p(u.data_ptr()), B + 8, N.c_p(idx.data_ptr()), N.c_p(w.data_ptr()), N.c_p(w32.data_ptr()), N.c_p(used.data_ptr()), 1, st)
+    )
+    oused, oidx, ow, _ = o.sample(B, 1234, u_np)
+    torch.cuda.synchronize()
+    assert int(used.item()) == oused
+    np.testing.assert_array_equal(idx.cpu().numpy(), oidx)
+    np.testing.assert_allclose(w.cpu().numpy(), ow, rtol=W_RTOL)
+    p32 = torch.tensor(np.abs(rng.standard_normal(B)), dtype=torch.float32, device=dev)
+    N.check(g.lib.srlx_per_update(g.h, B, N.c_p(idx.data_ptr()), N.c_p(p32.data_ptr()), N.PRIO_F32, 1, st))
+    o.update(oidx, p32.cpu().numpy())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(g.state()[3], o.tree())
+    assert g.state()[0] == o.max_priority
+
+
+def test_reference_statistical_scenario():
+    """tests/quick/rl/memories/test_priority_memories.py:29-91 ported onto the HIP memory: hit counts
+    strictly increase with priority, no duplicates when has_duplicate=False, backup/restore round trip."""
+    import collections
+
+    from simple_distributed_rl_amd.rl.memories.priority_memories.proportional_memory import ProportionalMemory
+
+    random.seed(11)
+    for check_dup in (True, False):
+        memory = ProportionalMemory(10, 0.8, 1, 10, has_duplicate=not check_dup)
+        for i in range(100):
+            memory.add((i, i, i, i), 0)
+        assert memory.length() == 10
+        for i in range(10):
+            i += 1
+            memory.add((i, i, i, i), i)
+        counter = []
+        for i in range(4000):
+            batches, weights, update_args = memory.sample(5, step=1)
+            assert len(batches) == 5 and len(weights) == 5
+            if check_dup:
+                assert len(set(batches)) == 5
+            counter.extend(b[0] for b in batches)
+            memory.update(update_args, np.array([b[3] for b in batches]))
+            if i % 50 == 0:
+                l1 = memory.length()
+                memory.restore(memory.backup())
+                assert l1 == memory.length()
+        c = collections.Counter(counter)
+        keys = sorted(c.keys())
+        if check_dup:
+            assert keys == list(range(1, 11))
+        vals = [c[k] for k in keys]
+        assert all(vals[i] < vals[i + 1] for i in range(len(vals) - 1))
+
+
+@pytest.mark.parametrize("alpha", [0, 0.2, 0.5, 0.8, 1.0])
+def test_reference_is_weight_known_answer(alpha):
+    """tests/quick/rl/memories/test_priority_memories.py:97-117,150-176 on the HIP memory (rel 1e-7)."""
+    import math
+
+    from simple_distributed_rl_amd.rl.memories.priority_memories.proportional_memory import ProportionalMemory
+
+    eps = 1e-4
+    memory = ProportionalMemory(capacity=10, alpha=alpha, beta_initial=1, epsilon=eps, has_duplicate=False)
+    pri = [1, 2, 4, 3]
+    true_p = [(t + eps) ** alpha for t in pri]
+    s = sum(true_p)
+    tw = np.array([(4 * (p / s)) ** -1 for p in true_p])
+    tw /= tw.max()
+    for i, p in enumerate(pri):
+        memory.add((i, i, i, i), priority=p)
+    batches, weights, _ = memory.sample(4, step=1)
+    for i, b in enumerate(batches):
+        assert math.isclose(weights[i], tw[b[0]], rel_tol=1e-7)
+
+
+def test_restore_into_different_capacity():
+    from simple_distributed_rl_amd.rl.memories.priority_memories.proportional_memory import ProportionalMemory
+
+    a = ProportionalMemory(7, alpha=0.5)
+    for i in range(11):
+        a.add(("item", i), float(i + 1))
+    b = ProportionalMemory(5, alpha=0.5)
+    b.restore(a.backup())
+    o = OraclePER(7, alpha=0.5)
+    for i in range(11):
+        o.add(float(i + 1))
+    o2 = OraclePER(5, alpha=0.5)
+    _, size, _, tree = o.get_state()
+    o2.restore_resized(7, size, tree)
+    np.testing.assert_array_equal(b.tree_array(), o2.tree())
+    assert b.length() == 5
+    bk = b.backup()
+    assert bk[0] == 5 and bk[3] == o2.write
+    c = ProportionalMemory(5, alpha=0.5)
+    c.restore(bk)
+    np.testing.assert_array_equal(c.tree_array(), o2.tree())
+    assert c.data == b.data

@@ -113,6 +113,107 @@ int srlx_per_state_ptr(srlx_per_t *h, void **d_state);
 /* re-read size/write from the device after HIP-graph replays that contained adds */
 int srlx_per_refresh(srlx_per_t *h, void *stream);
 
+/* SRLX_PRIO_NONE with a validity mask (uint8[n]): p = mask ? max_priority : 0.  Used by the
+ * vectorised actor, where the ring position holding an episode's terminal frame has no transition. */
+#define SRLX_PRIO_NONE_MASKED 4
+
+/* ------------------------------------------------------------------------------------
+ * Counter-based device RNG (the vectorised path has no reference stream to match; the
+ * single-env plugin path keeps drawing from Python's `random`).  out[i] = u53(mix(seed, *d_counter, i));
+ * afterwards *d_counter += 1.  Restated for tests in oracle/hot_path_oracle.py:rng_uniform.
+ * ------------------------------------------------------------------------------------ */
+int srlx_rng_uniform(uint64_t seed, int64_t *d_counter, int64_t n, double *d_out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Device-resident transition store for E lock-stepped environments (uint8 or float32 frames).
+ *
+ * Replaces, for the vectorised engine: WorkerRun frame stacking + tracking ring
+ * (srl/base/rl/worker_run.py:310-358,548-610, srl/base/spaces/box.py:303-312), the Rainbow
+ * worker's n-step item assembly incl. terminal padding (srl/algorithms/rainbow/rainbow.py:331-400),
+ * the zlib/pickle item storage of PriorityReplayBuffer (srl/rl/memories/priority_replay_buffer.py:205-217,242-243)
+ * and the list->ndarray batch assembly of calc_target_q (rainbow.py:190-194).
+ *
+ * Layout: frames [E][ring_len][obs_elems] (one n-step window is contiguous), scalars [E][ring_len].
+ * All envs share one ring position p that advances once per srlx_store_commit_step.  PER slot
+ * j <-> (env j % E, item time j / E); PER capacity = E * item_len, item_len = ring_len - (n_step + window).
+ * ------------------------------------------------------------------------------------ */
+typedef struct srlx_store srlx_store_t;
+#define SRLX_OBS_U8 0  /* uint8 frames, presented to the network as float32 u8/255 (image_processor.py:140-142) */
+#define SRLX_OBS_F32 1 /* float32 observations, copied */
+
+int srlx_store_create(srlx_store_t **out, int64_t n_envs, int64_t ring_len, int64_t obs_elems, int obs_dtype, int window,
+                      int n_step, int n_actions, int reward_clip, uint64_t seed, int device);
+int srlx_store_destroy(srlx_store_t *h);
+int64_t srlx_store_item_len(const srlx_store_t *h);   /* ring_len - (n_step + window) */
+int64_t srlx_store_per_capacity(const srlx_store_t *h); /* n_envs * item_len */
+/* start: write every env's first observation (device [E][obs_elems]) at position 0 */
+int srlx_store_reset_all(srlx_store_t *h, const void *d_first_obs, void *stream);
+/* policy input at the current position: out float32 [E][window][obs_elems] (oldest frame first,
+ * zeros before the episode start: worker_run.py:277 default states + box.py:303-312) */
+int srlx_store_stack_current(srlx_store_t *h, float *d_out, void *stream);
+/* one lock-step commit (rainbow.py:331-352 add_tracking): action/reward/terminated/done of the
+ * step taken at p, next observation -> p+1.  Envs whose previous step was `done` are in their reset
+ * step: position p (the terminal frame) is marked as holding no transition and d_next_obs is their new
+ * episode's first frame.  Also emits the validity mask uint8[E] of the items that became complete
+ * (position p-(n_step-1)) for srlx_per_add(..., SRLX_PRIO_NONE_MASKED). */
+int srlx_store_commit_step(srlx_store_t *h, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated,
+                           const uint8_t *d_done, const void *d_next_obs, uint8_t *d_item_mask, void *stream);
+/* device views: int64 position p; uint8 needs_reset[E]; int32 step_in_episode[E] (of position p) */
+int srlx_store_views(srlx_store_t *h, void **d_pos, void **d_needs_reset, void **d_step_in_ep);
+/* sampled PER tree indices -> training batch (rainbow.py:190-194 + terminal padding :354-372):
+ *   obs      float32 [B][n_step+1][window][obs_elems]
+ *   actions  int32   [B][n_step]      rewards float32 [B][n_step]    terminated float32 [B][n_step] */
+int srlx_store_gather_nstep(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, float *d_obs, int32_t *d_actions,
+                            float *d_rewards, float *d_terminated, void *stream);
+
+/* epsilon-greedy over a batch of Q rows (rainbow.py:301-329, dqn.py:192-211):
+ *   u[e][0] < eps[e] -> the floor(u[e][1]*n_valid)-th valid action, else first argmax of q with
+ *   invalid actions at -inf.  invalid: uint8 [E][A] or NULL. */
+int srlx_policy_epsilon_greedy(int64_t n_envs, int n_actions, const float *d_q, const float *d_eps, const double *d_u,
+                               const uint8_t *d_invalid, int32_t *d_actions, void *stream);
+
+/* synthetic 84x84-style environment batch: i.i.d. uint8 frames, reward in
+ * {-1,0,1}, episodes of episode_len steps ending `terminated`. Reads the store's reset/step state. */
+int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, float *d_rewards, uint8_t *d_terminated,
+                        uint8_t *d_done, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused learner arithmetic
+ *
+ * srlx_nstep_td_huber_priority replaces, in one launch: the numpy n-step/retrace target of
+ * CommonInterfaceParameter.calc_target_q (srl/algorithms/rainbow/rainbow.py:226-287), the
+ * selected-Q + HuberLoss(target*w, q*w) of Trainer.train (srl/algorithms/rainbow/model_torch.py:103-105),
+ * its gradient w.r.t. the online Q rows (seed for backward) and the new priorities |target - q| (:113).
+ *   q_on_next, q_tg_next : float32 [B][n][A]  online / target net on states s_1..s_n
+ *   q_on_0               : float32 [B][A]     online net on s_0 (requires grad on the torch side)
+ *   actions int32 [B][n], rewards/terminated float32 [B][n], invalid_next uint8 [B][n][A] or NULL
+ *   weights float32 [B] (IS weights)
+ * outputs: target f32 [B], loss f32 [1], grad_q0 f32 [B][A], priorities f32 [B]
+ * ------------------------------------------------------------------------------------ */
+int srlx_nstep_td_huber_priority(int64_t batch, int n_step, int n_actions, const float *d_q_on_next,
+                                 const float *d_q_tg_next, const float *d_q_on_0, const int32_t *d_actions,
+                                 const float *d_rewards, const float *d_terminated, const uint8_t *d_invalid_next,
+                                 const float *d_weights, double discount, double retrace_h, int enable_double_dqn,
+                                 int enable_rescale, float *d_target, float *d_loss, float *d_grad_q0,
+                                 float *d_priorities, void *stream);
+
+/* 1-step (double-)DQN target (srl/algorithms/dqn/dqn.py:144-176, rainbow_nomultisteps.py:10-43):
+ * invalid next actions are masked with min(q) of the WHOLE batch, not -inf (dqn.py:160,164).
+ *   q_on_next/q_tg_next f32 [B][A]; rewards f32 [B]; undone f32 [B]; out target f32 [B]
+ *   f64_accum=1: dqn.py:171 (int `undone` array promotes the expression to float64, cast at :176);
+ *   f64_accum=0: rainbow_nomultisteps.py:38 (all float32). */
+int srlx_dqn_target(int64_t batch, int n_actions, const float *d_q_on_next, const float *d_q_tg_next,
+                    const float *d_rewards, const float *d_undone, const uint8_t *d_invalid_next, double discount,
+                    int enable_double_dqn, int enable_rescale, int f64_accum, float *d_target, void *stream);
+
+/* GAE reverse scan per environment (srl/algorithms/ppo/ppo.py:389-404): for each env, episodes are
+ * delimited by done[t]; the last step of an episode uses delta = r - V (no bootstrap, :396-397).
+ *   rewards, values, done(uint8) laid out [T][E]; out advantages f32 [T][E].
+ *   last_values f32 [E] bootstraps a horizon cut that is not an episode end (NULL = no bootstrap,
+ *   which is what the reference does for every episode end, truncation included). */
+int srlx_gae_scan(int64_t n_envs, int64_t horizon, const float *d_rewards, const float *d_values, const uint8_t *d_done,
+                  const float *d_last_values, double discount, double gae_lambda, float *d_adv, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

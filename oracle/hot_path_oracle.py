@@ -1,0 +1,340 @@
+"""oracle/hot_path_oracle.py -- TEST INFRASTRUCTURE ONLY (not product code).
+
+numpy restatements of the reference's host-side arithmetic on the rollout -> replay -> train path,
+each following the cited reference lines (paths relative to the reference repository root).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Parity status: PINNED.  tests/test_hot_path_oracle_golden.py checks every function below against vectors
+recorded from the imported reference by oracle/gen_golden_algo.py (tests/golden/target_q_*.npz,
+train_step_*.npz, dqn_target_*.npz, functions.npz, rollout_items_*.npz).  `gae` follows
+srl/algorithms/ppo/ppo.py:389-404, whose module needs TensorFlow and cannot be imported here:
+parity UNPINNED for that one function (restated from source only).
+"""
+import numpy as np
+
+# ------------------------------------------------------------------------------------------
+# counter RNG of the vectorised path (definition; mirrored by csrc/srlx_rollout.hip)
+# ------------------------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(z):
+    z = np.asarray(z, np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def rng_u64(seed, a, b):
+    with np.errstate(over="ignore"):
+        s = np.uint64(seed) + np.asarray(a, np.uint64) * np.uint64(0xD1342543DE82EF95)
+        return _mix64(_mix64(s) + np.asarray(b, np.uint64) * np.uint64(0xAEF17502108EF2D9))
+
+
+def u53(x):
+    return (np.asarray(x, np.uint64) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def rng_uniform(seed, counter, n):
+    return u53(rng_u64(seed, np.uint64(counter), np.arange(n, dtype=np.uint64)))
+
+
+# ------------------------------------------------------------------------------------------
+# srl/rl/functions.py:10-17
+# ------------------------------------------------------------------------------------------
+def rescaling(x, eps=0.001):
+    return np.sign(x) * (np.sqrt(np.abs(x) + 1.0) - 1.0) + eps * x
+
+
+def inverse_rescaling(x, eps=0.001):
+    n = np.sqrt(1.0 + 4.0 * eps * (np.abs(x) + 1.0 + eps)) - 1.0
+    n = n / (2.0 * eps)
+    return np.sign(x) * ((n**2) - 1.0)
+
+
+# ------------------------------------------------------------------------------------------
+# srl/algorithms/rainbow/rainbow.py:185-287  CommonInterfaceParameter.calc_target_q, the part after
+# the two network forwards.  Array form of the nested-list inputs:
+#   q_online : (B, n, A) online net on s_1..s_n   (double DQN; (B, n-1, A) otherwise, :208-213)
+#   q_target : (B, n, A) target net on s_1..s_n
+#   actions  : (B, n) int   a_0..a_{n-1}          (one-hot in the reference)
+#   reward, done : (B, n) float32                 invalid : (B, n, A) bool (next_invalid_actions)
+# ------------------------------------------------------------------------------------------
+def nstep_target(q_online, q_target, actions, reward, done, invalid, discount, retrace_h, double_dqn, rescale, np_dtype=np.float32):
+    q_online = np.array(q_online, np_dtype, copy=True)
+    q_target = np.array(q_target, np_dtype, copy=True)
+    B, n, A = q_target.shape
+    reward = np.asarray(reward, np_dtype)
+    done = np.asarray(done, np_dtype)
+    multi_discounts = np.tile(np.array([discount**k for k in range(n)], dtype=np_dtype), (B, 1))  # :182,187
+    onehot = np.eye(A, dtype=np_dtype)[np.asarray(actions)]  # (B, n, A)
+    n_action = onehot[:, 1:, :]  # :200
+
+    q = np.sum(q_online[:, : n - 1, :] * n_action, axis=2)  # :231
+    q = np.insert(q, 0, 0, axis=1)  # :233
+
+    if invalid is None:
+        invalid = np.zeros((B, n, A), bool)
+    idx1, idx2, idx3 = np.nonzero(invalid)  # :241-243
+    if double_dqn:
+        q_online[idx1, idx2, idx3] = -np.inf  # :245-247
+        n_act_idx = np.argmax(q_online, axis=2)
+    else:
+        q_target[idx1, idx2, idx3] = -np.inf  # :248-250
+        n_act_idx = np.argmax(q_target, axis=2)
+    maxq = np.take_along_axis(q_target, np.expand_dims(n_act_idx, axis=2), axis=2)  # :251
+    maxq = np.squeeze(maxq, axis=2)
+    if rescale:
+        maxq = inverse_rescaling(maxq)  # :255
+    gains = reward + (1 - done) * discount * maxq  # :258
+    if rescale:
+        gains = rescaling(gains)  # :261
+    td_errors = gains - q  # :263
+
+    pi_probs = np.argmax(n_action, axis=2) == n_act_idx[:, 1:]  # :268
+    pi_probs = np.transpose(pi_probs, (1, 0))  # :272
+    retrace_list = [np.ones((B,))]
+    retrace = np.ones((B,))
+    for k in range(n - 1):
+        retrace *= retrace_h * pi_probs[k]  # :280
+        retrace_list.append(retrace.copy())
+    retrace_list = np.asarray(retrace_list).transpose((1, 0))  # :284
+    target_q = np.sum(td_errors * multi_discounts * retrace_list, axis=1, dtype=np_dtype)  # :285
+    return target_q
+
+
+# ------------------------------------------------------------------------------------------
+# srl/algorithms/rainbow/model_torch.py:103-105,113 (and dqn/model_torch.py:112-114,122):
+#   q = sum(Q(s) * onehot); loss = HuberLoss()(target*w, q*w); priorities = |target - q|
+# plus d loss / d Q(s) (what autograd hands to the network's backward).
+# ------------------------------------------------------------------------------------------
+def huber_loss_grad_priority(q_all, a0, target, weights):
+    q_all = np.asarray(q_all, np.float32)
+    target = np.asarray(target, np.float32)
+    w = np.asarray(weights, np.float32)
+    B, A = q_all.shape
+    q = q_all[np.arange(B), a0]
+    tw, qw = target * w, q * w
+    diff = (tw - qw).astype(np.float64)
+    z = np.abs(diff)
+    loss = np.where(z < 1.0, 0.5 * z * z, z - 0.5).mean()
+    grad = np.zeros((B, A), np.float32)
+    grad[np.arange(B), a0] = (-(w.astype(np.float64) * np.clip(diff, -1, 1)) / B).astype(np.float32)
+    return np.float32(loss), grad, np.abs(target - q)
+
+
+# ------------------------------------------------------------------------------------------
+# srl/algorithms/dqn/dqn.py:144-176 (f64_accum=True: `undone` is an int array there, so numpy
+# promotes the target expression to float64) and
+# srl/algorithms/rainbow/rainbow_nomultisteps.py:10-43 (f64_accum=False: all float32).
+# ------------------------------------------------------------------------------------------
+def dqn_target(q_online_next, q_target_next, reward, undone, invalid, discount, double_dqn, rescale, f64_accum):
+    n_q_target = np.array(q_target_next, np.float32, copy=True)
+    B, A = n_q_target.shape
+    reward = np.asarray(reward, np.float32)
+    undone = np.asarray(undone, np.int64 if f64_accum else np.float32)
+    i1, i2 = np.nonzero(invalid) if invalid is not None else (np.array([], int), np.array([], int))
+    if double_dqn:
+        n_q = np.array(q_online_next, np.float32, copy=True)
+        n_q[i1, i2] = np.min(n_q)  # dqn.py:160
+        n_act_idx = np.argmax(n_q, axis=1)
+        maxq = n_q_target[np.arange(B), n_act_idx]
+    else:
+        n_q_target[i1, i2] = np.min(n_q_target)  # dqn.py:164
+        maxq = np.max(n_q_target, axis=1)
+    if rescale:
+        maxq = inverse_rescaling(maxq)
+    target_q = reward + undone * discount * maxq  # dqn.py:171
+    if rescale:
+        target_q = rescaling(target_q)
+    return target_q.astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------
+# srl/algorithms/ppo/ppo.py:389-404 generalised to a [T][E] lock-step rollout: every `done` step is
+# the last step of an episode (delta = r - V, no bootstrap); a horizon cut may bootstrap from
+# last_values (no reference equivalent; None = treat like an episode end).  Parity UNPINNED.
+# ------------------------------------------------------------------------------------------
+def gae(rewards, values, done, last_values, discount, lam):
+    rewards = np.asarray(rewards, np.float32)
+    values = np.asarray(values, np.float32)
+    T, E = rewards.shape
+    adv = np.zeros((T, E), np.float32)
+    g = np.float32(discount)
+    gl = np.float32(discount * lam)
+    for e in range(E):
+        gae_v = np.float32(0)
+        for i in reversed(range(T)):
+            if done[i, e]:
+                delta = rewards[i, e] - values[i, e]
+                gae_v = np.float32(0)
+            elif i == T - 1:
+                if last_values is None:
+                    delta = rewards[i, e] - values[i, e]
+                else:
+                    delta = (rewards[i, e] + g * np.float32(last_values[e])) - values[i, e]
+            else:
+                delta = (rewards[i, e] + g * values[i + 1, e]) - values[i, e]
+            gae_v = np.float32(delta + gl * gae_v)
+            adv[i, e] = gae_v
+    return adv
+
+
+# ------------------------------------------------------------------------------------------
+# epsilon-greedy (srl/algorithms/rainbow/rainbow.py:301-329) with explicit uniforms; the random
+# branch picks the floor(u2 * n_valid)-th valid action (the reference uses random.choice on the
+# same list; a device stream cannot reproduce Python's _randbelow bit stream)
+# ------------------------------------------------------------------------------------------
+def epsilon_greedy(q, eps, u, invalid=None):
+    q = np.asarray(q, np.float32)
+    E, A = q.shape
+    out = np.zeros(E, np.int32)
+    for e in range(E):
+        inv = np.zeros(A, bool) if invalid is None else np.asarray(invalid[e], bool)
+        if u[e, 0] < float(eps[e]):
+            valid = [a for a in range(A) if not inv[a]]
+            k = min(int(u[e, 1] * len(valid)), len(valid) - 1)
+            out[e] = valid[k]
+        else:
+            qq = q[e].copy()
+            qq[inv] = -np.inf
+            out[e] = int(np.argmax(qq))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# Lock-step transition store: a plain-Python model of E environments following the reference's
+# per-environment semantics --
+#   frame stacking with zero history at episode start  (srl/base/rl/worker_run.py:277,316-322;
+#       srl/base/spaces/box.py:303-312; oldest frame first)
+#   n-step item = n+1 stacked states, n (action, reward, terminated) rows, and after an episode end
+#       rows repeat the terminal state with reward 0 / terminated 1 / a random action
+#       (srl/algorithms/rainbow/rainbow.py:331-372)
+#   reward clipping to {-1,0,1} (rainbow.py:337-343)
+# ------------------------------------------------------------------------------------------
+class StoreOracle:
+    TERM, DONE, INVALID = 1, 2, 4
+
+    def __init__(self, n_envs, ring_len, obs_elems, window, n_step, n_actions, reward_clip, seed, u8=True):
+        self.E, self.L, self.F, self.W, self.n, self.A = n_envs, ring_len, obs_elems, window, n_step, n_actions
+        self.reward_clip, self.seed, self.u8 = reward_clip, np.uint64(seed), u8
+        self.item_len = ring_len - (n_step + window)
+        self.obs = np.zeros((n_envs, ring_len, obs_elems), np.uint8 if u8 else np.float32)
+        self.action = np.zeros((n_envs, ring_len), np.int32)
+        self.reward = np.zeros((n_envs, ring_len), np.float32)
+        self.flags = np.zeros((n_envs, ring_len), np.uint8)
+        self.step_in_ep = np.zeros((n_envs, ring_len), np.int32)
+        self.needs_reset = np.zeros(n_envs, bool)
+        self.pos = 0
+
+    def reset_all(self, first_obs):
+        self.pos = 0
+        self.obs[:, 0] = first_obs
+        self.step_in_ep[:, 0] = 0
+        self.flags[:, 0] = 0
+        self.needs_reset[:] = False
+
+    def _norm(self, frame):
+        return frame.astype(np.float32) / np.float32(255.0) if self.u8 else frame.astype(np.float32)
+
+    def stack_at(self, e, x):
+        out = np.zeros((self.W, self.F), np.float32)
+        sie = self.step_in_ep[e, x % self.L]
+        for c in range(self.W):
+            back = self.W - 1 - c
+            if back <= sie:
+                out[c] = self._norm(self.obs[e, (x - back) % self.L])
+        return out
+
+    def stack_current(self):
+        return np.stack([self.stack_at(e, self.pos) for e in range(self.E)])
+
+    def commit_step(self, actions, rewards, terminated, done, next_obs):
+        p, L = self.pos, self.L
+        mask = np.zeros(self.E, np.uint8)
+        for e in range(self.E):
+            r, r1 = p % L, (p + 1) % L
+            self.obs[e, r1] = next_obs[e]
+            if self.needs_reset[e]:
+                self.flags[e, r] = self.INVALID
+                self.action[e, r] = 0
+                self.reward[e, r] = 0
+                self.step_in_ep[e, r1] = 0
+                self.needs_reset[e] = False
+            else:
+                rew = np.float32(rewards[e])
+                if self.reward_clip:
+                    rew = np.float32(-1 if rew < 0 else (1 if rew > 0 else 0))
+                self.flags[e, r] = (self.TERM if terminated[e] else 0) | (self.DONE if done[e] else 0)
+                self.action[e, r] = actions[e]
+                self.reward[e, r] = rew
+                self.step_in_ep[e, r1] = self.step_in_ep[e, r] + 1
+                self.needs_reset[e] = bool(done[e])
+            q = p - (self.n - 1)
+            mask[e] = 1 if (q >= 0 and not (self.flags[e, q % L] & self.INVALID)) else 0
+        self.pos += 1
+        return mask
+
+    def locate(self, tree_idx):
+        N = self.E * self.item_len
+        j = min(max(int(tree_idx) - (N - 1), 0), N - 1)
+        e, tau = j % self.E, j // self.E
+        p_last = self.pos - 1
+        p_add = p_last - ((p_last - tau) % self.item_len)
+        return e, max(p_add - (self.n - 1), 0)
+
+    def gather_item(self, e, q):
+        n, L = self.n, self.L
+        obs = np.zeros((n + 1, self.W, self.F), np.float32)
+        actions = np.zeros(n, np.int32)
+        rewards = np.zeros(n, np.float32)
+        terminated = np.zeros(n, np.float32)
+        jd = n
+        for k in range(n):
+            if self.flags[e, (q + k) % L] & self.DONE:
+                jd = k
+                break
+        for k in range(n + 1):
+            obs[k] = self.stack_at(e, q + min(k, jd + 1))
+        for k in range(n):
+            r = (q + k) % L
+            if k <= jd:
+                actions[k] = self.action[e, r]
+                rewards[k] = self.reward[e, r]
+                terminated[k] = 1.0 if self.flags[e, r] & self.TERM else 0.0
+            else:
+                key = np.uint64(e * 0x100000000 + (q & 0xFFFFFFFF))
+                actions[k] = int(rng_u64(self.seed ^ np.uint64(0x70616464), key, np.uint64(k)) % np.uint64(self.A))
+                rewards[k] = 0.0
+                terminated[k] = 1.0
+        return obs, actions, rewards, terminated, jd
+
+    def gather_nstep(self, tree_indices):
+        outs = [self.gather_item(*self.locate(ti))[:4] for ti in tree_indices]
+        return tuple(np.stack([o[i] for o in outs]) for i in range(4))
+
+
+def synth_env_step(store: StoreOracle, episode_len):
+    """Mirror of srlx_synth_env_step (synthetic workload definition)."""
+    E, F, p = store.E, store.F, store.pos
+    next_obs = np.zeros((E, F), np.uint8 if store.u8 else np.float32)
+    rewards = np.zeros(E, np.float32)
+    term = np.zeros(E, np.uint8)
+    done = np.zeros(E, np.uint8)
+    for e in range(E):
+        key = np.uint64(e * 0x100000000 + ((p + 1) & 0xFFFFFFFF))
+        if store.u8:
+            words = rng_u64(store.seed, key, np.arange((F + 7) // 8, dtype=np.uint64))
+            next_obs[e] = words.view(np.uint8)[:F]
+        else:
+            next_obs[e] = (2.0 * u53(rng_u64(store.seed, key, np.arange(F, dtype=np.uint64))) - 1.0).astype(np.float32)
+        if store.needs_reset[e]:
+            continue
+        key0 = np.uint64(e * 0x100000000 + (p & 0xFFFFFFFF))
+        rewards[e] = float(int(rng_u64(store.seed ^ np.uint64(0x726577), key0, np.uint64(0)) % np.uint64(3)) - 1)
+        d = 1 if store.step_in_ep[e, p % store.L] + 1 >= episode_len else 0
+        term[e] = d
+        done[e] = d
+    return next_obs, rewards, term, done

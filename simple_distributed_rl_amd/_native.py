@@ -50,7 +50,27 @@ SIGNATURES = {
     "srlx_per_tree_ptr": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i64)]),
     "srlx_per_state_ptr": (c_int, [c_p, ctypes.POINTER(c_p)]),
     "srlx_per_refresh": (c_int, [c_p, c_p]),
+    "srlx_rng_uniform": (c_int, [ctypes.c_uint64, c_p, c_i64, c_p, c_p]),
+    "srlx_store_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, c_int]),
+    "srlx_store_destroy": (c_int, [c_p]),
+    "srlx_store_item_len": (c_i64, [c_p]),
+    "srlx_store_per_capacity": (c_i64, [c_p]),
+    "srlx_store_reset_all": (c_int, [c_p, c_p, c_p]),
+    "srlx_store_stack_current": (c_int, [c_p, c_p, c_p]),
+    "srlx_store_commit_step": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_store_views": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p)]),
+    "srlx_store_gather_nstep": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_policy_epsilon_greedy": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_synth_env_step": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_nstep_td_huber_priority": (
+        c_int,
+        [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_int, c_int, c_p, c_p, c_p, c_p, c_p],
+    ),
+    "srlx_dqn_target": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_int, c_int, c_int, c_p, c_p]),
+    "srlx_gae_scan": (c_int, [c_i64, c_i64, c_p, c_p, c_p, c_p, c_f64, c_f64, c_p, c_p]),
 }
+OBS_U8, OBS_F32 = 0, 1
+PRIO_NONE_MASKED = 4
 
 _lib = None
 _lock = threading.Lock()
@@ -104,6 +124,11 @@ def device_info(device=0):
 
 def np_ptr(a):
     return a.ctypes.data_as(c_p)
+
+
+def tptr(t):
+    """device (or host) pointer of a torch tensor as c_void_p; None passes NULL."""
+    return None if t is None else c_p(t.data_ptr())
 
 
 def torch_stream_ptr():

@@ -72,6 +72,7 @@ __device__ __forceinline__ double load_prio(const void *prio, int kind, i64 i, d
         case SRLX_PRIO_NONE: return max_priority;
         case SRLX_PRIO_F64: return transform_f64(((const double *)prio)[i], eps, alpha);
         case SRLX_PRIO_F32: return transform_f32(((const float *)prio)[i], eps, alpha);
+        case SRLX_PRIO_NONE_MASKED: return ((const unsigned char *)prio)[i] ? max_priority : 0.0;
         default: return ((const double *)prio)[i];
     }
 }
@@ -602,7 +603,7 @@ namespace {
 
 hipStream_t pick_stream(srlx_per *h, void *stream) { return stream ? (hipStream_t)stream : h->stream; }
 
-size_t prio_elem_bytes(int kind) { return kind == SRLX_PRIO_F32 ? 4 : 8; }
+size_t prio_elem_bytes(int kind) { return kind == SRLX_PRIO_F32 ? 4 : (kind == SRLX_PRIO_NONE_MASKED ? 1 : 8); }
 
 int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st) {
     SRLX_TRY(h->scratch.reserve(srlx::Carver::padded((size_t)n * 8)));
@@ -784,7 +785,7 @@ int srlx_per_add(srlx_per_t *h, int64_t n, const void *prio, int prio_kind, int 
     SRLX_REQUIRE(h, "per_add: NULL handle");
     SRLX_REQUIRE(n >= 0 && n <= h->capacity, "per_add: n=%lld must be in [0, capacity=%lld]", (long long)n,
                  (long long)h->capacity);
-    SRLX_REQUIRE(prio_kind >= SRLX_PRIO_NONE && prio_kind <= SRLX_PRIO_RAW, "per_add: bad prio_kind %d", prio_kind);
+    SRLX_REQUIRE(prio_kind >= SRLX_PRIO_NONE && prio_kind <= SRLX_PRIO_NONE_MASKED, "per_add: bad prio_kind %d", prio_kind);
     SRLX_REQUIRE(prio_kind == SRLX_PRIO_NONE || prio != nullptr, "per_add: prio is NULL");
     if (n == 0) return SRLX_OK;
     srlx::DeviceGuard guard(h->device);

@@ -1,0 +1,546 @@
+// srlx_rollout.hip -- device-resident transition store + batched policy step for E lock-stepped envs.
+//
+// Replaces (vectorised engine): WorkerRun frame stacking / tracking ring
+// (srl/base/rl/worker_run.py:310-358,548-610; srl/base/spaces/box.py:303-312), the Rainbow worker's
+// n-step item assembly with terminal padding (srl/algorithms/rainbow/rainbow.py:331-400), the
+// zlib+pickle item storage (srl/rl/memories/priority_replay_buffer.py:205-217,242-243), the nested-list
+// -> ndarray batch assembly (rainbow.py:190-194) and epsilon-greedy selection (rainbow.py:301-329).
+//
+// HBM layout:  frames [E][L][F] uint8 (or float32) -- an item's n-step window (W+n frames) is ONE
+// contiguous span of the ring; scalars action/reward/flags/step_in_episode [E][L].  A stacked fp32
+// observation is never stored: it is rebuilt from W uint8 frames on every read (7 056 B read instead of
+// 112 896 B per state; the reference stores 451 584 B of float pixels per item).
+//
+// All frame movers handle 16 bytes per lane (global_load_dwordx4 -> 4 x global_store_dwordx4 for the
+// u8 -> f32 expansion); they are HBM-bound: algorithmic bytes per frame = F read + 4F written.
+#include <new>
+
+#include "srlx_common.h"
+
+namespace {
+
+using i64 = int64_t;
+using u64 = unsigned long long;
+using u8 = unsigned char;
+
+constexpr u8 kTerm = 1, kDone = 2, kInvalid = 4;
+
+__host__ __device__ __forceinline__ u64 mix64(u64 z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// keyed counter RNG: restated in oracle/hot_path_oracle.py (rng_u64)
+__host__ __device__ __forceinline__ u64 rng_u64(u64 seed, u64 a, u64 b) {
+    return mix64(mix64(seed + a * 0xD1342543DE82EF95ull) + b * 0xAEF17502108EF2D9ull);
+}
+__host__ __device__ __forceinline__ double u53(u64 x) { return (double)(x >> 11) * (1.0 / 9007199254740992.0); }
+
+__device__ __forceinline__ i64 posmod(i64 a, i64 m) {
+    i64 r = a % m;
+    return r < 0 ? r + m : r;
+}
+
+struct StoreDev {
+    i64 E, L, F;
+    int obs_dtype, W, n, A, reward_clip;
+    u64 seed;
+    i64 item_len;
+    void *obs;
+    int32_t *action;
+    float *reward;
+    u8 *flags;
+    int32_t *step_in_ep;
+    i64 *pos;  // [0] ring position p, [1] rng counter
+    u8 *needs_reset;
+};
+
+// u8/255 in float32, correctly rounded (image_processor.py:140-142 `state.astype(float32); state /= 255`)
+__device__ __forceinline__ float norm_u8(unsigned b) { return __fdiv_rn((float)b, 255.0f); }
+
+// one 16-byte chunk of a frame: u8 -> 16 normalised floats (or zeros)
+__device__ __forceinline__ void emit_chunk_u8(const u8 *src_frame, bool zero, i64 chunk, float *dst_frame) {
+    float4 *d = reinterpret_cast<float4 *>(dst_frame) + chunk * 4;
+    if (zero) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        d[0] = z;
+        d[1] = z;
+        d[2] = z;
+        d[3] = z;
+        return;
+    }
+    const uint4 v = reinterpret_cast<const uint4 *>(src_frame)[chunk];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        d[k] = make_float4(norm_u8(w[k] & 255u), norm_u8((w[k] >> 8) & 255u), norm_u8((w[k] >> 16) & 255u),
+                           norm_u8(w[k] >> 24));
+}
+
+// stacked observation at ring position x of env e: channel c holds the frame W-1-c steps back, zeros
+// before the episode start (worker_run.py:277,316-322)
+template <bool VEC>
+__device__ __forceinline__ void emit_stack_elem(const StoreDev &s, i64 e, i64 x, int c, i64 unit, float *dst_frame) {
+    const int back = s.W - 1 - c;
+    const i64 rx = posmod(x, s.L);
+    const bool zero = back > s.step_in_ep[e * s.L + rx];
+    const i64 rf = posmod(x - back, s.L);
+    if (s.obs_dtype == SRLX_OBS_U8) {
+        const u8 *src = (const u8 *)s.obs + (e * s.L + rf) * s.F;
+        if (VEC) {
+            emit_chunk_u8(src, zero, unit, dst_frame);
+        } else {
+            dst_frame[unit] = zero ? 0.f : norm_u8(src[unit]);
+        }
+    } else {
+        const float *src = (const float *)s.obs + (e * s.L + rf) * s.F;
+        if (VEC) {
+            reinterpret_cast<float4 *>(dst_frame)[unit] = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4 *>(src)[unit];
+        } else {
+            dst_frame[unit] = zero ? 0.f : src[unit];
+        }
+    }
+}
+
+// units per frame for the vector / scalar paths
+__host__ __device__ __forceinline__ i64 units_per_frame(i64 F, int obs_dtype, bool vec) {
+    if (!vec) return F;
+    return obs_dtype == SRLX_OBS_U8 ? F / 16 : F / 4;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_stack_current(StoreDev s, float *out) {
+    const i64 upf = units_per_frame(s.F, s.obs_dtype, VEC);
+    const i64 total = s.E * s.W * upf;
+    const i64 p = s.pos[0];
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        const i64 unit = t % upf;
+        const i64 fc = t / upf;
+        const int c = (int)(fc % s.W);
+        const i64 e = fc / s.W;
+        emit_stack_elem<VEC>(s, e, p, c, unit, out + fc * s.F);
+    }
+}
+
+__global__ void k_reset_all(StoreDev s, const void *first_obs) {
+    const i64 upf = s.obs_dtype == SRLX_OBS_U8 ? s.F : s.F * 4;  // bytes
+    const i64 total = s.E * upf;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        const i64 e = t / upf, b = t % upf;
+        ((u8 *)s.obs)[(e * s.L) * upf + b] = ((const u8 *)first_obs)[t];
+    }
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < s.E; e += (i64)gridDim.x * blockDim.x) {
+        s.needs_reset[e] = 0;
+        s.step_in_ep[e * s.L] = 0;
+        s.flags[e * s.L] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) s.pos[0] = 0;
+}
+
+// scalar part of a commit, one thread per env
+__global__ void __launch_bounds__(256) k_commit_scalars(StoreDev s, const int32_t *actions, const float *rewards,
+                                                         const u8 *terminated, const u8 *done, u8 *item_mask) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.E) return;
+    const i64 p = s.pos[0];
+    const i64 r = posmod(p, s.L), r1 = posmod(p + 1, s.L);
+    const i64 base = e * s.L;
+    if (s.needs_reset[e]) {
+        // position p holds the previous episode's terminal frame: no transition starts here
+        s.flags[base + r] = kInvalid;
+        s.action[base + r] = 0;
+        s.reward[base + r] = 0.f;
+        s.step_in_ep[base + r1] = 0;
+        s.needs_reset[e] = 0;
+    } else {
+        float rew = rewards[e];
+        if (s.reward_clip) rew = rew < 0.f ? -1.f : (rew > 0.f ? 1.f : 0.f);  // rainbow.py:337-343
+        const u8 d = done[e] ? 1 : 0, tm = terminated[e] ? 1 : 0;
+        s.flags[base + r] = (tm ? kTerm : 0) | (d ? kDone : 0);
+        s.action[base + r] = actions[e];
+        s.reward[base + r] = rew;
+        s.step_in_ep[base + r1] = s.step_in_ep[base + r] + 1;
+        s.needs_reset[e] = d;
+    }
+    if (item_mask) {
+        const i64 q = p - (s.n - 1);
+        item_mask[e] = (q >= 0 && !(s.flags[base + posmod(q, s.L)] & kInvalid)) ? 1 : 0;
+    }
+}
+
+// frame part of a commit: next_obs[e] -> ring position p+1 (16 B per lane when possible)
+__global__ void __launch_bounds__(256) k_commit_frames(StoreDev s, const void *next_obs) {
+    const i64 fb = s.obs_dtype == SRLX_OBS_U8 ? s.F : s.F * 4;  // frame bytes
+    const i64 r1 = posmod(s.pos[0] + 1, s.L);
+    if ((fb & 15) == 0) {
+        const i64 cpf = fb / 16, total = s.E * cpf;
+        for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+            const i64 e = t / cpf, c = t % cpf;
+            reinterpret_cast<uint4 *>((u8 *)s.obs + (e * s.L + r1) * fb)[c] = reinterpret_cast<const uint4 *>(next_obs)[t];
+        }
+    } else {
+        const i64 total = s.E * fb;
+        for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+            const i64 e = t / fb, c = t % fb;
+            ((u8 *)s.obs)[(e * s.L + r1) * fb + c] = ((const u8 *)next_obs)[t];
+        }
+    }
+}
+
+__global__ void k_advance(i64 *counter) { counter[0] += 1; }
+
+// ------------------------------------------------------------------------------------------
+// gather_nstep
+// ------------------------------------------------------------------------------------------
+struct ItemMeta {
+    i64 e, q;
+    int jd;  // first transition index that ended the episode (n if none)
+    int pad;
+};
+
+// per sampled item: locate (env, position), find the episode end inside the window, emit the scalars
+__global__ void __launch_bounds__(256) k_gather_meta(StoreDev s, i64 B, const i64 *tree_idx, ItemMeta *meta,
+                                                      int32_t *actions, float *rewards, float *terminated) {
+    const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const i64 N = s.E * s.item_len;
+    i64 j = tree_idx[b] - (N - 1);
+    if (j < 0) j = 0;
+    if (j >= N) j = N - 1;
+    const i64 e = j % s.E, tau = j / s.E;
+    const i64 p_last = s.pos[0] - 1;
+    const i64 p_add = p_last - posmod(p_last - tau, s.item_len);
+    i64 q = p_add - (s.n - 1);
+    if (q < 0) q = 0;
+    const i64 base = e * s.L;
+    int jd = s.n;
+    for (int k = 0; k < s.n; k++)
+        if (s.flags[base + posmod(q + k, s.L)] & kDone) {
+            jd = k;
+            break;
+        }
+    meta[b].e = e;
+    meta[b].q = q;
+    meta[b].jd = jd;
+    for (int k = 0; k < s.n; k++) {
+        const i64 r = base + posmod(q + k, s.L);
+        if (k <= jd) {
+            actions[b * s.n + k] = s.action[r];
+            rewards[b * s.n + k] = s.reward[r];
+            terminated[b * s.n + k] = (s.flags[r] & kTerm) ? 1.f : 0.f;
+        } else {
+            // terminal padding (rainbow.py:354-372): random action, reward 0, terminated 1.  The action is
+            // a fixed function of the item so that re-sampling the item reproduces it.
+            actions[b * s.n + k] = (int32_t)(rng_u64(s.seed ^ 0x70616464ull, (u64)(e * 0x100000000ll + (q & 0xffffffffll)), (u64)k) % (u64)s.A);
+            rewards[b * s.n + k] = 0.f;
+            terminated[b * s.n + k] = 1.f;
+        }
+    }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_gather_obs(StoreDev s, i64 B, const ItemMeta *meta, float *out) {
+    const i64 upf = units_per_frame(s.F, s.obs_dtype, VEC);
+    const int S = s.n + 1;
+    const i64 total = B * S * s.W * upf;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        const i64 unit = t % upf;
+        const i64 fc = t / upf;  // (b, k, c)
+        const int c = (int)(fc % s.W);
+        const i64 bk = fc / s.W;
+        const int k = (int)(bk % S);
+        const i64 b = bk / S;
+        const ItemMeta m = meta[b];
+        const int kk = k < m.jd + 1 ? k : m.jd + 1;  // states after the terminal one repeat it (rainbow.py:358)
+        emit_stack_elem<VEC>(s, m.e, m.q + kk, c, unit, out + fc * s.F);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// epsilon-greedy (rainbow.py:301-329)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_eps_greedy(i64 E, int A, const float *q, const float *eps, const double *u,
+                                                     const u8 *invalid, int32_t *actions) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const float *qe = q + e * A;
+    const u8 *inv = invalid ? invalid + e * A : nullptr;
+    if (u[2 * e] < (double)eps[e]) {  // random.random() < epsilon (:317)
+        int nv = 0;
+        for (int a = 0; a < A; a++) nv += !(inv && inv[a]);
+        int pick = (int)(u[2 * e + 1] * (double)nv);
+        if (pick >= nv) pick = nv - 1;
+        int act = 0;
+        for (int a = 0; a < A; a++) {
+            if (inv && inv[a]) continue;
+            if (pick == 0) {
+                act = a;
+                break;
+            }
+            pick--;
+        }
+        actions[e] = act;
+    } else {  // q[invalid] = -inf; argmax (first maximum, like np.argmax) (:321-325)
+        int best = 0;
+        float bv = -INFINITY;
+        bool have = false;
+        for (int a = 0; a < A; a++) {
+            const float v = (inv && inv[a]) ? -INFINITY : qe[a];
+            if (!have || v > bv) {
+                best = a;
+                bv = v;
+                have = true;
+            }
+        }
+        actions[e] = best;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rng_uniform(u64 seed, const i64 *counter, i64 n, double *out) {
+    const u64 c = (u64)counter[0];
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
+        out[i] = u53(rng_u64(seed, c, (u64)i));
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic environment batch
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_synth_frames(StoreDev s, void *next_obs) {
+    const i64 fb = s.obs_dtype == SRLX_OBS_U8 ? s.F : s.F * 4;
+    const i64 p1 = s.pos[0] + 1;
+    if (s.obs_dtype == SRLX_OBS_U8 && (fb & 15) == 0) {
+        const i64 cpf = fb / 16, total = s.E * cpf;
+        for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+            const i64 e = t / cpf, c = t % cpf;
+            const u64 key = (u64)(e * 0x100000000ll + (p1 & 0xffffffffll));
+            const u64 a = rng_u64(s.seed, key, (u64)(2 * c)), b = rng_u64(s.seed, key, (u64)(2 * c + 1));
+            reinterpret_cast<uint4 *>(next_obs)[t] = make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32));
+        }
+    } else if (s.obs_dtype == SRLX_OBS_U8) {
+        const i64 total = s.E * fb;
+        for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+            const i64 e = t / fb, c = t % fb;
+            const u64 key = (u64)(e * 0x100000000ll + (p1 & 0xffffffffll));
+            ((u8 *)next_obs)[t] = (u8)(rng_u64(s.seed, key, (u64)(c / 8)) >> (8 * (c % 8)));
+        }
+    } else {
+        const i64 total = s.E * s.F;
+        for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+            const i64 e = t / s.F, c = t % s.F;
+            const u64 key = (u64)(e * 0x100000000ll + (p1 & 0xffffffffll));
+            ((float *)next_obs)[t] = (float)(2.0 * u53(rng_u64(s.seed, key, (u64)c)) - 1.0);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_synth_scalars(StoreDev s, i64 episode_len, float *rewards, u8 *terminated, u8 *done) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.E) return;
+    const i64 p = s.pos[0];
+    if (s.needs_reset[e]) {
+        rewards[e] = 0.f;
+        terminated[e] = 0;
+        done[e] = 0;
+        return;
+    }
+    const u64 key = (u64)(e * 0x100000000ll + (p & 0xffffffffll));
+    rewards[e] = (float)((int)(rng_u64(s.seed ^ 0x726577ull, key, 0) % 3ull) - 1);
+    const int sie = s.step_in_ep[e * s.L + posmod(p, s.L)];
+    const u8 d = (sie + 1 >= episode_len) ? 1 : 0;
+    terminated[e] = d;
+    done[e] = d;
+}
+
+}  // namespace
+
+struct srlx_store {
+    StoreDev d;
+    int device;
+    hipStream_t stream;
+    srlx::Arena scratch;
+    bool vec;
+};
+
+namespace {
+hipStream_t pick(srlx_store *h, void *st) { return st ? (hipStream_t)st : h->stream; }
+int grid_for(i64 total, int cap = 256 * 16) {
+    i64 b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b < cap ? b : cap);
+}
+}  // namespace
+
+extern "C" {
+
+int srlx_store_create(srlx_store_t **out, int64_t n_envs, int64_t ring_len, int64_t obs_elems, int obs_dtype, int window,
+                      int n_step, int n_actions, int reward_clip, uint64_t seed, int device) {
+    SRLX_REQUIRE(out, "store_create: out is NULL");
+    SRLX_REQUIRE(n_envs > 0 && obs_elems > 0 && window >= 1 && n_step >= 1 && n_actions >= 1, "store_create: bad sizes");
+    SRLX_REQUIRE(obs_dtype == SRLX_OBS_U8 || obs_dtype == SRLX_OBS_F32, "store_create: bad obs_dtype %d", obs_dtype);
+    SRLX_REQUIRE(ring_len > (i64)n_step + window, "store_create: ring_len must exceed n_step + window");
+    int ndev = 0;
+    SRLX_HIP(hipGetDeviceCount(&ndev));
+    SRLX_REQUIRE(device >= 0 && device < ndev, "store_create: device %d not present", device);
+    srlx::DeviceGuard guard(device);
+    srlx_store *h = new (std::nothrow) srlx_store();
+    if (!h) return SRLX_ERR_NOMEM;
+    memset(&h->d, 0, sizeof(h->d));
+    h->device = device;
+    h->stream = nullptr;
+    StoreDev &d = h->d;
+    d.E = n_envs;
+    d.L = ring_len;
+    d.F = obs_elems;
+    d.obs_dtype = obs_dtype;
+    d.W = window;
+    d.n = n_step;
+    d.A = n_actions;
+    d.reward_clip = reward_clip;
+    d.seed = seed;
+    d.item_len = ring_len - (n_step + window);
+    const size_t eb = obs_dtype == SRLX_OBS_U8 ? 1 : 4;
+    const size_t cells = (size_t)n_envs * (size_t)ring_len;
+    h->vec = obs_dtype == SRLX_OBS_U8 ? (obs_elems % 16 == 0) : (obs_elems % 4 == 0);
+    hipError_t e = hipMalloc(&d.obs, cells * (size_t)obs_elems * eb);
+    if (e == hipSuccess) e = hipMalloc((void **)&d.action, cells * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d.reward, cells * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d.flags, cells);
+    if (e == hipSuccess) e = hipMalloc((void **)&d.step_in_ep, cells * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d.pos, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&d.needs_reset, (size_t)n_envs);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemset(d.flags, 0, cells);
+    if (e == hipSuccess) e = hipMemset(d.step_in_ep, 0, cells * 4);
+    if (e == hipSuccess) e = hipMemset(d.action, 0, cells * 4);
+    if (e == hipSuccess) e = hipMemset(d.reward, 0, cells * 4);
+    if (e == hipSuccess) e = hipMemset(d.pos, 0, 64);
+    if (e == hipSuccess) e = hipMemset(d.needs_reset, 0, (size_t)n_envs);
+    if (e != hipSuccess) {
+        srlx::set_error("store_create: %s", hipGetErrorString(e));
+        srlx_store_destroy(h);
+        return e == hipErrorOutOfMemory ? SRLX_ERR_NOMEM : SRLX_ERR_HIP;
+    }
+    *out = h;
+    return SRLX_OK;
+}
+
+int srlx_store_destroy(srlx_store_t *h) {
+    if (!h) return SRLX_OK;
+    srlx::DeviceGuard guard(h->device);
+    (void)hipDeviceSynchronize();
+    StoreDev &d = h->d;
+    if (d.obs) (void)hipFree(d.obs);
+    if (d.action) (void)hipFree(d.action);
+    if (d.reward) (void)hipFree(d.reward);
+    if (d.flags) (void)hipFree(d.flags);
+    if (d.step_in_ep) (void)hipFree(d.step_in_ep);
+    if (d.pos) (void)hipFree(d.pos);
+    if (d.needs_reset) (void)hipFree(d.needs_reset);
+    h->scratch.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return SRLX_OK;
+}
+
+int64_t srlx_store_item_len(const srlx_store_t *h) { return h ? h->d.item_len : -1; }
+int64_t srlx_store_per_capacity(const srlx_store_t *h) { return h ? h->d.E * h->d.item_len : -1; }
+
+int srlx_store_reset_all(srlx_store_t *h, const void *d_first_obs, void *stream) {
+    SRLX_REQUIRE(h && d_first_obs, "store_reset_all: NULL argument");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick(h, stream);
+    const i64 bytes = h->d.E * h->d.F * (h->d.obs_dtype == SRLX_OBS_U8 ? 1 : 4);
+    hipLaunchKernelGGL(k_reset_all, dim3(grid_for(bytes)), dim3(256), 0, st, h->d, d_first_obs);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_stack_current(srlx_store_t *h, float *d_out, void *stream) {
+    SRLX_REQUIRE(h && d_out, "store_stack_current: NULL argument");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick(h, stream);
+    const StoreDev &d = h->d;
+    const i64 total = d.E * d.W * units_per_frame(d.F, d.obs_dtype, h->vec);
+    if (h->vec)
+        hipLaunchKernelGGL(k_stack_current<true>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, d_out);
+    else
+        hipLaunchKernelGGL(k_stack_current<false>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, d_out);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_commit_step(srlx_store_t *h, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated,
+                           const uint8_t *d_done, const void *d_next_obs, uint8_t *d_item_mask, void *stream) {
+    SRLX_REQUIRE(h && d_actions && d_rewards && d_terminated && d_done && d_next_obs, "store_commit_step: NULL argument");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick(h, stream);
+    const StoreDev &d = h->d;
+    const i64 fb = d.F * (d.obs_dtype == SRLX_OBS_U8 ? 1 : 4);
+    hipLaunchKernelGGL(k_commit_frames, dim3(grid_for(d.E * (fb / 16 + 1))), dim3(256), 0, st, d, d_next_obs);
+    hipLaunchKernelGGL(k_commit_scalars, dim3((unsigned)((d.E + 255) / 256)), dim3(256), 0, st, d, d_actions, d_rewards,
+                       d_terminated, d_done, d_item_mask);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, d.pos);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_views(srlx_store_t *h, void **d_pos, void **d_needs_reset, void **d_step_in_ep) {
+    SRLX_REQUIRE(h, "store_views: NULL handle");
+    if (d_pos) *d_pos = h->d.pos;
+    if (d_needs_reset) *d_needs_reset = h->d.needs_reset;
+    if (d_step_in_ep) *d_step_in_ep = h->d.step_in_ep;
+    return SRLX_OK;
+}
+
+int srlx_store_gather_nstep(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, float *d_obs, int32_t *d_actions,
+                            float *d_rewards, float *d_terminated, void *stream) {
+    SRLX_REQUIRE(h && d_tree_idx && d_obs && d_actions && d_rewards && d_terminated, "store_gather_nstep: NULL argument");
+    SRLX_REQUIRE(batch > 0, "store_gather_nstep: batch must be positive");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick(h, stream);
+    const StoreDev &d = h->d;
+    SRLX_TRY(h->scratch.reserve((size_t)batch * sizeof(ItemMeta)));
+    ItemMeta *meta = (ItemMeta *)h->scratch.ptr;
+    hipLaunchKernelGGL(k_gather_meta, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, d, (i64)batch, d_tree_idx, meta,
+                       d_actions, d_rewards, d_terminated);
+    const i64 total = batch * (d.n + 1) * d.W * units_per_frame(d.F, d.obs_dtype, h->vec);
+    if (h->vec)
+        hipLaunchKernelGGL(k_gather_obs<true>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, (i64)batch, meta, d_obs);
+    else
+        hipLaunchKernelGGL(k_gather_obs<false>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, (i64)batch, meta, d_obs);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_policy_epsilon_greedy(int64_t n_envs, int n_actions, const float *d_q, const float *d_eps, const double *d_u,
+                               const uint8_t *d_invalid, int32_t *d_actions, void *stream) {
+    SRLX_REQUIRE(n_envs > 0 && n_actions > 0 && d_q && d_eps && d_u && d_actions, "policy_epsilon_greedy: bad argument");
+    hipLaunchKernelGGL(k_eps_greedy, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (i64)n_envs,
+                       n_actions, d_q, d_eps, d_u, d_invalid, d_actions);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_rng_uniform(uint64_t seed, int64_t *d_counter, int64_t n, double *d_out, void *stream) {
+    SRLX_REQUIRE(d_counter && d_out && n > 0, "rng_uniform: bad argument");
+    hipLaunchKernelGGL(k_rng_uniform, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (u64)seed, d_counter, (i64)n, d_out);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, d_counter);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, float *d_rewards, uint8_t *d_terminated,
+                        uint8_t *d_done, void *stream) {
+    SRLX_REQUIRE(h && d_next_obs && d_rewards && d_terminated && d_done && episode_len > 0, "synth_env_step: bad argument");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick(h, stream);
+    const StoreDev &d = h->d;
+    const i64 fb = d.F * (d.obs_dtype == SRLX_OBS_U8 ? 1 : 4);
+    hipLaunchKernelGGL(k_synth_frames, dim3(grid_for(d.E * (fb / 16 + 1))), dim3(256), 0, st, d, d_next_obs);
+    hipLaunchKernelGGL(k_synth_scalars, dim3((unsigned)((d.E + 255) / 256)), dim3(256), 0, st, d, (i64)episode_len, d_rewards,
+                       d_terminated, d_done);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// srlx_train.hip -- fused learner arithmetic: n-step/retrace TD target + Huber loss + gradient seed +
+// priority recompute in one launch; 1-step (double-)DQN target; GAE reverse scan.
+//
+// These replace host-side numpy between network calls in the reference:
+//   srl/algorithms/rainbow/rainbow.py:226-287        (calc_target_q after the two forwards)
+//   srl/algorithms/rainbow/model_torch.py:103-105,113 (selected Q, HuberLoss(target*w, q*w), |target-q|)
+//   srl/algorithms/dqn/dqn.py:144-176, srl/algorithms/rainbow/rainbow_nomultisteps.py:10-43
+//   srl/algorithms/ppo/ppo.py:389-404
+// All are tiny (B x n x A floats): latency-bound single-workgroup kernels whose point is to keep the
+// learner step free of device<->host hops (the reference does four per train()).
+// float32 arithmetic follows numpy's evaluation order of the cited lines.
+#include "srlx_common.h"
+
+namespace {
+
+using i64 = int64_t;
+using u8 = unsigned char;
+
+// srl/rl/functions.py:10-17 evaluated in float32 like numpy does on a float32 array
+__device__ __forceinline__ float signf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ float f_sqrt(float x) { return (float)__dsqrt_rn((double)x); }  // correctly rounded fp32 sqrt
+__device__ __forceinline__ float rescaling(float x) {
+    const float eps = 0.001f;
+    return signf(x) * (f_sqrt(fabsf(x) + 1.0f) - 1.0f) + eps * x;
+}
+__device__ __forceinline__ float inverse_rescaling(float x) {
+    const float eps = 0.001f;
+    float n = f_sqrt(1.0f + (float)(4.0 * 0.001) * ((fabsf(x) + 1.0f) + eps)) - 1.0f;
+    n = n / (float)(2.0 * 0.001);
+    return signf(x) * ((n * n) - 1.0f);
+}
+
+__device__ __forceinline__ int argmax_masked(const float *q, const u8 *inv, int A) {
+    int best = 0;
+    float bv = 0.f;
+    for (int a = 0; a < A; a++) {
+        const float v = (inv && inv[a]) ? -INFINITY : q[a];
+        if (a == 0 || v > bv) {  // np.argmax: first maximum
+            best = a;
+            bv = v;
+        }
+    }
+    return best;
+}
+
+constexpr int kMaxStep = 32;
+
+struct TdArgs {
+    i64 B;
+    int n, A;
+    const float *q_on_next, *q_tg_next, *q_on_0;
+    const int32_t *actions;
+    const float *rewards, *terminated;
+    const u8 *invalid_next;
+    const float *weights;
+    double discount, retrace_h;
+    int double_dqn, rescale;
+    float *target, *loss, *grad_q0, *priorities;
+};
+
+__global__ void __launch_bounds__(256) k_nstep_td_huber_priority(TdArgs a) {
+    __shared__ double red[256];
+    const int t = threadIdx.x, T = blockDim.x;
+    const int n = a.n, A = a.A;
+    const float disc_f = (float)a.discount;
+    double loss_acc = 0.0;
+    for (i64 b = t; b < a.B; b += T) {
+        const float *qon = a.q_on_next + b * n * A;
+        const float *qtg = a.q_tg_next + b * n * A;
+        const int32_t *act = a.actions + b * n;
+        const u8 *inv = a.invalid_next ? a.invalid_next + b * n * A : nullptr;
+        int nact[kMaxStep];
+        float td[kMaxStep];
+        for (int m = 0; m < n; m++) {
+            // rainbow.py:245-253: greedy next action from the online net (double DQN) or the target net
+            const float *sel = a.double_dqn ? qon + m * A : qtg + m * A;
+            nact[m] = argmax_masked(sel, inv ? inv + m * A : nullptr, A);
+            float maxq = qtg[m * A + nact[m]];
+            if (a.rescale) maxq = inverse_rescaling(maxq);  // :255-256
+            float gain = a.rewards[b * n + m] + ((1.0f - a.terminated[b * n + m]) * disc_f) * maxq;  // :258
+            if (a.rescale) gain = rescaling(gain);  // :260-261
+            // :231-233 action value of the online net for steps 1..n-1, 0 for the first step
+            const float qsel = (m == 0) ? 0.f : qon[(m - 1) * A + act[m]];
+            td[m] = gain - qsel;  // :263
+        }
+        // :268-286 retrace coefficients (float64 in the reference) and the discounted sum in float32
+        double c = 1.0;
+        float target = 0.f;
+        for (int m = 0; m < n; m++) {
+            if (m > 0) {
+                const bool pi = (act[m] == nact[m]);  // argmax(n_action)[m-1] == n_act_idx[:,1:][m-1]
+                c *= a.retrace_h * (pi ? 1.0 : 0.0);
+            }
+            // multi_discounts is float32(discount**m) (:182); python evaluates discount**m with pow()
+            const float dm = (float)pow(a.discount, (double)m);
+            const float term = (float)((double)(td[m] * dm) * c);
+            target = target + term;
+        }
+        a.target[b] = target;
+
+        // model_torch.py:103-105,113
+        const int a0 = act[0];
+        const float q0 = a.q_on_0[b * A + a0];
+        const float w = a.weights[b];
+        const float tw = target * w, qw = q0 * w;
+        const float diff = tw - qw;
+        const float z = fabsf(diff);
+        loss_acc += (z < 1.0f) ? 0.5 * (double)z * (double)z : (double)z - 0.5;  // HuberLoss, delta = 1
+        const float dclamp = diff > 1.0f ? 1.0f : (diff < -1.0f ? -1.0f : diff);
+        for (int k = 0; k < A; k++) a.grad_q0[b * A + k] = 0.f;
+        a.grad_q0[b * A + a0] = -(w * dclamp) / (float)a.B;  // d mean(huber(tw - q*w)) / d q
+        a.priorities[b] = fabsf(target - q0);
+    }
+    red[t] = loss_acc;
+    __syncthreads();
+    for (int s = T >> 1; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) a.loss[0] = (float)(red[0] / (double)a.B);
+}
+
+struct DqnArgs {
+    i64 B;
+    int A;
+    const float *q_on_next, *q_tg_next, *rewards, *undone;
+    const u8 *invalid_next;
+    double discount;
+    int double_dqn, rescale, f64_accum;
+    float *target;
+};
+
+__global__ void __launch_bounds__(256) k_dqn_target(DqnArgs a) {
+    __shared__ float red[256];
+    const int t = threadIdx.x, T = blockDim.x;
+    // np.min over the WHOLE (B, A) array of the net that is masked (dqn.py:160,164)
+    const float *masked = a.double_dqn ? a.q_on_next : a.q_tg_next;
+    float mn = INFINITY;
+    for (i64 i = t; i < a.B * a.A; i += T) mn = fminf(mn, masked[i]);
+    red[t] = mn;
+    __syncthreads();
+    for (int s = T >> 1; s > 0; s >>= 1) {
+        if (t < s) red[t] = fminf(red[t], red[t + s]);
+        __syncthreads();
+    }
+    const float qmin = red[0];
+    for (i64 b = t; b < a.B; b += T) {
+        const float *row = masked + b * a.A;
+        const u8 *inv = a.invalid_next ? a.invalid_next + b * a.A : nullptr;
+        int best = 0;
+        float bv = 0.f;
+        for (int k = 0; k < a.A; k++) {
+            const float v = (inv && inv[k]) ? qmin : row[k];
+            if (k == 0 || v > bv) {
+                best = k;
+                bv = v;
+            }
+        }
+        // double: value of the target net at the online argmax (:161-162); else max of the masked target row (:165)
+        float maxq = a.double_dqn ? a.q_tg_next[b * a.A + best] : bv;
+        if (a.rescale) maxq = inverse_rescaling(maxq);
+        float tq;
+        if (a.f64_accum) {  // dqn.py:171 with an int `undone` array: numpy promotes to float64, cast at :176
+            double v = (double)a.rewards[b] + ((double)a.undone[b] * a.discount) * (double)maxq;
+            tq = (float)v;
+            if (a.rescale) tq = (float)((v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0)) * (sqrt(fabs(v) + 1.0) - 1.0) + 0.001 * v);
+        } else {  // rainbow_nomultisteps.py:38 all float32
+            tq = a.rewards[b] + (a.undone[b] * (float)a.discount) * maxq;
+            if (a.rescale) tq = rescaling(tq);
+        }
+        a.target[b] = tq;
+    }
+}
+
+// one thread per environment, reverse scan over the horizon (ppo.py:389-404)
+__global__ void __launch_bounds__(256) k_gae_scan(i64 E, i64 T, const float *rewards, const float *values, const u8 *done,
+                                                   const float *last_values, double discount, double lam, float *adv) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const float g = (float)discount;
+    const float gl = (float)(discount * lam);  // python: discount * gae_discount (float64) * np.float32 -> float32
+    float gae = 0.f;
+    for (i64 i = T - 1; i >= 0; i--) {
+        const i64 k = i * E + e;
+        float delta;
+        if (done[k]) {
+            delta = rewards[k] - values[k];  // :396-397 last step of an episode: no bootstrap
+            gae = 0.f;
+        } else if (i == T - 1) {
+            delta = last_values ? (rewards[k] + g * last_values[e]) - values[k] : rewards[k] - values[k];
+        } else {
+            delta = (rewards[k] + g * values[k + E]) - values[k];  // :399
+        }
+        gae = delta + gl * gae;  // :400
+        adv[k] = gae;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int srlx_nstep_td_huber_priority(int64_t batch, int n_step, int n_actions, const float *d_q_on_next,
+                                 const float *d_q_tg_next, const float *d_q_on_0, const int32_t *d_actions,
+                                 const float *d_rewards, const float *d_terminated, const uint8_t *d_invalid_next,
+                                 const float *d_weights, double discount, double retrace_h, int enable_double_dqn,
+                                 int enable_rescale, float *d_target, float *d_loss, float *d_grad_q0,
+                                 float *d_priorities, void *stream) {
+    SRLX_REQUIRE(batch > 0 && n_step >= 1 && n_step <= kMaxStep && n_actions >= 1, "nstep_td: bad sizes (n_step <= %d)", kMaxStep);
+    SRLX_REQUIRE(d_q_on_next && d_q_tg_next && d_q_on_0 && d_actions && d_rewards && d_terminated && d_weights,
+                 "nstep_td: NULL input");
+    SRLX_REQUIRE(d_target && d_loss && d_grad_q0 && d_priorities, "nstep_td: NULL output");
+    TdArgs a{batch, n_step, n_actions, d_q_on_next, d_q_tg_next, d_q_on_0, d_actions, d_rewards, d_terminated,
+             d_invalid_next, d_weights, discount, retrace_h, enable_double_dqn, enable_rescale, d_target, d_loss,
+             d_grad_q0, d_priorities};
+    hipLaunchKernelGGL(k_nstep_td_huber_priority, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_dqn_target(int64_t batch, int n_actions, const float *d_q_on_next, const float *d_q_tg_next,
+                    const float *d_rewards, const float *d_undone, const uint8_t *d_invalid_next, double discount,
+                    int enable_double_dqn, int enable_rescale, int f64_accum, float *d_target, void *stream) {
+    SRLX_REQUIRE(batch > 0 && n_actions >= 1, "dqn_target: bad sizes");
+    SRLX_REQUIRE(d_q_tg_next && d_rewards && d_undone && d_target && (d_q_on_next || !enable_double_dqn), "dqn_target: NULL argument");
+    DqnArgs a{batch, n_actions, d_q_on_next, d_q_tg_next, d_rewards, d_undone, d_invalid_next, discount,
+              enable_double_dqn, enable_rescale, f64_accum, d_target};
+    hipLaunchKernelGGL(k_dqn_target, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_gae_scan(int64_t n_envs, int64_t horizon, const float *d_rewards, const float *d_values, const uint8_t *d_done,
+                  const float *d_last_values, double discount, double gae_lambda, float *d_adv, void *stream) {
+    SRLX_REQUIRE(n_envs > 0 && horizon > 0 && d_rewards && d_values && d_done && d_adv, "gae_scan: bad argument");
+    hipLaunchKernelGGL(k_gae_scan, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (i64)n_envs,
+                       (i64)horizon, d_rewards, d_values, d_done, d_last_values, discount, gae_lambda, d_adv);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+}  // extern "C"

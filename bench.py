@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""bench.py -- Rainbow 84x84x4 actor/learner throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input on every rank:
+    E lock-stepped synthetic Atari-shaped environments advance one step
+        (frame-stack -> Q-network -> epsilon-greedy -> env -> ring commit -> PER add), and
+    U full Rainbow learner updates run (PER sample B=32 -> n-step gather -> forwards -> fused
+        TD/Huber/priority kernel -> backward -> Adam -> PER update) against a 1M-transition PER.
+`value` = whole-job env-steps/s; learner updates/s is reported next to it.  All inputs (frame ring,
+sum-tree, networks) are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=1024, help="environments per GPU (E)")
+    ap.add_argument("--updates", type=int, default=8, help="learner updates per step on the learner rank (U)")
+    ap.add_argument("--capacity", type=int, default=1_000_000)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--episode-len", type=int, default=200)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
+    ap.add_argument("--per-micro", action="store_true", help="also time the bulk PER sample kernel (extra field)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    else:
+        dist = None
+
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+
+    cfg = RainbowDeviceConfig(n_envs=args.envs, batch_size=args.batch_size, memory_capacity=args.capacity, seed=rank)
+
+    if world > 1:
+        from simple_distributed_rl_amd.device.dist import DistributedRainbow
+
+        eng = DistributedRainbow(cfg, local_rank, args.episode_len, sync_interval=args.sync_interval)
+    else:
+        eng = RainbowEngine(cfg, local_rank, args.episode_len)
+    is_learner = rank == 0
+
+    # ---- fill the replay (untimed): random-policy rollout until the ring is full, then |delta| ~ U(0,1)
+    #      priorities like tests/quick/rl/memories/speedtest.py:40-41
+    eng.prefill()
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(args.updates)
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        eng.capture_graphs()
+
+    # HIP events around the dominant hand-written kernel (frame-stack expansion) on its launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        eng.step(args.updates, events=ev[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stack_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    stack_bytes = eng.stack_bytes_per_launch()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    env_steps = args.steps * args.envs * world
+    updates = args.steps * args.updates
+    info = eng.info()
+    out = {
+        "metric": "env-steps/sec + learner updates/sec, Rainbow 84x84x4",
+        "value": env_steps / elapsed,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "learner_updates_per_s": updates / elapsed,
+        "config": {
+            "workload": "Rainbow on synthetic 84x84x4 Atari frames, PER 1M transitions, n-step=3 (BASELINE.json configs[2])",
+            "envs_per_gpu": args.envs,
+            "learner_updates_per_step": args.updates,
+            "batch_size": args.batch_size,
+            "per_capacity": eng.replay.capacity,
+            "n_step": cfg.multisteps,
+            "window": cfg.window_length,
+            "n_actions": cfg.n_actions,
+            "noisy_dense": cfg.enable_noisy_dense,
+            "epsilon": cfg.epsilon,
+            "hip_graphs": not args.no_graph,
+            "topology": "1 GPU: actor+learner" if world == 1 else f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast",
+        },
+        "roofline": {
+            "kernel": "k_stack_current (uint8 frame ring -> float32 [E,4,84,84] policy input)",
+            "bound": "hbm",
+            "achieved": stack_bytes / (stack_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": stack_bytes / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_launch": stack_bytes,
+            "avg_launch_ms": stack_ms,
+        },
+        "final": {"loss": info["loss"], "train_count": info["train_count"], "memory": info["memory"]},
+    }
+    if args.per_micro:
+        out["per_micro"] = per_micro(eng)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, cfg)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def per_micro(eng, draws=1 << 20, reps=20):
+    """Bulk PER sampling (LDS-staged multi-workgroup descent) on the benchmark's own 1M-leaf tree."""
+    import torch
+
+    from simple_distributed_rl_amd import _native as N
+
+    r = eng.replay
+    d = r.dev
+    u = torch.rand(draws, dtype=torch.float64, device=d)
+    idx = torch.empty(draws, dtype=torch.int64, device=d)
+    w = torch.empty(draws, dtype=torch.float32, device=d)
+    used = torch.zeros(1, dtype=torch.int64, device=d)
+    step = torch.zeros(1, dtype=torch.int64, device=d)
+
+    def run():
+        N.check(r.lib.srlx_per_sample(r.h_per, draws, 0, N.tptr(step), N.tptr(u), draws, N.tptr(idx), None, N.tptr(w), N.tptr(used), 1, N.torch_stream_ptr()))
+
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    depth = (2 * r.capacity - 1).bit_length() - 1
+    bytes_per_draw = (depth + 1) * 8 + 8 + 12  # tree reads + uniform in + index/weight out
+    return {
+        "kernel": "per_sample bulk (descend+compact+weights+normalise)",
+        "draws_per_call": draws,
+        "ms_per_call": ms,
+        "draws_per_s": draws / (ms * 1e-3),
+        "algorithmic_GBs": draws * bytes_per_draw / (ms * 1e-3) / 1e9,
+        "frac_of_hbm_peak": draws * bytes_per_draw / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }
+
+
+def cpu_baseline(args, cfg):
+    """The reference-shaped CPU path (sequential, one environment, batch-1 policy inference, PER in the
+    C oracle, numpy target, torch-CPU network) timed on this box's host cores on a bounded sample of the
+    same workload at the same env-steps : learner-updates ratio.  kind = "port" (oracle/ restatement)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import torch
+
+    import hot_path_oracle as H
+    from oracle_bindings import OraclePER
+    from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    A, n, W, B = cfg.n_actions, cfg.multisteps, cfg.window_length, cfg.batch_size
+    q_on = atari_qnetwork(A)
+    q_tg = atari_qnetwork(A)
+    q_tg.load_state_dict(q_on.state_dict())
+    opt = torch.optim.Adam(q_on.parameters(), lr=cfg.lr)
+    cap = 100_000  # bounded: tree depth 17 instead of 20; the network dominates the CPU time anyway
+    per = OraclePER(cap, cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, True, cfg.memory_epsilon)
+    for x in rng.random(cap):
+        per.add(float(np.sqrt(x + 1e-4)), mode=2)
+    store = H.StoreOracle(1, 4096, 84 * 84, W, n, A, True, 0)
+    store.reset_all(rng.integers(0, 256, (1, 84 * 84), dtype=np.uint8))
+    ratio = max(1, args.envs // max(1, args.updates))  # env steps per learner update, same as the GPU run
+    env_steps = updates = 0
+    t0 = time.perf_counter()
+    deadline = t0 + args.cpu_seconds
+    while time.perf_counter() < deadline:
+        for _ in range(ratio):
+            s = store.stack_current().reshape(1, W, 84, 84)
+            with torch.no_grad():
+                q = q_on(torch.from_numpy(s), channels_first=True).numpy()
+            a = H.epsilon_greedy(q, [cfg.epsilon], rng.random((1, 2)))
+            nxt, rew, term, done = H.synth_env_step(store, args.episode_len)
+            store.commit_step(a, rew, term, done, nxt)
+            per.add(None)
+            env_steps += 1
+            if time.perf_counter() >= deadline:
+                break
+        # one learner update
+        _, idx, w, _ = per.sample(B, updates, rng.random(B + 8))
+        valid_q = rng.integers(8, max(9, store.pos - n - 1), B)
+        items = [store.gather_item(0, int(q_)) for q_ in valid_q]
+        obs = np.stack([it[0] for it in items]).reshape(B, n + 1, W, 84, 84)
+        act = np.stack([it[1] for it in items])
+        rew = np.stack([it[2] for it in items])
+        ter = np.stack([it[3] for it in items])
+        nxt_t = torch.from_numpy(obs[:, 1:].reshape(B * n, W, 84, 84))
+        with torch.no_grad():
+            qo = q_on(nxt_t, channels_first=True).numpy().reshape(B, n, A)
+            qt = q_tg(nxt_t, channels_first=True).numpy().reshape(B, n, A)
+        target = H.nstep_target(qo, qt, act, rew, ter, None, cfg.discount, cfg.retrace_h, True, False)
+        q0 = q_on(torch.from_numpy(obs[:, 0]), channels_first=True)
+        qsel = q0[torch.arange(B), torch.from_numpy(act[:, 0]).long()]
+        wt = torch.from_numpy(w.astype(np.float32))
+        tt = torch.from_numpy(target)
+        loss = torch.nn.functional.huber_loss(tt * wt, qsel * wt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        per.update(idx, np.abs(target - qsel.detach().numpy()).astype(np.float32))
+        updates += 1
+    el = time.perf_counter() - t0
+    return {
+        "value": env_steps / el,
+        "unit": "env-steps/s",
+        "learner_updates_per_s": updates / el,
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{env_steps} sequential env-steps (1 env, batch-1 inference) + {updates} learner updates (B={B}, n={n}) in {el:.1f}s, "
+        f"{ratio} env-steps per update as in the GPU run; PER capacity bounded to {cap}",
+    }
+
+
+if __name__ == "__main__":
+    main()

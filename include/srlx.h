@@ -10,7 +10,8 @@
  *     pinned memory, runs on `stream` and returns after the results are in the host arrays.
  *     `on_device` = 1: array arguments are DEVICE pointers on the handle's device; the call
  *     only enqueues work on `stream` (no host synchronisation, HIP-graph capturable).
- *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).
+ *   - `stream` is a hipStream_t passed as void* (NULL = HIP's default stream, which is also
+ *     PyTorch's default stream).
  *   - calls on one handle must be serialised by the caller (the Python shim holds a lock),
  *     matching the reference, whose memory is only ever touched under the GIL
  *     (srl/base/run/play_mp.py:248-286).

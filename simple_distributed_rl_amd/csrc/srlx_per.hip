@@ -592,7 +592,6 @@ struct srlx_per {
     double *d_tree;
     PerState *d_state;
     int *d_err;
-    hipStream_t stream;
     i64 size, write;  // host mirror
     srlx::Arena scratch;  // device
     srlx::Arena staging;  // device copies of host-mode arguments / results
@@ -601,7 +600,7 @@ struct srlx_per {
 
 namespace {
 
-hipStream_t pick_stream(srlx_per *h, void *stream) { return stream ? (hipStream_t)stream : h->stream; }
+hipStream_t pick_stream(srlx_per *, void *stream) { return (hipStream_t)stream; }  // NULL = HIP's default stream
 
 size_t prio_elem_bytes(int kind) { return kind == SRLX_PRIO_F32 ? 4 : (kind == SRLX_PRIO_NONE_MASKED ? 1 : 8); }
 
@@ -730,11 +729,9 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
     h->d_buf = nullptr;
     h->d_state = nullptr;
     h->d_err = nullptr;
-    h->stream = nullptr;
     hipError_t e = hipMalloc((void **)&h->d_buf, sizeof(double) * (size_t)(h->tree_len + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_state, sizeof(PerState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_err, sizeof(int));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         srlx::set_error("per_create: %s", hipGetErrorString(e));
         srlx_per_destroy(h);
@@ -743,7 +740,7 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
     h->d_tree = h->d_buf + 1;
     *out = h;
     int s = srlx_per_clear(h, nullptr);
-    if (s == SRLX_OK && hipStreamSynchronize(h->stream) != hipSuccess) s = SRLX_ERR_HIP;
+    if (s == SRLX_OK && hipStreamSynchronize(nullptr) != hipSuccess) s = SRLX_ERR_HIP;
     if (s != SRLX_OK) {
         srlx_per_destroy(h);
         *out = nullptr;
@@ -761,7 +758,6 @@ int srlx_per_destroy(srlx_per_t *h) {
     h->scratch.release();
     h->staging.release();
     h->pinned.release();
-    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SRLX_OK;
 }
@@ -901,9 +897,9 @@ int srlx_per_restore(srlx_per_t *h, double max_priority, int64_t size, int64_t w
     srlx::DeviceGuard guard(h->device);
     SRLX_HIP(hipDeviceSynchronize());
     SRLX_HIP(hipMemcpy(h->d_tree, tree_host, sizeof(double) * (size_t)h->tree_len, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_state_set, dim3(1), dim3(1), 0, h->stream, h->d_state, max_priority, (i64)size, (i64)write);
+    hipLaunchKernelGGL(k_state_set, dim3(1), dim3(1), 0, nullptr, h->d_state, max_priority, (i64)size, (i64)write);
     SRLX_HIP(hipGetLastError());
-    SRLX_HIP(hipStreamSynchronize(h->stream));
+    SRLX_HIP(hipStreamSynchronize(nullptr));
     h->size = size;
     h->write = write;
     return SRLX_OK;
@@ -918,7 +914,7 @@ int srlx_per_restore_resized(srlx_per_t *h, int64_t old_capacity, int64_t old_si
         const i64 m = (old_size - off < h->capacity) ? old_size - off : h->capacity;
         SRLX_TRY(srlx_per_add(h, m, leaves + off, SRLX_PRIO_RAW, 0, nullptr));
     }
-    SRLX_HIP(hipStreamSynchronize(h->stream));
+    SRLX_HIP(hipStreamSynchronize(nullptr));
     return SRLX_OK;
 }
 

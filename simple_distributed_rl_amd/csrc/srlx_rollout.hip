@@ -356,13 +356,12 @@ __global__ void __launch_bounds__(256) k_synth_scalars(StoreDev s, i64 episode_l
 struct srlx_store {
     StoreDev d;
     int device;
-    hipStream_t stream;
     srlx::Arena scratch;
     bool vec;
 };
 
 namespace {
-hipStream_t pick(srlx_store *h, void *st) { return st ? (hipStream_t)st : h->stream; }
+hipStream_t pick(srlx_store *, void *st) { return (hipStream_t)st; }  // NULL = HIP's default stream
 int grid_for(i64 total, int cap = 256 * 16) {
     i64 b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -386,7 +385,6 @@ int srlx_store_create(srlx_store_t **out, int64_t n_envs, int64_t ring_len, int6
     if (!h) return SRLX_ERR_NOMEM;
     memset(&h->d, 0, sizeof(h->d));
     h->device = device;
-    h->stream = nullptr;
     StoreDev &d = h->d;
     d.E = n_envs;
     d.L = ring_len;
@@ -408,7 +406,6 @@ int srlx_store_create(srlx_store_t **out, int64_t n_envs, int64_t ring_len, int6
     if (e == hipSuccess) e = hipMalloc((void **)&d.step_in_ep, cells * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d.pos, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&d.needs_reset, (size_t)n_envs);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemset(d.flags, 0, cells);
     if (e == hipSuccess) e = hipMemset(d.step_in_ep, 0, cells * 4);
     if (e == hipSuccess) e = hipMemset(d.action, 0, cells * 4);
@@ -437,7 +434,6 @@ int srlx_store_destroy(srlx_store_t *h) {
     if (d.pos) (void)hipFree(d.pos);
     if (d.needs_reset) (void)hipFree(d.needs_reset);
     h->scratch.release();
-    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SRLX_OK;
 }

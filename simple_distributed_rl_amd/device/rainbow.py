@@ -1,0 +1,283 @@
+"""Device-resident Rainbow actor/learner (the vectorised engine).
+
+One process drives ONE GPU.  Per step the actor advances E lock-stepped environments
+(frame-stack -> Q-network -> epsilon-greedy -> env -> ring commit -> PER add) and the learner does
+whole Rainbow updates (PER sample -> n-step gather -> 3 forwards -> fused TD/Huber/priority kernel ->
+backward -> Adam -> PER update) without a single device<->host hop; the reference does one hop per
+policy() and four per train().
+
+Reference semantics kept (file:line under the reference root):
+  srl/algorithms/rainbow/rainbow.py:301-329  Worker.policy          -> VectorActor.step
+  srl/algorithms/rainbow/rainbow.py:331-400  Worker.on_step/_add_batch (n-step items, padding) -> DeviceReplay
+  srl/algorithms/rainbow/model_torch.py:85-122  Trainer.train       -> Learner.train
+  srl/algorithms/rainbow/rainbow.py:185-287  calc_target_q          -> srlx_nstep_td_huber_priority
+Field names of RainbowDeviceConfig are those of rainbow.Config (rainbow.py:57-114).
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from simple_distributed_rl_amd import _native as N
+from simple_distributed_rl_amd.device.replay import DeviceReplay
+from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
+
+
+@dataclass
+class RainbowDeviceConfig:
+    # --- rainbow.Config fields (rainbow.py:57-114); defaults = set_atari_config (rainbow.py:116-148)
+    batch_size: int = 32
+    epsilon: float = 0.1
+    test_epsilon: float = 0.0
+    lr: float = 0.0000625
+    discount: float = 0.99
+    target_model_update_interval: int = 32000
+    enable_reward_clip: bool = True
+    enable_double_dqn: bool = True
+    enable_noisy_dense: bool = False
+    enable_rescale: bool = False
+    multisteps: int = 3
+    retrace_h: float = 1.0
+    window_length: int = 4
+    # --- memory (PriorityReplayBufferConfig, priority_replay_buffer.py:17-60)
+    memory_capacity: int = 1_000_000
+    memory_warmup_size: int = 80_000
+    memory_alpha: float = 0.5
+    memory_beta_initial: float = 0.4
+    memory_beta_steps: int = 1_000_000
+    memory_epsilon: float = 0.0001
+    # --- model (set_dqn_block + dueling (512,))
+    hidden_units: int = 512
+    filters: int = 32
+    # --- engine
+    obs_hw: tuple = (84, 84)
+    n_actions: int = 6
+    n_envs: int = 1024
+    seed: int = 0
+
+
+class SyntheticAtariVecEnv:
+    """E device-resident synthetic environments: uint8 84x84 frames i.i.d.
+    U{0..255}, reward in {-1,0,1}, episodes of `episode_len` steps ending `terminated`."""
+
+    def __init__(self, replay: DeviceReplay, episode_len: int = 200):
+        self.replay = replay
+        self.episode_len = int(episode_len)
+        d = replay.dev
+        E, F = replay.E, replay.F
+        self.next_obs = torch.zeros((E, F), dtype=torch.uint8 if replay.obs_uint8 else torch.float32, device=d)
+        self.rewards = torch.zeros(E, dtype=torch.float32, device=d)
+        self.terminated = torch.zeros(E, dtype=torch.uint8, device=d)
+        self.done = torch.zeros(E, dtype=torch.uint8, device=d)
+
+    def reset(self) -> torch.Tensor:
+        g = torch.Generator(device=self.replay.dev)
+        g.manual_seed(self.replay.seed)
+        if self.replay.obs_uint8:
+            return torch.randint(0, 256, self.next_obs.shape, dtype=torch.uint8, device=self.replay.dev, generator=g)
+        return torch.rand(self.next_obs.shape, device=self.replay.dev, generator=g) * 2 - 1
+
+    def step(self, actions: torch.Tensor):
+        r = self.replay
+        N.check(
+            r.lib.srlx_synth_env_step(
+                r.h_store, self.episode_len, N.tptr(self.next_obs), N.tptr(self.rewards), N.tptr(self.terminated), N.tptr(self.done), N.torch_stream_ptr()
+            )
+        )
+        return self.next_obs, self.rewards, self.terminated, self.done
+
+
+class RainbowEngine:
+    """Actor + learner on one GPU sharing the online network (the reference's sequential `Runner.train`
+    topology, core_play.py:115-214, with E environments per iteration)."""
+
+    def __init__(self, cfg: RainbowDeviceConfig, device: int = 0, episode_len: int = 200, ring_len: Optional[int] = None, env=None):
+        self.cfg = cfg
+        self.dev = torch.device(f"cuda:{device}")
+        self.lib = N.lib()
+        torch.manual_seed(cfg.seed)
+        H, W_ = cfg.obs_hw
+        E = cfg.n_envs
+        pad = cfg.multisteps + cfg.window_length
+        if ring_len is None:
+            ring_len = -(-cfg.memory_capacity // E) + pad  # item_len * E >= capacity
+        self.replay = DeviceReplay(
+            E, ring_len, H * W_, cfg.window_length, cfg.multisteps, cfg.n_actions, cfg.batch_size, True, cfg.enable_reward_clip,
+            cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
+        )
+        self.env = env if env is not None else SyntheticAtariVecEnv(self.replay, episode_len)
+        self.q_online = atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters).to(self.dev)
+        self.q_target = atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters).to(self.dev)
+        self.q_target.eval()
+        self.q_target.load_state_dict(self.q_online.state_dict())  # model_torch.py:41-42
+        self.q_online.train()
+        self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True)  # model_torch.py:71
+        d = self.dev
+        B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
+        self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
+        self.train_count = 0
+        self.sync_count = 0
+        self.total_env_steps = 0
+        self.eps = torch.full((E,), float(cfg.epsilon), dtype=torch.float32, device=d)
+        self.actions = torch.zeros(E, dtype=torch.int32, device=d)
+        self.u_policy = torch.zeros(2 * E, dtype=torch.float64, device=d)
+        self.policy_counter = torch.zeros(1, dtype=torch.int64, device=d)
+        self.target = torch.zeros(B, dtype=torch.float32, device=d)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=d)
+        self.grad_q0 = torch.zeros((B, A), dtype=torch.float32, device=d)
+        self.priorities = torch.zeros(B, dtype=torch.float32, device=d)
+        self._img = (cfg.window_length, H, W_)
+        self._actor_graph = None
+        self._learner_graph = None
+        self.replay.reset_all(self.env.reset())
+
+    # ---- actor (rainbow.py:301-329 + 331-400 for E envs) --------------------------------------
+    def _actor_stack(self):
+        """uint8 frame ring -> float32 [E, W, H, W] policy input (the HBM-heavy hand-written kernel)."""
+        return self.replay.stack_current().view(self.cfg.n_envs, *self._img)
+
+    def _actor_rest(self, obs):
+        r, cfg = self.replay, self.cfg
+        st = N.torch_stream_ptr()
+        with torch.no_grad():
+            q = self.q_online(obs, channels_first=True)
+        if cfg.enable_noisy_dense:
+            self.actions.copy_(torch.argmax(q, dim=1).to(torch.int32))  # noisy nets act greedily (rainbow.py:305-309)
+        else:
+            N.check(self.lib.srlx_rng_uniform(cfg.seed ^ 0xAC7, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
+            N.check(self.lib.srlx_policy_epsilon_greedy(cfg.n_envs, cfg.n_actions, N.tptr(q), N.tptr(self.eps), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
+        next_obs, rewards, terminated, done = self.env.step(self.actions)
+        r.commit(self.actions, rewards, terminated, done, next_obs)
+
+    def actor_step(self):
+        self._actor_rest(self._actor_stack())
+
+    def prefill(self, randomise_priorities: bool = True):
+        """Untimed set-up of the benchmark state: a random-policy rollout (epsilon = 1, no network) until
+        every PER leaf holds an item, then |delta| ~ U(0,1) priorities (speedtest.py:40-41)."""
+        r, cfg = self.replay, self.cfg
+        E = cfg.n_envs
+        st = N.torch_stream_ptr()
+        ones = torch.ones(E, dtype=torch.float32, device=self.dev)
+        zq = torch.zeros((E, cfg.n_actions), dtype=torch.float32, device=self.dev)
+        steps = r.item_len + cfg.multisteps - 1
+        for _ in range(steps):
+            N.check(self.lib.srlx_rng_uniform(cfg.seed ^ 0xF111, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
+            N.check(self.lib.srlx_policy_epsilon_greedy(E, cfg.n_actions, N.tptr(zq), N.tptr(ones), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
+            next_obs, rewards, terminated, done = self.env.step(self.actions)
+            r.commit(self.actions, rewards, terminated, done, next_obs)
+        self.total_env_steps += steps * E
+        if randomise_priorities:
+            g = torch.Generator(device=self.dev)
+            g.manual_seed(cfg.seed + 1)
+            chunk = 1024
+            base = r.capacity - 1
+            for lo in range(0, r.capacity, chunk):
+                m = min(chunk, r.capacity - lo)
+                idx = torch.arange(base + lo, base + lo + m, dtype=torch.int64, device=self.dev)
+                pri = torch.rand(m, dtype=torch.float32, device=self.dev, generator=g)
+                r.update(idx, pri)
+            torch.cuda.synchronize(self.dev)
+
+    def stack_bytes_per_launch(self) -> int:
+        """Algorithmic HBM bytes of one k_stack_current launch: W uint8 frames read + W float32 frames
+        written per environment."""
+        c = self.cfg
+        return c.n_envs * c.window_length * self.replay.F * (1 + 4)
+
+    # ---- learner (model_torch.py:85-122) -----------------------------------------------------
+    def _learner_body(self):
+        cfg, r = self.cfg, self.replay
+        B, n = cfg.batch_size, cfg.multisteps
+        b = r.sample(self.train_count_dev)
+        obs = b.obs.view(B, n + 1, *self._img)
+        nxt = obs[:, 1:].reshape(B * n, *self._img)
+        with torch.no_grad():
+            q_on_next = self.q_online(nxt, channels_first=True)  # rainbow.py:220
+            q_tg_next = self.q_target(nxt, channels_first=True)  # rainbow.py:221
+        q0 = self.q_online(obs[:, 0], channels_first=True)  # model_torch.py:103
+        N.check(
+            self.lib.srlx_nstep_td_huber_priority(
+                B, n, cfg.n_actions, N.tptr(q_on_next), N.tptr(q_tg_next), N.tptr(q0), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated),
+                None, N.tptr(b.weights), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
+                N.tptr(self.target), N.tptr(self.loss), N.tptr(self.grad_q0), N.tptr(self.priorities), N.torch_stream_ptr(),
+            )
+        )
+        self.optimizer.zero_grad(set_to_none=False)
+        q0.backward(self.grad_q0)  # model_torch.py:107-109: d loss / d q seeds autograd
+        self.optimizer.step()
+        r.update(b.indices, self.priorities)  # model_torch.py:113-114
+        self.train_count_dev.add_(1)
+
+    def learner_step(self) -> bool:
+        """Returns False while the replay is below warm-up (priority_replay_buffer.py:228-230)."""
+        if self.replay.is_warmup_needed():
+            return False
+        if self._learner_graph is not None:
+            self._learner_graph.replay()
+        else:
+            self._learner_body()
+        # model_torch.py:117-119 (fires at train_count 0 too)
+        if self.train_count % self.cfg.target_model_update_interval == 0:
+            self.sync_target()
+        self.train_count += 1
+        return True
+
+    def sync_target(self):
+        with torch.no_grad():
+            torch._foreach_copy_(list(self.q_target.parameters()), list(self.q_online.parameters()))
+        self.sync_count += 1
+
+    def step(self, learner_updates: int = 1, events=None):
+        """One engine step: E environment steps, then `learner_updates` Rainbow updates.  `events`
+        = (start, end) torch events recorded around the frame-stack kernel on its launch stream."""
+        if events is not None:
+            events[0].record()
+        obs = self._actor_stack()
+        if events is not None:
+            events[1].record()
+        if self._actor_graph is not None:
+            self._actor_graph.replay()
+            self.replay._steps_committed += 1
+        else:
+            self._actor_rest(obs)
+        self.total_env_steps += self.cfg.n_envs
+        for _ in range(learner_updates):
+            self.learner_step()
+
+    # ---- HIP graphs -------------------------------------------------------------------------
+    def capture_graphs(self, actor: bool = True, learner: bool = True):
+        """Captures the actor step and the learner step into HIP graphs (launch-bound inner loops).
+        Call after warm-up: arenas are sized and the replay is past its warm-up gate."""
+        torch.cuda.synchronize(self.dev)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            if actor:
+                self.actor_step()
+                self.total_env_steps += self.cfg.n_envs
+            if learner and not self.replay.is_warmup_needed():
+                self._learner_body()
+                self.train_count += 1
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        if actor:
+            obs = self._actor_stack()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._actor_rest(obs)
+            self.replay._steps_committed -= 1  # capture does not execute
+            self._actor_graph = g
+        if learner and not self.replay.is_warmup_needed():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._learner_body()
+            self._learner_graph = g
+        torch.cuda.synchronize(self.dev)
+
+    def refresh_host_mirrors(self):
+        N.check(self.lib.srlx_per_refresh(self.replay.h_per, N.torch_stream_ptr()))
+
+    def info(self):
+        return dict(loss=float(self.loss.item()), train_count=self.train_count, sync=self.sync_count, memory=self.replay.length())

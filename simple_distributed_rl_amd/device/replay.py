@@ -1,0 +1,168 @@
+"""DeviceReplay -- the HBM-resident replay of the vectorised engine: a lock-step frame/transition ring
+(libsrlx `srlx_store_*`) plus the proportional sum-tree (`srlx_per_*`) whose leaf j is the item of
+environment j % E at ring time j // E.
+
+Plays the role of srl/rl/memories/priority_replay_buffer.py:170-258 (PriorityReplayBuffer: add /
+sample / update with a warm-up gate) for E environments at once, without pickle/zlib and without the
+host: every method only enqueues kernels on torch's current stream and works on device tensors, so a
+whole actor or learner step can be captured in a HIP graph.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from simple_distributed_rl_amd import _native as N
+
+
+@dataclass
+class ReplayBatch:
+    indices: torch.Tensor  # int64 [B] tree indices (update_args)
+    weights: torch.Tensor  # float32 [B] IS weights / max
+    obs: torch.Tensor  # float32 [B, n+1, W, F]
+    actions: torch.Tensor  # int32 [B, n]
+    rewards: torch.Tensor  # float32 [B, n]
+    terminated: torch.Tensor  # float32 [B, n]
+
+
+class DeviceReplay:
+    def __init__(
+        self,
+        n_envs: int,
+        ring_len: int,
+        obs_elems: int,
+        window: int,
+        n_step: int,
+        n_actions: int,
+        batch_size: int,
+        obs_uint8: bool = True,
+        reward_clip: bool = False,
+        alpha: float = 0.6,
+        beta_initial: float = 0.4,
+        beta_steps: int = 1_000_000,
+        epsilon: float = 0.0001,
+        warmup_size: int = 1000,
+        seed: int = 0,
+        device: int = 0,
+        sample_slack: int = 8,
+    ):
+        self.lib = N.lib()
+        self.E, self.L, self.F, self.W, self.n, self.A, self.B = n_envs, ring_len, obs_elems, window, n_step, n_actions, batch_size
+        self.obs_uint8 = obs_uint8
+        self.device_index = int(device)
+        self.dev = torch.device(f"cuda:{device}")
+        self.seed = int(seed)
+        self.warmup_size = int(warmup_size)
+        self.slack = int(sample_slack)
+        hs = N.c_p()
+        N.check(
+            self.lib.srlx_store_create(
+                ctypes.byref(hs), n_envs, ring_len, obs_elems, N.OBS_U8 if obs_uint8 else N.OBS_F32, window, n_step, n_actions,
+                int(bool(reward_clip)), self.seed, self.device_index,
+            )
+        )
+        self.h_store = hs
+        self.item_len = int(self.lib.srlx_store_item_len(hs))
+        self.capacity = int(self.lib.srlx_store_per_capacity(hs))
+        hp = N.c_p()
+        N.check(
+            self.lib.srlx_per_create(ctypes.byref(hp), self.capacity, float(alpha), float(beta_initial), float(beta_steps), 1, float(epsilon), self.device_index)
+        )
+        self.h_per = hp
+        d = self.dev
+        B, n = batch_size, n_step
+        # preallocated device buffers (stable addresses: required for HIP-graph capture)
+        self.item_mask = torch.zeros(n_envs, dtype=torch.uint8, device=d)
+        self.u = torch.zeros(B + self.slack, dtype=torch.float64, device=d)
+        self.rng_counter = torch.zeros(1, dtype=torch.int64, device=d)
+        self.used = torch.zeros(1, dtype=torch.int64, device=d)
+        self.batch = ReplayBatch(
+            indices=torch.zeros(B, dtype=torch.int64, device=d),
+            weights=torch.zeros(B, dtype=torch.float32, device=d),
+            obs=torch.zeros((B, n + 1, window, obs_elems), dtype=torch.float32, device=d),
+            actions=torch.zeros((B, n), dtype=torch.int32, device=d),
+            rewards=torch.zeros((B, n), dtype=torch.float32, device=d),
+            terminated=torch.zeros((B, n), dtype=torch.float32, device=d),
+        )
+        self.stacked = torch.zeros((n_envs, window, obs_elems), dtype=torch.float32, device=d)
+        self._steps_committed = 0
+        pos, nr, sie = N.c_p(), N.c_p(), N.c_p()
+        N.check(self.lib.srlx_store_views(hs, ctypes.byref(pos), ctypes.byref(nr), ctypes.byref(sie)))
+        self._views = (pos, nr, sie)
+
+    def close(self):
+        if getattr(self, "h_store", None):
+            torch.cuda.synchronize(self.dev)
+            self.lib.srlx_store_destroy(self.h_store)
+            self.lib.srlx_per_destroy(self.h_per)
+            self.h_store = self.h_per = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- actor side ---------------------------------------------------------------------------
+    def reset_all(self, first_obs: torch.Tensor):
+        N.check(self.lib.srlx_store_reset_all(self.h_store, N.tptr(first_obs), N.torch_stream_ptr()))
+
+    def stack_current(self) -> torch.Tensor:
+        """float32 [E, W, F] policy input at the current ring position (oldest frame first)."""
+        N.check(self.lib.srlx_store_stack_current(self.h_store, N.tptr(self.stacked), N.torch_stream_ptr()))
+        return self.stacked
+
+    def commit(self, actions, rewards, terminated, done, next_obs):
+        """One lock-step transition of all E envs + the PER add of the items that became complete
+        (priority=None -> max_priority, proportional_memory.py:121-122; reset positions get 0)."""
+        st = N.torch_stream_ptr()
+        N.check(
+            self.lib.srlx_store_commit_step(
+                self.h_store, N.tptr(actions), N.tptr(rewards), N.tptr(terminated), N.tptr(done), N.tptr(next_obs), N.tptr(self.item_mask), st
+            )
+        )
+        N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(self.item_mask), N.PRIO_NONE_MASKED, 1, st))
+        self._steps_committed += 1
+
+    def length(self) -> int:
+        """Items in the tree.  Counted from committed lock-steps (E adds each) rather than the library's
+        host mirror, so it stays exact when commits are replayed from a HIP graph."""
+        return min(self.capacity, self._steps_committed * self.E)
+
+    def is_warmup_needed(self) -> bool:
+        return self.length() < self.warmup_size
+
+    # ---- learner side -------------------------------------------------------------------------
+    def sample(self, d_step: torch.Tensor, uniforms: torch.Tensor = None) -> ReplayBatch:
+        """PER sample of B items + gather of their n-step windows.  `d_step` is the device int64 train
+        count feeding the beta schedule.  Uniforms come from the counter RNG unless given."""
+        st = N.torch_stream_ptr()
+        b = self.batch
+        if uniforms is None:
+            N.check(self.lib.srlx_rng_uniform(self.seed ^ 0x5EED, N.tptr(self.rng_counter), self.u.numel(), N.tptr(self.u), st))
+            uniforms = self.u
+        N.check(
+            self.lib.srlx_per_sample(
+                self.h_per, self.B, 0, N.tptr(d_step), N.tptr(uniforms), uniforms.numel(), N.tptr(b.indices), None, N.tptr(b.weights), N.tptr(self.used), 1, st
+            )
+        )
+        N.check(
+            self.lib.srlx_store_gather_nstep(
+                self.h_store, self.B, N.tptr(b.indices), N.tptr(b.obs), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
+            )
+        )
+        return b
+
+    def update(self, indices: torch.Tensor, priorities: torch.Tensor):
+        """float32 |td| priorities, transformed on the device like numpy would (proportional_memory.py:172)."""
+        N.check(self.lib.srlx_per_update(self.h_per, indices.numel(), N.tptr(indices), N.tptr(priorities), N.PRIO_F32, 1, N.torch_stream_ptr()))
+
+    # ---- introspection ------------------------------------------------------------------------
+    def per_state(self):
+        mp, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+        N.check(self.lib.srlx_per_backup(self.h_per, ctypes.byref(mp), ctypes.byref(size), ctypes.byref(write), None))
+        return dict(max_priority=mp.value, size=size.value, write=write.value)
+
+    def hbm_bytes(self) -> int:
+        frame = self.F * (1 if self.obs_uint8 else 4)
+        return self.E * self.L * (frame + 13) + 16 * self.capacity

@@ -100,6 +100,12 @@ int srlx_per_sample(srlx_per_t *h, int64_t batch_size, int64_t step, const int64
 int srlx_per_update(srlx_per_t *h, int64_t n, const int64_t *indices, const void *prio, int prio_kind, int on_device,
                     void *stream);
 
+/* update() of the n CONSECUTIVE ring slots first_slot, first_slot+1, ... (mod capacity) in slot order:
+ * identical in effect to srlx_per_update with indices first_slot+capacity-1, ... but processed by the
+ * bulk contiguous-run kernels (O(n log n) work instead of the general kernel's O(n^2 log n)). */
+int srlx_per_set_range(srlx_per_t *h, int64_t first_slot, int64_t n, const void *prio, int prio_kind, int on_device,
+                       void *stream);
+
 /* backup()/restore()  (:179-205).  tree_host: 2*capacity-1 float64 (HOST pointers always). */
 int srlx_per_backup(srlx_per_t *h, double *max_priority, int64_t *size, int64_t *write, double *tree_host);
 int srlx_per_restore(srlx_per_t *h, double max_priority, int64_t size, int64_t write, const double *tree_host);

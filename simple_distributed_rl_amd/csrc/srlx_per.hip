@@ -516,8 +516,15 @@ struct AddArgs {
     const void *prio;
     int kind;
     double eps, alpha;
-    double *chg;  // scratch, n doubles
+    double *chg;     // scratch, n doubles
+    i64 start_slot;  // -1: append at state->write (add); >= 0: rewrite these ring slots in place (set_range)
+    int commit;      // advance write/size (add) or not (set_range)
+    int track_max;   // raise max_priority like update() does (:176-177)
+    double maxp_snapshot;  // bulk path only: filled from *maxp_dev by the leaf kernel's caller
+    const double *maxp_dev;
 };
+
+__device__ __forceinline__ i64 add_start(const AddArgs &a) { return a.start_slot >= 0 ? a.start_slot : a.state->write; }
 
 __device__ __forceinline__ void add_leaf(const AddArgs &a, i64 i, i64 write, double maxp) {
     i64 slot = write + i;
@@ -526,9 +533,12 @@ __device__ __forceinline__ void add_leaf(const AddArgs &a, i64 i, i64 write, dou
     const double p = load_prio(a.prio, a.kind, i, a.eps, a.alpha, maxp);
     a.chg[i] = p - a.tree[x];
     a.tree[x] = p;
+    // priorities are >= 0, so their bit patterns order like the values
+    if (a.track_max && p > maxp) atomicMax((u64 *)&a.state->max_priority, (u64)__double_as_longlong(p));
 }
 
 __device__ __forceinline__ void add_commit(const AddArgs &a) {
+    if (!a.commit) return;
     PerState *s = a.state;
     i64 w = s->write + a.n;
     if (w >= a.cap) w -= a.cap;
@@ -540,8 +550,9 @@ __device__ __forceinline__ void add_commit(const AddArgs &a) {
 // n <= kSmallAddMax: everything in one launch
 __global__ void __launch_bounds__(kWgAdd) k_add_wg(AddArgs a) {
     const int t = threadIdx.x, T = blockDim.x;
-    const i64 write = a.state->write;
+    const i64 write = add_start(a);
     const double maxp = a.state->max_priority;
+    __syncthreads();  // every thread has read max_priority before anyone raises it
     for (i64 i = t; i < a.n; i += T) add_leaf(a, i, write, maxp);
     __syncthreads();
     Run runs[4];
@@ -556,15 +567,18 @@ __global__ void __launch_bounds__(kWgAdd) k_add_wg(AddArgs a) {
 // bulk: leaf pass, then one ancestor launch per run (empty runs exit), then commit
 __global__ void __launch_bounds__(256) k_add_leaf_bulk(AddArgs a) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n) add_leaf(a, i, a.state->write, a.state->max_priority);
+    if (i < a.n) add_leaf(a, i, add_start(a), *a.maxp_dev);
 }
 __global__ void __launch_bounds__(256) k_add_anc_bulk(AddArgs a, int r) {
     Run runs[4];
-    const int nr = make_runs(a.cap, a.state->write, a.n, runs);
+    const int nr = make_runs(a.cap, add_start(a), a.n, runs);
     if (r >= nr) return;
     run_ancestors(a.tree, a.chg, runs[r], (i64)blockIdx.x * blockDim.x + threadIdx.x, (i64)gridDim.x * blockDim.x);
 }
 __global__ void k_add_commit(AddArgs a) { add_commit(a); }
+// max_priority as it was before this call (every add with priority=None uses that value, and
+// track_max compares against it); copied aside so the leaf kernel's atomics cannot feed back
+__global__ void k_snapshot_max(const PerState *s, double *out) { *out = s->max_priority; }
 
 __global__ void k_state_init(PerState *s) {
     s->max_priority = 1.0;
@@ -604,13 +618,17 @@ hipStream_t pick_stream(srlx_per *, void *stream) { return (hipStream_t)stream; 
 
 size_t prio_elem_bytes(int kind) { return kind == SRLX_PRIO_F32 ? 4 : (kind == SRLX_PRIO_NONE_MASKED ? 1 : 8); }
 
-int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st) {
-    SRLX_TRY(h->scratch.reserve(srlx::Carver::padded((size_t)n * 8)));
-    AddArgs a{h->d_tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr};
+int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st, i64 start_slot = -1) {
+    SRLX_TRY(h->scratch.reserve(srlx::Carver::padded((size_t)n * 8) + 256));
+    const bool append = start_slot < 0;
+    double *snap = (double *)((char *)h->scratch.ptr + srlx::Carver::padded((size_t)n * 8));
+    AddArgs a{h->d_tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr,
+              start_slot, append ? 1 : 0, append ? 0 : 1, 0.0, snap};
     if (n <= kSmallAddMax) {
         hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(kWgAdd), 0, st, a);
     } else {
         const int blocks = (int)((n + 255) / 256);
+        hipLaunchKernelGGL(k_snapshot_max, dim3(1), dim3(1), 0, st, h->d_state, snap);
         hipLaunchKernelGGL(k_add_leaf_bulk, dim3(blocks), dim3(256), 0, st, a);
         // ~2n ancestor nodes; the root owner walks all n changes, so more threads do not help it
         i64 anc_threads = 2 * n + 64;
@@ -620,9 +638,10 @@ int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st)
         hipLaunchKernelGGL(k_add_commit, dim3(1), dim3(1), 0, st, a);
     }
     SRLX_HIP(hipGetLastError());
-    // host mirror
-    h->write = (h->write + n) % h->capacity;
-    h->size = (h->size + n > h->capacity) ? h->capacity : h->size + n;
+    if (append) {  // host mirror
+        h->write = (h->write + n) % h->capacity;
+        h->size = (h->size + n > h->capacity) ? h->capacity : h->size + n;
+    }
     return SRLX_OK;
 }
 
@@ -793,6 +812,25 @@ int srlx_per_add(srlx_per_t *h, int64_t n, const void *prio, int prio_kind, int 
     memcpy(h->pinned.ptr, prio, bytes);
     SRLX_HIP(hipMemcpyAsync(h->staging.ptr, h->pinned.ptr, bytes, hipMemcpyHostToDevice, st));
     SRLX_TRY(launch_add(h, n, h->staging.ptr, prio_kind, st));
+    SRLX_HIP(hipStreamSynchronize(st));
+    return SRLX_OK;
+}
+
+int srlx_per_set_range(srlx_per_t *h, int64_t first_slot, int64_t n, const void *prio, int prio_kind, int on_device,
+                       void *stream) {
+    SRLX_REQUIRE(h, "per_set_range: NULL handle");
+    SRLX_REQUIRE(first_slot >= 0 && first_slot < h->capacity && n >= 0 && n <= h->capacity, "per_set_range: bad range");
+    SRLX_REQUIRE(prio_kind >= SRLX_PRIO_F64 && prio_kind <= SRLX_PRIO_RAW && prio, "per_set_range: bad prio");
+    if (n == 0) return SRLX_OK;
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick_stream(h, stream);
+    if (on_device) return launch_add(h, n, prio, prio_kind, st, first_slot);
+    const size_t bytes = (size_t)n * prio_elem_bytes(prio_kind);
+    SRLX_TRY(h->pinned.reserve(bytes));
+    SRLX_TRY(h->staging.reserve(bytes));
+    memcpy(h->pinned.ptr, prio, bytes);
+    SRLX_HIP(hipMemcpyAsync(h->staging.ptr, h->pinned.ptr, bytes, hipMemcpyHostToDevice, st));
+    SRLX_TRY(launch_add(h, n, h->staging.ptr, prio_kind, st, first_slot));
     SRLX_HIP(hipStreamSynchronize(st));
     return SRLX_OK;
 }

@@ -1,0 +1,204 @@
+"""Multi-GPU actor/learner topology over RCCL (torch.distributed backend "nccl" on ROCm).
+
+One process per GPU.  Every rank runs E lock-stepped actors against its own copy of the online
+network; rank 0 additionally owns the replay (frame ring + sum-tree for ALL world*E environments) and
+the learner.  Per step:
+    actors -> learner : one gather of fixed-size transition slabs (next frame uint8 [E,F] + action /
+                        reward / terminated / done) straight into the learner's HBM staging buffers,
+                        from where one commit kernel writes them into the ring and the PER tree
+    learner -> actors : every `sync_interval` steps one broadcast of the flat float32 parameter buffer
+                        (32 MB for the Atari network) that the actor networks alias (no unpack copy)
+
+This replaces the reference's multiprocessing transport -- pickled+zlib'd items on a Manager queue with
+back-pressure (srl/base/run/play_mp.py:76-118,248-286) and a pickled state_dict polled from a
+Manager.Value board on a timer (play_mp.py:121-165,289-318) -- for the intra-node case.  xGMI is a
+point-to-point mesh: the gather is 7 independent link transfers into rank 0 (7 MB per actor rank per
+step at E=1024, far below the ~153 GB/s per link), the broadcast is a 32 MB fan-out.
+`TransitionBus` only needs torch.distributed and tensors, so its protocol is tested on CPU with gloo
+(tests/test_dist_cpu.py); the kernels around it are tested on the GPU.
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from simple_distributed_rl_amd import _native as N
+
+
+class TransitionBus:
+    """Fixed-size per-step transition exchange and parameter fan-out between ranks."""
+
+    def __init__(self, n_envs_local: int, obs_elems: int, obs_dtype: torch.dtype, device: torch.device, group=None, learner_rank: int = 0):
+        self.E, self.F = n_envs_local, obs_elems
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.learner_rank = learner_rank
+        self.device = device
+        self.is_learner = self.rank == learner_rank
+        if self.is_learner:
+            T = self.world * self.E
+            self.g_actions = torch.zeros(T, dtype=torch.int32, device=device)
+            self.g_rewards = torch.zeros(T, dtype=torch.float32, device=device)
+            self.g_terminated = torch.zeros(T, dtype=torch.uint8, device=device)
+            self.g_done = torch.zeros(T, dtype=torch.uint8, device=device)
+            self.g_next_obs = torch.zeros((T, obs_elems), dtype=obs_dtype, device=device)
+
+    def _views(self, buf) -> Optional[List[torch.Tensor]]:
+        if not self.is_learner:
+            return None
+        return [buf[r * self.E : (r + 1) * self.E] for r in range(self.world)]
+
+    def push(self, actions, rewards, terminated, done, next_obs):
+        """Every rank contributes its E transitions; the learner rank gets them concatenated in rank
+        order (env index = rank * E + local index).  Returns the gathered tensors on the learner, None elsewhere."""
+        if self.world == 1:
+            return actions, rewards, terminated, done, next_obs
+        pairs = ((actions, "g_actions"), (rewards, "g_rewards"), (terminated, "g_terminated"), (done, "g_done"), (next_obs, "g_next_obs"))
+        staged = dist.get_backend(self.group) == "gloo" and actions.is_cuda  # test rigs: 2 ranks sharing one GPU
+        for t, name in pairs:
+            if staged:
+                parts = [torch.empty_like(t, device="cpu") for _ in range(self.world)] if self.is_learner else None
+                dist.gather(t.cpu(), parts, dst=self.learner_rank, group=self.group)
+                if self.is_learner:
+                    getattr(self, name).copy_(torch.cat(parts).to(self.device))
+            else:
+                dist.gather(t, self._views(getattr(self, name)) if self.is_learner else None, dst=self.learner_rank, group=self.group)
+        if self.is_learner:
+            return self.g_actions, self.g_rewards, self.g_terminated, self.g_done, self.g_next_obs
+        return None
+
+    def broadcast_params(self, flat: torch.Tensor):
+        if self.world <= 1:
+            return
+        if dist.get_backend(self.group) == "gloo" and flat.is_cuda:
+            host = flat.cpu()
+            dist.broadcast(host, src=self.learner_rank, group=self.group)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src=self.learner_rank, group=self.group)
+
+
+def flatten_parameters(module: torch.nn.Module) -> torch.Tensor:
+    """Re-homes every parameter of `module` into ONE contiguous float32 buffer and returns it; the
+    parameters become views of the buffer, so a broadcast into it updates the network in place."""
+    params = list(module.parameters())
+    total = sum(p.numel() for p in params)
+    flat = torch.empty(total, dtype=params[0].dtype, device=params[0].device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        flat[off : off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off : off + n].view_as(p)
+        off += n
+    return flat
+
+
+class DistributedRainbow:
+    """world ranks x E actors, learner + replay on rank 0 (BASELINE.json config 4 topology applied to Rainbow)."""
+
+    def __init__(self, cfg, device: int, episode_len: int = 200, sync_interval: int = 16):
+        import dataclasses
+
+        from simple_distributed_rl_amd.device.rainbow import RainbowEngine, SyntheticAtariVecEnv
+        from simple_distributed_rl_amd.device.replay import DeviceReplay
+
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.cfg = cfg
+        self.dev = torch.device(f"cuda:{device}")
+        self.sync_interval = int(sync_interval)
+        self.is_learner = self.rank == 0
+        E = cfg.n_envs
+        H, W_ = cfg.obs_hw
+        pad = cfg.multisteps + cfg.window_length
+        # every rank: a short local ring, only for frame stacking of its own envs (no PER use)
+        local_cfg = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62)
+        self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4)
+        self.flat = flatten_parameters(self.local.q_online)
+        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev)
+        self.step_count = 0
+        if self.is_learner:
+            total = self.world * E
+            ring_len = -(-cfg.memory_capacity // total) + pad
+            self.replay = DeviceReplay(
+                total, ring_len, H * W_, cfg.window_length, cfg.multisteps, cfg.n_actions, cfg.batch_size, True, cfg.enable_reward_clip,
+                cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
+            )
+            # the learner trains the SAME network object the local actors use; its replay is the global one
+        else:
+            self.replay = self.local.replay
+        self.bus.broadcast_params(self.flat)
+        # first observations of every env -> global ring position 0
+        obs0 = self.local.env.reset()  # same seeded frames the local ring was reset with
+        gathered = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, obs0)
+        if self.is_learner:
+            self.replay.reset_all(gathered[4])
+
+    # the learner's replay is the global one: swap it in around learner calls
+    def _with_global_replay(self, fn):
+        eng = self.local
+        saved = eng.replay
+        eng.replay = self.replay
+        try:
+            return fn()
+        finally:
+            eng.replay = saved
+
+    def actor_and_push(self, events=None, random_policy=False):
+        eng = self.local
+        if events is not None:
+            events[0].record()
+        obs = eng._actor_stack()
+        if events is not None:
+            events[1].record()
+        if random_policy:
+            eng._random_rest()
+        elif eng._actor_graph is not None:
+            eng._actor_graph.replay()
+            eng.replay._steps_committed += 1
+        else:
+            eng._actor_rest(obs)
+        env = eng.env
+        gathered = self.bus.push(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
+        if self.is_learner:
+            self.replay.commit(*gathered)
+
+    def step(self, learner_updates: int = 1, events=None):
+        self.actor_and_push(events)
+        self.step_count += 1
+        if self.is_learner:
+            for _ in range(learner_updates):
+                self._with_global_replay(self.local.learner_step)
+        if self.step_count % self.sync_interval == 0:
+            self.bus.broadcast_params(self.flat)
+
+    def prefill(self):
+        steps = 0
+        if self.is_learner:
+            steps = self.replay.item_len + self.cfg.multisteps - 1
+        t = torch.tensor([steps], dtype=torch.int64)
+        if dist.get_backend() != "gloo":
+            t = t.to(self.dev)
+        dist.broadcast(t, src=0)
+        for _ in range(int(t.item())):
+            self.actor_and_push(random_policy=True)
+        if self.is_learner:
+            g = torch.Generator(device=self.dev)
+            g.manual_seed(self.cfg.seed + 1)
+            pri = torch.rand(self.replay.capacity, dtype=torch.float32, device=self.dev, generator=g)
+            N.check(self.replay.lib.srlx_per_set_range(self.replay.h_per, 0, self.replay.capacity, N.tptr(pri), N.PRIO_F32, 1, N.torch_stream_ptr()))
+        torch.cuda.synchronize(self.dev)
+
+    def capture_graphs(self):
+        # actor step: local graph on every rank; learner: graph over the global replay on rank 0
+        self.local.capture_graphs(actor=True, learner=False)
+        if self.is_learner:
+            self._with_global_replay(lambda: self.local.capture_graphs(actor=False, learner=True))
+
+    def stack_bytes_per_launch(self):
+        return self.local.stack_bytes_per_launch()
+
+    def info(self):
+        d = self.local.info()
+        d["memory"] = self.replay.length()
+        return d

@@ -97,6 +97,9 @@ class RainbowEngine:
         self.dev = torch.device(f"cuda:{device}")
         self.lib = N.lib()
         torch.manual_seed(cfg.seed)
+        # MIOpen's immediate mode falls back to im2col-per-image / naive fp32 convolutions on gfx950
+        # (profiles/r1_kernel_stats_before_find.csv); let it benchmark its solvers once per shape instead.
+        torch.backends.cudnn.benchmark = True
         H, W_ = cfg.obs_hw
         E = cfg.n_envs
         pad = cfg.multisteps + cfg.window_length
@@ -153,32 +156,33 @@ class RainbowEngine:
     def actor_step(self):
         self._actor_rest(self._actor_stack())
 
-    def prefill(self, randomise_priorities: bool = True):
-        """Untimed set-up of the benchmark state: a random-policy rollout (epsilon = 1, no network) until
-        every PER leaf holds an item, then |delta| ~ U(0,1) priorities (speedtest.py:40-41)."""
+    def _random_rest(self):
+        """One lock-step with uniformly random actions (epsilon = 1, no network): used to fill the replay."""
         r, cfg = self.replay, self.cfg
         E = cfg.n_envs
         st = N.torch_stream_ptr()
-        ones = torch.ones(E, dtype=torch.float32, device=self.dev)
-        zq = torch.zeros((E, cfg.n_actions), dtype=torch.float32, device=self.dev)
+        if not hasattr(self, "_ones"):
+            self._ones = torch.ones(E, dtype=torch.float32, device=self.dev)
+            self._zq = torch.zeros((E, cfg.n_actions), dtype=torch.float32, device=self.dev)
+        N.check(self.lib.srlx_rng_uniform(cfg.seed ^ 0xF111, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
+        N.check(self.lib.srlx_policy_epsilon_greedy(E, cfg.n_actions, N.tptr(self._zq), N.tptr(self._ones), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
+        next_obs, rewards, terminated, done = self.env.step(self.actions)
+        r.commit(self.actions, rewards, terminated, done, next_obs)
+
+    def prefill(self, randomise_priorities: bool = True):
+        """Untimed set-up of the benchmark state: a random-policy rollout until every PER leaf holds an
+        item, then |delta| ~ U(0,1) priorities (speedtest.py:40-41)."""
+        r, cfg = self.replay, self.cfg
         steps = r.item_len + cfg.multisteps - 1
         for _ in range(steps):
-            N.check(self.lib.srlx_rng_uniform(cfg.seed ^ 0xF111, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
-            N.check(self.lib.srlx_policy_epsilon_greedy(E, cfg.n_actions, N.tptr(zq), N.tptr(ones), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
-            next_obs, rewards, terminated, done = self.env.step(self.actions)
-            r.commit(self.actions, rewards, terminated, done, next_obs)
-        self.total_env_steps += steps * E
+            self._random_rest()
+        self.total_env_steps += steps * cfg.n_envs
         if randomise_priorities:
             g = torch.Generator(device=self.dev)
             g.manual_seed(cfg.seed + 1)
-            chunk = 1024
-            base = r.capacity - 1
-            for lo in range(0, r.capacity, chunk):
-                m = min(chunk, r.capacity - lo)
-                idx = torch.arange(base + lo, base + lo + m, dtype=torch.int64, device=self.dev)
-                pri = torch.rand(m, dtype=torch.float32, device=self.dev, generator=g)
-                r.update(idx, pri)
-            torch.cuda.synchronize(self.dev)
+            pri = torch.rand(r.capacity, dtype=torch.float32, device=self.dev, generator=g)
+            N.check(self.lib.srlx_per_set_range(r.h_per, 0, r.capacity, N.tptr(pri), N.PRIO_F32, 1, N.torch_stream_ptr()))
+        torch.cuda.synchronize(self.dev)
 
     def stack_bytes_per_launch(self) -> int:
         """Algorithmic HBM bytes of one k_stack_current launch: W uint8 frames read + W float32 frames

@@ -1,0 +1,79 @@
+"""world_size-2 gloo test of the actor->learner transition gather and the learner->actor parameter
+broadcast (simple_distributed_rl_amd/device/dist.py:TransitionBus).  CPU only."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_distributed_rl_amd.device.dist import TransitionBus, flatten_parameters
+
+        E, F = 5, 48
+        dev = torch.device("cpu")
+        bus = TransitionBus(E, F, torch.uint8, dev)
+        ok = True
+        for step in range(3):
+            rng = np.random.default_rng(1000 * step + rank)
+            a = torch.tensor(rng.integers(0, 6, E), dtype=torch.int32)
+            r = torch.tensor(rng.standard_normal(E), dtype=torch.float32)
+            t = torch.tensor(rng.integers(0, 2, E), dtype=torch.uint8)
+            d = torch.tensor(rng.integers(0, 2, E), dtype=torch.uint8)
+            o = torch.tensor(rng.integers(0, 256, (E, F)), dtype=torch.uint8)
+            got = bus.push(a, r, t, d, o)
+            if rank == 0:
+                for src in range(world):
+                    g = np.random.default_rng(1000 * step + src)
+                    ea, er = g.integers(0, 6, E), g.standard_normal(E).astype(np.float32)
+                    et, ed = g.integers(0, 2, E), g.integers(0, 2, E)
+                    eo = g.integers(0, 256, (E, F))
+                    sl = slice(src * E, (src + 1) * E)
+                    ok &= bool((got[0][sl].numpy() == ea).all() and (got[1][sl].numpy() == er).all())
+                    ok &= bool((got[2][sl].numpy() == et).all() and (got[3][sl].numpy() == ed).all() and (got[4][sl].numpy() == eo).all())
+            else:
+                ok &= got is None
+        # parameter fan-out: the actor's network aliases the flat buffer
+        torch.manual_seed(rank)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        flat = flatten_parameters(net)
+        ok &= flat.numel() == sum(p.numel() for p in net.parameters())
+        x = torch.ones(2, 7)
+        before = net(x).detach().clone()
+        bus.broadcast_params(flat)
+        after = net(x).detach()
+        torch.manual_seed(0)
+        ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        ok &= bool(torch.equal(after, ref(x).detach()))
+        if rank != 0:
+            ok &= not torch.equal(before, after)
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transition_bus_gloo_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -1,0 +1,62 @@
+"""End-to-end check of the multi-rank actor/learner topology (device/dist.py:DistributedRainbow) with two
+ranks SHARING the one GPU of the test box (gloo rendezvous, tensors staged through the host): the global
+replay on rank 0 receives every rank's transitions, the learner trains, and the broadcast leaves the
+actor rank with the learner's weights.  The RCCL data path itself is exercised by bench.py --gpus N."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_distributed_rl_amd.device.dist import DistributedRainbow
+        from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig
+
+        cfg = RainbowDeviceConfig(n_envs=16, batch_size=8, memory_capacity=16 * 2 * 40, memory_warmup_size=64, obs_hw=(20, 20), hidden_units=32,
+                                  n_actions=4, seed=rank, target_model_update_interval=3)
+        eng = DistributedRainbow(cfg, 0, episode_len=7, sync_interval=2)
+        for _ in range(12):
+            eng.step(learner_updates=2)
+        torch.cuda.synchronize()
+        out = {"flat_sum": float(eng.flat.double().sum().item()), "flat_abs": float(eng.flat.double().abs().sum().item())}
+        if rank == 0:
+            info = eng.info()
+            out.update(info)
+            out["per"] = eng.replay.per_state()
+            out["global_envs"] = eng.replay.E
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_rainbow_two_ranks_one_gpu():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["global_envs"] == 32
+    assert r0["memory"] == 12 * 32  # every lock-step added one item per env of BOTH ranks
+    assert r0["per"]["size"] == 12 * 32
+    assert r0["train_count"] > 0 and r0["loss"] == r0["loss"]  # trained, loss not NaN
+    # step 12 ended with a broadcast (sync_interval=2): the actor rank holds the learner's exact weights
+    assert r0["flat_sum"] == r1["flat_sum"] and r0["flat_abs"] == r1["flat_abs"]

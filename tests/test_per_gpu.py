@@ -367,3 +367,23 @@ def test_restore_into_different_capacity():
     c.restore(bk)
     np.testing.assert_array_equal(c.tree_array(), o2.tree())
     assert c.data == b.data
+
+
+@pytest.mark.parametrize("capacity,first,n", [(1000, 0, 1000), (1000, 990, 300), (5, 3, 4), (1 << 12, 17, 3000), (1_000_000, 999_000, 200_000)])
+def test_set_range_equals_update(capacity, first, n):
+    """srlx_per_set_range (bulk contiguous-run kernels) == update() of the same consecutive leaves,
+    incl. ring wrap-around, both leaf depths and max_priority tracking."""
+    N = _N()
+    rng = np.random.default_rng(capacity + n)
+    g = AbiPER(capacity, 0.5, 0.4, 1000, True, 1e-4)
+    o = OraclePER(capacity, 0.5, 0.4, 1000, True, 1e-4)
+    g.add(None, n=capacity)
+    for _ in range(capacity):
+        o.add(None)
+    pri = (rng.random(n) * 3).astype(np.float32)
+    N.check(g.lib.srlx_per_set_range(g.h, first, n, N.np_ptr(pri), N.PRIO_F32, 0, None))
+    idx = (np.arange(first, first + n) % capacity) + capacity - 1
+    o.update(idx, pri)
+    mp, size, write, tree = g.state()
+    np.testing.assert_array_equal(tree, o.tree())
+    assert mp == o.max_priority and size == capacity and write == o.write

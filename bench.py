@@ -215,14 +215,31 @@ def cpu_baseline(args, cfg):
     from oracle_bindings import OraclePER
     from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    host_cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
     A, n, W, B = cfg.n_actions, cfg.multisteps, cfg.window_length, cfg.batch_size
     q_on = atari_qnetwork(A)
     q_tg = atari_qnetwork(A)
     q_tg.load_state_dict(q_on.state_dict())
     opt = torch.optim.Adam(q_on.parameters(), lr=cfg.lr)
+    # pick the intra-op thread count that makes the reference-shaped batch-1 inference fastest on this
+    # host (all-cores oversubscribes badly on many-core boxes); `cores` reports what was used
+    probe = torch.rand(1, W, 84, 84)
+    best, cores = None, 1
+    for th in sorted({1, 4, 8, 16, 32, min(64, host_cores), host_cores}):
+        if th > host_cores:
+            continue
+        torch.set_num_threads(th)
+        with torch.no_grad():
+            for _ in range(3):
+                q_on(probe, channels_first=True)
+            t = time.perf_counter()
+            for _ in range(10):
+                q_on(probe, channels_first=True)
+            t = time.perf_counter() - t
+        if best is None or t < best:
+            best, cores = t, th
+    torch.set_num_threads(cores)
     cap = 100_000  # bounded: tree depth 17 instead of 20; the network dominates the CPU time anyway
     per = OraclePER(cap, cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, True, cfg.memory_epsilon)
     for x in rng.random(cap):

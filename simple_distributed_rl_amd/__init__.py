@@ -7,3 +7,7 @@ fallback: using a device-backed class without the built library raises.
 """
 
 __version__ = "0.1.0"
+
+from simple_distributed_rl_amd.base.env.registration import EnvConfig  # noqa: E402,F401
+from simple_distributed_rl_amd.base.env.registration import make as make_env  # noqa: E402,F401
+from simple_distributed_rl_amd.runner.runner import Runner  # noqa: E402,F401

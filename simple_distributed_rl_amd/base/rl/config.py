@@ -1,0 +1,234 @@
+"""RLConfig: the algorithm-side configuration base (srl/base/rl/config.py:42-107,226-443,568-700).
+
+Kept: the dataclass fields an algorithm config relies on (window_length, frameskip, reward scale/shift,
+dtype, ...), `setup(env)` space negotiation for the two base types the hot path uses (discrete actions;
+ARRAY_DISCRETE or float-array observations; frame stacking through `create_stack_space`), state/action
+encode-decode, the `make_*` factories, device string, copy().  Render-image observations, MultiSpace and
+continuous-action division tables are out of scope."""
+import copy
+from abc import ABC, abstractmethod
+from dataclasses import dataclass, field
+from typing import Any, List, Optional
+
+import numpy as np
+
+from simple_distributed_rl_amd.base.define import RLBaseTypes, SpaceTypes
+from simple_distributed_rl_amd.base.exception import NotSupportedError
+from simple_distributed_rl_amd.base.spaces.array_discrete import ArrayDiscreteSpace
+from simple_distributed_rl_amd.base.spaces.box import BoxSpace
+from simple_distributed_rl_amd.base.spaces.discrete import DiscreteSpace
+
+
+@dataclass
+class RLConfig(ABC):
+    observation_mode: str = ""
+    frameskip: int = 0
+    processors: list = field(default_factory=list)
+    enable_rl_processors: bool = True
+    enable_state_encode: bool = True
+    enable_action_decode: bool = True
+    window_length: int = 1
+    reward_scale: float = 1.0
+    reward_shift: float = 0
+    enable_sanitize: bool = True
+    enable_assertion: bool = False
+    dtype: str = "float32"
+
+    def __post_init__(self) -> None:
+        self._is_setup = False
+        self._used_device_torch = "cpu"
+        self._rl_obs_space_one_step = None
+        self._rl_obs_space = None
+        self._rl_act_space = None
+        self._env_obs_space = None
+
+    # ---- to implement -------------------------------------------------------------------------
+    @abstractmethod
+    def get_name(self) -> str:
+        raise NotImplementedError()
+
+    @abstractmethod
+    def get_base_action_type(self) -> RLBaseTypes:
+        raise NotImplementedError()
+
+    @abstractmethod
+    def get_base_observation_type(self) -> RLBaseTypes:
+        raise NotImplementedError()
+
+    @abstractmethod
+    def get_framework(self) -> str:
+        raise NotImplementedError()
+
+    def validate_params(self) -> None:
+        if not (self.window_length > 0):
+            raise ValueError(f"assert {self.window_length} > 0")
+
+    def get_processors(self, prev_observation_space) -> list:
+        return []
+
+    def setup_from_env(self, env) -> None:
+        pass
+
+    def setup_from_actor(self, actor_num: int, actor_id: int) -> None:
+        pass
+
+    def use_backup_restore(self) -> bool:
+        return False
+
+    def use_render_image_state(self) -> bool:
+        return False
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def get_dtype(self, framework: str) -> Any:
+        if framework in ("np", "numpy"):
+            return getattr(np, self.dtype.lower())
+        if framework == "torch":
+            import torch
+
+            return getattr(torch, self.dtype.lower())
+        raise NotSupportedError(framework)
+
+    @property
+    def name(self) -> str:
+        return self.get_name()
+
+    @property
+    def used_device_torch(self) -> str:
+        return self._used_device_torch
+
+    def _set_device(self, dev: str):
+        self._used_device_torch = dev
+
+    def is_setup(self) -> bool:
+        return self._is_setup
+
+    # ---- space negotiation (config.py:226-443) ------------------------------------------------------
+    def setup(self, env, enable_log: bool = True) -> None:
+        if self._is_setup:
+            return
+        np_dtype = self.get_dtype("np")
+        act = env.action_space
+        if not isinstance(act, DiscreteSpace) or self.get_base_action_type() != RLBaseTypes.DISCRETE:
+            raise NotSupportedError(f"only discrete actions are on the hot path (got {act}, {self.get_base_action_type()})")
+        self._env_act_space = act.copy()
+        self._rl_act_space = act.copy()
+
+        obs = env.observation_space.copy()
+        self._env_obs_space = obs
+        want = self.get_base_observation_type()
+        self._obs_mode = "raw"
+        if want & RLBaseTypes.ARRAY_DISCRETE and not isinstance(obs, BoxSpace):
+            if isinstance(obs, DiscreteSpace):
+                one = ArrayDiscreteSpace(1, obs.start, obs.start + obs.n - 1)
+                self._obs_mode = "disc_to_list"
+            elif isinstance(obs, ArrayDiscreteSpace):
+                one = obs
+            else:
+                raise NotSupportedError(obs)
+        elif want & (RLBaseTypes.NP_ARRAY | RLBaseTypes.BOX | RLBaseTypes.ARRAY_CONTINUOUS | RLBaseTypes.ARRAY_DISCRETE):
+            if isinstance(obs, BoxSpace):
+                if obs.is_image_like():
+                    one = BoxSpace(obs.shape, obs.low, obs.high, np_dtype, obs.stype)
+                else:
+                    one = BoxSpace(obs.shape, obs.low, obs.high, np_dtype, SpaceTypes.CONTINUOUS)
+                self._obs_mode = "to_np"
+            elif isinstance(obs, DiscreteSpace):
+                one = BoxSpace((1,), obs.start, obs.start + obs.n - 1, np_dtype, SpaceTypes.CONTINUOUS)
+                self._obs_mode = "scalar_to_np"
+            elif isinstance(obs, ArrayDiscreteSpace):
+                one = BoxSpace((obs.size,), np.array(obs.low), np.array(obs.high), np_dtype, SpaceTypes.CONTINUOUS)
+                self._obs_mode = "to_np"
+            else:
+                raise NotSupportedError(obs)
+        else:
+            raise NotSupportedError(want)
+        self._rl_obs_space_one_step = one
+        self._rl_obs_space = one.create_stack_space(self.window_length) if self.window_length > 1 else one
+
+        self.validate_params()
+        for v in list(self.__dict__.values()):
+            if hasattr(v, "validate_params"):
+                v.validate_params()
+        self.setup_from_env(env)
+        self._is_setup = True
+
+    @property
+    def observation_space_one_step(self):
+        return self._rl_obs_space_one_step
+
+    @property
+    def observation_space(self):
+        return self._rl_obs_space
+
+    @property
+    def observation_space_of_env(self):
+        return self._env_obs_space
+
+    @property
+    def action_space(self):
+        return self._rl_act_space
+
+    @property
+    def action_space_of_env(self):
+        return self._env_act_space
+
+    def state_encode_one_step(self, env_state, env):
+        if not self.enable_state_encode or self._obs_mode == "raw":
+            return env_state
+        if self._obs_mode == "disc_to_list":
+            return [int(env_state)]
+        if self._obs_mode == "scalar_to_np":
+            return np.array([env_state], dtype=self.get_dtype("np"))
+        return np.asarray(env_state, dtype=self.get_dtype("np"))
+
+    def action_encode(self, env_action):
+        return int(env_action)
+
+    def action_decode(self, rl_action):
+        return int(rl_action)
+
+    # ---- factories (config.py:653-697) --------------------------------------------------------------
+    def make_memory(self, env=None):
+        from simple_distributed_rl_amd.base.rl.registration import make_memory
+
+        return make_memory(self, env=env)
+
+    def make_parameter(self, env=None):
+        from simple_distributed_rl_amd.base.rl.registration import make_parameter
+
+        return make_parameter(self, env=env)
+
+    def make_trainer(self, parameter, memory, env=None):
+        from simple_distributed_rl_amd.base.rl.registration import make_trainer
+
+        return make_trainer(self, parameter, memory, env=env)
+
+    def make_worker(self, env, parameter=None, memory=None):
+        from simple_distributed_rl_amd.base.rl.registration import make_worker
+
+        return make_worker(self, env, parameter, memory)
+
+    def make_workers(self, players, env, parameter=None, memory=None, main_worker=None):
+        from simple_distributed_rl_amd.base.rl.registration import make_workers
+
+        return make_workers(self, players, env, parameter, memory, main_worker)
+
+    def copy(self, reset_env_config: bool = False) -> "RLConfig":
+        c = copy.deepcopy(self)
+        if reset_env_config:
+            c._is_setup = False
+        return c
+
+
+class DummyRLConfig(RLConfig):
+    def get_name(self) -> str:
+        return "dummy"
+
+    def get_base_action_type(self) -> RLBaseTypes:
+        return RLBaseTypes.DISCRETE
+
+    def get_base_observation_type(self) -> RLBaseTypes:
+        return RLBaseTypes.NP_ARRAY
+
+    def get_framework(self) -> str:
+        return ""

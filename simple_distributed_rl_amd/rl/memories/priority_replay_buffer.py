@@ -1,0 +1,146 @@
+"""PriorityReplayBufferConfig / PriorityReplayBuffer / RLPriorityReplayBuffer
+(srl/rl/memories/priority_replay_buffer.py:17-274): warm-up gate, optional zlib+pickle item compression,
+weight dtype cast, `step` bookkeeping (sample uses the LAST update()'s step for beta, :232,250), and the
+memory selector.  "Proportional" and "Proportional_cpp" both resolve to the HBM-resident sum-tree of
+libsrlx (there is no CPU tree in this build); `set_custom` keeps working for user memories."""
+import pickle
+import zlib
+from dataclasses import dataclass, field
+from typing import Any, List, Optional
+
+import numpy as np
+
+from simple_distributed_rl_amd.base.exception import UndefinedError
+from simple_distributed_rl_amd.base.rl.memory import RLMemory
+
+from .priority_memories.imemory import IPriorityMemory
+
+
+@dataclass
+class PriorityReplayBufferConfig:
+    capacity: int = 100_000
+    warmup_size: int = 1_000
+    compress: bool = True
+    compress_level: int = -1
+    name: str = field(default="ReplayBuffer")
+    kwargs: dict = field(default_factory=dict)
+    enable_demo_memory: bool = False
+    select_memory: str = "main"
+    demo_ratio: float = 1.0 / 256.0
+
+    def set_replay_buffer(self):
+        self.name, self.kwargs = "ReplayBuffer", {}
+        return self
+
+    def set_proportional(self, alpha: float = 0.6, beta_initial: float = 0.4, beta_steps: int = 1_000_000, has_duplicate: bool = True,
+                         epsilon: float = 0.0001, device: int = 0):
+        self.name = "Proportional"
+        self.kwargs = dict(alpha=alpha, beta_initial=beta_initial, beta_steps=beta_steps, has_duplicate=has_duplicate, epsilon=epsilon, device=device)
+        return self
+
+    def set_proportional_cpp(self, alpha: float = 0.6, beta_initial: float = 0.4, beta_steps: int = 1_000_000, has_duplicate: bool = True,
+                             epsilon: float = 0.0001, force_build: bool = False):
+        """Same constructor surface as the pybind11 twin (cpp_module/src/proportional_memory.cpp:250-259); redirected to the HIP tree."""
+        self.set_proportional(alpha, beta_initial, beta_steps, has_duplicate, epsilon)
+        self.name = "Proportional_cpp"
+        return self
+
+    def set_custom(self, entry_point: str, kwargs: dict):
+        self.name = "custom"
+        self.kwargs = dict(entry_point=entry_point, kwargs=kwargs)
+        return self
+
+    def create_memory(self, capacity: int) -> IPriorityMemory:
+        if self.name == "ReplayBuffer":
+            from .priority_memories.replay_buffer import ReplayBuffer
+
+            return ReplayBuffer(capacity, **self.kwargs)
+        if self.name in ("Proportional", "Proportional_cpp"):
+            from .priority_memories.proportional_memory import ProportionalMemory
+
+            return ProportionalMemory(capacity, **self.kwargs)
+        if self.name == "custom":
+            from simple_distributed_rl_amd.utils.common import load_module
+
+            return load_module(self.kwargs["entry_point"])(capacity, **self.kwargs["kwargs"])
+        raise UndefinedError(self.name)  # RankBased* are SURVEY 8(f) "next"
+
+    def requires_priority(self) -> bool:
+        return self.name in ("Proportional", "Proportional_cpp", "RankBased", "RankBasedLinear")
+
+    def validate_params(self) -> None:
+        if not (self.warmup_size <= self.capacity):
+            raise ValueError(f"assert {self.warmup_size} <= {self.capacity}")
+
+
+class PriorityReplayBuffer:
+    def __init__(self, config: PriorityReplayBufferConfig, batch_size: int, dtype=np.float32):
+        self.cfg = config
+        self.dtype = dtype
+        self.memory = self.cfg.create_memory(self.cfg.capacity)
+        self.step = 0
+        if self.cfg.enable_demo_memory:
+            raise UndefinedError("demo memory is outside the hot path (SURVEY 8 a7)")
+        self.batch_size = batch_size
+        if not (self.cfg.warmup_size <= self.cfg.capacity):
+            raise ValueError(f"assert {self.cfg.warmup_size} <= {self.cfg.capacity}")
+        if not (batch_size > 0):
+            raise ValueError(f"assert {batch_size} > 0")
+        if not (batch_size <= self.cfg.warmup_size):
+            raise ValueError(f"assert {batch_size} <= {self.cfg.warmup_size}")
+
+    def length(self) -> int:
+        return self.memory.length()
+
+    def add(self, batch: Any, priority: Optional[float] = None, serialized: bool = False) -> None:
+        if serialized:
+            if not self.cfg.compress:
+                batch = pickle.loads(batch)
+        elif self.cfg.compress:
+            batch = zlib.compress(pickle.dumps(batch), level=self.cfg.compress_level)
+        self.memory.add(batch, priority)
+
+    def serialize(self, batch: Any, priority: Optional[float] = None) -> Any:
+        batch = pickle.dumps(batch)
+        if self.cfg.compress:
+            batch = zlib.compress(batch, level=self.cfg.compress_level)
+        return (batch, priority)
+
+    def is_warmup_needed(self) -> bool:
+        return self.memory.length() < self.cfg.warmup_size
+
+    def sample(self, step: int = -1, batch_size: int = -1):
+        if self.memory.length() < self.cfg.warmup_size:
+            return None
+        batch_size = batch_size if batch_size > -1 else self.batch_size
+        step = step if step > -1 else self.step
+        batches, weights, update_args = self.memory.sample(batch_size, step)
+        weights = np.asarray(weights, dtype=self.dtype)
+        if self.cfg.compress:
+            batches = [pickle.loads(zlib.decompress(b)) for b in batches]
+        return batches, weights, update_args
+
+    def update(self, update_args: List[Any], priorities: np.ndarray, step: int) -> None:
+        self.memory.update(update_args, priorities)
+        self.step = step
+
+    def call_backup(self, **kwargs):
+        return [self.memory.backup(), None]
+
+    def call_restore(self, data: Any, **kwargs) -> None:
+        self.memory.restore(data[0])
+
+
+class RLPriorityReplayBuffer(PriorityReplayBuffer, RLMemory):
+    def __init__(self, *args):
+        RLMemory.__init__(self, *args)
+        assert hasattr(self.config, "memory") and hasattr(self.config, "batch_size")
+        assert isinstance(self.config.memory, PriorityReplayBufferConfig)
+        PriorityReplayBuffer.__init__(self, self.config.memory, self.config.batch_size, self.config.get_dtype("np"))
+
+    def setup(self, register_add: bool = True, register_sample: bool = True) -> None:
+        if register_add:
+            self.register_worker_func_custom(self.add, self.serialize)
+        if register_sample:
+            self.register_trainer_recv_func(self.sample)
+            self.register_trainer_send_func(self.update)

@@ -1,0 +1,328 @@
+"""CPU tests of the mirrored plugin surface (Runner / Config / Worker / Trainer / Memory), modelled on the
+reference's tests/quick/{runner,base/rl,rl/memories}: BASELINE config 1 (QL on Grid via Runner), play modes,
+callback hooks, seed determinism, memory wrappers, save/load formats, frame stacking + n-step item assembly
+of the Rainbow worker against the reference-pinned store model."""
+import os
+import pickle
+import random
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import simple_distributed_rl_amd as srl  # noqa: E402
+from simple_distributed_rl_amd.algorithms import ql  # noqa: E402
+from simple_distributed_rl_amd.base.run.callback import RunCallback  # noqa: E402
+
+
+def test_readme_example_ql_on_grid_learns():
+    """README example / BASELINE config 1: `srl.Runner("Grid", ql.Config()).train(...)` then evaluate
+    beats the env's reward baseline (0.65, srl/envs/grid.py:26)."""
+    runner = srl.Runner("Grid", ql.Config())
+    runner.set_seed(1)
+    st = runner.train(max_steps=20_000)
+    assert st.total_step == 20_000 and st.train_count == 19_999 and st.end_reason == "max_steps over."
+    rewards = runner.evaluate(max_episodes=100)
+    assert len(rewards) == 100
+    assert np.mean(rewards) > runner.env.reward_baseline["baseline"]
+
+
+def test_seed_determinism():
+    """tests/quick/runner/test_random.py:7-50: same seed -> identical evaluation rewards, across fresh Runners."""
+    def run():
+        r = srl.Runner("Grid", ql.Config())
+        r.set_seed(7)
+        r.train(max_steps=3000)
+        return r.evaluate(max_episodes=20)
+
+    a, b = run(), run()
+    assert a == b
+    r = srl.Runner("Grid", ql.Config())
+    r.set_seed(8)
+    r.train(max_steps=3000)
+    assert r.evaluate(max_episodes=20) != a
+
+
+def test_rollout_save_load_train_only(tmp_path):
+    """rollout -> save memory -> load into a fresh runner -> train_only (common_quick_case.py:63-149 pattern)."""
+    r1 = srl.Runner("Grid", ql.Config())
+    st = r1.rollout(max_steps=500)
+    assert st.train_count == 0 and r1.memory.length() > 400
+    path = str(tmp_path / "mem.dat")
+    r1.save_memory(path)
+    r2 = srl.Runner("Grid", ql.Config())
+    r2.load_memory(path)
+    assert r2.memory.length() == r1.memory.length()
+    st2 = r2.train_only(max_train_count=100)
+    assert st2.train_count >= 100 and len(r2.parameter.Q) > 0
+    ppath = str(tmp_path / "param.dat")
+    r2.save_parameter(ppath)
+    r3 = srl.Runner("Grid", ql.Config())
+    r3.load_parameter(ppath)
+    assert r3.parameter.Q == r2.parameter.Q
+
+
+def test_save_file_is_reference_format(tmp_path):
+    """srl/utils/common.py:117-152: lzma container of a pickle (magic fd377a585a00) or a plain pickle."""
+    from simple_distributed_rl_amd.utils.common import load_file, save_file
+
+    p = str(tmp_path / "a.dat")
+    save_file(p, {"x": [1, 2, 3]}, compress=True)
+    assert open(p, "rb").read(6) == bytes.fromhex("fd377a585a00")
+    import lzma
+
+    assert pickle.loads(lzma.open(p).read()) == {"x": [1, 2, 3]}
+    assert load_file(p) == {"x": [1, 2, 3]}
+    save_file(p, (1, "b"), compress=False)
+    assert pickle.load(open(p, "rb")) == (1, "b") and load_file(p) == (1, "b")
+
+
+def test_callback_hooks_fire():
+    """tests/quick/base/run/test_callback.py: every hook the loop looks up is called."""
+    calls = {}
+
+    class CB(RunCallback):
+        def _hit(self, name):
+            calls[name] = calls.get(name, 0) + 1
+
+        def on_start(self, context, **kw):
+            self._hit("on_start")
+
+        def on_end(self, context, **kw):
+            self._hit("on_end")
+
+        def on_episodes_begin(self, context, state, **kw):
+            self._hit("on_episodes_begin")
+
+        def on_episodes_end(self, context, state, **kw):
+            self._hit("on_episodes_end")
+
+        def on_episode_begin(self, context, state, **kw):
+            self._hit("on_episode_begin")
+
+        def on_episode_end(self, context, state, **kw):
+            self._hit("on_episode_end")
+
+        def on_step_begin(self, context, state, **kw):
+            self._hit("on_step_begin")
+
+        def on_step_action_before(self, context, state, **kw):
+            self._hit("on_step_action_before")
+
+        def on_step_action_after(self, context, state, **kw):
+            self._hit("on_step_action_after")
+
+        def on_step_end(self, context, state, **kw):
+            self._hit("on_step_end")
+            return state.total_step >= 120  # intermediate stop
+
+    runner = srl.Runner("Grid", ql.Config())
+    st = runner.train(max_steps=10_000, callbacks=[CB()])
+    assert st.end_reason == "callback.intermediate_stop" and st.total_step == 120
+    for k in ("on_start", "on_end", "on_episodes_begin", "on_episodes_end"):
+        assert calls[k] == 1
+    assert calls["on_step_begin"] == calls["on_step_action_before"] == calls["on_step_action_after"] == calls["on_step_end"] == 120
+    assert calls["on_episode_begin"] >= 1 and calls["on_episode_end"] >= 1
+
+    tcalls = []
+
+    class TCB(RunCallback):
+        def on_trainer_start(self, context, state, **kw):
+            tcalls.append("start")
+
+        def on_train_before(self, context, state, **kw):
+            tcalls.append("before")
+
+        def on_train_after(self, context, state, **kw):
+            tcalls.append("after")
+
+        def on_trainer_end(self, context, state, **kw):
+            tcalls.append("end")
+
+    runner.rollout(max_steps=50)
+    runner.train_only(max_train_count=10, callbacks=[TCB()])
+    assert tcalls[0] == "start" and tcalls[-1] == "end" and tcalls.count("before") == tcalls.count("after") >= 1
+
+
+def test_stop_conditions():
+    r = srl.Runner("Grid", ql.Config())
+    assert r.train(max_episodes=5).end_reason == "episode_count over."
+    assert r.train(max_train_count=50).end_reason == "max_train_count over."
+    assert r.train(timeout=0.2).end_reason == "timeout."
+    with pytest.raises(AssertionError):
+        r.train()  # no stop condition (context.py check_context_parameter)
+
+
+def test_memory_wrappers_contract():
+    """tests/quick/rl/memories/test_memories.py:8-77 on the host-side memories: single-use buffer semantics;
+    uniform ReplayBuffer behind PriorityReplayBuffer: warm-up returns None, capacity clamp, float32 weights,
+    out-of-order sample/sample/update/sample/update/update, compress on/off, backup/restore."""
+    from simple_distributed_rl_amd.rl.memories.priority_replay_buffer import PriorityReplayBuffer, PriorityReplayBufferConfig
+    from simple_distributed_rl_amd.rl.memories.single_use_buffer import SingleUseBuffer
+
+    m = SingleUseBuffer()
+    m.add((1, "A", [2, 2, 2]))
+    m.add((2, "B", [3, 3, 3]))
+    m.call_restore(m.call_backup())
+    assert m.length() == 2
+    b = m.sample()
+    assert m.length() == 0 and len(b) == 2 and b[0][0] == 1 and m.sample() is None
+
+    for compress in (False, True):
+        cfg = PriorityReplayBufferConfig(10, 5, compress)
+        cfg.set_replay_buffer()
+        mem = PriorityReplayBuffer(cfg, 5)
+        assert mem.sample() is None
+        for i in range(100):
+            mem.add((i, i, i, i))
+        assert mem.length() == 10
+        mem.call_restore(mem.call_backup())
+        assert mem.length() == 10
+        for i in range(20):
+            b1, w1, a1 = mem.sample(i)
+            assert len(b1) == 5 and isinstance(w1, np.ndarray) and w1.dtype == np.float32
+            b2, w2, a2 = mem.sample(i)
+            mem.update(a1, np.array([x[3] for x in b1]), i)
+            b3, w3, a3 = mem.sample(i)
+            mem.update(a2, np.array([x[3] for x in b2]), i)
+            mem.update(a3, np.array([x[3] for x in b3]), i)
+            assert mem.length() == 10 and mem.step == i
+    with pytest.raises(ValueError):
+        PriorityReplayBuffer(PriorityReplayBufferConfig(10, 20), 5)  # warmup > capacity
+    with pytest.raises(ValueError):
+        PriorityReplayBuffer(PriorityReplayBufferConfig(10, 3), 5)  # batch > warmup
+
+
+def test_mp_registry_contract():
+    """tests/quick/rl/memories/test_rl_memories.py:10-58: worker funcs go through their serialiser and come
+    back with serialized=True; trainer recv/send funcs are registered; backup(compress)/restore round trip."""
+    from simple_distributed_rl_amd.rl.memories.priority_replay_buffer import PriorityReplayBufferConfig, RLPriorityReplayBuffer
+    from simple_distributed_rl_amd.base.rl.config import DummyRLConfig
+
+    cfg = DummyRLConfig()
+    cfg.batch_size = 4
+    cfg.memory = PriorityReplayBufferConfig(16, 4, True).set_replay_buffer()
+    mem = RLPriorityReplayBuffer(cfg)
+    funcs = mem.get_worker_funcs()
+    assert list(funcs) == ["add"]
+    add, ser = funcs["add"]
+    for i in range(8):
+        raw = ser((i, i), None)
+        raw = pickle.loads(pickle.dumps(raw))  # crosses a process boundary
+        add(*raw, serialized=True)
+    assert mem.length() == 8
+    assert [f.__name__ for f in mem.get_trainer_recv_funcs()] == ["sample"]
+    assert list(mem.get_trainer_send_funcs()) == ["update"]
+    batches, w, args = mem.get_trainer_recv_funcs()[0]()
+    assert len(batches) == 4 and batches[0][0] in range(8)
+    dat = mem.backup(compress=True)
+    assert isinstance(dat, tuple)
+    mem2 = RLPriorityReplayBuffer(cfg)
+    mem2.restore(dat)
+    assert mem2.length() == 8
+
+
+def test_rainbow_worker_items_match_store_model():
+    """The mirrored WorkerRun (frame stacking, lazy on_step, tracking ring) + rainbow.Worker (n-step items,
+    terminal padding, reward clip) emit, for a recorded trajectory, exactly the items of the store model
+    that tests/test_hot_path_oracle_golden.py pins to the reference's own emitted items."""
+    import hot_path_oracle as H
+    from simple_distributed_rl_amd.algorithms import rainbow
+    from simple_distributed_rl_amd.base.define import SpaceTypes
+    from simple_distributed_rl_amd.base.env import registration
+    from simple_distributed_rl_amd.base.spaces.box import BoxSpace
+    from simple_distributed_rl_amd.base.spaces.discrete import DiscreteSpace
+
+    registration.register("TinyImg", "test_plugin_surface:TinyImg", check_duplicate=False)
+    rl = rainbow.Config(multisteps=3, enable_reward_clip=True)
+    rl.window_length = 4
+    rl.memory.capacity, rl.memory.warmup_size, rl.memory.compress = 1000, 32, False
+    rl.hidden_block.set_dueling_network((16,))
+    runner = srl.Runner(srl.EnvConfig("TinyImg", kwargs=dict(ep_len=6, seed=3)), rl)
+    runner.set_seed(5)
+    runner.set_device("CPU")
+    runner.rollout(max_steps=40)
+    log = runner.env.unwrapped.log
+    items = runner.memory.memory.memory  # uniform ring: insertion order
+    assert len(items) == 37  # 6 episodes * 6 items + 1 (the last step's on_step has not run yet)
+
+    store = H.StoreOracle(1, 128, 64, 4, 3, 4, True, 0)
+    store.reset_all(log[0][0][None])
+    for f, a, r, term, trunc in log[1:]:
+        if a < 0:
+            store.commit_step([0], [0.0], [0], [0], f[None])
+        else:
+            store.commit_step([a], [r], [term], [term or trunc], f[None])
+    valid = [q for q in range(store.pos) if not (store.flags[0, q] & store.INVALID)]
+    for i, it in enumerate(items):
+        obs, act, rew, ter, jd = store.gather_item(0, valid[i])
+        got_obs = np.array([np.transpose(np.asarray(row[0], np.float32), (2, 0, 1)).reshape(4, -1) for row in it])
+        np.testing.assert_array_equal(got_obs, obs)
+        np.testing.assert_array_equal(np.array([row[2] for row in it[1:]], np.float32), rew)
+        np.testing.assert_array_equal(np.array([row[3] for row in it[1:]], np.float32), ter)
+        real = min(jd + 1, 3)
+        assert [int(np.argmax(row[1])) for row in it[1:]][:real] == act[:real].tolist()
+
+
+class TinyImg:
+    pass
+
+
+def _define_tiny():
+    from simple_distributed_rl_amd.base.define import SpaceTypes
+    from simple_distributed_rl_amd.base.env.base import EnvBase
+    from simple_distributed_rl_amd.base.spaces.box import BoxSpace
+    from simple_distributed_rl_amd.base.spaces.discrete import DiscreteSpace
+
+    class _TinyImg(EnvBase):
+        def __init__(self, hw=8, actions=4, ep_len=6, seed=0):
+            super().__init__()
+            self.hw, self.na, self.ep_len = hw, actions, ep_len
+            self.rng = np.random.default_rng(seed)
+            self.log = []
+
+        action_space = property(lambda self: DiscreteSpace(self.na))
+        observation_space = property(lambda self: BoxSpace((self.hw, self.hw, 1), 0, 1, np.float32, SpaceTypes.GRAY_HW1))
+        max_episode_steps = property(lambda self: 1000)
+        player_num = property(lambda self: 1)
+
+        def _frame(self):
+            return self.rng.integers(0, 256, (self.hw, self.hw, 1), dtype=np.uint8)
+
+        def reset(self, **kw):
+            self.t = 0
+            f = self._frame()
+            self.log.append((f.reshape(-1).copy(), -1, 0.0, False, False))
+            return f.astype(np.float32) / 255
+
+        def step(self, action):
+            self.t += 1
+            f = self._frame()
+            r = float(self.rng.integers(-2, 3))
+            term = self.t >= self.ep_len
+            self.log.append((f.reshape(-1).copy(), int(action), r, term, False))
+            return f.astype(np.float32) / 255, r, term, False
+
+        def backup(self, **kw):
+            return None
+
+        def restore(self, d, **kw):
+            pass
+
+    return _TinyImg
+
+
+TinyImg = _define_tiny()
+
+
+def test_train_mp_ql_two_actors():
+    """Runner.train_mp (play_mp.py:471-642): 2 actor processes feed the learner through the serialising
+    queue; parameters flow back through the board; the learner reaches max_train_count."""
+    runner = srl.Runner("Grid", ql.Config())
+    st = runner.train_mp(actor_num=2, max_train_count=3000, timeout=60, trainer_parameter_send_interval=0.2, actor_parameter_sync_interval=0.2)
+    assert st.train_count >= 3000 and st.end_reason == "max_train_count over."
+    assert st.trainer_recv_q > 0 and st.sync_trainer >= 0
+    assert len(runner.parameter.Q) > 3

@@ -31,7 +31,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=1024, help="environments per GPU (E)")
-    ap.add_argument("--updates", type=int, default=8, help="learner updates per step on the learner rank (U)")
+    ap.add_argument("--updates", type=int, default=1, help="learner updates per step on the learner rank (U); 1 balances actor and learner time at E=1024")
     ap.add_argument("--capacity", type=int, default=1_000_000)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--episode-len", type=int, default=200)

@@ -44,7 +44,6 @@ constexpr int kWgUpdate = 256;
 constexpr int kUpdateChunk = 1024;   // indices per general-update launch (LDS resident)
 constexpr int kWgAdd = 256;
 constexpr i64 kSmallAddMax = 1024;   // adds handled by the single-workgroup path
-constexpr int kTopLevels = 13;       // levels of the tree staged in LDS by the bulk descent (8191 nodes, 64 KiB)
 
 __device__ __forceinline__ int node_depth(i64 x) { return 63 - __clzll((u64)(x + 1)); }
 
@@ -115,6 +114,12 @@ __device__ __forceinline__ double beta_of(double beta_initial, double beta_steps
     // proportional_memory.py:138-140
     double beta = beta_initial + ((1.0 - beta_initial) * (double)step) / beta_steps;
     return beta > 1.0 ? 1.0 : beta;
+}
+
+// importance weight (size * p / total)^(-beta)  (proportional_memory.py:163-164).  exp2(-beta*log2(x)) is
+// within a few fp64 ulp of pow(x, -beta) (|log2 x| < 64, beta <= 1) at a third of the instruction count.
+__device__ __forceinline__ double is_weight(double size, double p, double total, double beta) {
+    return exp2(-beta * log2(size * (p / total)));
 }
 
 // block-wide max of one double per thread (blockDim.x <= 1024, power of two)
@@ -238,8 +243,7 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
     double wmax_local = 0.0;
     for (i64 i = t; i < B; i += T) {
         const i64 j = a.map[i];
-        const double prob = a.cand_p[j] / total;
-        const double w = pow(size * prob, -beta);
+        const double w = is_weight(size, a.cand_p[j], total, beta);
         a.wtmp[i] = w;
         a.out_idx[i] = a.cand_idx[j];
         wmax_local = fmax(wmax_local, w);
@@ -254,28 +258,96 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // per_sample, bulk path (thousands..millions of draws per launch: prefetching learners, the
-// PER micro-benchmark).  The top kTopLevels levels (64 KiB) are staged in LDS per workgroup;
-// the remaining levels are 16-byte pair loads.
+// PER micro-benchmark).  Random 16-byte reads of a 16 MB tree are latency-bound, so the kernel is
+// built for memory-level parallelism: only the top kBulkTop levels (16 KiB) are staged in LDS so that
+// 8 workgroups stay resident per CU, and every lane walks kIlp independent draws level by level,
+// issuing their pair loads back to back.  The IS weight of the no-rejection fast path is fused in.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_descend_bulk(SampleArgs a, u64 *zero_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *top = reinterpret_cast<double *>(smem);
-    const i64 top_cap = ((i64)1 << kTopLevels) - 1;
+constexpr int kBulkTop = 11;  // 2047 nodes
+constexpr int kIlp = 4;
+
+__global__ void __launch_bounds__(256) k_descend_bulk(SampleArgs a, u64 *zero_count, u64 *wmax_bits) {
+    __shared__ __attribute__((aligned(16))) double top[((1 << kBulkTop) - 1) + 1];
+    __shared__ double red[256];
+    const i64 top_cap = ((i64)1 << kBulkTop) - 1;
     const i64 top_n = a.tree_len < top_cap ? a.tree_len : top_cap;
     for (i64 k = threadIdx.x; k < top_n; k += blockDim.x) top[k] = a.tree[k];
     __syncthreads();
     const double total = top[0];
-    const i64 M = a.n_uniforms;
+    const i64 M = a.n_uniforms, B = a.batch, tree_len = a.tree_len;
+    const i64 step = a.d_step ? *a.d_step : a.step;
+    const double beta = beta_of(a.beta_initial, a.beta_steps, step);
+    const double size = (double)a.state->size;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
     unsigned zeros = 0;
-    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (i64)gridDim.x * blockDim.x) {
-        i64 idx;
-        double p;
-        descend<true>(a.tree, a.tree_len, top, top_n, a.uniforms[j] * total, idx, p);
-        a.cand_idx[j] = idx;
-        a.cand_p[j] = p;
-        zeros += (p == 0.0);
+    double wmax = 0.0;
+    for (i64 base = (i64)blockIdx.x * blockDim.x + threadIdx.x; base < M; base += stride * kIlp) {
+        i64 idx[kIlp];
+        double val[kIlp], p[kIlp];
+#pragma unroll
+        for (int d = 0; d < kIlp; d++) {
+            const i64 j = base + d * stride;
+            val[d] = j < M ? a.uniforms[j] * total : 0.0;  // :147
+            idx[d] = 0;
+            p[d] = total;  // tree_len == 1: the root is the leaf
+        }
+        // levels whose sibling pairs sit in LDS: the same count for every draw
+        i64 level_first = 0;  // index of the first node of the current level
+        while (2 * level_first + 2 < top_n) {
+#pragma unroll
+            for (int d = 0; d < kIlp; d++) {
+                const i64 left = 2 * idx[d] + 1;
+                const double l = top[left], r = top[left + 1];
+                const bool go_left = val[d] <= l;  // :61
+                val[d] = go_left ? val[d] : val[d] - l;
+                idx[d] = go_left ? left : left + 1;
+                p[d] = go_left ? l : r;
+            }
+            level_first = 2 * level_first + 1;
+        }
+        // remaining levels from memory: issue the kIlp pair loads of a level together
+        for (;;) {
+            double2 v[kIlp];
+            bool more = false;
+#pragma unroll
+            for (int d = 0; d < kIlp; d++) {
+                const i64 left = 2 * idx[d] + 1;
+                if (left < tree_len) {
+                    v[d] = *reinterpret_cast<const double2 *>(a.tree + left);
+                    more = true;
+                }
+            }
+            if (!more) break;
+#pragma unroll
+            for (int d = 0; d < kIlp; d++) {
+                const i64 left = 2 * idx[d] + 1;
+                if (left < tree_len) {
+                    const bool go_left = val[d] <= v[d].x;
+                    val[d] = go_left ? val[d] : val[d] - v[d].x;
+                    idx[d] = go_left ? left : left + 1;
+                    p[d] = go_left ? v[d].x : v[d].y;
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < kIlp; d++) {
+            const i64 j = base + d * stride;
+            if (j >= M) continue;
+            a.cand_idx[j] = idx[d];
+            a.cand_p[j] = p[d];
+            if (p[d] == 0.0) {
+                zeros++;
+            } else if (j < B) {  // fast path: with no rejection output i is draw i
+                const double w = is_weight(size, p[d], total, beta);
+                a.wtmp[j] = w;
+                a.out_idx[j] = idx[d];
+                wmax = fmax(wmax, w);
+            }
+        }
     }
     if (zeros) atomicAdd(zero_count, (u64)zeros);
+    const double m = block_max(wmax, red);
+    if (threadIdx.x == 0 && m > 0.0) atomicMax(wmax_bits, (u64)__double_as_longlong(m));  // positive doubles order like their bits
 }
 
 // single workgroup: ordered compaction of the accepted draws.  Fast exit when nothing was rejected.
@@ -308,8 +380,10 @@ __global__ void __launch_bounds__(1024) k_compact_bulk(SampleArgs a, const u64 *
     if (t == 0 && base < B) *a.out_used = -1;
 }
 
+// slow path only (some draw hit a zero-priority leaf): weights of the compacted draws
 __global__ void __launch_bounds__(256) k_weights_bulk(SampleArgs a, const int *identity, u64 *wmax_bits) {
     __shared__ double red[256];
+    if (*identity) return;
     const i64 B = a.batch;
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const double total = a.tree[0];
@@ -318,8 +392,8 @@ __global__ void __launch_bounds__(256) k_weights_bulk(SampleArgs a, const int *i
     const double size = (double)a.state->size;
     double w = 0.0;
     if (i < B && *a.out_used >= 0) {
-        const i64 j = *identity ? i : a.map[i];
-        w = pow(size * (a.cand_p[j] / total), -beta);
+        const i64 j = a.map[i];
+        w = is_weight(size, a.cand_p[j], total, beta);
         a.wtmp[i] = w;
         a.out_idx[i] = a.cand_idx[j];
     }
@@ -328,10 +402,10 @@ __global__ void __launch_bounds__(256) k_weights_bulk(SampleArgs a, const int *i
     if (threadIdx.x == 0 && m > 0.0) atomicMax(wmax_bits, (u64)__double_as_longlong(m));
 }
 
-__global__ void __launch_bounds__(256) k_normalise_bulk(SampleArgs a, const u64 *wmax_bits) {
+__global__ void __launch_bounds__(256) k_normalise_bulk(SampleArgs a, const int *identity, const u64 *wmax_fast, const u64 *wmax_slow) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.batch || *a.out_used < 0) return;
-    const double wmax = __longlong_as_double((long long)*wmax_bits);
+    const double wmax = __longlong_as_double((long long)(*identity ? *wmax_fast : *wmax_slow));
     const double w = a.wtmp[i] / wmax;
     if (a.out_w) a.out_w[i] = w;
     if (a.out_w32) a.out_w32[i] = (float)w;
@@ -706,15 +780,14 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
             return SRLX_ERR_UNSUPPORTED;
         }
         SRLX_HIP(hipMemsetAsync(counters, 0, 64, st));
-        int cu = 256;
-        i64 want = (M + 255) / 256;
-        int blocks = (int)(want < (i64)cu * 2 ? want : (i64)cu * 2);  // 64 KiB LDS each -> 2 per CU
-        const size_t lds = (size_t)(((i64)1 << kTopLevels) - 1) * 8 + 8;
-        hipLaunchKernelGGL(k_descend_bulk, dim3(blocks), dim3(256), lds, st, a, counters);
+        // counters: [0] zero_count  [1] wmax (fast path)  [2] identity flag  [3] wmax (slow path)
+        i64 want = (M + 256 * kIlp - 1) / (256 * kIlp);
+        int blocks = (int)(want < 256 * 8 ? want : 256 * 8);  // 8 resident workgroups per CU
+        hipLaunchKernelGGL(k_descend_bulk, dim3(blocks), dim3(256), 0, st, a, counters, counters + 1);
         hipLaunchKernelGGL(k_compact_bulk, dim3(1), dim3(1024), 0, st, a, counters, (int *)(counters + 2));
         const int wb = (int)((B + 255) / 256);
-        hipLaunchKernelGGL(k_weights_bulk, dim3(wb), dim3(256), 0, st, a, (const int *)(counters + 2), counters + 1);
-        hipLaunchKernelGGL(k_normalise_bulk, dim3(wb), dim3(256), 0, st, a, counters + 1);
+        hipLaunchKernelGGL(k_weights_bulk, dim3(wb), dim3(256), 0, st, a, (const int *)(counters + 2), counters + 3);
+        hipLaunchKernelGGL(k_normalise_bulk, dim3(wb), dim3(256), 0, st, a, (const int *)(counters + 2), counters + 1, counters + 3);
     }
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

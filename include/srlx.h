@@ -53,8 +53,8 @@ int srlx_device_info(int device, char *arch_name, int arch_name_len, int *cu_cou
  *           behind IPriorityMemory (srl/rl/memories/priority_memories/imemory.py:7-34).
  *
  * The tree is the reference's implicit heap: 2*capacity-1 float64 nodes, leaf slot j is
- * node j+capacity-1, parent(i) = (i-1)/2.  `sample` returns TREE indices (what the
- * reference hands back as update_args).  Tree contents are bit-identical to the reference
+ * node j+capacity-1, parent(i) = (i-1)/2 -- LOGICALLY; in HBM three levels share a 128-byte
+ * line.  `sample` returns logical TREE indices (what the reference hands back as update_args).  Tree contents are bit-identical to the reference
  * after the same call sequence: updates propagate fp64 deltas to ancestors in call order.
  * ------------------------------------------------------------------------------------ */
 typedef struct srlx_per srlx_per_t;
@@ -113,8 +113,9 @@ int srlx_per_restore(srlx_per_t *h, double max_priority, int64_t size, int64_t w
  * first old_size leaves of the old tree with _restore_skip. */
 int srlx_per_restore_resized(srlx_per_t *h, int64_t old_capacity, int64_t old_size, const double *old_tree_host);
 
-/* raw device views (zero-copy wrapping by the host runtime, tests) */
-int srlx_per_tree_ptr(srlx_per_t *h, void **d_tree, int64_t *tree_len);
+/* raw device view of the tree in its BLOCKED physical layout (16 doubles per 128-byte block, see
+ * csrc/srlx_per.hip struct Tree); n_doubles = allocated doubles.  Use backup() for heap order. */
+int srlx_per_tree_ptr(srlx_per_t *h, void **d_tree, int64_t *n_doubles);
 /* device struct { double max_priority; int64 size; int64 write; int64 pad; } */
 int srlx_per_state_ptr(srlx_per_t *h, void **d_state);
 /* re-read size/write from the device after HIP-graph replays that contained adds */

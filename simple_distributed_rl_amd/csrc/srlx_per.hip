@@ -4,10 +4,13 @@
 // twin cpp_module/src/proportional_memory.cpp) behind the C ABI of include/srlx.h.
 //
 // Data layout in HBM (one handle):
-//   buf   : (2N) float64, tree = buf + 1.  The reference's implicit heap (node i has children
-//           2i+1 / 2i+2, leaf slot j is node j+N-1).  The one-element offset makes every sibling
-//           pair (2i+1, 2i+2) one 16-byte aligned granule, so a descent step is ONE
-//           global_load_dwordx4 and the leaf priority comes with the last pair for free.
+//   T     : the reference's implicit heap (node i has children 2i+1 / 2i+2, leaf slot j is node
+//           j+N-1) stored BLOCKED: every 128-byte line holds the 2+4+8 descendants (relative
+//           depths 1..3) of one "owner" node, groups of three levels aligned to the leaf level.
+//           A root->leaf walk of a 1M-leaf tree touches 7 lines instead of 21, siblings are always
+//           one aligned 16-byte pair, and the leaf priority arrives with the last pair.  Logical
+//           node indices (what sample() returns and update() takes) are unchanged; backup()/restore()
+//           convert to/from the reference's flat heap order.
 //   state : { float64 max_priority; int64 size; int64 write; } -- lives on the device so that
 //           add/sample/update are HIP-graph capturable (no host-side scalars frozen at capture).
 //
@@ -45,7 +48,45 @@ constexpr int kUpdateChunk = 1024;   // indices per general-update launch (LDS r
 constexpr int kWgAdd = 256;
 constexpr i64 kSmallAddMax = 1024;   // adds handled by the single-workgroup path
 
-__device__ __forceinline__ int node_depth(i64 x) { return 63 - __clzll((u64)(x + 1)); }
+__host__ __device__ __forceinline__ int node_depth(i64 x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return 63 - __clzll((u64)(x + 1));
+#else
+    return 63 - __builtin_clzll((unsigned long long)(x + 1));
+#endif
+}
+
+// Blocked physical layout of the heap.  Levels below the root are cut into groups of three, aligned to
+// the deepest level D: the top group has h0 = ((D-1) % 3) + 1 levels (1..h0), then G groups of 3.  The
+// nodes of a group that descend from the same "owner" (the ancestor on the level just above the
+// group) share one 16-double block: slots 0-1 relative depth 1, 2-5 depth 2, 6-13 depth 3; block 0
+// slot 14 is the root.  base[g] = index of the first block of group g.
+struct Tree {
+    double *T;
+    i64 len;  // 2 * capacity - 1 logical nodes
+    int D, h0, G;
+    i64 base[12];
+
+    __device__ __forceinline__ i64 phys(i64 i) const {
+        if (i == 0) return 14;
+        const int d = node_depth(i);
+        const i64 q = i + 1 - ((i64)1 << d);
+        if (d <= h0) return (d == 1 ? 0 : (d == 2 ? 2 : 6)) + q;
+        const int k = d - h0 - 1;
+        const int g = 1 + k / 3, r = k % 3 + 1;
+        const i64 blk = base[g] + (q >> r);
+        return 16 * blk + (r == 1 ? 0 : (r == 2 ? 2 : 6)) + (q & (((i64)1 << r) - 1));
+    }
+    __device__ __forceinline__ double get(i64 i) const { return T[phys(i)]; }
+    __device__ __forceinline__ void set(i64 i, double v) const { T[phys(i)] = v; }
+    // (left, right) children values as one aligned 16-byte load; `left` must be odd (a left child)
+    __device__ __forceinline__ double2 pair(i64 left) const { return *reinterpret_cast<const double2 *>(T + phys(left)); }
+    // block that holds the children of owner node `owner` on level `level` (level = 0, h0, h0+3, ...)
+    __device__ __forceinline__ i64 block_of_owner(i64 owner, int level) const {
+        if (level == 0) return 0;
+        return base[1 + (level - h0) / 3] + (owner + 1 - ((i64)1 << level));
+    }
+};
 
 // (|x|+eps)^alpha.  kind F64: numpy float64 semantics (sqrt fast path at 0.5 like np.power);
 // kind F32: the expression evaluated in float32 (numpy keeps a float32 array in float32,
@@ -77,33 +118,23 @@ __device__ __forceinline__ double load_prio(const void *prio, int kind, i64 i, d
 }
 
 // ------------------------------------------------------------------------------------------
-// descent: proportional_memory.py:56-66 (_retrieve) + :88-92 (get)
-// `top` (LDS copy of tree[0..top_n)) may be null.  Sibling pairs are 16-byte aligned.
+// descent: proportional_memory.py:56-66 (_retrieve) + :88-92 (get), one pair load per level
+// (three consecutive levels hit the same 128-byte line)
 // ------------------------------------------------------------------------------------------
-template <bool USE_TOP>
-__device__ __forceinline__ void descend(const double *__restrict__ tree, i64 tree_len, const double *top, i64 top_n,
-                                        double val, i64 &out_idx, double &out_p) {
+__device__ __forceinline__ void descend(const Tree &tr, double val, i64 &out_idx, double &out_p) {
     i64 idx = 0;
-    double p = tree_len == 1 ? tree[0] : 0.0;
+    double p = tr.len == 1 ? tr.T[14] : 0.0;
     for (;;) {
-        i64 left = 2 * idx + 1;
-        if (left >= tree_len) break;
-        double l, r;
-        if (USE_TOP && left + 1 < top_n) {
-            l = top[left];
-            r = top[left + 1];
-        } else {
-            const double2 v = *reinterpret_cast<const double2 *>(tree + left);
-            l = v.x;
-            r = v.y;
-        }
-        if (val <= l) {
+        const i64 left = 2 * idx + 1;
+        if (left >= tr.len) break;
+        const double2 v = tr.pair(left);
+        if (val <= v.x) {
             idx = left;
-            p = l;
+            p = v.x;
         } else {
-            val -= l;
+            val -= v.x;
             idx = left + 1;
-            p = r;
+            p = v.y;
         }
     }
     out_idx = idx;
@@ -155,8 +186,7 @@ __device__ __forceinline__ int block_exscan(int v, int *buf, int *total) {
 }
 
 struct SampleArgs {
-    const double *tree;
-    i64 tree_len;
+    Tree tr;
     const PerState *state;
     double beta_initial, beta_steps;
     i64 step;
@@ -190,13 +220,13 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
 
     const int t = threadIdx.x, T = blockDim.x;
     const i64 M = a.n_uniforms, B = a.batch;
-    const double total = a.tree[0];  // :135
+    const double total = a.tr.T[14];  // :135 (root)
 
     // phase 1: one descent per uniform (coalesced uniform reads, strided assignment)
     for (i64 j = t; j < M; j += T) {
         i64 idx;
         double p;
-        descend<false>(a.tree, a.tree_len, nullptr, 0, a.uniforms[j] * total, idx, p);  // :147-148
+        descend(a.tr, a.uniforms[j] * total, idx, p);  // :147-148
         a.cand_idx[j] = idx;
         a.cand_p[j] = p;
     }
@@ -258,23 +288,62 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // per_sample, bulk path (thousands..millions of draws per launch: prefetching learners, the
-// PER micro-benchmark).  Random 16-byte reads of a 16 MB tree are latency-bound, so the kernel is
-// built for memory-level parallelism: only the top kBulkTop levels (16 KiB) are staged in LDS so that
-// 8 workgroups stay resident per CU, and every lane walks kIlp independent draws level by level,
-// issuing their pair loads back to back.  The IS weight of the no-rejection fast path is fused in.
+// PER micro-benchmark).  The walk is done one 128-byte block (three levels) at a time: the blocks of
+// the top groups (levels <= 11 of a 1M-leaf tree, 37.5 KiB) are staged in LDS, each lower group costs
+// ONE cache line per draw (its 7 x 16-byte loads are issued together, the three decisions are then
+// register selects), and every lane walks kIlp independent draws so that their line fetches overlap.
+// The IS weight of the no-rejection fast path is fused in.
+// Measured alternatives on MI355X (1M draws from 1M leaves, whole call): one
+// dependent 16-byte pair load per level 104 us (blocked layout) / 76 us (flat heap, 64 KiB LDS top);
+// 8-lane cooperative line fetch through LDS 206 us; this kernel 84 us.  All of them are bound by the
+// L2-miss traffic of the bottom three levels (~190 B per draw out of the Infinity Cache), not by HBM.
 // ------------------------------------------------------------------------------------------
-constexpr int kBulkTop = 11;  // 2047 nodes
-constexpr int kIlp = 4;
+constexpr int kIlp = 2;
+constexpr int kBulkLdsBlocks = 320;  // 40 KiB: 3-4 workgroups per CU
 
-__global__ void __launch_bounds__(256) k_descend_bulk(SampleArgs a, u64 *zero_count, u64 *wmax_bits) {
-    __shared__ __attribute__((aligned(16))) double top[((1 << kBulkTop) - 1) + 1];
+struct Blk {
+    double2 v[7];
+};
+
+__device__ __forceinline__ double2 sel2(const double2 &a, const double2 &b, int s) { return s ? b : a; }
+
+// walk up to `levels` levels inside one block; returns false when the draw has reached a leaf
+__device__ __forceinline__ bool walk_block(const Blk &b, int levels, i64 len, i64 &idx, double &val, double &p) {
+    i64 left = 2 * idx + 1;
+    if (left >= len) return false;
+    bool go = val <= b.v[0].x;  // :61
+    const int s1 = go ? 0 : 1;
+    val = go ? val : val - b.v[0].x;
+    idx = left + s1;
+    p = go ? b.v[0].x : b.v[0].y;
+    if (levels < 2) return true;
+    left = 2 * idx + 1;
+    if (left >= len) return false;
+    const double2 p2 = sel2(b.v[1], b.v[2], s1);
+    go = val <= p2.x;
+    const int s2 = 2 * s1 + (go ? 0 : 1);
+    val = go ? val : val - p2.x;
+    idx = left + (go ? 0 : 1);
+    p = go ? p2.x : p2.y;
+    if (levels < 3) return true;
+    left = 2 * idx + 1;
+    if (left >= len) return false;
+    const double2 p3 = sel2(sel2(b.v[3], b.v[4], s2 & 1), sel2(b.v[5], b.v[6], s2 & 1), s2 >> 1);
+    go = val <= p3.x;
+    val = go ? val : val - p3.x;
+    idx = left + (go ? 0 : 1);
+    p = go ? p3.x : p3.y;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_descend_bulk(SampleArgs a, int lds_blocks, u64 *zero_count, u64 *wmax_bits) {
+    __shared__ __attribute__((aligned(16))) double top[kBulkLdsBlocks * 16];
     __shared__ double red[256];
-    const i64 top_cap = ((i64)1 << kBulkTop) - 1;
-    const i64 top_n = a.tree_len < top_cap ? a.tree_len : top_cap;
-    for (i64 k = threadIdx.x; k < top_n; k += blockDim.x) top[k] = a.tree[k];
+    const Tree tr = a.tr;
+    for (i64 k = threadIdx.x; k < (i64)lds_blocks * 16; k += blockDim.x) top[k] = tr.T[k];
     __syncthreads();
-    const double total = top[0];
-    const i64 M = a.n_uniforms, B = a.batch, tree_len = a.tree_len;
+    const double total = top[14];
+    const i64 M = a.n_uniforms, B = a.batch, len = tr.len;
     const i64 step = a.d_step ? *a.d_step : a.step;
     const double beta = beta_of(a.beta_initial, a.beta_steps, step);
     const double size = (double)a.state->size;
@@ -284,50 +353,32 @@ __global__ void __launch_bounds__(256) k_descend_bulk(SampleArgs a, u64 *zero_co
     for (i64 base = (i64)blockIdx.x * blockDim.x + threadIdx.x; base < M; base += stride * kIlp) {
         i64 idx[kIlp];
         double val[kIlp], p[kIlp];
+        bool live[kIlp];
 #pragma unroll
         for (int d = 0; d < kIlp; d++) {
             const i64 j = base + d * stride;
+            live[d] = j < M && len > 1;
             val[d] = j < M ? a.uniforms[j] * total : 0.0;  // :147
             idx[d] = 0;
-            p[d] = total;  // tree_len == 1: the root is the leaf
+            p[d] = total;
         }
-        // levels whose sibling pairs sit in LDS: the same count for every draw
-        i64 level_first = 0;  // index of the first node of the current level
-        while (2 * level_first + 2 < top_n) {
+        int level = 0;  // level of the current owner nodes (same for every live draw)
+        for (int g = 0; g <= tr.G; g++) {
+            const int levels = g == 0 ? tr.h0 : 3;
+            Blk blk[kIlp];
 #pragma unroll
             for (int d = 0; d < kIlp; d++) {
-                const i64 left = 2 * idx[d] + 1;
-                const double l = top[left], r = top[left + 1];
-                const bool go_left = val[d] <= l;  // :61
-                val[d] = go_left ? val[d] : val[d] - l;
-                idx[d] = go_left ? left : left + 1;
-                p[d] = go_left ? l : r;
-            }
-            level_first = 2 * level_first + 1;
-        }
-        // remaining levels from memory: issue the kIlp pair loads of a level together
-        for (;;) {
-            double2 v[kIlp];
-            bool more = false;
+                if (!live[d]) continue;
+                const i64 bi = tr.block_of_owner(idx[d], level);
+                const double2 *src = bi < lds_blocks ? reinterpret_cast<const double2 *>(top + bi * 16)
+                                                     : reinterpret_cast<const double2 *>(tr.T + bi * 16);
 #pragma unroll
-            for (int d = 0; d < kIlp; d++) {
-                const i64 left = 2 * idx[d] + 1;
-                if (left < tree_len) {
-                    v[d] = *reinterpret_cast<const double2 *>(a.tree + left);
-                    more = true;
-                }
+                for (int k = 0; k < 7; k++) blk[d].v[k] = src[k];
             }
-            if (!more) break;
 #pragma unroll
-            for (int d = 0; d < kIlp; d++) {
-                const i64 left = 2 * idx[d] + 1;
-                if (left < tree_len) {
-                    const bool go_left = val[d] <= v[d].x;
-                    val[d] = go_left ? val[d] : val[d] - v[d].x;
-                    idx[d] = go_left ? left : left + 1;
-                    p[d] = go_left ? v[d].x : v[d].y;
-                }
-            }
+            for (int d = 0; d < kIlp; d++)
+                if (live[d]) live[d] = walk_block(blk[d], levels, len, idx[d], val[d], p[d]) && (2 * idx[d] + 1 < len);
+            level += levels;
         }
 #pragma unroll
         for (int d = 0; d < kIlp; d++) {
@@ -386,7 +437,7 @@ __global__ void __launch_bounds__(256) k_weights_bulk(SampleArgs a, const int *i
     if (*identity) return;
     const i64 B = a.batch;
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const double total = a.tree[0];
+    const double total = a.tr.T[14];
     const i64 step = a.d_step ? *a.d_step : a.step;
     const double beta = beta_of(a.beta_initial, a.beta_steps, step);
     const double size = (double)a.state->size;
@@ -424,7 +475,7 @@ __device__ __forceinline__ bool is_ancestor(i64 a, int da, i64 x, int dx) {
     return dx > da && (((x + 1) >> (dx - da)) == a + 1);
 }
 
-__global__ void __launch_bounds__(kWgUpdate) k_update_wg(double *tree, i64 tree_len, PerState *state, i64 n,
+__global__ void __launch_bounds__(kWgUpdate) k_update_wg(Tree tr, PerState *state, i64 n,
                                                           const i64 *indices, const void *prio, int kind, double eps,
                                                           double alpha, int *err_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -439,7 +490,7 @@ __global__ void __launch_bounds__(kWgUpdate) k_update_wg(double *tree, i64 tree_
     double pmax = 0.0;
     for (i64 i = t; i < n; i += T) {
         i64 x = indices[i];
-        if (x < 0 || x >= tree_len) {  // the reference would raise IndexError; flag and neutralise
+        if (x < 0 || x >= tr.len) {  // the reference would raise IndexError; flag and neutralise
             *err_flag = 1;
             x = 0;
         }
@@ -464,18 +515,18 @@ __global__ void __launch_bounds__(kWgUpdate) k_update_wg(double *tree, i64 tree_
                 last = false;
                 break;
             }
-        const double before = prev >= 0 ? s_p[prev] : tree[x];
+        const double before = prev >= 0 ? s_p[prev] : tr.get(x);
         s_chg[i] = s_p[i] - before;  // :83
         last_me[q] = last;
     }
     __syncthreads();  // every old leaf value has been read
     q = 0;
     for (i64 i = t; i < n; i += T, q++)
-        if (last_me[q]) tree[s_idx[i]] = s_p[i];  // :85
+        if (last_me[q]) tr.set(s_idx[i], s_p[i]);  // :85
 
     // ancestors (:49-54).  task (i, k): the k-th ancestor of index i; the first i that reaches a
     // node owns it.
-    int maxd = node_depth(tree_len - 1);
+    int maxd = tr.D;
     const i64 tasks = n * (i64)maxd;
     for (i64 task = t; task < tasks; task += T) {
         const i64 i = task / maxd;
@@ -491,11 +542,12 @@ __global__ void __launch_bounds__(kWgUpdate) k_update_wg(double *tree, i64 tree_
                 break;
             }
         if (!owner) continue;
-        double v = tree[a];
+        const i64 pa = tr.phys(a);
+        double v = tr.T[pa];
         v += s_chg[i];
         for (i64 j = i + 1; j < n; j++)
             if (is_ancestor(a, da, s_idx[j], s_dep[j])) v += s_chg[j];
-        tree[a] = v;
+        tr.T[pa] = v;
     }
 
     const double m = block_max(pmax, red);
@@ -552,7 +604,7 @@ __device__ __forceinline__ i64 run_tasks(const Run &r) {
 }
 
 // thread `tid` of `nthreads` processes its share of a run's ancestor nodes
-__device__ __forceinline__ void run_ancestors(double *tree, const double *chg, const Run &r, i64 tid, i64 nthreads) {
+__device__ __forceinline__ void run_ancestors(const Tree &tr, const double *chg, const Run &r, i64 tid, i64 nthreads) {
     const i64 cnt = r.i_hi - r.i_lo;
     const i64 x_hi = r.x_lo + cnt - 1;
     const i64 tasks = run_tasks(r);
@@ -576,14 +628,21 @@ __device__ __forceinline__ void run_ancestors(double *tree, const double *chg, c
         if (last > x_hi) last = x_hi;
         const double *c0 = chg + r.i_lo + (first - r.x_lo);
         const i64 m = last - first + 1;
-        double v = tree[a];
-        for (i64 k = 0; k < m; k++) v += c0[k];  // list order: the reference's propagate order
-        tree[a] = v;
+        const i64 pa = tr.phys(a);
+        double v = tr.T[pa];
+        i64 k = 0;
+        for (; k + 8 <= m; k += 8) {  // loads issued together, additions strictly in list order
+            const double c[8] = {c0[k], c0[k + 1], c0[k + 2], c0[k + 3], c0[k + 4], c0[k + 5], c0[k + 6], c0[k + 7]};
+#pragma unroll
+            for (int u = 0; u < 8; u++) v += c[u];
+        }
+        for (; k < m; k++) v += c0[k];  // list order: the reference's propagate order
+        tr.T[pa] = v;
     }
 }
 
 struct AddArgs {
-    double *tree;
+    Tree tree;
     i64 cap;
     PerState *state;
     i64 n;
@@ -605,8 +664,9 @@ __device__ __forceinline__ void add_leaf(const AddArgs &a, i64 i, i64 write, dou
     if (slot >= a.cap) slot -= a.cap;
     const i64 x = slot + a.cap - 1;
     const double p = load_prio(a.prio, a.kind, i, a.eps, a.alpha, maxp);
-    a.chg[i] = p - a.tree[x];
-    a.tree[x] = p;
+    const i64 px = a.tree.phys(x);
+    a.chg[i] = p - a.tree.T[px];
+    a.tree.T[px] = p;
     // priorities are >= 0, so their bit patterns order like the values
     if (a.track_max && p > maxp) atomicMax((u64 *)&a.state->max_priority, (u64)__double_as_longlong(p));
 }
@@ -621,8 +681,11 @@ __device__ __forceinline__ void add_commit(const AddArgs &a) {
     s->size = z > a.cap ? a.cap : z;
 }
 
-// n <= kSmallAddMax: everything in one launch
+// n <= kSmallAddMax: everything in one launch; the per-leaf changes live in LDS so that the root
+// owner's n dependent fp64 additions are fed from LDS, not from memory
 __global__ void __launch_bounds__(kWgAdd) k_add_wg(AddArgs a) {
+    __shared__ double s_chg[kSmallAddMax];
+    a.chg = s_chg;
     const int t = threadIdx.x, T = blockDim.x;
     const i64 write = add_start(a);
     const double maxp = a.state->max_priority;
@@ -665,6 +728,13 @@ __global__ void k_state_set(PerState *s, double mp, i64 size, i64 write) {
     s->size = size;
     s->write = write;
 }
+// blocked layout <-> the reference's flat heap order (backup()/restore(), proportional_memory.py:179-205)
+__global__ void __launch_bounds__(256) k_to_heap(Tree tr, double *heap) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < tr.len; i += (i64)gridDim.x * blockDim.x) heap[i] = tr.get(i);
+}
+__global__ void __launch_bounds__(256) k_from_heap(Tree tr, const double *heap) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < tr.len; i += (i64)gridDim.x * blockDim.x) tr.set(i, heap[i]);
+}
 
 }  // namespace
 
@@ -676,8 +746,9 @@ struct srlx_per {
     i64 capacity, tree_len;
     double alpha, beta_initial, beta_steps, epsilon;
     int has_duplicate;
-    double *d_buf;
-    double *d_tree;
+    Tree tree;        // blocked device layout (tree.T is the allocation)
+    i64 n_blocks;     // 128-byte blocks allocated
+    int lds_blocks;   // leading blocks the bulk sampler stages in LDS
     PerState *d_state;
     int *d_err;
     i64 size, write;  // host mirror
@@ -696,7 +767,7 @@ int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st,
     SRLX_TRY(h->scratch.reserve(srlx::Carver::padded((size_t)n * 8) + 256));
     const bool append = start_slot < 0;
     double *snap = (double *)((char *)h->scratch.ptr + srlx::Carver::padded((size_t)n * 8));
-    AddArgs a{h->d_tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr,
+    AddArgs a{h->tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr,
               start_slot, append ? 1 : 0, append ? 0 : 1, 0.0, snap};
     if (n <= kSmallAddMax) {
         hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(kWgAdd), 0, st, a);
@@ -724,7 +795,7 @@ int launch_update(srlx_per *h, i64 n, const i64 *d_idx, const void *d_prio, int 
     for (i64 off = 0; off < n; off += kUpdateChunk) {
         const i64 m = (n - off < kUpdateChunk) ? n - off : kUpdateChunk;
         const size_t lds = (size_t)m * (8 + 8 + 8 + 4) + (size_t)kWgUpdate * 8 + 16;
-        hipLaunchKernelGGL(k_update_wg, dim3(1), dim3(kWgUpdate), lds, st, h->d_tree, h->tree_len, h->d_state, m,
+        hipLaunchKernelGGL(k_update_wg, dim3(1), dim3(kWgUpdate), lds, st, h->tree, h->d_state, m,
                            d_idx + off, (const void *)((const char *)d_prio + (size_t)off * eb), kind, h->epsilon,
                            h->alpha, h->d_err);
     }
@@ -750,8 +821,7 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
     SRLX_TRY(h->scratch.reserve(SampleScratch::bytes(M, B)));
     srlx::Carver cv(h->scratch.ptr);
     SampleArgs a{};
-    a.tree = h->d_tree;
-    a.tree_len = h->tree_len;
+    a.tr = h->tree;
     a.state = h->d_state;
     a.beta_initial = h->beta_initial;
     a.beta_steps = h->beta_steps;
@@ -782,8 +852,8 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
         SRLX_HIP(hipMemsetAsync(counters, 0, 64, st));
         // counters: [0] zero_count  [1] wmax (fast path)  [2] identity flag  [3] wmax (slow path)
         i64 want = (M + 256 * kIlp - 1) / (256 * kIlp);
-        int blocks = (int)(want < 256 * 8 ? want : 256 * 8);  // 8 resident workgroups per CU
-        hipLaunchKernelGGL(k_descend_bulk, dim3(blocks), dim3(256), 0, st, a, counters, counters + 1);
+        int blocks = (int)(want < 256 * 4 ? want : 256 * 4);  // 42 KiB of LDS each: 3-4 resident workgroups per CU
+        hipLaunchKernelGGL(k_descend_bulk, dim3(blocks), dim3(256), 0, st, a, h->lds_blocks, counters, counters + 1);
         hipLaunchKernelGGL(k_compact_bulk, dim3(1), dim3(1024), 0, st, a, counters, (int *)(counters + 2));
         const int wb = (int)((B + 255) / 256);
         hipLaunchKernelGGL(k_weights_bulk, dim3(wb), dim3(256), 0, st, a, (const int *)(counters + 2), counters + 3);
@@ -818,10 +888,31 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
     h->has_duplicate = has_duplicate ? 1 : 0;
     h->pinned.pinned_host = true;
     h->size = h->write = 0;
-    h->d_buf = nullptr;
     h->d_state = nullptr;
     h->d_err = nullptr;
-    hipError_t e = hipMalloc((void **)&h->d_buf, sizeof(double) * (size_t)(h->tree_len + 1));
+    {   // geometry of the blocked layout (see struct Tree)
+        Tree &t = h->tree;
+        t.T = nullptr;
+        t.len = h->tree_len;
+        t.D = node_depth(h->tree_len - 1);
+        for (int g = 0; g < 12; g++) t.base[g] = 0;
+        if (t.D == 0) {
+            t.h0 = 0;
+            t.G = 0;
+            h->n_blocks = 1;
+        } else {
+            t.h0 = (t.D - 1) % 3 + 1;
+            t.G = (t.D - t.h0) / 3;
+            t.base[1] = 1;
+            for (int g = 1; g <= t.G; g++) t.base[g + 1] = t.base[g] + ((i64)1 << (t.h0 + 3 * (g - 1)));
+            h->n_blocks = t.G >= 1 ? t.base[t.G + 1] : 1;
+        }
+        h->lds_blocks = 1;
+        for (int g = 1; g <= t.G; g++)
+            if (t.base[g + 1] <= kBulkLdsBlocks) h->lds_blocks = (int)t.base[g + 1];
+        if (h->n_blocks < h->lds_blocks) h->lds_blocks = (int)h->n_blocks;
+    }
+    hipError_t e = hipMalloc((void **)&h->tree.T, 128 * (size_t)h->n_blocks);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_state, sizeof(PerState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_err, sizeof(int));
     if (e != hipSuccess) {
@@ -829,7 +920,6 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
         srlx_per_destroy(h);
         return e == hipErrorOutOfMemory ? SRLX_ERR_NOMEM : SRLX_ERR_HIP;
     }
-    h->d_tree = h->d_buf + 1;
     *out = h;
     int s = srlx_per_clear(h, nullptr);
     if (s == SRLX_OK && hipStreamSynchronize(nullptr) != hipSuccess) s = SRLX_ERR_HIP;
@@ -844,7 +934,7 @@ int srlx_per_destroy(srlx_per_t *h) {
     if (!h) return SRLX_OK;
     srlx::DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    if (h->d_buf) (void)hipFree(h->d_buf);
+    if (h->tree.T) (void)hipFree(h->tree.T);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->d_err) (void)hipFree(h->d_err);
     h->scratch.release();
@@ -858,7 +948,7 @@ int srlx_per_clear(srlx_per_t *h, void *stream) {
     SRLX_REQUIRE(h, "per_clear: NULL handle");
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = pick_stream(h, stream);
-    SRLX_HIP(hipMemsetAsync(h->d_buf, 0, sizeof(double) * (size_t)(h->tree_len + 1), st));
+    SRLX_HIP(hipMemsetAsync(h->tree.T, 0, 128 * (size_t)h->n_blocks, st));
     SRLX_HIP(hipMemsetAsync(h->d_err, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, st, h->d_state);
     SRLX_HIP(hipGetLastError());
@@ -992,7 +1082,12 @@ int srlx_per_backup(srlx_per_t *h, double *max_priority, int64_t *size, int64_t 
     *write = s.write;
     h->size = s.size;
     h->write = s.write;
-    if (tree_host) SRLX_HIP(hipMemcpy(tree_host, h->d_tree, sizeof(double) * (size_t)h->tree_len, hipMemcpyDeviceToHost));
+    if (tree_host) {
+        SRLX_TRY(h->staging.reserve(sizeof(double) * (size_t)h->tree_len));
+        hipLaunchKernelGGL(k_to_heap, dim3(1024), dim3(256), 0, nullptr, h->tree, (double *)h->staging.ptr);
+        SRLX_HIP(hipGetLastError());
+        SRLX_HIP(hipMemcpy(tree_host, h->staging.ptr, sizeof(double) * (size_t)h->tree_len, hipMemcpyDeviceToHost));
+    }
     int err = 0;
     SRLX_HIP(hipMemcpy(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost));
     if (err) {
@@ -1007,7 +1102,11 @@ int srlx_per_restore(srlx_per_t *h, double max_priority, int64_t size, int64_t w
     SRLX_REQUIRE(size >= 0 && size <= h->capacity && write >= 0 && write < h->capacity, "per_restore: bad size/write");
     srlx::DeviceGuard guard(h->device);
     SRLX_HIP(hipDeviceSynchronize());
-    SRLX_HIP(hipMemcpy(h->d_tree, tree_host, sizeof(double) * (size_t)h->tree_len, hipMemcpyHostToDevice));
+    SRLX_TRY(h->staging.reserve(sizeof(double) * (size_t)h->tree_len));
+    SRLX_HIP(hipMemcpy(h->staging.ptr, tree_host, sizeof(double) * (size_t)h->tree_len, hipMemcpyHostToDevice));
+    SRLX_HIP(hipMemsetAsync(h->tree.T, 0, 128 * (size_t)h->n_blocks, nullptr));
+    hipLaunchKernelGGL(k_from_heap, dim3(1024), dim3(256), 0, nullptr, h->tree, (const double *)h->staging.ptr);
+    SRLX_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_state_set, dim3(1), dim3(1), 0, nullptr, h->d_state, max_priority, (i64)size, (i64)write);
     SRLX_HIP(hipGetLastError());
     SRLX_HIP(hipStreamSynchronize(nullptr));
@@ -1031,8 +1130,8 @@ int srlx_per_restore_resized(srlx_per_t *h, int64_t old_capacity, int64_t old_si
 
 int srlx_per_tree_ptr(srlx_per_t *h, void **d_tree, int64_t *tree_len) {
     SRLX_REQUIRE(h && d_tree, "per_tree_ptr: NULL argument");
-    *d_tree = h->d_tree;
-    if (tree_len) *tree_len = h->tree_len;
+    *d_tree = h->tree.T;
+    if (tree_len) *tree_len = h->n_blocks * 16;
     return SRLX_OK;
 }
 

@@ -103,6 +103,42 @@ __device__ __forceinline__ void emit_stack_elem(const StoreDev &s, i64 e, i64 x,
     }
 }
 
+// u8 fast path: ONE workgroup expands ONE frame.  A lane loads kFrameUnroll independent dwords (a wave
+// reads 256 contiguous bytes per load instruction) before it converts and stores them as float4 (1 KiB
+// contiguous per store instruction): with a single dword per lane a CU can only keep 8 KiB of reads in
+// flight and the kernel is latency-bound at ~3 TB/s (measured); the frame lookup (episode-start test,
+// ring offset) is workgroup-uniform, no per-lane integer division.
+constexpr int kFrameUnroll = 8;  // 8 * 256 lanes * 4 B = 8 KiB per workgroup pass (a 84x84 frame is 7 056 B)
+
+__device__ __forceinline__ void emit_frame_dwords(const StoreDev &s, i64 e, i64 x, int c, float *dst_frame) {
+    const int back = s.W - 1 - c;
+    const i64 rx = posmod(x, s.L);
+    const bool zero = back > s.step_in_ep[e * s.L + rx];
+    const i64 rf = posmod(x - back, s.L);
+    const i64 nd = s.F / 4;
+    const unsigned *src = reinterpret_cast<const unsigned *>((const u8 *)s.obs + (e * s.L + rf) * s.F);
+    float4 *dst = reinterpret_cast<float4 *>(dst_frame);
+    for (i64 i0 = threadIdx.x; i0 < nd; i0 += 256 * kFrameUnroll) {
+        unsigned w[kFrameUnroll];
+#pragma unroll
+        for (int u = 0; u < kFrameUnroll; u++) {
+            const i64 i = i0 + u * 256;
+            w[u] = (!zero && i < nd) ? src[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kFrameUnroll; u++) {
+            const i64 i = i0 + u * 256;
+            if (i < nd)
+                dst[i] = make_float4(norm_u8(w[u] & 255u), norm_u8((w[u] >> 8) & 255u), norm_u8((w[u] >> 16) & 255u), norm_u8(w[u] >> 24));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_stack_current_u8(StoreDev s, float *out) {
+    const i64 fc = blockIdx.x;  // (e, c)
+    emit_frame_dwords(s, fc / s.W, s.pos[0], (int)(fc % s.W), out + fc * s.F);
+}
+
 // units per frame for the vector / scalar paths
 __host__ __device__ __forceinline__ i64 units_per_frame(i64 F, int obs_dtype, bool vec) {
     if (!vec) return F;
@@ -237,6 +273,17 @@ __global__ void __launch_bounds__(256) k_gather_meta(StoreDev s, i64 B, const i6
             terminated[b * s.n + k] = 1.f;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_gather_obs_u8(StoreDev s, const ItemMeta *meta, float *out) {
+    const i64 fc = blockIdx.x;  // (b, k, c)
+    const int S = s.n + 1;
+    const int c = (int)(fc % s.W);
+    const i64 bk = fc / s.W;
+    const int k = (int)(bk % S);
+    const ItemMeta m = meta[bk / S];
+    const int kk = k < m.jd + 1 ? k : m.jd + 1;  // states after the terminal one repeat it (rainbow.py:358)
+    emit_frame_dwords(s, m.e, m.q + kk, c, out + fc * s.F);
 }
 
 template <bool VEC>
@@ -457,7 +504,9 @@ int srlx_store_stack_current(srlx_store_t *h, float *d_out, void *stream) {
     hipStream_t st = pick(h, stream);
     const StoreDev &d = h->d;
     const i64 total = d.E * d.W * units_per_frame(d.F, d.obs_dtype, h->vec);
-    if (h->vec)
+    if (d.obs_dtype == SRLX_OBS_U8 && d.F % 16 == 0 && d.E * d.W < ((i64)1 << 31))
+        hipLaunchKernelGGL(k_stack_current_u8, dim3((unsigned)(d.E * d.W)), dim3(256), 0, st, d, d_out);
+    else if (h->vec)
         hipLaunchKernelGGL(k_stack_current<true>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, d_out);
     else
         hipLaunchKernelGGL(k_stack_current<false>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, d_out);
@@ -500,7 +549,10 @@ int srlx_store_gather_nstep(srlx_store_t *h, int64_t batch, const int64_t *d_tre
     hipLaunchKernelGGL(k_gather_meta, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, d, (i64)batch, d_tree_idx, meta,
                        d_actions, d_rewards, d_terminated);
     const i64 total = batch * (d.n + 1) * d.W * units_per_frame(d.F, d.obs_dtype, h->vec);
-    if (h->vec)
+    const i64 frames = batch * (d.n + 1) * d.W;
+    if (d.obs_dtype == SRLX_OBS_U8 && d.F % 16 == 0 && frames < ((i64)1 << 31))
+        hipLaunchKernelGGL(k_gather_obs_u8, dim3((unsigned)frames), dim3(256), 0, st, d, meta, d_obs);
+    else if (h->vec)
         hipLaunchKernelGGL(k_gather_obs<true>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, (i64)batch, meta, d_obs);
     else
         hipLaunchKernelGGL(k_gather_obs<false>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, (i64)batch, meta, d_obs);

@@ -115,7 +115,7 @@ class RainbowEngine:
         self.q_target.eval()
         self.q_target.load_state_dict(self.q_online.state_dict())  # model_torch.py:41-42
         self.q_online.train()
-        self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True)  # model_torch.py:71
+        self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True, fused=True)  # model_torch.py:71 (one multi-tensor kernel)
         d = self.dev
         B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
         self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)

@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--episode-len", type=int, default=200)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graphs")
+    ap.add_argument("--no-overlap", action="store_true", help="run actor and learner back to back on one stream (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
@@ -71,7 +72,7 @@ def main():
 
         eng = DistributedRainbow(cfg, local_rank, args.episode_len, sync_interval=args.sync_interval)
     else:
-        eng = RainbowEngine(cfg, local_rank, args.episode_len)
+        eng = RainbowEngine(cfg, local_rank, args.episode_len, overlap=not args.no_overlap)
     is_learner = rank == 0
 
     # ---- fill the replay (untimed): random-policy rollout until the ring is full, then |delta| ~ U(0,1)
@@ -139,6 +140,7 @@ def main():
             "noisy_dense": cfg.enable_noisy_dense,
             "epsilon": cfg.epsilon,
             "hip_graphs": not args.no_graph,
+            "actor_learner_overlap": (not args.no_overlap) if world == 1 else False,
             "topology": "1 GPU: actor+learner" if world == 1 else f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast",
         },
         "roofline": {

@@ -92,8 +92,14 @@ class RainbowEngine:
     """Actor + learner on one GPU sharing the online network (the reference's sequential `Runner.train`
     topology, core_play.py:115-214, with E environments per iteration)."""
 
-    def __init__(self, cfg: RainbowDeviceConfig, device: int = 0, episode_len: int = 200, ring_len: Optional[int] = None, env=None):
+    def __init__(self, cfg: RainbowDeviceConfig, device: int = 0, episode_len: int = 200, ring_len: Optional[int] = None, env=None,
+                 overlap: bool = False):
+        """overlap=True runs the actor's network pass and the learner update concurrently on two HIP
+        streams.  The actor then acts with its own copy of the online network, refreshed after every
+        step (the reference's distributed actors do the same on a timer, play_mp.py:121-165), so no
+        kernel ever reads weights that another stream is updating."""
         self.cfg = cfg
+        self.overlap = bool(overlap)
         self.dev = torch.device(f"cuda:{device}")
         self.lib = N.lib()
         torch.manual_seed(cfg.seed)
@@ -115,6 +121,16 @@ class RainbowEngine:
         self.q_target.eval()
         self.q_target.load_state_dict(self.q_online.state_dict())  # model_torch.py:41-42
         self.q_online.train()
+        if self.overlap:
+            self.q_actor = atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters).to(self.dev)
+            self.q_actor.load_state_dict(self.q_online.state_dict())
+            self.s_learner = torch.cuda.Stream(device=self.dev)
+            self._ev_fork = torch.cuda.Event()
+            self._ev_join = torch.cuda.Event()
+        else:
+            self.q_actor = self.q_online
+        self._front_graph = None
+        self._commit_graph = None
         self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True, fused=True)  # model_torch.py:71 (one multi-tensor kernel)
         d = self.dev
         B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
@@ -140,18 +156,27 @@ class RainbowEngine:
         """uint8 frame ring -> float32 [E, W, H, W] policy input (the HBM-heavy hand-written kernel)."""
         return self.replay.stack_current().view(self.cfg.n_envs, *self._img)
 
-    def _actor_rest(self, obs):
-        r, cfg = self.replay, self.cfg
+    def _actor_front(self, obs):
+        """Q-network -> epsilon-greedy -> environments: reads the ring, writes nothing shared."""
+        cfg = self.cfg
         st = N.torch_stream_ptr()
         with torch.no_grad():
-            q = self.q_online(obs, channels_first=True)
+            q = self.q_actor(obs, channels_first=True)
         if cfg.enable_noisy_dense:
             self.actions.copy_(torch.argmax(q, dim=1).to(torch.int32))  # noisy nets act greedily (rainbow.py:305-309)
         else:
             N.check(self.lib.srlx_rng_uniform(cfg.seed ^ 0xAC7, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
             N.check(self.lib.srlx_policy_epsilon_greedy(cfg.n_envs, cfg.n_actions, N.tptr(q), N.tptr(self.eps), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
-        next_obs, rewards, terminated, done = self.env.step(self.actions)
-        r.commit(self.actions, rewards, terminated, done, next_obs)
+        self.env.step(self.actions)
+
+    def _actor_commit(self):
+        """ring commit + PER add of the step `_actor_front` produced (the only actor writes to the replay)."""
+        e = self.env
+        self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs)
+
+    def _actor_rest(self, obs):
+        self._actor_front(obs)
+        self._actor_commit()
 
     def actor_step(self):
         self._actor_rest(self._actor_stack())
@@ -241,6 +266,9 @@ class RainbowEngine:
         obs = self._actor_stack()
         if events is not None:
             events[1].record()
+        if self.overlap:
+            self._step_overlapped(obs, learner_updates)
+            return
         if self._actor_graph is not None:
             self._actor_graph.replay()
             self.replay._steps_committed += 1
@@ -249,6 +277,28 @@ class RainbowEngine:
         self.total_env_steps += self.cfg.n_envs
         for _ in range(learner_updates):
             self.learner_step()
+
+    def _step_overlapped(self, obs, learner_updates: int):
+        main = torch.cuda.current_stream(self.dev)
+        self._ev_fork.record(main)
+        self.s_learner.wait_event(self._ev_fork)  # the learner sees the replay as of the end of the previous step
+        with torch.cuda.stream(self.s_learner):
+            for _ in range(learner_updates):
+                self.learner_step()
+            self._ev_join.record(self.s_learner)
+        if self._front_graph is not None:
+            self._front_graph.replay()
+        else:
+            self._actor_front(obs)
+        main.wait_event(self._ev_join)
+        if self._commit_graph is not None:
+            self._commit_graph.replay()
+            self.replay._steps_committed += 1
+        else:
+            self._actor_commit()
+        with torch.no_grad():  # refresh the actor's copy (8 M floats, one multi-tensor copy)
+            torch._foreach_copy_(list(self.q_actor.parameters()), list(self.q_online.parameters()))
+        self.total_env_steps += self.cfg.n_envs
 
     # ---- HIP graphs -------------------------------------------------------------------------
     def capture_graphs(self, actor: bool = True, learner: bool = True):
@@ -266,7 +316,18 @@ class RainbowEngine:
                 self.train_count += 1
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
-        if actor:
+        if actor and self.overlap:
+            obs = self._actor_stack()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._actor_front(obs)
+            self._front_graph = g
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._actor_commit()
+            self.replay._steps_committed -= 1  # capture does not execute
+            self._commit_graph = g
+        elif actor:
             obs = self._actor_stack()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

@@ -103,8 +103,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    stack_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-    stack_bytes = eng.stack_bytes_per_launch()
+    ev_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     if rank != 0:
         if dist is not None:
@@ -140,20 +139,11 @@ def main():
             "noisy_dense": cfg.enable_noisy_dense,
             "epsilon": cfg.epsilon,
             "hip_graphs": not args.no_graph,
+            "qnet_inference": "libsrlx fp32 MFMA kernels (grad path: torch)" if eng.mfma else "torch",
             "actor_learner_overlap": (not args.no_overlap) if world == 1 else False,
             "topology": "1 GPU: actor+learner" if world == 1 else f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast",
         },
-        "roofline": {
-            "kernel": "k_stack_current (uint8 frame ring -> float32 [E,4,84,84] policy input)",
-            "bound": "hbm",
-            "achieved": stack_bytes / (stack_ms * 1e-3) / 1e9,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": stack_bytes / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": None,
-            "bytes_per_launch": stack_bytes,
-            "avg_launch_ms": stack_ms,
-        },
+        "roofline": roofline(eng, ev_ms),
         "final": {"loss": info["loss"], "train_count": info["train_count"], "memory": info["memory"]},
     }
     if args.per_micro:
@@ -163,6 +153,41 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= the fp32 vector peak)
+
+
+def roofline(eng, ev_ms):
+    """The dominant hand-written kernel group of a step, timed with events on its launch stream."""
+    if eng.mfma:
+        flops = eng.actor_forward_flops()
+        tf = flops / (ev_ms * 1e-3) / 1e12
+        return {
+            "kernel": "srlx_qnet_forward_u8 over E envs: k_gemm<AU8> (conv1 from the uint8 ring) + k_gemm<AConv> x2 + k_gemm<APlain,splitK> (FC1) + k_head",
+            "bound": "mfma",
+            "achieved": tf,
+            "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": tf / MFMA_F32_PEAK_TFLOPS,
+            "traffic": None,
+            "flops_per_launch_group": flops,
+            "avg_launch_group_ms": ev_ms,
+            "dtype": "f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32)",
+        }
+    nbytes = eng.stack_bytes_per_launch()
+    gbs = nbytes / (ev_ms * 1e-3) / 1e9
+    return {
+        "kernel": "k_stack_current_u8 (uint8 frame ring -> float32 [E,4,84,84] policy input)",
+        "bound": "hbm",
+        "achieved": gbs,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": gbs / HBM_PEAK_GBS,
+        "traffic": None,
+        "bytes_per_launch": nbytes,
+        "avg_launch_ms": ev_ms,
+    }
 
 
 def per_micro(eng, draws=1 << 20, reps=20):

@@ -222,6 +222,49 @@ int srlx_dqn_target(int64_t batch, int n_actions, const float *d_q_on_next, cons
 int srlx_gae_scan(int64_t n_envs, int64_t horizon, const float *d_rewards, const float *d_values, const uint8_t *d_done,
                   const float *d_last_values, double discount, double gae_lambda, float *d_adv, void *stream);
 
+/* Frame-offset tables: byte offsets of uint8 frames inside the ring (-1 = all-zero history), consumed by
+ * srlx_qnet_forward_u8 so that the first convolution reads the ring directly.
+ *   srlx_store_obs_base            : device pointer of the frame ring (+ bytes per frame)
+ *   srlx_store_frame_table_current : int64 [E][window] for the policy step at the current position
+ *   srlx_store_gather_items        : like srlx_store_gather_nstep, but instead of float32 pixels it emits
+ *                                    int64 [B][k_count][window] offsets of states k_begin..k_begin+k_count-1
+ *   srlx_store_gather_obs          : float32 [B][k_count][window][obs_elems] pixels of a state range of the
+ *                                    items located by the preceding gather_items call (same stream) */
+int srlx_store_obs_base(srlx_store_t *h, void **d_base, int64_t *frame_bytes);
+int srlx_store_frame_table_current(srlx_store_t *h, int64_t *d_out, void *stream);
+int srlx_store_gather_items(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int k_begin, int k_count, int64_t *d_frame_off,
+                            int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream);
+int srlx_store_gather_obs(srlx_store_t *h, int64_t batch, int k_begin, int k_count, float *d_obs, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Q-network inference on the matrix cores (exact fp32: v_mfma_f32_32x32x2_f32)
+ *
+ * Replaces the no-grad forwards of the reference's torch modules -- DQNImageBlock
+ * (srl/rl/torch_/blocks/dqn_image_block.py:10-67) + DuelingNetworkBlock
+ * (srl/rl/torch_/blocks/dueling_network.py:8-59) behind pred_q / pred_target_q
+ * (srl/algorithms/rainbow/model_torch.py:55-67) -- for the actor's policy step and the
+ * learner's online/target evaluation of s_1..s_n.
+ *   dueling_type: 0 "average", 1 "max", 2 "" (naive)
+ *   srlx_qnet_bind: 12 device pointers to float32 parameters that the kernels read IN PLACE (no copy;
+ *   they must stay valid and may be updated between calls):
+ *     conv1.weight [F][window][8][8]      conv1.bias
+ *     conv2.weight [2F][4][4][F]  (torch channels_last memory of a [2F][F][4][4] weight)   conv2.bias
+ *     conv3.weight [2F][3][3][2F] (channels_last)                                         conv3.bias
+ *     fc1.weight [2*hidden][flat]: rows 0..hidden-1 = V head, the rest = A head; columns in NHWC
+ *                flatten order (pixel-major, channel-minor)                                fc1.bias
+ *     v2.weight [1][hidden]  v2.bias   a2.weight [A][hidden]  a2.bias
+ *   srlx_qnet_forward_u8 : input = uint8 frames + offset table [batch][window]
+ *   srlx_qnet_forward_f32: input = float32 [batch][window][H][W] (channels first)
+ *   output float32 [batch][n_actions]
+ * ------------------------------------------------------------------------------------ */
+typedef struct srlx_qnet srlx_qnet_t;
+int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filters, int hidden, int n_actions, int dueling_type, int64_t max_batch,
+                     int device);
+int srlx_qnet_destroy(srlx_qnet_t *h);
+int srlx_qnet_bind(srlx_qnet_t *h, const float *const *d_params);
+int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, void *stream);
+int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

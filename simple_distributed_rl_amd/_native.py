@@ -61,6 +61,15 @@ SIGNATURES = {
     "srlx_store_commit_step": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_store_views": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p)]),
     "srlx_store_gather_nstep": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_store_obs_base": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i64)]),
+    "srlx_store_frame_table_current": (c_int, [c_p, c_p, c_p]),
+    "srlx_store_gather_items": (c_int, [c_p, c_i64, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_store_gather_obs": (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p]),
+    "srlx_qnet_create": (c_int, [ctypes.POINTER(c_p), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_int]),
+    "srlx_qnet_destroy": (c_int, [c_p]),
+    "srlx_qnet_bind": (c_int, [c_p, c_p]),
+    "srlx_qnet_forward_u8": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "srlx_qnet_forward_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p]),
     "srlx_policy_epsilon_greedy": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_synth_env_step": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_nstep_td_huber_priority": (

@@ -1,0 +1,415 @@
+// srlx_qnet.hip -- exact-fp32 inference of the DQN-image + dueling Q-network on the CDNA4 matrix cores.
+//
+// Replaces, for the no-grad forwards of the hot path (the actor's policy step over E environments and
+// the learner's online/target evaluation of s_1..s_n), the stock torch modules of
+//   srl/rl/torch_/blocks/dqn_image_block.py:10-67   (conv 8/4 -> 4/2 -> 3/1, replicate padding, ReLU)
+//   srl/rl/torch_/blocks/dueling_network.py:8-59     (V/A heads, Q = V + A - mean A)
+//   srl/algorithms/rainbow/model_torch.py:55-67      (pred_q / pred_target_q incl. their H2D/D2H hops)
+// These dense layers are the only MFMA-shaped work on the path.  Every layer is an implicit GEMM
+//   C[M, N] = A[M, K] * W[N, K]^T (+ bias, ReLU),  M = samples x output pixels,
+// computed with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain, no TF32-like
+// shortcut exists on gfx950), so results stay within f32 round-off of the reference's f32 network
+// (the summation order differs from MIOpen's; tests/test_qnet_gpu.py bounds it at 1e-5 relative).
+//
+// Weights are NOT copied: the kernels read the torch parameters in place (srlx_qnet_bind).  The engine's
+// torch module keeps conv2/conv3 weights in channels_last memory ([Cout][ky][kx][Cin] = the K order of an
+// NHWC implicit GEMM), the fused V/A first layer as one [2*hidden][flat] matrix whose columns follow the
+// NHWC flatten order, so autograd/Adam and these kernels share one copy of the parameters.
+//
+// Data movement:
+//   conv1 reads the uint8 frame ring DIRECTLY through a per-sample frame-offset table (frame stacking,
+//   zero history at episode start, u8/255 normalisation and replicate padding happen in the tile loader):
+//   the float32 stacked observation (112 896 B per sample) is never written.
+//   Activations are NHWC float32, so the K dimension of conv2/conv3 is contiguous in memory and a
+//   layer's output tile is the next layer's input without a transpose.
+//   FC1 (7744 -> 2 x hidden, V and A heads concatenated) is split along K so that even a 96-sample learner
+//   batch fills the chip; the per-split partial sums are reduced, biased and ReLU-ed by the head kernel,
+//   which also does the tiny second layers and the dueling combine.  No atomics: results are deterministic.
+//
+// Tile: 128 (M) x 64|32 (N) x 32 (K) per 256-thread workgroup, 4 waves; LDS rows padded to 36 floats so
+// the 16-float fragment reads (4 x ds_read_b128 per lane) are bank-conflict free; global->register
+// prefetch of the next K-slab overlaps the 16 MFMAs of the current one.
+#include <new>
+
+#include "srlx_common.h"
+
+namespace {
+
+using i64 = int64_t;
+using u8 = unsigned char;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BK = 32, LDT = 36;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- A-operand loaders: one float4 (4 consecutive k) of one GEMM row ---------------------------------
+struct APlain {  // row-major [M][K]
+    const float *A;
+    i64 lda;
+    struct Row {
+        const float *p;
+    };
+    __device__ __forceinline__ Row row(i64 m, i64 M) const { return Row{m < M ? A + m * lda : nullptr}; }
+    __device__ __forceinline__ float4 load4(const Row &r, int k) const {
+        return r.p ? *reinterpret_cast<const float4 *>(r.p + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
+
+struct AConv {  // NHWC float32 input [B][H][W][C]; k = (ky * KW + kx) * C + c; replicate padding
+    const float *in;
+    int H, W, C, KW, S, P, OH, OW;
+    struct Row {
+        const float *img;  // null: row beyond M
+        int iy0, ix0;
+    };
+    __device__ __forceinline__ Row row(i64 m, i64 M) const {
+        if (m >= M) return Row{nullptr, 0, 0};
+        const int per = OH * OW;
+        const i64 b = m / per;
+        const int pix = (int)(m % per);
+        const int oy = pix / OW, ox = pix % OW;
+        return Row{in + b * (i64)H * W * C, oy * S - P, ox * S - P};
+    }
+    __device__ __forceinline__ float4 load4(const Row &r, int k) const {
+        if (!r.img) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int kyx = k / C, c = k % C;
+        const int iy = clampi(r.iy0 + kyx / KW, 0, H - 1), ix = clampi(r.ix0 + kyx % KW, 0, W - 1);
+        return *reinterpret_cast<const float4 *>(r.img + ((i64)iy * W + ix) * C + c);
+    }
+};
+
+struct AU8 {  // uint8 frames addressed through frame_off[sample][Wn] (bytes from `base`, < 0: zero frame);
+              // k = c * KH*KW + ky * KW + kx (torch conv weight order); replicate padding; value = u8 / 255
+    const u8 *base;
+    const i64 *frame_off;
+    int Wn, H, W, KH, KW, S, P, OH, OW;
+    struct Row {
+        const i64 *offs;  // null: row beyond M
+        int iy0, ix0;
+    };
+    __device__ __forceinline__ Row row(i64 m, i64 M) const {
+        if (m >= M) return Row{nullptr, 0, 0};
+        const int per = OH * OW;
+        const i64 b = m / per;
+        const int pix = (int)(m % per);
+        return Row{frame_off + b * Wn, (pix / OW) * S - P, (pix % OW) * S - P};
+    }
+    __device__ __forceinline__ float4 load4(const Row &r, int k) const {
+        if (!r.offs) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int kk = KH * KW;
+        const int c = k / kk, rem = k % kk;
+        const int ky = rem / KW, kx = rem % KW;
+        const i64 off = r.offs[c];
+        if (off < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const u8 *row = base + off + (i64)clampi(r.iy0 + ky, 0, H - 1) * W;
+        const int x = r.ix0 + kx;
+        return make_float4(__fdiv_rn((float)row[clampi(x, 0, W - 1)], 255.0f), __fdiv_rn((float)row[clampi(x + 1, 0, W - 1)], 255.0f),
+                           __fdiv_rn((float)row[clampi(x + 2, 0, W - 1)], 255.0f), __fdiv_rn((float)row[clampi(x + 3, 0, W - 1)], 255.0f));
+    }
+};
+
+// ---- the GEMM ------------------------------------------------------------------------------------------
+template <class AL, int BN, bool RELU, bool SPLITK>
+__global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ Bw, const float *__restrict__ bias, float *__restrict__ C, i64 M, int N,
+                                              int K, int k_per_split) {
+    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const i64 m0 = (i64)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int kbeg = SPLITK ? blockIdx.z * k_per_split : 0;
+    const int kend = SPLITK ? (kbeg + k_per_split < K ? kbeg + k_per_split : K) : K;
+    constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM), NB = BN / 32;
+    const int wn = wave % WN, wm = wave / WN;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    const int lrow = t >> 3, c4 = (t & 7) * 4;  // this lane stages rows lrow + 32 j, columns c4..c4+3 of a tile
+    typename AL::Row rows[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) rows[j] = al.row(m0 + lrow + 32 * j, M);
+    float4 ra[4], rb[NB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) ra[j] = al.load4(rows[j], k0 + c4);
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const int n = n0 + lrow + 32 * j;
+            rb[j] = n < N ? *reinterpret_cast<const float4 *>(Bw + (i64)n * K + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    const int h = lane >> 5, i = lane & 31;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(&As[(lrow + 32 * j) * LDT + c4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; j++) *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * j) * LDT + c4]) = rb[j];
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);  // overlaps with the MFMAs below
+        // fragments: lane (i, h) holds k = 16 h + s, s = 0..15, of row/column i (A and B use the same k order)
+        float bf[16];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const float4 x = *reinterpret_cast<const float4 *>(&Bs[(wn * 32 + i) * LDT + 16 * h + 4 * v]);
+            bf[4 * v] = x.x, bf[4 * v + 1] = x.y, bf[4 * v + 2] = x.z, bf[4 * v + 3] = x.w;
+        }
+#pragma unroll
+        for (int ms = 0; ms < MT; ms++) {
+            float af[16];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const float4 x = *reinterpret_cast<const float4 *>(&As[(wm * 32 * MT + ms * 32 + i) * LDT + 16 * h + 4 * v]);
+                af[4 * v] = x.x, af[4 * v + 1] = x.y, af[4 * v + 2] = x.z, af[4 * v + 3] = x.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; s++) acc[ms] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc[ms], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float *Cz = SPLITK ? C + (i64)blockIdx.z * M * N : C;
+    const int n = n0 + wn * 32 + i;
+    const float bv = (!SPLITK && bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int ms = 0; ms < MT; ms++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const i64 m = m0 + wm * 32 * MT + ms * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M && n < N) {
+                float v = acc[ms][r] + bv;
+                if (RELU) v = v > 0.f ? v : 0.f;
+                Cz[m * N + n] = v;
+            }
+        }
+}
+
+// ---- head: reduce FC1 splits (+bias, ReLU), second layers, dueling combine; one workgroup per sample ----
+constexpr int kMaxActions = 32;
+__global__ void __launch_bounds__(256) k_head(const float *__restrict__ partial, int splits, i64 M, int hidden, const float *__restrict__ b1,
+                                              const float *__restrict__ v2w, const float *__restrict__ v2b, const float *__restrict__ a2w,
+                                              const float *__restrict__ a2b, int A, int dueling, float *__restrict__ q) {
+    __shared__ float red[4][kMaxActions + 1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const i64 m = blockIdx.x;
+    const int N1 = 2 * hidden;
+    float v = 0.f, adv[kMaxActions];
+#pragma unroll
+    for (int j = 0; j < kMaxActions; j++) adv[j] = 0.f;
+    for (int u = t; u < hidden; u += 256) {
+        float hv = b1[u], ha = b1[hidden + u];
+        for (int s = 0; s < splits; s++) {  // fixed order: deterministic
+            const float *p = partial + ((i64)s * M + m) * N1;
+            hv += p[u];
+            ha += p[hidden + u];
+        }
+        hv = hv > 0.f ? hv : 0.f;
+        ha = ha > 0.f ? ha : 0.f;
+        v += hv * v2w[u];
+#pragma unroll
+        for (int j = 0; j < kMaxActions; j++)
+            if (j < A) adv[j] += ha * a2w[j * hidden + u];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_xor(v, off);
+#pragma unroll
+        for (int j = 0; j < kMaxActions; j++)
+            if (j < A) adv[j] += __shfl_xor(adv[j], off);
+    }
+    if (lane == 0) {
+        red[wave][kMaxActions] = v;
+#pragma unroll
+        for (int j = 0; j < kMaxActions; j++)
+            if (j < A) red[wave][j] = adv[j];
+    }
+    __syncthreads();
+    if (t == 0) {
+        v = red[0][kMaxActions] + red[1][kMaxActions] + red[2][kMaxActions] + red[3][kMaxActions] + v2b[0];
+        float mean = 0.f, mx = -INFINITY;
+        float out[kMaxActions];
+#pragma unroll
+        for (int j = 0; j < kMaxActions; j++)
+            if (j < A) {
+                out[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j] + a2b[j];
+                mean += out[j];
+                mx = out[j] > mx ? out[j] : mx;
+            }
+        mean /= (float)A;
+        const float sub = dueling == 0 ? mean : (dueling == 1 ? mx : 0.f);  // "average" / "max" / "" (dueling_network.py:49-56)
+#pragma unroll
+        for (int j = 0; j < kMaxActions; j++)
+            if (j < A) q[m * A + j] = v + out[j] - sub;
+    }
+}
+
+// stacked float32 NCHW [B][Wn][H][W] -> frame table for AU8 is not possible; for float input conv1 uses
+// this NCHW loader instead (k = c*KH*KW + ky*KW + kx, like AU8)
+struct ANchw {
+    const float *in;
+    int Wn, H, W, KH, KW, S, P, OH, OW;
+    struct Row {
+        const float *img;
+        int iy0, ix0;
+    };
+    __device__ __forceinline__ Row row(i64 m, i64 M) const {
+        if (m >= M) return Row{nullptr, 0, 0};
+        const int per = OH * OW;
+        const i64 b = m / per;
+        const int pix = (int)(m % per);
+        return Row{in + b * (i64)Wn * H * W, (pix / OW) * S - P, (pix % OW) * S - P};
+    }
+    __device__ __forceinline__ float4 load4(const Row &r, int k) const {
+        if (!r.img) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int kk = KH * KW;
+        const int c = k / kk, rem = k % kk;
+        const int ky = rem / KW, kx = rem % KW;
+        const float *row = r.img + ((i64)c * H + clampi(r.iy0 + ky, 0, H - 1)) * W;
+        const int x = r.ix0 + kx;
+        return make_float4(row[clampi(x, 0, W - 1)], row[clampi(x + 1, 0, W - 1)], row[clampi(x + 2, 0, W - 1)], row[clampi(x + 3, 0, W - 1)]);
+    }
+};
+
+}  // namespace
+
+struct srlx_qnet {
+    int device;
+    int H, W, Wn, F1, hidden, A, dueling;
+    int OH1, OW1, OH2, OW2, OH3, OW3;
+    i64 max_batch;
+    int flat;  // OH3*OW3*2*F1
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *wf, *bf, *v2w, *v2b, *a2w, *a2b;  // BORROWED: the torch parameters themselves
+    float *act1, *act2, *act3, *partial;
+    int max_splits;
+};
+
+namespace {
+int conv_out(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+template <class AL, int BN, bool RELU, bool SPLITK>
+void launch_gemm(const AL &al, const float *Bw, const float *bias, float *C, i64 M, int N, int K, int splits, hipStream_t st) {
+    int kps = K;
+    if (SPLITK) {
+        kps = ((K / BK + splits - 1) / splits) * BK;
+    }
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN), SPLITK ? (unsigned)splits : 1u);
+    hipLaunchKernelGGL((k_gemm<AL, BN, RELU, SPLITK>), grid, dim3(256), 0, st, al, Bw, bias, C, M, N, K, kps);
+}
+
+int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
+    // conv2: 4x4 stride 2 pad 2 on act1 [B][OH1][OW1][F1]
+    AConv c2{h->act1, h->OH1, h->OW1, h->F1, 4, 2, 2, h->OH2, h->OW2};
+    launch_gemm<AConv, 64, true, false>(c2, h->w2, h->b2, h->act2, B * h->OH2 * h->OW2, 2 * h->F1, 16 * h->F1, 1, st);
+    // conv3: 3x3 stride 1 pad 1
+    AConv c3{h->act2, h->OH2, h->OW2, 2 * h->F1, 3, 1, 1, h->OH3, h->OW3};
+    launch_gemm<AConv, 64, true, false>(c3, h->w3, h->b3, h->act3, B * h->OH3 * h->OW3, 2 * h->F1, 9 * 2 * h->F1, 1, st);
+    // FC1 split along K so that ~512 workgroups exist whatever the batch
+    const int N1 = 2 * h->hidden;
+    const i64 tiles = ((B + BM - 1) / BM) * ((N1 + 63) / 64);
+    int splits = (int)((512 + tiles - 1) / tiles);
+    const int ksteps = h->flat / BK;
+    if (splits > ksteps) splits = ksteps;
+    if (splits > h->max_splits) splits = h->max_splits;
+    if (splits < 1) splits = 1;
+    APlain fa{h->act3, h->flat};
+    launch_gemm<APlain, 64, false, true>(fa, h->wf, nullptr, h->partial, B, N1, h->flat, splits, st);
+    const int kps = ((ksteps + splits - 1) / splits);
+    const int used = (ksteps + kps - 1) / kps;  // splits that actually own a K range
+    hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(256), 0, st, h->partial, used, B, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
+                       h->a2b, h->A, h->dueling, d_q);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filters, int hidden, int n_actions, int dueling_type, int64_t max_batch,
+                     int device) {
+    SRLX_REQUIRE(out, "qnet_create: out is NULL");
+    SRLX_REQUIRE(in_h >= 8 && in_w >= 8 && window >= 1 && filters % 32 == 0 && hidden % 32 == 0 && n_actions >= 1 && n_actions <= kMaxActions && max_batch > 0,
+                 "qnet_create: unsupported shape (filters and hidden must be multiples of 32, n_actions <= %d)", kMaxActions);
+    SRLX_REQUIRE((window * 64) % BK == 0, "qnet_create: window*64 must be a multiple of %d", BK);
+    int ndev = 0;
+    SRLX_HIP(hipGetDeviceCount(&ndev));
+    SRLX_REQUIRE(device >= 0 && device < ndev, "qnet_create: device %d not present", device);
+    srlx::DeviceGuard guard(device);
+    srlx_qnet *h = new (std::nothrow) srlx_qnet();
+    if (!h) return SRLX_ERR_NOMEM;
+    memset(h, 0, sizeof(*h));
+    h->device = device;
+    h->H = in_h, h->W = in_w, h->Wn = window, h->F1 = filters, h->hidden = hidden, h->A = n_actions, h->dueling = dueling_type;
+    h->OH1 = conv_out(in_h, 8, 4, 3), h->OW1 = conv_out(in_w, 8, 4, 3);
+    h->OH2 = conv_out(h->OH1, 4, 2, 2), h->OW2 = conv_out(h->OW1, 4, 2, 2);
+    h->OH3 = conv_out(h->OH2, 3, 1, 1), h->OW3 = conv_out(h->OW2, 3, 1, 1);
+    h->flat = h->OH3 * h->OW3 * 2 * filters;
+    h->max_batch = max_batch;
+    h->max_splits = 64;
+    SRLX_REQUIRE(h->flat % BK == 0, "qnet_create: flattened size %d must be a multiple of %d", h->flat, BK);
+    const size_t f = sizeof(float);
+    struct {
+        float **p;
+        size_t n;
+    } bufs[] = {{&h->act1, (size_t)max_batch * h->OH1 * h->OW1 * filters},
+                {&h->act2, (size_t)max_batch * h->OH2 * h->OW2 * 2 * filters},
+                {&h->act3, (size_t)max_batch * h->flat},
+                // FC1 split-K partial sums: splits(B) * B <= 4096 + B for every batch B (see run_tail)
+                {&h->partial, (size_t)(4096 + 128 + max_batch) * 2 * hidden}};
+    for (auto &b : bufs) {
+        hipError_t e = hipMalloc((void **)b.p, b.n * f);
+        if (e != hipSuccess) {
+            srlx::set_error("qnet_create: %s", hipGetErrorString(e));
+            srlx_qnet_destroy(h);
+            return e == hipErrorOutOfMemory ? SRLX_ERR_NOMEM : SRLX_ERR_HIP;
+        }
+    }
+    *out = h;
+    return SRLX_OK;
+}
+
+int srlx_qnet_destroy(srlx_qnet_t *h) {
+    if (!h) return SRLX_OK;
+    srlx::DeviceGuard guard(h->device);
+    (void)hipDeviceSynchronize();
+    float *all[] = {h->act1, h->act2, h->act3, h->partial};
+    for (float *p : all)
+        if (p) (void)hipFree(p);
+    delete h;
+    return SRLX_OK;
+}
+
+int srlx_qnet_bind(srlx_qnet_t *h, const float *const *p) {
+    SRLX_REQUIRE(h && p, "qnet_bind: NULL argument");
+    for (int i = 0; i < 12; i++) SRLX_REQUIRE(p[i], "qnet_bind: parameter %d is NULL", i);
+    h->w1 = p[0], h->b1 = p[1], h->w2 = p[2], h->b2 = p[3], h->w3 = p[4], h->b3 = p[5];
+    h->wf = p[6], h->bf = p[7], h->v2w = p[8], h->v2b = p[9], h->a2w = p[10], h->a2b = p[11];
+    return SRLX_OK;
+}
+
+int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, void *stream) {
+    SRLX_REQUIRE(h && d_frame_base && d_frame_off && d_q, "qnet_forward_u8: NULL argument");
+    SRLX_REQUIRE(h->w1, "qnet_forward_u8: no parameters bound (srlx_qnet_bind)");
+    SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_u8: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    AU8 c1{d_frame_base, d_frame_off, h->Wn, h->H, h->W, 8, 8, 4, 3, h->OH1, h->OW1};
+    launch_gemm<AU8, 32, true, false>(c1, h->w1, h->b1, h->act1, batch * h->OH1 * h->OW1, h->F1, h->Wn * 64, 1, st);
+    return run_tail(h, batch, d_q, st);
+}
+
+int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream) {
+    SRLX_REQUIRE(h && d_obs_nchw && d_q, "qnet_forward_f32: NULL argument");
+    SRLX_REQUIRE(h->w1, "qnet_forward_f32: no parameters bound (srlx_qnet_bind)");
+    SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_f32: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    ANchw c1{d_obs_nchw, h->Wn, h->H, h->W, 8, 8, 4, 3, h->OH1, h->OW1};
+    launch_gemm<ANchw, 32, true, false>(c1, h->w1, h->b1, h->act1, batch * h->OH1 * h->OW1, h->F1, h->Wn * 64, 1, st);
+    return run_tail(h, batch, d_q, st);
+}
+
+}  // extern "C"

@@ -286,6 +286,18 @@ __global__ void __launch_bounds__(256) k_gather_obs_u8(StoreDev s, const ItemMet
     emit_frame_dwords(s, m.e, m.q + kk, c, out + fc * s.F);
 }
 
+// states k_begin .. k_begin+k_count-1 only (the learner needs float32 pixels for s_0 alone: s_1..s_n go
+// through srlx_qnet_forward_u8)
+__global__ void __launch_bounds__(256) k_gather_obs_sel_u8(StoreDev s, const ItemMeta *meta, int k_begin, int k_count, float *out) {
+    const i64 fc = blockIdx.x;  // (b, k', c)
+    const int c = (int)(fc % s.W);
+    const i64 bk = fc / s.W;
+    const int k = k_begin + (int)(bk % k_count);
+    const ItemMeta m = meta[bk / k_count];
+    const int kk = k < m.jd + 1 ? k : m.jd + 1;
+    emit_frame_dwords(s, m.e, m.q + kk, c, out + fc * s.F);
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_gather_obs(StoreDev s, i64 B, const ItemMeta *meta, float *out) {
     const i64 upf = units_per_frame(s.F, s.obs_dtype, VEC);
@@ -302,6 +314,32 @@ __global__ void __launch_bounds__(256) k_gather_obs(StoreDev s, i64 B, const Ite
         const int kk = k < m.jd + 1 ? k : m.jd + 1;  // states after the terminal one repeat it (rainbow.py:358)
         emit_stack_elem<VEC>(s, m.e, m.q + kk, c, unit, out + fc * s.F);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// frame-offset tables for srlx_qnet_forward_u8: per sample and stacked channel the BYTE offset of the
+// uint8 frame inside the ring (or -1 for the all-zero history before an episode start), so that the
+// first convolution can read the ring directly and the float32 stacked observation never exists.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ i64 frame_offset(const StoreDev &s, i64 e, i64 x, int c) {
+    const int back = s.W - 1 - c;
+    if (back > s.step_in_ep[e * s.L + posmod(x, s.L)]) return -1;
+    return (e * s.L + posmod(x - back, s.L)) * s.F;
+}
+__global__ void __launch_bounds__(256) k_frame_table_current(StoreDev s, i64 *out) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= s.E * s.W) return;
+    out[t] = frame_offset(s, t / s.W, s.pos[0], (int)(t % s.W));
+}
+__global__ void __launch_bounds__(256) k_frame_table_items(StoreDev s, i64 B, const ItemMeta *meta, int k_begin, int k_count, i64 *out) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * k_count * s.W) return;
+    const int c = (int)(t % s.W);
+    const i64 bk = t / s.W;
+    const int k = k_begin + (int)(bk % k_count);
+    const ItemMeta m = meta[bk / k_count];
+    const int kk = k < m.jd + 1 ? k : m.jd + 1;
+    out[t] = frame_offset(s, m.e, m.q + kk, c);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -587,6 +625,55 @@ int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, 
     hipLaunchKernelGGL(k_synth_frames, dim3(grid_for(d.E * (fb / 16 + 1))), dim3(256), 0, st, d, d_next_obs);
     hipLaunchKernelGGL(k_synth_scalars, dim3((unsigned)((d.E + 255) / 256)), dim3(256), 0, st, d, (i64)episode_len, d_rewards,
                        d_terminated, d_done);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+
+int srlx_store_obs_base(srlx_store_t *h, void **d_base, int64_t *frame_bytes) {
+    SRLX_REQUIRE(h && d_base, "store_obs_base: NULL argument");
+    *d_base = h->d.obs;
+    if (frame_bytes) *frame_bytes = h->d.F * (h->d.obs_dtype == SRLX_OBS_U8 ? 1 : 4);
+    return SRLX_OK;
+}
+
+int srlx_store_frame_table_current(srlx_store_t *h, int64_t *d_out, void *stream) {
+    SRLX_REQUIRE(h && d_out, "store_frame_table_current: NULL argument");
+    SRLX_REQUIRE(h->d.obs_dtype == SRLX_OBS_U8, "store_frame_table_current: uint8 stores only");
+    srlx::DeviceGuard guard(h->device);
+    const i64 n = h->d.E * h->d.W;
+    hipLaunchKernelGGL(k_frame_table_current, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pick(h, stream), h->d, (i64 *)d_out);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_gather_items(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int k_begin, int k_count, int64_t *d_frame_off,
+                            int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream) {
+    SRLX_REQUIRE(h && d_tree_idx && d_frame_off && d_actions && d_rewards && d_terminated, "store_gather_items: NULL argument");
+    SRLX_REQUIRE(batch > 0 && k_begin >= 0 && k_count > 0 && k_begin + k_count <= h->d.n + 1, "store_gather_items: bad range");
+    SRLX_REQUIRE(h->d.obs_dtype == SRLX_OBS_U8, "store_gather_items: uint8 stores only");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick(h, stream);
+    SRLX_TRY(h->scratch.reserve((size_t)batch * sizeof(ItemMeta)));
+    ItemMeta *meta = (ItemMeta *)h->scratch.ptr;
+    hipLaunchKernelGGL(k_gather_meta, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, h->d, (i64)batch, d_tree_idx, meta, d_actions,
+                       d_rewards, d_terminated);
+    const i64 n = batch * k_count * h->d.W;
+    hipLaunchKernelGGL(k_frame_table_items, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d, (i64)batch, meta, k_begin, k_count,
+                       (i64 *)d_frame_off);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_gather_obs(srlx_store_t *h, int64_t batch, int k_begin, int k_count, float *d_obs, void *stream) {
+    // float32 stacked observations of states k_begin..k_begin+k_count-1 of the items located by the LAST
+    // srlx_store_gather_items / srlx_store_gather_nstep call on this handle (same stream)
+    SRLX_REQUIRE(h && d_obs && batch > 0 && k_begin >= 0 && k_count > 0 && k_begin + k_count <= h->d.n + 1, "store_gather_obs: bad argument");
+    SRLX_REQUIRE(h->d.obs_dtype == SRLX_OBS_U8 && h->d.F % 16 == 0, "store_gather_obs: uint8 stores with 16-byte frames only");
+    SRLX_REQUIRE(h->scratch.bytes >= (size_t)batch * sizeof(ItemMeta), "store_gather_obs: no gather_items call preceded");
+    srlx::DeviceGuard guard(h->device);
+    hipLaunchKernelGGL(k_gather_obs_sel_u8, dim3((unsigned)(batch * k_count * h->d.W)), dim3(256), 0, pick(h, stream), h->d,
+                       (const ItemMeta *)h->scratch.ptr, k_begin, k_count, d_obs);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

@@ -88,8 +88,10 @@ def flatten_parameters(module: torch.nn.Module) -> torch.Tensor:
     off = 0
     for p in params:
         n = p.numel()
-        flat[off : off + n].copy_(p.data.reshape(-1))
-        p.data = flat[off : off + n].view_as(p)
+        # keep each parameter's own dense memory format (channels_last conv weights stay channels_last)
+        view = flat[off : off + n].as_strided(p.size(), p.stride())
+        view.copy_(p.data)
+        p.data = view
         off += n
     return flat
 
@@ -115,6 +117,9 @@ class DistributedRainbow:
         local_cfg = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62)
         self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4)
         self.flat = flatten_parameters(self.local.q_online)
+        if self.local.mfma:  # the parameters moved: point the inference kernels at their new home
+            self.local.inf_actor.bind()
+            self.local.inf_online.bind()
         self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev)
         self.step_count = 0
         if self.is_learner:
@@ -146,18 +151,27 @@ class DistributedRainbow:
 
     def actor_and_push(self, events=None, random_policy=False):
         eng = self.local
-        if events is not None:
-            events[0].record()
-        obs = eng._actor_stack()
-        if events is not None:
-            events[1].record()
         if random_policy:
             eng._random_rest()
-        elif eng._actor_graph is not None:
-            eng._actor_graph.replay()
-            eng.replay._steps_committed += 1
         else:
-            eng._actor_rest(obs)
+            if eng.mfma:
+                q = eng._actor_net(None, events)
+                if eng._select_graph is not None:
+                    eng._select_graph.replay()
+                else:
+                    eng._actor_select(q)
+            else:
+                if events is not None:
+                    events[0].record()
+                obs = eng._actor_stack()
+                if events is not None:
+                    events[1].record()
+                eng._actor_front(obs)
+            if eng._commit_graph is not None:
+                eng._commit_graph.replay()
+                eng.replay._steps_committed += 1
+            else:
+                eng._actor_commit()
         env = eng.env
         gathered = self.bus.push(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
         if self.is_learner:
@@ -197,6 +211,13 @@ class DistributedRainbow:
 
     def stack_bytes_per_launch(self):
         return self.local.stack_bytes_per_launch()
+
+    def actor_forward_flops(self):
+        return self.local.actor_forward_flops()
+
+    @property
+    def mfma(self):
+        return self.local.mfma
 
     def info(self):
         d = self.local.info()

@@ -1,0 +1,158 @@
+"""The engine's Q-network: one set of parameters shared by autograd/Adam (torch) and the libsrlx matrix-core
+inference kernels (`srlx_qnet_*`).
+
+`EngineQNet` computes exactly what the reference's QNetwork does for the Atari shape (DQN image block +
+one dueling head: srl/rl/torch_/blocks/dqn_image_block.py:10-67, dueling_network.py:8-59,
+rainbow/model_torch.py:15-29) but stores its parameters in the layout the kernels read in place:
+conv2/conv3 weights in channels_last memory, the V and A first layers fused into one
+[2*hidden, flat] matrix whose columns follow the NHWC flatten order.  `load_reference_state_dict` /
+`reference_state_dict` convert from/to the reference's state_dict keys and layouts, so checkpoints stay
+interchangeable.
+
+`QNetInference` binds those parameters (zero copy) and runs every no-grad forward of the vectorised engine:
+the actor's policy step and the learner's online/target evaluation of s_1..s_n, reading uint8 frames
+straight from the ring.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from simple_distributed_rl_amd import _native as N
+
+_DUELING = {"average": 0, "max": 1, "": 2}
+
+
+class EngineQNet(nn.Module):
+    def __init__(self, n_actions: int, hw=(84, 84), window: int = 4, hidden: int = 512, filters: int = 32, dueling_type: str = "average"):
+        super().__init__()
+        self.hw, self.window, self.hidden, self.filters, self.n_actions, self.dueling_type = tuple(hw), window, hidden, filters, n_actions, dueling_type
+        Fi = filters
+        self.conv1 = nn.Conv2d(window, Fi, 8, 4, padding=3, padding_mode="replicate")
+        self.conv2 = nn.Conv2d(Fi, 2 * Fi, 4, 2, padding=2, padding_mode="replicate")
+        self.conv3 = nn.Conv2d(2 * Fi, 2 * Fi, 3, 1, padding=1, padding_mode="replicate")
+        with torch.no_grad():
+            y = self.conv3(self.conv2(self.conv1(torch.zeros(1, window, hw[0], hw[1]))))
+        self.out_c, self.out_p = y.shape[1], y.shape[2] * y.shape[3]
+        self.flat = self.out_c * self.out_p
+        self.fc1 = nn.Linear(self.flat, 2 * hidden)
+        self.v2 = nn.Linear(hidden, 1)
+        self.a2 = nn.Linear(hidden, n_actions)
+        # reference-equivalent initialisation: build the mirrored module and convert it
+        from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
+
+        self.fix_formats()
+        self.load_reference_state_dict(atari_qnetwork(n_actions, hw, window, hidden, False, filters).state_dict())
+
+    def fix_formats(self):
+        """conv2/conv3 weights in channels_last memory = [Cout][ky][kx][Cin], the K order of an NHWC implicit GEMM."""
+        for conv in (self.conv2, self.conv3):
+            conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+        return self
+
+    def _apply(self, fn, *a, **k):  # .to(device) / .cuda(): keep the kernel layout
+        out = super()._apply(fn, *a, **k)
+        self.fix_formats()
+        return out
+
+    def forward(self, x, channels_first: bool = True):
+        if not channels_first:
+            x = x.permute(0, 3, 1, 2)
+        x = F.relu(self.conv1(x))
+        x = F.relu(self.conv2(x))
+        x = F.relu(self.conv3(x))
+        x = x.permute(0, 2, 3, 1).flatten(1)  # NHWC flatten: pixel-major, channel-minor
+        h = F.relu(self.fc1(x))
+        v = self.v2(h[:, : self.hidden])
+        adv = self.a2(h[:, self.hidden :])
+        if self.dueling_type == "average":
+            return v + adv - adv.mean(dim=-1, keepdim=True)
+        if self.dueling_type == "max":
+            return v + adv - adv.max(dim=-1, keepdim=True)[0]
+        return v + adv
+
+    # ---- reference <-> engine layouts -----------------------------------------------------------
+    _CONV_KEYS = {"conv1": "in_block.image_block.image_layers.0", "conv2": "in_block.image_block.image_layers.2", "conv3": "in_block.image_block.image_layers.4"}
+    _HEAD = "hidden_block.hidden_layers.0"
+
+    def load_reference_state_dict(self, sd):
+        C, P, H = self.out_c, self.out_p, self.hidden
+        with torch.no_grad():
+            for mine, ref in self._CONV_KEYS.items():
+                getattr(self, mine).weight.copy_(sd[ref + ".weight"])
+                getattr(self, mine).bias.copy_(sd[ref + ".bias"])
+            v1, a1 = sd[self._HEAD + ".v_layers.0.weight"], sd[self._HEAD + ".adv_layers.0.weight"]
+            w = torch.cat([v1, a1], dim=0).to(self.fc1.weight.device)  # [2H, C*P] columns c*P+p
+            self.fc1.weight.copy_(w.view(2 * H, C, P).permute(0, 2, 1).reshape(2 * H, P * C))
+            self.fc1.bias.copy_(torch.cat([sd[self._HEAD + ".v_layers.0.bias"], sd[self._HEAD + ".adv_layers.0.bias"]]))
+            self.v2.weight.copy_(sd[self._HEAD + ".v_layers.2.weight"])
+            self.v2.bias.copy_(sd[self._HEAD + ".v_layers.2.bias"])
+            self.a2.weight.copy_(sd[self._HEAD + ".adv_layers.2.weight"])
+            self.a2.bias.copy_(sd[self._HEAD + ".adv_layers.2.bias"])
+        return self
+
+    def reference_state_dict(self):
+        C, P, H = self.out_c, self.out_p, self.hidden
+        sd = {}
+        for mine, ref in self._CONV_KEYS.items():
+            sd[ref + ".weight"] = getattr(self, mine).weight.detach().contiguous().clone()
+            sd[ref + ".bias"] = getattr(self, mine).bias.detach().clone()
+        w = self.fc1.weight.detach().view(2 * H, P, C).permute(0, 2, 1).reshape(2 * H, C * P)
+        sd[self._HEAD + ".v_layers.0.weight"], sd[self._HEAD + ".adv_layers.0.weight"] = w[:H].clone(), w[H:].clone()
+        sd[self._HEAD + ".v_layers.0.bias"], sd[self._HEAD + ".adv_layers.0.bias"] = self.fc1.bias.detach()[:H].clone(), self.fc1.bias.detach()[H:].clone()
+        sd[self._HEAD + ".v_layers.2.weight"], sd[self._HEAD + ".v_layers.2.bias"] = self.v2.weight.detach().clone(), self.v2.bias.detach().clone()
+        sd[self._HEAD + ".adv_layers.2.weight"], sd[self._HEAD + ".adv_layers.2.bias"] = self.a2.weight.detach().clone(), self.a2.bias.detach().clone()
+        return sd
+
+
+class QNetInference:
+    """Matrix-core forward over the live parameters of an EngineQNet (zero copy)."""
+
+    def __init__(self, net: EngineQNet, max_batch: int, device: int = 0):
+        self.lib = N.lib()
+        self.net = net
+        self.window, self.n_actions = net.window, net.n_actions
+        self.max_batch = int(max_batch)
+        self.dev = torch.device(f"cuda:{device}")
+        hh = N.c_p()
+        N.check(
+            self.lib.srlx_qnet_create(ctypes.byref(hh), net.hw[0], net.hw[1], net.window, net.filters, net.hidden, net.n_actions,
+                                      _DUELING[net.dueling_type], self.max_batch, int(device))
+        )
+        self.h = hh
+        self.q = torch.zeros((self.max_batch, self.n_actions), dtype=torch.float32, device=self.dev)
+        self.bind()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            try:
+                torch.cuda.synchronize(self.dev)
+            except Exception:
+                pass
+            self.lib.srlx_qnet_destroy(self.h)
+            self.h = None
+
+    def bind(self):
+        n = self.net
+        params = [n.conv1.weight, n.conv1.bias, n.conv2.weight, n.conv2.bias, n.conv3.weight, n.conv3.bias, n.fc1.weight, n.fc1.bias,
+                  n.v2.weight, n.v2.bias, n.a2.weight, n.a2.bias]
+        for conv in (n.conv2, n.conv3):
+            assert conv.weight.is_contiguous(memory_format=torch.channels_last), "EngineQNet.fix_formats() was undone"
+        for p in params:
+            assert p.is_cuda and p.dtype == torch.float32
+        arr = (N.c_p * 12)(*[p.data_ptr() for p in params])
+        N.check(self.lib.srlx_qnet_bind(self.h, ctypes.cast(arr, N.c_p)))
+        self._bound = [p.data_ptr() for p in params]
+
+    def forward_f32(self, obs_nchw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        B = obs_nchw.shape[0]
+        q = self.q[:B] if out is None else out
+        N.check(self.lib.srlx_qnet_forward_f32(self.h, B, N.tptr(obs_nchw), N.tptr(q), N.torch_stream_ptr()))
+        return q
+
+    def forward_u8(self, frame_base_ptr: int, frame_off: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        B = frame_off.numel() // self.window
+        q = self.q[:B] if out is None else out
+        N.check(self.lib.srlx_qnet_forward_u8(self.h, B, N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(q), N.torch_stream_ptr()))
+        return q

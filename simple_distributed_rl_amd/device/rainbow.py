@@ -21,6 +21,7 @@ import torch
 
 from simple_distributed_rl_amd import _native as N
 from simple_distributed_rl_amd.device.replay import DeviceReplay
+from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference
 from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
 
 
@@ -116,20 +117,36 @@ class RainbowEngine:
             cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
         )
         self.env = env if env is not None else SyntheticAtariVecEnv(self.replay, episode_len)
-        self.q_online = atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters).to(self.dev)
-        self.q_target = atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters).to(self.dev)
+        # Matrix-core inference (libsrlx) for every no-grad forward; noisy nets keep the torch path (their
+        # per-forward Gaussian weights are not a fixed GEMM operand).
+        self.mfma = not cfg.enable_noisy_dense
+        B, n = cfg.batch_size, cfg.multisteps
+
+        def make_net():
+            if self.mfma:
+                return EngineQNet(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.filters).to(self.dev)
+            return atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters).to(self.dev)
+
+        self.q_online = make_net()
+        self.q_target = make_net()
         self.q_target.eval()
         self.q_target.load_state_dict(self.q_online.state_dict())  # model_torch.py:41-42
         self.q_online.train()
         if self.overlap:
-            self.q_actor = atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters).to(self.dev)
+            self.q_actor = make_net()
             self.q_actor.load_state_dict(self.q_online.state_dict())
             self.s_learner = torch.cuda.Stream(device=self.dev)
             self._ev_fork = torch.cuda.Event()
             self._ev_join = torch.cuda.Event()
         else:
             self.q_actor = self.q_online
+        if self.mfma:
+            # one inference handle per concurrent user (each owns its activation buffers)
+            self.inf_actor = QNetInference(self.q_actor, E, device)
+            self.inf_online = QNetInference(self.q_online, B * n, device)
+            self.inf_target = QNetInference(self.q_target, B * n, device)
         self._front_graph = None
+        self._select_graph = None
         self._commit_graph = None
         self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True, fused=True)  # model_torch.py:71 (one multi-tensor kernel)
         d = self.dev
@@ -153,21 +170,40 @@ class RainbowEngine:
 
     # ---- actor (rainbow.py:301-329 + 331-400 for E envs) --------------------------------------
     def _actor_stack(self):
-        """uint8 frame ring -> float32 [E, W, H, W] policy input (the HBM-heavy hand-written kernel)."""
+        """uint8 frame ring -> float32 [E, W, H, W] policy input.  Only the torch (noisy-net) path needs it:
+        the matrix-core network reads the ring directly."""
+        if self.mfma:
+            return None
         return self.replay.stack_current().view(self.cfg.n_envs, *self._img)
 
-    def _actor_front(self, obs):
-        """Q-network -> epsilon-greedy -> environments: reads the ring, writes nothing shared."""
+    def _actor_net(self, obs, events=None):
+        """Q-values of all E environments.  Matrix-core path: frame-offset table + srlx_qnet_forward_u8 straight
+        from the uint8 ring (`events` bracket the network kernels); torch path: modules on the float32 stack."""
+        if self.mfma:
+            off = self.replay.frame_table_current()
+            if events is not None:
+                events[0].record()
+            q = self.inf_actor.forward_u8(self.replay.obs_base, off)
+            if events is not None:
+                events[1].record()
+            return q
+        with torch.no_grad():
+            return self.q_actor(obs, channels_first=True)
+
+    def _actor_select(self, q):
+        """epsilon-greedy over the Q rows, then the environments step: writes nothing shared."""
         cfg = self.cfg
         st = N.torch_stream_ptr()
-        with torch.no_grad():
-            q = self.q_actor(obs, channels_first=True)
         if cfg.enable_noisy_dense:
             self.actions.copy_(torch.argmax(q, dim=1).to(torch.int32))  # noisy nets act greedily (rainbow.py:305-309)
         else:
             N.check(self.lib.srlx_rng_uniform(cfg.seed ^ 0xAC7, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
             N.check(self.lib.srlx_policy_epsilon_greedy(cfg.n_envs, cfg.n_actions, N.tptr(q), N.tptr(self.eps), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
         self.env.step(self.actions)
+
+    def _actor_front(self, obs, events=None):
+        """Q-network -> epsilon-greedy -> environments: reads the ring, writes nothing shared."""
+        self._actor_select(self._actor_net(obs, events))
 
     def _actor_commit(self):
         """ring commit + PER add of the step `_actor_front` produced (the only actor writes to the replay)."""
@@ -209,6 +245,17 @@ class RainbowEngine:
             N.check(self.lib.srlx_per_set_range(r.h_per, 0, r.capacity, N.tptr(pri), N.PRIO_F32, 1, N.torch_stream_ptr()))
         torch.cuda.synchronize(self.dev)
 
+    def actor_forward_flops(self) -> float:
+        """Algorithmic fp32 FLOPs of one policy-step network pass over E environments (19.97 M MAC per sample for A = 6)."""
+        c = self.cfg
+        F1 = c.filters
+        h1 = (c.obs_hw[0] + 6 - 8) // 4 + 1
+        w1 = (c.obs_hw[1] + 6 - 8) // 4 + 1
+        h2, w2 = (h1 + 4 - 4) // 2 + 1, (w1 + 4 - 4) // 2 + 1
+        mac = h1 * w1 * F1 * c.window_length * 64 + h2 * w2 * 2 * F1 * F1 * 16 + h2 * w2 * 2 * F1 * 2 * F1 * 9
+        mac += h2 * w2 * 2 * F1 * 2 * c.hidden_units + c.hidden_units * (1 + c.n_actions)
+        return 2.0 * mac * c.n_envs
+
     def stack_bytes_per_launch(self) -> int:
         """Algorithmic HBM bytes of one k_stack_current launch: W uint8 frames read + W float32 frames
         written per environment."""
@@ -219,13 +266,20 @@ class RainbowEngine:
     def _learner_body(self):
         cfg, r = self.cfg, self.replay
         B, n = cfg.batch_size, cfg.multisteps
-        b = r.sample(self.train_count_dev)
-        obs = b.obs.view(B, n + 1, *self._img)
-        nxt = obs[:, 1:].reshape(B * n, *self._img)
-        with torch.no_grad():
-            q_on_next = self.q_online(nxt, channels_first=True)  # rainbow.py:220
-            q_tg_next = self.q_target(nxt, channels_first=True)  # rainbow.py:221
-        q0 = self.q_online(obs[:, 0], channels_first=True)  # model_torch.py:103
+        if self.mfma:
+            b = r.sample_items(self.train_count_dev)
+            foff = r.frame_off_next.view(B * n, cfg.window_length)
+            q_on_next = self.inf_online.forward_u8(r.obs_base, foff)  # rainbow.py:220
+            q_tg_next = self.inf_target.forward_u8(r.obs_base, foff)  # rainbow.py:221
+            q0 = self.q_online(r.obs0.view(B, *self._img))  # model_torch.py:103 (autograd)
+        else:
+            b = r.sample(self.train_count_dev)
+            obs = b.obs.view(B, n + 1, *self._img)
+            nxt = obs[:, 1:].reshape(B * n, *self._img)
+            with torch.no_grad():
+                q_on_next = self.q_online(nxt, channels_first=True)  # rainbow.py:220
+                q_tg_next = self.q_target(nxt, channels_first=True)  # rainbow.py:221
+            q0 = self.q_online(obs[:, 0], channels_first=True)  # model_torch.py:103
         N.check(
             self.lib.srlx_nstep_td_huber_priority(
                 B, n, cfg.n_actions, N.tptr(q_on_next), N.tptr(q_tg_next), N.tptr(q0), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated),
@@ -259,46 +313,49 @@ class RainbowEngine:
         self.sync_count += 1
 
     def step(self, learner_updates: int = 1, events=None):
-        """One engine step: E environment steps, then `learner_updates` Rainbow updates.  `events`
-        = (start, end) torch events recorded around the frame-stack kernel on its launch stream."""
-        if events is not None:
-            events[0].record()
-        obs = self._actor_stack()
-        if events is not None:
-            events[1].record()
-        if self.overlap:
-            self._step_overlapped(obs, learner_updates)
-            return
-        if self._actor_graph is not None:
-            self._actor_graph.replay()
-            self.replay._steps_committed += 1
-        else:
-            self._actor_rest(obs)
-        self.total_env_steps += self.cfg.n_envs
-        for _ in range(learner_updates):
-            self.learner_step()
-
-    def _step_overlapped(self, obs, learner_updates: int):
+        """One engine step: E environment steps and `learner_updates` Rainbow updates.  `events` = (start, end)
+        torch events recorded around the dominant hand-written kernel group of the actor on its launch
+        stream: the matrix-core network pass (or, on the torch path, the frame-stack kernel)."""
         main = torch.cuda.current_stream(self.dev)
-        self._ev_fork.record(main)
-        self.s_learner.wait_event(self._ev_fork)  # the learner sees the replay as of the end of the previous step
-        with torch.cuda.stream(self.s_learner):
-            for _ in range(learner_updates):
-                self.learner_step()
-            self._ev_join.record(self.s_learner)
-        if self._front_graph is not None:
-            self._front_graph.replay()
+        if self.overlap:
+            self._ev_fork.record(main)
+            self.s_learner.wait_event(self._ev_fork)  # the learner sees the replay as of the end of the previous step
+            with torch.cuda.stream(self.s_learner):
+                for _ in range(learner_updates):
+                    self.learner_step()
+                self._ev_join.record(self.s_learner)
+        # ---- actor front: network + action selection + environments (reads the ring only)
+        if self.mfma:
+            q = self._actor_net(None, events)  # 5 eager launches, bracketed by the events
+            if self._select_graph is not None:
+                self._select_graph.replay()
+            else:
+                self._actor_select(q)
         else:
-            self._actor_front(obs)
-        main.wait_event(self._ev_join)
+            if events is not None:
+                events[0].record()
+            obs = self._actor_stack()
+            if events is not None:
+                events[1].record()
+            if self._front_graph is not None:
+                self._front_graph.replay()
+            else:
+                self._actor_front(obs)
+        # ---- actor commit: the only actor writes to the replay
+        if self.overlap:
+            main.wait_event(self._ev_join)
         if self._commit_graph is not None:
             self._commit_graph.replay()
             self.replay._steps_committed += 1
         else:
             self._actor_commit()
-        with torch.no_grad():  # refresh the actor's copy (8 M floats, one multi-tensor copy)
-            torch._foreach_copy_(list(self.q_actor.parameters()), list(self.q_online.parameters()))
         self.total_env_steps += self.cfg.n_envs
+        if self.overlap:
+            with torch.no_grad():  # refresh the actor's copy of the online network (one multi-tensor copy)
+                torch._foreach_copy_(list(self.q_actor.parameters()), list(self.q_online.parameters()))
+        else:
+            for _ in range(learner_updates):
+                self.learner_step()
 
     # ---- HIP graphs -------------------------------------------------------------------------
     def capture_graphs(self, actor: bool = True, learner: bool = True):
@@ -316,24 +373,24 @@ class RainbowEngine:
                 self.train_count += 1
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
-        if actor and self.overlap:
-            obs = self._actor_stack()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._actor_front(obs)
-            self._front_graph = g
+        if actor:
+            if self.mfma:
+                q = self._actor_net(None)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._actor_select(q)
+                self._select_graph = g
+            else:
+                obs = self._actor_stack()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._actor_front(obs)
+                self._front_graph = g
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._actor_commit()
             self.replay._steps_committed -= 1  # capture does not execute
             self._commit_graph = g
-        elif actor:
-            obs = self._actor_stack()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._actor_rest(obs)
-            self.replay._steps_committed -= 1  # capture does not execute
-            self._actor_graph = g
         if learner and not self.replay.is_warmup_needed():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

@@ -85,6 +85,13 @@ class DeviceReplay:
             terminated=torch.zeros((B, n), dtype=torch.float32, device=d),
         )
         self.stacked = torch.zeros((n_envs, window, obs_elems), dtype=torch.float32, device=d)
+        # frame-offset tables for the matrix-core network (conv1 reads the uint8 ring directly)
+        self.frame_off_actor = torch.zeros((n_envs, window), dtype=torch.int64, device=d)
+        self.frame_off_next = torch.zeros((B, n, window), dtype=torch.int64, device=d)
+        self.obs0 = torch.zeros((B, 1, window, obs_elems), dtype=torch.float32, device=d)
+        base, fb = N.c_p(), N.c_i64()
+        N.check(self.lib.srlx_store_obs_base(hs, ctypes.byref(base), ctypes.byref(fb)))
+        self.obs_base = base.value
         self._steps_committed = 0
         pos, nr, sie = N.c_p(), N.c_p(), N.c_p()
         N.check(self.lib.srlx_store_views(hs, ctypes.byref(pos), ctypes.byref(nr), ctypes.byref(sie)))
@@ -151,6 +158,32 @@ class DeviceReplay:
                 self.h_store, self.B, N.tptr(b.indices), N.tptr(b.obs), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
             )
         )
+        return b
+
+    def frame_table_current(self) -> torch.Tensor:
+        """int64 [E, W] byte offsets of the frames that form every env's current stacked observation."""
+        N.check(self.lib.srlx_store_frame_table_current(self.h_store, N.tptr(self.frame_off_actor), N.torch_stream_ptr()))
+        return self.frame_off_actor
+
+    def sample_items(self, d_step: torch.Tensor, uniforms: torch.Tensor = None) -> ReplayBatch:
+        """PER sample, then: frame-offset table of s_1..s_n (`frame_off_next`, for srlx_qnet_forward_u8),
+        float32 pixels of s_0 only (`obs0`, the one state autograd needs), and the n-step scalars."""
+        st = N.torch_stream_ptr()
+        b = self.batch
+        if uniforms is None:
+            N.check(self.lib.srlx_rng_uniform(self.seed ^ 0x5EED, N.tptr(self.rng_counter), self.u.numel(), N.tptr(self.u), st))
+            uniforms = self.u
+        N.check(
+            self.lib.srlx_per_sample(
+                self.h_per, self.B, 0, N.tptr(d_step), N.tptr(uniforms), uniforms.numel(), N.tptr(b.indices), None, N.tptr(b.weights), N.tptr(self.used), 1, st
+            )
+        )
+        N.check(
+            self.lib.srlx_store_gather_items(
+                self.h_store, self.B, N.tptr(b.indices), 1, self.n, N.tptr(self.frame_off_next), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
+            )
+        )
+        N.check(self.lib.srlx_store_gather_obs(self.h_store, self.B, 0, 1, N.tptr(self.obs0), st))
         return b
 
     def update(self, indices: torch.Tensor, priorities: torch.Tensor):

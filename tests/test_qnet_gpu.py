@@ -1,0 +1,140 @@
+"""GPU parity of the matrix-core Q-network forward (srlx_qnet_*) against the torch fp32 modules that mirror
+the reference's blocks (and are themselves pinned to the reference by tests/golden/train_step_rainbow.npz).
+Tolerance: 1e-5 relative on Q-values (north_star) -- exact-fp32 MFMA, only the summation order differs."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _mk(hw, window, hidden, A, filters=32, seed=0):
+    from simple_distributed_rl_amd.device.qnet import EngineQNet
+
+    torch.manual_seed(seed)
+    return EngineQNet(A, hw, window, hidden, filters).cuda()
+
+
+def test_engine_qnet_equals_reference_layout_network():
+    """EngineQNet (kernel-friendly parameter layout) == the reference-layout module, and converts back losslessly."""
+    from simple_distributed_rl_amd.device.qnet import EngineQNet
+    from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
+
+    torch.manual_seed(0)
+    ref = atari_qnetwork(6).cuda()
+    e = EngineQNet(6).cuda().load_reference_state_dict(ref.state_dict())
+    assert e.conv2.weight.is_contiguous(memory_format=torch.channels_last) and e.conv3.weight.is_contiguous(memory_format=torch.channels_last)
+    x = torch.rand(5, 4, 84, 84, device="cuda")
+    with torch.no_grad():
+        _close(e(x), ref(x, channels_first=True))
+    sd = e.reference_state_dict()
+    assert all(torch.equal(sd[k], v) for k, v in ref.state_dict().items())
+
+
+def _close(got, want):
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("hw,window,hidden,A,B", [((84, 84), 4, 512, 6, 37), ((84, 84), 4, 512, 18, 1024), ((32, 40), 2, 64, 3, 5), ((84, 84), 4, 512, 6, 96), ((84, 84), 4, 512, 6, 1)])
+def test_forward_f32_matches_torch(hw, window, hidden, A, B):
+    from simple_distributed_rl_amd.device.qnet import QNetInference
+
+    net = _mk(hw, window, hidden, A)
+    qn = QNetInference(net, max_batch=max(B, 8))
+    x = torch.rand(B, window, hw[0], hw[1], device="cuda")
+    with torch.no_grad():
+        want = net(x, channels_first=True)
+    got = qn.forward_f32(x)
+    torch.cuda.synchronize()
+    _close(got, want)
+    # the kernels read the live parameters: an in-place update is seen without any reload
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.01)
+        want2 = net(x, channels_first=True)
+    _close(qn.forward_f32(x), want2)
+
+
+def test_forward_golden_network():
+    """Reference-recorded network (state_dict + inputs + outputs of the reference's QNetwork on CPU)."""
+    from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference
+
+    z = np.load(os.path.join(GOLDEN, "train_step_rainbow.npz"))
+    net = EngineQNet(4, (8, 8), 4, 32).cuda()
+    net.load_reference_state_dict({k[7:]: torch.tensor(z[k]) for k in z.files if k.startswith("before.")})
+    qn = QNetInference(net, max_batch=16)
+    obs = torch.tensor(z["obs"][:, 0]).permute(0, 3, 1, 2).contiguous().cuda()  # (B, h, w, 4) -> NCHW
+    got = qn.forward_f32(obs)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy(), z["q_all"], rtol=1e-5, atol=2e-6)
+
+
+def test_forward_u8_reads_the_ring_directly():
+    """conv1 through the frame-offset table == torch on the float32 stack the store would have produced
+    (zero history at episode starts, ring wrap-around, gathered n-step items with terminal padding)."""
+    import hot_path_oracle as H
+    from simple_distributed_rl_amd import _native as N
+    from simple_distributed_rl_amd.device.qnet import QNetInference
+    from simple_distributed_rl_amd.device.replay import DeviceReplay
+
+    E, W, n, A = 6, 4, 3, 5
+    net = _mk((84, 84), W, 64, A, seed=1)
+    qn = QNetInference(net, max_batch=64)
+    r = DeviceReplay(E, 24, 84 * 84, W, n, A, batch_size=8, warmup_size=1, seed=3)
+    o = H.StoreOracle(E, 24, 84 * 84, W, n, A, False, 3)
+    rng = np.random.default_rng(0)
+    f0 = rng.integers(0, 256, (E, 84 * 84), dtype=np.uint8)
+    r.reset_all(torch.tensor(f0).cuda())
+    o.reset_all(f0)
+    lib = r.lib
+    base, fb = N.c_p(), N.c_i64()
+    N.check(lib.srlx_store_obs_base(r.h_store, ctypes.byref(base), ctypes.byref(fb)))
+    assert fb.value == 84 * 84
+    off = torch.zeros((E, W), dtype=torch.int64, device="cuda")
+    for step in range(40):
+        N.check(lib.srlx_store_frame_table_current(r.h_store, N.tptr(off), None))
+        got = qn.forward_u8(base.value, off)
+        stack = torch.tensor(o.stack_current()).cuda().view(E, W, 84, 84)
+        with torch.no_grad():
+            want = net(stack, channels_first=True)
+        torch.cuda.synchronize()
+        _close(got, want)
+        a = rng.integers(0, A, E).astype(np.int32)
+        rew = rng.standard_normal(E).astype(np.float32)
+        done = (rng.random(E) < 0.15).astype(np.uint8)
+        nxt = rng.integers(0, 256, (E, 84 * 84), dtype=np.uint8)
+        r.commit(torch.tensor(a).cuda(), torch.tensor(rew).cuda(), torch.tensor(done).cuda(), torch.tensor(done).cuda(), torch.tensor(nxt).cuda())
+        o.commit_step(a, rew, done, done, nxt)
+    torch.cuda.synchronize()
+    # gathered items: states 1..n through the table, state 0 as float32 pixels
+    Nn = E * o.item_len
+    taus = [(o.pos - 1 - k) % o.item_len for k in range(6)]
+    idx = [t * E + e + Nn - 1 for t in taus for e in range(E)]
+    idx = [i for i in idx if not (o.flags[o.locate(i)[0], o.locate(i)[1] % o.L] & o.INVALID)][:16]
+    B = len(idx)
+    t_idx = torch.tensor(idx, dtype=torch.int64).cuda()
+    foff = torch.zeros((B, n, W), dtype=torch.int64, device="cuda")
+    act = torch.zeros((B, n), dtype=torch.int32, device="cuda")
+    rew_t = torch.zeros((B, n), dtype=torch.float32, device="cuda")
+    ter = torch.zeros((B, n), dtype=torch.float32, device="cuda")
+    N.check(lib.srlx_store_gather_items(r.h_store, B, N.tptr(t_idx), 1, n, N.tptr(foff), N.tptr(act), N.tptr(rew_t), N.tptr(ter), None))
+    obs0 = torch.zeros((B, 1, W, 84 * 84), dtype=torch.float32, device="cuda")
+    N.check(lib.srlx_store_gather_obs(r.h_store, B, 0, 1, N.tptr(obs0), None))
+    got = qn.forward_u8(base.value, foff.view(B * n, W)).clone()
+    oo, oa, orw, ot = o.gather_nstep(idx)
+    with torch.no_grad():
+        want = net(torch.tensor(oo[:, 1:]).cuda().reshape(B * n, W, 84, 84), channels_first=True)
+    torch.cuda.synchronize()
+    _close(got, want)
+    np.testing.assert_array_equal(obs0.cpu().numpy()[:, 0], oo[:, 0])
+    np.testing.assert_array_equal(act.cpu().numpy(), oa)
+    np.testing.assert_array_equal(rew_t.cpu().numpy(), orw)
+    np.testing.assert_array_equal(ter.cpu().numpy(), ot)

@@ -135,7 +135,8 @@ class RainbowEngine:
         if self.overlap:
             self.q_actor = make_net()
             self.q_actor.load_state_dict(self.q_online.state_dict())
-            self.s_learner = torch.cuda.Stream(device=self.dev)
+            # high priority: the learner's many small kernels slot in between the actor's chip-filling GEMMs
+            self.s_learner = torch.cuda.Stream(device=self.dev, priority=-1)
             self._ev_fork = torch.cuda.Event()
             self._ev_join = torch.cuda.Event()
         else:

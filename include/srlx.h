@@ -209,10 +209,14 @@ int srlx_nstep_td_huber_priority(int64_t batch, int n_step, int n_actions, const
  * invalid next actions are masked with min(q) of the WHOLE batch, not -inf (dqn.py:160,164).
  *   q_on_next/q_tg_next f32 [B][A]; rewards f32 [B]; undone f32 [B]; out target f32 [B]
  *   f64_accum=1: dqn.py:171 (int `undone` array promotes the expression to float64, cast at :176);
- *   f64_accum=0: rainbow_nomultisteps.py:38 (all float32). */
+ *   f64_accum=0: rainbow_nomultisteps.py:38 (all float32).
+ *   d_discount_per_sample (f32 [B], NULL = use `discount`): Agent57_light's per-actor gamma,
+ *   srl/algorithms/agent57_light/agent57_light.py:218-268 (`undone` is its `dones` = int(not terminated));
+ *   float32 arithmetic, requires f64_accum=0. */
 int srlx_dqn_target(int64_t batch, int n_actions, const float *d_q_on_next, const float *d_q_tg_next,
                     const float *d_rewards, const float *d_undone, const uint8_t *d_invalid_next, double discount,
-                    int enable_double_dqn, int enable_rescale, int f64_accum, float *d_target, void *stream);
+                    const float *d_discount_per_sample, int enable_double_dqn, int enable_rescale, int f64_accum,
+                    float *d_target, void *stream);
 
 /* GAE reverse scan per environment (srl/algorithms/ppo/ppo.py:389-404): for each env, episodes are
  * delimited by done[t]; the last step of an episode uses delta = r - V (no bootstrap, :396-397).
@@ -221,6 +225,40 @@ int srlx_dqn_target(int64_t batch, int n_actions, const float *d_q_on_next, cons
  *   which is what the reference does for every episode end, truncation included). */
 int srlx_gae_scan(int64_t n_envs, int64_t horizon, const float *d_rewards, const float *d_values, const uint8_t *d_done,
                   const float *d_last_values, double discount, double gae_lambda, float *d_adv, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Never-Give-Up intrinsic reward + Agent57_light priorities
+ *
+ * srlx_ngu_t: one bounded episodic memory per environment, [E][emb_dim][capacity] float32 in HBM
+ * (replaces `collections.deque(maxlen=episodic_memory_capacity)` of numpy vectors,
+ * srl/algorithms/agent57_light/agent57_light.py:310-311).
+ *   srlx_ngu_episodic_reward : agent57_light.py:473-513 for every environment at once: distances of the
+ *       new embedding to every stored one, the k nearest, pseudo-count reward, then append (the oldest
+ *       entry is dropped when full).  d_emb f32 [E][emb_dim]; d_reset u8 [E] (NULL = none) empties an
+ *       environment's memory BEFORE the query (`on_reset`, :310-311); d_active u8 [E] (NULL = all) skips
+ *       environments entirely; d_reward f32 [E].  1 <= k <= 16.
+ *   srlx_ngu_reset           : empty every memory.
+ *   srlx_ngu_counts          : device pointer of the int64 [E] append counters (live = min(count, capacity)).
+ *   srlx_ngu_lifelong_reward : agent57_light.py:515-529, min(max(1 + mean((t-p)^2), 1), L) per row of
+ *       d_target/d_train f32 [n][dim].
+ *   srlx_agent57_priority    : srl/algorithms/agent57_light/model_torch.py:442,367-373:
+ *       td = target - q[action]; priorities = |td_ext + beta[actor] * td_int| (d_target_int NULL: |td_ext|).
+ *       d_td_ext / d_td_int (nullable) receive the signed TD errors.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct srlx_ngu srlx_ngu_t;
+int srlx_ngu_create(srlx_ngu_t **out, int64_t n_envs, int emb_dim, int64_t capacity, int k, double epsilon,
+                    double cluster_distance, double pseudo_counts, int device);
+int srlx_ngu_destroy(srlx_ngu_t *h);
+int srlx_ngu_reset(srlx_ngu_t *h, void *stream);
+int srlx_ngu_counts(srlx_ngu_t *h, int64_t **d_counts);
+int srlx_ngu_episodic_reward(srlx_ngu_t *h, const float *d_emb, const uint8_t *d_reset, const uint8_t *d_active,
+                             float *d_reward, void *stream);
+int srlx_ngu_lifelong_reward(int64_t n, int dim, const float *d_target, const float *d_train, double lifelong_max,
+                             float *d_reward, void *stream);
+int srlx_agent57_priority(int64_t batch, int n_actions, const float *d_target_ext, const float *d_q_ext,
+                          const float *d_target_int, const float *d_q_int, const int32_t *d_actions,
+                          const int32_t *d_actor_idx, const float *d_beta_list, float *d_td_ext, float *d_td_int,
+                          float *d_priorities, void *stream);
 
 /* Frame-offset tables: byte offsets of uint8 frames inside the ring (-1 = all-zero history), consumed by
  * srlx_qnet_forward_u8 so that the first convolution reads the ring directly.

@@ -299,6 +299,9 @@ def main():
         GENERATORS.update(ALGO_GENERATORS)
     except ImportError:
         pass
+    from gen_golden_agent57 import AGENT57_GENERATORS  # noqa: E402
+
+    GENERATORS.update(AGENT57_GENERATORS)
     only = [s for s in args.only.split(",") if s]
     for name, fn in GENERATORS.items():
         if only and name not in only:

@@ -9,6 +9,9 @@ recorded from the imported reference by oracle/gen_golden_algo.py (tests/golden/
 train_step_*.npz, dqn_target_*.npz, functions.npz, rollout_items_*.npz).  `gae` follows
 srl/algorithms/ppo/ppo.py:389-404, whose module needs TensorFlow and cannot be imported here:
 parity UNPINNED for that one function (restated from source only).
+The NGU / Agent57_light functions at the end (episodic and lifelong novelty, per-actor-discount target,
+mixed priority) are PINNED by tests/golden/ngu_*.npz, agent57_light_target_*.npz and
+train_step_agent57_light.npz (oracle/gen_golden_agent57.py).
 """
 import numpy as np
 
@@ -338,3 +341,63 @@ def synth_env_step(store: StoreOracle, episode_len):
         term[e] = d
         done[e] = d
     return next_obs, rewards, term, done
+
+
+# ------------------------------------------------------------------------------------------
+# NGU episodic novelty, srl/algorithms/agent57_light/agent57_light.py:473-513.  One memory per
+# environment; a bounded deque (oldest entry dropped).  All arithmetic is numpy float32 like the
+# reference (np.linalg.norm of a float32 vector = sqrt(x.dot(x)); np.sort/np.mean of float32).
+# ------------------------------------------------------------------------------------------
+def ngu_episodic_from_distances(dist, k, epsilon, cluster_distance, pseudo_counts):
+    """agent57_light.py:493-513 given the float32 distances to every stored embedding.  np.mean / np.sum of
+    a short float32 vector add in numpy's pairwise order (8 partial sums for n >= 8, then the tail; a plain
+    loop for n < 8) -- the device kernel follows the same order."""
+    near = np.sort(np.asarray(dist, np.float32))[:k]
+    ave = np.mean(near)  # :497
+    dn = near if ave == 0.0 else near / ave  # :498-502
+    dn = np.maximum(dn - cluster_distance, 0)  # :505 (python floats are weak under NEP 50: stays float32)
+    dn = epsilon / (dn + epsilon)  # :508
+    n_visits = np.sum(dn)
+    return np.float32(1 / (np.sqrt(n_visits) + pseudo_counts))  # :512
+
+
+class EpisodicMemoryOracle:
+    def __init__(self, capacity, k=10, epsilon=0.001, cluster_distance=0.008, pseudo_counts=0.1):
+        self.capacity, self.k, self.epsilon, self.cluster_distance, self.c = capacity, k, epsilon, cluster_distance, pseudo_counts
+        self.entries = []
+
+    def reset(self):
+        self.entries = []
+
+    def step(self, emb, exact_dot=True):
+        emb = np.asarray(emb, np.float32)
+        if not self.entries:  # :483-485
+            self.entries.append(emb.copy())
+            return np.float32(1 / self.c)
+        if exact_dot:  # per entry x.dot(x) like np.linalg.norm(m - cont_state, ord=2), :488
+            dist = np.array([np.sqrt((m - emb).dot(m - emb)) for m in self.entries], np.float32)
+        else:
+            diff = np.stack(self.entries) - emb
+            dist = np.sqrt(np.einsum("ij,ij->i", diff, diff)).astype(np.float32)
+        self.entries.append(emb.copy())  # :491
+        if len(self.entries) > self.capacity:
+            self.entries.pop(0)
+        return ngu_episodic_from_distances(dist, self.k, self.epsilon, self.cluster_distance, self.c)
+
+
+def ngu_lifelong_reward(target, train, lifelong_max):
+    """agent57_light.py:515-529 for a batch: 1 + mean squared RND error, clipped to [1, L]."""
+    target, train = np.asarray(target, np.float32), np.asarray(train, np.float32)
+    err = np.array([np.square(t - p).mean() for t, p in zip(target, train)], np.float32)
+    return np.minimum(np.maximum(np.float32(1) + err, np.float32(1)), np.float32(lifelong_max)).astype(np.float32)
+
+
+def agent57_target(q_online_next, q_target_next, rewards, dones, batch_discount, invalid, double_dqn, rescale):
+    """agent57_light.py:218-268: 1-step (double-)DQN target with a per-sample discount (the actor's gamma);
+    `dones` is the reference's continue flag int(not terminated) as float32; everything stays float32."""
+    return dqn_target(q_online_next, q_target_next, rewards, dones, invalid, np.asarray(batch_discount, np.float32), double_dqn, rescale, False)
+
+
+def agent57_priority(td_ext, td_int, batch_beta):
+    """agent57_light/model_torch.py:367-373: priorities = |td_ext + beta_actor * td_int| (float32)."""
+    return np.abs(np.asarray(td_ext, np.float32) + np.asarray(batch_beta, np.float32) * np.asarray(td_int, np.float32)).astype(np.float32)

@@ -76,8 +76,15 @@ SIGNATURES = {
         c_int,
         [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_int, c_int, c_p, c_p, c_p, c_p, c_p],
     ),
-    "srlx_dqn_target": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_int, c_int, c_int, c_p, c_p]),
+    "srlx_dqn_target": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_p, c_int, c_int, c_int, c_p, c_p]),
     "srlx_gae_scan": (c_int, [c_i64, c_i64, c_p, c_p, c_p, c_p, c_f64, c_f64, c_p, c_p]),
+    "srlx_ngu_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_int, c_i64, c_int, c_f64, c_f64, c_f64, c_int]),
+    "srlx_ngu_destroy": (c_int, [c_p]),
+    "srlx_ngu_reset": (c_int, [c_p, c_p]),
+    "srlx_ngu_counts": (c_int, [c_p, ctypes.POINTER(c_p)]),
+    "srlx_ngu_episodic_reward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_ngu_lifelong_reward": (c_int, [c_i64, c_int, c_p, c_p, c_f64, c_p, c_p]),
+    "srlx_agent57_priority": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
 }
 OBS_U8, OBS_F32 = 0, 1
 PRIO_NONE_MASKED = 4

@@ -60,13 +60,64 @@ class TdOps:
         ones = torch.ones((B, 1), dtype=torch.float32, device=self.dev)
         return self.nstep(z, z, q_all, actions.view(B, 1), target.view(B, 1), ones, None, weights, 0.0, 1.0, True, False)
 
-    def dqn_target(self, q_on_next, q_tg_next, rewards, undone, invalid, discount, double_dqn, rescale, f64_accum):
+    def dqn_target(self, q_on_next, q_tg_next, rewards, undone, invalid, discount, double_dqn, rescale, f64_accum, discount_per_sample=None):
         B, A = q_tg_next.shape
         out = torch.empty(B, dtype=torch.float32, device=self.dev)
-        keep = [t.contiguous() if t is not None else None for t in (q_on_next, q_tg_next, rewards, undone, invalid)]
+        keep = [t.contiguous() if t is not None else None for t in (q_on_next, q_tg_next, rewards, undone, invalid, discount_per_sample)]
         N.check(
             self.lib.srlx_dqn_target(B, A, N.tptr(keep[0]), N.tptr(keep[1]), N.tptr(keep[2]), N.tptr(keep[3]), N.tptr(keep[4]), float(discount),
-                                     int(double_dqn), int(rescale), int(f64_accum), N.tptr(out), N.torch_stream_ptr())
+                                     N.tptr(keep[5]), int(double_dqn), int(rescale), int(f64_accum), N.tptr(out), N.torch_stream_ptr())
         )
         self._keep2 = keep
+        return out
+
+    def agent57_priority(self, target_ext, q_ext, target_int, q_int, actions, actor_idx, beta_list):
+        """|td_ext + beta[actor] * td_int| with td = target - q[action] (agent57_light/model_torch.py:442,367-373);
+        returns (td_ext, td_int or None, priorities)."""
+        B, A = q_ext.shape
+        d = self.dev
+        pri = torch.empty(B, dtype=torch.float32, device=d)
+        td_e = torch.empty(B, dtype=torch.float32, device=d)
+        td_i = torch.empty(B, dtype=torch.float32, device=d) if target_int is not None else None
+        keep = [t.detach().contiguous() if t is not None else None for t in (target_ext, q_ext, target_int, q_int, actions, actor_idx, beta_list)]
+        N.check(
+            self.lib.srlx_agent57_priority(B, A, *[N.tptr(t) for t in keep], N.tptr(td_e), N.tptr(td_i), N.tptr(pri), N.torch_stream_ptr())
+        )
+        self._keep3 = keep
+        return td_e, td_i, pri
+
+
+class NguOps:
+    """Device-resident episodic memories + novelty rewards (csrc/srlx_ngu.hip)."""
+
+    def __init__(self, device: torch.device, n_envs: int, emb_dim: int, capacity: int, k: int, epsilon: float, cluster_distance: float, pseudo_counts: float):
+        import ctypes
+
+        self.dev, self.lib, self.n_envs, self.emb_dim = device, N.lib(), n_envs, emb_dim
+        h = ctypes.c_void_p()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        N.check(self.lib.srlx_ngu_create(ctypes.byref(h), n_envs, emb_dim, capacity, k, float(epsilon), float(cluster_distance), float(pseudo_counts), idx))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.srlx_ngu_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        N.check(self.lib.srlx_ngu_reset(self.h, N.torch_stream_ptr()))
+
+    def episodic(self, emb: torch.Tensor, reset: torch.Tensor = None, active: torch.Tensor = None) -> torch.Tensor:
+        emb = emb.detach().to(torch.float32).contiguous().view(self.n_envs, self.emb_dim)
+        out = torch.empty(self.n_envs, dtype=torch.float32, device=self.dev)
+        self._keep = (emb, reset, active)
+        N.check(self.lib.srlx_ngu_episodic_reward(self.h, N.tptr(emb), N.tptr(reset), N.tptr(active), N.tptr(out), N.torch_stream_ptr()))
+        return out
+
+    def lifelong(self, target: torch.Tensor, train: torch.Tensor, lifelong_max: float) -> torch.Tensor:
+        target, train = target.detach().contiguous(), train.detach().contiguous()
+        n, dim = target.shape
+        out = torch.empty(n, dtype=torch.float32, device=self.dev)
+        self._keep_l = (target, train)
+        N.check(self.lib.srlx_ngu_lifelong_reward(n, dim, N.tptr(target), N.tptr(train), float(lifelong_max), N.tptr(out), N.torch_stream_ptr()))
         return out

@@ -126,6 +126,7 @@ struct DqnArgs {
     const float *q_on_next, *q_tg_next, *rewards, *undone;
     const u8 *invalid_next;
     double discount;
+    const float *discount_per_sample;
     int double_dqn, rescale, f64_accum;
     float *target;
 };
@@ -165,7 +166,9 @@ __global__ void __launch_bounds__(256) k_dqn_target(DqnArgs a) {
             tq = (float)v;
             if (a.rescale) tq = (float)((v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0)) * (sqrt(fabs(v) + 1.0) - 1.0) + 0.001 * v);
         } else {  // rainbow_nomultisteps.py:38 all float32
-            tq = a.rewards[b] + (a.undone[b] * (float)a.discount) * maxq;
+            // agent57_light.py:263: the same expression with the sampled actor's gamma (float32 [B])
+            const float g = a.discount_per_sample ? a.discount_per_sample[b] : (float)a.discount;
+            tq = a.rewards[b] + (a.undone[b] * g) * maxq;
             if (a.rescale) tq = rescaling(tq);
         }
         a.target[b] = tq;
@@ -220,10 +223,12 @@ int srlx_nstep_td_huber_priority(int64_t batch, int n_step, int n_actions, const
 
 int srlx_dqn_target(int64_t batch, int n_actions, const float *d_q_on_next, const float *d_q_tg_next,
                     const float *d_rewards, const float *d_undone, const uint8_t *d_invalid_next, double discount,
-                    int enable_double_dqn, int enable_rescale, int f64_accum, float *d_target, void *stream) {
+                    const float *d_discount_per_sample, int enable_double_dqn, int enable_rescale, int f64_accum, float *d_target,
+                    void *stream) {
     SRLX_REQUIRE(batch > 0 && n_actions >= 1, "dqn_target: bad sizes");
+    SRLX_REQUIRE(!(d_discount_per_sample && f64_accum), "dqn_target: a per-sample discount is float32 arithmetic (f64_accum must be 0)");
     SRLX_REQUIRE(d_q_tg_next && d_rewards && d_undone && d_target && (d_q_on_next || !enable_double_dqn), "dqn_target: NULL argument");
-    DqnArgs a{batch, n_actions, d_q_on_next, d_q_tg_next, d_rewards, d_undone, d_invalid_next, discount,
+    DqnArgs a{batch, n_actions, d_q_on_next, d_q_tg_next, d_rewards, d_undone, d_invalid_next, discount, d_discount_per_sample,
               enable_double_dqn, enable_rescale, f64_accum, d_target};
     hipLaunchKernelGGL(k_dqn_target, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     SRLX_HIP(hipGetLastError());

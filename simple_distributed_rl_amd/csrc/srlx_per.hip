@@ -185,6 +185,11 @@ __device__ __forceinline__ int block_exscan(int v, int *buf, int *total) {
     return incl - v;
 }
 
+struct Cand {  // bulk paths: leaf reached by a draw and its priority, one 16-byte store
+    i64 idx;
+    double p;
+};
+
 struct SampleArgs {
     Tree tr;
     const PerState *state;
@@ -198,6 +203,7 @@ struct SampleArgs {
     // scratch
     i64 *cand_idx;
     double *cand_p;
+    Cand *cand;
     i64 *map;
     double *wtmp;
     // outputs
@@ -299,7 +305,7 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
 // L2-miss traffic of the bottom three levels (~190 B per draw out of the Infinity Cache), not by HBM.
 // ------------------------------------------------------------------------------------------
 constexpr int kIlp = 2;
-constexpr int kBulkLdsBlocks = 320;  // 40 KiB: 3-4 workgroups per CU
+constexpr int kBulkLdsBlocks = 296;  // 37 KiB (+2 KiB reduction buffer): 4 workgroups per CU
 
 struct Blk {
     double2 v[7];
@@ -336,7 +342,25 @@ __device__ __forceinline__ bool walk_block(const Blk &b, int levels, i64 len, i6
     return true;
 }
 
-__global__ void __launch_bounds__(256) k_descend_bulk(SampleArgs a, int lds_blocks, u64 *zero_count, u64 *wmax_bits) {
+// walk up to `levels` levels inside the 16-double block at `blk`, one dependent pair read per level
+__device__ __forceinline__ bool walk_block_pairs(const double *blk, int levels, i64 len, i64 &idx, double &val, double &p) {
+    int pos = 0;
+#pragma unroll
+    for (int r = 1; r <= 3; r++) {
+        if (r > levels) break;
+        const i64 left = 2 * idx + 1;
+        if (left >= len) return false;
+        const double2 v = *reinterpret_cast<const double2 *>(blk + (r == 1 ? 0 : (r == 2 ? 2 : 6)) + 2 * pos);
+        const bool go = val <= v.x;  // :61
+        val = go ? val : val - v.x;
+        idx = left + (go ? 0 : 1);
+        p = go ? v.x : v.y;
+        pos = 2 * pos + (go ? 0 : 1);
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256, 4) k_descend_bulk(SampleArgs a, int lds_blocks, u64 *zero_count, u64 *wmax_bits) {
     __shared__ __attribute__((aligned(16))) double top[kBulkLdsBlocks * 16];
     __shared__ double red[256];
     const Tree tr = a.tr;
@@ -365,34 +389,40 @@ __global__ void __launch_bounds__(256) k_descend_bulk(SampleArgs a, int lds_bloc
         int level = 0;  // level of the current owner nodes (same for every live draw)
         for (int g = 0; g <= tr.G; g++) {
             const int levels = g == 0 ? tr.h0 : 3;
-            Blk blk[kIlp];
+            if (tr.base[g + 1] <= lds_blocks || g == 0) {
+                // group staged in LDS: one dependent 16-byte pair read per level (fewer, conflict-poorer reads than the whole block)
 #pragma unroll
-            for (int d = 0; d < kIlp; d++) {
-                if (!live[d]) continue;
-                const i64 bi = tr.block_of_owner(idx[d], level);
-                const double2 *src = bi < lds_blocks ? reinterpret_cast<const double2 *>(top + bi * 16)
-                                                     : reinterpret_cast<const double2 *>(tr.T + bi * 16);
+                for (int d = 0; d < kIlp; d++)
+                    if (live[d])
+                        live[d] = walk_block_pairs(top + tr.block_of_owner(idx[d], level) * 16, levels, len, idx[d], val[d], p[d]) && (2 * idx[d] + 1 < len);
+            } else {
+                // group in memory: ONE line per draw, its 7 x 16-byte loads issued together, decisions are register selects
+                Blk blk[kIlp];
 #pragma unroll
-                for (int k = 0; k < 7; k++) blk[d].v[k] = src[k];
+                for (int d = 0; d < kIlp; d++) {
+                    if (!live[d]) continue;
+                    const double2 *src = reinterpret_cast<const double2 *>(tr.T + tr.block_of_owner(idx[d], level) * 16);
+#pragma unroll
+                    for (int k = 0; k < 7; k++) blk[d].v[k] = src[k];
+                }
+#pragma unroll
+                for (int d = 0; d < kIlp; d++)
+                    if (live[d]) live[d] = walk_block(blk[d], levels, len, idx[d], val[d], p[d]) && (2 * idx[d] + 1 < len);
             }
-#pragma unroll
-            for (int d = 0; d < kIlp; d++)
-                if (live[d]) live[d] = walk_block(blk[d], levels, len, idx[d], val[d], p[d]) && (2 * idx[d] + 1 < len);
             level += levels;
         }
 #pragma unroll
         for (int d = 0; d < kIlp; d++) {
             const i64 j = base + d * stride;
             if (j >= M) continue;
-            a.cand_idx[j] = idx[d];
-            a.cand_p[j] = p[d];
+            Cand c;
+            c.idx = idx[d];
+            c.p = p[d];
+            a.cand[j] = c;
             if (p[d] == 0.0) {
                 zeros++;
             } else if (j < B) {  // fast path: with no rejection output i is draw i
-                const double w = is_weight(size, p[d], total, beta);
-                a.wtmp[j] = w;
-                a.out_idx[j] = idx[d];
-                wmax = fmax(wmax, w);
+                wmax = fmax(wmax, is_weight(size, p[d], total, beta));
             }
         }
     }
@@ -401,11 +431,227 @@ __global__ void __launch_bounds__(256) k_descend_bulk(SampleArgs a, int lds_bloc
     if (threadIdx.x == 0 && m > 0.0) atomicMax(wmax_bits, (u64)__double_as_longlong(m));  // positive doubles order like their bits
 }
 
+// ------------------------------------------------------------------------------------------
+// Binned bulk descent (alternative, SRLX_PER_BULK=binned).  The flat walk above spends its time issuing divergent
+// loads (PMC: 54 % of wave cycles waiting on memory, 30 % stalled at issue; 3.6 L2 requests per draw, 43 % L2
+// misses on the bottom group), so here the draws are first counting-sorted by the subtree they reach at owner
+// level Lb (2048 subtrees at 1M leaves) and every walk finishes in LDS:
+//   k_bin_top      walks the top `gb` groups out of LDS (one dependent 16-byte pair read per level), writes
+//                  the residual value + bin of every draw, histograms the bins (k_bin_offsets scans them);
+//   k_bin_scatter  moves (residual, draw id) records into bin order (LDS ranks, one range reservation per
+//                  bin per workgroup);
+//   k_descend_bin  one workgroup per bin stages the bin's whole subtree (73 blocks, 9.3 KB, read once,
+//                  coalesced) in LDS and finishes every walk there -- no scattered tree fetch is left.
+// Results are written to cand[j] at the draw's own position, so acceptance order, indices and weights are
+// exactly those of the unbinned walk (tests compare the two).
+// Measured on MI355X, 1M draws from 1M leaves: k_bin_top 24 us + k_bin_offsets 5 + k_bin_scatter 20 + k_descend_bin 23
+// = 72 us against 60 us for k_descend_bulk (whole call 100 vs 81 us); 4M draws: 285 vs 252 us.  Seven dependent
+// launches at >= 4.5 us each and two extra passes over the draws cost more than the scattered fetches they remove,
+// so the flat walk stays the default.
+// ------------------------------------------------------------------------------------------
+struct BinRec {
+    double val;
+    int j, pad;
+};
+struct BinGeom {
+    int gb;          // top groups walked by k_bin_top (groups 0..gb-1)
+    int Lb;          // owner level of the bin roots = h0 + 3*(gb-1)
+    int nb;          // bins = 2^Lb
+    int R;           // groups below a bin root (<= 3: 1 + 8 + 64 blocks)
+    int top_blocks;  // blocks of groups 0..gb-1
+};
+constexpr int kBinMax = 4096;
+constexpr int kScatterTile = 16;  // draws per thread in k_bin_scatter
+
+__global__ void __launch_bounds__(256) k_bin_top(SampleArgs a, BinGeom bg, double *val_out, unsigned short *bin_out, unsigned *hist) {
+    __shared__ __attribute__((aligned(16))) double top[kBulkLdsBlocks * 16];
+    __shared__ unsigned s_hist[kBinMax];
+    const Tree tr = a.tr;
+    for (int k = threadIdx.x; k < bg.top_blocks * 16; k += blockDim.x) top[k] = tr.T[k];
+    for (int k = threadIdx.x; k < bg.nb; k += blockDim.x) s_hist[k] = 0;
+    __syncthreads();
+    const double total = top[14];
+    const i64 first = ((i64)1 << bg.Lb) - 1;
+    constexpr int kTopIlp = 4;  // independent walks per lane: their dependent LDS reads overlap
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 j0 = (i64)blockIdx.x * blockDim.x + threadIdx.x; j0 < a.n_uniforms; j0 += stride * kTopIlp) {
+        double val[kTopIlp], p;
+        i64 idx[kTopIlp];
+#pragma unroll
+        for (int d = 0; d < kTopIlp; d++) {
+            const i64 j = j0 + d * stride;
+            val[d] = j < a.n_uniforms ? a.uniforms[j] * total : 0.0;  // :147
+            idx[d] = 0;
+        }
+        int level = 0;
+        for (int g = 0; g < bg.gb; g++) {
+            const int levels = g == 0 ? tr.h0 : 3;
+#pragma unroll
+            for (int d = 0; d < kTopIlp; d++) walk_block_pairs(top + tr.block_of_owner(idx[d], level) * 16, levels, tr.len, idx[d], val[d], p);
+            level += levels;
+        }
+#pragma unroll
+        for (int d = 0; d < kTopIlp; d++) {
+            const i64 j = j0 + d * stride;
+            if (j >= a.n_uniforms) continue;
+            const int bin = (int)(idx[d] - first);
+            val_out[j] = val[d];
+            bin_out[j] = (unsigned short)bin;
+            atomicAdd(&s_hist[bin], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < bg.nb; k += blockDim.x)
+        if (s_hist[k]) atomicAdd(&hist[k], s_hist[k]);
+}
+
+// exclusive scan of the bin histogram (one workgroup; a last-workgroup-done scan inside k_bin_top would need an
+// agent-scope release fence per workgroup, i.e. an L2 write-back each: measured +35 us)
+__global__ void __launch_bounds__(256) k_bin_offsets(BinGeom bg, const unsigned *hist, unsigned *offs) {
+    __shared__ int ibuf[256];
+    const int per = (bg.nb + 255) / 256;  // <= 16
+    unsigned hv[kBinMax / 256];
+#pragma unroll
+    for (int k = 0; k < kBinMax / 256; k++) {
+        const int b = threadIdx.x * per + k;
+        hv[k] = (k < per && b < bg.nb) ? hist[b] : 0u;
+    }
+    unsigned mine = 0;
+#pragma unroll
+    for (int k = 0; k < kBinMax / 256; k++) mine += hv[k];
+    int tot;
+    unsigned run = (unsigned)block_exscan((int)mine, ibuf, &tot);
+#pragma unroll
+    for (int k = 0; k < kBinMax / 256; k++) {
+        const int b = threadIdx.x * per + k;
+        if (k < per && b < bg.nb) {
+            offs[b] = run;
+            run += hv[k];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bin_scatter(SampleArgs a, BinGeom bg, const double *val_in, const unsigned short *bin_in, const unsigned *offs,
+                                                     unsigned *cursor, BinRec *recs) {
+    __shared__ unsigned s_cnt[kBinMax], s_base[kBinMax];
+    for (int k = threadIdx.x; k < bg.nb; k += blockDim.x) s_cnt[k] = 0;
+    __syncthreads();
+    const i64 tile0 = (i64)blockIdx.x * (256 * kScatterTile);
+    int bin[kScatterTile];
+    unsigned rank[kScatterTile];
+#pragma unroll
+    for (int d = 0; d < kScatterTile; d++) {
+        const i64 j = tile0 + d * 256 + threadIdx.x;
+        bin[d] = j < a.n_uniforms ? (int)bin_in[j] : -1;
+    }
+#pragma unroll
+    for (int d = 0; d < kScatterTile; d++)
+        if (bin[d] >= 0) rank[d] = atomicAdd(&s_cnt[bin[d]], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < bg.nb; k += blockDim.x) {
+        const unsigned c = s_cnt[k];
+        if (c) s_base[k] = offs[k] + atomicAdd(&cursor[k], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < kScatterTile; d++) {
+        if (bin[d] < 0) continue;
+        const i64 j = tile0 + d * 256 + threadIdx.x;
+        BinRec r;
+        r.val = val_in[j];
+        r.j = (int)j;
+        r.pad = 0;
+        recs[s_base[bin[d]] + rank[d]] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_descend_bin(SampleArgs a, BinGeom bg, const unsigned *hist, const unsigned *offs, const BinRec *recs,
+                                                     unsigned *part_zero, double *part_wmax) {
+    __shared__ __attribute__((aligned(16))) double sub[73 * 16];
+    __shared__ double red[256];
+    const Tree tr = a.tr;
+    const int bin = blockIdx.x;
+    const unsigned count = hist[bin];
+    if (count == 0) {
+        if (threadIdx.x == 0) {
+            part_zero[bin] = 0;
+            part_wmax[bin] = 0.0;
+        }
+        return;
+    }
+    // the R groups below this bin's root: 1, 8, 64 blocks, each run contiguous in the tree
+    for (int t = 0, off = 0; t < bg.R; off += 1 << (3 * t), t++) {
+        const double *src = tr.T + (tr.base[bg.gb + t] + ((i64)bin << (3 * t))) * 16;
+        for (int k = threadIdx.x; k < (16 << (3 * t)); k += blockDim.x) sub[off * 16 + k] = src[k];
+    }
+    __syncthreads();
+    const unsigned begin = offs[bin];
+    const double total = tr.T[14];
+    const i64 B = a.batch, len = tr.len;
+    const i64 step = a.d_step ? *a.d_step : a.step;
+    const double beta = beta_of(a.beta_initial, a.beta_steps, step);
+    const double size = (double)a.state->size;
+    const i64 root = ((i64)1 << bg.Lb) - 1 + bin;
+    unsigned zeros = 0;
+    double wmax = 0.0;
+    for (unsigned e = threadIdx.x; e < count; e += 256) {
+        const BinRec r = recs[begin + e];
+        double val = r.val, p = 0.0;
+        i64 idx = root;
+        int level = bg.Lb;
+        for (int t = 0; t < bg.R; t++) {
+            const i64 q = idx + 1 - ((i64)1 << level) - ((i64)bin << (3 * t));
+            const int off = t == 0 ? 0 : (t == 1 ? 1 : 9);
+            if (!walk_block_pairs(sub + (off + q) * 16, 3, len, idx, val, p)) break;
+            level += 3;
+        }
+        Cand c;
+        c.idx = idx;
+        c.p = p;
+        a.cand[r.j] = c;
+        if (p == 0.0)
+            zeros++;
+        else if (r.j < B)
+            wmax = fmax(wmax, is_weight(size, p, total, beta));
+    }
+    // one (zeros, wmax) partial per bin, reduced by k_compact_bulk: thousands of same-address device atomics cost ~7 us
+    __shared__ unsigned s_zero;
+    if (threadIdx.x == 0) s_zero = 0;
+    const double m = block_max(wmax, red);
+    if (zeros) atomicAdd(&s_zero, zeros);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part_zero[bin] = s_zero;
+        part_wmax[bin] = m;
+    }
+}
+
 // single workgroup: ordered compaction of the accepted draws.  Fast exit when nothing was rejected.
-__global__ void __launch_bounds__(1024) k_compact_bulk(SampleArgs a, const u64 *zero_count, int *identity) {
+__global__ void __launch_bounds__(1024) k_compact_bulk(SampleArgs a, u64 *zero_count, int *identity, int n_part, const unsigned *part_zero,
+                                                       const double *part_wmax, u64 *wmax_bits) {
     __shared__ int ibuf[1024];
+    __shared__ double dred[1024];
     const i64 M = a.n_uniforms, B = a.batch;
     const int t = threadIdx.x, T = blockDim.x;
+    if (n_part > 0) {  // binned walk: fold the per-bin partials into the counters the later kernels read
+        unsigned z = 0;
+        double m = 0.0;
+        for (int k = t; k < n_part; k += T) {
+            z += part_zero[k];
+            m = fmax(m, part_wmax[k]);
+        }
+        ibuf[t] = (int)z;
+        m = block_max(m, dred);
+        for (int s2 = T >> 1; s2 > 0; s2 >>= 1) {
+            if (t < s2) ibuf[t] += ibuf[t + s2];
+            __syncthreads();
+        }
+        if (t == 0) {
+            *zero_count = (u64)(unsigned)ibuf[0];
+            *wmax_bits = (u64)__double_as_longlong(m);
+        }
+        __syncthreads();
+    }
     if (*zero_count == 0) {
         if (t == 0) {
             *identity = 1;
@@ -418,7 +664,7 @@ __global__ void __launch_bounds__(1024) k_compact_bulk(SampleArgs a, const u64 *
     bool done = false;
     for (i64 tile = 0; tile < M && !done; tile += T) {
         const i64 j = tile + t;
-        const int ok = (j < M && a.cand_p[j] != 0.0) ? 1 : 0;
+        const int ok = (j < M && a.cand[j].p != 0.0) ? 1 : 0;
         int tot;
         const i64 pos = base + block_exscan(ok, ibuf, &tot);
         if (ok && pos < B) {
@@ -444,9 +690,10 @@ __global__ void __launch_bounds__(256) k_weights_bulk(SampleArgs a, const int *i
     double w = 0.0;
     if (i < B && *a.out_used >= 0) {
         const i64 j = a.map[i];
-        w = is_weight(size, a.cand_p[j], total, beta);
+        const Cand c = a.cand[j];
+        w = is_weight(size, c.p, total, beta);
         a.wtmp[i] = w;
-        a.out_idx[i] = a.cand_idx[j];
+        a.out_idx[i] = c.idx;
     }
     const double m = block_max(w, red);
     // positive doubles order like their bit patterns
@@ -456,8 +703,16 @@ __global__ void __launch_bounds__(256) k_weights_bulk(SampleArgs a, const int *i
 __global__ void __launch_bounds__(256) k_normalise_bulk(SampleArgs a, const int *identity, const u64 *wmax_fast, const u64 *wmax_slow) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.batch || *a.out_used < 0) return;
-    const double wmax = __longlong_as_double((long long)(*identity ? *wmax_fast : *wmax_slow));
-    const double w = a.wtmp[i] / wmax;
+    double w;
+    if (*identity) {  // nothing was rejected: output i is draw i
+        const i64 step = a.d_step ? *a.d_step : a.step;
+        const Cand c = a.cand[i];
+        const double wi = is_weight((double)a.state->size, c.p, a.tr.T[14], beta_of(a.beta_initial, a.beta_steps, step));
+        w = wi / __longlong_as_double((long long)*wmax_fast);
+        a.out_idx[i] = c.idx;
+    } else {
+        w = a.wtmp[i] / __longlong_as_double((long long)*wmax_slow);
+    }
     if (a.out_w) a.out_w[i] = w;
     if (a.out_w32) a.out_w32[i] = (float)w;
 }
@@ -749,6 +1004,7 @@ struct srlx_per {
     Tree tree;        // blocked device layout (tree.T is the allocation)
     i64 n_blocks;     // 128-byte blocks allocated
     int lds_blocks;   // leading blocks the bulk sampler stages in LDS
+    int bulk_binned;  // SRLX_PER_BULK=binned: counting-sorted bulk descent (kept for A/B timing; default is the flat walk)
     PerState *d_state;
     int *d_err;
     i64 size, write;  // host mirror
@@ -805,20 +1061,35 @@ int launch_update(srlx_per *h, i64 n, const i64 *d_idx, const void *d_prio, int 
 
 // scratch layout for sample
 struct SampleScratch {
-    i64 *cand_idx;
-    double *cand_p;
-    i64 *map;
-    double *wtmp;
-    u64 *counters;  // [0] zero_count, [1] wmax_bits, [2] identity (int)
-    static size_t bytes(i64 M, i64 B) {
+    static constexpr size_t kCtlBytes = 64 + (2 * kBinMax + 16) * 4;  // counters | hist | cursor | done (zeroed per call)
+    static size_t bytes(i64 M, i64 B, bool bulk) {
         using C = srlx::Carver;
-        return C::padded((size_t)M * 8) * 2 + C::padded((size_t)B * 8) * 2 + C::padded(64);
+        if (!bulk) return C::padded((size_t)M * 8) * 2 + C::padded((size_t)B * 8) * 2;
+        return C::padded((size_t)B * 8) * 2 + C::padded(kCtlBytes) + C::padded((kBinMax + 1) * 4) + C::padded((size_t)M * 16) * 2 +
+               C::padded((size_t)M * 8) + C::padded((size_t)M * 2) + C::padded(kBinMax * 4) + C::padded(kBinMax * 8);
     }
 };
 
+// geometry of the binned bulk walk; returns false when this tree shape is served by the unbinned kernel
+bool bin_geometry(const Tree &t, BinGeom *bg) {
+    for (int gb = 4; gb >= 2; gb--) {
+        if (gb > t.G) continue;
+        const int Lb = t.h0 + 3 * (gb - 1), R = t.G - gb + 1;
+        if (t.base[gb] > kBulkLdsBlocks || Lb > 12 || R < 1 || R > 3) continue;
+        bg->gb = gb;
+        bg->Lb = Lb;
+        bg->nb = 1 << Lb;
+        bg->R = R;
+        bg->top_blocks = (int)t.base[gb];
+        return true;
+    }
+    return false;
+}
+
 int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double *d_u, i64 M, i64 *d_idx, double *d_w,
                   float *d_w32, i64 *d_used, hipStream_t st) {
-    SRLX_TRY(h->scratch.reserve(SampleScratch::bytes(M, B)));
+    const bool bulk = M > kSmallSampleMax;
+    SRLX_TRY(h->scratch.reserve(SampleScratch::bytes(M, B, bulk)));
     srlx::Carver cv(h->scratch.ptr);
     SampleArgs a{};
     a.tr = h->tree;
@@ -831,17 +1102,16 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
     a.uniforms = d_u;
     a.n_uniforms = M;
     a.batch = B;
-    a.cand_idx = cv.take<i64>(M);
-    a.cand_p = cv.take<double>(M);
-    a.map = cv.take<i64>(B);
-    a.wtmp = cv.take<double>(B);
-    u64 *counters = cv.take<u64>(8);
     a.out_idx = d_idx;
     a.out_w = d_w;
     a.out_w32 = d_w32;
     a.out_used = d_used;
 
-    if (M <= kSmallSampleMax) {
+    if (!bulk) {
+        a.cand_idx = cv.take<i64>(M);
+        a.cand_p = cv.take<double>(M);
+        a.map = cv.take<i64>(B);
+        a.wtmp = cv.take<double>(B);
         const size_t lds = (size_t)kWgSample * (8 + 4) + (size_t)M + 16;
         hipLaunchKernelGGL(k_sample_wg, dim3(1), dim3(kWgSample), lds, st, a);
     } else {
@@ -849,12 +1119,39 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
             srlx::set_error("per_sample: has_duplicate=False is limited to %lld uniforms per call", (long long)kSmallSampleMax);
             return SRLX_ERR_UNSUPPORTED;
         }
-        SRLX_HIP(hipMemsetAsync(counters, 0, 64, st));
+        a.map = cv.take<i64>(B);
+        a.wtmp = cv.take<double>(B);
         // counters: [0] zero_count  [1] wmax (fast path)  [2] identity flag  [3] wmax (slow path)
-        i64 want = (M + 256 * kIlp - 1) / (256 * kIlp);
-        int blocks = (int)(want < 256 * 4 ? want : 256 * 4);  // 42 KiB of LDS each: 3-4 resident workgroups per CU
-        hipLaunchKernelGGL(k_descend_bulk, dim3(blocks), dim3(256), 0, st, a, h->lds_blocks, counters, counters + 1);
-        hipLaunchKernelGGL(k_compact_bulk, dim3(1), dim3(1024), 0, st, a, counters, (int *)(counters + 2));
+        u64 *counters = (u64 *)cv.take<char>(SampleScratch::kCtlBytes);
+        unsigned *hist = (unsigned *)(counters + 8), *cursor = hist + kBinMax;
+        unsigned *offs = cv.take<unsigned>(kBinMax + 1);
+        a.cand = cv.take<Cand>(M);
+        BinRec *recs = cv.take<BinRec>(M);
+        double *val2 = cv.take<double>(M);
+        unsigned short *bins = cv.take<unsigned short>(M);
+        unsigned *part_zero = cv.take<unsigned>(kBinMax);
+        double *part_wmax = cv.take<double>(kBinMax);
+        int n_part = 0;
+        BinGeom bg{};
+        if (h->bulk_binned && M >= ((i64)1 << 16) && M < ((i64)1 << 31) && bin_geometry(h->tree, &bg)) {
+            SRLX_HIP(hipMemsetAsync(counters, 0, SampleScratch::kCtlBytes, st));
+            const i64 want = (M + 256 * 8 - 1) / (256 * 8);
+            hipLaunchKernelGGL(k_bin_top, dim3((unsigned)(want < 512 ? want : 512)), dim3(256), 0, st, a, bg, val2, bins, hist);
+            hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(256), 0, st, bg, (const unsigned *)hist, offs);
+            const i64 tiles = (M + 256 * kScatterTile - 1) / (256 * kScatterTile);
+            hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)tiles), dim3(256), 0, st, a, bg, (const double *)val2, (const unsigned short *)bins,
+                               (const unsigned *)offs, cursor, recs);
+            hipLaunchKernelGGL(k_descend_bin, dim3((unsigned)bg.nb), dim3(256), 0, st, a, bg, (const unsigned *)hist, (const unsigned *)offs,
+                               (const BinRec *)recs, part_zero, part_wmax);
+            n_part = bg.nb;
+        } else {
+            SRLX_HIP(hipMemsetAsync(counters, 0, 64, st));
+            i64 want = (M + 256 * kIlp - 1) / (256 * kIlp);
+            int blocks = (int)(want < 256 * 4 ? want : 256 * 4);  // 42 KiB of LDS each: 3-4 resident workgroups per CU
+            hipLaunchKernelGGL(k_descend_bulk, dim3(blocks), dim3(256), 0, st, a, h->lds_blocks, counters, counters + 1);
+        }
+        hipLaunchKernelGGL(k_compact_bulk, dim3(1), dim3(1024), 0, st, a, counters, (int *)(counters + 2), n_part, (const unsigned *)part_zero,
+                           (const double *)part_wmax, counters + 1);
         const int wb = (int)((B + 255) / 256);
         hipLaunchKernelGGL(k_weights_bulk, dim3(wb), dim3(256), 0, st, a, (const int *)(counters + 2), counters + 3);
         hipLaunchKernelGGL(k_normalise_bulk, dim3(wb), dim3(256), 0, st, a, (const int *)(counters + 2), counters + 1, counters + 3);
@@ -908,6 +1205,8 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
             h->n_blocks = t.G >= 1 ? t.base[t.G + 1] : 1;
         }
         h->lds_blocks = 1;
+        const char *bulk = getenv("SRLX_PER_BULK");
+        h->bulk_binned = bulk && !strcmp(bulk, "binned");  // measured slower than the flat walk at 1M..4M draws
         for (int g = 1; g <= t.G; g++)
             if (t.base[g + 1] <= kBulkLdsBlocks) h->lds_blocks = (int)t.base[g + 1];
         if (h->n_blocks < h->lds_blocks) h->lds_blocks = (int)h->n_blocks;

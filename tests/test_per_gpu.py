@@ -248,6 +248,30 @@ def test_full_size_1M_bulk_paths():
     assert abs(tree[0] - tree[cap - 1 :].sum()) / tree[0] < 1e-9
 
 
+@pytest.mark.parametrize("cap", [1_000_000, 300_001])
+def test_binned_bulk_walk_equals_oracle(cap, monkeypatch):
+    """SRLX_PER_BULK=binned (counting-sorted bulk descent, the measured alternative to the flat walk): same
+    indices, uniform consumption and weights as the oracle, zero-priority rejections included."""
+    monkeypatch.setenv("SRLX_PER_BULK", "binned")  # read at srlx_per_create
+    N = _N()
+    rng = np.random.default_rng(5)
+    g = AbiPER(cap, 0.5, 0.4, 1_000_000, True, 1e-4)
+    o = OraclePER(cap, 0.5, 0.4, 1_000_000, True, 1e-4)
+    pri = rng.random(cap)
+    pri[rng.random(cap) < 0.02] = 0.0  # zero leaves: in-order rejection on the slow path
+    g.add(pri, N.PRIO_RAW)
+    for x in pri:
+        o.add(float(x), mode=2)
+    np.testing.assert_array_equal(g.state()[3], o.tree())
+    M, B = 150_000, 120_000
+    u = rng.random(M)
+    st, used, idx, w, w32 = g.sample(B, 1000, u)
+    oused, oidx, ow, _ = o.sample(B, 1000, u)
+    assert st == 0 and used == oused
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_allclose(w, ow, rtol=W_RTOL, atol=0)
+
+
 def test_on_device_pointers_with_torch():
     """on_device=1: device pointers (torch tensors), work enqueued on torch's current stream,
     step read from a device scalar -- same results as the host-pointer path."""

@@ -227,6 +227,42 @@ int srlx_gae_scan(int64_t n_envs, int64_t horizon, const float *d_rewards, const
                   const float *d_last_values, double discount, double gae_lambda, float *d_adv, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * PPO on the vectorised path (BASELINE config 5).  The reference module needs TensorFlow
+ * (srl/algorithms/ppo/ppo.py:6-7) and cannot be imported in the build container: parity UNPINNED, restated
+ * from the cited lines and checked against oracle/hot_path_oracle.py + torch autograd.
+ *   srlx_ppo_normal_act  : ppo.py:316-339 + srl/rl/tf/distributions/normal_dist_block.py:13-20,64-74,144-149:
+ *       action = loc + exp(clip(log_scale)) * N(0,1)  (keyed counter RNG, *d_counter += 1), per-dimension
+ *       log-probability floored at log(1e-6) (ppo.py:322); deterministic != 0: action = loc (evaluation, :318-319).
+ *       All arrays f32 [n] (n = envs x action_dim).
+ *   srlx_ppo_loss_normal : compute_train_loss (ppo.py:102-169) for a Normal policy, forward + gradient seeds.
+ *       loc/log_scale/action/old_logpi f32 [B][action_dim]; advantage/v/v_target/old_v f32 [B];
+ *       baseline_advantage: advantage -= stop_gradient(v) (:121-122); surrogate_clip 1 = "clip" (:127-137),
+ *       0 = "" (:148-149) ("kl" needs tensorflow_probability in the reference and is not offered);
+ *       losses f32 [3] = policy, value, entropy as the reference reports them;
+ *       grad_loc/grad_log_scale f32 [B][action_dim], grad_v f32 [B] = d(policy+value+entropy)/d(.)
+ *   srlx_ppo_loss_logpi  : the same given the policy head's log-probabilities f32 [B][n_logpi]
+ *       (Categorical: n_logpi = 1, the taken action); returns d loss / d new_logpi and d loss / d v.
+ *   srlx_pendulum_step   : Pendulum-shaped synthetic environments (obs (cos th, sin th, thdot), one torque in
+ *       [-2, 2], reward -(th^2 + .1 thdot^2 + .001 u^2), time limit `episode_len` -> done + auto-reset).
+ *       state f32 [E][2], step_in_episode i32 [E], action f32 [E], obs f32 [E][3], reward f32 [E], done u8 [E].
+ * ------------------------------------------------------------------------------------------------ */
+int srlx_ppo_normal_act(int64_t n, const float *d_loc, const float *d_log_scale, double log_scale_min, double log_scale_max,
+                        uint64_t seed, int64_t *d_counter, int deterministic, float *d_action, float *d_logprob, void *stream);
+int srlx_ppo_loss_normal(int64_t batch, int action_dim, const float *d_loc, const float *d_log_scale, double log_scale_min,
+                         double log_scale_max, const float *d_action, const float *d_old_logpi, const float *d_advantage,
+                         const float *d_v, const float *d_v_target, const float *d_old_v, int baseline_advantage,
+                         int surrogate_clip, double policy_clip_range, int enable_value_clip, double value_clip_range,
+                         double value_loss_weight, double entropy_weight, float *d_losses, float *d_grad_loc,
+                         float *d_grad_log_scale, float *d_grad_v, void *stream);
+int srlx_ppo_loss_logpi(int64_t batch, int n_logpi, const float *d_new_logpi, const float *d_old_logpi, const float *d_advantage,
+                        const float *d_v, const float *d_v_target, const float *d_old_v, int baseline_advantage,
+                        int surrogate_clip, double policy_clip_range, int enable_value_clip, double value_clip_range,
+                        double value_loss_weight, double entropy_weight, float *d_losses, float *d_grad_logpi, float *d_grad_v,
+                        void *stream);
+int srlx_pendulum_step(int64_t n_envs, float *d_state, int32_t *d_step_in_episode, const float *d_action, int64_t episode_len,
+                       uint64_t seed, int64_t *d_counter, float *d_obs, float *d_reward, uint8_t *d_done, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Never-Give-Up intrinsic reward + Agent57_light priorities
  *
  * srlx_ngu_t: one bounded episodic memory per environment, [E][emb_dim][capacity] float32 in HBM

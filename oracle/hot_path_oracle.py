@@ -401,3 +401,58 @@ def agent57_target(q_online_next, q_target_next, rewards, dones, batch_discount,
 def agent57_priority(td_ext, td_int, batch_beta):
     """agent57_light/model_torch.py:367-373: priorities = |td_ext + beta_actor * td_int| (float32)."""
     return np.abs(np.asarray(td_ext, np.float32) + np.asarray(batch_beta, np.float32) * np.asarray(td_int, np.float32)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------
+# PPO (srl/algorithms/ppo/ppo.py; the module imports TensorFlow and cannot be imported here: parity UNPINNED,
+# restated from the cited lines in float32 numpy)
+# ------------------------------------------------------------------------------------------
+def normal_logprob(x, loc, log_scale):
+    """srl/rl/tf/distributions/normal_dist_block.py:13-20"""
+    x, loc, log_scale = (np.asarray(t, np.float32) for t in (x, loc, log_scale))
+    return (np.float32(-0.5 * np.log(2 * np.pi)) - log_scale - np.float32(0.5) * ((x - loc) / np.exp(log_scale)) ** 2).astype(np.float32)
+
+
+def ppo_loss(new_logpi, old_logpi, advantage, v, v_target, old_v, baseline_advantage, surrogate_clip, policy_clip_range, enable_value_clip,
+             value_clip_range, value_loss_weight, entropy_weight):
+    """compute_train_loss, ppo.py:102-169 ("clip" and "" surrogates): returns (policy_loss, value_loss, entropy_loss).
+    new_logpi/old_logpi [B][K]; advantage/v/v_target/old_v [B] (the reference carries them as [B][1])."""
+    f = np.float32
+    lp, olp = np.asarray(new_logpi, f), np.asarray(old_logpi, f)
+    v, vt = np.asarray(v, f)[:, None], np.asarray(v_target, f)[:, None]
+    adv = np.asarray(advantage, f)[:, None]
+    if baseline_advantage:
+        adv = adv - v  # :121-122
+    ratio = np.exp(lp - olp)  # :126
+    if surrogate_clip:
+        rc = np.clip(ratio, f(1 - policy_clip_range), f(1 + policy_clip_range))
+        policy = np.minimum(ratio * adv, rc * adv)  # :128-137
+    else:
+        policy = ratio * adv
+    policy_loss = -np.mean(policy, dtype=np.float64)  # :152
+    if enable_value_clip:
+        ov = np.asarray(old_v, f)[:, None]
+        vc = np.clip(v, ov - f(value_clip_range), ov + f(value_clip_range))
+        value = np.maximum((v - vt) ** 2, (vc - vt) ** 2)  # :155-157
+    else:
+        value = (v - vt) ** 2
+    value_loss = value_loss_weight * np.mean(value, dtype=np.float64)  # :161
+    entropy = np.sum(-np.exp(lp) * lp, axis=-1)  # :166
+    entropy_loss = entropy_weight * -np.mean(entropy, dtype=np.float64)  # :167
+    return f(policy_loss), f(value_loss), f(entropy_loss)
+
+
+def pendulum_step(state, t_in_ep, action, episode_len):
+    """The Pendulum-shaped synthetic workload of BASELINE config 5 (definition; mirrored by csrc/srlx_ppo.hip),
+    without the reset draw: returns (new_state, new_t, obs, reward, done) where done envs keep their stepped state."""
+    f = np.float32
+    th, thd = np.asarray(state, f)[:, 0].copy(), np.asarray(state, f)[:, 1].copy()
+    u = np.clip(np.asarray(action, f), f(-2), f(2))
+    an = np.mod(th + f(np.pi), f(2 * np.pi)) - f(np.pi)
+    reward = -(an * an + f(0.1) * thd * thd + f(0.001) * u * u)
+    thd = np.clip(thd + (f(15.0) * np.sin(th) + f(3.0) * u) * f(0.05), f(-8), f(8)).astype(f)
+    th = (th + thd * f(0.05)).astype(f)
+    t = np.asarray(t_in_ep) + 1
+    done = t >= episode_len
+    obs = np.stack([np.cos(th), np.sin(th), thd], axis=1).astype(f)
+    return np.stack([th, thd], axis=1), t, obs, reward.astype(f), done

@@ -16,6 +16,7 @@ PRIO_NONE, PRIO_F64, PRIO_F32, PRIO_RAW = 0, 1, 2, 3
 
 c_i64 = ctypes.c_int64
 c_f64 = ctypes.c_double
+c_u64 = ctypes.c_uint64
 c_int = ctypes.c_int
 c_p = ctypes.c_void_p
 
@@ -78,6 +79,11 @@ SIGNATURES = {
     ),
     "srlx_dqn_target": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_p, c_int, c_int, c_int, c_p, c_p]),
     "srlx_gae_scan": (c_int, [c_i64, c_i64, c_p, c_p, c_p, c_p, c_f64, c_f64, c_p, c_p]),
+    "srlx_ppo_normal_act": (c_int, [c_i64, c_p, c_p, c_f64, c_f64, c_u64, c_p, c_int, c_p, c_p, c_p]),
+    "srlx_ppo_loss_normal": (c_int, [c_i64, c_int, c_p, c_p, c_f64, c_f64, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f64, c_int, c_f64, c_f64, c_f64,
+                                     c_p, c_p, c_p, c_p, c_p]),
+    "srlx_ppo_loss_logpi": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f64, c_int, c_f64, c_f64, c_f64, c_p, c_p, c_p, c_p]),
+    "srlx_pendulum_step": (c_int, [c_i64, c_p, c_p, c_p, c_i64, c_u64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_ngu_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_int, c_i64, c_int, c_f64, c_f64, c_f64, c_int]),
     "srlx_ngu_destroy": (c_int, [c_p]),
     "srlx_ngu_reset": (c_int, [c_p, c_p]),

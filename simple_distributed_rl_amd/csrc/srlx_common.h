@@ -86,6 +86,19 @@ struct Carver {
     static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 };
 
+// keyed counter RNG of the vectorised path (definition; restated in oracle/hot_path_oracle.py: rng_u64 / u53)
+using u64 = unsigned long long;
+__host__ __device__ __forceinline__ u64 mix64(u64 z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ u64 rng_u64(u64 seed, u64 a, u64 b) {
+    return mix64(mix64(seed + a * 0xD1342543DE82EF95ull) + b * 0xAEF17502108EF2D9ull);
+}
+__host__ __device__ __forceinline__ double u53(u64 x) { return (double)(x >> 11) * (1.0 / 9007199254740992.0); }
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = false;

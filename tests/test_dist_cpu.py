@@ -77,3 +77,38 @@ def test_transition_bus_gloo_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _grad_avg_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    from simple_distributed_rl_amd.device.ppo import flat_grad_all_reduce
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    x = torch.full((4, 3), float(rank + 1))
+    net(x).sum().backward()
+    mine = [p.grad.clone() for p in net.parameters()]
+    flat_grad_all_reduce(net)
+    q.put((rank, [g.numpy() for g in mine], [p.grad.numpy().copy() for p in net.parameters()]))
+    dist.destroy_process_group()
+
+
+def test_ppo_gradient_average_world2():
+    """Data-parallel PPO (BASELINE config 5): one flat all-reduce leaves every rank with the mean gradient."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_grad_avg_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, g0, a0), (_, g1, a1) = res
+    for x0, x1, y0, y1 in zip(g0, g1, a0, a1):
+        np.testing.assert_allclose(y0, (x0 + x1) / 2, rtol=1e-6)
+        np.testing.assert_array_equal(y0, y1)

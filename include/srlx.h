@@ -279,7 +279,8 @@ int srlx_pendulum_step(int64_t n_envs, float *d_state, int32_t *d_step_in_episod
  *       d_target/d_train f32 [n][dim].
  *   srlx_agent57_priority    : srl/algorithms/agent57_light/model_torch.py:442,367-373:
  *       td = target - q[action]; priorities = |td_ext + beta[actor] * td_int| (d_target_int NULL: |td_ext|).
- *       d_td_ext / d_td_int (nullable) receive the signed TD errors.
+ *       d_td_ext / d_td_int (nullable) receive the signed TD errors.  d_q_ext == d_q_int == NULL: d_target_* already
+ *       hold TD errors (Agent57's per-sequence means, srl/algorithms/agent57/model_torch.py:388-391).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct srlx_ngu srlx_ngu_t;
 int srlx_ngu_create(srlx_ngu_t **out, int64_t n_envs, int emb_dim, int64_t capacity, int k, double epsilon,
@@ -291,6 +292,18 @@ int srlx_ngu_episodic_reward(srlx_ngu_t *h, const float *d_emb, const uint8_t *d
                              float *d_reward, void *stream);
 int srlx_ngu_lifelong_reward(int64_t n, int dim, const float *d_target, const float *d_train, double lifelong_max,
                              float *d_reward, void *stream);
+/* Agent57 (LSTM, sequence replay) learner arithmetic after the forwards, srl/algorithms/agent57/agent57.py:301-379
+ * (calc_target_q: double-DQN gains with the actor's gamma, greedy-policy retrace coefficients, backward target
+ * recursion) + model_torch.py:469-492 (selected Q, HuberLoss(target*w, q*w) over [seq][batch], mean TD error):
+ *   q / q_target f32 [B][S+1][A] (online / target network over the S+1 in-sequence states), actions i32 [B][S],
+ *   rewards / dones f32 [B][S] (dones = 0 after a terminal step), invalid_next u8 [B][S][A] or NULL,
+ *   discounts / weights f32 [B];  out: target f32 [S][B], loss f32 [1], grad_q f32 [B][S+1][A] = d loss / d q,
+ *   td_mean f32 [B] = mean_t(q[a_t] - target_t);  scratch >= 2*B*S floats. */
+int srlx_agent57_seq_td(int64_t batch, int seq_len, int n_actions, const float *d_q, const float *d_q_target,
+                        const int32_t *d_actions, const float *d_rewards, const float *d_dones, const uint8_t *d_invalid_next,
+                        const float *d_discounts, const float *d_weights, double retrace_h, int enable_double_dqn,
+                        int enable_rescale, float *d_target, float *d_loss, float *d_grad_q, float *d_td_mean, float *d_scratch,
+                        void *stream);
 int srlx_agent57_priority(int64_t batch, int n_actions, const float *d_target_ext, const float *d_q_ext,
                           const float *d_target_int, const float *d_q_int, const int32_t *d_actions,
                           const int32_t *d_actor_idx, const float *d_beta_list, float *d_td_ext, float *d_td_int,

@@ -243,3 +243,184 @@ def gen_train_step():
 
 
 AGENT57_GENERATORS = dict(ngu_episodic=gen_episodic, ngu_lifelong=gen_lifelong, agent57_ucb=gen_ucb, agent57_target=gen_target, agent57_train_step=gen_train_step)
+
+
+# ----------------------------------------------------------------------------------------
+# Agent57 (LSTM): calc_target_q (agent57.py:301-379) with scripted Q tensors
+# ----------------------------------------------------------------------------------------
+def gen_a57_target():
+    from srl.algorithms.agent57 import agent57 as a57
+    from srl.rl import functions as F
+
+    rng = np.random.default_rng(41)
+    dlist = np.array(F.create_discount_list(32), np.float64)
+    for name, B, S, A, double_dqn, rescale, h, with_inv in [("s5_double", 16, 5, 4, True, False, 1.0, False), ("s9_single_inv_h095", 12, 9, 5, False, False, 0.95, True),
+                                                            ("s4_double_rescale_inv", 10, 4, 3, True, True, 0.9, True), ("s1_double", 8, 1, 4, True, False, 1.0, False)]:
+        q = (rng.standard_normal((B, S + 1, A)) * 2).astype(np.float32)
+        qt = (q + 0.3 * rng.standard_normal((B, S + 1, A))).astype(np.float32)
+        # make the greedy action coincide with the taken action often (otherwise every retrace coefficient is 0)
+        actions = np.where(rng.random((B, S)) < 0.6, np.argmax(q[:, 1:, :], axis=2), rng.integers(0, A, (B, S))).astype(np.int32)
+        onehot = np.identity(A, dtype=np.float32)[actions]
+        action_q = np.take_along_axis(q[:, :-1, :], actions[..., None], axis=2)[..., 0]
+        rewards = rng.standard_normal((B, S)).astype(np.float32)
+        dones = (rng.random((B, S)) < 0.85).astype(np.float32)
+        actor = rng.integers(0, 32, B)
+        disc = np.array([dlist[a] for a in actor], np.float32)
+        i1, i2, i3 = [], [], []
+        invalid = np.zeros((B, S, A), bool)
+        if with_inv:
+            for b in range(B):
+                for t in range(S):
+                    for a in rng.choice(A, size=int(rng.integers(0, 2)), replace=False):
+                        i1.append(b), i2.append(t), i3.append(int(a))
+                        invalid[b, t, a] = True
+        cfg = a57.Config(enable_double_dqn=double_dqn, enable_rescale=rescale, retrace_h=h, sequence_length=S, batch_size=B)
+        fake = types.SimpleNamespace(config=cfg)
+        tgt = a57.CommonInterfaceParameter.calc_target_q(fake, q.copy(), qt.copy(), action_q.copy(), rewards, onehot, dones, i1, i2, i3, disc)
+        np.savez_compressed(os.path.join(OUT, f"agent57_target_{name}.npz"), double_dqn=np.int64(double_dqn), rescale=np.int64(rescale), retrace_h=np.float64(h), q=q,
+                            q_target=qt, actions=actions, rewards=rewards, dones=dones, discounts=disc, invalid=invalid, target=np.asarray(tgt))
+        print(f"agent57_target_{name}: {np.asarray(tgt).dtype} {np.asarray(tgt).shape} range [{np.min(tgt):.3f}, {np.max(tgt):.3f}]")
+
+
+def _a57_config(**kw):
+    import srl
+    from srl.algorithms import agent57
+
+    from gen_golden_algo import _register_env
+
+    _register_env()
+    cfg = agent57.Config(batch_size=8, actor_num=4, target_model_update_interval=5, lr_ext=0.001, lr_int=0.002, lstm_units=16, burnin=2, sequence_length=3, **kw)
+    cfg.window_length = 1
+    cfg.memory.warmup_size = 8
+    cfg.memory.capacity = 1000
+    cfg.memory.compress = False
+    cfg.memory.set_proportional(alpha=0.5, beta_initial=0.4, beta_steps=1000)
+    cfg.hidden_block.set_dueling_network((16,))
+    cfg.set_torch()
+    return cfg
+
+
+# ----------------------------------------------------------------------------------------
+# the sequence items the reference Agent57 worker emits (window shifting, dummy-state padding at episode end,
+# stored LSTM states, UCB actor choice) for a recorded trajectory
+# ----------------------------------------------------------------------------------------
+def gen_a57_rollout():
+    import srl
+    import torch
+
+    cfg = _a57_config(enable_intrinsic_reward=False)
+    env_config = srl.EnvConfig("TinyImageEnvGolden", kwargs=dict(hw=8, actions=4, ep_len=4, seed=13))
+    runner = srl.Runner(env_config, cfg)
+    runner.set_seed(6)
+    torch.manual_seed(6)
+    runner.rollout(max_steps=14)
+    env = runner.env.unwrapped if hasattr(runner.env, "unwrapped") else runner.env.env
+    log = env.log
+    mem = runner.memory.memory
+    items = [mem.tree.data[i] for i in range(mem.size)]
+    sd = {k: v.detach().numpy() for k, v in runner.parameter.q_ext_online.state_dict().items()}
+    sdi = {k: v.detach().numpy() for k, v in runner.parameter.q_int_online.state_dict().items()}
+    save = dict(
+        frames=np.array([l[0].reshape(-1) for l in log], np.uint8), env_actions=np.array([l[1] for l in log], np.int32), env_rewards=np.array([l[2] for l in log], np.float32),
+        env_terminated=np.array([l[3] for l in log], np.uint8),
+        item_states=np.array([np.asarray(it[0], np.float32) for it in items]), item_actions=np.array([np.argmax(np.asarray(it[1]), axis=1) for it in items], np.int32),
+        item_rewards_ext=np.array([it[2] for it in items], np.float32), item_rewards_int=np.array([it[3] for it in items], np.float32),
+        item_dones=np.array([it[4] for it in items], np.float32), item_actor=np.array([it[5] for it in items], np.int32),
+        item_h_ext=np.array([it[7][0] for it in items], np.float32), item_c_ext=np.array([it[7][1] for it in items], np.float32),
+        item_h_int=np.array([it[8][0] for it in items], np.float32), item_c_int=np.array([it[8][1] for it in items], np.float32),
+        seed=np.int64(6),
+    )
+    for k, v in sd.items():
+        save["q_ext." + k] = v
+    for k, v in sdi.items():
+        save["q_int." + k] = v
+    np.savez_compressed(os.path.join(OUT, "rollout_items_agent57.npz"), **save)
+    print(f"rollout_items_agent57: {len(log)} env records, {len(items)} items, actors {sorted(set(save['item_actor'].tolist()))}")
+
+
+# ----------------------------------------------------------------------------------------
+# one full Trainer.train() of Agent57 (agent57/model_torch.py:273-493)
+# ----------------------------------------------------------------------------------------
+def gen_a57_train_step():
+    import torch
+
+    import srl
+    from srl.base.context import RunContext
+
+    cfg = _a57_config()
+    env = srl.EnvConfig("TinyImageEnvGolden", kwargs=dict(hw=8, actions=4)).make()
+    cfg.setup(env)
+    torch.manual_seed(8)
+    random.seed(8)
+    parameter = cfg.make_parameter()
+    with torch.no_grad():
+        for net in (parameter.q_ext_target, parameter.q_int_target):
+            for p in net.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+    memory = cfg.make_memory()
+    trainer = cfg.make_trainer(parameter, memory)
+    trainer.setup(RunContext())
+    rng = np.random.default_rng(9)
+    obs_shape = tuple(cfg.observation_space.shape)
+    A, n_items, L, U = 4, 24, cfg.burnin + cfg.sequence_length + 1, cfg.lstm_units
+    eye = np.identity(A, dtype=int)
+    for _ in range(n_items):
+        memory.add([
+            [rng.random(obs_shape, dtype=np.float32) for _ in range(L)], [eye[int(rng.integers(0, A))] for _ in range(L)],
+            [float(rng.integers(-1, 2)) for _ in range(L)], [float(np.float32(rng.random() * 3)) for _ in range(L)],
+            [int(rng.random() < 0.85) for _ in range(cfg.sequence_length)], int(rng.integers(0, 4)), [[] for _ in range(cfg.sequence_length)],
+            [(rng.standard_normal((1, U)) * 0.3).astype(np.float32), (rng.standard_normal((1, U)) * 0.3).astype(np.float32)],
+            [(rng.standard_normal((1, U)) * 0.3).astype(np.float32), (rng.standard_normal((1, U)) * 0.3).astype(np.float32)],
+        ], None)
+    mem = memory.memory
+    mem.update([i + mem.capacity - 1 for i in range(n_items)], rng.random(n_items).astype(np.float32))
+    nets = dict(q_ext=parameter.q_ext_online, q_int=parameter.q_int_online, q_ext_target=parameter.q_ext_target, q_int_target=parameter.q_int_target,
+                emb=parameter.emb_network, lifelong_target=parameter.lifelong_target, lifelong_train=parameter.lifelong_train)
+    before = {n: {k: v.detach().clone().numpy() for k, v in m.state_dict().items()} for n, m in nets.items()}
+    rec = {}
+    _sample, _update = memory.sample, memory.update
+
+    def sample(*a, **k):
+        out = _sample(*a, **k)
+        rec["batches"], rec["weights"], rec["update_args"] = out
+        return out
+
+    def update(update_args, priorities, step):
+        rec["priorities"] = np.asarray(priorities).copy()
+        return _update(update_args, priorities, step)
+
+    memory.sample, memory.update = sample, update
+    _tq = trainer._train_q
+    tds = []
+
+    def tq(*a, **k):
+        td, loss = _tq(*a, **k)
+        tds.append(np.asarray(td).copy())
+        return td, loss
+
+    trainer._train_q = tq
+    trainer.train_count = 1
+    trainer.train()
+    after = {n: {k: v.detach().clone().numpy() for k, v in m.state_dict().items()} for n, m in nets.items()}
+    b = rec["batches"]
+    save = dict(
+        states=np.array([x[0] for x in b], np.float32), actions=np.array([np.argmax(np.asarray(x[1]), axis=1) for x in b], np.int32),
+        rewards_ext=np.array([x[2] for x in b], np.float32), rewards_int=np.array([x[3] for x in b], np.float32), dones=np.array([x[4] for x in b], np.float32),
+        actor_idx=np.array([x[5] for x in b], np.int32), h_ext=np.array([x[7][0] for x in b], np.float32), c_ext=np.array([x[7][1] for x in b], np.float32),
+        h_int=np.array([x[8][0] for x in b], np.float32), c_int=np.array([x[8][1] for x in b], np.float32), weights=np.asarray(rec["weights"]),
+        td_ext=tds[0], td_int=tds[1], priorities=rec["priorities"], ext_loss=np.float32(trainer.info["ext_loss"]), int_loss=np.float32(trainer.info["int_loss"]),
+        emb_loss=np.float32(trainer.info["emb_loss"]), lifelong_loss=np.float32(trainer.info["lifelong_loss"]), lr_ext=np.float64(cfg.lr_ext), lr_int=np.float64(cfg.lr_int),
+        episodic_lr=np.float64(cfg.episodic_lr), lifelong_lr=np.float64(cfg.lifelong_lr), actor_num=np.int64(4), n_actions=np.int64(A), burnin=np.int64(cfg.burnin),
+        sequence_length=np.int64(cfg.sequence_length), lstm_units=np.int64(U),
+    )
+    for n in nets:
+        for k, v in before[n].items():
+            save[f"before.{n}.{k}"] = v
+        if not n.endswith("_target") or n == "lifelong_target":
+            for k, v in after[n].items():
+                save[f"after.{n}.{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "train_step_agent57.npz"), **save)
+    print("train_step_agent57:", {k: round(float(v), 6) for k, v in trainer.info.items() if "loss" in k})
+
+
+AGENT57_GENERATORS.update(agent57_seq_target=gen_a57_target, agent57_rollout=gen_a57_rollout, agent57_seq_train_step=gen_a57_train_step)

@@ -456,3 +456,63 @@ def pendulum_step(state, t_in_ep, action, episode_len):
     done = t >= episode_len
     obs = np.stack([np.cos(th), np.sin(th), thd], axis=1).astype(f)
     return np.stack([th, thd], axis=1), t, obs, reward.astype(f), done
+
+
+# ------------------------------------------------------------------------------------------
+# Agent57 (LSTM, sequence replay): srl/algorithms/agent57/agent57.py:301-379 (calc_target_q) and
+# srl/algorithms/agent57/model_torch.py:469-492.  PINNED by tests/golden/agent57_target_*.npz, train_step_agent57.npz.
+# ------------------------------------------------------------------------------------------
+def agent57_seq_target(q, q_target, actions, rewards, dones, invalid, discounts, retrace_h, double_dqn, rescale):
+    """q / q_target [B][S+1][A]; actions int [B][S]; rewards / dones [B][S]; invalid bool [B][S][A] or None;
+    discounts [B].  Returns target float32 [S][B]."""
+    f = np.float32
+    q, q_target = np.array(q, f, copy=True), np.array(q_target, f, copy=True)
+    B, S = np.asarray(actions).shape
+    action_q = np.take_along_axis(q[:, :-1, :], np.asarray(actions)[..., None].astype(np.int64), axis=2)[..., 0].T  # before the in-place mask below
+    n_q, n_qt = q[:, 1:, :], q_target[:, 1:, :]
+    mask = np.zeros(n_q.shape, bool) if invalid is None else np.asarray(invalid, bool)
+    if double_dqn:  # :318-320
+        n_q[mask] = -np.inf
+        greedy = np.argmax(n_q, axis=2)
+    else:
+        n_qt[mask] = -np.inf
+        greedy = np.argmax(n_qt, axis=2)
+    maxq = np.take_along_axis(n_qt, greedy[..., None], axis=2)[..., 0]
+    if rescale:
+        maxq = inverse_rescaling(maxq)
+    disc = np.asarray(discounts, f)
+    gains = np.asarray(rewards, f) + np.asarray(dones, f) * disc[:, None] * maxq  # :334
+    if rescale:
+        gains = rescaling(gains)
+    gains = gains.T  # [S][B]
+    on_policy = (np.asarray(actions) == greedy).T  # :351 the taken action equals the greedy one
+    coef = np.ones((S, B), f)  # retrace_seq[t] * discounts_seq[t]
+    retrace = np.ones(B, f)
+    dseq = disc.copy()
+    for t in range(S):
+        coef[t] = retrace * dseq
+        if t + 1 < S:
+            retrace = (retrace.astype(np.float64) * (retrace_h * on_policy[t])).astype(f)  # float32 array *= float64 array, :361
+            dseq = dseq * disc
+    target = np.zeros((S, B), f)
+    next_td = np.zeros(B, f)
+    for t in reversed(range(S)):  # :369-376
+        target[t] = gains[t] + coef[t] * next_td
+        next_td = target[t] - action_q[t]
+    return target
+
+
+def agent57_seq_loss(q, target, actions, weights):
+    """model_torch.py:471-492: Huber(target*w, q[a]*w) averaged over [S][B]; d loss / d q; mean TD error per row."""
+    f = np.float32
+    q = np.asarray(q, f)
+    B, S = np.asarray(actions).shape
+    aq = np.take_along_axis(q[:, :-1, :], np.asarray(actions)[..., None].astype(np.int64), axis=2)[..., 0].T  # [S][B]
+    w = np.asarray(weights, f)[None, :]
+    d = aq * w - target * w
+    ad = np.abs(d)
+    loss = f(np.mean(np.where(ad < 1, 0.5 * d * d, ad - 0.5), dtype=np.float64))
+    g = np.where(ad < 1, d, np.sign(d)) * w / f(S * B)
+    grad = np.zeros_like(q)
+    np.put_along_axis(grad[:, :-1, :], np.asarray(actions)[..., None].astype(np.int64), g.T[..., None], axis=2)
+    return loss, grad, np.mean(aq - target, axis=0)

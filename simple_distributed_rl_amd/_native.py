@@ -90,6 +90,7 @@ SIGNATURES = {
     "srlx_ngu_counts": (c_int, [c_p, ctypes.POINTER(c_p)]),
     "srlx_ngu_episodic_reward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_ngu_lifelong_reward": (c_int, [c_i64, c_int, c_p, c_p, c_f64, c_p, c_p]),
+    "srlx_agent57_seq_td": (c_int, [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_agent57_priority": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
 }
 OBS_U8, OBS_F32 = 0, 1

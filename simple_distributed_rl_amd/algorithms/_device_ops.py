@@ -71,10 +71,11 @@ class TdOps:
         self._keep2 = keep
         return out
 
-    def agent57_priority(self, target_ext, q_ext, target_int, q_int, actions, actor_idx, beta_list):
+    def agent57_priority(self, target_ext, q_ext, target_int, q_int, actions, actor_idx, beta_list, n_actions=None):
         """|td_ext + beta[actor] * td_int| with td = target - q[action] (agent57_light/model_torch.py:442,367-373);
-        returns (td_ext, td_int or None, priorities)."""
-        B, A = q_ext.shape
+        q_ext=None: target_ext / target_int already are TD errors (Agent57's sequence means).
+        Returns (td_ext, td_int or None, priorities)."""
+        B, A = (q_ext.shape if q_ext is not None else (target_ext.shape[0], n_actions))
         d = self.dev
         pri = torch.empty(B, dtype=torch.float32, device=d)
         td_e = torch.empty(B, dtype=torch.float32, device=d)

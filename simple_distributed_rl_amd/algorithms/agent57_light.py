@@ -300,8 +300,8 @@ class Trainer(RLTrainer):
 class UcbMetaController:
     """Sliding-window UCB over the actor (beta, epsilon, gamma) family, agent57_light.py:317-353."""
 
-    def __init__(self, actor_num: int, window_size: int, epsilon: float, beta: float):
-        self.actor_num, self.window_size, self.epsilon, self.beta = actor_num, window_size, epsilon, beta
+    def __init__(self, actor_num: int, window_size: int, epsilon: float, beta: float, tie_break=funcs.get_random_max_index):
+        self.actor_num, self.window_size, self.epsilon, self.beta, self.tie_break = actor_num, window_size, epsilon, beta, tie_break
         self.actor_index = -1
         self.recent: List[tuple] = []
         self.count = [1] * actor_num  # every arm counts as tried once
@@ -323,7 +323,7 @@ class UcbMetaController:
             self.actor_index = random.randint(0, self.actor_num - 1)
         else:
             ucbs = [self.reward[i] / self.count[i] + self.beta * np.sqrt(np.log(n_recent) / self.count[i]) for i in range(self.actor_num)]
-            self.actor_index = funcs.get_random_max_index(ucbs)
+            self.actor_index = self.tie_break(ucbs)
         return self.actor_index
 
 

@@ -230,16 +230,119 @@ __global__ void __launch_bounds__(256) k_agent57_priority(i64 B, int A, const fl
                                                           float *td_ext_out, float *td_int_out, float *pri) {
     const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int a = actions[b];
-    const float te = target_ext[b] - q_ext[b * A + a];  // model_torch.py:442
+    // q_ext == NULL: target_ext / target_int already hold the TD errors (Agent57's sequence means, agent57/model_torch.py:388-391)
+    const int a = actions ? actions[b] : 0;
+    const float te = q_ext ? target_ext[b] - q_ext[b * A + a] : target_ext[b];  // agent57_light/model_torch.py:442
     float p = te;
     if (target_int) {
-        const float ti = target_int[b] - q_int[b * A + a];
+        const float ti = q_int ? target_int[b] - q_int[b * A + a] : target_int[b];
         p = te + beta_list[actor_idx[b]] * ti;  // :371-372
         if (td_int_out) td_int_out[b] = ti;
     }
     if (td_ext_out) td_ext_out[b] = te;
     pri[b] = fabsf(p);
+}
+
+// ------------------------------------------------------------------------------------------
+// Agent57 (R2D2-style) sequence retrace target + Huber loss + gradient seed + TD means in one launch:
+// srl/algorithms/agent57/agent57.py:301-379 (calc_target_q) and model_torch.py:469-492 (_train_q after the
+// forwards).  One thread per batch row walks its sequence (S <= 1024); float32 arithmetic in numpy's order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float signf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ float rescaling(float x) { return signf(x) * (f_sqrt(fabsf(x) + 1.0f) - 1.0f) + 0.001f * x; }
+__device__ __forceinline__ float inverse_rescaling(float x) {
+    float n = f_sqrt(1.0f + (float)(4.0 * 0.001) * ((fabsf(x) + 1.0f) + 0.001f)) - 1.0f;
+    n = n / (float)(2.0 * 0.001);
+    return signf(x) * ((n * n) - 1.0f);
+}
+
+struct SeqArgs {
+    i64 B;
+    int S, A;
+    const float *q, *q_target;  // [B][S+1][A]
+    const int32_t *actions;     // [B][S]
+    const float *rewards, *dones;  // [B][S]; dones = 0 after a terminal step, else 1
+    const u8 *invalid;          // [B][S][A] for the S "next" positions, or NULL
+    const float *discounts, *weights;  // [B]
+    double retrace_h;
+    int double_dqn, rescale;
+    float *target;   // [S][B]
+    float *loss;     // [1]
+    float *grad_q;   // [B][S+1][A]
+    float *td_mean;  // [B]  mean_t(action_q - target)
+    float *scratch;  // [B][S] gains, then reused
+    u8 *pi;          // [B][S]
+};
+
+__global__ void __launch_bounds__(256) k_agent57_seq_td(SeqArgs a) {
+    __shared__ float red[256];
+    const int S = a.S, A = a.A;
+    float loss_part = 0.f;
+    const float inv_n = 1.0f / (float)(a.B * S);
+    for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += (i64)gridDim.x * blockDim.x) {
+        const float *q = a.q + b * (S + 1) * A, *qt = a.q_target + b * (S + 1) * A;
+        float *gq = a.grad_q + b * (S + 1) * A;
+        for (int i = 0; i < (S + 1) * A; i++) gq[i] = 0.f;
+        const float disc = a.discounts[b], w = a.weights[b];
+        float *gains = a.scratch + b * S;
+        u8 *pi = a.pi + b * S;
+        for (int t = 0; t < S; t++) {  // agent57.py:317-341
+            const float *nq = q + (t + 1) * A, *nqt = qt + (t + 1) * A;
+            const u8 *inv = a.invalid ? a.invalid + (b * S + t) * A : nullptr;
+            const float *sel = a.double_dqn ? nq : nqt;
+            int best = 0;
+            float bv = 0.f;
+            for (int k = 0; k < A; k++) {
+                const float v = (inv && inv[k]) ? -INFINITY : sel[k];
+                if (k == 0 || v > bv) {
+                    best = k;
+                    bv = v;
+                }
+            }
+            float maxq = (!a.double_dqn && inv && inv[best]) ? -INFINITY : nqt[best];
+            if (a.rescale) maxq = inverse_rescaling(maxq);
+            float g = a.rewards[b * S + t] + (a.dones[b * S + t] * disc) * maxq;
+            if (a.rescale) g = rescaling(g);
+            gains[t] = g;
+            pi[t] = a.actions[b * S + t] == best;  // :351
+        }
+        // retrace_seq[t] and discounts_seq[t] are needed back to front: precompute the products forward (:355-366)
+        // coef[t] = retrace_seq[t] * discounts_seq[t]; stored over the `target` column of this row temporarily
+        float retrace = 1.0f, dseq = disc;
+        for (int t = 0; t < S; t++) {
+            a.target[(i64)t * a.B + b] = retrace * dseq;
+            if (t + 1 < S) {
+                retrace = (float)((double)retrace * (a.retrace_h * (pi[t] ? 1.0 : 0.0)));  // float32 *= float64 array
+                dseq = dseq * disc;
+            }
+        }
+        float next_td = 0.f;
+        for (int t = S - 1; t >= 0; t--) {  // :369-376
+            const float coef = a.target[(i64)t * a.B + b];
+            const float aq = q[t * A + a.actions[b * S + t]];
+            const float tq = gains[t] + coef * next_td;
+            a.target[(i64)t * a.B + b] = tq;
+            next_td = tq - aq;
+            // HuberLoss(target*w, action_q*w), delta = 1, mean over S*B (model_torch.py:483)
+            const float d = aq * w - tq * w;
+            const float ad = fabsf(d);
+            loss_part += ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
+            const float dl = ad < 1.0f ? d : signf(d);
+            gq[t * A + a.actions[b * S + t]] += inv_n * dl * w;
+            gains[t] = aq - tq;
+        }
+        // np.mean(action_q - target, axis=0) of a C-contiguous [S][B] array: rows are added in order t = 0..S-1 (model_torch.py:491)
+        float td_sum = 0.f;
+        for (int t = 0; t < S; t++) td_sum = td_sum + gains[t];
+        a.td_mean[b] = td_sum / (float)S;
+    }
+    red[threadIdx.x] = loss_part;
+    __syncthreads();
+    for (int s2 = blockDim.x >> 1; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(a.loss, red[0] * inv_n);
 }
 
 }  // namespace
@@ -341,10 +444,44 @@ int srlx_ngu_lifelong_reward(int64_t n, int dim, const float *d_target, const fl
 int srlx_agent57_priority(int64_t batch, int n_actions, const float *d_target_ext, const float *d_q_ext, const float *d_target_int, const float *d_q_int,
                           const int32_t *d_actions, const int32_t *d_actor_idx, const float *d_beta_list, float *d_td_ext, float *d_td_int, float *d_priorities,
                           void *stream) {
-    SRLX_REQUIRE(batch > 0 && n_actions > 0 && d_target_ext && d_q_ext && d_actions && d_priorities, "agent57_priority: bad argument");
-    SRLX_REQUIRE(!d_target_int || (d_q_int && d_actor_idx && d_beta_list), "agent57_priority: intrinsic inputs incomplete");
+    SRLX_REQUIRE(batch > 0 && n_actions > 0 && d_target_ext && d_priorities && (!d_q_ext || d_actions), "agent57_priority: bad argument");
+    SRLX_REQUIRE(!d_target_int || (d_actor_idx && d_beta_list && (!d_q_ext) == (!d_q_int)), "agent57_priority: intrinsic inputs incomplete");
     hipLaunchKernelGGL(k_agent57_priority, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (i64)batch, n_actions, d_target_ext, d_q_ext,
                        d_target_int, d_q_int, d_actions, d_actor_idx, d_beta_list, d_td_ext, d_td_int, d_priorities);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_agent57_seq_td(int64_t batch, int seq_len, int n_actions, const float *d_q, const float *d_q_target, const int32_t *d_actions,
+                        const float *d_rewards, const float *d_dones, const uint8_t *d_invalid_next, const float *d_discounts, const float *d_weights,
+                        double retrace_h, int enable_double_dqn, int enable_rescale, float *d_target, float *d_loss, float *d_grad_q, float *d_td_mean,
+                        float *d_scratch, void *stream) {
+    SRLX_REQUIRE(batch > 0 && seq_len >= 1 && n_actions >= 1, "agent57_seq_td: bad sizes");
+    SRLX_REQUIRE(d_q && d_q_target && d_actions && d_rewards && d_dones && d_discounts && d_weights && d_target && d_loss && d_grad_q && d_td_mean && d_scratch,
+                 "agent57_seq_td: NULL argument");
+    SeqArgs a{};
+    a.B = batch;
+    a.S = seq_len;
+    a.A = n_actions;
+    a.q = d_q;
+    a.q_target = d_q_target;
+    a.actions = d_actions;
+    a.rewards = d_rewards;
+    a.dones = d_dones;
+    a.invalid = d_invalid_next;
+    a.discounts = d_discounts;
+    a.weights = d_weights;
+    a.retrace_h = retrace_h;
+    a.double_dqn = enable_double_dqn;
+    a.rescale = enable_rescale;
+    a.target = d_target;
+    a.loss = d_loss;
+    a.grad_q = d_grad_q;
+    a.td_mean = d_td_mean;
+    a.scratch = d_scratch;
+    a.pi = (u8 *)(d_scratch + batch * seq_len);
+    SRLX_HIP(hipMemsetAsync(d_loss, 0, sizeof(float), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_agent57_seq_td, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

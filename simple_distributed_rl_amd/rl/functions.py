@@ -78,3 +78,35 @@ def create_fancy_index_for_invalid_actions(idx_list: List[List[int]]):
     idx1 = [i for i, sub in enumerate(idx_list) for _ in sub]
     idx2 = [e for sub in idx_list for e in sub]
     return idx1, idx2
+
+
+def random_choice_by_probs(probs, total=None):
+    """Roulette selection with ONE `random.random()` draw (srl/rl/functions.py:183-194)."""
+    if total is None:
+        total = sum(probs)
+    r = random.random() * total
+    acc = 0
+    for i, weight in enumerate(probs):
+        acc += weight
+        if r <= acc:
+            return i
+    raise ValueError(f"not coming. total: {total}, r: {r}, num: {acc}, probs: {probs}")
+
+
+def calc_epsilon_greedy_probs(q, invalid_actions, epsilon, action_num):
+    """epsilon-greedy as a probability vector: epsilon spread over the valid actions, the rest over the
+    (possibly tied) maxima (srl/rl/functions.py:197-214)."""
+    qv = np.array([(-np.inf if a in invalid_actions else v) for a, v in enumerate(q)])
+    q_max = np.amax(qv, axis=0)
+    n_max = np.count_nonzero(qv == q_max)
+    n_valid = action_num - len(invalid_actions)
+    probs = []
+    for a in range(action_num):
+        if a in invalid_actions:
+            probs.append(0.0)
+            continue
+        p = epsilon / n_valid
+        if qv[a] == q_max:
+            p += (1 - epsilon) / n_max
+        probs.append(p)
+    return probs

@@ -90,3 +90,83 @@ def test_plugin_registered_with_reference_compatible_networks():
     data = param.backup(serialized=True)
     assert len(data) == 5 and all(v.device.type == "cpu" for sd in data for v in sd.values())
     param.restore(data, from_serialized=True)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Agent57 (LSTM, sequence replay), SURVEY 8 a19
+# ------------------------------------------------------------------------------------------------------
+import glob  # noqa: E402
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "agent57_target_*.npz"))), ids=lambda p: os.path.basename(p)[15:-4])
+def test_oracle_agent57_sequence_target_matches_reference(path):
+    """agent57.py:301-379 on scripted Q tensors (double / single, rescale, invalid actions, retrace_h < 1, S = 1): bit-equal."""
+    z = np.load(path)
+    got = H.agent57_seq_target(z["q"], z["q_target"], z["actions"], z["rewards"], z["dones"], z["invalid"], z["discounts"], float(z["retrace_h"]),
+                               bool(z["double_dqn"]), bool(z["rescale"]))
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got, z["target"])
+
+
+def _agent57_runner(z, intrinsic, device="CPU", **env_kw):
+    import simple_distributed_rl_amd as srl
+    from simple_distributed_rl_amd.algorithms import agent57
+    from simple_distributed_rl_amd.base.env import registration
+    from test_plugin_surface import TinyImg  # noqa: F401
+
+    registration.register("TinyImg", "test_plugin_surface:TinyImg", check_duplicate=False)
+    rl = agent57.Config(batch_size=8, actor_num=4, target_model_update_interval=5, lr_ext=0.001, lr_int=0.002, lstm_units=16, burnin=2, sequence_length=3,
+                        enable_intrinsic_reward=intrinsic)
+    rl.window_length = 1
+    rl.memory.capacity, rl.memory.warmup_size, rl.memory.compress = 1000, 8, False
+    rl.hidden_block.set_dueling_network((16,))
+    if device == "CPU":
+        rl.memory.set_replay_buffer()
+    runner = srl.Runner(srl.EnvConfig("TinyImg", kwargs=env_kw), rl)
+    runner.set_device(device)
+    return runner, rl
+
+
+def test_agent57_worker_items_match_reference_rollout():
+    """The sequence items the worker emits for a recorded trajectory (window of burnin + seq + 1 steps shifted per step,
+    dummy-state padding after the episode end, recurrent states captured at the window head, round-robin actor
+    choice) equal the reference's own emitted items (rollout_items_agent57.npz).  Actions are epsilon-greedy draws and
+    do not feed the networks (input_action=False): states, rewards, flags, actors and LSTM states must agree."""
+    import torch
+
+    z = np.load(os.path.join(GOLDEN, "rollout_items_agent57.npz"))
+    runner, rl = _agent57_runner(z, intrinsic=False, ep_len=4, seed=13)
+    runner.set_seed(int(z["seed"]))
+    param = runner.make_parameter()
+    for name, net, tgt in (("q_ext", param.q_ext_online, param.q_ext_target), ("q_int", param.q_int_online, param.q_int_target)):
+        sd = {k[len(name) + 1:]: torch.tensor(z[k]) for k in z.files if k.startswith(name + ".")}
+        assert set(sd) == set(net.state_dict()), name  # the reference's state_dict keys
+        net.load_state_dict(sd)
+        tgt.load_state_dict(sd)
+    runner.rollout(max_steps=14)
+    frames = np.array([l[0] for l in runner.env.unwrapped.log], np.uint8)
+    np.testing.assert_array_equal(frames, z["frames"][: len(frames)])  # same environment trajectory
+    items = runner.memory.memory.memory
+    n = len(items)
+    assert n == len(z["item_actor"])
+    np.testing.assert_array_equal(np.array([np.asarray(it[0], np.float32) for it in items]), z["item_states"])
+    np.testing.assert_array_equal(np.array([it[2] for it in items], np.float32), z["item_rewards_ext"])
+    np.testing.assert_array_equal(np.array([it[3] for it in items], np.float32), z["item_rewards_int"])
+    np.testing.assert_array_equal(np.array([it[4] for it in items], np.float32), z["item_dones"])
+    np.testing.assert_array_equal(np.array([it[5] for it in items], np.int32), z["item_actor"])
+    for key, col, part in (("item_h_ext", 7, 0), ("item_c_ext", 7, 1), ("item_h_int", 8, 0), ("item_c_int", 8, 1)):
+        np.testing.assert_allclose(np.array([it[col][part] for it in items], np.float32), z[key], rtol=1e-5, atol=1e-6, err_msg=key)
+    acts = np.array([np.argmax(np.asarray(it[1]), axis=1) for it in items])
+    assert acts.shape == z["item_actions"].shape and acts.min() >= 0 and acts.max() < 4
+
+
+def test_agent57_networks_carry_reference_keys():
+    import simple_distributed_rl_amd  # noqa: F401
+
+    z = np.load(os.path.join(GOLDEN, "train_step_agent57.npz"))
+    runner, rl = _agent57_runner(z, intrinsic=True)
+    param = runner.make_parameter()
+    nets = dict(q_ext=param.q_ext_online, q_int=param.q_int_online, emb=param.emb_network, lifelong_target=param.lifelong_target, lifelong_train=param.lifelong_train)
+    for name, net in nets.items():
+        want = {k[len("before.") + len(name) + 1:]: z[k].shape for k in z.files if k.startswith(f"before.{name}.")}
+        assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == want, name

@@ -219,3 +219,122 @@ def test_agent57_light_runner_end_to_end():
         assert np.isfinite(info[key]), key
     rewards = runner.evaluate(max_episodes=2)
     assert len(rewards) == 2
+
+
+# ------------------------------------------------------------------------------------------------------
+# Agent57 (LSTM, sequence replay), SURVEY 8 a19
+# ------------------------------------------------------------------------------------------------------
+import glob  # noqa: E402
+
+
+def _seq_td(N, lib, torch, dev, q, qt, actions, rewards, dones, invalid, disc, w, h, double_dqn, rescale):
+    B, S1, A = q.shape
+    S = S1 - 1
+    t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)  # noqa: E731
+    ins = [t(q), t(qt), t(actions, torch.int32), t(rewards), t(dones), t(invalid, torch.uint8) if invalid is not None else None, t(disc), t(w)]
+    target, loss = torch.empty((S, B), device=dev), torch.empty(1, device=dev)
+    grad, td, scratch = torch.empty((B, S1, A), device=dev), torch.empty(B, device=dev), torch.empty(2 * B * S, device=dev)
+    N.check(lib.srlx_agent57_seq_td(B, S, A, *[N.tptr(x) for x in ins], float(h), int(double_dqn), int(rescale), N.tptr(target), N.tptr(loss), N.tptr(grad),
+                                    N.tptr(td), N.tptr(scratch), None))
+    torch.cuda.synchronize()
+    return target.cpu().numpy(), float(loss.item()), grad.cpu().numpy(), td.cpu().numpy()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "agent57_target_*.npz"))), ids=lambda p: os.path.basename(p)[15:-4])
+def test_agent57_sequence_td_kernel_matches_reference(path):
+    """srlx_agent57_seq_td vs the reference's recorded calc_target_q (bit-equal, 1e-5 with rescaling) and the oracle's
+    Huber loss / gradient seed / mean TD error."""
+    N, lib, torch, dev = _env()
+    z = np.load(path)
+    rng = np.random.default_rng(1)
+    B = z["q"].shape[0]
+    w = rng.random(B).astype(np.float32)
+    target, loss, grad, td = _seq_td(N, lib, torch, dev, z["q"], z["q_target"], z["actions"], z["rewards"], z["dones"], z["invalid"], z["discounts"], w,
+                                     float(z["retrace_h"]), bool(z["double_dqn"]), bool(z["rescale"]))
+    if bool(z["rescale"]):
+        np.testing.assert_allclose(target, z["target"], rtol=RTOL, atol=1e-6)
+    else:
+        np.testing.assert_array_equal(target, z["target"])
+    o_loss, o_grad, o_td = H.agent57_seq_loss(z["q"], z["target"], z["actions"], w)
+    np.testing.assert_allclose(loss, o_loss, rtol=RTOL)
+    np.testing.assert_allclose(grad, o_grad, rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(td, o_td, rtol=1e-4, atol=2e-6)
+
+
+def test_agent57_sequence_td_atari_shape_vs_oracle():
+    """set_atari_config sizes (batch 64, burn-in 40 + sequence 80, 18 actions) on seeded inputs vs the pinned oracle."""
+    N, lib, torch, dev = _env()
+    rng = np.random.default_rng(2)
+    B, S, A = 64, 80, 18
+    q = rng.standard_normal((B, S + 1, A)).astype(np.float32)
+    qt = (q + 0.2 * rng.standard_normal((B, S + 1, A))).astype(np.float32)
+    actions = np.where(rng.random((B, S)) < 0.7, np.argmax(q[:, 1:], axis=2), rng.integers(0, A, (B, S))).astype(np.int32)
+    rewards, dones = rng.standard_normal((B, S)).astype(np.float32), (rng.random((B, S)) < 0.97).astype(np.float32)
+    disc, w = (0.99 + 0.009 * rng.random(B)).astype(np.float32), rng.random(B).astype(np.float32)
+    target, loss, grad, td = _seq_td(N, lib, torch, dev, q, qt, actions, rewards, dones, None, disc, w, 0.95, True, False)
+    want = H.agent57_seq_target(q, qt, actions, rewards, dones, None, disc, 0.95, True, False)
+    np.testing.assert_array_equal(target, want)
+    o_loss, o_grad, o_td = H.agent57_seq_loss(q, want, actions, w)
+    np.testing.assert_allclose(loss, o_loss, rtol=RTOL)
+    np.testing.assert_allclose(td, o_td, rtol=1e-4, atol=1e-5)
+
+
+def test_agent57_trainer_step_matches_reference_golden():
+    """One full Agent57 Trainer.train() (burn-in, LSTM sequence pass, retrace targets, both Q-networks, embedding, RND,
+    priorities) vs the reference's recorded step on the same weights, batch and stored recurrent states."""
+    N, lib, torch, dev = _env()
+    from simple_distributed_rl_amd.base.context import RunContext
+    from test_agent57_cpu import _agent57_runner
+
+    z = np.load(os.path.join(GOLDEN, "train_step_agent57.npz"))
+    runner, rl = _agent57_runner(z, intrinsic=True, device="cuda:0")
+    param, trainer = runner.parameter, runner.trainer
+    ctx = RunContext(runner.env_config, rl)
+    ctx.setup_device()
+    trainer.setup(ctx)
+    nets = dict(q_ext=param.q_ext_online, q_int=param.q_int_online, q_ext_target=param.q_ext_target, q_int_target=param.q_int_target, emb=param.emb_network,
+                lifelong_target=param.lifelong_target, lifelong_train=param.lifelong_train)
+    for name, net in nets.items():
+        pre = f"before.{name}."
+        net.load_state_dict({k[len(pre):]: torch.tensor(z[k]) for k in z.files if k.startswith(pre)})
+    A, B = int(z["n_actions"]), len(z["actor_idx"])
+    eye = np.identity(A, dtype=int)
+    batches = [[list(z["states"][b]), [eye[a] for a in z["actions"][b]], list(z["rewards_ext"][b]), list(z["rewards_int"][b]), list(z["dones"][b]),
+                int(z["actor_idx"][b]), [[] for _ in range(int(z["sequence_length"]))], [z["h_ext"][b], z["c_ext"][b]], [z["h_int"][b], z["c_int"][b]]]
+               for b in range(B)]
+    rec = {}
+    trainer.memory.sample = lambda *a, **k: (batches, z["weights"], list(range(B)))
+    trainer.memory.update = lambda args, pri, step: rec.update(pri=np.asarray(pri).copy())
+    trainer.train_count = 1
+    trainer.train()
+    np.testing.assert_allclose(trainer.td_ext.cpu().numpy(), z["td_ext"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(trainer.td_int.cpu().numpy(), z["td_int"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(rec["pri"], z["priorities"], rtol=1e-4, atol=2e-6)
+    for key in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"):
+        np.testing.assert_allclose(trainer.info[key], float(z[key]), rtol=RTOL, err_msg=key)
+    for name in ("q_ext", "q_int", "emb", "lifelong_train"):
+        pre = f"after.{name}."
+        sd = nets[name].state_dict()
+        for k in z.files:
+            if k.startswith(pre):
+                got = sd[k[len(pre):]].cpu().numpy()
+                # Adam's first step moves a weight by lr * g / (|g| + 1e-8): at this batch size (8) some gradients are ~1e-8 and a
+                # last-ulp difference becomes a fraction of lr -- bound those by lr / 4 and require them to be rare
+                lr = dict(q_ext=float(z["lr_ext"]), q_int=float(z["lr_int"]), emb=float(z["episodic_lr"]), lifelong_train=float(z["lifelong_lr"]))[name]
+                np.testing.assert_allclose(got, z[k], rtol=1e-5, atol=lr / 4, err_msg=k)
+                assert np.mean(np.abs(got - z[k]) > 5e-6) < 2e-2, k
+
+
+def test_agent57_runner_end_to_end():
+    N, lib, torch, dev = _env()
+    from test_agent57_cpu import _agent57_runner
+
+    runner, rl = _agent57_runner(None, intrinsic=True, device="cuda:0", ep_len=6, seed=1)
+    rl.episodic_memory_capacity = 64
+    runner.set_seed(3)
+    st = runner.train(max_train_count=15)
+    assert st.train_count == 15
+    info = runner.trainer.info
+    for key in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"):
+        assert np.isfinite(info[key]), key
+    assert len(runner.evaluate(max_episodes=2)) == 2

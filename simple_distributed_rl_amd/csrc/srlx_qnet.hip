@@ -133,6 +133,110 @@ struct AU8 {  // uint8 frames addressed through frame_off[sample][Wn] (bytes fro
     }
 };
 
+// ---- conv1 straight from the uint8 frame ring ---------------------------------------------------------
+// The generic implicit GEMM re-gathers every byte of a frame four times from HBM-resident memory and pays the
+// address arithmetic per element; with N = 32 there are only 16 MFMAs per K-slab to hide that behind (measured:
+// 200 us at 1024 samples = 24 % of the matrix-core peak).  Here ONE workgroup owns ONE sample: its window of
+// frames is staged once into LDS (uint8, replicate padding materialised: 88 x 88 per frame), the 32 x 256 filter
+// matrix next to it, and every A fragment is two 8-byte LDS reads + 16 exact u8/255 conversions in registers.
+// Fragment order: slab (frame c, kernel rows kyb..kyb+3); lane (i, h) holds rows kyb + 2h, kyb + 2h + 1, kx = 0..7,
+// i.e. k = c*64 + kyb*8 + 16h + s -- the same 16 contiguous floats of the [32][256] weight row for B.
+constexpr int kC1Pad = 88;                     // padded frame side: 4*20 + 8
+constexpr int kC1Frame = kC1Pad * kC1Pad;      // bytes per staged frame
+constexpr int kC1WStride = 260;                // floats per staged weight row (256 + 4: conflict-free b128 reads)
+
+__global__ void __launch_bounds__(256) k_conv1_u8(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, int Wn, int H, int W, int OH, int OW,
+                                                  const float *__restrict__ w1, const float *__restrict__ b1, float *__restrict__ act1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *ws = reinterpret_cast<float *>(smem);                 // [32][kC1WStride]
+    u8 *fr = smem + 32 * kC1WStride * sizeof(float);             // [Wn][88][88]
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const i64 b = blockIdx.x;
+    const int K = Wn * 64;
+    for (int idx = t; idx < 32 * (K / 4); idx += 256) {  // weights: float4 granularity
+        const int n = idx / (K / 4), q = idx % (K / 4);
+        *reinterpret_cast<float4 *>(ws + n * kC1WStride + 4 * q) = *reinterpret_cast<const float4 *>(w1 + (i64)n * K + 4 * q);
+    }
+    // frames: padded dword (row r, dword d) covers padded columns 4d..4d+3 = image columns clamp(4d - 3 .. 4d), image row
+    // clamp(r - 3).  The ring lives in HBM: all loads of a frame are issued before the first LDS store (8 in flight per
+    // lane), each is ONE in-bounds unaligned dword whose bytes are re-picked at the left / right border.
+    constexpr int kPer = (kC1Pad * (kC1Pad / 4) + 255) / 256;  // 8 dwords per lane per frame
+    for (int c = 0; c < Wn; c++) {
+        const i64 off = frame_off[b * Wn + c];
+        unsigned *dst = reinterpret_cast<unsigned *>(fr + c * kC1Frame);
+        unsigned v[kPer];
+        int xs[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int idx = t + 256 * j;
+            v[j] = 0u;
+            xs[j] = 0;
+            if (off >= 0 && idx < kC1Pad * (kC1Pad / 4)) {
+                const int r = idx / (kC1Pad / 4), d = idx % (kC1Pad / 4);
+                xs[j] = clampi(4 * d - 3, 0, W - 4);
+                __builtin_memcpy(&v[j], base + off + (i64)clampi(r - 3, 0, H - 1) * W + xs[j], 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int idx = t + 256 * j;
+            if (idx >= kC1Pad * (kC1Pad / 4)) continue;
+            const int x = 4 * (idx % (kC1Pad / 4)) - 3;
+            unsigned o = v[j];
+            if (off >= 0 && x != xs[j]) {  // border: column clamp(x + q) sits at byte clamp(x + q) - xs of the loaded dword
+                o = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) o |= ((v[j] >> (8 * (clampi(x + q, 0, W - 1) - xs[j]))) & 255u) << (8 * q);
+            }
+            dst[idx] = o;
+        }
+    }
+    __syncthreads();
+    const int h = lane >> 5, i = lane & 31;
+    const int M = OH * OW, tiles = (M + 31) / 32;
+    const float bias = b1[i];
+    for (int tile = wave; tile < tiles; tile += 4) {
+        const int m = tile * 32 + i < M ? tile * 32 + i : M - 1;
+        const int oy = m / OW, ox = m % OW;
+        const u8 *win = fr + (4 * oy + 2 * h) * kC1Pad + 4 * ox;  // this lane's first kernel row inside a slab
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        for (int c = 0; c < Wn; c++) {
+#pragma unroll
+            for (int kyb = 0; kyb < 8; kyb += 4) {
+                const u8 *p = win + c * kC1Frame + kyb * kC1Pad;
+                unsigned w[4];
+                w[0] = *reinterpret_cast<const unsigned *>(p);
+                w[1] = *reinterpret_cast<const unsigned *>(p + 4);
+                w[2] = *reinterpret_cast<const unsigned *>(p + kC1Pad);
+                w[3] = *reinterpret_cast<const unsigned *>(p + kC1Pad + 4);
+                float bf[16];
+                const float *wp = ws + i * kC1WStride + c * 64 + kyb * 8 + 16 * h;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const float4 x = *reinterpret_cast<const float4 *>(wp + 4 * v);
+                    bf[4 * v] = x.x, bf[4 * v + 1] = x.y, bf[4 * v + 2] = x.z, bf[4 * v + 3] = x.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 16; s++) {
+                    const float a = byte_to_unit((w[s >> 2] >> (8 * (s & 3))) & 255u);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s], acc, 0, 0, 0);
+                }
+            }
+        }
+        // C/D layout of the 32x32 MFMA: col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 h (pixel)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mm = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mm < M) {
+                const float v = acc[r] + bias;
+                act1[(b * M + mm) * 32 + i] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+}
+
 // ---- the GEMM ------------------------------------------------------------------------------------------
 template <class AL, int BN, bool RELU, bool SPLITK>
 __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ Bw, const float *__restrict__ bias, float *__restrict__ C, i64 M, int N,
@@ -421,8 +525,15 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
     SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_u8: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
-    AU8 c1{d_frame_base, d_frame_off, h->Wn, h->H, h->W, 4, 3, h->OH1, h->OW1};
-    launch_gemm<AU8, 32, true, false>(c1, h->w1, h->b1, h->act1, batch * h->OH1 * h->OW1, h->F1, h->Wn * 64, 1, st);
+    const size_t lds = 32 * kC1WStride * sizeof(float) + (size_t)h->Wn * kC1Frame;
+    if (h->F1 == 32 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && 4 * (h->OW1 - 1) + 8 <= kC1Pad && lds <= 64 * 1024 && h->W % 4 == 0) {
+        // one workgroup per sample, frames + filters staged in LDS
+        hipLaunchKernelGGL(k_conv1_u8, dim3((unsigned)batch), dim3(256), lds, st, d_frame_base, d_frame_off, h->Wn, h->H, h->W, h->OH1, h->OW1, h->w1, h->b1,
+                           h->act1);
+    } else {
+        AU8 c1{d_frame_base, d_frame_off, h->Wn, h->H, h->W, 4, 3, h->OH1, h->OW1};
+        launch_gemm<AU8, 32, true, false>(c1, h->w1, h->b1, h->act1, batch * h->OH1 * h->OW1, h->F1, h->Wn * 64, 1, st);
+    }
     return run_tail(h, batch, d_q, st);
 }
 

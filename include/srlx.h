@@ -350,6 +350,16 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
 int srlx_qnet_destroy(srlx_qnet_t *h);
 int srlx_qnet_bind(srlx_qnet_t *h, const float *const *d_params);
 int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, void *stream);
+/* Training on the vectorised path (replaces `loss.backward()` + the framework forward it needs,
+ * srl/algorithms/rainbow/model_torch.py:103-109):
+ *   srlx_qnet_enable_training : from now on every forward keeps its post-ReLU hidden layer, and gradient scratch for up
+ *       to max_train_batch (<= 64) samples is allocated.  Covers the DQN image block with 32 filters, dueling "average"/"".
+ *   srlx_qnet_backward_u8     : given d loss / d Q  f32 [batch][n_actions] for the samples at rows 0, stride, 2*stride, ...
+ *       of the LAST srlx_qnet_forward_u8 on this handle (same d_frame_base / d_frame_off), writes every parameter
+ *       gradient into d_grads[12] (same order and memory layouts as srlx_qnet_bind: the torch parameters' own layouts). */
+int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch);
+int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off,
+                          const float *d_grad_q, float *const *d_grads, void *stream);
 int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream);
 
 #ifdef __cplusplus

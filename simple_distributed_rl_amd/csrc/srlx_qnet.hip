@@ -31,7 +31,7 @@
 // prefetch of the next K-slab overlaps the 16 MFMAs of the current one.
 #include <new>
 
-#include "srlx_common.h"
+#include "srlx_qnet_int.h"
 
 namespace {
 
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
 constexpr int kMaxActions = 32;
 __global__ void __launch_bounds__(256) k_head(const float *__restrict__ partial, int splits, i64 M, int hidden, const float *__restrict__ b1,
                                               const float *__restrict__ v2w, const float *__restrict__ v2b, const float *__restrict__ a2w,
-                                              const float *__restrict__ a2b, int A, int dueling, float *__restrict__ q) {
+                                              const float *__restrict__ a2b, int A, int dueling, float *__restrict__ q, float *__restrict__ h1) {
     __shared__ float red[4][kMaxActions + 1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const i64 m = blockIdx.x;
@@ -337,6 +337,10 @@ __global__ void __launch_bounds__(256) k_head(const float *__restrict__ partial,
         }
         hv = hv > 0.f ? hv : 0.f;
         ha = ha > 0.f ? ha : 0.f;
+        if (h1) {  // training: the backward pass needs the hidden layer
+            h1[m * N1 + u] = hv;
+            h1[m * N1 + hidden + u] = ha;
+        }
         v += hv * v2w[u];
 #pragma unroll
         for (int j = 0; j < kMaxActions; j++)
@@ -402,17 +406,6 @@ struct ANchw {
 
 }  // namespace
 
-struct srlx_qnet {
-    int device;
-    int H, W, Wn, F1, hidden, A, dueling;
-    int OH1, OW1, OH2, OW2, OH3, OW3;
-    i64 max_batch;
-    int flat;  // OH3*OW3*2*F1
-    const float *w1, *b1, *w2, *b2, *w3, *b3, *wf, *bf, *v2w, *v2b, *a2w, *a2b;  // BORROWED: the torch parameters themselves
-    float *act1, *act2, *act3, *partial;
-    int max_splits;
-};
-
 namespace {
 int conv_out(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
@@ -448,7 +441,7 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     const int kps = ((ksteps + splits - 1) / splits);
     const int used = (ksteps + kps - 1) / kps;  // splits that actually own a K range
     hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(256), 0, st, h->partial, used, B, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
-                       h->a2b, h->A, h->dueling, d_q);
+                       h->a2b, h->A, h->dueling, d_q, h->h1);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }
@@ -504,7 +497,7 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     if (!h) return SRLX_OK;
     srlx::DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    float *all[] = {h->act1, h->act2, h->act3, h->partial};
+    float *all[] = {h->act1, h->act2, h->act3, h->partial, h->h1, h->dh1, h->dact3, h->dact2, h->dact1, h->fc_part, h->w_part};
     for (float *p : all)
         if (p) (void)hipFree(p);
     delete h;

@@ -1,0 +1,21 @@
+// srlx_qnet_int.h -- the srlx_qnet handle shared by the forward (srlx_qnet.hip) and backward (srlx_qnet_bwd.hip) kernels.
+#pragma once
+#include "srlx_common.h"
+
+struct srlx_qnet {
+    int device;
+    int H, W, Wn, F1, hidden, A, dueling;
+    int OH1, OW1, OH2, OW2, OH3, OW3;
+    int64_t max_batch;
+    int flat;  // OH3*OW3*2*F1
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *wf, *bf, *v2w, *v2b, *a2w, *a2b;  // BORROWED: the torch parameters themselves
+    float *act1, *act2, *act3, *partial;
+    int max_splits;
+    // training (srlx_qnet_enable_training): post-ReLU hidden layer of every forward row + gradient scratch
+    int64_t max_train;
+    float *h1;                            // [max_batch][2*hidden]
+    float *dh1, *dact3, *dact2, *dact1;   // [max_train][...]
+    float *fc_part;                       // [kFcSplits][max_train][flat]
+    float *w_part;                        // weight-gradient partial sums (largest layer)
+    size_t w_part_floats;
+};

@@ -145,6 +145,28 @@ class QNetInference:
         N.check(self.lib.srlx_qnet_bind(self.h, ctypes.cast(arr, N.c_p)))
         self._bound = [p.data_ptr() for p in params]
 
+    def _params(self):
+        n = self.net
+        return [n.conv1.weight, n.conv1.bias, n.conv2.weight, n.conv2.bias, n.conv3.weight, n.conv3.bias, n.fc1.weight, n.fc1.bias,
+                n.v2.weight, n.v2.bias, n.a2.weight, n.a2.bias]
+
+    def enable_training(self, max_train_batch: int):
+        """Allocates the backward scratch and static gradient tensors (`p.grad`, in each parameter's own memory format,
+        so that the fused Adam reads what `backward_u8` writes and both can live in one HIP graph)."""
+        N.check(self.lib.srlx_qnet_enable_training(self.h, int(max_train_batch)))
+        for p in self._params():
+            p.grad = torch.zeros_like(p)  # preserve_format: conv2/conv3 stay channels_last
+        self._grads = [p.grad for p in self._params()]
+        self._grad_arr = (N.c_p * 12)(*[g.data_ptr() for g in self._grads])
+        return self
+
+    def backward_u8(self, frame_base_ptr: int, frame_off: torch.Tensor, grad_q: torch.Tensor, sample_stride: int = 1):
+        """Parameter gradients of sum(q * grad_q) for the samples at rows 0, stride, 2*stride, ... of the last forward_u8."""
+        B = grad_q.shape[0]
+        assert grad_q.is_contiguous() and grad_q.shape[1] == self.n_actions
+        N.check(self.lib.srlx_qnet_backward_u8(self.h, B, int(sample_stride), N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(grad_q),
+                                               ctypes.cast(self._grad_arr, N.c_p), N.torch_stream_ptr()))
+
     def forward_f32(self, obs_nchw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         B = obs_nchw.shape[0]
         q = self.q[:B] if out is None else out

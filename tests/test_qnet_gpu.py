@@ -138,3 +138,39 @@ def test_forward_u8_reads_the_ring_directly():
     np.testing.assert_array_equal(act.cpu().numpy(), oa)
     np.testing.assert_array_equal(rew_t.cpu().numpy(), orw)
     np.testing.assert_array_equal(ter.cpu().numpy(), ot)
+
+
+@pytest.mark.parametrize("A,dueling,B,stride", [(6, "average", 32, 1), (18, "", 32, 4), (6, "average", 5, 3), (4, "average", 64, 2)])
+def test_backward_u8_matches_autograd(A, dueling, B, stride):
+    """srlx_qnet_backward_u8 (hand-written backward of every layer, gradients written in the parameters' own memory
+    layouts) vs torch autograd on the float32 stack of the same uint8 frames, incl. zero-history frames, a row
+    stride (train samples interleaved with no-grad samples in one forward) and replicate-padding borders."""
+    from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference
+
+    torch.manual_seed(3)
+    net = EngineQNet(A, (84, 84), 4, 512, 32, dueling).cuda()
+    rows = B * stride
+    qn = QNetInference(net, max_batch=max(rows, 64)).enable_training(64)
+    F, n_frames = 84 * 84, 300
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ring = torch.randint(0, 256, (n_frames * F,), dtype=torch.uint8, device="cuda", generator=g)
+    sel = torch.randint(0, n_frames, (rows, 4), device="cuda", generator=g)
+    off = sel * F
+    off[torch.rand((rows, 4), device="cuda", generator=g) < 0.1] = -1  # zero history
+    q = qn.forward_u8(ring.data_ptr(), off).clone()
+    frames = ring.view(n_frames, 84, 84)[sel.clamp(min=0)].float() / 255
+    frames = torch.where((off < 0)[..., None, None], torch.zeros_like(frames), frames)
+    net.zero_grad(set_to_none=True)
+    want_q = net(frames, channels_first=True)
+    _close(q, want_q.detach())
+    grad_q = torch.randn((B, A), device="cuda", generator=g)
+    want_q[::stride][:B].backward(grad_q)
+    want = [p.grad.detach().clone() for p in qn._params()]
+    qn.enable_training(64)  # re-creates zeroed static gradient tensors
+    qn.backward_u8(ring.data_ptr(), off, grad_q, sample_stride=stride)
+    torch.cuda.synchronize()
+    names = ["conv1.w", "conv1.b", "conv2.w", "conv2.b", "conv3.w", "conv3.b", "fc1.w", "fc1.b", "v2.w", "v2.b", "a2.w", "a2.b"]
+    for name, p, w in zip(names, qn._params(), want):
+        assert p.grad.stride() == p.stride(), name  # the fused Adam walks parameter and gradient with the same strides
+        scale = float(w.abs().max()) + 1e-12
+        np.testing.assert_allclose(p.grad.cpu().numpy(), w.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg=name)

@@ -23,8 +23,7 @@ using i64 = int64_t;
 using u8 = unsigned char;
 
 constexpr int kFcSplits = 16;   // splits of the hidden dimension in the dense data-gradient
-constexpr int kWgSplits = 16;   // splits of the row dimension in the conv weight-gradients
-constexpr int kMaxPairs = 8;
+constexpr int kWgSplits = 64;   // splits of the row dimension in the conv weight-gradients
 constexpr int kMaxSide = 96;
 constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad, kC1Chunks = 4;
 
@@ -37,7 +36,7 @@ __device__ __forceinline__ float byte_to_unit(unsigned b) {  // u8 / 255, correc
 
 // ---- dueling head + second dense layers (dueling_network.py:43-58) ------------------------------------------
 // one thread per hidden unit u; dq [B][A] (rows `stride` apart in nothing: dq is dense), h1 rows at i*sample_stride
-__global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden, int A, int dueling, const float *__restrict__ dq,
+__global__ void __launch_bounds__(64) k_head_bwd(int B, i64 sstride, int hidden, int A, int dueling, const float *__restrict__ dq,
                                                   const float *__restrict__ h1, const float *__restrict__ v2w, const float *__restrict__ a2w,
                                                   float *__restrict__ dh1, float *__restrict__ g_bf, float *__restrict__ g_v2w, float *__restrict__ g_v2b,
                                                   float *__restrict__ g_a2w, float *__restrict__ g_a2b) {
@@ -57,6 +56,7 @@ __global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden
 #pragma unroll
         for (int j = 0; j < 32; j++) ga[j] = 0.f;
         const float wv = v2w[u];
+#pragma unroll 4
         for (int b = 0; b < B; b++) {
             const float hv = h1[(i64)b * sstride * N1 + u], ha = h1[(i64)b * sstride * N1 + hidden + u];
             gv += dv[b] * hv;
@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(256) k_fc1_wgrad(int B, i64 sstride, int N1, i
     float acc[32];
 #pragma unroll
     for (int j = 0; j < 32; j++) acc[j] = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; b++) {
         const float a = act3[(i64)b * sstride * K + k];
 #pragma unroll
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(256) k_fc1_dgrad(int B, int N1, int K, const f
     float acc[BT];
 #pragma unroll
     for (int b = 0; b < BT; b++) acc[b] = 0.f;
+#pragma unroll 8
     for (int nn = 0; nn < per; nn++) {
         const float w = wf[(i64)(n0 + nn) * K + k];
 #pragma unroll
@@ -158,7 +160,7 @@ struct ConvGeo {
 };
 template <int CI, int CO>
 __global__ void __launch_bounds__(256) k_conv_wgrad(ConvGeo g, int B, i64 sstride, const float *__restrict__ X, const float *__restrict__ dY,
-                                                    float *__restrict__ part) {
+                                                    float *__restrict__ part, float *__restrict__ bias_part /*[split][CO]*/) {
     constexpr int TCI = CI / 16, TCO = CO / 16;
     __shared__ __attribute__((aligned(16))) float sx[16 * CI];
     __shared__ __attribute__((aligned(16))) float sy[16 * CO];
@@ -174,6 +176,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvGeo g, int B, i64 sstrid
     for (int a = 0; a < TCO; a++)
 #pragma unroll
         for (int c = 0; c < TCI; c++) acc[a][c] = 0.f;
+    float bsum = 0.f;  // tap 0, threads < CO: bias gradient of this split (sum of its dY rows)
     for (i64 m0 = m_lo; m0 < m_hi; m0 += 16) {
         for (int idx = t; idx < 16 * CI; idx += 256) {
             const i64 m = m0 + idx / CI;
@@ -190,6 +193,9 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvGeo g, int B, i64 sstrid
             sy[idx] = m < m_hi ? dY[m * CO + idx % CO] : 0.f;
         }
         __syncthreads();
+        if (tap == 0 && t < CO)
+#pragma unroll
+            for (int r = 0; r < 16; r++) bsum += sy[r * CO + t];
 #pragma unroll 4
         for (int r = 0; r < 16; r++) {
             float yv[TCO], xv[TCI];
@@ -209,6 +215,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvGeo g, int B, i64 sstrid
     for (int a = 0; a < TCO; a++)
 #pragma unroll
         for (int c = 0; c < TCI; c++) part[(((i64)split * CO + cg * TCO + a) * taps + tap) * CI + ig * TCI + c] = acc[a][c];
+    if (tap == 0 && t < CO) bias_part[split * CO + t] = bsum;
 }
 
 // out[i] = sum_p part[p][i], fixed order
@@ -216,53 +223,106 @@ __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ 
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int p = 0; p < P; p++) s += part[(i64)p * n + i];
+#pragma unroll 16
+    for (int p = 0; p < P; p++) s += part[(i64)p * n + i];  // loads are independent: 16 in flight, the adds stay in order
     out[i] = s;
 }
 
-// bias gradient: g_b[co] = sum_m dY[m][co]; one workgroup of CO x (256/CO) lanes, fixed order
-__global__ void __launch_bounds__(256) k_bias_grad(const float *__restrict__ dY, i64 M, int CO, float *__restrict__ g_b) {
-    __shared__ float red[256];
-    const int co = threadIdx.x % CO, lane = threadIdx.x / CO, lanes = 256 / CO;
-    float s = 0.f;
-    for (i64 m = lane; m < M; m += lanes) s += dY[m * CO + co];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (lane == 0) {
-        for (int l = 1; l < lanes; l++) s += red[l * CO + co];
-        g_b[co] = s;
-    }
-}
-
 // ---- convolution data gradient through replicate padding ---------------------------------------------------
-// pairs[i][.] lists every (output coordinate o, tap k) with clamp(o*S + k - P) == i (same table for y and x:
-// square layers); dX[b][iy][ix][ci] = [X > 0] * sum over pairs_y x pairs_x x co of dY[b][oy][ox][co] * W[co][ky][kx][ci]
-struct PairTab {
-    unsigned char n[kMaxSide];
-    unsigned char o[kMaxSide][kMaxPairs], k[kMaxSide][kMaxPairs];
+// omap[i][k] lists the output coordinates o with clamp(o*S + k - P) == i (0, 1 or 2 of them; the same table serves
+// y and x: square layers).  dX[b][iy][ix][ci] = [X > 0] * sum_{ky, oy in omap[iy][ky]} sum_{kx, ox in omap[ix][kx]}
+// sum_co dY[b][oy][ox][co] * W[co][ky][kx][ci].
+// workgroup = one input row (b, iy): the <= 4 output rows it touches are staged in LDS; thread = one input channel x a
+// group of columns: the CO filter values of a tap sit in registers and are reused across the thread's columns, dY is a
+// wavefront-wide LDS broadcast.
+struct OutMap {
+    unsigned char n[kMaxSide][8], o0[kMaxSide][8], o1[kMaxSide][8];
 };
+constexpr int kDgNB = 2;    // samples per workgroup: the filter registers of a tap are reused across them
+constexpr int kDgOW = 12;   // staged output-row stride (OW <= 12)
 template <int CI, int CO>
-__global__ void __launch_bounds__(256) k_conv_dgrad(ConvGeo g, i64 sstride, const PairTab *__restrict__ tab, const float *__restrict__ dY,
+__global__ void __launch_bounds__(256) k_conv_dgrad(ConvGeo g, int B, i64 sstride, const OutMap *__restrict__ om_g, const float *__restrict__ dY,
                                                     const float *__restrict__ Wt, const float *__restrict__ X, float *__restrict__ dX) {
-    const int b = blockIdx.x / g.H, iy = blockIdx.x % g.H;
+    constexpr int GROUPS = 256 / CI;  // column groups
+    constexpr int MAXC = 4;           // columns per thread: ceil(21 / 8) = 3, ceil(11 / 4) = 3
+    __shared__ __attribute__((aligned(16))) float sdy[kDgNB * 4 * kDgOW * CO];  // [sample][row slot][ox][co]
+    __shared__ int s_row[4], s_nrow;
+    __shared__ OutMap s_om;  // the map is consulted in the innermost loops: keep it out of global memory
+    const int b0 = (blockIdx.x / g.H) * kDgNB, iy = blockIdx.x % g.H;
+    const int t = threadIdx.x, ci = t % CI, grp = t / CI;
     const int taps = g.KH * g.KW;
-    const int ny = tab->n[iy];
-    for (int idx = threadIdx.x; idx < g.W * CI; idx += 256) {
-        const int ix = idx / CI, ci = idx % CI;
-        const int nx = tab->n[ix];
-        float acc = 0.f;
-        for (int py = 0; py < ny; py++) {
-            const int oy = tab->o[iy][py], ky = tab->k[iy][py];
-            for (int px = 0; px < nx; px++) {
-                const int ox = tab->o[ix][px], kx = tab->k[ix][px];
-                const float *dy = dY + (((i64)b * g.OH + oy) * g.OW + ox) * CO;
-                const float *w = Wt + (i64)(ky * g.KW + kx) * CI + ci;
-#pragma unroll 8
-                for (int co = 0; co < CO; co++) acc += dy[co] * w[(i64)co * taps * CI];
+    for (int idx = t; idx < (int)(sizeof(OutMap) / 4); idx += 256) reinterpret_cast<unsigned *>(&s_om)[idx] = reinterpret_cast<const unsigned *>(om_g)[idx];
+    __syncthreads();
+    const OutMap *om = &s_om;
+    if (t == 0) {  // distinct output rows touched by this input row
+        int nr = 0;
+        for (int ky = 0; ky < g.KH; ky++)
+            for (int q = 0; q < om->n[iy][ky]; q++) {
+                const int oy = q == 0 ? om->o0[iy][ky] : om->o1[iy][ky];
+                bool seen = false;
+                for (int r = 0; r < nr; r++) seen = seen || s_row[r] == oy;
+                if (!seen && nr < 4) s_row[nr++] = oy;
+            }
+        s_nrow = nr;
+    }
+    __syncthreads();
+    const int nrow = s_nrow;
+    const int rowf = g.OW * CO;
+    for (int idx = t; idx < kDgNB * nrow * rowf; idx += 256) {
+        const int nb = idx / (nrow * rowf), r = (idx / rowf) % nrow, rem = idx % rowf;
+        sdy[((nb * 4 + r) * kDgOW) * CO + rem] = b0 + nb < B ? dY[(((i64)(b0 + nb) * g.OH + s_row[r]) * g.OW) * CO + rem] : 0.f;
+    }
+    __syncthreads();
+    float acc[kDgNB][MAXC];
+#pragma unroll
+    for (int nb = 0; nb < kDgNB; nb++)
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) acc[nb][c] = 0.f;
+    for (int ky = 0; ky < g.KH; ky++) {
+        const int ny = om->n[iy][ky];
+        for (int qy = 0; qy < ny; qy++) {
+            const int oy = qy == 0 ? om->o0[iy][ky] : om->o1[iy][ky];
+            int slot = 0;
+            for (int r = 0; r < nrow; r++) slot = s_row[r] == oy ? r : slot;
+            for (int kx = 0; kx < g.KW; kx++) {
+                float w[CO];
+                const float *wp = Wt + (i64)(ky * g.KW + kx) * CI + ci;
+#pragma unroll
+                for (int co = 0; co < CO; co++) w[co] = wp[(i64)co * taps * CI];
+#pragma unroll
+                for (int c = 0; c < MAXC; c++) {
+                    const int ix = grp + c * GROUPS;
+                    if (ix >= g.W) break;
+                    const int nx = om->n[ix][kx];
+                    for (int qx = 0; qx < nx; qx++) {
+                        const int ox = qx == 0 ? om->o0[ix][kx] : om->o1[ix][kx];
+#pragma unroll
+                        for (int nb = 0; nb < kDgNB; nb++) {
+                            const float4 *dy = reinterpret_cast<const float4 *>(sdy + ((nb * 4 + slot) * kDgOW + ox) * CO);
+                            float a = 0.f;
+#pragma unroll
+                            for (int v = 0; v < CO / 4; v++) {
+                                const float4 d = dy[v];
+                                a += d.x * w[4 * v] + d.y * w[4 * v + 1] + d.z * w[4 * v + 2] + d.w * w[4 * v + 3];
+                            }
+                            acc[nb][c] += a;
+                        }
+                    }
+                }
             }
         }
-        const i64 xi = (((i64)b * sstride * g.H + iy) * g.W + ix) * CI + ci;
-        dX[(((i64)b * g.H + iy) * g.W + ix) * CI + ci] = X[xi] > 0.f ? acc : 0.f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < kDgNB; nb++) {
+        const int b = b0 + nb;
+        if (b >= B) break;
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) {
+            const int ix = grp + c * GROUPS;
+            if (ix >= g.W) break;
+            const i64 xi = (((i64)b * sstride * g.H + iy) * g.W + ix) * CI + ci;
+            dX[(((i64)b * g.H + iy) * g.W + ix) * CI + ci] = X[xi] > 0.f ? acc[nb][c] : 0.f;
+        }
     }
 }
 
@@ -270,7 +330,7 @@ __global__ void __launch_bounds__(256) k_conv_dgrad(ConvGeo g, i64 sstride, cons
 // workgroup = (sample, pixel chunk); frames staged like the forward (padded 88 x 88 uint8); thread = one filter tap k
 // (c, ky, kx) accumulating all 32 output channels; part[(b*chunks + chunk)][co][k]
 __global__ void __launch_bounds__(256) k_conv1_wgrad(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, i64 sstride, int Wn, int H, int W, int OH,
-                                                     int OW, const float *__restrict__ dY1, float *__restrict__ part) {
+                                                     int OW, const float *__restrict__ dY1, float *__restrict__ part, float *__restrict__ bias_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u8 *fr = smem;                                                        // [Wn][88][88]
     float *sy = reinterpret_cast<float *>(smem + (size_t)Wn * kC1Frame);  // [pixels of the chunk][32]
@@ -295,6 +355,11 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad(const u8 *__restrict__ base
     }
     for (int idx = t; idx < (p_hi - p_lo) * 32; idx += 256) sy[idx] = dY1[((i64)b * M + p_lo) * 32 + idx];
     __syncthreads();
+    if (t < 32) {  // bias gradient of this (sample, chunk): sum of its dY rows
+        float bs = 0.f;
+        for (int p = 0; p < p_hi - p_lo; p++) bs += sy[p * 32 + t];
+        bias_part[((i64)b * kC1Chunks + chunk) * 32 + t] = bs;
+    }
     const int K = Wn * 64;
     for (int k = t; k < K; k += 256) {
         const int c = k >> 6, ky = (k >> 3) & 7, kx = k & 7;
@@ -316,18 +381,16 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad(const u8 *__restrict__ base
     }
 }
 
-void fill_pairs(PairTab *t, int in_size, int out_size, int K, int S, int P) {
+void fill_outmap(OutMap *t, int in_size, int out_size, int K, int S, int P) {
     memset(t, 0, sizeof(*t));
     for (int o = 0; o < out_size; o++)
-        for (int k = 0; k < K; k++) {
+        for (int k = 0; k < K && k < 8; k++) {
             int i = o * S + k - P;
             i = i < 0 ? 0 : (i > in_size - 1 ? in_size - 1 : i);
-            const int n = t->n[i];
-            if (n < kMaxPairs) {
-                t->o[i][n] = (unsigned char)o;
-                t->k[i][n] = (unsigned char)k;
-                t->n[i] = (unsigned char)(n + 1);
-            }
+            const int n = t->n[i][k];
+            if (n == 0) t->o0[i][k] = (unsigned char)o;
+            if (n == 1) t->o1[i][k] = (unsigned char)o;
+            t->n[i][k] = (unsigned char)(n < 2 ? n + 1 : 2);
         }
 }
 
@@ -339,7 +402,7 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
     SRLX_REQUIRE(h, "qnet_enable_training: NULL handle");
     SRLX_REQUIRE(max_train_batch > 0 && max_train_batch <= 64 && max_train_batch <= h->max_batch, "qnet_enable_training: 1 <= max_train_batch <= 64");
     SRLX_REQUIRE(h->F1 == 32 && h->dueling != 1 && h->H == h->W && h->OH1 <= kMaxSide && h->W % 4 == 0 && (2 * h->hidden) % kFcSplits == 0 &&
-                     2 * h->hidden / kFcSplits <= 64 && 4 * (h->OH1 - 1) + 8 <= kC1Pad,
+                     2 * h->hidden / kFcSplits <= 64 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && h->OW2 <= kDgOW && h->OW3 <= kDgOW,
                  "qnet_enable_training: the backward kernels cover the DQN image block with 32 filters, square frames, hidden <= 512, dueling average / none");
     if (h->max_train >= max_train_batch) return SRLX_OK;
     SRLX_REQUIRE(h->max_train == 0, "qnet_enable_training: already enabled with a smaller batch");
@@ -358,7 +421,7 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
                 {&h->dact2, (size_t)max_train_batch * h->OH2 * h->OW2 * 2 * h->F1},
                 {&h->dact1, (size_t)max_train_batch * h->OH1 * h->OW1 * h->F1},
                 {&h->fc_part, (size_t)kFcSplits * max_train_batch * h->flat},
-                {&h->w_part, wp + sizeof(PairTab) * 2 / sizeof(float) + 64}};
+                {&h->w_part, wp + sizeof(OutMap) * 2 / sizeof(float) + 64 + 2 * kWgSplits * 64 + 64 * kC1Chunks * 32}};
     for (auto &b : bufs) {
         hipError_t e = hipMalloc((void **)b.p, b.n * sizeof(float));
         if (e != hipSuccess) {
@@ -367,9 +430,9 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
         }
     }
     // pair tables of the two data-gradient layers live behind the partial-sum scratch
-    PairTab host[2];
-    fill_pairs(&host[0], h->OH2, h->OH3, 3, 1, 1);  // conv3: input act2 (OH2), output OH3
-    fill_pairs(&host[1], h->OH1, h->OH2, 4, 2, 2);  // conv2: input act1 (OH1), output OH2
+    OutMap host[2];
+    fill_outmap(&host[0], h->OH2, h->OH3, 3, 1, 1);  // conv3: input act2 (OH2), output OH3
+    fill_outmap(&host[1], h->OH1, h->OH2, 4, 2, 2);  // conv2: input act1 (OH1), output OH2
     SRLX_HIP(hipMemcpy(h->w_part + wp, host, sizeof(host), hipMemcpyHostToDevice));
     h->max_train = max_train_batch;
     return SRLX_OK;
@@ -388,10 +451,11 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     const i64 ss = sample_stride;
     float *g_w1 = g[0], *g_b1 = g[1], *g_w2 = g[2], *g_b2 = g[3], *g_w3 = g[4], *g_b3 = g[5], *g_wf = g[6], *g_bf = g[7], *g_v2w = g[8], *g_v2b = g[9], *g_a2w = g[10],
           *g_a2b = g[11];
-    const PairTab *tabs = reinterpret_cast<const PairTab *>(h->w_part + h->w_part_floats);
+    const OutMap *tabs = reinterpret_cast<const OutMap *>(h->w_part + h->w_part_floats);
+    float *bias_part = h->w_part + h->w_part_floats + (2 * sizeof(OutMap) + sizeof(float) - 1) / sizeof(float);  // [splits][CO] partial bias sums
 
     // head + second layers -> dh1 (masked by the first layer's ReLU), bias gradient of the first layer
-    hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((h->hidden + 255) / 256)), dim3(256), (size_t)(B + B * A) * sizeof(float), st, B, ss, h->hidden, A, h->dueling,
+    hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((h->hidden + 63) / 64)), dim3(64), (size_t)(B + B * A) * sizeof(float), st, B, ss, h->hidden, A, h->dueling,
                        d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
     // first dense layer
     hipLaunchKernelGGL(k_fc1_wgrad, dim3((unsigned)((K + 255) / 256), (unsigned)(N1 / 32)), dim3(256), 0, st, B, ss, N1, K, h->dh1, h->act3, g_wf);
@@ -403,27 +467,24 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     // conv3: 3x3 stride 1 pad 1, act2 -> act3
     const int C2 = 2 * h->F1;
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
-    const i64 M3 = (i64)B * h->OH3 * h->OW3;
-    hipLaunchKernelGGL((k_conv_wgrad<64, 64>), dim3(9, kWgSplits), dim3(256), 0, st, g3, B, ss, h->act2, h->dact3, h->w_part);
+    hipLaunchKernelGGL((k_conv_wgrad<64, 64>), dim3(9, kWgSplits), dim3(256), 0, st, g3, B, ss, h->act2, h->dact3, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3);
-    hipLaunchKernelGGL(k_bias_grad, dim3(1), dim3(256), 0, st, h->dact3, M3, C2, g_b3);
-    hipLaunchKernelGGL((k_conv_dgrad<64, 64>), dim3((unsigned)(B * h->OH2)), dim3(256), 0, st, g3, ss, tabs + 0, h->dact3, h->w3, h->act2, h->dact2);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, st, bias_part, kWgSplits, (i64)C2, g_b3);
+    hipLaunchKernelGGL((k_conv_dgrad<64, 64>), dim3((unsigned)(((B + kDgNB - 1) / kDgNB) * h->OH2)), dim3(256), 0, st, g3, B, ss, tabs + 0, h->dact3, h->w3, h->act2, h->dact2);
     // conv2: 4x4 stride 2 pad 2, act1 -> act2
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
-    const i64 M2 = (i64)B * h->OH2 * h->OW2;
-    hipLaunchKernelGGL((k_conv_wgrad<32, 64>), dim3(16, kWgSplits), dim3(256), 0, st, g2, B, ss, h->act1, h->dact2, h->w_part);
+    hipLaunchKernelGGL((k_conv_wgrad<32, 64>), dim3(16, kWgSplits), dim3(256), 0, st, g2, B, ss, h->act1, h->dact2, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 16 * h->F1, g_w2);
-    hipLaunchKernelGGL(k_bias_grad, dim3(1), dim3(256), 0, st, h->dact2, M2, C2, g_b2);
-    hipLaunchKernelGGL((k_conv_dgrad<32, 64>), dim3((unsigned)(B * h->OH1)), dim3(256), 0, st, g2, ss, tabs + 1, h->dact2, h->w2, h->act1, h->dact1);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, st, bias_part, kWgSplits, (i64)C2, g_b2);
+    hipLaunchKernelGGL((k_conv_dgrad<32, 64>), dim3((unsigned)(((B + kDgNB - 1) / kDgNB) * h->OH1)), dim3(256), 0, st, g2, B, ss, tabs + 1, h->dact2, h->w2, h->act1, h->dact1);
     // conv1: weight gradient from the uint8 frames
-    const i64 M1 = (i64)B * h->OH1 * h->OW1;
     const int per = (h->OH1 * h->OW1 + kC1Chunks - 1) / kC1Chunks;
     const size_t lds = (size_t)h->Wn * kC1Frame + (size_t)per * 32 * sizeof(float);
     SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
     hipLaunchKernelGGL(k_conv1_wgrad, dim3((unsigned)B, kC1Chunks), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, h->dact1,
-                       h->w_part);
+                       h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 255) / 256)), dim3(256), 0, st, h->w_part, B * kC1Chunks, (i64)32 * h->Wn * 64, g_w1);
-    hipLaunchKernelGGL(k_bias_grad, dim3(1), dim3(256), 0, st, h->dact1, M1, 32, g_b1);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, st, bias_part, B * kC1Chunks, (i64)32, g_b1);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

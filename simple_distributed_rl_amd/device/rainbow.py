@@ -14,6 +14,7 @@ Reference semantics kept (file:line under the reference root):
 Field names of RainbowDeviceConfig are those of rainbow.Config (rainbow.py:57-114).
 """
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -144,8 +145,16 @@ class RainbowEngine:
         if self.mfma:
             # one inference handle per concurrent user (each owns its activation buffers)
             self.inf_actor = QNetInference(self.q_actor, E, device)
-            self.inf_online = QNetInference(self.q_online, B * n, device)
+            self.inf_online = QNetInference(self.q_online, max(B * (n + 1), 64), device)
             self.inf_target = QNetInference(self.q_target, B * n, device)
+            # hand-written training pass (srlx_qnet_backward_u8): one forward over s_0..s_n of every item, gradients of the
+            # s_0 rows written straight into p.grad -- no autograd graph, no float32 copy of s_0
+            self.mfma_train = (cfg.filters == 32 and cfg.hidden_units <= 512 and B <= 64 and H == W_ and W_ % 4 == 0
+                               and os.environ.get("SRLX_TORCH_BACKWARD", "0") != "1")
+            if self.mfma_train:
+                self.inf_online.enable_training(B)
+        else:
+            self.mfma_train = False
         self._front_graph = None
         self._select_graph = None
         self._commit_graph = None
@@ -267,7 +276,13 @@ class RainbowEngine:
     def _learner_body(self):
         cfg, r = self.cfg, self.replay
         B, n = cfg.batch_size, cfg.multisteps
-        if self.mfma:
+        if self.mfma_train:
+            b = r.sample_items(self.train_count_dev, all_states=True)
+            q_all = self.inf_online.forward_u8(r.obs_base, r.frame_off_all.view(B * (n + 1), cfg.window_length)).view(B, n + 1, cfg.n_actions)
+            q_tg_next = self.inf_target.forward_u8(r.obs_base, r.frame_off_next.view(B * n, cfg.window_length))  # rainbow.py:221
+            q_on_next = q_all[:, 1:].contiguous()  # rainbow.py:220
+            q0 = q_all[:, 0].contiguous()  # model_torch.py:103
+        elif self.mfma:
             b = r.sample_items(self.train_count_dev)
             foff = r.frame_off_next.view(B * n, cfg.window_length)
             q_on_next = self.inf_online.forward_u8(r.obs_base, foff)  # rainbow.py:220
@@ -288,8 +303,11 @@ class RainbowEngine:
                 N.tptr(self.target), N.tptr(self.loss), N.tptr(self.grad_q0), N.tptr(self.priorities), N.torch_stream_ptr(),
             )
         )
-        self.optimizer.zero_grad(set_to_none=False)
-        q0.backward(self.grad_q0)  # model_torch.py:107-109: d loss / d q seeds autograd
+        if self.mfma_train:  # model_torch.py:107-109 without autograd: every p.grad is (over)written by the backward kernels
+            self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
+        else:
+            self.optimizer.zero_grad(set_to_none=False)
+            q0.backward(self.grad_q0)  # model_torch.py:107-109: d loss / d q seeds autograd
         self.optimizer.step()
         r.update(b.indices, self.priorities)  # model_torch.py:113-114
         self.train_count_dev.add_(1)

@@ -88,6 +88,7 @@ class DeviceReplay:
         # frame-offset tables for the matrix-core network (conv1 reads the uint8 ring directly)
         self.frame_off_actor = torch.zeros((n_envs, window), dtype=torch.int64, device=d)
         self.frame_off_next = torch.zeros((B, n, window), dtype=torch.int64, device=d)
+        self.frame_off_all = torch.zeros((B, n + 1, window), dtype=torch.int64, device=d)
         self.obs0 = torch.zeros((B, 1, window, obs_elems), dtype=torch.float32, device=d)
         base, fb = N.c_p(), N.c_i64()
         N.check(self.lib.srlx_store_obs_base(hs, ctypes.byref(base), ctypes.byref(fb)))
@@ -165,9 +166,10 @@ class DeviceReplay:
         N.check(self.lib.srlx_store_frame_table_current(self.h_store, N.tptr(self.frame_off_actor), N.torch_stream_ptr()))
         return self.frame_off_actor
 
-    def sample_items(self, d_step: torch.Tensor, uniforms: torch.Tensor = None) -> ReplayBatch:
+    def sample_items(self, d_step: torch.Tensor, uniforms: torch.Tensor = None, all_states: bool = False) -> ReplayBatch:
         """PER sample, then: frame-offset table of s_1..s_n (`frame_off_next`, for srlx_qnet_forward_u8),
-        float32 pixels of s_0 only (`obs0`, the one state autograd needs), and the n-step scalars."""
+        float32 pixels of s_0 only (`obs0`, the one state autograd needs), and the n-step scalars.
+        all_states=True (hand-written training pass): the table of s_0..s_n (`frame_off_all`) instead of the pixels."""
         st = N.torch_stream_ptr()
         b = self.batch
         if uniforms is None:
@@ -183,7 +185,14 @@ class DeviceReplay:
                 self.h_store, self.B, N.tptr(b.indices), 1, self.n, N.tptr(self.frame_off_next), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
             )
         )
-        N.check(self.lib.srlx_store_gather_obs(self.h_store, self.B, 0, 1, N.tptr(self.obs0), st))
+        if all_states:
+            N.check(
+                self.lib.srlx_store_gather_items(
+                    self.h_store, self.B, N.tptr(b.indices), 0, self.n + 1, N.tptr(self.frame_off_all), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
+                )
+            )
+        else:
+            N.check(self.lib.srlx_store_gather_obs(self.h_store, self.B, 0, 1, N.tptr(self.obs0), st))
         return b
 
     def update(self, indices: torch.Tensor, priorities: torch.Tensor):

@@ -36,6 +36,7 @@ __device__ __forceinline__ float byte_to_unit(unsigned b) {  // u8 / 255, correc
 
 // ---- dueling head + second dense layers (dueling_network.py:43-58) ------------------------------------------
 // one thread per hidden unit u; dq [B][A] (rows `stride` apart in nothing: dq is dense), h1 rows at i*sample_stride
+template <int AMAX>
 __global__ void __launch_bounds__(64) k_head_bwd(int B, i64 sstride, int hidden, int A, int dueling, const float *__restrict__ dq,
                                                   const float *__restrict__ h1, const float *__restrict__ v2w, const float *__restrict__ a2w,
                                                   float *__restrict__ dh1, float *__restrict__ g_bf, float *__restrict__ g_v2w, float *__restrict__ g_v2b,
@@ -52,17 +53,17 @@ __global__ void __launch_bounds__(64) k_head_bwd(int B, i64 sstride, int hidden,
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int N1 = 2 * hidden;
     if (u < hidden) {
-        float gv = 0.f, gbv = 0.f, gba = 0.f, ga[32];
+        float gv = 0.f, gbv = 0.f, gba = 0.f, ga[AMAX];
 #pragma unroll
-        for (int j = 0; j < 32; j++) ga[j] = 0.f;
+        for (int j = 0; j < AMAX; j++) ga[j] = 0.f;
         const float wv = v2w[u];
-#pragma unroll 4
+#pragma unroll 8
         for (int b = 0; b < B; b++) {
             const float hv = h1[(i64)b * sstride * N1 + u], ha = h1[(i64)b * sstride * N1 + hidden + u];
             gv += dv[b] * hv;
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 32; j++)
+            for (int j = 0; j < AMAX; j++)
                 if (j < A) {
                     ga[j] += da[b * A + j] * ha;
                     s += da[b * A + j] * a2w[j * hidden + u];
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(64) k_head_bwd(int B, i64 sstride, int hidden,
         g_bf[u] = gbv;
         g_bf[hidden + u] = gba;
 #pragma unroll
-        for (int j = 0; j < 32; j++)
+        for (int j = 0; j < AMAX; j++)
             if (j < A) g_a2w[j * hidden + u] = ga[j];
     }
     if (blockIdx.x == 0 && threadIdx.x <= A) {
@@ -218,10 +219,17 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvGeo g, int B, i64 sstrid
     if (tap == 0 && t < CO) bias_part[split * CO + t] = bsum;
 }
 
-// out[i] = sum_p part[p][i], fixed order
-__global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, int P, i64 n, float *__restrict__ out) {
-    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_p part[p][i] (fixed order) for a weight gradient (n entries) and, in the same launch, its bias gradient (nb entries)
+__global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, int P, i64 n, float *__restrict__ out, const float *__restrict__ bpart, int nb,
+                                                      float *__restrict__ bout) {
+    i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n + nb) return;
+    if (i >= n) {
+        i -= n;
+        part = bpart;
+        n = nb;
+        out = bout;
+    }
     float s = 0.f;
 #pragma unroll 16
     for (int p = 0; p < P; p++) s += part[(i64)p * n + i];  // loads are independent: 16 in flight, the adds stay in order
@@ -455,8 +463,16 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     float *bias_part = h->w_part + h->w_part_floats + (2 * sizeof(OutMap) + sizeof(float) - 1) / sizeof(float);  // [splits][CO] partial bias sums
 
     // head + second layers -> dh1 (masked by the first layer's ReLU), bias gradient of the first layer
-    hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((h->hidden + 63) / 64)), dim3(64), (size_t)(B + B * A) * sizeof(float), st, B, ss, h->hidden, A, h->dueling,
-                       d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+    {
+        const dim3 hg((unsigned)((h->hidden + 63) / 64));
+        const size_t hl = (size_t)(B + B * A) * sizeof(float);
+        if (A <= 8)
+            hipLaunchKernelGGL(k_head_bwd<8>, hg, dim3(64), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+        else if (A <= 16)
+            hipLaunchKernelGGL(k_head_bwd<16>, hg, dim3(64), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+        else
+            hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(64), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+    }
     // first dense layer
     hipLaunchKernelGGL(k_fc1_wgrad, dim3((unsigned)((K + 255) / 256), (unsigned)(N1 / 32)), dim3(256), 0, st, B, ss, N1, K, h->dh1, h->act3, g_wf);
     if (B <= 32)
@@ -468,14 +484,13 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     const int C2 = 2 * h->F1;
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
     hipLaunchKernelGGL((k_conv_wgrad<64, 64>), dim3(9, kWgSplits), dim3(256), 0, st, g3, B, ss, h->act2, h->dact3, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, st, bias_part, kWgSplits, (i64)C2, g_b3);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
     hipLaunchKernelGGL((k_conv_dgrad<64, 64>), dim3((unsigned)(((B + kDgNB - 1) / kDgNB) * h->OH2)), dim3(256), 0, st, g3, B, ss, tabs + 0, h->dact3, h->w3, h->act2, h->dact2);
     // conv2: 4x4 stride 2 pad 2, act1 -> act2
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
     hipLaunchKernelGGL((k_conv_wgrad<32, 64>), dim3(16, kWgSplits), dim3(256), 0, st, g2, B, ss, h->act1, h->dact2, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 16 * h->F1, g_w2);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, st, bias_part, kWgSplits, (i64)C2, g_b2);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2,
+                       g_b2);
     hipLaunchKernelGGL((k_conv_dgrad<32, 64>), dim3((unsigned)(((B + kDgNB - 1) / kDgNB) * h->OH1)), dim3(256), 0, st, g2, B, ss, tabs + 1, h->dact2, h->w2, h->act1, h->dact1);
     // conv1: weight gradient from the uint8 frames
     const int per = (h->OH1 * h->OW1 + kC1Chunks - 1) / kC1Chunks;
@@ -483,8 +498,8 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
     hipLaunchKernelGGL(k_conv1_wgrad, dim3((unsigned)B, kC1Chunks), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, h->dact1,
                        h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 255) / 256)), dim3(256), 0, st, h->w_part, B * kC1Chunks, (i64)32 * h->Wn * 64, g_w1);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, st, bias_part, B * kC1Chunks, (i64)32, g_b1);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, st, h->w_part, B * kC1Chunks, (i64)32 * h->Wn * 64, g_w1, bias_part, 32,
+                       g_b1);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

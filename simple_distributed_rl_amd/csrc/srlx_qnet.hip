@@ -404,6 +404,43 @@ struct ANchw {
     }
 };
 
+
+// data gradient of a convolution as an implicit GEMM over the PADDED input grid (replicate padding = an explicit pad
+// followed by a plain convolution, so its gradient is the plain transposed convolution on the padded grid; the caller
+// folds the border rows/columns back): row m = (b, py, px), k = tap * CO + co, value = dY[b][(py-ky)/S][(px-kx)/S][co]
+// where that output exists, else 0.  CO is 32 or 64: a 32-wide slab has one tap.
+struct ADgrad {
+    const float *dY;
+    int HP, WP, OH, OW, CO, KW, S;
+    unsigned char tap_y[80], tap_x[80];
+    struct Row {
+        const float *img;  // null: row beyond M
+        int py, px;
+    };
+    __device__ __forceinline__ Row row(i64 m, i64 M) const {
+        if (m >= M) return Row{nullptr, 0, 0};
+        const int per = HP * WP;
+        const i64 b = m / per;
+        const int pix = (int)(m % per);
+        return Row{dY + b * (i64)OH * OW * CO, pix / WP, pix % WP};
+    }
+    __device__ __forceinline__ float4 load4(const Row &r, int k0, int c4) const {
+        if (!r.img) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int slab = k0 >> 5;
+        const int oy = r.py - tap_y[slab], ox = r.px - tap_x[slab];
+        if (oy < 0 || ox < 0 || oy % S || ox % S || oy / S >= OH || ox / S >= OW) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int co = (k0 & (CO - 1) & ~31) + c4;
+        return *reinterpret_cast<const float4 *>(r.img + ((i64)(oy / S) * OW + ox / S) * CO + co);
+    }
+    void fill_taps(int K) {
+        for (int sl = 0; sl < K / 32 && sl < 80; sl++) {
+            const int tap = (sl * 32) / CO;
+            tap_y[sl] = (unsigned char)(tap / KW);
+            tap_x[sl] = (unsigned char)(tap % KW);
+        }
+    }
+};
+
 }  // namespace
 
 namespace {
@@ -446,6 +483,22 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     return SRLX_OK;
 }
 }  // namespace
+
+// dXpad[M = B*HP*WP][CI] = ADgrad(dY) x WT[CI][taps*CO]^T  (srlx_qnet_bwd.hip)
+int srlx_qnet_dgrad_gemm(const float *dY, int B, int HP, int WP, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXpad,
+                         hipStream_t st) {
+    ADgrad a{dY, HP, WP, OH, OW, CO, KW, S, {}, {}};
+    const int K = KH * KW * CO;
+    SRLX_REQUIRE((CO == 32 || CO == 64) && K % BK == 0 && K / 32 <= 80 && (CI == 32 || CI == 64), "dgrad_gemm: unsupported channel counts");
+    a.fill_taps(K);
+    const i64 M = (i64)B * HP * WP;
+    if (CI == 64)
+        launch_gemm<ADgrad, 64, false, false>(a, wT, nullptr, dXpad, M, CI, K, 1, st);
+    else
+        launch_gemm<ADgrad, 32, false, false>(a, wT, nullptr, dXpad, M, CI, K, 1, st);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
 
 extern "C" {
 
@@ -497,7 +550,7 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     if (!h) return SRLX_OK;
     srlx::DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    float *all[] = {h->act1, h->act2, h->act3, h->partial, h->h1, h->dh1, h->dact3, h->dact2, h->dact1, h->fc_part, h->w_part};
+    float *all[] = {h->act1, h->act2, h->act3, h->partial, h->h1, h->dh1, h->dact3, h->dact2, h->dact1, h->fc_part, h->w_part, h->dxpad, h->w_t};
     for (float *p : all)
         if (p) (void)hipFree(p);
     delete h;

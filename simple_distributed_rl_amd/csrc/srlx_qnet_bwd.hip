@@ -24,7 +24,6 @@ using u8 = unsigned char;
 
 constexpr int kFcSplits = 16;   // splits of the hidden dimension in the dense data-gradient
 constexpr int kWgSplits = 64;   // splits of the row dimension in the conv weight-gradients
-constexpr int kMaxSide = 96;
 constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad, kC1Chunks = 4;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -237,101 +236,28 @@ __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ 
 }
 
 // ---- convolution data gradient through replicate padding ---------------------------------------------------
-// omap[i][k] lists the output coordinates o with clamp(o*S + k - P) == i (0, 1 or 2 of them; the same table serves
-// y and x: square layers).  dX[b][iy][ix][ci] = [X > 0] * sum_{ky, oy in omap[iy][ky]} sum_{kx, ox in omap[ix][kx]}
-// sum_co dY[b][oy][ox][co] * W[co][ky][kx][ci].
-// workgroup = one input row (b, iy): the <= 4 output rows it touches are staged in LDS; thread = one input channel x a
-// group of columns: the CO filter values of a tap sit in registers and are reused across the thread's columns, dY is a
-// wavefront-wide LDS broadcast.
-struct OutMap {
-    unsigned char n[kMaxSide][8], o0[kMaxSide][8], o1[kMaxSide][8];
-};
-constexpr int kDgNB = 2;    // samples per workgroup: the filter registers of a tap are reused across them
-constexpr int kDgOW = 12;   // staged output-row stride (OW <= 12)
-template <int CI, int CO>
-__global__ void __launch_bounds__(256) k_conv_dgrad(ConvGeo g, int B, i64 sstride, const OutMap *__restrict__ om_g, const float *__restrict__ dY,
-                                                    const float *__restrict__ Wt, const float *__restrict__ X, float *__restrict__ dX) {
-    constexpr int GROUPS = 256 / CI;  // column groups
-    constexpr int MAXC = 4;           // columns per thread: ceil(21 / 8) = 3, ceil(11 / 4) = 3
-    __shared__ __attribute__((aligned(16))) float sdy[kDgNB * 4 * kDgOW * CO];  // [sample][row slot][ox][co]
-    __shared__ int s_row[4], s_nrow;
-    __shared__ OutMap s_om;  // the map is consulted in the innermost loops: keep it out of global memory
-    const int b0 = (blockIdx.x / g.H) * kDgNB, iy = blockIdx.x % g.H;
-    const int t = threadIdx.x, ci = t % CI, grp = t / CI;
-    const int taps = g.KH * g.KW;
-    for (int idx = t; idx < (int)(sizeof(OutMap) / 4); idx += 256) reinterpret_cast<unsigned *>(&s_om)[idx] = reinterpret_cast<const unsigned *>(om_g)[idx];
-    __syncthreads();
-    const OutMap *om = &s_om;
-    if (t == 0) {  // distinct output rows touched by this input row
-        int nr = 0;
-        for (int ky = 0; ky < g.KH; ky++)
-            for (int q = 0; q < om->n[iy][ky]; q++) {
-                const int oy = q == 0 ? om->o0[iy][ky] : om->o1[iy][ky];
-                bool seen = false;
-                for (int r = 0; r < nr; r++) seen = seen || s_row[r] == oy;
-                if (!seen && nr < 4) s_row[nr++] = oy;
-            }
-        s_nrow = nr;
-    }
-    __syncthreads();
-    const int nrow = s_nrow;
-    const int rowf = g.OW * CO;
-    for (int idx = t; idx < kDgNB * nrow * rowf; idx += 256) {
-        const int nb = idx / (nrow * rowf), r = (idx / rowf) % nrow, rem = idx % rowf;
-        sdy[((nb * 4 + r) * kDgOW) * CO + rem] = b0 + nb < B ? dY[(((i64)(b0 + nb) * g.OH + s_row[r]) * g.OW) * CO + rem] : 0.f;
-    }
-    __syncthreads();
-    float acc[kDgNB][MAXC];
-#pragma unroll
-    for (int nb = 0; nb < kDgNB; nb++)
-#pragma unroll
-        for (int c = 0; c < MAXC; c++) acc[nb][c] = 0.f;
-    for (int ky = 0; ky < g.KH; ky++) {
-        const int ny = om->n[iy][ky];
-        for (int qy = 0; qy < ny; qy++) {
-            const int oy = qy == 0 ? om->o0[iy][ky] : om->o1[iy][ky];
-            int slot = 0;
-            for (int r = 0; r < nrow; r++) slot = s_row[r] == oy ? r : slot;
-            for (int kx = 0; kx < g.KW; kx++) {
-                float w[CO];
-                const float *wp = Wt + (i64)(ky * g.KW + kx) * CI + ci;
-#pragma unroll
-                for (int co = 0; co < CO; co++) w[co] = wp[(i64)co * taps * CI];
-#pragma unroll
-                for (int c = 0; c < MAXC; c++) {
-                    const int ix = grp + c * GROUPS;
-                    if (ix >= g.W) break;
-                    const int nx = om->n[ix][kx];
-                    for (int qx = 0; qx < nx; qx++) {
-                        const int ox = qx == 0 ? om->o0[ix][kx] : om->o1[ix][kx];
-#pragma unroll
-                        for (int nb = 0; nb < kDgNB; nb++) {
-                            const float4 *dy = reinterpret_cast<const float4 *>(sdy + ((nb * 4 + slot) * kDgOW + ox) * CO);
-                            float a = 0.f;
-#pragma unroll
-                            for (int v = 0; v < CO / 4; v++) {
-                                const float4 d = dy[v];
-                                a += d.x * w[4 * v] + d.y * w[4 * v + 1] + d.z * w[4 * v + 2] + d.w * w[4 * v + 3];
-                            }
-                            acc[nb][c] += a;
-                        }
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int nb = 0; nb < kDgNB; nb++) {
-        const int b = b0 + nb;
-        if (b >= B) break;
-#pragma unroll
-        for (int c = 0; c < MAXC; c++) {
-            const int ix = grp + c * GROUPS;
-            if (ix >= g.W) break;
-            const i64 xi = (((i64)b * sstride * g.H + iy) * g.W + ix) * CI + ci;
-            dX[(((i64)b * g.H + iy) * g.W + ix) * CI + ci] = X[xi] > 0.f ? acc[nb][c] : 0.f;
-        }
-    }
+// Replicate padding is an explicit pad followed by a plain convolution, so the data gradient is the plain transposed
+// convolution evaluated on the PADDED grid (an implicit GEMM on the matrix cores, srlx_qnet_dgrad_gemm: rows = padded
+// pixels, K = taps x CO, N = CI, filters transposed to [ci][tap][co]) followed by folding the pad rows / columns back
+// onto the border pixels they replicate, fused with the ReLU mask of the layer input.
+__global__ void __launch_bounds__(256) k_transpose_filter(const float *__restrict__ W, int CO, int taps, int CI, float *__restrict__ wT) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= CO * taps * CI) return;
+    const int ci = i % CI, tap = (i / CI) % taps, co = i / (CI * taps);  // W[co][tap][ci]
+    wT[((i64)ci * taps + tap) * CO + co] = W[i];
+}
+
+__global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int W, int CI, int P, int HP, int WP, const float *__restrict__ dxpad,
+                                                  const float *__restrict__ X, float *__restrict__ dX) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (i64)B * H * W * CI) return;
+    const int ci = (int)(i % CI), ix = (int)((i / CI) % W), iy = (int)((i / ((i64)CI * W)) % H), b = (int)(i / ((i64)CI * W * H));
+    const int y0 = iy == 0 ? 0 : iy + P, y1 = iy == H - 1 ? HP - 1 : iy + P;
+    const int x0 = ix == 0 ? 0 : ix + P, x1 = ix == W - 1 ? WP - 1 : ix + P;
+    float s = 0.f;
+    for (int py = y0; py <= y1; py++)
+        for (int px = x0; px <= x1; px++) s += dxpad[(((i64)b * HP + py) * WP + px) * CI + ci];
+    dX[i] = X[(((i64)b * sstride * H + iy) * W + ix) * CI + ci] > 0.f ? s : 0.f;
 }
 
 // ---- conv1 weight gradient straight from the uint8 ring ------------------------------------------------------
@@ -389,19 +315,6 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad(const u8 *__restrict__ base
     }
 }
 
-void fill_outmap(OutMap *t, int in_size, int out_size, int K, int S, int P) {
-    memset(t, 0, sizeof(*t));
-    for (int o = 0; o < out_size; o++)
-        for (int k = 0; k < K && k < 8; k++) {
-            int i = o * S + k - P;
-            i = i < 0 ? 0 : (i > in_size - 1 ? in_size - 1 : i);
-            const int n = t->n[i][k];
-            if (n == 0) t->o0[i][k] = (unsigned char)o;
-            if (n == 1) t->o1[i][k] = (unsigned char)o;
-            t->n[i][k] = (unsigned char)(n < 2 ? n + 1 : 2);
-        }
-}
-
 }  // namespace
 
 extern "C" {
@@ -409,8 +322,8 @@ extern "C" {
 int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
     SRLX_REQUIRE(h, "qnet_enable_training: NULL handle");
     SRLX_REQUIRE(max_train_batch > 0 && max_train_batch <= 64 && max_train_batch <= h->max_batch, "qnet_enable_training: 1 <= max_train_batch <= 64");
-    SRLX_REQUIRE(h->F1 == 32 && h->dueling != 1 && h->H == h->W && h->OH1 <= kMaxSide && h->W % 4 == 0 && (2 * h->hidden) % kFcSplits == 0 &&
-                     2 * h->hidden / kFcSplits <= 64 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && h->OW2 <= kDgOW && h->OW3 <= kDgOW,
+    SRLX_REQUIRE(h->F1 == 32 && h->dueling != 1 && h->H == h->W && h->W % 4 == 0 && (2 * h->hidden) % kFcSplits == 0 &&
+                     2 * h->hidden / kFcSplits <= 64 && 4 * (h->OH1 - 1) + 8 <= kC1Pad,
                  "qnet_enable_training: the backward kernels cover the DQN image block with 32 filters, square frames, hidden <= 512, dueling average / none");
     if (h->max_train >= max_train_batch) return SRLX_OK;
     SRLX_REQUIRE(h->max_train == 0, "qnet_enable_training: already enabled with a smaller batch");
@@ -429,7 +342,11 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
                 {&h->dact2, (size_t)max_train_batch * h->OH2 * h->OW2 * 2 * h->F1},
                 {&h->dact1, (size_t)max_train_batch * h->OH1 * h->OW1 * h->F1},
                 {&h->fc_part, (size_t)kFcSplits * max_train_batch * h->flat},
-                {&h->w_part, wp + sizeof(OutMap) * 2 / sizeof(float) + 64 + 2 * kWgSplits * 64 + 64 * kC1Chunks * 32}};
+                {&h->dxpad, (size_t)max_train_batch * ((size_t)(h->OH1 + 4) * (h->OW1 + 4) * h->F1 > (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1
+                                                             ? (size_t)(h->OH1 + 4) * (h->OW1 + 4) * h->F1
+                                                             : (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1)},
+                {&h->w_t, c3 > c2 ? c3 : c2},
+                {&h->w_part, wp + 64 + 2 * kWgSplits * 64 + 64 * kC1Chunks * 32}};
     for (auto &b : bufs) {
         hipError_t e = hipMalloc((void **)b.p, b.n * sizeof(float));
         if (e != hipSuccess) {
@@ -437,11 +354,6 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
             return e == hipErrorOutOfMemory ? SRLX_ERR_NOMEM : SRLX_ERR_HIP;
         }
     }
-    // pair tables of the two data-gradient layers live behind the partial-sum scratch
-    OutMap host[2];
-    fill_outmap(&host[0], h->OH2, h->OH3, 3, 1, 1);  // conv3: input act2 (OH2), output OH3
-    fill_outmap(&host[1], h->OH1, h->OH2, 4, 2, 2);  // conv2: input act1 (OH1), output OH2
-    SRLX_HIP(hipMemcpy(h->w_part + wp, host, sizeof(host), hipMemcpyHostToDevice));
     h->max_train = max_train_batch;
     return SRLX_OK;
 }
@@ -459,8 +371,7 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     const i64 ss = sample_stride;
     float *g_w1 = g[0], *g_b1 = g[1], *g_w2 = g[2], *g_b2 = g[3], *g_w3 = g[4], *g_b3 = g[5], *g_wf = g[6], *g_bf = g[7], *g_v2w = g[8], *g_v2b = g[9], *g_a2w = g[10],
           *g_a2b = g[11];
-    const OutMap *tabs = reinterpret_cast<const OutMap *>(h->w_part + h->w_part_floats);
-    float *bias_part = h->w_part + h->w_part_floats + (2 * sizeof(OutMap) + sizeof(float) - 1) / sizeof(float);  // [splits][CO] partial bias sums
+    float *bias_part = h->w_part + h->w_part_floats;  // [splits][CO] partial bias sums
 
     // head + second layers -> dh1 (masked by the first layer's ReLU), bias gradient of the first layer
     {
@@ -485,13 +396,25 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
     hipLaunchKernelGGL((k_conv_wgrad<64, 64>), dim3(9, kWgSplits), dim3(256), 0, st, g3, B, ss, h->act2, h->dact3, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
-    hipLaunchKernelGGL((k_conv_dgrad<64, 64>), dim3((unsigned)(((B + kDgNB - 1) / kDgNB) * h->OH2)), dim3(256), 0, st, g3, B, ss, tabs + 0, h->dact3, h->w3, h->act2, h->dact2);
+    {   // conv3 data gradient: padded grid (OH2 + 2)^2
+        const int HP = h->OH2 + 2, WP = h->OW2 + 2, n = C2 * 9 * C2;
+        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->w3, C2, 9, C2, h->w_t);
+        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st));
+        const i64 tot = (i64)B * h->OH2 * h->OW2 * C2;
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, h->dxpad, h->act2, h->dact2);
+    }
     // conv2: 4x4 stride 2 pad 2, act1 -> act2
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
     hipLaunchKernelGGL((k_conv_wgrad<32, 64>), dim3(16, kWgSplits), dim3(256), 0, st, g2, B, ss, h->act1, h->dact2, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2,
                        g_b2);
-    hipLaunchKernelGGL((k_conv_dgrad<32, 64>), dim3((unsigned)(((B + kDgNB - 1) / kDgNB) * h->OH1)), dim3(256), 0, st, g2, B, ss, tabs + 1, h->dact2, h->w2, h->act1, h->dact1);
+    {   // conv2 data gradient: padded grid (OH1 + 4)^2
+        const int HP = h->OH1 + 4, WP = h->OW1 + 4, n = C2 * 16 * h->F1;
+        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->w2, C2, 16, h->F1, h->w_t);
+        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact2, B, HP, WP, h->OH2, h->OW2, C2, 4, 4, 2, h->w_t, h->F1, h->dxpad, st));
+        const i64 tot = (i64)B * h->OH1 * h->OW1 * h->F1;
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, h->dxpad, h->act1, h->dact1);
+    }
     // conv1: weight gradient from the uint8 frames
     const int per = (h->OH1 * h->OW1 + kC1Chunks - 1) / kC1Chunks;
     const size_t lds = (size_t)h->Wn * kC1Frame + (size_t)per * 32 * sizeof(float);

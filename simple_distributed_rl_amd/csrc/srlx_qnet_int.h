@@ -17,5 +17,10 @@ struct srlx_qnet {
     float *dh1, *dact3, *dact2, *dact1;   // [max_train][...]
     float *fc_part;                       // [kFcSplits][max_train][flat]
     float *w_part;                        // weight-gradient partial sums (largest layer)
+    float *dxpad, *w_t;                   // padded data gradient [max_train][HP*WP*CI], transposed filters [CI][taps*CO]
     size_t w_part_floats;
 };
+
+// implicit-GEMM data gradient on the matrix cores (defined next to k_gemm in srlx_qnet.hip)
+int srlx_qnet_dgrad_gemm(const float *dY, int B, int HP, int WP, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXpad,
+                         hipStream_t st);

@@ -139,7 +139,7 @@ def main():
             "noisy_dense": cfg.enable_noisy_dense,
             "epsilon": cfg.epsilon,
             "hip_graphs": not args.no_graph,
-            "qnet_inference": "libsrlx fp32 MFMA kernels (grad path: torch)" if eng.mfma else "torch",
+            "qnet": ("libsrlx: fp32 MFMA forward, hand-written backward (no autograd)" if getattr(eng, "mfma_train", False) else "libsrlx fp32 MFMA forward, torch autograd backward") if eng.mfma else "torch",
             "actor_learner_overlap": (not args.no_overlap) if world == 1 else False,
             "topology": "1 GPU: actor+learner" if world == 1 else f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast",
         },
@@ -164,7 +164,7 @@ def roofline(eng, ev_ms):
         flops = eng.actor_forward_flops()
         tf = flops / (ev_ms * 1e-3) / 1e12
         return {
-            "kernel": "srlx_qnet_forward_u8 over E envs: k_gemm<AU8> (conv1 from the uint8 ring) + k_gemm<AConv> x2 + k_gemm<APlain,splitK> (FC1) + k_head",
+            "kernel": "srlx_qnet_forward_u8 over E envs: k_conv1_u8 (conv1 from the uint8 ring) + k_gemm<AConv> x2 + k_gemm<APlain,splitK> (FC1) + k_head",
             "bound": "mfma",
             "achieved": tf,
             "peak": MFMA_F32_PEAK_TFLOPS,

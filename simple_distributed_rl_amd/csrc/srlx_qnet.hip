@@ -237,18 +237,24 @@ __global__ void __launch_bounds__(256) k_conv1_u8(const u8 *__restrict__ base, c
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also drains vmcnt, i.e. it makes every wave wait for
+// the global loads of the NEXT K-slab that were issued a few hundred cycles earlier -- the prefetch then hides at most one
+// MFMA phase (0.85 us) of memory latency and the matrix pipe idles behind the barrier.  The prefetched registers are
+// consumed after the next barrier; the compiler inserts the vmcnt wait there.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- the GEMM ------------------------------------------------------------------------------------------
-template <class AL, int BN, bool RELU, bool SPLITK>
+template <class AL, int BN, bool RELU, bool SPLITK, int TBM = 128>
 __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ Bw, const float *__restrict__ bias, float *__restrict__ C, i64 M, int N,
                                               int K, int k_per_split) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+    __shared__ __attribute__((aligned(16))) float As[TBM * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const i64 m0 = (i64)blockIdx.x * BM;
+    const i64 m0 = (i64)blockIdx.x * TBM;
     const int n0 = blockIdx.y * BN;
     const int kbeg = SPLITK ? blockIdx.z * k_per_split : 0;
     const int kend = SPLITK ? (kbeg + k_per_split < K ? kbeg + k_per_split : K) : K;
-    constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (32 * WM), NB = BN / 32;
+    constexpr int WN = BN / 32, WM = 4 / WN, MT = TBM / (32 * WM), NB = BN / 32, MR = TBM / 32;
     const int wn = wave % WN, wm = wave / WN;
     f32x16 acc[MT];
 #pragma unroll
@@ -257,13 +263,13 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
         for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
     const int lrow = t >> 3, c4 = (t & 7) * 4;  // this lane stages rows lrow + 32 j, columns c4..c4+3 of a tile
-    typename AL::Row rows[4];
+    typename AL::Row rows[MR];
 #pragma unroll
-    for (int j = 0; j < 4; j++) rows[j] = al.row(m0 + lrow + 32 * j, M);
-    float4 ra[4], rb[NB];
+    for (int j = 0; j < MR; j++) rows[j] = al.row(m0 + lrow + 32 * j, M);
+    float4 ra[MR], rb[NB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) ra[j] = al.load4(rows[j], k0, c4);
+        for (int j = 0; j < MR; j++) ra[j] = al.load4(rows[j], k0, c4);
 #pragma unroll
         for (int j = 0; j < NB; j++) {
             const int n = n0 + lrow + 32 * j;
@@ -274,10 +280,10 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
     const int h = lane >> 5, i = lane & 31;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(&As[(lrow + 32 * j) * LDT + c4]) = ra[j];
+        for (int j = 0; j < MR; j++) *reinterpret_cast<float4 *>(&As[(lrow + 32 * j) * LDT + c4]) = ra[j];
 #pragma unroll
         for (int j = 0; j < NB; j++) *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * j) * LDT + c4]) = rb[j];
-        __syncthreads();
+        lds_barrier();
         if (k0 + BK < kend) fetch(k0 + BK);  // overlaps with the MFMAs below
         // fragments: lane (i, h) holds k = 16 h + s, s = 0..15, of row/column i (A and B use the same k order)
         float bf[16];
@@ -297,7 +303,7 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
 #pragma unroll
             for (int s = 0; s < 16; s++) acc[ms] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc[ms], 0, 0, 0);
         }
-        __syncthreads();
+        lds_barrier();
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float *Cz = SPLITK ? C + (i64)blockIdx.z * M * N : C;
@@ -330,7 +336,8 @@ __global__ void __launch_bounds__(256) k_head(const float *__restrict__ partial,
     for (int j = 0; j < kMaxActions; j++) adv[j] = 0.f;
     for (int u = t; u < hidden; u += 256) {
         float hv = b1[u], ha = b1[hidden + u];
-        for (int s = 0; s < splits; s++) {  // fixed order: deterministic
+#pragma unroll 32
+        for (int s = 0; s < splits; s++) {  // fixed order: deterministic (the loads are independent: 32 in flight)
             const float *p = partial + ((i64)s * M + m) * N1;
             hv += p[u];
             ha += p[hidden + u];
@@ -451,6 +458,12 @@ void launch_gemm(const AL &al, const float *Bw, const float *bias, float *C, i64
     int kps = K;
     if (SPLITK) {
         kps = ((K / BK + splits - 1) / splits) * BK;
+    }
+    const i64 wgs = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (SPLITK ? splits : 1);
+    if constexpr (BN == 64) if (wgs < 200) {  // small batches: 64-row tiles double the workgroup count (one 32x32 block per wave)
+        dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + BN - 1) / BN), SPLITK ? (unsigned)splits : 1u);
+        hipLaunchKernelGGL((k_gemm<AL, BN, RELU, SPLITK, 64>), grid, dim3(256), 0, st, al, Bw, bias, C, M, N, K, kps);
+        return;
     }
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN), SPLITK ? (unsigned)splits : 1u);
     hipLaunchKernelGGL((k_gemm<AL, BN, RELU, SPLITK>), grid, dim3(256), 0, st, al, Bw, bias, C, M, N, K, kps);

@@ -161,41 +161,46 @@ __global__ void __launch_bounds__(256) k_conv1_u8(const u8 *__restrict__ base, c
     // clamp(r - 3).  The ring lives in HBM: all loads of a frame are issued before the first LDS store (8 in flight per
     // lane), each is ONE in-bounds unaligned dword whose bytes are re-picked at the left / right border.
     constexpr int kPer = (kC1Pad * (kC1Pad / 4) + 255) / 256;  // 8 dwords per lane per frame
-    for (int c = 0; c < Wn; c++) {
-        const i64 off = frame_off[b * Wn + c];
-        unsigned *dst = reinterpret_cast<unsigned *>(fr + c * kC1Frame);
-        unsigned v[kPer];
-        int xs[kPer];
+    for (int c0 = 0; c0 < Wn; c0 += 4) {  // up to four frames (32 loads per lane) in flight together
+        i64 off[4];
 #pragma unroll
-        for (int j = 0; j < kPer; j++) {
-            const int idx = t + 256 * j;
-            v[j] = 0u;
-            xs[j] = 0;
-            if (off >= 0 && idx < kC1Pad * (kC1Pad / 4)) {
-                const int r = idx / (kC1Pad / 4), d = idx % (kC1Pad / 4);
-                xs[j] = clampi(4 * d - 3, 0, W - 4);
-                __builtin_memcpy(&v[j], base + off + (i64)clampi(r - 3, 0, H - 1) * W + xs[j], 4);
+        for (int q = 0; q < 4; q++) off[q] = c0 + q < Wn ? frame_off[b * Wn + c0 + q] : -1;
+        unsigned v[4][kPer];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int j = 0; j < kPer; j++) {
+                const int idx = t + 256 * j;
+                v[q][j] = 0u;
+                if (off[q] >= 0 && idx < kC1Pad * (kC1Pad / 4)) {
+                    const int r = idx / (kC1Pad / 4), d = idx % (kC1Pad / 4);
+                    __builtin_memcpy(&v[q][j], base + off[q] + (i64)clampi(r - 3, 0, H - 1) * W + clampi(4 * d - 3, 0, W - 4), 4);
+                }
             }
-        }
 #pragma unroll
-        for (int j = 0; j < kPer; j++) {
-            const int idx = t + 256 * j;
-            if (idx >= kC1Pad * (kC1Pad / 4)) continue;
-            const int x = 4 * (idx % (kC1Pad / 4)) - 3;
-            unsigned o = v[j];
-            if (off >= 0 && x != xs[j]) {  // border: column clamp(x + q) sits at byte clamp(x + q) - xs of the loaded dword
-                o = 0u;
+        for (int q = 0; q < 4; q++) {
+            if (c0 + q >= Wn) break;
+            unsigned *dst = reinterpret_cast<unsigned *>(fr + (c0 + q) * kC1Frame);
 #pragma unroll
-                for (int q = 0; q < 4; q++) o |= ((v[j] >> (8 * (clampi(x + q, 0, W - 1) - xs[j]))) & 255u) << (8 * q);
+            for (int j = 0; j < kPer; j++) {
+                const int idx = t + 256 * j;
+                if (idx >= kC1Pad * (kC1Pad / 4)) continue;
+                const int x = 4 * (idx % (kC1Pad / 4)) - 3, xs = clampi(x, 0, W - 4);
+                unsigned o = v[q][j];
+                if (off[q] >= 0 && x != xs) {  // border: column clamp(x + p) sits at byte clamp(x + p) - xs of the loaded dword
+                    o = 0u;
+#pragma unroll
+                    for (int p = 0; p < 4; p++) o |= ((v[q][j] >> (8 * (clampi(x + p, 0, W - 1) - xs))) & 255u) << (8 * p);
+                }
+                dst[idx] = o;
             }
-            dst[idx] = o;
         }
     }
     __syncthreads();
     const int h = lane >> 5, i = lane & 31;
     const int M = OH * OW, tiles = (M + 31) / 32;
     const float bias = b1[i];
-    for (int tile = wave; tile < tiles; tile += 4) {
+    for (int tile = wave * gridDim.y + blockIdx.y; tile < tiles; tile += 4 * gridDim.y) {  // gridDim.y workgroups share a sample at small batches
         const int m = tile * 32 + i < M ? tile * 32 + i : M - 1;
         const int oy = m / OW, ox = m % OW;
         const u8 *win = fr + (4 * oy + 2 * h) * kC1Pad + 4 * ox;  // this lane's first kernel row inside a slab
@@ -335,13 +340,22 @@ __global__ void __launch_bounds__(256) k_head(const float *__restrict__ partial,
 #pragma unroll
     for (int j = 0; j < kMaxActions; j++) adv[j] = 0.f;
     for (int u = t; u < hidden; u += 256) {
-        float hv = b1[u], ha = b1[hidden + u];
-#pragma unroll 32
-        for (int s = 0; s < splits; s++) {  // fixed order: deterministic (the loads are independent: 32 in flight)
-            const float *p = partial + ((i64)s * M + m) * N1;
-            hv += p[u];
-            ha += p[hidden + u];
+        // split sums in a fixed order with four independent chains (eight loads in flight per iteration)
+        float v4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f};
+        const float *p = partial + m * N1 + u;
+        const i64 ss = M * N1;
+        int s = 0;
+        for (; s + 4 <= splits; s += 4)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                v4[q] += p[(s + q) * ss];
+                a4[q] += p[(s + q) * ss + hidden];
+            }
+        for (; s < splits; s++) {
+            v4[0] += p[s * ss];
+            a4[0] += p[s * ss + hidden];
         }
+        float hv = b1[u] + ((v4[0] + v4[1]) + (v4[2] + v4[3])), ha = b1[hidden + u] + ((a4[0] + a4[1]) + (a4[2] + a4[3]));
         hv = hv > 0.f ? hv : 0.f;
         ha = ha > 0.f ? ha : 0.f;
         if (h1) {  // training: the backward pass needs the hidden layer
@@ -587,7 +601,7 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
     const size_t lds = 32 * kC1WStride * sizeof(float) + (size_t)h->Wn * kC1Frame;
     if (h->F1 == 32 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && 4 * (h->OW1 - 1) + 8 <= kC1Pad && lds <= 64 * 1024 && h->W % 4 == 0) {
         // one workgroup per sample, frames + filters staged in LDS
-        hipLaunchKernelGGL(k_conv1_u8, dim3((unsigned)batch), dim3(256), lds, st, d_frame_base, d_frame_off, h->Wn, h->H, h->W, h->OH1, h->OW1, h->w1, h->b1,
+        hipLaunchKernelGGL(k_conv1_u8, dim3((unsigned)batch, batch < 200 ? 2u : 1u), dim3(256), lds, st, d_frame_base, d_frame_off, h->Wn, h->H, h->W, h->OH1, h->OW1, h->w1, h->b1,
                            h->act1);
     } else {
         AU8 c1{d_frame_base, d_frame_off, h->Wn, h->H, h->W, 4, 3, h->OH1, h->OW1};

@@ -580,6 +580,9 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     float *all[] = {h->act1, h->act2, h->act3, h->partial, h->h1, h->dh1, h->dact3, h->dact2, h->dact1, h->fc_part, h->w_part, h->dxpad, h->w_t};
     for (float *p : all)
         if (p) (void)hipFree(p);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join})
+        if (e) (void)hipEventDestroy(e);
     delete h;
     return SRLX_OK;
 }

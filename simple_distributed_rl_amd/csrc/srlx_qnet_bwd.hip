@@ -354,6 +354,9 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
             return e == hipErrorOutOfMemory ? SRLX_ERR_NOMEM : SRLX_ERR_HIP;
         }
     }
+    // the weight-gradient branch of the backward pass runs on its own stream, forked from / joined to the caller's
+    SRLX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&h->ev_fork, &h->ev_d3, &h->ev_d2, &h->ev_d1, &h->ev_join}) SRLX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     h->max_train = max_train_batch;
     return SRLX_OK;
 }
@@ -384,45 +387,56 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
         else
             hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(64), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
     }
-    // first dense layer
-    hipLaunchKernelGGL(k_fc1_wgrad, dim3((unsigned)((K + 255) / 256), (unsigned)(N1 / 32)), dim3(256), 0, st, B, ss, N1, K, h->dh1, h->act3, g_wf);
+    // Two branches from here (fork/join with events; capturable into a HIP graph): the data-gradient chain stays on the
+    // caller's stream, every weight gradient runs on h->side as soon as the activation gradient it needs exists.
+    hipStream_t sd = h->side;
+    SRLX_HIP(hipEventRecord(h->ev_fork, st));
+    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
+    const int C2 = 2 * h->F1;
+    // ---- data-gradient chain (caller's stream)
     if (B <= 32)
         hipLaunchKernelGGL(k_fc1_dgrad<32>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
     else
         hipLaunchKernelGGL(k_fc1_dgrad<64>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
     hipLaunchKernelGGL(k_fc1_dgrad_reduce, dim3((unsigned)(((i64)B * K + 255) / 256)), dim3(256), 0, st, B, ss, K, h->fc_part, h->act3, h->dact3);
-    // conv3: 3x3 stride 1 pad 1, act2 -> act3
-    const int C2 = 2 * h->F1;
-    ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
-    hipLaunchKernelGGL((k_conv_wgrad<64, 64>), dim3(9, kWgSplits), dim3(256), 0, st, g3, B, ss, h->act2, h->dact3, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
-    {   // conv3 data gradient: padded grid (OH2 + 2)^2
+    SRLX_HIP(hipEventRecord(h->ev_d3, st));
+    {   // conv3 (3x3 stride 1 pad 1, act2 -> act3) data gradient: padded grid (OH2 + 2)^2
         const int HP = h->OH2 + 2, WP = h->OW2 + 2, n = C2 * 9 * C2;
         hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->w3, C2, 9, C2, h->w_t);
         SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st));
         const i64 tot = (i64)B * h->OH2 * h->OW2 * C2;
         hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, h->dxpad, h->act2, h->dact2);
     }
-    // conv2: 4x4 stride 2 pad 2, act1 -> act2
-    ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
-    hipLaunchKernelGGL((k_conv_wgrad<32, 64>), dim3(16, kWgSplits), dim3(256), 0, st, g2, B, ss, h->act1, h->dact2, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, st, h->w_part, kWgSplits, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2,
-                       g_b2);
-    {   // conv2 data gradient: padded grid (OH1 + 4)^2
+    SRLX_HIP(hipEventRecord(h->ev_d2, st));
+    {   // conv2 (4x4 stride 2 pad 2, act1 -> act2) data gradient: padded grid (OH1 + 4)^2
         const int HP = h->OH1 + 4, WP = h->OW1 + 4, n = C2 * 16 * h->F1;
         hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->w2, C2, 16, h->F1, h->w_t);
         SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact2, B, HP, WP, h->OH2, h->OW2, C2, 4, 4, 2, h->w_t, h->F1, h->dxpad, st));
         const i64 tot = (i64)B * h->OH1 * h->OW1 * h->F1;
         hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, h->dxpad, h->act1, h->dact1);
     }
-    // conv1: weight gradient from the uint8 frames
+    SRLX_HIP(hipEventRecord(h->ev_d1, st));
+    // ---- weight-gradient branch (side stream)
+    hipLaunchKernelGGL(k_fc1_wgrad, dim3((unsigned)((K + 255) / 256), (unsigned)(N1 / 32)), dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf);
+    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
+    ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
+    hipLaunchKernelGGL((k_conv_wgrad<64, 64>), dim3(9, kWgSplits), dim3(256), 0, sd, g3, B, ss, h->act2, h->dact3, h->w_part, bias_part);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
+    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
+    ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
+    hipLaunchKernelGGL((k_conv_wgrad<32, 64>), dim3(16, kWgSplits), dim3(256), 0, sd, g2, B, ss, h->act1, h->dact2, h->w_part, bias_part);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, kWgSplits, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2,
+                       g_b2);
+    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d1, 0));
     const int per = (h->OH1 * h->OW1 + kC1Chunks - 1) / kC1Chunks;
     const size_t lds = (size_t)h->Wn * kC1Frame + (size_t)per * 32 * sizeof(float);
     SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
-    hipLaunchKernelGGL(k_conv1_wgrad, dim3((unsigned)B, kC1Chunks), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, h->dact1,
+    hipLaunchKernelGGL(k_conv1_wgrad, dim3((unsigned)B, kC1Chunks), dim3(256), lds, sd, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, h->dact1,
                        h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, st, h->w_part, B * kC1Chunks, (i64)32 * h->Wn * 64, g_w1, bias_part, 32,
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, sd, h->w_part, B * kC1Chunks, (i64)32 * h->Wn * 64, g_w1, bias_part, 32,
                        g_b1);
+    SRLX_HIP(hipEventRecord(h->ev_join, sd));
+    SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

@@ -19,6 +19,8 @@ struct srlx_qnet {
     float *w_part;                        // weight-gradient partial sums (largest layer)
     float *dxpad, *w_t;                   // padded data gradient [max_train][HP*WP*CI], transposed filters [CI][taps*CO]
     size_t w_part_floats;
+    hipStream_t side;                     // weight-gradient branch of the backward pass (forks from / joins the caller's stream)
+    hipEvent_t ev_fork, ev_d3, ev_d2, ev_d1, ev_join;
 };
 
 // implicit-GEMM data gradient on the matrix cores (defined next to k_gemm in srlx_qnet.hip)

@@ -153,6 +153,9 @@ class RainbowEngine:
                                and os.environ.get("SRLX_TORCH_BACKWARD", "0") != "1")
             if self.mfma_train:
                 self.inf_online.enable_training(B)
+                # the target network's pass is independent of the online pass until the TD kernel: its own stream
+                self.s_target = torch.cuda.Stream(device=self.dev, priority=-1)
+                self._ev_t0, self._ev_t1 = torch.cuda.Event(), torch.cuda.Event()
         else:
             self.mfma_train = False
         self._front_graph = None
@@ -278,8 +281,14 @@ class RainbowEngine:
         B, n = cfg.batch_size, cfg.multisteps
         if self.mfma_train:
             b = r.sample_items(self.train_count_dev, all_states=True)
+            cur = torch.cuda.current_stream(self.dev)
+            self._ev_t0.record(cur)
+            self.s_target.wait_event(self._ev_t0)
+            with torch.cuda.stream(self.s_target):  # fork: target network (rainbow.py:221) alongside the online network
+                q_tg_next = self.inf_target.forward_u8(r.obs_base, r.frame_off_next.view(B * n, cfg.window_length))
+                self._ev_t1.record(self.s_target)
             q_all = self.inf_online.forward_u8(r.obs_base, r.frame_off_all.view(B * (n + 1), cfg.window_length)).view(B, n + 1, cfg.n_actions)
-            q_tg_next = self.inf_target.forward_u8(r.obs_base, r.frame_off_next.view(B * n, cfg.window_length))  # rainbow.py:221
+            cur.wait_event(self._ev_t1)  # join before the TD kernel
             q_on_next = q_all[:, 1:].contiguous()  # rainbow.py:220
             q0 = q_all[:, 0].contiguous()  # model_torch.py:103
         elif self.mfma:

@@ -251,7 +251,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ---- the GEMM ------------------------------------------------------------------------------------------
 template <class AL, int BN, bool RELU, bool SPLITK, int TBM = 128>
 __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ Bw, const float *__restrict__ bias, float *__restrict__ C, i64 M, int N,
-                                              int K, int k_per_split) {
+                                              int K, int k_per_split, i64 zstride_w = 0, i64 zstride_c = 0) {
+    if (!SPLITK) {  // batched GEMMs (blockIdx.z): same A loader, one weight matrix and one output per z
+        Bw += blockIdx.z * zstride_w;
+        C += blockIdx.z * zstride_c;
+    }
     __shared__ __attribute__((aligned(16))) float As[TBM * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -426,38 +430,39 @@ struct ANchw {
 };
 
 
-// data gradient of a convolution as an implicit GEMM over the PADDED input grid (replicate padding = an explicit pad
+// data gradient of a convolution as implicit GEMMs over the PADDED input grid (replicate padding = an explicit pad
 // followed by a plain convolution, so its gradient is the plain transposed convolution on the padded grid; the caller
-// folds the border rows/columns back): row m = (b, py, px), k = tap * CO + co, value = dY[b][(py-ky)/S][(px-kx)/S][co]
-// where that output exists, else 0.  CO is 32 or 64: a 32-wide slab has one tap.
+// folds the border rows/columns back).  With stride S only the taps ky = py mod S (+ S a) reach a padded row py, so the
+// grid is split into S*S parity classes, one GEMM each (blockIdx.z), with K = (KH/S)(KW/S) CO instead of KH KW CO:
+// row m = (b, qy, qx) with py = S qy + cy; k = (a, b', co); value = dY[b][qy - a][qx - b'][co] where that output exists.
 struct ADgrad {
     const float *dY;
-    int HP, WP, OH, OW, CO, KW, S;
-    unsigned char tap_y[80], tap_x[80];
+    int QH, QW, OH, OW, CO;
+    unsigned char tap_a[80], tap_b[80];
     struct Row {
         const float *img;  // null: row beyond M
-        int py, px;
+        int qy, qx;
     };
     __device__ __forceinline__ Row row(i64 m, i64 M) const {
         if (m >= M) return Row{nullptr, 0, 0};
-        const int per = HP * WP;
+        const int per = QH * QW;
         const i64 b = m / per;
         const int pix = (int)(m % per);
-        return Row{dY + b * (i64)OH * OW * CO, pix / WP, pix % WP};
+        return Row{dY + b * (i64)OH * OW * CO, pix / QW, pix % QW};
     }
     __device__ __forceinline__ float4 load4(const Row &r, int k0, int c4) const {
         if (!r.img) return make_float4(0.f, 0.f, 0.f, 0.f);
         const int slab = k0 >> 5;
-        const int oy = r.py - tap_y[slab], ox = r.px - tap_x[slab];
-        if (oy < 0 || ox < 0 || oy % S || ox % S || oy / S >= OH || ox / S >= OW) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int oy = r.qy - tap_a[slab], ox = r.qx - tap_b[slab];
+        if (oy < 0 || ox < 0 || oy >= OH || ox >= OW) return make_float4(0.f, 0.f, 0.f, 0.f);
         const int co = (k0 & (CO - 1) & ~31) + c4;
-        return *reinterpret_cast<const float4 *>(r.img + ((i64)(oy / S) * OW + ox / S) * CO + co);
+        return *reinterpret_cast<const float4 *>(r.img + ((i64)oy * OW + ox) * CO + co);
     }
-    void fill_taps(int K) {
+    void fill_taps(int K, int KWS) {
         for (int sl = 0; sl < K / 32 && sl < 80; sl++) {
             const int tap = (sl * 32) / CO;
-            tap_y[sl] = (unsigned char)(tap / KW);
-            tap_x[sl] = (unsigned char)(tap % KW);
+            tap_a[sl] = (unsigned char)(tap / KWS);
+            tap_b[sl] = (unsigned char)(tap % KWS);
         }
     }
 };
@@ -511,18 +516,23 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
 }
 }  // namespace
 
-// dXpad[M = B*HP*WP][CI] = ADgrad(dY) x WT[CI][taps*CO]^T  (srlx_qnet_bwd.hip)
-int srlx_qnet_dgrad_gemm(const float *dY, int B, int HP, int WP, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXpad,
+// per parity class z: dXq[z][M = B*QH*QW][CI] = ADgrad(dY) x WT[z][CI][K]^T, K = (KH/S)(KW/S) CO  (srlx_qnet_bwd.hip)
+int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,
                          hipStream_t st) {
-    ADgrad a{dY, HP, WP, OH, OW, CO, KW, S, {}, {}};
-    const int K = KH * KW * CO;
+    SRLX_REQUIRE(KH % S == 0 && KW % S == 0, "dgrad_gemm: the kernel size must be a multiple of the stride");
+    ADgrad a{dY, QH, QW, OH, OW, CO, {}, {}};
+    const int K = (KH / S) * (KW / S) * CO;
     SRLX_REQUIRE((CO == 32 || CO == 64) && K % BK == 0 && K / 32 <= 80 && (CI == 32 || CI == 64), "dgrad_gemm: unsupported channel counts");
-    a.fill_taps(K);
-    const i64 M = (i64)B * HP * WP;
-    if (CI == 64)
-        launch_gemm<ADgrad, 64, false, false>(a, wT, nullptr, dXpad, M, CI, K, 1, st);
-    else
-        launch_gemm<ADgrad, 32, false, false>(a, wT, nullptr, dXpad, M, CI, K, 1, st);
+    a.fill_taps(K, KW / S);
+    const i64 M = (i64)B * QH * QW;
+    const unsigned Z = (unsigned)(S * S);
+    if (CI == 64) {
+        dim3 grid((unsigned)((M + 63) / 64), 1, Z);
+        hipLaunchKernelGGL((k_gemm<ADgrad, 64, false, false, 64>), grid, dim3(256), 0, st, a, wT, nullptr, dXq, M, CI, K, K, (i64)CI * K, M * CI);
+    } else {
+        dim3 grid((unsigned)((M + BM - 1) / BM), 1, Z);
+        hipLaunchKernelGGL((k_gemm<ADgrad, 32, false, false>), grid, dim3(256), 0, st, a, wT, nullptr, dXq, M, CI, K, K, (i64)CI * K, M * CI);
+    }
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }
@@ -577,7 +587,7 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     if (!h) return SRLX_OK;
     srlx::DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    float *all[] = {h->act1, h->act2, h->act3, h->partial, h->h1, h->dh1, h->dact3, h->dact2, h->dact1, h->fc_part, h->w_part, h->dxpad, h->w_t};
+    float *all[] = {h->act1, h->act2, h->act3, h->partial, h->h1, h->dh1, h->dact3, h->dact2, h->dact1, h->fc_part, h->w_part, h->dxpad, h->w_t, h->w_t2};
     for (float *p : all)
         if (p) (void)hipFree(p);
     if (h->side) (void)hipStreamDestroy(h->side);

@@ -24,7 +24,7 @@ using u8 = unsigned char;
 
 constexpr int kFcSplits = 16;   // splits of the hidden dimension in the dense data-gradient
 constexpr int kWgSplits = 64;   // splits of the row dimension in the conv weight-gradients
-constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad, kC1Chunks = 4;
+constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad, kC1Chunks = 8;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float byte_to_unit(unsigned b) {  // u8 / 255, correctly rounded (see srlx_qnet.hip)
@@ -240,23 +240,30 @@ __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ 
 // convolution evaluated on the PADDED grid (an implicit GEMM on the matrix cores, srlx_qnet_dgrad_gemm: rows = padded
 // pixels, K = taps x CO, N = CI, filters transposed to [ci][tap][co]) followed by folding the pad rows / columns back
 // onto the border pixels they replicate, fused with the ReLU mask of the layer input.
-__global__ void __launch_bounds__(256) k_transpose_filter(const float *__restrict__ W, int CO, int taps, int CI, float *__restrict__ wT) {
+// wT[cls][ci][(a * KWS + b') * CO + co] = W[co][(cy + S a) * KW + (cx + S b')][ci],  cls = cy * S + cx
+__global__ void __launch_bounds__(256) k_transpose_filter(const float *__restrict__ W, int CO, int KH, int KW, int S, int CI, float *__restrict__ wT) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const int taps = KH * KW;
     if (i >= CO * taps * CI) return;
     const int ci = i % CI, tap = (i / CI) % taps, co = i / (CI * taps);  // W[co][tap][ci]
-    wT[((i64)ci * taps + tap) * CO + co] = W[i];
+    const int ky = tap / KW, kx = tap % KW, KWS = KW / S, Kc = (KH / S) * KWS * CO;
+    const int cls = (ky % S) * S + (kx % S);
+    wT[((i64)cls * CI + ci) * Kc + ((ky / S) * KWS + kx / S) * CO + co] = W[i];
 }
 
-__global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int W, int CI, int P, int HP, int WP, const float *__restrict__ dxpad,
-                                                  const float *__restrict__ X, float *__restrict__ dX) {
+// dX[b][iy][ix][ci] = [X > 0] * sum over the padded positions that replicate (iy, ix) of dXq[class][b][py / S][px / S][ci]
+__global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int W, int CI, int P, int HP, int WP, int S, int QH, int QW,
+                                                  const float *__restrict__ dxq, const float *__restrict__ X, float *__restrict__ dX) {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= (i64)B * H * W * CI) return;
     const int ci = (int)(i % CI), ix = (int)((i / CI) % W), iy = (int)((i / ((i64)CI * W)) % H), b = (int)(i / ((i64)CI * W * H));
     const int y0 = iy == 0 ? 0 : iy + P, y1 = iy == H - 1 ? HP - 1 : iy + P;
     const int x0 = ix == 0 ? 0 : ix + P, x1 = ix == W - 1 ? WP - 1 : ix + P;
+    const i64 cls_stride = (i64)B * QH * QW * CI;
     float s = 0.f;
     for (int py = y0; py <= y1; py++)
-        for (int px = x0; px <= x1; px++) s += dxpad[(((i64)b * HP + py) * WP + px) * CI + ci];
+        for (int px = x0; px <= x1; px++)
+            s += dxq[((py % S) * S + px % S) * cls_stride + (((i64)b * QH + py / S) * QW + px / S) * CI + ci];
     dX[i] = X[(((i64)b * sstride * H + iy) * W + ix) * CI + ci] > 0.f ? s : 0.f;
 }
 
@@ -342,10 +349,11 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
                 {&h->dact2, (size_t)max_train_batch * h->OH2 * h->OW2 * 2 * h->F1},
                 {&h->dact1, (size_t)max_train_batch * h->OH1 * h->OW1 * h->F1},
                 {&h->fc_part, (size_t)kFcSplits * max_train_batch * h->flat},
-                {&h->dxpad, (size_t)max_train_batch * ((size_t)(h->OH1 + 4) * (h->OW1 + 4) * h->F1 > (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1
-                                                             ? (size_t)(h->OH1 + 4) * (h->OW1 + 4) * h->F1
-                                                             : (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1)},
-                {&h->w_t, c3 > c2 ? c3 : c2},
+                {&h->dxpad, (size_t)max_train_batch * (4 * (size_t)((h->OH1 + 5) / 2) * ((h->OW1 + 5) / 2) * h->F1 > (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1
+                                                             ? 4 * (size_t)((h->OH1 + 5) / 2) * ((h->OW1 + 5) / 2) * h->F1
+                                                             : (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1) + 128 * 64},
+                {&h->w_t, c3},
+                {&h->w_t2, c2},
                 {&h->w_part, wp + 64 + 2 * kWgSplits * 64 + 64 * kC1Chunks * 32}};
     for (auto &b : bufs) {
         hipError_t e = hipMalloc((void **)b.p, b.n * sizeof(float));
@@ -400,20 +408,20 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
         hipLaunchKernelGGL(k_fc1_dgrad<64>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
     hipLaunchKernelGGL(k_fc1_dgrad_reduce, dim3((unsigned)(((i64)B * K + 255) / 256)), dim3(256), 0, st, B, ss, K, h->fc_part, h->act3, h->dact3);
     SRLX_HIP(hipEventRecord(h->ev_d3, st));
-    {   // conv3 (3x3 stride 1 pad 1, act2 -> act3) data gradient: padded grid (OH2 + 2)^2
+    {   // conv3 (3x3 stride 1 pad 1, act2 -> act3) data gradient on the padded grid (OH2 + 2)^2
         const int HP = h->OH2 + 2, WP = h->OW2 + 2, n = C2 * 9 * C2;
-        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->w3, C2, 9, C2, h->w_t);
+        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->w3, C2, 3, 3, 1, C2, h->w_t);
         SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st));
         const i64 tot = (i64)B * h->OH2 * h->OW2 * C2;
-        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, h->dxpad, h->act2, h->dact2);
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, 1, HP, WP, h->dxpad, h->act2, h->dact2);
     }
     SRLX_HIP(hipEventRecord(h->ev_d2, st));
-    {   // conv2 (4x4 stride 2 pad 2, act1 -> act2) data gradient: padded grid (OH1 + 4)^2
-        const int HP = h->OH1 + 4, WP = h->OW1 + 4, n = C2 * 16 * h->F1;
-        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->w2, C2, 16, h->F1, h->w_t);
-        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact2, B, HP, WP, h->OH2, h->OW2, C2, 4, 4, 2, h->w_t, h->F1, h->dxpad, st));
+    {   // conv2 (4x4 stride 2 pad 2, act1 -> act2) data gradient on the padded grid (OH1 + 4)^2, four parity classes
+        const int HP = h->OH1 + 4, WP = h->OW1 + 4, QH = (HP + 1) / 2, QW = (WP + 1) / 2, n = C2 * 16 * h->F1;
+        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->w2, C2, 4, 4, 2, h->F1, h->w_t2);
+        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact2, B, QH, QW, h->OH2, h->OW2, C2, 4, 4, 2, h->w_t2, h->F1, h->dxpad, st));
         const i64 tot = (i64)B * h->OH1 * h->OW1 * h->F1;
-        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, h->dxpad, h->act1, h->dact1);
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, 2, QH, QW, h->dxpad, h->act1, h->dact1);
     }
     SRLX_HIP(hipEventRecord(h->ev_d1, st));
     // ---- weight-gradient branch (side stream)

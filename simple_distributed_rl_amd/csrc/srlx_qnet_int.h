@@ -17,12 +17,12 @@ struct srlx_qnet {
     float *dh1, *dact3, *dact2, *dact1;   // [max_train][...]
     float *fc_part;                       // [kFcSplits][max_train][flat]
     float *w_part;                        // weight-gradient partial sums (largest layer)
-    float *dxpad, *w_t;                   // padded data gradient [max_train][HP*WP*CI], transposed filters [CI][taps*CO]
+    float *dxpad, *w_t, *w_t2;            // padded data gradient (per parity class), transposed filters of conv3 / conv2
     size_t w_part_floats;
     hipStream_t side;                     // weight-gradient branch of the backward pass (forks from / joins the caller's stream)
     hipEvent_t ev_fork, ev_d3, ev_d2, ev_d1, ev_join;
 };
 
 // implicit-GEMM data gradient on the matrix cores (defined next to k_gemm in srlx_qnet.hip)
-int srlx_qnet_dgrad_gemm(const float *dY, int B, int HP, int WP, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXpad,
+int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,
                          hipStream_t st);

@@ -114,7 +114,7 @@ class PPOEngine:
         self.dev = torch.device(f"cuda:{device}")
         torch.manual_seed(cfg.seed)
         self.net = ActorCritic(cfg).to(self.dev)
-        self.opt = torch.optim.Adam(self.net.parameters(), lr=cfg.lr)
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=cfg.lr, capturable=True)
         self.grad_sync = grad_sync
         self.env = PendulumVecEnv(cfg.n_envs, cfg.episode_len, cfg.seed, self.dev)
         self.ls_range = (math.log(cfg.stable_gradients_scale_range[0]), math.log(cfg.stable_gradients_scale_range[1]))
@@ -131,6 +131,8 @@ class PPOEngine:
         self.losses = torch.zeros(3, **f32)
         self.b_obs[0].copy_(self.env.obs)
         self.iterations = 0
+        self._rollout_graph = None
+        self._update_graph = None
         self.episode_return = torch.zeros(E, **f32)
         self.finished_returns = torch.zeros(2, **f32)  # sum, count of finished episodes since the last read
 
@@ -199,11 +201,38 @@ class PPOEngine:
                     torch.nn.utils.clip_grad_norm_(self.net.parameters(), cfg.global_gradient_clip_norm)
                 self.opt.step()
 
+    def capture_graphs(self):
+        """Captures the T-step rollout (+ GAE) and the whole update phase into two HIP graphs: an iteration becomes two
+        graph launches instead of ~T*20 + epochs*minibatches*60 eager ones.  Call after a few eager iterations (Adam
+        state and every scratch buffer must exist)."""
+        torch.cuda.synchronize(self.dev)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):  # warm-up on a capture-style stream
+            self.rollout()
+            self.update()
+            self.b_obs[0].copy_(self.b_obs[self.cfg.horizon])
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self.rollout()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            self.update()
+            self.b_obs[0].copy_(self.b_obs[self.cfg.horizon])
+        self._rollout_graph, self._update_graph = g1, g2
+        torch.cuda.synchronize(self.dev)
+
     def step(self):
         """one PPO iteration: T x E environment steps + epochs x minibatches updates"""
-        self.rollout()
-        self.update()
-        self.b_obs[0].copy_(self.b_obs[self.cfg.horizon])
+        if self._rollout_graph is not None:
+            self._rollout_graph.replay()
+            self._update_graph.replay()
+        else:
+            self.rollout()
+            self.update()
+            self.b_obs[0].copy_(self.b_obs[self.cfg.horizon])
         self.iterations += 1
 
     def pop_mean_episode_return(self) -> float:

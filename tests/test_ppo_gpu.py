@@ -192,3 +192,26 @@ def test_data_parallel_ppo_two_ranks_one_gpu(tmp_path):
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_ppo_engine_hip_graphs():
+    """The whole rollout (T steps + GAE) and the whole update phase replay as two HIP graphs: environments advance,
+    parameters move, losses stay finite, episodes finish on schedule."""
+    N, lib, torch, dev = _env()
+    from simple_distributed_rl_amd.device.ppo import PPODeviceConfig, PPOEngine
+
+    eng = PPOEngine(PPODeviceConfig(n_envs=512, horizon=25, seed=2), 0)
+    for _ in range(2):
+        eng.step()
+    eng.capture_graphs()
+    before = [p.detach().clone() for p in eng.net.parameters()]
+    obs0 = eng.b_obs[0].clone()
+    eng.pop_mean_episode_return()
+    for _ in range(16):  # 400 environment steps: every environment finishes two 200-step episodes
+        eng.step()
+    torch.cuda.synchronize()
+    assert int(eng.finished_returns[1].item()) == 2 * 512
+    assert np.isfinite(eng.pop_mean_episode_return())
+    assert all(np.isfinite(list(eng.info().values())))
+    assert any(float((p - q).abs().max()) > 0 for p, q in zip(eng.net.parameters(), before))
+    assert not torch.equal(eng.b_obs[0], obs0)

@@ -1,20 +1,22 @@
-"""Probe: PPO engine learning curve / throughput on the Pendulum-shaped workload."""
+"""Probe: PPO engine learning curve / throughput on the Pendulum-shaped workload (eager vs HIP graphs)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from simple_distributed_rl_amd.device.ppo import PPODeviceConfig, PPOEngine
-for name, kw in [
-    ("ref-defaults", dict()),
-    ("return-noVclip", dict(v_target="return", enable_value_clip=False, discount=0.95, gae_discount=0.9, lr=1e-3, entropy_weight=0.0)),
-    ("return-noVclip-g99", dict(v_target="return", enable_value_clip=False, discount=0.99, gae_discount=0.95, lr=1e-3, entropy_weight=0.0, epochs=8)),
-]:
-    cfg = PPODeviceConfig(n_envs=1024, horizon=50, seed=1, **kw)
+for name, E, graphs in [("eager-1024", 1024, False), ("graphs-1024", 1024, True), ("graphs-4096", 4096, True)]:
+    cfg = PPODeviceConfig(n_envs=E, horizon=50, seed=1)
     eng = PPOEngine(cfg, 0)
+    for _ in range(3):
+        eng.step()
+    if graphs:
+        eng.capture_graphs()
+    eng.pop_mean_episode_return()
     torch.cuda.synchronize(); t0 = time.time()
     curve = []
-    for it in range(200):
+    iters = 200
+    for it in range(iters):
         eng.step()
-        if (it + 1) % 20 == 0:
+        if (it + 1) % 40 == 0:
             curve.append(round(eng.pop_mean_episode_return()))
     torch.cuda.synchronize(); dt = time.time() - t0
-    print(name, curve, f"{200*cfg.n_envs*cfg.horizon/dt/1e6:.2f} M env-steps/s", eng.info())
+    print(name, curve, f"{iters*cfg.n_envs*cfg.horizon/dt/1e6:.2f} M env-steps/s", eng.info())

@@ -99,7 +99,7 @@ def flatten_parameters(module: torch.nn.Module) -> torch.Tensor:
 class DistributedRainbow:
     """world ranks x E actors, learner + replay on rank 0 (BASELINE.json config 4 topology applied to Rainbow)."""
 
-    def __init__(self, cfg, device: int, episode_len: int = 200, sync_interval: int = 16):
+    def __init__(self, cfg, device: int, episode_len: int = 200, sync_interval: int = 16, overlap: bool = True):
         import dataclasses
 
         from simple_distributed_rl_amd.device.rainbow import RainbowEngine, SyntheticAtariVecEnv
@@ -115,7 +115,9 @@ class DistributedRainbow:
         pad = cfg.multisteps + cfg.window_length
         # every rank: a short local ring, only for frame stacking of its own envs (no PER use)
         local_cfg = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62)
-        self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4)
+        # the learner rank overlaps its update with its own actors (second stream, private actor copy of the network),
+        # exactly like the single-GPU engine; the other ranks only act
+        self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, overlap=self.is_learner and overlap)
         self.flat = flatten_parameters(self.local.q_online)
         if self.local.mfma:  # the parameters moved: point the inference kernels at their new home
             self.local.inf_actor.bind()
@@ -173,16 +175,31 @@ class DistributedRainbow:
             else:
                 eng._actor_commit()
         env = eng.env
-        gathered = self.bus.push(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
-        if self.is_learner:
-            self.replay.commit(*gathered)
+        return self.bus.push(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
 
     def step(self, learner_updates: int = 1, events=None):
-        self.actor_and_push(events)
+        eng = self.local
+        overlapped = self.is_learner and eng.overlap
+        if overlapped:  # the learner works on the replay as of the end of the previous step, beside this step's actors
+            main = torch.cuda.current_stream(self.dev)
+            eng._ev_fork.record(main)
+            eng.s_learner.wait_event(eng._ev_fork)
+            with torch.cuda.stream(eng.s_learner):
+                for _ in range(learner_updates):
+                    self._with_global_replay(eng.learner_step)
+                eng._ev_join.record(eng.s_learner)
+        gathered = self.actor_and_push(events)
         self.step_count += 1
         if self.is_learner:
-            for _ in range(learner_updates):
-                self._with_global_replay(self.local.learner_step)
+            if overlapped:
+                main.wait_event(eng._ev_join)  # the commit below is the first write to the global replay
+            self.replay.commit(*gathered)
+            if overlapped:
+                with torch.no_grad():
+                    torch._foreach_copy_(list(eng.q_actor.parameters()), list(eng.q_online.parameters()))
+            else:
+                for _ in range(learner_updates):
+                    self._with_global_replay(eng.learner_step)
         if self.step_count % self.sync_interval == 0:
             self.bus.broadcast_params(self.flat)
 
@@ -195,7 +212,9 @@ class DistributedRainbow:
             t = t.to(self.dev)
         dist.broadcast(t, src=0)
         for _ in range(int(t.item())):
-            self.actor_and_push(random_policy=True)
+            gathered = self.actor_and_push(random_policy=True)
+            if self.is_learner:
+                self.replay.commit(*gathered)
         if self.is_learner:
             g = torch.Generator(device=self.dev)
             g.manual_seed(self.cfg.seed + 1)

@@ -158,11 +158,30 @@ def main():
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= the fp32 vector peak)
 
 
+def _isolated_forward_ms(eng, reps=20):
+    """The same kernel group with nothing else on the GPU (in the timed region the learner's streams share the chip)."""
+    import torch
+
+    local = getattr(eng, "local", eng)
+    for _ in range(3):
+        local._actor_net(None)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    off = local.replay.frame_table_current()
+    a.record()
+    for _ in range(reps):
+        local.inf_actor.forward_u8(local.replay.obs_base, off)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
 def roofline(eng, ev_ms):
     """The dominant hand-written kernel group of a step, timed with events on its launch stream."""
     if eng.mfma:
         flops = eng.actor_forward_flops()
         tf = flops / (ev_ms * 1e-3) / 1e12
+        iso_ms = _isolated_forward_ms(eng)
         return {
             "kernel": "srlx_qnet_forward_u8 over E envs: k_conv1_u8 (conv1 from the uint8 ring) + k_gemm<AConv> x2 + k_gemm<APlain,splitK> (FC1) + k_head",
             "bound": "mfma",
@@ -173,6 +192,8 @@ def roofline(eng, ev_ms):
             "traffic": None,
             "flops_per_launch_group": flops,
             "avg_launch_group_ms": ev_ms,
+            "note": "timed inside the step loop, where the learner's three streams run beside it; `isolated` = the same launches alone",
+            "isolated": {"avg_launch_group_ms": iso_ms, "achieved": flops / (iso_ms * 1e-3) / 1e12, "frac": flops / (iso_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
             "dtype": "f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32)",
         }
     nbytes = eng.stack_bytes_per_launch()

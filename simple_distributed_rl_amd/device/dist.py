@@ -224,7 +224,7 @@ class DistributedRainbow:
 
     def capture_graphs(self):
         # actor step: local graph on every rank; learner: graph over the global replay on rank 0
-        self.local.capture_graphs(actor=True, learner=False)
+        self.local.capture_graphs(actor=True, learner=False, warm_actor=False)
         if self.is_learner:
             self._with_global_replay(lambda: self.local.capture_graphs(actor=False, learner=True))
 

@@ -386,14 +386,16 @@ class RainbowEngine:
                 self.learner_step()
 
     # ---- HIP graphs -------------------------------------------------------------------------
-    def capture_graphs(self, actor: bool = True, learner: bool = True):
+    def capture_graphs(self, actor: bool = True, learner: bool = True, warm_actor: bool = True):
         """Captures the actor step and the learner step into HIP graphs (launch-bound inner loops).
-        Call after warm-up: arenas are sized and the replay is past its warm-up gate."""
+        Call after warm-up: arenas are sized and the replay is past its warm-up gate.  `warm_actor=False` skips the
+        extra eager actor step (the distributed wrapper has already stepped, and an un-pushed step would desynchronise
+        the learner's global ring from this rank's environments)."""
         torch.cuda.synchronize(self.dev)
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
-            if actor:
+            if actor and warm_actor:
                 self.actor_step()
                 self.total_env_steps += self.cfg.n_envs
             if learner and not self.replay.is_warmup_needed():

@@ -34,7 +34,10 @@ def _worker(rank, world, port, ret):
         cfg = RainbowDeviceConfig(n_envs=16, batch_size=8, memory_capacity=16 * 2 * 40, memory_warmup_size=64, obs_hw=(20, 20), hidden_units=32,
                                   n_actions=4, seed=rank, target_model_update_interval=3)
         eng = DistributedRainbow(cfg, 0, episode_len=7, sync_interval=2)
-        for _ in range(12):
+        for _ in range(8):
+            eng.step(learner_updates=2)
+        eng.capture_graphs()  # HIP graphs mid-run: must not step the local environments without pushing
+        for _ in range(4):
             eng.step(learner_updates=2)
         torch.cuda.synchronize()
         out = {"flat_sum": float(eng.flat.double().sum().item()), "flat_abs": float(eng.flat.double().abs().sum().item())}

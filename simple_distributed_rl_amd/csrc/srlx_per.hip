@@ -46,7 +46,7 @@ constexpr i64 kSmallSampleMax = 8192;  // uniforms handled by the single-workgro
 constexpr int kWgUpdate = 256;
 constexpr int kUpdateChunk = 1024;   // indices per general-update launch (LDS resident)
 constexpr int kWgAdd = 256;
-constexpr i64 kSmallAddMax = 1024;   // adds handled by the single-workgroup path
+constexpr i64 kSmallAddMax = 8192;   // adds handled by the single-workgroup path (changes in LDS: 64 KB at 8192 = 8 GPUs x 1024 envs)
 
 __host__ __device__ __forceinline__ int node_depth(i64 x) {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -938,8 +938,8 @@ __device__ __forceinline__ void add_commit(const AddArgs &a) {
 
 // n <= kSmallAddMax: everything in one launch; the per-leaf changes live in LDS so that the root
 // owner's n dependent fp64 additions are fed from LDS, not from memory
-__global__ void __launch_bounds__(kWgAdd) k_add_wg(AddArgs a) {
-    __shared__ double s_chg[kSmallAddMax];
+__global__ void __launch_bounds__(1024) k_add_wg(AddArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double s_chg[];  // n doubles
     a.chg = s_chg;
     const int t = threadIdx.x, T = blockDim.x;
     const i64 write = add_start(a);
@@ -1026,7 +1026,7 @@ int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st,
     AddArgs a{h->tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr,
               start_slot, append ? 1 : 0, append ? 0 : 1, 0.0, snap};
     if (n <= kSmallAddMax) {
-        hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(kWgAdd), 0, st, a);
+        hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(n <= 1024 ? kWgAdd : 1024), (size_t)n * sizeof(double), st, a);
     } else {
         const int blocks = (int)((n + 255) / 256);
         hipLaunchKernelGGL(k_snapshot_max, dim3(1), dim3(1), 0, st, h->d_state, snap);

@@ -248,6 +248,32 @@ def test_full_size_1M_bulk_paths():
     assert abs(tree[0] - tree[cap - 1 :].sum()) / tree[0] < 1e-9
 
 
+@pytest.mark.parametrize("capacity,n", [(20_000, 8192), (9000, 5000), (1_000_448, 8192), (6000, 3000)])
+def test_multi_gpu_sized_adds_vs_oracle(capacity, n):
+    """The learner rank of an N-GPU run adds N x E consecutive slots per step (8192 = 8 x 1024): the single-workgroup
+    add with its per-leaf changes in 64 KB of LDS, incl. ring wrap-around, masked (zero-priority) slots and both leaf
+    depths -- tree bit-equal to the oracle's one-by-one adds."""
+    N = _N()
+    rng = np.random.default_rng(n)
+    g = AbiPER(capacity, 0.5, 0.4, 5000, True, 1e-4)
+    o = OraclePER(capacity, 0.5, 0.4, 5000, True, 1e-4)
+    rounds = 4 if capacity < 100_000 else 2
+    for it in range(rounds):
+        if it % 2 == 0:
+            v = rng.random(n) * 2
+            g.add(v, N.PRIO_F64)
+            for x in v:
+                o.add(float(np.sqrt(abs(x) + 1e-4)), mode=2)
+        else:
+            g.add(None, n=n)
+            for _ in range(n):
+                o.add(None)
+    mp, size, write, tree = g.state()
+    omp, osize, owrite, otree = o.get_state()
+    np.testing.assert_array_equal(tree, otree)
+    assert (mp, size, write) == (omp, osize, owrite)
+
+
 @pytest.mark.parametrize("cap", [1_000_000, 300_001])
 def test_binned_bulk_walk_equals_oracle(cap, monkeypatch):
     """SRLX_PER_BULK=binned (counting-sorted bulk descent, the measured alternative to the flat walk): same

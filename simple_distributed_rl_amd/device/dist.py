@@ -43,6 +43,7 @@ class TransitionBus:
             self.g_terminated = torch.zeros(T, dtype=torch.uint8, device=device)
             self.g_done = torch.zeros(T, dtype=torch.uint8, device=device)
             self.g_next_obs = torch.zeros((T, obs_elems), dtype=obs_dtype, device=device)
+            self.g_scal = torch.zeros((self.world, 10 * self.E), dtype=torch.uint8, device=device)  # packed scalar records
 
     def _views(self, buf) -> Optional[List[torch.Tensor]]:
         if not self.is_learner:
@@ -54,17 +55,30 @@ class TransitionBus:
         order (env index = rank * E + local index).  Returns the gathered tensors on the learner, None elsewhere."""
         if self.world == 1:
             return actions, rewards, terminated, done, next_obs
-        pairs = ((actions, "g_actions"), (rewards, "g_rewards"), (terminated, "g_terminated"), (done, "g_done"), (next_obs, "g_next_obs"))
+        # two collectives per step: the frames, and ONE packed record buffer for the four scalar fields
+        # ([actions 4E | rewards 4E | terminated E | done E] bytes per rank) that the learner unpacks with strided copies
+        E = self.E
+        scal = torch.cat([actions.contiguous().view(torch.uint8), rewards.contiguous().view(torch.uint8), terminated.contiguous().view(torch.uint8),
+                          done.contiguous().view(torch.uint8)])
         staged = dist.get_backend(self.group) == "gloo" and actions.is_cuda  # test rigs: 2 ranks sharing one GPU
-        for t, name in pairs:
+        for t, name in ((scal, "g_scal"), (next_obs, "g_next_obs")):
             if staged:
                 parts = [torch.empty_like(t, device="cpu") for _ in range(self.world)] if self.is_learner else None
                 dist.gather(t.cpu(), parts, dst=self.learner_rank, group=self.group)
                 if self.is_learner:
-                    getattr(self, name).copy_(torch.cat(parts).to(self.device))
+                    getattr(self, name).view(-1).copy_(torch.cat([p.view(-1) for p in parts]).to(self.device).view(getattr(self, name).dtype))
             else:
-                dist.gather(t, self._views(getattr(self, name)) if self.is_learner else None, dst=self.learner_rank, group=self.group)
+                views = None
+                if self.is_learner:
+                    buf = getattr(self, name)
+                    views = [buf[r] for r in range(self.world)] if name == "g_scal" else self._views(buf)
+                dist.gather(t, views, dst=self.learner_rank, group=self.group)
         if self.is_learner:
+            g = self.g_scal
+            self.g_actions.view(torch.uint8).view(self.world, 4 * E).copy_(g[:, : 4 * E])
+            self.g_rewards.view(torch.uint8).view(self.world, 4 * E).copy_(g[:, 4 * E : 8 * E])
+            self.g_terminated.view(self.world, E).copy_(g[:, 8 * E : 9 * E])
+            self.g_done.view(self.world, E).copy_(g[:, 9 * E :])
             return self.g_actions, self.g_rewards, self.g_terminated, self.g_done, self.g_next_obs
         return None
 

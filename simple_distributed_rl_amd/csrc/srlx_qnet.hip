@@ -136,27 +136,23 @@ struct AU8 {  // uint8 frames addressed through frame_off[sample][Wn] (bytes fro
 // ---- conv1 straight from the uint8 frame ring ---------------------------------------------------------
 // The generic implicit GEMM re-gathers every byte of a frame four times from HBM-resident memory and pays the
 // address arithmetic per element; with N = 32 there are only 16 MFMAs per K-slab to hide that behind (measured:
-// 200 us at 1024 samples = 24 % of the matrix-core peak).  Here ONE workgroup owns ONE sample: its window of
-// frames is staged once into LDS (uint8, replicate padding materialised: 88 x 88 per frame), the 32 x 256 filter
-// matrix next to it, and every A fragment is two 8-byte LDS reads + 16 exact u8/255 conversions in registers.
+// 200 us at 1024 samples = 24 % of the matrix-core peak).  Here ONE workgroup owns ONE sample: its window of four
+// frames is staged once into LDS (uint8, replicate padding materialised: 88 x 88 per frame = 31 KB, so several
+// workgroups share a CU and one's staging hides behind the others' MFMAs), every lane keeps ITS slice of the 32 x 256
+// filter matrix in registers for all the tiles of its wave (8 K-slabs x 16 floats), and every A fragment is two 8-byte
+// LDS reads + 16 exact u8/255 conversions in registers.
 // Fragment order: slab (frame c, kernel rows kyb..kyb+3); lane (i, h) holds rows kyb + 2h, kyb + 2h + 1, kx = 0..7,
 // i.e. k = c*64 + kyb*8 + 16h + s -- the same 16 contiguous floats of the [32][256] weight row for B.
 constexpr int kC1Pad = 88;                     // padded frame side: 4*20 + 8
 constexpr int kC1Frame = kC1Pad * kC1Pad;      // bytes per staged frame
-constexpr int kC1WStride = 260;                // floats per staged weight row (256 + 4: conflict-free b128 reads)
 
-__global__ void __launch_bounds__(256) k_conv1_u8(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, int Wn, int H, int W, int OH, int OW,
+__global__ void __launch_bounds__(256, 3) k_conv1_u8(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, int Wn, int H, int W, int OH, int OW,
                                                   const float *__restrict__ w1, const float *__restrict__ b1, float *__restrict__ act1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *ws = reinterpret_cast<float *>(smem);                 // [32][kC1WStride]
-    u8 *fr = smem + 32 * kC1WStride * sizeof(float);             // [Wn][88][88]
+    u8 *fr = smem;  // [4][88][88]
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const i64 b = blockIdx.x;
-    const int K = Wn * 64;
-    for (int idx = t; idx < 32 * (K / 4); idx += 256) {  // weights: float4 granularity
-        const int n = idx / (K / 4), q = idx % (K / 4);
-        *reinterpret_cast<float4 *>(ws + n * kC1WStride + 4 * q) = *reinterpret_cast<const float4 *>(w1 + (i64)n * K + 4 * q);
-    }
+    constexpr int K = 256;  // Wn == 4 (checked by the launcher)
     // frames: padded dword (row r, dword d) covers padded columns 4d..4d+3 = image columns clamp(4d - 3 .. 4d), image row
     // clamp(r - 3).  The ring lives in HBM: all loads of a frame are issued before the first LDS store (8 in flight per
     // lane), each is ONE in-bounds unaligned dword whose bytes are re-picked at the left / right border.
@@ -196,6 +192,18 @@ __global__ void __launch_bounds__(256) k_conv1_u8(const u8 *__restrict__ base, c
             }
         }
     }
+    // this lane's B fragments of all eight K-slabs: filter row n = lane & 31, k = slab*32 + 16 (lane >> 5) + 0..15
+    float bfr[8][16];
+    {
+        const float *wp = w1 + (i64)(lane & 31) * K + 16 * (lane >> 5);
+#pragma unroll
+        for (int sl = 0; sl < 8; sl++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const float4 x = *reinterpret_cast<const float4 *>(wp + sl * 32 + 4 * v);
+                bfr[sl][4 * v] = x.x, bfr[sl][4 * v + 1] = x.y, bfr[sl][4 * v + 2] = x.z, bfr[sl][4 * v + 3] = x.w;
+            }
+    }
     __syncthreads();
     const int h = lane >> 5, i = lane & 31;
     const int M = OH * OW, tiles = (M + 31) / 32;
@@ -207,7 +215,8 @@ __global__ void __launch_bounds__(256) k_conv1_u8(const u8 *__restrict__ base, c
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        for (int c = 0; c < Wn; c++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
 #pragma unroll
             for (int kyb = 0; kyb < 8; kyb += 4) {
                 const u8 *p = win + c * kC1Frame + kyb * kC1Pad;
@@ -216,17 +225,10 @@ __global__ void __launch_bounds__(256) k_conv1_u8(const u8 *__restrict__ base, c
                 w[1] = *reinterpret_cast<const unsigned *>(p + 4);
                 w[2] = *reinterpret_cast<const unsigned *>(p + kC1Pad);
                 w[3] = *reinterpret_cast<const unsigned *>(p + kC1Pad + 4);
-                float bf[16];
-                const float *wp = ws + i * kC1WStride + c * 64 + kyb * 8 + 16 * h;
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const float4 x = *reinterpret_cast<const float4 *>(wp + 4 * v);
-                    bf[4 * v] = x.x, bf[4 * v + 1] = x.y, bf[4 * v + 2] = x.z, bf[4 * v + 3] = x.w;
-                }
 #pragma unroll
                 for (int s = 0; s < 16; s++) {
                     const float a = byte_to_unit((w[s >> 2] >> (8 * (s & 3))) & 255u);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[2 * c + kyb / 4][s], acc, 0, 0, 0);
                 }
             }
         }
@@ -611,8 +613,8 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
     SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_u8: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = 32 * kC1WStride * sizeof(float) + (size_t)h->Wn * kC1Frame;
-    if (h->F1 == 32 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && 4 * (h->OW1 - 1) + 8 <= kC1Pad && lds <= 64 * 1024 && h->W % 4 == 0) {
+    const size_t lds = (size_t)h->Wn * kC1Frame;
+    if (h->F1 == 32 && h->Wn == 4 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && 4 * (h->OW1 - 1) + 8 <= kC1Pad && h->W % 4 == 0) {
         // one workgroup per sample, frames + filters staged in LDS
         hipLaunchKernelGGL(k_conv1_u8, dim3((unsigned)batch, batch < 200 ? 2u : 1u), dim3(256), lds, st, d_frame_base, d_frame_off, h->Wn, h->H, h->W, h->OH1, h->OW1, h->w1, h->b1,
                            h->act1);

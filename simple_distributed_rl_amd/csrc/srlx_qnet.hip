@@ -60,7 +60,8 @@ struct AConv {  // NHWC float32 input [B][H][W][C]; k = (ky * KW + kx) * C + c; 
                 // so the 32 k of one slab share their filter tap: (ky, kx) come from a per-slab table, no per-lane division
     const float *in;
     int H, W, C, KW, S, P, OH, OW;
-    unsigned char tap_y[80], tap_x[80];  // slab (k0 / 32) -> filter tap
+    int tap[80];  // slab (k0 / 32) -> filter tap ky | kx << 8: dwords, so that the uniform lookup is a scalar load (byte tables are
+                  // fetched with per-lane global_load_ubyte + vmcnt(0), which serialised the four row fetches of a slab)
     struct Row {
         const float *img;  // null: row beyond M
         int iy0, ix0;
@@ -77,14 +78,14 @@ struct AConv {  // NHWC float32 input [B][H][W][C]; k = (ky * KW + kx) * C + c; 
         if (!r.img) return make_float4(0.f, 0.f, 0.f, 0.f);
         const int slab = k0 >> 5;                 // uniform across the workgroup
         const int c = (k0 & (C - 1) & ~31) + c4;  // C is 32 or a multiple of 64 that is a power of two
-        const int iy = clampi(r.iy0 + tap_y[slab], 0, H - 1), ix = clampi(r.ix0 + tap_x[slab], 0, W - 1);
+        const int tp = tap[slab];
+        const int iy = clampi(r.iy0 + (tp & 255), 0, H - 1), ix = clampi(r.ix0 + (tp >> 8), 0, W - 1);
         return *reinterpret_cast<const float4 *>(r.img + ((i64)iy * W + ix) * C + c);
     }
     void fill_taps(int K) {
         for (int sl = 0; sl < K / 32 && sl < 80; sl++) {
             const int kyx = (sl * 32) / C;
-            tap_y[sl] = (unsigned char)(kyx / KW);
-            tap_x[sl] = (unsigned char)(kyx % KW);
+            tap[sl] = (kyx / KW) | ((kyx % KW) << 8);
         }
     }
 };
@@ -440,7 +441,7 @@ struct ANchw {
 struct ADgrad {
     const float *dY;
     int QH, QW, OH, OW, CO;
-    unsigned char tap_a[80], tap_b[80];
+    int tap[80];  // slab -> a | b' << 8 (dwords: scalar loads)
     struct Row {
         const float *img;  // null: row beyond M
         int qy, qx;
@@ -455,16 +456,16 @@ struct ADgrad {
     __device__ __forceinline__ float4 load4(const Row &r, int k0, int c4) const {
         if (!r.img) return make_float4(0.f, 0.f, 0.f, 0.f);
         const int slab = k0 >> 5;
-        const int oy = r.qy - tap_a[slab], ox = r.qx - tap_b[slab];
+        const int tp = tap[slab];
+        const int oy = r.qy - (tp & 255), ox = r.qx - (tp >> 8);
         if (oy < 0 || ox < 0 || oy >= OH || ox >= OW) return make_float4(0.f, 0.f, 0.f, 0.f);
         const int co = (k0 & (CO - 1) & ~31) + c4;
         return *reinterpret_cast<const float4 *>(r.img + ((i64)oy * OW + ox) * CO + co);
     }
     void fill_taps(int K, int KWS) {
         for (int sl = 0; sl < K / 32 && sl < 80; sl++) {
-            const int tap = (sl * 32) / CO;
-            tap_a[sl] = (unsigned char)(tap / KWS);
-            tap_b[sl] = (unsigned char)(tap % KWS);
+            const int t = (sl * 32) / CO;
+            tap[sl] = (t / KWS) | ((t % KWS) << 8);
         }
     }
 };
@@ -492,11 +493,11 @@ void launch_gemm(const AL &al, const float *Bw, const float *bias, float *C, i64
 
 int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     // conv2: 4x4 stride 2 pad 2 on act1 [B][OH1][OW1][F1]
-    AConv c2{h->act1, h->OH1, h->OW1, h->F1, 4, 2, 2, h->OH2, h->OW2, {}, {}};
+    AConv c2{h->act1, h->OH1, h->OW1, h->F1, 4, 2, 2, h->OH2, h->OW2, {}};
     c2.fill_taps(16 * h->F1);
     launch_gemm<AConv, 64, true, false>(c2, h->w2, h->b2, h->act2, B * h->OH2 * h->OW2, 2 * h->F1, 16 * h->F1, 1, st);
     // conv3: 3x3 stride 1 pad 1
-    AConv c3{h->act2, h->OH2, h->OW2, 2 * h->F1, 3, 1, 1, h->OH3, h->OW3, {}, {}};
+    AConv c3{h->act2, h->OH2, h->OW2, 2 * h->F1, 3, 1, 1, h->OH3, h->OW3, {}};
     c3.fill_taps(9 * 2 * h->F1);
     launch_gemm<AConv, 64, true, false>(c3, h->w3, h->b3, h->act3, B * h->OH3 * h->OW3, 2 * h->F1, 9 * 2 * h->F1, 1, st);
     // FC1 split along K so that ~512 workgroups exist whatever the batch
@@ -522,7 +523,7 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
 int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,
                          hipStream_t st) {
     SRLX_REQUIRE(KH % S == 0 && KW % S == 0, "dgrad_gemm: the kernel size must be a multiple of the stride");
-    ADgrad a{dY, QH, QW, OH, OW, CO, {}, {}};
+    ADgrad a{dY, QH, QW, OH, OW, CO, {}};
     const int K = (KH / S) * (KW / S) * CO;
     SRLX_REQUIRE((CO == 32 || CO == 64) && K % BK == 0 && K / 32 <= 80 && (CI == 32 || CI == 64), "dgrad_gemm: unsupported channel counts");
     a.fill_taps(K, KW / S);

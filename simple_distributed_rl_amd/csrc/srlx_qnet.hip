@@ -202,14 +202,21 @@ __global__ void __launch_bounds__(256, 3) k_conv1_u8(const u8 *__restrict__ base
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const float4 x = *reinterpret_cast<const float4 *>(wp + sl * 32 + 4 * v);
-                bfr[sl][4 * v] = x.x, bfr[sl][4 * v + 1] = x.y, bfr[sl][4 * v + 2] = x.z, bfr[sl][4 * v + 3] = x.w;
+                // 1/255 is folded into the filter slice ONCE per lane: the A operand is then the raw byte (one v_cvt_f32_ubyte per
+                // MFMA instead of cvt + 3-op exact division; f32 MFMAs and VALU instructions share the SIMD's issue slots).
+                // byte * RN(w/255) differs from RN(byte/255) * w by <= 1 ulp per product: Q-values stay inside the 1e-5 bar.
+                bfr[sl][4 * v] = x.x * (1.0f / 255.0f), bfr[sl][4 * v + 1] = x.y * (1.0f / 255.0f), bfr[sl][4 * v + 2] = x.z * (1.0f / 255.0f),
+                bfr[sl][4 * v + 3] = x.w * (1.0f / 255.0f);
             }
     }
     __syncthreads();
     const int h = lane >> 5, i = lane & 31;
     const int M = OH * OW, tiles = (M + 31) / 32;
     const float bias = b1[i];
-    for (int tile = wave * gridDim.y + blockIdx.y; tile < tiles; tile += 4 * gridDim.y) {  // gridDim.y workgroups share a sample at small batches
+    // 14 tiles over 4 waves is 4/4/3/3: rotate the assignment with the sample index so that every SIMD of a CU gets the same
+    // number of tiles over the samples it hosts
+    const int wrot = (wave + (int)(b & 3)) & 3;
+    for (int tile = wrot * gridDim.y + blockIdx.y; tile < tiles; tile += 4 * gridDim.y) {  // gridDim.y workgroups share a sample at small batches
         const int m = tile * 32 + i < M ? tile * 32 + i : M - 1;
         const int oy = m / OW, ox = m % OW;
         const u8 *win = fr + (4 * oy + 2 * h) * kC1Pad + 4 * ox;  // this lane's first kernel row inside a slab
@@ -228,7 +235,7 @@ __global__ void __launch_bounds__(256, 3) k_conv1_u8(const u8 *__restrict__ base
                 w[3] = *reinterpret_cast<const unsigned *>(p + kC1Pad + 4);
 #pragma unroll
                 for (int s = 0; s < 16; s++) {
-                    const float a = byte_to_unit((w[s >> 2] >> (8 * (s & 3))) & 255u);
+                    const float a = (float)((w[s >> 2] >> (8 * (s & 3))) & 255u);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[2 * c + kyb / 4][s], acc, 0, 0, 0);
                 }
             }

@@ -227,6 +227,23 @@ int srlx_gae_scan(int64_t n_envs, int64_t horizon, const float *d_rewards, const
                   const float *d_last_values, double discount, double gae_lambda, float *d_adv, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Rank-based prioritised replay: srl/rl/memories/priority_memories/rankbased_memory.py:13-77.
+ * Which ranks are drawn depends only on N, alpha and numpy's generator and stays on the host (bit-identical
+ * np.random.choice); the data-dependent half -- np.argsort(-priorities[:N]) on EVERY sample (:47) -- is a descending
+ * radix sort of (priority, index) pairs in HBM + a gather of the drawn ranks.  Ties: the device sort is stable
+ * (lower index first), numpy's introsort is not: results agree whenever the priorities are distinct.
+ *   srlx_rank_set        : add (:33-40, d_idx NULL: slots (start + i) % capacity) / update (:60-62) of float32 priorities
+ *   srlx_rank_select     : out[i] = index of the ranks[i]-th largest of priorities[0..n_live)
+ *   srlx_rank_priorities : device pointer of the float32 [capacity] priority array (backup / restore, :64-77)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct srlx_rank srlx_rank_t;
+int srlx_rank_create(srlx_rank_t **out, int64_t capacity, int device);
+int srlx_rank_destroy(srlx_rank_t *h);
+int srlx_rank_set(srlx_rank_t *h, int64_t n, const int64_t *d_idx, const float *d_val, int64_t start, void *stream);
+int srlx_rank_select(srlx_rank_t *h, int64_t n_live, int64_t n, const int64_t *d_ranks, int64_t *d_out, void *stream);
+int srlx_rank_priorities(srlx_rank_t *h, float **d_prio);
+
+/* ------------------------------------------------------------------------------------------------
  * PPO on the vectorised path (BASELINE config 5).  The reference module needs TensorFlow
  * (srl/algorithms/ppo/ppo.py:6-7) and cannot be imported in the build container: parity UNPINNED, restated
  * from the cited lines and checked against oracle/hot_path_oracle.py + torch autograd.

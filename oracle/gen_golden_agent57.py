@@ -424,3 +424,36 @@ def gen_a57_train_step():
 
 
 AGENT57_GENERATORS.update(agent57_seq_target=gen_a57_target, agent57_rollout=gen_a57_rollout, agent57_seq_train_step=gen_a57_train_step)
+
+
+# ----------------------------------------------------------------------------------------
+# rank-based memory (srl/rl/memories/priority_memories/rankbased_memory.py) scripted trace
+# ----------------------------------------------------------------------------------------
+def gen_rankbased():
+    from srl.rl.memories.priority_memories.rankbased_memory import RankBasedMemory
+
+    rng = np.random.default_rng(51)
+    cap, alpha = 300, 0.6
+    mem = RankBasedMemory(cap, alpha, 0.4, 1000)
+    np.random.seed(123)
+    adds = rng.permutation(1000)[:460].astype(np.float32) / 7  # distinct priorities; 440 adds > capacity: the ring wraps
+    ops = []
+    k = 0
+    for rnd in range(12):
+        n_add = 60 if rnd < 5 else 20
+        for _ in range(n_add):
+            mem.add(int(k), float(adds[k]))
+            k += 1
+        B = 16
+        batches, weights, idx = mem.sample(B, 100 * rnd)
+        new_p = (rng.permutation(5000)[:B].astype(np.float32) + 2000) / 3  # distinct from everything stored
+        mem.update(idx, new_p)
+        ops.append((n_add, np.asarray(batches), np.asarray(weights), np.asarray(idx), new_p))
+    np.savez_compressed(os.path.join(OUT, "rankbased_trace.npz"), capacity=np.int64(cap), alpha=np.float64(alpha), beta_initial=np.float64(0.4), beta_steps=np.int64(1000),
+                        seed=np.int64(123), add_priorities=adds[:k], n_add=np.array([o[0] for o in ops]), batches=np.array([o[1] for o in ops]),
+                        weights=np.array([o[2] for o in ops]), indices=np.array([o[3] for o in ops]), new_priorities=np.array([o[4] for o in ops]),
+                        final_priorities=mem.priorities.copy())
+    print(f"rankbased_trace: {k} adds, 12 samples of 16")
+
+
+AGENT57_GENERATORS.update(rankbased=gen_rankbased)

@@ -516,3 +516,17 @@ def agent57_seq_loss(q, target, actions, weights):
     grad = np.zeros_like(q)
     np.put_along_axis(grad[:, :-1, :], np.asarray(actions)[..., None].astype(np.int64), g.T[..., None], axis=2)
     return loss, grad, np.mean(aq - target, axis=0)
+
+
+# ------------------------------------------------------------------------------------------
+# rank-based memory, srl/rl/memories/priority_memories/rankbased_memory.py:42-58 (PINNED by rankbased_trace.npz)
+# ------------------------------------------------------------------------------------------
+def rankbased_sample(priorities_live, batch_size, alpha, beta):
+    """Draws with numpy's GLOBAL generator exactly like the reference: returns (buffer indices, weights)."""
+    n = len(priorities_live)
+    order = np.argsort(-np.asarray(priorities_live, np.float32))  # :47
+    probs = (1 / np.arange(1, n + 1)) ** alpha
+    probs /= probs.sum()
+    ranks = np.random.choice(n, size=batch_size, p=probs, replace=False)  # == np.random.choice(order, ..., p=probs): same stream
+    w = (n * probs[ranks]) ** (-beta)
+    return order[ranks], w / w.max()

@@ -81,6 +81,11 @@ SIGNATURES = {
     ),
     "srlx_dqn_target": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_p, c_int, c_int, c_int, c_p, c_p]),
     "srlx_gae_scan": (c_int, [c_i64, c_i64, c_p, c_p, c_p, c_p, c_f64, c_f64, c_p, c_p]),
+    "srlx_rank_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_int]),
+    "srlx_rank_destroy": (c_int, [c_p]),
+    "srlx_rank_set": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_p]),
+    "srlx_rank_select": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "srlx_rank_priorities": (c_int, [c_p, ctypes.POINTER(c_p)]),
     "srlx_ppo_normal_act": (c_int, [c_i64, c_p, c_p, c_f64, c_f64, c_u64, c_p, c_int, c_p, c_p, c_p]),
     "srlx_ppo_loss_normal": (c_int, [c_i64, c_int, c_p, c_p, c_f64, c_f64, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f64, c_int, c_f64, c_f64, c_f64,
                                      c_p, c_p, c_p, c_p, c_p]),

@@ -112,3 +112,28 @@ def test_oracle_backup_restore_and_resize():
     got = m3.tree()[4:]
     # slots 0,1 overwritten by old leaves 5,6
     np.testing.assert_array_equal(got, np.array([leaves_old[5], leaves_old[6], leaves_old[2], leaves_old[3], leaves_old[4]]))
+
+
+def test_rankbased_oracle_matches_reference_trace():
+    """rankbased_memory.py:42-58 replayed with the oracle restatement under the same numpy seed: indices and weights equal."""
+    import os as _os
+    import sys as _sys
+
+    _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "oracle"))
+    import hot_path_oracle as H
+
+    z = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "rankbased_trace.npz"))
+    cap, alpha = int(z["capacity"]), float(z["alpha"])
+    pri = np.zeros(cap, np.float32)
+    pos = size = k = 0
+    np.random.seed(int(z["seed"]))
+    for rnd in range(len(z["n_add"])):
+        for _ in range(int(z["n_add"][rnd])):
+            pri[pos] = z["add_priorities"][k]
+            pos, size, k = (pos + 1) % cap, min(size + 1, cap), k + 1
+        beta = min(1, float(z["beta_initial"]) + (1 - float(z["beta_initial"])) * (100 * rnd) / int(z["beta_steps"]))
+        idx, w = H.rankbased_sample(pri[:size], 16, alpha, beta)
+        np.testing.assert_array_equal(idx, z["indices"][rnd])
+        np.testing.assert_array_equal(w, z["weights"][rnd])
+        pri[idx] = z["new_priorities"][rnd]
+    np.testing.assert_array_equal(pri, z["final_priorities"])

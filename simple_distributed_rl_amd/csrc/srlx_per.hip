@@ -7,8 +7,10 @@
 //   T     : the reference's implicit heap (node i has children 2i+1 / 2i+2, leaf slot j is node
 //           j+N-1) stored BLOCKED: every 128-byte line holds the 2+4+8 descendants (relative
 //           depths 1..3) of one "owner" node, groups of three levels aligned to the leaf level.
-//           A root->leaf walk of a 1M-leaf tree touches 7 lines instead of 21, siblings are always
-//           one aligned 16-byte pair, and the leaf priority arrives with the last pair.  Logical
+//           Inside a line the seven LEFT children come first (64 bytes), the seven right children
+//           second: a descent only ever compares against left children (proportional_memory.py:61),
+//           so a root->leaf walk of a 1M-leaf tree touches 7 half-lines instead of 21 lines and the
+//           right half is read once, for the priority of the leaf that was reached.  Logical
 //           node indices (what sample() returns and update() takes) are unchanged; backup()/restore()
 //           convert to/from the reference's flat heap order.
 //   state : { float64 max_priority; int64 size; int64 write; } -- lives on the device so that
@@ -59,8 +61,13 @@ __host__ __device__ __forceinline__ int node_depth(i64 x) {
 // Blocked physical layout of the heap.  Levels below the root are cut into groups of three, aligned to
 // the deepest level D: the top group has h0 = ((D-1) % 3) + 1 levels (1..h0), then G groups of 3.  The
 // nodes of a group that descend from the same "owner" (the ancestor on the level just above the
-// group) share one 16-double block: slots 0-1 relative depth 1, 2-5 depth 2, 6-13 depth 3; block 0
-// slot 14 is the root.  base[g] = index of the first block of group g.
+// group) share one 16-double block.  A node at relative depth r (1..3) with in-block offset m (0..2^r-1)
+// sits in slot (m&1)*8 + {0,1,3}[r-1] + (m>>1): left children in slots 0..6, their right siblings 8 slots
+// further (8..14); block 0 slot 7 is the root.  base[g] = index of the first block of group g.
+constexpr int kRootSlot = 7;
+__host__ __device__ __forceinline__ int slot_in_block(int r, int64_t m) {
+    return (int)(m & 1) * 8 + (r == 1 ? 0 : (r == 2 ? 1 : 3)) + (int)(m >> 1);
+}
 struct Tree {
     double *T;
     i64 len;  // 2 * capacity - 1 logical nodes
@@ -68,19 +75,25 @@ struct Tree {
     i64 base[12];
 
     __device__ __forceinline__ i64 phys(i64 i) const {
-        if (i == 0) return 14;
+        if (i == 0) return kRootSlot;
         const int d = node_depth(i);
         const i64 q = i + 1 - ((i64)1 << d);
-        if (d <= h0) return (d == 1 ? 0 : (d == 2 ? 2 : 6)) + q;
+        if (d <= h0) return slot_in_block(d, q);
         const int k = d - h0 - 1;
         const int g = 1 + k / 3, r = k % 3 + 1;
         const i64 blk = base[g] + (q >> r);
-        return 16 * blk + (r == 1 ? 0 : (r == 2 ? 2 : 6)) + (q & (((i64)1 << r) - 1));
+        return 16 * blk + slot_in_block(r, q & (((i64)1 << r) - 1));
     }
     __device__ __forceinline__ double get(i64 i) const { return T[phys(i)]; }
     __device__ __forceinline__ void set(i64 i, double v) const { T[phys(i)] = v; }
-    // (left, right) children values as one aligned 16-byte load; `left` must be odd (a left child)
-    __device__ __forceinline__ double2 pair(i64 left) const { return *reinterpret_cast<const double2 *>(T + phys(left)); }
+    // (left, right) children values: two independent 8-byte loads from one line; `left` must be odd (a left child)
+    __device__ __forceinline__ double2 pair(i64 left) const {
+        const double *s = T + phys(left);
+        double2 v;
+        v.x = s[0];
+        v.y = s[8];
+        return v;
+    }
     // block that holds the children of owner node `owner` on level `level` (level = 0, h0, h0+3, ...)
     __device__ __forceinline__ i64 block_of_owner(i64 owner, int level) const {
         if (level == 0) return 0;
@@ -123,7 +136,7 @@ __device__ __forceinline__ double load_prio(const void *prio, int kind, i64 i, d
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void descend(const Tree &tr, double val, i64 &out_idx, double &out_p) {
     i64 idx = 0;
-    double p = tr.len == 1 ? tr.T[14] : 0.0;
+    double p = tr.len == 1 ? tr.T[kRootSlot] : 0.0;
     for (;;) {
         const i64 left = 2 * idx + 1;
         if (left >= tr.len) break;
@@ -151,6 +164,12 @@ __device__ __forceinline__ double beta_of(double beta_initial, double beta_steps
 // within a few fp64 ulp of pow(x, -beta) (|log2 x| < 64, beta <= 1) at a third of the instruction count.
 __device__ __forceinline__ double is_weight(double size, double p, double total, double beta) {
     return exp2(-beta * log2(size * (p / total)));
+}
+
+// out-of-line copy for the bulk walk: inlined, its polynomial constants are hoisted into VGPRs for the whole kernel and
+// push the walk (128-VGPR budget at 16 waves per CU) into scratch spills
+__device__ __attribute__((noinline)) double is_weight_call(double size, double p, double total, double beta) {
+    return is_weight(size, p, total, beta);
 }
 
 // block-wide max of one double per thread (blockDim.x <= 1024, power of two)
@@ -185,9 +204,9 @@ __device__ __forceinline__ int block_exscan(int v, int *buf, int *total) {
     return incl - v;
 }
 
-struct Cand {  // bulk paths: leaf reached by a draw and its priority, one 16-byte store
+struct Cand {  // bulk paths: leaf reached by a draw and its un-normalised IS weight (0 = zero-priority leaf, rejected), one 16-byte store
     i64 idx;
-    double p;
+    double w;
 };
 
 struct SampleArgs {
@@ -226,7 +245,7 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
 
     const int t = threadIdx.x, T = blockDim.x;
     const i64 M = a.n_uniforms, B = a.batch;
-    const double total = a.tr.T[14];  // :135 (root)
+    const double total = a.tr.T[kRootSlot];  // :135 (root)
 
     // phase 1: one descent per uniform (coalesced uniform reads, strided assignment)
     for (i64 j = t; j < M; j += T) {
@@ -304,69 +323,97 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
 // 8-lane cooperative line fetch through LDS 206 us; this kernel 84 us.  All of them are bound by the
 // L2-miss traffic of the bottom three levels (~190 B per draw out of the Infinity Cache), not by HBM.
 // ------------------------------------------------------------------------------------------
-constexpr int kIlp = 2;
-constexpr int kBulkLdsBlocks = 296;  // 37 KiB (+2 KiB reduction buffer): 4 workgroups per CU
+constexpr int kBulkTopSmall = 296;        // left halves staged by a 256-thread workgroup of the flat walk (18.5 KiB)
+constexpr int kBulkTopBig = 2400;         // ... by a 1024-thread workgroup (150 KiB + 8 KiB reduction buffer of the 160 KiB)
+constexpr i64 kBulkBigMin = (i64)1 << 19; // draws from which the one-workgroup-per-CU configuration is used
 
-struct Blk {
-    double2 v[7];
+// One draw in flight.  The reference reads the priority of the leaf it reached after the walk (:88-92); here the
+// walk remembers the last decision instead: the left value it compared against and where that node's right
+// sibling lives, so the right half of a line is only ever read for that one value.
+struct Draw {
+    i64 idx;
+    double val;
+    double pl;     // value of the left child at the last decision (the root total before any decision)
+    i64 rpos;      // physical position of its right sibling
+    bool wl;       // last decision went left
+    bool live;     // not at a leaf yet
 };
 
-__device__ __forceinline__ double2 sel2(const double2 &a, const double2 &b, int s) { return s ? b : a; }
-
-// walk up to `levels` levels inside one block; returns false when the draw has reached a leaf
-__device__ __forceinline__ bool walk_block(const Blk &b, int levels, i64 len, i64 &idx, double &val, double &p) {
-    i64 left = 2 * idx + 1;
-    if (left >= len) return false;
-    bool go = val <= b.v[0].x;  // :61
+// walk up to `levels` levels inside the block whose 8 left slots are in registers (four 16-byte loads)
+__device__ __forceinline__ void walk_block_regs(const double (&L)[8], i64 blockpos, int levels, i64 len, Draw &w) {
+    i64 left = 2 * w.idx + 1;
+    if (left >= len) { w.live = false; return; }
+    double l = L[0];
+    bool go = w.val <= l;  // :61
     const int s1 = go ? 0 : 1;
-    val = go ? val : val - b.v[0].x;
-    idx = left + s1;
-    p = go ? b.v[0].x : b.v[0].y;
-    if (levels < 2) return true;
-    left = 2 * idx + 1;
-    if (left >= len) return false;
-    const double2 p2 = sel2(b.v[1], b.v[2], s1);
-    go = val <= p2.x;
+    w.val = go ? w.val : w.val - l;
+    w.idx = left + s1;
+    w.pl = l; w.wl = go; w.rpos = blockpos + 8;
+    if (levels < 2) return;
+    left = 2 * w.idx + 1;
+    if (left >= len) { w.live = false; return; }
+    l = s1 ? L[2] : L[1];
+    go = w.val <= l;
     const int s2 = 2 * s1 + (go ? 0 : 1);
-    val = go ? val : val - p2.x;
-    idx = left + (go ? 0 : 1);
-    p = go ? p2.x : p2.y;
-    if (levels < 3) return true;
-    left = 2 * idx + 1;
-    if (left >= len) return false;
-    const double2 p3 = sel2(sel2(b.v[3], b.v[4], s2 & 1), sel2(b.v[5], b.v[6], s2 & 1), s2 >> 1);
-    go = val <= p3.x;
-    val = go ? val : val - p3.x;
-    idx = left + (go ? 0 : 1);
-    p = go ? p3.x : p3.y;
-    return true;
+    w.val = go ? w.val : w.val - l;
+    w.idx = left + (go ? 0 : 1);
+    w.pl = l; w.wl = go; w.rpos = blockpos + 9 + s1;
+    if (levels < 3) return;
+    left = 2 * w.idx + 1;
+    if (left >= len) { w.live = false; return; }
+    const double la = (s2 & 1) ? L[4] : L[3], lb = (s2 & 1) ? L[6] : L[5];
+    l = (s2 >> 1) ? lb : la;
+    go = w.val <= l;
+    w.val = go ? w.val : w.val - l;
+    w.idx = left + (go ? 0 : 1);
+    w.pl = l; w.wl = go; w.rpos = blockpos + 11 + s2;
 }
 
-// walk up to `levels` levels inside the 16-double block at `blk`, one dependent pair read per level
-__device__ __forceinline__ bool walk_block_pairs(const double *blk, int levels, i64 len, i64 &idx, double &val, double &p) {
+// the same walk out of a block staged in LDS: one dependent 8-byte read per level
+__device__ __forceinline__ void walk_block_lds(const double *blk, i64 blockpos, int levels, i64 len, Draw &w) {
     int pos = 0;
 #pragma unroll
     for (int r = 1; r <= 3; r++) {
         if (r > levels) break;
-        const i64 left = 2 * idx + 1;
-        if (left >= len) return false;
-        const double2 v = *reinterpret_cast<const double2 *>(blk + (r == 1 ? 0 : (r == 2 ? 2 : 6)) + 2 * pos);
-        const bool go = val <= v.x;  // :61
-        val = go ? val : val - v.x;
-        idx = left + (go ? 0 : 1);
-        p = go ? v.x : v.y;
+        const i64 left = 2 * w.idx + 1;
+        if (left >= len) { w.live = false; return; }
+        const int slot = (r == 1 ? 0 : (r == 2 ? 1 : 3)) + pos;
+        const double l = blk[slot];
+        const bool go = w.val <= l;  // :61
+        w.val = go ? w.val : w.val - l;
+        w.idx = left + (go ? 0 : 1);
+        w.pl = l; w.wl = go; w.rpos = blockpos + 8 + slot;
         pos = 2 * pos + (go ? 0 : 1);
     }
-    return true;
 }
 
-__global__ void __launch_bounds__(256, 4) k_descend_bulk(SampleArgs a, int lds_blocks, u64 *zero_count, u64 *wmax_bits) {
-    __shared__ __attribute__((aligned(16))) double top[kBulkLdsBlocks * 16];
-    __shared__ double red[256];
+// Dynamic LDS: the LEFT halves (64 bytes) of the first `lds_blocks` blocks, then blockDim doubles for the reduction.
+// Large calls run one 1024-thread workgroup per CU with 2341 staged blocks (150 KB: the 14 top levels of a 1M-leaf
+// tree, so only two lines per draw are fetched from memory); small calls run 256-thread workgroups with 293 blocks.
+// The walk has two phases.  LDS-staged groups whose levels all lie above the shallowest leaf (5 of the 7 groups of a
+// 1M-leaf tree) need no end-of-tree test: they run branch-free on 32-bit in-level offsets with the kIlp draws of a
+// lane interleaved level by level, so their dependent LDS reads overlap.  The remaining groups use the checked
+// walkers above.  (Measured: the kernel is bound by the two scattered line fetches per draw, not by instruction
+// issue -- the branch-free phase alone changes its time by < 1 %.)
+
+// one branch-free decision (:61-66): left if val <= l, else subtract and go right
+__device__ __forceinline__ void step_free(double l, double &val, unsigned &pos) {
+    const bool go = val <= l;
+    val = go ? val : val - l;
+    pos = 2 * pos + (go ? 0u : 1u);
+}
+
+constexpr int kIlp = 2;
+template <int kThreads>
+__global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int lds_blocks, int free_groups, u64 *zero_count, u64 *wmax_bits) {
+    extern __shared__ __attribute__((aligned(16))) double bulk_smem[];
+    double *top = bulk_smem;                      // block b, left slot s (0..7) at top[8 * b + s]
+    double *red = bulk_smem + (size_t)lds_blocks * 8;
     const Tree tr = a.tr;
-    for (i64 k = threadIdx.x; k < (i64)lds_blocks * 16; k += blockDim.x) top[k] = tr.T[k];
+    for (int k = threadIdx.x; k < lds_blocks * 4; k += blockDim.x)
+        reinterpret_cast<double2 *>(top)[k] = reinterpret_cast<const double2 *>(tr.T)[(k >> 2) * 8 + (k & 3)];
     __syncthreads();
-    const double total = top[14];
+    const double total = top[kRootSlot];
     const i64 M = a.n_uniforms, B = a.batch, len = tr.len;
     const i64 step = a.d_step ? *a.d_step : a.step;
     const double beta = beta_of(a.beta_initial, a.beta_steps, step);
@@ -375,54 +422,108 @@ __global__ void __launch_bounds__(256, 4) k_descend_bulk(SampleArgs a, int lds_b
     unsigned zeros = 0;
     double wmax = 0.0;
     for (i64 base = (i64)blockIdx.x * blockDim.x + threadIdx.x; base < M; base += stride * kIlp) {
-        i64 idx[kIlp];
-        double val[kIlp], p[kIlp];
-        bool live[kIlp];
+        double val[kIlp];
+        unsigned q[kIlp];  // offset of the current owner node inside its level
 #pragma unroll
         for (int d = 0; d < kIlp; d++) {
             const i64 j = base + d * stride;
-            live[d] = j < M && len > 1;
-            val[d] = j < M ? a.uniforms[j] * total : 0.0;  // :147
-            idx[d] = 0;
-            p[d] = total;
+            val[d] = j < M ? a.uniforms[j] * total : 0.0;  // :147 (a draw past M walks the left edge, harmlessly)
+            q[d] = 0;
         }
-        int level = 0;  // level of the current owner nodes (same for every live draw)
-        for (int g = 0; g <= tr.G; g++) {
+        int level = 0;  // level of the current owner nodes (same for every draw)
+        int g = 0;
+        for (; g < free_groups && (g == 0 || tr.base[g + 1] <= lds_blocks); g++) {
             const int levels = g == 0 ? tr.h0 : 3;
-            if (tr.base[g + 1] <= lds_blocks || g == 0) {
-                // group staged in LDS: one dependent 16-byte pair read per level (fewer, conflict-poorer reads than the whole block)
-#pragma unroll
-                for (int d = 0; d < kIlp; d++)
-                    if (live[d])
-                        live[d] = walk_block_pairs(top + tr.block_of_owner(idx[d], level) * 16, levels, len, idx[d], val[d], p[d]) && (2 * idx[d] + 1 < len);
-            } else {
-                // group in memory: ONE line per draw, its 7 x 16-byte loads issued together, decisions are register selects
-                Blk blk[kIlp];
+            const unsigned gbase = (unsigned)tr.base[g];
+            unsigned pos[kIlp];
+            {
+                const double *blk[kIlp];
+                double l[kIlp];
 #pragma unroll
                 for (int d = 0; d < kIlp; d++) {
-                    if (!live[d]) continue;
-                    const double2 *src = reinterpret_cast<const double2 *>(tr.T + tr.block_of_owner(idx[d], level) * 16);
+                    blk[d] = top + (size_t)(gbase + q[d]) * 8;
+                    pos[d] = 0;
+                }
 #pragma unroll
-                    for (int k = 0; k < 7; k++) blk[d].v[k] = src[k];
+                for (int d = 0; d < kIlp; d++) l[d] = blk[d][0];
+#pragma unroll
+                for (int d = 0; d < kIlp; d++) step_free(l[d], val[d], pos[d]);
+                if (levels >= 2) {
+#pragma unroll
+                    for (int d = 0; d < kIlp; d++) l[d] = blk[d][1 + pos[d]];
+#pragma unroll
+                    for (int d = 0; d < kIlp; d++) step_free(l[d], val[d], pos[d]);
+                }
+                if (levels >= 3) {
+#pragma unroll
+                    for (int d = 0; d < kIlp; d++) l[d] = blk[d][3 + pos[d]];
+#pragma unroll
+                    for (int d = 0; d < kIlp; d++) step_free(l[d], val[d], pos[d]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < kIlp; d++) q[d] = (q[d] << levels) + pos[d];
+            level += levels;
+        }
+        Draw w[kIlp];
+#pragma unroll
+        for (int d = 0; d < kIlp; d++) {
+            const i64 j = base + d * stride;
+            w[d].live = j < M && len > 1;
+            w[d].val = val[d];
+            w[d].idx = (i64)q[d] + (((i64)1 << level) - 1);
+            w[d].pl = total;
+            w[d].wl = true;
+            w[d].rpos = 0;
+        }
+        for (; g <= tr.G; g++) {
+            const int levels = g == 0 ? tr.h0 : 3;
+            if (tr.base[g + 1] <= lds_blocks || g == 0) {
+                // group staged in LDS: one dependent 8-byte read per level
+#pragma unroll
+                for (int d = 0; d < kIlp; d++)
+                    if (w[d].live) {
+                        const i64 blk = tr.block_of_owner(w[d].idx, level);
+                        walk_block_lds(top + blk * 8, blk * 16, levels, len, w[d]);
+                    }
+            } else {
+                double L[kIlp][8];
+                i64 bp[kIlp];
+#pragma unroll
+                for (int d = 0; d < kIlp; d++) {
+                    if (!w[d].live) continue;
+                    bp[d] = tr.block_of_owner(w[d].idx, level) * 16;
+                    const double2 *src = reinterpret_cast<const double2 *>(tr.T + bp[d]);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const double2 v = src[k];
+                        L[d][2 * k] = v.x;
+                        L[d][2 * k + 1] = v.y;
+                    }
                 }
 #pragma unroll
                 for (int d = 0; d < kIlp; d++)
-                    if (live[d]) live[d] = walk_block(blk[d], levels, len, idx[d], val[d], p[d]) && (2 * idx[d] + 1 < len);
+                    if (w[d].live) walk_block_regs(L[d], bp[d], levels, len, w[d]);
             }
             level += levels;
         }
+        double pr[kIlp];
+#pragma unroll
+        for (int d = 0; d < kIlp; d++) pr[d] = w[d].wl ? 0.0 : tr.T[w[d].rpos];  // the one read of a right child: the leaf's own priority
 #pragma unroll
         for (int d = 0; d < kIlp; d++) {
             const i64 j = base + d * stride;
             if (j >= M) continue;
+            const double p = w[d].wl ? w[d].pl : pr[d];
+            const double wi = p == 0.0 ? 0.0 : is_weight_call(size, p, total, beta);  // :163-164, computed once per draw
             Cand c;
-            c.idx = idx[d];
-            c.p = p[d];
+            c.idx = w[d].idx;
+            c.w = wi;
             a.cand[j] = c;
-            if (p[d] == 0.0) {
+            if (p == 0.0) {
                 zeros++;
             } else if (j < B) {  // fast path: with no rejection output i is draw i
-                wmax = fmax(wmax, is_weight(size, p[d], total, beta));
+                wmax = fmax(wmax, wi);
             }
         }
     }
@@ -432,289 +533,129 @@ __global__ void __launch_bounds__(256, 4) k_descend_bulk(SampleArgs a, int lds_b
 }
 
 // ------------------------------------------------------------------------------------------
-// Binned bulk descent (alternative, SRLX_PER_BULK=binned).  The flat walk above spends its time issuing divergent
-// loads (PMC: 54 % of wave cycles waiting on memory, 30 % stalled at issue; 3.6 L2 requests per draw, 43 % L2
-// misses on the bottom group), so here the draws are first counting-sorted by the subtree they reach at owner
-// level Lb (2048 subtrees at 1M leaves) and every walk finishes in LDS:
-//   k_bin_top      walks the top `gb` groups out of LDS (one dependent 16-byte pair read per level), writes
-//                  the residual value + bin of every draw, histograms the bins (k_bin_offsets scans them);
-//   k_bin_scatter  moves (residual, draw id) records into bin order (LDS ranks, one range reservation per
-//                  bin per workgroup);
-//   k_descend_bin  one workgroup per bin stages the bin's whole subtree (73 blocks, 9.3 KB, read once,
-//                  coalesced) in LDS and finishes every walk there -- no scattered tree fetch is left.
-// Results are written to cand[j] at the draw's own position, so acceptance order, indices and weights are
-// exactly those of the unbinned walk (tests compare the two).
-// Measured on MI355X, 1M draws from 1M leaves: k_bin_top 24 us + k_bin_offsets 5 + k_bin_scatter 20 + k_descend_bin 23
-// = 72 us against 60 us for k_descend_bulk (whole call 100 vs 81 us); 4M draws: 285 vs 252 us.  Seven dependent
-// launches at >= 4.5 us each and two extra passes over the draws cost more than the scattered fetches they remove,
-// so the flat walk stays the default.
+// After the walk.  Counters (handle-owned, zero between calls): [0] zero-priority draws seen by the walk,
+// [1] max weight of draws < B (bits), [2] "some draw was rejected" (rewritten by every call), [3] max weight of the
+// compacted draws (bits), [4] tile tickets.  Each counter is re-armed by a kernel that does not read it.
+//   k_finish_fast   nothing was rejected (the common case): output i is draw i, one pass writes index and
+//                   normalised weight (:163-167); returns at once otherwise
+//   k_compact_bulk  returns at once (apart from out_used) when nothing was rejected; else the ORDERED compaction of the
+//                   accepted draws (in-order rejection, :146-157) over the whole device: one 2048-draw tile per
+//                   workgroup, tile offsets by a decoupled look-back scan (a tile publishes its count, then its
+//                   first wave sums 64 predecessors per step until it meets a resolved prefix)
+//   k_finish_slow   normalises the compacted weights (no per-call memset anywhere: safe under HIP-graph replay)
+// (A counting-sorted "binned" walk -- sort the draws by the subtree they reach so that every walk finishes in
+// LDS -- was measured at 100 us against 81 us per 2^20 draws and removed; DESIGN.md section 4 keeps the numbers.)
 // ------------------------------------------------------------------------------------------
-struct BinRec {
-    double val;
-    int j, pad;
-};
-struct BinGeom {
-    int gb;          // top groups walked by k_bin_top (groups 0..gb-1)
-    int Lb;          // owner level of the bin roots = h0 + 3*(gb-1)
-    int nb;          // bins = 2^Lb
-    int R;           // groups below a bin root (<= 3: 1 + 8 + 64 blocks)
-    int top_blocks;  // blocks of groups 0..gb-1
-};
-constexpr int kBinMax = 4096;
-constexpr int kScatterTile = 16;  // draws per thread in k_bin_scatter
+constexpr int kTileThreads = 256, kTilePer = 8, kTile = kTileThreads * kTilePer;
+constexpr u64 kStAggregate = 1ull << 62, kStPrefix = 2ull << 62, kStMask = 3ull << 62;
 
-__global__ void __launch_bounds__(256) k_bin_top(SampleArgs a, BinGeom bg, double *val_out, unsigned short *bin_out, unsigned *hist) {
-    __shared__ __attribute__((aligned(16))) double top[kBulkLdsBlocks * 16];
-    __shared__ unsigned s_hist[kBinMax];
-    const Tree tr = a.tr;
-    for (int k = threadIdx.x; k < bg.top_blocks * 16; k += blockDim.x) top[k] = tr.T[k];
-    for (int k = threadIdx.x; k < bg.nb; k += blockDim.x) s_hist[k] = 0;
-    __syncthreads();
-    const double total = top[14];
-    const i64 first = ((i64)1 << bg.Lb) - 1;
-    constexpr int kTopIlp = 4;  // independent walks per lane: their dependent LDS reads overlap
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 j0 = (i64)blockIdx.x * blockDim.x + threadIdx.x; j0 < a.n_uniforms; j0 += stride * kTopIlp) {
-        double val[kTopIlp], p;
-        i64 idx[kTopIlp];
-#pragma unroll
-        for (int d = 0; d < kTopIlp; d++) {
-            const i64 j = j0 + d * stride;
-            val[d] = j < a.n_uniforms ? a.uniforms[j] * total : 0.0;  // :147
-            idx[d] = 0;
-        }
-        int level = 0;
-        for (int g = 0; g < bg.gb; g++) {
-            const int levels = g == 0 ? tr.h0 : 3;
-#pragma unroll
-            for (int d = 0; d < kTopIlp; d++) walk_block_pairs(top + tr.block_of_owner(idx[d], level) * 16, levels, tr.len, idx[d], val[d], p);
-            level += levels;
-        }
-#pragma unroll
-        for (int d = 0; d < kTopIlp; d++) {
-            const i64 j = j0 + d * stride;
-            if (j >= a.n_uniforms) continue;
-            const int bin = (int)(idx[d] - first);
-            val_out[j] = val[d];
-            bin_out[j] = (unsigned short)bin;
-            atomicAdd(&s_hist[bin], 1u);
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < bg.nb; k += blockDim.x)
-        if (s_hist[k]) atomicAdd(&hist[k], s_hist[k]);
-}
-
-// exclusive scan of the bin histogram (one workgroup; a last-workgroup-done scan inside k_bin_top would need an
-// agent-scope release fence per workgroup, i.e. an L2 write-back each: measured +35 us)
-__global__ void __launch_bounds__(256) k_bin_offsets(BinGeom bg, const unsigned *hist, unsigned *offs) {
-    __shared__ int ibuf[256];
-    const int per = (bg.nb + 255) / 256;  // <= 16
-    unsigned hv[kBinMax / 256];
-#pragma unroll
-    for (int k = 0; k < kBinMax / 256; k++) {
-        const int b = threadIdx.x * per + k;
-        hv[k] = (k < per && b < bg.nb) ? hist[b] : 0u;
-    }
-    unsigned mine = 0;
-#pragma unroll
-    for (int k = 0; k < kBinMax / 256; k++) mine += hv[k];
-    int tot;
-    unsigned run = (unsigned)block_exscan((int)mine, ibuf, &tot);
-#pragma unroll
-    for (int k = 0; k < kBinMax / 256; k++) {
-        const int b = threadIdx.x * per + k;
-        if (k < per && b < bg.nb) {
-            offs[b] = run;
-            run += hv[k];
-        }
+__global__ void __launch_bounds__(256) k_finish_fast(SampleArgs a, u64 *counters) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[3] = 0;  // re-arm: nothing in this kernel reads it
+    if (counters[0] != 0 || a.n_uniforms < a.batch) return;
+    const double wmax = __longlong_as_double((long long)counters[1]);
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < a.batch; i += (i64)gridDim.x * blockDim.x) {
+        const Cand c = a.cand[i];
+        const double w = c.w / wmax;  // :167
+        a.out_idx[i] = c.idx;
+        if (a.out_w) a.out_w[i] = w;
+        if (a.out_w32) a.out_w32[i] = (float)w;
     }
 }
 
-__global__ void __launch_bounds__(256) k_bin_scatter(SampleArgs a, BinGeom bg, const double *val_in, const unsigned short *bin_in, const unsigned *offs,
-                                                     unsigned *cursor, BinRec *recs) {
-    __shared__ unsigned s_cnt[kBinMax], s_base[kBinMax];
-    for (int k = threadIdx.x; k < bg.nb; k += blockDim.x) s_cnt[k] = 0;
-    __syncthreads();
-    const i64 tile0 = (i64)blockIdx.x * (256 * kScatterTile);
-    int bin[kScatterTile];
-    unsigned rank[kScatterTile];
-#pragma unroll
-    for (int d = 0; d < kScatterTile; d++) {
-        const i64 j = tile0 + d * 256 + threadIdx.x;
-        bin[d] = j < a.n_uniforms ? (int)bin_in[j] : -1;
-    }
-#pragma unroll
-    for (int d = 0; d < kScatterTile; d++)
-        if (bin[d] >= 0) rank[d] = atomicAdd(&s_cnt[bin[d]], 1u);
-    __syncthreads();
-    for (int k = threadIdx.x; k < bg.nb; k += blockDim.x) {
-        const unsigned c = s_cnt[k];
-        if (c) s_base[k] = offs[k] + atomicAdd(&cursor[k], c);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < kScatterTile; d++) {
-        if (bin[d] < 0) continue;
-        const i64 j = tile0 + d * 256 + threadIdx.x;
-        BinRec r;
-        r.val = val_in[j];
-        r.j = (int)j;
-        r.pad = 0;
-        recs[s_base[bin[d]] + rank[d]] = r;
-    }
-}
-
-__global__ void __launch_bounds__(256) k_descend_bin(SampleArgs a, BinGeom bg, const unsigned *hist, const unsigned *offs, const BinRec *recs,
-                                                     unsigned *part_zero, double *part_wmax) {
-    __shared__ __attribute__((aligned(16))) double sub[73 * 16];
-    __shared__ double red[256];
-    const Tree tr = a.tr;
-    const int bin = blockIdx.x;
-    const unsigned count = hist[bin];
-    if (count == 0) {
-        if (threadIdx.x == 0) {
-            part_zero[bin] = 0;
-            part_wmax[bin] = 0.0;
-        }
-        return;
-    }
-    // the R groups below this bin's root: 1, 8, 64 blocks, each run contiguous in the tree
-    for (int t = 0, off = 0; t < bg.R; off += 1 << (3 * t), t++) {
-        const double *src = tr.T + (tr.base[bg.gb + t] + ((i64)bin << (3 * t))) * 16;
-        for (int k = threadIdx.x; k < (16 << (3 * t)); k += blockDim.x) sub[off * 16 + k] = src[k];
-    }
-    __syncthreads();
-    const unsigned begin = offs[bin];
-    const double total = tr.T[14];
-    const i64 B = a.batch, len = tr.len;
-    const i64 step = a.d_step ? *a.d_step : a.step;
-    const double beta = beta_of(a.beta_initial, a.beta_steps, step);
-    const double size = (double)a.state->size;
-    const i64 root = ((i64)1 << bg.Lb) - 1 + bin;
-    unsigned zeros = 0;
-    double wmax = 0.0;
-    for (unsigned e = threadIdx.x; e < count; e += 256) {
-        const BinRec r = recs[begin + e];
-        double val = r.val, p = 0.0;
-        i64 idx = root;
-        int level = bg.Lb;
-        for (int t = 0; t < bg.R; t++) {
-            const i64 q = idx + 1 - ((i64)1 << level) - ((i64)bin << (3 * t));
-            const int off = t == 0 ? 0 : (t == 1 ? 1 : 9);
-            if (!walk_block_pairs(sub + (off + q) * 16, 3, len, idx, val, p)) break;
-            level += 3;
-        }
-        Cand c;
-        c.idx = idx;
-        c.p = p;
-        a.cand[r.j] = c;
-        if (p == 0.0)
-            zeros++;
-        else if (r.j < B)
-            wmax = fmax(wmax, is_weight(size, p, total, beta));
-    }
-    // one (zeros, wmax) partial per bin, reduced by k_compact_bulk: thousands of same-address device atomics cost ~7 us
-    __shared__ unsigned s_zero;
-    if (threadIdx.x == 0) s_zero = 0;
-    const double m = block_max(wmax, red);
-    if (zeros) atomicAdd(&s_zero, zeros);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        part_zero[bin] = s_zero;
-        part_wmax[bin] = m;
-    }
-}
-
-// single workgroup: ordered compaction of the accepted draws.  Fast exit when nothing was rejected.
-__global__ void __launch_bounds__(1024) k_compact_bulk(SampleArgs a, u64 *zero_count, int *identity, int n_part, const unsigned *part_zero,
-                                                       const double *part_wmax, u64 *wmax_bits) {
-    __shared__ int ibuf[1024];
-    __shared__ double dred[1024];
+__global__ void __launch_bounds__(kTileThreads) k_compact_bulk(SampleArgs a, u64 *counters, u64 *tile_state, i64 ntiles) {
+    __shared__ int ibuf[kTileThreads];
+    __shared__ double dred[kTileThreads];
+    __shared__ i64 s_prefix;
+    __shared__ unsigned s_tile;
     const i64 M = a.n_uniforms, B = a.batch;
-    const int t = threadIdx.x, T = blockDim.x;
-    if (n_part > 0) {  // binned walk: fold the per-bin partials into the counters the later kernels read
-        unsigned z = 0;
-        double m = 0.0;
-        for (int k = t; k < n_part; k += T) {
-            z += part_zero[k];
-            m = fmax(m, part_wmax[k]);
-        }
-        ibuf[t] = (int)z;
-        m = block_max(m, dred);
-        for (int s2 = T >> 1; s2 > 0; s2 >>= 1) {
-            if (t < s2) ibuf[t] += ibuf[t + s2];
-            __syncthreads();
-        }
-        if (t == 0) {
-            *zero_count = (u64)(unsigned)ibuf[0];
-            *wmax_bits = (u64)__double_as_longlong(m);
-        }
-        __syncthreads();
-    }
-    if (*zero_count == 0) {
-        if (t == 0) {
-            *identity = 1;
+    const int t = threadIdx.x;
+    if (counters[0] == 0) {
+        if (blockIdx.x == 0 && t == 0) {
+            counters[2] = 0;
             *a.out_used = (M >= B) ? B : -1;
         }
         return;
     }
-    if (t == 0) *identity = 0;
-    i64 base = 0;
-    bool done = false;
-    for (i64 tile = 0; tile < M && !done; tile += T) {
-        const i64 j = tile + t;
-        const int ok = (j < M && a.cand[j].p != 0.0) ? 1 : 0;
-        int tot;
-        const i64 pos = base + block_exscan(ok, ibuf, &tot);
-        if (ok && pos < B) {
-            a.map[pos] = j;
-            if (pos == B - 1) *a.out_used = j + 1;
+    // tiles are handed out in scheduling order, so every predecessor a tile waits for has been taken by a running workgroup
+  for (;;) {
+    __syncthreads();
+    if (t == 0) s_tile = (unsigned)atomicAdd(&counters[4], 1ull);
+    __syncthreads();
+    const i64 tile = s_tile;
+    if (tile >= ntiles) return;
+    if (tile == 0 && t == 0) counters[2] = 1;
+    const i64 j0 = tile * kTile + (i64)t * kTilePer;
+    double w[kTilePer];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kTilePer; k++) {
+        w[k] = j0 + k < M ? a.cand[j0 + k].w : 0.0;
+        cnt += w[k] != 0.0 ? 1 : 0;
+    }
+    int tot;
+    const int local = block_exscan(cnt, ibuf, &tot);
+    if (t < 64) {  // first wave: decoupled look-back
+        if (t == 0)
+            __hip_atomic_store(&tile_state[tile], (tile == 0 ? kStPrefix : kStAggregate) | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i64 excl = 0, hi = tile - 1;
+        bool done = tile == 0;
+        while (!done) {
+            const i64 p = hi - t;
+            u64 v = kStPrefix;  // "tiles" before the first: resolved, nothing accepted
+            if (p >= 0) {
+                do {
+                    v = __hip_atomic_load(&tile_state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((v & kStMask) == 0);
+            }
+            const u64 resolved = __ballot((v & kStMask) == kStPrefix);
+            const int first = resolved ? __ffsll((unsigned long long)resolved) - 1 : 64;
+            i64 part = t <= first ? (i64)(v & ~kStMask) : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            excl += part;
+            done = resolved != 0;
+            hi -= 64;
         }
-        base += tot;
-        done = base >= B;
+        if (t == 0) {
+            if (tile != 0) __hip_atomic_store(&tile_state[tile], kStPrefix | (u64)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = excl;
+        }
     }
-    if (t == 0 && base < B) *a.out_used = -1;
+    __syncthreads();
+    const i64 prefix = s_prefix;
+    i64 pos = prefix + local;
+    double wm = 0.0;
+#pragma unroll
+    for (int k = 0; k < kTilePer; k++) {
+        if (w[k] == 0.0) continue;
+        if (pos < B) {
+            a.out_idx[pos] = a.cand[j0 + k].idx;
+            a.wtmp[pos] = w[k];
+            wm = fmax(wm, w[k]);
+            if (pos == B - 1) *a.out_used = j0 + k + 1;  // uniforms consumed = index of the B-th accept + 1
+        }
+        pos++;
+    }
+    wm = block_max(wm, dred);
+    if (t == 0) {
+        if (wm > 0.0) atomicMax(&counters[3], (u64)__double_as_longlong(wm));  // positive doubles order like their bits
+        if (tile == ntiles - 1 && prefix + tot < B) *a.out_used = -1;
+    }
+  }
 }
 
-// slow path only (some draw hit a zero-priority leaf): weights of the compacted draws
-__global__ void __launch_bounds__(256) k_weights_bulk(SampleArgs a, const int *identity, u64 *wmax_bits) {
-    __shared__ double red[256];
-    if (*identity) return;
-    const i64 B = a.batch;
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const double total = a.tr.T[14];
-    const i64 step = a.d_step ? *a.d_step : a.step;
-    const double beta = beta_of(a.beta_initial, a.beta_steps, step);
-    const double size = (double)a.state->size;
-    double w = 0.0;
-    if (i < B && *a.out_used >= 0) {
-        const i64 j = a.map[i];
-        const Cand c = a.cand[j];
-        w = is_weight(size, c.p, total, beta);
-        a.wtmp[i] = w;
-        a.out_idx[i] = c.idx;
+__global__ void __launch_bounds__(256) k_finish_slow(SampleArgs a, u64 *counters, u64 *tile_state, i64 ntiles) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[0] = counters[1] = counters[4] = 0;  // re-arm: nothing in this kernel reads them
+    if (counters[2] == 0) return;
+    const i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x, gsz = (i64)gridDim.x * blockDim.x;
+    for (i64 i = gid; i < ntiles; i += gsz) tile_state[i] = 0;
+    if (*a.out_used < 0) return;
+    const double wmax = __longlong_as_double((long long)counters[3]);
+    for (i64 i = gid; i < a.batch; i += gsz) {
+        const double w = a.wtmp[i] / wmax;  // :167
+        if (a.out_w) a.out_w[i] = w;
+        if (a.out_w32) a.out_w32[i] = (float)w;
     }
-    const double m = block_max(w, red);
-    // positive doubles order like their bit patterns
-    if (threadIdx.x == 0 && m > 0.0) atomicMax(wmax_bits, (u64)__double_as_longlong(m));
-}
-
-__global__ void __launch_bounds__(256) k_normalise_bulk(SampleArgs a, const int *identity, const u64 *wmax_fast, const u64 *wmax_slow) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.batch || *a.out_used < 0) return;
-    double w;
-    if (*identity) {  // nothing was rejected: output i is draw i
-        const i64 step = a.d_step ? *a.d_step : a.step;
-        const Cand c = a.cand[i];
-        const double wi = is_weight((double)a.state->size, c.p, a.tr.T[14], beta_of(a.beta_initial, a.beta_steps, step));
-        w = wi / __longlong_as_double((long long)*wmax_fast);
-        a.out_idx[i] = c.idx;
-    } else {
-        w = a.wtmp[i] / __longlong_as_double((long long)*wmax_slow);
-    }
-    if (a.out_w) a.out_w[i] = w;
-    if (a.out_w32) a.out_w32[i] = (float)w;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1004,7 +945,12 @@ struct srlx_per {
     Tree tree;        // blocked device layout (tree.T is the allocation)
     i64 n_blocks;     // 128-byte blocks allocated
     int lds_blocks;   // leading blocks the bulk sampler stages in LDS
-    int bulk_binned;  // SRLX_PER_BULK=binned: counting-sorted bulk descent (kept for A/B timing; default is the flat walk)
+    int lds_blocks_big;  // ... by its one-workgroup-per-CU configuration
+    int n_cu;
+    int free_groups;  // leading groups of the blocked layout that cannot contain a leaf (walked without end-of-tree tests)
+    u64 *d_ctl;       // 8 counters of the bulk sampler (zero between calls)
+    u64 *d_tiles;     // look-back state of the bulk compaction (zero between calls)
+    i64 tiles_cap;
     PerState *d_state;
     int *d_err;
     i64 size, write;  // host mirror
@@ -1061,30 +1007,12 @@ int launch_update(srlx_per *h, i64 n, const i64 *d_idx, const void *d_prio, int 
 
 // scratch layout for sample
 struct SampleScratch {
-    static constexpr size_t kCtlBytes = 64 + (2 * kBinMax + 16) * 4;  // counters | hist | cursor | done (zeroed per call)
     static size_t bytes(i64 M, i64 B, bool bulk) {
         using C = srlx::Carver;
         if (!bulk) return C::padded((size_t)M * 8) * 2 + C::padded((size_t)B * 8) * 2;
-        return C::padded((size_t)B * 8) * 2 + C::padded(kCtlBytes) + C::padded((kBinMax + 1) * 4) + C::padded((size_t)M * 16) * 2 +
-               C::padded((size_t)M * 8) + C::padded((size_t)M * 2) + C::padded(kBinMax * 4) + C::padded(kBinMax * 8);
+        return C::padded((size_t)B * 8) + C::padded((size_t)M * 16);  // compacted weights | (leaf, weight) per draw
     }
 };
-
-// geometry of the binned bulk walk; returns false when this tree shape is served by the unbinned kernel
-bool bin_geometry(const Tree &t, BinGeom *bg) {
-    for (int gb = 4; gb >= 2; gb--) {
-        if (gb > t.G) continue;
-        const int Lb = t.h0 + 3 * (gb - 1), R = t.G - gb + 1;
-        if (t.base[gb] > kBulkLdsBlocks || Lb > 12 || R < 1 || R > 3) continue;
-        bg->gb = gb;
-        bg->Lb = Lb;
-        bg->nb = 1 << Lb;
-        bg->R = R;
-        bg->top_blocks = (int)t.base[gb];
-        return true;
-    }
-    return false;
-}
 
 int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double *d_u, i64 M, i64 *d_idx, double *d_w,
                   float *d_w32, i64 *d_used, hipStream_t st) {
@@ -1119,42 +1047,36 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
             srlx::set_error("per_sample: has_duplicate=False is limited to %lld uniforms per call", (long long)kSmallSampleMax);
             return SRLX_ERR_UNSUPPORTED;
         }
-        a.map = cv.take<i64>(B);
         a.wtmp = cv.take<double>(B);
-        // counters: [0] zero_count  [1] wmax (fast path)  [2] identity flag  [3] wmax (slow path)
-        u64 *counters = (u64 *)cv.take<char>(SampleScratch::kCtlBytes);
-        unsigned *hist = (unsigned *)(counters + 8), *cursor = hist + kBinMax;
-        unsigned *offs = cv.take<unsigned>(kBinMax + 1);
         a.cand = cv.take<Cand>(M);
-        BinRec *recs = cv.take<BinRec>(M);
-        double *val2 = cv.take<double>(M);
-        unsigned short *bins = cv.take<unsigned short>(M);
-        unsigned *part_zero = cv.take<unsigned>(kBinMax);
-        double *part_wmax = cv.take<double>(kBinMax);
-        int n_part = 0;
-        BinGeom bg{};
-        if (h->bulk_binned && M >= ((i64)1 << 16) && M < ((i64)1 << 31) && bin_geometry(h->tree, &bg)) {
-            SRLX_HIP(hipMemsetAsync(counters, 0, SampleScratch::kCtlBytes, st));
-            const i64 want = (M + 256 * 8 - 1) / (256 * 8);
-            hipLaunchKernelGGL(k_bin_top, dim3((unsigned)(want < 512 ? want : 512)), dim3(256), 0, st, a, bg, val2, bins, hist);
-            hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(256), 0, st, bg, (const unsigned *)hist, offs);
-            const i64 tiles = (M + 256 * kScatterTile - 1) / (256 * kScatterTile);
-            hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)tiles), dim3(256), 0, st, a, bg, (const double *)val2, (const unsigned short *)bins,
-                               (const unsigned *)offs, cursor, recs);
-            hipLaunchKernelGGL(k_descend_bin, dim3((unsigned)bg.nb), dim3(256), 0, st, a, bg, (const unsigned *)hist, (const unsigned *)offs,
-                               (const BinRec *)recs, part_zero, part_wmax);
-            n_part = bg.nb;
-        } else {
-            SRLX_HIP(hipMemsetAsync(counters, 0, 64, st));
-            i64 want = (M + 256 * kIlp - 1) / (256 * kIlp);
-            int blocks = (int)(want < 256 * 4 ? want : 256 * 4);  // 42 KiB of LDS each: 3-4 resident workgroups per CU
-            hipLaunchKernelGGL(k_descend_bulk, dim3(blocks), dim3(256), 0, st, a, h->lds_blocks, counters, counters + 1);
+        u64 *counters = h->d_ctl;
+        const i64 ntiles = (M + kTile - 1) / kTile;
+        if (ntiles > h->tiles_cap) {  // look-back state of the compaction, zero between calls
+            if (h->d_tiles) SRLX_HIP(hipFree(h->d_tiles));
+            h->d_tiles = nullptr;
+            h->tiles_cap = 0;
+            const i64 cap = ntiles < 1024 ? 1024 : 2 * ntiles;
+            SRLX_HIP(hipMalloc((void **)&h->d_tiles, (size_t)cap * 8));
+            SRLX_HIP(hipMemset(h->d_tiles, 0, (size_t)cap * 8));
+            h->tiles_cap = cap;
         }
-        hipLaunchKernelGGL(k_compact_bulk, dim3(1), dim3(1024), 0, st, a, counters, (int *)(counters + 2), n_part, (const unsigned *)part_zero,
-                           (const double *)part_wmax, counters + 1);
-        const int wb = (int)((B + 255) / 256);
-        hipLaunchKernelGGL(k_weights_bulk, dim3(wb), dim3(256), 0, st, a, (const int *)(counters + 2), counters + 3);
-        hipLaunchKernelGGL(k_normalise_bulk, dim3(wb), dim3(256), 0, st, a, (const int *)(counters + 2), counters + 1, counters + 3);
+        const bool big = M >= kBulkBigMin;
+        const int threads = big ? 1024 : 256;
+        const int top_blocks = big ? h->lds_blocks_big : h->lds_blocks;
+        const int resident = big ? h->n_cu : 4 * h->n_cu;
+        const i64 want = (M + threads * kIlp - 1) / (threads * kIlp);
+        const int blocks = (int)(want < resident ? want : resident);
+        const size_t lds = (size_t)top_blocks * 64 + (size_t)threads * 8;
+        if (big)
+            hipLaunchKernelGGL((k_descend_bulk<1024>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, counters, counters + 1);
+        else
+            hipLaunchKernelGGL((k_descend_bulk<256>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, counters, counters + 1);
+        const i64 fw = (B + 256 * 4 - 1) / (256 * 4);
+        const int fb = (int)(fw < 8 * h->n_cu ? fw : 8 * h->n_cu);
+        hipLaunchKernelGGL(k_finish_fast, dim3(fb), dim3(256), 0, st, a, counters);
+        const i64 cw = 2 * (i64)h->n_cu;
+        hipLaunchKernelGGL(k_compact_bulk, dim3((unsigned)(ntiles < cw ? ntiles : cw)), dim3(kTileThreads), 0, st, a, counters, h->d_tiles, ntiles);
+        hipLaunchKernelGGL(k_finish_slow, dim3(fb < h->n_cu ? fb : h->n_cu), dim3(256), 0, st, a, counters, h->d_tiles, ntiles);
     }
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
@@ -1187,6 +1109,9 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
     h->size = h->write = 0;
     h->d_state = nullptr;
     h->d_err = nullptr;
+    h->d_ctl = nullptr;
+    h->d_tiles = nullptr;
+    h->tiles_cap = 0;
     {   // geometry of the blocked layout (see struct Tree)
         Tree &t = h->tree;
         t.T = nullptr;
@@ -1205,15 +1130,29 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
             h->n_blocks = t.G >= 1 ? t.base[t.G + 1] : 1;
         }
         h->lds_blocks = 1;
-        const char *bulk = getenv("SRLX_PER_BULK");
-        h->bulk_binned = bulk && !strcmp(bulk, "binned");  // measured slower than the flat walk at 1M..4M draws
-        for (int g = 1; g <= t.G; g++)
-            if (t.base[g + 1] <= kBulkLdsBlocks) h->lds_blocks = (int)t.base[g + 1];
+        h->lds_blocks_big = 1;
+        h->free_groups = 0;
+        if (t.D > 0) {
+            const int shallowest_leaf = node_depth(capacity - 1);  // node N-1 is the first leaf
+            for (int g = 0; g <= t.G && t.h0 + 3 * g < shallowest_leaf; g++) h->free_groups = g + 1;
+        }
+        for (int g = 1; g <= t.G; g++) {
+            if (t.base[g + 1] <= kBulkTopSmall) h->lds_blocks = (int)t.base[g + 1];
+            if (t.base[g + 1] <= kBulkTopBig) h->lds_blocks_big = (int)t.base[g + 1];
+        }
         if (h->n_blocks < h->lds_blocks) h->lds_blocks = (int)h->n_blocks;
+        if (h->n_blocks < h->lds_blocks_big) h->lds_blocks_big = (int)h->n_blocks;
+        hipDeviceProp_t prop;
+        SRLX_HIP(hipGetDeviceProperties(&prop, device));
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        SRLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend_bulk<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kBulkTopBig * 64 + 1024 * 8));
     }
     hipError_t e = hipMalloc((void **)&h->tree.T, 128 * (size_t)h->n_blocks);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_state, sizeof(PerState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_err, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_ctl, 64);
+    if (e == hipSuccess) e = hipMemset(h->d_ctl, 0, 64);
     if (e != hipSuccess) {
         srlx::set_error("per_create: %s", hipGetErrorString(e));
         srlx_per_destroy(h);
@@ -1236,6 +1175,8 @@ int srlx_per_destroy(srlx_per_t *h) {
     if (h->tree.T) (void)hipFree(h->tree.T);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->d_err) (void)hipFree(h->d_err);
+    if (h->d_ctl) (void)hipFree(h->d_ctl);
+    if (h->d_tiles) (void)hipFree(h->d_tiles);
     h->scratch.release();
     h->staging.release();
     h->pinned.release();

@@ -275,27 +275,54 @@ def test_multi_gpu_sized_adds_vs_oracle(capacity, n):
 
 
 @pytest.mark.parametrize("cap", [1_000_000, 300_001])
-def test_binned_bulk_walk_equals_oracle(cap, monkeypatch):
-    """SRLX_PER_BULK=binned (counting-sorted bulk descent, the measured alternative to the flat walk): same
-    indices, uniform consumption and weights as the oracle, zero-priority rejections included."""
-    monkeypatch.setenv("SRLX_PER_BULK", "binned")  # read at srlx_per_create
+def test_bulk_walk_per_cu_configuration_equals_oracle(cap):
+    """Calls of >= 2^19 draws run the one-workgroup-per-CU walk (14 top levels of left children staged in 150 KB of
+    LDS).  Same indices, uniform consumption and weights as the oracle on the rejecting path, twice in a row (the
+    kernels re-arm their own counters), then on the no-rejection path, and for smaller calls (256-thread
+    configuration) on the same handle.  A zero-priority leaf has zero width, so rejections are forced the way the
+    reference can meet them: the leftmost leaf holds priority 0 and some uniforms are exactly 0.0 (always-left walk)."""
     N = _N()
     rng = np.random.default_rng(5)
     g = AbiPER(cap, 0.5, 0.4, 1_000_000, True, 1e-4)
     o = OraclePER(cap, 0.5, 0.4, 1_000_000, True, 1e-4)
     pri = rng.random(cap)
-    pri[rng.random(cap) < 0.02] = 0.0  # zero leaves: in-order rejection on the slow path
+    pri[rng.random(cap) < 0.02] = 0.0
+    node = 0
+    while 2 * node + 1 < 2 * cap - 1:
+        node = 2 * node + 1
+    leftmost = node - (cap - 1)
+    pri[leftmost] = 0.0
     g.add(pri, N.PRIO_RAW)
     for x in pri:
         o.add(float(x), mode=2)
     np.testing.assert_array_equal(g.state()[3], o.tree())
-    M, B = 150_000, 120_000
-    u = rng.random(M)
-    st, used, idx, w, w32 = g.sample(B, 1000, u)
-    oused, oidx, ow, _ = o.sample(B, 1000, u)
-    assert st == 0 and used == oused
-    np.testing.assert_array_equal(idx, oidx)
-    np.testing.assert_allclose(w, ow, rtol=W_RTOL, atol=0)
+
+    def same(M, B, step):
+        u = rng.random(M)
+        u[rng.random(M) < 0.03] = 0.0
+        st, used, idx, w, w32 = g.sample(B, step, u)
+        oused, oidx, ow, _ = o.sample(B, step, u)
+        assert st == 0 and used == oused
+        np.testing.assert_array_equal(idx, oidx)
+        np.testing.assert_allclose(w, ow, rtol=W_RTOL, atol=0)
+        return used
+
+    assert same(600_000, 560_000, 1000) > 560_000
+    assert same(600_000, 560_000, 2000) > 560_000
+    # more accepted draws wanted than the uniforms can give: reported, and the next call is unaffected
+    u = rng.random(600_000)
+    u[rng.random(600_000) < 0.03] = 0.0
+    st, used, *_ = g.sample(599_000, 2500, u)
+    assert st == N.ERR_UNIFORMS_EXHAUSTED and used == -1
+    assert same(150_000, 120_000, 3000) > 120_000
+    pri2 = rng.random(cap) + 0.01  # the leftmost leaf is drawable again: u == 0.0 is accepted
+    g.add(pri2, N.PRIO_RAW)
+    for x in pri2:
+        o.add(float(x), mode=2)
+    np.testing.assert_array_equal(g.state()[3], o.tree())
+    assert same(600_000, 600_000, 4000) == 600_000
+    assert same(1 << 20, 1 << 20, 5000) == 1 << 20
+    assert same(100_000, 100_000, 6000) == 100_000
 
 
 def test_on_device_pointers_with_torch():

@@ -1,0 +1,1 @@
+cd $GRAFT_REPO_ROOT; timeout 900 python -m pytest tests/test_per_gpu.py -x -q -m gpu 2>&1 | tail -40

@@ -1,23 +1,28 @@
 """Probe: time the bulk PER sample pipeline stand-alone (used with rocprofv3 for per-kernel times).
-SRLX_PER_BULK=flat selects the unbinned walk; the printed checksums must agree between the two."""
+The printed checksums pin the outputs across kernel variants."""
 import sys, os, ctypes, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from simple_distributed_rl_amd import _native as N
 lib = N.lib()
 dev = torch.device("cuda:0")
-for cap, zero_frac in ((1_000_000, 0.0), (1_000_000, 0.01), (300_001, 0.0)):
+QUICK = len(sys.argv) > 1 and sys.argv[1] == "quick"
+for cap, zero_frac in (((1_000_000, 0.0),) if QUICK else ((1_000_000, 0.0), (1_000_000, 0.01), (300_001, 0.0))):
     h = N.c_p(); N.check(lib.srlx_per_create(ctypes.byref(h), cap, 0.5, 0.4, 1e6, 1, 1e-4, 0))
     g = torch.Generator(device="cuda").manual_seed(1)
     pri = torch.rand(cap, dtype=torch.float64, device=dev, generator=g)
     if zero_frac:
         pri[torch.rand(cap, device=dev, generator=g) < zero_frac] = 0.0
+        node = 0
+        while 2 * node + 1 < 2 * cap - 1: node = 2 * node + 1
+        pri[node - (cap - 1)] = 0.0  # the leftmost leaf: a uniform of exactly 0.0 lands on it and is rejected
         N.check(lib.srlx_per_add(h, cap, N.tptr(pri), N.PRIO_RAW if hasattr(N, "PRIO_RAW") else 3, 1, None))
     else:
         N.check(lib.srlx_per_add(h, cap, N.tptr(pri), N.PRIO_F64, 1, None))
-    for draws in (1 << 20, 1 << 22):
+    for draws in ((1 << 20, 1 << 22) if QUICK else (1 << 20, 1 << 22, 1 << 24)):
         u = torch.rand(draws, dtype=torch.float64, device=dev, generator=g)
         B = draws if not zero_frac else draws // 2
+        if zero_frac: u[torch.rand(draws, device=dev, generator=g) < zero_frac] = 0.0  # forces the in-order rejection path
         idx = torch.empty(B, dtype=torch.int64, device=dev); w = torch.empty(B, dtype=torch.float32, device=dev)
         used = torch.zeros(1, dtype=torch.int64, device=dev); step = torch.zeros(1, dtype=torch.int64, device=dev)
         def run():

@@ -7,7 +7,8 @@ from simple_distributed_rl_amd import _native as N
 lib = N.lib()
 dev = torch.device("cuda:0")
 QUICK = len(sys.argv) > 1 and sys.argv[1] == "quick"
-for cap, zero_frac in (((1_000_000, 0.0),) if QUICK else ((1_000_000, 0.0), (1_000_000, 0.01), (300_001, 0.0))):
+CAPS = [(int(c), 0.0) for c in sys.argv[2:]]
+for cap, zero_frac in (CAPS if CAPS else ((1_000_000, 0.0),) if QUICK else ((1_000_000, 0.0), (1_000_000, 0.01), (300_001, 0.0))):
     h = N.c_p(); N.check(lib.srlx_per_create(ctypes.byref(h), cap, 0.5, 0.4, 1e6, 1, 1e-4, 0))
     g = torch.Generator(device="cuda").manual_seed(1)
     pri = torch.rand(cap, dtype=torch.float64, device=dev, generator=g)

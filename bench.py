@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
     ap.add_argument("--per-micro", action="store_true", help="also time the bulk PER sample kernel (extra field)")
+    ap.add_argument("--dist-selftest", action="store_true", help="run the N>1 code path (DistributedRainbow, RCCL gathers/broadcasts) at world size 1")
     return ap.parse_args()
 
 
@@ -55,11 +56,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    if world > 1 or args.dist_selftest:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
     else:
         dist = None
 
@@ -67,10 +69,10 @@ def main():
 
     cfg = RainbowDeviceConfig(n_envs=args.envs, batch_size=args.batch_size, memory_capacity=args.capacity, seed=rank)
 
-    if world > 1:
+    if dist is not None:
         from simple_distributed_rl_amd.device.dist import DistributedRainbow
 
-        eng = DistributedRainbow(cfg, local_rank, args.episode_len, sync_interval=args.sync_interval)
+        eng = DistributedRainbow(cfg, local_rank, args.episode_len, sync_interval=args.sync_interval, always_collective=args.dist_selftest)
     else:
         eng = RainbowEngine(cfg, local_rank, args.episode_len, overlap=not args.no_overlap)
     is_learner = rank == 0
@@ -140,8 +142,8 @@ def main():
             "epsilon": cfg.epsilon,
             "hip_graphs": not args.no_graph,
             "qnet": ("libsrlx: fp32 MFMA forward, hand-written backward (no autograd)" if getattr(eng, "mfma_train", False) else "libsrlx fp32 MFMA forward, torch autograd backward") if eng.mfma else "torch",
-            "actor_learner_overlap": (not args.no_overlap) if world == 1 else False,
-            "topology": "1 GPU: actor+learner" if world == 1 else f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast",
+            "actor_learner_overlap": (not args.no_overlap) if dist is None else True,
+            "topology": "1 GPU: actor+learner" if dist is None else f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast",
         },
         "roofline": roofline(eng, ev_ms),
         "final": {"loss": info["loss"], "train_count": info["train_count"], "memory": info["memory"]},

@@ -28,8 +28,10 @@ from simple_distributed_rl_amd import _native as N
 class TransitionBus:
     """Fixed-size per-step transition exchange and parameter fan-out between ranks."""
 
-    def __init__(self, n_envs_local: int, obs_elems: int, obs_dtype: torch.dtype, device: torch.device, group=None, learner_rank: int = 0):
+    def __init__(self, n_envs_local: int, obs_elems: int, obs_dtype: torch.dtype, device: torch.device, group=None, learner_rank: int = 0,
+                 always_collective: bool = False):
         self.E, self.F = n_envs_local, obs_elems
+        self.always_collective = always_collective  # run the collectives even at world size 1 (transport tests on a 1-GPU box)
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -53,7 +55,7 @@ class TransitionBus:
     def push(self, actions, rewards, terminated, done, next_obs):
         """Every rank contributes its E transitions; the learner rank gets them concatenated in rank
         order (env index = rank * E + local index).  Returns the gathered tensors on the learner, None elsewhere."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return actions, rewards, terminated, done, next_obs
         # two collectives per step: the frames, and ONE packed record buffer for the four scalar fields
         # ([actions 4E | rewards 4E | terminated E | done E] bytes per rank) that the learner unpacks with strided copies
@@ -61,7 +63,7 @@ class TransitionBus:
         scal = torch.cat([actions.contiguous().view(torch.uint8), rewards.contiguous().view(torch.uint8), terminated.contiguous().view(torch.uint8),
                           done.contiguous().view(torch.uint8)])
         staged = dist.get_backend(self.group) == "gloo" and actions.is_cuda  # test rigs: 2 ranks sharing one GPU
-        for t, name in ((scal, "g_scal"), (next_obs, "g_next_obs")):
+        for t, name in ((scal, "g_scal"), (next_obs.contiguous(), "g_next_obs")):
             if staged:
                 parts = [torch.empty_like(t, device="cpu") for _ in range(self.world)] if self.is_learner else None
                 dist.gather(t.cpu(), parts, dst=self.learner_rank, group=self.group)
@@ -83,7 +85,7 @@ class TransitionBus:
         return None
 
     def broadcast_params(self, flat: torch.Tensor):
-        if self.world <= 1:
+        if self.world <= 1 and not self.always_collective:
             return
         if dist.get_backend(self.group) == "gloo" and flat.is_cuda:
             host = flat.cpu()
@@ -113,7 +115,7 @@ def flatten_parameters(module: torch.nn.Module) -> torch.Tensor:
 class DistributedRainbow:
     """world ranks x E actors, learner + replay on rank 0 (BASELINE.json config 4 topology applied to Rainbow)."""
 
-    def __init__(self, cfg, device: int, episode_len: int = 200, sync_interval: int = 16, overlap: bool = True):
+    def __init__(self, cfg, device: int, episode_len: int = 200, sync_interval: int = 16, overlap: bool = True, always_collective: bool = False):
         import dataclasses
 
         from simple_distributed_rl_amd.device.rainbow import RainbowEngine, SyntheticAtariVecEnv
@@ -136,7 +138,7 @@ class DistributedRainbow:
         if self.local.mfma:  # the parameters moved: point the inference kernels at their new home
             self.local.inf_actor.bind()
             self.local.inf_online.bind()
-        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev)
+        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective)
         self.step_count = 0
         if self.is_learner:
             total = self.world * E

@@ -1,7 +1,9 @@
 """End-to-end check of the multi-rank actor/learner topology (device/dist.py:DistributedRainbow) with two
 ranks SHARING the one GPU of the test box (gloo rendezvous, tensors staged through the host): the global
 replay on rank 0 receives every rank's transitions, the learner trains, and the broadcast leaves the
-actor rank with the learner's weights.  The RCCL data path itself is exercised by bench.py --gpus N."""
+actor rank with the learner's weights.  The RCCL transport (backend "nccl") cannot be given two ranks on one GPU, so its
+calls -- the uint8 gathers into views of the staging buffers, the parameter broadcast, the barrier and the MAX
+all-reduce bench.py uses -- are run at world size 1 on the real backend; N > 1 over xGMI is bench.py --gpus N."""
 import os
 import socket
 import sys
@@ -63,3 +65,47 @@ def test_distributed_rainbow_two_ranks_one_gpu():
     assert r0["train_count"] > 0 and r0["loss"] == r0["loss"]  # trained, loss not NaN
     # step 12 ended with a broadcast (sync_interval=2): the actor rank holds the learner's exact weights
     assert r0["flat_sum"] == r1["flat_sum"] and r0["flat_abs"] == r1["flat_abs"]
+
+
+def _rccl_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from simple_distributed_rl_amd.device.dist import TransitionBus
+
+        E, F = 64, 84 * 84
+        bus = TransitionBus(E, F, torch.uint8, dev, always_collective=True)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        ok = True
+        for _ in range(3):
+            actions = torch.randint(0, 6, (E,), dtype=torch.int32, device=dev, generator=g)
+            rewards = torch.randn(E, device=dev, generator=g)
+            term = (torch.rand(E, device=dev, generator=g) < 0.1).to(torch.uint8)
+            done = (torch.rand(E, device=dev, generator=g) < 0.2).to(torch.uint8)
+            frames = torch.randint(0, 256, (E, F), dtype=torch.uint8, device=dev, generator=g)
+            got = bus.push(actions, rewards, term, done, frames)
+            torch.cuda.synchronize()
+            ok = ok and all(torch.equal(a, b) for a, b in zip(got, (actions, rewards, term, done, frames)))
+        flat = torch.randn(1 << 20, device=dev, generator=g)
+        ref = flat.clone()
+        bus.broadcast_params(flat)
+        dist.barrier()
+        t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n = torch.tensor([7], dtype=torch.int64, device=dev)
+        dist.broadcast(n, src=0)
+        torch.cuda.synchronize()
+        ret[rank] = {"push_ok": bool(ok), "bcast_ok": bool(torch.equal(flat, ref)), "max": float(t.item()), "n": int(n.item()),
+                     "backend": dist.get_backend()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_transport_calls_at_world_size_one():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret[0] == {"push_ok": True, "bcast_ok": True, "max": 1.25, "n": 7, "backend": "nccl"}

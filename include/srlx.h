@@ -218,6 +218,14 @@ int srlx_dqn_target(int64_t batch, int n_actions, const float *d_q_on_next, cons
                     const float *d_discount_per_sample, int enable_double_dqn, int enable_rescale, int f64_accum,
                     float *d_target, void *stream);
 
+/* torch.optim.Adam(params, lr) .step() (srl/algorithms/rainbow/model_torch.py:71,109; dqn/model_torch.py:75,119) for up
+ * to 16 float32 parameter tensors in one launch.  The four pointer arrays and numels are HOST arrays of n_tensors
+ * entries (device pointers, 16-byte aligned; exp_avg / exp_avg_sq are the optimizer state, zero before the first step);
+ * *d_step = optimizer steps already taken (device scalar, so the call is HIP-graph replayable; the caller increments it). */
+int srlx_adam_step(int n_tensors, float *const *d_params, const float *const *d_grads, float *const *d_exp_avg,
+                   float *const *d_exp_avg_sq, const int64_t *numels, double lr, double beta1, double beta2, double eps,
+                   const int64_t *d_step, void *stream);
+
 /* GAE reverse scan per environment (srl/algorithms/ppo/ppo.py:389-404): for each env, episodes are
  * delimited by done[t]; the last step of an episode uses delta = r - V (no bootstrap, :396-397).
  *   rewards, values, done(uint8) laid out [T][E]; out advantages f32 [T][E].

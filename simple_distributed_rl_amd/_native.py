@@ -81,6 +81,7 @@ SIGNATURES = {
     ),
     "srlx_dqn_target": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_p, c_int, c_int, c_int, c_p, c_p]),
     "srlx_gae_scan": (c_int, [c_i64, c_i64, c_p, c_p, c_p, c_p, c_f64, c_f64, c_p, c_p]),
+    "srlx_adam_step": (c_int, [c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_f64, c_f64, c_p, c_p]),
     "srlx_rank_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_int]),
     "srlx_rank_destroy": (c_int, [c_p]),
     "srlx_rank_set": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_p]),

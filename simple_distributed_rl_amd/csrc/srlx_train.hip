@@ -1,11 +1,12 @@
 // srlx_train.hip -- fused learner arithmetic: n-step/retrace TD target + Huber loss + gradient seed +
-// priority recompute in one launch; 1-step (double-)DQN target; GAE reverse scan.
+// priority recompute in one launch; 1-step (double-)DQN target; GAE reverse scan; multi-tensor Adam step.
 //
 // These replace host-side numpy between network calls in the reference:
 //   srl/algorithms/rainbow/rainbow.py:226-287        (calc_target_q after the two forwards)
 //   srl/algorithms/rainbow/model_torch.py:103-105,113 (selected Q, HuberLoss(target*w, q*w), |target-q|)
 //   srl/algorithms/dqn/dqn.py:144-176, srl/algorithms/rainbow/rainbow_nomultisteps.py:10-43
 //   srl/algorithms/ppo/ppo.py:389-404
+//   srl/algorithms/rainbow/model_torch.py:71,109      (torch.optim.Adam step)
 // All are tiny (B x n x A floats): latency-bound single-workgroup kernels whose point is to keep the
 // learner step free of device<->host hops (the reference does four per train()).
 // float32 arithmetic follows numpy's evaluation order of the cited lines.
@@ -199,6 +200,71 @@ __global__ void __launch_bounds__(256) k_gae_scan(i64 E, i64 T, const float *rew
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Adam (model_torch.py:71: torch.optim.Adam(lr); :109 optimizer.step()) for every parameter tensor of the network in
+// ONE launch: 28 B of traffic per element (p, g, m, v read; p, m, v written), HBM bound -- 8.0 M parameters = 224 MB.
+// The tensor table travels as a kernel argument; a workgroup owns one 2048-element chunk of one tensor.
+// Arithmetic order follows torch's Adam (step starts at 1; exp_avg = lerp(exp_avg, g, 1-b1); bias corrections in
+// double; denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom), evaluated in float32.
+// ------------------------------------------------------------------------------------------
+constexpr int kAdamMaxTensors = 16;
+constexpr int kAdamChunk = 2048;
+struct AdamTable {
+    float *p[kAdamMaxTensors];
+    const float *g[kAdamMaxTensors];
+    float *m[kAdamMaxTensors];
+    float *v[kAdamMaxTensors];
+    i64 n[kAdamMaxTensors];
+    int chunk_start[kAdamMaxTensors + 1];
+    int n_tensors;
+};
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float w1, float b2, float w2, float step_size, float bc2_sqrt, float eps) {
+    m = m + w1 * (g - m);
+    v = b2 * v + (w2 * g) * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - (step_size * m) / denom;
+}
+
+__global__ void __launch_bounds__(256) k_adam(AdamTable tb, double lr, double beta1, double beta2, double eps, const i64 *d_step) {
+    int ti = 0;
+    while (ti + 1 < tb.n_tensors && (int)blockIdx.x >= tb.chunk_start[ti + 1]) ti++;
+    const i64 off = (i64)((int)blockIdx.x - tb.chunk_start[ti]) * kAdamChunk;
+    const i64 n = tb.n[ti];
+    float *p = tb.p[ti] + off, *m = tb.m[ti] + off, *v = tb.v[ti] + off;
+    const float *g = tb.g[ti] + off;
+    const double step = (double)(*d_step + 1);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2), e = (float)eps;
+    const i64 left = n - off;
+    const int cnt = left < kAdamChunk ? (int)left : kAdamChunk;
+    const int t = threadIdx.x;
+    if (cnt == kAdamChunk) {  // chunks start at multiples of 2048 floats of a 16-byte aligned tensor
+#pragma unroll
+        for (int r = 0; r < kAdamChunk / (256 * 4); r++) {
+            const int k = (r * 256 + t) * 4;
+            float4 pp = *reinterpret_cast<float4 *>(p + k), mm = *reinterpret_cast<float4 *>(m + k), vv = *reinterpret_cast<float4 *>(v + k);
+            const float4 gg = *reinterpret_cast<const float4 *>(g + k);
+            adam_one(pp.x, gg.x, mm.x, vv.x, w1, b2, w2, step_size, bc2_sqrt, e);
+            adam_one(pp.y, gg.y, mm.y, vv.y, w1, b2, w2, step_size, bc2_sqrt, e);
+            adam_one(pp.z, gg.z, mm.z, vv.z, w1, b2, w2, step_size, bc2_sqrt, e);
+            adam_one(pp.w, gg.w, mm.w, vv.w, w1, b2, w2, step_size, bc2_sqrt, e);
+            *reinterpret_cast<float4 *>(p + k) = pp;
+            *reinterpret_cast<float4 *>(m + k) = mm;
+            *reinterpret_cast<float4 *>(v + k) = vv;
+        }
+    } else {
+        for (int k = t; k < cnt; k += 256) {
+            float pp = p[k], mm = m[k], vv = v[k];
+            adam_one(pp, g[k], mm, vv, w1, b2, w2, step_size, bc2_sqrt, e);
+            p[k] = pp;
+            m[k] = mm;
+            v[k] = vv;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -240,6 +306,31 @@ int srlx_gae_scan(int64_t n_envs, int64_t horizon, const float *d_rewards, const
     SRLX_REQUIRE(n_envs > 0 && horizon > 0 && d_rewards && d_values && d_done && d_adv, "gae_scan: bad argument");
     hipLaunchKernelGGL(k_gae_scan, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (i64)n_envs,
                        (i64)horizon, d_rewards, d_values, d_done, d_last_values, discount, gae_lambda, d_adv);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_adam_step(int n_tensors, float *const *d_params, const float *const *d_grads, float *const *d_exp_avg, float *const *d_exp_avg_sq,
+                   const int64_t *numels, double lr, double beta1, double beta2, double eps, const int64_t *d_step, void *stream) {
+    SRLX_REQUIRE(n_tensors > 0 && n_tensors <= kAdamMaxTensors, "adam_step: 1..%d tensors per call (got %d)", kAdamMaxTensors, n_tensors);
+    SRLX_REQUIRE(d_params && d_grads && d_exp_avg && d_exp_avg_sq && numels && d_step, "adam_step: NULL argument");
+    AdamTable tb{};
+    tb.n_tensors = n_tensors;
+    int chunks = 0;
+    for (int i = 0; i < n_tensors; i++) {
+        SRLX_REQUIRE(d_params[i] && d_grads[i] && d_exp_avg[i] && d_exp_avg_sq[i] && numels[i] > 0, "adam_step: tensor %d is NULL or empty", i);
+        SRLX_REQUIRE(((uintptr_t)d_params[i] | (uintptr_t)d_grads[i] | (uintptr_t)d_exp_avg[i] | (uintptr_t)d_exp_avg_sq[i]) % 16 == 0,
+                     "adam_step: tensor %d is not 16-byte aligned", i);
+        tb.p[i] = d_params[i];
+        tb.g[i] = d_grads[i];
+        tb.m[i] = d_exp_avg[i];
+        tb.v[i] = d_exp_avg_sq[i];
+        tb.n[i] = numels[i];
+        tb.chunk_start[i] = chunks;
+        chunks += (int)((numels[i] + kAdamChunk - 1) / kAdamChunk);
+    }
+    tb.chunk_start[n_tensors] = chunks;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, tb, lr, beta1, beta2, eps, (const i64 *)d_step);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

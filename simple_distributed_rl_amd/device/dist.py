@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 from simple_distributed_rl_amd import _native as N
+from simple_distributed_rl_amd.device.qnet import DeviceAdam
 
 
 class TransitionBus:
@@ -138,6 +139,8 @@ class DistributedRainbow:
         if self.local.mfma:  # the parameters moved: point the inference kernels at their new home
             self.local.inf_actor.bind()
             self.local.inf_online.bind()
+            if isinstance(self.local.optimizer, DeviceAdam):
+                self.local.optimizer.bind()
         self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective)
         self.step_count = 0
         if self.is_learner:

@@ -178,3 +178,44 @@ class QNetInference:
         q = self.q[:B] if out is None else out
         N.check(self.lib.srlx_qnet_forward_u8(self.h, B, N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(q), N.torch_stream_ptr()))
         return q
+
+
+class DeviceAdam:
+    """torch.optim.Adam(params, lr) for a fixed list of float32 device tensors as ONE libsrlx launch
+    (`srlx_adam_step`; reference: `optim.Adam(self.q_online.parameters(), lr=...)`, model_torch.py:71, and
+    `optimizer.step()`, :109).  Reads `p.grad`, keeps `exp_avg` / `exp_avg_sq` in each parameter's own memory format,
+    takes the step count from a device scalar so the call replays inside a HIP graph."""
+
+    def __init__(self, params, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.params = [p for p in params]
+        assert 0 < len(self.params) <= 16 and all(p.is_cuda and p.dtype == torch.float32 for p in self.params)
+        assert all(p.grad is not None for p in self.params), "DeviceAdam needs static gradient tensors (QNetInference.enable_training)"
+        self.lib = N.lib()
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]  # preserve_format
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        k = len(self.params)
+        self.bind()
+        self._g = (N.c_p * k)(*[p.grad.data_ptr() for p in self.params])
+        self._m = (N.c_p * k)(*[t.data_ptr() for t in self.exp_avg])
+        self._v = (N.c_p * k)(*[t.data_ptr() for t in self.exp_avg_sq])
+        self._n = (N.c_i64 * k)(*[p.numel() for p in self.params])
+        for p, m in zip(self.params, self.exp_avg):
+            assert p.stride() == m.stride() == p.grad.stride(), "parameter, gradient and Adam state must share one memory format"
+
+    def bind(self):
+        """(Re)reads the parameters' addresses: call again after they have been re-homed (device/dist.py:flatten_parameters)."""
+        self._p = (N.c_p * len(self.params))(*[p.data_ptr() for p in self.params])
+
+    def step(self, steps_taken_dev: torch.Tensor):
+        """One Adam step; `steps_taken_dev` (int64 device scalar) = steps already taken (the caller increments it)."""
+        k = len(self.params)
+        N.check(self.lib.srlx_adam_step(k, ctypes.cast(self._p, N.c_p), ctypes.cast(self._g, N.c_p), ctypes.cast(self._m, N.c_p), ctypes.cast(self._v, N.c_p),
+                                        ctypes.cast(self._n, N.c_p), self.lr, self.betas[0], self.betas[1], self.eps, N.tptr(steps_taken_dev), N.torch_stream_ptr()))
+
+    def state_dict(self):
+        return {"exp_avg": [t.clone() for t in self.exp_avg], "exp_avg_sq": [t.clone() for t in self.exp_avg_sq]}
+
+    def load_state_dict(self, sd):
+        for dst, src in zip(self.exp_avg + self.exp_avg_sq, list(sd["exp_avg"]) + list(sd["exp_avg_sq"])):
+            dst.copy_(src)

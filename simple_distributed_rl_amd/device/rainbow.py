@@ -22,7 +22,7 @@ import torch
 
 from simple_distributed_rl_amd import _native as N
 from simple_distributed_rl_amd.device.replay import DeviceReplay
-from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference
+from simple_distributed_rl_amd.device.qnet import DeviceAdam, EngineQNet, QNetInference
 from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
 
 
@@ -161,7 +161,10 @@ class RainbowEngine:
         self._front_graph = None
         self._select_graph = None
         self._commit_graph = None
-        self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True, fused=True)  # model_torch.py:71 (one multi-tensor kernel)
+        if self.mfma_train:  # model_torch.py:71 as one libsrlx launch over the 12 parameter tensors
+            self.optimizer = DeviceAdam(self.inf_online._params(), lr=cfg.lr)
+        else:
+            self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True, fused=True)
         d = self.dev
         B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
         self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
@@ -314,10 +317,11 @@ class RainbowEngine:
         )
         if self.mfma_train:  # model_torch.py:107-109 without autograd: every p.grad is (over)written by the backward kernels
             self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
+            self.optimizer.step(self.train_count_dev)
         else:
             self.optimizer.zero_grad(set_to_none=False)
             q0.backward(self.grad_q0)  # model_torch.py:107-109: d loss / d q seeds autograd
-        self.optimizer.step()
+            self.optimizer.step()
         r.update(b.indices, self.priorities)  # model_torch.py:113-114
         self.train_count_dev.add_(1)
 

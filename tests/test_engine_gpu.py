@@ -70,3 +70,41 @@ def test_engine_overlap_and_graphs():
     assert any(float((p - q).abs().max()) > 0 for p, q in zip(eng.q_online.parameters(), before))
     for p, q in zip(eng.q_actor.parameters(), eng.q_online.parameters()):
         assert torch.equal(p, q)  # the actor's copy is refreshed after every step
+
+
+def test_device_adam_matches_torch_adam():
+    """`srlx_adam_step` (one launch over all parameter tensors, step count from a device scalar) against
+    torch.optim.Adam on the same gradients: parameters and both moment estimates after every one of 6 steps.
+    Shapes cover whole 2048-element chunks, ragged tails, a tensor smaller than one chunk and a channels_last weight."""
+    from simple_distributed_rl_amd.device.qnet import DeviceAdam
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(32, 4, 8, 8), (32,), (64, 32, 4, 4), (512, 3136), (7,), (6, 512), (4097,)]
+    ours, ref = [], []
+    for i, s in enumerate(shapes):
+        t = torch.randn(s, device=dev, generator=g) * 0.1
+        if len(s) == 4 and i == 2:
+            t = t.contiguous(memory_format=torch.channels_last)
+        a = torch.nn.Parameter(t.clone(memory_format=torch.preserve_format))
+        a.grad = torch.zeros_like(a)
+        ours.append(a)
+        ref.append(torch.nn.Parameter(t.clone(memory_format=torch.preserve_format)))
+    opt = DeviceAdam(ours, lr=2.5e-4)
+    topt = torch.optim.Adam(ref, lr=2.5e-4)
+    steps = torch.zeros(1, dtype=torch.int64, device=dev)
+    for it in range(6):
+        for a, b in zip(ours, ref):
+            gr = torch.randn(a.shape, device=dev, generator=g) * (10.0 ** (-it))  # large and tiny gradients
+            a.grad.copy_(gr)
+            b.grad = gr.clone(memory_format=torch.preserve_format)
+        opt.step(steps)
+        steps.add_(1)
+        topt.step()
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(zip(ours, ref)):
+            st = topt.state[b]
+            m_ref = st["exp_avg"].cpu().numpy()  # m + w (g - m) cancels: compare on the scale of the tensor
+            np.testing.assert_allclose(opt.exp_avg[k].cpu().numpy(), m_ref, rtol=2e-6, atol=2e-7 * float(np.abs(m_ref).max()), err_msg=f"m {k} step {it}")
+            np.testing.assert_allclose(opt.exp_avg_sq[k].cpu().numpy(), st["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=1e-20, err_msg=f"v {k} step {it}")
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-6, atol=2e-8, err_msg=f"p {k} step {it}")

@@ -1,1 +1,1 @@
-cd $GRAFT_REPO_ROOT; timeout 900 python -X faulthandler bench.py --dist-selftest --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/selftest.log 2>&1; echo "rc=$?"; tail -30 gpurun_out/selftest.log | cut -c1-400
+cd $GRAFT_REPO_ROOT; timeout 900 python -m pytest tests/test_engine_gpu.py -x -q -m gpu -k adam 2>&1 | tail -5

@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
     ap.add_argument("--per-micro", action="store_true", help="also time the bulk PER sample kernel (extra field)")
+    ap.add_argument("--learner-acts", choices=("auto", "yes", "no"), default="auto",
+                    help="N>1: does the learner rank run actors too? auto = yes below 4 GPUs, no (dedicated learner GPU) from 4")
     ap.add_argument("--dist-selftest", action="store_true", help="run the N>1 code path (DistributedRainbow, RCCL gathers/broadcasts) at world size 1")
     return ap.parse_args()
 
@@ -72,7 +74,8 @@ def main():
     if dist is not None:
         from simple_distributed_rl_amd.device.dist import DistributedRainbow
 
-        eng = DistributedRainbow(cfg, local_rank, args.episode_len, sync_interval=args.sync_interval, always_collective=args.dist_selftest)
+        eng = DistributedRainbow(cfg, local_rank, args.episode_len, sync_interval=args.sync_interval, always_collective=args.dist_selftest,
+                                 learner_acts={"auto": None, "yes": True, "no": False}[args.learner_acts])
     else:
         eng = RainbowEngine(cfg, local_rank, args.episode_len, overlap=not args.no_overlap)
     is_learner = rank == 0
@@ -106,13 +109,18 @@ def main():
         elapsed = float(t.item())
 
     ev_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    if dist is not None:  # a learner-only rank 0 runs no actor pass: report the slowest actor rank's
+        t = torch.tensor([ev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ev_ms = float(t.item())
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    env_steps = args.steps * args.envs * world
+    actor_gpus = world if dist is None else eng.n_actor_ranks
+    env_steps = args.steps * args.envs * actor_gpus
     updates = args.steps * args.updates
     info = eng.info()
     out = {
@@ -143,7 +151,9 @@ def main():
             "hip_graphs": not args.no_graph,
             "qnet": ("libsrlx: fp32 MFMA forward, hand-written backward (no autograd)" if getattr(eng, "mfma_train", False) else "libsrlx fp32 MFMA forward, torch autograd backward") if eng.mfma else "torch",
             "actor_learner_overlap": (not args.no_overlap) if dist is None else True,
-            "topology": "1 GPU: actor+learner" if dist is None else f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast",
+            "topology": "1 GPU: actor+learner" if dist is None else (f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast" if eng.learner_acts
+                         else f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology), RCCL gather/broadcast"),
+            "actor_gpus": actor_gpus,
         },
         "roofline": roofline(eng, ev_ms),
         "final": {"loss": info["loss"], "train_count": info["train_count"], "memory": info["memory"]},

@@ -55,7 +55,8 @@ def _worker(rank, world, port, ret):
         torch.manual_seed(rank)
         net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
         flat = flatten_parameters(net)
-        ok &= flat.numel() == sum(p.numel() for p in net.parameters())
+        ok &= flat.numel() == sum(-(-p.numel() // 64) * 64 for p in net.parameters())  # every parameter starts on a 256-byte boundary
+        ok &= all(p.data_ptr() % 256 == flat.data_ptr() % 256 for p in net.parameters())
         x = torch.ones(2, 7)
         before = net(x).detach().clone()
         bus.broadcast_params(flat)

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, learner_acts=True):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,7 +35,7 @@ def _worker(rank, world, port, ret):
 
         cfg = RainbowDeviceConfig(n_envs=16, batch_size=8, memory_capacity=16 * 2 * 40, memory_warmup_size=64, obs_hw=(20, 20), hidden_units=32,
                                   n_actions=4, seed=rank, target_model_update_interval=3)
-        eng = DistributedRainbow(cfg, 0, episode_len=7, sync_interval=2)
+        eng = DistributedRainbow(cfg, 0, episode_len=7, sync_interval=2, learner_acts=learner_acts)
         for _ in range(8):
             eng.step(learner_updates=2)
         eng.capture_graphs()  # HIP graphs mid-run: must not step the local environments without pushing
@@ -48,22 +48,48 @@ def _worker(rank, world, port, ret):
             out.update(info)
             out["per"] = eng.replay.per_state()
             out["global_envs"] = eng.replay.E
+        out["env_steps_local"] = int(eng.env_steps_local)
         ret[rank] = out
+    except Exception:  # the peer's "connection closed" would otherwise hide the first failure
+        import traceback
+
+        ret[f"error{rank}"] = traceback.format_exc()
+        raise
     finally:
         dist.destroy_process_group()
 
 
-def test_distributed_rainbow_two_ranks_one_gpu():
-    world = 2
+def _spawn(world, *args):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    try:
+        mp.spawn(_worker, args=(world, _free_port(), ret) + args, nprocs=world, join=True)
+    except Exception:
+        errs = [v for k, v in sorted(ret.items(), key=lambda kv: str(kv[0])) if str(k).startswith("error")]
+        raise AssertionError("worker failed:\n" + "\n".join(errs))
+    return ret
+
+
+def test_distributed_rainbow_two_ranks_one_gpu():
+    ret = _spawn(2)
     r0, r1 = ret[0], ret[1]
     assert r0["global_envs"] == 32
     assert r0["memory"] == 12 * 32  # every lock-step added one item per env of BOTH ranks
     assert r0["per"]["size"] == 12 * 32
     assert r0["train_count"] > 0 and r0["loss"] == r0["loss"]  # trained, loss not NaN
     # step 12 ended with a broadcast (sync_interval=2): the actor rank holds the learner's exact weights
+    assert r0["flat_sum"] == r1["flat_sum"] and r0["flat_abs"] == r1["flat_abs"]
+
+
+def test_distributed_rainbow_dedicated_learner_rank():
+    """learner_acts=False (the default from 4 ranks, BASELINE.json configs[3]): rank 0 only learns -- the global replay holds
+    the actor rank's environments only, rank 0 steps no environment, and the broadcast still hands its weights over."""
+    ret = _spawn(2, False)
+    r0, r1 = ret[0], ret[1]
+    assert r0["global_envs"] == 16
+    assert r0["memory"] == 12 * 16 and r0["per"]["size"] == 12 * 16
+    assert r0["train_count"] > 0 and r0["loss"] == r0["loss"]
+    assert r0["env_steps_local"] == 0 and r1["env_steps_local"] > 0
     assert r0["flat_sum"] == r1["flat_sum"] and r0["flat_abs"] == r1["flat_abs"]
 
 

@@ -160,7 +160,7 @@ def main():
     }
     if args.per_micro:
         out["per_micro"] = per_micro(eng)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other runs would only repeat it
         out["cpu_baseline"] = cpu_baseline(args, cfg)
     print(json.dumps(out))
     if dist is not None:

@@ -1,7 +1,15 @@
+# Round-end measurement pass on the GPU box: full GPU suite, smoke, bench (+ PER micro), rocprofv3 kernel stats of the
+# same bench command, PER bulk-sampling probe with its kernel stats, and the N>1 code path at world size 1.
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py --per-micro > gpurun_out/bench_r1.json 2> gpurun_out/bench_r1.err; tail -c 1500 gpurun_out/bench_r1.json
+python bench.py --dist-selftest --no-cpu-baseline 2>/dev/null | grep metric > gpurun_out/bench_r1_dist_selftest.json
+python tools/per_probe.py > gpurun_out/per_probe.log 2>&1; cat gpurun_out/per_probe.log | cut -c1-150
+R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profb -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --cpu-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/bench_r1_profiled.json 2>/dev/null
-f=$(find /tmp/profb -name "*kernel_stats.csv" | head -1); cp "$f" $GRAFT_REPO_ROOT/gpurun_out/r1_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profb -- python $R/bench.py --steps 200 --warmup 20 --cpu-seconds 0 > $R/gpurun_out/bench_r1_profiled.json 2>/dev/null
+f=$(find /tmp/profb -name "*kernel_stats.csv" | head -1); cp "$f" $R/gpurun_out/r1_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profp -- python $R/tools/per_probe.py quick > /dev/null 2>&1
+f=$(find /tmp/profp -name "*kernel_stats.csv" | head -1); grep -v "at::native" "$f" | cut -c1-400 > $R/gpurun_out/r1_per_kernel_stats.csv
+head -8 $R/gpurun_out/r1_per_kernel_stats.csv | cut -c1-200

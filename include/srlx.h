@@ -204,6 +204,13 @@ int srlx_nstep_td_huber_priority(int64_t batch, int n_step, int n_actions, const
                                  const float *d_weights, double discount, double retrace_h, int enable_double_dqn,
                                  int enable_rescale, float *d_target, float *d_loss, float *d_grad_q0,
                                  float *d_priorities, void *stream);
+/* Same, with the online network's Q rows of s_0..s_n in ONE buffer float32 [B][n+1][A] -- what a single forward over
+ * all states of the sampled items produces (row 0 = s_0, rows 1..n = s_1..s_n): no strided copies in front of it. */
+int srlx_nstep_td_huber_priority_packed(int64_t batch, int n_step, int n_actions, const float *d_q_on_all,
+                                        const float *d_q_tg_next, const int32_t *d_actions, const float *d_rewards,
+                                        const float *d_terminated, const uint8_t *d_invalid_next, const float *d_weights,
+                                        double discount, double retrace_h, int enable_double_dqn, int enable_rescale,
+                                        float *d_target, float *d_loss, float *d_grad_q0, float *d_priorities, void *stream);
 
 /* 1-step (double-)DQN target (srl/algorithms/dqn/dqn.py:144-176, rainbow_nomultisteps.py:10-43):
  * invalid next actions are masked with min(q) of the WHOLE batch, not -inf (dqn.py:160,164).
@@ -341,10 +348,15 @@ int srlx_agent57_priority(int64_t batch, int n_actions, const float *d_target_ex
  *   srlx_store_gather_items        : like srlx_store_gather_nstep, but instead of float32 pixels it emits
  *                                    int64 [B][k_count][window] offsets of states k_begin..k_begin+k_count-1
  *   srlx_store_gather_obs          : float32 [B][k_count][window][obs_elems] pixels of a state range of the
- *                                    items located by the preceding gather_items call (same stream) */
+ *                                    items located by the preceding gather_items call (same stream)
+ *   srlx_store_gather_train        : the hand-written training pass's gather in ONE launch: n-step scalars as in
+ *                                    gather_nstep, int64 [B][n+1][window] offsets of s_0..s_n (online network) and,
+ *                                    if not NULL, int64 [B][n][window] offsets of s_1..s_n (target network) */
 int srlx_store_obs_base(srlx_store_t *h, void **d_base, int64_t *frame_bytes);
 int srlx_store_frame_table_current(srlx_store_t *h, int64_t *d_out, void *stream);
 int srlx_store_gather_items(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int k_begin, int k_count, int64_t *d_frame_off,
+                            int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream);
+int srlx_store_gather_train(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int64_t *d_frame_off_all, int64_t *d_frame_off_next,
                             int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream);
 int srlx_store_gather_obs(srlx_store_t *h, int64_t batch, int k_begin, int k_count, float *d_obs, void *stream);
 

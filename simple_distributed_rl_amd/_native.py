@@ -65,6 +65,7 @@ SIGNATURES = {
     "srlx_store_obs_base": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i64)]),
     "srlx_store_frame_table_current": (c_int, [c_p, c_p, c_p]),
     "srlx_store_gather_items": (c_int, [c_p, c_i64, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_store_gather_train": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_store_gather_obs": (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p]),
     "srlx_qnet_create": (c_int, [ctypes.POINTER(c_p), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_int]),
     "srlx_qnet_destroy": (c_int, [c_p]),
@@ -78,6 +79,10 @@ SIGNATURES = {
     "srlx_nstep_td_huber_priority": (
         c_int,
         [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_int, c_int, c_p, c_p, c_p, c_p, c_p],
+    ),
+    "srlx_nstep_td_huber_priority_packed": (
+        c_int,
+        [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_int, c_int, c_p, c_p, c_p, c_p, c_p],
     ),
     "srlx_dqn_target": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_p, c_int, c_int, c_int, c_p, c_p]),
     "srlx_gae_scan": (c_int, [c_i64, c_i64, c_p, c_p, c_p, c_p, c_f64, c_f64, c_p, c_p]),

@@ -671,7 +671,7 @@ __device__ __forceinline__ bool is_ancestor(i64 a, int da, i64 x, int dx) {
     return dx > da && (((x + 1) >> (dx - da)) == a + 1);
 }
 
-__global__ void __launch_bounds__(kWgUpdate) k_update_wg(Tree tr, PerState *state, i64 n,
+__global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i64 n,
                                                           const i64 *indices, const void *prio, int kind, double eps,
                                                           double alpha, int *err_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -996,8 +996,10 @@ int launch_update(srlx_per *h, i64 n, const i64 *d_idx, const void *d_prio, int 
     const size_t eb = prio_elem_bytes(kind);
     for (i64 off = 0; off < n; off += kUpdateChunk) {
         const i64 m = (n - off < kUpdateChunk) ? n - off : kUpdateChunk;
-        const size_t lds = (size_t)m * (8 + 8 + 8 + 4) + (size_t)kWgUpdate * 8 + 16;
-        hipLaunchKernelGGL(k_update_wg, dim3(1), dim3(kWgUpdate), lds, st, h->tree, h->d_state, m,
+        // one thread per (index, ancestor) task where that fits: the B = 32 learner call is 640 tasks, one round at 1024 threads
+        const int threads = m * (i64)h->tree.D > kWgUpdate ? 1024 : kWgUpdate;
+        const size_t lds = (size_t)m * (8 + 8 + 8 + 4) + (size_t)threads * 8 + 16;
+        hipLaunchKernelGGL(k_update_wg, dim3(1), dim3(threads), lds, st, h->tree, h->d_state, m,
                            d_idx + off, (const void *)((const char *)d_prio + (size_t)off * eb), kind, h->epsilon,
                            h->alpha, h->d_err);
     }

@@ -354,22 +354,23 @@ __global__ void __launch_bounds__(256) k_head(const float *__restrict__ partial,
 #pragma unroll
     for (int j = 0; j < kMaxActions; j++) adv[j] = 0.f;
     for (int u = t; u < hidden; u += 256) {
-        // split sums in a fixed order with four independent chains (eight loads in flight per iteration)
-        float v4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f};
+        // split sums in a fixed order with eight independent chains (sixteen loads in flight per iteration)
+        float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float *p = partial + m * N1 + u;
         const i64 ss = M * N1;
         int s = 0;
-        for (; s + 4 <= splits; s += 4)
+        for (; s + 8 <= splits; s += 8)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                v4[q] += p[(s + q) * ss];
-                a4[q] += p[(s + q) * ss + hidden];
+            for (int q = 0; q < 8; q++) {
+                v8[q] += p[(s + q) * ss];
+                a8[q] += p[(s + q) * ss + hidden];
             }
         for (; s < splits; s++) {
-            v4[0] += p[s * ss];
-            a4[0] += p[s * ss + hidden];
+            v8[s & 7] += p[s * ss];
+            a8[s & 7] += p[s * ss + hidden];
         }
-        float hv = b1[u] + ((v4[0] + v4[1]) + (v4[2] + v4[3])), ha = b1[hidden + u] + ((a4[0] + a4[1]) + (a4[2] + a4[3]));
+        float hv = b1[u] + (((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7])));
+        float ha = b1[hidden + u] + (((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7])));
         hv = hv > 0.f ? hv : 0.f;
         ha = ha > 0.f ? ha : 0.f;
         if (h1) {  // training: the backward pass needs the hidden layer

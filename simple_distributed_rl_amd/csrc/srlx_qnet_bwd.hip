@@ -34,14 +34,16 @@ __device__ __forceinline__ float byte_to_unit(unsigned b) {  // u8 / 255, correc
 }
 
 // ---- dueling head + second dense layers (dueling_network.py:43-58) ------------------------------------------
-// one thread per hidden unit u; dq [B][A] (rows `stride` apart in nothing: dq is dense), h1 rows at i*sample_stride
+// 64 hidden units per workgroup x 4 sample slices (thread = (unit, slice); slice s takes samples s, s+4, ...): the
+// dependent chain over the batch is a quarter as long, the four partial sums are combined in slice order.
+// dq [B][A] is dense, h1 rows at i*sample_stride.
 template <int AMAX>
-__global__ void __launch_bounds__(64) k_head_bwd(int B, i64 sstride, int hidden, int A, int dueling, const float *__restrict__ dq,
-                                                  const float *__restrict__ h1, const float *__restrict__ v2w, const float *__restrict__ a2w,
-                                                  float *__restrict__ dh1, float *__restrict__ g_bf, float *__restrict__ g_v2w, float *__restrict__ g_v2b,
-                                                  float *__restrict__ g_a2w, float *__restrict__ g_a2b) {
-    extern __shared__ float sm[];  // dv[B], da[B][A]
-    float *dv = sm, *da = sm + B;
+__global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden, int A, int dueling, const float *__restrict__ dq,
+                                                   const float *__restrict__ h1, const float *__restrict__ v2w, const float *__restrict__ a2w,
+                                                   float *__restrict__ dh1, float *__restrict__ g_bf, float *__restrict__ g_v2w, float *__restrict__ g_v2b,
+                                                   float *__restrict__ g_a2w, float *__restrict__ g_a2b) {
+    extern __shared__ float sm[];  // dv[B], da[B][A], part[3 + AMAX][256]
+    float *dv = sm, *da = sm + B, *part = sm + B + B * A;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         float s = 0.f;
         for (int j = 0; j < A; j++) s += dq[b * A + j];
@@ -49,15 +51,19 @@ __global__ void __launch_bounds__(64) k_head_bwd(int B, i64 sstride, int hidden,
         for (int j = 0; j < A; j++) da[b * A + j] = dueling == 0 ? dq[b * A + j] - s / (float)A : dq[b * A + j];
     }
     __syncthreads();
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ul = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int u = blockIdx.x * 64 + ul;
     const int N1 = 2 * hidden;
-    if (u < hidden) {
-        float gv = 0.f, gbv = 0.f, gba = 0.f, ga[AMAX];
+    float gv = 0.f, gbv = 0.f, gba = 0.f, ga[AMAX];
 #pragma unroll
-        for (int j = 0; j < AMAX; j++) ga[j] = 0.f;
+    for (int j = 0; j < AMAX; j++) ga[j] = 0.f;
+    if (u < hidden) {
         const float wv = v2w[u];
+        float wa[AMAX];
+#pragma unroll
+        for (int j = 0; j < AMAX; j++) wa[j] = j < A ? a2w[j * hidden + u] : 0.f;
 #pragma unroll 8
-        for (int b = 0; b < B; b++) {
+        for (int b = slice; b < B; b += 4) {
             const float hv = h1[(i64)b * sstride * N1 + u], ha = h1[(i64)b * sstride * N1 + hidden + u];
             gv += dv[b] * hv;
             float s = 0.f;
@@ -65,7 +71,7 @@ __global__ void __launch_bounds__(64) k_head_bwd(int B, i64 sstride, int hidden,
             for (int j = 0; j < AMAX; j++)
                 if (j < A) {
                     ga[j] += da[b * A + j] * ha;
-                    s += da[b * A + j] * a2w[j * hidden + u];
+                    s += da[b * A + j] * wa[j];
                 }
             const float dhv = hv > 0.f ? dv[b] * wv : 0.f, dha = ha > 0.f ? s : 0.f;  // ReLU of the first dense layer
             dh1[(i64)b * N1 + u] = dhv;
@@ -73,12 +79,22 @@ __global__ void __launch_bounds__(64) k_head_bwd(int B, i64 sstride, int hidden,
             gbv += dhv;
             gba += dha;
         }
-        g_v2w[u] = gv;
-        g_bf[u] = gbv;
-        g_bf[hidden + u] = gba;
+    }
+    part[0 * 256 + threadIdx.x] = gv;
+    part[1 * 256 + threadIdx.x] = gbv;
+    part[2 * 256 + threadIdx.x] = gba;
+#pragma unroll
+    for (int j = 0; j < AMAX; j++)
+        if (j < A) part[(3 + j) * 256 + threadIdx.x] = ga[j];
+    __syncthreads();
+    if (slice == 0 && u < hidden) {
+        auto sum4 = [&](int row) { return ((part[row * 256 + ul] + part[row * 256 + 64 + ul]) + part[row * 256 + 128 + ul]) + part[row * 256 + 192 + ul]; };
+        g_v2w[u] = sum4(0);
+        g_bf[u] = sum4(1);
+        g_bf[hidden + u] = sum4(2);
 #pragma unroll
         for (int j = 0; j < AMAX; j++)
-            if (j < A) g_a2w[j * hidden + u] = ga[j];
+            if (j < A) g_a2w[j * hidden + u] = sum4(3 + j);
     }
     if (blockIdx.x == 0 && threadIdx.x <= A) {
         float s = 0.f;
@@ -387,13 +403,13 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     // head + second layers -> dh1 (masked by the first layer's ReLU), bias gradient of the first layer
     {
         const dim3 hg((unsigned)((h->hidden + 63) / 64));
-        const size_t hl = (size_t)(B + B * A) * sizeof(float);
+        const size_t hl = (size_t)(B + B * A + (3 + (A <= 8 ? 8 : (A <= 16 ? 16 : 32))) * 256) * sizeof(float);
         if (A <= 8)
-            hipLaunchKernelGGL(k_head_bwd<8>, hg, dim3(64), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+            hipLaunchKernelGGL(k_head_bwd<8>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
         else if (A <= 16)
-            hipLaunchKernelGGL(k_head_bwd<16>, hg, dim3(64), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+            hipLaunchKernelGGL(k_head_bwd<16>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
         else
-            hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(64), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+            hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
     }
     // Two branches from here (fork/join with events; capturable into a HIP graph): the data-gradient chain stays on the
     // caller's stream, every weight gradient runs on h->side as soon as the activation gradient it needs exists.

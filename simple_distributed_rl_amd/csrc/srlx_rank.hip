@@ -48,8 +48,9 @@ int srlx_rank_create(srlx_rank_t **out, int64_t capacity, int device) {
     memset(h, 0, sizeof(*h));
     h->device = device;
     h->capacity = capacity;
-    hipcub::DeviceRadixSort::SortPairsDescending(nullptr, h->tmp_bytes, (const float *)nullptr, (float *)nullptr, (const int *)nullptr, (int *)nullptr, (int)capacity);
-    hipError_t e = hipMalloc(&h->prio, sizeof(float) * capacity);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, h->tmp_bytes, (const float *)nullptr, (float *)nullptr, (const int *)nullptr,
+                                                                 (int *)nullptr, (int)capacity);  // size query
+    if (e == hipSuccess) e = hipMalloc(&h->prio, sizeof(float) * capacity);
     if (e == hipSuccess) e = hipMalloc(&h->keys_out, sizeof(float) * capacity);
     if (e == hipSuccess) e = hipMalloc(&h->idx_in, sizeof(int) * capacity);
     if (e == hipSuccess) e = hipMalloc(&h->idx_out, sizeof(int) * capacity);

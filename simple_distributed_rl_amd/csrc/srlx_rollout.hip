@@ -228,10 +228,8 @@ struct ItemMeta {
 };
 
 // per sampled item: locate (env, position), find the episode end inside the window, emit the scalars
-__global__ void __launch_bounds__(256) k_gather_meta(StoreDev s, i64 B, const i64 *tree_idx, ItemMeta *meta,
-                                                      int32_t *actions, float *rewards, float *terminated) {
-    const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+__device__ __forceinline__ ItemMeta item_meta(const StoreDev &s, i64 b, const i64 *tree_idx, int32_t *actions, float *rewards, float *terminated) {
+    ItemMeta out;
     const i64 N = s.E * s.item_len;
     i64 j = tree_idx[b] - (N - 1);
     if (j < 0) j = 0;
@@ -248,9 +246,10 @@ __global__ void __launch_bounds__(256) k_gather_meta(StoreDev s, i64 B, const i6
             jd = k;
             break;
         }
-    meta[b].e = e;
-    meta[b].q = q;
-    meta[b].jd = jd;
+    out.e = e;
+    out.q = q;
+    out.jd = jd;
+    out.pad = 0;
     for (int k = 0; k < s.n; k++) {
         const i64 r = base + posmod(q + k, s.L);
         if (k <= jd) {
@@ -265,6 +264,13 @@ __global__ void __launch_bounds__(256) k_gather_meta(StoreDev s, i64 B, const i6
             terminated[b * s.n + k] = 1.f;
         }
     }
+    return out;
+}
+__global__ void __launch_bounds__(256) k_gather_meta(StoreDev s, i64 B, const i64 *tree_idx, ItemMeta *meta,
+                                                      int32_t *actions, float *rewards, float *terminated) {
+    const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    meta[b] = item_meta(s, b, tree_idx, actions, rewards, terminated);
 }
 
 __global__ void __launch_bounds__(256) k_gather_obs_u8(StoreDev s, const ItemMeta *meta, float *out) {
@@ -334,6 +340,31 @@ __global__ void __launch_bounds__(256) k_frame_table_items(StoreDev s, i64 B, co
     out[t] = frame_offset(s, m.e, m.q + kk, c);
 }
 
+// the learner's whole "gather" in one launch: item location + n-step scalars (k_gather_meta) and both offset tables
+// (s_0..s_n for the online network, s_1..s_n for the target network); 64 items per workgroup, their metadata in LDS
+constexpr int kTrainItems = 64;
+__global__ void __launch_bounds__(256) k_gather_train(StoreDev s, i64 B, const i64 *tree_idx, ItemMeta *meta, int32_t *actions, float *rewards,
+                                                       float *terminated, i64 *off_all, i64 *off_next) {
+    __shared__ ItemMeta sm[kTrainItems];
+    const int t = threadIdx.x;
+    const i64 b0 = (i64)blockIdx.x * kTrainItems;
+    const int cnt = (int)(B - b0 < kTrainItems ? B - b0 : kTrainItems);
+    if (t < cnt) {
+        sm[t] = item_meta(s, b0 + t, tree_idx, actions, rewards, terminated);
+        meta[b0 + t] = sm[t];
+    }
+    __syncthreads();
+    const int S = s.n + 1, W = s.W;
+    for (int x = t; x < cnt * S * W; x += 256) {
+        const int c = x % W, k = (x / W) % S, bl = x / (W * S);
+        const ItemMeta m = sm[bl];
+        const int kk = k < m.jd + 1 ? k : m.jd + 1;  // states after the terminal one repeat it (rainbow.py:358)
+        const i64 off = frame_offset(s, m.e, m.q + kk, c);
+        off_all[((b0 + bl) * S + k) * W + c] = off;
+        if (off_next && k >= 1) off_next[((b0 + bl) * s.n + (k - 1)) * W + c] = off;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // epsilon-greedy (rainbow.py:301-329)
 // ------------------------------------------------------------------------------------------
@@ -378,6 +409,13 @@ __global__ void __launch_bounds__(256) k_rng_uniform(u64 seed, const i64 *counte
     const u64 c = (u64)counter[0];
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
         out[i] = u53(rng_u64(seed, c, (u64)i));
+}
+// same values from a single workgroup that also advances the counter (every thread has read it before the barrier)
+__global__ void __launch_bounds__(1024) k_rng_uniform_wg(u64 seed, i64 *counter, i64 n, double *out) {
+    const u64 c = (u64)counter[0];
+    for (i64 i = threadIdx.x; i < n; i += blockDim.x) out[i] = u53(rng_u64(seed, c, (u64)i));
+    __syncthreads();
+    if (threadIdx.x == 0) counter[0] = (i64)c + 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -601,6 +639,11 @@ int srlx_policy_epsilon_greedy(int64_t n_envs, int n_actions, const float *d_q, 
 
 int srlx_rng_uniform(uint64_t seed, int64_t *d_counter, int64_t n, double *d_out, void *stream) {
     SRLX_REQUIRE(d_counter && d_out && n > 0, "rng_uniform: bad argument");
+    if (n <= 8192) {  // the per-step calls (B + slack, 2 E uniforms): one workgroup draws and advances the counter itself
+        hipLaunchKernelGGL(k_rng_uniform_wg, dim3(1), dim3(1024), 0, (hipStream_t)stream, (u64)seed, d_counter, (i64)n, d_out);
+        SRLX_HIP(hipGetLastError());
+        return SRLX_OK;
+    }
     hipLaunchKernelGGL(k_rng_uniform, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (u64)seed, d_counter, (i64)n, d_out);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, d_counter);
     SRLX_HIP(hipGetLastError());
@@ -653,6 +696,21 @@ int srlx_store_gather_items(srlx_store_t *h, int64_t batch, const int64_t *d_tre
     const i64 n = batch * k_count * h->d.W;
     hipLaunchKernelGGL(k_frame_table_items, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d, (i64)batch, meta, k_begin, k_count,
                        (i64 *)d_frame_off);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_gather_train(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int64_t *d_frame_off_all, int64_t *d_frame_off_next,
+                            int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream) {
+    SRLX_REQUIRE(h && d_tree_idx && d_frame_off_all && d_actions && d_rewards && d_terminated, "store_gather_train: NULL argument");
+    SRLX_REQUIRE(batch > 0, "store_gather_train: empty batch");
+    SRLX_REQUIRE(h->d.obs_dtype == SRLX_OBS_U8, "store_gather_train: uint8 stores only");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick(h, stream);
+    SRLX_TRY(h->scratch.reserve((size_t)batch * sizeof(ItemMeta)));
+    ItemMeta *meta = (ItemMeta *)h->scratch.ptr;
+    hipLaunchKernelGGL(k_gather_train, dim3((unsigned)((batch + kTrainItems - 1) / kTrainItems)), dim3(256), 0, st, h->d, (i64)batch, d_tree_idx, meta,
+                       d_actions, d_rewards, d_terminated, (i64 *)d_frame_off_all, (i64 *)d_frame_off_next);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

@@ -57,6 +57,7 @@ struct TdArgs {
     double discount, retrace_h;
     int double_dqn, rescale;
     float *target, *loss, *grad_q0, *priorities;
+    i64 on_next_stride, on_0_stride;  // floats between consecutive items (dense: n*A and A; packed [B][n+1][A]: (n+1)*A for both)
 };
 
 __global__ void __launch_bounds__(256) k_nstep_td_huber_priority(TdArgs a) {
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(256) k_nstep_td_huber_priority(TdArgs a) {
     const float disc_f = (float)a.discount;
     double loss_acc = 0.0;
     for (i64 b = t; b < a.B; b += T) {
-        const float *qon = a.q_on_next + b * n * A;
+        const float *qon = a.q_on_next + b * a.on_next_stride;
         const float *qtg = a.q_tg_next + b * n * A;
         const int32_t *act = a.actions + b * n;
         const u8 *inv = a.invalid_next ? a.invalid_next + b * n * A : nullptr;
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256) k_nstep_td_huber_priority(TdArgs a) {
 
         // model_torch.py:103-105,113
         const int a0 = act[0];
-        const float q0 = a.q_on_0[b * A + a0];
+        const float q0 = a.q_on_0[b * a.on_0_stride + a0];
         const float w = a.weights[b];
         const float tw = target * w, qw = q0 * w;
         const float diff = tw - qw;
@@ -281,7 +282,24 @@ int srlx_nstep_td_huber_priority(int64_t batch, int n_step, int n_actions, const
     SRLX_REQUIRE(d_target && d_loss && d_grad_q0 && d_priorities, "nstep_td: NULL output");
     TdArgs a{batch, n_step, n_actions, d_q_on_next, d_q_tg_next, d_q_on_0, d_actions, d_rewards, d_terminated,
              d_invalid_next, d_weights, discount, retrace_h, enable_double_dqn, enable_rescale, d_target, d_loss,
-             d_grad_q0, d_priorities};
+             d_grad_q0, d_priorities, (i64)n_step * n_actions, (i64)n_actions};
+    hipLaunchKernelGGL(k_nstep_td_huber_priority, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_nstep_td_huber_priority_packed(int64_t batch, int n_step, int n_actions, const float *d_q_on_all, const float *d_q_tg_next,
+                                        const int32_t *d_actions, const float *d_rewards, const float *d_terminated,
+                                        const uint8_t *d_invalid_next, const float *d_weights, double discount, double retrace_h,
+                                        int enable_double_dqn, int enable_rescale, float *d_target, float *d_loss, float *d_grad_q0,
+                                        float *d_priorities, void *stream) {
+    SRLX_REQUIRE(batch > 0 && n_step >= 1 && n_step <= kMaxStep && n_actions >= 1, "nstep_td_packed: bad sizes (n_step <= %d)", kMaxStep);
+    SRLX_REQUIRE(d_q_on_all && d_q_tg_next && d_actions && d_rewards && d_terminated && d_weights, "nstep_td_packed: NULL input");
+    SRLX_REQUIRE(d_target && d_loss && d_grad_q0 && d_priorities, "nstep_td_packed: NULL output");
+    const i64 row = (i64)(n_step + 1) * n_actions;
+    TdArgs a{batch, n_step, n_actions, d_q_on_all + n_actions, d_q_tg_next, d_q_on_all, d_actions, d_rewards, d_terminated,
+             d_invalid_next, d_weights, discount, retrace_h, enable_double_dqn, enable_rescale, d_target, d_loss,
+             d_grad_q0, d_priorities, row, row};
     hipLaunchKernelGGL(k_nstep_td_huber_priority, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

@@ -292,8 +292,14 @@ class RainbowEngine:
                 self._ev_t1.record(self.s_target)
             q_all = self.inf_online.forward_u8(r.obs_base, r.frame_off_all.view(B * (n + 1), cfg.window_length)).view(B, n + 1, cfg.n_actions)
             cur.wait_event(self._ev_t1)  # join before the TD kernel
-            q_on_next = q_all[:, 1:].contiguous()  # rainbow.py:220
-            q0 = q_all[:, 0].contiguous()  # model_torch.py:103
+            # rainbow.py:220 + model_torch.py:103: the TD kernel reads s_0 and s_1..s_n rows straight out of the one forward
+            N.check(
+                self.lib.srlx_nstep_td_huber_priority_packed(
+                    B, n, cfg.n_actions, N.tptr(q_all), N.tptr(q_tg_next), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), None,
+                    N.tptr(b.weights), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
+                    N.tptr(self.target), N.tptr(self.loss), N.tptr(self.grad_q0), N.tptr(self.priorities), N.torch_stream_ptr(),
+                )
+            )
         elif self.mfma:
             b = r.sample_items(self.train_count_dev)
             foff = r.frame_off_next.view(B * n, cfg.window_length)
@@ -308,13 +314,14 @@ class RainbowEngine:
                 q_on_next = self.q_online(nxt, channels_first=True)  # rainbow.py:220
                 q_tg_next = self.q_target(nxt, channels_first=True)  # rainbow.py:221
             q0 = self.q_online(obs[:, 0], channels_first=True)  # model_torch.py:103
-        N.check(
-            self.lib.srlx_nstep_td_huber_priority(
-                B, n, cfg.n_actions, N.tptr(q_on_next), N.tptr(q_tg_next), N.tptr(q0), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated),
-                None, N.tptr(b.weights), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
-                N.tptr(self.target), N.tptr(self.loss), N.tptr(self.grad_q0), N.tptr(self.priorities), N.torch_stream_ptr(),
+        if not self.mfma_train:
+            N.check(
+                self.lib.srlx_nstep_td_huber_priority(
+                    B, n, cfg.n_actions, N.tptr(q_on_next), N.tptr(q_tg_next), N.tptr(q0), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated),
+                    None, N.tptr(b.weights), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
+                    N.tptr(self.target), N.tptr(self.loss), N.tptr(self.grad_q0), N.tptr(self.priorities), N.torch_stream_ptr(),
+                )
             )
-        )
         if self.mfma_train:  # model_torch.py:107-109 without autograd: every p.grad is (over)written by the backward kernels
             self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
             self.optimizer.step(self.train_count_dev)

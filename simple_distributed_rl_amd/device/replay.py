@@ -180,18 +180,19 @@ class DeviceReplay:
                 self.h_per, self.B, 0, N.tptr(d_step), N.tptr(uniforms), uniforms.numel(), N.tptr(b.indices), None, N.tptr(b.weights), N.tptr(self.used), 1, st
             )
         )
-        N.check(
-            self.lib.srlx_store_gather_items(
-                self.h_store, self.B, N.tptr(b.indices), 1, self.n, N.tptr(self.frame_off_next), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
-            )
-        )
-        if all_states:
+        if all_states:  # item location, n-step scalars and both offset tables (s_0..s_n, s_1..s_n) in one launch
             N.check(
-                self.lib.srlx_store_gather_items(
-                    self.h_store, self.B, N.tptr(b.indices), 0, self.n + 1, N.tptr(self.frame_off_all), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
+                self.lib.srlx_store_gather_train(
+                    self.h_store, self.B, N.tptr(b.indices), N.tptr(self.frame_off_all), N.tptr(self.frame_off_next), N.tptr(b.actions), N.tptr(b.rewards),
+                    N.tptr(b.terminated), st
                 )
             )
         else:
+            N.check(
+                self.lib.srlx_store_gather_items(
+                    self.h_store, self.B, N.tptr(b.indices), 1, self.n, N.tptr(self.frame_off_next), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
+                )
+            )
             N.check(self.lib.srlx_store_gather_obs(self.h_store, self.B, 0, 1, N.tptr(self.obs0), st))
         return b
 

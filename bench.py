@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--per-micro", action="store_true", help="also time the bulk PER sample kernel (extra field)")
     ap.add_argument("--learner-acts", choices=("auto", "yes", "no"), default="auto",
                     help="N>1: does the learner rank run actors too? auto = yes below 4 GPUs, no (dedicated learner GPU) from 4")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--dist-selftest", action="store_true", help="run the N>1 code path (DistributedRainbow, RCCL gathers/broadcasts) at world size 1")
     return ap.parse_args()
 
@@ -56,14 +57,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    dev_index = local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank  # rehearsal: ranks may share a GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
     if world > 1 or args.dist_selftest:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         dist = None
 
@@ -74,10 +79,10 @@ def main():
     if dist is not None:
         from simple_distributed_rl_amd.device.dist import DistributedRainbow
 
-        eng = DistributedRainbow(cfg, local_rank, args.episode_len, sync_interval=args.sync_interval, always_collective=args.dist_selftest,
+        eng = DistributedRainbow(cfg, dev_index, args.episode_len, sync_interval=args.sync_interval, always_collective=args.dist_selftest,
                                  learner_acts={"auto": None, "yes": True, "no": False}[args.learner_acts])
     else:
-        eng = RainbowEngine(cfg, local_rank, args.episode_len, overlap=not args.no_overlap)
+        eng = RainbowEngine(cfg, dev_index, args.episode_len, overlap=not args.no_overlap)
     is_learner = rank == 0
 
     # ---- fill the replay (untimed): random-policy rollout until the ring is full, then |delta| ~ U(0,1)
@@ -104,13 +109,13 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     ev_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     if dist is not None:  # a learner-only rank 0 runs no actor pass: report the slowest actor rank's
-        t = torch.tensor([ev_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([ev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ev_ms = float(t.item())
 

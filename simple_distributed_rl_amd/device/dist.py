@@ -241,9 +241,10 @@ class DistributedRainbow:
             if overlapped:
                 main.wait_event(eng._ev_join)  # the commit below is the first write to the global replay
             self.replay.commit(*self._actor_rows(gathered))
-            if overlapped and self.acts:
-                with torch.no_grad():
-                    torch._foreach_copy_(list(eng.q_actor.parameters()), list(eng.q_online.parameters()))
+            if overlapped:
+                if self.acts:  # refresh the local actors' copy of the online network
+                    with torch.no_grad():
+                        torch._foreach_copy_(list(eng.q_actor.parameters()), list(eng.q_online.parameters()))
             else:
                 for _ in range(learner_updates):
                     self._with_global_replay(eng.learner_step)

@@ -90,6 +90,7 @@ def test_distributed_rainbow_dedicated_learner_rank():
     assert r0["memory"] == 12 * 16 and r0["per"]["size"] == 12 * 16
     assert r0["train_count"] > 0 and r0["loss"] == r0["loss"]
     assert r0["env_steps_local"] == 0 and r1["env_steps_local"] > 0
+    assert r0["train_count"] <= 2 * 12 + 1  # learner_updates=2 per step (+1 for the graph capture), not twice that
     assert r0["flat_sum"] == r1["flat_sum"] and r0["flat_abs"] == r1["flat_abs"]
 
 
@@ -135,3 +136,25 @@ def test_rccl_transport_calls_at_world_size_one():
     ret = mgr.dict()
     mp.spawn(_rccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
     assert ret[0] == {"push_ok": True, "bcast_ok": True, "max": 1.25, "n": 7, "backend": "nccl"}
+
+
+@pytest.mark.parametrize("n,actor_gpus", [(2, 2), (4, 3)])
+def test_bench_multi_rank_rehearsal(n, actor_gpus):
+    """`bench.py --gpus N` under the driver's launcher with N ranks sharing the test GPU (`--backend gloo`): the whole N>1
+    bench path -- rendezvous, prefill, warm-up, graph capture, timed loop, barriers, MAX all-reduces, the JSON line and its
+    env-step accounting for both topologies (2: rank 0 acts and learns; 4: dedicated learner rank) -- minus the RCCL transport."""
+    import json
+    import subprocess
+
+    steps, warmup = 12, 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--steps", str(steps), "--warmup", str(warmup), "--envs", "128",
+           "--capacity", "100000", "--batch-size", "16"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["config"]["actor_gpus"] == actor_gpus and d["scaling"] == "weak"
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 128 * actor_gpus) < 1e-6 * 128 * actor_gpus  # value = all actor ranks' env-steps / time
+    assert d["final"]["train_count"] == steps + warmup + 1  # one update per step (+1: graph capture), on either topology
+    assert "cpu_baseline" not in d and d["roofline"]["avg_launch_group_ms"] > 0

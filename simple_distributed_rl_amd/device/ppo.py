@@ -215,10 +215,10 @@ class PPOEngine:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
             self.rollout()
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
             self.update()
             self.b_obs[0].copy_(self.b_obs[self.cfg.horizon])
         self._rollout_graph, self._update_graph = g1, g2

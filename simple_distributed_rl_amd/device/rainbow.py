@@ -418,23 +418,23 @@ class RainbowEngine:
             if self.mfma:
                 q = self._actor_net(None)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
                     self._actor_select(q)
                 self._select_graph = g
             else:
                 obs = self._actor_stack()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
                     self._actor_front(obs)
                 self._front_graph = g
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
                 self._actor_commit()
             self.replay._steps_committed -= 1  # capture does not execute
             self._commit_graph = g
         if learner and not self.replay.is_warmup_needed():
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
                 self._learner_body()
             self._learner_graph = g
         torch.cuda.synchronize(self.dev)

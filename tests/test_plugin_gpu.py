@@ -102,3 +102,25 @@ def test_trainer_refuses_cpu():
     runner.set_device("CPU")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         runner.train(max_steps=10)
+
+
+def test_dqn_cartpole_config_runs_and_learns():
+    """BASELINE.json configs[1]: DQN on CartPole-v1, uniform replay 1e5, batch 32, one GPU, through srl.Runner.
+    Plumbing (environment -> WorkerRun -> uniform ReplayBuffer -> device trainer -> evaluate) plus a learning signal:
+    a random policy balances the pole for ~22 steps."""
+    from simple_distributed_rl_amd.algorithms import dqn
+
+    from simple_distributed_rl_amd.utils.common import set_seed
+
+    set_seed(3, enable_gpu=True)
+    rl = dqn.Config(batch_size=32, lr=0.001, target_model_update_interval=200, discount=0.99)
+    rl.memory.set_replay_buffer()
+    rl.memory.capacity, rl.memory.warmup_size = 100_000, 500
+    rl.epsilon_scheduler.set_linear(1.0, 0.05, 3000)
+    rl.hidden_block.set((64, 64))
+    runner = srl.Runner("CartPole-v1", rl)
+    runner.set_device("cuda:0")
+    runner.train(max_train_count=6000, enable_progress=False)
+    assert runner.trainer.train_count >= 6000 and runner.memory.length() >= 6000
+    rewards = runner.evaluate(max_episodes=10, enable_progress=False)
+    assert len(rewards) == 10 and np.mean(rewards) > 60, rewards

@@ -457,3 +457,38 @@ def gen_rankbased():
 
 
 AGENT57_GENERATORS.update(rankbased=gen_rankbased)
+
+
+# ----------------------------------------------------------------------------------------
+# rank-based linear memory (srl/rl/memories/priority_memories/rankbased_memory_linear.py) scripted trace
+# ----------------------------------------------------------------------------------------
+def gen_rankbased_linear():
+    import random
+
+    from srl.rl.memories.priority_memories.rankbased_memory_linear import RankBasedMemoryLinear
+
+    rng = np.random.default_rng(77)
+    cap, alpha = 200, 0.8
+    mem = RankBasedMemoryLinear(cap, alpha, 0.4, 1000)
+    random.seed(321)
+    adds = rng.permutation(4000)[:420].astype(np.float64) / 9  # distinct priorities; more adds than capacity: the lowest ones drop out
+    ops, k = [], 0
+    for rnd in range(10):
+        n_add = 90 if rnd < 3 else 15
+        for _ in range(n_add):
+            mem.add(int(k), float(adds[k]))
+            k += 1
+        B = 12
+        batches, weights, upd = mem.sample(B, 120 * rnd)
+        new_p = (rng.permutation(9000)[:B].astype(np.float64) + 5000) / 11  # distinct from everything stored
+        mem.update(upd, new_p)
+        ops.append((n_add, np.asarray(batches), np.asarray(weights), new_p, mem.length()))
+    np.savez_compressed(os.path.join(OUT, "rankbased_linear_trace.npz"), capacity=np.int64(cap), alpha=np.float64(alpha), beta_initial=np.float64(0.4),
+                        beta_steps=np.int64(1000), seed=np.int64(321), add_priorities=adds[:k], n_add=np.array([o[0] for o in ops]),
+                        batches=np.array([o[1] for o in ops]), weights=np.array([o[2] for o in ops]), new_priorities=np.array([o[3] for o in ops]),
+                        lengths=np.array([o[4] for o in ops]), final_keys=np.array([m[0] for m in mem.memory]), final_items=np.array([m[1] for m in mem.memory]),
+                        max_priority=np.float64(mem.max_priority))
+    print(f"rankbased_linear_trace: {k} adds, 10 samples of 12")
+
+
+AGENT57_GENERATORS.update(rankbased_linear=gen_rankbased_linear)

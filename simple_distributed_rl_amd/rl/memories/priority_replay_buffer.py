@@ -50,6 +50,11 @@ class PriorityReplayBufferConfig:
         self.kwargs = dict(alpha=alpha, beta_initial=beta_initial, beta_steps=beta_steps, device=device)
         return self
 
+    def set_rankbased_linear(self, alpha: float = 0.6, beta_initial: float = 0.4, beta_steps: int = 1_000_000):
+        self.name = "RankBasedLinear"
+        self.kwargs = dict(alpha=alpha, beta_initial=beta_initial, beta_steps=beta_steps)
+        return self
+
     def set_custom(self, entry_point: str, kwargs: dict):
         self.name = "custom"
         self.kwargs = dict(entry_point=entry_point, kwargs=kwargs)
@@ -68,11 +73,15 @@ class PriorityReplayBufferConfig:
             from .priority_memories.rankbased_memory import RankBasedMemory
 
             return RankBasedMemory(capacity, **self.kwargs)
+        if self.name == "RankBasedLinear":
+            from .priority_memories.rankbased_memory_linear import RankBasedMemoryLinear
+
+            return RankBasedMemoryLinear(capacity, **self.kwargs)
         if self.name == "custom":
             from simple_distributed_rl_amd.utils.common import load_module
 
             return load_module(self.kwargs["entry_point"])(capacity, **self.kwargs["kwargs"])
-        raise UndefinedError(self.name)  # RankBasedLinear (a host-side sorted list, no device work) is not built
+        raise UndefinedError(self.name)
 
     def requires_priority(self) -> bool:
         return self.name in ("Proportional", "Proportional_cpp", "RankBased", "RankBasedLinear")

@@ -326,3 +326,35 @@ def test_train_mp_ql_two_actors():
     assert st.train_count >= 3000 and st.end_reason == "max_train_count over."
     assert st.trainer_recv_q > 0 and st.sync_trainer >= 0
     assert len(runner.parameter.Q) > 3
+
+
+def test_rankbased_linear_memory_matches_reference_trace():
+    """RankBasedMemoryLinear (rankbased_memory_linear.py:26-113; host-side, no device work) replayed on the trace recorded from
+    the imported reference under the same `random` seed: sampled items, weights, lengths and the final sorted memory equal."""
+    import random
+
+    from simple_distributed_rl_amd.rl.memories.priority_replay_buffer import PriorityReplayBufferConfig
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rankbased_linear_trace.npz"))
+    cfg = PriorityReplayBufferConfig()
+    cfg.set_rankbased_linear(alpha=float(z["alpha"]), beta_initial=float(z["beta_initial"]), beta_steps=int(z["beta_steps"]))
+    mem = cfg.create_memory(int(z["capacity"]))
+    assert type(mem).__name__ == "RankBasedMemoryLinear" and cfg.requires_priority()
+    random.seed(int(z["seed"]))
+    k = 0
+    for rnd in range(len(z["n_add"])):
+        for _ in range(int(z["n_add"][rnd])):
+            mem.add(int(k), float(z["add_priorities"][k]))
+            k += 1
+        batches, weights, upd = mem.sample(12, 120 * rnd)
+        np.testing.assert_array_equal(np.asarray(batches), z["batches"][rnd])
+        np.testing.assert_array_equal(np.asarray(weights), z["weights"][rnd])
+        mem.update(upd, z["new_priorities"][rnd])
+        assert mem.length() == int(z["lengths"][rnd])
+    np.testing.assert_array_equal(np.asarray(mem.keys), z["final_keys"])
+    np.testing.assert_array_equal(np.asarray(mem.items), z["final_items"])
+    assert mem.max_priority == float(z["max_priority"])
+    b = mem.backup()
+    m2 = cfg.create_memory(int(z["capacity"]))
+    m2.restore(b)
+    assert m2.keys == mem.keys and m2.items == mem.items and m2.max_priority == mem.max_priority

@@ -492,3 +492,40 @@ def gen_rankbased_linear():
 
 
 AGENT57_GENERATORS.update(rankbased_linear=gen_rankbased_linear)
+
+
+# ----------------------------------------------------------------------------------------
+# episode replay buffer (srl/rl/memories/episode_replay_buffer.py) scripted trace
+# ----------------------------------------------------------------------------------------
+def gen_episode_buffer():
+    import random
+
+    from srl.rl.memories.episode_replay_buffer import EpisodeReplayBuffer
+
+    rng = np.random.default_rng(12)
+    kw = dict(batch_size=4, capacity=120, warmup_size=20, compress=True, prefix_size=2, suffix_size=1, skip_head=1, skip_tail=1, sequential_stride=2)
+    mem = EpisodeReplayBuffer(**kw)
+    random.seed(99)
+    lengths = rng.integers(5, 30, size=14)
+    out_sample, out_seq, out_steps, out_len = [], [], [], []
+    step_id = 0
+    for ep, L in enumerate(lengths):
+        steps = [[int(step_id + t), int(ep)] for t in range(int(L))]
+        step_id += int(L)
+        if ep % 2 == 0:
+            mem.add(steps)
+        else:
+            mem.add(*mem.serialize(steps), serialized=True)
+        out_len.append(mem.length())
+        if ep >= 3:
+            b = mem.sample()
+            out_sample.append(np.asarray(b)[..., 0])
+            s = mem.sample_sequential(dummy_step=[-1, -1])
+            out_seq.append(np.asarray(s)[..., 0])
+            out_steps.append(np.asarray(mem.sample_steps())[:, 0][:5])
+    np.savez_compressed(os.path.join(OUT, "episode_buffer_trace.npz"), seed=np.int64(99), lengths=lengths, total=np.array(out_len), sample=np.array(out_sample),
+                        sequential=np.array(out_seq), steps_head=np.array(out_steps), **{k: np.int64(v) for k, v in kw.items()})
+    print(f"episode_buffer_trace: {len(lengths)} episodes")
+
+
+AGENT57_GENERATORS.update(episode_buffer=gen_episode_buffer)

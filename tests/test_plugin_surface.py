@@ -358,3 +358,34 @@ def test_rankbased_linear_memory_matches_reference_trace():
     m2 = cfg.create_memory(int(z["capacity"]))
     m2.restore(b)
     assert m2.keys == mem.keys and m2.items == mem.items and m2.max_priority == mem.max_priority
+
+
+def test_episode_replay_buffer_matches_reference_trace():
+    """EpisodeReplayBuffer (episode_replay_buffer.py:10-191) on a trace recorded from the imported reference: capacity accounting
+    in sampleable window starts, compressed and pre-serialized adds, `sample`, `sample_sequential` (with the de-phasing dummy
+    steps) and `sample_steps` draw the same windows under the same `random` seed."""
+    import random
+
+    from simple_distributed_rl_amd.rl.memories.episode_replay_buffer import EpisodeReplayBuffer
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "episode_buffer_trace.npz"))
+    kw = {k: int(z[k]) for k in ("batch_size", "capacity", "warmup_size", "prefix_size", "suffix_size", "skip_head", "skip_tail", "sequential_stride")}
+    mem = EpisodeReplayBuffer(compress=bool(z["compress"]), **kw)
+    random.seed(int(z["seed"]))
+    step_id, r = 0, 0
+    for ep, L in enumerate(z["lengths"]):
+        steps = [[int(step_id + t), int(ep)] for t in range(int(L))]
+        step_id += int(L)
+        if ep % 2 == 0:
+            mem.add(steps)
+        else:
+            mem.add(*mem.serialize(steps), serialized=True)
+        assert mem.length() == int(z["total"][ep])
+        if ep >= 3:
+            np.testing.assert_array_equal(np.asarray(mem.sample())[..., 0], z["sample"][r])
+            np.testing.assert_array_equal(np.asarray(mem.sample_sequential(dummy_step=[-1, -1]))[..., 0], z["sequential"][r])
+            np.testing.assert_array_equal(np.asarray(mem.sample_steps())[:, 0][:5], z["steps_head"][r])
+            r += 1
+    m2 = EpisodeReplayBuffer(compress=bool(z["compress"]), **kw)
+    m2.call_restore(mem.call_backup())
+    assert m2.length() == mem.length() and len(m2.buffer) == len(mem.buffer)

@@ -21,6 +21,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# two HIP hardware queues (see simple_distributed_rl_amd/_native.py): must be in the environment before the runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
@@ -156,6 +158,7 @@ def main():
             "hip_graphs": not args.no_graph,
             "qnet": ("libsrlx: fp32 MFMA forward, hand-written backward (no autograd)" if getattr(eng, "mfma_train", False) else "libsrlx fp32 MFMA forward, torch autograd backward") if eng.mfma else "torch",
             "actor_learner_overlap": (not args.no_overlap) if dist is None else True,
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "topology": "1 GPU: actor+learner" if dist is None else (f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast" if eng.learner_acts
                          else f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology), RCCL gather/broadcast"),
             "actor_gpus": actor_gpus,

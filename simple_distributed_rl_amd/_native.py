@@ -10,6 +10,13 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrlx.so")
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The engines synchronise their few streams with
+# events many times per step, and an event wait that crosses hardware queues costs tens of microseconds: with 3+ queues the
+# placement of the learner's streams decides between a 0.5 ms and a 1.4 ms update.  Two queues keep
+# actors and learner concurrent and make the placement irrelevant.  Read by the runtime when it initialises, so it is set
+# before the first device call of the process (setdefault: an explicit choice of the user wins).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNIFORMS_EXHAUSTED, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 PRIO_NONE, PRIO_F64, PRIO_F32, PRIO_RAW = 0, 1, 2, 3

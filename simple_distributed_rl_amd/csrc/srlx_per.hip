@@ -131,28 +131,10 @@ __device__ __forceinline__ double load_prio(const void *prio, int kind, i64 i, d
 }
 
 // ------------------------------------------------------------------------------------------
-// descent: proportional_memory.py:56-66 (_retrieve) + :88-92 (get), one pair load per level
-// (three consecutive levels hit the same 128-byte line)
+// descent: proportional_memory.py:56-66 (_retrieve) + :88-92 (get).  Defined next to the bulk walkers below: the same
+// block-wise walk, seven dependent half-line fetches per draw instead of twenty dependent pair loads.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void descend(const Tree &tr, double val, i64 &out_idx, double &out_p) {
-    i64 idx = 0;
-    double p = tr.len == 1 ? tr.T[kRootSlot] : 0.0;
-    for (;;) {
-        const i64 left = 2 * idx + 1;
-        if (left >= tr.len) break;
-        const double2 v = tr.pair(left);
-        if (val <= v.x) {
-            idx = left;
-            p = v.x;
-        } else {
-            val -= v.x;
-            idx = left + 1;
-            p = v.y;
-        }
-    }
-    out_idx = idx;
-    out_p = p;
-}
+__device__ void descend(const Tree &tr, double val, i64 &out_idx, double &out_p);
 
 __device__ __forceinline__ double beta_of(double beta_initial, double beta_steps, i64 step) {
     // proportional_memory.py:138-140
@@ -367,6 +349,34 @@ __device__ __forceinline__ void walk_block_regs(const double (&L)[8], i64 blockp
     w.val = go ? w.val : w.val - l;
     w.idx = left + (go ? 0 : 1);
     w.pl = l; w.wl = go; w.rpos = blockpos + 11 + s2;
+}
+
+// one draw of the small (single-workgroup) sampler: block by block out of memory
+__device__ void descend(const Tree &tr, double val, i64 &out_idx, double &out_p) {
+    Draw w;
+    w.idx = 0;
+    w.val = val;
+    w.pl = tr.T[kRootSlot];
+    w.wl = true;
+    w.rpos = 0;
+    w.live = tr.len > 1;
+    int level = 0;
+    for (int g = 0; g <= tr.G && w.live; g++) {
+        const int levels = g == 0 ? tr.h0 : 3;
+        const i64 bp = tr.block_of_owner(w.idx, level) * 16;
+        const double2 *src = reinterpret_cast<const double2 *>(tr.T + bp);
+        double L[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double2 v = src[k];
+            L[2 * k] = v.x;
+            L[2 * k + 1] = v.y;
+        }
+        walk_block_regs(L, bp, levels, tr.len, w);
+        level += levels;
+    }
+    out_idx = w.idx;
+    out_p = w.wl ? w.pl : tr.T[w.rpos];
 }
 
 // the same walk out of a block staged in LDS: one dependent 8-byte read per level

@@ -192,3 +192,24 @@ def test_ppo_plugin_loss_matches_oracle_and_cartpole_learns():
     runner.train(max_train_count=1200, enable_progress=False)
     rewards = runner.evaluate(max_episodes=10, enable_progress=False)
     assert np.mean(rewards) > 60, rewards
+
+
+def test_train_mp_dqn_cartpole_on_gpu():
+    """Runner.train_mp (play_mp.py:471-642) with the device trainer: two actor processes and the learner share the GPU, items
+    cross the serialising queue, parameters flow back through the board, and the result plays CartPole far better than random."""
+    from simple_distributed_rl_amd.algorithms import dqn
+    from simple_distributed_rl_amd.utils.common import set_seed
+
+    set_seed(3, enable_gpu=True)
+    rl = dqn.Config(batch_size=32, lr=0.001, target_model_update_interval=200, discount=0.99)
+    rl.memory.set_replay_buffer()
+    rl.memory.capacity, rl.memory.warmup_size = 100_000, 500
+    rl.epsilon_scheduler.set_linear(1.0, 0.05, 3000)
+    rl.hidden_block.set((64, 64))
+    runner = srl.Runner("CartPole-v1", rl)
+    runner.set_device("cuda:0")
+    st = runner.train_mp(actor_num=2, max_train_count=4000, timeout=240, trainer_parameter_send_interval=0.5, actor_parameter_sync_interval=0.5,
+                         enable_progress=False)
+    assert st.train_count >= 4000 and st.end_reason == "max_train_count over." and st.trainer_recv_q > 4000
+    rewards = runner.evaluate(max_episodes=10, enable_progress=False)
+    assert np.mean(rewards) > 50, rewards

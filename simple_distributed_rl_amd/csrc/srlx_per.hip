@@ -186,11 +186,6 @@ __device__ __forceinline__ int block_exscan(int v, int *buf, int *total) {
     return incl - v;
 }
 
-struct Cand {  // bulk paths: leaf reached by a draw and its un-normalised IS weight (0 = zero-priority leaf, rejected), one 16-byte store
-    i64 idx;
-    double w;
-};
-
 struct SampleArgs {
     Tree tr;
     const PerState *state;
@@ -204,7 +199,6 @@ struct SampleArgs {
     // scratch
     i64 *cand_idx;
     double *cand_p;
-    Cand *cand;
     i64 *map;
     double *wtmp;
     // outputs
@@ -526,10 +520,10 @@ __global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int 
             if (j >= M) continue;
             const double p = w[d].wl ? w[d].pl : pr[d];
             const double wi = p == 0.0 ? 0.0 : is_weight_call(size, p, total, beta);  // :163-164, computed once per draw
-            Cand c;
-            c.idx = w[d].idx;
-            c.w = wi;
-            a.cand[j] = c;
+            // scratch for the rejecting path (struct of arrays) + the speculative output: with nothing rejected draw j IS output j
+            a.cand_idx[j] = w[d].idx;
+            a.cand_p[j] = wi;
+            if (j < B) a.out_idx[j] = w[d].idx;
             if (p == 0.0) {
                 zeros++;
             } else if (j < B) {  // fast path: with no rejection output i is draw i
@@ -564,9 +558,7 @@ __global__ void __launch_bounds__(256) k_finish_fast(SampleArgs a, u64 *counters
     if (counters[0] != 0 || a.n_uniforms < a.batch) return;
     const double wmax = __longlong_as_double((long long)counters[1]);
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < a.batch; i += (i64)gridDim.x * blockDim.x) {
-        const Cand c = a.cand[i];
-        const double w = c.w / wmax;  // :167
-        a.out_idx[i] = c.idx;
+        const double w = a.cand_p[i] / wmax;  // :167 (the index was written by the walk)
         if (a.out_w) a.out_w[i] = w;
         if (a.out_w32) a.out_w32[i] = (float)w;
     }
@@ -599,7 +591,7 @@ __global__ void __launch_bounds__(kTileThreads) k_compact_bulk(SampleArgs a, u64
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < kTilePer; k++) {
-        w[k] = j0 + k < M ? a.cand[j0 + k].w : 0.0;
+        w[k] = j0 + k < M ? a.cand_p[j0 + k] : 0.0;
         cnt += w[k] != 0.0 ? 1 : 0;
     }
     int tot;
@@ -639,7 +631,7 @@ __global__ void __launch_bounds__(kTileThreads) k_compact_bulk(SampleArgs a, u64
     for (int k = 0; k < kTilePer; k++) {
         if (w[k] == 0.0) continue;
         if (pos < B) {
-            a.out_idx[pos] = a.cand[j0 + k].idx;
+            a.out_idx[pos] = a.cand_idx[j0 + k];
             a.wtmp[pos] = w[k];
             wm = fmax(wm, w[k]);
             if (pos == B - 1) *a.out_used = j0 + k + 1;  // uniforms consumed = index of the B-th accept + 1
@@ -1022,7 +1014,7 @@ struct SampleScratch {
     static size_t bytes(i64 M, i64 B, bool bulk) {
         using C = srlx::Carver;
         if (!bulk) return C::padded((size_t)M * 8) * 2 + C::padded((size_t)B * 8) * 2;
-        return C::padded((size_t)B * 8) + C::padded((size_t)M * 16);  // compacted weights | (leaf, weight) per draw
+        return C::padded((size_t)B * 8) + C::padded((size_t)M * 8) * 2;  // compacted weights | leaf per draw | weight per draw
     }
 };
 
@@ -1060,7 +1052,8 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
             return SRLX_ERR_UNSUPPORTED;
         }
         a.wtmp = cv.take<double>(B);
-        a.cand = cv.take<Cand>(M);
+        a.cand_idx = cv.take<i64>(M);
+        a.cand_p = cv.take<double>(M);  // un-normalised IS weight of the draw (0 = zero-priority leaf, rejected)
         u64 *counters = h->d_ctl;
         const i64 ntiles = (M + kTile - 1) / kTile;
         if (ntiles > h->tiles_cap) {  // look-back state of the compaction, zero between calls

@@ -266,7 +266,7 @@ def per_micro(eng, draws=1 << 20, reps=20):
         gbs = n * bytes_per_draw / (ms * 1e-3) / 1e9
         return {"draws_per_call": n, "ms_per_call": ms, "draws_per_s": n / (ms * 1e-3), "algorithmic_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
 
-    out = {"kernel": "per_sample bulk (k_descend_bulk + k_finish_fast; device-wide ordered compaction only when a draw is rejected)", "bytes_per_draw": bytes_per_draw}
+    out = {"kernel": "per_sample bulk (k_descend_bulk + k_compact_bulk: normalising pass, or device-wide ordered compaction when a draw is rejected)", "bytes_per_draw": bytes_per_draw}
     out.update(one(draws, reps))
     out["by_draws"] = [one(1 << 22, 10), one(1 << 24, 5)]
     return out

@@ -417,6 +417,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int 
     for (int k = threadIdx.x; k < lds_blocks * 4; k += blockDim.x)
         reinterpret_cast<double2 *>(top)[k] = reinterpret_cast<const double2 *>(tr.T)[(k >> 2) * 8 + (k & 3)];
     __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) zero_count[3] = 0;  // re-arm the rejecting path's max weight: nothing in this kernel reads it
     const double total = top[kRootSlot];
     const i64 M = a.n_uniforms, B = a.batch, len = tr.len;
     const i64 step = a.d_step ? *a.d_step : a.step;
@@ -540,9 +541,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int 
 // After the walk.  Counters (handle-owned, zero between calls): [0] zero-priority draws seen by the walk,
 // [1] max weight of draws < B (bits), [2] "some draw was rejected" (rewritten by every call), [3] max weight of the
 // compacted draws (bits), [4] tile tickets.  Each counter is re-armed by a kernel that does not read it.
-//   k_finish_fast   nothing was rejected (the common case): output i is draw i, one pass writes index and
-//                   normalised weight (:163-167); returns at once otherwise
-//   k_compact_bulk  returns at once (apart from out_used) when nothing was rejected; else the ORDERED compaction of the
+//   k_compact_bulk  nothing was rejected (the common case): output i is draw i, the walk already wrote the indices, one
+//                   pass writes the normalised weights (:163-167); else the ORDERED compaction of the
 //                   accepted draws (in-order rejection, :146-157) over the whole device: one 2048-draw tile per
 //                   workgroup, tile offsets by a decoupled look-back scan (a tile publishes its count, then its
 //                   first wave sums 64 predecessors per step until it meets a resolved prefix)
@@ -553,31 +553,28 @@ __global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int 
 constexpr int kTileThreads = 256, kTilePer = 8, kTile = kTileThreads * kTilePer;
 constexpr u64 kStAggregate = 1ull << 62, kStPrefix = 2ull << 62, kStMask = 3ull << 62;
 
-__global__ void __launch_bounds__(256) k_finish_fast(SampleArgs a, u64 *counters) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[3] = 0;  // re-arm: nothing in this kernel reads it
-    if (counters[0] != 0 || a.n_uniforms < a.batch) return;
-    const double wmax = __longlong_as_double((long long)counters[1]);
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < a.batch; i += (i64)gridDim.x * blockDim.x) {
-        const double w = a.cand_p[i] / wmax;  // :167 (the index was written by the walk)
-        if (a.out_w) a.out_w[i] = w;
-        if (a.out_w32) a.out_w32[i] = (float)w;
-    }
-}
-
-__global__ void __launch_bounds__(kTileThreads) k_compact_bulk(SampleArgs a, u64 *counters, u64 *tile_state, i64 ntiles) {
+__global__ void __launch_bounds__(kTileThreads) k_compact_bulk(SampleArgs a, u64 *counters, u64 *tile_state, i64 ntiles, int slow_workgroups) {
     __shared__ int ibuf[kTileThreads];
     __shared__ double dred[kTileThreads];
     __shared__ i64 s_prefix;
     __shared__ unsigned s_tile;
     const i64 M = a.n_uniforms, B = a.batch;
     const int t = threadIdx.x;
-    if (counters[0] == 0) {
+    if (counters[0] == 0) {  // nothing was rejected (the common case): output i is draw i, the walk already wrote the indices
         if (blockIdx.x == 0 && t == 0) {
             counters[2] = 0;
             *a.out_used = (M >= B) ? B : -1;
         }
+        if (M < B) return;
+        const double wmax = __longlong_as_double((long long)counters[1]);
+        for (i64 i = (i64)blockIdx.x * blockDim.x + t; i < B; i += (i64)gridDim.x * blockDim.x) {
+            const double w = a.cand_p[i] / wmax;  // :167
+            if (a.out_w) a.out_w[i] = w;
+            if (a.out_w32) a.out_w32[i] = (float)w;
+        }
         return;
     }
+    if ((int)blockIdx.x >= slow_workgroups) return;  // the grid is sized for the normalising pass; the compaction wants fewer, persistent workgroups
     // tiles are handed out in scheduling order, so every predecessor a tile waits for has been taken by a running workgroup
   for (;;) {
     __syncthreads();
@@ -1076,12 +1073,12 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
             hipLaunchKernelGGL((k_descend_bulk<1024>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, counters, counters + 1);
         else
             hipLaunchKernelGGL((k_descend_bulk<256>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, counters, counters + 1);
+        // one launch finishes either path: the normalising pass when nothing was rejected, else the ordered compaction
         const i64 fw = (B + 256 * 4 - 1) / (256 * 4);
-        const int fb = (int)(fw < 8 * h->n_cu ? fw : 8 * h->n_cu);
-        hipLaunchKernelGGL(k_finish_fast, dim3(fb), dim3(256), 0, st, a, counters);
-        const i64 cw = 2 * (i64)h->n_cu;
-        hipLaunchKernelGGL(k_compact_bulk, dim3((unsigned)(ntiles < cw ? ntiles : cw)), dim3(kTileThreads), 0, st, a, counters, h->d_tiles, ntiles);
-        hipLaunchKernelGGL(k_finish_slow, dim3(fb < h->n_cu ? fb : h->n_cu), dim3(256), 0, st, a, counters, h->d_tiles, ntiles);
+        const i64 cw = 8 * (i64)h->n_cu, need = ntiles > fw ? ntiles : fw;
+        hipLaunchKernelGGL(k_compact_bulk, dim3((unsigned)(need < cw ? need : cw)), dim3(kTileThreads), 0, st, a, counters, h->d_tiles, ntiles,
+                           2 * h->n_cu);
+        hipLaunchKernelGGL(k_finish_slow, dim3((unsigned)(fw < h->n_cu ? fw : h->n_cu)), dim3(256), 0, st, a, counters, h->d_tiles, ntiles);
     }
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

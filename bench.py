@@ -98,13 +98,22 @@ def main():
     if not args.no_graph:
         eng.capture_graphs()
 
-    # HIP events around the dominant hand-written kernel (frame-stack expansion) on its launch stream
+    # HIP events around the actors' network pass (the dominant kernel group) and, inside it, around the two launches of the
+    # dominant single kernel (k_gemm<AConv>: conv2 + conv3), all on the stream they are launched on
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    local = getattr(eng, "local", eng)
+    probing = bool(local.mfma) and getattr(eng, "acts", True)
+    pr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if probing else []
+    for a, b in pr:  # torch creates the underlying hipEvent_t at the first record
+        a.record()
+        b.record()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if probing:
+            local.inf_actor.set_probe(*pr[k])
         eng.step(args.updates, events=ev[k])
     torch.cuda.synchronize()
     if dist is not None:
@@ -116,10 +125,11 @@ def main():
         elapsed = float(t.item())
 
     ev_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    conv_ms = sum(a.elapsed_time(b) for a, b in pr) / len(pr) if probing else 0.0
     if dist is not None:  # a learner-only rank 0 runs no actor pass: report the slowest actor rank's
-        t = torch.tensor([ev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([ev_ms, conv_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ev_ms = float(t.item())
+        ev_ms, conv_ms = float(t[0].item()), float(t[1].item())
 
     if rank != 0:
         if dist is not None:
@@ -163,7 +173,7 @@ def main():
                          else f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology), RCCL gather/broadcast"),
             "actor_gpus": actor_gpus,
         },
-        "roofline": roofline(eng, ev_ms),
+        "roofline": roofline(eng, ev_ms, conv_ms),
         "final": {"loss": info["loss"], "train_count": info["train_count"], "memory": info["memory"]},
     }
     if args.per_micro:
@@ -196,26 +206,42 @@ def _isolated_forward_ms(eng, reps=20):
     return a.elapsed_time(b) / reps
 
 
-def roofline(eng, ev_ms):
-    """The dominant hand-written kernel group of a step, timed with events on its launch stream."""
+def roofline(eng, ev_ms, conv_ms=0.0):
+    """The dominant hand-written kernel, timed live with events on its launch stream: k_gemm<AConv> (the implicit-GEMM
+    convolutions conv2 + conv3 of the actors' network pass, two launches per step).  `pass` = the whole pass (5 kernels)."""
     if eng.mfma:
         flops = eng.actor_forward_flops()
         tf = flops / (ev_ms * 1e-3) / 1e12
         iso_ms = _isolated_forward_ms(eng)
-        return {
+        group = {
             "kernel": "srlx_qnet_forward_u8 over E envs: k_conv1_u8 (conv1 from the uint8 ring) + k_gemm<AConv> x2 + k_gemm<APlain,splitK> (FC1) + k_head",
-            "bound": "mfma",
             "achieved": tf,
-            "peak": MFMA_F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
             "frac": tf / MFMA_F32_PEAK_TFLOPS,
-            "traffic": None,
             "flops_per_launch_group": flops,
             "avg_launch_group_ms": ev_ms,
-            "note": "timed inside the step loop, where the learner's three streams run beside it; `isolated` = the same launches alone",
             "isolated": {"avg_launch_group_ms": iso_ms, "achieved": flops / (iso_ms * 1e-3) / 1e12, "frac": flops / (iso_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
-            "dtype": "f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32)",
         }
+        if conv_ms > 0.0:
+            cf = eng.conv_gemm_flops()
+            ctf = cf / (conv_ms * 1e-3) / 1e12
+            return {
+                "kernel": "k_gemm<AConv, 64, true, false, 128>: implicit-GEMM convolutions conv2 + conv3 of the actors' pass (2 launches per step, "
+                          "v_mfma_f32_32x32x2_f32); rocprofv3 check: 2 x this kernel's AverageNs in profiles/*_kernel_stats.csv = avg_launch_pair_ms",
+                "bound": "mfma",
+                "achieved": ctf,
+                "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ctf / MFMA_F32_PEAK_TFLOPS,
+                "traffic": None,
+                "flops_per_launch_pair": cf,
+                "avg_launch_pair_ms": conv_ms,
+                "note": "timed inside the step loop, where the learner's streams run beside it; `pass` = the whole network pass of the actors, "
+                        "`pass.isolated` = that pass alone on an idle GPU",
+                "pass": group,
+                "dtype": "f32 in / f32 accumulate",
+            }
+        group.update({"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "dtype": "f32 in / f32 accumulate"})
+        return group
     nbytes = eng.stack_bytes_per_launch()
     gbs = nbytes / (ev_ms * 1e-3) / 1e9
     return {
@@ -256,13 +282,16 @@ def per_micro(eng, draws=1 << 20, reps=20):
         for _ in range(3):
             run()
         torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            run()
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / reps
+        times = []
+        for _ in range(3):  # median of three timed batches: one disturbed batch does not become the reported number
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                run()
+            b.record()
+            torch.cuda.synchronize()
+            times.append(a.elapsed_time(b) / reps)
+        ms = sorted(times)[1]
         gbs = n * bytes_per_draw / (ms * 1e-3) / 1e9
         return {"draws_per_call": n, "ms_per_call": ms, "draws_per_s": n / (ms * 1e-3), "algorithmic_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
 

@@ -387,6 +387,10 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
 int srlx_qnet_destroy(srlx_qnet_t *h);
 int srlx_qnet_bind(srlx_qnet_t *h, const float *const *d_params);
 int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, void *stream);
+/* Measurement hook: the NEXT forward on this handle records the two caller-owned HIP events (hipEvent_t) on its stream right
+ * before the conv2 launch and right after the conv3 launch -- the two launches of the dominant kernel k_gemm<AConv> -- so that
+ * bench.py can time that kernel live, on the stream it runs on.  NULL events switch it off. */
+int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end);
 /* Training on the vectorised path (replaces `loss.backward()` + the framework forward it needs,
  * srl/algorithms/rainbow/model_torch.py:103-109):
  *   srlx_qnet_enable_training : from now on every forward keeps its post-ReLU hidden layer, and gradient scratch for up

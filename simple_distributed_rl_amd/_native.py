@@ -79,6 +79,7 @@ SIGNATURES = {
     "srlx_qnet_bind": (c_int, [c_p, c_p]),
     "srlx_qnet_forward_u8": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     "srlx_qnet_enable_training": (c_int, [c_p, c_i64]),
+    "srlx_qnet_set_probe": (c_int, [c_p, c_p, c_p]),
     "srlx_qnet_backward_u8": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_qnet_forward_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p]),
     "srlx_policy_epsilon_greedy": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -503,11 +503,14 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     // conv2: 4x4 stride 2 pad 2 on act1 [B][OH1][OW1][F1]
     AConv c2{h->act1, h->OH1, h->OW1, h->F1, 4, 2, 2, h->OH2, h->OW2, {}};
     c2.fill_taps(16 * h->F1);
+    if (h->probe0) SRLX_HIP(hipEventRecord(h->probe0, st));
     launch_gemm<AConv, 64, true, false>(c2, h->w2, h->b2, h->act2, B * h->OH2 * h->OW2, 2 * h->F1, 16 * h->F1, 1, st);
     // conv3: 3x3 stride 1 pad 1
     AConv c3{h->act2, h->OH2, h->OW2, 2 * h->F1, 3, 1, 1, h->OH3, h->OW3, {}};
     c3.fill_taps(9 * 2 * h->F1);
     launch_gemm<AConv, 64, true, false>(c3, h->w3, h->b3, h->act3, B * h->OH3 * h->OW3, 2 * h->F1, 9 * 2 * h->F1, 1, st);
+    if (h->probe1) SRLX_HIP(hipEventRecord(h->probe1, st));
+    h->probe0 = h->probe1 = nullptr;  // one forward only
     // FC1 split along K so that ~512 workgroups exist whatever the batch
     const int N1 = 2 * h->hidden;
     const i64 tiles = ((B + BM - 1) / BM) * ((N1 + 63) / 64);
@@ -613,6 +616,13 @@ int srlx_qnet_bind(srlx_qnet_t *h, const float *const *p) {
     for (int i = 0; i < 12; i++) SRLX_REQUIRE(p[i], "qnet_bind: parameter %d is NULL", i);
     h->w1 = p[0], h->b1 = p[1], h->w2 = p[2], h->b2 = p[3], h->w3 = p[4], h->b3 = p[5];
     h->wf = p[6], h->bf = p[7], h->v2w = p[8], h->v2b = p[9], h->a2w = p[10], h->a2b = p[11];
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end) {
+    SRLX_REQUIRE(h, "qnet_set_probe: NULL handle");
+    h->probe0 = (hipEvent_t)ev_start;
+    h->probe1 = (hipEvent_t)ev_end;
     return SRLX_OK;
 }
 

@@ -21,6 +21,7 @@ struct srlx_qnet {
     size_t w_part_floats;
     hipStream_t side;                     // weight-gradient branch of the backward pass (forks from / joins the caller's stream)
     hipEvent_t ev_fork, ev_d3, ev_d2, ev_d1, ev_join;
+    hipEvent_t probe0, probe1;            // optional, caller-owned: recorded around the two conv GEMM launches of the next forward (srlx_qnet_set_probe)
 };
 
 // implicit-GEMM data gradient on the matrix cores (defined next to k_gemm in srlx_qnet.hip)

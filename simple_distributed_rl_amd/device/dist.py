@@ -283,6 +283,9 @@ class DistributedRainbow:
     def actor_forward_flops(self):
         return self.local.actor_forward_flops()
 
+    def conv_gemm_flops(self):
+        return self.local.conv_gemm_flops()
+
     @property
     def mfma(self):
         return self.local.mfma

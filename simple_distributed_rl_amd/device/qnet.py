@@ -167,6 +167,10 @@ class QNetInference:
         N.check(self.lib.srlx_qnet_backward_u8(self.h, B, int(sample_stride), N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(grad_q),
                                                ctypes.cast(self._grad_arr, N.c_p), N.torch_stream_ptr()))
 
+    def set_probe(self, ev_start: torch.cuda.Event, ev_end: torch.cuda.Event):
+        """The next forward records the two (timing-enabled, already created) events around its two conv GEMM launches."""
+        N.check(self.lib.srlx_qnet_set_probe(self.h, N.c_p(ev_start.cuda_event), N.c_p(ev_end.cuda_event)))
+
     def forward_f32(self, obs_nchw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         B = obs_nchw.shape[0]
         q = self.q[:B] if out is None else out

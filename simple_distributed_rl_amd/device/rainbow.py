@@ -272,6 +272,15 @@ class RainbowEngine:
         mac += h2 * w2 * 2 * F1 * 2 * c.hidden_units + c.hidden_units * (1 + c.n_actions)
         return 2.0 * mac * c.n_envs
 
+    def conv_gemm_flops(self) -> float:
+        """Algorithmic fp32 FLOPs of the two implicit-GEMM convolution launches (conv2 + conv3) of one policy-step pass over E environments."""
+        c = self.cfg
+        F1 = c.filters
+        h1 = (c.obs_hw[0] + 6 - 8) // 4 + 1
+        w1 = (c.obs_hw[1] + 6 - 8) // 4 + 1
+        h2, w2 = (h1 + 4 - 4) // 2 + 1, (w1 + 4 - 4) // 2 + 1
+        return 2.0 * (h2 * w2 * 2 * F1 * F1 * 16 + h2 * w2 * 2 * F1 * 2 * F1 * 9) * c.n_envs
+
     def stack_bytes_per_launch(self) -> int:
         """Algorithmic HBM bytes of one k_stack_current launch: W uint8 frames read + W float32 frames
         written per environment."""

@@ -10,6 +10,18 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profb -- python $R/bench.py --steps 200 --warmup 20 --cpu-seconds 0 > $R/gpurun_out/bench_r1_profiled.json 2>/dev/null
 f=$(find /tmp/profb -name "*kernel_stats.csv" | head -1); cp "$f" $R/gpurun_out/r1_kernel_stats.csv
+python - "$f" $R/gpurun_out/bench_r1_profiled.json > $R/gpurun_out/r1_roofline_check.txt <<'PY'
+import csv, json, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+d = json.loads([l for l in open(sys.argv[2]) if l.startswith('{')][0])
+print("same command, same run (python bench.py --steps 200 --warmup 20 --cpu-seconds 0 under rocprofv3 --kernel-trace --stats):")
+for r in rows:
+    if 'AConv, 64, true, false, 128' in r['Name']:
+        print("rocprofv3 kernel_stats: k_gemm<AConv, 64, true, false, 128>  calls %s  AverageNs %s  -> two launches per step = %.1f us" % (r['Calls'], r['AverageNs'], 2 * float(r['AverageNs']) / 1e3))
+print("bench.py roofline (HIP events on the launch stream, around the two launches): avg_launch_pair_ms = %.4f ms (includes the gap between the two launches)" % d['roofline']['avg_launch_pair_ms'])
+print("bench.py of that run: ms_per_step %.4f (kernel tracing serialises the streams; the unprofiled run is profiles/r1_bench.json)" % d['ms_per_step'])
+PY
+cat $R/gpurun_out/r1_roofline_check.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profp -- python $R/tools/per_probe.py quick > /dev/null 2>&1
 f=$(find /tmp/profp -name "*kernel_stats.csv" | head -1); grep -v "at::native" "$f" | cut -c1-400 > $R/gpurun_out/r1_per_kernel_stats.csv
 head -8 $R/gpurun_out/r1_per_kernel_stats.csv | cut -c1-200

@@ -1,40 +1,47 @@
-"""SingleUseBuffer (srl/rl/memories/single_use_buffer.py:8-46): everything added since the last sample,
-handed out once (on-policy / tabular algorithms)."""
+"""On-policy hand-over buffer (reference contract: srl/rl/memories/single_use_buffer.py:8-46).
+
+Everything the workers add since the previous `sample()` is handed to the trainer exactly once, in arrival order; the
+tabular and on-policy algorithms (QL) use it.  Items are opaque Python objects; over a process boundary they travel
+pickled (`serialize` on the actor side, `add(..., serialized=True)` on the trainer side)."""
 import pickle
-from typing import Any
+from typing import Any, List, Optional
 
 from simple_distributed_rl_amd.base.rl.memory import RLMemory
 
 
 class SingleUseBuffer:
     def __init__(self):
-        self.buffer = []
+        self._pending: List[Any] = []
 
-    def length(self) -> int:
-        return len(self.buffer)
-
-    def add(self, batch: Any, serialized: bool = False) -> None:
-        if serialized:
-            batch = pickle.loads(batch)
-        self.buffer.append(batch)
-
-    def serialize(self, batch: Any) -> Any:
+    # -- producer side ---------------------------------------------------------------------------
+    def serialize(self, batch: Any) -> bytes:
         return pickle.dumps(batch)
 
-    def sample(self):
-        if len(self.buffer) == 0:
-            return None
-        buffer, self.buffer = self.buffer, []
-        return buffer
+    def add(self, batch: Any, serialized: bool = False) -> None:
+        self._pending.append(pickle.loads(batch) if serialized else batch)
 
-    def call_backup(self, **kwargs):
-        return self.buffer[:]
+    # -- consumer side ---------------------------------------------------------------------------
+    def sample(self) -> Optional[List[Any]]:
+        if not self._pending:
+            return None
+        handed_over = self._pending
+        self._pending = []
+        return handed_over
+
+    def length(self) -> int:
+        return len(self._pending)
+
+    # -- checkpointing ---------------------------------------------------------------------------
+    def call_backup(self, **kwargs) -> List[Any]:
+        return list(self._pending)
 
     def call_restore(self, data: Any, **kwargs) -> None:
-        self.buffer = data[:]
+        self._pending = list(data)
 
 
 class RLSingleUseBuffer(SingleUseBuffer, RLMemory):
+    """The RLMemory flavour: registers `add` (with its serialiser) for workers and `sample` for the trainer."""
+
     def __init__(self, *args):
         RLMemory.__init__(self, *args)
         SingleUseBuffer.__init__(self)

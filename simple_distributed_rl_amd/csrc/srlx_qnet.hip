@@ -343,17 +343,18 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
 
 // ---- head: reduce FC1 splits (+bias, ReLU), second layers, dueling combine; one workgroup per sample ----
 constexpr int kMaxActions = 32;
-__global__ void __launch_bounds__(256) k_head(const float *__restrict__ partial, int splits, i64 M, int hidden, const float *__restrict__ b1,
+__global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial, int splits, i64 M, int hidden, const float *__restrict__ b1,
                                               const float *__restrict__ v2w, const float *__restrict__ v2b, const float *__restrict__ a2w,
                                               const float *__restrict__ a2b, int A, int dueling, float *__restrict__ q, float *__restrict__ h1) {
-    __shared__ float red[4][kMaxActions + 1];
+    __shared__ float red[8][kMaxActions + 1];  // one row per wave (256 or 512 threads)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const i64 m = blockIdx.x;
     const int N1 = 2 * hidden;
     float v = 0.f, adv[kMaxActions];
 #pragma unroll
     for (int j = 0; j < kMaxActions; j++) adv[j] = 0.f;
-    for (int u = t; u < hidden; u += 256) {
+    const int nwaves = blockDim.x >> 6;
+    for (int u = t; u < hidden; u += blockDim.x) {
         // split sums in a fixed order with eight independent chains (sixteen loads in flight per iteration)
         float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float *p = partial + m * N1 + u;
@@ -397,13 +398,17 @@ __global__ void __launch_bounds__(256) k_head(const float *__restrict__ partial,
     }
     __syncthreads();
     if (t == 0) {
-        v = red[0][kMaxActions] + red[1][kMaxActions] + red[2][kMaxActions] + red[3][kMaxActions] + v2b[0];
+        v = 0.f;
+        for (int w = 0; w < nwaves; w++) v += red[w][kMaxActions];
+        v += v2b[0];
         float mean = 0.f, mx = -INFINITY;
         float out[kMaxActions];
 #pragma unroll
         for (int j = 0; j < kMaxActions; j++)
             if (j < A) {
-                out[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j] + a2b[j];
+                float o = 0.f;
+                for (int w = 0; w < nwaves; w++) o += red[w][j];
+                out[j] = o + a2b[j];
                 mean += out[j];
                 mx = out[j] > mx ? out[j] : mx;
             }
@@ -523,7 +528,8 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     launch_gemm<APlain, 64, false, true>(fa, h->wf, nullptr, h->partial, B, N1, h->flat, splits, st);
     const int kps = ((ksteps + splits - 1) / splits);
     const int used = (ksteps + kps - 1) / kps;  // splits that actually own a K range
-    hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(256), 0, st, h->partial, used, B, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
+    // small launches (the learner's 128 / 96 rows) are one workgroup per row and far from filling the chip: twice the threads per row
+    hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(B <= 256 && h->hidden > 256 ? 512 : 256), 0, st, h->partial, used, B, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
                        h->a2b, h->A, h->dueling, d_q, h->h1);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

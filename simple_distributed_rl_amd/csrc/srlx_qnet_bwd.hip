@@ -160,10 +160,11 @@ __global__ void __launch_bounds__(256) k_fc1_dgrad(int B, int N1, int K, const f
 // dact3[b][k] = act3[b][k] > 0 ? sum_s part[s][b][k] : 0   (ReLU of conv3)
 __global__ void __launch_bounds__(256) k_fc1_dgrad_reduce(int B, i64 sstride, int K, const float *__restrict__ part, const float *__restrict__ act3,
                                                           float *__restrict__ dact3) {
-    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (i64)B * K) return;
-    const int b = (int)(i / K), k = (int)(i % K);
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;  // B * K <= 64 * 7744: 32-bit index arithmetic
+    if (i >= (unsigned)(B * K)) return;
+    const int b = (int)(i / (unsigned)K), k = (int)(i % (unsigned)K);
     float s = 0.f;
+#pragma unroll
     for (int sp = 0; sp < kFcSplits; sp++) s += part[((i64)sp * B + b) * K + k];
     dact3[i] = act3[(i64)b * sstride * K + k] > 0.f ? s : 0.f;
 }
@@ -270,9 +271,11 @@ __global__ void __launch_bounds__(256) k_transpose_filter(const float *__restric
 // dX[b][iy][ix][ci] = [X > 0] * sum over the padded positions that replicate (iy, ix) of dXq[class][b][py / S][px / S][ci]
 __global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int W, int CI, int P, int HP, int WP, int S, int QH, int QW,
                                                   const float *__restrict__ dxq, const float *__restrict__ X, float *__restrict__ dX) {
-    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (i64)B * H * W * CI) return;
-    const int ci = (int)(i % CI), ix = (int)((i / CI) % W), iy = (int)((i / ((i64)CI * W)) % H), b = (int)(i / ((i64)CI * W * H));
+    // 32-bit index arithmetic: B <= 64 samples of at most 21 x 21 x 64 values (64-bit divisions cost more than the kernel's traffic)
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)(B * H * W * CI)) return;
+    const unsigned uci = (unsigned)CI, uw = (unsigned)W, uh = (unsigned)H;
+    const int ci = (int)(i % uci), ix = (int)((i / uci) % uw), iy = (int)((i / (uci * uw)) % uh), b = (int)(i / (uci * uw * uh));
     const int y0 = iy == 0 ? 0 : iy + P, y1 = iy == H - 1 ? HP - 1 : iy + P;
     const int x0 = ix == 0 ? 0 : ix + P, x1 = ix == W - 1 ? WP - 1 : ix + P;
     const i64 cls_stride = (i64)B * QH * QW * CI;

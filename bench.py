@@ -52,11 +52,15 @@ def parse_args():
 
 def main():
     args = parse_args()
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and rank != 0:
+        # the launcher merges every rank's stdout: only rank 0 may write there (RCCL prints a version banner through C stdio,
+        # flushed when a process exits -- it must not land behind rank 0's JSON line)
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    import torch
+
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev_index = local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank  # rehearsal: ranks may share a GPU
@@ -180,9 +184,14 @@ def main():
         out["per_micro"] = per_micro(eng)
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other runs would only repeat it
         out["cpu_baseline"] = cpu_baseline(args, cfg)
-    print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: first drain what native libraries (RCCL's banner) left in C stdio buffers
+    import ctypes
+
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= the fp32 vector peak)

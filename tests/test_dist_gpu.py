@@ -153,6 +153,7 @@ def test_bench_multi_rank_rehearsal(n, actor_gpus):
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0]  # the JSON line is the last thing on the merged stdout of all ranks
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["config"]["actor_gpus"] == actor_gpus and d["scaling"] == "weak"
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 128 * actor_gpus) < 1e-6 * 128 * actor_gpus  # value = all actor ranks' env-steps / time

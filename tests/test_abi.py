@@ -44,3 +44,18 @@ def test_no_gpu_calls_fail_cleanly():
 
     with pytest.raises(N.SrlxError):
         ProportionalMemory(100)
+
+
+def test_hardware_queue_default_is_set_before_the_runtime_starts():
+    """Importing the binding module puts GPU_MAX_HW_QUEUES=2 into the environment (unless the user already chose): the engines'
+    stream placement must not decide between a 0.5 and a 1.4 ms update."""
+    import subprocess
+    import sys
+
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import simple_distributed_rl_amd._native as n; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip().splitlines()[-1] == "2", out.stderr[-2000:]
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '4'; import simple_distributed_rl_amd._native as n; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip().splitlines()[-1] == "4"

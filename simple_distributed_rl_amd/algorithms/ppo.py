@@ -1,5 +1,5 @@
-"""PPO plugin for discrete action spaces (srl/algorithms/ppo/config.py:31-128, srl/algorithms/ppo/ppo.py:28-404),
-registered as "PPO:torch".
+"""PPO plugin for discrete and continuous action spaces (srl/algorithms/ppo/config.py:31-128,
+srl/algorithms/ppo/ppo.py:28-404), registered as "PPO:torch".
 
 The reference's PPO is a TensorFlow/Keras model (`get_framework() == "tensorflow"`, ppo.py:6-7) and cannot be imported
 in the build container, so this module is a restatement of the cited lines on the torch/ROCm stack, NOT pinned against
@@ -12,7 +12,10 @@ value target and the advantage (:389-404, :214-215), here one `srlx_gae_scan` la
 Trainer: `train_num` minibatch updates per call (:191-201); the clipped surrogate, clipped value loss and entropy
 bonus with their gradient seeds come from one `srlx_ppo_loss_logpi` launch, torch only back-propagates the seeds
 through the small actor-critic MLP; global-norm clipping and Adam with the staircase schedule as configured.
-Continuous (NpArraySpace) actions are served by the vectorised engine (device/ppo.py), not by this plugin."""
+Continuous (NpArraySpace) actions: a Normal policy head (loc, log-scale clipped to the stable-gradient range,
+srl/rl/tf/distributions/normal_dist_block.py:76-155), the worker samples loc + scale * N(0,1), rescales [-1, 1] onto the
+environment's bounds and sanitises (:332-339), the trainer's losses and seeds come from `srlx_ppo_loss_normal`.  The
+vectorised engine for the same policy (E environments on the device) is device/ppo.py."""
 import math
 from dataclasses import dataclass, field
 from typing import Any, Optional, Tuple
@@ -23,12 +26,13 @@ import torch.nn as nn
 
 from simple_distributed_rl_amd import _native as N
 from simple_distributed_rl_amd.base.exception import UndefinedError
-from simple_distributed_rl_amd.base.rl.algorithms.base_dqn import RLConfig, RLWorker
+from simple_distributed_rl_amd.base.rl.algorithms.base_ppo import RLConfig, RLWorker
 from simple_distributed_rl_amd.base.rl.memory import RLMemory
 from simple_distributed_rl_amd.base.rl.parameter import RLParameter
 from simple_distributed_rl_amd.base.rl.registration import register
 from simple_distributed_rl_amd.base.rl.trainer import RLTrainer
 from simple_distributed_rl_amd.base.spaces.discrete import DiscreteSpace
+from simple_distributed_rl_amd.base.spaces.np_array import NpArraySpace
 from simple_distributed_rl_amd.rl.memories.replay_buffer import ReplayBuffer
 from simple_distributed_rl_amd.rl.models.config import HiddenBlockConfig, InputBlockConfig
 from simple_distributed_rl_amd.rl.schedulers.lr_scheduler import LRSchedulerConfig
@@ -69,6 +73,8 @@ class Config(RLConfig):
     global_gradient_clip_norm: float = 0.5
     state_clip: Optional[Tuple[float, float]] = None
     reward_clip: Optional[Tuple[float, float]] = None
+    enable_stable_gradients: bool = True
+    stable_gradients_scale_range: tuple = (1e-10, 10)
 
     def get_name(self) -> str:
         return "PPO"
@@ -115,8 +121,6 @@ class ActorCriticNetwork(nn.Module):
 
     def __init__(self, config: Config):
         super().__init__()
-        if not isinstance(config.action_space, DiscreteSpace):
-            raise UndefinedError(config.action_space)
         self.in_block = config.input_block.create_torch_block(config)
         self.hidden_block = config.hidden_block.create_torch_block(self.in_block.out_size)
         h = self.hidden_block.out_size
@@ -125,13 +129,29 @@ class ActorCriticNetwork(nn.Module):
         nn.init.orthogonal_(self.value_out.weight)
         nn.init.zeros_(self.value_out.bias)
         self.policy_block = config.policy_block.create_torch_block(h)
-        self.policy_out = nn.Linear(self.policy_block.out_size, config.action_space.n)  # CategoricalDistBlock: logits
+        ph = self.policy_block.out_size
+        self.continuous = isinstance(config.action_space, NpArraySpace)
+        if isinstance(config.action_space, DiscreteSpace):
+            self.policy_out = nn.Linear(ph, config.action_space.n)  # CategoricalDistBlock: logits
+        elif self.continuous:  # NormalDistBlock: a loc layer (truncated-normal bias) and a log-scale layer (zero bias)
+            self.policy_out = nn.Linear(ph, config.action_space.size)
+            nn.init.trunc_normal_(self.policy_out.bias, std=0.05)
+            self.log_scale_out = nn.Linear(ph, config.action_space.size)
+            nn.init.zeros_(self.log_scale_out.bias)
+            lo, hi = config.stable_gradients_scale_range if config.enable_stable_gradients else (1e-30, 1e30)
+            self.log_scale_range = (math.log(lo), math.log(hi))
+        else:
+            raise UndefinedError(config.action_space)
 
     def forward(self, x):
+        """(v, logits) for discrete actions, (v, loc, log_scale) for continuous ones (log_scale NOT yet clipped: the loss kernel
+        clips it itself so that the clip's zero gradient is part of its seeds)."""
         x = self.hidden_block(self.in_block(x))
         v = self.value_out(self.value_block(x))
-        logits = self.policy_out(self.policy_block(x))
-        return v, logits
+        p = self.policy_block(x)
+        if self.continuous:
+            return v, self.policy_out(p), self.log_scale_out(p)
+        return v, self.policy_out(p)
 
 
 class Parameter(RLParameter):
@@ -157,8 +177,7 @@ class Parameter(RLParameter):
 
     def pred(self, state: np.ndarray):
         with torch.no_grad():
-            v, logits = self.model(torch.as_tensor(np.asarray(state, dtype=self.np_dtype), device=self.device))
-        return v, logits
+            return self.model(torch.as_tensor(np.asarray(state, dtype=self.np_dtype), device=self.device))
 
 
 class Trainer(RLTrainer):
@@ -197,6 +216,24 @@ class Trainer(RLTrainer):
         self._keep = keep
         return losses, g_lp, g_v
 
+    def losses_and_seeds_normal(self, loc, log_scale, action, old_logpi, advantage, v, v_target, old_v):
+        """The same for a Normal policy (`srlx_ppo_loss_normal`): (losses[3], d/d loc, d/d log_scale, d/d v)."""
+        cfg, d = self.config, self.device
+        B, D = loc.shape
+        losses = torch.empty(3, dtype=torch.float32, device=d)
+        g_loc = torch.empty((B, D), dtype=torch.float32, device=d)
+        g_ls = torch.empty((B, D), dtype=torch.float32, device=d)
+        g_v = torch.empty(B, dtype=torch.float32, device=d)
+        keep = [t.detach().contiguous().float() for t in (loc, log_scale, action, old_logpi, advantage, v, v_target, old_v)]
+        lo, hi = self.parameter.model.log_scale_range
+        N.check(self.lib.srlx_ppo_loss_normal(
+            B, D, N.tptr(keep[0]), N.tptr(keep[1]), float(lo), float(hi), N.tptr(keep[2]), N.tptr(keep[3]), N.tptr(keep[4]), N.tptr(keep[5]), N.tptr(keep[6]),
+            N.tptr(keep[7]), int(cfg.baseline_type in ("advantage", "v")), int(cfg.surrogate_type == "clip"), float(cfg.policy_clip_range),
+            int(bool(cfg.enable_value_clip)), float(cfg.value_clip_range), float(cfg.value_loss_weight), float(cfg.entropy_weight), N.tptr(losses),
+            N.tptr(g_loc), N.tptr(g_ls), N.tptr(g_v), N.torch_stream_ptr()))
+        self._keep = keep
+        return losses, g_loc, g_ls, g_v
+
     def _train(self) -> bool:
         batches = self.memory.sample()
         if batches is None:
@@ -216,16 +253,22 @@ class Trainer(RLTrainer):
             adv = (adv - np.mean(adv)) / (np.std(adv) + 1e-8)
         elif bt not in ("", "none", "advantage", "v"):
             raise UndefinedError(bt)
-        actions = torch.as_tensor(np.asarray([e["action"] for e in batches], dtype=np.float32), device=d)  # one-hot rows
-        old_logpi = torch.as_tensor(np.asarray([e["log_prob"] for e in batches], dtype=np.float32), device=d).view(-1, 1)
+        actions = torch.as_tensor(np.asarray([e["action"] for e in batches], dtype=np.float32), device=d)  # one-hot rows / action vectors
+        old_logpi = torch.as_tensor(np.asarray([e["log_prob"] for e in batches], dtype=np.float32), device=d).view(len(batches), -1)
         old_v = torch.as_tensor(np.asarray([e["v"] for e in batches], dtype=np.float32), device=d)
-
-        v, logits = self.parameter.model(torch.as_tensor(states.astype(self.np_dtype), device=d))
-        new_logpi = (torch.log_softmax(logits, dim=-1) * actions).sum(-1, keepdim=True)  # CategoricalDist.log_prob(onehot)
-        v1 = v.view(-1)
-        losses, g_lp, g_v = self.losses_and_seeds(new_logpi, old_logpi, torch.as_tensor(adv, device=d), v1, torch.as_tensor(v_target, device=d), old_v)
+        adv_t, vt_t = torch.as_tensor(adv, device=d), torch.as_tensor(v_target, device=d)
+        out = self.parameter.model(torch.as_tensor(states.astype(self.np_dtype), device=d))
+        v1 = out[0].view(-1)
+        if self.parameter.model.continuous:
+            loc, log_scale = out[1], out[2]
+            losses, g_loc, g_ls, g_v = self.losses_and_seeds_normal(loc, log_scale, actions.view(loc.shape), old_logpi, adv_t, v1, vt_t, old_v)
+            heads, seeds = [loc, log_scale, v1], [g_loc, g_ls, g_v]
+        else:
+            new_logpi = (torch.log_softmax(out[1], dim=-1) * actions).sum(-1, keepdim=True)  # CategoricalDist.log_prob(onehot)
+            losses, g_lp, g_v = self.losses_and_seeds(new_logpi, old_logpi, adv_t, v1, vt_t, old_v)
+            heads, seeds = [new_logpi, v1], [g_lp, g_v]
         self.optimizer.zero_grad()
-        torch.autograd.backward([new_logpi, v1], [g_lp, g_v])  # the fused kernel's seeds through the network
+        torch.autograd.backward(heads, seeds)  # the fused kernel's seeds through the network
         if cfg.global_gradient_clip_norm != 0:  # :269-270
             torch.nn.utils.clip_grad_norm_(self.parameter.model.parameters(), cfg.global_gradient_clip_norm)
         self.optimizer.step()
@@ -252,10 +295,29 @@ class Worker(RLWorker):
         c = self.config.state_clip
         return state if c is None else np.clip(state, c[0], c[1])
 
-    def policy(self, worker) -> int:
+    def policy(self, worker):
         state = self._clip_state(worker.state)
-        v, logits = self.parameter.pred(state[np.newaxis, ...])
-        logp = torch.log_softmax(logits, dim=-1)[0]
+        out = self.parameter.pred(state[np.newaxis, ...])
+        v = out[0]
+        if self.parameter.model.continuous:
+            loc, log_scale = out[1][0], out[2][0]
+            lo, hi = self.parameter.model.log_scale_range
+            log_scale = torch.clamp(log_scale, lo, hi)
+            scale = torch.exp(log_scale)
+            action = loc + scale * torch.randn_like(loc) if self.training else loc  # NormalDist.sample / mean (:316-319)
+            logp = -0.5 * math.log(2 * math.pi) - log_scale - 0.5 * ((action - loc) / scale) ** 2  # normal_dist_block.py:13-20
+            a_np = action.cpu().numpy().astype(np.float32)
+            self.recent_batch.append({
+                "state": state,
+                "action": a_np,
+                "v": float(v.item()),
+                "log_prob": np.maximum(logp.cpu().numpy().astype(np.float32), math.log(1e-6)),  # :322
+            })
+            if np.isnan(a_np).any():  # :333-335
+                return self.config.action_space.sample()
+            env_action = self.config.action_space.rescale_from(a_np)  # the policy's [-1, 1] onto the environment's bounds (:336)
+            return self.config.action_space.sanitize(env_action)
+        logp = torch.log_softmax(out[1], dim=-1)[0]
         if self.training:
             a = int(torch.multinomial(torch.exp(logp), 1).item())  # CategoricalDist.sample (:301)
         else:
@@ -293,7 +355,7 @@ class Worker(RLWorker):
         elif cfg.experience_collection_method == "GAE":  # :395-410
             d = self.parameter.device
             states = np.asarray([e["state"] for e in self.recent_batch], dtype=self.parameter.np_dtype)
-            v, _ = self.parameter.pred(states)
+            v = self.parameter.pred(states)[0]
             # the scan bootstraps step t with V(s_t+1) = v[t+1] inside an episode; the reference evaluates the network
             # on the stored next states, which ARE the following states (:396-397), and drops the bootstrap at the end
             rew = torch.as_tensor(np.asarray(self.recent_rewards, dtype=np.float32), device=d).view(T, 1)

@@ -108,10 +108,19 @@ class RLConfig(ABC):
             return
         np_dtype = self.get_dtype("np")
         act = env.action_space
-        if not isinstance(act, DiscreteSpace) or self.get_base_action_type() != RLBaseTypes.DISCRETE:
-            raise NotSupportedError(f"only discrete actions are on the hot path (got {act}, {self.get_base_action_type()})")
+        base_act = self.get_base_action_type()
         self._env_act_space = act.copy()
-        self._rl_act_space = act.copy()
+        if isinstance(act, DiscreteSpace) and base_act & RLBaseTypes.DISCRETE:
+            self._rl_act_space = act.copy()
+            self._act_mode = "discrete"
+        elif isinstance(act, BoxSpace) and not act.is_image_like() and base_act & RLBaseTypes.NP_ARRAY:
+            # continuous control (base_ppo.py:19): the algorithm sees a flat float vector with the environment's bounds
+            from simple_distributed_rl_amd.base.spaces.np_array import NpArraySpace
+
+            self._rl_act_space = NpArraySpace(int(np.prod(act.shape)), act.low.reshape(-1), act.high.reshape(-1), np.float32)
+            self._act_mode = "np_array"
+        else:
+            raise NotSupportedError(f"action space {act} is not served by this algorithm ({base_act})")
 
         obs = env.observation_space.copy()
         self._env_obs_space = obs
@@ -182,9 +191,13 @@ class RLConfig(ABC):
         return np.asarray(env_state, dtype=self.get_dtype("np"))
 
     def action_encode(self, env_action):
+        if getattr(self, "_act_mode", "discrete") == "np_array":
+            return np.asarray(env_action, np.float32).reshape(-1)
         return int(env_action)
 
     def action_decode(self, rl_action):
+        if getattr(self, "_act_mode", "discrete") == "np_array":
+            return np.asarray(rl_action, self._env_act_space.dtype).reshape(self._env_act_space.shape)
         return int(rl_action)
 
     # ---- factories (config.py:653-697) --------------------------------------------------------------

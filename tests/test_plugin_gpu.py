@@ -213,3 +213,46 @@ def test_train_mp_dqn_cartpole_on_gpu():
     assert st.train_count >= 4000 and st.end_reason == "max_train_count over." and st.trainer_recv_q > 4000
     rewards = runner.evaluate(max_episodes=10, enable_progress=False)
     assert np.mean(rewards) > 50, rewards
+
+
+def test_ppo_plugin_continuous_pendulum():
+    """"PPO:torch" with a continuous action space (BASELINE.json configs[4] shapes through the plugin surface): the space
+    negotiation hands the algorithm an NpArraySpace with the environment's bounds, the Normal-policy loss of the trainer
+    (`srlx_ppo_loss_normal`) equals the oracle's restatement, actions reach the environment inside its bounds, and
+    Pendulum-v1 improves far beyond the untrained policy (about -1450 per episode)."""
+    sys.path.insert(0, ROOT)
+    from oracle import hot_path_oracle as O
+    from simple_distributed_rl_amd.algorithms import ppo
+    from simple_distributed_rl_amd.base.spaces.np_array import NpArraySpace
+    from simple_distributed_rl_amd.utils.common import set_seed
+
+    set_seed(1, enable_gpu=True)
+    rl = ppo.Config(batch_size=64, lr=0.001, train_num=20, discount=0.95, gae_discount=0.9, entropy_weight=0.001, baseline_type="advantage")
+    rl.memory.warmup_size = 1000
+    rl.lr_scheduler.set_constant()
+    runner = srl.Runner("Pendulum-v1", rl)
+    runner.set_device("cuda:0")
+    runner.train(max_train_count=1500, enable_progress=False)
+    space = runner.rl_config.action_space if hasattr(runner, "rl_config") else rl.action_space
+    assert isinstance(space, NpArraySpace) and space.size == 1 and float(space.low[0]) == -2.0 and float(space.high[0]) == 2.0
+    a = space.sanitize(space.rescale_from(np.array([3.0], np.float32)))
+    assert a.shape == (1,) and float(a[0]) == 2.0  # a policy output beyond [-1, 1] is clipped onto the torque bound
+
+    trainer = runner.trainer
+    dev = trainer.device
+    rng = np.random.default_rng(2)
+    B, D = 48, 1
+    T = lambda x: torch.tensor(np.asarray(x, np.float32), device=dev)  # noqa: E731
+    loc, ls, act = rng.standard_normal((B, D)), 0.3 * rng.standard_normal((B, D)) - 0.5, rng.standard_normal((B, D))
+    olp, adv, v, vt = -np.abs(rng.standard_normal((B, D))) - 0.2, rng.standard_normal(B), rng.standard_normal(B), rng.standard_normal(B)
+    ov = v + 0.3 * rng.standard_normal(B)
+    losses, g_loc, g_ls, g_v = trainer.losses_and_seeds_normal(T(loc), T(ls), T(act), T(olp), T(adv), T(v), T(vt), T(ov))
+    lo, hi = runner.parameter.model.log_scale_range
+    new_lp = O.normal_logprob(np.float32(act), np.float32(loc), np.clip(np.float32(ls), np.float32(lo), np.float32(hi)))
+    want = O.ppo_loss(new_lp, np.float32(olp), np.float32(adv), np.float32(v), np.float32(vt), np.float32(ov), True, True, rl.policy_clip_range, True,
+                      rl.value_clip_range, rl.value_loss_weight, rl.entropy_weight)
+    np.testing.assert_allclose(losses.cpu().numpy(), np.asarray(want, np.float32), rtol=1e-5, atol=1e-7)
+    assert np.isfinite(g_loc.cpu().numpy()).all() and np.isfinite(g_ls.cpu().numpy()).all() and np.isfinite(g_v.cpu().numpy()).all()
+
+    rewards = runner.evaluate(max_episodes=5, enable_progress=False)
+    assert np.mean(rewards) > -900, rewards

@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- Rainbow 84x84x4 actor/learner throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of synthetic input on every rank:
+One "step" = one pass of the hot path over one batch of synthetic input on every rank: `--inner` (default 64)
+lock-steps, in each of which
     E lock-stepped synthetic Atari-shaped environments advance one step
         (frame-stack -> Q-network -> epsilon-greedy -> env -> ring commit -> PER add), and
     U full Rainbow learner updates run (PER sample B=32 -> n-step gather -> forwards -> fused
-        TD/Huber/priority kernel -> backward -> Adam -> PER update) against a 1M-transition PER.
+        TD/Huber/priority kernel -> backward -> Adam -> PER update) against a 1M-transition PER,
+i.e. a batch of 64 x 1024 transitions per GPU, so that even `--steps 20` times about a second of GPU work.
 `value` = whole-job env-steps/s; learner updates/s is reported next to it.  All inputs (frame ring,
 sum-tree, networks) are resident in HBM before the timed region.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 20 --warmup 2
+    python bench.py --gpus 8                       # no launcher: spawns the 8 ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -30,9 +33,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=1024, help="environments per GPU (E)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--inner", type=int, default=64, help="lock-steps per bench step (one step = inner x E transitions per GPU)")
+    ap.add_argument("--envs", type=int, default=1024, help="environments per actor GPU (E); with --scaling strong: of the WHOLE job")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --envs environments on every actor GPU; strong: --envs environments split over the actor GPUs")
     ap.add_argument("--updates", type=int, default=1, help="learner updates per step on the learner rank (U); 1 balances actor and learner time at E=1024")
     ap.add_argument("--capacity", type=int, default=1_000_000)
     ap.add_argument("--batch-size", type=int, default=32)
@@ -42,7 +48,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
-    ap.add_argument("--per-micro", action="store_true", help="also time the bulk PER sample kernel (extra field)")
+    ap.add_argument("--no-per-micro", action="store_true", help="skip the PER micro-benchmark (sample / update / add ops/s, bulk-sample HBM fraction)")
+    ap.add_argument("--no-subfigures", action="store_true", help="skip the actor-only / learner-only timings")
     ap.add_argument("--learner-acts", choices=("auto", "yes", "no"), default="auto",
                     help="N>1: does the learner rank run actors too? auto = yes below 4 GPUs, no (dedicated learner GPU) from 4")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 code path with several ranks on ONE GPU)")
@@ -50,8 +57,32 @@ def parse_args():
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's launcher would
+    (one process per GPU over RCCL), and pass rank 0's JSON line through.  Fails loudly when the node has fewer GPUs."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if args.backend == "nccl" and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible -- refusing to measure fewer GPUs than asked "
+                         f"(use --backend gloo to rehearse the N > 1 code path with several ranks on one GPU)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -61,7 +92,7 @@ def main():
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     import torch
 
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev_index = local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(dev_index)
@@ -80,48 +111,64 @@ def main():
 
     from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
 
-    cfg = RainbowDeviceConfig(n_envs=args.envs, batch_size=args.batch_size, memory_capacity=args.capacity, seed=rank)
+    learner_acts = {"auto": None, "yes": True, "no": False}[args.learner_acts]
+    if world == 1:
+        actor_ranks = 1
+    else:
+        actor_ranks = world if (learner_acts if learner_acts is not None else world < 4) else world - 1
+    envs_per_gpu = args.envs if args.scaling == "weak" else max(1, args.envs // actor_ranks)
+    cfg = RainbowDeviceConfig(n_envs=envs_per_gpu, batch_size=args.batch_size, memory_capacity=args.capacity, seed=0)
 
     if dist is not None:
         from simple_distributed_rl_amd.device.dist import DistributedRainbow
 
         eng = DistributedRainbow(cfg, dev_index, args.episode_len, sync_interval=args.sync_interval, always_collective=args.dist_selftest,
-                                 learner_acts={"auto": None, "yes": True, "no": False}[args.learner_acts])
+                                 learner_acts=learner_acts)
+        assert eng.n_actor_ranks == actor_ranks
     else:
         eng = RainbowEngine(cfg, dev_index, args.episode_len, overlap=not args.no_overlap)
-    is_learner = rank == 0
 
     # ---- fill the replay (untimed): random-policy rollout until the ring is full, then |delta| ~ U(0,1)
     #      priorities like tests/quick/rl/memories/speedtest.py:40-41
     eng.prefill()
     torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    inner = max(1, args.inner)
+    for _ in range(max(1, args.warmup) * min(inner, 8)):  # eager lock-steps: arenas sized, MIOpen/torch caches warm
         eng.step(args.updates)
     torch.cuda.synchronize()
     if not args.no_graph:
         eng.capture_graphs()
-        for _ in range(2):  # untimed: the first replay of a freshly captured graph instantiates it (tens of ms), whatever --warmup was
+        for _ in range(2):  # the first replay of a freshly captured graph instantiates it (tens of ms)
             eng.step(args.updates)
         torch.cuda.synchronize()
+    for _ in range(args.warmup * inner):
+        eng.step(args.updates)
+    torch.cuda.synchronize()
 
     # HIP events around the actors' network pass (the dominant kernel group) and, inside it, around the two launches of the
-    # dominant single kernel (k_gemm<AConv>: conv2 + conv3), all on the stream they are launched on
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # dominant single kernel (conv2 + conv3), all on the stream they are launched on; every 4th lock-step is probed
+    n_lock = args.steps * inner
+    probe_every = 4
+    n_probe = (n_lock + probe_every - 1) // probe_every
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe)]
     local = getattr(eng, "local", eng)
     probing = bool(local.mfma) and getattr(eng, "acts", True)
-    pr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if probing else []
-    for a, b in pr:  # torch creates the underlying hipEvent_t at the first record
-        a.record()
-        b.record()
+    pr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe)] if probing else []
+    for a_, b_ in pr:  # torch creates the underlying hipEvent_t at the first record
+        a_.record()
+        b_.record()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        if probing:
-            local.inf_actor.set_probe(*pr[k])
-        eng.step(args.updates, events=ev[k])
+    for k in range(n_lock):
+        if k % probe_every == 0:
+            if probing:
+                local.inf_actor.set_probe(*pr[k // probe_every])
+            eng.step(args.updates, events=ev[k // probe_every])
+        else:
+            eng.step(args.updates)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -130,22 +177,23 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        eng.flush()
 
-    ev_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-    conv_ms = sum(a.elapsed_time(b) for a, b in pr) / len(pr) if probing else 0.0
+    ev_ms = sum(a_.elapsed_time(b_) for a_, b_ in ev) / len(ev)
+    conv_ms = sum(a_.elapsed_time(b_) for a_, b_ in pr) / len(pr) if probing else 0.0
     if dist is not None:  # a learner-only rank 0 runs no actor pass: report the slowest actor rank's
         t = torch.tensor([ev_ms, conv_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ev_ms, conv_ms = float(t[0].item()), float(t[1].item())
+    rccl_ranks = dist.get_world_size() if (dist is not None and args.backend == "nccl") else (1 if dist is None else 0)
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    actor_gpus = world if dist is None else eng.n_actor_ranks
-    env_steps = args.steps * args.envs * actor_gpus
-    updates = args.steps * args.updates
+    env_steps = n_lock * envs_per_gpu * actor_ranks
+    updates = n_lock * args.updates
     info = eng.info()
     out = {
         "metric": "env-steps/sec + learner updates/sec, Rainbow 84x84x4",
@@ -156,15 +204,20 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "learner_updates_per_s": updates / elapsed,
+        "ms_per_lock_step": 1e3 * elapsed / n_lock,
+        "rccl_ranks": rccl_ranks,
         "config": {
             "workload": "Rainbow on synthetic 84x84x4 Atari frames, PER 1M transitions, n-step=3 (BASELINE.json configs[2])",
-            "envs_per_gpu": args.envs,
-            "learner_updates_per_step": args.updates,
+            "lock_steps_per_step": inner,
+            "transitions_per_step": inner * envs_per_gpu * actor_ranks,
+            "envs_per_gpu": envs_per_gpu,
+            "envs_total": envs_per_gpu * actor_ranks,
+            "learner_updates_per_lock_step": args.updates,
             "batch_size": args.batch_size,
             "per_capacity": eng.replay.capacity,
             "n_step": cfg.multisteps,
@@ -173,18 +226,20 @@ def main():
             "noisy_dense": cfg.enable_noisy_dense,
             "epsilon": cfg.epsilon,
             "hip_graphs": not args.no_graph,
-            "untimed_steps_after_graph_capture": 0 if args.no_graph else 2,
-            "qnet": ("libsrlx: fp32 MFMA forward, hand-written backward (no autograd)" if getattr(eng, "mfma_train", False) else "libsrlx fp32 MFMA forward, torch autograd backward") if eng.mfma else "torch",
+            "qnet": ("libsrlx: fp32 MFMA forward, hand-written backward (no autograd)" if getattr(local, "mfma_train", False) else "libsrlx fp32 MFMA forward, torch autograd backward") if eng.mfma else "torch",
             "actor_learner_overlap": (not args.no_overlap) if dist is None else True,
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "backend": "none" if dist is None else args.backend,
             "topology": "1 GPU: actor+learner" if dist is None else (f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast" if eng.learner_acts
                          else f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology), RCCL gather/broadcast"),
-            "actor_gpus": actor_gpus,
+            "actor_gpus": actor_ranks,
         },
         "roofline": roofline(eng, ev_ms, conv_ms),
         "final": {"loss": info["loss"], "train_count": info["train_count"], "memory": info["memory"]},
     }
-    if args.per_micro:
+    if dist is None and not args.no_subfigures:
+        out["subfigures"] = subfigures(eng, args, inner)
+    if not args.no_per_micro:
         out["per_micro"] = per_micro(eng)
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other runs would only repeat it
         out["cpu_baseline"] = cpu_baseline(args, cfg)
@@ -196,6 +251,37 @@ def main():
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(out), flush=True)
+
+
+def subfigures(eng, args, inner):
+    """The two halves of a lock-step on their own (same engine, same graphs, idle GPU otherwise): actors only (no updates
+    forked) and learner updates only (back to back on the learner's stream)."""
+    import torch
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    reps = max(64, inner)
+    t_act = timed(lambda: eng.step(0), reps)
+    if eng.overlap:
+        def upd():
+            eng.fork_learner(1)
+            eng.join_learner()
+    else:
+        upd = eng.learner_step
+    t_upd = timed(upd, reps)
+    return {
+        "actors_only": {"ms_per_lock_step": 1e3 * t_act, "env_steps_per_s": eng.cfg.n_envs / t_act},
+        "learner_only": {"ms_per_update": 1e3 * t_upd, "updates_per_s": 1.0 / t_upd},
+        "note": "the timed region runs both concurrently (actor pass on the main stream, updates on the learner's streams)",
+    }
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= the fp32 vector peak)

@@ -185,6 +185,17 @@ int srlx_policy_epsilon_greedy(int64_t n_envs, int n_actions, const float *d_q, 
 int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, float *d_rewards, uint8_t *d_terminated,
                         uint8_t *d_done, void *stream);
 
+/* Episode ledger of E device-resident environments, one call per lock-step BEFORE the commit.
+ * Replaces the per-step host bookkeeping of srl/base/env/env_run.py:334-352 (step counter, episode reward sums) and
+ * srl/base/run/core_play.py:200-214 (episode_rewards_list / last_episode_* at episode end).
+ *   d_skip      uint8 [E] or NULL: lanes that did not take an environment step in this lock-step (the store's
+ *               needs_reset view: they only received the first frame of their next episode)
+ *   d_ep_return float32 [E], d_ep_len int32 [E]: running return / length of every environment (caller zeroes them once)
+ *   d_ring      float32 [ring_cap][2]: (return, length) of finished episodes, appended in environment order
+ *   d_totals    32 bytes: int64 episodes finished, int64 environment steps, float64 sum of returns, int64 sum of lengths */
+int srlx_episode_account(int64_t n_envs, const float *d_rewards, const uint8_t *d_done, const uint8_t *d_skip, float *d_ep_return,
+                         int32_t *d_ep_len, float *d_ring, int64_t ring_cap, void *d_totals, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Fused learner arithmetic
  *

@@ -83,6 +83,7 @@ SIGNATURES = {
     "srlx_qnet_backward_u8": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_qnet_forward_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p]),
     "srlx_policy_epsilon_greedy": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_episode_account": (c_int, [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "srlx_synth_env_step": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_nstep_td_huber_priority": (
         c_int,

@@ -1,9 +1,16 @@
-"""Tabular Q-learning (srl/algorithms/ql.py:29-189): BASELINE config 1, the CPU plumbing check of the
-Runner / Config / Worker / Trainer / Memory surface (no device work: a dict Q-table stored as JSON)."""
+"""Tabular Q-learning, registered as "QL" -- BASELINE.json configs[0]: the CPU plumbing check of the
+Runner / Config / Worker / Trainer / Memory surface (there is no device work in it).
+
+Behaviour follows srl/algorithms/ql.py:29-189: a table `Q[state string] -> [value per action]`, created lazily
+per `q_init`, invalid actions pinned to -inf when they are first seen as a successor's mask, one TD(0) update
+and one `train_count` per stored transition, epsilon-greedy with random tie-breaking, parameter backup as the
+JSON text of the table (the reference's wire format, :90-95).  Written around a `QTable` value object so that
+the update rule reads as arithmetic on rows rather than dictionary plumbing."""
 import json
+import math
 import random
 from dataclasses import dataclass, field
-from typing import Any, List
+from typing import Any, Dict, Iterable, List
 
 import numpy as np
 
@@ -11,7 +18,7 @@ from simple_distributed_rl_amd.base.rl.algorithms.base_ql import RLConfig, RLWor
 from simple_distributed_rl_amd.base.rl.parameter import RLParameter
 from simple_distributed_rl_amd.base.rl.registration import register
 from simple_distributed_rl_amd.base.rl.trainer import RLTrainer
-from simple_distributed_rl_amd.rl import functions as funcs
+from simple_distributed_rl_amd.rl.functions import get_random_max_index
 from simple_distributed_rl_amd.rl.memories.single_use_buffer import RLSingleUseBuffer
 from simple_distributed_rl_amd.rl.schedulers.scheduler import SchedulerConfig
 
@@ -24,7 +31,7 @@ class Config(RLConfig):
     lr: float = 0.1
     lr_scheduler: SchedulerConfig = field(default_factory=lambda: SchedulerConfig())
     discount: float = 0.9
-    q_init: str = ""  # "", "random", "normal"
+    q_init: str = ""  # "" (zeros) | "random" (U[0,1) from `random`) | "normal" (N(0,1) from numpy)
 
     def get_name(self) -> str:
         return "QL"
@@ -37,28 +44,43 @@ class Memory(RLSingleUseBuffer):
     pass
 
 
+class QTable(dict):
+    """state string -> list of action values; rows appear on first touch."""
+
+    def __init__(self, n_actions: int, init: str = ""):
+        super().__init__()
+        self.n_actions, self.init = n_actions, init
+
+    def _fresh(self) -> List[float]:
+        if self.init == "random":
+            return [random.random() for _ in range(self.n_actions)]
+        if self.init == "normal":
+            return [float(np.random.normal()) for _ in range(self.n_actions)]
+        return [0.0] * self.n_actions
+
+    def row(self, key: str, forbid: Iterable[int] = ()) -> List[float]:
+        r = self.get(key)
+        if r is None:
+            r = self[key] = self._fresh()
+        for a in forbid:
+            r[a] = -math.inf
+        return r
+
+
 class Parameter(RLParameter):
     def setup(self):
-        self.Q = {}
+        self.Q = QTable(self.config.action_space.n, self.config.q_init)
 
-    def call_restore(self, data: Any, **kwargs) -> None:
-        self.Q = json.loads(data)
-
-    def call_backup(self, **kwargs):
+    def call_backup(self, **kwargs) -> str:
         return json.dumps(self.Q)
 
+    def call_restore(self, data: Any, **kwargs) -> None:
+        table = QTable(self.config.action_space.n, self.config.q_init)
+        table.update(json.loads(data))
+        self.Q = table
+
     def get_action_values(self, state: str, update_invalid_actions: list = []) -> List[float]:
-        if state not in self.Q:
-            n = self.config.action_space.n
-            if self.config.q_init == "random":
-                self.Q[state] = [random.random() for _ in range(n)]
-            elif self.config.q_init == "normal":
-                self.Q[state] = [np.random.normal() for _ in range(n)]
-            else:
-                self.Q[state] = [0.0 for _ in range(n)]
-        for a in update_invalid_actions:
-            self.Q[state][a] = -np.inf
-        return self.Q[state]
+        return self.Q.row(state, update_invalid_actions)
 
 
 class Trainer(RLTrainer):
@@ -66,40 +88,40 @@ class Trainer(RLTrainer):
         self.lr_sch = self.config.lr_scheduler.create(self.config.lr)
 
     def train(self) -> None:
-        batches = self.memory.sample()
-        if batches is None:
+        transitions = self.memory.sample()
+        if transitions is None:
             return
-        td_error = 0
+        table, gamma = self.parameter.Q, self.config.discount
         lr = self.lr_sch.update(self.train_count).to_float()
-        for state, n_state, action, reward, done, next_invalid_actions in batches:
-            target_q = reward
-            if not done:
-                target_q += self.config.discount * max(self.parameter.get_action_values(n_state, next_invalid_actions))
-            td_error = target_q - self.parameter.get_action_values(state)[action]
-            self.parameter.Q[state][action] += lr * td_error
+        delta = 0.0
+        for s, s_next, a, r, is_terminal, masked_next in transitions:
+            bootstrap = 0.0 if is_terminal else gamma * max(table.row(s_next, masked_next))
+            values = table.row(s)
+            delta = (r + bootstrap) - values[a]
+            values[a] += lr * delta
             self.train_count += 1
-        self.info["size"] = len(self.parameter.Q)
-        self.info["td_error"] = td_error
-        self.info["lr"] = lr
+        self.info.update(size=len(table), td_error=delta, lr=lr)
 
 
 class Worker(RLWorker):
     def on_setup(self, worker, context) -> None:
         self.epsilon_sch = self.config.epsilon_scheduler.create(self.config.epsilon)
 
+    def _key(self, observation) -> str:
+        return self.config.observation_space.to_str(observation)
+
     def policy(self, worker) -> int:
-        self.state = self.config.observation_space.to_str(worker.state)
-        epsilon = self.epsilon_sch.update(self.step_in_training).to_float() if self.training else self.config.test_epsilon
-        if random.random() < epsilon:
-            action = random.choice([a for a in range(self.config.action_space.n) if a not in worker.invalid_actions])
+        self.state = self._key(worker.state)
+        masked = worker.invalid_actions
+        if self.training:
+            eps = self.epsilon_sch.update(self.step_in_training).to_float()
         else:
-            action = funcs.get_random_max_index(self.parameter.get_action_values(self.state), worker.invalid_actions)
-        self.info["epsilon"] = epsilon
-        return action
+            eps = self.config.test_epsilon
+        self.info["epsilon"] = eps
+        if random.random() < eps:
+            return random.choice([a for a in range(self.config.action_space.n) if a not in masked])
+        return get_random_max_index(self.parameter.Q.row(self.state), masked)
 
     def on_step(self, worker):
-        if not self.training:
-            return
-        self.memory.add(
-            [self.state, self.config.observation_space.to_str(worker.next_state), worker.action, worker.reward, worker.terminated, worker.next_invalid_actions]
-        )
+        if self.training:
+            self.memory.add([self.state, self._key(worker.next_state), worker.action, worker.reward, worker.terminated, worker.next_invalid_actions])

@@ -1,10 +1,20 @@
-"""WorkerRun: drives one RLWorker against one EnvRun (srl/base/rl/worker_run.py:24-610).
+"""WorkerRun: what a plugin `RLWorker` sees of one seat of one host environment.
 
-Kept semantics: state shifting prev_state/state/next_state with the on_step view (:104-130), frame stacking
-over `window_length` one-step states that start as the space default (:277,316-322), invalid-action
-tracking, reward shift/scale (:346), lazy `on_step` -- the plugin's on_step for step t runs inside the
-NEXT policy() call, or immediately when the episode ended (:310-358,375-401) -- and the bounded tracking
-ring (:548-610).  Rendering is out of scope."""
+Interface of srl/base/rl/worker_run.py:24-672 (the attribute and method names below are what algorithm plugins
+call: `worker.state`, `worker.next_state`, `worker.reward`, `worker.add_tracking(...)`, ...).  The mechanics are
+this package's own, split into three small parts:
+
+    _Lagged        a value with one step of history -- observation, invalid actions and action each are one
+    _FrameWindow   the `window_length` most recent one-step observations (bounded deque; the reference shifts a list)
+    _TrackingRing  the bounded per-episode record ring behind add_tracking / get_trackings
+
+Timing contract kept from the reference (worker_run.py:310-401): the plugin's `on_step` for transition t is
+delivered lazily, at the start of the NEXT `policy()` call -- or at once when the environment reports the end
+of the episode -- and while it runs the views shift by one step (`state` is the observation the action was
+chosen in, `next_state` the one it led to).  The device engine does not use this class: its E environments
+keep their frame history in the HBM frame ring (device/replay.py) and never build a stacked observation.
+"""
+from collections import deque
 from typing import Any, Dict, List, Optional
 
 from simple_distributed_rl_amd.base.context import RunContext, RunState
@@ -12,160 +22,160 @@ from simple_distributed_rl_amd.base.define import DoneTypes
 from simple_distributed_rl_amd.base.exception import SRLError
 
 
+class _Lagged:
+    """`new` is the latest value, `old` the one before it."""
+
+    __slots__ = ("old", "new")
+
+    def __init__(self, initial_old, initial_new):
+        self.old, self.new = initial_old, initial_new
+
+    def push(self, value):
+        self.old, self.new = self.new, value
+
+    def view(self, delivering: bool):
+        """(previous, current, next) as the plugin sees them: shifted one step back while on_step runs."""
+        return (None, self.old, self.new) if delivering else (self.old, self.new, None)
+
+
+class _FrameWindow:
+    def __init__(self, one_step_space, length: int):
+        self._space, self._length = one_step_space, length
+        self.frames: deque = deque(maxlen=max(1, length))
+        self.clear()
+
+    def clear(self):
+        self.frames.clear()
+        self.frames.extend(self._space.get_default() for _ in range(self._length))  # zero history (worker_run.py:277)
+
+    def absorb(self, one_step_state):
+        """Newest frame in, oldest out; returns what the algorithm sees."""
+        if self._length <= 1:
+            return one_step_state
+        self.frames.append(one_step_state)
+        return self._space.encode_stack(list(self.frames))
+
+
+class _TrackingRing:
+    def __init__(self):
+        self.limit = -1
+        self.clear()
+
+    def clear(self):
+        self.rows: deque = deque(maxlen=self.limit if self.limit > 0 else None)
+        self.keys: List[str] = []
+
+    def set_limit(self, limit: int):
+        self.limit = limit
+        self.rows = deque(self.rows, maxlen=limit if limit > 0 else None)
+
+    def add(self, row: Dict[str, Any]):
+        self.keys.extend(k for k in row if k not in self.keys)
+        self.rows.append(row)
+
+    def column(self, key: str, size: Optional[int], dummy: Any) -> list:
+        col = [r.get(key, dummy) for r in self.rows]
+        if size is None:
+            return col
+        if size <= 0:
+            return []
+        return [dummy] * (size - len(col)) + col if len(col) < size else col[-size:]
+
+    def table(self, keys: Optional[List[str]], size: int, padding: dict, pad_at: str) -> list:
+        keys = self.keys if keys is None else keys
+        body = [[r.get(k) for k in keys] for r in self.rows]
+        if size <= 0:
+            return body
+        missing = size - len(body)
+        if missing <= 0:
+            return body[-size:]
+        filler = [[padding.get(k) for k in keys] for _ in range(missing)]
+        if pad_at == "head":
+            return filler + body
+        if pad_at == "tail":
+            return body + filler
+        raise ValueError(pad_at)
+
+
 class WorkerRun:
     def __init__(self, worker, env):
         worker.config.setup(env, enable_log=False)
         worker._set_worker_run(self)
-        self._worker = worker
-        self._config = worker.config
-        self._env = env
+        self._worker, self._config, self._env = worker, worker.config, env
         self._is_setup = False
-        self._setup_val(RunContext(), RunState())
-        self._reset_val(0)
+        self._context, self._run_state = RunContext(), RunState()
+        self._step_in_training = 0
+        self._tracking = _TrackingRing()
+        self._window = _FrameWindow(self._config.observation_space_one_step, self._config.window_length)
+        self._begin_episode(0, None)
 
-    # ---- properties ---------------------------------------------------------------------------
-    @property
-    def worker(self):
-        return self._worker
+    # ---- who / where ----------------------------------------------------------------------------
+    worker = property(lambda self: self._worker)
+    config = property(lambda self: self._config)
+    env = property(lambda self: self._env)
+    context = property(lambda self: self._context)
+    run_state = property(lambda self: self._run_state)
+    info = property(lambda self: self._worker.info)
+    player_index = property(lambda self: self._seat)
+    episode_seed = property(lambda self: self._episode_seed)
+    distributed = property(lambda self: self._context.distributed)
+    training = property(lambda self: self._context.training)
+    train_only = property(lambda self: self._context.train_only)
+    rollout = property(lambda self: self._context.rollout)
+    actor_id = property(lambda self: self._context.actor_id)
+    train_count = property(lambda self: self._run_state.train_count)
+    step_in_training = property(lambda self: self._step_in_training)
+    step_in_episode = property(lambda self: self._step_in_episode)
 
-    @property
-    def config(self):
-        return self._config
-
-    @property
-    def env(self):
-        return self._env
-
-    @property
-    def context(self) -> RunContext:
-        return self._context
-
-    @property
-    def distributed(self) -> bool:
-        return self._context.distributed
-
-    @property
-    def training(self) -> bool:
-        return self._context.training
-
-    @property
-    def train_only(self) -> bool:
-        return self._context.train_only
-
-    @property
-    def rollout(self) -> bool:
-        return self._context.rollout
-
-    @property
-    def actor_id(self) -> int:
-        return self._context.actor_id
-
-    @property
-    def player_index(self) -> int:
-        return self._player_index
-
-    @property
-    def info(self) -> dict:
-        return self._worker.info
-
-    @property
-    def run_state(self) -> RunState:
-        return self._run_state
-
-    @property
-    def train_count(self) -> int:
-        return self._run_state.train_count
-
-    # inside on_step the views shift by one step (:104-130)
-    @property
-    def prev_state(self):
-        return None if self._on_step_in_progress else self._prev_state
-
-    @property
-    def state(self):
-        return self._prev_state if self._on_step_in_progress else self._state
-
-    @property
-    def next_state(self):
-        return self._state if self._on_step_in_progress else None
+    # ---- the transition as the plugin sees it ---------------------------------------------------
+    prev_state = property(lambda self: self._obs.view(self._delivering)[0])
+    state = property(lambda self: self._obs.view(self._delivering)[1])
+    next_state = property(lambda self: self._obs.view(self._delivering)[2])
+    prev_invalid_actions = property(lambda self: self._invalid.view(self._delivering)[0])
+    invalid_actions = property(lambda self: self._invalid.view(self._delivering)[1])
+    next_invalid_actions = property(lambda self: self._invalid.view(self._delivering)[2])
+    prev_action = property(lambda self: self._act.old)
+    action = property(lambda self: self._act.new)
+    reward = property(lambda self: self._reward)
+    done_type = property(lambda self: self._env._done)
+    done = property(lambda self: self._env._done != DoneTypes.NONE)
+    terminated = property(lambda self: self._env._done == DoneTypes.TERMINATED)
+    done_reason = property(lambda self: self._env.env.done_reason)
 
     def get_state_one_step(self, idx: int = -1):
-        return self._one_states[idx] if self._use_stacked_state else self._state
-
-    @property
-    def prev_action(self):
-        return self._prev_action
-
-    @property
-    def action(self):
-        return self._action
+        return self._window.frames[idx] if self._config.window_length > 1 else self._obs.new
 
     def get_onehot_prev_action(self):
-        return self._config.action_space.get_onehot(self._prev_action)
+        return self._config.action_space.get_onehot(self._act.old)
 
     def get_onehot_action(self, action=None):
-        return self._config.action_space.get_onehot(self._action if action is None else action)
+        return self._config.action_space.get_onehot(self._act.new if action is None else action)
 
-    @property
-    def reward(self) -> float:
-        return self._reward
+    def get_valid_actions(self) -> list:
+        return self._config.action_space.get_valid_actions(self.invalid_actions)
 
-    @property
-    def done(self) -> bool:
-        return self._env._done != DoneTypes.NONE
+    def add_invalid_actions(self, invalid_actions: list, encode: bool = False) -> None:
+        extra = [self._config.action_encode(a) for a in invalid_actions] if encode else list(invalid_actions)
+        self._invalid.new = list(set(self._invalid.new) | set(extra))
 
-    @property
-    def terminated(self) -> bool:
-        return self._env._done == DoneTypes.TERMINATED
+    def sample_action(self):
+        return self._config.action_space.sample(self._invalid.new)
 
-    @property
-    def done_type(self) -> DoneTypes:
-        return self._env._done
+    def override_action(self, env_action, encode: bool = True):
+        self._act.new = self._config.action_encode(env_action) if encode else env_action
+        return self._act.new
 
-    @property
-    def done_reason(self) -> str:
-        return self._env.env.done_reason
+    def abort_episode(self):
+        self._env.abort_episode()
 
-    @property
-    def prev_invalid_actions(self) -> list:
-        return None if self._on_step_in_progress else self._prev_invalid_actions
-
-    @property
-    def invalid_actions(self) -> list:
-        return self._prev_invalid_actions if self._on_step_in_progress else self._invalid_actions
-
-    @property
-    def next_invalid_actions(self) -> list:
-        return self._invalid_actions if self._on_step_in_progress else None
-
-    @property
-    def step_in_training(self) -> int:
-        return self._step_in_training
-
-    @property
-    def step_in_episode(self) -> int:
-        return self._step_in_episode
-
-    @property
-    def episode_seed(self) -> Optional[int]:
-        return self._episode_seed
-
-    # ---- lifecycle ----------------------------------------------------------------------------
+    # ---- lifecycle ------------------------------------------------------------------------------
     def setup(self, context: Optional[RunContext] = None, render_mode: str = "", run_state: Optional[RunState] = None):
-        if context is None:
-            context = RunContext(self._env.config, self._config)
-        if run_state is None:
-            run_state = RunState()
-        self._setup_val(context, run_state)
-        self._worker.on_setup(self, context)
-        self._is_setup = True
-
-    def _setup_val(self, context: RunContext, run_state: RunState):
-        self._context = context
-        self._run_state = run_state
+        self._context = RunContext(self._env.config, self._config) if context is None else context
+        self._run_state = RunState() if run_state is None else run_state
         self._step_in_training = 0
-        self._use_stacked_state = self._config.window_length > 1
-        self._tracking_size = -1
+        self._tracking.set_limit(-1)
+        self._worker.on_setup(self, self._context)
+        self._is_setup = True
 
     def teardown(self):
         self._worker.on_teardown(self)
@@ -174,147 +184,106 @@ class WorkerRun:
     def reset(self, player_index: int, seed: Optional[int] = None) -> None:
         if not self._is_setup:
             raise SRLError("Cannot call worker.on_reset() before calling worker.setup()")
-        self._reset_val(player_index, seed)
+        self._begin_episode(player_index, seed)
 
-    def _reset_val(self, player_index: int, seed: Optional[int] = None):
-        self._player_index = player_index
-        self._episode_seed = seed
-        self._is_reset = False
+    def _begin_episode(self, seat: int, seed: Optional[int]):
+        cfg = self._config
+        self._seat, self._episode_seed = seat, seed
+        self._announced = False  # on_reset not delivered yet
+        self._delivering = False  # inside the plugin's on_step
         self._step_in_episode = 0
-        self._on_step_in_progress = False
-        obs, one = self._config.observation_space, self._config.observation_space_one_step
-        self._prev_state = obs.get_default()
-        self._state = obs.get_default()
-        self._one_states = [one.get_default() for _ in range(self._config.window_length)]
-        self._prev_action = self._config.action_space.get_default()
-        self._action = self._config.action_space.get_default()
-        self._step_reward = 0.0
+        self._obs = _Lagged(cfg.observation_space.get_default(), cfg.observation_space.get_default())
+        self._invalid = _Lagged([], [])
+        self._act = _Lagged(cfg.action_space.get_default(), cfg.action_space.get_default())
+        self._pending_reward = 0.0  # env reward accumulated since the last delivery
         self._reward = 0.0
-        self._prev_invalid_actions: list = []
-        self._invalid_actions: list = []
-        self._tracking_data: List[Dict[str, Any]] = []
-        self._tracking_keys: List[str] = []
+        self._window.clear()
+        self._tracking.clear()
 
-    def _ready_policy(self):
-        """First call of an episode -> on_reset, afterwards -> on_step (worker_run.py:310-358)."""
-        self._prev_state = self._state
-        state = self._config.state_encode_one_step(self._env.state, self._env)
-        if self._use_stacked_state:
-            del self._one_states[0]
-            self._one_states.append(state)
-            state = self._config.observation_space_one_step.encode_stack(self._one_states)
-        self._state = state
-
-        self._prev_invalid_actions = self._invalid_actions
-        self._invalid_actions = [self._config.action_encode(a) for a in self._env.get_invalid_actions(self._player_index)]
-
-        if not self._is_reset:
-            self._is_reset = True
+    def _absorb(self):
+        """Take the environment's current observation in, then tell the plugin: `on_reset` for the first
+        observation of an episode, `on_step` (with the shifted views) for every later one."""
+        cfg, env = self._config, self._env
+        self._obs.push(self._window.absorb(cfg.state_encode_one_step(env.state, env)))
+        self._invalid.push([cfg.action_encode(a) for a in env.get_invalid_actions(self._seat)])
+        if not self._announced:
+            self._announced = True
             self._worker.on_reset(self)
-        else:
-            self._reward = (self._step_reward + self._config.reward_shift) * self._config.reward_scale
-            self._step_reward = 0.0
-            self._step_in_episode += 1
-            self._step_in_training += 1
-            self._on_step_in_progress = True
+            return
+        self._reward = (self._pending_reward + cfg.reward_shift) * cfg.reward_scale  # worker_run.py:346
+        self._pending_reward = 0.0
+        self._step_in_episode += 1
+        self._step_in_training += 1
+        self._delivering = True
+        try:
             self._worker.on_step(self)
-            self._on_step_in_progress = False
+        finally:
+            self._delivering = False
 
     def policy(self):
-        self._ready_policy()
-        self._prev_action = self._action
-        self._action = None
-        self._action = self._worker.policy(self)
-        return self._config.action_decode(self._action)
+        self._absorb()
+        self._act.push(None)
+        self._act.new = self._worker.policy(self)
+        return self._config.action_decode(self._act.new)
 
     def on_step(self) -> None:
-        if not self._is_reset:
+        """Called by the loop after every env.step (also for seats that did not act)."""
+        if not self._announced:
             return
-        self._step_reward += self._env.rewards[self._player_index]
+        self._pending_reward += self._env.rewards[self._seat]
         if self._env._done != DoneTypes.NONE:
-            self._ready_policy()  # deliver the terminal state to the plugin now
+            self._absorb()  # there will be no further policy() in this episode: deliver the terminal transition now
 
-    # ---- invalid actions ------------------------------------------------------------------------
-    def get_valid_actions(self) -> list:
-        return self._config.action_space.get_valid_actions(self.invalid_actions)
-
-    def add_invalid_actions(self, invalid_actions: list, encode: bool = False) -> None:
-        if encode:
-            invalid_actions = [self._config.action_encode(a) for a in invalid_actions]
-        self._invalid_actions = list(set(self._invalid_actions + invalid_actions))
-
-    # ---- tracking ring (:548-610) -------------------------------------------------------------------
+    # ---- tracking ring (worker_run.py:548-610) --------------------------------------------------
     def set_tracking_max_size(self, max_size: int = -1):
-        self._tracking_size = max_size
+        self._tracking.set_limit(max_size)
 
     def get_tracking_length(self) -> int:
-        return len(self._tracking_data)
+        return len(self._tracking.rows)
 
     def add_tracking(self, data: Dict[str, Any]):
-        if self._tracking_size > 0 and len(self._tracking_data) == self._tracking_size:
-            del self._tracking_data[0]
-        for k in data:
-            if k not in self._tracking_keys:
-                self._tracking_keys.append(k)
-        self._tracking_data.append(data)
+        self._tracking.add(data)
 
     def get_tracking_data(self) -> List[Dict[str, Any]]:
-        return self._tracking_data
+        return list(self._tracking.rows)
 
     def get_tracking(self, key: str, size: Optional[int] = None, dummy: Any = None) -> list:
-        vals = [d.get(key, dummy) for d in self._tracking_data]
-        if size is None:
-            return vals
-        if size <= 0:
-            return []
-        if len(vals) < size:
-            return [dummy] * (size - len(vals)) + vals
-        return vals[-size:]
+        return self._tracking.column(key, size, dummy)
 
     def get_trackings(self, keys: Optional[List[str]] = None, size: int = 0, padding_data: dict = {}, padding_direct: str = "head") -> list:
-        if keys is None:
-            keys = self._tracking_keys
-        rows = [[d.get(k) for k in keys] for d in self._tracking_data]
-        if size <= 0:
-            return rows
-        if len(rows) >= size:
-            return rows[-size:]
-        pad = [[padding_data.get(k) for k in keys] for _ in range(size - len(rows))]
-        if padding_direct == "head":
-            return pad + rows
-        if padding_direct == "tail":
-            return rows + pad
-        raise ValueError(padding_direct)
+        return self._tracking.table(keys, size, padding_data, padding_direct)
 
-    # ---- backup / restore (:612-672) ----------------------------------------------------------------
+    # ---- backup / restore (worker_run.py:612-672; search-type algorithms roll a worker back) -------
+    _SNAPSHOT = ("_is_setup", "_step_in_training", "_seat", "_episode_seed", "_announced", "_step_in_episode", "_pending_reward", "_reward")
+
     def backup(self) -> Any:
         obs, one, act = self._config.observation_space, self._config.observation_space_one_step, self._config.action_space
-        return [
-            self._is_setup, self._step_in_training, self._tracking_size, self._player_index, self._episode_seed, self._is_reset,
-            self._step_in_episode, obs.copy_value(self._prev_state), obs.copy_value(self._state), [one.copy_value(s) for s in self._one_states],
-            act.copy_value(self._prev_action), act.copy_value(self._action), self._step_reward, self._reward,
-            self._prev_invalid_actions[:], self._invalid_actions[:], self._env.backup(), [d.copy() for d in self._tracking_data],
-        ]
+        return dict(
+            scalars={k: getattr(self, k) for k in self._SNAPSHOT},
+            obs=(obs.copy_value(self._obs.old), obs.copy_value(self._obs.new)),
+            frames=[one.copy_value(f) for f in self._window.frames],
+            act=(act.copy_value(self._act.old), act.copy_value(self._act.new)),
+            invalid=(list(self._invalid.old), list(self._invalid.new)),
+            tracking=(self._tracking.limit, list(self._tracking.keys), [dict(r) for r in self._tracking.rows]),
+            env=self._env.backup(),
+        )
 
-    def restore(self, d: Any):
-        (self._is_setup, self._step_in_training, self._tracking_size, self._player_index, self._episode_seed, self._is_reset,
-         self._step_in_episode, self._prev_state, self._state, self._one_states, self._prev_action, self._action, self._step_reward,
-         self._reward, self._prev_invalid_actions, self._invalid_actions, env_dat, tracking) = d
-        self._env.restore(env_dat)
-        self._tracking_data = [x.copy() for x in tracking]
-
-    # ---- utils ------------------------------------------------------------------------------
-    def sample_action(self):
-        return self._config.action_space.sample(self._invalid_actions)
-
-    def override_action(self, env_action, encode: bool = True):
-        self._action = self._config.action_encode(env_action) if encode else env_action
-        return self._action
-
-    def abort_episode(self):
-        self._env.abort_episode()
+    def restore(self, snap: Any):
+        for k, v in snap["scalars"].items():
+            setattr(self, k, v)
+        self._obs = _Lagged(*snap["obs"])
+        self._window.frames.clear()
+        self._window.frames.extend(snap["frames"])
+        self._act = _Lagged(*snap["act"])
+        self._invalid = _Lagged(list(snap["invalid"][0]), list(snap["invalid"][1]))
+        limit, keys, rows = snap["tracking"]
+        self._tracking.set_limit(limit)
+        self._tracking.clear()
+        self._tracking.keys = list(keys)
+        self._tracking.rows.extend(dict(r) for r in rows)
+        self._env.restore(snap["env"])
 
     def print_discrete_action_info(self, maxa: int, func) -> None:
-        for action in range(min(15, self._config.action_space.n)):
-            mark = "x" if action in self.invalid_actions else ("*" if action == maxa else " ")
-            print(f"{mark}{self._env.action_to_str(action):3s}: {func(action)}")
+        for a in range(min(15, self._config.action_space.n)):
+            flag = "x" if a in self.invalid_actions else ("*" if a == maxa else " ")
+            print(f"{flag}{self._env.action_to_str(a):3s}: {func(a)}")

@@ -104,7 +104,7 @@ class _ActorInterrupt(RunCallback):
 def _run_actor(cfg_blob: bytes, remote_queue, remote_qsize, board, actor_id: int, end_signal):
     try:
         from simple_distributed_rl_amd.base.env.registration import make as make_env
-        from simple_distributed_rl_amd.base.run.core_play import play
+        from simple_distributed_rl_amd.base.run.sequence import play
 
         mp_cfg: MpConfig = pickle.loads(cfg_blob)
         c = mp_cfg.context
@@ -189,7 +189,7 @@ class _TrainerInterrupt(RunCallback):
 
 
 def train(mp_cfg: MpConfig, parameter, memory):
-    from simple_distributed_rl_amd.base.run.core_train_only import play_trainer_only
+    from simple_distributed_rl_amd.base.run.sequence import play_trainer_only
 
     context = mp_cfg.context
     context.check_context_parameter()

@@ -42,6 +42,7 @@ class TransitionBus:
         self.learner_rank = learner_rank
         self.device = device
         self.is_learner = self.rank == learner_rank
+        self._pending, self._direct, self._keep = [], None, None
         if self.is_learner:
             T = self.world * self.E
             self.g_actions = torch.zeros(T, dtype=torch.int32, device=device)
@@ -56,17 +57,24 @@ class TransitionBus:
             return None
         return [buf[r * self.E : (r + 1) * self.E] for r in range(self.world)]
 
-    def push(self, actions, rewards, terminated, done, next_obs):
-        """Every rank contributes its E transitions; the learner rank gets them concatenated in rank
-        order (env index = rank * E + local index).  Returns the gathered tensors on the learner, None elsewhere."""
+    def push_begin(self, actions, rewards, terminated, done, next_obs):
+        """Start the per-step exchange: every rank contributes its E transitions, the learner rank receives them in rank order
+        (env index = rank * E + local index).  On RCCL the two gathers are issued `async_op=True`: they run on the communicator's
+        own stream once everything enqueued on the current stream so far has finished, and nothing waits for them until
+        `push_end` -- an actor rank runs its NEXT network pass meanwhile (the reference's actors likewise keep playing while
+        their items sit in the queue, srl/base/run/play_mp.py:76-118).  The caller must not overwrite the five tensors
+        before `push_end`."""
+        self._pending = []
+        self._direct = None
         if self.world == 1 and not self.always_collective:
-            return actions, rewards, terminated, done, next_obs
+            self._direct = (actions, rewards, terminated, done, next_obs)
+            return
         # two collectives per step: the frames, and ONE packed record buffer for the four scalar fields
         # ([actions 4E | rewards 4E | terminated E | done E] bytes per rank) that the learner unpacks with strided copies
-        E = self.E
         scal = torch.cat([actions.contiguous().view(torch.uint8), rewards.contiguous().view(torch.uint8), terminated.contiguous().view(torch.uint8),
                           done.contiguous().view(torch.uint8)])
-        staged = dist.get_backend(self.group) == "gloo" and actions.is_cuda  # test rigs: 2 ranks sharing one GPU
+        self._keep = (scal, next_obs)  # inputs stay alive until the collectives are done
+        staged = dist.get_backend(self.group) == "gloo" and actions.is_cuda  # test rigs: ranks sharing one GPU
         for t, name in ((scal, "g_scal"), (next_obs.contiguous(), "g_next_obs")):
             if staged:
                 parts = [torch.empty_like(t, device="cpu") for _ in range(self.world)] if self.is_learner else None
@@ -78,15 +86,31 @@ class TransitionBus:
                 if self.is_learner:
                     buf = getattr(self, name)
                     views = [buf[r] for r in range(self.world)] if name == "g_scal" else self._views(buf)
-                dist.gather(t, views, dst=self.learner_rank, group=self.group)
+                self._pending.append(dist.gather(t, views, dst=self.learner_rank, group=self.group, async_op=True))
+
+    def push_end(self):
+        """The current stream waits for the exchange started by `push_begin` (a stream-level wait on RCCL, the host does not
+        block).  Returns the gathered tensors on the learner rank, None elsewhere."""
+        if self._direct is not None:
+            out, self._direct = self._direct, None
+            return out
+        for work in self._pending:
+            work.wait()
+        self._pending = []
+        self._keep = None
         if self.is_learner:
-            g = self.g_scal
+            E, g = self.E, self.g_scal
             self.g_actions.view(torch.uint8).view(self.world, 4 * E).copy_(g[:, : 4 * E])
             self.g_rewards.view(torch.uint8).view(self.world, 4 * E).copy_(g[:, 4 * E : 8 * E])
             self.g_terminated.view(self.world, E).copy_(g[:, 8 * E : 9 * E])
             self.g_done.view(self.world, E).copy_(g[:, 9 * E :])
             return self.g_actions, self.g_rewards, self.g_terminated, self.g_done, self.g_next_obs
         return None
+
+    def push(self, actions, rewards, terminated, done, next_obs):
+        """`push_begin` + `push_end` back to back."""
+        self.push_begin(actions, rewards, terminated, done, next_obs)
+        return self.push_end()
 
     def broadcast_params(self, flat: torch.Tensor):
         if self.world <= 1 and not self.always_collective:
@@ -121,7 +145,7 @@ class DistributedRainbow:
     """world ranks x E actors, learner + replay on rank 0 (BASELINE.json config 4 topology applied to Rainbow)."""
 
     def __init__(self, cfg, device: int, episode_len: int = 200, sync_interval: int = 16, overlap: bool = True, always_collective: bool = False,
-                 learner_acts: Optional[bool] = None):
+                 learner_acts: Optional[bool] = None, env=None):
         import dataclasses
 
         from simple_distributed_rl_amd.device.rainbow import RainbowEngine, SyntheticAtariVecEnv
@@ -143,10 +167,12 @@ class DistributedRainbow:
         H, W_ = cfg.obs_hw
         pad = cfg.multisteps + cfg.window_length
         # every rank: a short local ring, only for frame stacking of its own envs (no PER use)
-        local_cfg = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62)
+        # every rank draws its environments, its exploration and its padding actions from its OWN stream: ranks acting on the
+        # same broadcast weights must not produce byte-identical transitions (the learner's replay seed stays cfg.seed)
+        local_cfg = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62, seed=cfg.seed + 1_000_003 * self.rank)
         # the learner rank overlaps its update with its own actors (second stream, private actor copy of the network),
         # exactly like the single-GPU engine; the other ranks only act
-        self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, overlap=self.is_learner and overlap)
+        self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, env=env, overlap=self.is_learner and overlap)
         self.overlap = self.is_learner and overlap
         self.flat = flatten_parameters(self.local.q_online)
         if self.local.mfma:  # the parameters moved: point the inference kernels at their new home
@@ -156,6 +182,7 @@ class DistributedRainbow:
                 self.local.optimizer.bind()
         self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective)
         self.step_count = 0
+        self._in_flight = False  # an exchange started by push_begin and not yet finished
         self.env_steps_local = 0  # environment steps taken by THIS rank's actors
         if self.is_learner:
             total = self.n_actor_ranks * E
@@ -169,7 +196,7 @@ class DistributedRainbow:
             self.replay = self.local.replay
         self.bus.broadcast_params(self.flat)
         # first observations of every env -> global ring position 0
-        obs0 = self.local.env.reset()  # same seeded frames the local ring was reset with
+        obs0 = self.local.first_obs  # the frames the local ring was reset with
         gathered = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, obs0)
         if self.is_learner:
             self.replay.reset_all(self._actor_rows(gathered)[4])
@@ -214,42 +241,80 @@ class DistributedRainbow:
                 if events is not None:
                     events[1].record()
                 eng._actor_front(obs)
-            if eng._commit_graph is not None:
-                eng._commit_graph.replay()
-                eng.replay._steps_committed += 1
-            else:
-                eng._actor_commit()
+            eng.actor_commit()
         env = eng.env
         if self.acts:
             self.env_steps_local += self.cfg.n_envs
         return self.bus.push(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
 
     def step(self, learner_updates: int = 1, events=None):
+        """One lock-step of the whole job, software-pipelined over the exchange: the transitions of lock-step t travel
+        (push_begin) while every actor rank already runs the network pass of lock-step t+1, and are committed to the global
+        replay at the start of the learner rank's next call.  Order on every rank (collectives are issued in the same order
+        everywhere): network pass -> push_end(t-1) -> [learner: join updates, commit t-1, fork updates] -> action selection +
+        environments + local ring -> push_begin(t) -> parameter broadcast every `sync_interval` steps."""
         eng = self.local
-        overlapped = self.is_learner and eng.overlap
-        if overlapped:  # the learner works on the replay as of the end of the previous step, beside this step's actors
-            main = torch.cuda.current_stream(self.dev)
-            eng._ev_fork.record(main)
-            eng.s_learner.wait_event(eng._ev_fork)
-            with torch.cuda.stream(eng.s_learner):
-                for _ in range(learner_updates):
-                    self._with_global_replay(eng.learner_step)
-                eng._ev_join.record(eng.s_learner)
-        gathered = self.actor_and_push(events)
-        self.step_count += 1
+        main = torch.cuda.current_stream(self.dev)
+        q = obs = None
+        if self.acts:  # the network pass reads the local ring only: it does not depend on the exchange in flight
+            if eng.mfma:
+                q = eng._actor_net(None, events)
+            else:
+                if events is not None:
+                    events[0].record()
+                obs = eng._actor_stack()
+                if events is not None:
+                    events[1].record()
+        elif events is not None:
+            events[0].record()
+            events[1].record()
+        gathered = self.bus.push_end() if self._in_flight else None
+        self._in_flight = False
         if self.is_learner:
-            if overlapped:
-                main.wait_event(eng._ev_join)  # the commit below is the first write to the global replay
-            self.replay.commit(*self._actor_rows(gathered))
-            if overlapped:
-                if self.acts:  # refresh the local actors' copy of the online network
-                    with torch.no_grad():
-                        torch._foreach_copy_(list(eng.q_actor.parameters()), list(eng.q_online.parameters()))
+            if self.overlap:
+                eng.join_learner()  # the previous call's updates read the replay: they finish before it changes
+            if gathered is not None:
+                self.replay.commit(*self._actor_rows(gathered))
+            if self.overlap:
+                if self.acts:  # this rank's actors act on a private copy: refresh it between two updates
+                    eng.refresh_actor_copy()
+                # updates run beside this lock-step's selection / exchange and the next network pass
+                self._with_global_replay(lambda: eng.fork_learner(learner_updates))
             else:
                 for _ in range(learner_updates):
                     self._with_global_replay(eng.learner_step)
+        if self.acts:
+            if eng.mfma:
+                if eng._select_graph is not None:
+                    eng._select_graph.replay()
+                else:
+                    eng._actor_select(q)
+            else:
+                eng._actor_front(obs)
+            eng.actor_commit()  # the local ring (frame stacking of this rank's environments)
+            self.env_steps_local += self.cfg.n_envs
+        env = eng.env
+        self.bus.push_begin(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
+        self._in_flight = True
+        self.step_count += 1
         if self.step_count % self.sync_interval == 0:
+            if self.is_learner and self.overlap:
+                eng.join_learner()  # broadcast consistent weights: not while Adam is writing them
             self.bus.broadcast_params(self.flat)
+
+    def flush(self):
+        """Commit the exchange still in flight (end of a run, before the process group goes away)."""
+        if self._in_flight:
+            gathered = self.bus.push_end()
+            self._in_flight = False
+            if self.is_learner:
+                if self.overlap:
+                    self.local.join_learner()
+                if gathered is not None:
+                    self.replay.commit(*self._actor_rows(gathered))
+        if self.is_learner and self.overlap:
+            self.local.join_learner()
+        torch.cuda.synchronize(self.dev)
 
     def prefill(self):
         steps = 0

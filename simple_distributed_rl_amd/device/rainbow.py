@@ -52,6 +52,7 @@ class RainbowDeviceConfig:
     # --- model (set_dqn_block + dueling (512,))
     hidden_units: int = 512
     filters: int = 32
+    dueling_type: str = "average"  # DuelingNetworkConfig: "average" | "max" | ""
     # --- engine
     obs_hw: tuple = (84, 84)
     n_actions: int = 6
@@ -117,7 +118,10 @@ class RainbowEngine:
             E, ring_len, H * W_, cfg.window_length, cfg.multisteps, cfg.n_actions, cfg.batch_size, True, cfg.enable_reward_clip,
             cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
         )
-        self.env = env if env is not None else SyntheticAtariVecEnv(self.replay, episode_len)
+        if env is None:
+            self.env = SyntheticAtariVecEnv(self.replay, episode_len)
+        else:  # a ready batch environment, or a factory that needs this engine's replay (device/vector_runner.py)
+            self.env = env(self.replay) if callable(env) else env
         # Matrix-core inference (libsrlx) for every no-grad forward; noisy nets keep the torch path (their
         # per-forward Gaussian weights are not a fixed GEMM operand).
         self.mfma = not cfg.enable_noisy_dense
@@ -125,8 +129,8 @@ class RainbowEngine:
 
         def make_net():
             if self.mfma:
-                return EngineQNet(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.filters).to(self.dev)
-            return atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters).to(self.dev)
+                return EngineQNet(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.filters, cfg.dueling_type).to(self.dev)
+            return atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters, cfg.dueling_type).to(self.dev)
 
         self.q_online = make_net()
         self.q_target = make_net()
@@ -182,7 +186,10 @@ class RainbowEngine:
         self._img = (cfg.window_length, H, W_)
         self._actor_graph = None
         self._learner_graph = None
-        self.replay.reset_all(self.env.reset())
+        self._learner_pending = False
+        self.ledger = None  # optional EpisodeLedger (device/vector_runner.py): per-episode returns without leaving HBM
+        self.first_obs = self.env.reset()
+        self.replay.reset_all(self.first_obs)
 
     # ---- actor (rainbow.py:301-329 + 331-400 for E envs) --------------------------------------
     def _actor_stack(self):
@@ -224,6 +231,8 @@ class RainbowEngine:
     def _actor_commit(self):
         """ring commit + PER add of the step `_actor_front` produced (the only actor writes to the replay)."""
         e = self.env
+        if self.ledger is not None:  # before the commit: the store's needs_reset view still marks the lanes that only received a first frame
+            self.ledger.account(e.rewards, e.done, self.replay.needs_reset_ptr)
         self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs)
 
     def _actor_rest(self, obs):
@@ -360,19 +369,35 @@ class RainbowEngine:
             torch._foreach_copy_(list(self.q_target.parameters()), list(self.q_online.parameters()))
         self.sync_count += 1
 
-    def step(self, learner_updates: int = 1, events=None):
-        """One engine step: E environment steps and `learner_updates` Rainbow updates.  `events` = (start, end)
-        torch events recorded around the dominant hand-written kernel group of the actor on its launch
-        stream: the matrix-core network pass (or, on the torch path, the frame-stack kernel)."""
+    # ---- the pieces of a step (the Runner's vectorised loop drives them one by one: device/vector_runner.py) --------
+    def fork_learner(self, updates: int) -> int:
+        """overlap=True: enqueue `updates` learner updates on the learner's stream, ordered after everything enqueued on the
+        current stream so far (they see the replay as of now).  Returns how many ran (0 below the warm-up)."""
         main = torch.cuda.current_stream(self.dev)
-        if self.overlap:
-            self._ev_fork.record(main)
-            self.s_learner.wait_event(self._ev_fork)  # the learner sees the replay as of the end of the previous step
-            with torch.cuda.stream(self.s_learner):
-                for _ in range(learner_updates):
-                    self.learner_step()
-                self._ev_join.record(self.s_learner)
-        # ---- actor front: network + action selection + environments (reads the ring only)
+        self._ev_fork.record(main)
+        self.s_learner.wait_event(self._ev_fork)
+        ran = 0
+        with torch.cuda.stream(self.s_learner):
+            for _ in range(updates):
+                ran += int(self.learner_step())
+            self._ev_join.record(self.s_learner)
+        self._learner_pending = True
+        return ran
+
+    def join_learner(self):
+        """The current stream waits for the forked updates (before the next write to the replay)."""
+        if self._learner_pending:
+            torch.cuda.current_stream(self.dev).wait_event(self._ev_join)
+            self._learner_pending = False
+
+    def refresh_actor_copy(self):
+        """overlap=True: one multi-tensor copy online -> the actor's private network."""
+        if self.q_actor is not self.q_online:
+            with torch.no_grad():
+                torch._foreach_copy_(list(self.q_actor.parameters()), list(self.q_online.parameters()))
+
+    def actor_front(self, events=None):
+        """Network pass + action selection + environments of one lock-step: reads the ring, writes nothing shared."""
         if self.mfma:
             q = self._actor_net(None, events)  # 5 eager launches, bracketed by the events
             if self._select_graph is not None:
@@ -389,24 +414,34 @@ class RainbowEngine:
                 self._front_graph.replay()
             else:
                 self._actor_front(obs)
-        # ---- actor commit: the only actor writes to the replay
-        if self.overlap:
-            main.wait_event(self._ev_join)
+
+    def actor_commit(self):
+        """Ring commit + PER add of the lock-step `actor_front` produced: the only actor writes to the replay."""
         if self._commit_graph is not None:
             self._commit_graph.replay()
             self.replay._steps_committed += 1
         else:
             self._actor_commit()
         self.total_env_steps += self.cfg.n_envs
+
+    def step(self, learner_updates: int = 1, events=None):
+        """One engine step: E environment steps and `learner_updates` Rainbow updates.  `events` = (start, end)
+        torch events recorded around the dominant hand-written kernel group of the actor on its launch
+        stream: the matrix-core network pass (or, on the torch path, the frame-stack kernel)."""
+        if self.overlap:  # the learner sees the replay as of the end of the previous step
+            self.fork_learner(learner_updates)
+        self.actor_front(events)
         if self.overlap:
-            with torch.no_grad():  # refresh the actor's copy of the online network (one multi-tensor copy)
-                torch._foreach_copy_(list(self.q_actor.parameters()), list(self.q_online.parameters()))
+            self.join_learner()
+        self.actor_commit()
+        if self.overlap:
+            self.refresh_actor_copy()
         else:
             for _ in range(learner_updates):
                 self.learner_step()
 
     # ---- HIP graphs -------------------------------------------------------------------------
-    def capture_graphs(self, actor: bool = True, learner: bool = True, warm_actor: bool = True):
+    def capture_graphs(self, actor: bool = True, learner: bool = True, warm_actor: bool = True, warm_learner: bool = True):
         """Captures the actor step and the learner step into HIP graphs (launch-bound inner loops).
         Call after warm-up: arenas are sized and the replay is past its warm-up gate.  `warm_actor=False` skips the
         extra eager actor step (the distributed wrapper has already stepped, and an un-pushed step would desynchronise
@@ -418,9 +453,8 @@ class RainbowEngine:
             if actor and warm_actor:
                 self.actor_step()
                 self.total_env_steps += self.cfg.n_envs
-            if learner and not self.replay.is_warmup_needed():
-                self._learner_body()
-                self.train_count += 1
+            if learner and warm_learner and not self.replay.is_warmup_needed():
+                self.learner_step()  # a real update (eager: sizes the arenas), target sync and counters included
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         if actor:

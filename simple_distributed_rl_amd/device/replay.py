@@ -97,6 +97,7 @@ class DeviceReplay:
         pos, nr, sie = N.c_p(), N.c_p(), N.c_p()
         N.check(self.lib.srlx_store_views(hs, ctypes.byref(pos), ctypes.byref(nr), ctypes.byref(sie)))
         self._views = (pos, nr, sie)
+        self.needs_reset_ptr = nr  # uint8 [E]: lanes whose next lock-step only delivers the first frame of a new episode
 
     def close(self):
         if getattr(self, "h_store", None):

@@ -237,7 +237,8 @@ class QNetwork(nn.Module):
         return self.hidden_block(self.in_block(x, channels_first=channels_first))
 
 
-def atari_qnetwork(n_actions: int, hw=(84, 84), window: int = 4, hidden: int = 512, enable_noisy_dense: bool = False, filters: int = 32):
+def atari_qnetwork(n_actions: int, hw=(84, 84), window: int = 4, hidden: int = 512, enable_noisy_dense: bool = False, filters: int = 32,
+                   dueling_type: str = "average"):
     """The network of rainbow.Config.set_atari_config (rainbow.py:116-148): DQN image block + dueling (512,) average."""
     in_block = InputImageBlock((hw[0], hw[1], window), filters=filters)
-    return QNetwork(in_block, create_dueling_hidden_block(in_block.out_size, n_actions, (hidden,), "average", "ReLU", enable_noisy_dense))
+    return QNetwork(in_block, create_dueling_hidden_block(in_block.out_size, n_actions, (hidden,), dueling_type, "ReLU", enable_noisy_dense))

@@ -7,14 +7,21 @@ parameter / memory / trainer / worker from (env_config, rl_config) and drives th
 
 Kept: train / rollout / train_only / train_mp / evaluate with the reference's keyword names, set_seed,
 set_device, save/load of parameter and memory, the RunContext handed to callbacks.  Render / play_window /
-history viewers / mlflow are out of scope."""
+history viewers / mlflow are out of scope.
+
+Where the work runs: `train()` and `train_mp()` first ask `device/vector_runner.py` whether the (environment,
+algorithm, device) triple is served by the hand-written engine -- the Rainbow family on a GPU with image frames.
+If so the same loop (`base/run/sequence.py`) is driven by the device drivers with `vector_envs` environments per
+iteration (`set_vector_envs`; "AUTO" = 1024 device-resident lanes, 64 for host-stepped environments) and the trained
+weights are written back into `runner.parameter` at the end, so `evaluate()` / `save_parameter()` see them.
+Everything else runs the registered plugin classes on one host environment, as the reference does;
+`runner.vector_reason` says why."""
 from typing import List, Optional, Union
 
 from simple_distributed_rl_amd.base.context import RunContext
 from simple_distributed_rl_amd.base.env.registration import EnvConfig
 from simple_distributed_rl_amd.base.env.registration import make as make_env_run
-from simple_distributed_rl_amd.base.run.core_play import play
-from simple_distributed_rl_amd.base.run.core_train_only import play_trainer_only
+from simple_distributed_rl_amd.base.run.sequence import play, play_trainer_only, run_sequence
 
 
 class Runner:
@@ -34,6 +41,9 @@ class Runner:
         self._trainer = None
         self._worker = None
         self.state = None
+        self._vector_actor = None
+        self._vector_envs: Union[str, int] = "AUTO"
+        self.vector_reason = ""  # why the last train() ran on the plugin path ("" = it ran on the device engine)
 
     # ---- lazy factories (runner_base.py:170-256) ----------------------------------------------------
     def make_env(self):
@@ -92,6 +102,34 @@ class Runner:
     def set_device(self, device: str = "AUTO", **kwargs):
         self.context.device = device
 
+    def set_vector_envs(self, n_envs: Union[str, int] = "AUTO"):
+        """Environments per iteration on the device engine: "AUTO", a count, or 0 to stay on the plugin path."""
+        self._vector_envs = n_envs
+
+    def _device_drivers(self, c: RunContext, with_learner: bool = True):
+        """(actor, learner) drivers of the device engine for this run, or None (reason in `vector_reason`)."""
+        if self._vector_envs == 0:
+            self.vector_reason = "set_vector_envs(0)"
+            return None
+        env = self.make_env()
+        self.setup_rl_config()
+        c.setup_device()
+        if not str(c.used_device_torch).startswith("cuda"):
+            self.vector_reason = "the run is not on a GPU device"
+            return None
+        from simple_distributed_rl_amd.device import vector_runner as vr
+
+        self.vector_reason = vr.why_not_vector(c, env, self.rl_config)
+        if self.vector_reason:
+            return None
+        lanes = self._vector_envs
+        if isinstance(lanes, str):
+            lanes = 1024 if hasattr(type(env.unwrapped), "device_vector") else 64
+        actor = self._vector_actor
+        if actor is None or actor.lanes != int(lanes):
+            actor = self._vector_actor = vr.VectorActor(env, self.rl_config, self.make_parameter(), int(lanes))
+        return actor, (vr.VectorLearner(actor) if with_learner else None)
+
     def save_parameter(self, path: str, compress: bool = True):
         self.make_parameter().save(path, compress)
 
@@ -121,7 +159,11 @@ class Runner:
                        max_memory=max_memory, players=players, shuffle_player=shuffle_player, train_interval=train_interval, train_repeat=train_repeat)
         c.play_mode, c.run_name = "train", "main"
         c.disable_trainer, c.distributed, c.training, c.train_only, c.rollout = False, False, True, False, False
-        self.state = play(c, env=self.make_env(), worker=self.make_worker(), trainer=self.make_trainer())
+        drivers = self._device_drivers(c)
+        if drivers is not None:
+            self.state = run_sequence(c, *drivers)
+        else:
+            self.state = play(c, env=self.make_env(), worker=self.make_worker(), trainer=self.make_trainer())
         return self.state
 
     def rollout(self, max_episodes: int = -1, timeout: float = -1, max_steps: int = -1, max_memory: int = -1, players: list = [],
@@ -169,6 +211,23 @@ class Runner:
         c.max_episodes = c.max_steps = c.max_memory = 0
         c.disable_trainer, c.distributed, c.training, c.train_only, c.rollout = False, True, True, False, False
         self.setup_rl_config()
+        if self._vector_envs != 0:
+            c.setup_device()
+            if str(c.used_device_torch).startswith("cuda"):
+                from simple_distributed_rl_amd.device import vector_runner as vr
+
+                self.vector_reason = vr.why_not_vector(c, self.make_env(), self.rl_config)
+                if not self.vector_reason:  # one process per GPU over RCCL (device/mp_runner.py); this process is the learner rank
+                    from simple_distributed_rl_amd.device.mp_runner import train_mp_on_engine
+
+                    lanes = self._vector_envs
+                    if isinstance(lanes, str):
+                        lanes = 1024 if hasattr(type(self.make_env().unwrapped), "device_vector") else 64
+                    self.state = train_mp_on_engine(self, c, int(lanes), actor_num, actor_devices, updates_per_step=int(kwargs.get("updates_per_step", 1)),
+                                                    sync_interval_steps=int(kwargs.get("sync_interval_steps", 16)))
+                    return self.state
+            else:
+                self.vector_reason = "the run is not on a GPU device"
         self.state = play_mp.train(
             play_mp.MpConfig(c, [], queue_capacity=queue_capacity, trainer_parameter_send_interval=trainer_parameter_send_interval,
                              actor_parameter_sync_interval=actor_parameter_sync_interval),

@@ -39,7 +39,11 @@ def _worker(rank, world, port, ret):
             t = torch.tensor(rng.integers(0, 2, E), dtype=torch.uint8)
             d = torch.tensor(rng.integers(0, 2, E), dtype=torch.uint8)
             o = torch.tensor(rng.integers(0, 256, (E, F)), dtype=torch.uint8)
-            got = bus.push(a, r, t, d, o)
+            if step == 1:  # the split form the engines use: the exchange is in flight between the two calls
+                bus.push_begin(a, r, t, d, o)
+                got = bus.push_end()
+            else:
+                got = bus.push(a, r, t, d, o)
             if rank == 0:
                 for src in range(world):
                     g = np.random.default_rng(1000 * step + src)
@@ -74,7 +78,7 @@ def _worker(rank, world, port, ret):
 def test_transition_bus_gloo_world2():
     world = 2
     port = _free_port()
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}

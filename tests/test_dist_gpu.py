@@ -41,6 +41,7 @@ def _worker(rank, world, port, ret, learner_acts=True):
         eng.capture_graphs()  # HIP graphs mid-run: must not step the local environments without pushing
         for _ in range(4):
             eng.step(learner_updates=2)
+        eng.flush()  # the exchange of the last lock-step is still in flight (software-pipelined push): commit it
         torch.cuda.synchronize()
         out = {"flat_sum": float(eng.flat.double().sum().item()), "flat_abs": float(eng.flat.double().abs().sum().item())}
         if rank == 0:
@@ -60,7 +61,7 @@ def _worker(rank, world, port, ret, learner_acts=True):
 
 
 def _spawn(world, *args):
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()  # never fork a process that has initialised HIP
     ret = mgr.dict()
     try:
         mp.spawn(_worker, args=(world, _free_port(), ret) + args, nprocs=world, join=True)
@@ -113,8 +114,11 @@ def _rccl_worker(rank, world, port, ret):
             term = (torch.rand(E, device=dev, generator=g) < 0.1).to(torch.uint8)
             done = (torch.rand(E, device=dev, generator=g) < 0.2).to(torch.uint8)
             frames = torch.randint(0, 256, (E, F), dtype=torch.uint8, device=dev, generator=g)
-            got = bus.push(actions, rewards, term, done, frames)
+            bus.push_begin(actions, rewards, term, done, frames)  # async_op gathers on the communicator's stream
+            busy = torch.randn(256, 256, device=dev, generator=g) @ torch.randn(256, 256, device=dev, generator=g)  # work that overlaps the exchange
+            got = bus.push_end()
             torch.cuda.synchronize()
+            assert busy.shape == (256, 256)
             ok = ok and all(torch.equal(a, b) for a, b in zip(got, (actions, rewards, term, done, frames)))
         flat = torch.randn(1 << 20, device=dev, generator=g)
         ref = flat.clone()
@@ -132,30 +136,50 @@ def _rccl_worker(rank, world, port, ret):
 
 
 def test_rccl_transport_calls_at_world_size_one():
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     mp.spawn(_rccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
     assert ret[0] == {"push_ok": True, "bcast_ok": True, "max": 1.25, "n": 7, "backend": "nccl"}
 
 
-@pytest.mark.parametrize("n,actor_gpus", [(2, 2), (4, 3)])
-def test_bench_multi_rank_rehearsal(n, actor_gpus):
-    """`bench.py --gpus N` under the driver's launcher with N ranks sharing the test GPU (`--backend gloo`): the whole N>1
-    bench path -- rendezvous, prefill, warm-up, graph capture, timed loop, barriers, MAX all-reduces, the JSON line and its
-    env-step accounting for both topologies (2: rank 0 acts and learns; 4: dedicated learner rank) -- minus the RCCL transport."""
+@pytest.mark.parametrize("n,actor_gpus,launcher", [(2, 2, True), (4, 3, True), (2, 2, False)])
+def test_bench_multi_rank_rehearsal(n, actor_gpus, launcher):
+    """`bench.py --gpus N` with N ranks sharing the test GPU (`--backend gloo`), under the driver's launcher and WITHOUT one
+    (bench.py then starts the ranks itself): the whole N>1 bench path -- rendezvous, prefill, warm-up, graph capture, timed loop,
+    barriers, MAX all-reduces, the JSON line and its env-step accounting for both topologies (2: rank 0 acts and learns; 4:
+    dedicated learner rank) -- minus the RCCL transport."""
     import json
     import subprocess
 
-    steps, warmup = 12, 3
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--steps", str(steps), "--warmup", str(warmup), "--envs", "128",
-           "--capacity", "100000", "--batch-size", "16"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    steps, warmup, inner = 3, 1, 4
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--steps", str(steps), "--warmup", str(warmup), "--inner", str(inner),
+             "--envs", "128", "--capacity", "100000", "--batch-size", "16", "--no-per-micro"]
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port",
+               str(_free_port())] + bench
+    else:
+        cmd = [sys.executable] + bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
     assert r.stdout.rstrip().splitlines()[-1] == lines[0]  # the JSON line is the last thing on the merged stdout of all ranks
     d = json.loads(lines[0])
-    assert d["n_gpus"] == n and d["config"]["actor_gpus"] == actor_gpus and d["scaling"] == "weak"
-    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 128 * actor_gpus) < 1e-6 * 128 * actor_gpus  # value = all actor ranks' env-steps / time
-    assert d["final"]["train_count"] == steps + warmup + 3  # one update per step (+1: graph capture, +2: untimed steps after it), on either topology
+    assert d["n_gpus"] == n and d["config"]["actor_gpus"] == actor_gpus and d["scaling"] == "weak" and d["rccl_ranks"] == 0  # gloo rehearsal: no RCCL ranks
+    per_step = inner * 128 * actor_gpus
+    assert d["config"]["transitions_per_step"] == per_step
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - per_step) < 1e-6 * per_step  # value = all actor ranks' env-steps / time
+    # one update per lock-step: eager warm-up (warmup x min(inner, 8)), graph capture (1), 2 after it, warm-up, timed region
+    assert d["final"]["train_count"] == warmup * min(inner, 8) + 1 + 2 + warmup * inner + steps * inner
     assert "cpu_baseline" not in d and d["roofline"]["avg_launch_pair_ms"] > 0 and d["roofline"]["pass"]["avg_launch_group_ms"] > 0
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """`python bench.py --gpus 8` on a smaller node over RCCL must fail loudly instead of timing one GPU."""
+    import subprocess
+
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this node really has 8 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -357,8 +357,12 @@ def roofline(eng, ev_ms, conv_ms=0.0):
 
 
 def per_micro(eng, draws=1 << 20, reps=20):
-    """Bulk PER sampling (LDS-staged multi-workgroup descent) on the benchmark's own 1M-leaf tree; the headline entry is
-    2^20 draws per call, `by_draws` shows how the fixed per-call cost amortises at 2^22 and 2^24."""
+    """PER micro-benchmark on the benchmark's own 1M-leaf tree.
+    Bulk sampling (LDS-staged multi-workgroup descent): the headline entry is 2^20 draws per call, priced with SURVEY's
+    176 algorithmic bytes per draw ((depth+1) x 8 B of tree reads + 4 B index + 4 B weight at depth 20); `state_bytes_per_draw`
+    adds what the kernel also moves (the 8 B uniform in, 8 B index out).  `ops`: the three operations at the sizes the
+    reference's speedtest uses (tests/quick/rl/memories/speedtest.py:15-58: sample 64, update 64) and the engine's add (E per
+    lock-step), device-resident arguments, HIP events around back-to-back calls."""
     import torch
 
     from simple_distributed_rl_amd import _native as N
@@ -366,18 +370,10 @@ def per_micro(eng, draws=1 << 20, reps=20):
     r = eng.replay
     d = r.dev
     depth = (2 * r.capacity - 1).bit_length() - 1
-    bytes_per_draw = (depth + 1) * 8 + 8 + 12  # tree reads + uniform in + index/weight out
+    bytes_per_draw = (depth + 1) * 8 + 4 + 4  # 176 B at depth 20
+    state_bytes_per_draw = (depth + 1) * 8 + 8 + 12
 
-    def one(n, reps):
-        u = torch.rand(n, dtype=torch.float64, device=d)
-        idx = torch.empty(n, dtype=torch.int64, device=d)
-        w = torch.empty(n, dtype=torch.float32, device=d)
-        used = torch.zeros(1, dtype=torch.int64, device=d)
-        step = torch.zeros(1, dtype=torch.int64, device=d)
-
-        def run():
-            N.check(r.lib.srlx_per_sample(r.h_per, n, 0, N.tptr(step), N.tptr(u), n, N.tptr(idx), None, N.tptr(w), N.tptr(used), 1, N.torch_stream_ptr()))
-
+    def timed(run, reps):
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -390,13 +386,44 @@ def per_micro(eng, draws=1 << 20, reps=20):
             b.record()
             torch.cuda.synchronize()
             times.append(a.elapsed_time(b) / reps)
-        ms = sorted(times)[1]
-        gbs = n * bytes_per_draw / (ms * 1e-3) / 1e9
-        return {"draws_per_call": n, "ms_per_call": ms, "draws_per_s": n / (ms * 1e-3), "algorithmic_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+        return sorted(times)[1]
 
-    out = {"kernel": "per_sample bulk (k_descend_bulk + k_compact_bulk: normalising pass, or device-wide ordered compaction when a draw is rejected)", "bytes_per_draw": bytes_per_draw}
+    def sampler(n):
+        u = torch.rand(n, dtype=torch.float64, device=d)
+        idx = torch.empty(n, dtype=torch.int64, device=d)
+        w = torch.empty(n, dtype=torch.float32, device=d)
+        used = torch.zeros(1, dtype=torch.int64, device=d)
+        step = torch.zeros(1, dtype=torch.int64, device=d)
+
+        def run():
+            N.check(r.lib.srlx_per_sample(r.h_per, n, 0, N.tptr(step), N.tptr(u), n, N.tptr(idx), None, N.tptr(w), N.tptr(used), 1, N.torch_stream_ptr()))
+
+        return run, idx
+
+    def one(n, reps):
+        ms = timed(sampler(n)[0], reps)
+        gbs = n * bytes_per_draw / (ms * 1e-3) / 1e9
+        return {"draws_per_call": n, "ms_per_call": ms, "draws_per_s": n / (ms * 1e-3), "algorithmic_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                "frac_with_state_bytes": n * state_bytes_per_draw / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    out = {"kernel": "per_sample bulk (k_descend_bulk + k_compact_bulk: normalising pass, or device-wide ordered compaction when a draw is rejected)",
+           "bytes_per_draw": bytes_per_draw, "state_bytes_per_draw": state_bytes_per_draw, "hbm_peak_GBs": HBM_PEAK_GBS}
     out.update(one(draws, reps))
     out["by_draws"] = [one(1 << 22, 10), one(1 << 24, 5)]
+    # ---- the three operations at training sizes
+    ops = {}
+    for B in (32, 64):
+        run, idx = sampler(B)
+        ms = timed(run, 200)
+        ops[f"sample_{B}"] = {"us_per_call": 1e3 * ms, "indices_per_s": B / (ms * 1e-3)}
+        pri = torch.rand(B, dtype=torch.float32, device=d)
+        ms = timed(lambda: N.check(r.lib.srlx_per_update(r.h_per, B, N.tptr(idx), N.tptr(pri), N.PRIO_F32, 1, N.torch_stream_ptr())), 200)
+        ops[f"update_{B}"] = {"us_per_call": 1e3 * ms, "updates_per_s": B / (ms * 1e-3), "algorithmic_bytes_per_index": 16 + depth * 16}
+    E = r.E
+    mask = torch.ones(E, dtype=torch.uint8, device=d)
+    ms = timed(lambda: N.check(r.lib.srlx_per_add(r.h_per, E, N.tptr(mask), N.PRIO_NONE_MASKED, 1, N.torch_stream_ptr())), 100)
+    ops[f"add_{E}"] = {"us_per_call": 1e3 * ms, "adds_per_s": E / (ms * 1e-3), "algorithmic_bytes_per_item": 16 + depth * 16 + 8}
+    out["ops"] = ops
     return out
 
 
@@ -438,10 +465,15 @@ def cpu_baseline(args, cfg):
         if best is None or t < best:
             best, cores = t, th
     torch.set_num_threads(cores)
-    cap = 100_000  # bounded: tree depth 17 instead of 20; the network dominates the CPU time anyway
+    cap = args.capacity  # the stated workload: 1M leaves, depth 20
     per = OraclePER(cap, cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, True, cfg.memory_epsilon)
-    for x in rng.random(cap):
-        per.add(float(np.sqrt(x + 1e-4)), mode=2)
+    mp0, _, _, tree0 = per.get_state()
+    leaves = np.sqrt(rng.random(cap) + 1e-4)  # |delta| ~ U(0,1) through (|delta| + eps)^0.5, as on the GPU
+    tree0[cap - 1:] = leaves
+    for i in range(cap - 2, -1, -1):  # parents = left + right (set-up only; the timed operations below are the restated ones)
+        tree0[i] = tree0[2 * i + 1] + tree0[2 * i + 2]
+    per.set_state(float(leaves.max()), cap, 0, tree0)
+    per_ops = cpu_per_ops(per, rng)
     store = H.StoreOracle(1, 4096, 84 * 84, W, n, A, True, 0)
     store.reset_all(rng.integers(0, 256, (1, 84 * 84), dtype=np.uint8))
     ratio = max(1, args.envs // max(1, args.updates))  # env steps per learner update, same as the GPU run
@@ -491,8 +523,64 @@ def cpu_baseline(args, cfg):
         "cores": cores,
         "kind": "port",
         "sample": f"{env_steps} sequential env-steps (1 env, batch-1 inference) + {updates} learner updates (B={B}, n={n}) in {el:.1f}s, "
-        f"{ratio} env-steps per update as in the GPU run; PER capacity bounded to {cap}",
+        f"{ratio} env-steps per update as in the GPU run; PER capacity {cap}",
+        "per_ops": per_ops,
     }
+
+
+def cpu_per_ops(per, rng, rounds=3000):
+    """PER operations/s of the CPU side on the same tree (the shape of tests/quick/rl/memories/speedtest.py:15-58: add, sample 64,
+    update 64 per round, each timed on its own): `port` = the C restatement (oracle/per_oracle.c, one thread); `reference` = the
+    reference's own pybind11 C++ sum-tree built by oracle/Makefile into oracle/_ref/, when that build is present."""
+    import importlib.util
+
+    import numpy as np
+
+    B = 64
+    t_add = t_s = t_u = 0.0
+    for k in range(rounds):
+        u = rng.random(B + 8)
+        td = rng.random(B).astype(np.float32)
+        t = time.perf_counter()
+        per.add(None)
+        t_add += time.perf_counter() - t
+        t = time.perf_counter()
+        _, idx, _, _ = per.sample(B, k, u)
+        t_s += time.perf_counter() - t
+        t = time.perf_counter()
+        per.update(idx, td)
+        t_u += time.perf_counter() - t
+    out = {"port": {"sample_idx_per_s": rounds * B / t_s, "update_per_s": rounds * B / t_u, "add_per_s": rounds / t_add, "threads": 1,
+                    "what": f"oracle/per_oracle.c through ctypes, capacity {per.capacity}, {rounds} x (add, sample {B}, update {B})"}}
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    so = [f for f in (os.listdir(ref_dir) if os.path.isdir(ref_dir) else []) if f.startswith("proportional_memory_cpp") and f.endswith(".so")]
+    if so:
+        try:
+            spec = importlib.util.spec_from_file_location("proportional_memory_cpp", os.path.join(ref_dir, so[0]))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            m = mod.ProportionalMemory(per.capacity, 0.5, 0.4, 1_000_000, True, 0.0001)
+            for x in rng.random(min(per.capacity, 100_000)):  # speedtest.py:40-41 warm-up
+                m.add(0, float(x))
+            r2 = rounds
+            t_add = t_s = t_u = 0.0
+            for k in range(r2):
+                td = rng.random(B).astype(np.float32)
+                t = time.perf_counter()
+                m.add(0, None)
+                t_add += time.perf_counter() - t
+                t = time.perf_counter()
+                _, _, args_ = m.sample(B, k)
+                t_s += time.perf_counter() - t
+                t = time.perf_counter()
+                m.update(args_, td)
+                t_u += time.perf_counter() - t
+            out["reference"] = {"sample_idx_per_s": r2 * B / t_s, "update_per_s": r2 * B / t_u, "add_per_s": r2 / t_add, "threads": 1,
+                                "what": "the reference's pybind11 ProportionalMemory (cpp_module/src/proportional_memory.cpp) built into oracle/_ref, "
+                                        f"capacity {per.capacity}, 100 000 warm-up adds, {r2} x (add, sample {B}, update {B})"}
+        except Exception as e:  # the checker build is optional on the GPU box
+            out["reference"] = {"error": repr(e)}
+    return out
 
 
 if __name__ == "__main__":

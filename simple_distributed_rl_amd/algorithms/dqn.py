@@ -68,10 +68,16 @@ class Memory(RLPriorityReplayBuffer):
 
 
 def build_qnetwork(config) -> QNetwork:
+    """Module trees (hence state_dict keys, hence parameter files) of the reference: DQN is in_block -> hidden_block (MLP) ->
+    `out_layer` (dqn/model_torch.py:17-29); Rainbow's dueling hidden block carries its own head (rainbow/model_torch.py:15-29)."""
+    from simple_distributed_rl_amd.rl.models.config import DuelingNetworkConfig
+
     in_block = config.input_block.create_torch_block(config)
-    hidden = config.hidden_block.create_torch_block(in_block.out_size, config.action_space.n, **(
-        dict(enable_noisy_dense=config.enable_noisy_dense) if hasattr(config, "enable_noisy_dense") else {}))
-    return QNetwork(in_block, hidden)
+    if isinstance(config.hidden_block, DuelingNetworkConfig):
+        hidden = config.hidden_block.create_torch_block(in_block.out_size, config.action_space.n, enable_noisy_dense=getattr(config, "enable_noisy_dense", False))
+        return QNetwork(in_block, hidden)
+    hidden = config.hidden_block.create_torch_block(in_block.out_size)
+    return QNetwork(in_block, hidden, torch.nn.Linear(hidden.out_size, config.action_space.n))
 
 
 class Parameter(RLParameter):

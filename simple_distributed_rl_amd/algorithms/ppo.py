@@ -75,6 +75,11 @@ class Config(RLConfig):
     reward_clip: Optional[Tuple[float, float]] = None
     enable_stable_gradients: bool = True
     stable_gradients_scale_range: tuple = (1e-10, 10)
+    #: NOT a reference field.  The reference's `Trainer.train` (ppo.py:203-205) loops `for _ in range(train_num): f = f or
+    #: self._train()`, and `or` short-circuits: after the first successful minibatch update the remaining `train_num - 1`
+    #: iterations do nothing, so ONE gradient step is taken per collected buffer before it is cleared.  False (default) keeps
+    #: exactly that; True applies all `train_num` minibatch updates per buffer (what the field name suggests).
+    train_every_epoch: bool = False
 
     def get_name(self) -> str:
         return "PPO"
@@ -197,7 +202,10 @@ class Trainer(RLTrainer):
             return
         trained = False
         for _ in range(self.config.train_num):
-            trained = self._train() or trained
+            if self.config.train_every_epoch:
+                trained = self._train() or trained
+            else:
+                trained = trained or self._train()  # the reference's short-circuit (ppo.py:203-205): one update per buffer
         if trained:
             self.memory.clear()
 
@@ -284,6 +292,8 @@ class Worker(RLWorker):
     def on_setup(self, worker, context) -> None:
         if self.distributed:
             raise NotImplementedError("NotSupported")  # ppo.py:295-297
+        if self.training and self.config.experience_collection_method == "GAE":
+            require_gpu(str(self.parameter.device))  # the episode GAE is srlx_gae_scan: it takes device pointers, there is no CPU path
         self.lib = N.lib()
 
     def on_reset(self, worker):

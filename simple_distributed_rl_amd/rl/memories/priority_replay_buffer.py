@@ -2,7 +2,10 @@
 (srl/rl/memories/priority_replay_buffer.py:17-274): warm-up gate, optional zlib+pickle item compression,
 weight dtype cast, `step` bookkeeping (sample uses the LAST update()'s step for beta, :232,250), and the
 memory selector.  "Proportional" and "Proportional_cpp" both resolve to the HBM-resident sum-tree of
-libsrlx (there is no CPU tree in this build); `set_custom` keeps working for user memories."""
+libsrlx (there is no CPU tree in this build); `set_custom` keeps working for user memories.  The demo-memory mix
+(:175-187,237-240) is kept: a uniform host ring of demonstration items supplies `max(1, int(batch_size * demo_ratio))` items of
+every batch with weight 1 (the reference appends a single weight whatever that count is and would decode an already decoded
+item under `compress`; here every demonstration item gets its weight and is decoded once)."""
 import pickle
 import zlib
 from dataclasses import dataclass, field
@@ -97,8 +100,12 @@ class PriorityReplayBuffer:
         self.dtype = dtype
         self.memory = self.cfg.create_memory(self.cfg.capacity)
         self.step = 0
-        if self.cfg.enable_demo_memory:
-            raise UndefinedError("demo memory is outside the hot path (SURVEY 8 a7)")
+        if self.cfg.enable_demo_memory:  # :175-187: a second, uniform ring of demonstration items that takes a share of every batch
+            from simple_distributed_rl_amd.rl.memories.replay_buffer import ReplayBuffer
+
+            self.demo_batch_size = max(1, int(batch_size * self.cfg.demo_ratio))
+            self.demo_memory = ReplayBuffer(self.demo_batch_size, self.cfg.capacity, self.demo_batch_size, self.cfg.compress, self.cfg.compress_level)
+            batch_size = batch_size - self.demo_batch_size
         self.batch_size = batch_size
         if not (self.cfg.warmup_size <= self.cfg.capacity):
             raise ValueError(f"assert {self.cfg.warmup_size} <= {self.cfg.capacity}")
@@ -108,9 +115,15 @@ class PriorityReplayBuffer:
             raise ValueError(f"assert {batch_size} <= {self.cfg.warmup_size}")
 
     def length(self) -> int:
-        return self.memory.length()
+        return self.memory.length() + (self.demo_memory.length() if self.cfg.enable_demo_memory else 0)
 
     def add(self, batch: Any, priority: Optional[float] = None, serialized: bool = False) -> None:
+        to_demo = self.cfg.enable_demo_memory and self.cfg.select_memory == "demo"  # :212-215
+        if to_demo:
+            if serialized:  # the demo ring has its own codec: hand it the plain item
+                batch = pickle.loads(zlib.decompress(batch) if self.cfg.compress else batch)
+            self.demo_memory.add(batch)
+            return
         if serialized:
             if not self.cfg.compress:
                 batch = pickle.loads(batch)
@@ -136,17 +149,26 @@ class PriorityReplayBuffer:
         weights = np.asarray(weights, dtype=self.dtype)
         if self.cfg.compress:
             batches = [pickle.loads(zlib.decompress(b)) for b in batches]
+        if self.cfg.enable_demo_memory:  # :237-240: demonstration items ride at the tail of the batch with weight 1
+            demo = self.demo_memory.sample(self.demo_batch_size)
+            if demo is not None:
+                batches = list(batches) + demo
+                weights = np.append(weights, np.ones(len(demo))).astype(weights.dtype)
         return batches, weights, update_args
 
     def update(self, update_args: List[Any], priorities: np.ndarray, step: int) -> None:
+        if self.cfg.enable_demo_memory:
+            priorities = priorities[: self.batch_size]  # :247-248: the demonstration tail has no priority
         self.memory.update(update_args, priorities)
         self.step = step
 
     def call_backup(self, **kwargs):
-        return [self.memory.backup(), None]
+        return [self.memory.backup(), self.demo_memory.call_backup() if self.cfg.enable_demo_memory else None]
 
     def call_restore(self, data: Any, **kwargs) -> None:
         self.memory.restore(data[0])
+        if self.cfg.enable_demo_memory and data[1] is not None:
+            self.demo_memory.call_restore(data[1])
 
 
 class RLPriorityReplayBuffer(PriorityReplayBuffer, RLMemory):

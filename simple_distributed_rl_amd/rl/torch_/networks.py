@@ -228,13 +228,16 @@ def create_mlp_hidden_block(in_size: int, out_size: int, layer_sizes: Sequence[i
 class QNetwork(nn.Module):
     """in_block -> hidden_block (rainbow/model_torch.py:15-29, dqn/model_torch.py:17-29)."""
 
-    def __init__(self, in_block: nn.Module, hidden_block: nn.Module):
+    def __init__(self, in_block: nn.Module, hidden_block: nn.Module, out_layer: nn.Module = None):
         super().__init__()
         self.in_block = in_block
         self.hidden_block = hidden_block
+        if out_layer is not None:  # DQN: a separate head module named `out_layer` (dqn/model_torch.py:24)
+            self.out_layer = out_layer
 
     def forward(self, x, channels_first: bool = False):
-        return self.hidden_block(self.in_block(x, channels_first=channels_first))
+        x = self.hidden_block(self.in_block(x, channels_first=channels_first))
+        return self.out_layer(x) if hasattr(self, "out_layer") else x
 
 
 def atari_qnetwork(n_actions: int, hw=(84, 84), window: int = 4, hidden: int = 512, enable_noisy_dense: bool = False, filters: int = 32,

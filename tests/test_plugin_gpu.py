@@ -136,7 +136,7 @@ def test_ppo_plugin_loss_matches_oracle_and_cartpole_learns():
     from simple_distributed_rl_amd.utils.common import set_seed
 
     set_seed(7, enable_gpu=True)
-    rl = ppo.Config(batch_size=64, lr=0.002, train_num=20, discount=0.98, gae_discount=0.95, entropy_weight=0.01)
+    rl = ppo.Config(batch_size=64, lr=0.002, train_num=20, discount=0.98, gae_discount=0.95, entropy_weight=0.01, train_every_epoch=True)
     rl.memory.warmup_size = 1000
     rl.lr_scheduler.set_constant()
     runner = srl.Runner("CartPole-v1", rl)
@@ -227,7 +227,7 @@ def test_ppo_plugin_continuous_pendulum():
     from simple_distributed_rl_amd.utils.common import set_seed
 
     set_seed(1, enable_gpu=True)
-    rl = ppo.Config(batch_size=64, lr=0.001, train_num=20, discount=0.95, gae_discount=0.9, entropy_weight=0.001, baseline_type="advantage")
+    rl = ppo.Config(batch_size=64, lr=0.001, train_num=20, discount=0.95, gae_discount=0.9, entropy_weight=0.001, baseline_type="advantage", train_every_epoch=True)
     rl.memory.warmup_size = 1000
     rl.lr_scheduler.set_constant()
     runner = srl.Runner("Pendulum-v1", rl)
@@ -256,3 +256,28 @@ def test_ppo_plugin_continuous_pendulum():
 
     rewards = runner.evaluate(max_episodes=5, enable_progress=False)
     assert np.mean(rewards) > -900, rewards
+
+
+def test_ppo_train_count_per_call_follows_the_reference():
+    """srl/algorithms/ppo/ppo.py:203-205: `f = f or self._train()` short-circuits, so one `train()` call on a warm buffer takes
+    exactly ONE gradient step before the buffer is cleared, whatever `train_num` says; `train_every_epoch=True` (this build's
+    documented extension) takes `train_num`.  And a GAE worker on a CPU context refuses cleanly (no host pointer reaches a kernel)."""
+    from simple_distributed_rl_amd.algorithms import ppo
+
+    for every, want in ((False, 1), (True, 7)):
+        rl = ppo.Config(batch_size=16, train_num=7, train_every_epoch=every)
+        rl.memory.warmup_size = 64
+        runner = srl.Runner("CartPole-v1", rl)
+        runner.set_device("cuda:0")
+        runner.rollout(max_memory=200, enable_progress=False)
+        trainer = runner.trainer
+        trainer.setup(runner.context)
+        assert runner.memory.length() >= 64
+        before = trainer.train_count
+        trainer.train()
+        assert trainer.train_count - before == want
+        assert runner.memory.length() == 0  # cleared after a trained call
+    cpu = srl.Runner("CartPole-v1", ppo.Config())
+    cpu.set_device("CPU")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cpu.rollout(max_steps=50, enable_progress=False)

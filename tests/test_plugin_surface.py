@@ -426,3 +426,31 @@ def test_continuous_action_negotiation_and_pendulum_env():
         obs, r, term, trunc = e.step(np.array([2.0], np.float32))
         assert abs(obs[2]) <= 8.0 and not term and not trunc
     assert e.step(np.array([0.0], np.float32))[3] is True  # truncated at 200 steps
+
+
+def test_demo_memory_mix():
+    """priority_replay_buffer.py:175-187,212-215,237-248: with enable_demo_memory a share of every batch comes from a second,
+    uniform ring that `select_memory="demo"` fills; those items ride at the tail with weight 1 and have no priority."""
+    from simple_distributed_rl_amd.rl.memories.priority_replay_buffer import PriorityReplayBuffer, PriorityReplayBufferConfig
+
+    for compress in (False, True):
+        cfg = PriorityReplayBufferConfig(100, 8, compress)
+        cfg.set_replay_buffer()
+        cfg.enable_demo_memory, cfg.demo_ratio = True, 0.25
+        mem = PriorityReplayBuffer(cfg, 8)
+        assert mem.demo_batch_size == 2 and mem.batch_size == 6
+        cfg.select_memory = "demo"
+        for i in range(5):
+            mem.add(("demo", i))
+        cfg.select_memory = "main"
+        for i in range(20):
+            mem.add(("main", i))
+        assert mem.length() == 25 and mem.memory.length() == 20
+        batches, w, args = mem.sample()
+        assert len(batches) == 8 and [b[0] for b in batches] == ["main"] * 6 + ["demo"] * 2
+        assert w.shape == (8,) and w.dtype == np.float32 and (w[6:] == 1).all()
+        mem.update(args, np.arange(8, dtype=np.float32), 3)
+        assert mem.step == 3
+        other = PriorityReplayBuffer(cfg, 8)
+        other.call_restore(mem.call_backup())
+        assert other.length() == 25 and other.demo_memory.length() == 5

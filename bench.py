@@ -308,7 +308,7 @@ def _isolated_forward_ms(eng, reps=20):
 def roofline(eng, ev_ms, conv_ms=0.0):
     """The dominant hand-written kernel, timed live with events on its launch stream: k_gemm<AConv> (the implicit-GEMM
     convolutions conv2 + conv3 of the actors' network pass, two launches per step).  `pass` = the whole pass (5 kernels)."""
-    if eng.mfma:
+    if True:
         flops = eng.actor_forward_flops()
         tf = flops / (ev_ms * 1e-3) / 1e12
         iso_ms = _isolated_forward_ms(eng)
@@ -341,19 +341,7 @@ def roofline(eng, ev_ms, conv_ms=0.0):
             }
         group.update({"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "dtype": "f32 in / f32 accumulate"})
         return group
-    nbytes = eng.stack_bytes_per_launch()
-    gbs = nbytes / (ev_ms * 1e-3) / 1e9
-    return {
-        "kernel": "k_stack_current_u8 (uint8 frame ring -> float32 [E,4,84,84] policy input)",
-        "bound": "hbm",
-        "achieved": gbs,
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": gbs / HBM_PEAK_GBS,
-        "traffic": None,
-        "bytes_per_launch": nbytes,
-        "avg_launch_ms": ev_ms,
-    }
+    raise RuntimeError("the engine has no network path besides libsrlx")
 
 
 def per_micro(eng, draws=1 << 20, reps=20):

@@ -414,6 +414,25 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
                           const float *d_grad_q, float *const *d_grads, void *stream);
 int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream);
 
+/* NoisyLinear dense layers (replaces srl/rl/torch_/modules/noisy_linear.py:26-52, the dense layers of the reference's
+ * rainbow.Config.set_atari_config(), rainbow.py:116-148): W = w_mu + w_sigma * eps, b = b_mu + b_sigma * eps, eps ~ N(0,1)
+ * independent per element, ONE draw per forward call shared by all its rows.
+ *   srlx_qnet_bind_noisy      : d_sigma[6] = sigma tensors of {fc1 weight [2*hidden][flat], fc1 bias, v2 weight, v2 bias, a2 weight,
+ *       a2 bias}, same layouts as the mu tensors given to srlx_qnet_bind (entries 6..11).  From then on every forward first
+ *       materialises the effective tensors of a fresh draw (keyed counter generator: eps is a function of (seed, draw id, tensor,
+ *       element), so the backward pass regenerates it).
+ *   srlx_qnet_redraw_rows     : re-evaluates the dense layers with ANOTHER fresh draw for rows 0, stride, 2*stride, ... of the last
+ *       forward and overwrites their q rows -- the reference's train step evaluates q_online(s_1..s_n) and q_online(s_0) in two
+ *       forward calls, i.e. under two draws (rainbow.py:220, model_torch.py:103); the backward pass then belongs to this draw.
+ *   srlx_qnet_bind_noisy_grads: gradient tensors of the six sigmas; srlx_qnet_backward_u8 fills them (d_grads[6..11] are then the
+ *       gradients of the mu tensors).
+ *   srlx_qnet_noisy_effective : copies an effective tensor (0 fc1 weight .. 5 a2 bias) into d_out (device, may be NULL) and reports
+ *       its element count and the id of the draw it holds (tests, diagnostics). */
+int srlx_qnet_bind_noisy(srlx_qnet_t *h, const float *const *d_sigma, uint64_t seed);
+int srlx_qnet_bind_noisy_grads(srlx_qnet_t *h, float *const *d_grad_sigma);
+int srlx_qnet_redraw_rows(srlx_qnet_t *h, int64_t rows, int64_t row_stride, float *d_q, void *stream);
+int srlx_qnet_noisy_effective(srlx_qnet_t *h, int which, float *d_out, int64_t *n_elems, int64_t *draw_id, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

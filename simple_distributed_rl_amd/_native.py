@@ -82,6 +82,10 @@ SIGNATURES = {
     "srlx_qnet_set_probe": (c_int, [c_p, c_p, c_p]),
     "srlx_qnet_backward_u8": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_qnet_forward_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p]),
+    "srlx_qnet_bind_noisy": (c_int, [c_p, c_p, c_u64]),
+    "srlx_qnet_bind_noisy_grads": (c_int, [c_p, c_p]),
+    "srlx_qnet_redraw_rows": (c_int, [c_p, c_i64, c_i64, c_p, c_p]),
+    "srlx_qnet_noisy_effective": (c_int, [c_p, c_int, c_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_p]),
     "srlx_policy_epsilon_greedy": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_episode_account": (c_int, [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "srlx_synth_env_step": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),

@@ -345,11 +345,14 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
 constexpr int kMaxActions = 32;
 __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial, int splits, i64 M, int hidden, const float *__restrict__ b1,
                                               const float *__restrict__ v2w, const float *__restrict__ v2b, const float *__restrict__ a2w,
-                                              const float *__restrict__ a2b, int A, int dueling, float *__restrict__ q, float *__restrict__ h1) {
+                                              const float *__restrict__ a2b, int A, int dueling, float *__restrict__ q, float *__restrict__ h1, i64 ostride,
+                                              i64 *__restrict__ draw) {
     __shared__ float red[8][kMaxActions + 1];  // one row per wave (256 or 512 threads)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const i64 m = blockIdx.x;
+    const i64 mo = m * ostride;  // row of q / h1 this sample's results go to (the partial sums are dense over the launch's rows)
     const int N1 = 2 * hidden;
+    if (draw && blockIdx.x == 0 && t == 0) draw[0] += 1;  // NoisyLinear: the draw this pass used is spent (every reader of draw[0] ran in an earlier launch)
     float v = 0.f, adv[kMaxActions];
 #pragma unroll
     for (int j = 0; j < kMaxActions; j++) adv[j] = 0.f;
@@ -375,8 +378,8 @@ __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial,
         hv = hv > 0.f ? hv : 0.f;
         ha = ha > 0.f ? ha : 0.f;
         if (h1) {  // training: the backward pass needs the hidden layer
-            h1[m * N1 + u] = hv;
-            h1[m * N1 + hidden + u] = ha;
+            h1[mo * N1 + u] = hv;
+            h1[mo * N1 + hidden + u] = ha;
         }
         v += hv * v2w[u];
 #pragma unroll
@@ -416,7 +419,7 @@ __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial,
         const float sub = dueling == 0 ? mean : (dueling == 1 ? mx : 0.f);  // "average" / "max" / "" (dueling_network.py:49-56)
 #pragma unroll
         for (int j = 0; j < kMaxActions; j++)
-            if (j < A) q[m * A + j] = v + out[j] - sub;
+            if (j < A) q[mo * A + j] = v + out[j] - sub;
     }
 }
 
@@ -516,7 +519,14 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     launch_gemm<AConv, 64, true, false>(c3, h->w3, h->b3, h->act3, B * h->OH3 * h->OW3, 2 * h->F1, 9 * 2 * h->F1, 1, st);
     if (h->probe1) SRLX_HIP(hipEventRecord(h->probe1, st));
     h->probe0 = h->probe1 = nullptr;  // one forward only
-    // FC1 split along K so that ~512 workgroups exist whatever the batch
+    SRLX_TRY(srlx_qnet_noisy_refresh(h, st));  // NoisyLinear: one noise draw per forward call (noisy_linear.py:35-52); no-op for plain layers
+    return srlx_qnet_dense_rows(h, B, 1, d_q, st);
+}
+}  // namespace
+
+// The dense layers over `rows` activation rows act3[i * stride] (i < rows): FC1 split along K so that ~512 workgroups exist whatever
+// the batch, then the head (split reduction + bias + ReLU, second layers, dueling combine) writing q / h1 rows i * stride.
+int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hipStream_t st) {
     const int N1 = 2 * h->hidden;
     const i64 tiles = ((B + BM - 1) / BM) * ((N1 + 63) / 64);
     int splits = (int)((512 + tiles - 1) / tiles);
@@ -524,17 +534,16 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     if (splits > ksteps) splits = ksteps;
     if (splits > h->max_splits) splits = h->max_splits;
     if (splits < 1) splits = 1;
-    APlain fa{h->act3, h->flat};
+    APlain fa{h->act3, (i64)h->flat * stride};
     launch_gemm<APlain, 64, false, true>(fa, h->wf, nullptr, h->partial, B, N1, h->flat, splits, st);
     const int kps = ((ksteps + splits - 1) / splits);
     const int used = (ksteps + kps - 1) / kps;  // splits that actually own a K range
     // small launches (the learner's 128 / 96 rows) are one workgroup per row and far from filling the chip: twice the threads per row
     hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(B <= 256 && h->hidden > 256 ? 512 : 256), 0, st, h->partial, used, B, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
-                       h->a2b, h->A, h->dueling, d_q, h->h1);
+                       h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, h->sig[0] ? h->d_draw : nullptr);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }
-}  // namespace
 
 // per parity class z: dXq[z][M = B*QH*QW][CI] = ADgrad(dY) x WT[z][CI][K]^T, K = (KH/S)(KW/S) CO  (srlx_qnet_bwd.hip)
 int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,
@@ -610,6 +619,9 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     float *all[] = {h->act1, h->act2, h->act3, h->partial, h->h1, h->dh1, h->dact3, h->dact2, h->dact1, h->fc_part, h->w_part, h->dxpad, h->w_t, h->w_t2};
     for (float *p : all)
         if (p) (void)hipFree(p);
+    for (float *p : h->eff)
+        if (p) (void)hipFree(p);
+    if (h->d_draw) (void)hipFree(h->d_draw);
     if (h->side) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join})
         if (e) (void)hipEventDestroy(e);
@@ -621,6 +633,10 @@ int srlx_qnet_bind(srlx_qnet_t *h, const float *const *p) {
     SRLX_REQUIRE(h && p, "qnet_bind: NULL argument");
     for (int i = 0; i < 12; i++) SRLX_REQUIRE(p[i], "qnet_bind: parameter %d is NULL", i);
     h->w1 = p[0], h->b1 = p[1], h->w2 = p[2], h->b2 = p[3], h->w3 = p[4], h->b3 = p[5];
+    if (h->eff[0]) {  // NoisyLinear: the dense-layer entries are the mu tensors; the kernels keep reading the effective tensors
+        for (int t = 0; t < 6; t++) h->mu[t] = p[6 + t];
+        return SRLX_OK;
+    }
     h->wf = p[6], h->bf = p[7], h->v2w = p[8], h->v2b = p[9], h->a2w = p[10], h->a2b = p[11];
     return SRLX_OK;
 }

@@ -464,6 +464,8 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
                        g_b1);
     SRLX_HIP(hipEventRecord(h->ev_join, sd));
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    // NoisyLinear: d loss / d sigma = d loss / d W_effective * eps of the draw the forward used (regenerated, not stored)
+    SRLX_TRY(srlx_qnet_noisy_sigma_grads(h, g, st));
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

@@ -22,7 +22,22 @@ struct srlx_qnet {
     hipStream_t side;                     // weight-gradient branch of the backward pass (forks from / joins the caller's stream)
     hipEvent_t ev_fork, ev_d3, ev_d2, ev_d1, ev_join;
     hipEvent_t probe0, probe1;            // optional, caller-owned: recorded around the two conv GEMM launches of the next forward (srlx_qnet_set_probe)
+    // NoisyLinear dense layers (srlx_qnet_bind_noisy, srlx_noisy.hip): wf..a2b above then point at `eff`, the effective tensors
+    // mu + sigma * eps of the current noise draw; order of the six: wf, bf, v2w, v2b, a2w, a2b
+    const float *mu[6], *sig[6];          // BORROWED torch parameters
+    float *eff[6];                        // owned
+    int64_t eff_n[6];
+    unsigned long long noisy_seed;
+    int64_t *d_draw;                      // device: [0] id of the next draw, [1] id of the draw `eff` holds
+    float *g_sig[6];                      // BORROWED gradient tensors of the sigmas (srlx_qnet_bind_noisy_grads)
 };
+
+// srlx_noisy.hip: (re)materialise the effective dense-layer tensors with a fresh draw (no-op for a plain network)
+int srlx_qnet_noisy_refresh(srlx_qnet *h, hipStream_t st);
+// gradients of the sigmas from the gradients of the effective tensors (g[6..11] of srlx_qnet_backward_u8) and the draw `eff` holds
+int srlx_qnet_noisy_sigma_grads(srlx_qnet *h, float *const *g, hipStream_t st);
+// the dense layers (FC1 split-K + head) of srlx_qnet.hip over `rows` activation rows starting at act3 + first*flat, row stride `stride` rows
+int srlx_qnet_dense_rows(srlx_qnet *h, int64_t rows, int64_t stride, float *d_q, hipStream_t st);
 
 // implicit-GEMM data gradient on the matrix cores (defined next to k_gemm in srlx_qnet.hip)
 int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,

@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) k_gae_scan(i64 E, i64 T, const float *rew
 // Arithmetic order follows torch's Adam (step starts at 1; exp_avg = lerp(exp_avg, g, 1-b1); bias corrections in
 // double; denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom), evaluated in float32.
 // ------------------------------------------------------------------------------------------
-constexpr int kAdamMaxTensors = 16;
+constexpr int kAdamMaxTensors = 24;
 constexpr int kAdamChunk = 2048;
 struct AdamTable {
     float *p[kAdamMaxTensors];

@@ -175,11 +175,11 @@ class DistributedRainbow:
         self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, env=env, overlap=self.is_learner and overlap)
         self.overlap = self.is_learner and overlap
         self.flat = flatten_parameters(self.local.q_online)
-        if self.local.mfma:  # the parameters moved: point the inference kernels at their new home
-            self.local.inf_actor.bind()
-            self.local.inf_online.bind()
-            if isinstance(self.local.optimizer, DeviceAdam):
-                self.local.optimizer.bind()
+        # the parameters moved: point the inference kernels (and the fused Adam) at their new home
+        self.local.inf_actor.bind()
+        self.local.inf_online.bind()
+        if isinstance(self.local.optimizer, DeviceAdam):
+            self.local.optimizer.bind()
         self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective)
         self.step_count = 0
         self._in_flight = False  # an exchange started by push_begin and not yet finished
@@ -228,19 +228,7 @@ class DistributedRainbow:
         elif random_policy:
             eng._random_rest()
         else:
-            if eng.mfma:
-                q = eng._actor_net(None, events)
-                if eng._select_graph is not None:
-                    eng._select_graph.replay()
-                else:
-                    eng._actor_select(q)
-            else:
-                if events is not None:
-                    events[0].record()
-                obs = eng._actor_stack()
-                if events is not None:
-                    events[1].record()
-                eng._actor_front(obs)
+            eng.actor_front(events)
             eng.actor_commit()
         env = eng.env
         if self.acts:
@@ -255,16 +243,9 @@ class DistributedRainbow:
         environments + local ring -> push_begin(t) -> parameter broadcast every `sync_interval` steps."""
         eng = self.local
         main = torch.cuda.current_stream(self.dev)
-        q = obs = None
+        q = None
         if self.acts:  # the network pass reads the local ring only: it does not depend on the exchange in flight
-            if eng.mfma:
-                q = eng._actor_net(None, events)
-            else:
-                if events is not None:
-                    events[0].record()
-                obs = eng._actor_stack()
-                if events is not None:
-                    events[1].record()
+            q = eng._actor_net(None, events)
         elif events is not None:
             events[0].record()
             events[1].record()
@@ -284,13 +265,10 @@ class DistributedRainbow:
                 for _ in range(learner_updates):
                     self._with_global_replay(eng.learner_step)
         if self.acts:
-            if eng.mfma:
-                if eng._select_graph is not None:
-                    eng._select_graph.replay()
-                else:
-                    eng._actor_select(q)
+            if eng._select_graph is not None:
+                eng._select_graph.replay()
             else:
-                eng._actor_front(obs)
+                eng._actor_select(q)
             eng.actor_commit()  # the local ring (frame stacking of this rank's environments)
             self.env_steps_local += self.cfg.n_envs
         env = eng.env
@@ -341,9 +319,6 @@ class DistributedRainbow:
             self.local.capture_graphs(actor=True, learner=False, warm_actor=False)
         if self.is_learner:
             self._with_global_replay(lambda: self.local.capture_graphs(actor=False, learner=True))
-
-    def stack_bytes_per_launch(self):
-        return self.local.stack_bytes_per_launch()
 
     def actor_forward_flops(self):
         return self.local.actor_forward_flops()

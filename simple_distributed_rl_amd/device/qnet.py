@@ -25,9 +25,12 @@ _DUELING = {"average": 0, "max": 1, "": 2}
 
 
 class EngineQNet(nn.Module):
-    def __init__(self, n_actions: int, hw=(84, 84), window: int = 4, hidden: int = 512, filters: int = 32, dueling_type: str = "average"):
+    def __init__(self, n_actions: int, hw=(84, 84), window: int = 4, hidden: int = 512, filters: int = 32, dueling_type: str = "average", noisy: bool = False):
+        """noisy=True: the dense layers are NoisyLinear (srl/rl/torch_/modules/noisy_linear.py:8-52): `fc1`/`v2`/`a2` hold the mu
+        tensors, `fc1_sigma_w` ... `a2_sigma_b` the sigmas, in the same (fused, NHWC-column) layouts."""
         super().__init__()
         self.hw, self.window, self.hidden, self.filters, self.n_actions, self.dueling_type = tuple(hw), window, hidden, filters, n_actions, dueling_type
+        self.noisy = bool(noisy)
         Fi = filters
         self.conv1 = nn.Conv2d(window, Fi, 8, 4, padding=3, padding_mode="replicate")
         self.conv2 = nn.Conv2d(Fi, 2 * Fi, 4, 2, padding=2, padding_mode="replicate")
@@ -39,11 +42,15 @@ class EngineQNet(nn.Module):
         self.fc1 = nn.Linear(self.flat, 2 * hidden)
         self.v2 = nn.Linear(hidden, 1)
         self.a2 = nn.Linear(hidden, n_actions)
+        if self.noisy:
+            for name, lin in (("fc1", self.fc1), ("v2", self.v2), ("a2", self.a2)):
+                setattr(self, name + "_sigma_w", nn.Parameter(torch.zeros_like(lin.weight)))
+                setattr(self, name + "_sigma_b", nn.Parameter(torch.zeros_like(lin.bias)))
         # reference-equivalent initialisation: build the mirrored module and convert it
         from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
 
         self.fix_formats()
-        self.load_reference_state_dict(atari_qnetwork(n_actions, hw, window, hidden, False, filters).state_dict())
+        self.load_reference_state_dict(atari_qnetwork(n_actions, hw, window, hidden, self.noisy, filters, dueling_type).state_dict())
 
     def fix_formats(self):
         """conv2/conv3 weights in channels_last memory = [Cout][ky][kx][Cin], the K order of an NHWC implicit GEMM."""
@@ -63,9 +70,20 @@ class EngineQNet(nn.Module):
         x = F.relu(self.conv2(x))
         x = F.relu(self.conv3(x))
         x = x.permute(0, 2, 3, 1).flatten(1)  # NHWC flatten: pixel-major, channel-minor
-        h = F.relu(self.fc1(x))
-        v = self.v2(h[:, : self.hidden])
-        adv = self.a2(h[:, self.hidden :])
+        if self.noisy:  # one draw per call, shared by every row (noisy_linear.py:35-52)
+            def lin(name, inp):
+                base = getattr(self, name)
+                w = base.weight + getattr(self, name + "_sigma_w") * torch.randn_like(base.weight)
+                b = base.bias + getattr(self, name + "_sigma_b") * torch.randn_like(base.bias)
+                return F.linear(inp, w, b)
+
+            h = F.relu(lin("fc1", x))
+            v = lin("v2", h[:, : self.hidden])
+            adv = lin("a2", h[:, self.hidden :])
+        else:
+            h = F.relu(self.fc1(x))
+            v = self.v2(h[:, : self.hidden])
+            adv = self.a2(h[:, self.hidden :])
         if self.dueling_type == "average":
             return v + adv - adv.mean(dim=-1, keepdim=True)
         if self.dueling_type == "max":
@@ -76,42 +94,89 @@ class EngineQNet(nn.Module):
     _CONV_KEYS = {"conv1": "in_block.image_block.image_layers.0", "conv2": "in_block.image_block.image_layers.2", "conv3": "in_block.image_block.image_layers.4"}
     _HEAD = "hidden_block.hidden_layers.0"
 
-    def load_reference_state_dict(self, sd):
+    def _fuse_fc1(self, v1, a1):
+        """[H, C*P] x 2 (columns c*P+p) -> [2H, P*C] (NHWC columns)"""
         C, P, H = self.out_c, self.out_p, self.hidden
+        w = torch.cat([v1, a1], dim=0)
+        return w.view(2 * H, C, P).permute(0, 2, 1).reshape(2 * H, P * C)
+
+    def _split_fc1(self, w):
+        C, P, H = self.out_c, self.out_p, self.hidden
+        w = w.detach().view(2 * H, P, C).permute(0, 2, 1).reshape(2 * H, C * P)
+        return w[:H].clone(), w[H:].clone()
+
+    def load_reference_state_dict(self, sd):
+        """The reference's keys and layouts (plain layers: `.weight` / `.bias`; NoisyLinear: `.w_mu` / `.w_sigma` / `.b_mu` / `.b_sigma`)."""
+        H = self.hidden
+        wk, bk = ("w_mu", "b_mu") if self.noisy else ("weight", "bias")
+        dev = self.fc1.weight.device
         with torch.no_grad():
             for mine, ref in self._CONV_KEYS.items():
                 getattr(self, mine).weight.copy_(sd[ref + ".weight"])
                 getattr(self, mine).bias.copy_(sd[ref + ".bias"])
-            v1, a1 = sd[self._HEAD + ".v_layers.0.weight"], sd[self._HEAD + ".adv_layers.0.weight"]
-            w = torch.cat([v1, a1], dim=0).to(self.fc1.weight.device)  # [2H, C*P] columns c*P+p
-            self.fc1.weight.copy_(w.view(2 * H, C, P).permute(0, 2, 1).reshape(2 * H, P * C))
-            self.fc1.bias.copy_(torch.cat([sd[self._HEAD + ".v_layers.0.bias"], sd[self._HEAD + ".adv_layers.0.bias"]]))
-            self.v2.weight.copy_(sd[self._HEAD + ".v_layers.2.weight"])
-            self.v2.bias.copy_(sd[self._HEAD + ".v_layers.2.bias"])
-            self.a2.weight.copy_(sd[self._HEAD + ".adv_layers.2.weight"])
-            self.a2.bias.copy_(sd[self._HEAD + ".adv_layers.2.bias"])
+            hd = self._HEAD
+            self.fc1.weight.copy_(self._fuse_fc1(sd[f"{hd}.v_layers.0.{wk}"].to(dev), sd[f"{hd}.adv_layers.0.{wk}"].to(dev)))
+            self.fc1.bias.copy_(torch.cat([sd[f"{hd}.v_layers.0.{bk}"], sd[f"{hd}.adv_layers.0.{bk}"]]))
+            self.v2.weight.copy_(sd[f"{hd}.v_layers.2.{wk}"])
+            self.v2.bias.copy_(sd[f"{hd}.v_layers.2.{bk}"])
+            self.a2.weight.copy_(sd[f"{hd}.adv_layers.2.{wk}"])
+            self.a2.bias.copy_(sd[f"{hd}.adv_layers.2.{bk}"])
+            if self.noisy:
+                self.fc1_sigma_w.copy_(self._fuse_fc1(sd[f"{hd}.v_layers.0.w_sigma"].to(dev), sd[f"{hd}.adv_layers.0.w_sigma"].to(dev)))
+                self.fc1_sigma_b.copy_(torch.cat([sd[f"{hd}.v_layers.0.b_sigma"], sd[f"{hd}.adv_layers.0.b_sigma"]]))
+                self.v2_sigma_w.copy_(sd[f"{hd}.v_layers.2.w_sigma"])
+                self.v2_sigma_b.copy_(sd[f"{hd}.v_layers.2.b_sigma"])
+                self.a2_sigma_w.copy_(sd[f"{hd}.adv_layers.2.w_sigma"])
+                self.a2_sigma_b.copy_(sd[f"{hd}.adv_layers.2.b_sigma"])
         return self
 
     def reference_state_dict(self):
-        C, P, H = self.out_c, self.out_p, self.hidden
+        H = self.hidden
+        wk, bk = ("w_mu", "b_mu") if self.noisy else ("weight", "bias")
         sd = {}
         for mine, ref in self._CONV_KEYS.items():
             sd[ref + ".weight"] = getattr(self, mine).weight.detach().contiguous().clone()
             sd[ref + ".bias"] = getattr(self, mine).bias.detach().clone()
-        w = self.fc1.weight.detach().view(2 * H, P, C).permute(0, 2, 1).reshape(2 * H, C * P)
-        sd[self._HEAD + ".v_layers.0.weight"], sd[self._HEAD + ".adv_layers.0.weight"] = w[:H].clone(), w[H:].clone()
-        sd[self._HEAD + ".v_layers.0.bias"], sd[self._HEAD + ".adv_layers.0.bias"] = self.fc1.bias.detach()[:H].clone(), self.fc1.bias.detach()[H:].clone()
-        sd[self._HEAD + ".v_layers.2.weight"], sd[self._HEAD + ".v_layers.2.bias"] = self.v2.weight.detach().clone(), self.v2.bias.detach().clone()
-        sd[self._HEAD + ".adv_layers.2.weight"], sd[self._HEAD + ".adv_layers.2.bias"] = self.a2.weight.detach().clone(), self.a2.bias.detach().clone()
+        hd = self._HEAD
+
+        def put(layer, sub, w, b, sw=None, sb=None):
+            sd[f"{hd}.{layer}.{sub}.{wk}"], sd[f"{hd}.{layer}.{sub}.{bk}"] = w, b
+            if self.noisy:
+                sd[f"{hd}.{layer}.{sub}.w_sigma"], sd[f"{hd}.{layer}.{sub}.b_sigma"] = sw, sb
+
+        wv, wa = self._split_fc1(self.fc1.weight)
+        bv, ba = self.fc1.bias.detach()[:H].clone(), self.fc1.bias.detach()[H:].clone()
+        if self.noisy:
+            sv, sa = self._split_fc1(self.fc1_sigma_w)
+            sbv, sba = self.fc1_sigma_b.detach()[:H].clone(), self.fc1_sigma_b.detach()[H:].clone()
+            put("v_layers", 0, wv, bv, sv, sbv)
+            put("adv_layers", 0, wa, ba, sa, sba)
+            put("v_layers", 2, self.v2.weight.detach().clone(), self.v2.bias.detach().clone(), self.v2_sigma_w.detach().clone(), self.v2_sigma_b.detach().clone())
+            put("adv_layers", 2, self.a2.weight.detach().clone(), self.a2.bias.detach().clone(), self.a2_sigma_w.detach().clone(), self.a2_sigma_b.detach().clone())
+        else:
+            put("v_layers", 0, wv, bv)
+            put("adv_layers", 0, wa, ba)
+            put("v_layers", 2, self.v2.weight.detach().clone(), self.v2.bias.detach().clone())
+            put("adv_layers", 2, self.a2.weight.detach().clone(), self.a2.bias.detach().clone())
         return sd
+
+    def kernel_parameters(self):
+        """The tensors libsrlx binds, in its order: 12 (conv1..a2, weight then bias; mu for noisy layers) + the 6 sigmas of a noisy net."""
+        n = self
+        ps = [n.conv1.weight, n.conv1.bias, n.conv2.weight, n.conv2.bias, n.conv3.weight, n.conv3.bias, n.fc1.weight, n.fc1.bias,
+              n.v2.weight, n.v2.bias, n.a2.weight, n.a2.bias]
+        if self.noisy:
+            ps += [n.fc1_sigma_w, n.fc1_sigma_b, n.v2_sigma_w, n.v2_sigma_b, n.a2_sigma_w, n.a2_sigma_b]
+        return ps
 
 
 class QNetInference:
     """Matrix-core forward over the live parameters of an EngineQNet (zero copy)."""
 
-    def __init__(self, net: EngineQNet, max_batch: int, device: int = 0):
+    def __init__(self, net: EngineQNet, max_batch: int, device: int = 0, noise_seed: int = 0):
         self.lib = N.lib()
         self.net = net
+        self.noise_seed = int(noise_seed)
         self.window, self.n_actions = net.window, net.n_actions
         self.max_batch = int(max_batch)
         self.dev = torch.device(f"cuda:{device}")
@@ -134,21 +199,22 @@ class QNetInference:
             self.h = None
 
     def bind(self):
+        """(Re)reads the parameters' addresses (again after they have been re-homed: device/dist.py:flatten_parameters)."""
         n = self.net
-        params = [n.conv1.weight, n.conv1.bias, n.conv2.weight, n.conv2.bias, n.conv3.weight, n.conv3.bias, n.fc1.weight, n.fc1.bias,
-                  n.v2.weight, n.v2.bias, n.a2.weight, n.a2.bias]
+        params = n.kernel_parameters()
         for conv in (n.conv2, n.conv3):
             assert conv.weight.is_contiguous(memory_format=torch.channels_last), "EngineQNet.fix_formats() was undone"
         for p in params:
             assert p.is_cuda and p.dtype == torch.float32
-        arr = (N.c_p * 12)(*[p.data_ptr() for p in params])
+        arr = (N.c_p * 12)(*[p.data_ptr() for p in params[:12]])
         N.check(self.lib.srlx_qnet_bind(self.h, ctypes.cast(arr, N.c_p)))
+        if n.noisy:  # every forward from now on materialises mu + sigma * eps of a fresh draw first
+            sig = (N.c_p * 6)(*[p.data_ptr() for p in params[12:]])
+            N.check(self.lib.srlx_qnet_bind_noisy(self.h, ctypes.cast(sig, N.c_p), self.noise_seed))
         self._bound = [p.data_ptr() for p in params]
 
     def _params(self):
-        n = self.net
-        return [n.conv1.weight, n.conv1.bias, n.conv2.weight, n.conv2.bias, n.conv3.weight, n.conv3.bias, n.fc1.weight, n.fc1.bias,
-                n.v2.weight, n.v2.bias, n.a2.weight, n.a2.bias]
+        return self.net.kernel_parameters()
 
     def enable_training(self, max_train_batch: int):
         """Allocates the backward scratch and static gradient tensors (`p.grad`, in each parameter's own memory format,
@@ -157,15 +223,26 @@ class QNetInference:
         for p in self._params():
             p.grad = torch.zeros_like(p)  # preserve_format: conv2/conv3 stay channels_last
         self._grads = [p.grad for p in self._params()]
-        self._grad_arr = (N.c_p * 12)(*[g.data_ptr() for g in self._grads])
+        self._grad_arr = (N.c_p * 12)(*[g.data_ptr() for g in self._grads[:12]])
+        if self.net.noisy:
+            self._sig_grad_arr = (N.c_p * 6)(*[g.data_ptr() for g in self._grads[12:]])
+            N.check(self.lib.srlx_qnet_bind_noisy_grads(self.h, ctypes.cast(self._sig_grad_arr, N.c_p)))
         return self
 
-    def backward_u8(self, frame_base_ptr: int, frame_off: torch.Tensor, grad_q: torch.Tensor, sample_stride: int = 1):
-        """Parameter gradients of sum(q * grad_q) for the samples at rows 0, stride, 2*stride, ... of the last forward_u8."""
-        B = grad_q.shape[0]
-        assert grad_q.is_contiguous() and grad_q.shape[1] == self.n_actions
-        N.check(self.lib.srlx_qnet_backward_u8(self.h, B, int(sample_stride), N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(grad_q),
-                                               ctypes.cast(self._grad_arr, N.c_p), N.torch_stream_ptr()))
+    def redraw_rows(self, rows: int, row_stride: int, out: torch.Tensor = None) -> torch.Tensor:
+        """NoisyLinear: the dense layers of rows 0, stride, ... of the last forward again, under a fresh noise draw (the draw the
+        backward pass then differentiates); overwrites their rows of `out` / the handle's q buffer."""
+        q = self.q if out is None else out
+        N.check(self.lib.srlx_qnet_redraw_rows(self.h, int(rows), int(row_stride), N.tptr(q), N.torch_stream_ptr()))
+        return q
+
+    def effective(self, which: int):
+        """(copy of an effective tensor = mu + sigma * eps of the current draw, draw id): 0 fc1 weight, 1 fc1 bias, 2 v2 w, 3 v2 b, 4 a2 w, 5 a2 b."""
+        n, draw = N.c_i64(), N.c_i64()
+        N.check(self.lib.srlx_qnet_noisy_effective(self.h, int(which), None, ctypes.byref(n), None, N.torch_stream_ptr()))
+        out = torch.empty(n.value, dtype=torch.float32, device=self.dev)
+        N.check(self.lib.srlx_qnet_noisy_effective(self.h, int(which), N.tptr(out), None, ctypes.byref(draw), N.torch_stream_ptr()))
+        return out, draw.value
 
     def set_probe(self, ev_start: torch.cuda.Event, ev_end: torch.cuda.Event):
         """The next forward records the two (timing-enabled, already created) events around its two conv GEMM launches."""
@@ -192,7 +269,7 @@ class DeviceAdam:
 
     def __init__(self, params, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
         self.params = [p for p in params]
-        assert 0 < len(self.params) <= 16 and all(p.is_cuda and p.dtype == torch.float32 for p in self.params)
+        assert 0 < len(self.params) <= 24 and all(p.is_cuda and p.dtype == torch.float32 for p in self.params)
         assert all(p.grad is not None for p in self.params), "DeviceAdam needs static gradient tensors (QNetInference.enable_training)"
         self.lib = N.lib()
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)

@@ -23,7 +23,6 @@ import torch
 from simple_distributed_rl_amd import _native as N
 from simple_distributed_rl_amd.device.replay import DeviceReplay
 from simple_distributed_rl_amd.device.qnet import DeviceAdam, EngineQNet, QNetInference
-from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
 
 
 @dataclass
@@ -93,7 +92,13 @@ class SyntheticAtariVecEnv:
 
 class RainbowEngine:
     """Actor + learner on one GPU sharing the online network (the reference's sequential `Runner.train`
-    topology, core_play.py:115-214, with E environments per iteration)."""
+    topology, core_play.py:115-214, with E environments per iteration).
+
+    Every network pass is hand-written HIP (libsrlx `srlx_qnet_*`): the actors' policy pass, the learner's online /
+    target evaluation and the gradient step's forward + backward, with plain dense layers or NoisyLinear ones
+    (`enable_noisy_dense`, the reference's own Atari configuration).  `SRLX_TORCH_BACKWARD=1` swaps the gradient step for
+    torch autograd on float32 pixels: a test-only yardstick (tests/test_engine_gpu.py), never a fallback -- shapes the
+    kernels do not cover raise."""
 
     def __init__(self, cfg: RainbowDeviceConfig, device: int = 0, episode_len: int = 200, ring_len: Optional[int] = None, env=None,
                  overlap: bool = False):
@@ -106,31 +111,32 @@ class RainbowEngine:
         self.dev = torch.device(f"cuda:{device}")
         self.lib = N.lib()
         torch.manual_seed(cfg.seed)
-        # MIOpen's immediate mode falls back to im2col-per-image / naive fp32 convolutions on gfx950
-        # (profiles/r1_kernel_stats_before_find.csv); let it benchmark its solvers once per shape instead.
-        torch.backends.cudnn.benchmark = True
         H, W_ = cfg.obs_hw
         E = cfg.n_envs
-        pad = cfg.multisteps + cfg.window_length
+        B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
+        pad = n + cfg.window_length
         if ring_len is None:
             ring_len = -(-cfg.memory_capacity // E) + pad  # item_len * E >= capacity
         self.replay = DeviceReplay(
-            E, ring_len, H * W_, cfg.window_length, cfg.multisteps, cfg.n_actions, cfg.batch_size, True, cfg.enable_reward_clip,
+            E, ring_len, H * W_, cfg.window_length, n, A, B, True, cfg.enable_reward_clip,
             cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
         )
         if env is None:
             self.env = SyntheticAtariVecEnv(self.replay, episode_len)
         else:  # a ready batch environment, or a factory that needs this engine's replay (device/vector_runner.py)
             self.env = env(self.replay) if callable(env) else env
-        # Matrix-core inference (libsrlx) for every no-grad forward; noisy nets keep the torch path (their
-        # per-forward Gaussian weights are not a fixed GEMM operand).
-        self.mfma = not cfg.enable_noisy_dense
-        B, n = cfg.batch_size, cfg.multisteps
+        self.noisy = bool(cfg.enable_noisy_dense)
+        self.mfma = True  # (kept for callers that used to branch on it: there is no other network path)
+        self.autograd_yardstick = os.environ.get("SRLX_TORCH_BACKWARD", "0") == "1"
+        covered = cfg.filters == 32 and cfg.hidden_units <= 512 and cfg.hidden_units % 32 == 0 and B <= 64 and H == W_ and W_ % 4 == 0 and cfg.dueling_type != "max"
+        if not covered and not self.autograd_yardstick:
+            raise ValueError("RainbowEngine: the hand-written gradient step covers the DQN image block with 32 filters on square frames (side % 4 == 0), one dueling "
+                             f"layer of <= 512 units (average / none) and batches <= 64; got filters={cfg.filters}, hidden={cfg.hidden_units}, batch={B}, "
+                             f"frames={cfg.obs_hw}, dueling='{cfg.dueling_type}'.  There is no fallback network path.")
+        self.mfma_train = covered and not self.autograd_yardstick
 
         def make_net():
-            if self.mfma:
-                return EngineQNet(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.filters, cfg.dueling_type).to(self.dev)
-            return atari_qnetwork(cfg.n_actions, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.enable_noisy_dense, cfg.filters, cfg.dueling_type).to(self.dev)
+            return EngineQNet(A, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.filters, cfg.dueling_type, noisy=self.noisy).to(self.dev)
 
         self.q_online = make_net()
         self.q_target = make_net()
@@ -146,36 +152,29 @@ class RainbowEngine:
             self._ev_join = torch.cuda.Event()
         else:
             self.q_actor = self.q_online
-        if self.mfma:
-            # one inference handle per concurrent user (each owns its activation buffers)
-            self.inf_actor = QNetInference(self.q_actor, E, device)
-            self.inf_online = QNetInference(self.q_online, max(B * (n + 1), 64), device)
-            self.inf_target = QNetInference(self.q_target, B * n, device)
+        # one inference handle per concurrent user (each owns its activation buffers and, for noisy layers, its noise stream)
+        self.inf_actor = QNetInference(self.q_actor, E, device, noise_seed=cfg.seed * 3 + 0xA11CE)
+        self.inf_online = QNetInference(self.q_online, max(B * (n + 1), 64), device, noise_seed=cfg.seed * 3 + 0x0B0E)
+        self.inf_target = QNetInference(self.q_target, B * n, device, noise_seed=cfg.seed * 3 + 0x7A26)
+        if self.mfma_train:
             # hand-written training pass (srlx_qnet_backward_u8): one forward over s_0..s_n of every item, gradients of the
             # s_0 rows written straight into p.grad -- no autograd graph, no float32 copy of s_0
-            self.mfma_train = (cfg.filters == 32 and cfg.hidden_units <= 512 and B <= 64 and H == W_ and W_ % 4 == 0
-                               and os.environ.get("SRLX_TORCH_BACKWARD", "0") != "1")
-            if self.mfma_train:
-                self.inf_online.enable_training(B)
-                # the target network's pass is independent of the online pass until the TD kernel: its own stream
-                self.s_target = torch.cuda.Stream(device=self.dev, priority=-1)
-                self._ev_t0, self._ev_t1 = torch.cuda.Event(), torch.cuda.Event()
-        else:
-            self.mfma_train = False
-        self._front_graph = None
-        self._select_graph = None
-        self._commit_graph = None
-        if self.mfma_train:  # model_torch.py:71 as one libsrlx launch over the 12 parameter tensors
-            self.optimizer = DeviceAdam(self.inf_online._params(), lr=cfg.lr)
+            self.inf_online.enable_training(B)
+            # the target network's pass is independent of the online pass until the TD kernel: its own stream
+            self.s_target = torch.cuda.Stream(device=self.dev, priority=-1)
+            self._ev_t0, self._ev_t1 = torch.cuda.Event(), torch.cuda.Event()
+            self.optimizer = DeviceAdam(self.inf_online._params(), lr=cfg.lr)  # model_torch.py:71 as one libsrlx launch over all parameter tensors
         else:
             self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True, fused=True)
+        self._select_graph = None
+        self._commit_graph = None
         d = self.dev
-        B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
         self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
         self.train_count = 0
         self.sync_count = 0
         self.total_env_steps = 0
-        self.eps = torch.full((E,), float(cfg.epsilon), dtype=torch.float32, device=d)
+        # noisy nets act greedily (rainbow.py:305-309): epsilon-greedy with epsilon = 0
+        self.eps = torch.full((E,), 0.0 if self.noisy else float(cfg.epsilon), dtype=torch.float32, device=d)
         self.actions = torch.zeros(E, dtype=torch.int32, device=d)
         self.u_policy = torch.zeros(2 * E, dtype=torch.float64, device=d)
         self.policy_counter = torch.zeros(1, dtype=torch.int64, device=d)
@@ -184,7 +183,6 @@ class RainbowEngine:
         self.grad_q0 = torch.zeros((B, A), dtype=torch.float32, device=d)
         self.priorities = torch.zeros(B, dtype=torch.float32, device=d)
         self._img = (cfg.window_length, H, W_)
-        self._actor_graph = None
         self._learner_graph = None
         self._learner_pending = False
         self.ledger = None  # optional EpisodeLedger (device/vector_runner.py): per-episode returns without leaving HBM
@@ -192,55 +190,36 @@ class RainbowEngine:
         self.replay.reset_all(self.first_obs)
 
     # ---- actor (rainbow.py:301-329 + 331-400 for E envs) --------------------------------------
-    def _actor_stack(self):
-        """uint8 frame ring -> float32 [E, W, H, W] policy input.  Only the torch (noisy-net) path needs it:
-        the matrix-core network reads the ring directly."""
-        if self.mfma:
-            return None
-        return self.replay.stack_current().view(self.cfg.n_envs, *self._img)
-
-    def _actor_net(self, obs, events=None):
-        """Q-values of all E environments.  Matrix-core path: frame-offset table + srlx_qnet_forward_u8 straight
-        from the uint8 ring (`events` bracket the network kernels); torch path: modules on the float32 stack."""
-        if self.mfma:
-            off = self.replay.frame_table_current()
-            if events is not None:
-                events[0].record()
-            q = self.inf_actor.forward_u8(self.replay.obs_base, off)
-            if events is not None:
-                events[1].record()
-            return q
-        with torch.no_grad():
-            return self.q_actor(obs, channels_first=True)
+    def _actor_net(self, obs=None, events=None):
+        """Q-values of all E environments: frame-offset table + srlx_qnet_forward_u8 straight from the uint8 ring
+        (`events` bracket the network kernels)."""
+        off = self.replay.frame_table_current()
+        if events is not None:
+            events[0].record()
+        q = self.inf_actor.forward_u8(self.replay.obs_base, off)
+        if events is not None:
+            events[1].record()
+        return q
 
     def _actor_select(self, q):
-        """epsilon-greedy over the Q rows, then the environments step: writes nothing shared."""
+        """epsilon-greedy over the Q rows (epsilon = 0 for noisy nets), then the environments step: writes nothing shared."""
         cfg = self.cfg
         st = N.torch_stream_ptr()
-        if cfg.enable_noisy_dense:
-            self.actions.copy_(torch.argmax(q, dim=1).to(torch.int32))  # noisy nets act greedily (rainbow.py:305-309)
-        else:
-            N.check(self.lib.srlx_rng_uniform(cfg.seed ^ 0xAC7, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
-            N.check(self.lib.srlx_policy_epsilon_greedy(cfg.n_envs, cfg.n_actions, N.tptr(q), N.tptr(self.eps), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
+        N.check(self.lib.srlx_rng_uniform(cfg.seed ^ 0xAC7, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
+        N.check(self.lib.srlx_policy_epsilon_greedy(cfg.n_envs, cfg.n_actions, N.tptr(q), N.tptr(self.eps), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
         self.env.step(self.actions)
 
-    def _actor_front(self, obs, events=None):
-        """Q-network -> epsilon-greedy -> environments: reads the ring, writes nothing shared."""
-        self._actor_select(self._actor_net(obs, events))
-
     def _actor_commit(self):
-        """ring commit + PER add of the step `_actor_front` produced (the only actor writes to the replay)."""
+        """ring commit + PER add of the lock-step the front produced (the only actor writes to the replay)."""
         e = self.env
         if self.ledger is not None:  # before the commit: the store's needs_reset view still marks the lanes that only received a first frame
             self.ledger.account(e.rewards, e.done, self.replay.needs_reset_ptr)
         self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs)
 
-    def _actor_rest(self, obs):
-        self._actor_front(obs)
-        self._actor_commit()
-
     def actor_step(self):
-        self._actor_rest(self._actor_stack())
+        """One eager lock-step of the actors (no graphs, no learner)."""
+        self._actor_select(self._actor_net())
+        self._actor_commit()
 
     def _random_rest(self):
         """One lock-step with uniformly random actions (epsilon = 1, no network): used to fill the replay."""
@@ -290,16 +269,10 @@ class RainbowEngine:
         h2, w2 = (h1 + 4 - 4) // 2 + 1, (w1 + 4 - 4) // 2 + 1
         return 2.0 * (h2 * w2 * 2 * F1 * F1 * 16 + h2 * w2 * 2 * F1 * 2 * F1 * 9) * c.n_envs
 
-    def stack_bytes_per_launch(self) -> int:
-        """Algorithmic HBM bytes of one k_stack_current launch: W uint8 frames read + W float32 frames
-        written per environment."""
-        c = self.cfg
-        return c.n_envs * c.window_length * self.replay.F * (1 + 4)
-
     # ---- learner (model_torch.py:85-122) -----------------------------------------------------
     def _learner_body(self):
         cfg, r = self.cfg, self.replay
-        B, n = cfg.batch_size, cfg.multisteps
+        B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
         if self.mfma_train:
             b = r.sample_items(self.train_count_dev, all_states=True)
             cur = torch.cuda.current_stream(self.dev)
@@ -308,42 +281,37 @@ class RainbowEngine:
             with torch.cuda.stream(self.s_target):  # fork: target network (rainbow.py:221) alongside the online network
                 q_tg_next = self.inf_target.forward_u8(r.obs_base, r.frame_off_next.view(B * n, cfg.window_length))
                 self._ev_t1.record(self.s_target)
-            q_all = self.inf_online.forward_u8(r.obs_base, r.frame_off_all.view(B * (n + 1), cfg.window_length)).view(B, n + 1, cfg.n_actions)
+            q_all = self.inf_online.forward_u8(r.obs_base, r.frame_off_all.view(B * (n + 1), cfg.window_length))
+            if self.noisy:
+                # the reference evaluates q_online(s_1..s_n) (rainbow.py:220) and q_online(s_0) (model_torch.py:103) in two forward
+                # calls, i.e. under two noise draws: re-evaluate the dense layers of the s_0 rows under a fresh one
+                self.inf_online.redraw_rows(B, n + 1, out=q_all)
+            q_all = q_all.view(B, n + 1, A)
             cur.wait_event(self._ev_t1)  # join before the TD kernel
             # rainbow.py:220 + model_torch.py:103: the TD kernel reads s_0 and s_1..s_n rows straight out of the one forward
             N.check(
                 self.lib.srlx_nstep_td_huber_priority_packed(
-                    B, n, cfg.n_actions, N.tptr(q_all), N.tptr(q_tg_next), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), None,
+                    B, n, A, N.tptr(q_all), N.tptr(q_tg_next), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), None,
                     N.tptr(b.weights), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
                     N.tptr(self.target), N.tptr(self.loss), N.tptr(self.grad_q0), N.tptr(self.priorities), N.torch_stream_ptr(),
                 )
             )
-        elif self.mfma:
+            # model_torch.py:107-109 without autograd: every p.grad is (over)written by the backward kernels
+            self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
+            self.optimizer.step(self.train_count_dev)
+        else:  # SRLX_TORCH_BACKWARD=1: the test yardstick -- matrix-core evaluation of s_1..s_n, autograd for the gradient step
             b = r.sample_items(self.train_count_dev)
             foff = r.frame_off_next.view(B * n, cfg.window_length)
             q_on_next = self.inf_online.forward_u8(r.obs_base, foff)  # rainbow.py:220
             q_tg_next = self.inf_target.forward_u8(r.obs_base, foff)  # rainbow.py:221
             q0 = self.q_online(r.obs0.view(B, *self._img))  # model_torch.py:103 (autograd)
-        else:
-            b = r.sample(self.train_count_dev)
-            obs = b.obs.view(B, n + 1, *self._img)
-            nxt = obs[:, 1:].reshape(B * n, *self._img)
-            with torch.no_grad():
-                q_on_next = self.q_online(nxt, channels_first=True)  # rainbow.py:220
-                q_tg_next = self.q_target(nxt, channels_first=True)  # rainbow.py:221
-            q0 = self.q_online(obs[:, 0], channels_first=True)  # model_torch.py:103
-        if not self.mfma_train:
             N.check(
                 self.lib.srlx_nstep_td_huber_priority(
-                    B, n, cfg.n_actions, N.tptr(q_on_next), N.tptr(q_tg_next), N.tptr(q0), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated),
+                    B, n, A, N.tptr(q_on_next), N.tptr(q_tg_next), N.tptr(q0), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated),
                     None, N.tptr(b.weights), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
                     N.tptr(self.target), N.tptr(self.loss), N.tptr(self.grad_q0), N.tptr(self.priorities), N.torch_stream_ptr(),
                 )
             )
-        if self.mfma_train:  # model_torch.py:107-109 without autograd: every p.grad is (over)written by the backward kernels
-            self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
-            self.optimizer.step(self.train_count_dev)
-        else:
             self.optimizer.zero_grad(set_to_none=False)
             q0.backward(self.grad_q0)  # model_torch.py:107-109: d loss / d q seeds autograd
             self.optimizer.step()
@@ -398,22 +366,11 @@ class RainbowEngine:
 
     def actor_front(self, events=None):
         """Network pass + action selection + environments of one lock-step: reads the ring, writes nothing shared."""
-        if self.mfma:
-            q = self._actor_net(None, events)  # 5 eager launches, bracketed by the events
-            if self._select_graph is not None:
-                self._select_graph.replay()
-            else:
-                self._actor_select(q)
+        q = self._actor_net(None, events)  # eager launches, bracketed by the events
+        if self._select_graph is not None:
+            self._select_graph.replay()
         else:
-            if events is not None:
-                events[0].record()
-            obs = self._actor_stack()
-            if events is not None:
-                events[1].record()
-            if self._front_graph is not None:
-                self._front_graph.replay()
-            else:
-                self._actor_front(obs)
+            self._actor_select(q)
 
     def actor_commit(self):
         """Ring commit + PER add of the lock-step `actor_front` produced: the only actor writes to the replay."""
@@ -458,18 +415,11 @@ class RainbowEngine:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         if actor:
-            if self.mfma:
-                q = self._actor_net(None)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
-                    self._actor_select(q)
-                self._select_graph = g
-            else:
-                obs = self._actor_stack()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
-                    self._actor_front(obs)
-                self._front_graph = g
+            q = self._actor_net(None)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
+                self._actor_select(q)
+            self._select_graph = g
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
                 self._actor_commit()

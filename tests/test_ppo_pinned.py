@@ -103,9 +103,10 @@ def test_ppo_loss_kernel_matches_reference_steps(name):
     for z, s in _steps(name):
         B, K = s["new_logpi"].shape
         adv = _advantage(z, s)
-        v = np.ascontiguousarray(s["v"][:, 0])
+        # device tensors held in locals: a temporary would be freed (and its memory reused) before the kernel runs
+        lp_t, olp_t, adv_t, v_t = t(s["new_logpi"]), t(s["old_logpi"]), t(adv), t(s["v"][:, 0])
         losses, g_lp, g_v = torch.zeros(3, device=dev), torch.empty((B, K), device=dev), torch.empty(B, device=dev)
-        N.check(lib.srlx_ppo_loss_logpi(B, K, N.tptr(t(s["new_logpi"])), N.tptr(t(s["old_logpi"])), N.tptr(t(adv)), N.tptr(t(v)), N.tptr(t(v)), N.tptr(t(v)), 0, 1,
+        N.check(lib.srlx_ppo_loss_logpi(B, K, N.tptr(lp_t), N.tptr(olp_t), N.tptr(adv_t), N.tptr(v_t), N.tptr(v_t), N.tptr(v_t), 0, 1,
                                         float(z["clip_range"]), 0, 0.0, 1.0, 1.0, N.tptr(losses), N.tptr(g_lp), N.tptr(g_v), None))
         torch.cuda.synchronize()
         got = losses.cpu().numpy()
@@ -114,8 +115,9 @@ def test_ppo_loss_kernel_matches_reference_steps(name):
         if name == "continuous":  # the fused Normal variant computes the log-probability itself
             losses.zero_()
             g_loc, g_ls = torch.empty((B, K), device=dev), torch.empty((B, K), device=dev)
-            N.check(lib.srlx_ppo_loss_normal(B, K, N.tptr(t(s["loc"])), N.tptr(t(s["log_scale"])), math.log(1e-10), math.log(10), N.tptr(t(s["action"])),
-                                             N.tptr(t(s["old_logpi"])), N.tptr(t(adv)), N.tptr(t(v)), N.tptr(t(v)), N.tptr(t(v)), 0, 1, float(z["clip_range"]), 0, 0.0,
+            loc_t, ls_t, act_t = t(s["loc"]), t(s["log_scale"]), t(s["action"])
+            N.check(lib.srlx_ppo_loss_normal(B, K, N.tptr(loc_t), N.tptr(ls_t), math.log(1e-10), math.log(10), N.tptr(act_t),
+                                             N.tptr(olp_t), N.tptr(adv_t), N.tptr(v_t), N.tptr(v_t), N.tptr(v_t), 0, 1, float(z["clip_range"]), 0, 0.0,
                                              1.0, 1.0, N.tptr(losses), N.tptr(g_loc), N.tptr(g_ls), N.tptr(g_v), None))
             torch.cuda.synchronize()
             got = losses.cpu().numpy()
@@ -140,6 +142,7 @@ def test_gae_kernel_known_answer():
     cut = torch.zeros((3, 1), dtype=torch.uint8, device=dev)
     last = torch.tensor([7.0], device=dev)
     out3 = torch.empty((3, 1), device=dev)
-    N.check(lib.srlx_gae_scan(1, 3, N.tptr(r[:3].contiguous()), N.tptr(v[:3].contiguous()), N.tptr(cut), N.tptr(last), 0.5, 0.5, N.tptr(out3), None))
+    r3, v3 = r[:3].contiguous(), v[:3].contiguous()
+    N.check(lib.srlx_gae_scan(1, 3, N.tptr(r3), N.tptr(v3), N.tptr(cut), N.tptr(last), 0.5, 0.5, N.tptr(out3), None))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out3.cpu().numpy()[:, 0], np.array([0.96875, 1.375, 4.5], np.float32))

@@ -402,6 +402,9 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
  * before the conv2 launch and right after the conv3 launch -- the two launches of the dominant kernel k_gemm<AConv> -- so that
  * bench.py can time that kernel live, on the stream it runs on.  NULL events switch it off. */
 int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end);
+/* measurement aid: d_phase_stamps = device uint64 [8 waves][8] (or NULL to switch off): the fused convolution kernel's workgroup 0
+ * records its shader clock at the phase boundaries (start, frames issued, staged, conv1 done, barrier, conv2 done, barrier, end) */
+int srlx_qnet_set_debug(srlx_qnet_t *h, void *d_phase_stamps);
 /* Training on the vectorised path (replaces `loss.backward()` + the framework forward it needs,
  * srl/algorithms/rainbow/model_torch.py:103-109):
  *   srlx_qnet_enable_training : from now on every forward keeps its post-ReLU hidden layer, and gradient scratch for up

@@ -507,6 +507,9 @@ void launch_gemm(const AL &al, const float *Bw, const float *bias, float *C, i64
     hipLaunchKernelGGL((k_gemm<AL, BN, RELU, SPLITK>), grid, dim3(256), 0, st, al, Bw, bias, C, M, N, K, kps);
 }
 
+int run_dense(srlx_qnet *h, i64 B, float *d_q, hipStream_t st);
+
+// conv2 + conv3 as implicit GEMMs over act1 (every geometry; the Atari geometry takes the fused kernel instead), then the dense layers
 int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     // conv2: 4x4 stride 2 pad 2 on act1 [B][OH1][OW1][F1]
     AConv c2{h->act1, h->OH1, h->OW1, h->F1, 4, 2, 2, h->OH2, h->OW2, {}};
@@ -519,6 +522,10 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     launch_gemm<AConv, 64, true, false>(c3, h->w3, h->b3, h->act3, B * h->OH3 * h->OW3, 2 * h->F1, 9 * 2 * h->F1, 1, st);
     if (h->probe1) SRLX_HIP(hipEventRecord(h->probe1, st));
     h->probe0 = h->probe1 = nullptr;  // one forward only
+    return run_dense(h, B, d_q, st);
+}
+
+int run_dense(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     SRLX_TRY(srlx_qnet_noisy_refresh(h, st));  // NoisyLinear: one noise draw per forward call (noisy_linear.py:35-52); no-op for plain layers
     return srlx_qnet_dense_rows(h, B, 1, d_q, st);
 }
@@ -622,6 +629,7 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     for (float *p : h->eff)
         if (p) (void)hipFree(p);
     if (h->d_draw) (void)hipFree(h->d_draw);
+    if (h->wpack) (void)hipFree(h->wpack);
     if (h->side) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join})
         if (e) (void)hipEventDestroy(e);
@@ -641,6 +649,12 @@ int srlx_qnet_bind(srlx_qnet_t *h, const float *const *p) {
     return SRLX_OK;
 }
 
+int srlx_qnet_set_debug(srlx_qnet_t *h, void *d_phase_stamps) {
+    SRLX_REQUIRE(h, "qnet_set_debug: NULL handle");
+    h->fused_dbg = d_phase_stamps;
+    return SRLX_OK;
+}
+
 int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end) {
     SRLX_REQUIRE(h, "qnet_set_probe: NULL handle");
     h->probe0 = (hipEvent_t)ev_start;
@@ -654,6 +668,15 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
     SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_u8: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
+    static const bool no_fused = getenv("SRLX_NO_FUSED_CONV") && getenv("SRLX_NO_FUSED_CONV")[0] == '1';  // A/B switch for measurements
+    if (!no_fused && h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32) {
+        // conv1 -> conv2 -> conv3 in one kernel, one workgroup per sample, activations in LDS (srlx_qnet_fused.hip)
+        if (h->probe0) SRLX_HIP(hipEventRecord(h->probe0, st));
+        SRLX_REQUIRE(srlx_qnet_fused_convs(h, batch, d_frame_base, d_frame_off, st), "qnet_forward_u8: launching the fused convolution kernel failed");
+        if (h->probe1) SRLX_HIP(hipEventRecord(h->probe1, st));
+        h->probe0 = h->probe1 = nullptr;
+        return run_dense(h, batch, d_q, st);
+    }
     const size_t lds = (size_t)h->Wn * kC1Frame;
     if (h->F1 == 32 && h->Wn == 4 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && 4 * (h->OW1 - 1) + 8 <= kC1Pad && h->W % 4 == 0) {
         // one workgroup per sample, frames + filters staged in LDS

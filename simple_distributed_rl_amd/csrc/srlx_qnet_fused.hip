@@ -1,0 +1,296 @@
+// srlx_qnet_fused.hip -- conv1 -> conv2 -> conv3 of the DQN image block as ONE kernel, one workgroup per sample.
+//
+// Replaces the three launches k_conv1_u8 + k_gemm<AConv> x 2 of srlx_qnet.hip for the Atari geometry (84 x 84 x 4 frames,
+// 32 / 64 / 64 filters; srl/rl/torch_/blocks/dqn_image_block.py:29-54).  The implicit-GEMM kernels spend a third of the f32
+// matrix-core peak on their im2col: 93 VALU instructions per 32 MFMAs for clamped addresses, and f32 MFMAs share issue
+// slots with VALU on gfx950.  Here a workgroup (8 waves) owns one sample end to end:
+//   frames  4 x 88 x 88 uint8 (replicate padding materialised)     31.0 KB of LDS   <- the ring, through the frame-offset table
+//   act1    441 pixels x 32 channels f32, pixel stride 36           63.5 KB          <- conv1 (filters in registers, as k_conv1_u8)
+//   act2    121 pixels x 64 channels f32, pixel stride 68           32.9 KB          <- conv2
+//   act3    121 x 64 f32 -> HBM (NHWC flatten, the FC1 GEMM's A operand)             <- conv3
+// The activations never leave the CU, and because a lane's GEMM rows (output pixels) are fixed for a whole layer, every
+// im2col address is computed ONCE per tile and tap before the K loop, which is then ds_read_b128 (A fragments out of LDS),
+// global_load_dwordx4 (B fragments: the filters stream from L2, 272 KB shared by every workgroup) and MFMAs only.
+// Tiles: 32 x 32 outputs per wave (v_mfma_f32_32x32x2_f32, exact f32); conv2 / conv3 are 4 pixel tiles x 2 channel tiles = one
+// tile per wave, conv1 14 pixel tiles over the 8 waves.  Pixel strides 36 / 68 floats spread the 16-lane groups of a
+// ds_read_b128 over the 64 banks.  With `act1_out` / `act2_out` the activations are ALSO written to HBM for the backward
+// pass of a training forward.
+#include "srlx_qnet_int.h"
+
+namespace {
+
+using i64 = int64_t;
+using u8 = unsigned char;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kPad = 88, kFrame = kPad * kPad;     // staged frame side / bytes
+constexpr int kP1 = 21, kM1 = kP1 * kP1;           // conv1 output side / pixels
+constexpr int kP2 = 11, kM2 = kP2 * kP2;           // conv2 = conv3 output side / pixels
+constexpr int kS1 = 36, kS2 = 68;                  // LDS pixel strides (floats) of act1 / act2
+constexpr int kWaves = 8;
+constexpr size_t kLdsBytes = 4 * kFrame + (size_t)kM1 * kS1 * 4 + (size_t)kM2 * kS2 * 4;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Filters in MFMA-fragment order.  A wave's B fragment of one K-slab is, per lane (i = lane & 31, h = lane >> 5), the 16 floats
+// W[n0 + i][slab*32 + 16 h .. + 15]: read from the torch layout ([n][K] rows of 512 / 576 / 256 floats) every lane of a load
+// instruction touches its own 128-byte line -- 64 tag look-ups per instruction, and with eight waves streaming filters the
+// texture-address unit is as busy as the matrix pipe.  Packed as [slab][n-tile][v][lane][4] a load instruction of a wave is one
+// contiguous KiB (8 lines).  311 KB for the three layers, rebuilt by one small launch per forward (the filters are the torch
+// parameters themselves and change with every optimiser step).
+constexpr int kW1 = 32 * 256, kW2 = 64 * 512, kW3 = 64 * 576;
+constexpr int kPackFloats = kW1 + kW2 + kW3;
+
+__global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
+                                                      float *__restrict__ out) {
+    // one thread per float4 of the packed buffer
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n4 = kPackFloats / 4;
+    if (q >= n4) return;
+    const float *src;
+    int K, tiles, local;
+    if (q < kW1 / 4) src = w1, K = 256, tiles = 1, local = q;
+    else if (q < (kW1 + kW2) / 4) src = w2, K = 512, tiles = 2, local = q - kW1 / 4;
+    else src = w3, K = 576, tiles = 2, local = q - (kW1 + kW2) / 4;
+    const int lane = local & 63, v = (local >> 6) & 3, rest = local >> 8;  // rest = slab * tiles + nt
+    const int nt = rest % tiles, slab = rest / tiles;
+    const int i = lane & 31, hh = lane >> 5;
+    reinterpret_cast<float4 *>(out)[q] = *reinterpret_cast<const float4 *>(src + (i64)(nt * 32 + i) * K + slab * 32 + 16 * hh + 4 * v);
+}
+
+// one 32 (pixels) x 32 (channels) tile of a convolution whose input sits in LDS (pixel-major, `stride` floats per pixel):
+//   acc += sum over slabs of A[pixel rows][32 k] * W[32 channel rows][32 k]^T,  slab = (tap, 32-channel group)
+// `abase[t]` = LDS float index of this lane's row for tap t (clamped pixel * stride + 16 h); `wpk` = packed filters of the layer
+// + (nt * 4 * 64 + lane) * 4: the lane's float4 of (slab 0, v = 0); slabs are 2 * 4 * 64 * 4 floats apart, v's 64 * 4.
+template <int TAPS, int CG>  // CG = 32-channel groups per tap (1 for C = 32, 2 for C = 64)
+__device__ __forceinline__ void tile_from_lds(const float *__restrict__ lds_in, const int (&abase)[TAPS], const float *__restrict__ wpk, f32x16 &acc) {
+    constexpr int S = TAPS * CG;
+    static_assert(S % 2 == 0, "the slab loop is unrolled by two (ping-pong fragment registers)");
+    float4 a0[4], b0[4], a1[4], b1[4];
+    auto load = [&](int sl, float4(&A)[4], float4(&B)[4]) {
+        const float *pa = lds_in + abase[sl / CG] + (sl % CG) * 32;
+        const float *pb = wpk + sl * (2 * 4 * 64 * 4);
+#pragma unroll
+        for (int v = 0; v < 4; v++) B[v] = *reinterpret_cast<const float4 *>(pb + v * 256);  // filters: L2 -> registers (the long latency first)
+#pragma unroll
+        for (int v = 0; v < 4; v++) A[v] = *reinterpret_cast<const float4 *>(pa + 4 * v);  // activations: LDS -> registers
+    };
+    auto mfma16 = [&](const float4(&A)[4], const float4(&B)[4]) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[v].x, B[v].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[v].y, B[v].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[v].z, B[v].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[v].w, B[v].w, acc, 0, 0, 0);
+        }
+    };
+    // software pipeline, one slab ahead: the fragments of slab s+1 are requested BEFORE the 16 MFMAs of slab s.  hipcc's scheduler
+    // otherwise sinks every load next to its first use (one dwordx4 + s_waitcnt vmcnt(0) per 4 MFMAs: the matrix pipe then idles
+    // for an L2 round trip per quarter slab); the scheduling barriers pin the order, the waitcnts stay the compiler's.
+    load(0, a0, b0);
+#pragma unroll
+    for (int sl = 0; sl < S; sl += 2) {
+        load(sl + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sl + 2 < S) load(sl + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
+                                                                const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
+                                                                float *__restrict__ act3,
+                                                                float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u8 *fr = smem;                                                 // [4][88][88]
+    float *a1 = reinterpret_cast<float *>(smem + 4 * kFrame);      // [441][36]
+    float *a2 = a1 + kM1 * kS1;                                    // [121][68]
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, h = lane >> 5, i = lane & 31;
+    const i64 b = blockIdx.x;
+    constexpr int H = 84, W = 84, NT = 64 * kWaves;
+    auto stamp = [&](int k) {  // phase timestamps of every wave of workgroup 0 (tools/fused_phases.py); dbg is NULL in production
+        if (dbg && blockIdx.x == 0 && lane == 0) dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
+    // ---- stage the four frames (uint8, replicate padding materialised): padded dword (row r, dword d) covers image columns
+    //      clamp(4d - 3 .. 4d), image row clamp(r - 3); all loads of all frames are in flight before the first LDS store
+    {
+        constexpr int kDw = kPad * (kPad / 4);              // 1936 dwords per frame
+        constexpr int kPer = (4 * kDw + NT - 1) / NT;       // dwords per lane over the four frames
+        unsigned v[kPer];
+        const i64 o0 = frame_off[b * 4], o1 = frame_off[b * 4 + 1], o2 = frame_off[b * 4 + 2], o3 = frame_off[b * 4 + 3];  // one round trip, then every frame load is independent
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int idx = t + NT * j, q = idx / kDw, d = idx % kDw;
+            v[j] = 0u;
+            if (idx < 4 * kDw) {
+                const i64 o = q == 0 ? o0 : (q == 1 ? o1 : (q == 2 ? o2 : o3));
+                if (o >= 0) {
+                    const int r = d / (kPad / 4), c = d % (kPad / 4);
+                    __builtin_memcpy(&v[j], base + o + (i64)clampi(r - 3, 0, H - 1) * W + clampi(4 * c - 3, 0, W - 4), 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int idx = t + NT * j;
+            if (idx >= 4 * kDw) continue;
+            const int d = idx % kDw;
+            const int x = 4 * (d % (kPad / 4)) - 3, xs = clampi(x, 0, W - 4);
+            unsigned o = v[j];
+            if (x != xs) {  // border: column clamp(x + p) sits at byte clamp(x + p) - xs of the loaded dword (zero frames stay zero)
+                o = 0u;
+#pragma unroll
+                for (int p = 0; p < 4; p++) o |= ((v[j] >> (8 * (clampi(x + p, 0, W - 1) - xs))) & 255u) << (8 * p);
+            }
+            reinterpret_cast<unsigned *>(fr)[idx] = o;
+        }
+    }
+    // ---- conv1: this lane's B fragments of all eight K-slabs (filter row i, k = slab*32 + 16 h + 0..15), 1/255 folded in
+    {
+        float bfr[8][16];
+        const float *wp = wpk + lane * 4;  // conv1's filters lead the packed buffer: [slab][v][lane][4]
+#pragma unroll
+        for (int sl = 0; sl < 8; sl++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const float4 x = *reinterpret_cast<const float4 *>(wp + (sl * 4 + v) * 256);
+                bfr[sl][4 * v] = x.x * (1.0f / 255.0f), bfr[sl][4 * v + 1] = x.y * (1.0f / 255.0f), bfr[sl][4 * v + 2] = x.z * (1.0f / 255.0f),
+                bfr[sl][4 * v + 3] = x.w * (1.0f / 255.0f);
+            }
+        const float bias = b1[i];
+        stamp(1);
+        __syncthreads();
+        stamp(2);
+        constexpr int tiles = (kM1 + 31) / 32;  // 14
+        const int wrot = (wave + (int)(b & 7)) & 7;  // rotate the 2/2/2/2/2/2/1/1 split with the sample index
+        for (int tile = wrot; tile < tiles; tile += kWaves) {
+            const int m = tile * 32 + i < kM1 ? tile * 32 + i : kM1 - 1;
+            const int oy = m / kP1, ox = m % kP1;
+            const u8 *win = fr + (4 * oy + 2 * h) * kPad + 4 * ox;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            // eight K-slabs (frame c, kernel rows kyb..kyb+3); the four dwords of slab g+1 are read from LDS before the 16 MFMAs of slab g
+            unsigned wa[4], wb[4];
+            auto fetch = [&](int g, unsigned(&w)[4]) {
+                const u8 *p = win + (g >> 1) * kFrame + (g & 1) * 4 * kPad;
+                w[0] = *reinterpret_cast<const unsigned *>(p);
+                w[1] = *reinterpret_cast<const unsigned *>(p + 4);
+                w[2] = *reinterpret_cast<const unsigned *>(p + kPad);
+                w[3] = *reinterpret_cast<const unsigned *>(p + kPad + 4);
+            };
+            auto mfma16 = [&](int g, const unsigned(&w)[4]) {
+#pragma unroll
+                for (int s = 0; s < 16; s++) {
+                    const float a = (float)((w[s >> 2] >> (8 * (s & 3))) & 255u);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[g][s], acc, 0, 0, 0);
+                }
+            };
+            fetch(0, wa);
+#pragma unroll
+            for (int g = 0; g < 8; g += 2) {
+                fetch(g + 1, wb);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(g, wa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < 8) fetch(g + 2, wa);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(g + 1, wb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 h (pixel)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mm = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (mm < kM1) {
+                    float v = acc[r] + bias;
+                    v = v > 0.f ? v : 0.f;
+                    a1[mm * kS1 + i] = v;
+                    if (act1_out) act1_out[(b * kM1 + mm) * 32 + i] = v;
+                }
+            }
+        }
+    }
+    stamp(3);
+    __syncthreads();
+    stamp(4);
+    const int mt = wave >> 1, nt = wave & 1;  // conv2 / conv3: one 32 x 32 output tile per wave
+    const int m = mt * 32 + i < kM2 ? mt * 32 + i : kM2 - 1;
+    const int oy = m / kP2, ox = m % kP2;
+    // ---- conv2: 4 x 4 stride 2 pad 2 over act1 (21 x 21 x 32), K = 16 taps x 32
+    {
+        int ab[16];
+#pragma unroll
+        for (int tp = 0; tp < 16; tp++) {
+            const int iy = clampi(2 * oy - 2 + (tp >> 2), 0, kP1 - 1), ix = clampi(2 * ox - 2 + (tp & 3), 0, kP1 - 1);
+            ab[tp] = (iy * kP1 + ix) * kS1 + 16 * h;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        tile_from_lds<16, 1>(a1, ab, wpk + kW1 + (nt * 4 * 64 + lane) * 4, acc);
+        const float bias = b2[nt * 32 + i];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mm < kM2) {
+                float v = acc[r] + bias;
+                v = v > 0.f ? v : 0.f;
+                a2[mm * kS2 + nt * 32 + i] = v;
+                if (act2_out) act2_out[(b * kM2 + mm) * 64 + nt * 32 + i] = v;
+            }
+        }
+    }
+    stamp(5);
+    __syncthreads();
+    stamp(6);
+    // ---- conv3: 3 x 3 stride 1 pad 1 over act2 (11 x 11 x 64), K = 9 taps x 64
+    {
+        int ab[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++) {
+            const int iy = clampi(oy - 1 + tp / 3, 0, kP2 - 1), ix = clampi(ox - 1 + tp % 3, 0, kP2 - 1);
+            ab[tp] = (iy * kP2 + ix) * kS2 + 16 * h;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        tile_from_lds<9, 2>(a2, ab, wpk + kW1 + kW2 + (nt * 4 * 64 + lane) * 4, acc);
+        const float bias = b3[nt * 32 + i];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mm < kM2) {
+                const float v = acc[r] + bias;
+                act3[(b * kM2 + mm) * 64 + nt * 32 + i] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+    stamp(7);
+}
+
+}  // namespace
+
+// Launcher: true when the fused kernel covers this handle's geometry (then act3 -- and act1 / act2 when training is enabled -- are valid).
+bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st) {
+    if (!(h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32)) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_convnet_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess) return false;
+        attr_set = true;
+    }
+    if (!h->wpack) {
+        if (hipMalloc((void **)&h->wpack, (size_t)kPackFloats * sizeof(float)) != hipSuccess) return false;
+    }
+    hipLaunchKernelGGL(k_pack_filters, dim3((kPackFloats / 4 + 255) / 256), dim3(256), 0, st, h->w1, h->w2, h->w3, h->wpack);
+    const bool keep = h->max_train > 0;  // a training handle: the backward pass reads act1 / act2
+    hipLaunchKernelGGL(k_convnet_fused, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3,
+                       h->act3, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
+    return hipGetLastError() == hipSuccess;
+}

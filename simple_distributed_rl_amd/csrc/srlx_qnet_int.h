@@ -30,6 +30,8 @@ struct srlx_qnet {
     unsigned long long noisy_seed;
     int64_t *d_draw;                      // device: [0] id of the next draw, [1] id of the draw `eff` holds
     float *g_sig[6];                      // BORROWED gradient tensors of the sigmas (srlx_qnet_bind_noisy_grads)
+    void *fused_dbg;                      // optional device buffer [8 waves][8] of phase timestamps (srlx_qnet_set_debug; NULL in production)
+    float *wpack;                         // conv filters in MFMA-fragment order (srlx_qnet_fused.hip), rebuilt per forward
 };
 
 // srlx_noisy.hip: (re)materialise the effective dense-layer tensors with a fresh draw (no-op for a plain network)
@@ -38,6 +40,9 @@ int srlx_qnet_noisy_refresh(srlx_qnet *h, hipStream_t st);
 int srlx_qnet_noisy_sigma_grads(srlx_qnet *h, float *const *g, hipStream_t st);
 // the dense layers (FC1 split-K + head) of srlx_qnet.hip over `rows` activation rows starting at act3 + first*flat, row stride `stride` rows
 int srlx_qnet_dense_rows(srlx_qnet *h, int64_t rows, int64_t stride, float *d_q, hipStream_t st);
+
+// srlx_qnet_fused.hip: conv1 -> conv2 -> conv3 in one kernel (activations in LDS); false when the geometry is not the Atari one
+bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st);
 
 // implicit-GEMM data gradient on the matrix cores (defined next to k_gemm in srlx_qnet.hip)
 int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,

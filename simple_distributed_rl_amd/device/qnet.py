@@ -244,6 +244,14 @@ class QNetInference:
         N.check(self.lib.srlx_qnet_noisy_effective(self.h, int(which), N.tptr(out), None, ctypes.byref(draw), N.torch_stream_ptr()))
         return out, draw.value
 
+    def backward_u8(self, frame_base_ptr: int, frame_off: torch.Tensor, grad_q: torch.Tensor, sample_stride: int = 1):
+        """Parameter gradients of sum(q * grad_q) for the samples at rows 0, stride, 2*stride, ... of the last forward_u8
+        (for a noisy net: of the draw the dense layers of those rows were last evaluated under; sigma gradients included)."""
+        B = grad_q.shape[0]
+        assert grad_q.is_contiguous() and grad_q.shape[1] == self.n_actions
+        N.check(self.lib.srlx_qnet_backward_u8(self.h, B, int(sample_stride), N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(grad_q),
+                                               ctypes.cast(self._grad_arr, N.c_p), N.torch_stream_ptr()))
+
     def set_probe(self, ev_start: torch.cuda.Event, ev_end: torch.cuda.Event):
         """The next forward records the two (timing-enabled, already created) events around its two conv GEMM launches."""
         N.check(self.lib.srlx_qnet_set_probe(self.h, N.c_p(ev_start.cuda_event), N.c_p(ev_end.cuda_event)))

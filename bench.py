@@ -53,6 +53,10 @@ def parse_args():
     ap.add_argument("--learner-acts", choices=("auto", "yes", "no"), default="auto",
                     help="N>1: does the learner rank run actors too? auto = yes below 4 GPUs, no (dedicated learner GPU) from 4")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 code path with several ranks on ONE GPU)")
+    ap.add_argument("--noisy", action="store_true", help="NoisyLinear dense layers (the reference's set_atari_config: enable_noisy_dense=True)")
+    ap.add_argument("--algo", choices=("rainbow", "agent57_light"), default="rainbow",
+                    help="rainbow = BASELINE.json configs[2] (the headline metric); agent57_light = the configs[3] workload (two UVFA Q-networks, NGU "
+                         "intrinsic reward, per-environment UCB) on the E-environment engine")
     ap.add_argument("--dist-selftest", action="store_true", help="run the N>1 code path (DistributedRainbow, RCCL gathers/broadcasts) at world size 1")
     return ap.parse_args()
 
@@ -117,7 +121,9 @@ def main():
     else:
         actor_ranks = world if (learner_acts if learner_acts is not None else world < 4) else world - 1
     envs_per_gpu = args.envs if args.scaling == "weak" else max(1, args.envs // actor_ranks)
-    cfg = RainbowDeviceConfig(n_envs=envs_per_gpu, batch_size=args.batch_size, memory_capacity=args.capacity, seed=0)
+    if args.algo == "agent57_light":
+        return bench_agent57_light(args, dev_index, rank, world)
+    cfg = RainbowDeviceConfig(n_envs=envs_per_gpu, batch_size=args.batch_size, memory_capacity=args.capacity, seed=0, enable_noisy_dense=args.noisy)
 
     if dist is not None:
         from simple_distributed_rl_amd.device.dist import DistributedRainbow
@@ -250,6 +256,66 @@ def main():
 
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
+
+
+def bench_agent57_light(args, dev_index, rank, world):
+    """The configs[3] workload on ONE GPU: Agent57_light with 84x84x4 frames, E environments + learner (torch networks, libsrlx for everything
+    around them).  `roofline` = the uint8 ring -> float32 stack kernel (the engine's dominant hand-written HBM kernel), timed in isolation."""
+    import torch
+
+    import simple_distributed_rl_amd as srl
+    from simple_distributed_rl_amd.algorithms import agent57_light
+    from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
+
+    assert world == 1, "bench.py --algo agent57_light is a single-GPU line (the 7+1 topology is Runner.train_mp / tests/test_dist_gpu.py)"
+    rl = agent57_light.Config(batch_size=args.batch_size)
+    rl.window_length = 4
+    rl.memory.capacity, rl.memory.warmup_size = args.capacity, min(args.capacity // 2, 80_000)
+    rl.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1_000_000)
+    rl.input_block.image.set_dqn_block()
+    rl.hidden_block.set_dueling_network((512,))
+    env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(episode_len=args.episode_len)))
+    rl.setup(env)
+    eng = Agent57LightEngine(rl, args.envs, dev_index, episode_len=args.episode_len, seed=0)
+    eng.prefill()
+    inner = max(1, args.inner)
+    for _ in range(max(1, args.warmup) * inner):
+        eng.step(args.updates)
+    torch.cuda.synchronize()
+    n_lock = args.steps * inner
+    t0 = time.perf_counter()
+    for _ in range(n_lock):
+        eng.step(args.updates)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # roofline of the stack kernel, isolated
+    reps = 50
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        eng.replay.stack_current()
+    a.record()
+    for _ in range(reps):
+        eng.replay.stack_current()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    nbytes = args.envs * 4 * 84 * 84 * (1 + 4)
+    info = eng.info()
+    out = {
+        "metric": "env-steps/sec + learner updates/sec, Agent57_light 84x84x4", "value": n_lock * args.envs / elapsed, "unit": "env-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "learner_updates_per_s": n_lock * args.updates / elapsed, "ms_per_lock_step": 1e3 * elapsed / n_lock, "rccl_ranks": 1,
+        "config": {"workload": "Agent57_light on synthetic 84x84x4 Atari frames (BASELINE.json configs[3] workload on one GPU): 2 UVFA Q-networks, NGU episodic + RND "
+                               "lifelong intrinsic reward, per-environment sliding-window UCB, PER", "lock_steps_per_step": inner, "envs_per_gpu": args.envs,
+                   "learner_updates_per_lock_step": args.updates, "batch_size": args.batch_size, "per_capacity": eng.replay.capacity, "actor_num": rl.actor_num,
+                   "networks": "torch modules (MIOpen / hipBLASLt); libsrlx: frame ring + stack, epsilon-greedy, UCB, NGU kNN / RND reward, targets, losses, priorities, PER",
+                   "hip_graphs": False},
+        "roofline": {"kernel": "k_stack_current_u8 (uint8 frame ring -> float32 [E,4,84,84] network input)", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes,
+                     "avg_launch_ms": ms, "note": "isolated launches"},
+        "final": {"loss": info.get("loss"), "train_count": info["train_count"], "memory": info["memory"]},
+    }
     print(json.dumps(out), flush=True)
 
 

@@ -347,6 +347,15 @@ int srlx_agent57_seq_td(int64_t batch, int seq_len, int n_actions, const float *
                         const float *d_discounts, const float *d_weights, double retrace_h, int enable_double_dqn,
                         int enable_rescale, float *d_target, float *d_loss, float *d_grad_q, float *d_td_mean, float *d_scratch,
                         void *stream);
+/* Sliding-window UCB meta-controller of Agent57(_light), one per device-resident environment (replaces the per-actor-process
+ * controller of srl/algorithms/agent57_light/agent57_light.py:317-353).  State (caller-allocated device arrays): ring_arm int32
+ * [E][window], ring_reward f32 [E][window], head int32 [E] (0), n_recent int32 [E] (0), count int32 [E][N] (ALL ONES), sum f64 [E][N]
+ * (0), arm int32 [E] (-1).  Environments with done[e] != 0 (NULL = all) book `episode_reward[e]` for their current arm and choose the
+ * next: arms 0..N-1 in order first, then with u[e][0] < epsilon the arm floor(u[e][1] * N), else the UCB maximiser with ties broken by
+ * u[e][2].  u: f64 [E][3] uniforms. */
+int srlx_agent57_ucb_step(int64_t n_envs, int n_arms, int window, int32_t *d_ring_arm, float *d_ring_reward, int32_t *d_head, int32_t *d_n_recent,
+                          int32_t *d_count, double *d_sum, int32_t *d_arm, const uint8_t *d_done, const float *d_episode_reward, const double *d_u,
+                          double epsilon, double beta, void *stream);
 int srlx_agent57_priority(int64_t batch, int n_actions, const float *d_target_ext, const float *d_q_ext,
                           const float *d_target_int, const float *d_q_int, const int32_t *d_actions,
                           const int32_t *d_actor_idx, const float *d_beta_list, float *d_td_ext, float *d_td_int,
@@ -364,6 +373,9 @@ int srlx_agent57_priority(int64_t batch, int n_actions, const float *d_target_ex
  *                                    gather_nstep, int64 [B][n+1][window] offsets of s_0..s_n (online network) and,
  *                                    if not NULL, int64 [B][n][window] offsets of s_1..s_n (target network) */
 int srlx_store_obs_base(srlx_store_t *h, void **d_base, int64_t *frame_bytes);
+/* sampled tree indices -> (environment, ring slot of the item's first transition, ring slot of the transition before it or -1 when the
+ * item starts an episode): lets an engine gather per-step fields it keeps in its own [ring slot][env] arrays (Agent57's UVFA inputs) */
+int srlx_store_locate(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int64_t *d_env, int64_t *d_slot, int64_t *d_prev_slot, void *stream);
 int srlx_store_frame_table_current(srlx_store_t *h, int64_t *d_out, void *stream);
 int srlx_store_gather_items(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int k_begin, int k_count, int64_t *d_frame_off,
                             int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream);

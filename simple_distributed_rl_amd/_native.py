@@ -69,6 +69,8 @@ SIGNATURES = {
     "srlx_store_commit_step": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_store_views": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p)]),
     "srlx_store_gather_nstep": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_store_locate": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_agent57_ucb_step": (c_int, [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_p]),
     "srlx_store_obs_base": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i64)]),
     "srlx_store_frame_table_current": (c_int, [c_p, c_p, c_p]),
     "srlx_store_gather_items": (c_int, [c_p, c_i64, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_p]),

@@ -206,94 +206,46 @@ class Parameter(RLParameter):
 
 
 class Trainer(RLTrainer):
+    """Host batch -> GPU once, then `Agent57LightLearner` (device/agent57_light.py): the update shared with the E-environment engine."""
+
     def on_setup(self) -> None:
+        from simple_distributed_rl_amd.device.agent57_light import Agent57LightLearner
+
         self.device = require_gpu(self.config.used_device_torch)
         self.parameter.to_device(self.device)
-        self.ops = TdOps(self.device)
-        c, p = self.config, self.parameter
-        self.q_ext_optimizer = torch.optim.Adam(p.q_ext_online.parameters(), lr=c.lr_ext)
-        self.q_int_optimizer = torch.optim.Adam(p.q_int_online.parameters(), lr=c.lr_int)
-        self.emb_optimizer = torch.optim.Adam(p.emb_network.parameters(), lr=c.episodic_lr)
-        self.lifelong_optimizer = torch.optim.Adam(p.lifelong_train.parameters(), lr=c.lifelong_lr)
-        self.beta_list = torch.tensor(np.array(funcs.create_beta_list(c.actor_num), np.float32), device=self.device)
-        self.discount_list = torch.tensor(np.array(funcs.create_discount_list(c.actor_num), np.float32), device=self.device)
-        self.actor_eye = torch.eye(c.actor_num, dtype=torch.float32, device=self.device)
-        self.action_eye = torch.eye(c.action_space.n, dtype=torch.float32, device=self.device)
-        self.sync_count = 0
-        self.np_dtype = c.get_dtype("np")
+        self.core = Agent57LightLearner(self.config, self.parameter, self.device, channels_first=False)
+        self.core.train_count = self.train_count
+        self.np_dtype = self.config.get_dtype("np")
 
-    def _update_q(self, online, target_net, optimizer, rewards, next_inputs, cur_inputs, undone, discount, inv, action, w):
-        """model_torch.py:384-443 with the arithmetic around the three forwards in libsrlx."""
-        cfg = self.config
-        with torch.no_grad():  # agent57_light.py:241-257
-            online.eval()
-            q_tg_next = target_net(next_inputs)
-            q_on_next = online(next_inputs) if cfg.enable_double_dqn else None
-        target = self.ops.dqn_target(q_on_next, q_tg_next, rewards, undone, inv, 0.0, cfg.enable_double_dqn, cfg.enable_rescale, False, discount_per_sample=discount)
-        online.train()
-        q = online(cur_inputs)
-        _, loss, grad, _ = self.ops.huber(target, q, action, w)
-        optimizer.zero_grad()
-        q.backward(grad)
-        optimizer.step()
-        return target, q.detach(), loss
+    # the optimisers / lists of the reference trainer, for callers that reach into it
+    q_ext_optimizer = property(lambda self: self.core.q_ext_optimizer)
+    q_int_optimizer = property(lambda self: self.core.q_int_optimizer)
+    emb_optimizer = property(lambda self: self.core.emb_optimizer)
+    lifelong_optimizer = property(lambda self: self.core.lifelong_optimizer)
+    beta_list = property(lambda self: self.core.beta_list)
+    discount_list = property(lambda self: self.core.discount_list)
+    sync_count = property(lambda self: self.core.sync_count)
+    td_ext = property(lambda self: self.core.td_ext)
+    td_int = property(lambda self: self.core.td_int)
 
     def train(self) -> None:
         sampled = self.memory.sample()
         if sampled is None:
             return
         batches, weights, update_args = sampled
-        cfg, d, p = self.config, self.device, self.parameter
+        cfg, d = self.config, self.device
         (states, n_states, onehot_actions, next_invalid, rewards_ext, rewards_int, undone, prev_onehot_actions, prev_rewards_ext, prev_rewards_int,
          actor_idx) = zip(*batches)
         B, A = len(batches), cfg.action_space.n
         f32 = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32), device=d)  # noqa: E731
-        states, n_states = f32(states), f32(n_states)
-        action = torch.as_tensor(np.argmax(np.asarray(onehot_actions), axis=1).astype(np.int32), device=d)
+        action = torch.as_tensor(np.argmax(np.asarray(onehot_actions), axis=1).astype(np.int64), device=d)
         prev_action = torch.as_tensor(np.argmax(np.asarray(prev_onehot_actions), axis=1).astype(np.int64), device=d)
-        r_ext, r_int, undone_t = f32(rewards_ext), f32(rewards_int), f32(undone)
-        pr_ext, pr_int = f32(prev_rewards_ext).view(B, 1), f32(prev_rewards_int).view(B, 1)
-        actor = torch.as_tensor(np.asarray(actor_idx, dtype=np.int32), device=d)
-        w = f32(weights)
-        inv = invalid_mask(next_invalid, (B, A), d)
-        actor_onehot = self.actor_eye[actor.long()]
-        discount = self.discount_list[actor.long()]  # model_torch.py:287
-        onehot_action = self.action_eye[action.long()]
-        next_inputs = [n_states, r_ext.view(B, 1), r_int.view(B, 1), onehot_action, actor_onehot]  # :294-299
-        cur_inputs = [states, pr_ext, pr_int, self.action_eye[prev_action], actor_onehot]  # :427-433
-
-        tgt_e, q_e, ext_loss = self._update_q(p.q_ext_online, p.q_ext_target, self.q_ext_optimizer, r_ext, next_inputs, cur_inputs, undone_t, discount, inv, action, w)
-        self.info["ext_loss"] = float(ext_loss.item())
-        tgt_i = q_i = None
-        if cfg.enable_intrinsic_reward:
-            tgt_i, q_i, int_loss = self._update_q(p.q_int_online, p.q_int_target, self.q_int_optimizer, r_int, next_inputs, cur_inputs, undone_t, discount, inv, action, w)
-            self.info["int_loss"] = float(int_loss.item())
-            # inverse-dynamics embedding (:341-348)
-            p.emb_network.train()
-            emb_loss = torch.nn.functional.mse_loss(p.emb_network([states, n_states]), onehot_action)
-            self.emb_optimizer.zero_grad()
-            emb_loss.backward()
-            self.emb_optimizer.step()
-            self.info["emb_loss"] = float(emb_loss.item())
-            # RND (:353-362)
-            with torch.no_grad():
-                lifelong_target_val = p.lifelong_target(states)
-            p.lifelong_train.train()
-            lifelong_loss = torch.nn.functional.mse_loss(lifelong_target_val, p.lifelong_train(states))
-            self.lifelong_optimizer.zero_grad()
-            lifelong_loss.backward()
-            self.lifelong_optimizer.step()
-            self.info["lifelong_loss"] = float(lifelong_loss.item())
-
-        use_int = cfg.enable_intrinsic_reward and not cfg.disable_int_priority  # :367-372
-        self.td_ext, self.td_int, priorities = self.ops.agent57_priority(tgt_e, q_e, tgt_i if use_int else None, q_i if use_int else None, action, actor, self.beta_list)
+        actor = torch.as_tensor(np.asarray(actor_idx, dtype=np.int64), device=d)
+        self.core.train_count = self.train_count
+        priorities = self.core.update(f32(states), f32(n_states), action, f32(rewards_ext), f32(rewards_int), f32(undone), prev_action, f32(prev_rewards_ext),
+                                      f32(prev_rewards_int), actor, f32(weights), invalid_mask(next_invalid, (B, A), d))
+        self.info.update(self.core.losses())
         self.memory.update(update_args, priorities.cpu().numpy(), self.train_count)
-
-        if self.train_count % cfg.target_model_update_interval == 0:  # :376-379
-            p.q_ext_target.load_state_dict(p.q_ext_online.state_dict())
-            p.q_int_target.load_state_dict(p.q_int_online.state_dict())
-            self.sync_count += 1
-        self.info["sync"] = self.sync_count
         self.train_count += 1
 
 

@@ -345,6 +345,78 @@ __global__ void __launch_bounds__(256) k_agent57_seq_td(SeqArgs a) {
     if (threadIdx.x == 0) atomicAdd(a.loss, red[0] * inv_n);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Sliding-window UCB meta-controller, one per environment (agent57_light.py:317-353: `_calc_actor_index`).
+// Every actor process of the reference keeps ONE controller; E device-resident environments keep E of them: the window of the
+// last `window - 1` (arm, episode reward) pairs as a ring, per-arm counts (every arm starts at 1) and reward sums in float64 like
+// the Python floats.  One thread per environment; only environments whose episode just ended (`done`) advance.
+//   u[e][0] < epsilon  -> a uniformly random arm floor(u[e][1] * N); otherwise the arm of maximal
+//   reward/count + beta * sqrt(log(n_recent) / count), ties broken uniformly with u[e][2] (get_random_max_index).
+// ------------------------------------------------------------------------------------------------------------------
+struct UcbDev {
+    i64 E;
+    int N, window;
+    int32_t *ring_arm;   // [E][window]
+    float *ring_reward;  // [E][window]
+    int32_t *head, *n_recent, *count;  // [E], [E], [E][N]
+    double *sum;         // [E][N]
+    int32_t *arm;        // [E] current arm (-1 before the first episode)
+};
+
+__global__ void __launch_bounds__(256) k_ucb_step(UcbDev s, const unsigned char *done, const float *episode_reward, const double *u, double epsilon, double beta) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.E || (done && !done[e])) return;
+    int32_t *cnt = s.count + e * s.N;
+    double *sum = s.sum + e * s.N;
+    int n = s.n_recent[e];
+    const int a_prev = s.arm[e];
+    if (a_prev >= 0) {  // the episode that just ended was played by a_prev
+        const float r = episode_reward[e];
+        const int slot = (s.head[e] + n) % s.window;
+        s.ring_arm[e * s.window + slot] = a_prev;
+        s.ring_reward[e * s.window + slot] = r;
+        n += 1;
+        cnt[a_prev] += 1;
+        sum[a_prev] += (double)r;
+        if (n >= s.window) {  // `if len(recent) >= window: pop(0)`
+            const int h0 = s.head[e];
+            const int a_old = s.ring_arm[e * s.window + h0];
+            cnt[a_old] -= 1;
+            sum[a_old] -= (double)s.ring_reward[e * s.window + h0];
+            s.head[e] = (h0 + 1) % s.window;
+            n -= 1;
+        }
+        s.n_recent[e] = n;
+    }
+    int next;
+    if (n < s.N) {
+        next = n;  // every arm once, in order
+    } else if (u[e * 3] < epsilon) {
+        next = (int)(u[e * 3 + 1] * s.N);
+        next = next >= s.N ? s.N - 1 : next;
+    } else {
+        const double ln = log((double)n);
+        double best = -INFINITY;
+        int ties = 0;
+        for (int i = 0; i < s.N; i++) {
+            const double v = sum[i] / (double)cnt[i] + beta * sqrt(ln / (double)cnt[i]);
+            if (v > best) best = v, ties = 1;
+            else if (v == best) ties++;
+        }
+        int pick = (int)(u[e * 3 + 2] * ties);
+        pick = pick >= ties ? ties - 1 : pick;
+        next = 0;
+        for (int i = 0; i < s.N; i++) {
+            const double v = sum[i] / (double)cnt[i] + beta * sqrt(ln / (double)cnt[i]);
+            if (v == best && pick-- == 0) {
+                next = i;
+                break;
+            }
+        }
+    }
+    s.arm[e] = next;
+}
 }  // namespace
 
 struct srlx_ngu {
@@ -482,6 +554,18 @@ int srlx_agent57_seq_td(int64_t batch, int seq_len, int n_actions, const float *
     a.pi = (u8 *)(d_scratch + batch * seq_len);
     SRLX_HIP(hipMemsetAsync(d_loss, 0, sizeof(float), (hipStream_t)stream));
     hipLaunchKernelGGL(k_agent57_seq_td, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+
+int srlx_agent57_ucb_step(int64_t n_envs, int n_arms, int window, int32_t *d_ring_arm, float *d_ring_reward, int32_t *d_head, int32_t *d_n_recent,
+                          int32_t *d_count, double *d_sum, int32_t *d_arm, const uint8_t *d_done, const float *d_episode_reward, const double *d_u,
+                          double epsilon, double beta, void *stream) {
+    SRLX_REQUIRE(n_envs > 0 && n_arms > 0 && window > 1 && d_ring_arm && d_ring_reward && d_head && d_n_recent && d_count && d_sum && d_arm && d_episode_reward && d_u,
+                 "agent57_ucb_step: bad argument");
+    UcbDev s{n_envs, n_arms, window, d_ring_arm, d_ring_reward, d_head, d_n_recent, d_count, d_sum, d_arm};
+    hipLaunchKernelGGL(k_ucb_step, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s, d_done, d_episode_reward, d_u, epsilon, beta);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

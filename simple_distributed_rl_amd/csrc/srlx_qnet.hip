@@ -631,7 +631,7 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     if (h->d_draw) (void)hipFree(h->d_draw);
     if (h->wpack) (void)hipFree(h->wpack);
     if (h->side) (void)hipStreamDestroy(h->side);
-    for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join})
+    for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join, h->ev_wt})
         if (e) (void)hipEventDestroy(e);
     delete h;
     return SRLX_OK;

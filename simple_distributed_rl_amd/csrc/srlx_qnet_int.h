@@ -20,7 +20,7 @@ struct srlx_qnet {
     float *dxpad, *w_t, *w_t2;            // padded data gradient (per parity class), transposed filters of conv3 / conv2
     size_t w_part_floats;
     hipStream_t side;                     // weight-gradient branch of the backward pass (forks from / joins the caller's stream)
-    hipEvent_t ev_fork, ev_d3, ev_d2, ev_d1, ev_join;
+    hipEvent_t ev_fork, ev_d3, ev_d2, ev_d1, ev_join, ev_wt;
     hipEvent_t probe0, probe1;            // optional, caller-owned: recorded around the two conv GEMM launches of the next forward (srlx_qnet_set_probe)
     // NoisyLinear dense layers (srlx_qnet_bind_noisy, srlx_noisy.hip): wf..a2b above then point at `eff`, the effective tensors
     // mu + sigma * eps of the current noise draw; order of the six: wf, bf, v2w, v2b, a2w, a2b

@@ -273,6 +273,24 @@ __global__ void __launch_bounds__(256) k_gather_meta(StoreDev s, i64 B, const i6
     meta[b] = item_meta(s, b, tree_idx, actions, rewards, terminated);
 }
 
+// (environment, ring slot of the first transition, ring slot of the transition before it or -1 at an episode start) of sampled items:
+// what an engine needs to gather per-step fields it keeps in its own [ring slot][env] arrays next to the store's
+__global__ void __launch_bounds__(256) k_locate(StoreDev s, i64 B, const i64 *tree_idx, i64 *env, i64 *slot, i64 *prev_slot) {
+    const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const i64 N = s.E * s.item_len;
+    i64 j = tree_idx[b] - (N - 1);
+    j = j < 0 ? 0 : (j >= N ? N - 1 : j);
+    const i64 e = j % s.E, tau = j / s.E;
+    const i64 p_last = s.pos[0] - 1;
+    i64 q = p_last - posmod(p_last - tau, s.item_len) - (s.n - 1);
+    if (q < 0) q = 0;
+    const i64 r = posmod(q, s.L);
+    env[b] = e;
+    slot[b] = r;
+    if (prev_slot) prev_slot[b] = s.step_in_ep[e * s.L + r] == 0 ? -1 : posmod(q - 1, s.L);
+}
+
 __global__ void __launch_bounds__(256) k_gather_obs_u8(StoreDev s, const ItemMeta *meta, float *out) {
     const i64 fc = blockIdx.x;  // (b, k, c)
     const int S = s.n + 1;
@@ -624,6 +642,14 @@ int srlx_store_gather_nstep(srlx_store_t *h, int64_t batch, const int64_t *d_tre
         hipLaunchKernelGGL(k_gather_obs<true>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, (i64)batch, meta, d_obs);
     else
         hipLaunchKernelGGL(k_gather_obs<false>, dim3(grid_for(total, 256 * 32)), dim3(256), 0, st, d, (i64)batch, meta, d_obs);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_locate(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int64_t *d_env, int64_t *d_slot, int64_t *d_prev_slot, void *stream) {
+    SRLX_REQUIRE(h && d_tree_idx && d_env && d_slot && batch > 0, "store_locate: bad argument");
+    srlx::DeviceGuard guard(h->device);
+    hipLaunchKernelGGL(k_locate, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->d, batch, d_tree_idx, d_env, d_slot, d_prev_slot);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

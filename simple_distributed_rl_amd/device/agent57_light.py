@@ -1,0 +1,377 @@
+"""Device-resident Agent57_light actor/learner: E lock-stepped environments on one GPU (BASELINE.json configs[3] workload).
+
+The reference runs ONE environment per actor process (srl/algorithms/agent57_light/agent57_light.py:271-471) and trains from
+pickled 11-field items (:420-432, model_torch.py:263-443).  Here every per-actor quantity becomes a per-environment device
+array and every list comprehension a kernel:
+
+    UVFA inputs (prev action / prev extrinsic reward / prev intrinsic reward / one-hot arm)   per-environment tensors
+    sliding-window UCB meta-controller (:317-353), one per environment                          srlx_agent57_ucb_step
+    epsilon-greedy on q_ext + beta[arm] * q_int (:355-375)                                      srlx_policy_epsilon_greedy
+    frame stacking, item storage (state, next state, action, reward, undone)                    srlx_store_* (uint8 ring, n_step = 1)
+    the other item fields (intrinsic reward, arm, previous action / rewards)                    [ring slot][env] arrays, gathered
+                                                                                                by (slot, env) from srlx_store_locate
+    episodic novelty: kNN over the episode's embeddings (:473-513)                              srlx_ngu_episodic_reward (E memories)
+    lifelong novelty: clipped RND error (:515-529)                                              srlx_ngu_lifelong_reward
+    per-arm-discount double-DQN targets, Huber + gradient seed, |td_ext + beta td_int|          srlx_dqn_target, fused TD kernel,
+                                                                                                srlx_agent57_priority
+    proportional replay                                                                         srlx_per_*
+
+The five networks (two UVFA Q-networks, the inverse-dynamics embedding, RND target / predictor) are the plugin's torch
+modules (algorithms/agent57_light.py: the reference's module trees, so parameters stay interchangeable); their convolutions
+and GEMMs run through MIOpen / hipBLASLt.  `Agent57LightLearner` is shared with the single-environment plugin trainer.
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from simple_distributed_rl_amd import _native as N
+from simple_distributed_rl_amd.algorithms._device_ops import NguOps, TdOps
+from simple_distributed_rl_amd.device.replay import DeviceReplay
+from simple_distributed_rl_amd.rl import functions as funcs
+
+
+def q_values(net, state_cf, r_ext, r_int, onehot_action, onehot_actor):
+    """QNetwork.forward (agent57_light/model_torch.py:35-64) on a channels-first float32 stack."""
+    parts = [net.in_block(state_cf, channels_first=True)]
+    if net.input_ext_reward:
+        parts.append(r_ext)
+    if net.input_int_reward:
+        parts.append(r_int)
+    if net.input_action:
+        parts.append(onehot_action)
+    parts.append(onehot_actor)
+    return net.hidden_block(torch.cat(parts, dim=1))
+
+
+def embed(net, state_cf):
+    return net.emb_block(net.in_block(state_cf, channels_first=True))
+
+
+def rnd(net, state_cf):
+    return net.hidden_normalize(net.hidden_block(net.in_block(state_cf, channels_first=True)))
+
+
+class UcbBank:
+    """E sliding-window UCB meta-controllers in HBM (agent57_light.py:317-353)."""
+
+    def __init__(self, n_envs: int, n_arms: int, window: int, epsilon: float, beta: float, device: torch.device, seed: int):
+        self.E, self.n_arms, self.window, self.epsilon, self.beta, self.dev, self.seed = n_envs, n_arms, window, epsilon, beta, device, seed
+        self.lib = N.lib()
+        d = device
+        self.ring_arm = torch.zeros((n_envs, window), dtype=torch.int32, device=d)
+        self.ring_reward = torch.zeros((n_envs, window), dtype=torch.float32, device=d)
+        self.head = torch.zeros(n_envs, dtype=torch.int32, device=d)
+        self.n_recent = torch.zeros(n_envs, dtype=torch.int32, device=d)
+        self.count = torch.ones((n_envs, n_arms), dtype=torch.int32, device=d)
+        self.sum = torch.zeros((n_envs, n_arms), dtype=torch.float64, device=d)
+        self.arm = torch.full((n_envs,), -1, dtype=torch.int32, device=d)
+        self.u = torch.zeros((n_envs, 3), dtype=torch.float64, device=d)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=d)
+
+    def step(self, done: Optional[torch.Tensor], episode_reward: torch.Tensor, uniforms: Optional[torch.Tensor] = None):
+        st = N.torch_stream_ptr()
+        if uniforms is None:
+            N.check(self.lib.srlx_rng_uniform(self.seed ^ 0x0C8, N.tptr(self.counter), self.u.numel(), N.tptr(self.u), st))
+            uniforms = self.u
+        N.check(self.lib.srlx_agent57_ucb_step(self.E, self.n_arms, self.window, N.tptr(self.ring_arm), N.tptr(self.ring_reward), N.tptr(self.head),
+                                               N.tptr(self.n_recent), N.tptr(self.count), N.tptr(self.sum), N.tptr(self.arm), N.tptr(done),
+                                               N.tptr(episode_reward), N.tptr(uniforms), float(self.epsilon), float(self.beta), st))
+        return self.arm
+
+
+class Agent57LightLearner:
+    """One Agent57_light update on device tensors (model_torch.py:263-443): both Q-networks, the embedding and the RND
+    predictor, the mixed priorities.  Used by the plugin Trainer (one host batch put on the GPU) and by the engine."""
+
+    def __init__(self, config, parameter, device: torch.device, channels_first: bool):
+        c, p = config, parameter
+        self.config, self.parameter, self.device, self.cf = c, p, device, channels_first
+        self.ops = TdOps(device)
+        self.q_ext_optimizer = torch.optim.Adam(p.q_ext_online.parameters(), lr=c.lr_ext)
+        self.q_int_optimizer = torch.optim.Adam(p.q_int_online.parameters(), lr=c.lr_int)
+        self.emb_optimizer = torch.optim.Adam(p.emb_network.parameters(), lr=c.episodic_lr)
+        self.lifelong_optimizer = torch.optim.Adam(p.lifelong_train.parameters(), lr=c.lifelong_lr)
+        self.beta_list = torch.tensor(np.array(funcs.create_beta_list(c.actor_num), np.float32), device=device)
+        self.discount_list = torch.tensor(np.array(funcs.create_discount_list(c.actor_num), np.float32), device=device)
+        self.actor_eye = torch.eye(c.actor_num, dtype=torch.float32, device=device)
+        self.action_eye = torch.eye(c.action_space.n, dtype=torch.float32, device=device)
+        self.train_count = 0
+        self.sync_count = 0
+        self.info: dict = {}
+
+    def _q(self, net, inputs):
+        return q_values(net, *inputs) if self.cf else net(inputs)
+
+    def _update_q(self, online, target_net, optimizer, rewards, next_inputs, cur_inputs, undone, discount, inv, action, w):
+        """model_torch.py:384-443 with the arithmetic around the three forwards in libsrlx."""
+        cfg = self.config
+        with torch.no_grad():  # agent57_light.py:241-257
+            online.eval()
+            q_tg_next = self._q(target_net, next_inputs)
+            q_on_next = self._q(online, next_inputs) if cfg.enable_double_dqn else None
+        target = self.ops.dqn_target(q_on_next, q_tg_next, rewards, undone, inv, 0.0, cfg.enable_double_dqn, cfg.enable_rescale, False, discount_per_sample=discount)
+        online.train()
+        q = self._q(online, cur_inputs)
+        _, loss, grad, _ = self.ops.huber(target, q, action, w)
+        optimizer.zero_grad()
+        q.backward(grad)
+        optimizer.step()
+        return target, q.detach(), loss
+
+    def update(self, states, n_states, action, r_ext, r_int, undone, prev_action, prev_r_ext, prev_r_int, actor, weights, invalid=None):
+        """states / n_states float32 (channels-first stacks for the engine, the reference's layout for the plugin); action / prev_action /
+        actor int tensors [B]; the rest float32 [B].  Returns the new priorities (device float32 [B])."""
+        cfg, p = self.config, self.parameter
+        B = action.shape[0]
+        actor_onehot = self.actor_eye[actor.long()]
+        discount = self.discount_list[actor.long()]  # model_torch.py:287
+        onehot_action = self.action_eye[action.long()]
+        next_inputs = [n_states, r_ext.view(B, 1), r_int.view(B, 1), onehot_action, actor_onehot]  # :294-299
+        cur_inputs = [states, prev_r_ext.view(B, 1), prev_r_int.view(B, 1), self.action_eye[prev_action.long()], actor_onehot]  # :427-433
+        action32 = action.to(torch.int32)
+        tgt_e, q_e, ext_loss = self._update_q(p.q_ext_online, p.q_ext_target, self.q_ext_optimizer, r_ext, next_inputs, cur_inputs, undone, discount, invalid,
+                                              action32, weights)
+        self.ext_loss = ext_loss
+        tgt_i = q_i = None
+        if cfg.enable_intrinsic_reward:
+            tgt_i, q_i, int_loss = self._update_q(p.q_int_online, p.q_int_target, self.q_int_optimizer, r_int, next_inputs, cur_inputs, undone, discount, invalid,
+                                                  action32, weights)
+            self.int_loss = int_loss
+            # inverse-dynamics embedding (:341-348)
+            p.emb_network.train()
+            if self.cf:
+                h = torch.cat([embed(p.emb_network, states), embed(p.emb_network, n_states)], dim=1)
+                probs = torch.softmax(p.emb_network.out_block_out1(p.emb_network.out_block_normalize(p.emb_network.out_block(h))), dim=1)
+            else:
+                probs = p.emb_network([states, n_states])
+            emb_loss = torch.nn.functional.mse_loss(probs, onehot_action)
+            self.emb_optimizer.zero_grad()
+            emb_loss.backward()
+            self.emb_optimizer.step()
+            self.emb_loss = emb_loss.detach()
+            # RND (:353-362)
+            with torch.no_grad():
+                lifelong_target_val = rnd(p.lifelong_target, states) if self.cf else p.lifelong_target(states)
+            p.lifelong_train.train()
+            lifelong_loss = torch.nn.functional.mse_loss(lifelong_target_val, rnd(p.lifelong_train, states) if self.cf else p.lifelong_train(states))
+            self.lifelong_optimizer.zero_grad()
+            lifelong_loss.backward()
+            self.lifelong_optimizer.step()
+            self.lifelong_loss = lifelong_loss.detach()
+        use_int = cfg.enable_intrinsic_reward and not cfg.disable_int_priority  # :367-372
+        self.td_ext, self.td_int, priorities = self.ops.agent57_priority(tgt_e, q_e, tgt_i if use_int else None, q_i if use_int else None, action32,
+                                                                         actor.to(torch.int32), self.beta_list)
+        if self.train_count % cfg.target_model_update_interval == 0:  # :376-379 (fires at 0 too)
+            p.q_ext_target.load_state_dict(p.q_ext_online.state_dict())
+            p.q_int_target.load_state_dict(p.q_int_online.state_dict())
+            self.sync_count += 1
+        self.train_count += 1
+        return priorities
+
+    def losses(self) -> dict:
+        out = {"ext_loss": float(self.ext_loss.item()), "sync": self.sync_count}
+        if self.config.enable_intrinsic_reward:
+            out.update(int_loss=float(self.int_loss.item()), emb_loss=float(self.emb_loss.item()), lifelong_loss=float(self.lifelong_loss.item()))
+        return out
+
+
+class Agent57LightEngine:
+    """E environments + learner on one GPU.  `rl_config`: a set-up algorithms.agent57_light.Config (image observations, window 4);
+    `parameter`: its Parameter (the five networks), created here when not given."""
+
+    def __init__(self, rl_config, n_envs: int, device: int = 0, episode_len: int = 200, seed: int = 0, env=None, parameter=None, ring_len: Optional[int] = None):
+        from simple_distributed_rl_amd.device.rainbow import SyntheticAtariVecEnv
+
+        c = self.cfg = rl_config
+        assert c.is_setup(), "rl_config.setup(env) first: the networks are built from the negotiated spaces"
+        self.dev = torch.device(f"cuda:{device}")
+        self.lib = N.lib()
+        self.E, self.seed = int(n_envs), int(seed)
+        shape = c.observation_space.shape  # (H, W, window)
+        H, W_, Wn = int(shape[0]), int(shape[1]), int(shape[2])
+        assert Wn == c.window_length
+        self.hw, self.Wn, self.A = (H, W_), Wn, c.action_space.n
+        E, B = self.E, c.batch_size
+        mem = c.memory
+        kw = mem.kwargs if mem.name != "ReplayBuffer" else {}
+        pad = 1 + Wn
+        if ring_len is None:
+            ring_len = -(-mem.capacity // E) + pad
+        self.replay = DeviceReplay(E, ring_len, H * W_, Wn, 1, self.A, B, True, False, float(kw.get("alpha", 0.0)), float(kw.get("beta_initial", 0.4)),
+                                   int(kw.get("beta_steps", 1_000_000)), float(kw.get("epsilon", 1e-4)), mem.warmup_size, self.seed, device)
+        self.L = self.replay.L
+        if env is None:
+            self.env = SyntheticAtariVecEnv(self.replay, episode_len)
+        else:
+            self.env = env(self.replay) if callable(env) else env
+        c._set_device(str(self.dev))
+        if parameter is None:
+            parameter = c.make_parameter()
+        parameter.to_device(self.dev)
+        self.parameter = p = parameter
+        self.learner = Agent57LightLearner(c, p, self.dev, channels_first=True)
+        d = self.dev
+        Na = c.actor_num
+        self.beta_list, self.discount_list = self.learner.beta_list, self.learner.discount_list
+        self.eps_list = torch.tensor(np.array(funcs.create_epsilon_list(Na), np.float32), device=d)
+        self.actor_eye, self.action_eye = self.learner.actor_eye, self.learner.action_eye
+        self.ucb = UcbBank(E, Na, c.ucb_window_size, c.ucb_epsilon, c.ucb_beta, d, self.seed)
+        self.ngu = None
+        if c.enable_intrinsic_reward:
+            self.ngu = NguOps(d, E, p.emb_network.emb_block.out_size, c.episodic_memory_capacity, c.episodic_count_max, c.episodic_epsilon,
+                              c.episodic_cluster_distance, c.episodic_pseudo_counts)
+        # per-environment actor state (the reference keeps these on the worker object, :288-311)
+        self.episode_reward = torch.zeros(E, dtype=torch.float32, device=d)
+        self.prev_action = torch.zeros(E, dtype=torch.int64, device=d)
+        self.prev_r_ext = torch.zeros(E, dtype=torch.float32, device=d)
+        self.prev_r_int = torch.zeros(E, dtype=torch.float32, device=d)
+        self.actions = torch.zeros(E, dtype=torch.int32, device=d)
+        self.u_policy = torch.zeros(2 * E, dtype=torch.float64, device=d)
+        self.policy_counter = torch.zeros(1, dtype=torch.int64, device=d)
+        self.reset_lane = torch.zeros(E, dtype=torch.uint8, device=d)  # lanes whose lock-step only delivers a new episode's first frame
+        self.gen = torch.Generator(device=d)
+        self.gen.manual_seed(self.seed + 17)
+        # the item fields the store does not keep, [ring slot][env]
+        L = self.L
+        self.x_r_int = torch.zeros((L, E), dtype=torch.float32, device=d)
+        self.x_actor = torch.zeros((L, E), dtype=torch.int64, device=d)
+        self.x_prev_action = torch.zeros((L, E), dtype=torch.int64, device=d)
+        self.x_prev_r_ext = torch.zeros((L, E), dtype=torch.float32, device=d)
+        self.x_prev_r_int = torch.zeros((L, E), dtype=torch.float32, device=d)
+        self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
+        self.loc_env = torch.zeros(B, dtype=torch.int64, device=d)
+        self.loc_slot = torch.zeros(B, dtype=torch.int64, device=d)
+        self.total_env_steps = 0
+        self.ledger = None
+        self.overlap = False  # the drivers of device/vector_runner.py: updates run on the caller's stream
+        self.training = True
+        self.first_obs = self.env.reset()
+        self.replay.reset_all(self.first_obs)
+        self._begin_episodes(None)
+        self.state = self._stack()
+
+    # ---- helpers --------------------------------------------------------------------------------
+    @property
+    def train_count(self) -> int:
+        return self.learner.train_count
+
+    def _stack(self) -> torch.Tensor:
+        return self.replay.stack_current().view(self.E, self.Wn, *self.hw)
+
+    def _begin_episodes(self, done: Optional[torch.Tensor]):
+        """on_reset (:288-311) for the lanes in `done` (None = all): next arm from the lane's UCB controller, random previous action, zero
+        previous rewards; the arm's (beta, epsilon, discount) are looked up when used."""
+        self.ucb.step(done, self.episode_reward)
+        rnd_a = torch.randint(0, self.A, (self.E,), device=self.dev, generator=self.gen)
+        if done is None:
+            self.prev_action.copy_(rnd_a)
+            self.prev_r_ext.zero_()
+            self.prev_r_int.zero_()
+            self.episode_reward.zero_()
+        else:
+            m = done.bool()
+            self.prev_action = torch.where(m, rnd_a, self.prev_action)
+            self.prev_r_ext = torch.where(m, torch.zeros_like(self.prev_r_ext), self.prev_r_ext)
+            self.prev_r_int = torch.where(m, torch.zeros_like(self.prev_r_int), self.prev_r_int)
+            self.episode_reward = torch.where(m, torch.zeros_like(self.episode_reward), self.episode_reward)
+
+    def arm(self) -> torch.Tensor:
+        return self.ucb.arm.long() if self.training else torch.zeros(self.E, dtype=torch.int64, device=self.dev)
+
+    # ---- actor ----------------------------------------------------------------------------------
+    def policy_q(self):
+        """q_ext, q_int and q = q_ext + beta[arm] * q_int of every lane in its current state (:355-363)."""
+        p, arm = self.parameter, self.arm()
+        inputs = (self.state, self.prev_r_ext.view(-1, 1), self.prev_r_int.view(-1, 1), self.action_eye[self.prev_action], self.actor_eye[arm])
+        with torch.no_grad():
+            q_ext = q_values(p.q_ext_online, *inputs)
+            q_int = q_values(p.q_int_online, *inputs)
+        beta = self.beta_list[arm] if self.training else torch.full((self.E,), float(self.cfg.test_beta), device=self.dev)
+        return q_ext, q_int, (q_ext + beta.view(-1, 1) * q_int).contiguous()
+
+    def actor_step(self):
+        c, r, st = self.cfg, self.replay, N.torch_stream_ptr()
+        E = self.E
+        arm = self.arm()
+        _, _, q = self.policy_q()
+        eps = (self.eps_list[arm] if self.training else torch.full((E,), float(c.test_epsilon), device=self.dev)).contiguous()
+        N.check(self.lib.srlx_rng_uniform(self.seed ^ 0xAC7, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
+        N.check(self.lib.srlx_policy_epsilon_greedy(E, self.A, N.tptr(q), N.tptr(eps), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
+        next_obs, rewards, terminated, done = self.env.step(self.actions)
+        slot = r._steps_committed % self.L  # the ring slot this lock-step's transition goes to
+        self.x_actor[slot] = arm
+        self.x_prev_action[slot] = self.prev_action
+        self.x_prev_r_ext[slot] = self.prev_r_ext
+        self.x_prev_r_int[slot] = self.prev_r_int
+        if self.ledger is not None:
+            self.ledger.account(rewards, done, r.needs_reset_ptr)
+        r.commit(self.actions, rewards, terminated, done, next_obs)
+        self.state = self._stack()  # s_{t+1}: the next lock-step's policy input AND the intrinsic reward's argument
+        live = (self.reset_lane == 0)
+        r_int = torch.zeros(E, dtype=torch.float32, device=self.dev)
+        if c.enable_intrinsic_reward:
+            p = self.parameter
+            with torch.no_grad():
+                p.emb_network.eval()
+                p.lifelong_train.eval()
+                episodic = self.ngu.episodic(embed(p.emb_network, self.state), reset=self.reset_lane, active=live.to(torch.uint8))
+                lifelong = self.ngu.lifelong(rnd(p.lifelong_target, self.state), rnd(p.lifelong_train, self.state), c.lifelong_max)
+            r_int = torch.where(live, episodic * lifelong, r_int)  # :383-391
+        self.x_r_int[slot] = r_int
+        # the worker's bookkeeping (:393-417): lanes in a reset lock-step took no action
+        self.prev_action = torch.where(live, self.actions.long(), self.prev_action)
+        self.prev_r_ext = torch.where(live, rewards, self.prev_r_ext)
+        self.prev_r_int = torch.where(live, r_int, self.prev_r_int)
+        self.episode_reward = self.episode_reward + torch.where(live, rewards, torch.zeros_like(rewards))
+        if self.training:
+            self._begin_episodes(done)  # lanes whose episode just ended: book it with their UCB controller, draw the next arm
+        self.reset_lane = done.clone()
+        self.total_env_steps += E
+
+    # ---- learner --------------------------------------------------------------------------------
+    def learner_step(self) -> bool:
+        r, c = self.replay, self.cfg
+        if r.is_warmup_needed():
+            return False
+        b = r.sample(self.train_count_dev)
+        N.check(self.lib.srlx_store_locate(r.h_store, r.B, N.tptr(b.indices), N.tptr(self.loc_env), N.tptr(self.loc_slot), None, N.torch_stream_ptr()))
+        e, s = self.loc_env, self.loc_slot
+        obs = b.obs.view(r.B, 2, self.Wn, *self.hw)
+        pri = self.learner.update(obs[:, 0], obs[:, 1], b.actions.view(-1), b.rewards.view(-1), self.x_r_int[s, e], 1.0 - b.terminated.view(-1),
+                                  self.x_prev_action[s, e], self.x_prev_r_ext[s, e], self.x_prev_r_int[s, e], self.x_actor[s, e], b.weights)
+        r.update(b.indices, pri)
+        self.train_count_dev.add_(1)
+        return True
+
+    def step(self, learner_updates: int = 1, events=None):
+        if events is not None:
+            events[0].record()
+        self.actor_step()
+        if events is not None:
+            events[1].record()
+        for _ in range(learner_updates):
+            self.learner_step()
+
+    def prefill(self, randomise_priorities: bool = True):
+        """Random-policy rollout until every PER leaf holds an item (untimed benchmark set-up)."""
+        saved = self.eps_list
+        self.eps_list = torch.ones_like(saved)
+        steps = self.replay.item_len
+        for _ in range(steps):
+            self.actor_step()
+        self.eps_list = saved
+        if randomise_priorities:
+            g = torch.Generator(device=self.dev)
+            g.manual_seed(self.seed + 1)
+            pri = torch.rand(self.replay.capacity, dtype=torch.float32, device=self.dev, generator=g)
+            N.check(self.lib.srlx_per_set_range(self.replay.h_per, 0, self.replay.capacity, N.tptr(pri), N.PRIO_F32, 1, N.torch_stream_ptr()))
+        torch.cuda.synchronize(self.dev)
+
+    def info(self) -> dict:
+        d = dict(train_count=self.train_count, memory=self.replay.length())
+        if self.train_count > 0:
+            d.update(self.learner.losses())
+            d["loss"] = d["ext_loss"]
+        return d

@@ -33,8 +33,10 @@ class TransitionBus:
     """Fixed-size per-step transition exchange and parameter fan-out between ranks."""
 
     def __init__(self, n_envs_local: int, obs_elems: int, obs_dtype: torch.dtype, device: torch.device, group=None, learner_rank: int = 0,
-                 always_collective: bool = False):
-        self.E, self.F = n_envs_local, obs_elems
+                 always_collective: bool = False, extra_floats: int = 0):
+        """extra_floats: further float32 fields per environment that ride in the packed record buffer (Agent57_light's intrinsic reward,
+        arm, previous action / rewards)."""
+        self.E, self.F, self.K = n_envs_local, obs_elems, int(extra_floats)
         self.always_collective = always_collective  # run the collectives even at world size 1 (transport tests on a 1-GPU box)
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -50,14 +52,15 @@ class TransitionBus:
             self.g_terminated = torch.zeros(T, dtype=torch.uint8, device=device)
             self.g_done = torch.zeros(T, dtype=torch.uint8, device=device)
             self.g_next_obs = torch.zeros((T, obs_elems), dtype=obs_dtype, device=device)
-            self.g_scal = torch.zeros((self.world, 10 * self.E), dtype=torch.uint8, device=device)  # packed scalar records
+            self.g_scal = torch.zeros((self.world, (10 + 4 * self.K) * self.E), dtype=torch.uint8, device=device)  # packed scalar records
+            self.g_extra = torch.zeros((T, self.K), dtype=torch.float32, device=device) if self.K else None
 
     def _views(self, buf) -> Optional[List[torch.Tensor]]:
         if not self.is_learner:
             return None
         return [buf[r * self.E : (r + 1) * self.E] for r in range(self.world)]
 
-    def push_begin(self, actions, rewards, terminated, done, next_obs):
+    def push_begin(self, actions, rewards, terminated, done, next_obs, extra=None):
         """Start the per-step exchange: every rank contributes its E transitions, the learner rank receives them in rank order
         (env index = rank * E + local index).  On RCCL the two gathers are issued `async_op=True`: they run on the communicator's
         own stream once everything enqueued on the current stream so far has finished, and nothing waits for them until
@@ -66,13 +69,17 @@ class TransitionBus:
         before `push_end`."""
         self._pending = []
         self._direct = None
+        assert (extra is not None) == (self.K > 0)
         if self.world == 1 and not self.always_collective:
-            self._direct = (actions, rewards, terminated, done, next_obs)
+            self._direct = (actions, rewards, terminated, done, next_obs) + ((extra,) if self.K else ())
             return
         # two collectives per step: the frames, and ONE packed record buffer for the four scalar fields
         # ([actions 4E | rewards 4E | terminated E | done E] bytes per rank) that the learner unpacks with strided copies
-        scal = torch.cat([actions.contiguous().view(torch.uint8), rewards.contiguous().view(torch.uint8), terminated.contiguous().view(torch.uint8),
-                          done.contiguous().view(torch.uint8)])
+        fields = [actions.contiguous().view(torch.uint8), rewards.contiguous().view(torch.uint8), terminated.contiguous().view(torch.uint8),
+                  done.contiguous().view(torch.uint8)]
+        if self.K:
+            fields.append(extra.to(torch.float32).contiguous().view(-1).view(torch.uint8))  # [E][K] row-major
+        scal = torch.cat(fields)
         self._keep = (scal, next_obs)  # inputs stay alive until the collectives are done
         staged = dist.get_backend(self.group) == "gloo" and actions.is_cuda  # test rigs: ranks sharing one GPU
         for t, name in ((scal, "g_scal"), (next_obs.contiguous(), "g_next_obs")):
@@ -103,13 +110,16 @@ class TransitionBus:
             self.g_actions.view(torch.uint8).view(self.world, 4 * E).copy_(g[:, : 4 * E])
             self.g_rewards.view(torch.uint8).view(self.world, 4 * E).copy_(g[:, 4 * E : 8 * E])
             self.g_terminated.view(self.world, E).copy_(g[:, 8 * E : 9 * E])
-            self.g_done.view(self.world, E).copy_(g[:, 9 * E :])
+            self.g_done.view(self.world, E).copy_(g[:, 9 * E : 10 * E])
+            if self.K:
+                self.g_extra.view(torch.uint8).view(self.world, 4 * self.K * E).copy_(g[:, 10 * E :])
+                return self.g_actions, self.g_rewards, self.g_terminated, self.g_done, self.g_next_obs, self.g_extra
             return self.g_actions, self.g_rewards, self.g_terminated, self.g_done, self.g_next_obs
         return None
 
-    def push(self, actions, rewards, terminated, done, next_obs):
+    def push(self, actions, rewards, terminated, done, next_obs, extra=None):
         """`push_begin` + `push_end` back to back."""
-        self.push_begin(actions, rewards, terminated, done, next_obs)
+        self.push_begin(actions, rewards, terminated, done, next_obs, extra)
         return self.push_end()
 
     def broadcast_params(self, flat: torch.Tensor):
@@ -338,4 +348,148 @@ class DistributedRainbow:
     def info(self):
         d = self.local.info()
         d["memory"] = self.replay.length()
+        return d
+
+
+class DistributedAgent57Light:
+    """BASELINE.json configs[3]: Agent57_light on `world` ranks -- actor ranks x E environments, learner + global replay on rank 0 (7 actor
+    GPUs + 1 learner GPU from 4 ranks up; with fewer ranks rank 0 also acts).  Every rank runs an `Agent57LightEngine` on a short local ring
+    (frame stacking, its environments' episodic memories and UCB controllers: the intrinsic reward is an ACTOR-side quantity in the
+    reference too, agent57_light.py:383-391).  Per lock-step an actor rank ships next frame, action, reward, flags and the five UVFA /
+    intrinsic fields of its E environments (`TransitionBus` with `extra_floats=5`); rank 0 commits them to the global ring + tree + field
+    arrays and trains; every `sync_interval` lock-steps the five online networks travel back as ONE flat broadcast.  The reference moves
+    the same information as pickled 11-field items on a queue and a pickled list of five state_dicts on a timer
+    (srl/base/run/play_mp.py:76-118,289-318; model_torch.py:148-156)."""
+
+    FIELDS = 5  # r_int, arm, prev_action, prev_r_ext, prev_r_int
+
+    def __init__(self, rl_config, n_envs: int, device: int, episode_len: int = 200, sync_interval: int = 16, learner_acts: Optional[bool] = None, seed: int = 0,
+                 env=None, parameter=None, always_collective: bool = False):
+        import copy
+
+        from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
+        from simple_distributed_rl_amd.device.replay import DeviceReplay
+
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.dev = torch.device(f"cuda:{device}")
+        self.sync_interval = int(sync_interval)
+        self.is_learner = self.rank == 0
+        self.learner_acts = (self.world < 4) if learner_acts is None else bool(learner_acts)
+        if self.world == 1:
+            self.learner_acts = True
+        self.acts = self.learner_acts or not self.is_learner
+        self.first_actor_rank = 0 if self.learner_acts else 1
+        self.n_actor_ranks = self.world - self.first_actor_rank
+        E = self.E = int(n_envs)
+        self.cfg = rl_config
+        local_cfg = copy.deepcopy(rl_config)
+        local_cfg.memory.capacity, local_cfg.memory.warmup_size = E * 4, 1 << 60  # the local ring only stacks frames; nobody samples it
+        self.local = Agent57LightEngine(local_cfg, E, device, episode_len, seed=seed + 1_000_003 * self.rank, env=env, parameter=parameter,
+                                        ring_len=1 + rl_config.window_length + 4)
+        p = self.local.parameter
+        self.nets = torch.nn.ModuleList([p.q_ext_online, p.q_int_online, p.emb_network, p.lifelong_target, p.lifelong_train])  # model_torch.py:148-156
+        self.flat = flatten_parameters(self.nets)
+        H, W_ = self.local.hw
+        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective, extra_floats=self.FIELDS)
+        self.step_count, self._in_flight, self.env_steps_local = 0, False, 0
+        if self.is_learner:
+            total = self.n_actor_ranks * E
+            mem = rl_config.memory
+            kw = mem.kwargs if mem.name != "ReplayBuffer" else {}
+            ring_len = -(-mem.capacity // total) + 1 + rl_config.window_length
+            self.replay = DeviceReplay(total, ring_len, H * W_, rl_config.window_length, 1, self.local.A, rl_config.batch_size, True, False,
+                                       float(kw.get("alpha", 0.0)), float(kw.get("beta_initial", 0.4)), int(kw.get("beta_steps", 1_000_000)),
+                                       float(kw.get("epsilon", 1e-4)), mem.warmup_size, seed, device)
+            L = self.replay.L
+            self.x = torch.zeros((L, total, self.FIELDS), dtype=torch.float32, device=self.dev)
+            B = rl_config.batch_size
+            self.loc_env = torch.zeros(B, dtype=torch.int64, device=self.dev)
+            self.loc_slot = torch.zeros(B, dtype=torch.int64, device=self.dev)
+            self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        else:
+            self.replay = self.local.replay
+        self.bus.broadcast_params(self.flat)
+        gathered = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, self.local.first_obs,
+                                 torch.zeros((E, self.FIELDS), dtype=torch.float32, device=self.dev))
+        if self.is_learner:
+            self.replay.reset_all(self._actor_rows(gathered)[4])
+
+    def _actor_rows(self, gathered):
+        if self.first_actor_rank == 0:
+            return gathered
+        k = self.first_actor_rank * self.E
+        return tuple(t[k:] for t in gathered)
+
+    @property
+    def global_envs(self) -> int:
+        return self.n_actor_ranks * self.E
+
+    @property
+    def train_count(self) -> int:
+        return self.local.learner.train_count
+
+    def _slab(self):
+        eng = self.local
+        slot = (eng.replay._steps_committed - 1) % eng.L  # the slot the lock-step just taken was written to
+        extra = torch.stack([eng.x_r_int[slot], eng.x_actor[slot].float(), eng.x_prev_action[slot].float(), eng.x_prev_r_ext[slot], eng.x_prev_r_int[slot]], dim=1)
+        env = eng.env
+        return eng.actions, env.rewards, env.terminated, env.done, env.next_obs, extra
+
+    def _commit(self, gathered):
+        a, r, t, d, obs, extra = self._actor_rows(gathered)
+        slot = self.replay._steps_committed % self.replay.L
+        self.x[slot] = extra
+        self.replay.commit(a, r, t, d, obs)
+
+    def learner_step(self) -> bool:
+        rp, eng = self.replay, self.local
+        if rp.is_warmup_needed():
+            return False
+        b = rp.sample(self.train_count_dev)
+        N.check(rp.lib.srlx_store_locate(rp.h_store, rp.B, N.tptr(b.indices), N.tptr(self.loc_env), N.tptr(self.loc_slot), None, N.torch_stream_ptr()))
+        x = self.x[self.loc_slot, self.loc_env]  # [B][5]
+        obs = b.obs.view(rp.B, 2, eng.Wn, *eng.hw)
+        pri = eng.learner.update(obs[:, 0], obs[:, 1], b.actions.view(-1), b.rewards.view(-1), x[:, 0].contiguous(), 1.0 - b.terminated.view(-1),
+                                 x[:, 2].long(), x[:, 3].contiguous(), x[:, 4].contiguous(), x[:, 1].long(), b.weights)
+        rp.update(b.indices, pri)
+        self.train_count_dev.add_(1)
+        return True
+
+    def step(self, learner_updates: int = 1, events=None):
+        """One lock-step of the job, pipelined over the exchange like DistributedRainbow.step: the slab of lock-step t travels while the
+        actor ranks play lock-step t+1; rank 0 commits it at the start of its next call and trains while the next exchange is in flight."""
+        if self.acts:
+            if events is not None:
+                events[0].record()
+            self.local.actor_step()
+            if events is not None:
+                events[1].record()
+            self.env_steps_local += self.E
+        gathered = self.bus.push_end() if self._in_flight else None
+        self._in_flight = False
+        if self.is_learner and gathered is not None:
+            self._commit(gathered)
+        slab = self._slab() if self.acts else (self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, self.local.first_obs,
+                                               torch.zeros((self.E, self.FIELDS), dtype=torch.float32, device=self.dev))
+        self.bus.push_begin(*slab)
+        self._in_flight = True
+        if self.is_learner:
+            for _ in range(learner_updates):
+                self.learner_step()
+        self.step_count += 1
+        if self.step_count % self.sync_interval == 0:
+            self.bus.broadcast_params(self.flat)
+
+    def flush(self):
+        if self._in_flight:
+            gathered = self.bus.push_end()
+            self._in_flight = False
+            if self.is_learner and gathered is not None:
+                self._commit(gathered)
+        torch.cuda.synchronize(self.dev)
+
+    def info(self):
+        d = dict(train_count=self.train_count, memory=self.replay.length())
+        if self.is_learner and self.train_count > 0:
+            d.update(self.local.learner.losses())
         return d

@@ -107,14 +107,25 @@ class _JobLoop:
         eng.flush()
 
 
-def _actor_rank_main(rank: int, world: int, port: int, plan: dict, cfg, env_spec: dict, opts: dict):
+def _make_engine(kind: str, cfg, device: int, plan: dict, env_spec: dict, opts: dict, parameter=None):
+    """The rank's distributed engine: DistributedRainbow (cfg = RainbowDeviceConfig) or DistributedAgent57Light (cfg = the set-up rl_config)."""
+    from simple_distributed_rl_amd.device import dist as D
+
+    if kind == "agent57_light":
+        if not cfg.is_setup():
+            from simple_distributed_rl_amd.base.env.registration import make as make_env_run
+
+            cfg.setup(make_env_run(env_spec["env_config"]))
+        return D.DistributedAgent57Light(cfg, opts["lanes"], device, sync_interval=opts["sync_interval_steps"], learner_acts=plan["learner_acts"],
+                                         seed=int(env_spec.get("seed") or 0), env=_env_factory(env_spec), parameter=parameter)
+    return D.DistributedRainbow(cfg, device, sync_interval=opts["sync_interval_steps"], learner_acts=plan["learner_acts"], env=_env_factory(env_spec))
+
+
+def _actor_rank_main(rank: int, world: int, port: int, plan: dict, kind: str, cfg, env_spec: dict, opts: dict):
     """Entry point of a spawned actor rank."""
     dist = _init_group(rank, world, port, plan["backend"], plan["devices"][rank])
     try:
-        from simple_distributed_rl_amd.device.dist import DistributedRainbow
-
-        eng = DistributedRainbow(cfg, plan["devices"][rank], sync_interval=opts["sync_interval_steps"], learner_acts=plan["learner_acts"],
-                                 env=_env_factory(env_spec))
+        eng = _make_engine(kind, cfg, plan["devices"][rank], plan, env_spec, opts)
         eng.bus.broadcast_params(eng.flat)  # the weights the learner rank started from (runner.parameter)
         _JobLoop(eng, plan["backend"], opts["updates_per_step"], opts["check_every"]).run(lambda: False)
     finally:
@@ -143,34 +154,36 @@ def _env_factory(env_spec: dict):
 def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, actor_devices, updates_per_step: int = 1,
                        sync_interval_steps: int = 16, check_every: int = 16) -> RunStateTrainer:
     from simple_distributed_rl_amd.device import vector_runner as vr
-    from simple_distributed_rl_amd.device.dist import DistributedRainbow
 
     context.check_context_parameter()
     plan = plan_ranks(context.used_device_torch, actor_num, actor_devices)
     world = len(plan["devices"])
     seed = 0 if context.seed is None else int(context.seed)
-    cfg = vr.device_config_from(runner.rl_config, runner.make_env(), lanes, seed)
+    kind = vr.engine_kind(runner.rl_config)
+    cfg = runner.rl_config if kind == "agent57_light" else vr.device_config_from(runner.rl_config, runner.make_env(), lanes, seed)
     env_spec = dict(env_config=runner.env_config, seed=context.seed)
-    opts = dict(updates_per_step=updates_per_step, sync_interval_steps=sync_interval_steps, check_every=check_every)
+    opts = dict(updates_per_step=updates_per_step, sync_interval_steps=sync_interval_steps, check_every=check_every, lanes=lanes)
     port = _free_port()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = None
     if world > 1:
-        procs = _spawn_ranks(world, port, plan, cfg, env_spec, opts)
+        procs = _spawn_ranks(world, port, plan, kind, cfg, env_spec, opts)
     state = RunStateTrainer()
     hooks = HookTable(context.callbacks, context=context, state=state)
     dist = _init_group(0, world, port, plan["backend"], plan["devices"][0])
     eng = None
     try:
-        eng = DistributedRainbow(cfg, plan["devices"][0], sync_interval=sync_interval_steps, learner_acts=plan["learner_acts"], env=_env_factory(env_spec))
         parameter = runner.make_parameter()
-        _load_reference_weights(eng, parameter)
+        eng = _make_engine(kind, cfg, plan["devices"][0], plan, env_spec, opts, parameter=parameter)  # agent57_light trains `parameter` in place
+        if kind == "rainbow":
+            _load_reference_weights(eng, parameter)
         eng.bus.broadcast_params(eng.flat)
         state.parameter, state.memory, state.trainer = parameter, vr._ReplayFacade(eng.replay), eng
         hooks.fire("on_start")
         hooks.fire("on_trainer_start")
         state.elapsed_t0 = time.time()
-        start_count = eng.local.train_count
+        trained = (lambda: eng.local.train_count) if kind == "rainbow" else (lambda: eng.train_count)
+        start_count = trained()
         E_total = eng.global_envs
 
         def should_stop() -> bool:
@@ -183,7 +196,7 @@ def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, 
             return False
 
         def after() -> bool:
-            done = eng.local.train_count - start_count
+            done = trained() - start_count
             state.is_step_trained = done > state.train_count
             state.train_count = done
             state.trainer_recv_q += E_total
@@ -194,7 +207,8 @@ def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, 
             return False
 
         _JobLoop(eng, plan["backend"], updates_per_step, check_every).run(should_stop, before=lambda: hooks.fire("on_train_before"), after=after)
-        _store_reference_weights(eng, parameter)
+        if kind == "rainbow":
+            _store_reference_weights(eng, parameter)
         state.shared_vars["actor_env_steps"] = eng.step_count * E_total
     finally:
         try:
@@ -207,11 +221,11 @@ def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, 
     return state
 
 
-def _spawn_ranks(world, port, plan, cfg, env_spec, opts):
+def _spawn_ranks(world, port, plan, kind, cfg, env_spec, opts):
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_actor_rank_main, args=(r, world, port, plan, cfg, env_spec, opts), daemon=True) for r in range(1, world)]
+    procs = [ctx.Process(target=_actor_rank_main, args=(r, world, port, plan, kind, cfg, env_spec, opts), daemon=True) for r in range(1, world)]
     for p in procs:
         p.start()
     return procs

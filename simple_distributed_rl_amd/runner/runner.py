@@ -127,7 +127,8 @@ class Runner:
             lanes = 1024 if hasattr(type(env.unwrapped), "device_vector") else 64
         actor = self._vector_actor
         if actor is None or actor.lanes != int(lanes):
-            actor = self._vector_actor = vr.VectorActor(env, self.rl_config, self.make_parameter(), int(lanes))
+            cls = vr.VectorAgent57Actor if vr.engine_kind(self.rl_config) == "agent57_light" else vr.VectorActor
+            actor = self._vector_actor = cls(env, self.rl_config, self.make_parameter(), int(lanes))
         return actor, (vr.VectorLearner(actor) if with_learner else None)
 
     def save_parameter(self, path: str, compress: bool = True):
@@ -228,10 +229,15 @@ class Runner:
                     return self.state
             else:
                 self.vector_reason = "the run is not on a GPU device"
-        self.state = play_mp.train(
-            play_mp.MpConfig(c, [], queue_capacity=queue_capacity, trainer_parameter_send_interval=trainer_parameter_send_interval,
-                             actor_parameter_sync_interval=actor_parameter_sync_interval),
-            self.make_parameter(), self.make_memory(),
-        )
+        mp_cfg = play_mp.MpConfig(c, [], queue_capacity=queue_capacity, trainer_parameter_send_interval=trainer_parameter_send_interval,
+                                  actor_parameter_sync_interval=actor_parameter_sync_interval)
+        if enable_mp_memory:  # the reference's default: the replay in a process of its own (play_mp_memory.py:595-796)
+            from simple_distributed_rl_amd.base.run import play_mp_memory
+
+            self.state = play_mp_memory.train(mp_cfg, self.make_parameter(), self.make_memory(),
+                                              play_mp_memory.MemoryLink(int(kwargs.get("mem_to_train_queue_capacity", 5)), int(kwargs.get("train_to_mem_queue_capacity", 100)),
+                                                                        bool(kwargs.get("return_memory_data", False))))
+        else:
+            self.state = play_mp.train(mp_cfg, self.make_parameter(), self.make_memory())
         self._trainer = None
         return self.state

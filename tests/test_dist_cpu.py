@@ -55,6 +55,14 @@ def _worker(rank, world, port, ret):
                     ok &= bool((got[2][sl].numpy() == et).all() and (got[3][sl].numpy() == ed).all() and (got[4][sl].numpy() == eo).all())
             else:
                 ok &= got is None
+        # the packed record buffer also carries per-environment float fields (Agent57_light: intrinsic reward, arm, previous action / rewards)
+        bus5 = TransitionBus(E, F, torch.uint8, dev, extra_floats=5)
+        x = torch.arange(E * 5, dtype=torch.float32).view(E, 5) + 1000 * rank
+        got = bus5.push(a, r, t, d, o, x)
+        if rank == 0:
+            ok &= len(got) == 6 and tuple(got[5].shape) == (world * E, 5)
+            for src in range(world):
+                ok &= bool(torch.equal(got[5][src * E : (src + 1) * E], torch.arange(E * 5, dtype=torch.float32).view(E, 5) + 1000 * src))
         # parameter fan-out: the actor's network aliases the flat buffer
         torch.manual_seed(rank)
         net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))

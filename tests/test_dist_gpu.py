@@ -183,3 +183,61 @@ def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def _a57_worker(rank, world, port, ret, learner_acts):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import simple_distributed_rl_amd as srl
+        from simple_distributed_rl_amd.algorithms import agent57_light
+        from simple_distributed_rl_amd.device.dist import DistributedAgent57Light
+
+        cfg = agent57_light.Config(batch_size=8, actor_num=4, target_model_update_interval=5, episodic_memory_capacity=64, ucb_window_size=6)
+        cfg.window_length = 4
+        cfg.memory.capacity, cfg.memory.warmup_size = 2 * 8 * 30, 32
+        cfg.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1000)
+        cfg.hidden_block.set_dueling_network((32,))
+        env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(20, 20), n_actions=3, episode_len=7)))
+        cfg.setup(env)
+        torch.manual_seed(100 + rank)  # ranks start from DIFFERENT weights: the first broadcast must make them equal
+        eng = DistributedAgent57Light(cfg, 8, 0, episode_len=7, sync_interval=2, learner_acts=learner_acts, seed=5)
+        for _ in range(12):
+            eng.step(learner_updates=1)
+        eng.flush()
+        out = {"flat_sum": float(eng.flat.double().sum().item()), "env_steps_local": eng.env_steps_local, "arm_max": int(eng.local.ucb.arm.max().item())}
+        if rank == 0:
+            out.update(eng.info())
+            out["global_envs"] = eng.replay.E
+            out["x_nonzero"] = float(eng.x[..., 0].abs().sum().item())
+            out["arms_seen"] = sorted(set(eng.x[: eng.replay._steps_committed % eng.replay.L, :, 1].flatten().long().tolist()))
+        ret[rank] = out
+    except Exception:
+        import traceback
+
+        ret[f"error{rank}"] = traceback.format_exc()
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("learner_acts", [True, False])
+def test_distributed_agent57_light_two_ranks_one_gpu(learner_acts):
+    """BASELINE.json configs[3] topology with Agent57_light (dedicated learner rank for learner_acts=False), two ranks time-sharing the
+    test GPU: transitions AND the five UVFA / intrinsic fields reach the learner's global replay, it trains all five networks, and the
+    flat broadcast leaves the actor rank with the learner's weights."""
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    try:
+        mp.spawn(_a57_worker, args=(2, _free_port(), ret, learner_acts), nprocs=2, join=True)
+    except Exception:
+        errs = [v for k, v in sorted(ret.items(), key=lambda kv: str(kv[0])) if str(k).startswith("error")]
+        raise AssertionError("worker failed:\n" + "\n".join(errs))
+    r0, r1 = ret[0], ret[1]
+    actor_ranks = 2 if learner_acts else 1
+    assert r0["global_envs"] == 8 * actor_ranks and r0["memory"] == 12 * 8 * actor_ranks
+    assert r0["train_count"] > 0 and all(r0[k] == r0[k] for k in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"))
+    assert r0["x_nonzero"] > 0 and set(r0["arms_seen"]) <= {0, 1, 2, 3} and len(r0["arms_seen"]) > 1  # intrinsic rewards and arms arrived
+    assert (r0["env_steps_local"] > 0) == learner_acts and r1["env_steps_local"] == 12 * 8
+    assert r0["flat_sum"] == r1["flat_sum"]  # step 12 ended with a broadcast (sync_interval = 2)

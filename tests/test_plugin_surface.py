@@ -454,3 +454,48 @@ def test_demo_memory_mix():
         other = PriorityReplayBuffer(cfg, 8)
         other.call_restore(mem.call_backup())
         assert other.length() == 25 and other.demo_memory.length() == 5
+
+
+def test_train_mp_with_the_memory_process():
+    """Runner.train_mp(enable_mp_memory=True) -- the reference's default (play_mp_memory.py:595-796): actors -> memory process -> learner.
+    The learner trains from prefetched batches; with return_memory_data the memory's contents come back at the end."""
+    runner = srl.Runner("Grid", ql.Config())
+    st = runner.train_mp(actor_num=2, max_train_count=2000, timeout=90, trainer_parameter_send_interval=0.2, actor_parameter_sync_interval=0.2,
+                         enable_mp_memory=True, return_memory_data=True)
+    assert st.train_count >= 2000 and st.end_reason == "max_train_count over."
+    assert st.trainer_recv_q > 0 and len(runner.parameter.Q) > 3
+    st2 = runner.train_mp(actor_num=1, max_train_count=500, timeout=90, enable_mp_memory=False)  # the two-role topology stays selectable
+    assert st2.train_count >= 500
+
+
+def test_prefetched_memory_protocol():
+    """The learner-side stand-in of the memory in isolation: recv functions pop delivered batches (None when empty), send functions
+    enqueue for the memory process and respect the write-back bound."""
+    import multiprocessing as mp
+
+    from simple_distributed_rl_amd.base.run.play_mp_memory import MemoryLink, _Counter, _PrefetchedMemory
+    from simple_distributed_rl_amd.base.rl.config import DummyRLConfig
+    from simple_distributed_rl_amd.rl.memories.priority_replay_buffer import PriorityReplayBufferConfig, RLPriorityReplayBuffer
+
+    ctx = mp.get_context("spawn")
+    cfg = DummyRLConfig()
+    cfg.batch_size = 4
+    cfg.memory = PriorityReplayBufferConfig(16, 4, False).set_replay_buffer()
+    base = RLPriorityReplayBuffer(cfg)
+    import ctypes
+
+    end = ctx.Value(ctypes.c_bool, False)
+    n_b, n_w, q = [_Counter(ctx)], _Counter(ctx), ctx.Queue()
+    client = _PrefetchedMemory(base, MemoryLink(5, 2), n_b, q, n_w, end)
+    assert client.sample() is None and client.length() == 0
+    n_b[0].add(2)
+    client.deliver(0, ("batch", 1))
+    client.deliver(0, ("batch", 2))
+    assert client.length() == 2 and client.sample() == ("batch", 2) and n_b[0].value == 1
+    client.update([1, 2], np.ones(2), 7)
+    client.update([3], np.ones(1), 8)
+    assert n_w.value == 2
+    name, blob = q.get(timeout=5)
+    args, kwargs = pickle.loads(blob)
+    assert name == "update" and args[0] == [1, 2] and args[2] == 7
+    assert client.batch_size == 4  # everything else falls through to the real memory

@@ -2,7 +2,7 @@
 # kernel timeline of one learner update (learner alone: 16 envs), from rocprofv3's kernel trace
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tr
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $GRAFT_REPO_ROOT/bench.py --envs 16 --capacity 200000 --steps 40 --warmup 10 --no-cpu-baseline $EXTRA > /tmp/tr.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $GRAFT_REPO_ROOT/bench.py --envs 16 --capacity 200000 --steps 2 --warmup 1 --inner 20 --no-cpu-baseline --no-per-micro --no-subfigures $EXTRA > /tmp/tr.log 2>&1
 f=$(find /tmp/tr -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys

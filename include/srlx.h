@@ -196,6 +196,16 @@ int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, 
 int srlx_episode_account(int64_t n_envs, const float *d_rewards, const uint8_t *d_done, const uint8_t *d_skip, float *d_ep_return,
                          int32_t *d_ep_len, float *d_ring, int64_t ring_cap, void *d_totals, void *stream);
 
+/* Frame preprocessing on the device (replaces srl/rl/processors/image_processor.py:104-151: cv2.cvtColor RGB2GRAY, the trimming slice,
+ * cv2.resize INTER_LINEAR, the 0to1 / -1to1 normalisation) for a batch of uint8 images [n][src_h][src_w][src_channels]:
+ *   to_gray      3 channels -> 1 with OpenCV's 14-bit coefficients
+ *   trim_*       the window rows [top, bottom) x columns [left, right) (0, 0, src_h, src_w = no trimming)
+ *   out_h/out_w  bilinear resize with OpenCV's 8-bit fixed-point arithmetic (== the window size: no resize)
+ *   d_out_u8     uint8 [n][out_h][out_w][c] (what the frame ring stores) and / or
+ *   d_out_f32    float32 of the same shape, normalize 0: as is, 1: / max_val ("0to1"), 2: * 2 / max_val - 1 ("-1to1") */
+int srlx_image_preprocess(int64_t n_images, int src_h, int src_w, int src_channels, const uint8_t *d_src, int to_gray, int trim_top, int trim_left,
+                          int trim_bottom, int trim_right, int out_h, int out_w, uint8_t *d_out_u8, float *d_out_f32, int normalize, double max_val, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Fused learner arithmetic
  *

@@ -90,6 +90,7 @@ SIGNATURES = {
     "srlx_qnet_redraw_rows": (c_int, [c_p, c_i64, c_i64, c_p, c_p]),
     "srlx_qnet_noisy_effective": (c_int, [c_p, c_int, c_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_p]),
     "srlx_policy_epsilon_greedy": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_image_preprocess": (c_int, [c_i64, c_int, c_int, c_int, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_int, c_f64, c_p]),
     "srlx_episode_account": (c_int, [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "srlx_synth_env_step": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_nstep_td_huber_priority": (

@@ -124,6 +124,14 @@ class RLConfig(ABC):
 
         obs = env.observation_space.copy()
         self._env_obs_space = obs
+        # observation processors (config.py:268-287): every processor that remaps the space is applied to each observation, in order
+        self._obs_processors = []
+        if self.enable_rl_processors:
+            for proc in list(self.processors) + list(self.get_processors(obs)):
+                new = proc.remap_observation_space(obs) if hasattr(proc, "remap_observation_space") else None
+                if new is not None:
+                    self._obs_processors.append((proc, obs, new))
+                    obs = new
         want = self.get_base_observation_type()
         self._obs_mode = "raw"
         if want & RLBaseTypes.ARRAY_DISCRETE and not isinstance(obs, BoxSpace):
@@ -182,6 +190,8 @@ class RLConfig(ABC):
         return self._env_act_space
 
     def state_encode_one_step(self, env_state, env):
+        for proc, prev, new in getattr(self, "_obs_processors", ()):
+            env_state = proc.remap_observation(env_state, prev, new, env_run=env)
         if not self.enable_state_encode or self._obs_mode == "raw":
             return env_state
         if self._obs_mode == "disc_to_list":

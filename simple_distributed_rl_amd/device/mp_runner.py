@@ -144,7 +144,7 @@ def _env_factory(env_spec: dict):
         maker = getattr(type(probe.unwrapped), "device_vector", None)
         if maker is not None:
             return maker(replay, **env_config.kwargs)
-        env = HostVecEnv(env_config, replay.E, replay.dev, env_spec.get("seed"))
+        env = HostVecEnv(env_config, replay.E, replay.dev, env_spec.get("seed"), processor=env_spec.get("processor"))
         env.setup(None)
         return env
 
@@ -161,7 +161,7 @@ def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, 
     seed = 0 if context.seed is None else int(context.seed)
     kind = vr.engine_kind(runner.rl_config)
     cfg = runner.rl_config if kind == "agent57_light" else vr.device_config_from(runner.rl_config, runner.make_env(), lanes, seed)
-    env_spec = dict(env_config=runner.env_config, seed=context.seed)
+    env_spec = dict(env_config=runner.env_config, seed=context.seed, processor=vr.frame_processor(runner.rl_config))
     opts = dict(updates_per_step=updates_per_step, sync_interval_steps=sync_interval_steps, check_every=check_every, lanes=lanes)
     port = _free_port()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

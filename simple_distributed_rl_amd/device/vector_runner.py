@@ -113,14 +113,23 @@ class HostVecEnv:
 
     capturable = False  # step() synchronises with the host
 
-    def __init__(self, env_config, n_envs: int, device: torch.device, seed: Optional[int] = None):
+    def __init__(self, env_config, n_envs: int, device: torch.device, seed: Optional[int] = None, processor=None):
+        """processor: an ImageProcessor whose space has been remapped from this environment's (raw uint8 frames, e.g. ALE's 210 x 160 x 3):
+        the raw frames are uploaded as they are and ONE srlx_image_preprocess launch per lock-step turns them into the ring's gray frames
+        -- the reference runs OpenCV per frame on the host and hands the network float32 (image_processor.py:104-151)."""
         from simple_distributed_rl_amd.base.env.registration import make as make_env_run
 
         self.envs = [make_env_run(env_config) for _ in range(n_envs)]
         self.E, self.dev = n_envs, device
         self.seed = seed
+        self.processor = processor
         sp = self.envs[0].observation_space
-        self.F = int(np.prod(sp.shape))
+        if processor is not None:
+            self._raw_shape = tuple(sp.shape)
+            self._host_raw = torch.zeros((n_envs,) + self._raw_shape, dtype=torch.uint8).pin_memory()
+            self.F = int(processor._out_hw[0] * processor._out_hw[1])
+        else:
+            self.F = int(np.prod(sp.shape))
         self._scale = 255.0 if float(np.max(sp.high)) <= 1.0 else 1.0  # "0to1" frames (image_processor.py:140-142) back to bytes
         self._host_obs = torch.zeros((n_envs, self.F), dtype=torch.uint8).pin_memory()
         self._host_scal = torch.zeros((n_envs, 3), dtype=torch.float32).pin_memory()
@@ -134,11 +143,27 @@ class HostVecEnv:
     def _bytes(self, frame) -> np.ndarray:
         return np.rint(np.asarray(frame, np.float32).reshape(-1) * self._scale).astype(np.uint8)
 
+    def _take(self, i: int):
+        """Lane i's current frame into the staging row: raw bytes when a device processor follows, ring bytes otherwise."""
+        if self.processor is not None:
+            self._host_raw[i] = torch.from_numpy(np.ascontiguousarray(self.envs[i].state, dtype=np.uint8).reshape(self._raw_shape))
+        else:
+            self._host_obs.numpy()[i] = self._bytes(self.envs[i].state)
+
+    def _upload(self, dst: torch.Tensor) -> torch.Tensor:
+        if self.processor is not None:
+            raw = self._host_raw.to(self.dev, non_blocking=True)
+            self.processor.preprocess_batch(raw, out_u8=dst.view((self.E,) + tuple(self.processor._out_hw)))
+            self._raw_keep = raw  # alive until the kernel has read it
+        else:
+            dst.copy_(self._host_obs, non_blocking=True)
+        return dst
+
     def _reset_lane(self, i: int):
         seed = None if self.seed is None else self.seed + self._episodes
         self._episodes += 1
         self.envs[i].reset(seed=seed)
-        return self._bytes(self.envs[i].state)
+        self._take(i)
 
     def setup(self, context):
         for e in self.envs:
@@ -149,29 +174,30 @@ class HostVecEnv:
             e.teardown()
 
     def reset(self) -> torch.Tensor:
-        obs = self._host_obs.numpy()
         for i in range(self.E):
-            obs[i] = self._reset_lane(i)
-        return self._host_obs.to(self.dev, non_blocking=False)
+            self._reset_lane(i)
+        first = self._upload(torch.zeros((self.E, self.F), dtype=torch.uint8, device=self.dev))
+        torch.cuda.current_stream(self.dev).synchronize()
+        return first
 
     def step(self, actions: torch.Tensor):
         from simple_distributed_rl_amd.base.define import DoneTypes
 
-        acts = actions.cpu().numpy()
-        obs, scal = self._host_obs.numpy(), self._host_scal.numpy()
+        acts = actions.cpu().numpy()  # also orders this call after the previous lock-step's uploads
+        scal = self._host_scal.numpy()
         for i, env in enumerate(self.envs):
             if self._needs_reset[i]:
-                obs[i] = self._reset_lane(i)
+                self._reset_lane(i)
                 scal[i] = 0.0
                 self._needs_reset[i] = False
                 continue
             env.step(int(acts[i]))
-            obs[i] = self._bytes(env.state)
+            self._take(i)
             scal[i, 0] = env.reward
             scal[i, 1] = 1.0 if env.done_type == DoneTypes.TERMINATED else 0.0
             scal[i, 2] = 1.0 if env.done else 0.0
             self._needs_reset[i] = env.done
-        self.next_obs.copy_(self._host_obs, non_blocking=True)
+        self._upload(self.next_obs)
         dev_scal = self._host_scal.to(self.dev, non_blocking=True)
         self.rewards.copy_(dev_scal[:, 0])
         self.terminated.copy_(dev_scal[:, 1].to(torch.uint8))
@@ -205,9 +231,11 @@ def why_not_vector(context, env, rl_config) -> str:
 
     if not isinstance(env.action_space, DiscreteSpace) or env.action_space.n > 32:
         return "the engine serves discrete action spaces of at most 32 actions"
-    hw = _image_hw(env.observation_space)
+    if getattr(rl_config, "_obs_processors", None) and frame_processor(rl_config) is None:
+        return "observation processors other than one ImageProcessor over uint8 frames are served by the plugin path"
+    hw = _image_hw(frame_space(env, rl_config))
     if hw is None or hw[0] < 8 or hw[1] < 8:
-        return "observations are not single-channel image frames"
+        return "observations are not single-channel image frames (after the config's ImageProcessor, if any)"
     mem = rl_config.memory
     if mem.name not in ("Proportional", "Proportional_cpp", "ReplayBuffer"):
         return f"no device replay for memory '{mem.name}'"
@@ -240,6 +268,22 @@ def engine_kind(rl_config) -> Optional[str]:
     return {"Rainbow": "rainbow", "Rainbow_no_multisteps": "rainbow", "Agent57_light": "agent57_light"}.get(rl_config.get_name())
 
 
+def frame_space(env, rl_config):
+    """The observation space the algorithm sees per step: the environment's, remapped by the config's observation processors."""
+    procs = getattr(rl_config, "_obs_processors", None)
+    return procs[-1][2] if procs else env.observation_space
+
+
+def frame_processor(rl_config):
+    """The (single) ImageProcessor of the config that a host-stepped batch environment can run on the device, or None."""
+    from simple_distributed_rl_amd.rl.processors.image_processor import ImageProcessor
+
+    procs = getattr(rl_config, "_obs_processors", None) or []
+    if len(procs) == 1 and isinstance(procs[0][0], ImageProcessor) and "int" in str(np.dtype(procs[0][1].dtype)):
+        return procs[0][0]
+    return None
+
+
 def device_config_from(rl_config, env, n_envs: int, seed: int):
     """rainbow.Config (srl/algorithms/rainbow/rainbow.py:57-114) -> the engine's configuration."""
     from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig
@@ -247,7 +291,7 @@ def device_config_from(rl_config, env, n_envs: int, seed: int):
     mem = rl_config.memory
     prop = mem.name != "ReplayBuffer"
     kw = mem.kwargs if prop else {}
-    hw = _image_hw(env.observation_space)
+    hw = _image_hw(frame_space(env, rl_config))
     hb = rl_config.hidden_block
     return RainbowDeviceConfig(
         batch_size=rl_config.batch_size, epsilon=rl_config.epsilon, test_epsilon=rl_config.test_epsilon, lr=rl_config.lr, discount=rl_config.discount,
@@ -296,7 +340,7 @@ class VectorActor(ActorDriver):
         maker = getattr(type(base), "device_vector", None)
         if maker is not None:
             return maker(replay, **self.env_run.config.kwargs)
-        env = HostVecEnv(self.env_run.config, self.lanes, replay.dev, context.seed)
+        env = HostVecEnv(self.env_run.config, self.lanes, replay.dev, context.seed, processor=frame_processor(self.rl_config))
         env.setup(context)
         return env
 

@@ -280,3 +280,30 @@ def test_train_mp_on_the_engine_two_ranks_sharing_the_gpu():
     assert st.trainer_recv_q > 0 and st.sync_trainer > 0 and st.memory.length() > 64
     after = runner.parameter.q_online.state_dict()
     assert any(not torch.equal(before[k], after[k].cpu()) for k in before)
+
+
+def test_uniform_replay_buffer_on_the_device():
+    """a6: `memory.set_replay_buffer()` (srl/rl/memories/priority_memories/replay_buffer.py:10-55: uniform draws, all weights 1, update a no-op)
+    on the engine is the alpha = 0 corner of the HBM sum-tree: every stored item weighs 1, so draws are uniform over the stored items, every
+    importance weight is exactly 1 and priority updates leave the distribution unchanged."""
+    cfg = _atari_like(capacity=16 * 64, warmup=128, hidden=64)
+    cfg.batch_size = 32
+    cfg.memory.set_replay_buffer()
+    runner = srl.Runner(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(episode_len=50)), cfg)
+    runner.set_vector_envs(16)
+    st = runner.train(max_train_count=60, train_interval=16)
+    assert runner.vector_reason == "" and st.train_count >= 60
+    eng = runner._vector_actor.engine
+    rep = eng.replay
+    assert rep.per_state()["max_priority"] == 1.0  # (|p| + eps)^0
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    hits = np.zeros(rep.capacity, np.int64)
+    for _ in range(400):
+        b = rep.sample_items(step, all_states=True)
+        torch.cuda.synchronize()
+        assert float(b.weights.min()) == 1.0 == float(b.weights.max())
+        np.add.at(hits, b.indices.cpu().numpy() - (rep.capacity - 1), 1)
+    live = hits[: rep.length()] if rep.length() < rep.capacity else hits
+    filled = (live > 0).mean()
+    assert filled > 0.95 and live.max() < 12 * live.mean()  # 12 800 draws over <= 1024 items: every item is hit (the 2 % of ring positions that hold
+    # an episode's terminal frame are no items and weigh 0), nothing dominates

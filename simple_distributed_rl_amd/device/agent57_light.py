@@ -354,6 +354,9 @@ class Agent57LightEngine:
         for _ in range(learner_updates):
             self.learner_step()
 
+    def join_learner(self):
+        """(driver interface of device/vector_runner.py: updates run on the caller's stream, nothing to join)"""
+
     def prefill(self, randomise_priorities: bool = True):
         """Random-policy rollout until every PER leaf holds an item (untimed benchmark set-up)."""
         saved = self.eps_list

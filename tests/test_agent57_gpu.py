@@ -212,8 +212,9 @@ def test_agent57_light_runner_end_to_end():
     runner = srl.Runner(srl.EnvConfig("TinyImg"), rl)
     runner.set_device("cuda:0")
     runner.set_seed(2)
+    runner.set_vector_envs(0)  # the single-environment plugin classes (the E-environment engine: tests/test_agent57_engine_gpu.py)
     st = runner.train(max_train_count=25)
-    assert st.train_count == 25
+    assert st.train_count == 25 and runner.vector_reason == "set_vector_envs(0)"
     info = runner.trainer.info if hasattr(runner, "trainer") and runner.trainer is not None else st.trainer.info
     for key in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"):
         assert np.isfinite(info[key]), key

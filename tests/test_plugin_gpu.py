@@ -269,7 +269,7 @@ def test_ppo_train_count_per_call_follows_the_reference():
         rl.memory.warmup_size = 64
         runner = srl.Runner("CartPole-v1", rl)
         runner.set_device("cuda:0")
-        runner.rollout(max_memory=200, enable_progress=False)
+        runner.rollout(max_steps=600, enable_progress=False)  # items arrive at episode ends (ppo.py:381-404)
         trainer = runner.trainer
         trainer.setup(runner.context)
         assert runner.memory.length() >= 64

@@ -424,6 +424,9 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
  * before the conv2 launch and right after the conv3 launch -- the two launches of the dominant kernel k_gemm<AConv> -- so that
  * bench.py can time that kernel live, on the stream it runs on.  NULL events switch it off. */
 int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end);
+/* the weight-gradient branch of srlx_qnet_backward_u8 runs on a stream of the handle's own; a caller that confines the learner to a set
+ * of CUs (hipExtStreamCreateWithCUMask) hands in a stream carrying that mask instead (caller-owned, must outlive the handle's use) */
+int srlx_qnet_set_side_stream(srlx_qnet_t *h, void *stream);
 /* measurement aid: d_phase_stamps = device uint64 [8 waves][8] (or NULL to switch off): the fused convolution kernel's workgroup 0
  * records its shader clock at the phase boundaries (start, frames issued, staged, conv1 done, barrier, conv2 done, barrier, end) */
 int srlx_qnet_set_debug(srlx_qnet_t *h, void *d_phase_stamps);

@@ -630,7 +630,7 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
         if (p) (void)hipFree(p);
     if (h->d_draw) (void)hipFree(h->d_draw);
     if (h->wpack) (void)hipFree(h->wpack);
-    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->side && !h->side_external) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join, h->ev_wt})
         if (e) (void)hipEventDestroy(e);
     delete h;
@@ -646,6 +646,15 @@ int srlx_qnet_bind(srlx_qnet_t *h, const float *const *p) {
         return SRLX_OK;
     }
     h->wf = p[6], h->bf = p[7], h->v2w = p[8], h->v2b = p[9], h->a2w = p[10], h->a2b = p[11];
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_side_stream(srlx_qnet_t *h, void *stream) {
+    SRLX_REQUIRE(h && stream, "qnet_set_side_stream: NULL argument");
+    SRLX_REQUIRE(h->max_train > 0, "qnet_set_side_stream: call srlx_qnet_enable_training first");
+    if (h->side && !h->side_external) (void)hipStreamDestroy(h->side);
+    h->side = (hipStream_t)stream;
+    h->side_external = true;
     return SRLX_OK;
 }
 
@@ -677,6 +686,7 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
         h->probe0 = h->probe1 = nullptr;
         return run_dense(h, batch, d_q, st);
     }
+    h->wt_from_forward = false;
     const size_t lds = (size_t)h->Wn * kC1Frame;
     if (h->F1 == 32 && h->Wn == 4 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && 4 * (h->OW1 - 1) + 8 <= kC1Pad && h->W % 4 == 0) {
         // one workgroup per sample, frames + filters staged in LDS
@@ -695,6 +705,7 @@ int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw
     SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_f32: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
+    h->wt_from_forward = false;
     ANchw c1{d_obs_nchw, h->Wn, h->H, h->W, 4, 3, h->OH1, h->OW1};
     launch_gemm<ANchw, 32, true, false>(c1, h->w1, h->b1, h->act1, batch * h->OH1 * h->OW1, h->F1, h->Wn * 64, 1, st);
     return run_tail(h, batch, d_q, st);

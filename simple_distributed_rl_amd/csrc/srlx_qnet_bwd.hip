@@ -420,11 +420,12 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     SRLX_HIP(hipEventRecord(h->ev_fork, st));
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
     const int C2 = 2 * h->F1;
-    // the transposed filters of the two data-gradient GEMMs depend on the weights only: build them on the side stream while the dense
-    // data gradient runs (they used to sit on the critical path between the GEMMs)
-    hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((C2 * 9 * C2 + 255) / 256)), dim3(256), 0, sd, h->w3, C2, 3, 3, 1, C2, h->w_t);
-    hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((C2 * 16 * h->F1 + 255) / 256)), dim3(256), 0, sd, h->w2, C2, 4, 4, 2, h->F1, h->w_t2);
-    SRLX_HIP(hipEventRecord(h->ev_wt, sd));
+    // the transposed filters of the two data-gradient GEMMs depend on the weights only: the fused forward of a training handle has
+    // built them already (k_pack_filters); otherwise they are built here, ahead of the chain that needs them
+    if (!h->wt_from_forward) {
+        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((C2 * 9 * C2 + 255) / 256)), dim3(256), 0, st, h->w3, C2, 3, 3, 1, C2, h->w_t);
+        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((C2 * 16 * h->F1 + 255) / 256)), dim3(256), 0, st, h->w2, C2, 4, 4, 2, h->F1, h->w_t2);
+    }
     // ---- data-gradient chain (caller's stream)
     if (B <= 32)
         hipLaunchKernelGGL(k_fc1_dgrad<32>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
@@ -434,7 +435,6 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     SRLX_HIP(hipEventRecord(h->ev_d3, st));
     {   // conv3 (3x3 stride 1 pad 1, act2 -> act3) data gradient on the padded grid (OH2 + 2)^2
         const int HP = h->OH2 + 2, WP = h->OW2 + 2;
-        SRLX_HIP(hipStreamWaitEvent(st, h->ev_wt, 0));
         SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st));
         const i64 tot = (i64)B * h->OH2 * h->OW2 * C2;
         hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, 1, HP, WP, h->dxpad, h->act2, h->dact2);

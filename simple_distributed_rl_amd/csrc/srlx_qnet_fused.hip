@@ -41,12 +41,27 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 constexpr int kW1 = 32 * 256, kW2 = 64 * 512, kW3 = 64 * 576;
 constexpr int kPackFloats = kW1 + kW2 + kW3;
 
+// A training handle's launch also builds the transposed filters of the backward pass's two data-gradient GEMMs (wT3 / wT2: layout of
+// k_transpose_filter in srlx_qnet_bwd.hip) -- they depend on the weights only, and the weights do not change between this forward and
+// its backward, so two launches leave the learner's critical path.
 __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
-                                                      float *__restrict__ out) {
+                                                      float *__restrict__ out, float *__restrict__ wT3, float *__restrict__ wT2) {
     // one thread per float4 of the packed buffer
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = kPackFloats / 4;
-    if (q >= n4) return;
+    if (q >= n4) {
+        if (!wT3) return;
+        int i = q - n4;
+        if (i < kW3) {  // conv3: 64 x (3 x 3) x 64, stride 1: wT[ci][tap * 64 + co] = W[co][tap][ci]
+            const int ci = i % 64, tap = (i / 64) % 9, co = i / (64 * 9);
+            wT3[ci * 576 + tap * 64 + co] = w3[i];
+        } else if ((i -= kW3) < kW2) {  // conv2: 64 x (4 x 4) x 32, stride 2: four parity classes, wT[cls][ci][((ky/2) * 2 + kx/2) * 64 + co]
+            const int ci = i % 32, tap = (i / 32) % 16, co = i / (32 * 16);
+            const int ky = tap / 4, kx = tap % 4, cls = (ky % 2) * 2 + (kx % 2);
+            wT2[(cls * 32 + ci) * 256 + ((ky / 2) * 2 + kx / 2) * 64 + co] = w2[i];
+        }
+        return;
+    }
     const float *src;
     int K, tiles, local;
     if (q < kW1 / 4) src = w1, K = 256, tiles = 1, local = q;
@@ -288,8 +303,11 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     if (!h->wpack) {
         if (hipMalloc((void **)&h->wpack, (size_t)kPackFloats * sizeof(float)) != hipSuccess) return false;
     }
-    hipLaunchKernelGGL(k_pack_filters, dim3((kPackFloats / 4 + 255) / 256), dim3(256), 0, st, h->w1, h->w2, h->w3, h->wpack);
-    const bool keep = h->max_train > 0;  // a training handle: the backward pass reads act1 / act2
+    const bool keep = h->max_train > 0;  // a training handle: the backward pass reads act1 / act2 and the transposed filters
+    const int pack_threads = kPackFloats / 4 + (keep ? kW3 + kW2 : 0);
+    hipLaunchKernelGGL(k_pack_filters, dim3((pack_threads + 255) / 256), dim3(256), 0, st, h->w1, h->w2, h->w3, h->wpack, keep ? h->w_t : nullptr,
+                       keep ? h->w_t2 : nullptr);
+    h->wt_from_forward = keep;
     hipLaunchKernelGGL(k_convnet_fused, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3,
                        h->act3, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
     return hipGetLastError() == hipSuccess;

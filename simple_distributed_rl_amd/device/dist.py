@@ -333,8 +333,12 @@ class DistributedRainbow:
     def actor_forward_flops(self):
         return self.local.actor_forward_flops()
 
-    def conv_gemm_flops(self):
-        return self.local.conv_gemm_flops()
+    def conv_gemm_flops(self, with_conv1: bool = False):
+        return self.local.conv_gemm_flops(with_conv1)
+
+    @property
+    def fused_convs(self):
+        return self.local.fused_convs
 
     @property
     def mfma(self):

@@ -260,14 +260,23 @@ class RainbowEngine:
         mac += h2 * w2 * 2 * F1 * 2 * c.hidden_units + c.hidden_units * (1 + c.n_actions)
         return 2.0 * mac * c.n_envs
 
-    def conv_gemm_flops(self) -> float:
-        """Algorithmic fp32 FLOPs of the two implicit-GEMM convolution launches (conv2 + conv3) of one policy-step pass over E environments."""
+    def conv_gemm_flops(self, with_conv1: bool = False) -> float:
+        """Algorithmic fp32 FLOPs of conv2 + conv3 (+ conv1: the fused kernel computes all three) of one policy-step pass over E environments."""
         c = self.cfg
         F1 = c.filters
         h1 = (c.obs_hw[0] + 6 - 8) // 4 + 1
         w1 = (c.obs_hw[1] + 6 - 8) // 4 + 1
         h2, w2 = (h1 + 4 - 4) // 2 + 1, (w1 + 4 - 4) // 2 + 1
-        return 2.0 * (h2 * w2 * 2 * F1 * F1 * 16 + h2 * w2 * 2 * F1 * 2 * F1 * 9) * c.n_envs
+        mac = h2 * w2 * 2 * F1 * F1 * 16 + h2 * w2 * 2 * F1 * 2 * F1 * 9
+        if with_conv1:
+            mac += h1 * w1 * F1 * c.window_length * 64
+        return 2.0 * mac * c.n_envs
+
+    @property
+    def fused_convs(self) -> bool:
+        """Does the policy pass take the one-kernel conv1 -> conv2 -> conv3 path (srlx_qnet_fused.hip)?"""
+        c = self.cfg
+        return tuple(c.obs_hw) == (84, 84) and c.window_length == 4 and c.filters == 32 and os.environ.get("SRLX_NO_FUSED_CONV", "0") != "1"
 
     # ---- learner (model_torch.py:85-122) -----------------------------------------------------
     def _learner_body(self):

@@ -171,7 +171,7 @@ def test_bench_multi_rank_rehearsal(n, actor_gpus, launcher):
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - per_step) < 1e-6 * per_step  # value = all actor ranks' env-steps / time
     # one update per lock-step: eager warm-up (warmup x min(inner, 8)), graph capture (1), 2 after it, warm-up, timed region
     assert d["final"]["train_count"] == warmup * min(inner, 8) + 1 + 2 + warmup * inner + steps * inner
-    assert "cpu_baseline" not in d and d["roofline"]["avg_launch_pair_ms"] > 0 and d["roofline"]["pass"]["avg_launch_group_ms"] > 0
+    assert "cpu_baseline" not in d and d["roofline"]["avg_launch_ms"] > 0 and d["roofline"]["pass"]["avg_launch_group_ms"] > 0
 
 
 def test_bench_refuses_to_measure_fewer_gpus_than_asked():

@@ -283,6 +283,8 @@ def bench_agent57_light(args, dev_index, rank, world):
     for _ in range(max(1, args.warmup) * inner):
         eng.step(args.updates)
     torch.cuda.synchronize()
+    if not args.no_graph:
+        eng.capture_graphs()  # the update (five networks, four optimisers) as one HIP graph
     n_lock = args.steps * inner
     t0 = time.perf_counter()
     for _ in range(n_lock):
@@ -310,7 +312,7 @@ def bench_agent57_light(args, dev_index, rank, world):
                                "lifelong intrinsic reward, per-environment sliding-window UCB, PER", "lock_steps_per_step": inner, "envs_per_gpu": args.envs,
                    "learner_updates_per_lock_step": args.updates, "batch_size": args.batch_size, "per_capacity": eng.replay.capacity, "actor_num": rl.actor_num,
                    "networks": "torch modules (MIOpen / hipBLASLt); libsrlx: frame ring + stack, epsilon-greedy, UCB, NGU kNN / RND reward, targets, losses, priorities, PER",
-                   "hip_graphs": False},
+                   "hip_graphs": "learner update" if not args.no_graph else False},
         "roofline": {"kernel": "k_stack_current_u8 (uint8 frame ring -> float32 [E,4,84,84] network input)", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes,
                      "avg_launch_ms": ms, "note": "isolated launches"},

@@ -559,4 +559,11 @@ class VectorAgent57Actor(VectorActor):
         state.shared_vars["env_steps_exact"] = total[1]
 
     def ensure_graphs(self):
-        return 0  # eager: the torch networks' autograd step is not captured
+        """The whole update as one HIP graph once the replay is warm (its warm-up updates are real ones and are counted by the caller)."""
+        eng = self.engine
+        if self._graphs_ready or not self.use_graphs:
+            return 0
+        before = eng.train_count
+        eng.capture_graphs()
+        self._graphs_ready = True
+        return eng.train_count - before

@@ -102,6 +102,40 @@ def _batch_arrays(batches, n, A, np_dtype):
     return state_list, actions, reward, done, inv
 
 
+def device_targets(cfg, p, ops, d, np_dtype, batches, weights):
+    """calc_target_q (rainbow.py:185-287 / rainbow_nomultisteps.py:10-43) + the loss arithmetic of model_torch.py:103-114 on the device: forwards through
+    torch, everything around them in ONE libsrlx kernel; returns (target, loss, grad seed, priorities, q rows).  Used by the trainer (a sampled batch)
+    and, in distributed mode, by the worker for the initial priority of a single item (rainbow.py:389-398)."""
+    B, A, n = len(batches), cfg.action_space.n, cfg.multisteps
+    w = torch.as_tensor(np.asarray(weights, dtype=np.float32), device=d)
+    if n == 1:  # rainbow_nomultisteps.py:10-43: items are [s, s', onehot, r, undone, invalid]
+        state, n_state, onehot, reward, undone, next_invalid = zip(*batches)
+        s0 = torch.as_tensor(np.asarray(state, dtype=np_dtype), device=d)
+        s1 = torch.as_tensor(np.asarray(n_state, dtype=np_dtype), device=d)
+        action = torch.as_tensor(np.argmax(np.asarray(onehot), axis=1).astype(np.int32), device=d)
+        with torch.no_grad():
+            q_tg = p.q_target(s1)
+            q_on = p.q_online(s1) if cfg.enable_double_dqn else None
+        target = ops.dqn_target(q_on, q_tg, torch.as_tensor(np.asarray(reward, np.float32), device=d),
+                                     torch.as_tensor(np.asarray(undone, np.float32), device=d), invalid_mask(next_invalid, (B, A), d),
+                                     cfg.discount, cfg.enable_double_dqn, cfg.enable_rescale, False)
+        q = p.q_online(s0)
+        _, loss, grad, pri = ops.huber(target, q, action, w)
+        return target, loss, grad, pri, q
+    states, actions, reward, done, inv = _batch_arrays(batches, n, A, np_dtype)
+    st = torch.as_tensor(states, device=d)  # (B, n+1, ...)
+    nxt = st[:, 1:].reshape((B * n,) + tuple(st.shape[2:]))
+    with torch.no_grad():  # rainbow.py:220-221
+        q_on_next = p.q_online(nxt).view(B, n, A)
+        q_tg_next = p.q_target(nxt).view(B, n, A)
+    q = p.q_online(st[:, 0])  # model_torch.py:103
+    target, loss, grad, pri = ops.nstep(
+        q_on_next, q_tg_next, q, torch.as_tensor(actions, device=d), torch.as_tensor(reward, device=d), torch.as_tensor(done, device=d),
+        invalid_mask(inv, (B, n, A), d), w, cfg.discount, cfg.retrace_h, cfg.enable_double_dqn, cfg.enable_rescale)
+    return target, loss, grad, pri, q
+
+
+
 class Trainer(RLTrainer):
     def on_setup(self) -> None:
         self.device = require_gpu(self.config.used_device_torch)
@@ -113,35 +147,7 @@ class Trainer(RLTrainer):
         self.parameter.q_online.train()
 
     def calc(self, batches, weights):
-        """Forwards + fused kernel; returns (target, loss, grad seed, priorities, q rows)."""
-        cfg, d, p = self.config, self.device, self.parameter
-        B, A, n = len(batches), cfg.action_space.n, cfg.multisteps
-        w = torch.as_tensor(np.asarray(weights, dtype=np.float32), device=d)
-        if n == 1:  # rainbow_nomultisteps.py:10-43: items are [s, s', onehot, r, undone, invalid]
-            state, n_state, onehot, reward, undone, next_invalid = zip(*batches)
-            s0 = torch.as_tensor(np.asarray(state, dtype=self.np_dtype), device=d)
-            s1 = torch.as_tensor(np.asarray(n_state, dtype=self.np_dtype), device=d)
-            action = torch.as_tensor(np.argmax(np.asarray(onehot), axis=1).astype(np.int32), device=d)
-            with torch.no_grad():
-                q_tg = p.q_target(s1)
-                q_on = p.q_online(s1) if cfg.enable_double_dqn else None
-            target = self.ops.dqn_target(q_on, q_tg, torch.as_tensor(np.asarray(reward, np.float32), device=d),
-                                         torch.as_tensor(np.asarray(undone, np.float32), device=d), invalid_mask(next_invalid, (B, A), d),
-                                         cfg.discount, cfg.enable_double_dqn, cfg.enable_rescale, False)
-            q = p.q_online(s0)
-            _, loss, grad, pri = self.ops.huber(target, q, action, w)
-            return target, loss, grad, pri, q
-        states, actions, reward, done, inv = _batch_arrays(batches, n, A, self.np_dtype)
-        st = torch.as_tensor(states, device=d)  # (B, n+1, ...)
-        nxt = st[:, 1:].reshape((B * n,) + tuple(st.shape[2:]))
-        with torch.no_grad():  # rainbow.py:220-221
-            q_on_next = p.q_online(nxt).view(B, n, A)
-            q_tg_next = p.q_target(nxt).view(B, n, A)
-        q = p.q_online(st[:, 0])  # model_torch.py:103
-        target, loss, grad, pri = self.ops.nstep(
-            q_on_next, q_tg_next, q, torch.as_tensor(actions, device=d), torch.as_tensor(reward, device=d), torch.as_tensor(done, device=d),
-            invalid_mask(inv, (B, n, A), d), w, cfg.discount, cfg.retrace_h, cfg.enable_double_dqn, cfg.enable_rescale)
-        return target, loss, grad, pri, q
+        return device_targets(self.config, self.parameter, self.ops, self.device, self.np_dtype, batches, weights)
 
     def train(self) -> None:
         sampled = self.memory.sample()
@@ -169,6 +175,7 @@ class Worker(RLWorker):
         self.epsilon_sch = self.config.epsilon_scheduler.create(self.config.epsilon)
         worker.set_tracking_max_size(self.config.multisteps + 1)
         self.q = None
+        self._init_priority_ops(context)
 
     def on_reset(self, worker):
         worker.add_tracking({"state": worker.state})
@@ -210,11 +217,32 @@ class Worker(RLWorker):
         if worker.get_tracking_length() < self.config.multisteps + 1:
             return
         batch = worker.get_trackings(["state", "action", "reward", "terminated", "next_invalid_actions"], size=self.config.multisteps + 1)
-        # Distributed actors of the reference estimate an initial priority with calc_target_q([batch]) on the
-        # actor (:389-398).  Here every item enters with priority=None -> the learner's max_priority
-        # (proportional_memory.py:121-122): the TD arithmetic exists only as a device kernel in this build, and
-        # the reference itself hands None to `custom` memories (requires_priority() typo, priority_replay_buffer.py:164).
-        self.memory.add(batch, None)
+        self.memory.add(batch, self._initial_priority(worker, batch))
+
+
+def _init_priority_ops(self, context):
+    """Distributed actors estimate an item's first priority themselves (rainbow.py:389-398): the learner's max_priority is not visible to them.
+    The TD arithmetic exists only as device kernels in this build, so an actor on a GPU device computes it (same kernels as the trainer);
+    an actor on the CPU sends None and the item enters at the learner's max_priority -- what the reference itself does for `custom`
+    memories (requires_priority() typo, priority_replay_buffer.py:164)."""
+    self._prio_ops = None
+    if context.distributed and self.config.memory.requires_priority() and str(getattr(self.parameter, "device", "cpu")).startswith("cuda"):
+        self._prio_ops = TdOps(require_gpu(str(self.parameter.device)))
+
+
+def _initial_priority(self, worker, batch):
+    if getattr(self, "_prio_ops", None) is None:
+        return None
+    if self.q is None:  # the action was a random one: evaluate the state it was chosen in (:393-394)
+        self.q = self.parameter.pred_q(worker.state[np.newaxis, ...])[0]
+    select_q = float(self.q[worker.action])
+    with torch.no_grad():
+        target, *_ = device_targets(self.config, self.parameter, self._prio_ops, self.parameter.device, self.np_dtype, [batch], [1.0])
+    return abs(float(target[0].item()) - select_q)
+
+
+Worker._init_priority_ops = _init_priority_ops
+Worker._initial_priority = _initial_priority
 
 
 class WorkerNoMultisteps(RLWorker):
@@ -224,8 +252,11 @@ class WorkerNoMultisteps(RLWorker):
         self.epsilon_sch = self.config.epsilon_scheduler.create(self.config.epsilon)
         self.np_dtype = self.config.get_dtype("np")
         self.q = None
+        self._init_priority_ops(context)
 
     policy = Worker.policy
+    _init_priority_ops = _init_priority_ops
+    _initial_priority = _initial_priority
 
     def on_step(self, worker):
         if not self.training:
@@ -234,4 +265,4 @@ class WorkerNoMultisteps(RLWorker):
         if self.config.enable_reward_clip:
             reward = -1 if reward < 0 else (1 if reward > 0 else 0)
         batch = [worker.state, worker.next_state, worker.get_onehot_action(), reward, int(not worker.terminated), worker.next_invalid_actions]
-        self.memory.add(batch, None)
+        self.memory.add(batch, self._initial_priority(worker, batch))

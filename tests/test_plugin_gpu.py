@@ -281,3 +281,53 @@ def test_ppo_train_count_per_call_follows_the_reference():
     cpu.set_device("CPU")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         cpu.rollout(max_steps=50, enable_progress=False)
+
+
+@pytest.mark.parametrize("name", ["n3", "n1"])
+def test_distributed_actor_initial_priorities_match_the_reference(name):
+    """rainbow.py:389-398 / rainbow_nomultisteps.py:108-119: a distributed actor computes its items' first priorities itself.  Same weights,
+    same seed, same environment as the run oracle/gen_golden_actor_priority.py recorded from the reference's worker: same actions, same priorities."""
+    import random
+
+    from simple_distributed_rl_amd.algorithms import rainbow
+    from simple_distributed_rl_amd.base.context import RunContext
+    from simple_distributed_rl_amd.base.env import registration
+    from simple_distributed_rl_amd.utils import common
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_plugin_surface  # noqa: F401  (defines TinyImg)
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"actor_priority_{name}.npz"))
+    registration.register("TinyImg", "test_plugin_surface:TinyImg", check_duplicate=False)
+    rl = rainbow.Config(multisteps=int(z["multisteps"]), enable_double_dqn=True, enable_rescale=False, retrace_h=1.0, discount=0.99, batch_size=16, lr=0.001,
+                        target_model_update_interval=5, enable_reward_clip=True, epsilon=float(z["epsilon"]))
+    rl.window_length = 4
+    rl.memory.capacity, rl.memory.warmup_size, rl.memory.compress = 1000, 16, False
+    rl.memory.set_proportional(alpha=0.5, beta_initial=0.4, beta_steps=1000)
+    rl.hidden_block.set_dueling_network((32,))
+    runner = srl.Runner(srl.EnvConfig("TinyImg", kwargs=dict(hw=8, actions=4, ep_len=6, seed=9)), rl)
+    runner.set_device("cuda:0")
+    env, parameter, memory = runner.make_env(), runner.make_parameter(), runner.make_memory()
+    sd = {k[2:]: torch.as_tensor(z[k]) for k in z.files if k.startswith("w:")}
+    parameter.q_online.load_state_dict(sd)
+    parameter.q_target.load_state_dict(sd)
+    worker = runner.make_worker(parameter, memory)
+    got = []
+    worker.worker.memory = type("Rec", (), {"add": staticmethod(lambda batch, priority=None, **kw: got.append(priority)), "config": memory.config})()
+    ctx = RunContext(runner.env_config, rl)
+    ctx.distributed, ctx.training, ctx.actor_num, ctx.actor_id = True, True, 1, 0
+    ctx.device = "cuda:0"
+    ctx.setup_device()
+    common.set_seed(int(z["seed"]))
+    env.setup(ctx)
+    worker.setup(ctx)
+    for ep in range(5):
+        env.reset()
+        worker.reset(0)
+        while not env.done:
+            env.step(worker.policy())
+            worker.on_step()
+    log = env.unwrapped.log
+    np.testing.assert_array_equal(np.array([l[1] for l in log], np.int32), z["actions"])  # the same trajectory (epsilon draws, argmax, padding draws)
+    assert len(got) == len(z["priorities"]) and all(p is not None for p in got)
+    np.testing.assert_allclose(np.array(got), z["priorities"], rtol=2e-4, atol=2e-5)

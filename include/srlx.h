@@ -69,6 +69,9 @@ typedef struct srlx_per srlx_per_t;
 int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double beta_initial, double beta_steps,
                     int has_duplicate, double epsilon, int device);
 int srlx_per_destroy(srlx_per_t *h);
+/* switch the duplicate rule of later srlx_per_sample calls (the shim completes a batch WITH duplicates when a has_duplicate=False draw
+ * cannot be satisfied: the reference does the same after 9999 tries per draw, proportional_memory.py:146-158) */
+int srlx_per_set_has_duplicate(srlx_per_t *h, int has_duplicate);
 int srlx_per_clear(srlx_per_t *h, void *stream);
 /* length() (:117-118).  Host mirror; exact as long as adds go through srlx_per_add. */
 int64_t srlx_per_length(const srlx_per_t *h);

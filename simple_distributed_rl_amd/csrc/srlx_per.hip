@@ -1170,6 +1170,12 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
     return s;
 }
 
+int srlx_per_set_has_duplicate(srlx_per_t *h, int has_duplicate) {
+    SRLX_REQUIRE(h, "per_set_has_duplicate: NULL handle");
+    h->has_duplicate = has_duplicate ? 1 : 0;
+    return SRLX_OK;
+}
+
 int srlx_per_destroy(srlx_per_t *h) {
     if (!h) return SRLX_OK;
     srlx::DeviceGuard guard(h->device);

@@ -110,15 +110,27 @@ class ProportionalMemory(IPriorityMemory):
         with self._lock:
             state = random.getstate()
             m = batch_size if self.has_duplicate else 4 * batch_size
+            cap = 8192 if not self.has_duplicate else 9999 * batch_size  # without duplicates one call walks at most 8192 uniforms
+            forced = False
             while True:
+                m = min(m, cap)
                 u = np.fromiter((random.random() for _ in range(m)), np.float64, m)
                 st = self._lib.srlx_per_sample(
                     self._h, batch_size, int(step), None, N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), 0, None
                 )
-                if st == N.ERR_UNIFORMS_EXHAUSTED and m < 9999 * batch_size:  # :146 "for safety" bound
+                if st == N.ERR_UNIFORMS_EXHAUSTED and m < cap:  # rejected draws ate the uniforms: again with more
                     random.setstate(state)
                     m = 2 * m + 16
                     continue
+                if st == N.ERR_UNIFORMS_EXHAUSTED and not self.has_duplicate and not forced:
+                    # fewer distinct non-zero leaves than the batch needs: the reference gives up on a draw after 9999 tries and takes
+                    # it, duplicate or not (:146-158); here the batch is completed with duplicates from the same uniforms
+                    N.check(self._lib.srlx_per_set_has_duplicate(self._h, 1))
+                    forced = True
+                    random.setstate(state)
+                    continue
+                if forced:
+                    N.check(self._lib.srlx_per_set_has_duplicate(self._h, 0))
                 N.check(st)
                 break
             if used.value != m:  # rejected draws: leave `random` where the reference would

@@ -518,3 +518,23 @@ def test_rankbased_select_large_vs_numpy():
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), np.argsort(-pri, kind="stable")[ranks])
     lib.srlx_rank_destroy(h)
+
+
+def test_no_duplicate_sampling_with_too_few_leaves_completes_like_the_reference():
+    """has_duplicate=False with fewer distinct non-zero leaves than the batch: the reference tries 9999 times per draw and then takes the draw
+    anyway (proportional_memory.py:146-158) -- it keeps training.  The shim completes the batch with duplicates instead of raising; with
+    enough leaves the no-duplicate rule holds."""
+    from simple_distributed_rl_amd.rl.memories.priority_memories.proportional_memory import ProportionalMemory
+
+    m = ProportionalMemory(64, alpha=0.5, has_duplicate=False)
+    for i in range(10):
+        m.add(("item", i), float(i + 1))
+    random.seed(3)
+    batches, w, idx = m.sample(16, 0)
+    assert len(idx) == 16 and len(set(idx)) <= 10 and all(b is not None for b in batches) and np.isfinite(w).all()
+    batches, w, idx = m.sample(10, 0)  # exactly as many as there are leaves: all distinct (coupon collector inside the 8192-uniform bound)
+    assert len(set(idx)) == 10
+    for i in range(10, 40):
+        m.add(("item", i), 1.0)
+    _, _, idx = m.sample(16, 0)
+    assert len(set(idx)) == 16

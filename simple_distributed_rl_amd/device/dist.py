@@ -249,11 +249,14 @@ class DistributedRainbow:
         """One lock-step of the whole job, software-pipelined over the exchange: the transitions of lock-step t travel
         (push_begin) while every actor rank already runs the network pass of lock-step t+1, and are committed to the global
         replay at the start of the learner rank's next call.  Order on every rank (collectives are issued in the same order
-        everywhere): network pass -> push_end(t-1) -> [learner: join updates, commit t-1, fork updates] -> action selection +
+        everywhere): [learner: fork updates] -> network pass -> push_end(t-1) -> [learner: join updates, commit t-1] -> action selection +
         environments + local ring -> push_begin(t) -> parameter broadcast every `sync_interval` steps."""
         eng = self.local
-        main = torch.cuda.current_stream(self.dev)
         q = None
+        if self.is_learner and self.overlap:
+            # the updates run beside this lock-step's network pass, on the replay as of the last commit (the exchange in flight is one
+            # lock-step younger: it is committed below, after they have been joined)
+            self._with_global_replay(lambda: eng.fork_learner(learner_updates))
         if self.acts:  # the network pass reads the local ring only: it does not depend on the exchange in flight
             q = eng._actor_net(None, events)
         elif events is not None:
@@ -263,14 +266,12 @@ class DistributedRainbow:
         self._in_flight = False
         if self.is_learner:
             if self.overlap:
-                eng.join_learner()  # the previous call's updates read the replay: they finish before it changes
+                eng.join_learner()  # the updates read the replay: they finish before it changes
             if gathered is not None:
                 self.replay.commit(*self._actor_rows(gathered))
             if self.overlap:
-                if self.acts:  # this rank's actors act on a private copy: refresh it between two updates
+                if self.acts:  # this rank's actors act on a private copy of the network: refresh it between two updates
                     eng.refresh_actor_copy()
-                # updates run beside this lock-step's selection / exchange and the next network pass
-                self._with_global_replay(lambda: eng.fork_learner(learner_updates))
             else:
                 for _ in range(learner_updates):
                     self._with_global_replay(eng.learner_step)

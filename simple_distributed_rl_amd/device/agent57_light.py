@@ -202,6 +202,9 @@ class Agent57LightEngine:
         assert c.is_setup(), "rl_config.setup(env) first: the networks are built from the negotiated spaces"
         self.dev = torch.device(f"cuda:{device}")
         self.lib = N.lib()
+        # MIOpen's immediate mode falls back to im2col-per-image / naive fp32 convolutions on gfx950 (profiles/r1_kernel_stats_before_find.csv);
+        # let it benchmark its solvers once per shape instead
+        torch.backends.cudnn.benchmark = True
         self.E, self.seed = int(n_envs), int(seed)
         shape = c.observation_space.shape  # (H, W, window)
         H, W_, Wn = int(shape[0]), int(shape[1]), int(shape[2])

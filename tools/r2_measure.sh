@@ -37,4 +37,4 @@ print(json.dumps(out, indent=1))
 PY
 cd $R
 timeout 400 python bench.py --noisy --no-cpu-baseline --no-per-micro > gpurun_out/r2_bench_noisy.json 2>/dev/null; python -c "import json;d=json.loads(open('gpurun_out/r2_bench_noisy.json').read().strip().splitlines()[-1]);print('noisy', round(d['value']), d['ms_per_lock_step'], d['learner_updates_per_s'])"
-timeout 500 python bench.py --algo agent57_light --envs 256 --capacity 200000 --steps 4 --inner 16 --warmup 1 > gpurun_out/r2_bench_agent57_light.json 2>/dev/null; python -c "import json;d=json.loads(open('gpurun_out/r2_bench_agent57_light.json').read().strip().splitlines()[-1]);print('agent57_light', round(d['value']), d['ms_per_lock_step'], d['learner_updates_per_s'])"
+timeout 500 python bench.py --algo agent57_light --envs 1024 --capacity 200000 --steps 4 --inner 16 --warmup 1 > gpurun_out/r2_bench_agent57_light.json 2>/dev/null; python -c "import json;d=json.loads(open('gpurun_out/r2_bench_agent57_light.json').read().strip().splitlines()[-1]);print('agent57_light', round(d['value']), d['ms_per_lock_step'], d['learner_updates_per_s'])"

@@ -439,8 +439,15 @@ int srlx_qnet_set_debug(srlx_qnet_t *h, void *d_phase_stamps);
  *       to max_train_batch (<= 64) samples is allocated.  Covers the DQN image block with 32 filters, dueling "average"/"".
  *   srlx_qnet_backward_u8     : given d loss / d Q  f32 [batch][n_actions] for the samples at rows 0, stride, 2*stride, ...
  *       of the LAST srlx_qnet_forward_u8 on this handle (same d_frame_base / d_frame_off), writes every parameter
- *       gradient into d_grads[12] (same order and memory layouts as srlx_qnet_bind: the torch parameters' own layouts). */
+ *       gradient into d_grads[12] (same order and memory layouts as srlx_qnet_bind: the torch parameters' own layouts).
+ *   srlx_qnet_fuse_adam_fc1   : the first dense layer's weight [2*hidden][flat] holds 97 % of the network's parameters.  With its
+ *       Adam state bound here (d_exp_avg / d_exp_avg_sq in the weight's layout, d_steps_taken = device scalar of optimiser steps
+ *       already applied, the same one srlx_adam_step reads), srlx_qnet_backward_u8 applies `optimizer.step()` (model_torch.py:109)
+ *       to that tensor inside its weight-gradient kernel: d_grads[6] is NOT written and the caller's srlx_adam_step must leave the
+ *       tensor out.  d_exp_avg = NULL unbinds.  Refused for NoisyLinear handles (the sigma gradient needs the weight gradient). */
 int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch);
+int srlx_qnet_fuse_adam_fc1(srlx_qnet_t *h, float *d_exp_avg, float *d_exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                            const int64_t *d_steps_taken);
 int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off,
                           const float *d_grad_q, float *const *d_grads, void *stream);
 int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream);

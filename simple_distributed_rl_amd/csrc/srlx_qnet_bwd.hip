@@ -15,16 +15,18 @@
 // over host-built pair tables instead of scattering.
 #include <new>
 
+#include "srlx_adam_math.h"
 #include "srlx_qnet_int.h"
 
 namespace {
 
 using i64 = int64_t;
 using u8 = unsigned char;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kFcSplits = 16;   // splits of the hidden dimension in the dense data-gradient
 constexpr int kWgSplits = 64;   // splits of the row dimension in the conv weight-gradients
-constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad, kC1Chunks = 8;
+constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float byte_to_unit(unsigned b) {  // u8 / 255, correctly rounded (see srlx_qnet.hip)
@@ -40,8 +42,8 @@ __device__ __forceinline__ float byte_to_unit(unsigned b) {  // u8 / 255, correc
 template <int AMAX>
 __global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden, int A, int dueling, const float *__restrict__ dq,
                                                    const float *__restrict__ h1, const float *__restrict__ v2w, const float *__restrict__ a2w,
-                                                   float *__restrict__ dh1, float *__restrict__ g_bf, float *__restrict__ g_v2w, float *__restrict__ g_v2b,
-                                                   float *__restrict__ g_a2w, float *__restrict__ g_a2b) {
+                                                   float *__restrict__ dh1, float *__restrict__ dh1t /*[N1][32] or NULL*/, float *__restrict__ g_bf,
+                                                   float *__restrict__ g_v2w, float *__restrict__ g_v2b, float *__restrict__ g_a2w, float *__restrict__ g_a2b) {
     extern __shared__ float sm[];  // dv[B], da[B][A], part[3 + AMAX][256]
     float *dv = sm, *da = sm + B, *part = sm + B + B * A;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
@@ -76,9 +78,13 @@ __global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden
             const float dhv = hv > 0.f ? dv[b] * wv : 0.f, dha = ha > 0.f ? s : 0.f;  // ReLU of the first dense layer
             dh1[(i64)b * N1 + u] = dhv;
             dh1[(i64)b * N1 + hidden + u] = dha;
+            if (dh1t) dh1t[u * 32 + b] = dhv, dh1t[(hidden + u) * 32 + b] = dha;
             gbv += dhv;
             gba += dha;
         }
+        if (dh1t)  // the matrix-core data gradient multiplies whole 32-sample tiles: absent samples contribute zeros
+            for (int b = slice; b < 32; b += 4)
+                if (b >= B) dh1t[u * 32 + b] = 0.f, dh1t[(hidden + u) * 32 + b] = 0.f;
     }
     part[0 * 256 + threadIdx.x] = gv;
     part[1 * 256 + threadIdx.x] = gbv;
@@ -169,6 +175,96 @@ __global__ void __launch_bounds__(256) k_fc1_dgrad_reduce(int B, i64 sstride, in
     dact3[i] = act3[(i64)b * sstride * K + k] > 0.f ? s : 0.f;
 }
 
+// ---- first dense layer, batch <= 32: data gradient on the matrix cores, no partial sums ------------------------
+//   dact3[b][k] = [act3[b][k] > 0] * sum_n dh1[b][n] * wf[n][k]
+// The batch IS the 32-row tile of v_mfma_f32_32x32x2_f32: every weight is used by exactly one MFMA, so the B operand is loaded
+// straight from global memory (lane (i, h) reads wf[n + h][k0 + i]: two coalesced 128-byte rows per instruction) and the A
+// operand from the transposed gradient dh1t[n + h][i] (256 contiguous bytes, L2 resident).  A workgroup owns one 32-column tile
+// of k; its four waves split the hidden dimension and their 32 x 32 partial tiles are summed through LDS in wave order.
+// (The VALU kernel below spends 32 LDS broadcasts per 32 FMAs and needs a second launch to add up its 16 splits.)
+__global__ void __launch_bounds__(256) k_fc1_dgrad_mfma(int B, i64 sstride, int N1, int K, const float *__restrict__ dh1t, const float *__restrict__ wf,
+                                                        const float *__restrict__ act3, float *__restrict__ dact3) {
+    __shared__ float red[3][16][64];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const int k0 = blockIdx.x * 32;
+    const int per = N1 / 4;  // hidden units of this wave (a multiple of 16: hidden % 32 == 0)
+    const float *pa = dh1t + ((i64)wave * per + h) * 32 + i;
+    const float *pb = wf + ((i64)wave * per + h) * K + k0 + i;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float a0[8], b0[8], a1[8], b1[8];
+    auto fetch = [&](float *a, float *b, int s0) {  // MFMA steps s0 .. s0+7 (two hidden units per step)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            a[q] = pa[(i64)(s0 + q) * 64];
+            b[q] = pb[(i64)(s0 + q) * 2 * K];
+        }
+    };
+    const int steps = per / 2;  // a multiple of 8
+    fetch(a0, b0, 0);
+    for (int s0 = 0; s0 < steps; s0 += 16) {
+        if (s0 + 8 < steps) fetch(a1, b1, s0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0 + 8 >= steps) break;
+        if (s0 + 16 < steps) fetch(a0, b0, s0 + 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wave > 0)
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wave - 1][r][lane] = acc[r];
+    __syncthreads();
+    if (wave == 0)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int b = (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout: row = sample, column = lane & 31
+            if (b < B) {
+                const float sum = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+                dact3[(i64)b * K + k0 + i] = act3[(i64)b * sstride * K + k0 + i] > 0.f ? sum : 0.f;
+            }
+        }
+}
+
+// ---- first dense layer: weight gradient with Adam applied in the epilogue (srlx_qnet_fuse_adam_fc1) -----------------------------
+// Same accumulation as k_fc1_wgrad; the 32 MB gradient is never written: each thread updates its 32 weights (and their two
+// moment estimates) in place.  226 MB of traffic becomes 161 MB, and the update of 97 % of the network's parameters leaves the
+// tail of the backward pass (it runs beside the convolution gradients instead of after them).
+__global__ void __launch_bounds__(256) k_fc1_wgrad_adam(int B, i64 sstride, int N1, int K, const float *__restrict__ dh1, const float *__restrict__ act3,
+                                                        float *__restrict__ wf, float *__restrict__ m, float *__restrict__ v, double lr, double beta1, double beta2,
+                                                        double eps, const i64 *__restrict__ d_step) {
+    __shared__ float sd[64 * 32];
+    const int n0 = blockIdx.y * 32;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    for (int idx = threadIdx.x; idx < B * 32; idx += 256) sd[idx] = dh1[(i64)(idx / 32) * N1 + n0 + (idx % 32)];
+    __syncthreads();
+    if (k >= K) return;
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) acc[j] = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < B; b++) {
+        const float a = act3[(i64)b * sstride * K + k];
+#pragma unroll
+        for (int j = 0; j < 32; j++) acc[j] += sd[b * 32 + j] * a;
+    }
+    const srlx::AdamCoef c = srlx::adam_coef(lr, beta1, beta2, eps, *d_step);
+#pragma unroll 8
+    for (int j = 0; j < 32; j++) {
+        const i64 at = (i64)(n0 + j) * K + k;
+        float pp = wf[at], mm = m[at], vv = v[at];
+        srlx::adam_one(pp, acc[j], mm, vv, c);
+        wf[at] = pp;
+        m[at] = mm;
+        v[at] = vv;
+    }
+}
+
 // ---- convolution weight gradient (NHWC input X, NHWC output gradient dY already masked by its ReLU) ----------
 //   part[split][co][tap][ci] = sum_{m in split} dY[m][co] * X[b, clamp(oy*S + ky - P), clamp(ox*S + kx - P), ci]
 // workgroup = (tap, split); thread = 4 output channels x (CI/16) input channels; rows staged 16 at a time in LDS
@@ -235,21 +331,33 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(ConvGeo g, int B, i64 sstrid
     if (tap == 0 && t < CO) bias_part[split * CO + t] = bsum;
 }
 
-// out[i] = sum_p part[p][i] (fixed order) for a weight gradient (n entries) and, in the same launch, its bias gradient (nb entries)
-__global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, int P, i64 n, float *__restrict__ out, const float *__restrict__ bpart, int nb,
-                                                      float *__restrict__ bout) {
-    i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n + nb) return;
+// out[i] = sum_p part[p][i] for a weight gradient (n entries) and, in the same launch, its bias gradient (nb entries).
+// 64 outputs x 16 slices per workgroup: slice s adds its run of parts in order (all its loads in flight at once), the slices are
+// then added in order -- a fixed summation order, and a 256-part reduction is 16 loads deep instead of 256.
+__global__ void __launch_bounds__(1024) k_reduce_parts(const float *__restrict__ part, int P, i64 n, float *__restrict__ out, const float *__restrict__ bpart, int nb,
+                                                       float *__restrict__ bout) {
+    __shared__ float sm[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    i64 i = (i64)blockIdx.x * 64 + lane;
+    const bool live = i < n + nb;
     if (i >= n) {
         i -= n;
         part = bpart;
         n = nb;
         out = bout;
     }
+    const int per = (P + 15) / 16, p_lo = sl * per, p_hi = p_lo + per < P ? p_lo + per : P;
     float s = 0.f;
-#pragma unroll 16
-    for (int p = 0; p < P; p++) s += part[(i64)p * n + i];  // loads are independent: 16 in flight, the adds stay in order
-    out[i] = s;
+    if (live)
+#pragma unroll 8
+        for (int p = p_lo; p < p_hi; p++) s += part[(i64)p * n + i];
+    sm[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && live) {
+#pragma unroll
+        for (int q = 1; q < 16; q++) s += sm[q][lane];
+        out[i] = s;
+    }
 }
 
 // ---- convolution data gradient through replicate padding ---------------------------------------------------
@@ -286,22 +394,27 @@ __global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int
     dX[i] = X[(((i64)b * sstride * H + iy) * W + ix) * CI + ci] > 0.f ? s : 0.f;
 }
 
-// ---- conv1 weight gradient straight from the uint8 ring ------------------------------------------------------
-// workgroup = (sample, pixel chunk); frames staged like the forward (padded 88 x 88 uint8); thread = one filter tap k
-// (c, ky, kx) accumulating all 32 output channels; part[(b*chunks + chunk)][co][k]
-__global__ void __launch_bounds__(256) k_conv1_wgrad(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, i64 sstride, int Wn, int H, int W, int OH,
-                                                     int OW, const float *__restrict__ dY1, float *__restrict__ part, float *__restrict__ bias_part) {
+// ---- conv1 weight gradient straight from the uint8 ring, on the matrix cores ------------------------------------
+//   part[b, half][co][c*64 + ky*8 + kx] = sum over the half's pixels p of dY1[b][p][co] * frame_c[4 oy + ky - 3][4 ox + kx - 3] / 255
+// workgroup = (sample, frame c of the window, half of the output pixels): one padded 88 x 88 uint8 frame, the half's dY rows
+// and a pixel -> window-origin table in LDS.  The product is a 32 (co) x 64 (taps of frame c) x pixels GEMM: wave (tt, ph)
+// owns taps ky in [4 tt, 4 tt + 4) and the pixel pairs jj = ph mod 2; per MFMA a lane reads one dY value, one table entry and
+// one byte.  The two pixel interleaves are added through LDS (ph order), so a sample leaves 2 partial tensors, not 8.
+__global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, i64 sstride, int Wn, int H, int W,
+                                                          int OH, int OW, int per, const float *__restrict__ dY1, float *__restrict__ part,
+                                                          float *__restrict__ bias_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u8 *fr = smem;                                                        // [Wn][88][88]
-    float *sy = reinterpret_cast<float *>(smem + (size_t)Wn * kC1Frame);  // [pixels of the chunk][32]
-    const int t = threadIdx.x;
+    u8 *fr = smem;                                                           // [88][88]
+    int *poff = reinterpret_cast<int *>(smem + kC1Frame);                    // [per]
+    float *sy = reinterpret_cast<float *>(smem + kC1Frame + (size_t)per * 4);  // [per][32]
+    float *red = sy + (size_t)per * 32;                                      // [2][16][64]
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
     const i64 b = blockIdx.x;
-    const int chunk = blockIdx.y;
-    const int M = OH * OW, per = (M + kC1Chunks - 1) / kC1Chunks;
-    const int p_lo = chunk * per, p_hi = p_lo + per < M ? p_lo + per : M;
-    for (int c = 0; c < Wn; c++) {
+    const int c = blockIdx.y >> 1, half = blockIdx.y & 1;
+    const int M = OH * OW, p_lo = half * per, cnt = (p_lo + per < M ? p_lo + per : M) - p_lo;
+    {
         const i64 off = frame_off[b * sstride * Wn + c];
-        unsigned *dst = reinterpret_cast<unsigned *>(fr + c * kC1Frame);
+        unsigned *dst = reinterpret_cast<unsigned *>(fr);
         for (int idx = t; idx < kC1Pad * (kC1Pad / 4); idx += 256) {
             unsigned o = 0u;
             if (off >= 0) {
@@ -313,31 +426,45 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad(const u8 *__restrict__ base
             dst[idx] = o;
         }
     }
-    for (int idx = t; idx < (p_hi - p_lo) * 32; idx += 256) sy[idx] = dY1[((i64)b * M + p_lo) * 32 + idx];
-    __syncthreads();
-    if (t < 32) {  // bias gradient of this (sample, chunk): sum of its dY rows
-        float bs = 0.f;
-        for (int p = 0; p < p_hi - p_lo; p++) bs += sy[p * 32 + t];
-        bias_part[((i64)b * kC1Chunks + chunk) * 32 + t] = bs;
+    for (int idx = t; idx < per * 32; idx += 256) sy[idx] = idx < cnt * 32 ? dY1[((i64)b * M + p_lo) * 32 + idx] : 0.f;  // pad rows multiply as zeros
+    for (int p = t; p < per; p += 256) {
+        const int pp = p < cnt ? p_lo + p : p_lo;
+        poff[p] = 4 * (pp / OW) * kC1Pad + 4 * (pp % OW);
     }
-    const int K = Wn * 64;
-    for (int k = t; k < K; k += 256) {
-        const int c = k >> 6, ky = (k >> 3) & 7, kx = k & 7;
-        const u8 *f = fr + c * kC1Frame + ky * kC1Pad + kx;
-        float acc[32];
-#pragma unroll
-        for (int j = 0; j < 32; j++) acc[j] = 0.f;
-        for (int p = p_lo; p < p_hi; p++) {
-            const float a = byte_to_unit(f[(4 * (p / OW)) * kC1Pad + 4 * (p % OW)]);
-            const float4 *y = reinterpret_cast<const float4 *>(sy + (p - p_lo) * 32);
-#pragma unroll
-            for (int v = 0; v < 8; v++) {
-                const float4 d = y[v];
-                acc[4 * v] += d.x * a, acc[4 * v + 1] += d.y * a, acc[4 * v + 2] += d.z * a, acc[4 * v + 3] += d.w * a;
-            }
+    __syncthreads();
+    if (c == 0) {  // bias gradient of this (sample, half): column sums of its dY rows, eight slices added in order
+        float bs = 0.f;
+        for (int p = t >> 5; p < cnt; p += 8) bs += sy[p * 32 + i];
+        red[t] = bs;
+        __syncthreads();
+        if (t < 32) {
+            float tot = red[t];
+            for (int q = 1; q < 8; q++) tot += red[q * 32 + t];
+            bias_part[((i64)b * 2 + half) * 32 + t] = tot;
         }
+        __syncthreads();
+    }
+    const int tt = wave & 1, ph = wave >> 1;
+    const int tap = (4 * tt + (i >> 3)) * kC1Pad + (i & 7);
+    f32x16 acc;
 #pragma unroll
-        for (int j = 0; j < 32; j++) part[(((i64)b * kC1Chunks + chunk) * 32 + j) * K + k] = acc[j];
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const int pairs = per / 2;
+    for (int jj = ph; jj < pairs; jj += 2) {
+        const int p = 2 * jj + h;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sy[p * 32 + i], byte_to_unit(fr[poff[p] + tap]), acc, 0, 0, 0);
+    }
+    if (ph == 1)
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[(tt * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (ph == 0) {
+        const int K = Wn * 64;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout: row = output channel, column = tap
+            part[(((i64)b * 2 + half) * 32 + co) * K + c * 64 + tt * 32 + i] = acc[r] + red[(tt * 16 + r) * 64 + lane];
+        }
     }
 }
 
@@ -355,15 +482,15 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
     SRLX_REQUIRE(h->max_train == 0, "qnet_enable_training: already enabled with a smaller batch");
     srlx::DeviceGuard guard(h->device);
     const int N1 = 2 * h->hidden;
-    const size_t c3 = (size_t)2 * h->F1 * 9 * 2 * h->F1, c2 = (size_t)2 * h->F1 * 16 * h->F1, c1 = (size_t)max_train_batch * kC1Chunks * 32 * h->Wn * 64;
-    size_t wp = kWgSplits * (c3 > c2 ? c3 : c2);
-    if (c1 > wp) wp = c1;
+    const size_t c3 = (size_t)2 * h->F1 * 9 * 2 * h->F1, c2 = (size_t)2 * h->F1 * 16 * h->F1, c1 = (size_t)max_train_batch * 2 * 32 * h->Wn * 64;
+    const size_t wp = kWgSplits * (c3 > c2 ? c3 : c2) + c1;  // [conv2 / conv3 splits][conv1 (sample, half) parts]
     h->w_part_floats = wp;
     struct {
         float **p;
         size_t n;
     } bufs[] = {{&h->h1, (size_t)h->max_batch * N1},
                 {&h->dh1, (size_t)max_train_batch * N1},
+                {&h->dh1t, (size_t)N1 * 32},
                 {&h->dact3, (size_t)max_train_batch * h->flat},
                 {&h->dact2, (size_t)max_train_batch * h->OH2 * h->OW2 * 2 * h->F1},
                 {&h->dact1, (size_t)max_train_batch * h->OH1 * h->OW1 * h->F1},
@@ -373,7 +500,7 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
                                                              : (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1) + 128 * 64},
                 {&h->w_t, c3},
                 {&h->w_t2, c2},
-                {&h->w_part, wp + 64 + 2 * kWgSplits * 64 + 64 * kC1Chunks * 32}};
+                {&h->w_part, wp + 64 + 2 * kWgSplits * 64 + 64 * 2 * 32}};  // + bias partials: [splits][64] conv2/conv3 (x2), [sample, half][32] conv1
     for (auto &b : bufs) {
         hipError_t e = hipMalloc((void **)b.p, b.n * sizeof(float));
         if (e != hipSuccess) {
@@ -382,9 +509,28 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
         }
     }
     // the weight-gradient branch of the backward pass runs on its own stream, forked from / joined to the caller's
+    // (one side stream, default priority: more streams, or priorities on them, spread the learner over more hardware queues than
+    // the command processor serves at once -- measured 2x slower updates)
     SRLX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    for (hipEvent_t *e : {&h->ev_fork, &h->ev_d3, &h->ev_d2, &h->ev_d1, &h->ev_join, &h->ev_wt}) SRLX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t *e : {&h->ev_fork, &h->ev_d3, &h->ev_d2, &h->ev_d1, &h->ev_join, &h->ev_wt})
+        SRLX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     h->max_train = max_train_batch;
+    return SRLX_OK;
+}
+
+int srlx_qnet_fuse_adam_fc1(srlx_qnet_t *h, float *d_exp_avg, float *d_exp_avg_sq, double lr, double beta1, double beta2, double eps, const int64_t *d_steps_taken) {
+    SRLX_REQUIRE(h, "qnet_fuse_adam_fc1: NULL handle");
+    SRLX_REQUIRE(h->max_train > 0, "qnet_fuse_adam_fc1: call srlx_qnet_enable_training first");
+    if (!d_exp_avg) {  // back to writing the gradient out
+        h->adam_m = h->adam_v = nullptr;
+        h->adam_step = nullptr;
+        return SRLX_OK;
+    }
+    SRLX_REQUIRE(!h->sig[0], "qnet_fuse_adam_fc1: NoisyLinear layers need the gradient of the effective weight (for mu AND sigma): not fusable");
+    SRLX_REQUIRE(d_exp_avg_sq && d_steps_taken && lr > 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "qnet_fuse_adam_fc1: bad argument");
+    h->adam_m = d_exp_avg, h->adam_v = d_exp_avg_sq;
+    h->adam_lr = lr, h->adam_b1 = beta1, h->adam_b2 = beta2, h->adam_eps = eps;
+    h->adam_step = d_steps_taken;
     return SRLX_OK;
 }
 
@@ -402,20 +548,27 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     float *g_w1 = g[0], *g_b1 = g[1], *g_w2 = g[2], *g_b2 = g[3], *g_w3 = g[4], *g_b3 = g[5], *g_wf = g[6], *g_bf = g[7], *g_v2w = g[8], *g_v2b = g[9], *g_a2w = g[10],
           *g_a2b = g[11];
     float *bias_part = h->w_part + h->w_part_floats;  // [splits][CO] partial bias sums
+    const size_t c3 = (size_t)2 * h->F1 * 9 * 2 * h->F1, c2 = (size_t)2 * h->F1 * 16 * h->F1;
 
     // head + second layers -> dh1 (masked by the first layer's ReLU), bias gradient of the first layer
+    const bool mfma_dgrad = B <= 32;  // the batch fits one 32-row MFMA tile
     {
         const dim3 hg((unsigned)((h->hidden + 63) / 64));
         const size_t hl = (size_t)(B + B * A + (3 + (A <= 8 ? 8 : (A <= 16 ? 16 : 32))) * 256) * sizeof(float);
+        float *dh1t = mfma_dgrad ? h->dh1t : nullptr;
         if (A <= 8)
-            hipLaunchKernelGGL(k_head_bwd<8>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+            hipLaunchKernelGGL(k_head_bwd<8>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, dh1t, g_bf, g_v2w, g_v2b, g_a2w,
+                               g_a2b);
         else if (A <= 16)
-            hipLaunchKernelGGL(k_head_bwd<16>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+            hipLaunchKernelGGL(k_head_bwd<16>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, dh1t, g_bf, g_v2w, g_v2b, g_a2w,
+                               g_a2b);
         else
-            hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, g_bf, g_v2w, g_v2b, g_a2w, g_a2b);
+            hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, dh1t, g_bf, g_v2w, g_v2b, g_a2w,
+                               g_a2b);
     }
-    // Two branches from here (fork/join with events; capturable into a HIP graph): the data-gradient chain stays on the
-    // caller's stream, every weight gradient runs on h->side as soon as the activation gradient it needs exists.
+    // Two branches from here (fork/join with events; capturable into a HIP graph): the data-gradient chain, then conv1's weight
+    // gradient (which needs the end of it), stay on the caller's stream; the other weight gradients run on h->side as soon as the
+    // activation gradient each needs exists -- the first dense layer's with Adam in its epilogue when the optimiser state is bound.
     hipStream_t sd = h->side;
     SRLX_HIP(hipEventRecord(h->ev_fork, st));
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
@@ -427,12 +580,13 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
         hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((C2 * 16 * h->F1 + 255) / 256)), dim3(256), 0, st, h->w2, C2, 4, 4, 2, h->F1, h->w_t2);
     }
     // ---- data-gradient chain (caller's stream)
-    if (B <= 32)
-        hipLaunchKernelGGL(k_fc1_dgrad<32>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
-    else
+    if (mfma_dgrad) {
+        hipLaunchKernelGGL(k_fc1_dgrad_mfma, dim3((unsigned)(K / 32)), dim3(256), 0, st, B, ss, N1, K, h->dh1t, h->wf, h->act3, h->dact3);
+    } else {
         hipLaunchKernelGGL(k_fc1_dgrad<64>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
-    hipLaunchKernelGGL(k_fc1_dgrad_reduce, dim3((unsigned)(((i64)B * K + 255) / 256)), dim3(256), 0, st, B, ss, K, h->fc_part, h->act3, h->dact3);
-    SRLX_HIP(hipEventRecord(h->ev_d3, st));
+        hipLaunchKernelGGL(k_fc1_dgrad_reduce, dim3((unsigned)(((i64)B * K + 255) / 256)), dim3(256), 0, st, B, ss, K, h->fc_part, h->act3, h->dact3);
+    }
+    SRLX_HIP(hipEventRecord(h->ev_d3, st));  // dact3 exists; nothing reads the first dense layer's weights any more
     {   // conv3 (3x3 stride 1 pad 1, act2 -> act3) data gradient on the padded grid (OH2 + 2)^2
         const int HP = h->OH2 + 2, WP = h->OW2 + 2;
         SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st));
@@ -447,26 +601,31 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
         hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, 2, QH, QW, h->dxpad, h->act1, h->dact1);
     }
     SRLX_HIP(hipEventRecord(h->ev_d1, st));
-    // ---- weight-gradient branch (side stream)
-    hipLaunchKernelGGL(k_fc1_wgrad, dim3((unsigned)((K + 255) / 256), (unsigned)(N1 / 32)), dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf);
+    // ---- weight gradients of conv3, the first dense layer and conv2 (side stream)
+    const dim3 fg((unsigned)((K + 255) / 256), (unsigned)(N1 / 32));
+    if (!h->adam_m) hipLaunchKernelGGL(k_fc1_wgrad, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
     hipLaunchKernelGGL((k_conv_wgrad<64, 64>), dim3(9, kWgSplits), dim3(256), 0, sd, g3, B, ss, h->act2, h->dact3, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 63) / 64)), dim3(1024), 0, sd, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
+    if (h->adam_m)  // Adam in the epilogue updates the weights in place: after ev_d3, when the data gradient has read them
+        hipLaunchKernelGGL(k_fc1_wgrad_adam, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr, h->adam_b1,
+                           h->adam_b2, h->adam_eps, h->adam_step);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
     hipLaunchKernelGGL((k_conv_wgrad<32, 64>), dim3(16, kWgSplits), dim3(256), 0, sd, g2, B, ss, h->act1, h->dact2, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, kWgSplits, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2,
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 63) / 64)), dim3(1024), 0, sd, h->w_part, kWgSplits, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2,
                        g_b2);
-    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d1, 0));
-    const int per = (h->OH1 * h->OW1 + kC1Chunks - 1) / kC1Chunks;
-    const size_t lds = (size_t)h->Wn * kC1Frame + (size_t)per * 32 * sizeof(float);
-    SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
-    hipLaunchKernelGGL(k_conv1_wgrad, dim3((unsigned)B, kC1Chunks), dim3(256), lds, sd, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, h->dact1,
-                       h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, sd, h->w_part, B * kC1Chunks, (i64)32 * h->Wn * 64, g_w1, bias_part, 32,
-                       g_b1);
     SRLX_HIP(hipEventRecord(h->ev_join, sd));
+    // conv1's weight gradient needs the END of the data-gradient chain: it follows it on the caller's stream instead of queueing behind
+    // the conv2 / conv3 weight gradients on the side stream
+    const int per = ((h->OH1 * h->OW1 + 1) / 2 + 1) & ~1;  // output pixels per half, even (the MFMA consumes pixel pairs)
+    const size_t lds = (size_t)kC1Frame + (size_t)per * 4 + (size_t)per * 32 * sizeof(float) + 2 * 16 * 64 * sizeof(float);
+    SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
+    float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
+    hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(2 * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
+                       h->dact1, c1_part, c1_bias);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 63) / 64)), dim3(1024), 0, st, c1_part, 2 * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     // NoisyLinear: d loss / d sigma = d loss / d W_effective * eps of the draw the forward used (regenerated, not stored)
     SRLX_TRY(srlx_qnet_noisy_sigma_grads(h, g, st));

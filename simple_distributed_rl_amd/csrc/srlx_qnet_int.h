@@ -15,12 +15,18 @@ struct srlx_qnet {
     int64_t max_train;
     float *h1;                            // [max_batch][2*hidden]
     float *dh1, *dact3, *dact2, *dact1;   // [max_train][...]
-    float *fc_part;                       // [kFcSplits][max_train][flat]
+    float *fc_part;                       // [kFcSplits][max_train][flat] (first dense layer's data gradient, batches above 32)
+    float *dh1t;                          // [2*hidden][32]: dh1 transposed, rows of samples >= batch are zero (matrix-core data gradient, batch <= 32)
     float *w_part;                        // weight-gradient partial sums (largest layer)
     float *dxpad, *w_t, *w_t2;            // padded data gradient (per parity class), transposed filters of conv3 / conv2
     size_t w_part_floats;
     hipStream_t side;                     // weight-gradient branch of the backward pass (forks from / joins the caller's stream)
     hipEvent_t ev_fork, ev_d3, ev_d2, ev_d1, ev_join, ev_wt;
+    // Adam applied to the first dense layer's weight inside its weight-gradient kernel (srlx_qnet_fuse_adam_fc1), which then
+    // runs once the data gradient has read the weights
+    float *adam_m, *adam_v;               // BORROWED optimiser state of wf (NULL: the gradient is written out instead)
+    double adam_lr, adam_b1, adam_b2, adam_eps;
+    const int64_t *adam_step;             // BORROWED device scalar: optimiser steps already taken
     hipEvent_t probe0, probe1;            // optional, caller-owned: recorded around the two conv GEMM launches of the next forward (srlx_qnet_set_probe)
     // NoisyLinear dense layers (srlx_qnet_bind_noisy, srlx_noisy.hip): wf..a2b above then point at `eff`, the effective tensors
     // mu + sigma * eps of the current noise draw; order of the six: wf, bf, v2w, v2b, a2w, a2b

@@ -10,6 +10,7 @@
 // All are tiny (B x n x A floats): latency-bound single-workgroup kernels whose point is to keep the
 // learner step free of device<->host hops (the reference does four per train()).
 // float32 arithmetic follows numpy's evaluation order of the cited lines.
+#include "srlx_adam_math.h"
 #include "srlx_common.h"
 
 namespace {
@@ -204,12 +205,11 @@ __global__ void __launch_bounds__(256) k_gae_scan(i64 E, i64 T, const float *rew
 // ------------------------------------------------------------------------------------------
 // Adam (model_torch.py:71: torch.optim.Adam(lr); :109 optimizer.step()) for every parameter tensor of the network in
 // ONE launch: 28 B of traffic per element (p, g, m, v read; p, m, v written), HBM bound -- 8.0 M parameters = 224 MB.
-// The tensor table travels as a kernel argument; a workgroup owns one 2048-element chunk of one tensor.
-// Arithmetic order follows torch's Adam (step starts at 1; exp_avg = lerp(exp_avg, g, 1-b1); bias corrections in
-// double; denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom), evaluated in float32.
+// The tensor table travels as a kernel argument; a workgroup owns one 4096-element chunk of one tensor.
+// The per-element arithmetic (torch's order of operations) is srlx_adam_math.h.
 // ------------------------------------------------------------------------------------------
 constexpr int kAdamMaxTensors = 24;
-constexpr int kAdamChunk = 2048;
+constexpr int kAdamChunk = 4096;
 struct AdamTable {
     float *p[kAdamMaxTensors];
     const float *g[kAdamMaxTensors];
@@ -220,13 +220,6 @@ struct AdamTable {
     int n_tensors;
 };
 
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float w1, float b2, float w2, float step_size, float bc2_sqrt, float eps) {
-    m = m + w1 * (g - m);
-    v = b2 * v + (w2 * g) * g;
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p = p - (step_size * m) / denom;
-}
-
 __global__ void __launch_bounds__(256) k_adam(AdamTable tb, double lr, double beta1, double beta2, double eps, const i64 *d_step) {
     int ti = 0;
     while (ti + 1 < tb.n_tensors && (int)blockIdx.x >= tb.chunk_start[ti + 1]) ti++;
@@ -234,23 +227,20 @@ __global__ void __launch_bounds__(256) k_adam(AdamTable tb, double lr, double be
     const i64 n = tb.n[ti];
     float *p = tb.p[ti] + off, *m = tb.m[ti] + off, *v = tb.v[ti] + off;
     const float *g = tb.g[ti] + off;
-    const double step = (double)(*d_step + 1);
-    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
-    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-    const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2), e = (float)eps;
+    const srlx::AdamCoef c = srlx::adam_coef(lr, beta1, beta2, eps, *d_step);
     const i64 left = n - off;
     const int cnt = left < kAdamChunk ? (int)left : kAdamChunk;
     const int t = threadIdx.x;
-    if (cnt == kAdamChunk) {  // chunks start at multiples of 2048 floats of a 16-byte aligned tensor
+    if (cnt == kAdamChunk) {  // chunks start at multiples of 4096 floats of a 16-byte aligned tensor
 #pragma unroll
         for (int r = 0; r < kAdamChunk / (256 * 4); r++) {
             const int k = (r * 256 + t) * 4;
             float4 pp = *reinterpret_cast<float4 *>(p + k), mm = *reinterpret_cast<float4 *>(m + k), vv = *reinterpret_cast<float4 *>(v + k);
             const float4 gg = *reinterpret_cast<const float4 *>(g + k);
-            adam_one(pp.x, gg.x, mm.x, vv.x, w1, b2, w2, step_size, bc2_sqrt, e);
-            adam_one(pp.y, gg.y, mm.y, vv.y, w1, b2, w2, step_size, bc2_sqrt, e);
-            adam_one(pp.z, gg.z, mm.z, vv.z, w1, b2, w2, step_size, bc2_sqrt, e);
-            adam_one(pp.w, gg.w, mm.w, vv.w, w1, b2, w2, step_size, bc2_sqrt, e);
+            srlx::adam_one(pp.x, gg.x, mm.x, vv.x, c);
+            srlx::adam_one(pp.y, gg.y, mm.y, vv.y, c);
+            srlx::adam_one(pp.z, gg.z, mm.z, vv.z, c);
+            srlx::adam_one(pp.w, gg.w, mm.w, vv.w, c);
             *reinterpret_cast<float4 *>(p + k) = pp;
             *reinterpret_cast<float4 *>(m + k) = mm;
             *reinterpret_cast<float4 *>(v + k) = vv;
@@ -258,7 +248,7 @@ __global__ void __launch_bounds__(256) k_adam(AdamTable tb, double lr, double be
     } else {
         for (int k = t; k < cnt; k += 256) {
             float pp = p[k], mm = m[k], vv = v[k];
-            adam_one(pp, g[k], mm, vv, w1, b2, w2, step_size, bc2_sqrt, e);
+            srlx::adam_one(pp, g[k], mm, vv, c);
             p[k] = pp;
             m[k] = mm;
             v[k] = vv;

@@ -283,22 +283,41 @@ class DeviceAdam:
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.exp_avg = [torch.zeros_like(p) for p in self.params]  # preserve_format
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
-        k = len(self.params)
-        self.bind()
-        self._g = (N.c_p * k)(*[p.grad.data_ptr() for p in self.params])
-        self._m = (N.c_p * k)(*[t.data_ptr() for t in self.exp_avg])
-        self._v = (N.c_p * k)(*[t.data_ptr() for t in self.exp_avg_sq])
-        self._n = (N.c_i64 * k)(*[p.numel() for p in self.params])
         for p, m in zip(self.params, self.exp_avg):
             assert p.stride() == m.stride() == p.grad.stride(), "parameter, gradient and Adam state must share one memory format"
+        self._fused = None  # index of the tensor the network's backward pass updates itself (fuse_first_dense)
+        self._tables()
+
+    def _tables(self):
+        self._idx = [i for i in range(len(self.params)) if i != self._fused]
+        k = len(self._idx)
+        self._g = (N.c_p * k)(*[self.params[i].grad.data_ptr() for i in self._idx])
+        self._m = (N.c_p * k)(*[self.exp_avg[i].data_ptr() for i in self._idx])
+        self._v = (N.c_p * k)(*[self.exp_avg_sq[i].data_ptr() for i in self._idx])
+        self._n = (N.c_i64 * k)(*[self.params[i].numel() for i in self._idx])
+        self.bind()
 
     def bind(self):
         """(Re)reads the parameters' addresses: call again after they have been re-homed (device/dist.py:flatten_parameters)."""
-        self._p = (N.c_p * len(self.params))(*[p.data_ptr() for p in self.params])
+        self._p = (N.c_p * len(self._idx))(*[self.params[i].data_ptr() for i in self._idx])
+
+    def fuse_first_dense(self, inf: "QNetInference", steps_taken_dev: torch.Tensor):
+        """The first dense layer's weight (97 % of the parameters) gets its Adam step inside `inf.backward_u8`'s weight-gradient kernel
+        (srlx_qnet_fuse_adam_fc1): its gradient is never written to memory and `step()` covers the remaining tensors only.
+        `steps_taken_dev` must be the device scalar later handed to `step()`.  Not available for NoisyLinear networks."""
+        assert self._fused is None and not inf.net.noisy
+        k = [i for i, p in enumerate(self.params) if p is inf.net.fc1.weight]
+        assert len(k) == 1, "the optimiser does not hold this network's first dense layer"
+        self._fused = k[0]
+        self._fused_steps = steps_taken_dev  # keeps the scalar alive: the library holds its address
+        N.check(self.lib.srlx_qnet_fuse_adam_fc1(inf.h, N.tptr(self.exp_avg[self._fused]), N.tptr(self.exp_avg_sq[self._fused]), self.lr, self.betas[0], self.betas[1],
+                                                 self.eps, N.tptr(steps_taken_dev)))
+        self._tables()
 
     def step(self, steps_taken_dev: torch.Tensor):
         """One Adam step; `steps_taken_dev` (int64 device scalar) = steps already taken (the caller increments it)."""
-        k = len(self.params)
+        assert self._fused is None or steps_taken_dev.data_ptr() == self._fused_steps.data_ptr()
+        k = len(self._idx)
         N.check(self.lib.srlx_adam_step(k, ctypes.cast(self._p, N.c_p), ctypes.cast(self._g, N.c_p), ctypes.cast(self._m, N.c_p), ctypes.cast(self._v, N.c_p),
                                         ctypes.cast(self._n, N.c_p), self.lr, self.betas[0], self.betas[1], self.eps, N.tptr(steps_taken_dev), N.torch_stream_ptr()))
 

@@ -170,6 +170,9 @@ class RainbowEngine:
         self._commit_graph = None
         d = self.dev
         self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
+        if self.mfma_train and not self.noisy and os.environ.get("SRLX_NO_FUSED_ADAM", "0") != "1":
+            # the 32 MB first dense layer takes its Adam step inside the backward pass, beside the convolution gradients (A/B switch for measurements)
+            self.optimizer.fuse_first_dense(self.inf_online, self.train_count_dev)
         self.train_count = 0
         self.sync_count = 0
         self.total_env_steps = 0

@@ -11,23 +11,26 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _engine(torch_backward: bool, **kw):
+def _engine(torch_backward: bool, fused_adam: bool = True, **kw):
     from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
 
     os.environ["SRLX_TORCH_BACKWARD"] = "1" if torch_backward else "0"
+    os.environ["SRLX_NO_FUSED_ADAM"] = "0" if fused_adam else "1"
     try:
         cfg = RainbowDeviceConfig(n_envs=8, batch_size=8, memory_capacity=8 * 64, memory_warmup_size=32, target_model_update_interval=4, lr=1e-4, seed=3)
         return RainbowEngine(cfg, 0, episode_len=9, **kw)
     finally:
         os.environ.pop("SRLX_TORCH_BACKWARD", None)
+        os.environ.pop("SRLX_NO_FUSED_ADAM", None)
 
 
 def test_training_pass_equals_autograd_path():
     """Two engines on the same seed: one differentiates with the libsrlx backward kernels (one forward over s_0..s_n read
     from the uint8 ring), the other with torch autograd on float32 pixels.  Same sampled items, TD targets, loss,
-    priorities and parameter gradients at every learner step."""
-    a, b = _engine(False), _engine(True)
-    assert a.mfma_train and not b.mfma_train
+    priorities and parameter gradients at every learner step.  (The gradient of the first dense layer is only materialised
+    with its Adam step left in `srlx_adam_step`: test_fused_first_dense_adam_is_the_same_update covers the fused kernel.)"""
+    a, b = _engine(False, fused_adam=False), _engine(True)
+    assert a.mfma_train and not b.mfma_train and a.optimizer._fused is None
     b.q_online.load_state_dict(a.q_online.state_dict())
     b.q_target.load_state_dict(a.q_target.state_dict())
     steps = 0
@@ -51,6 +54,28 @@ def test_training_pass_equals_autograd_path():
     assert steps >= 5
     for pa, pb in zip(a.q_online.parameters(), b.q_online.parameters()):
         assert float((pa - pb).detach().abs().max()) < 5 * 1e-4 * steps  # lr per Adam step bounds the drift
+
+
+def test_fused_first_dense_adam_is_the_same_update():
+    """srlx_qnet_fuse_adam_fc1: Adam inside the first dense layer's weight-gradient kernel (the engine's default) against the same
+    engine with that tensor left to srlx_adam_step -- same accumulation order, same arithmetic: parameters and both moment
+    estimates of EVERY tensor stay bit-equal over the learner steps, and the fused tensor does move."""
+    a, c = _engine(False), _engine(False, fused_adam=False)
+    k = a.optimizer._fused
+    assert k is not None and a.optimizer.params[k] is a.q_online.fc1.weight and c.optimizer._fused is None
+    c.q_online.load_state_dict(a.q_online.state_dict())
+    c.q_target.load_state_dict(a.q_target.state_dict())
+    w0 = a.q_online.fc1.weight.detach().clone()
+    for it in range(12):
+        for e in (a, c):
+            e.step(learner_updates=1)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(a.priorities.cpu().numpy(), c.priorities.cpu().numpy())
+        for i, (pa, pc) in enumerate(zip(a.optimizer.params, c.optimizer.params)):
+            assert torch.equal(pa, pc), (it, i)
+            assert torch.equal(a.optimizer.exp_avg[i], c.optimizer.exp_avg[i]) and torch.equal(a.optimizer.exp_avg_sq[i], c.optimizer.exp_avg_sq[i]), (it, i)
+    assert a.train_count >= 5 and float((a.q_online.fc1.weight - w0).abs().max()) > 0
+    assert float(a.optimizer.exp_avg[k].abs().max()) > 0
 
 
 def test_engine_overlap_and_graphs():
@@ -163,7 +188,7 @@ def test_engine_learns_a_cue_task():
 
     A = 4
     cfg = RainbowDeviceConfig(n_envs=64, batch_size=32, memory_capacity=64 * 64, memory_warmup_size=256, obs_hw=(20, 20), hidden_units=64,
-                              n_actions=A, seed=5, target_model_update_interval=25, lr=1e-3, epsilon=0.2, discount=0.9)
+                              n_actions=A, seed=6, target_model_update_interval=25, lr=1e-3, epsilon=0.2, discount=0.9)
     eng = RainbowEngine(cfg, 0, episode_len=6, overlap=False)
     env = _CueVecEnv(eng.replay, 6, A, seed=9)
     eng.env = env

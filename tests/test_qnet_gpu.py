@@ -140,25 +140,26 @@ def test_forward_u8_reads_the_ring_directly():
     np.testing.assert_array_equal(ter.cpu().numpy(), ot)
 
 
-@pytest.mark.parametrize("A,dueling,B,stride", [(6, "average", 32, 1), (18, "", 32, 4), (6, "average", 5, 3), (4, "average", 64, 2)])
-def test_backward_u8_matches_autograd(A, dueling, B, stride):
+@pytest.mark.parametrize("A,dueling,B,stride,hw,hidden", [(6, "average", 32, 1, 84, 512), (18, "", 32, 4, 84, 512), (6, "average", 5, 3, 84, 512),
+                                                         (4, "average", 64, 2, 84, 512), (4, "average", 32, 4, 20, 64), (3, "", 7, 1, 36, 32)])
+def test_backward_u8_matches_autograd(A, dueling, B, stride, hw, hidden):
     """srlx_qnet_backward_u8 (hand-written backward of every layer, gradients written in the parameters' own memory
     layouts) vs torch autograd on the float32 stack of the same uint8 frames, incl. zero-history frames, a row
     stride (train samples interleaved with no-grad samples in one forward) and replicate-padding borders."""
     from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference
 
     torch.manual_seed(3)
-    net = EngineQNet(A, (84, 84), 4, 512, 32, dueling).cuda()
+    net = EngineQNet(A, (hw, hw), 4, hidden, 32, dueling).cuda()
     rows = B * stride
     qn = QNetInference(net, max_batch=max(rows, 64)).enable_training(64)
-    F, n_frames = 84 * 84, 300
+    F, n_frames = hw * hw, 300
     g = torch.Generator(device="cuda").manual_seed(1)
     ring = torch.randint(0, 256, (n_frames * F,), dtype=torch.uint8, device="cuda", generator=g)
     sel = torch.randint(0, n_frames, (rows, 4), device="cuda", generator=g)
     off = sel * F
     off[torch.rand((rows, 4), device="cuda", generator=g) < 0.1] = -1  # zero history
     q = qn.forward_u8(ring.data_ptr(), off).clone()
-    frames = ring.view(n_frames, 84, 84)[sel.clamp(min=0)].float() / 255
+    frames = ring.view(n_frames, hw, hw)[sel.clamp(min=0)].float() / 255
     frames = torch.where((off < 0)[..., None, None], torch.zeros_like(frames), frames)
     net.zero_grad(set_to_none=True)
     want_q = net(frames, channels_first=True)

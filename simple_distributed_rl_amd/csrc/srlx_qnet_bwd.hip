@@ -7,9 +7,10 @@
 // the fused [2*hidden][flat] first dense layer), where the fused Adam reads them.
 //
 // At B = 32 the whole backward pass is 2.6 GFLOP against 64 MB of weight-sized traffic: every kernel here is
-// HBM/latency bound, not MFMA bound (the two dense-layer kernels stream the 32 MB matrix once each), so they are
-// plain FMA kernels laid out for coalesced streaming; summation orders are fixed (no atomics): results are
-// deterministic and agree with autograd to float32 round-off (tests/test_qnet_gpu.py, 1e-4 relative).
+// HBM/latency bound, not MFMA bound (the two dense-layer kernels stream the 32 MB matrix once each).  The dense layer and
+// conv1 use the matrix cores all the same -- with the batch (or the pixel pair) as the K dimension an MFMA needs one operand
+// load per 2 x 32 x 32 FMAs where a plain FMA kernel needs one LDS broadcast per FMA.  Summation orders are fixed (no
+// atomics): results are deterministic and agree with autograd to float32 round-off (tests/test_qnet_gpu.py, 1e-4 relative).
 //
 // Replicate padding: a border input pixel is read by several (output, tap) pairs; the data-gradient kernels gather
 // over host-built pair tables instead of scattering.
@@ -114,26 +115,55 @@ __global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden
     }
 }
 
-// ---- first dense layer: weight gradient  g_wf[n][k] = sum_b dh1[b][n] * act3[b][k]  (writes 32 MB once) ---------
+// ---- first dense layer: weight gradient  g_wf[n][k] = sum_b dh1[b][n] * act3[b][k]  on the matrix cores -------------------------
+// One wave per 32 x 32 tile of the 32 MB matrix: the batch is the K dimension of v_mfma_f32_32x32x2_f32 (two samples per
+// instruction), both operands come straight from global memory as coalesced 128-byte rows (dh1[b][n0 + i], act3[b][k0 + i]), no
+// LDS.  ADAM = true (srlx_qnet_fuse_adam_fc1): the gradient is never written -- each lane applies the optimiser step to its
+// 16 weights and their two moment estimates in place (their loads are issued before the MFMAs): 226 MB of traffic for
+// "write g, then Adam" becomes 161 MB, and the update of 97 % of the parameters runs beside the convolution gradients instead
+// of after them.  Both variants run the same instruction sequence, so the fused update is bit-equal to the separate one.
+template <bool ADAM>
 __global__ void __launch_bounds__(256) k_fc1_wgrad(int B, i64 sstride, int N1, int K, const float *__restrict__ dh1, const float *__restrict__ act3,
-                                                   float *__restrict__ g_wf) {
-    __shared__ float sd[64 * 32];  // dh1[b][n0 .. n0+31], b < 64
-    const int n0 = blockIdx.y * 32;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    for (int idx = threadIdx.x; idx < B * 32; idx += 256) sd[idx] = dh1[(i64)(idx / 32) * N1 + n0 + (idx % 32)];
-    __syncthreads();
-    if (k >= K) return;
-    float acc[32];
+                                                   float *__restrict__ g_wf, float *__restrict__ wf, float *__restrict__ m, float *__restrict__ v, double lr, double beta1,
+                                                   double beta2, double eps, const i64 *__restrict__ d_step) {
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32, n0 = blockIdx.y * 32;
+    if (k0 >= K) return;  // (wave-uniform; no barriers in this kernel)
+    float pp[16], mm[16], vv[16];
+    if (ADAM)
 #pragma unroll
-    for (int j = 0; j < 32; j++) acc[j] = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; b++) {
-        const float a = act3[(i64)b * sstride * K + k];
+        for (int r = 0; r < 16; r++) {
+            const i64 at = (i64)(n0 + (r & 3) + 8 * (r >> 2) + 4 * h) * K + k0 + i;  // C/D layout: row = hidden unit, column = lane & 31
+            pp[r] = wf[at], mm[r] = m[at], vv[r] = v[at];
+        }
+    f32x16 acc;
 #pragma unroll
-        for (int j = 0; j < 32; j++) acc[j] += sd[b * 32 + j] * a;
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const float *pa = dh1 + (i64)h * N1 + n0 + i, *pb = act3 + (i64)h * sstride * K + k0 + i;
+    const int steps = (B + 1) / 2;
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const bool live = 2 * (s0 + q) + h < B;
+            av[q] = live ? pa[(i64)(s0 + q) * 2 * N1] : 0.f;
+            bv[q] = live ? pb[(i64)(s0 + q) * 2 * sstride * K] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
     }
+    if (ADAM) {
+        const srlx::AdamCoef c = srlx::adam_coef(lr, beta1, beta2, eps, *d_step);
 #pragma unroll
-    for (int j = 0; j < 32; j++) g_wf[(i64)(n0 + j) * K + k] = acc[j];
+        for (int r = 0; r < 16; r++) {
+            const i64 at = (i64)(n0 + (r & 3) + 8 * (r >> 2) + 4 * h) * K + k0 + i;
+            srlx::adam_one(pp[r], acc[r], mm[r], vv[r], c);
+            wf[at] = pp[r], m[at] = mm[r], v[at] = vv[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) g_wf[(i64)(n0 + (r & 3) + 8 * (r >> 2) + 4 * h) * K + k0 + i] = acc[r];
+    }
 }
 
 // ---- first dense layer: data gradient, split over the hidden dimension (reads the 32 MB matrix once) ---------
@@ -229,40 +259,6 @@ __global__ void __launch_bounds__(256) k_fc1_dgrad_mfma(int B, i64 sstride, int 
                 dact3[(i64)b * K + k0 + i] = act3[(i64)b * sstride * K + k0 + i] > 0.f ? sum : 0.f;
             }
         }
-}
-
-// ---- first dense layer: weight gradient with Adam applied in the epilogue (srlx_qnet_fuse_adam_fc1) -----------------------------
-// Same accumulation as k_fc1_wgrad; the 32 MB gradient is never written: each thread updates its 32 weights (and their two
-// moment estimates) in place.  226 MB of traffic becomes 161 MB, and the update of 97 % of the network's parameters leaves the
-// tail of the backward pass (it runs beside the convolution gradients instead of after them).
-__global__ void __launch_bounds__(256) k_fc1_wgrad_adam(int B, i64 sstride, int N1, int K, const float *__restrict__ dh1, const float *__restrict__ act3,
-                                                        float *__restrict__ wf, float *__restrict__ m, float *__restrict__ v, double lr, double beta1, double beta2,
-                                                        double eps, const i64 *__restrict__ d_step) {
-    __shared__ float sd[64 * 32];
-    const int n0 = blockIdx.y * 32;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    for (int idx = threadIdx.x; idx < B * 32; idx += 256) sd[idx] = dh1[(i64)(idx / 32) * N1 + n0 + (idx % 32)];
-    __syncthreads();
-    if (k >= K) return;
-    float acc[32];
-#pragma unroll
-    for (int j = 0; j < 32; j++) acc[j] = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; b++) {
-        const float a = act3[(i64)b * sstride * K + k];
-#pragma unroll
-        for (int j = 0; j < 32; j++) acc[j] += sd[b * 32 + j] * a;
-    }
-    const srlx::AdamCoef c = srlx::adam_coef(lr, beta1, beta2, eps, *d_step);
-#pragma unroll 8
-    for (int j = 0; j < 32; j++) {
-        const i64 at = (i64)(n0 + j) * K + k;
-        float pp = wf[at], mm = m[at], vv = v[at];
-        srlx::adam_one(pp, acc[j], mm, vv, c);
-        wf[at] = pp;
-        m[at] = mm;
-        v[at] = vv;
-    }
 }
 
 // ---- convolution weight gradient (NHWC input X, NHWC output gradient dY already masked by its ReLU) ----------
@@ -602,15 +598,16 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     }
     SRLX_HIP(hipEventRecord(h->ev_d1, st));
     // ---- weight gradients of conv3, the first dense layer and conv2 (side stream)
-    const dim3 fg((unsigned)((K + 255) / 256), (unsigned)(N1 / 32));
-    if (!h->adam_m) hipLaunchKernelGGL(k_fc1_wgrad, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf);
+    const dim3 fg((unsigned)((K / 32 + 3) / 4), (unsigned)(N1 / 32));  // one wave per 32 x 32 tile of the weight
+    if (!h->adam_m)
+        hipLaunchKernelGGL(k_fc1_wgrad<false>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
     hipLaunchKernelGGL((k_conv_wgrad<64, 64>), dim3(9, kWgSplits), dim3(256), 0, sd, g3, B, ss, h->act2, h->dact3, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 63) / 64)), dim3(1024), 0, sd, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
     if (h->adam_m)  // Adam in the epilogue updates the weights in place: after ev_d3, when the data gradient has read them
-        hipLaunchKernelGGL(k_fc1_wgrad_adam, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr, h->adam_b1,
-                           h->adam_b2, h->adam_eps, h->adam_step);
+        hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
+                           h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
     hipLaunchKernelGGL((k_conv_wgrad<32, 64>), dim3(16, kWgSplits), dim3(256), 0, sd, g2, B, ss, h->act1, h->dact2, h->w_part, bias_part);

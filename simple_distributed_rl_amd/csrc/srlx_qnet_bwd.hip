@@ -26,7 +26,7 @@ using u8 = unsigned char;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kFcSplits = 16;   // splits of the hidden dimension in the dense data-gradient
-constexpr int kWgSplits = 64;   // splits of the row dimension in the conv weight-gradients
+constexpr int kWgSplits = 64;   // partial tensors of a conv weight gradient: one per sample (max_train <= 64)
 constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -261,78 +261,83 @@ __global__ void __launch_bounds__(256) k_fc1_dgrad_mfma(int B, i64 sstride, int 
         }
 }
 
-// ---- convolution weight gradient (NHWC input X, NHWC output gradient dY already masked by its ReLU) ----------
-//   part[split][co][tap][ci] = sum_{m in split} dY[m][co] * X[b, clamp(oy*S + ky - P), clamp(ox*S + kx - P), ci]
-// workgroup = (tap, split); thread = 4 output channels x (CI/16) input channels; rows staged 16 at a time in LDS
+// ---- convolution weight gradient (NHWC input X, NHWC output gradient dY already masked by its ReLU), on the matrix cores ----
+//   part[b][co][tap][ci] = sum over the pixels m of sample b of dY[b, m][co] * X[b, clamp(oy*S + ky - P), clamp(ox*S + kx - P), ci]
+// One wave per (tap, 32 output channels, 32 input channels, sample): the sample's output pixels are the K dimension of
+// v_mfma_f32_32x32x2_f32 (two pixels per instruction); lane (i, h) loads dY[m + h][co0 + i] and X[pixel(m + h, tap)][ci0 + i] straight
+// from global memory -- both 128-byte rows -- eight steps ahead of the MFMAs that consume them.  No LDS, no barriers: the
+// workgroups fit next to the actors' 127 KB convolution workgroups, where the staged FMA kernel this replaces ran 5x slower
+// inside the lock-step loop than alone.  CO = 64.
 struct ConvGeo {
     int H, W, CI, OH, OW, CO, KH, KW, S, P;
 };
-template <int CI, int CO>
-__global__ void __launch_bounds__(256) k_conv_wgrad(ConvGeo g, int B, i64 sstride, const float *__restrict__ X, const float *__restrict__ dY,
-                                                    float *__restrict__ part, float *__restrict__ bias_part /*[split][CO]*/) {
-    constexpr int TCI = CI / 16, TCO = CO / 16;
-    __shared__ __attribute__((aligned(16))) float sx[16 * CI];
-    __shared__ __attribute__((aligned(16))) float sy[16 * CO];
-    const int tap = blockIdx.x, split = blockIdx.y, t = threadIdx.x;
+template <int CI>
+__global__ void __launch_bounds__(256) k_conv_wgrad_mfma(ConvGeo g, i64 sstride, const float *__restrict__ X, const float *__restrict__ dY, float *__restrict__ part,
+                                                         float *__restrict__ bias_part /*[sample][CO]*/) {
+    constexpr int NCI = CI / 32, CO = 64;
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int combo = blockIdx.x * 4 + (threadIdx.x >> 6), taps = g.KH * g.KW;
+    if (combo >= taps * 2 * NCI) return;  // (wave-uniform)
+    const int cit = combo % NCI, cot = (combo / NCI) & 1, tap = combo / (2 * NCI);
     const int ky = tap / g.KW, kx = tap % g.KW;
-    const int per_img = g.OH * g.OW;
-    const i64 M = (i64)B * per_img;
-    const i64 chunk = (M + kWgSplits - 1) / kWgSplits;
-    const i64 m_lo = (i64)split * chunk, m_hi = m_lo + chunk < M ? m_lo + chunk : M;
-    const int cg = t / 16, ig = t % 16;  // co group, ci group
-    float acc[TCO][TCI];
+    const i64 b = blockIdx.y;
+    const int per_img = g.OH * g.OW, steps = (per_img + 1) / 2;
+    const float *pa = dY + b * per_img * CO + cot * 32 + i;
+    const float *px = X + b * sstride * g.H * g.W * CI + cit * 32 + i;
+    int m = h, oy = 0, ox = h;  // this lane's pixel of the next step to fetch (OW >= 2)
+    f32x16 acc;
 #pragma unroll
-    for (int a = 0; a < TCO; a++)
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float bsum = 0.f;
+    float a0[8], x0[8], a1[8], x1[8];
+    auto fetch = [&](float *a, float *x) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < TCI; c++) acc[a][c] = 0.f;
-    float bsum = 0.f;  // tap 0, threads < CO: bias gradient of this split (sum of its dY rows)
-    for (i64 m0 = m_lo; m0 < m_hi; m0 += 16) {
-        for (int idx = t; idx < 16 * CI; idx += 256) {
-            const i64 m = m0 + idx / CI;
-            float v = 0.f;
-            if (m < m_hi) {
-                const int b = (int)(m / per_img), pix = (int)(m % per_img);
-                const int iy = clampi((pix / g.OW) * g.S + ky - g.P, 0, g.H - 1), ix = clampi((pix % g.OW) * g.S + kx - g.P, 0, g.W - 1);
-                v = X[(((i64)b * sstride * g.H + iy) * g.W + ix) * CI + idx % CI];
-            }
-            sx[idx] = v;
+        for (int q = 0; q < 8; q++) {
+            const bool live = m < per_img;
+            const int iy = clampi(oy * g.S + ky - g.P, 0, g.H - 1), ix = clampi(ox * g.S + kx - g.P, 0, g.W - 1);
+            a[q] = live ? pa[(i64)m * CO] : 0.f;
+            x[q] = live ? px[((i64)iy * g.W + ix) * CI] : 0.f;
+            m += 2, ox += 2;
+            if (ox >= g.OW) ox -= g.OW, oy++;
         }
-        for (int idx = t; idx < 16 * CO; idx += 256) {
-            const i64 m = m0 + idx / CO;
-            sy[idx] = m < m_hi ? dY[m * CO + idx % CO] : 0.f;
+    };
+    auto mfma8 = [&](const float *a, const float *x) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            bsum += a[q];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], x[q], acc, 0, 0, 0);
         }
-        __syncthreads();
-        if (tap == 0 && t < CO)
-#pragma unroll
-            for (int r = 0; r < 16; r++) bsum += sy[r * CO + t];
-#pragma unroll 4
-        for (int r = 0; r < 16; r++) {
-            float yv[TCO], xv[TCI];
-#pragma unroll
-            for (int a = 0; a < TCO; a++) yv[a] = sy[r * CO + cg * TCO + a];
-#pragma unroll
-            for (int c = 0; c < TCI; c++) xv[c] = sx[r * CI + ig * TCI + c];
-#pragma unroll
-            for (int a = 0; a < TCO; a++)
-#pragma unroll
-                for (int c = 0; c < TCI; c++) acc[a][c] += yv[a] * xv[c];
-        }
-        __syncthreads();
+    };
+    fetch(a0, x0);
+    for (int s0 = 0; s0 < steps; s0 += 16) {
+        if (s0 + 8 < steps) fetch(a1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0 + 8 >= steps) break;
+        if (s0 + 16 < steps) fetch(a0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a1, x1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    const int taps = g.KH * g.KW;
 #pragma unroll
-    for (int a = 0; a < TCO; a++)
-#pragma unroll
-        for (int c = 0; c < TCI; c++) part[(((i64)split * CO + cg * TCO + a) * taps + tap) * CI + ig * TCI + c] = acc[a][c];
-    if (tap == 0 && t < CO) bias_part[split * CO + t] = bsum;
+    for (int r = 0; r < 16; r++) {
+        const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout: row = output channel, column = input channel
+        part[((b * CO + co) * taps + tap) * CI + cit * 32 + i] = acc[r];
+    }
+    if (tap == 0 && cit == 0) {  // bias gradient of this sample: the dY column sums the A operand already walked (even pixels + odd pixels)
+        const float tot = bsum + __shfl_xor(bsum, 32);
+        if (h == 0) bias_part[b * CO + cot * 32 + i] = tot;
+    }
 }
 
 // out[i] = sum_p part[p][i] for a weight gradient (n entries) and, in the same launch, its bias gradient (nb entries).
-// 64 outputs x 16 slices per workgroup: slice s adds its run of parts in order (all its loads in flight at once), the slices are
-// then added in order -- a fixed summation order, and a 256-part reduction is 16 loads deep instead of 256.
-__global__ void __launch_bounds__(1024) k_reduce_parts(const float *__restrict__ part, int P, i64 n, float *__restrict__ out, const float *__restrict__ bpart, int nb,
-                                                       float *__restrict__ bout) {
-    __shared__ float sm[16][64];
+// 64 outputs x 4 slices per workgroup: slice s adds its run of parts in order (the loads of a run are independent: up to 16 in
+// flight), the slices are then added in order -- a fixed summation order.  (256 threads, not more: a 1024-thread workgroup waits
+// for sixteen free wave slots on one CU, which beside the actors' convolution workgroups took 25 us per launch.)
+__global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, int P, i64 n, float *__restrict__ out, const float *__restrict__ bpart, int nb,
+                                                      float *__restrict__ bout) {
+    __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     i64 i = (i64)blockIdx.x * 64 + lane;
     const bool live = i < n + nb;
@@ -342,18 +347,14 @@ __global__ void __launch_bounds__(1024) k_reduce_parts(const float *__restrict__
         n = nb;
         out = bout;
     }
-    const int per = (P + 15) / 16, p_lo = sl * per, p_hi = p_lo + per < P ? p_lo + per : P;
+    const int per = (P + 3) / 4, p_lo = sl * per, p_hi = p_lo + per < P ? p_lo + per : P;
     float s = 0.f;
     if (live)
-#pragma unroll 8
+#pragma unroll 16
         for (int p = p_lo; p < p_hi; p++) s += part[(i64)p * n + i];
     sm[sl][lane] = s;
     __syncthreads();
-    if (sl == 0 && live) {
-#pragma unroll
-        for (int q = 1; q < 16; q++) s += sm[q][lane];
-        out[i] = s;
-    }
+    if (sl == 0 && live) out[i] = ((s + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
 }
 
 // ---- convolution data gradient through replicate padding ---------------------------------------------------
@@ -603,16 +604,15 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
         hipLaunchKernelGGL(k_fc1_wgrad<false>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
-    hipLaunchKernelGGL((k_conv_wgrad<64, 64>), dim3(9, kWgSplits), dim3(256), 0, sd, g3, B, ss, h->act2, h->dact3, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 63) / 64)), dim3(1024), 0, sd, h->w_part, kWgSplits, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
+    hipLaunchKernelGGL(k_conv_wgrad_mfma<64>, dim3((9 * 2 * 2 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g3, ss, h->act2, h->dact3, h->w_part, bias_part);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 63) / 64)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
     if (h->adam_m)  // Adam in the epilogue updates the weights in place: after ev_d3, when the data gradient has read them
         hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
                            h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
-    hipLaunchKernelGGL((k_conv_wgrad<32, 64>), dim3(16, kWgSplits), dim3(256), 0, sd, g2, B, ss, h->act1, h->dact2, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 63) / 64)), dim3(1024), 0, sd, h->w_part, kWgSplits, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2,
-                       g_b2);
+    hipLaunchKernelGGL(k_conv_wgrad_mfma<32>, dim3((16 * 2 * 1 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g2, ss, h->act1, h->dact2, h->w_part, bias_part);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 63) / 64)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2);
     SRLX_HIP(hipEventRecord(h->ev_join, sd));
     // conv1's weight gradient needs the END of the data-gradient chain: it follows it on the caller's stream instead of queueing behind
     // the conv2 / conv3 weight gradients on the side stream
@@ -622,7 +622,7 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
     hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(2 * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
                        h->dact1, c1_part, c1_bias);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 63) / 64)), dim3(1024), 0, st, c1_part, 2 * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 63) / 64)), dim3(256), 0, st, c1_part, 2 * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     // NoisyLinear: d loss / d sigma = d loss / d W_effective * eps of the draw the forward used (regenerated, not stored)
     SRLX_TRY(srlx_qnet_noisy_sigma_grads(h, g, st));

@@ -21,6 +21,7 @@ modules (algorithms/agent57_light.py: the reference's module trees, so parameter
 and GEMMs run through MIOpen / hipBLASLt.  `Agent57LightLearner` is shared with the single-environment plugin trainer.
 """
 import ctypes
+import functools
 from typing import Optional
 
 import numpy as np
@@ -191,6 +192,17 @@ class Agent57LightLearner:
         return out
 
 
+def _miopen_find(fn):
+    """Runs an engine entry point with torch.backends.cudnn.benchmark on (MIOpen find mode) and restores the previous setting."""
+
+    @functools.wraps(fn)
+    def scoped(self, *a, **kw):
+        with torch.backends.cudnn.flags(enabled=True, benchmark=True):
+            return fn(self, *a, **kw)
+
+    return scoped
+
+
 class Agent57LightEngine:
     """E environments + learner on one GPU.  `rl_config`: a set-up algorithms.agent57_light.Config (image observations, window 4);
     `parameter`: its Parameter (the five networks), created here when not given."""
@@ -202,9 +214,9 @@ class Agent57LightEngine:
         assert c.is_setup(), "rl_config.setup(env) first: the networks are built from the negotiated spaces"
         self.dev = torch.device(f"cuda:{device}")
         self.lib = N.lib()
-        # MIOpen's immediate mode falls back to im2col-per-image / naive fp32 convolutions on gfx950 (profiles/r1_kernel_stats_before_find.csv);
-        # let it benchmark its solvers once per shape instead
-        torch.backends.cudnn.benchmark = True
+        # MIOpen's immediate mode falls back to im2col-per-image / naive fp32 convolutions on gfx950 (profiles/r1_kernel_stats_before_find.csv):
+        # the engine's entry points run under `_miopen_find` (solver benchmarking once per shape), scoped so that the process-wide flag --
+        # and with it the convolution algorithms every other torch user of the process gets -- is left as it was
         self.E, self.seed = int(n_envs), int(seed)
         shape = c.observation_space.shape  # (H, W, window)
         H, W_, Wn = int(shape[0]), int(shape[1]), int(shape[2])
@@ -299,6 +311,7 @@ class Agent57LightEngine:
         return self.ucb.arm.long() if self.training else torch.zeros(self.E, dtype=torch.int64, device=self.dev)
 
     # ---- actor ----------------------------------------------------------------------------------
+    @_miopen_find
     def policy_q(self):
         """q_ext, q_int and q = q_ext + beta[arm] * q_int of every lane in its current state (:355-363)."""
         p, arm = self.parameter, self.arm()
@@ -309,6 +322,7 @@ class Agent57LightEngine:
         beta = self.beta_list[arm] if self.training else torch.full((self.E,), float(self.cfg.test_beta), device=self.dev)
         return q_ext, q_int, (q_ext + beta.view(-1, 1) * q_int).contiguous()
 
+    @_miopen_find
     def actor_step(self):
         c, r, st = self.cfg, self.replay, N.torch_stream_ptr()
         E = self.E
@@ -361,6 +375,7 @@ class Agent57LightEngine:
         r.update(b.indices, pri)
         self.train_count_dev.add_(1)
 
+    @_miopen_find
     def learner_step(self) -> bool:
         if self.replay.is_warmup_needed():
             return False
@@ -371,6 +386,7 @@ class Agent57LightEngine:
         self.learner.after_update()
         return True
 
+    @_miopen_find
     def capture_graphs(self, warm_updates: int = 3):
         """The whole update (sampling, gathers, four forward/backward passes, four fused Adam steps, priority write-back) as ONE HIP graph:
         eager it is ~400 small launches and the host is the bottleneck (7.9 ms per update at B = 32).  Call once the replay is warm."""

@@ -72,6 +72,10 @@ int srlx_per_destroy(srlx_per_t *h);
 /* switch the duplicate rule of later srlx_per_sample calls (the shim completes a batch WITH duplicates when a has_duplicate=False draw
  * cannot be satisfied: the reference does the same after 9999 tries per draw, proportional_memory.py:146-158) */
 int srlx_per_set_has_duplicate(srlx_per_t *h, int has_duplicate);
+/* d_counter (device int64, caller-owned, NULL to switch off): every device-side srlx_per_update call adds 1 to it -- the learner's
+ * train_count (trainer.py: `self.train_count += 1` after the priority write-back, model_torch.py:113-122) kept on the device without
+ * a launch of its own.  Launches queued after the update see the new value. */
+int srlx_per_set_update_counter(srlx_per_t *h, int64_t *d_counter);
 int srlx_per_clear(srlx_per_t *h, void *stream);
 /* length() (:117-118).  Host mirror; exact as long as adds go through srlx_per_add. */
 int64_t srlx_per_length(const srlx_per_t *h);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "srlx_per_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_f64, c_f64, c_f64, c_int, c_f64, c_int]),
     "srlx_per_destroy": (c_int, [c_p]),
     "srlx_per_set_has_duplicate": (c_int, [c_p, c_int]),
+    "srlx_per_set_update_counter": (c_int, [c_p, c_p]),
     "srlx_per_clear": (c_int, [c_p, c_p]),
     "srlx_per_length": (c_i64, [c_p]),
     "srlx_per_capacity": (c_i64, [c_p]),

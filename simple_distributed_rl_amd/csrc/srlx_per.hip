@@ -672,8 +672,9 @@ __device__ __forceinline__ bool is_ancestor(i64 a, int da, i64 x, int dx) {
 
 __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i64 n,
                                                           const i64 *indices, const void *prio, int kind, double eps,
-                                                          double alpha, int *err_flag) {
+                                                          double alpha, int *err_flag, i64 *bump) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (bump && threadIdx.x == 0) *bump += 1;  // srlx_per_set_update_counter: the caller's count of priority write-backs (read by later launches only)
     double *s_p = reinterpret_cast<double *>(smem);
     double *s_chg = s_p + n;
     double *red = s_chg + n;                                    // blockDim doubles
@@ -952,6 +953,7 @@ struct srlx_per {
     i64 tiles_cap;
     PerState *d_state;
     int *d_err;
+    i64 *d_update_counter;  // BORROWED (srlx_per_set_update_counter) or NULL
     i64 size, write;  // host mirror
     srlx::Arena scratch;  // device
     srlx::Arena staging;  // device copies of host-mode arguments / results
@@ -1000,7 +1002,7 @@ int launch_update(srlx_per *h, i64 n, const i64 *d_idx, const void *d_prio, int 
         const size_t lds = (size_t)m * (8 + 8 + 8 + 4) + (size_t)threads * 8 + 16;
         hipLaunchKernelGGL(k_update_wg, dim3(1), dim3(threads), lds, st, h->tree, h->d_state, m,
                            d_idx + off, (const void *)((const char *)d_prio + (size_t)off * eb), kind, h->epsilon,
-                           h->alpha, h->d_err);
+                           h->alpha, h->d_err, off + m >= n ? h->d_update_counter : nullptr);
     }
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
@@ -1173,6 +1175,12 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
 int srlx_per_set_has_duplicate(srlx_per_t *h, int has_duplicate) {
     SRLX_REQUIRE(h, "per_set_has_duplicate: NULL handle");
     h->has_duplicate = has_duplicate ? 1 : 0;
+    return SRLX_OK;
+}
+
+int srlx_per_set_update_counter(srlx_per_t *h, int64_t *d_counter) {
+    SRLX_REQUIRE(h, "per_set_update_counter: NULL handle");
+    h->d_update_counter = d_counter;
     return SRLX_OK;
 }
 

@@ -27,7 +27,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kFcSplits = 16;   // splits of the hidden dimension in the dense data-gradient
 constexpr int kWgSplits = 64;   // partial tensors of a conv weight gradient: one per sample (max_train <= 64)
-constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad;
+constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad, kC1Chunks = 4;  // conv1 weight gradient: pixel chunks per (sample, frame)
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float byte_to_unit(unsigned b) {  // u8 / 255, correctly rounded (see srlx_qnet.hip)
@@ -392,11 +392,11 @@ __global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int
 }
 
 // ---- conv1 weight gradient straight from the uint8 ring, on the matrix cores ------------------------------------
-//   part[b, half][co][c*64 + ky*8 + kx] = sum over the half's pixels p of dY1[b][p][co] * frame_c[4 oy + ky - 3][4 ox + kx - 3] / 255
-// workgroup = (sample, frame c of the window, half of the output pixels): one padded 88 x 88 uint8 frame, the half's dY rows
+//   part[b, chunk][co][c*64 + ky*8 + kx] = sum over the chunk's pixels p of dY1[b][p][co] * frame_c[4 oy + ky - 3][4 ox + kx - 3] / 255
+// workgroup = (sample, frame c of the window, quarter of the output pixels): one padded 88 x 88 uint8 frame, the chunk's dY rows
 // and a pixel -> window-origin table in LDS.  The product is a 32 (co) x 64 (taps of frame c) x pixels GEMM: wave (tt, ph)
 // owns taps ky in [4 tt, 4 tt + 4) and the pixel pairs jj = ph mod 2; per MFMA a lane reads one dY value, one table entry and
-// one byte.  The two pixel interleaves are added through LDS (ph order), so a sample leaves 2 partial tensors, not 8.
+// one byte.  The two pixel interleaves are added through LDS (ph order): a sample leaves 4 partial tensors.
 __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, i64 sstride, int Wn, int H, int W,
                                                           int OH, int OW, int per, const float *__restrict__ dY1, float *__restrict__ part,
                                                           float *__restrict__ bias_part) {
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
     float *red = sy + (size_t)per * 32;                                      // [2][16][64]
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
     const i64 b = blockIdx.x;
-    const int c = blockIdx.y >> 1, half = blockIdx.y & 1;
+    const int c = blockIdx.y / kC1Chunks, half = blockIdx.y % kC1Chunks;  // (`half`: the pixel chunk)
     const int M = OH * OW, p_lo = half * per, cnt = (p_lo + per < M ? p_lo + per : M) - p_lo;
     {
         const i64 off = frame_off[b * sstride * Wn + c];
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
         if (t < 32) {
             float tot = red[t];
             for (int q = 1; q < 8; q++) tot += red[q * 32 + t];
-            bias_part[((i64)b * 2 + half) * 32 + t] = tot;
+            bias_part[((i64)b * kC1Chunks + half) * 32 + t] = tot;
         }
         __syncthreads();
     }
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int co = (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout: row = output channel, column = tap
-            part[(((i64)b * 2 + half) * 32 + co) * K + c * 64 + tt * 32 + i] = acc[r] + red[(tt * 16 + r) * 64 + lane];
+            part[(((i64)b * kC1Chunks + half) * 32 + co) * K + c * 64 + tt * 32 + i] = acc[r] + red[(tt * 16 + r) * 64 + lane];
         }
     }
 }
@@ -479,8 +479,8 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
     SRLX_REQUIRE(h->max_train == 0, "qnet_enable_training: already enabled with a smaller batch");
     srlx::DeviceGuard guard(h->device);
     const int N1 = 2 * h->hidden;
-    const size_t c3 = (size_t)2 * h->F1 * 9 * 2 * h->F1, c2 = (size_t)2 * h->F1 * 16 * h->F1, c1 = (size_t)max_train_batch * 2 * 32 * h->Wn * 64;
-    const size_t wp = kWgSplits * (c3 > c2 ? c3 : c2) + c1;  // [conv2 / conv3 splits][conv1 (sample, half) parts]
+    const size_t c3 = (size_t)2 * h->F1 * 9 * 2 * h->F1, c2 = (size_t)2 * h->F1 * 16 * h->F1, c1 = (size_t)max_train_batch * kC1Chunks * 32 * h->Wn * 64;
+    const size_t wp = kWgSplits * (c3 > c2 ? c3 : c2) + c1;  // [conv2 / conv3 per-sample parts][conv1 (sample, pixel chunk) parts]
     h->w_part_floats = wp;
     struct {
         float **p;
@@ -497,7 +497,7 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
                                                              : (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1) + 128 * 64},
                 {&h->w_t, c3},
                 {&h->w_t2, c2},
-                {&h->w_part, wp + 64 + 2 * kWgSplits * 64 + 64 * 2 * 32}};  // + bias partials: [splits][64] conv2/conv3 (x2), [sample, half][32] conv1
+                {&h->w_part, wp + 64 + 2 * kWgSplits * 64 + 64 * kC1Chunks * 32}};  // + bias partials: [sample][64] conv2/conv3 (x2), [sample, chunk][32] conv1
     for (auto &b : bufs) {
         hipError_t e = hipMalloc((void **)b.p, b.n * sizeof(float));
         if (e != hipSuccess) {
@@ -506,8 +506,9 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
         }
     }
     // the weight-gradient branch of the backward pass runs on its own stream, forked from / joined to the caller's
-    // (one side stream, default priority: more streams, or priorities on them, spread the learner over more hardware queues than
-    // the command processor serves at once -- measured 2x slower updates)
+    // (one side stream, created WITHOUT a priority: a second side stream, or hipStreamCreateWithPriority at either end of the range,
+    // changes which hardware queues the learner's branches land on -- measured: the update then no longer overlaps the actors' pass
+    // at all (0.84 instead of 0.755 ms per lock-step); GPU_MAX_HW_QUEUES above the default 4 triples the update's own time)
     SRLX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     for (hipEvent_t *e : {&h->ev_fork, &h->ev_d3, &h->ev_d2, &h->ev_d1, &h->ev_join, &h->ev_wt})
         SRLX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -598,7 +599,8 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
         hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, 2, QH, QW, h->dxpad, h->act1, h->dact1);
     }
     SRLX_HIP(hipEventRecord(h->ev_d1, st));
-    // ---- weight gradients of conv3, the first dense layer and conv2 (side stream)
+    // ---- weight gradients of conv3, conv2 and the first dense layer (side stream).  The dense layer's comes last: with Adam in its
+    // epilogue it streams 160 MB, and beside the data-gradient chain it tripled the duration of that chain's pad-fold kernels
     const dim3 fg((unsigned)((K / 32 + 3) / 4), (unsigned)(N1 / 32));  // one wave per 32 x 32 tile of the weight
     if (!h->adam_m)
         hipLaunchKernelGGL(k_fc1_wgrad<false>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr);
@@ -606,23 +608,25 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
     hipLaunchKernelGGL(k_conv_wgrad_mfma<64>, dim3((9 * 2 * 2 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g3, ss, h->act2, h->dact3, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 63) / 64)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
-    if (h->adam_m)  // Adam in the epilogue updates the weights in place: after ev_d3, when the data gradient has read them
-        hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
-                           h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
     hipLaunchKernelGGL(k_conv_wgrad_mfma<32>, dim3((16 * 2 * 1 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g2, ss, h->act1, h->dact2, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 63) / 64)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2);
+    if (h->adam_m)  // Adam in the epilogue updates the weights in place: (long) after ev_d3, when the data gradient has read them
+        hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
+                           h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
     SRLX_HIP(hipEventRecord(h->ev_join, sd));
     // conv1's weight gradient needs the END of the data-gradient chain: it follows it on the caller's stream instead of queueing behind
     // the conv2 / conv3 weight gradients on the side stream
-    const int per = ((h->OH1 * h->OW1 + 1) / 2 + 1) & ~1;  // output pixels per half, even (the MFMA consumes pixel pairs)
+    // output pixels per chunk, even (the MFMA consumes pixel pairs); four chunks keep the workgroup's LDS (31 KB for 84 x 84 frames) under the
+    // 33 KB a CU has left beside one of the actors' convolution workgroups -- with two (45 KB) the kernel took 65 us in the loop, 20 alone
+    const int per = ((h->OH1 * h->OW1 + kC1Chunks - 1) / kC1Chunks + 1) & ~1;
     const size_t lds = (size_t)kC1Frame + (size_t)per * 4 + (size_t)per * 32 * sizeof(float) + 2 * 16 * 64 * sizeof(float);
     SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
     float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
-    hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(2 * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
+    hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(kC1Chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
                        h->dact1, c1_part, c1_bias);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 63) / 64)), dim3(256), 0, st, c1_part, 2 * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 63) / 64)), dim3(256), 0, st, c1_part, kC1Chunks * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     // NoisyLinear: d loss / d sigma = d loss / d W_effective * eps of the draw the forward used (regenerated, not stored)
     SRLX_TRY(srlx_qnet_noisy_sigma_grads(h, g, st));

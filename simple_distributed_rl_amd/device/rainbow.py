@@ -170,6 +170,7 @@ class RainbowEngine:
         self._commit_graph = None
         d = self.dev
         self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
+        self.replay.count_updates_in(self.train_count_dev)  # train_count += 1 rides on the priority write-back's launch
         if self.mfma_train and not self.noisy and os.environ.get("SRLX_NO_FUSED_ADAM", "0") != "1":
             # the 32 MB first dense layer takes its Adam step inside the backward pass, beside the convolution gradients (A/B switch for measurements)
             self.optimizer.fuse_first_dense(self.inf_online, self.train_count_dev)
@@ -327,8 +328,7 @@ class RainbowEngine:
             self.optimizer.zero_grad(set_to_none=False)
             q0.backward(self.grad_q0)  # model_torch.py:107-109: d loss / d q seeds autograd
             self.optimizer.step()
-        r.update(b.indices, self.priorities)  # model_torch.py:113-114
-        self.train_count_dev.add_(1)
+        r.update(b.indices, self.priorities)  # model_torch.py:113-114; train_count_dev += 1 in the same launch (count_updates_in)
 
     def learner_step(self) -> bool:
         """Returns False while the replay is below warm-up (priority_replay_buffer.py:228-230)."""

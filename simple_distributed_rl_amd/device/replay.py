@@ -197,6 +197,11 @@ class DeviceReplay:
             N.check(self.lib.srlx_store_gather_obs(self.h_store, self.B, 0, 1, N.tptr(self.obs0), st))
         return b
 
+    def count_updates_in(self, counter: torch.Tensor):
+        """Every later `update()` also adds 1 to `counter` (int64 device scalar): srlx_per_set_update_counter."""
+        self._update_counter = counter  # keeps it alive
+        N.check(self.lib.srlx_per_set_update_counter(self.h_per, N.tptr(counter)))
+
     def update(self, indices: torch.Tensor, priorities: torch.Tensor):
         """float32 |td| priorities, transformed on the device like numpy would (proportional_memory.py:172)."""
         N.check(self.lib.srlx_per_update(self.h_per, indices.numel(), N.tptr(indices), N.tptr(priorities), N.PRIO_F32, 1, N.torch_stream_ptr()))

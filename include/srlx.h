@@ -101,6 +101,11 @@ int srlx_per_add(srlx_per_t *h, int64_t n, const void *prio, int prio_kind, int 
 int srlx_per_sample(srlx_per_t *h, int64_t batch_size, int64_t step, const int64_t *d_step, const double *uniforms,
                     int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used,
                     int on_device, void *stream);
+/* The learner's call without the launch that draws its uniforms: uniform j is what srlx_rng_uniform(seed, d_counter, n_uniforms, u)
+ * would have put into u[j], and *d_counter advances the same way -- results identical to that call followed by
+ * srlx_per_sample(..., u, n_uniforms, ..., on_device = 1).  Device pointers only; n_uniforms within the single-workgroup sampler's range. */
+int srlx_per_sample_keyed(srlx_per_t *h, int64_t batch_size, const int64_t *d_step, uint64_t seed, int64_t *d_counter, int64_t n_uniforms,
+                          int64_t *d_out_idx, double *d_out_w, float *d_out_w32, int64_t *d_out_used, void *stream);
 
 /* update()  (:171-177, SumTree.update :81-86).  indices are tree indices from sample();
  * duplicates inside one call see each other's writes in list order, as in the reference. */

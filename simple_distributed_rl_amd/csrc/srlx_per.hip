@@ -193,7 +193,9 @@ struct SampleArgs {
     i64 step;
     const i64 *d_step;
     int has_duplicate;
-    const double *uniforms;
+    const double *uniforms;  // NULL: uniform j = u53(rng_u64(key_seed, *key_counter, j)), and the call advances *key_counter (srlx_per_sample_keyed)
+    u64 key_seed;
+    i64 *key_counter;
     i64 n_uniforms;
     i64 batch;
     // scratch
@@ -224,14 +226,17 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
     const double total = a.tr.T[kRootSlot];  // :135 (root)
 
     // phase 1: one descent per uniform (coalesced uniform reads, strided assignment)
+    const u64 kc = a.uniforms ? 0 : (u64)a.key_counter[0];
     for (i64 j = t; j < M; j += T) {
         i64 idx;
         double p;
-        descend(a.tr, a.uniforms[j] * total, idx, p);  // :147-148
+        const double u = a.uniforms ? a.uniforms[j] : srlx::u53(srlx::rng_u64(a.key_seed, kc, (u64)j));
+        descend(a.tr, u * total, idx, p);  // :147-148
         a.cand_idx[j] = idx;
         a.cand_p[j] = p;
     }
     __syncthreads();
+    if (!a.uniforms && t == 0) a.key_counter[0] = (i64)kc + 1;  // like srlx_rng_uniform: one counter value per call (every thread has read it)
 
     // phase 2: acceptance.  A draw is rejected if its leaf priority is 0 (:150-152) or, without
     // duplicates, if an earlier non-zero draw already produced the same leaf (:155-156).
@@ -1018,7 +1023,7 @@ struct SampleScratch {
 };
 
 int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double *d_u, i64 M, i64 *d_idx, double *d_w,
-                  float *d_w32, i64 *d_used, hipStream_t st) {
+                  float *d_w32, i64 *d_used, hipStream_t st, u64 key_seed = 0, i64 *key_counter = nullptr) {
     const bool bulk = M > kSmallSampleMax;
     SRLX_TRY(h->scratch.reserve(SampleScratch::bytes(M, B, bulk)));
     srlx::Carver cv(h->scratch.ptr);
@@ -1031,6 +1036,8 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
     a.d_step = d_step;
     a.has_duplicate = h->has_duplicate;
     a.uniforms = d_u;
+    a.key_seed = key_seed;
+    a.key_counter = key_counter;
     a.n_uniforms = M;
     a.batch = B;
     a.out_idx = d_idx;
@@ -1296,6 +1303,17 @@ int srlx_per_sample(srlx_per_t *h, int64_t batch_size, int64_t step, const int64
     if (out_w) memcpy(out_w, h_w, (size_t)batch_size * 8);
     if (out_w32) memcpy(out_w32, h_w32, (size_t)batch_size * 4);
     return SRLX_OK;
+}
+
+int srlx_per_sample_keyed(srlx_per_t *h, int64_t batch_size, const int64_t *d_step, uint64_t seed, int64_t *d_counter, int64_t n_uniforms,
+                          int64_t *d_out_idx, double *d_out_w, float *d_out_w32, int64_t *d_out_used, void *stream) {
+    SRLX_REQUIRE(h, "per_sample_keyed: NULL handle");
+    SRLX_REQUIRE(batch_size > 0 && n_uniforms >= batch_size, "per_sample_keyed: need at least batch_size uniforms (%lld < %lld)", (long long)n_uniforms,
+                 (long long)batch_size);
+    SRLX_REQUIRE(n_uniforms <= kSmallSampleMax, "per_sample_keyed: at most %lld uniforms per call (the single-workgroup sampler)", (long long)kSmallSampleMax);
+    SRLX_REQUIRE(d_step && d_counter && d_out_idx && d_out_used, "per_sample_keyed: NULL argument");
+    srlx::DeviceGuard guard(h->device);
+    return launch_sample(h, batch_size, 0, d_step, nullptr, n_uniforms, d_out_idx, d_out_w, d_out_w32, d_out_used, pick_stream(h, stream), seed, d_counter);
 }
 
 int srlx_per_update(srlx_per_t *h, int64_t n, const int64_t *indices, const void *prio, int prio_kind, int on_device,

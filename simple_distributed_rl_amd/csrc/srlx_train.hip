@@ -227,31 +227,48 @@ __global__ void __launch_bounds__(256) k_adam(AdamTable tb, double lr, double be
     const i64 n = tb.n[ti];
     float *p = tb.p[ti] + off, *m = tb.m[ti] + off, *v = tb.v[ti] + off;
     const float *g = tb.g[ti] + off;
-    const srlx::AdamCoef c = srlx::adam_coef(lr, beta1, beta2, eps, *d_step);
     const i64 left = n - off;
     const int cnt = left < kAdamChunk ? (int)left : kAdamChunk;
     const int t = threadIdx.x;
+    // Every load of the kernel -- the step count included -- is issued before anything is computed: one memory round trip per launch
+    // instead of two (inside the lock-step loop a round trip costs this kernel more than its arithmetic).
     if (cnt == kAdamChunk) {  // chunks start at multiples of 4096 floats of a 16-byte aligned tensor
+        constexpr int R = kAdamChunk / (256 * 4);
+        float4 pp[R], mm[R], vv[R], gg[R];
 #pragma unroll
-        for (int r = 0; r < kAdamChunk / (256 * 4); r++) {
+        for (int r = 0; r < R; r++) {
             const int k = (r * 256 + t) * 4;
-            float4 pp = *reinterpret_cast<float4 *>(p + k), mm = *reinterpret_cast<float4 *>(m + k), vv = *reinterpret_cast<float4 *>(v + k);
-            const float4 gg = *reinterpret_cast<const float4 *>(g + k);
-            srlx::adam_one(pp.x, gg.x, mm.x, vv.x, c);
-            srlx::adam_one(pp.y, gg.y, mm.y, vv.y, c);
-            srlx::adam_one(pp.z, gg.z, mm.z, vv.z, c);
-            srlx::adam_one(pp.w, gg.w, mm.w, vv.w, c);
-            *reinterpret_cast<float4 *>(p + k) = pp;
-            *reinterpret_cast<float4 *>(m + k) = mm;
-            *reinterpret_cast<float4 *>(v + k) = vv;
+            pp[r] = *reinterpret_cast<float4 *>(p + k), mm[r] = *reinterpret_cast<float4 *>(m + k), vv[r] = *reinterpret_cast<float4 *>(v + k);
+            gg[r] = *reinterpret_cast<const float4 *>(g + k);
+        }
+        const srlx::AdamCoef c = srlx::adam_coef(lr, beta1, beta2, eps, *d_step);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int k = (r * 256 + t) * 4;
+            srlx::adam_one(pp[r].x, gg[r].x, mm[r].x, vv[r].x, c);
+            srlx::adam_one(pp[r].y, gg[r].y, mm[r].y, vv[r].y, c);
+            srlx::adam_one(pp[r].z, gg[r].z, mm[r].z, vv[r].z, c);
+            srlx::adam_one(pp[r].w, gg[r].w, mm[r].w, vv[r].w, c);
+            *reinterpret_cast<float4 *>(p + k) = pp[r];
+            *reinterpret_cast<float4 *>(m + k) = mm[r];
+            *reinterpret_cast<float4 *>(v + k) = vv[r];
         }
     } else {
-        for (int k = t; k < cnt; k += 256) {
-            float pp = p[k], mm = m[k], vv = v[k];
-            srlx::adam_one(pp, g[k], mm, vv, c);
-            p[k] = pp;
-            m[k] = mm;
-            v[k] = vv;
+        constexpr int R = kAdamChunk / 256;
+        float pp[R], mm[R], vv[R], gg[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int k = r * 256 + t;
+            if (k < cnt) pp[r] = p[k], mm[r] = m[k], vv[r] = v[k], gg[r] = g[k];
+        }
+        const srlx::AdamCoef c = srlx::adam_coef(lr, beta1, beta2, eps, *d_step);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int k = r * 256 + t;
+            if (k < cnt) {
+                srlx::adam_one(pp[r], gg[r], mm[r], vv[r], c);
+                p[k] = pp[r], m[k] = mm[r], v[k] = vv[r];
+            }
         }
     }
 }

@@ -8,6 +8,7 @@ host: every method only enqueues kernels on torch's current stream and works on 
 whole actor or learner step can be captured in a HIP graph.
 """
 import ctypes
+from typing import Optional
 from dataclasses import dataclass
 
 import torch
@@ -142,19 +143,23 @@ class DeviceReplay:
         return self.length() < self.warmup_size
 
     # ---- learner side -------------------------------------------------------------------------
+    def _draw(self, d_step: torch.Tensor, uniforms: Optional[torch.Tensor], st):
+        """B indices + IS weights into `self.batch`.  Without explicit uniforms the sampler generates them itself from the keyed counter
+        generator (srlx_per_sample_keyed: the values srlx_rng_uniform would have written for this seed and counter, one launch less)."""
+        b = self.batch
+        if uniforms is None:
+            N.check(self.lib.srlx_per_sample_keyed(self.h_per, self.B, N.tptr(d_step), self.seed ^ 0x5EED, N.tptr(self.rng_counter), self.u.numel(), N.tptr(b.indices),
+                                                   None, N.tptr(b.weights), N.tptr(self.used), st))
+        else:
+            N.check(self.lib.srlx_per_sample(self.h_per, self.B, 0, N.tptr(d_step), N.tptr(uniforms), uniforms.numel(), N.tptr(b.indices), None, N.tptr(b.weights),
+                                             N.tptr(self.used), 1, st))
+
     def sample(self, d_step: torch.Tensor, uniforms: torch.Tensor = None) -> ReplayBatch:
         """PER sample of B items + gather of their n-step windows.  `d_step` is the device int64 train
         count feeding the beta schedule.  Uniforms come from the counter RNG unless given."""
         st = N.torch_stream_ptr()
         b = self.batch
-        if uniforms is None:
-            N.check(self.lib.srlx_rng_uniform(self.seed ^ 0x5EED, N.tptr(self.rng_counter), self.u.numel(), N.tptr(self.u), st))
-            uniforms = self.u
-        N.check(
-            self.lib.srlx_per_sample(
-                self.h_per, self.B, 0, N.tptr(d_step), N.tptr(uniforms), uniforms.numel(), N.tptr(b.indices), None, N.tptr(b.weights), N.tptr(self.used), 1, st
-            )
-        )
+        self._draw(d_step, uniforms, st)
         N.check(
             self.lib.srlx_store_gather_nstep(
                 self.h_store, self.B, N.tptr(b.indices), N.tptr(b.obs), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
@@ -173,14 +178,7 @@ class DeviceReplay:
         all_states=True (hand-written training pass): the table of s_0..s_n (`frame_off_all`) instead of the pixels."""
         st = N.torch_stream_ptr()
         b = self.batch
-        if uniforms is None:
-            N.check(self.lib.srlx_rng_uniform(self.seed ^ 0x5EED, N.tptr(self.rng_counter), self.u.numel(), N.tptr(self.u), st))
-            uniforms = self.u
-        N.check(
-            self.lib.srlx_per_sample(
-                self.h_per, self.B, 0, N.tptr(d_step), N.tptr(uniforms), uniforms.numel(), N.tptr(b.indices), None, N.tptr(b.weights), N.tptr(self.used), 1, st
-            )
-        )
+        self._draw(d_step, uniforms, st)
         if all_states:  # item location, n-step scalars and both offset tables (s_0..s_n, s_1..s_n) in one launch
             N.check(
                 self.lib.srlx_store_gather_train(

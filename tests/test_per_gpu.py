@@ -538,3 +538,49 @@ def test_no_duplicate_sampling_with_too_few_leaves_completes_like_the_reference(
         m.add(("item", i), 1.0)
     _, _, idx = m.sample(16, 0)
     assert len(set(idx)) == 16
+
+
+@pytest.mark.parametrize("has_duplicate", [True, False])
+def test_keyed_sample_and_update_counter_equal_the_separate_launches(has_duplicate):
+    """srlx_per_sample_keyed = srlx_rng_uniform + srlx_per_sample (same indices, weights, consumed uniforms, counter) -- also
+    with zero-priority and duplicate rejects; srlx_per_set_update_counter: every device-side update adds one."""
+    import torch
+
+    N = _N()
+    lib = N.lib()
+    dev = torch.device("cuda:0")
+    per = AbiPER(300, 0.7, 0.4, 1000, has_duplicate, 1e-4)
+    rng = np.random.default_rng(5)
+    vals = rng.random(300)
+    vals[rng.random(300) < 0.3] = 0.0  # zero-priority leaves: rejected draws
+    N.check(lib.srlx_per_add(per.h, 300, N.np_ptr(vals), N.PRIO_RAW, 0, None))
+    B, M, seed = 32, 96, 0xABCDEF
+    step = torch.tensor([17], dtype=torch.int64, device=dev)
+    c_a, c_b = torch.tensor([5], dtype=torch.int64, device=dev), torch.tensor([5], dtype=torch.int64, device=dev)
+    u = torch.zeros(M, dtype=torch.float64, device=dev)
+    out = []
+    for rounds in range(3):
+        ia, wa, wa32, ua = (torch.zeros(B, dtype=torch.int64, device=dev), torch.zeros(B, dtype=torch.float64, device=dev),
+                            torch.zeros(B, dtype=torch.float32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
+        ib, wb, wb32, ub = torch.zeros_like(ia), torch.zeros_like(wa), torch.zeros_like(wa32), torch.zeros_like(ua)
+        N.check(lib.srlx_rng_uniform(seed, N.tptr(c_a), M, N.tptr(u), None))
+        N.check(lib.srlx_per_sample(per.h, B, 0, N.tptr(step), N.tptr(u), M, N.tptr(ia), N.tptr(wa), N.tptr(wa32), N.tptr(ua), 1, None))
+        N.check(lib.srlx_per_sample_keyed(per.h, B, N.tptr(step), seed, N.tptr(c_b), M, N.tptr(ib), N.tptr(wb), N.tptr(wb32), N.tptr(ub), None))
+        torch.cuda.synchronize()
+        assert int(ua) > 0 and torch.equal(ua, ub) and torch.equal(c_a, c_b) and int(c_a) == 6 + rounds
+        assert torch.equal(ia, ib) and torch.equal(wa, wb) and torch.equal(wa32, wb32)
+        out.append(ia.cpu().numpy().copy())
+    assert not np.array_equal(out[0], out[1])  # the counter moved: fresh uniforms every call
+    if not has_duplicate:
+        assert all(len(set(o.tolist())) == B for o in out)
+    count = torch.tensor([40], dtype=torch.int64, device=dev)
+    N.check(lib.srlx_per_set_update_counter(per.h, N.tptr(count)))
+    pri = torch.rand(B, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        N.check(lib.srlx_per_update(per.h, B, N.tptr(ib), N.tptr(pri), N.PRIO_F32, 1, None))
+    torch.cuda.synchronize()
+    assert int(count) == 43
+    N.check(lib.srlx_per_set_update_counter(per.h, None))
+    N.check(lib.srlx_per_update(per.h, B, N.tptr(ib), N.tptr(pri), N.PRIO_F32, 1, None))
+    torch.cuda.synchronize()
+    assert int(count) == 43

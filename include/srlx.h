@@ -459,6 +459,14 @@ int srlx_qnet_fuse_adam_fc1(srlx_qnet_t *h, float *d_exp_avg, float *d_exp_avg_s
                             const int64_t *d_steps_taken);
 int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off,
                           const float *d_grad_q, float *const *d_grads, void *stream);
+/* srlx_nstep_td_huber_priority_packed + srlx_qnet_backward_u8 in one call (one launch less on the learner's chain): the head kernel of
+ * the backward pass evaluates the TD target / Huber loss / gradient seed / priorities itself (arguments and results as in
+ * srlx_nstep_td_huber_priority_packed, bit-equal; d_q_on_all = the [batch][n_step+1][n_actions] output of the LAST forward on this handle,
+ * i.e. sample_stride = n_step + 1) and back-propagates that seed. */
+int srlx_qnet_backward_td_u8(srlx_qnet_t *h, int64_t batch, int n_step, const uint8_t *d_frame_base, const int64_t *d_frame_off, const float *d_q_on_all,
+                             const float *d_q_tg_next, const int32_t *d_actions, const float *d_rewards, const float *d_terminated,
+                             const uint8_t *d_invalid_next, const float *d_weights, double discount, double retrace_h, int enable_double_dqn,
+                             int enable_rescale, float *d_target, float *d_loss, float *d_grad_q0, float *d_priorities, float *const *d_grads, void *stream);
 int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream);
 
 /* NoisyLinear dense layers (replaces srl/rl/torch_/modules/noisy_linear.py:26-52, the dense layers of the reference's

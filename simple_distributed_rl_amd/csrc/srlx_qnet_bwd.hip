@@ -18,6 +18,7 @@
 
 #include "srlx_adam_math.h"
 #include "srlx_qnet_int.h"
+#include "srlx_td_math.h"
 
 namespace {
 
@@ -41,12 +42,35 @@ __device__ __forceinline__ float byte_to_unit(unsigned b) {  // u8 / 255, correc
 // dependent chain over the batch is a quarter as long, the four partial sums are combined in slice order.
 // dq [B][A] is dense, h1 rows at i*sample_stride.
 template <int AMAX>
-__global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden, int A, int dueling, const float *__restrict__ dq,
+__global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden, int A, int dueling, const float *dq,
                                                    const float *__restrict__ h1, const float *__restrict__ v2w, const float *__restrict__ a2w,
                                                    float *__restrict__ dh1, float *__restrict__ dh1t /*[N1][32] or NULL*/, float *__restrict__ g_bf,
-                                                   float *__restrict__ g_v2w, float *__restrict__ g_v2b, float *__restrict__ g_a2w, float *__restrict__ g_a2b) {
-    extern __shared__ float sm[];  // dv[B], da[B][A], part[3 + AMAX][256]
+                                                   float *__restrict__ g_v2w, float *__restrict__ g_v2b, float *__restrict__ g_a2w, float *__restrict__ g_a2b,
+                                                   srlx::TdArgs td, int with_td) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // dv[B], da[B][A], part[3 + AMAX][256] (+ with_td: dq[B][A], 256 doubles)
     float *dv = sm, *da = sm + B, *part = sm + B + B * A;
+    if (with_td) {
+        // srlx_qnet_backward_td_u8: d loss / d Q is not an input -- every workgroup evaluates the TD target / Huber gradient of the
+        // B items itself (a few hundred flops per item, the same rows in the same order as k_nstep_td_huber_priority), workgroup 0 also
+        // stores target, priorities, gradient seed and the loss: one launch less on the learner's chain
+        float *sdq = part + (3 + AMAX) * 256;
+        int off = B + 2 * B * A + (3 + AMAX) * 256;
+        off += off & 1;
+        double *red = reinterpret_cast<double *>(sm + off);
+        const int t = threadIdx.x;
+        const double la = srlx::td_rows(td, t, 256, sdq, blockIdx.x == 0);
+        if (blockIdx.x == 0) {
+            red[t] = la;
+            __syncthreads();
+            for (int s = 128; s > 0; s >>= 1) {
+                if (t < s) red[t] += red[t + s];
+                __syncthreads();
+            }
+            if (t == 0) td.loss[0] = (float)(red[0] / (double)td.B);
+        }
+        __syncthreads();
+        dq = sdq;
+    }
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         float s = 0.f;
         for (int j = 0; j < A; j++) s += dq[b * A + j];
@@ -532,9 +556,10 @@ int srlx_qnet_fuse_adam_fc1(srlx_qnet_t *h, float *d_exp_avg, float *d_exp_avg_s
     return SRLX_OK;
 }
 
-int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off,
-                          const float *d_grad_q, float *const *g, void *stream) {
-    SRLX_REQUIRE(h && d_frame_base && d_frame_off && d_grad_q && g, "qnet_backward_u8: NULL argument");
+// `td` != NULL: d loss / d Q is computed by the head kernel itself (srlx_qnet_backward_td_u8), d_grad_q is not read
+static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off, const float *d_grad_q,
+                         const srlx::TdArgs *td, float *const *g, void *stream) {
+    SRLX_REQUIRE(h && d_frame_base && d_frame_off && (d_grad_q || td) && g, "qnet_backward_u8: NULL argument");
     SRLX_REQUIRE(h->max_train > 0, "qnet_backward_u8: call srlx_qnet_enable_training first");
     SRLX_REQUIRE(batch > 0 && batch <= h->max_train && sample_stride >= 1 && batch * sample_stride <= h->max_batch, "qnet_backward_u8: batch %lld x stride %lld out of range",
                  (long long)batch, (long long)sample_stride);
@@ -552,17 +577,19 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     const bool mfma_dgrad = B <= 32;  // the batch fits one 32-row MFMA tile
     {
         const dim3 hg((unsigned)((h->hidden + 63) / 64));
-        const size_t hl = (size_t)(B + B * A + (3 + (A <= 8 ? 8 : (A <= 16 ? 16 : 32))) * 256) * sizeof(float);
+        const size_t hl = (size_t)(B + B * A + (3 + (A <= 8 ? 8 : (A <= 16 ? 16 : 32))) * 256 + (td ? B * A + 2 + 512 : 0)) * sizeof(float);
         float *dh1t = mfma_dgrad ? h->dh1t : nullptr;
+        const srlx::TdArgs tda = td ? *td : srlx::TdArgs{};
+        const int with_td = td ? 1 : 0;
         if (A <= 8)
             hipLaunchKernelGGL(k_head_bwd<8>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, dh1t, g_bf, g_v2w, g_v2b, g_a2w,
-                               g_a2b);
+                               g_a2b, tda, with_td);
         else if (A <= 16)
             hipLaunchKernelGGL(k_head_bwd<16>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, dh1t, g_bf, g_v2w, g_v2b, g_a2w,
-                               g_a2b);
+                               g_a2b, tda, with_td);
         else
             hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, dh1t, g_bf, g_v2w, g_v2b, g_a2w,
-                               g_a2b);
+                               g_a2b, tda, with_td);
     }
     // Two branches from here (fork/join with events; capturable into a HIP graph): the data-gradient chain, then conv1's weight
     // gradient (which needs the end of it), stay on the caller's stream; the other weight gradients run on h->side as soon as the
@@ -632,6 +659,27 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
     SRLX_TRY(srlx_qnet_noisy_sigma_grads(h, g, st));
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
+}
+
+int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off,
+                          const float *d_grad_q, float *const *g, void *stream) {
+    SRLX_REQUIRE(d_grad_q, "qnet_backward_u8: NULL argument");
+    return backward_impl(h, batch, sample_stride, d_frame_base, d_frame_off, d_grad_q, nullptr, g, stream);
+}
+
+int srlx_qnet_backward_td_u8(srlx_qnet_t *h, int64_t batch, int n_step, const uint8_t *d_frame_base, const int64_t *d_frame_off, const float *d_q_on_all,
+                             const float *d_q_tg_next, const int32_t *d_actions, const float *d_rewards, const float *d_terminated, const uint8_t *d_invalid_next,
+                             const float *d_weights, double discount, double retrace_h, int enable_double_dqn, int enable_rescale, float *d_target, float *d_loss,
+                             float *d_grad_q0, float *d_priorities, float *const *g, void *stream) {
+    SRLX_REQUIRE(h, "qnet_backward_td_u8: NULL handle");
+    SRLX_REQUIRE(batch > 0 && batch <= 256 && n_step >= 1 && n_step <= srlx::kTdMaxStep, "qnet_backward_td_u8: bad sizes (n_step <= %d)", srlx::kTdMaxStep);
+    SRLX_REQUIRE(d_q_on_all && d_q_tg_next && d_actions && d_rewards && d_terminated && d_weights, "qnet_backward_td_u8: NULL input");
+    SRLX_REQUIRE(d_target && d_loss && d_grad_q0 && d_priorities, "qnet_backward_td_u8: NULL output");
+    const int A = h->A;
+    const int64_t row = (int64_t)(n_step + 1) * A;
+    const srlx::TdArgs td{batch, n_step, A, d_q_on_all + A, d_q_tg_next, d_q_on_all, d_actions, d_rewards, d_terminated, d_invalid_next, d_weights, discount, retrace_h,
+                          enable_double_dqn, enable_rescale, d_target, d_loss, d_grad_q0, d_priorities, row, row};
+    return backward_impl(h, batch, n_step + 1, d_frame_base, d_frame_off, nullptr, &td, g, stream);
 }
 
 }  // extern "C"

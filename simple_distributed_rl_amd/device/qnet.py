@@ -252,6 +252,16 @@ class QNetInference:
         N.check(self.lib.srlx_qnet_backward_u8(self.h, B, int(sample_stride), N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(grad_q),
                                                ctypes.cast(self._grad_arr, N.c_p), N.torch_stream_ptr()))
 
+    def backward_td_u8(self, frame_base_ptr: int, frame_off: torch.Tensor, n_step: int, q_on_all, q_tg_next, actions, rewards, terminated, weights, discount: float,
+                       retrace_h: float, double_dqn: bool, rescale: bool, target, loss, grad_q0, priorities):
+        """`srlx_nstep_td_huber_priority_packed` + `backward_u8(..., sample_stride=n_step + 1)` as one call: the backward's head kernel computes
+        the TD target / Huber loss / gradient seed / priorities of the B items in its prologue (srlx_qnet_backward_td_u8)."""
+        B = grad_q0.shape[0]
+        N.check(self.lib.srlx_qnet_backward_td_u8(self.h, B, int(n_step), N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(q_on_all), N.tptr(q_tg_next), N.tptr(actions),
+                                                  N.tptr(rewards), N.tptr(terminated), None, N.tptr(weights), float(discount), float(retrace_h), int(double_dqn),
+                                                  int(rescale), N.tptr(target), N.tptr(loss), N.tptr(grad_q0), N.tptr(priorities), ctypes.cast(self._grad_arr, N.c_p),
+                                                  N.torch_stream_ptr()))
+
     def set_probe(self, ev_start: torch.cuda.Event, ev_end: torch.cuda.Event):
         """The next forward records the two (timing-enabled, already created) events around its two conv GEMM launches."""
         N.check(self.lib.srlx_qnet_set_probe(self.h, N.c_p(ev_start.cuda_event), N.c_p(ev_end.cuda_event)))

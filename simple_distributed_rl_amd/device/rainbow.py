@@ -170,6 +170,7 @@ class RainbowEngine:
         self._commit_graph = None
         d = self.dev
         self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
+        self._fused_td = os.environ.get("SRLX_NO_FUSED_TD", "0") != "1"  # TD / Huber / priorities inside the backward's head kernel (A/B switch)
         self.replay.count_updates_in(self.train_count_dev)  # train_count += 1 rides on the priority write-back's launch
         if self.mfma_train and not self.noisy and os.environ.get("SRLX_NO_FUSED_ADAM", "0") != "1":
             # the 32 MB first dense layer takes its Adam step inside the backward pass, beside the convolution gradients (A/B switch for measurements)
@@ -301,16 +302,20 @@ class RainbowEngine:
                 self.inf_online.redraw_rows(B, n + 1, out=q_all)
             q_all = q_all.view(B, n + 1, A)
             cur.wait_event(self._ev_t1)  # join before the TD kernel
-            # rainbow.py:220 + model_torch.py:103: the TD kernel reads s_0 and s_1..s_n rows straight out of the one forward
-            N.check(
-                self.lib.srlx_nstep_td_huber_priority_packed(
-                    B, n, A, N.tptr(q_all), N.tptr(q_tg_next), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), None,
-                    N.tptr(b.weights), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
-                    N.tptr(self.target), N.tptr(self.loss), N.tptr(self.grad_q0), N.tptr(self.priorities), N.torch_stream_ptr(),
-                )
-            )
+            # rainbow.py:220 + model_torch.py:103: the TD arithmetic reads s_0 and s_1..s_n rows straight out of the one forward;
             # model_torch.py:107-109 without autograd: every p.grad is (over)written by the backward kernels
-            self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
+            if self._fused_td:  # ... in the prologue of the backward's first kernel
+                self.inf_online.backward_td_u8(r.obs_base, r.frame_off_all, n, q_all, q_tg_next, b.actions, b.rewards, b.terminated, b.weights, cfg.discount,
+                                               cfg.retrace_h, cfg.enable_double_dqn, cfg.enable_rescale, self.target, self.loss, self.grad_q0, self.priorities)
+            else:
+                N.check(
+                    self.lib.srlx_nstep_td_huber_priority_packed(
+                        B, n, A, N.tptr(q_all), N.tptr(q_tg_next), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), None,
+                        N.tptr(b.weights), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
+                        N.tptr(self.target), N.tptr(self.loss), N.tptr(self.grad_q0), N.tptr(self.priorities), N.torch_stream_ptr(),
+                    )
+                )
+                self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
             self.optimizer.step(self.train_count_dev)
         else:  # SRLX_TORCH_BACKWARD=1: the test yardstick -- matrix-core evaluation of s_1..s_n, autograd for the gradient step
             b = r.sample_items(self.train_count_dev)

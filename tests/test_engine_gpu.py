@@ -11,17 +11,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _engine(torch_backward: bool, fused_adam: bool = True, **kw):
+def _engine(torch_backward: bool, fused_adam: bool = True, fused_td: bool = True, **kw):
     from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
 
     os.environ["SRLX_TORCH_BACKWARD"] = "1" if torch_backward else "0"
     os.environ["SRLX_NO_FUSED_ADAM"] = "0" if fused_adam else "1"
+    os.environ["SRLX_NO_FUSED_TD"] = "0" if fused_td else "1"
     try:
         cfg = RainbowDeviceConfig(n_envs=8, batch_size=8, memory_capacity=8 * 64, memory_warmup_size=32, target_model_update_interval=4, lr=1e-4, seed=3)
         return RainbowEngine(cfg, 0, episode_len=9, **kw)
     finally:
         os.environ.pop("SRLX_TORCH_BACKWARD", None)
         os.environ.pop("SRLX_NO_FUSED_ADAM", None)
+        os.environ.pop("SRLX_NO_FUSED_TD", None)
 
 
 def test_training_pass_equals_autograd_path():
@@ -76,6 +78,24 @@ def test_fused_first_dense_adam_is_the_same_update():
             assert torch.equal(a.optimizer.exp_avg[i], c.optimizer.exp_avg[i]) and torch.equal(a.optimizer.exp_avg_sq[i], c.optimizer.exp_avg_sq[i]), (it, i)
     assert a.train_count >= 5 and float((a.q_online.fc1.weight - w0).abs().max()) > 0
     assert float(a.optimizer.exp_avg[k].abs().max()) > 0
+
+
+def test_td_inside_the_backward_head_kernel_is_the_same_update():
+    """srlx_qnet_backward_td_u8 (TD target / Huber loss / gradient seed / priorities evaluated in the prologue of the backward's head
+    kernel: the engine's default) against srlx_nstep_td_huber_priority_packed + srlx_qnet_backward_u8: everything bit-equal."""
+    a, c = _engine(False), _engine(False, fused_td=False)
+    assert a._fused_td and not c._fused_td
+    c.q_online.load_state_dict(a.q_online.state_dict())
+    c.q_target.load_state_dict(a.q_target.state_dict())
+    for it in range(10):
+        for e in (a, c):
+            e.step(learner_updates=1)
+        torch.cuda.synchronize()
+        for name in ("target", "loss", "grad_q0", "priorities"):
+            assert torch.equal(getattr(a, name), getattr(c, name)), (it, name)
+        for i, (pa, pc) in enumerate(zip(a.optimizer.params, c.optimizer.params)):
+            assert torch.equal(pa, pc), (it, i)
+    assert a.train_count >= 5 and float(a.grad_q0.abs().max()) > 0 and float(a.priorities.max()) > 0
 
 
 def test_engine_overlap_and_graphs():

@@ -54,7 +54,7 @@ def parse_args():
                     help="N>1: does the learner rank run actors too? auto = yes below 4 GPUs, no (dedicated learner GPU) from 4")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 code path with several ranks on ONE GPU)")
     ap.add_argument("--noisy", action="store_true", help="NoisyLinear dense layers (the reference's set_atari_config: enable_noisy_dense=True)")
-    ap.add_argument("--algo", choices=("rainbow", "agent57_light"), default="rainbow",
+    ap.add_argument("--algo", choices=("rainbow", "agent57_light", "ppo"), default="rainbow",
                     help="rainbow = BASELINE.json configs[2] (the headline metric); agent57_light = the configs[3] workload (two UVFA Q-networks, NGU "
                          "intrinsic reward, per-environment UCB) on the E-environment engine")
     ap.add_argument("--dist-selftest", action="store_true", help="run the N>1 code path (DistributedRainbow, RCCL gathers/broadcasts) at world size 1")
@@ -123,6 +123,8 @@ def main():
     envs_per_gpu = args.envs if args.scaling == "weak" else max(1, args.envs // actor_ranks)
     if args.algo == "agent57_light":
         return bench_agent57_light(args, dev_index, rank, world)
+    if args.algo == "ppo":
+        return bench_ppo(args, dev_index, rank, world, dist)
     cfg = RainbowDeviceConfig(n_envs=envs_per_gpu, batch_size=args.batch_size, memory_capacity=args.capacity, seed=0, enable_noisy_dense=args.noisy)
 
     if dist is not None:
@@ -317,6 +319,87 @@ def bench_agent57_light(args, dev_index, rank, world):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes,
                      "avg_launch_ms": ms, "note": "isolated launches"},
         "final": {"loss": info.get("loss"), "train_count": info["train_count"], "memory": info["memory"]},
+    }
+    print(json.dumps(out), flush=True)
+
+
+def bench_ppo(args, dev_index, rank, world, dist):
+    """The configs[4] workload: PPO, continuous actions, Pendulum-shaped observations, E environments per GPU (default 4096), data-parallel
+    over the ranks (one flat gradient all-reduce per minibatch).  One bench step = one PPO iteration = horizon x E environment steps +
+    epochs x minibatches updates per GPU.  `roofline` = srlx_gae_scan (the fused GAE kernel), timed in isolation."""
+    import torch
+
+    from simple_distributed_rl_amd import _native as N
+    from simple_distributed_rl_amd.device.ppo import DistributedPPO, PPODeviceConfig, PPOEngine
+
+    E = args.envs if args.envs != 1024 else 4096  # (1024 is the Rainbow default of --envs; configs[4] says 4096)
+    if args.scaling == "strong":
+        E = max(1, E // world)
+    cfg = PPODeviceConfig(n_envs=E, seed=0)
+    if world > 1:
+        wrap = DistributedPPO(cfg, dev_index)
+        eng, step = wrap.engine, wrap.step
+    else:
+        eng = PPOEngine(cfg, dev_index)
+        step = eng.step
+    for _ in range(max(2, args.warmup)):
+        step()
+    if not args.no_graph and world == 1:  # (the data-parallel update calls the collective from Python between minibatches: eager)
+        eng.capture_graphs()
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}")
+        if args.backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            t = h
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    # the GAE scan in isolation: 16 B read + 8 B written per (environment, step) (SURVEY section 8d)
+    T = cfg.horizon
+    dev = torch.device(f"cuda:{dev_index}")
+    r, v, d, lv, adv = (torch.rand(T, E, device=dev), torch.rand(T, E, device=dev), (torch.rand(T, E, device=dev) < 0.01).to(torch.uint8), torch.rand(E, device=dev),
+                        torch.zeros(T, E, device=dev))
+    lib = N.lib()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 200
+    for k in range(reps + 5):
+        if k == 5:
+            a.record()
+        N.check(lib.srlx_gae_scan(E, T, N.tptr(r), N.tptr(v), N.tptr(d), N.tptr(lv), cfg.discount, cfg.gae_discount, N.tptr(adv), N.torch_stream_ptr()))
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    nbytes = T * E * 13 + 4 * E  # rewards, values (f32), done (u8) read + advantage written, + the bootstrap values
+    updates = args.steps * cfg.epochs * cfg.minibatches
+    info = eng.info()
+    out = {
+        "metric": "env-steps/sec + learner updates/sec, PPO continuous (Pendulum-shaped)", "value": args.steps * T * E * world / elapsed, "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "learner_updates_per_s": updates / elapsed,
+        "rccl_ranks": (dist.get_world_size() if dist is not None and args.backend == "nccl" else 1),
+        "config": {"workload": "PPO continuous actions on Pendulum-shaped vectorised environments (BASELINE.json configs[4]); one step = one iteration: horizon x envs "
+                               "environment steps + epochs x minibatches updates per GPU", "envs_per_gpu": E, "horizon": T, "epochs": cfg.epochs, "minibatches": cfg.minibatches,
+                   "parallelism": f"dp{world}: identical networks, disjoint environments, one flat gradient all-reduce per minibatch" if world > 1 else "single GPU",
+                   "networks": "torch MLPs (64-64 trunk, 64 value, 64 policy); libsrlx: environments, normal-policy sampling, GAE scan, PPO loss + gradient seeds",
+                   "hip_graphs": (not args.no_graph) and world == 1},
+        "roofline": {"kernel": "k_gae_scan (srlx_gae_scan: the whole [T][E] rollout in one launch)", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes, "avg_launch_ms": ms,
+                     "note": "isolated launches; 2.7 MB per launch at E = 4096, T = 32: latency-bound (the kernel is one dependent chain of T steps per environment)"},
+        "final": {k: info.get(k) for k in ("policy_loss", "value_loss", "entropy_loss")},
     }
     print(json.dumps(out), flush=True)
 

@@ -227,8 +227,16 @@ class PPOEngine:
     def step(self):
         """one PPO iteration: T x E environment steps + epochs x minibatches updates"""
         if self._rollout_graph is not None:
+            # One hipStreamSynchronize per iteration.  Measured on ROCm 7.2 / torch 2.10: with iterations of these two ~700 / ~1000-node
+            # graphs queued back to back the results depend on how far the host runs ahead and turn non-finite at E = 4096 within ten
+            # iterations; a stream (or device) synchronisation per iteration gives the eager results, waiting on an EVENT recorded after
+            # the iteration does not (so it is host-side bookkeeping of the runtime that the synchronisation advances, not a missing
+            # dependency on the GPU).  The Rainbow / Agent57_light graphs (~45 / ~400 nodes, eager launches between replays) are
+            # bit-stable over thousands of unsynchronised replays (tools/graph_replay_check.py).  Cost here: the host launches the next
+            # rollout graph with the GPU idle, ~1 ms of a 24 ms iteration.
             self._rollout_graph.replay()
             self._update_graph.replay()
+            torch.cuda.current_stream(self.dev).synchronize()
         else:
             self.rollout()
             self.update()

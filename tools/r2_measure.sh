@@ -37,6 +37,7 @@ print(json.dumps(out, indent=1))
 PY
 cd $R
 timeout 400 python bench.py --noisy --no-cpu-baseline --no-per-micro > gpurun_out/r2_bench_noisy.json 2>/dev/null; python -c "import json;d=json.loads(open('gpurun_out/r2_bench_noisy.json').read().strip().splitlines()[-1]);print('noisy', round(d['value']), d['ms_per_lock_step'], d['learner_updates_per_s'])"
+timeout 300 python bench.py --algo ppo --steps 20 > gpurun_out/r2_bench_ppo.json 2>/dev/null; python -c "import json;d=json.loads(open('gpurun_out/r2_bench_ppo.json').read().strip().splitlines()[-1]);print('ppo', round(d['value']), d['ms_per_step'], d['learner_updates_per_s'])"
 timeout 500 python bench.py --algo agent57_light --envs 1024 --capacity 200000 --steps 4 --inner 16 --warmup 1 > gpurun_out/r2_bench_agent57_light.json 2>/dev/null; python -c "import json;d=json.loads(open('gpurun_out/r2_bench_agent57_light.json').read().strip().splitlines()[-1]);print('agent57_light', round(d['value']), d['ms_per_lock_step'], d['learner_updates_per_s'])"
 # kernel timelines: one lock-step of the bench loop (actors + learner), one update of the learner alone
 bash $R/tools/_trace_loop.sh > $R/gpurun_out/r2_loop_timeline.txt 2>&1; head -3 $R/gpurun_out/r2_loop_timeline.txt

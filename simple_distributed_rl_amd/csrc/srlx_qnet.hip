@@ -266,8 +266,9 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
         Bw += blockIdx.z * zstride_w;
         C += blockIdx.z * zstride_c;
     }
-    __shared__ __attribute__((aligned(16))) float As[TBM * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+    // two LDS buffers: slab s+1 is stored while slab s is still being read by slower waves -- ONE barrier per K-slab instead of two
+    __shared__ __attribute__((aligned(16))) float As2[2][TBM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs2[2][BN * LDT];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const i64 m0 = (i64)blockIdx.x * TBM;
     const int n0 = blockIdx.y * BN;
@@ -295,15 +296,23 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
             rb[j] = n < N ? *reinterpret_cast<const float4 *>(Bw + (i64)n * K + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    if (kbeg < kend) fetch(kbeg);
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < MR; j++) *reinterpret_cast<float4 *>(&As2[buf][(lrow + 32 * j) * LDT + c4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; j++) *reinterpret_cast<float4 *>(&Bs2[buf][(lrow + 32 * j) * LDT + c4]) = rb[j];
+    };
     const int h = lane >> 5, i = lane & 31;
+    int cur = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stage(0);
+    }
+    lds_barrier();
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-#pragma unroll
-        for (int j = 0; j < MR; j++) *reinterpret_cast<float4 *>(&As[(lrow + 32 * j) * LDT + c4]) = ra[j];
-#pragma unroll
-        for (int j = 0; j < NB; j++) *reinterpret_cast<float4 *>(&Bs[(lrow + 32 * j) * LDT + c4]) = rb[j];
-        lds_barrier();
-        if (k0 + BK < kend) fetch(k0 + BK);  // overlaps with the MFMAs below
+        const bool more = k0 + BK < kend;
+        if (more) fetch(k0 + BK);  // overlaps with the MFMAs below
+        const float *As = As2[cur], *Bs = Bs2[cur];
         // fragments: lane (i, h) holds k = 16 h + s, s = 0..15, of row/column i (A and B use the same k order)
         float bf[16];
 #pragma unroll
@@ -322,7 +331,9 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
 #pragma unroll
             for (int s = 0; s < 16; s++) acc[ms] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc[ms], 0, 0, 0);
         }
+        if (more) stage(cur ^ 1);  // the other buffer: every wave left it before the barrier that ended the previous slab
         lds_barrier();
+        cur ^= 1;
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float *Cz = SPLITK ? C + (i64)blockIdx.z * M * N : C;

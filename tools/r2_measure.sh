@@ -42,3 +42,4 @@ timeout 500 python bench.py --algo agent57_light --envs 1024 --capacity 200000 -
 # kernel timelines: one lock-step of the bench loop (actors + learner), one update of the learner alone
 bash $R/tools/_trace_loop.sh > $R/gpurun_out/r2_loop_timeline.txt 2>&1; head -3 $R/gpurun_out/r2_loop_timeline.txt
 bash $R/tools/_trace_learner.sh > $R/gpurun_out/r2_learner_timeline.txt 2>&1; head -3 $R/gpurun_out/r2_learner_timeline.txt
+timeout 900 python $R/tools/graph_replay_check.py 2>&1 | grep -v "amdgpu\|Warning\|detach\|benchmark_limit" > $R/gpurun_out/r2_graph_replay_check.txt; cat $R/gpurun_out/r2_graph_replay_check.txt

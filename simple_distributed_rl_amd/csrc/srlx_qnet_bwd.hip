@@ -356,14 +356,14 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_mfma(ConvGeo g, i64 sstride,
 }
 
 // out[i] = sum_p part[p][i] for a weight gradient (n entries) and, in the same launch, its bias gradient (nb entries).
-// 64 outputs x 4 slices per workgroup: slice s adds its run of parts in order (the loads of a run are independent: up to 16 in
+// 256 outputs (64 lanes x float4) x 4 slices per workgroup: slice s adds its run of parts in order (the loads of a run are independent: up to 16 in
 // flight), the slices are then added in order -- a fixed summation order.  (256 threads, not more: a 1024-thread workgroup waits
 // for sixteen free wave slots on one CU, which beside the actors' convolution workgroups took 25 us per launch.)
 __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, int P, i64 n, float *__restrict__ out, const float *__restrict__ bpart, int nb,
                                                       float *__restrict__ bout) {
-    __shared__ float sm[4][64];
+    __shared__ float4 sm[4][64];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    i64 i = (i64)blockIdx.x * 64 + lane;
+    i64 i = ((i64)blockIdx.x * 64 + lane) * 4;  // four consecutive outputs per lane (n and nb are multiples of 4)
     const bool live = i < n + nb;
     if (i >= n) {
         i -= n;
@@ -372,13 +372,19 @@ __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ 
         out = bout;
     }
     const int per = (P + 3) / 4, p_lo = sl * per, p_hi = p_lo + per < P ? p_lo + per : P;
-    float s = 0.f;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live)
-#pragma unroll 16
-        for (int p = p_lo; p < p_hi; p++) s += part[(i64)p * n + i];
+#pragma unroll 8
+        for (int p = p_lo; p < p_hi; p++) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + (i64)p * n + i);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
     sm[sl][lane] = s;
     __syncthreads();
-    if (sl == 0 && live) out[i] = ((s + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+    if (sl == 0 && live) {
+        const float4 a = sm[1][lane], b = sm[2][lane], c = sm[3][lane];
+        *reinterpret_cast<float4 *>(out + i) = make_float4(((s.x + a.x) + b.x) + c.x, ((s.y + a.y) + b.y) + c.y, ((s.z + a.z) + b.z) + c.z, ((s.w + a.w) + b.w) + c.w);
+    }
 }
 
 // ---- convolution data gradient through replicate padding ---------------------------------------------------
@@ -398,21 +404,26 @@ __global__ void __launch_bounds__(256) k_transpose_filter(const float *__restric
 }
 
 // dX[b][iy][ix][ci] = [X > 0] * sum over the padded positions that replicate (iy, ix) of dXq[class][b][py / S][px / S][ci]
+// one thread per four channels (float4 loads / stores; CI is a multiple of 32)
 __global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int W, int CI, int P, int HP, int WP, int S, int QH, int QW,
                                                   const float *__restrict__ dxq, const float *__restrict__ X, float *__restrict__ dX) {
     // 32-bit index arithmetic: B <= 64 samples of at most 21 x 21 x 64 values (64-bit divisions cost more than the kernel's traffic)
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= (unsigned)(B * H * W * CI)) return;
-    const unsigned uci = (unsigned)CI, uw = (unsigned)W, uh = (unsigned)H;
-    const int ci = (int)(i % uci), ix = (int)((i / uci) % uw), iy = (int)((i / (uci * uw)) % uh), b = (int)(i / (uci * uw * uh));
+    const unsigned i4 = blockIdx.x * 256u + threadIdx.x;
+    const unsigned c4n = (unsigned)CI / 4u;
+    if (i4 >= (unsigned)(B * H * W) * c4n) return;
+    const unsigned uw = (unsigned)W, uh = (unsigned)H;
+    const int ci = 4 * (int)(i4 % c4n), ix = (int)((i4 / c4n) % uw), iy = (int)((i4 / (c4n * uw)) % uh), b = (int)(i4 / (c4n * uw * uh));
     const int y0 = iy == 0 ? 0 : iy + P, y1 = iy == H - 1 ? HP - 1 : iy + P;
     const int x0 = ix == 0 ? 0 : ix + P, x1 = ix == W - 1 ? WP - 1 : ix + P;
     const i64 cls_stride = (i64)B * QH * QW * CI;
-    float s = 0.f;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int py = y0; py <= y1; py++)
-        for (int px = x0; px <= x1; px++)
-            s += dxq[((py % S) * S + px % S) * cls_stride + (((i64)b * QH + py / S) * QW + px / S) * CI + ci];
-    dX[i] = X[(((i64)b * sstride * H + iy) * W + ix) * CI + ci] > 0.f ? s : 0.f;
+        for (int px = x0; px <= x1; px++) {
+            const float4 v = *reinterpret_cast<const float4 *>(dxq + ((py % S) * S + px % S) * cls_stride + (((i64)b * QH + py / S) * QW + px / S) * CI + ci);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+    const float4 x = *reinterpret_cast<const float4 *>(X + (((i64)b * sstride * H + iy) * W + ix) * CI + ci);
+    *reinterpret_cast<float4 *>(dX + (i64)i4 * 4) = make_float4(x.x > 0.f ? s.x : 0.f, x.y > 0.f ? s.y : 0.f, x.z > 0.f ? s.z : 0.f, x.w > 0.f ? s.w : 0.f);
 }
 
 // ---- conv1 weight gradient straight from the uint8 ring, on the matrix cores ------------------------------------
@@ -616,14 +627,14 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
         const int HP = h->OH2 + 2, WP = h->OW2 + 2;
         SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st));
         const i64 tot = (i64)B * h->OH2 * h->OW2 * C2;
-        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, 1, HP, WP, h->dxpad, h->act2, h->dact2);
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, 1, HP, WP, h->dxpad, h->act2, h->dact2);
     }
     SRLX_HIP(hipEventRecord(h->ev_d2, st));
     {   // conv2 (4x4 stride 2 pad 2, act1 -> act2) data gradient on the padded grid (OH1 + 4)^2, four parity classes
         const int HP = h->OH1 + 4, WP = h->OW1 + 4, QH = (HP + 1) / 2, QW = (WP + 1) / 2;
         SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact2, B, QH, QW, h->OH2, h->OW2, C2, 4, 4, 2, h->w_t2, h->F1, h->dxpad, st));
         const i64 tot = (i64)B * h->OH1 * h->OW1 * h->F1;
-        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, 2, QH, QW, h->dxpad, h->act1, h->dact1);
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, 2, QH, QW, h->dxpad, h->act1, h->dact1);
     }
     SRLX_HIP(hipEventRecord(h->ev_d1, st));
     // ---- weight gradients of conv3, conv2 and the first dense layer (side stream).  The dense layer's comes last: with Adam in its
@@ -634,11 +645,11 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
     hipLaunchKernelGGL(k_conv_wgrad_mfma<64>, dim3((9 * 2 * 2 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g3, ss, h->act2, h->dact3, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 63) / 64)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
     hipLaunchKernelGGL(k_conv_wgrad_mfma<32>, dim3((16 * 2 * 1 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g2, ss, h->act1, h->dact2, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 63) / 64)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2);
     if (h->adam_m)  // Adam in the epilogue updates the weights in place: (long) after ev_d3, when the data gradient has read them
         hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
                            h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
@@ -653,7 +664,7 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
     float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
     hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(kC1Chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
                        h->dact1, c1_part, c1_bias);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 63) / 64)), dim3(256), 0, st, c1_part, kC1Chunks * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, st, c1_part, kC1Chunks * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     // NoisyLinear: d loss / d sigma = d loss / d W_effective * eps of the draw the forward used (regenerated, not stored)
     SRLX_TRY(srlx_qnet_noisy_sigma_grads(h, g, st));

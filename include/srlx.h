@@ -432,6 +432,12 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
 int srlx_qnet_destroy(srlx_qnet_t *h);
 int srlx_qnet_bind(srlx_qnet_t *h, const float *const *d_params);
 int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, void *stream);
+/* The image block alone (DQNImageBlock, srl/rl/torch_/blocks/dqn_image_block.py:29-54: three convolutions with replicate padding + ReLU) for
+ * networks whose dense part is not the dueling head of this handle (Agent57_light's UVFA Q-networks, its embedding and RND networks,
+ * agent57_light/model_torch.py:35-64,98-131,160-193): d_features = float32 [batch][OH3*OW3][2*filters] -- the post-ReLU conv3 output in
+ * PIXEL-major order (torch's `flatten` of the NCHW tensor is channel-major: transpose the last two axes).  Only entries 0..5 of
+ * srlx_qnet_bind are read. */
+int srlx_qnet_forward_convs_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_features, void *stream);
 /* Measurement hook: the NEXT forward on this handle records the two caller-owned HIP events (hipEvent_t) on its stream right
  * before the conv2 launch and right after the conv3 launch -- the two launches of the dominant kernel k_gemm<AConv> -- so that
  * bench.py can time that kernel live, on the stream it runs on.  NULL events switch it off. */

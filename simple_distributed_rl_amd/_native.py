@@ -83,6 +83,7 @@ SIGNATURES = {
     "srlx_qnet_destroy": (c_int, [c_p]),
     "srlx_qnet_bind": (c_int, [c_p, c_p]),
     "srlx_qnet_forward_u8": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "srlx_qnet_forward_convs_u8": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     "srlx_qnet_enable_training": (c_int, [c_p, c_i64]),
     "srlx_qnet_set_probe": (c_int, [c_p, c_p, c_p]),
     "srlx_qnet_set_debug": (c_int, [c_p, c_p]),

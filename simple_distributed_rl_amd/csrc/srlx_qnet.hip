@@ -533,7 +533,7 @@ int run_tail(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
     launch_gemm<AConv, 64, true, false>(c3, h->w3, h->b3, h->act3, B * h->OH3 * h->OW3, 2 * h->F1, 9 * 2 * h->F1, 1, st);
     if (h->probe1) SRLX_HIP(hipEventRecord(h->probe1, st));
     h->probe0 = h->probe1 = nullptr;  // one forward only
-    return run_dense(h, B, d_q, st);
+    return d_q ? run_dense(h, B, d_q, st) : SRLX_OK;  // (d_q == NULL: the convolutions only, srlx_qnet_forward_convs_u8)
 }
 
 int run_dense(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
@@ -682,12 +682,8 @@ int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end) {
     return SRLX_OK;
 }
 
-int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, void *stream) {
-    SRLX_REQUIRE(h && d_frame_base && d_frame_off && d_q, "qnet_forward_u8: NULL argument");
-    SRLX_REQUIRE(h->w1, "qnet_forward_u8: no parameters bound (srlx_qnet_bind)");
-    SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_u8: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
-    srlx::DeviceGuard guard(h->device);
-    hipStream_t st = (hipStream_t)stream;
+// conv1 -> conv2 -> conv3 from the uint8 ring into h->act3, then (d_q != NULL) the dense layers
+static int forward_u8_impl(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, hipStream_t st) {
     static const bool no_fused = getenv("SRLX_NO_FUSED_CONV") && getenv("SRLX_NO_FUSED_CONV")[0] == '1';  // A/B switch for measurements
     if (!no_fused && h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32) {
         // conv1 -> conv2 -> conv3 in one kernel, one workgroup per sample, activations in LDS (srlx_qnet_fused.hip)
@@ -695,7 +691,7 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
         SRLX_REQUIRE(srlx_qnet_fused_convs(h, batch, d_frame_base, d_frame_off, st), "qnet_forward_u8: launching the fused convolution kernel failed");
         if (h->probe1) SRLX_HIP(hipEventRecord(h->probe1, st));
         h->probe0 = h->probe1 = nullptr;
-        return run_dense(h, batch, d_q, st);
+        return d_q ? run_dense(h, batch, d_q, st) : SRLX_OK;
     }
     h->wt_from_forward = false;
     const size_t lds = (size_t)h->Wn * kC1Frame;
@@ -708,6 +704,25 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
         launch_gemm<AU8, 32, true, false>(c1, h->w1, h->b1, h->act1, batch * h->OH1 * h->OW1, h->F1, h->Wn * 64, 1, st);
     }
     return run_tail(h, batch, d_q, st);
+}
+
+int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, void *stream) {
+    SRLX_REQUIRE(h && d_frame_base && d_frame_off && d_q, "qnet_forward_u8: NULL argument");
+    SRLX_REQUIRE(h->w1, "qnet_forward_u8: no parameters bound (srlx_qnet_bind)");
+    SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_u8: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
+    srlx::DeviceGuard guard(h->device);
+    return forward_u8_impl(h, batch, d_frame_base, d_frame_off, d_q, (hipStream_t)stream);
+}
+
+int srlx_qnet_forward_convs_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_features, void *stream) {
+    SRLX_REQUIRE(h && d_frame_base && d_frame_off && d_features, "qnet_forward_convs_u8: NULL argument");
+    SRLX_REQUIRE(h->w1, "qnet_forward_convs_u8: no parameters bound (srlx_qnet_bind)");
+    SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_convs_u8: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    SRLX_TRY(forward_u8_impl(h, batch, d_frame_base, d_frame_off, nullptr, st));
+    SRLX_HIP(hipMemcpyAsync(d_features, h->act3, (size_t)batch * h->flat * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return SRLX_OK;
 }
 
 int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream) {

@@ -22,6 +22,7 @@ and GEMMs run through MIOpen / hipBLASLt.  `Agent57LightLearner` is shared with 
 """
 import ctypes
 import functools
+import os
 from typing import Optional
 
 import numpy as np
@@ -33,9 +34,10 @@ from simple_distributed_rl_amd.device.replay import DeviceReplay
 from simple_distributed_rl_amd.rl import functions as funcs
 
 
-def q_values(net, state_cf, r_ext, r_int, onehot_action, onehot_actor):
-    """QNetwork.forward (agent57_light/model_torch.py:35-64) on a channels-first float32 stack."""
-    parts = [net.in_block(state_cf, channels_first=True)]
+def q_values(net, state_cf, r_ext, r_int, onehot_action, onehot_actor, features=None):
+    """QNetwork.forward (agent57_light/model_torch.py:35-64) on a channels-first float32 stack (or on `features` = the image block's
+    flattened output computed elsewhere: device/qnet.py:ImageTrunk)."""
+    parts = [net.in_block(state_cf, channels_first=True) if features is None else features]
     if net.input_ext_reward:
         parts.append(r_ext)
     if net.input_int_reward:
@@ -46,12 +48,12 @@ def q_values(net, state_cf, r_ext, r_int, onehot_action, onehot_actor):
     return net.hidden_block(torch.cat(parts, dim=1))
 
 
-def embed(net, state_cf):
-    return net.emb_block(net.in_block(state_cf, channels_first=True))
+def embed(net, state_cf, features=None):
+    return net.emb_block(net.in_block(state_cf, channels_first=True) if features is None else features)
 
 
-def rnd(net, state_cf):
-    return net.hidden_normalize(net.hidden_block(net.in_block(state_cf, channels_first=True)))
+def rnd(net, state_cf, features=None):
+    return net.hidden_normalize(net.hidden_block(net.in_block(state_cf, channels_first=True) if features is None else features))
 
 
 class UcbBank:
@@ -247,6 +249,21 @@ class Agent57LightEngine:
         self.eps_list = torch.tensor(np.array(funcs.create_epsilon_list(Na), np.float32), device=d)
         self.actor_eye, self.action_eye = self.learner.actor_eye, self.learner.action_eye
         self.ucb = UcbBank(E, Na, c.ucb_window_size, c.ucb_epsilon, c.ucb_beta, d, self.seed)
+        # The actors' five image blocks (two UVFA Q-networks, embedding, RND target / predictor) straight from the uint8 ring through libsrlx's
+        # convolution kernels (device/qnet.py:ImageTrunk) -- MIOpen's fp32 convolutions + replication-pad + layout transposes were 60 % of a
+        # lock-step; the dense parts and the whole learner stay torch.  SRLX_A57_TORCH_TRUNKS=1: the all-torch pass (A/B, tests).
+        from simple_distributed_rl_amd.device.qnet import ImageTrunk
+
+        self._trunks = {}
+        nets = {"q_ext": p.q_ext_online, "q_int": p.q_int_online}
+        if c.enable_intrinsic_reward:
+            nets.update(emb=p.emb_network, rnd_target=p.lifelong_target, rnd_train=p.lifelong_train)
+        if os.environ.get("SRLX_A57_TORCH_TRUNKS", "0") != "1":
+            for name, net in nets.items():
+                blk = getattr(getattr(net, "in_block", None), "image_block", None)
+                if blk is not None and getattr(net.in_block, "out_flatten", False) and ImageTrunk.supported(blk):
+                    self._trunks[name] = ImageTrunk(blk, shape[:2], E, device)
+        self._all_fused = len(self._trunks) == len(nets)
         self.ngu = None
         if c.enable_intrinsic_reward:
             self.ngu = NguOps(d, E, p.emb_network.emb_block.out_size, c.episodic_memory_capacity, c.episodic_count_max, c.episodic_epsilon,
@@ -287,7 +304,18 @@ class Agent57LightEngine:
     def train_count(self) -> int:
         return self.learner.train_count
 
-    def _stack(self) -> torch.Tensor:
+    def _stack(self) -> Optional[torch.Tensor]:
+        """The policy / intrinsic-reward input after a commit: the image features of every fused trunk (from the frame-offset table), and the
+        float32 stack itself only when some network still needs it."""
+        self._feat = {}
+        if self._trunks:
+            self._frame_off = self.replay.frame_table_current()  # (valid until the next commit)
+            with torch.no_grad():
+                for name, trunk in self._trunks.items():
+                    if not name.startswith("q_"):  # embedding / RND: used right away; the Q-networks' at policy time (an update may come first)
+                        self._feat[name] = trunk(self.replay.obs_base, self._frame_off)
+        if self._all_fused:
+            return None
         return self.replay.stack_current().view(self.E, self.Wn, *self.hw)
 
     def _begin_episodes(self, done: Optional[torch.Tensor]):
@@ -317,8 +345,10 @@ class Agent57LightEngine:
         p, arm = self.parameter, self.arm()
         inputs = (self.state, self.prev_r_ext.view(-1, 1), self.prev_r_int.view(-1, 1), self.action_eye[self.prev_action], self.actor_eye[arm])
         with torch.no_grad():
-            q_ext = q_values(p.q_ext_online, *inputs)
-            q_int = q_values(p.q_int_online, *inputs)
+            fe = self._trunks["q_ext"](self.replay.obs_base, self._frame_off) if "q_ext" in self._trunks else None
+            q_ext = q_values(p.q_ext_online, *inputs, features=fe)
+            fi = self._trunks["q_int"](self.replay.obs_base, self._frame_off) if "q_int" in self._trunks else None
+            q_int = q_values(p.q_int_online, *inputs, features=fi)
         beta = self.beta_list[arm] if self.training else torch.full((self.E,), float(self.cfg.test_beta), device=self.dev)
         return q_ext, q_int, (q_ext + beta.view(-1, 1) * q_int).contiguous()
 
@@ -348,8 +378,10 @@ class Agent57LightEngine:
             with torch.no_grad():
                 p.emb_network.eval()
                 p.lifelong_train.eval()
-                episodic = self.ngu.episodic(embed(p.emb_network, self.state), reset=self.reset_lane, active=live.to(torch.uint8))
-                lifelong = self.ngu.lifelong(rnd(p.lifelong_target, self.state), rnd(p.lifelong_train, self.state), c.lifelong_max)
+                f = self._feat
+                episodic = self.ngu.episodic(embed(p.emb_network, self.state, f.get("emb")), reset=self.reset_lane, active=live.to(torch.uint8))
+                lifelong = self.ngu.lifelong(rnd(p.lifelong_target, self.state, f.get("rnd_target")), rnd(p.lifelong_train, self.state, f.get("rnd_train")),
+                                             c.lifelong_max)
             r_int = torch.where(live, episodic * lifelong, r_int)  # :383-391
         self.x_r_int[slot] = r_int
         # the worker's bookkeeping (:393-417): lanes in a reset lock-step took no action

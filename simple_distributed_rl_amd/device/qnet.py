@@ -279,6 +279,71 @@ class QNetInference:
         return q
 
 
+class ImageTrunk:
+    """The image block of a torch network (DQNImageBlock, dqn_image_block.py:29-54: 8x8/4, 4x4/2, 3x3/1 convolutions with replicate padding
+    and ReLU) evaluated by libsrlx straight from the uint8 frame ring -- for networks whose dense part is NOT the dueling head of
+    `EngineQNet` (Agent57_light's UVFA Q-networks, embedding network and RND networks).  The module's own parameters are bound by address
+    (conv2 / conv3 are switched to channels_last memory, which torch's convolution keeps accepting: autograd training of the same module
+    goes on unchanged), so the features always reflect the current weights.  `__call__` returns what `image_block(x).flatten(1)` returns
+    on the float32 stack of the same frames (pixel values / 255), to float32 round-off (tests/test_agent57_engine_gpu.py)."""
+
+    @staticmethod
+    def supported(image_block) -> bool:
+        layers = list(getattr(image_block, "image_layers", []))
+        if len(layers) != 6 or not all(isinstance(m, nn.Conv2d) for m in layers[0::2]) or not all(isinstance(m, nn.ReLU) for m in layers[1::2]):
+            return False
+        c1, c2, c3 = layers[0::2]
+        geo = [(c.kernel_size, c.stride, c.padding, c.padding_mode) for c in (c1, c2, c3)]
+        want = [((8, 8), (4, 4), (3, 3), "replicate"), ((4, 4), (2, 2), (2, 2), "replicate"), ((3, 3), (1, 1), (1, 1), "replicate")]
+        f = c1.out_channels
+        return geo == want and f in (32, 64, 128) and c2.out_channels == 2 * f and c3.out_channels == 2 * f and c3.in_channels == 2 * f and c1.bias is not None
+
+    def __init__(self, image_block, hw, max_batch: int, device: int = 0):
+        assert ImageTrunk.supported(image_block)
+        self.lib = N.lib()
+        self.convs = list(image_block.image_layers)[0::2]
+        c1 = self.convs[0]
+        self.max_batch = int(max_batch)
+        self.dev = torch.device(f"cuda:{device}")
+        for conv in self.convs[1:]:
+            conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+        hh = N.c_p()
+        N.check(self.lib.srlx_qnet_create(ctypes.byref(hh), int(hw[0]), int(hw[1]), c1.in_channels, c1.out_channels, 32, 1, 0, self.max_batch, int(device)))
+        self.h = hh
+        self._unused = torch.zeros(64, dtype=torch.float32, device=self.dev)  # the dense-layer entries of srlx_qnet_bind (never read by forward_convs)
+        with torch.no_grad():
+            y = image_block(torch.zeros((1, c1.in_channels, int(hw[0]), int(hw[1])), device=self.dev))
+        self.channels, self.pixels = y.shape[1], y.shape[2] * y.shape[3]
+        self.out = torch.empty((self.max_batch, self.pixels, self.channels), dtype=torch.float32, device=self.dev)
+        self.bind()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            try:
+                torch.cuda.synchronize(self.dev)
+            except Exception:
+                pass
+            self.lib.srlx_qnet_destroy(self.h)
+            self.h = None
+
+    def bind(self):
+        ps = [t for c in self.convs for t in (c.weight, c.bias)]
+        assert all(p.is_cuda and p.dtype == torch.float32 for p in ps)
+        arr = (N.c_p * 12)(*([p.data_ptr() for p in ps] + [self._unused.data_ptr()] * 6))
+        N.check(self.lib.srlx_qnet_bind(self.h, ctypes.cast(arr, N.c_p)))
+        self._bound = [p.data_ptr() for p in ps]
+
+    def __call__(self, frame_base_ptr: int, frame_off: torch.Tensor) -> torch.Tensor:
+        B = frame_off.shape[0]
+        ps = [t for c in self.convs for t in (c.weight, c.bias)]
+        if [p.data_ptr() for p in ps] != self._bound:  # the parameters were re-homed (load_state_dict keeps them, .to() / flattening does not)
+            self.bind()
+        for conv in self.convs[1:]:
+            assert conv.weight.is_contiguous(memory_format=torch.channels_last), "ImageTrunk: a convolution weight left channels_last memory"
+        N.check(self.lib.srlx_qnet_forward_convs_u8(self.h, B, N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(self.out), N.torch_stream_ptr()))
+        return self.out[:B].transpose(1, 2).reshape(B, self.channels * self.pixels)  # pixel-major -> torch's channel-major flatten
+
+
 class DeviceAdam:
     """torch.optim.Adam(params, lr) for a fixed list of float32 device tensors as ONE libsrlx launch
     (`srlx_adam_step`; reference: `optim.Adam(self.q_online.parameters(), lr=...)`, model_torch.py:71, and

@@ -162,3 +162,41 @@ def test_runner_train_and_train_mp_with_agent57_light():
     assert any(not torch.equal(before[k], after[k]) for k in before)  # the Runner's own parameter object was trained
     st = runner.train_mp(actor_num=2, actor_devices=["cuda:0", "cuda:0"], max_train_count=12, timeout=300, sync_interval_steps=4)
     assert runner.vector_reason == "" and st.end_reason == "max_train_count over." and st.train_count >= 12 and st.trainer_recv_q > 0
+
+
+@pytest.mark.parametrize("hw", [84, 20])
+def test_image_trunks_equal_the_torch_image_blocks(hw):
+    """device/qnet.py:ImageTrunk (libsrlx convolutions straight from the uint8 ring, the module's own weights bound by address) vs the
+    torch image block on the float32 stack of the same frames, for the engine's five networks -- and the actor's Q-values / intrinsic
+    reward inputs built from them (84 x 84: the fused kernel; 20 x 20: the three-launch path)."""
+    from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine, embed, q_values, rnd
+
+    cfg = agent57_light.Config(batch_size=8, actor_num=4, target_model_update_interval=5, episodic_memory_capacity=64, ucb_window_size=6)
+    cfg.window_length = 4
+    cfg.memory.capacity, cfg.memory.warmup_size = 8 * 40, 32
+    cfg.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1000)
+    cfg.input_block.image.set_dqn_block()
+    cfg.hidden_block.set_dueling_network((32,))
+    env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(hw, hw), n_actions=3, episode_len=9)))
+    cfg.setup(env)
+    eng = Agent57LightEngine(cfg, 8, 0, episode_len=9, seed=3)
+    assert eng._all_fused and set(eng._trunks) == {"q_ext", "q_int", "emb", "rnd_target", "rnd_train"}
+    p = eng.parameter
+    for it in range(14):
+        eng.step(learner_updates=1)  # the weights move: the trunks must follow them
+        stack = eng.replay.stack_current().view(eng.E, eng.Wn, *eng.hw)
+        off = eng.replay.frame_table_current()
+        nets = {"q_ext": p.q_ext_online, "q_int": p.q_int_online, "emb": p.emb_network, "rnd_target": p.lifelong_target, "rnd_train": p.lifelong_train}
+        with torch.no_grad():
+            for name, net in nets.items():
+                want = net.in_block(stack, channels_first=True)
+                got = eng._trunks[name](eng.replay.obs_base, off)
+                torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()), msg=lambda m, n=name: f"{n} (iteration {it}): {m}")
+            arm = eng.arm()
+            inputs = (stack, eng.prev_r_ext.view(-1, 1), eng.prev_r_int.view(-1, 1), eng.action_eye[eng.prev_action], eng.actor_eye[arm])
+            q_ext, q_int, _ = eng.policy_q()
+            torch.testing.assert_close(q_ext, q_values(p.q_ext_online, *inputs), rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(q_int, q_values(p.q_int_online, *inputs), rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(embed(p.emb_network, None, eng._trunks["emb"](eng.replay.obs_base, off)), embed(p.emb_network, stack), rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(rnd(p.lifelong_train, None, eng._trunks["rnd_train"](eng.replay.obs_base, off)), rnd(p.lifelong_train, stack), rtol=1e-4, atol=1e-5)
+    assert eng.train_count > 5

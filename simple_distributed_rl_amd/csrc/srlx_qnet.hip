@@ -270,9 +270,22 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
     __shared__ __attribute__((aligned(16))) float As2[2][TBM * LDT];
     __shared__ __attribute__((aligned(16))) float Bs2[2][BN * LDT];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const i64 m0 = (i64)blockIdx.x * TBM;
-    const int n0 = blockIdx.y * BN;
-    const int kbeg = SPLITK ? blockIdx.z * k_per_split : 0;
+    // XCD-aware tile order for the split-K launches (FC1).  Workgroups go round-robin over the 8 XCDs in linear-id order, each XCD has its
+    // own 4 MB L2: with the plain mapping (x = M tile fastest, 8 M tiles) XCD i computes M tile i against EVERY weight tile, i.e. the 32 MB
+    // weight matrix is fetched once per XCD -- rocprofv3 FETCH_SIZE: 302 MB per launch at 1024 rows against 80 MB algorithmic.  Handing XCD i
+    // the i-th CONTIGUOUS eighth of the (split, N tile, M tile) space gives it one K range x half the N tiles x all M tiles: every weight tile
+    // is fetched by one XCD, every activation K-slice by two.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (SPLITK) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        if (total % 8 == 0) {
+            const unsigned lin = bx + gx * (by + gy * bz), tile = (lin % 8) * (total / 8) + lin / 8;
+            bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
+        }
+    }
+    const i64 m0 = (i64)bx * TBM;
+    const int n0 = by * BN;
+    const int kbeg = SPLITK ? bz * k_per_split : 0;
     const int kend = SPLITK ? (kbeg + k_per_split < K ? kbeg + k_per_split : K) : K;
     constexpr int WN = BN / 32, WM = 4 / WN, MT = TBM / (32 * WM), NB = BN / 32, MR = TBM / 32;
     const int wn = wave % WN, wm = wave / WN;
@@ -336,7 +349,7 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
         cur ^= 1;
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float *Cz = SPLITK ? C + (i64)blockIdx.z * M * N : C;
+    float *Cz = SPLITK ? C + (i64)bz * M * N : C;
     const int n = n0 + wn * 32 + i;
     const float bv = (!SPLITK && bias && n < N) ? bias[n] : 0.f;
 #pragma unroll

@@ -22,6 +22,7 @@ namespace {
 using i64 = int64_t;
 using u8 = unsigned char;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int kPad = 88, kFrame = kPad * kPad;     // staged frame side / bytes
 constexpr int kP1 = 21, kM1 = kP1 * kP1;           // conv1 output side / pixels
@@ -39,19 +40,41 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // contiguous KiB (8 lines).  311 KB for the three layers, rebuilt by one small launch per forward (the filters are the torch
 // parameters themselves and change with every optimiser step).
 constexpr int kW1 = 32 * 256, kW2 = 64 * 512, kW3 = 64 * 576;
-constexpr int kPackFloats = kW1 + kW2 + kW3;
+constexpr int kW1B = 16 * 3 * 64 * 4;  // conv1's filters once more as split-bf16 MFMA fragments: [step 16][part 3][lane 64] x 16 bytes (in floats)
+constexpr int kPackFloats = kW1 + kW2 + kW3 + kW1B;
 
 // A training handle's launch also builds the transposed filters of the backward pass's two data-gradient GEMMs (wT3 / wT2: layout of
 // k_transpose_filter in srlx_qnet_bwd.hip) -- they depend on the weights only, and the weights do not change between this forward and
 // its backward, so two launches leave the learner's critical path.
 __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
                                                       float *__restrict__ out, float *__restrict__ wT3, float *__restrict__ wT2) {
-    // one thread per float4 of the packed buffer
+    // one thread per float4 of the packed float32 buffer, then one per (step, lane) of conv1's split-bf16 fragments
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n4 = kPackFloats / 4;
+    const int n4 = (kW1 + kW2 + kW3) / 4;
+    if (q >= n4 && q < n4 + 16 * 64) {
+        // conv1 on the bf16 matrix pipe, exactly: w / 255 (float32, as the float32 path folds it) = p0 + p1 + p2 with three bf16 parts (8 + 8 + 8
+        // mantissa bits; each remainder is exact in float32), the pixel operand is a uint8 and exact in ONE bf16, every partial product is exact in
+        // the float32 accumulator.  Fragment of v_mfma_f32_32x32x16_bf16: lane (i, h) holds k = 16 step + 8 h + 0..7 of filter row i.
+        const int idx = q - n4, lane = idx & 63, step = idx >> 6, i = lane & 31, hh = lane >> 5;
+        bf16x8 part[3];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float r = w1[i * 256 + step * 16 + hh * 8 + j] * (1.0f / 255.0f);
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const __bf16 b = (__bf16)r;
+                part[t][j] = b;
+                r -= (float)b;
+            }
+        }
+        bf16x8 *dst = reinterpret_cast<bf16x8 *>(out + kW1 + kW2 + kW3);
+#pragma unroll
+        for (int t = 0; t < 3; t++) dst[(step * 3 + t) * 64 + lane] = part[t];
+        return;
+    }
     if (q >= n4) {
         if (!wT3) return;
-        int i = q - n4;
+        int i = q - n4 - 16 * 64;
         if (i < kW3) {  // conv3: 64 x (3 x 3) x 64, stride 1: wT[ci][tap * 64 + co] = W[co][tap][ci]
             const int ci = i % 64, tap = (i / 64) % 9, co = i / (64 * 9);
             wT3[ci * 576 + tap * 64 + co] = w3[i];
@@ -118,7 +141,7 @@ __device__ __forceinline__ void tile_from_lds(const float *__restrict__ lds_in, 
 
 // BIG = a launch of at least 512 samples (the actors' policy pass): a template parameter only so that profiles list the chip-filling
 // launches and the learner's 96 / 128-sample launches as separate kernels (same code).
-template <bool BIG>
+template <bool BIG, bool C1B16>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
                                                                 float *__restrict__ act3,
@@ -169,8 +192,73 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
             reinterpret_cast<unsigned *>(fr)[idx] = o;
         }
     }
-    // ---- conv1: this lane's B fragments of all eight K-slabs (filter row i, k = slab*32 + 16 h + 0..15), 1/255 folded in
-    {
+    // ---- conv1 on the bf16 matrix pipe, exactly (see k_pack_filters): the A operand is the uint8 pixel itself (one bf16), the filter / 255 is
+    //      the sum of three bf16 parts, v_mfma_f32_32x32x16_bf16 accumulates the exact partial products in float32.  3 MFMAs of 32 cycles per
+    //      16 K instead of 8 of 64: the layer's matrix time drops 5.3x; what remains is the LDS / conversion stream (two dwords and twelve
+    //      VALU instructions per step).  Step s = (frame c = s >> 2, kernel rows 2 (s & 3) + h), a lane's 8 k = the 8 kernel columns.
+    if constexpr (C1B16) {
+        bf16x8 bw[16][3];
+        const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3) + lane;
+#pragma unroll
+        for (int sp = 0; sp < 16; sp++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) bw[sp][q] = wp[(sp * 3 + q) * 64];
+        const float bias = b1[i];
+        stamp(1);
+        __syncthreads();
+        stamp(2);
+        constexpr int tiles = (kM1 + 31) / 32;  // 14
+        const int wrot = (wave + (int)(b & 7)) & 7;  // rotate the 2/2/2/2/2/2/1/1 split with the sample index
+        for (int tile = wrot; tile < tiles; tile += kWaves) {
+            const int m = tile * 32 + i < kM1 ? tile * 32 + i : kM1 - 1;
+            const int oy = m / kP1, ox = m % kP1;
+            const u8 *win = fr + (4 * oy + h) * kPad + 4 * ox;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            uint2 wa, wb;
+            auto fetch = [&](int sp, uint2 &w) __attribute__((always_inline)) {
+                const u8 *p = win + (sp >> 2) * kFrame + 2 * (sp & 3) * kPad;
+                w.x = *reinterpret_cast<const unsigned *>(p);
+                w.y = *reinterpret_cast<const unsigned *>(p + 4);
+            };
+            auto mfma3 = [&](int sp, const uint2 &w) __attribute__((always_inline)) {
+                bf16x8 a;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    a[j] = (__bf16)(float)((w.x >> (8 * j)) & 255u);
+                    a[4 + j] = (__bf16)(float)((w.y >> (8 * j)) & 255u);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[sp][q], acc, 0, 0, 0);
+            };
+            fetch(0, wa);
+#pragma unroll
+            for (int sp = 0; sp < 16; sp += 2) {
+                fetch(sp + 1, wb);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma3(sp, wa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sp + 2 < 16) fetch(sp + 2, wa);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma3(sp + 1, wb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 h (pixel)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mm = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (mm < kM1) {
+                    float v = acc[r] + bias;
+                    v = v > 0.f ? v : 0.f;
+                    a1[mm * kS1 + i] = v;
+                    if (act1_out) act1_out[(b * kM1 + mm) * 32 + i] = v;
+                }
+            }
+        }
+    }
+    // ---- conv1, float32 MFMAs (SRLX_CONV1_F32=1): this lane's B fragments of all eight K-slabs (filter row i, k = slab*32 + 16 h + 0..15), 1/255 folded in
+    if constexpr (!C1B16) {
         float bfr[8][16];
         const float *wp = wpk + lane * 4;  // conv1's filters lead the packed buffer: [slab][v][lane][4]
 #pragma unroll
@@ -300,23 +388,28 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     if (!(h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32)) return false;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_convnet_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess) return false;
-        if (hipFuncSetAttribute((const void *)k_convnet_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess) return false;
+        const void *kerns[] = {(const void *)k_convnet_fused<true, true>, (const void *)k_convnet_fused<false, true>, (const void *)k_convnet_fused<true, false>,
+                               (const void *)k_convnet_fused<false, false>};
+        for (const void *kp : kerns)
+            if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess) return false;
         attr_set = true;
     }
     if (!h->wpack) {
         if (hipMalloc((void **)&h->wpack, (size_t)kPackFloats * sizeof(float)) != hipSuccess) return false;
     }
     const bool keep = h->max_train > 0;  // a training handle: the backward pass reads act1 / act2 and the transposed filters
-    const int pack_threads = kPackFloats / 4 + (keep ? kW3 + kW2 : 0);
+    const int pack_threads = (kW1 + kW2 + kW3) / 4 + 16 * 64 + (keep ? kW3 + kW2 : 0);
     hipLaunchKernelGGL(k_pack_filters, dim3((pack_threads + 255) / 256), dim3(256), 0, st, h->w1, h->w2, h->w3, h->wpack, keep ? h->w_t : nullptr,
                        keep ? h->w_t2 : nullptr);
     h->wt_from_forward = keep;
+    static const bool c1_f32 = getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1';  // A/B switch: conv1 on the float32 matrix pipe
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, h->act3,
+                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
+    };
     if (batch >= 512)
-        hipLaunchKernelGGL(k_convnet_fused<true>, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3,
-                           h->act3, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
+        c1_f32 ? launch(k_convnet_fused<true, false>) : launch(k_convnet_fused<true, true>);
     else
-        hipLaunchKernelGGL(k_convnet_fused<false>, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3,
-                           h->act3, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
+        c1_f32 ? launch(k_convnet_fused<false, false>) : launch(k_convnet_fused<false, true>);
     return hipGetLastError() == hipSuccess;
 }

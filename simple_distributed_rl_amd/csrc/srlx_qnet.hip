@@ -38,6 +38,7 @@ namespace {
 using i64 = int64_t;
 using u8 = unsigned char;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int BM = 128, BK = 32, LDT = 36;
 
@@ -365,6 +366,111 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
         }
 }
 
+// ---- FC1 at chip-filling batches on the bf16 matrix pipe: float32 x float32 from six exact partial products ------------------------
+// A float32 is the sum of three bf16 parts exactly (8 + 8 + 8 mantissa bits; each remainder is exact in float32).  a * b is evaluated
+// as the six largest of the nine partial products a_p * b_q (p + q <= 2), each exact in the float32 accumulator of
+// v_mfma_f32_32x32x16_bf16; the three dropped ones are below 2^-24 |a b|, the size of float32's own rounding of the product.
+// 6 MFMAs of 32 cycles per 16 K against 8 of 64 on the float32 pipe: 2.7x less matrix time; the kernel is then bound by LDS reads
+// (18 ds_read_b128 per 24 MFMAs per wave).  k_split3 writes the parts as three bf16 planes [3][rows][K] (activations and weights, once
+// per forward: 63 MB read + 95 MB written at 1024 rows, ~25 us, against ~60 us saved); tiles and split-K as k_gemm.
+__global__ void __launch_bounds__(256) k_split3(const float *__restrict__ x, i64 n8, i64 plane, __bf16 *__restrict__ out) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const float4 v0 = reinterpret_cast<const float4 *>(x)[2 * i], v1 = reinterpret_cast<const float4 *>(x)[2 * i + 1];
+    float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    bf16x8 part[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const __bf16 b = (__bf16)r[j];
+            part[t][j] = b;
+            r[j] -= (float)b;
+        }
+#pragma unroll
+    for (int t = 0; t < 3; t++) reinterpret_cast<bf16x8 *>(out + t * plane)[i] = part[t];
+}
+
+constexpr int kRowB = 80;  // LDS bytes per tile row: 32 bf16 (64 B) + 16 B pad: the 16 lanes of a ds_read_b128 pass start 20 banks apart
+__global__ void __launch_bounds__(256) k_gemm_b16(const __bf16 *__restrict__ Ap, i64 a_plane, const __bf16 *__restrict__ Wp, i64 w_plane, float *__restrict__ C, i64 M, int N,
+                                                  int K, int k_per_split) {
+    constexpr int TBM = 128, BN = 64, MT = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char As[3 * TBM * kRowB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BN * kRowB];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {   // XCD-aware tile order (see k_gemm)
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        if (total % 8 == 0) {
+            const unsigned lin = bx + gx * (by + gy * bz), tile = (lin % 8) * (total / 8) + lin / 8;
+            bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
+        }
+    }
+    const i64 m0 = (i64)bx * TBM;
+    const int n0 = by * BN;
+    const int kbeg = bz * k_per_split, kend = kbeg + k_per_split < K ? kbeg + k_per_split : K;
+    const int wn = wave & 1, wm = wave >> 1;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+    const int srow = t >> 2, sch = t & 3;  // staging: this lane copies 16 bytes (8 k) of rows srow (+ 64) per plane
+    uint4 ra[3][2], rb[3];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const i64 m = m0 + srow + 64 * q;
+                ra[p][q] = m < M ? *reinterpret_cast<const uint4 *>(Ap + p * a_plane + m * K + k0 + 8 * sch) : make_uint4(0, 0, 0, 0);
+            }
+            const int n = n0 + srow;
+            rb[p] = n < N ? *reinterpret_cast<const uint4 *>(Wp + p * w_plane + (i64)n * K + k0 + 8 * sch) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) *reinterpret_cast<uint4 *>(&As[(p * TBM + srow + 64 * q) * kRowB + 16 * sch]) = ra[p][q];
+            *reinterpret_cast<uint4 *>(&Bs[(p * BN + srow) * kRowB + 16 * sch]) = rb[p];
+        }
+        lds_barrier();
+        if (k0 + BK < kend) fetch(k0 + BK);  // overlaps with the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 bf[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) bf[p] = *reinterpret_cast<const bf16x8 *>(&Bs[(p * BN + wn * 32 + i) * kRowB + (2 * ks + h) * 16]);
+#pragma unroll
+            for (int ms = 0; ms < MT; ms++) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) af[p] = *reinterpret_cast<const bf16x8 *>(&As[(p * TBM + wm * 64 + ms * 32 + i) * kRowB + (2 * ks + h) * 16]);
+                // smallest partial products first
+                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[ms], 0, 0, 0);
+                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[ms], 0, 0, 0);
+                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[ms], 0, 0, 0);
+                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[ms], 0, 0, 0);
+                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[ms], 0, 0, 0);
+                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[ms], 0, 0, 0);
+            }
+        }
+        lds_barrier();
+    }
+    float *Cz = C + (i64)bz * M * N;
+    const int n = n0 + wn * 32 + i;
+#pragma unroll
+    for (int ms = 0; ms < MT; ms++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const i64 m = m0 + wm * 64 + ms * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M && n < N) Cz[m * N + n] = acc[ms][r];
+        }
+}
+
 // ---- head: reduce FC1 splits (+bias, ReLU), second layers, dueling combine; one workgroup per sample ----
 constexpr int kMaxActions = 32;
 __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial, int splits, i64 M, int hidden, const float *__restrict__ b1,
@@ -565,10 +671,23 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     if (splits > ksteps) splits = ksteps;
     if (splits > h->max_splits) splits = h->max_splits;
     if (splits < 1) splits = 1;
-    APlain fa{h->act3, (i64)h->flat * stride};
-    launch_gemm<APlain, 64, false, true>(fa, h->wf, nullptr, h->partial, B, N1, h->flat, splits, st);
     const int kps = ((ksteps + splits - 1) / splits);
     const int used = (ksteps + kps - 1) / kps;  // splits that actually own a K range
+    static const bool fc1_f32 = getenv("SRLX_FC1_F32") && getenv("SRLX_FC1_F32")[0] == '1';  // A/B switch: FC1 on the float32 matrix pipe at every batch
+    if (B >= 512 && stride == 1 && h->planes && !fc1_f32) {
+        // the actors' launches: float32 x float32 as six exact bf16 partial products (k_gemm_b16); the learner's 96 / 128 rows stay on k_gemm
+        const i64 a_plane = (i64)h->max_batch * h->flat, w_plane = (i64)N1 * h->flat;
+        SRLX_REQUIRE(h->planes, "qnet_forward: the split-bf16 operand buffer is missing");
+        __bf16 *ap = (__bf16 *)h->planes, *wp = ap + 3 * a_plane;
+        const i64 a8 = B * h->flat / 8, w8 = w_plane / 8;
+        hipLaunchKernelGGL(k_split3, dim3((unsigned)((a8 + 255) / 256)), dim3(256), 0, st, h->act3, a8, a_plane, ap);
+        hipLaunchKernelGGL(k_split3, dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, h->wf, w8, w_plane, wp);
+        const dim3 grid((unsigned)((B + 127) / 128), (unsigned)((N1 + 63) / 64), (unsigned)splits);
+        hipLaunchKernelGGL(k_gemm_b16, grid, dim3(256), 0, st, ap, a_plane, wp, w_plane, h->partial, B, N1, h->flat, kps * BK);
+    } else {
+        APlain fa{h->act3, (i64)h->flat * stride};
+        launch_gemm<APlain, 64, false, true>(fa, h->wf, nullptr, h->partial, B, N1, h->flat, splits, st);
+    }
     // small launches (the learner's 128 / 96 rows) are one workgroup per row and far from filling the chip: twice the threads per row
     hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(B <= 256 && h->hidden > 256 ? 512 : 256), 0, st, h->partial, used, B, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
                        h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, h->sig[0] ? h->d_draw : nullptr);
@@ -631,6 +750,14 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
                 {&h->act3, (size_t)max_batch * h->flat},
                 // FC1 split-K partial sums: splits(B) * B <= 4096 + B for every batch B (see run_tail)
                 {&h->partial, (size_t)(4096 + 128 + max_batch) * 2 * hidden}};
+    if (max_batch >= 512 && h->flat % 8 == 0) {  // chip-filling launches run FC1 on split-bf16 operands (k_gemm_b16): three bf16 planes of act3 and of the weight
+        hipError_t e = hipMalloc(&h->planes, (size_t)3 * ((size_t)max_batch * h->flat + (size_t)2 * hidden * h->flat) * sizeof(__bf16));
+        if (e != hipSuccess) {
+            srlx::set_error("qnet_create: %s", hipGetErrorString(e));
+            srlx_qnet_destroy(h);
+            return e == hipErrorOutOfMemory ? SRLX_ERR_NOMEM : SRLX_ERR_HIP;
+        }
+    }
     for (auto &b : bufs) {
         hipError_t e = hipMalloc((void **)b.p, b.n * f);
         if (e != hipSuccess) {
@@ -654,6 +781,7 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
         if (p) (void)hipFree(p);
     if (h->d_draw) (void)hipFree(h->d_draw);
     if (h->wpack) (void)hipFree(h->wpack);
+    if (h->planes) (void)hipFree(h->planes);
     if (h->side && !h->side_external) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join, h->ev_wt})
         if (e) (void)hipEventDestroy(e);

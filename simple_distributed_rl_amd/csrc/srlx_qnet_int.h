@@ -10,6 +10,7 @@ struct srlx_qnet {
     int flat;  // OH3*OW3*2*F1
     const float *w1, *b1, *w2, *b2, *w3, *b3, *wf, *bf, *v2w, *v2b, *a2w, *a2b;  // BORROWED: the torch parameters themselves
     float *act1, *act2, *act3, *partial;
+    void *planes;  // split-bf16 operands of the FC1 GEMM at chip-filling batches (allocated on first use): [3][max_batch][flat] activations, [3][2*hidden][flat] weights
     int max_splits;
     // training (srlx_qnet_enable_training): post-ReLU hidden layer of every forward row + gradient scratch
     int64_t max_train;

@@ -3,6 +3,7 @@ the reference's blocks (and are themselves pinned to the reference by tests/gold
 Tolerance: 1e-5 relative on Q-values (north_star) -- exact-fp32 MFMA, only the summation order differs."""
 import ctypes
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -175,3 +176,36 @@ def test_backward_u8_matches_autograd(A, dueling, B, stride, hw, hidden):
         assert p.grad.stride() == p.stride(), name  # the fused Adam walks parameter and gradient with the same strides
         scale = float(w.abs().max()) + 1e-12
         np.testing.assert_allclose(p.grad.cpu().numpy(), w.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg=name)
+
+
+def test_conv1_on_the_bf16_pipe_equals_the_float32_pipe(tmp_path):
+    """The fused kernel's conv1 runs on v_mfma_f32_32x32x16_bf16 with the pixel as ONE bf16 and the filter / 255 as three bf16 parts (exact partial
+    products, float32 accumulation).  Against the same kernel with conv1 on the float32 pipe (SRLX_CONV1_F32=1; switches are read once per
+    process, hence the subprocesses): Q-values within 2e-6 of max |Q| -- float32 round-off of a different summation order; and the float32-pipe
+    fused kernel stays bit-identical to the three-launch path."""
+    script = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference\n"
+        "torch.manual_seed(0)\n"
+        "net = EngineQNet(6).cuda()\n"
+        "qn = QNetInference(net, 160)\n"
+        "g = torch.Generator(device='cuda').manual_seed(1)\n"
+        "F = 84 * 84\n"
+        "ring = torch.randint(0, 256, (600 * F,), dtype=torch.uint8, device='cuda', generator=g)\n"
+        "off = torch.randint(0, 600, (160, 4), device='cuda', generator=g) * F\n"
+        "off[torch.rand((160, 4), device='cuda', generator=g) < 0.1] = -1\n"
+        "torch.save(qn.forward_u8(ring.data_ptr(), off).cpu(), sys.argv[1])\n" % ROOT
+    )
+    outs = {}
+    for name, env in (("bf16", {}), ("f32", {"SRLX_CONV1_F32": "1"}), ("three_launches", {"SRLX_NO_FUSED_CONV": "1"})):
+        path = str(tmp_path / f"q_{name}.pt")
+        e = {k: v for k, v in os.environ.items() if k not in ("SRLX_CONV1_F32", "SRLX_NO_FUSED_CONV")}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", script, path], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = torch.load(path)
+    assert torch.equal(outs["f32"], outs["three_launches"])
+    scale = float(outs["f32"].abs().max())
+    diff = float((outs["bf16"] - outs["f32"]).abs().max())
+    assert 0 < scale and diff <= 2e-6 * scale, (diff, scale)

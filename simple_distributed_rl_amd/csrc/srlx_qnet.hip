@@ -444,19 +444,17 @@ __global__ void __launch_bounds__(256) k_gemm_b16(const __bf16 *__restrict__ Ap,
             bf16x8 bf[3];
 #pragma unroll
             for (int p = 0; p < 3; p++) bf[p] = *reinterpret_cast<const bf16x8 *>(&Bs[(p * BN + wn * 32 + i) * kRowB + (2 * ks + h) * 16]);
+            bf16x8 af[MT][3];
 #pragma unroll
-            for (int ms = 0; ms < MT; ms++) {
-                bf16x8 af[3];
+            for (int ms = 0; ms < MT; ms++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) af[p] = *reinterpret_cast<const bf16x8 *>(&As[(p * TBM + wm * 64 + ms * 32 + i) * kRowB + (2 * ks + h) * 16]);
-                // smallest partial products first
-                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[ms], 0, 0, 0);
-                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[ms], 0, 0, 0);
-                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[ms], 0, 0, 0);
-                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[ms], 0, 0, 0);
-                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[ms], 0, 0, 0);
-                acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[ms], 0, 0, 0);
-            }
+                for (int p = 0; p < 3; p++) af[ms][p] = *reinterpret_cast<const bf16x8 *>(&As[(p * TBM + wm * 64 + ms * 32 + i) * kRowB + (2 * ks + h) * 16]);
+            // smallest partial products first; the two accumulators alternate so that no MFMA waits for the one issued just before it
+            constexpr int pq[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int ms = 0; ms < MT; ms++) acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ms][pq[c][0]], bf[pq[c][1]], acc[ms], 0, 0, 0);
         }
         lds_barrier();
     }

@@ -678,7 +678,7 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
         SRLX_REQUIRE(h->planes, "qnet_forward: the split-bf16 operand buffer is missing");
         __bf16 *ap = (__bf16 *)h->planes, *wp = ap + 3 * a_plane;
         const i64 a8 = B * h->flat / 8, w8 = w_plane / 8;
-        hipLaunchKernelGGL(k_split3, dim3((unsigned)((a8 + 255) / 256)), dim3(256), 0, st, h->act3, a8, a_plane, ap);
+        if (!h->act3_in_planes) hipLaunchKernelGGL(k_split3, dim3((unsigned)((a8 + 255) / 256)), dim3(256), 0, st, h->act3, a8, a_plane, ap);
         hipLaunchKernelGGL(k_split3, dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, h->wf, w8, w_plane, wp);
         const dim3 grid((unsigned)((B + 127) / 128), (unsigned)((N1 + 63) / 64), (unsigned)splits);
         hipLaunchKernelGGL(k_gemm_b16, grid, dim3(256), 0, st, ap, a_plane, wp, w_plane, h->partial, B, N1, h->flat, kps * BK);
@@ -827,12 +827,13 @@ static int forward_u8_impl(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame
     if (!no_fused && h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32) {
         // conv1 -> conv2 -> conv3 in one kernel, one workgroup per sample, activations in LDS (srlx_qnet_fused.hip)
         if (h->probe0) SRLX_HIP(hipEventRecord(h->probe0, st));
-        SRLX_REQUIRE(srlx_qnet_fused_convs(h, batch, d_frame_base, d_frame_off, st), "qnet_forward_u8: launching the fused convolution kernel failed");
+        SRLX_REQUIRE(srlx_qnet_fused_convs(h, batch, d_frame_base, d_frame_off, st, d_q != nullptr), "qnet_forward_u8: launching the fused convolution kernel failed");
         if (h->probe1) SRLX_HIP(hipEventRecord(h->probe1, st));
         h->probe0 = h->probe1 = nullptr;
         return d_q ? run_dense(h, batch, d_q, st) : SRLX_OK;
     }
     h->wt_from_forward = false;
+    h->act3_in_planes = false;
     const size_t lds = (size_t)h->Wn * kC1Frame;
     if (h->F1 == 32 && h->Wn == 4 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && 4 * (h->OW1 - 1) + 8 <= kC1Pad && h->W % 4 == 0) {
         // one workgroup per sample, frames + filters staged in LDS

@@ -41,7 +41,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // parameters themselves and change with every optimiser step).
 constexpr int kW1 = 32 * 256, kW2 = 64 * 512, kW3 = 64 * 576;
 constexpr int kW1B = 16 * 3 * 64 * 4;  // conv1's filters once more as split-bf16 MFMA fragments: [step 16][part 3][lane 64] x 16 bytes (in floats)
-constexpr int kPackFloats = kW1 + kW2 + kW3 + kW1B;
+constexpr int kW2B = 32 * 2 * 3 * 64 * 4, kW3B = 36 * 2 * 3 * 64 * 4;  // conv2 / conv3 filters as split-bf16 fragments: [step][n-tile][part][lane] x 16 bytes (in floats)
+constexpr int kPackFloats = kW1 + kW2 + kW3 + kW1B + kW2B + kW3B;
 
 // A training handle's launch also builds the transposed filters of the backward pass's two data-gradient GEMMs (wT3 / wT2: layout of
 // k_transpose_filter in srlx_qnet_bwd.hip) -- they depend on the weights only, and the weights do not change between this forward and
@@ -72,9 +73,34 @@ __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ 
         for (int t = 0; t < 3; t++) dst[(step * 3 + t) * 64 + lane] = part[t];
         return;
     }
+    if (q >= n4 + 16 * 64 && q < n4 + 16 * 64 + (32 + 36) * 2 * 64) {
+        // conv2 / conv3 filters as three bf16 parts in MFMA-fragment order (k_convnet_fused<.., C23B16 = true>): lane (i, h) of (step, n-tile) holds
+        // k = 16 step + 8 h + 0..7 of filter row n-tile * 32 + i; K = (tap, channel) as in the float32 path
+        int idx = q - n4 - 16 * 64;
+        const bool third = idx >= 32 * 2 * 64;
+        if (third) idx -= 32 * 2 * 64;
+        const int lane = idx & 63, nt = (idx >> 6) & 1, step = idx >> 7, i = lane & 31, hh = lane >> 5;
+        const float *src = third ? w3 : w2;
+        const int K = third ? 576 : 512;
+        bf16x8 part[3];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float r = src[(nt * 32 + i) * K + step * 16 + hh * 8 + j];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const __bf16 b = (__bf16)r;
+                part[t][j] = b;
+                r -= (float)b;
+            }
+        }
+        bf16x8 *dst = reinterpret_cast<bf16x8 *>(out + kW1 + kW2 + kW3 + kW1B + (third ? kW2B : 0));
+#pragma unroll
+        for (int t = 0; t < 3; t++) dst[((step * 2 + nt) * 3 + t) * 64 + lane] = part[t];
+        return;
+    }
     if (q >= n4) {
         if (!wT3) return;
-        int i = q - n4 - 16 * 64;
+        int i = q - n4 - 16 * 64 - (32 + 36) * 2 * 64;
         if (i < kW3) {  // conv3: 64 x (3 x 3) x 64, stride 1: wT[ci][tap * 64 + co] = W[co][tap][ci]
             const int ci = i % 64, tap = (i / 64) % 9, co = i / (64 * 9);
             wT3[ci * 576 + tap * 64 + co] = w3[i];
@@ -139,9 +165,113 @@ __device__ __forceinline__ void tile_from_lds(const float *__restrict__ lds_in, 
     }
 }
 
+// conv2 / conv3 on the bf16 matrix pipe (float32 x float32 from six exact partial products, like k_gemm_b16 of srlx_qnet.hip).  With one 32 x 32
+// tile per wave an MFMA needs 2 KB of operands -- 256 B per clock per CU at the bf16 pipe's rate, twice what LDS delivers and four times what L2
+// does -- so here a wave owns a 64 x 64 output BLOCK (2 pixel tiles x both channel tiles: four accumulators, every fragment used twice) over a
+// QUARTER of K; the eight waves are 2 blocks x 4 K quarters and the quarters are summed through LDS afterwards.  A fragments: float32 out of LDS
+// (layout unchanged), split into three bf16 parts on the fly (88 VALU instructions beside 24 MFMAs); B fragments: pre-split by k_pack_filters.
+//   LAYER 2: 4 x 4 stride 2 pad 2 over act1 (21 x 21 x 32), K = 16 taps x 32 = 32 steps of 16;  LAYER 3: 3 x 3 stride 1 pad 1 over act2 (11 x 11 x 64), 36 steps
+template <int LAYER>
+__device__ __forceinline__ void block_b16(const float *__restrict__ lds_in, const bf16x8 *__restrict__ wfrag, int blk, int kq, int lane, f32x16 (&acc)[2][2]) {
+    constexpr int S = LAYER == 2 ? 32 : 36, SPT = LAYER == 2 ? 2 : 4, KW = LAYER == 2 ? 4 : 3, STR = LAYER == 2 ? 2 : 1, PAD = LAYER == 2 ? 2 : 1;
+    constexpr int IN = LAYER == 2 ? kP1 : kP2, PS = LAYER == 2 ? kS1 : kS2, QS = S / 4;
+    const int i = lane & 31, h = lane >> 5;
+    int oy[2], ox[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const int m = (2 * blk + a) * 32 + i < kM2 ? (2 * blk + a) * 32 + i : kM2 - 1;
+        oy[a] = m / kP2, ox[a] = m % kP2;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][n][r] = 0.f;
+    float4 fa0[2][2], fa1[2][2];  // [pixel tile][half of the 8 floats]
+    bf16x8 fb0[2][3], fb1[2][3];  // [channel tile][part]
+    auto load = [&](int sl, float4(&fa)[2][2], bf16x8(&fb)[2][3]) __attribute__((always_inline)) {
+        const int sp = kq * QS + sl, tap = sp / SPT, cg = sp % SPT, ky = tap / KW, kx = tap % KW;
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) fb[n][q] = wfrag[((sp * 2 + n) * 3 + q) * 64 + lane];  // filters: L2 -> registers (the long latency first)
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int iy = clampi(oy[a] * STR + ky - PAD, 0, IN - 1), ix = clampi(ox[a] * STR + kx - PAD, 0, IN - 1);
+            const float *pa = lds_in + (iy * IN + ix) * PS + cg * 16 + 8 * h;
+            fa[a][0] = *reinterpret_cast<const float4 *>(pa);
+            fa[a][1] = *reinterpret_cast<const float4 *>(pa + 4);
+        }
+    };
+    auto mfma24 = [&](const float4(&fa)[2][2], const bf16x8(&fb)[2][3]) __attribute__((always_inline)) {
+        bf16x8 pa[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            float r[8] = {fa[a][0].x, fa[a][0].y, fa[a][0].z, fa[a][0].w, fa[a][1].x, fa[a][1].y, fa[a][1].z, fa[a][1].w};
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const __bf16 b = (__bf16)r[j];
+                    pa[a][t][j] = b;
+                    r[j] -= (float)b;
+                }
+        }
+        constexpr int pq[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};  // smallest partial products first
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][pq[c][0]], fb[n][pq[c][1]], acc[a][n], 0, 0, 0);
+    };
+    load(0, fa0, fb0);
+#pragma unroll
+    for (int sl = 0; sl < QS; sl += 2) {
+        if (sl + 1 < QS) load(sl + 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma24(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sl + 2 < QS) load(sl + 2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sl + 1 < QS) mfma24(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Sums the four K-quarter partial blocks of every output tile through `scratch` (24 KB of LDS nobody else uses meanwhile): in round t the wave
+// with kq == t is the OWNER of tile t = (pixel tile t >> 1, channel tile t & 1) of its block -- the other three waves of the block park their
+// partial tile, the owner adds them in K order and runs `epilogue(pixel tile, channel tile, sum)`.  Four rounds, two barriers each.
+template <class F>
+__device__ __forceinline__ void reduce_quarters(float *__restrict__ scratch, int blk, int kq, int lane, f32x16 (&acc)[2][2], F epilogue) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        f32x16 &mine = acc[t >> 1][t & 1];
+        if (kq != t) {
+            const int slot = blk * 3 + (kq < t ? kq : kq - 1);
+#pragma unroll
+            for (int r = 0; r < 16; r++) scratch[(slot * 16 + r) * 64 + lane] = mine[r];
+        }
+        __syncthreads();
+        if (kq == t) {
+            f32x16 sum;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) v += k == t ? mine[r] : scratch[((blk * 3 + (k < t ? k : k - 1)) * 16 + r) * 64 + lane];  // K quarters in order
+                sum[r] = v;
+            }
+            epilogue(2 * blk + (t >> 1), t & 1, sum);
+        }
+        __syncthreads();
+    }
+}
+
 // BIG = a launch of at least 512 samples (the actors' policy pass): a template parameter only so that profiles list the chip-filling
 // launches and the learner's 96 / 128-sample launches as separate kernels (same code).
-template <bool BIG, bool C1B16>
+template <bool BIG, bool C1B16, bool C23B16>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
                                                                 float *__restrict__ act3, __bf16 *__restrict__ act3_planes, i64 a_plane,
@@ -326,48 +456,8 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     stamp(3);
     __syncthreads();
     stamp(4);
-    const int mt = wave >> 1, nt = wave & 1;  // conv2 / conv3: one 32 x 32 output tile per wave
-    const int m = mt * 32 + i < kM2 ? mt * 32 + i : kM2 - 1;
-    const int oy = m / kP2, ox = m % kP2;
-    // ---- conv2: 4 x 4 stride 2 pad 2 over act1 (21 x 21 x 32), K = 16 taps x 32
-    {
-        int ab[16];
-#pragma unroll
-        for (int tp = 0; tp < 16; tp++) {
-            const int iy = clampi(2 * oy - 2 + (tp >> 2), 0, kP1 - 1), ix = clampi(2 * ox - 2 + (tp & 3), 0, kP1 - 1);
-            ab[tp] = (iy * kP1 + ix) * kS1 + 16 * h;
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        tile_from_lds<16, 1>(a1, ab, wpk + kW1 + (nt * 4 * 64 + lane) * 4, acc);
-        const float bias = b2[nt * 32 + i];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int mm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (mm < kM2) {
-                float v = acc[r] + bias;
-                v = v > 0.f ? v : 0.f;
-                a2[mm * kS2 + nt * 32 + i] = v;
-                if (act2_out) act2_out[(b * kM2 + mm) * 64 + nt * 32 + i] = v;
-            }
-        }
-    }
-    stamp(5);
-    __syncthreads();
-    stamp(6);
-    // ---- conv3: 3 x 3 stride 1 pad 1 over act2 (11 x 11 x 64), K = 9 taps x 64
-    {
-        int ab[9];
-#pragma unroll
-        for (int tp = 0; tp < 9; tp++) {
-            const int iy = clampi(oy - 1 + tp / 3, 0, kP2 - 1), ix = clampi(ox - 1 + tp % 3, 0, kP2 - 1);
-            ab[tp] = (iy * kP2 + ix) * kS2 + 16 * h;
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        tile_from_lds<9, 2>(a2, ab, wpk + kW1 + kW2 + (nt * 4 * 64 + lane) * 4, acc);
+    // conv3's output tile (pixel tile mt, channel tile nt): bias + ReLU, then float32 act3 or its bf16 planes
+    auto store_act3 = [&](int mt, int nt, const f32x16 &acc) __attribute__((always_inline)) {
         const float bias = b3[nt * 32 + i];
         if (act3_planes) {
             // The FC1 GEMM of a chip-filling launch multiplies split-bf16 operands (srlx_qnet.hip:k_gemm_b16): write act3 as its three bf16 parts
@@ -406,6 +496,75 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
                 }
             }
         }
+    };
+    if constexpr (C23B16) {
+        const int blk = wave & 1, kq = wave >> 1;  // 64 x 64 output block (pixel tiles 2 blk, 2 blk + 1; both channel tiles) x K quarter
+        f32x16 acc4[2][2];
+        float *scratch = reinterpret_cast<float *>(fr);  // the staged frames are dead after conv1: 24 of their 31 KB park the K-quarter partials
+        const bf16x8 *wf2 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B), *wf3 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B + kW2B);
+        block_b16<2>(a1, wf2, blk, kq, lane, acc4);
+        stamp(5);
+        reduce_quarters(scratch, blk, kq, lane, acc4, [&](int mt, int nt, const f32x16 &sum) __attribute__((always_inline)) {
+            const float bias = b2[nt * 32 + i];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (mm < kM2) {
+                    float v = sum[r] + bias;
+                    v = v > 0.f ? v : 0.f;
+                    a2[mm * kS2 + nt * 32 + i] = v;
+                    if (act2_out) act2_out[(b * kM2 + mm) * 64 + nt * 32 + i] = v;
+                }
+            }
+        });
+        stamp(6);
+        block_b16<3>(a2, wf3, blk, kq, lane, acc4);
+        reduce_quarters(scratch, blk, kq, lane, acc4, store_act3);
+    } else {
+        const int mt = wave >> 1, nt = wave & 1;  // conv2 / conv3: one 32 x 32 output tile per wave
+        const int m = mt * 32 + i < kM2 ? mt * 32 + i : kM2 - 1;
+        const int oy = m / kP2, ox = m % kP2;
+        // ---- conv2: 4 x 4 stride 2 pad 2 over act1 (21 x 21 x 32), K = 16 taps x 32
+        {
+            int ab[16];
+    #pragma unroll
+            for (int tp = 0; tp < 16; tp++) {
+                const int iy = clampi(2 * oy - 2 + (tp >> 2), 0, kP1 - 1), ix = clampi(2 * ox - 2 + (tp & 3), 0, kP1 - 1);
+                ab[tp] = (iy * kP1 + ix) * kS1 + 16 * h;
+            }
+            f32x16 acc;
+    #pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            tile_from_lds<16, 1>(a1, ab, wpk + kW1 + (nt * 4 * 64 + lane) * 4, acc);
+            const float bias = b2[nt * 32 + i];
+    #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (mm < kM2) {
+                    float v = acc[r] + bias;
+                    v = v > 0.f ? v : 0.f;
+                    a2[mm * kS2 + nt * 32 + i] = v;
+                    if (act2_out) act2_out[(b * kM2 + mm) * 64 + nt * 32 + i] = v;
+                }
+            }
+        }
+        stamp(5);
+        __syncthreads();
+        stamp(6);
+        // ---- conv3: 3 x 3 stride 1 pad 1 over act2 (11 x 11 x 64), K = 9 taps x 64
+        {
+            int ab[9];
+    #pragma unroll
+            for (int tp = 0; tp < 9; tp++) {
+                const int iy = clampi(oy - 1 + tp / 3, 0, kP2 - 1), ix = clampi(ox - 1 + tp % 3, 0, kP2 - 1);
+                ab[tp] = (iy * kP2 + ix) * kS2 + 16 * h;
+            }
+            f32x16 acc;
+    #pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            tile_from_lds<9, 2>(a2, ab, wpk + kW1 + kW2 + (nt * 4 * 64 + lane) * 4, acc);
+            store_act3(mt, nt, acc);
+        }
     }
     stamp(7);
 }
@@ -417,8 +576,9 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     if (!(h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32)) return false;
     static bool attr_set = false;
     if (!attr_set) {
-        const void *kerns[] = {(const void *)k_convnet_fused<true, true>, (const void *)k_convnet_fused<false, true>, (const void *)k_convnet_fused<true, false>,
-                               (const void *)k_convnet_fused<false, false>};
+        const void *kerns[] = {(const void *)k_convnet_fused<true, true, true>,  (const void *)k_convnet_fused<false, true, true>,
+                               (const void *)k_convnet_fused<true, true, false>, (const void *)k_convnet_fused<false, true, false>,
+                               (const void *)k_convnet_fused<true, false, false>, (const void *)k_convnet_fused<false, false, false>};
         for (const void *kp : kerns)
             if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess) return false;
         attr_set = true;
@@ -427,7 +587,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
         if (hipMalloc((void **)&h->wpack, (size_t)kPackFloats * sizeof(float)) != hipSuccess) return false;
     }
     const bool keep = h->max_train > 0;  // a training handle: the backward pass reads act1 / act2 and the transposed filters
-    const int pack_threads = (kW1 + kW2 + kW3) / 4 + 16 * 64 + (keep ? kW3 + kW2 : 0);
+    const int pack_threads = (kW1 + kW2 + kW3) / 4 + 16 * 64 + (32 + 36) * 2 * 64 + (keep ? kW3 + kW2 : 0);
     hipLaunchKernelGGL(k_pack_filters, dim3((pack_threads + 255) / 256), dim3(256), 0, st, h->w1, h->w2, h->w3, h->wpack, keep ? h->w_t : nullptr,
                        keep ? h->w_t2 : nullptr);
     h->wt_from_forward = keep;
@@ -440,9 +600,10 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
         hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, h->act3, a3p,
                            (i64)h->max_batch * h->flat, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
     };
+    static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
     if (batch >= 512)
-        c1_f32 ? launch(k_convnet_fused<true, false>) : launch(k_convnet_fused<true, true>);
+        c1_f32 ? launch(k_convnet_fused<true, false, false>) : c23_f32 ? launch(k_convnet_fused<true, true, false>) : launch(k_convnet_fused<true, true, true>);
     else
-        c1_f32 ? launch(k_convnet_fused<false, false>) : launch(k_convnet_fused<false, true>);
+        c1_f32 ? launch(k_convnet_fused<false, false, false>) : c23_f32 ? launch(k_convnet_fused<false, true, false>) : launch(k_convnet_fused<false, true, true>);
     return hipGetLastError() == hipSuccess;
 }

@@ -240,33 +240,37 @@ __device__ __forceinline__ void block_b16(const float *__restrict__ lds_in, cons
     }
 }
 
-// Sums the four K-quarter partial blocks of every output tile through `scratch` (24 KB of LDS nobody else uses meanwhile): in round t the wave
-// with kq == t is the OWNER of tile t = (pixel tile t >> 1, channel tile t & 1) of its block -- the other three waves of the block park their
-// partial tile, the owner adds them in K order and runs `epilogue(pixel tile, channel tile, sum)`.  Four rounds, two barriers each.
-template <class F>
-__device__ __forceinline__ void reduce_quarters(float *__restrict__ scratch, int blk, int kq, int lane, f32x16 (&acc)[2][2], F epilogue) {
+// Sums the four K-quarter partial blocks of every output tile through `scratch` (24 KB of LDS nobody else uses meanwhile).  Wave (blk, kq) ends up
+// OWNING tile kq = (pixel tile kq >> 1, channel tile kq & 1) of its block: in round t the three other waves of a block park their partial of tile t
+// (four ds_write_b128 each), the owner adds them in K order.  Four rounds, two barriers each; the epilogues then run on all eight waves at once.
+__device__ __forceinline__ f32x16 reduce_quarters(float *__restrict__ scratch, int blk, int kq, int lane, f32x16 (&acc)[2][2]) {
+    float4 *sc = reinterpret_cast<float4 *>(scratch);
+    f32x16 sum;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        f32x16 &mine = acc[t >> 1][t & 1];
+        const f32x16 &mine = acc[t >> 1][t & 1];
         if (kq != t) {
             const int slot = blk * 3 + (kq < t ? kq : kq - 1);
 #pragma unroll
-            for (int r = 0; r < 16; r++) scratch[(slot * 16 + r) * 64 + lane] = mine[r];
+            for (int v = 0; v < 4; v++) sc[(slot * 4 + v) * 64 + lane] = make_float4(mine[4 * v], mine[4 * v + 1], mine[4 * v + 2], mine[4 * v + 3]);
         }
         __syncthreads();
         if (kq == t) {
-            f32x16 sum;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                float v = 0.f;
+            for (int v = 0; v < 4; v++) {
+                float4 part[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) v += k == t ? mine[r] : scratch[((blk * 3 + (k < t ? k : k - 1)) * 16 + r) * 64 + lane];  // K quarters in order
-                sum[r] = v;
+                for (int k = 0; k < 4; k++)
+                    part[k] = k == t ? make_float4(mine[4 * v], mine[4 * v + 1], mine[4 * v + 2], mine[4 * v + 3]) : sc[((blk * 3 + (k < t ? k : k - 1)) * 4 + v) * 64 + lane];
+                sum[4 * v] = ((part[0].x + part[1].x) + part[2].x) + part[3].x;  // K quarters in order
+                sum[4 * v + 1] = ((part[0].y + part[1].y) + part[2].y) + part[3].y;
+                sum[4 * v + 2] = ((part[0].z + part[1].z) + part[2].z) + part[3].z;
+                sum[4 * v + 3] = ((part[0].w + part[1].w) + part[2].w) + part[3].w;
             }
-            epilogue(2 * blk + (t >> 1), t & 1, sum);
         }
         __syncthreads();
     }
+    return sum;
 }
 
 // BIG = a launch of at least 512 samples (the actors' policy pass): a template parameter only so that profiles list the chip-filling
@@ -504,7 +508,9 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
         const bf16x8 *wf2 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B), *wf3 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B + kW2B);
         block_b16<2>(a1, wf2, blk, kq, lane, acc4);
         stamp(5);
-        reduce_quarters(scratch, blk, kq, lane, acc4, [&](int mt, int nt, const f32x16 &sum) __attribute__((always_inline)) {
+        const int mt = 2 * blk + (kq >> 1), nt = kq & 1;  // the tile this wave owns after the reduction
+        {
+            const f32x16 sum = reduce_quarters(scratch, blk, kq, lane, acc4);
             const float bias = b2[nt * 32 + i];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -516,10 +522,11 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
                     if (act2_out) act2_out[(b * kM2 + mm) * 64 + nt * 32 + i] = v;
                 }
             }
-        });
+        }
+        __syncthreads();  // act2 is complete
         stamp(6);
         block_b16<3>(a2, wf3, blk, kq, lane, acc4);
-        reduce_quarters(scratch, blk, kq, lane, acc4, store_act3);
+        store_act3(mt, nt, reduce_quarters(scratch, blk, kq, lane, acc4));
     } else {
         const int mt = wave >> 1, nt = wave & 1;  // conv2 / conv3: one 32 x 32 output tile per wave
         const int m = mt * 32 + i < kM2 ? mt * 32 + i : kM2 - 1;

@@ -492,17 +492,24 @@ def roofline(eng, ev_ms, conv_ms=0.0):
         cf = eng.conv_gemm_flops(with_conv1=fused)
         ctf = cf / (conv_ms * 1e-3) / 1e12
         c1_bf16 = fused and os.environ.get("SRLX_CONV1_F32", "0") != "1"
+        c23_bf16 = c1_bf16 and os.environ.get("SRLX_CONV23_F32", "0") != "1"
         mixed = None
         if c1_bf16:
-            # conv1 runs on the bf16 pipe as THREE exact partial products per multiply-add (pixel = one bf16, filter = three bf16 parts); conv2 / conv3 on
-            # the float32 pipe: the kernel's own time floor is the sum of the two pipes' floors
+            # float32 products evaluated on the bf16 pipe as exact partial products: conv1 THREE per multiply-add (the pixel is one bf16, the filter three
+            # parts), conv2 / conv3 SIX (three parts each side, p + q <= 2) -- or conv2 / conv3 on the float32 pipe (SRLX_CONV23_F32=1).  The kernel's own
+            # time floor is the sum of the pipes' floors.
             f23 = eng.conv_gemm_flops(with_conv1=False)
-            floor_ms = (3.0 * (cf - f23) / (MFMA_BF16_PEAK_TFLOPS * 1e12) + f23 / (MFMA_F32_PEAK_TFLOPS * 1e12)) * 1e3
-            mixed = {"floor_ms": floor_ms, "frac": floor_ms / conv_ms, "conv1_flops": cf - f23, "conv1_pipe": "bf16, 3 exact partial products per multiply-add, peak %.0f TFLOP/s dense"
-                     % MFMA_BF16_PEAK_TFLOPS, "conv2_conv3_flops": f23, "conv2_conv3_pipe": "f32, peak %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS}
+            t1 = 3.0 * (cf - f23) / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+            t23 = 6.0 * f23 / (MFMA_BF16_PEAK_TFLOPS * 1e12) if c23_bf16 else f23 / (MFMA_F32_PEAK_TFLOPS * 1e12)
+            floor_ms = (t1 + t23) * 1e3
+            mixed = {"floor_ms": floor_ms, "frac": floor_ms / conv_ms, "conv1_flops": cf - f23,
+                     "conv1_pipe": "bf16, 3 exact partial products per multiply-add, peak %.0f TFLOP/s dense" % MFMA_BF16_PEAK_TFLOPS, "conv2_conv3_flops": f23,
+                     "conv2_conv3_pipe": ("bf16, 6 exact partial products per multiply-add, peak %.0f TFLOP/s dense" % MFMA_BF16_PEAK_TFLOPS) if c23_bf16 else
+                     "f32, peak %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS}
         return {
-            "kernel": ("k_convnet_fused: conv1 -> conv2 -> conv3 of the actors' pass, one workgroup per sample, activations in LDS (1 launch per lock-step; conv2 / conv3 "
-                       "v_mfma_f32_32x32x2_f32, conv1 " + ("v_mfma_f32_32x32x16_bf16 on exact split operands" if c1_bf16 else "v_mfma_f32_32x32x2_f32") +
+            "kernel": ("k_convnet_fused: conv1 -> conv2 -> conv3 of the actors' pass, one workgroup per sample, activations in LDS (1 launch per lock-step; conv2 / conv3 " +
+                       ("v_mfma_f32_32x32x16_bf16 on exact split operands" if c23_bf16 else "v_mfma_f32_32x32x2_f32") + ", conv1 " +
+                       ("v_mfma_f32_32x32x16_bf16 on exact split operands" if c1_bf16 else "v_mfma_f32_32x32x2_f32") +
                        "); rocprofv3 check: this kernel's AverageNs in profiles/r2_kernel_stats.csv" if fused else
                        "k_gemm<AConv, 64, true, false, 128>: implicit-GEMM convolutions conv2 + conv3 of the actors' pass (2 launches per lock-step)"),
             "bound": "mfma",
@@ -516,11 +523,11 @@ def roofline(eng, ev_ms, conv_ms=0.0):
             "algorithmic_bytes_per_launch": (eng.cfg.n_envs if hasattr(eng, "cfg") else 0) * (4 * 7056 + 121 * 64 * 4) + 311296 if fused else None,
             "note": "timed inside the lock-step loop, where the learner's streams run beside it; `pass` = the whole network pass of the actors, "
                     "`pass.isolated` = that pass alone on an idle GPU; traffic = PMC bytes per launch from profiles/r2_pmc_traffic.json (isolated launches); "
-                    "`frac` = algorithmic FLOP/s over the float32 MFMA peak as in every earlier line -- with conv1 on the bf16 pipe that peak no longer bounds "
-                    "30 % of the flops: `mixed_roof.frac` = the kernel's own floor (both pipes) over its measured time",
+                    "`frac` = algorithmic FLOP/s over the float32 MFMA peak as in every earlier line -- with the layers evaluated on the bf16 pipe (as exact partial "
+                    "products: 3 or 6 MFMA flops per algorithmic flop) that peak is no longer the kernel's bound: `mixed_roof.frac` = the kernel's own floor over its measured time",
             "mixed_roof": mixed,
             "pass": group,
-            "dtype": "f32 results (conv1: exact split-bf16 products, f32 accumulate; everything else f32 in / f32 accumulate)" if c1_bf16 else "f32 in / f32 accumulate",
+            "dtype": "f32 results (float32 products as exact split-bf16 partial products, f32 accumulate)" if c1_bf16 else "f32 in / f32 accumulate",
         }
     group.update({"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "dtype": "f32 in / f32 accumulate"})
     return group

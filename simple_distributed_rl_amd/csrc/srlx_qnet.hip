@@ -366,34 +366,17 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
         }
 }
 
-// ---- FC1 at chip-filling batches on the bf16 matrix pipe: float32 x float32 from six exact partial products ------------------------
+// ---- FC1 on the bf16 matrix pipe: float32 x float32 from six exact partial products ---------------------------------------------------
 // A float32 is the sum of three bf16 parts exactly (8 + 8 + 8 mantissa bits; each remainder is exact in float32).  a * b is evaluated
 // as the six largest of the nine partial products a_p * b_q (p + q <= 2), each exact in the float32 accumulator of
 // v_mfma_f32_32x32x16_bf16; the three dropped ones are below 2^-24 |a b|, the size of float32's own rounding of the product.
-// 6 MFMAs of 32 cycles per 16 K against 8 of 64 on the float32 pipe: 2.7x less matrix time; the kernel is then bound by LDS reads
-// (18 ds_read_b128 per 24 MFMAs per wave).  k_split3 writes the parts as three bf16 planes [3][rows][K] (activations and weights, once
-// per forward: 63 MB read + 95 MB written at 1024 rows, ~25 us, against ~60 us saved); tiles and split-K as k_gemm.
-__global__ void __launch_bounds__(256) k_split3(const float *__restrict__ x, i64 n8, i64 plane, __bf16 *__restrict__ out) {
-    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n8) return;
-    const float4 v0 = reinterpret_cast<const float4 *>(x)[2 * i], v1 = reinterpret_cast<const float4 *>(x)[2 * i + 1];
-    float r[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    bf16x8 part[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const __bf16 b = (__bf16)r[j];
-            part[t][j] = b;
-            r[j] -= (float)b;
-        }
-#pragma unroll
-    for (int t = 0; t < 3; t++) reinterpret_cast<bf16x8 *>(out + t * plane)[i] = part[t];
-}
-
+// 6 MFMAs of 32 cycles per 16 K against 8 of 64 on the float32 pipe.  The splitting is done while STAGING: the operands are read as float32
+// (activation rows with a row stride, the weight in place), each thread turns its 24 floats per K-slab into three bf16 parts (~130 VALU
+// instructions, in the shadow of the slab's 24 MFMAs) and stores them to three plane tiles in LDS.  (Pre-split operand planes in HBM -- one
+// splitting pass over the 32 MB weight per forward, act3 written as planes by the convolution kernel -- were built first and measured slower inside
+// the lock-step loop: 0.573 against 0.545 ms.)  Tiles, split-K and XCD-aware order as k_gemm.
 constexpr int kRowB = 80;  // LDS bytes per tile row: 32 bf16 (64 B) + 16 B pad: the 16 lanes of a ds_read_b128 pass start 20 banks apart
-__global__ void __launch_bounds__(256) k_gemm_b16(const __bf16 *__restrict__ Ap, i64 a_plane, const __bf16 *__restrict__ Wp, i64 w_plane, float *__restrict__ C, i64 M, int N,
-                                                  int K, int k_per_split) {
+__global__ void __launch_bounds__(256) k_gemm_s16(const float *__restrict__ A, i64 lda, const float *__restrict__ Bw, float *__restrict__ C, i64 M, int N, int K, int k_per_split) {
     constexpr int TBM = 128, BN = 64, MT = 2;
     __shared__ __attribute__((aligned(16))) unsigned char As[3 * TBM * kRowB];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BN * kRowB];
@@ -415,28 +398,41 @@ __global__ void __launch_bounds__(256) k_gemm_b16(const __bf16 *__restrict__ Ap,
     for (int a = 0; a < MT; a++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
-    const int srow = t >> 2, sch = t & 3;  // staging: this lane copies 16 bytes (8 k) of rows srow (+ 64) per plane
-    uint4 ra[3][2], rb[3];
+    const int lrow = t >> 3, c4 = (t & 7) * 4;  // this lane stages rows lrow + 32 j, columns c4..c4+3 of a tile (as k_gemm)
+    float4 ra[4], rb[2];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
+        for (int j = 0; j < 4; j++) {
+            const i64 m = m0 + lrow + 32 * j;
+            ra[j] = m < M ? *reinterpret_cast<const float4 *>(A + m * lda + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const i64 m = m0 + srow + 64 * q;
-                ra[p][q] = m < M ? *reinterpret_cast<const uint4 *>(Ap + p * a_plane + m * K + k0 + 8 * sch) : make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < 2; j++) {
+            const int n = n0 + lrow + 32 * j;
+            rb[j] = n < N ? *reinterpret_cast<const float4 *>(Bw + (i64)n * K + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto put = [&](unsigned char *tile, int rows, int row, const float4 &x) __attribute__((always_inline)) {  // three bf16 parts of four floats -> the three plane tiles
+        float r[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 part;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const __bf16 b = (__bf16)r[j];
+                part[j] = b;
+                r[j] -= (float)b;
             }
-            const int n = n0 + srow;
-            rb[p] = n < N ? *reinterpret_cast<const uint4 *>(Wp + p * w_plane + (i64)n * K + k0 + 8 * sch) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<bf16x4 *>(&tile[(p * rows + row) * kRowB + 2 * c4]) = part;
         }
     };
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
+        for (int j = 0; j < 4; j++) put(As, TBM, lrow + 32 * j, ra[j]);
 #pragma unroll
-            for (int q = 0; q < 2; q++) *reinterpret_cast<uint4 *>(&As[(p * TBM + srow + 64 * q) * kRowB + 16 * sch]) = ra[p][q];
-            *reinterpret_cast<uint4 *>(&Bs[(p * BN + srow) * kRowB + 16 * sch]) = rb[p];
-        }
+        for (int j = 0; j < 2; j++) put(Bs, BN, lrow + 32 * j, rb[j]);
         lds_barrier();
         if (k0 + BK < kend) fetch(k0 + BK);  // overlaps with the MFMAs below
 #pragma unroll
@@ -449,7 +445,6 @@ __global__ void __launch_bounds__(256) k_gemm_b16(const __bf16 *__restrict__ Ap,
             for (int ms = 0; ms < MT; ms++)
 #pragma unroll
                 for (int p = 0; p < 3; p++) af[ms][p] = *reinterpret_cast<const bf16x8 *>(&As[(p * TBM + wm * 64 + ms * 32 + i) * kRowB + (2 * ks + h) * 16]);
-            // smallest partial products first; the two accumulators alternate so that no MFMA waits for the one issued just before it
             constexpr int pq[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
 #pragma unroll
             for (int c = 0; c < 6; c++)
@@ -671,17 +666,10 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     if (splits < 1) splits = 1;
     const int kps = ((ksteps + splits - 1) / splits);
     const int used = (ksteps + kps - 1) / kps;  // splits that actually own a K range
-    static const bool fc1_f32 = getenv("SRLX_FC1_F32") && getenv("SRLX_FC1_F32")[0] == '1';  // A/B switch: FC1 on the float32 matrix pipe at every batch
-    if (B >= 512 && stride == 1 && h->planes && !fc1_f32) {
-        // the actors' launches: float32 x float32 as six exact bf16 partial products (k_gemm_b16); the learner's 96 / 128 rows stay on k_gemm
-        const i64 a_plane = (i64)h->max_batch * h->flat, w_plane = (i64)N1 * h->flat;
-        SRLX_REQUIRE(h->planes, "qnet_forward: the split-bf16 operand buffer is missing");
-        __bf16 *ap = (__bf16 *)h->planes, *wp = ap + 3 * a_plane;
-        const i64 a8 = B * h->flat / 8, w8 = w_plane / 8;
-        if (!h->act3_in_planes) hipLaunchKernelGGL(k_split3, dim3((unsigned)((a8 + 255) / 256)), dim3(256), 0, st, h->act3, a8, a_plane, ap);
-        hipLaunchKernelGGL(k_split3, dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, h->wf, w8, w_plane, wp);
+    static const bool fc1_f32 = getenv("SRLX_FC1_F32") && getenv("SRLX_FC1_F32")[0] == '1';  // A/B switch: FC1 on the float32 matrix pipe
+    if (!fc1_f32 && h->flat % BK == 0) {
         const dim3 grid((unsigned)((B + 127) / 128), (unsigned)((N1 + 63) / 64), (unsigned)splits);
-        hipLaunchKernelGGL(k_gemm_b16, grid, dim3(256), 0, st, ap, a_plane, wp, w_plane, h->partial, B, N1, h->flat, kps * BK);
+        hipLaunchKernelGGL(k_gemm_s16, grid, dim3(256), 0, st, h->act3, (i64)h->flat * stride, h->wf, h->partial, B, N1, h->flat, kps * BK);
     } else {
         APlain fa{h->act3, (i64)h->flat * stride};
         launch_gemm<APlain, 64, false, true>(fa, h->wf, nullptr, h->partial, B, N1, h->flat, splits, st);
@@ -748,14 +736,6 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
                 {&h->act3, (size_t)max_batch * h->flat},
                 // FC1 split-K partial sums: splits(B) * B <= 4096 + B for every batch B (see run_tail)
                 {&h->partial, (size_t)(4096 + 128 + max_batch) * 2 * hidden}};
-    if (max_batch >= 512 && h->flat % 8 == 0) {  // chip-filling launches run FC1 on split-bf16 operands (k_gemm_b16): three bf16 planes of act3 and of the weight
-        hipError_t e = hipMalloc(&h->planes, (size_t)3 * ((size_t)max_batch * h->flat + (size_t)2 * hidden * h->flat) * sizeof(__bf16));
-        if (e != hipSuccess) {
-            srlx::set_error("qnet_create: %s", hipGetErrorString(e));
-            srlx_qnet_destroy(h);
-            return e == hipErrorOutOfMemory ? SRLX_ERR_NOMEM : SRLX_ERR_HIP;
-        }
-    }
     for (auto &b : bufs) {
         hipError_t e = hipMalloc((void **)b.p, b.n * f);
         if (e != hipSuccess) {
@@ -779,7 +759,6 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
         if (p) (void)hipFree(p);
     if (h->d_draw) (void)hipFree(h->d_draw);
     if (h->wpack) (void)hipFree(h->wpack);
-    if (h->planes) (void)hipFree(h->planes);
     if (h->side && !h->side_external) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join, h->ev_wt})
         if (e) (void)hipEventDestroy(e);
@@ -827,13 +806,12 @@ static int forward_u8_impl(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame
     if (!no_fused && h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32) {
         // conv1 -> conv2 -> conv3 in one kernel, one workgroup per sample, activations in LDS (srlx_qnet_fused.hip)
         if (h->probe0) SRLX_HIP(hipEventRecord(h->probe0, st));
-        SRLX_REQUIRE(srlx_qnet_fused_convs(h, batch, d_frame_base, d_frame_off, st, d_q != nullptr), "qnet_forward_u8: launching the fused convolution kernel failed");
+        SRLX_REQUIRE(srlx_qnet_fused_convs(h, batch, d_frame_base, d_frame_off, st), "qnet_forward_u8: launching the fused convolution kernel failed");
         if (h->probe1) SRLX_HIP(hipEventRecord(h->probe1, st));
         h->probe0 = h->probe1 = nullptr;
         return d_q ? run_dense(h, batch, d_q, st) : SRLX_OK;
     }
     h->wt_from_forward = false;
-    h->act3_in_planes = false;
     const size_t lds = (size_t)h->Wn * kC1Frame;
     if (h->F1 == 32 && h->Wn == 4 && 4 * (h->OH1 - 1) + 8 <= kC1Pad && 4 * (h->OW1 - 1) + 8 <= kC1Pad && h->W % 4 == 0) {
         // one workgroup per sample, frames + filters staged in LDS

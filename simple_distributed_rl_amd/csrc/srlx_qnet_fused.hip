@@ -278,7 +278,7 @@ __device__ __forceinline__ f32x16 reduce_quarters(float *__restrict__ scratch, i
 template <bool BIG, bool C1B16, bool C23B16>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
-                                                                float *__restrict__ act3, __bf16 *__restrict__ act3_planes, i64 a_plane,
+                                                                float *__restrict__ act3,
                                                                 float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u8 *fr = smem;                                                 // [4][88][88]
@@ -460,44 +460,15 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     stamp(3);
     __syncthreads();
     stamp(4);
-    // conv3's output tile (pixel tile mt, channel tile nt): bias + ReLU, then float32 act3 or its bf16 planes
+    // conv3's output tile (pixel tile mt, channel tile nt): bias + ReLU, act3 to HBM
     auto store_act3 = [&](int mt, int nt, const f32x16 &acc) __attribute__((always_inline)) {
         const float bias = b3[nt * 32 + i];
-        if (act3_planes) {
-            // The FC1 GEMM of a chip-filling launch multiplies split-bf16 operands (srlx_qnet.hip:k_gemm_b16): write act3 as its three bf16 parts
-            // right here instead of as float32 for a splitting pass to re-read.  Two channels per dword: lanes i, i ^ 1 exchange their parts;
-            // the even lane stores the even accumulator rows, the odd lane the odd ones.
-            unsigned *dst = reinterpret_cast<unsigned *>(act3_planes);
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                float v = acc[r] + bias;
-                v = v > 0.f ? v : 0.f;
-                unsigned part[3];
-#pragma unroll
-                for (int t = 0; t < 3; t++) {
-                    const __bf16 pb = (__bf16)v;
-                    v -= (float)pb;
-                    part[t] = (unsigned)__builtin_bit_cast(unsigned short, pb);
-                }
-                const unsigned mine01 = part[0] | (part[1] << 16), theirs01 = (unsigned)__shfl_xor((int)mine01, 1), theirs2 = (unsigned)__shfl_xor((int)part[2], 1);
-                const int mm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (mm < kM2 && ((r ^ i) & 1) == 0) {  // even lane: even r; odd lane: odd r
-                    const unsigned lo01 = (i & 1) ? theirs01 : mine01, hi01 = (i & 1) ? mine01 : theirs01;  // channel i & ~1 in the low half
-                    const unsigned lo2 = (i & 1) ? theirs2 : part[2], hi2 = (i & 1) ? part[2] : theirs2;
-                    const i64 at = ((b * kM2 + mm) * 64 + nt * 32 + (i & ~1)) / 2;  // dword index inside a plane
-                    dst[at] = (lo01 & 0xffffu) | (hi01 << 16);
-                    dst[a_plane / 2 + at] = (lo01 >> 16) | (hi01 & 0xffff0000u);
-                    dst[a_plane + at] = (lo2 & 0xffffu) | (hi2 << 16);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int mm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (mm < kM2) {
-                    const float v = acc[r] + bias;
-                    act3[(b * kM2 + mm) * 64 + nt * 32 + i] = v > 0.f ? v : 0.f;
-                }
+        for (int r = 0; r < 16; r++) {
+            const int mm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mm < kM2) {
+                const float v = acc[r] + bias;
+                act3[(b * kM2 + mm) * 64 + nt * 32 + i] = v > 0.f ? v : 0.f;
             }
         }
     };
@@ -579,7 +550,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
 }  // namespace
 
 // Launcher: true when the fused kernel covers this handle's geometry (then act3 -- and act1 / act2 when training is enabled -- are valid).
-bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st, bool want_planes) {
+bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st) {
     if (!(h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32)) return false;
     static bool attr_set = false;
     if (!attr_set) {
@@ -598,14 +569,10 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     hipLaunchKernelGGL(k_pack_filters, dim3((pack_threads + 255) / 256), dim3(256), 0, st, h->w1, h->w2, h->w3, h->wpack, keep ? h->w_t : nullptr,
                        keep ? h->w_t2 : nullptr);
     h->wt_from_forward = keep;
-    // a chip-filling launch of an inference handle feeds the split-bf16 FC1 GEMM: act3 leaves the kernel as bf16 planes (h->act3 is then NOT written)
-    static const bool fc1_f32 = getenv("SRLX_FC1_F32") && getenv("SRLX_FC1_F32")[0] == '1';
-    __bf16 *a3p = (batch >= 512 && h->planes && !keep && !fc1_f32 && want_planes) ? (__bf16 *)h->planes : nullptr;
-    h->act3_in_planes = a3p != nullptr;
     static const bool c1_f32 = getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1';  // A/B switch: conv1 on the float32 matrix pipe
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, h->act3, a3p,
-                           (i64)h->max_batch * h->flat, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
+        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, h->act3,
+                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
     };
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
     if (batch >= 512)

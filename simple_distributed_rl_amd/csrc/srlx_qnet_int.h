@@ -10,8 +10,6 @@ struct srlx_qnet {
     int flat;  // OH3*OW3*2*F1
     const float *w1, *b1, *w2, *b2, *w3, *b3, *wf, *bf, *v2w, *v2b, *a2w, *a2b;  // BORROWED: the torch parameters themselves
     float *act1, *act2, *act3, *partial;
-    bool act3_in_planes;  // the last convolution pass wrote act3 as bf16 planes into `planes` (not as float32 into act3)
-    void *planes;  // split-bf16 operands of the FC1 GEMM at chip-filling batches (allocated on first use): [3][max_batch][flat] activations, [3][2*hidden][flat] weights
     int max_splits;
     // training (srlx_qnet_enable_training): post-ReLU hidden layer of every forward row + gradient scratch
     int64_t max_train;
@@ -52,8 +50,7 @@ int srlx_qnet_noisy_sigma_grads(srlx_qnet *h, float *const *g, hipStream_t st);
 int srlx_qnet_dense_rows(srlx_qnet *h, int64_t rows, int64_t stride, float *d_q, hipStream_t st);
 
 // srlx_qnet_fused.hip: conv1 -> conv2 -> conv3 in one kernel (activations in LDS); false when the geometry is not the Atari one
-// want_planes: the caller goes on to the dense layers (act3 may leave the kernel as the split-bf16 planes of k_gemm_b16, h->act3_in_planes, instead of float32)
-bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st, bool want_planes);
+bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st);
 
 // implicit-GEMM data gradient on the matrix cores (defined next to k_gemm in srlx_qnet.hip)
 int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,

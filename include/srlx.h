@@ -410,8 +410,8 @@ int srlx_store_gather_obs(srlx_store_t *h, int64_t batch, int k_begin, int k_cou
  * Arithmetic: v_mfma_f32_32x32x2_f32 (products of two float32 operands), except where a float32 product is evaluated
  * on the 16x faster bf16 pipe (v_mfma_f32_32x32x16_bf16) as a sum of EXACT partial products -- a float32 is the sum of three bf16
  * parts exactly, a product of two bf16 is exact in the float32 accumulator: conv1 of the 84x84x4 geometry (the uint8 pixel is one
- * bf16, the filter / 255 three parts: all three products kept), conv2 / conv3 of that geometry and the first dense layer of launches
- * of >= 512 rows (six of the nine partial products; the dropped ones are below 2^-24 |a b|).  Q-values agree with the all-float32 pipe to float32 round-off (< 1e-6
+ * bf16, the filter / 255 three parts: all three products kept), conv2 / conv3 of that geometry and the first dense layer
+ * (six of the nine partial products; the dropped ones are below 2^-24 |a b|).  Q-values agree with the all-float32 pipe to float32 round-off (< 1e-6
  * relative; the tolerance promised against the reference is 1e-5).  Environment switches SRLX_CONV1_F32=1 (all convolutions) / SRLX_CONV23_F32=1 /
  * SRLX_FC1_F32=1 (read once per process) keep them on the float32 pipe.
  *

@@ -376,13 +376,19 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
 // splitting pass over the 32 MB weight per forward, act3 written as planes by the convolution kernel -- were built first and measured slower inside
 // the lock-step loop: 0.573 against 0.545 ms.)  Tiles, split-K and XCD-aware order as k_gemm.
 constexpr int kRowB = 80;  // LDS bytes per tile row: 32 bf16 (64 B) + 16 B pad: the 16 lanes of a ds_read_b128 pass start 20 banks apart
-__global__ void __launch_bounds__(256) k_gemm_s16(const float *__restrict__ A, i64 lda, const float *__restrict__ Bw, float *__restrict__ C, i64 M, int N, int K, int k_per_split) {
-    constexpr int TBM = 128, BN = 64, MT = 2;
+template <class AL, int BN, bool SPLITK, int TBM = 128>
+__global__ void __launch_bounds__(256) k_gemm_s16(AL al, const float *__restrict__ Bw, float *__restrict__ C, i64 M, int N, int K, int k_per_split, i64 zstride_w = 0,
+                                                  i64 zstride_c = 0) {
+    if (!SPLITK) {  // batched GEMMs (blockIdx.z): same A loader, one weight matrix and one output per z
+        Bw += blockIdx.z * zstride_w;
+        C += blockIdx.z * zstride_c;
+    }
+    constexpr int WN = BN / 32, WM = 4 / WN, MT = TBM / (32 * WM), NB = BN / 32, MR = TBM / 32;
     __shared__ __attribute__((aligned(16))) unsigned char As[3 * TBM * kRowB];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BN * kRowB];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    {   // XCD-aware tile order (see k_gemm)
+    if (SPLITK) {  // XCD-aware tile order (see k_gemm)
         const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
         if (total % 8 == 0) {
             const unsigned lin = bx + gx * (by + gy * bz), tile = (lin % 8) * (total / 8) + lin / 8;
@@ -391,28 +397,29 @@ __global__ void __launch_bounds__(256) k_gemm_s16(const float *__restrict__ A, i
     }
     const i64 m0 = (i64)bx * TBM;
     const int n0 = by * BN;
-    const int kbeg = bz * k_per_split, kend = kbeg + k_per_split < K ? kbeg + k_per_split : K;
-    const int wn = wave & 1, wm = wave >> 1;
+    const int kbeg = SPLITK ? bz * k_per_split : 0;
+    const int kend = SPLITK ? (kbeg + k_per_split < K ? kbeg + k_per_split : K) : K;
+    const int wn = wave % WN, wm = wave / WN;
     f32x16 acc[MT];
 #pragma unroll
     for (int a = 0; a < MT; a++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
     const int lrow = t >> 3, c4 = (t & 7) * 4;  // this lane stages rows lrow + 32 j, columns c4..c4+3 of a tile (as k_gemm)
-    float4 ra[4], rb[2];
+    typename AL::Row rows[MR];
+#pragma unroll
+    for (int j = 0; j < MR; j++) rows[j] = al.row(m0 + lrow + 32 * j, M);
+    float4 ra[MR], rb[NB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const i64 m = m0 + lrow + 32 * j;
-            ra[j] = m < M ? *reinterpret_cast<const float4 *>(A + m * lda + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int j = 0; j < MR; j++) ra[j] = al.load4(rows[j], k0, c4);
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < NB; j++) {
             const int n = n0 + lrow + 32 * j;
             rb[j] = n < N ? *reinterpret_cast<const float4 *>(Bw + (i64)n * K + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto put = [&](unsigned char *tile, int rows, int row, const float4 &x) __attribute__((always_inline)) {  // three bf16 parts of four floats -> the three plane tiles
+    auto put = [&](unsigned char *tile, int rows_, int row, const float4 &x) __attribute__((always_inline)) {  // three bf16 parts of four floats -> the three plane tiles
         float r[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int p = 0; p < 3; p++) {
@@ -424,15 +431,15 @@ __global__ void __launch_bounds__(256) k_gemm_s16(const float *__restrict__ A, i
                 part[j] = b;
                 r[j] -= (float)b;
             }
-            *reinterpret_cast<bf16x4 *>(&tile[(p * rows + row) * kRowB + 2 * c4]) = part;
+            *reinterpret_cast<bf16x4 *>(&tile[(p * rows_ + row) * kRowB + 2 * c4]) = part;
         }
     };
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) put(As, TBM, lrow + 32 * j, ra[j]);
+        for (int j = 0; j < MR; j++) put(As, TBM, lrow + 32 * j, ra[j]);
 #pragma unroll
-        for (int j = 0; j < 2; j++) put(Bs, BN, lrow + 32 * j, rb[j]);
+        for (int j = 0; j < NB; j++) put(Bs, BN, lrow + 32 * j, rb[j]);
         lds_barrier();
         if (k0 + BK < kend) fetch(k0 + BK);  // overlaps with the MFMAs below
 #pragma unroll
@@ -444,7 +451,8 @@ __global__ void __launch_bounds__(256) k_gemm_s16(const float *__restrict__ A, i
 #pragma unroll
             for (int ms = 0; ms < MT; ms++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) af[ms][p] = *reinterpret_cast<const bf16x8 *>(&As[(p * TBM + wm * 64 + ms * 32 + i) * kRowB + (2 * ks + h) * 16]);
+                for (int p = 0; p < 3; p++) af[ms][p] = *reinterpret_cast<const bf16x8 *>(&As[(p * TBM + wm * 32 * MT + ms * 32 + i) * kRowB + (2 * ks + h) * 16]);
+            // smallest partial products first; the accumulators alternate so that no MFMA waits for the one issued just before it
             constexpr int pq[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
 #pragma unroll
             for (int c = 0; c < 6; c++)
@@ -453,13 +461,13 @@ __global__ void __launch_bounds__(256) k_gemm_s16(const float *__restrict__ A, i
         }
         lds_barrier();
     }
-    float *Cz = C + (i64)bz * M * N;
+    float *Cz = SPLITK ? C + (i64)bz * M * N : C;
     const int n = n0 + wn * 32 + i;
 #pragma unroll
     for (int ms = 0; ms < MT; ms++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const i64 m = m0 + wm * 64 + ms * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const i64 m = m0 + wm * 32 * MT + ms * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m < M && n < N) Cz[m * N + n] = acc[ms][r];
         }
 }
@@ -669,7 +677,8 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     static const bool fc1_f32 = getenv("SRLX_FC1_F32") && getenv("SRLX_FC1_F32")[0] == '1';  // A/B switch: FC1 on the float32 matrix pipe
     if (!fc1_f32 && h->flat % BK == 0) {
         const dim3 grid((unsigned)((B + 127) / 128), (unsigned)((N1 + 63) / 64), (unsigned)splits);
-        hipLaunchKernelGGL(k_gemm_s16, grid, dim3(256), 0, st, h->act3, (i64)h->flat * stride, h->wf, h->partial, B, N1, h->flat, kps * BK);
+        APlain fa{h->act3, (i64)h->flat * stride};
+        hipLaunchKernelGGL((k_gemm_s16<APlain, 64, true>), grid, dim3(256), 0, st, fa, h->wf, h->partial, B, N1, h->flat, kps * BK);
     } else {
         APlain fa{h->act3, (i64)h->flat * stride};
         launch_gemm<APlain, 64, false, true>(fa, h->wf, nullptr, h->partial, B, N1, h->flat, splits, st);
@@ -691,12 +700,19 @@ int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW,
     a.fill_taps(K, KW / S);
     const i64 M = (i64)B * QH * QW;
     const unsigned Z = (unsigned)(S * S);
+    static const bool dgrad_f32 = getenv("SRLX_DGRAD_F32") && getenv("SRLX_DGRAD_F32")[0] == '1';  // A/B switch: the data-gradient GEMMs on the float32 matrix pipe
     if (CI == 64) {
         dim3 grid((unsigned)((M + 63) / 64), 1, Z);
-        hipLaunchKernelGGL((k_gemm<ADgrad, 64, false, false, 64>), grid, dim3(256), 0, st, a, wT, nullptr, dXq, M, CI, K, K, (i64)CI * K, M * CI);
+        if (dgrad_f32)
+            hipLaunchKernelGGL((k_gemm<ADgrad, 64, false, false, 64>), grid, dim3(256), 0, st, a, wT, nullptr, dXq, M, CI, K, K, (i64)CI * K, M * CI);
+        else  // six exact bf16 partial products, operands split while staging (k_gemm_s16)
+            hipLaunchKernelGGL((k_gemm_s16<ADgrad, 64, false, 64>), grid, dim3(256), 0, st, a, wT, dXq, M, CI, K, K, (i64)CI * K, M * CI);
     } else {
         dim3 grid((unsigned)((M + BM - 1) / BM), 1, Z);
-        hipLaunchKernelGGL((k_gemm<ADgrad, 32, false, false>), grid, dim3(256), 0, st, a, wT, nullptr, dXq, M, CI, K, K, (i64)CI * K, M * CI);
+        if (dgrad_f32)
+            hipLaunchKernelGGL((k_gemm<ADgrad, 32, false, false>), grid, dim3(256), 0, st, a, wT, nullptr, dXq, M, CI, K, K, (i64)CI * K, M * CI);
+        else
+            hipLaunchKernelGGL((k_gemm_s16<ADgrad, 32, false>), grid, dim3(256), 0, st, a, wT, dXq, M, CI, K, K, (i64)CI * K, M * CI);
     }
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

@@ -178,11 +178,12 @@ def test_backward_u8_matches_autograd(A, dueling, B, stride, hw, hidden):
         np.testing.assert_allclose(p.grad.cpu().numpy(), w.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg=name)
 
 
-def test_conv1_on_the_bf16_pipe_equals_the_float32_pipe(tmp_path):
-    """The fused kernel's conv1 runs on v_mfma_f32_32x32x16_bf16 with the pixel as ONE bf16 and the filter / 255 as three bf16 parts (exact partial
-    products, float32 accumulation).  Against the same kernel with conv1 on the float32 pipe (SRLX_CONV1_F32=1; switches are read once per
-    process, hence the subprocesses): Q-values within 2e-6 of max |Q| -- float32 round-off of a different summation order; and the float32-pipe
-    fused kernel stays bit-identical to the three-launch path."""
+def test_the_bf16_pipe_equals_the_float32_pipe(tmp_path):
+    """The forward pass evaluates its float32 products on v_mfma_f32_32x32x16_bf16 as exact partial products of bf16 parts (conv1: the pixel is ONE
+    bf16, the filter / 255 three parts; conv2 / conv3 and FC1: six of the nine products of three parts each), float32 accumulation.  Against the same
+    kernels on the float32 pipe (SRLX_CONV1_F32=1 for the convolutions, SRLX_FC1_F32=1 for the dense layer; switches are read once per process, hence
+    the subprocesses): Q-values within 2e-6 of max |Q| -- float32 round-off of different summation orders; and the float32-pipe fused kernel stays
+    bit-identical to the three-launch path."""
     script = (
         "import sys, torch\n"
         "sys.path.insert(0, %r)\n"
@@ -198,14 +199,16 @@ def test_conv1_on_the_bf16_pipe_equals_the_float32_pipe(tmp_path):
         "torch.save(qn.forward_u8(ring.data_ptr(), off).cpu(), sys.argv[1])\n" % ROOT
     )
     outs = {}
-    for name, env in (("bf16", {}), ("f32", {"SRLX_CONV1_F32": "1"}), ("three_launches", {"SRLX_NO_FUSED_CONV": "1"})):
+    for name, env in (("bf16", {}), ("f32", {"SRLX_CONV1_F32": "1"}), ("three_launches", {"SRLX_NO_FUSED_CONV": "1"}),
+                      ("all_f32", {"SRLX_CONV1_F32": "1", "SRLX_FC1_F32": "1"}), ("convs_bf16_only", {"SRLX_FC1_F32": "1"})):
         path = str(tmp_path / f"q_{name}.pt")
-        e = {k: v for k, v in os.environ.items() if k not in ("SRLX_CONV1_F32", "SRLX_NO_FUSED_CONV")}
+        e = {k: v for k, v in os.environ.items() if k not in ("SRLX_CONV1_F32", "SRLX_CONV23_F32", "SRLX_FC1_F32", "SRLX_NO_FUSED_CONV")}
         e.update(env)
         r = subprocess.run([sys.executable, "-c", script, path], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = torch.load(path)
     assert torch.equal(outs["f32"], outs["three_launches"])
-    scale = float(outs["f32"].abs().max())
-    diff = float((outs["bf16"] - outs["f32"]).abs().max())
-    assert 0 < scale and diff <= 2e-6 * scale, (diff, scale)
+    scale = float(outs["all_f32"].abs().max())
+    for a, b in (("bf16", "f32"), ("bf16", "all_f32"), ("convs_bf16_only", "all_f32"), ("f32", "all_f32")):
+        diff = float((outs[a] - outs[b]).abs().max())
+        assert 0 < scale and 0 < diff <= 2e-6 * scale, (a, b, diff, scale)

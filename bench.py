@@ -586,7 +586,7 @@ def per_micro(eng, draws=1 << 20, reps=20):
     out = {"kernel": "per_sample bulk (k_descend_bulk + k_compact_bulk: normalising pass, or device-wide ordered compaction when a draw is rejected)",
            "bytes_per_draw": bytes_per_draw, "state_bytes_per_draw": state_bytes_per_draw, "hbm_peak_GBs": HBM_PEAK_GBS}
     out.update(one(draws, reps))
-    out["by_draws"] = [one(1 << 22, 10), one(1 << 24, 5)]
+    out["by_draws"] = [one(1 << 21, 10), one(1 << 22, 10), one(1 << 24, 5)]  # the fixed cost of the three launches is 13 us: 2^21 draws is where the call crosses 50 %
     # ---- the three operations at training sizes
     ops = {}
     for B in (32, 64):

@@ -225,3 +225,31 @@ def test_engine_learns_a_cue_task():
     torch.cuda.synchronize()
     score = env.reward_sum / env.reward_n
     assert score > 0.8, f"greedy score {score:.3f} after {eng.train_count} updates (random play: -0.5)"
+
+
+def test_graph_replays_are_bit_stable_without_host_synchronisation():
+    """The captured actor / learner graphs replayed back to back (as bench.py and the Runner drivers do) against one host synchronisation per
+    lock-step: parameters, loss, train count and priorities bit-equal after 300 lock-steps with the two-stream overlap on (the PPO engine's
+    large torch-captured graphs were NOT stable that way: device/ppo.py:step)."""
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+
+    def run(sync):
+        cfg = RainbowDeviceConfig(n_envs=64, batch_size=32, memory_capacity=20_000, memory_warmup_size=500, seed=0)
+        eng = RainbowEngine(cfg, 0, 50, overlap=True)
+        eng.prefill()
+        for _ in range(5):
+            eng.step(1)
+        torch.cuda.synchronize()
+        eng.capture_graphs()
+        for _ in range(300):
+            eng.step(1)
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in eng.q_online.parameters()], float(eng.loss), int(eng.train_count_dev), eng.priorities.clone()
+
+    pa, la, ca, ra = run(True)
+    pb, lb, cb, rb = run(False)
+    assert ca == cb and ca >= 300 and la == lb and torch.equal(ra, rb)
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)

@@ -331,12 +331,20 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     //      16 K instead of 8 of 64: the layer's matrix time drops 5.3x; what remains is the LDS / conversion stream (two dwords and twelve
     //      VALU instructions per step).  Step s = (frame c = s >> 2, kernel rows 2 (s & 3) + h), a lane's 8 k = the 8 kernel columns.
     if constexpr (C1B16) {
-        bf16x8 bw[16][3];
-        const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3) + lane;
+        // Filter fragments: every wave needs all 48 KB of them.  Fetched per wave they cost the CU's load path 384 KB per sample (4.8 k clocks of the
+        // staging phase).  The act2 region of LDS is idle until conv2: the workgroup fetches parts 0 and 1 of all 16 steps ONCE into it (32 KB,
+        // [step][part][lane] x 16 B), only part 2 stays in registers (16 x 16 B per lane).
+        bf16x8 bw2[16];
+        const bf16x8 *wsrc = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3);
+        bf16x8 *wl = reinterpret_cast<bf16x8 *>(a2);
+        static_assert(16 * 2 * 64 * 16 <= kM2 * kS2 * 4, "conv1's shared filter parts must fit into the act2 region");
 #pragma unroll
-        for (int sp = 0; sp < 16; sp++)
+        for (int j = 0; j < 4; j++) {
+            const int e = t + NT * j, l = e & 63, sp2 = e >> 6;  // sp2 = step * 2 + part
+            wl[e] = wsrc[((sp2 >> 1) * 3 + (sp2 & 1)) * 64 + l];
+        }
 #pragma unroll
-            for (int q = 0; q < 3; q++) bw[sp][q] = wp[(sp * 3 + q) * 64];
+        for (int sp = 0; sp < 16; sp++) bw2[sp] = wsrc[(sp * 3 + 2) * 64 + lane];
         const float bias = b1[i];
         stamp(1);
         __syncthreads();
@@ -350,21 +358,27 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
-            uint2 wa, wb;
-            auto fetch = [&](int sp, uint2 &w) __attribute__((always_inline)) {
+            struct Step {
+                unsigned x, y;   // the lane's 8 pixels
+                bf16x8 f0, f1;   // filter parts 0 / 1 of the step (LDS)
+            } wa, wb;
+            auto fetch = [&](int sp, Step &w) __attribute__((always_inline)) {
                 const u8 *p = win + (sp >> 2) * kFrame + 2 * (sp & 3) * kPad;
                 w.x = *reinterpret_cast<const unsigned *>(p);
                 w.y = *reinterpret_cast<const unsigned *>(p + 4);
+                w.f0 = wl[(sp * 2) * 64 + lane];
+                w.f1 = wl[(sp * 2 + 1) * 64 + lane];
             };
-            auto mfma3 = [&](int sp, const uint2 &w) __attribute__((always_inline)) {
+            auto mfma3 = [&](int sp, const Step &w) __attribute__((always_inline)) {
                 bf16x8 a;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     a[j] = (__bf16)(float)((w.x >> (8 * j)) & 255u);
                     a[4 + j] = (__bf16)(float)((w.y >> (8 * j)) & 255u);
                 }
-#pragma unroll
-                for (int q = 0; q < 3; q++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[sp][q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w.f0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w.f1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw2[sp], acc, 0, 0, 0);
             };
             fetch(0, wa);
 #pragma unroll

@@ -124,13 +124,17 @@ class RLConfig(ABC):
 
         obs = env.observation_space.copy()
         self._env_obs_space = obs
-        # observation processors (config.py:268-287): every processor that remaps the space is applied to each observation, in order
+        # observation processors (config.py:301-325): the algorithm's own (`get_processors`, gated by enable_rl_processors) FIRST, then the user's;
+        # the whole step only when enable_state_encode; every processor is a private copy (instances are not shared between configs or processes);
+        # a processor that remaps the space is applied to each observation, in order
         self._obs_processors = []
-        if self.enable_rl_processors:
-            for proc in list(self.processors) + list(self.get_processors(obs)):
-                new = proc.remap_observation_space(obs) if hasattr(proc, "remap_observation_space") else None
+        if self.enable_state_encode:
+            p_list = (list(self.get_processors(obs)) if self.enable_rl_processors else []) + list(self.processors)
+            for proc in [pr.copy() if hasattr(pr, "copy") else copy.deepcopy(pr) for pr in p_list]:
+                new = proc.remap_observation_space(obs, env_run=env, rl_config=self) if hasattr(proc, "remap_observation_space") else None
                 if new is not None:
-                    self._obs_processors.append((proc, obs, new))
+                    if hasattr(proc, "remap_observation"):
+                        self._obs_processors.append((proc, obs, new))
                     obs = new
         want = self.get_base_observation_type()
         self._obs_mode = "raw"
@@ -190,9 +194,11 @@ class RLConfig(ABC):
         return self._env_act_space
 
     def state_encode_one_step(self, env_state, env):
+        if not self.enable_state_encode:  # config.py:585-590: no processor and no encoding at all
+            return env_state
         for proc, prev, new in getattr(self, "_obs_processors", ()):
-            env_state = proc.remap_observation(env_state, prev, new, env_run=env)
-        if not self.enable_state_encode or self._obs_mode == "raw":
+            env_state = proc.remap_observation(env_state, prev, new, env_run=env, rl_config=self)
+        if self._obs_mode == "raw":
             return env_state
         if self._obs_mode == "disc_to_list":
             return [int(env_state)]

@@ -17,6 +17,7 @@ sum-tree of libsrlx) the memory process opens its own HIP context on the same GP
 import ctypes
 import logging
 import multiprocessing as mp
+import collections
 import pickle
 import queue as pyqueue
 import threading
@@ -131,10 +132,10 @@ class _PrefetchedMemory:
     def __init__(self, base_memory, link: MemoryLink, n_batches: List, q_writeback, n_writeback, end_signal):
         self._base, self._link, self._end = base_memory, link, end_signal
         self._n_batches, self._q_wb, self._n_wb = n_batches, q_writeback, n_writeback
-        self._waiting: List[list] = []
+        self._waiting: List[collections.deque] = []  # FIFO like the reference's mem_to_train queue: the oldest prefetched batch is trained on first
         self._lock = threading.Lock()
         for i, f in enumerate(base_memory.get_trainer_recv_funcs()):
-            self._waiting.append([])
+            self._waiting.append(collections.deque())
             setattr(self, f.__name__, self._make_pop(i))
         for name in base_memory.get_trainer_send_funcs():
             setattr(self, name, self._make_send(name))
@@ -145,7 +146,7 @@ class _PrefetchedMemory:
             with self._lock:
                 if not self._waiting[i]:
                     return None
-                batch = self._waiting[i].pop()
+                batch = self._waiting[i].popleft()  # arrival order: update_args and the beta step of a batch must not go stale at the bottom of a stack
             self._n_batches[i].add(-1)
             return batch
 

@@ -64,7 +64,13 @@ class ActorDriver:
 
     lanes: int = 1
 
+    def attach(self, context: RunContext, state: RunStateActor) -> None:
+        """Fill `state.env / worker / workers / parameter / memory` -- BEFORE on_start fires: the reference populates the run state first
+        (core_play.py:49-69), and callbacks read it in on_start (e.g. `state.env.get_render_interval()`).  Optional: a driver without
+        run-state objects of its own leaves it empty."""
+
     def open(self, context: RunContext, state: RunStateActor) -> None:
+        """After on_start: seeding and the setup() calls (core_play.py:71-90)."""
         raise NotImplementedError
 
     def roll_episodes(self, context: RunContext, state: RunStateActor, hooks: HookTable) -> bool:
@@ -85,6 +91,9 @@ class ActorDriver:
 
 
 class LearnerDriver:
+    def attach(self, context: RunContext, state) -> None:
+        """Fill `state.trainer` (and memory / parameter when no actor did) before on_start.  Optional."""
+
     def open(self, context: RunContext, state) -> None:
         raise NotImplementedError
 
@@ -119,6 +128,10 @@ def run_sequence(context: RunContext, actor: ActorDriver, learner: Optional[Lear
         state = RunStateActor()
     hooks = HookTable(context.callbacks, context=context, state=state)
     top_level = not context.distributed  # inside train_mp the launcher owns on_start / on_end
+    # the run state is complete when on_start fires (core_play.py:49-69 before :71-72)
+    actor.attach(context, state)
+    if learner is not None:
+        learner.attach(context, state)
     if top_level:
         hooks.fire("on_start")
     opened_actor = opened_learner = False
@@ -175,9 +188,10 @@ def run_learner_only(context: RunContext, learner: LearnerDriver, state: Optiona
         state = RunStateTrainer()
     hooks = HookTable(context.callbacks, context=context, state=state)
     top_level = not context.distributed
-    learner.open(context, state)
+    learner.attach(context, state)
     if top_level:
         hooks.fire("on_start")
+    learner.open(context, state)
     hooks.fire("on_trainer_start")
     try:
         rules = StopRules(context, True, None)
@@ -215,7 +229,7 @@ class PluginActor(ActorDriver):
     def __init__(self, env, worker, workers: Optional[List] = None):
         self.env, self.worker, self.workers = env, worker, workers
 
-    def open(self, context, state):
+    def attach(self, context, state):
         env, plugin = self.env, self.worker.worker
         state.env, state.worker = env, self.worker
         state.parameter, state.memory = plugin.parameter, plugin.memory
@@ -223,6 +237,9 @@ class PluginActor(ActorDriver):
             self.workers, _ = context.rl_config.make_workers(context.players, env, state.parameter, state.memory, self.worker)
         state.workers = self.workers
         assert env.player_num == len(self.workers)
+
+    def open(self, context, state):
+        env = self.env
         if context.distributed:
             self.worker.config.setup_from_actor(context.actor_num, context.actor_id)
         if context.seed is not None:
@@ -293,14 +310,16 @@ class PluginLearner(LearnerDriver):
     def __init__(self, trainer):
         self.trainer = trainer
 
-    def open(self, context, state):
+    def attach(self, context, state):
         t = self.trainer
         state.trainer = t
         if getattr(state, "memory", None) is None:
             state.memory = t.memory
         if getattr(state, "parameter", None) is None:
             state.parameter = t.parameter
-        t.setup(context)
+
+    def open(self, context, state):
+        self.trainer.setup(context)
 
     def update(self, count: int, state) -> int:
         t = self.trainer

@@ -353,11 +353,22 @@ class Agent57LightEngine:
         return q_ext, q_int, (q_ext + beta.view(-1, 1) * q_int).contiguous()
 
     @_miopen_find
-    def actor_step(self):
-        c, r, st = self.cfg, self.replay, N.torch_stream_ptr()
-        E = self.E
+    def actor_net(self):
+        """First half of a lock-step: the two Q-networks over every lane's current state.  Reads the ring and the per-lane UVFA state only --
+        none of the tensors a transition exchange in flight still holds (device/dist.py) -- so it may run while that exchange travels."""
         arm = self.arm()
         _, _, q = self.policy_q()
+        return arm, q
+
+    def actor_step(self):
+        self.actor_rest(*self.actor_net())
+
+    @_miopen_find
+    def actor_rest(self, arm, q):
+        """Second half: action selection, environments, ring commit, intrinsic reward, per-lane bookkeeping (overwrites actions / rewards / flags /
+        next_obs: an exchange that still reads them must have been waited for)."""
+        c, r, st = self.cfg, self.replay, N.torch_stream_ptr()
+        E = self.E
         eps = (self.eps_list[arm] if self.training else torch.full((E,), float(c.test_epsilon), device=self.dev)).contiguous()
         N.check(self.lib.srlx_rng_uniform(self.seed ^ 0xAC7, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
         N.check(self.lib.srlx_policy_epsilon_greedy(E, self.A, N.tptr(q), N.tptr(eps), N.tptr(self.u_policy), None, N.tptr(self.actions), st))

@@ -463,17 +463,23 @@ class DistributedAgent57Light:
     def step(self, learner_updates: int = 1, events=None):
         """One lock-step of the job, pipelined over the exchange like DistributedRainbow.step: the slab of lock-step t travels while the
         actor ranks play lock-step t+1; rank 0 commits it at the start of its next call and trains while the next exchange is in flight."""
+        # Order (as DistributedRainbow.step): network pass -> push_end(t-1) -> commit(t-1) -> selection + environments -> push_begin(t).  The exchange
+        # in flight holds the LIVE tensors of lock-step t-1 (actions, rewards, flags, next_obs -- uncopied on the world-1 direct path and on RCCL's
+        # asynchronous gather), so nothing may overwrite them before push_end; the network pass only reads the ring and the per-lane UVFA state.
+        net = None
         if self.acts:
             if events is not None:
                 events[0].record()
-            self.local.actor_step()
-            if events is not None:
-                events[1].record()
-            self.env_steps_local += self.E
+            net = self.local.actor_net()
         gathered = self.bus.push_end() if self._in_flight else None
         self._in_flight = False
         if self.is_learner and gathered is not None:
             self._commit(gathered)
+        if self.acts:
+            self.local.actor_rest(*net)
+            if events is not None:
+                events[1].record()
+            self.env_steps_local += self.E
         slab = self._slab() if self.acts else (self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, self.local.first_obs,
                                                torch.zeros((self.E, self.FIELDS), dtype=torch.float32, device=self.dev))
         self.bus.push_begin(*slab)

@@ -345,6 +345,9 @@ class VectorActor(ActorDriver):
         return env
 
     def open(self, context, state):
+        """(everything happens in `attach`: the engine draws from its own seeded generators, not from the process-wide ones on_start may precede)"""
+
+    def attach(self, context, state):
         from simple_distributed_rl_amd.device.rainbow import RainbowEngine
 
         dev = torch.device(context.used_device_torch)
@@ -484,8 +487,11 @@ class VectorLearner(LearnerDriver):
     def train_count(self) -> int:
         return self.engine.train_count if self.engine is not None else 0
 
-    def open(self, context, state):
+    def attach(self, context, state):
         state.trainer = self
+
+    def open(self, context, state):
+        pass
 
     def train(self):
         self.update(1, None)
@@ -516,7 +522,7 @@ class VectorAgent57Actor(VectorActor):
     """`Runner.train()` with Agent57_light on a GPU: E lanes of `Agent57LightEngine` (device/agent57_light.py).  The engine trains the
     Runner's own Parameter object (the five torch networks), so nothing has to be copied back."""
 
-    def open(self, context, state):
+    def attach(self, context, state):
         from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
 
         dev = torch.device(context.used_device_torch)

@@ -143,6 +143,8 @@ class PriorityReplayBuffer:
     def sample(self, step: int = -1, batch_size: int = -1):
         if self.memory.length() < self.cfg.warmup_size:
             return None
+        if self.cfg.enable_demo_memory and self.demo_memory.length() < self.demo_batch_size:
+            return None  # the demonstration ring cannot fill its share yet (the reference's random.sample raises here): still warming up, never a short batch
         batch_size = batch_size if batch_size > -1 else self.batch_size
         step = step if step > -1 else self.step
         batches, weights, update_args = self.memory.sample(batch_size, step)

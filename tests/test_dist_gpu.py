@@ -241,3 +241,82 @@ def test_distributed_agent57_light_two_ranks_one_gpu(learner_acts):
     assert r0["x_nonzero"] > 0 and set(r0["arms_seen"]) <= {0, 1, 2, 3} and len(r0["arms_seen"]) > 1  # intrinsic rewards and arms arrived
     assert (r0["env_steps_local"] > 0) == learner_acts and r1["env_steps_local"] == 12 * 8
     assert r0["flat_sum"] == r1["flat_sum"]  # step 12 ended with a broadcast (sync_interval = 2)
+
+
+def _a57_world1_worker(rank, world, port, ret, backend, always_collective):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import copy
+
+        import simple_distributed_rl_amd as srl
+        from simple_distributed_rl_amd import _native as N
+        from simple_distributed_rl_amd.algorithms import agent57_light
+        from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
+        from simple_distributed_rl_amd.device.dist import DistributedAgent57Light
+
+        cfg = agent57_light.Config(batch_size=16, actor_num=4, target_model_update_interval=5, episodic_memory_capacity=64, ucb_window_size=6)
+        cfg.window_length = 4
+        cfg.memory.capacity, cfg.memory.warmup_size = 8 * 30, 32
+        cfg.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1000)
+        cfg.hidden_block.set_dueling_network((32,))
+        env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(20, 20), n_actions=3, episode_len=7)))
+        cfg.setup(env)
+        torch.manual_seed(7)
+        ref = Agent57LightEngine(copy.deepcopy(cfg), 8, 0, episode_len=7, seed=5)
+        torch.manual_seed(7)
+        eng = DistributedAgent57Light(copy.deepcopy(cfg), 8, 0, episode_len=7, sync_interval=4, seed=5, always_collective=always_collective)
+        steps = 17
+        for _ in range(steps):
+            ref.actor_step()
+            eng.step(learner_updates=0)
+        eng.flush()
+        torch.cuda.synchronize()
+        zero = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+        out = {"committed": (ref.replay._steps_committed, eng.replay._steps_committed), "len": (ref.replay.length(), eng.replay.length())}
+        same = True
+        for _ in range(4):  # four seeded draws from both replays: same tree, same generator -> the same items, field by field
+            b1, b2 = ref.replay.sample(zero), eng.replay.sample(zero)
+            same = same and all(torch.equal(getattr(b1, k), getattr(b2, k)) for k in ("indices", "obs", "actions", "rewards", "terminated", "weights"))
+            loc = []
+            for rp in (ref.replay, eng.replay):
+                e, s = torch.zeros(rp.B, dtype=torch.int64, device="cuda:0"), torch.zeros(rp.B, dtype=torch.int64, device="cuda:0")
+                N.check(rp.lib.srlx_store_locate(rp.h_store, rp.B, N.tptr(b1.indices), N.tptr(e), N.tptr(s), None, N.torch_stream_ptr()))
+                loc.append((e, s))
+            (e1, s1), (e2, s2) = loc
+            same = same and torch.equal(e1, e2) and torch.equal(s1, s2)
+            x2 = eng.x[s2, e2]
+            for k, t in enumerate((ref.x_r_int, ref.x_actor, ref.x_prev_action, ref.x_prev_r_ext, ref.x_prev_r_int)):
+                same = same and torch.equal(t[s1, e1].float(), x2[:, k])
+        out["same"] = bool(same)
+        out["r_int_nonzero"] = float(eng.x[..., 0].abs().sum().item())
+        ret[rank] = out
+    except Exception:
+        import traceback
+
+        ret[f"error{rank}"] = traceback.format_exc()
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,always_collective", [("gloo", False), ("nccl", True)])
+def test_distributed_agent57_light_world_one_equals_the_single_engine(backend, always_collective):
+    """The pipelined exchange must hand the learner the transition of lock-step t with the UVFA / intrinsic fields of lock-step t: at world size 1
+    (the direct path that returns the live tensors, and RCCL's asynchronous gather into the staging buffers) the global replay + field arrays equal,
+    item by item, what a plain Agent57LightEngine with the same seed stored -- nothing torn, nothing shifted by one slot, the first lock-step there."""
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    try:
+        mp.spawn(_a57_world1_worker, args=(1, _free_port(), ret, backend, always_collective), nprocs=1, join=True)
+    except Exception:
+        errs = [v for k, v in sorted(ret.items(), key=lambda kv: str(kv[0])) if str(k).startswith("error")]
+        raise AssertionError("worker failed:\n" + "\n".join(errs))
+    r = ret[0]
+    assert r["committed"][0] == r["committed"][1] == 17 and r["len"][0] == r["len"][1]
+    assert r["same"] and r["r_int_nonzero"] > 0

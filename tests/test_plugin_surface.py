@@ -88,8 +88,10 @@ def test_callback_hooks_fire():
         def _hit(self, name):
             calls[name] = calls.get(name, 0) + 1
 
-        def on_start(self, context, **kw):
+        def on_start(self, context, state=None, **kw):
             self._hit("on_start")
+            # the run state is complete when on_start fires (core_play.py:49-72; the reference's rendering callback reads state.env there)
+            calls["state_at_start"] = all(getattr(state, k, None) is not None for k in ("env", "worker", "workers", "parameter", "memory", "trainer"))
 
         def on_end(self, context, **kw):
             self._hit("on_end")
@@ -124,6 +126,7 @@ def test_callback_hooks_fire():
     assert st.end_reason == "callback.intermediate_stop" and st.total_step == 120
     for k in ("on_start", "on_end", "on_episodes_begin", "on_episodes_end"):
         assert calls[k] == 1
+    assert calls["state_at_start"]
     assert calls["on_step_begin"] == calls["on_step_action_before"] == calls["on_step_action_after"] == calls["on_step_end"] == 120
     assert calls["on_episode_begin"] >= 1 and calls["on_episode_end"] >= 1
 
@@ -491,7 +494,7 @@ def test_prefetched_memory_protocol():
     n_b[0].add(2)
     client.deliver(0, ("batch", 1))
     client.deliver(0, ("batch", 2))
-    assert client.length() == 2 and client.sample() == ("batch", 2) and n_b[0].value == 1
+    assert client.length() == 2 and client.sample() == ("batch", 1) and n_b[0].value == 1  # arrival order (the reference's mem_to_train queue is FIFO)
     client.update([1, 2], np.ones(2), 7)
     client.update([3], np.ones(1), 8)
     assert n_w.value == 2
@@ -499,3 +502,49 @@ def test_prefetched_memory_protocol():
     args, kwargs = pickle.loads(blob)
     assert name == "update" and args[0] == [1, 2] and args[2] == 7
     assert client.batch_size == 4  # everything else falls through to the real memory
+
+
+def test_observation_processor_wiring_follows_the_reference():
+    """srl/base/rl/config.py:301-325,585-590: algorithm processors (gated by enable_rl_processors) run BEFORE the user's; the user's run even with
+    enable_rl_processors=False; nothing runs with enable_state_encode=False; every applied processor is a private copy and is handed env_run / rl_config."""
+    from simple_distributed_rl_amd.base.rl.config import DummyRLConfig
+    from simple_distributed_rl_amd.base.spaces.box import BoxSpace
+
+    log = []
+
+    class Tag:
+        def __init__(self, name, add):
+            self.name, self.add, self.kw = name, add, None
+
+        def remap_observation_space(self, prev, **kw):
+            self.kw = sorted(kw)
+            log.append(self.name)
+            return BoxSpace((2,), -1000.0, 1000.0, np.float32)
+
+        def remap_observation(self, state, prev, new, **kw):
+            return np.asarray(state) * 2 + self.add  # order-sensitive
+
+    class Cfg(DummyRLConfig):
+        def get_processors(self, prev):
+            return [Tag("algo", 1.0)]
+
+    env = srl.make_env("Grid")
+    user = Tag("user", 10.0)
+
+    def build(**kw):
+        log.clear()
+        cfg = Cfg(**kw)
+        cfg.processors = [user]
+        cfg.setup(env)
+        return cfg
+
+    cfg = build()
+    assert log == ["algo", "user"]
+    applied = [p for p, _, _ in cfg._obs_processors]
+    assert [p.name for p in applied] == ["algo", "user"] and applied[1] is not user and applied[1].kw == ["env_run", "rl_config"]
+    x = np.asarray(cfg.state_encode_one_step([1, 2], env), np.float64)
+    assert x.tolist() == [(1 * 2 + 1) * 2 + 10, (2 * 2 + 1) * 2 + 10]  # algorithm processor first, then the user's
+    cfg = build(enable_rl_processors=False)
+    assert log == ["user"] and [p.name for p, _, _ in cfg._obs_processors] == ["user"]
+    cfg = build(enable_state_encode=False)
+    assert log == [] and cfg._obs_processors == [] and cfg.state_encode_one_step([1, 2], env) == [1, 2]

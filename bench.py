@@ -163,7 +163,8 @@ def main():
     local = getattr(eng, "local", eng)
     probing = bool(local.mfma) and getattr(eng, "acts", True)
     pr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe)] if probing else []
-    for a_, b_ in pr:  # torch creates the underlying hipEvent_t at the first record
+    pf = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe)] if probing else []
+    for a_, b_ in pr + pf:  # torch creates the underlying hipEvent_t at the first record
         a_.record()
         b_.record()
     if dist is not None:
@@ -174,6 +175,7 @@ def main():
         if k % probe_every == 0:
             if probing:
                 local.inf_actor.set_probe(*pr[k // probe_every])
+                local.inf_actor.set_probe_fc1(*pf[k // probe_every])
             eng.step(args.updates, events=ev[k // probe_every])
         else:
             eng.step(args.updates)
@@ -189,10 +191,11 @@ def main():
 
     ev_ms = sum(a_.elapsed_time(b_) for a_, b_ in ev) / len(ev)
     conv_ms = sum(a_.elapsed_time(b_) for a_, b_ in pr) / len(pr) if probing else 0.0
+    fc1_ms = sum(a_.elapsed_time(b_) for a_, b_ in pf) / len(pf) if probing else 0.0
     if dist is not None:  # a learner-only rank 0 runs no actor pass: report the slowest actor rank's
-        t = torch.tensor([ev_ms, conv_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([ev_ms, conv_ms, fc1_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ev_ms, conv_ms = float(t[0].item()), float(t[1].item())
+        ev_ms, conv_ms, fc1_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
     rccl_ranks = dist.get_world_size() if (dist is not None and args.backend == "nccl") else (1 if dist is None else 0)
 
     if rank != 0:
@@ -234,7 +237,9 @@ def main():
             "noisy_dense": cfg.enable_noisy_dense,
             "epsilon": cfg.epsilon,
             "hip_graphs": not args.no_graph,
-            "qnet": ("libsrlx: fp32 MFMA forward, hand-written backward (no autograd)" if getattr(local, "mfma_train", False) else "libsrlx fp32 MFMA forward, torch autograd backward") if eng.mfma else "torch",
+            "qnet": ("libsrlx: float32 results; forward = float32 products as exact split-bf16 partial products on v_mfma_f32_32x32x16_bf16 (conv1 3, conv2 / conv3 / "
+                     "first dense layer 6 per multiply-add), float32 accumulate; " +
+                     ("hand-written backward (no autograd)" if getattr(local, "mfma_train", False) else "torch autograd backward (SRLX_TORCH_BACKWARD=1 yardstick)")),
             "actor_learner_overlap": (not args.no_overlap) if dist is None else True,
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "backend": "none" if dist is None else args.backend,
@@ -242,7 +247,7 @@ def main():
                          else f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology), RCCL gather/broadcast"),
             "actor_gpus": actor_ranks,
         },
-        "roofline": roofline(eng, ev_ms, conv_ms),
+        "roofline": roofline(eng, ev_ms, conv_ms, fc1_ms),
         "final": {"loss": info["loss"], "train_count": info["train_count"], "memory": info["memory"]},
     }
     if dist is None and not args.no_subfigures:
@@ -457,80 +462,101 @@ def _isolated_forward_ms(eng, reps=20):
     return a.elapsed_time(b) / reps
 
 
-def _pmc_traffic(kernel: str, launches_scale: float = 1.0):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r2_pmc_traffic.json, written by tools/r2_measure.sh from
-    two separate `rocprofv3 --pmc` runs: FETCH_SIZE and WRITE_SIZE do not fit one pass; FETCH_SIZE doubled as MI355X_MICROARCH.md
+PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+
+
+def _pmc_traffic(kernel: str):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r3_pmc_traffic.json, written by tools/r3_measure.sh from two separate
+    `rocprofv3 --pmc` runs of tools/actor_pass_probe.py -- FETCH_SIZE and WRITE_SIZE do not fit one pass; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for wide coalesced reads on gfx950).  None when no such profile has been recorded."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
-    if not os.path.exists(path):
+    if not os.path.exists(PMC_FILE):
         return None
     try:
-        d = json.load(open(path)).get(kernel)
-        return None if d is None else d["hbm_bytes_per_launch"] * launches_scale
+        d = json.load(open(PMC_FILE)).get(kernel)
+        return None if d is None else d["hbm_bytes_per_launch"]
     except Exception:
         return None
 
 
-def roofline(eng, ev_ms, conv_ms=0.0):
-    """The dominant hand-written kernel, timed live with events on its launch stream: k_convnet_fused (conv1 -> conv2 -> conv3 of the
-    actors' network pass in one launch) -- or, where that kernel does not apply, the two k_gemm<AConv> launches (conv2 + conv3).
-    `pass` = the whole pass (fused convolutions + FC1 GEMM + head)."""
+def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0):
+    """The dominant hand-written kernel, timed live with HIP events on its launch stream: k_convnet_fused (conv1 -> conv2 -> conv3 of the actors' network
+    pass in one launch).  It evaluates float32 products on the bf16 matrix pipe as exact split partial products, so its bound is the dense bf16 MFMA
+    peak and its work is what it EXECUTES there: 3 MFMA flops per conv1 multiply-add flop, 6 per conv2 / conv3 one.
+    `fc1` = the second-largest kernel (first dense layer of the same pass) priced the same way; `pass` = the whole pass."""
     flops = eng.actor_forward_flops()
-    tf = flops / (ev_ms * 1e-3) / 1e12
     iso_ms = _isolated_forward_ms(eng)
     fused = bool(eng.fused_convs)
+    E = eng.cfg.n_envs if hasattr(eng, "cfg") else 0
+    c1_bf16 = fused and os.environ.get("SRLX_CONV1_F32", "0") != "1"
+    c23_bf16 = c1_bf16 and os.environ.get("SRLX_CONV23_F32", "0") != "1"
+    fc1_bf16 = os.environ.get("SRLX_FC1_F32", "0") != "1"
+    f_conv = eng.conv_gemm_flops(with_conv1=fused)
+    f_23 = eng.conv_gemm_flops(with_conv1=False)
+    f_1 = f_conv - f_23
+    local = getattr(eng, "local", eng)
+    cfg = local.cfg
+    flat = 121 * 2 * cfg.filters if tuple(cfg.obs_hw) == (84, 84) else None
+    f_fc1 = 2.0 * E * flat * 2 * cfg.hidden_units if flat else 0.0
+    f_head = flops - f_conv - f_fc1
+    exe_conv = (3.0 if c1_bf16 else 1.0) * f_1 + (6.0 if c23_bf16 else 1.0) * f_23
+    exe_fc1 = (6.0 if fc1_bf16 else 1.0) * f_fc1
     group = {
         "kernel": "srlx_qnet_forward_u8 over E envs: " + ("k_pack_filters + k_convnet_fused (conv1..conv3 from the uint8 ring)" if fused else
-                  "k_conv1_u8 + k_gemm<AConv> x2") + " + k_gemm<APlain,splitK> (FC1) + k_head",
-        "achieved": tf,
-        "frac": tf / MFMA_F32_PEAK_TFLOPS,
-        "flops_per_launch_group": flops,
+                  "k_conv1_u8 + k_gemm<AConv> x2") + " + first dense layer (k_fc1_planes on operand planes, or k_gemm_s16) + k_head",
+        "algorithmic_f32_flops_per_launch_group": flops,
+        "executed_mfma_flops_per_launch_group": exe_conv + exe_fc1 + f_head,
         "avg_launch_group_ms": ev_ms,
-        "isolated": {"avg_launch_group_ms": iso_ms, "achieved": flops / (iso_ms * 1e-3) / 1e12, "frac": flops / (iso_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+        "achieved": (exe_conv + exe_fc1 + f_head) / (ev_ms * 1e-3) / 1e12,
+        "frac": (exe_conv + exe_fc1 + f_head) / (ev_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+        "algorithmic_f32_tflops": flops / (ev_ms * 1e-3) / 1e12,
+        "isolated": {"avg_launch_group_ms": iso_ms, "achieved": (exe_conv + exe_fc1 + f_head) / (iso_ms * 1e-3) / 1e12,
+                     "frac": (exe_conv + exe_fc1 + f_head) / (iso_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "algorithmic_f32_tflops": flops / (iso_ms * 1e-3) / 1e12},
     }
-    if conv_ms > 0.0:
-        cf = eng.conv_gemm_flops(with_conv1=fused)
-        ctf = cf / (conv_ms * 1e-3) / 1e12
-        c1_bf16 = fused and os.environ.get("SRLX_CONV1_F32", "0") != "1"
-        c23_bf16 = c1_bf16 and os.environ.get("SRLX_CONV23_F32", "0") != "1"
-        mixed = None
-        if c1_bf16:
-            # float32 products evaluated on the bf16 pipe as exact partial products: conv1 THREE per multiply-add (the pixel is one bf16, the filter three
-            # parts), conv2 / conv3 SIX (three parts each side, p + q <= 2) -- or conv2 / conv3 on the float32 pipe (SRLX_CONV23_F32=1).  The kernel's own
-            # time floor is the sum of the pipes' floors.
-            f23 = eng.conv_gemm_flops(with_conv1=False)
-            t1 = 3.0 * (cf - f23) / (MFMA_BF16_PEAK_TFLOPS * 1e12)
-            t23 = 6.0 * f23 / (MFMA_BF16_PEAK_TFLOPS * 1e12) if c23_bf16 else f23 / (MFMA_F32_PEAK_TFLOPS * 1e12)
-            floor_ms = (t1 + t23) * 1e3
-            mixed = {"floor_ms": floor_ms, "frac": floor_ms / conv_ms, "conv1_flops": cf - f23,
-                     "conv1_pipe": "bf16, 3 exact partial products per multiply-add, peak %.0f TFLOP/s dense" % MFMA_BF16_PEAK_TFLOPS, "conv2_conv3_flops": f23,
-                     "conv2_conv3_pipe": ("bf16, 6 exact partial products per multiply-add, peak %.0f TFLOP/s dense" % MFMA_BF16_PEAK_TFLOPS) if c23_bf16 else
-                     "f32, peak %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS}
-        return {
-            "kernel": ("k_convnet_fused: conv1 -> conv2 -> conv3 of the actors' pass, one workgroup per sample, activations in LDS (1 launch per lock-step; conv2 / conv3 " +
-                       ("v_mfma_f32_32x32x16_bf16 on exact split operands" if c23_bf16 else "v_mfma_f32_32x32x2_f32") + ", conv1 " +
-                       ("v_mfma_f32_32x32x16_bf16 on exact split operands" if c1_bf16 else "v_mfma_f32_32x32x2_f32") +
-                       "); rocprofv3 check: this kernel's AverageNs in profiles/r2_kernel_stats.csv" if fused else
-                       "k_gemm<AConv, 64, true, false, 128>: implicit-GEMM convolutions conv2 + conv3 of the actors' pass (2 launches per lock-step)"),
-            "bound": "mfma",
-            "achieved": ctf,
-            "peak": MFMA_F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": ctf / MFMA_F32_PEAK_TFLOPS,
-            "traffic": _pmc_traffic("k_convnet_fused") if fused else None,
-            "flops_per_launch": cf,
-            "avg_launch_ms": conv_ms,
-            "algorithmic_bytes_per_launch": (eng.cfg.n_envs if hasattr(eng, "cfg") else 0) * (4 * 7056 + 121 * 64 * 4) + 311296 if fused else None,
-            "note": "timed inside the lock-step loop, where the learner's streams run beside it; `pass` = the whole network pass of the actors, "
-                    "`pass.isolated` = that pass alone on an idle GPU; traffic = PMC bytes per launch from profiles/r2_pmc_traffic.json (isolated launches); "
-                    "`frac` = algorithmic FLOP/s over the float32 MFMA peak as in every earlier line -- with the layers evaluated on the bf16 pipe (as exact partial "
-                    "products: 3 or 6 MFMA flops per algorithmic flop) that peak is no longer the kernel's bound: `mixed_roof.frac` = the kernel's own floor over its measured time",
-            "mixed_roof": mixed,
-            "pass": group,
-            "dtype": "f32 results (float32 products as exact split-bf16 partial products, f32 accumulate)" if c1_bf16 else "f32 in / f32 accumulate",
+    if conv_ms <= 0.0:
+        group.update({"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None})
+        return group
+    pipe = lambda b16, k: ("bf16 pipe, %d exact partial products per multiply-add" % k) if b16 else "f32 pipe (v_mfma_f32_32x32x2_f32)"  # noqa: E731
+    fc1_planes = bool(getattr(local.inf_actor, "_planes", False))
+    fc1_alg_bytes = (E * flat * 6 + 2 * cfg.hidden_units * flat * 6 if fc1_planes else E * flat * 4 + 2 * cfg.hidden_units * flat * 4) + 4 * E * 2 * cfg.hidden_units * 4 if flat else None
+    fc1_traffic = _pmc_traffic("fc1")
+    fc1 = None
+    if fc1_ms > 0.0 and flat:
+        fc1 = {
+            "kernel": ("k_fc1_planes: [E][7744] x [2 hidden][7744]^T on pre-split bf16 operand planes (LDS-DMA tiles, no conversions), split-K partials reduced by k_head"
+                       if fc1_planes else "k_gemm_s16<APlain>: operands split into bf16 parts while staging"),
+            "bound": "mfma", "achieved": exe_fc1 / (fc1_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS if fc1_bf16 else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": exe_fc1 / (fc1_ms * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS if fc1_bf16 else MFMA_F32_PEAK_TFLOPS),
+            "executed_mfma_flops_per_launch": exe_fc1, "algorithmic_f32_flops_per_launch": f_fc1, "avg_launch_ms": fc1_ms, "pipe": pipe(fc1_bf16, 6),
+            "traffic": fc1_traffic, "algorithmic_bytes_per_launch": fc1_alg_bytes,
+            "traffic_over_algorithmic": (fc1_traffic / fc1_alg_bytes) if (fc1_traffic and fc1_alg_bytes) else None,
+            "note": "algorithmic bytes = both operands once (planes: 6 B per element) + the four split-K partial slabs written",
         }
-    group.update({"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "dtype": "f32 in / f32 accumulate"})
-    return group
+    conv_alg_bytes = E * (4 * 7056 + (121 * 64 * 6 if fc1_planes else 121 * 64 * 4)) + 466944 if fused else None  # 4 frames in + act3 out per sample + the split-bf16 packed filters once
+    conv_traffic = _pmc_traffic("k_convnet_fused") if fused else None
+    return {
+        "kernel": ("k_convnet_fused: conv1 -> conv2 -> conv3 of the actors' pass, one workgroup per sample, activations in LDS, 1 launch per lock-step"
+                   if fused else "k_gemm<AConv, 64, true, false, 128>: implicit-GEMM convolutions conv2 + conv3 of the actors' pass (2 launches per lock-step)"),
+        "bound": "mfma",
+        "achieved": exe_conv / (conv_ms * 1e-3) / 1e12,
+        "peak": MFMA_BF16_PEAK_TFLOPS if c1_bf16 else MFMA_F32_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": exe_conv / (conv_ms * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS if c1_bf16 else MFMA_F32_PEAK_TFLOPS),
+        "traffic": conv_traffic,
+        "executed_mfma_flops_per_launch": exe_conv,
+        "algorithmic_f32_flops_per_launch": f_conv,
+        "avg_launch_ms": conv_ms,
+        "algorithmic_bytes_per_launch": conv_alg_bytes,
+        "traffic_over_algorithmic": (conv_traffic / conv_alg_bytes) if (conv_traffic and conv_alg_bytes) else None,
+        "pipes": {"conv1": pipe(c1_bf16, 3), "conv2_conv3": pipe(c23_bf16, 6), "conv1_f32_flops": f_1, "conv2_conv3_f32_flops": f_23},
+        "f32_equivalent": {"achieved": f_conv / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "frac": f_conv / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                           "note": "algorithmic float32 FLOP/s over the f32 MFMA peak (the `frac` of the round-1/2 lines); NOT this kernel's bound: it does not run on that pipe"},
+        "note": "timed inside the lock-step loop (HIP events on the launch stream, right around this kernel), where the learner's streams share the chip; `frac` = "
+                "executed bf16-MFMA flops / time / 2.5 PFLOP/s dense; traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/r3_pmc_traffic.json (isolated "
+                "launches of tools/actor_pass_probe.py); rocprofv3 cross-check: this kernel's AverageNs in profiles/r3_kernel_stats.csv",
+        "fc1": fc1,
+        "pass": group,
+        "dtype": "f32 results (float32 products as exact split-bf16 partial products, f32 accumulate)" if c1_bf16 else "f32 in / f32 accumulate",
+    }
 
 
 def per_micro(eng, draws=1 << 20, reps=20):

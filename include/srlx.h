@@ -446,9 +446,22 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
  * srlx_qnet_bind are read. */
 int srlx_qnet_forward_convs_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_features, void *stream);
 /* Measurement hook: the NEXT forward on this handle records the two caller-owned HIP events (hipEvent_t) on its stream right
- * before the conv2 launch and right after the conv3 launch -- the two launches of the dominant kernel k_gemm<AConv> -- so that
- * bench.py can time that kernel live, on the stream it runs on.  NULL events switch it off. */
+ * around the dominant kernel -- the one k_convnet_fused launch of the Atari geometry (the filter-packing launch before it excluded), or the
+ * conv2 + conv3 launches of k_gemm<AConv> elsewhere -- so that bench.py can time that kernel live, on the stream it runs on.  NULL events
+ * switch it off. */
 int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end);
+/* the same for the first dense layer's GEMM launch (FC1: the second-largest kernel of a lock-step) */
+int srlx_qnet_set_probe_fc1(srlx_qnet_t *h, void *ev_start, void *ev_end);
+/* The first dense layer of chip-filling launches (>= 512 rows, a multiple of 128: the actors' policy pass) on PRE-SPLIT operands.  The layer evaluates
+ * float32 x float32 as six exact bf16 partial products; by default both operands are split while staging, in every workgroup, every K-slab.  A handle
+ * with planes enabled keeps its weight as three bf16 parts ([unit][K/8][3][8 bf16], 1.5x the float32 bytes), the convolution kernel writes its output
+ * in the same form, and the GEMM runs without conversions (bit-identical results).  The planes are a CACHE of the float32 weight: after every change of
+ * the weight call srlx_qnet_refresh_fc1_planes (d_src_wf = NULL: split the bound weight; otherwise split `d_src_wf`, and when d_copy_dst != NULL also
+ * write the float32 values there -- the per-lock-step refresh of an actor's private copy of the online network, play_mp.py:121-165, and its planes in
+ * one pass), or srlx_qnet_invalidate_fc1_planes to fall back to the staging split until the next refresh. */
+int srlx_qnet_enable_fc1_planes(srlx_qnet_t *h);
+int srlx_qnet_refresh_fc1_planes(srlx_qnet_t *h, const float *d_src_wf, float *d_copy_dst, void *stream);
+int srlx_qnet_invalidate_fc1_planes(srlx_qnet_t *h);
 /* the weight-gradient branch of srlx_qnet_backward_u8 runs on a stream of the handle's own; a caller that confines the learner to a set
  * of CUs (hipExtStreamCreateWithCUMask) hands in a stream carrying that mask instead (caller-owned, must outlive the handle's use) */
 int srlx_qnet_set_side_stream(srlx_qnet_t *h, void *stream);

@@ -86,6 +86,10 @@ SIGNATURES = {
     "srlx_qnet_forward_convs_u8": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     "srlx_qnet_enable_training": (c_int, [c_p, c_i64]),
     "srlx_qnet_set_probe": (c_int, [c_p, c_p, c_p]),
+    "srlx_qnet_set_probe_fc1": (c_int, [c_p, c_p, c_p]),
+    "srlx_qnet_enable_fc1_planes": (c_int, [c_p]),
+    "srlx_qnet_refresh_fc1_planes": (c_int, [c_p, c_p, c_p, c_p]),
+    "srlx_qnet_invalidate_fc1_planes": (c_int, [c_p]),
     "srlx_qnet_set_debug": (c_int, [c_p, c_p]),
     "srlx_qnet_set_side_stream": (c_int, [c_p, c_p]),
     "srlx_qnet_fuse_adam_fc1": (c_int, [c_p, c_p, c_p, c_f64, c_f64, c_f64, c_f64, c_p]),

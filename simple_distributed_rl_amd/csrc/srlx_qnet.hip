@@ -675,7 +675,14 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     const int kps = ((ksteps + splits - 1) / splits);
     const int used = (ksteps + kps - 1) / kps;  // splits that actually own a K range
     static const bool fc1_f32 = getenv("SRLX_FC1_F32") && getenv("SRLX_FC1_F32")[0] == '1';  // A/B switch: FC1 on the float32 matrix pipe
-    if (!fc1_f32 && h->flat % BK == 0) {
+    // chip-filling launches of a handle with valid weight planes (the actors' pass): conversion-free GEMM on pre-split operands, bit-identical to k_gemm_s16
+    const bool planes = !fc1_f32 && stride == 1 && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, B);
+    if (planes && !h->a3_planes_fresh) SRLX_TRY(srlx_fc1_planes_split_act(h, B, st));  // (a convolution path that wrote float32 act3 only)
+    h->a3_planes_fresh = false;
+    if (h->probe_fc0) SRLX_HIP(hipEventRecord(h->probe_fc0, st));
+    if (planes) {
+        SRLX_TRY(srlx_fc1_planes_gemm(h, B, splits, kps, st));
+    } else if (!fc1_f32 && h->flat % BK == 0) {
         const dim3 grid((unsigned)((B + 127) / 128), (unsigned)((N1 + 63) / 64), (unsigned)splits);
         APlain fa{h->act3, (i64)h->flat * stride};
         hipLaunchKernelGGL((k_gemm_s16<APlain, 64, true>), grid, dim3(256), 0, st, fa, h->wf, h->partial, B, N1, h->flat, kps * BK);
@@ -683,6 +690,8 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
         APlain fa{h->act3, (i64)h->flat * stride};
         launch_gemm<APlain, 64, false, true>(fa, h->wf, nullptr, h->partial, B, N1, h->flat, splits, st);
     }
+    if (h->probe_fc1) SRLX_HIP(hipEventRecord(h->probe_fc1, st));
+    h->probe_fc0 = h->probe_fc1 = nullptr;  // one forward only
     // small launches (the learner's 128 / 96 rows) are one workgroup per row and far from filling the chip: twice the threads per row
     hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(B <= 256 && h->hidden > 256 ? 512 : 256), 0, st, h->partial, used, B, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
                        h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, h->sig[0] ? h->d_draw : nullptr);
@@ -775,6 +784,8 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
         if (p) (void)hipFree(p);
     if (h->d_draw) (void)hipFree(h->d_draw);
     if (h->wpack) (void)hipFree(h->wpack);
+    if (h->wf_planes) (void)hipFree(h->wf_planes);
+    if (h->a3_planes) (void)hipFree(h->a3_planes);
     if (h->side && !h->side_external) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join, h->ev_wt})
         if (e) (void)hipEventDestroy(e);
@@ -791,6 +802,28 @@ int srlx_qnet_bind(srlx_qnet_t *h, const float *const *p) {
         return SRLX_OK;
     }
     h->wf = p[6], h->bf = p[7], h->v2w = p[8], h->v2b = p[9], h->a2w = p[10], h->a2b = p[11];
+    return SRLX_OK;
+}
+
+int srlx_qnet_enable_fc1_planes(srlx_qnet_t *h) {
+    SRLX_REQUIRE(h, "qnet_enable_fc1_planes: NULL handle");
+    SRLX_REQUIRE(!h->eff[0], "qnet_enable_fc1_planes: NoisyLinear layers draw a new effective weight per forward: no persistent planes");
+    srlx::DeviceGuard guard(h->device);
+    return srlx_fc1_planes_alloc(h);
+}
+
+int srlx_qnet_refresh_fc1_planes(srlx_qnet_t *h, const float *d_src_wf, float *d_copy_dst, void *stream) {
+    SRLX_REQUIRE(h && h->wf_planes, "qnet_refresh_fc1_planes: planes are not enabled on this handle (srlx_qnet_enable_fc1_planes)");
+    SRLX_REQUIRE(d_src_wf || h->wf, "qnet_refresh_fc1_planes: no weight bound and none given");
+    srlx::DeviceGuard guard(h->device);
+    SRLX_TRY(srlx_fc1_planes_split_weight(h, d_src_wf ? d_src_wf : h->wf, d_copy_dst, (hipStream_t)stream));
+    h->planes_valid = true;
+    return SRLX_OK;
+}
+
+int srlx_qnet_invalidate_fc1_planes(srlx_qnet_t *h) {
+    SRLX_REQUIRE(h, "qnet_invalidate_fc1_planes: NULL handle");
+    h->planes_valid = false;
     return SRLX_OK;
 }
 
@@ -816,14 +849,21 @@ int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end) {
     return SRLX_OK;
 }
 
+int srlx_qnet_set_probe_fc1(srlx_qnet_t *h, void *ev_start, void *ev_end) {
+    SRLX_REQUIRE(h, "qnet_set_probe_fc1: NULL handle");
+    h->probe_fc0 = (hipEvent_t)ev_start;
+    h->probe_fc1 = (hipEvent_t)ev_end;
+    return SRLX_OK;
+}
+
 // conv1 -> conv2 -> conv3 from the uint8 ring into h->act3, then (d_q != NULL) the dense layers
 static int forward_u8_impl(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, hipStream_t st) {
     static const bool no_fused = getenv("SRLX_NO_FUSED_CONV") && getenv("SRLX_NO_FUSED_CONV")[0] == '1';  // A/B switch for measurements
     if (!no_fused && h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32) {
         // conv1 -> conv2 -> conv3 in one kernel, one workgroup per sample, activations in LDS (srlx_qnet_fused.hip)
-        if (h->probe0) SRLX_HIP(hipEventRecord(h->probe0, st));
+        // (the probe events are recorded inside, right around k_convnet_fused: the filter-packing launch before it is not part of the timed kernel)
+        h->want_planes_out = d_q != nullptr;
         SRLX_REQUIRE(srlx_qnet_fused_convs(h, batch, d_frame_base, d_frame_off, st), "qnet_forward_u8: launching the fused convolution kernel failed");
-        if (h->probe1) SRLX_HIP(hipEventRecord(h->probe1, st));
         h->probe0 = h->probe1 = nullptr;
         return d_q ? run_dense(h, batch, d_q, st) : SRLX_OK;
     }

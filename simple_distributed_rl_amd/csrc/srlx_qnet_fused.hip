@@ -171,7 +171,9 @@ __device__ __forceinline__ void tile_from_lds(const float *__restrict__ lds_in, 
 // QUARTER of K; the eight waves are 2 blocks x 4 K quarters and the quarters are summed through LDS afterwards.  A fragments: float32 out of LDS
 // (layout unchanged), split into three bf16 parts on the fly (88 VALU instructions beside 24 MFMAs); B fragments: pre-split by k_pack_filters.
 //   LAYER 2: 4 x 4 stride 2 pad 2 over act1 (21 x 21 x 32), K = 16 taps x 32 = 32 steps of 16;  LAYER 3: 3 x 3 stride 1 pad 1 over act2 (11 x 11 x 64), 36 steps
-template <int LAYER>
+// SWAP: the MFMA operands trade places (filters as the A operand), so each accumulator tile comes out TRANSPOSED -- rows = channels, columns = pixels: a lane
+// then holds runs of four consecutive channels of ONE pixel, which is what the bf16 operand planes of the first dense layer are made of (store_act3_planes).
+template <int LAYER, bool SWAP = false>
 __device__ __forceinline__ void block_b16(const float *__restrict__ lds_in, const bf16x8 *__restrict__ wfrag, int blk, int kq, int lane, f32x16 (&acc)[2][2]) {
     constexpr int S = LAYER == 2 ? 32 : 36, SPT = LAYER == 2 ? 2 : 4, KW = LAYER == 2 ? 4 : 3, STR = LAYER == 2 ? 2 : 1, PAD = LAYER == 2 ? 2 : 1;
     constexpr int IN = LAYER == 2 ? kP1 : kP2, PS = LAYER == 2 ? kS1 : kS2, QS = S / 4;
@@ -224,7 +226,9 @@ __device__ __forceinline__ void block_b16(const float *__restrict__ lds_in, cons
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
-                for (int n = 0; n < 2; n++) acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][pq[c][0]], fb[n][pq[c][1]], acc[a][n], 0, 0, 0);
+                for (int n = 0; n < 2; n++)
+                    acc[a][n] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][pq[c][1]], pa[a][pq[c][0]], acc[a][n], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][pq[c][0]], fb[n][pq[c][1]], acc[a][n], 0, 0, 0);
     };
     load(0, fa0, fb0);
 #pragma unroll
@@ -275,11 +279,14 @@ __device__ __forceinline__ f32x16 reduce_quarters(float *__restrict__ scratch, i
 
 // BIG = a launch of at least 512 samples (the actors' policy pass): a template parameter only so that profiles list the chip-filling
 // launches and the learner's 96 / 128-sample launches as separate kernels (same code).
-template <bool BIG, bool C1B16, bool C23B16>
+// PLANES (chip-filling launches of a handle with operand planes, srlx_fc1_planes.hip): act3 is written as the three bf16 part planes the first dense
+// layer's GEMM reads -- [K/32 slabs][batch rows][4 k-groups][3 parts][8 bf16], K = pixel * 64 + channel -- instead of float32; `act3` then points at them.
+template <bool BIG, bool C1B16, bool C23B16, bool PLANES = false>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
                                                                 float *__restrict__ act3,
                                                                 float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg) {
+    static_assert(!PLANES || C23B16, "operand planes come out of the split-bf16 conv3 only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u8 *fr = smem;                                                 // [4][88][88]
     float *a1 = reinterpret_cast<float *>(smem + 4 * kFrame);      // [441][36]
@@ -510,8 +517,41 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
         }
         __syncthreads();  // act2 is complete
         stamp(6);
-        block_b16<3>(a2, wf3, blk, kq, lane, acc4);
-        store_act3(mt, nt, reduce_quarters(scratch, blk, kq, lane, acc4));
+        if constexpr (PLANES) {
+            block_b16<3, true>(a2, wf3, blk, kq, lane, acc4);
+            const f32x16 sum = reduce_quarters(scratch, blk, kq, lane, acc4);
+            // transposed tile: column i = pixel mt * 32 + i, row (r & 3) + 8 (r >> 2) + 4 h = channel within the tile's 32 = within K-slab (pixel * 2 + nt):
+            // k-group g = r >> 2, elements 4 h .. 4 h + 3 of the group: one 8-byte half of a 16-byte chunk per (g, part)
+            const int pix = mt * 32 + i;
+            if (pix < kM2) {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                const i64 rows = gridDim.x;
+                unsigned char *dst = reinterpret_cast<unsigned char *>(act3) + (((i64)(pix * 2 + nt) * rows + b) * 4) * 48 + h * 8;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float x = sum[4 * g + e] + b3[nt * 32 + 8 * g + 4 * h + e];
+                        v[e] = x > 0.f ? x : 0.f;
+                    }
+#pragma unroll
+                    for (int p = 0; p < 3; p++) {
+                        bf16x4 part;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const __bf16 q = (__bf16)v[e];
+                            part[e] = q;
+                            v[e] -= (float)q;
+                        }
+                        *reinterpret_cast<bf16x4 *>(dst + g * 48 + p * 16) = part;
+                    }
+                }
+            }
+        } else {
+            block_b16<3>(a2, wf3, blk, kq, lane, acc4);
+            store_act3(mt, nt, reduce_quarters(scratch, blk, kq, lane, acc4));
+        }
     } else {
         const int mt = wave >> 1, nt = wave & 1;  // conv2 / conv3: one 32 x 32 output tile per wave
         const int m = mt * 32 + i < kM2 ? mt * 32 + i : kM2 - 1;
@@ -568,7 +608,8 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     if (!(h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32)) return false;
     static bool attr_set = false;
     if (!attr_set) {
-        const void *kerns[] = {(const void *)k_convnet_fused<true, true, true>,  (const void *)k_convnet_fused<false, true, true>,
+        const void *kerns[] = {(const void *)k_convnet_fused<true, true, true, true>,
+                               (const void *)k_convnet_fused<true, true, true>,  (const void *)k_convnet_fused<false, true, true>,
                                (const void *)k_convnet_fused<true, true, false>, (const void *)k_convnet_fused<false, true, false>,
                                (const void *)k_convnet_fused<true, false, false>, (const void *)k_convnet_fused<false, false, false>};
         for (const void *kp : kerns)
@@ -584,14 +625,24 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
                        keep ? h->w_t2 : nullptr);
     h->wt_from_forward = keep;
     static const bool c1_f32 = getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1';  // A/B switch: conv1 on the float32 matrix pipe
+    float *out3 = h->act3;
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, h->act3,
+        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
                            keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
     };
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
-    if (batch >= 512)
+    if (h->probe0 && hipEventRecord(h->probe0, st) != hipSuccess) return false;  // measurement hook: exactly this kernel, on its launch stream
+    // the dense layers will run on operand planes (srlx_qnet_dense_rows's own condition): conv3 writes them itself, float32 act3 is not produced
+    static const bool no_planes_out = getenv("SRLX_NO_CONV_PLANES") && getenv("SRLX_NO_CONV_PLANES")[0] == '1';  // A/B switch: float32 act3 + a split pass
+    h->a3_planes_fresh = false;
+    if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && !keep && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch)) {
+        out3 = reinterpret_cast<float *>(h->a3_planes);
+        launch(k_convnet_fused<true, true, true, true>);
+        h->a3_planes_fresh = true;
+    } else if (batch >= 512)
         c1_f32 ? launch(k_convnet_fused<true, false, false>) : c23_f32 ? launch(k_convnet_fused<true, true, false>) : launch(k_convnet_fused<true, true, true>);
     else
         c1_f32 ? launch(k_convnet_fused<false, false, false>) : c23_f32 ? launch(k_convnet_fused<false, true, false>) : launch(k_convnet_fused<false, true, true>);
+    if (h->probe1 && hipEventRecord(h->probe1, st) != hipSuccess) return false;
     return hipGetLastError() == hipSuccess;
 }

@@ -27,7 +27,8 @@ struct srlx_qnet {
     float *adam_m, *adam_v;               // BORROWED optimiser state of wf (NULL: the gradient is written out instead)
     double adam_lr, adam_b1, adam_b2, adam_eps;
     const int64_t *adam_step;             // BORROWED device scalar: optimiser steps already taken
-    hipEvent_t probe0, probe1;            // optional, caller-owned: recorded around the two conv GEMM launches of the next forward (srlx_qnet_set_probe)
+    hipEvent_t probe0, probe1;            // optional, caller-owned: recorded right around the convolution kernel launch(es) of the next forward (srlx_qnet_set_probe)
+    hipEvent_t probe_fc0, probe_fc1;      // the same around the first dense layer's GEMM launch (srlx_qnet_set_probe_fc1)
     // NoisyLinear dense layers (srlx_qnet_bind_noisy, srlx_noisy.hip): wf..a2b above then point at `eff`, the effective tensors
     // mu + sigma * eps of the current noise draw; order of the six: wf, bf, v2w, v2b, a2w, a2b
     const float *mu[6], *sig[6];          // BORROWED torch parameters
@@ -40,6 +41,12 @@ struct srlx_qnet {
     bool side_external;                   // h->side was handed in (srlx_qnet_set_side_stream): not ours to destroy
     bool wt_from_forward;                 // the last forward already built w_t / w_t2 (fused path of a training handle)
     float *wpack;                         // conv filters in MFMA-fragment order (srlx_qnet_fused.hip), rebuilt per forward
+    // pre-split bf16 operand planes of the first dense layer (srlx_fc1_planes.hip; srlx_qnet_enable_fc1_planes): [row][K/8][3 parts][8 bf16]
+    void *wf_planes;                      // [2*hidden][flat] as planes: valid after srlx_qnet_refresh_fc1_planes
+    void *a3_planes;                      // [max_batch][flat] as planes: written by the convolution kernel's epilogue (or by a split pass)
+    bool planes_valid;                    // wf_planes holds the weight the next forward should use
+    bool a3_planes_fresh;                 // the convolution kernel of THIS forward wrote a3_planes itself
+    bool want_planes_out;                 // this forward continues into the dense layers (set by forward_u8_impl; a convs-only call needs float32 act3)
 };
 
 // srlx_noisy.hip: (re)materialise the effective dense-layer tensors with a fresh draw (no-op for a plain network)
@@ -51,6 +58,13 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t rows, int64_t stride, float *d_q,
 
 // srlx_qnet_fused.hip: conv1 -> conv2 -> conv3 in one kernel (activations in LDS); false when the geometry is not the Atari one
 bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st);
+
+// srlx_fc1_planes.hip: the first dense layer of chip-filling launches as a conversion-free GEMM on pre-split bf16 operand planes
+int srlx_fc1_planes_alloc(srlx_qnet *h);
+int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst, hipStream_t st);
+int srlx_fc1_planes_split_act(srlx_qnet *h, int64_t rows, hipStream_t st);
+bool srlx_fc1_planes_applicable(const srlx_qnet *h, int64_t rows);
+int srlx_fc1_planes_gemm(srlx_qnet *h, int64_t rows, int splits, int kps, hipStream_t st);
 
 // implicit-GEMM data gradient on the matrix cores (defined next to k_gemm in srlx_qnet.hip)
 int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,

@@ -49,6 +49,8 @@ class EngineQNet(nn.Module):
         # reference-equivalent initialisation: build the mirrored module and convert it
         from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
 
+        self.weights_version = 0  # bumped by every state-dict load: caches derived from the weights (QNetInference's operand planes) compare it
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._bump_version())
         self.fix_formats()
         self.load_reference_state_dict(atari_qnetwork(n_actions, hw, window, hidden, self.noisy, filters, dueling_type).state_dict())
 
@@ -105,8 +107,12 @@ class EngineQNet(nn.Module):
         w = w.detach().view(2 * H, P, C).permute(0, 2, 1).reshape(2 * H, C * P)
         return w[:H].clone(), w[H:].clone()
 
+    def _bump_version(self):
+        self.weights_version += 1
+
     def load_reference_state_dict(self, sd):
         """The reference's keys and layouts (plain layers: `.weight` / `.bias`; NoisyLinear: `.w_mu` / `.w_sigma` / `.b_mu` / `.b_sigma`)."""
+        self._bump_version()
         H = self.hidden
         wk, bk = ("w_mu", "b_mu") if self.noisy else ("weight", "bias")
         dev = self.fc1.weight.device
@@ -263,18 +269,60 @@ class QNetInference:
                                                   N.torch_stream_ptr()))
 
     def set_probe(self, ev_start: torch.cuda.Event, ev_end: torch.cuda.Event):
-        """The next forward records the two (timing-enabled, already created) events around its two conv GEMM launches."""
+        """The next forward records the two (timing-enabled, already created) events right around its convolution kernel launch(es)."""
         N.check(self.lib.srlx_qnet_set_probe(self.h, N.c_p(ev_start.cuda_event), N.c_p(ev_end.cuda_event)))
+
+    def set_probe_fc1(self, ev_start: torch.cuda.Event, ev_end: torch.cuda.Event):
+        """The same around the first dense layer's GEMM launch."""
+        N.check(self.lib.srlx_qnet_set_probe_fc1(self.h, N.c_p(ev_start.cuda_event), N.c_p(ev_end.cuda_event)))
+
+    # ---- first dense layer on pre-split operand planes (srlx_fc1_planes.hip): for the chip-filling launches of an actor handle ----------------
+    def enable_fc1_planes(self, private_weights: bool):
+        """Keep the first dense layer's weight also as three bf16 part planes and run chip-filling forwards (>= 512 rows, multiples of 128) on them,
+        conversion-free and bit-identical.  `private_weights=True`: nobody but `refresh_from` / `weights_changed` changes this network's weights
+        (the engine's private actor copy), so the planes stay valid between those calls; False: the weights are shared with a learner, every
+        chip-filling forward re-splits them first (one 80 MB pass)."""
+        assert not self.net.noisy
+        N.check(self.lib.srlx_qnet_enable_fc1_planes(self.h))
+        self._planes, self._planes_private, self._planes_stale, self._planes_version = True, bool(private_weights), True, -1
+
+    def weights_changed(self):
+        """The bound float32 weights were written by somebody else (load_state_dict, a broadcast): the planes are stale."""
+        if getattr(self, "_planes", False):
+            self._planes_stale = True
+            N.check(self.lib.srlx_qnet_invalidate_fc1_planes(self.h))
+
+    def refresh_from(self, online: "EngineQNet"):
+        """This network := `online` (all parameter tensors), the first dense layer's weight copied AND split into planes in one pass."""
+        mine, theirs = self.net.kernel_parameters(), online.kernel_parameters()
+        if getattr(self, "_planes", False):
+            k = [i for i, p in enumerate(mine) if p is self.net.fc1.weight][0]
+            with torch.no_grad():
+                torch._foreach_copy_([p for i, p in enumerate(mine) if i != k], [p for i, p in enumerate(theirs) if i != k])
+            N.check(self.lib.srlx_qnet_refresh_fc1_planes(self.h, N.tptr(theirs[k]), N.tptr(mine[k]), N.torch_stream_ptr()))
+            self._planes_stale, self._planes_version = False, self.net.weights_version
+        else:
+            with torch.no_grad():
+                torch._foreach_copy_(mine, theirs)
+
+    def _planes_ready(self, B: int):
+        if not getattr(self, "_planes", False) or B < 512 or B % 128:
+            return
+        if self._planes_stale or not self._planes_private or self._planes_version != self.net.weights_version:
+            N.check(self.lib.srlx_qnet_refresh_fc1_planes(self.h, None, None, N.torch_stream_ptr()))
+            self._planes_stale, self._planes_version = False, self.net.weights_version
 
     def forward_f32(self, obs_nchw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         B = obs_nchw.shape[0]
         q = self.q[:B] if out is None else out
+        self._planes_ready(B)
         N.check(self.lib.srlx_qnet_forward_f32(self.h, B, N.tptr(obs_nchw), N.tptr(q), N.torch_stream_ptr()))
         return q
 
     def forward_u8(self, frame_base_ptr: int, frame_off: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         B = frame_off.numel() // self.window
         q = self.q[:B] if out is None else out
+        self._planes_ready(B)
         N.check(self.lib.srlx_qnet_forward_u8(self.h, B, N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(q), N.torch_stream_ptr()))
         return q
 

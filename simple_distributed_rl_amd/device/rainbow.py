@@ -154,6 +154,10 @@ class RainbowEngine:
             self.q_actor = self.q_online
         # one inference handle per concurrent user (each owns its activation buffers and, for noisy layers, its noise stream)
         self.inf_actor = QNetInference(self.q_actor, E, device, noise_seed=cfg.seed * 3 + 0xA11CE)
+        if not self.noisy and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0 and os.environ.get("SRLX_NO_FC1_PLANES", "0") != "1":
+            # chip-filling policy passes: the first dense layer on pre-split bf16 operand planes (srlx_fc1_planes.hip); with overlap the actor's
+            # private copy changes only in refresh_actor_copy, which also writes the planes (SRLX_NO_FC1_PLANES=1: A/B switch for measurements)
+            self.inf_actor.enable_fc1_planes(private_weights=self.q_actor is not self.q_online)
         self.inf_online = QNetInference(self.q_online, max(B * (n + 1), 64), device, noise_seed=cfg.seed * 3 + 0x0B0E)
         self.inf_target = QNetInference(self.q_target, B * n, device, noise_seed=cfg.seed * 3 + 0x7A26)
         if self.mfma_train:
@@ -378,8 +382,7 @@ class RainbowEngine:
     def refresh_actor_copy(self):
         """overlap=True: one multi-tensor copy online -> the actor's private network."""
         if self.q_actor is not self.q_online:
-            with torch.no_grad():
-                torch._foreach_copy_(list(self.q_actor.parameters()), list(self.q_online.parameters()))
+            self.inf_actor.refresh_from(self.q_online)
 
     def actor_front(self, events=None):
         """Network pass + action selection + environments of one lock-step: reads the ring, writes nothing shared."""

@@ -212,3 +212,40 @@ def test_the_bf16_pipe_equals_the_float32_pipe(tmp_path):
     for a, b in (("bf16", "f32"), ("bf16", "all_f32"), ("convs_bf16_only", "all_f32"), ("f32", "all_f32")):
         diff = float((outs[a] - outs[b]).abs().max())
         assert 0 < scale and 0 < diff <= 2e-6 * scale, (a, b, diff, scale)
+
+
+def test_fc1_operand_planes_path_is_bit_identical():
+    """The chip-filling launches' first dense layer on pre-split bf16 operand planes (srlx_fc1_planes.hip: LDS-DMA tiles, no conversions) computes the same
+    six partial products in the same order as the staging-split GEMM: Q-values bit for bit, also after the weights changed (refresh_from / a state-dict
+    load) -- and a handle whose planes were never refreshed must not use stale ones."""
+    from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference
+
+    E, F = 1024, 84 * 84
+    net, other = _mk((84, 84), 4, 512, 6, seed=0), _mk((84, 84), 4, 512, 6, seed=1)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ring = torch.randint(0, 256, (512 * F,), dtype=torch.uint8, device="cuda", generator=g)
+    off = torch.randint(0, 512, (E, 4), device="cuda", generator=g) * F
+    off[5, :2] = -1  # zero-history frames
+    plain = QNetInference(net, E)
+    want = plain.forward_u8(ring.data_ptr(), off).clone()
+    shared = QNetInference(net, E)
+    shared.enable_fc1_planes(private_weights=False)
+    assert torch.equal(shared.forward_u8(ring.data_ptr(), off), want)
+    with torch.no_grad():  # a learner updates the shared weights in place: the next forward must see them
+        net.fc1.weight.mul_(1.5)
+        net.conv3.bias.add_(0.01)
+    want2 = plain.forward_u8(ring.data_ptr(), off).clone()
+    assert not torch.equal(want, want2) and torch.equal(shared.forward_u8(ring.data_ptr(), off), want2)
+    # a private actor copy: refreshed from the online network in one pass (float32 copy + planes)
+    actor_net = _mk((84, 84), 4, 512, 6, seed=2)
+    priv = QNetInference(actor_net, E)
+    priv.enable_fc1_planes(private_weights=True)
+    priv.refresh_from(net)
+    assert all(torch.equal(a, b) for a, b in zip(actor_net.kernel_parameters(), net.kernel_parameters()))
+    assert torch.equal(priv.forward_u8(ring.data_ptr(), off), want2)
+    actor_net.load_reference_state_dict(other.reference_state_dict())  # weights replaced behind the handle's back: planes are re-split, not reused
+    plain_other = QNetInference(other, E)
+    assert torch.equal(priv.forward_u8(ring.data_ptr(), off), plain_other.forward_u8(ring.data_ptr(), off))
+    for rows in (640, 96):  # 5 row tiles (another K split than 1024 rows); small launches keep the staging-split kernel
+        o = off[:rows].contiguous()
+        assert torch.equal(priv.forward_u8(ring.data_ptr(), o), plain_other.forward_u8(ring.data_ptr(), o))

@@ -29,7 +29,16 @@ constexpr int kP1 = 21, kM1 = kP1 * kP1;           // conv1 output side / pixels
 constexpr int kP2 = 11, kM2 = kP2 * kP2;           // conv2 = conv3 output side / pixels
 constexpr int kS1 = 36, kS2 = 68;                  // LDS pixel strides (floats) of act1 / act2
 constexpr int kWaves = 8;
-constexpr size_t kLdsBytes = 4 * kFrame + (size_t)kM1 * kS1 * 4 + (size_t)kM2 * kS2 * 4;
+constexpr size_t kLdsF32 = 4 * kFrame + (size_t)kM1 * kS1 * 4 + (size_t)kM2 * kS2 * 4;  // every activation float32 (the f32-pipe A/B variants)
+// The split-bf16 kernel keeps act1 / act2 in LDS as three bf16 part planes per pixel ([part][channel]; 16 bytes of padding make the pixel stride an odd
+// multiple of 16 bytes, so the 16 lanes of a ds_read_b128 phase hit 16 different bank quads):
+//   [frames 31.0 KB | conv1's shared filter parts 32.1 KB] -> later act2 planes (121 x 400 B = 47.3 KB) | act1 planes 441 x 208 B = 89.6 KB
+// the K-quarter reductions park their partials in the act1 region once its readers are done.
+constexpr int kPB1 = 3 * 32 * 2 + 16, kPB2 = 3 * 64 * 2 + 16;
+constexpr size_t kOffA1P = 4 * kFrame + (size_t)kM2 * kS2 * 4;
+constexpr size_t kLdsPlanes = kOffA1P + (size_t)kM1 * kPB1;
+constexpr size_t kLdsBytes = kLdsPlanes > kLdsF32 ? kLdsPlanes : kLdsF32;
+static_assert((size_t)kM2 * kPB2 <= kOffA1P && kOffA1P % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS plan of the split-bf16 kernel");
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -168,15 +177,18 @@ __device__ __forceinline__ void tile_from_lds(const float *__restrict__ lds_in, 
 // conv2 / conv3 on the bf16 matrix pipe (float32 x float32 from six exact partial products, like k_gemm_b16 of srlx_qnet.hip).  With one 32 x 32
 // tile per wave an MFMA needs 2 KB of operands -- 256 B per clock per CU at the bf16 pipe's rate, twice what LDS delivers and four times what L2
 // does -- so here a wave owns a 64 x 64 output BLOCK (2 pixel tiles x both channel tiles: four accumulators, every fragment used twice) over a
-// QUARTER of K; the eight waves are 2 blocks x 4 K quarters and the quarters are summed through LDS afterwards.  A fragments: float32 out of LDS
-// (layout unchanged), split into three bf16 parts on the fly (88 VALU instructions beside 24 MFMAs); B fragments: pre-split by k_pack_filters.
+// QUARTER of K; the eight waves are 2 blocks x 4 K quarters and the quarters are summed through LDS afterwards.
+// Both operands arrive PRE-SPLIT: the filters by k_pack_filters, the activations by the epilogue of the layer that produced them (act1 / act2 live in LDS
+// as three bf16 part planes per pixel: [part][channel], kPB1 / kPB2 bytes per pixel).  Splitting the A fragments inside this loop cost 88 vector
+// instructions per 24 MFMAs, and on gfx950 vector instructions take their issue slots from the matrix pipe (tools/mfma_peak.hip): the loop ran at 60 % of its
+// MFMA time.  Now a K step is 6 global_load_dwordx4 + 6 ds_read_b128 + 24 MFMAs and the address arithmetic of one tap.
 //   LAYER 2: 4 x 4 stride 2 pad 2 over act1 (21 x 21 x 32), K = 16 taps x 32 = 32 steps of 16;  LAYER 3: 3 x 3 stride 1 pad 1 over act2 (11 x 11 x 64), 36 steps
-// SWAP: the MFMA operands trade places (filters as the A operand), so each accumulator tile comes out TRANSPOSED -- rows = channels, columns = pixels: a lane
-// then holds runs of four consecutive channels of ONE pixel, which is what the bf16 operand planes of the first dense layer are made of (store_act3_planes).
-template <int LAYER, bool SWAP = false>
-__device__ __forceinline__ void block_b16(const float *__restrict__ lds_in, const bf16x8 *__restrict__ wfrag, int blk, int kq, int lane, f32x16 (&acc)[2][2]) {
+// The MFMA operands are SWAPPED (filters as the A operand), so each accumulator tile comes out transposed -- rows = channels, columns = pixels: a lane
+// holds runs of four consecutive channels of ONE pixel, i.e. 8-byte pieces of the next layer's part planes (and float4s of the float32 tensors).
+template <int LAYER>
+__device__ __forceinline__ void block_planes(const unsigned char *__restrict__ lds_in, const bf16x8 *__restrict__ wfrag, int blk, int kq, int lane, f32x16 (&acc)[2][2]) {
     constexpr int S = LAYER == 2 ? 32 : 36, SPT = LAYER == 2 ? 2 : 4, KW = LAYER == 2 ? 4 : 3, STR = LAYER == 2 ? 2 : 1, PAD = LAYER == 2 ? 2 : 1;
-    constexpr int IN = LAYER == 2 ? kP1 : kP2, PS = LAYER == 2 ? kS1 : kS2, QS = S / 4;
+    constexpr int IN = LAYER == 2 ? kP1 : kP2, PB = LAYER == 2 ? kPB1 : kPB2, CB = LAYER == 2 ? 64 : 128, QS = S / 4;
     const int i = lane & 31, h = lane >> 5;
     int oy[2], ox[2];
 #pragma unroll
@@ -190,10 +202,12 @@ __device__ __forceinline__ void block_b16(const float *__restrict__ lds_in, cons
         for (int n = 0; n < 2; n++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][n][r] = 0.f;
-    float4 fa0[2][2], fa1[2][2];  // [pixel tile][half of the 8 floats]
+    bf16x8 fa0[2][3], fa1[2][3];  // [pixel tile][part]
     bf16x8 fb0[2][3], fb1[2][3];  // [channel tile][part]
-    auto load = [&](int sl, float4(&fa)[2][2], bf16x8(&fb)[2][3]) __attribute__((always_inline)) {
-        const int sp = kq * QS + sl, tap = sp / SPT, cg = sp % SPT, ky = tap / KW, kx = tap % KW;
+    auto load = [&](int sl, bf16x8(&fa)[2][3], bf16x8(&fb)[2][3]) __attribute__((always_inline)) {
+        // which K steps a quarter owns: conv2 -- kernel row kq (8 consecutive steps); conv3 -- the 16-channel group kq of every tap, so that the tap of
+        // step sl is a compile-time constant and the clamped pixel address costs a handful of instructions (a quarter of consecutive steps: 355 VALU per pass)
+        const int sp = LAYER == 2 ? kq * QS + sl : sl * SPT + kq, tap = LAYER == 2 ? sp / SPT : sl, cg = LAYER == 2 ? sp % SPT : kq, ky = tap / KW, kx = tap % KW;
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
@@ -201,34 +215,19 @@ __device__ __forceinline__ void block_b16(const float *__restrict__ lds_in, cons
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             const int iy = clampi(oy[a] * STR + ky - PAD, 0, IN - 1), ix = clampi(ox[a] * STR + kx - PAD, 0, IN - 1);
-            const float *pa = lds_in + (iy * IN + ix) * PS + cg * 16 + 8 * h;
-            fa[a][0] = *reinterpret_cast<const float4 *>(pa);
-            fa[a][1] = *reinterpret_cast<const float4 *>(pa + 4);
+            const unsigned char *pa = lds_in + (iy * IN + ix) * PB + cg * 32 + 16 * h;
+#pragma unroll
+            for (int q = 0; q < 3; q++) fa[a][q] = *reinterpret_cast<const bf16x8 *>(pa + q * CB);
         }
     };
-    auto mfma24 = [&](const float4(&fa)[2][2], const bf16x8(&fb)[2][3]) __attribute__((always_inline)) {
-        bf16x8 pa[2][3];
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            float r[8] = {fa[a][0].x, fa[a][0].y, fa[a][0].z, fa[a][0].w, fa[a][1].x, fa[a][1].y, fa[a][1].z, fa[a][1].w};
-#pragma unroll
-            for (int t = 0; t < 3; t++)
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const __bf16 b = (__bf16)r[j];
-                    pa[a][t][j] = b;
-                    r[j] -= (float)b;
-                }
-        }
+    auto mfma24 = [&](const bf16x8(&fa)[2][3], const bf16x8(&fb)[2][3]) __attribute__((always_inline)) {
         constexpr int pq[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};  // smallest partial products first
 #pragma unroll
         for (int c = 0; c < 6; c++)
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
-                for (int n = 0; n < 2; n++)
-                    acc[a][n] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][pq[c][1]], pa[a][pq[c][0]], acc[a][n], 0, 0, 0)
-                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][pq[c][0]], fb[n][pq[c][1]], acc[a][n], 0, 0, 0);
+                for (int n = 0; n < 2; n++) acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][pq[c][1]], fa[a][pq[c][0]], acc[a][n], 0, 0, 0);
     };
     load(0, fa0, fb0);
 #pragma unroll
@@ -244,35 +243,59 @@ __device__ __forceinline__ void block_b16(const float *__restrict__ lds_in, cons
     }
 }
 
-// Sums the four K-quarter partial blocks of every output tile through `scratch` (24 KB of LDS nobody else uses meanwhile).  Wave (blk, kq) ends up
-// OWNING tile kq = (pixel tile kq >> 1, channel tile kq & 1) of its block: in round t the three other waves of a block park their partial of tile t
-// (four ds_write_b128 each), the owner adds them in K order.  Four rounds, two barriers each; the epilogues then run on all eight waves at once.
+// bias + ReLU on four consecutive channels of one pixel (one quarter g of a transposed accumulator tile), then the exact three-way bf16 split
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+__device__ __forceinline__ float4 bias_relu4(const f32x16 &acc, int g, const float4 &bias) {
+    float4 v = make_float4(acc[4 * g] + bias.x, acc[4 * g + 1] + bias.y, acc[4 * g + 2] + bias.z, acc[4 * g + 3] + bias.w);
+    v.x = v.x > 0.f ? v.x : 0.f, v.y = v.y > 0.f ? v.y : 0.f, v.z = v.z > 0.f ? v.z : 0.f, v.w = v.w > 0.f ? v.w : 0.f;
+    return v;
+}
+__device__ __forceinline__ void split3(const float4 &x, bf16x4 (&part)[3]) {
+    float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const __bf16 q = (__bf16)v[e];
+            part[p][e] = q;
+            v[e] -= (float)q;
+        }
+}
+
+// Sums the four K-quarter partial blocks of every output tile through `scratch` (96 KB of LDS nobody else uses meanwhile).  Wave (blk, kq) ends up
+// OWNING tile kq = (pixel tile kq >> 1, channel tile kq & 1) of its block: every wave parks its partials of the three tiles it does not own (twelve
+// ds_write_b128), ONE barrier, the owner adds the four partials in K order (twelve ds_read_b128); the epilogues then run on all eight waves at once.
+// (Round by round through 24 KB -- four rounds of two barriers -- this took 5.4 k clocks per layer, a tenth of the kernel.)
+constexpr size_t kScratchBytes = 2 * 4 * 3 * 4 * 64 * 16;
 __device__ __forceinline__ f32x16 reduce_quarters(float *__restrict__ scratch, int blk, int kq, int lane, f32x16 (&acc)[2][2]) {
     float4 *sc = reinterpret_cast<float4 *>(scratch);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const f32x16 &part = acc[t >> 1][t & 1];
+        if (kq != t) {
+            const int slot = (blk * 4 + t) * 3 + (kq < t ? kq : kq - 1);
+#pragma unroll
+            for (int v = 0; v < 4; v++) sc[(slot * 4 + v) * 64 + lane] = make_float4(part[4 * v], part[4 * v + 1], part[4 * v + 2], part[4 * v + 3]);
+        }
+    }
+    __syncthreads();
     f32x16 sum;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const f32x16 &mine = acc[t >> 1][t & 1];
-        if (kq != t) {
-            const int slot = blk * 3 + (kq < t ? kq : kq - 1);
-#pragma unroll
-            for (int v = 0; v < 4; v++) sc[(slot * 4 + v) * 64 + lane] = make_float4(mine[4 * v], mine[4 * v + 1], mine[4 * v + 2], mine[4 * v + 3]);
-        }
-        __syncthreads();
         if (kq == t) {
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 float4 part[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    part[k] = k == t ? make_float4(mine[4 * v], mine[4 * v + 1], mine[4 * v + 2], mine[4 * v + 3]) : sc[((blk * 3 + (k < t ? k : k - 1)) * 4 + v) * 64 + lane];
+                    part[k] = k == t ? make_float4(mine[4 * v], mine[4 * v + 1], mine[4 * v + 2], mine[4 * v + 3]) : sc[(((blk * 4 + t) * 3 + (k < t ? k : k - 1)) * 4 + v) * 64 + lane];
                 sum[4 * v] = ((part[0].x + part[1].x) + part[2].x) + part[3].x;  // K quarters in order
                 sum[4 * v + 1] = ((part[0].y + part[1].y) + part[2].y) + part[3].y;
                 sum[4 * v + 2] = ((part[0].z + part[1].z) + part[2].z) + part[3].z;
                 sum[4 * v + 3] = ((part[0].w + part[1].w) + part[2].w) + part[3].w;
             }
         }
-        __syncthreads();
     }
     return sum;
 }
@@ -287,10 +310,13 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
                                                                 float *__restrict__ act3,
                                                                 float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg) {
     static_assert(!PLANES || C23B16, "operand planes come out of the split-bf16 conv3 only");
+    static_assert(!C23B16 || C1B16, "the split-bf16 conv2 / conv3 read the part planes conv1's split-bf16 epilogue writes");
+    constexpr bool PL = C23B16;  // act1 / act2 as bf16 part planes in LDS (kPB1 / kPB2 bytes per pixel) instead of float32
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u8 *fr = smem;                                                 // [4][88][88]
-    float *a1 = reinterpret_cast<float *>(smem + 4 * kFrame);      // [441][36]
+    float *a1 = reinterpret_cast<float *>(smem + 4 * kFrame);      // [441][36]            (float32 layout)
     float *a2 = a1 + kM1 * kS1;                                    // [121][68]
+    unsigned char *a1p = smem + kOffA1P, *a2p = smem;              // [441][kPB1], [121][kPB2] (plane layout; act2 overlays the frames and conv1's filters)
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, h = lane >> 5, i = lane & 31;
     const i64 b = blockIdx.x;
     constexpr int H = 84, W = 84, NT = 64 * kWaves;
@@ -301,37 +327,53 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
 
     // ---- stage the four frames (uint8, replicate padding materialised): padded dword (row r, dword d) covers image columns
     //      clamp(4d - 3 .. 4d), image row clamp(r - 3); all loads of all frames are in flight before the first LDS store
+    //      A lane owns the SAME four padded dwords (t + 512 j) of every frame, so the clamped source offset and the border byte pattern are computed
+    //      once per lane and dword -- the address arithmetic used to be 1000 VALU instructions per wave (8 k of the kernel's 70 k clocks per sample:
+    //      vector instructions take their issue slots from the matrix pipe on gfx950); (row, dword) advance by 512 = 23 x 22 + 6 per j.
+    // conv1's filter fragments do not depend on the sample: requested first, they travel during the frame-offset round trip (see the conv1 section)
+    bf16x8 bw2[C1B16 ? 16 : 1], wtmp[C1B16 ? 4 : 1];
+    if constexpr (C1B16) {
+        const bf16x8 *wsrc = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int e = t + NT * j, l = e & 63, sp2 = e >> 6;  // sp2 = step * 2 + part
+            wtmp[j] = wsrc[((sp2 >> 1) * 3 + (sp2 & 1)) * 64 + l];
+        }
+#pragma unroll
+        for (int sp = 0; sp < 16; sp++) bw2[sp] = wsrc[(sp * 3 + 2) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
     {
         constexpr int kDw = kPad * (kPad / 4);              // 1936 dwords per frame
-        constexpr int kPer = (4 * kDw + NT - 1) / NT;       // dwords per lane over the four frames
-        unsigned v[kPer];
-        const i64 o0 = frame_off[b * 4], o1 = frame_off[b * 4 + 1], o2 = frame_off[b * 4 + 2], o3 = frame_off[b * 4 + 3];  // one round trip, then every frame load is independent
+        constexpr int kCols = kPad / 4;                      // 22 dwords per padded row
+        constexpr int kPer = (kDw + NT - 1) / NT;            // 4 dwords per lane and frame (the last one for t < 400 only)
+        static_assert(NT == 23 * kCols + 6, "the (row, dword) stepping below assumes 512 lanes over 22-dword rows");
+        unsigned v[4][kPer], goff[kPer], sel[kPer];
+        i64 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) o[q] = frame_off[b * 4 + q];  // one round trip, then every frame load is independent
+        int r = t / kCols, c = t % kCols;
 #pragma unroll
         for (int j = 0; j < kPer; j++) {
-            const int idx = t + NT * j, q = idx / kDw, d = idx % kDw;
-            v[j] = 0u;
-            if (idx < 4 * kDw) {
-                const i64 o = q == 0 ? o0 : (q == 1 ? o1 : (q == 2 ? o2 : o3));
-                if (o >= 0) {
-                    const int r = d / (kPad / 4), c = d % (kPad / 4);
-                    __builtin_memcpy(&v[j], base + o + (i64)clampi(r - 3, 0, H - 1) * W + clampi(4 * c - 3, 0, W - 4), 4);
-                }
-            }
+            goff[j] = (unsigned)(clampi(r - 3, 0, H - 1) * W + clampi(4 * c - 3, 0, W - 4));
+            // border dwords: column clamp(x + p) sits at byte clamp(x + p) - xs of the loaded dword (x = 4 c - 3, xs = clamp(x)): left edge = byte 0 four
+            // times, right edge (c = 21: columns 81 82 83 83 out of the dword at 80) = bytes 1 2 3 3; v_perm_b32 selectors, zero frames stay zero
+            sel[j] = c == 0 ? 0x00000000u : (c == kCols - 1 ? 0x03030201u : 0x03020100u);
+            c += 6, r += 23;
+            if (c >= kCols) c -= kCols, r += 1;
         }
 #pragma unroll
-        for (int j = 0; j < kPer; j++) {
-            const int idx = t + NT * j;
-            if (idx >= 4 * kDw) continue;
-            const int d = idx % kDw;
-            const int x = 4 * (d % (kPad / 4)) - 3, xs = clampi(x, 0, W - 4);
-            unsigned o = v[j];
-            if (x != xs) {  // border: column clamp(x + p) sits at byte clamp(x + p) - xs of the loaded dword (zero frames stay zero)
-                o = 0u;
+        for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int p = 0; p < 4; p++) o |= ((v[j] >> (8 * (clampi(x + p, 0, W - 1) - xs))) & 255u) << (8 * p);
+            for (int j = 0; j < kPer; j++) {
+                v[q][j] = 0u;
+                if ((j + 1 < kPer || t + NT * j < kDw) && o[q] >= 0) __builtin_memcpy(&v[q][j], base + o[q] + goff[j], 4);
             }
-            reinterpret_cast<unsigned *>(fr)[idx] = o;
-        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int j = 0; j < kPer; j++)
+                if (j + 1 < kPer || t + NT * j < kDw) reinterpret_cast<unsigned *>(fr)[q * kDw + t + NT * j] = __builtin_amdgcn_perm(0u, v[q][j], sel[j]);
     }
     // ---- conv1 on the bf16 matrix pipe, exactly (see k_pack_filters): the A operand is the uint8 pixel itself (one bf16), the filter / 255 is
     //      the sum of three bf16 parts, v_mfma_f32_32x32x16_bf16 accumulates the exact partial products in float32.  3 MFMAs of 32 cycles per
@@ -341,18 +383,14 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
         // Filter fragments: every wave needs all 48 KB of them.  Fetched per wave they cost the CU's load path 384 KB per sample (4.8 k clocks of the
         // staging phase).  The act2 region of LDS is idle until conv2: the workgroup fetches parts 0 and 1 of all 16 steps ONCE into it (32 KB,
         // [step][part][lane] x 16 B), only part 2 stays in registers (16 x 16 B per lane).
-        bf16x8 bw2[16];
-        const bf16x8 *wsrc = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3);
-        bf16x8 *wl = reinterpret_cast<bf16x8 *>(a2);
+        bf16x8 *wl = reinterpret_cast<bf16x8 *>(smem + (PL ? (size_t)4 * kFrame : (size_t)4 * kFrame + (size_t)kM1 * kS1 * 4));
         static_assert(16 * 2 * 64 * 16 <= kM2 * kS2 * 4, "conv1's shared filter parts must fit into the act2 region");
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int e = t + NT * j, l = e & 63, sp2 = e >> 6;  // sp2 = step * 2 + part
-            wl[e] = wsrc[((sp2 >> 1) * 3 + (sp2 & 1)) * 64 + l];
-        }
-#pragma unroll
-        for (int sp = 0; sp < 16; sp++) bw2[sp] = wsrc[(sp * 3 + 2) * 64 + lane];
+        for (int j = 0; j < 4; j++) wl[t + NT * j] = wtmp[j];
         const float bias = b1[i];
+        float4 bias4[4];  // plane layout: the tile comes out transposed (rows = channels), a lane's quarter g = channels 8 g + 4 h .. + 3
+#pragma unroll
+        for (int g = 0; g < 4; g++) bias4[g] = PL ? *reinterpret_cast<const float4 *>(b1 + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
         stamp(1);
         __syncthreads();
         stamp(2);
@@ -383,9 +421,15 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
                     a[j] = (__bf16)(float)((w.x >> (8 * j)) & 255u);
                     a[4 + j] = (__bf16)(float)((w.y >> (8 * j)) & 255u);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w.f0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w.f1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw2[sp], acc, 0, 0, 0);
+                if constexpr (PL) {  // operands swapped: the transposed tile (rows = channels, columns = pixels), same sums
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f0, a, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f1, a, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw2[sp], a, acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w.f0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w.f1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw2[sp], acc, 0, 0, 0);
+                }
             };
             fetch(0, wa);
 #pragma unroll
@@ -399,15 +443,32 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
                 mfma3(sp + 1, wb);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 h (pixel)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int mm = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if constexpr (PL) {
+                // transposed C/D layout: col = lane & 31 = pixel, row = (r & 3) + 8 (r >> 2) + 4 h = channel: four consecutive channels of one pixel per quarter
+                // g = r >> 2 -> bias, ReLU, the exact three-way bf16 split ONCE per activation, 8-byte pieces of the pixel's three part planes
+                const int mm = tile * 32 + i;
                 if (mm < kM1) {
-                    float v = acc[r] + bias;
-                    v = v > 0.f ? v : 0.f;
-                    a1[mm * kS1 + i] = v;
-                    if (act1_out) act1_out[(b * kM1 + mm) * 32 + i] = v;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const float4 v = bias_relu4(acc, g, bias4[g]);
+                        if (act1_out) *reinterpret_cast<float4 *>(act1_out + (b * kM1 + mm) * 32 + 8 * g + 4 * h) = v;
+                        bf16x4 part[3];
+                        split3(v, part);
+#pragma unroll
+                        for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(a1p + mm * kPB1 + q * 64 + (8 * g + 4 * h) * 2) = part[q];
+                    }
+                }
+            } else {
+                // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 h (pixel)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int mm = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (mm < kM1) {
+                        float v = acc[r] + bias;
+                        v = v > 0.f ? v : 0.f;
+                        a1[mm * kS1 + i] = v;
+                        if (act1_out) act1_out[(b * kM1 + mm) * 32 + i] = v;
+                    }
                 }
             }
         }
@@ -496,61 +557,52 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     if constexpr (C23B16) {
         const int blk = wave & 1, kq = wave >> 1;  // 64 x 64 output block (pixel tiles 2 blk, 2 blk + 1; both channel tiles) x K quarter
         f32x16 acc4[2][2];
-        float *scratch = reinterpret_cast<float *>(fr);  // the staged frames are dead after conv1: 24 of their 31 KB park the K-quarter partials
+        // the K-quarter partials park in the 96 KB behind the act2 planes: act1 (and the tail of conv1's filter region) is dead once conv2's block loops are done
+        constexpr size_t kOffScratch = ((size_t)kM2 * kPB2 + 1023) / 1024 * 1024;
+        static_assert(kOffScratch + kScratchBytes <= kLdsBytes, "reduction scratch");
+        float *scratch = reinterpret_cast<float *>(smem + kOffScratch);
         const bf16x8 *wf2 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B), *wf3 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B + kW2B);
-        block_b16<2>(a1, wf2, blk, kq, lane, acc4);
+        block_planes<2>(a1p, wf2, blk, kq, lane, acc4);
         stamp(5);
-        const int mt = 2 * blk + (kq >> 1), nt = kq & 1;  // the tile this wave owns after the reduction
+        __syncthreads();  // every wave has read its last act1 fragment
+        const int mt = 2 * blk + (kq >> 1), nt = kq & 1;  // the tile this wave owns after the reduction: channels nt * 32 + 8 g + 4 h + e of pixel mt * 32 + i
+        const int pix = mt * 32 + i;
         {
             const f32x16 sum = reduce_quarters(scratch, blk, kq, lane, acc4);
-            const float bias = b2[nt * 32 + i];
+            if (pix < kM2) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int mm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (mm < kM2) {
-                    float v = sum[r] + bias;
-                    v = v > 0.f ? v : 0.f;
-                    a2[mm * kS2 + nt * 32 + i] = v;
-                    if (act2_out) act2_out[(b * kM2 + mm) * 64 + nt * 32 + i] = v;
+                for (int g = 0; g < 4; g++) {
+                    const float4 v = bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b2 + nt * 32 + 8 * g + 4 * h));
+                    if (act2_out) *reinterpret_cast<float4 *>(act2_out + (b * kM2 + pix) * 64 + nt * 32 + 8 * g + 4 * h) = v;
+                    bf16x4 part[3];
+                    split3(v, part);
+#pragma unroll
+                    for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(a2p + pix * kPB2 + q * 128 + (nt * 32 + 8 * g + 4 * h) * 2) = part[q];
                 }
             }
         }
         __syncthreads();  // act2 is complete
         stamp(6);
-        if constexpr (PLANES) {
-            block_b16<3, true>(a2, wf3, blk, kq, lane, acc4);
-            const f32x16 sum = reduce_quarters(scratch, blk, kq, lane, acc4);
-            // transposed tile: column i = pixel mt * 32 + i, row (r & 3) + 8 (r >> 2) + 4 h = channel within the tile's 32 = within K-slab (pixel * 2 + nt):
-            // k-group g = r >> 2, elements 4 h .. 4 h + 3 of the group: one 8-byte half of a 16-byte chunk per (g, part)
-            const int pix = mt * 32 + i;
-            if (pix < kM2) {
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        block_planes<3>(a2p, wf3, blk, kq, lane, acc4);
+        const f32x16 sum = reduce_quarters(scratch, blk, kq, lane, acc4);
+        if (pix < kM2) {
+            if constexpr (PLANES) {
+                // k-group g of K-slab (pixel * 2 + nt) = channels nt * 32 + 8 g .. + 7: this lane's four are the 8-byte half h of a 16-byte chunk per (g, part)
                 const i64 rows = gridDim.x;
                 unsigned char *dst = reinterpret_cast<unsigned char *>(act3) + (((i64)(pix * 2 + nt) * rows + b) * 4) * 48 + h * 8;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    float v[4];
+                    bf16x4 part[3];
+                    split3(bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b3 + nt * 32 + 8 * g + 4 * h)), part);
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float x = sum[4 * g + e] + b3[nt * 32 + 8 * g + 4 * h + e];
-                        v[e] = x > 0.f ? x : 0.f;
-                    }
-#pragma unroll
-                    for (int p = 0; p < 3; p++) {
-                        bf16x4 part;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const __bf16 q = (__bf16)v[e];
-                            part[e] = q;
-                            v[e] -= (float)q;
-                        }
-                        *reinterpret_cast<bf16x4 *>(dst + g * 48 + p * 16) = part;
-                    }
+                    for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(dst + g * 48 + q * 16) = part[q];
                 }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    *reinterpret_cast<float4 *>(act3 + (b * kM2 + pix) * 64 + nt * 32 + 8 * g + 4 * h) =
+                        bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b3 + nt * 32 + 8 * g + 4 * h));
             }
-        } else {
-            block_b16<3>(a2, wf3, blk, kq, lane, acc4);
-            store_act3(mt, nt, reduce_quarters(scratch, blk, kq, lane, acc4));
         }
     } else {
         const int mt = wave >> 1, nt = wave & 1;  // conv2 / conv3: one 32 x 32 output tile per wave

@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrlx.so")
+LIB_PATH = os.environ.get("SRLX_LIB") or os.path.join(_HERE, "libsrlx.so")  # SRLX_LIB: another BUILD of libsrlx (A/B timing of kernel variants on one box)
 
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The engines synchronise their few streams with
 # events many times per step, and an event wait that crosses hardware queues costs tens of microseconds: with 3+ queues the

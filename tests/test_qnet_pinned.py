@@ -1,0 +1,126 @@
+"""The Q-network at the BENCHMARK geometry (84 x 84 x 4 frames, 6 actions, dueling 512) against the reference's own QNetwork
+(tests/golden/qnet84_{init,wide}.npz, recorded by oracle/gen_golden_qnet84.py from srl/algorithms/rainbow/model_torch.py:15-29 on CPU torch).
+The 8.0 M weights are regenerated from the generator's numpy recipe (bit for bit), only inputs and Q-values are stored.
+
+CPU part: the torch module that mirrors the reference's blocks reproduces the recorded Q-values (so every GPU test that uses the mirror as its
+yardstick is anchored to the reference at this geometry too, not only at the 8 x 8 toy of train_step_rainbow.npz).
+GPU part: the hand-written forward (split-bf16 matrix pipe, through the float32 entry AND through the uint8 ring) against the recording:
+  * rtol 1e-5 (north_star) on every Q-value; the only absolute slack is twice the reference's own float32 uncertainty (|f32 - f64| of ITS evaluation);
+  * against the reference evaluated in FLOAT64: the kernels' error is at most 2x the error of the reference's own float32 evaluation
+    (+ one ulp of max |Q|).  float32 products are evaluated as 6 of their 9 bf16 partial products; the three dropped ones are <= 2^-24 |ab| each,
+    i.e. of the size of float32's own rounding -- this is the test that says so on weights spanning 2^-6 .. 2^6 with sign-alternating runs
+    (`wide`), not only on an initialisation."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+KINDS = ("init", "wide")
+
+
+def _golden(kind):
+    import ast
+
+    from gen_golden_qnet84 import recipe_state_dict
+
+    z = np.load(os.path.join(GOLDEN, f"qnet84_{kind}.npz"))
+    keys_shapes = [(str(k), ast.literal_eval(str(s))) for k, s in zip(z["keys"], z["shapes"])]
+    sd = {k: torch.tensor(v) for k, v in recipe_state_dict(keys_shapes, kind, int(z["seed"])).items()}
+    return z, sd
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_the_mirror_module_reproduces_the_reference_network(kind):
+    from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
+
+    z, sd = _golden(kind)
+    net = atari_qnetwork(6)
+    assert list(net.state_dict().keys()) == list(sd.keys()), "the mirror keeps the reference's parameter names and order"
+    net.load_state_dict(sd)
+    x = torch.tensor(z["frames"].astype(np.float32) / 255)  # (B, H, W, C) like the reference's input
+    with torch.no_grad():
+        q = net(x).numpy()
+    np.testing.assert_allclose(q, z["q_ref_f32"], rtol=2e-6, atol=2e-6 * np.abs(z["q_ref_f32"]).max())
+
+
+def _check(q, z, label):
+    """rtol 1e-5 against the reference's float32 Q-values, with the reference's OWN float32 uncertainty (its distance to its float64 evaluation) as the
+    only absolute slack -- on the `wide` set Q-values are residues of sums a thousand times larger, and two correct float32 implementations differ by
+    that much (the float32 matrix pipe does: 2e-5 relative on |Q| > 1e-3 max |Q|; tools/qnet_accuracy.py prints the table); and against float64: at most
+    twice the reference's float32 error + one ulp of max |Q|.  Measured (tools/qnet_accuracy.py, `wide`): split-bf16 pipe 9.0e-7 max / 3.1e-7 rms of
+    max |Q|, float32 pipe 9.1e-7 / 2.8e-7, the reference's float32 evaluation 9.8e-7 max."""
+    ref32, ref64 = z["q_ref_f32"].astype(np.float64), z["q_ref_f64"]
+    q = q.astype(np.float64)
+    scale = np.abs(ref64).max()
+    err_ref = np.abs(ref32 - ref64).max()
+    excess = np.abs(q - ref32) - 1e-5 * np.abs(ref32)
+    assert excess.max() <= 2.0 * err_ref, f"{label}: {excess.max():.3e} beyond rtol 1e-5, reference uncertainty {err_ref:.3e}"
+    err = np.abs(q - ref64).max()
+    assert err <= 2.0 * err_ref + 2.0 ** -23 * scale, f"{label}: error vs float64 {err:.3e}, the reference's float32 evaluation {err_ref:.3e}"
+    return err, err_ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_device_forward_against_the_reference_network(kind):
+    from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference
+
+    z, sd = _golden(kind)
+    net = EngineQNet(6).cuda().load_reference_state_dict(sd)
+    B = z["frames"].shape[0]
+    qn = QNetInference(net, max_batch=1024)
+    x = torch.tensor(z["frames"].astype(np.float32) / 255).permute(0, 3, 1, 2).contiguous().cuda()
+    q_f32_entry = qn.forward_f32(x).cpu().numpy()
+    _check(q_f32_entry, z, "forward_f32")
+    # through the uint8 ring: channel c of sample b is frame 4 b + c; the two zero-history channels of the last sample as "no frame" (-1)
+    ring = torch.tensor(z["frames"]).permute(0, 3, 1, 2).contiguous().view(B * 4, 84 * 84).cuda()
+    off = (torch.arange(B * 4, device="cuda", dtype=torch.int64) * (84 * 84)).view(B, 4).clone()
+    off[5, :2] = -1
+    q_u8 = qn.forward_u8(ring.data_ptr(), off).cpu().numpy()
+    _check(q_u8, z, "forward_u8")
+    # the chip-filling launch (1024 rows: other tile shapes, operand planes for the first dense layer): the six samples tiled
+    rep = (1024 + B - 1) // B
+    off_big = off.repeat(rep, 1)[:1024].contiguous()
+    qn.enable_fc1_planes(private_weights=True)
+    qn.weights_changed()
+    q_big = qn.forward_u8(ring.data_ptr(), off_big).cpu().numpy()
+    for r in range(0, 1024 - B + 1, B * 37):
+        _check(q_big[r:r + B], z, f"forward_u8 rows {r}..")
+    assert np.array_equal(q_big[:B], q_big[B * 5:B * 6]), "the same sample gives the same bits wherever it sits in the batch"
+
+
+@pytest.mark.gpu
+def test_split_products_on_a_trained_network_against_float64():
+    """Weights that are no longer an initialisation: the engine trains for 300 updates on synthetic frames, then the hand-written forward is
+    compared with the SAME weights evaluated in float64 by torch on the CPU: error <= 2x that of torch's own float32 evaluation (+ 1 ulp)."""
+    from simple_distributed_rl_amd.device.qnet import QNetInference
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+    from simple_distributed_rl_amd.rl.torch_.networks import atari_qnetwork
+
+    cfg = RainbowDeviceConfig(n_envs=64, batch_size=32, memory_capacity=64 * 128, memory_warmup_size=256, target_model_update_interval=50, lr=1e-3)
+    eng = RainbowEngine(cfg, 0, episode_len=50)
+    for _ in range(320):
+        eng.step(learner_updates=1)
+    torch.cuda.synchronize()
+    assert eng.info()["train_count"] >= 250
+    sd = {k: v.detach().cpu() for k, v in eng.q_online.reference_state_dict().items()}
+    mirror = atari_qnetwork(6)
+    mirror.load_state_dict(sd)
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, (8, 84, 84, 4), dtype=np.uint8)
+    x = torch.tensor(frames.astype(np.float32) / 255)
+    with torch.no_grad():
+        q32 = mirror(x).numpy().astype(np.float64)
+        q64 = mirror.double()(x.double()).numpy()
+    qn = QNetInference(eng.q_online, max_batch=8)
+    ring = torch.tensor(frames).permute(0, 3, 1, 2).contiguous().view(32, 84 * 84).cuda()  # through the uint8 ring: the fused split-bf16 convolutions
+    off = (torch.arange(32, device="cuda", dtype=torch.int64) * (84 * 84)).view(8, 4).contiguous()
+    q = qn.forward_u8(ring.data_ptr(), off).cpu().numpy().astype(np.float64)
+    scale = np.abs(q64).max()
+    err, err_ref = np.abs(q - q64).max(), np.abs(q32 - q64).max()
+    assert err <= 2.0 * err_ref + 2.0 ** -23 * scale, (err, err_ref, scale)

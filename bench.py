@@ -122,7 +122,7 @@ def main():
         actor_ranks = world if (learner_acts if learner_acts is not None else world < 4) else world - 1
     envs_per_gpu = args.envs if args.scaling == "weak" else max(1, args.envs // actor_ranks)
     if args.algo == "agent57_light":
-        return bench_agent57_light(args, dev_index, rank, world)
+        return bench_agent57_light(args, dev_index, rank, world, dist, envs_per_gpu, actor_ranks, learner_acts)
     if args.algo == "ppo":
         return bench_ppo(args, dev_index, rank, world, dist)
     cfg = RainbowDeviceConfig(n_envs=envs_per_gpu, batch_size=args.batch_size, memory_capacity=args.capacity, seed=0, enable_noisy_dense=args.noisy)
@@ -266,16 +266,18 @@ def main():
     print(json.dumps(out), flush=True)
 
 
-def bench_agent57_light(args, dev_index, rank, world):
-    """The configs[3] workload on ONE GPU: Agent57_light with 84x84x4 frames, E environments + learner (torch networks, libsrlx for everything
-    around them).  `roofline` = the uint8 ring -> float32 stack kernel (the engine's dominant hand-written HBM kernel), timed in isolation."""
+def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=None, actor_ranks=1, learner_acts=None):
+    """The configs[3] workload: Agent57_light with 84x84x4 frames.  N = 1: E environments + learner on one GPU.  N > 1: `DistributedAgent57Light` --
+    actor ranks x E environments, learner + global replay on rank 0 (from 4 ranks up rank 0 ONLY learns: "7 actor GPUs + 1 learner GPU"), the transition
+    push as grouped point-to-point transfers, the five online networks back as one flat broadcast.  `roofline` = the uint8 ring -> float32 stack kernel
+    (the engine's dominant hand-written HBM kernel), timed in isolation on rank 0."""
     import torch
 
     import simple_distributed_rl_amd as srl
     from simple_distributed_rl_amd.algorithms import agent57_light
     from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
 
-    assert world == 1, "bench.py --algo agent57_light is a single-GPU line (the 7+1 topology is Runner.train_mp / tests/test_dist_gpu.py)"
+    E = envs_per_gpu or args.envs
     rl = agent57_light.Config(batch_size=args.batch_size)
     rl.window_length = 4
     rl.memory.capacity, rl.memory.warmup_size = args.capacity, min(args.capacity // 2, 80_000)
@@ -284,47 +286,87 @@ def bench_agent57_light(args, dev_index, rank, world):
     rl.hidden_block.set_dueling_network((512,))
     env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(episode_len=args.episode_len)))
     rl.setup(env)
-    eng = Agent57LightEngine(rl, args.envs, dev_index, episode_len=args.episode_len, seed=0)
-    eng.prefill()
+    dev = torch.device(f"cuda:{dev_index}")
+    if dist is not None:
+        from simple_distributed_rl_amd.device.dist import DistributedAgent57Light
+
+        eng = DistributedAgent57Light(rl, E, dev_index, episode_len=args.episode_len, sync_interval=args.sync_interval, learner_acts=learner_acts, seed=0)
+        assert eng.n_actor_ranks == actor_ranks
+        while True:  # untimed: play until the learner's replay is warm (every rank takes the same number of lock-steps)
+            for _ in range(16):
+                eng.step(0)
+            t = torch.tensor([0 if (not eng.is_learner or not eng.replay.is_warmup_needed()) else 1], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if int(t.item()) == 0:
+                break
+        stack_replay = eng.local.replay
+    else:
+        eng = Agent57LightEngine(rl, E, dev_index, episode_len=args.episode_len, seed=0)
+        eng.prefill()
+        stack_replay = eng.replay
     inner = max(1, args.inner)
     for _ in range(max(1, args.warmup) * inner):
         eng.step(args.updates)
     torch.cuda.synchronize()
-    if not args.no_graph:
+    if not args.no_graph and dist is None:
         eng.capture_graphs()  # the update (five networks, four optimisers) as one HIP graph
     n_lock = args.steps * inner
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_lock):
         eng.step(args.updates)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
+    rccl_ranks = 1
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        eng.flush()
+        rccl_ranks = dist.get_world_size() if args.backend == "nccl" else 0
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     # roofline of the stack kernel, isolated
     reps = 50
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
-        eng.replay.stack_current()
+        stack_replay.stack_current()
     a.record()
     for _ in range(reps):
-        eng.replay.stack_current()
+        stack_replay.stack_current()
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / reps
-    nbytes = args.envs * 4 * 84 * 84 * (1 + 4)
+    nbytes = E * 4 * 84 * 84 * (1 + 4)
     info = eng.info()
     out = {
-        "metric": "env-steps/sec + learner updates/sec, Agent57_light 84x84x4", "value": n_lock * args.envs / elapsed, "unit": "env-steps/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "learner_updates_per_s": n_lock * args.updates / elapsed, "ms_per_lock_step": 1e3 * elapsed / n_lock, "rccl_ranks": 1,
+        "metric": "env-steps/sec + learner updates/sec, Agent57_light 84x84x4", "value": n_lock * E * actor_ranks / elapsed, "unit": "env-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "learner_updates_per_s": n_lock * args.updates / elapsed, "ms_per_lock_step": 1e3 * elapsed / n_lock, "rccl_ranks": rccl_ranks,
         "config": {"workload": "Agent57_light on synthetic 84x84x4 Atari frames (BASELINE.json configs[3] workload on one GPU): 2 UVFA Q-networks, NGU episodic + RND "
-                               "lifelong intrinsic reward, per-environment sliding-window UCB, PER", "lock_steps_per_step": inner, "envs_per_gpu": args.envs,
+                               "lifelong intrinsic reward, per-environment sliding-window UCB, PER", "lock_steps_per_step": inner, "envs_per_gpu": E, "envs_total": E * actor_ranks, "actor_gpus": actor_ranks,
+                   "topology": "1 GPU: actors + learner" if dist is None else (f"{world} GPUs: rank0 learner + actors, {world - 1} actor ranks" if eng.learner_acts else
+                                f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology)") + ", grouped send/recv push, flat broadcast",
+                   "backend": "none" if dist is None else args.backend,
                    "learner_updates_per_lock_step": args.updates, "batch_size": args.batch_size, "per_capacity": eng.replay.capacity, "actor_num": rl.actor_num,
                    "networks": "torch modules (MIOpen / hipBLASLt); libsrlx: frame ring + stack, epsilon-greedy, UCB, NGU kNN / RND reward, targets, losses, priorities, PER",
-                   "hip_graphs": "learner update" if not args.no_graph else False},
+                   "hip_graphs": "learner update" if (not args.no_graph and dist is None) else False},
         "roofline": {"kernel": "k_stack_current_u8 (uint8 frame ring -> float32 [E,4,84,84] network input)", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes,
                      "avg_launch_ms": ms, "note": "isolated launches"},
         "final": {"loss": info.get("loss"), "train_count": info["train_count"], "memory": info["memory"]},
     }
+    if dist is not None:
+        dist.destroy_process_group()
+    import ctypes
+
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
     print(json.dumps(out), flush=True)
 
 

@@ -6,9 +6,10 @@ learner.  With `learner_acts=True` (default for 2 ranks) rank 0 is an actor rank
 `learner_acts=False` (default from 4 ranks: BASELINE.json config 4, "7 actor GPUs + 1 learner GPU") it only
 learns: its update runs beside the gather instead of beside its own actors, so the step time of the job is
 the actor ranks' step, not rank 0's actor + commit + learner.  Per step:
-    actors -> learner : one gather of fixed-size transition slabs (next frame uint8 [E,F] + action /
-                        reward / terminated / done) straight into the learner's HBM staging buffers,
-                        from where one commit kernel writes them into the ring and the PER tree
+    actors -> learner : one GROUP of point-to-point transfers (grouped ncclSend / ncclRecv) of fixed-size transition
+                        slabs (next frame uint8 [E,F] + one packed record buffer: action / reward / terminated /
+                        done) straight into the learner's HBM staging buffers, from where one commit kernel writes
+                        them into the ring and the PER tree; a rank that only learns sends nothing
     learner -> actors : every `sync_interval` steps one broadcast of the flat float32 parameter buffer
                         (32 MB for the Atari network) that the actor networks alias (no unpack copy)
 
@@ -33,9 +34,13 @@ class TransitionBus:
     """Fixed-size per-step transition exchange and parameter fan-out between ranks."""
 
     def __init__(self, n_envs_local: int, obs_elems: int, obs_dtype: torch.dtype, device: torch.device, group=None, learner_rank: int = 0,
-                 always_collective: bool = False, extra_floats: int = 0):
+                 always_collective: bool = False, extra_floats: int = 0, actor_ranks=None, p2p: Optional[bool] = None):
         """extra_floats: further float32 fields per environment that ride in the packed record buffer (Agent57_light's intrinsic reward,
-        arm, previous action / rewards)."""
+        arm, previous action / rewards).  actor_ranks: the ranks that have transitions to ship (default: all).  p2p (default: whenever there is
+        more than one rank): the exchange is ONE group of point-to-point transfers -- every actor rank sends its two buffers to the learner rank,
+        which posts the matching receives straight into its staging buffers (`batch_isend_irecv` = grouped ncclSend / ncclRecv on RCCL); a rank
+        that only learns sends nothing, and the learner rank's own transitions (when it also acts) are a copy inside its HBM.  p2p=False keeps the
+        gather collective (every rank contributes an equal part, a learner-only rank a placeholder)."""
         self.E, self.F, self.K = n_envs_local, obs_elems, int(extra_floats)
         self.always_collective = always_collective  # run the collectives even at world size 1 (transport tests on a 1-GPU box)
         self.group = group
@@ -44,7 +49,11 @@ class TransitionBus:
         self.learner_rank = learner_rank
         self.device = device
         self.is_learner = self.rank == learner_rank
-        self._pending, self._direct, self._keep = [], None, None
+        self.actor_ranks = list(range(self.world)) if actor_ranks is None else [int(r) for r in actor_ranks]
+        self.contributes = self.rank in self.actor_ranks
+        self.p2p = (self.world > 1) if p2p is None else bool(p2p)
+        self.sent_bytes = self.recv_bytes = 0  # what this rank put on / took off the wire (tests: a learner-only rank sends nothing)
+        self._pending, self._direct, self._keep, self._staged_in = [], None, None, []
         if self.is_learner:
             T = self.world * self.E
             self.g_actions = torch.zeros(T, dtype=torch.int32, device=device)
@@ -82,6 +91,28 @@ class TransitionBus:
         scal = torch.cat(fields)
         self._keep = (scal, next_obs)  # inputs stay alive until the collectives are done
         staged = dist.get_backend(self.group) == "gloo" and actions.is_cuda  # test rigs: ranks sharing one GPU
+        if self.p2p:
+            ops, self._staged_in = [], []
+            for t, name in ((scal, "g_scal"), (next_obs.contiguous(), "g_next_obs")):
+                if self.is_learner:
+                    buf = getattr(self, name)
+                    views = [buf[r] for r in range(self.world)] if name == "g_scal" else self._views(buf)
+                    for r in self.actor_ranks:
+                        if r == self.rank:
+                            views[r].view(-1).copy_(t.view(-1).view(buf.dtype))  # this rank's own transitions never leave its HBM
+                            continue
+                        dst = torch.empty(views[r].shape, dtype=views[r].dtype, device="cpu") if staged else views[r]
+                        if staged:
+                            self._staged_in.append((dst, views[r]))
+                        ops.append(dist.P2POp(dist.irecv, dst, r, self.group))
+                        self.recv_bytes += dst.numel() * dst.element_size()
+                elif self.contributes:
+                    src = t.cpu() if staged else t
+                    self._keep = self._keep + (src,)
+                    ops.append(dist.P2POp(dist.isend, src, self.learner_rank, self.group))
+                    self.sent_bytes += src.numel() * src.element_size()
+            self._pending = list(dist.batch_isend_irecv(ops)) if ops else []
+            return
         for t, name in ((scal, "g_scal"), (next_obs.contiguous(), "g_next_obs")):
             if staged:
                 parts = [torch.empty_like(t, device="cpu") for _ in range(self.world)] if self.is_learner else None
@@ -104,6 +135,9 @@ class TransitionBus:
         for work in self._pending:
             work.wait()
         self._pending = []
+        for host, view in self._staged_in:
+            view.copy_(host.to(self.device))
+        self._staged_in = []
         self._keep = None
         if self.is_learner:
             E, g = self.E, self.g_scal
@@ -190,7 +224,7 @@ class DistributedRainbow:
         self.local.inf_online.bind()
         if isinstance(self.local.optimizer, DeviceAdam):
             self.local.optimizer.bind()
-        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective)
+        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective, actor_ranks=range(self.first_actor_rank, self.world))
         self.step_count = 0
         self._in_flight = False  # an exchange started by push_begin and not yet finished
         self.env_steps_local = 0  # environment steps taken by THIS rank's actors
@@ -212,8 +246,7 @@ class DistributedRainbow:
             self.replay.reset_all(self._actor_rows(gathered)[4])
 
     def _actor_rows(self, gathered):
-        """The gathered slabs of the actor ranks (a learner-only rank 0 contributes a slab nobody reads: the gather
-        needs one from every rank)."""
+        """The staging rows of the actor ranks (a learner-only rank 0 owns row block 0 of the staging buffers and never fills it)."""
         if self.first_actor_rank == 0:
             return gathered
         k = self.first_actor_rank * self.cfg.n_envs
@@ -231,7 +264,7 @@ class DistributedRainbow:
 
     def actor_and_push(self, events=None, random_policy=False):
         eng = self.local
-        if not self.acts:  # learner-only rank: nothing to step, its slab is a placeholder
+        if not self.acts:  # learner-only rank: nothing to step, nothing to send (the bus only posts its receives)
             if events is not None:
                 events[0].record()
                 events[1].record()
@@ -395,7 +428,8 @@ class DistributedAgent57Light:
         self.nets = torch.nn.ModuleList([p.q_ext_online, p.q_int_online, p.emb_network, p.lifelong_target, p.lifelong_train])  # model_torch.py:148-156
         self.flat = flatten_parameters(self.nets)
         H, W_ = self.local.hw
-        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective, extra_floats=self.FIELDS)
+        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective, extra_floats=self.FIELDS,
+                                 actor_ranks=range(self.first_actor_rank, self.world))
         self.step_count, self._in_flight, self.env_steps_local = 0, False, 0
         if self.is_learner:
             total = self.n_actor_ranks * E

@@ -92,6 +92,54 @@ def test_transition_bus_gloo_world2():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _learner_only_worker(rank, world, port, ret):
+    """BASELINE configs[3] in small: rank 0 only learns, ranks 1.. act.  The exchange is one group of point-to-point transfers."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_distributed_rl_amd.device.dist import TransitionBus
+
+        E, F, K = 4, 32, 5
+        bus = TransitionBus(E, F, torch.uint8, torch.device("cpu"), extra_floats=K, actor_ranks=range(1, world))
+        gather = TransitionBus(E, F, torch.uint8, torch.device("cpu"), extra_floats=K, p2p=False)  # the collective form, every rank an equal part
+        assert bus.p2p and not gather.p2p
+        ok = True
+        for step in range(3):
+            rng = np.random.default_rng(77 * step + rank)
+            a = torch.tensor(rng.integers(0, 6, E), dtype=torch.int32)
+            r = torch.tensor(rng.standard_normal(E), dtype=torch.float32)
+            t = torch.tensor(rng.integers(0, 2, E), dtype=torch.uint8)
+            d = torch.tensor(rng.integers(0, 2, E), dtype=torch.uint8)
+            o = torch.tensor(rng.integers(0, 256, (E, F)), dtype=torch.uint8)
+            x = torch.tensor(rng.standard_normal((E, K)), dtype=torch.float32)
+            bus.push_begin(a, r, t, d, o, x)
+            got = bus.push_end()
+            want = gather.push(a, r, t, d, o, x)
+            if rank == 0:
+                for g, w in zip(got, want):  # the actor ranks' rows agree with what the gather delivers; row block 0 (nobody acts there) is never written
+                    ok &= bool(torch.equal(g[E:], w[E:])) and not bool(g[:E].any())
+            else:
+                ok &= got is None
+        per_step = (10 + 4 * K) * E + E * F
+        if rank == 0:
+            ok &= bus.sent_bytes == 0 and bus.recv_bytes == 3 * per_step * (world - 1)
+        else:
+            ok &= bus.sent_bytes == 3 * per_step and bus.recv_bytes == 0
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_learner_only_rank_sends_nothing_gloo_world3():
+    world = 3
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_learner_only_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True, 2: True}
+
+
 def _grad_avg_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

@@ -174,6 +174,28 @@ def test_bench_multi_rank_rehearsal(n, actor_gpus, launcher):
     assert "cpu_baseline" not in d and d["roofline"]["avg_launch_ms"] > 0 and d["roofline"]["pass"]["avg_launch_group_ms"] > 0
 
 
+@pytest.mark.parametrize("n,actor_gpus", [(2, 2), (4, 3)])
+def test_bench_agent57_light_multi_rank_rehearsal(n, actor_gpus):
+    """BASELINE configs[3] as a bench line: `bench.py --algo agent57_light --gpus N` (here N ranks sharing the test GPU over gloo): DistributedAgent57Light,
+    the grouped send/recv transition push, the flat five-network broadcast, barriers and MAX all-reduce, env-step accounting over the ACTOR ranks."""
+    import json
+    import subprocess
+
+    steps, inner = 2, 4
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--algo", "agent57_light", "--gpus", str(n), "--backend", "gloo", "--steps", str(steps), "--warmup", "1", "--inner", str(inner),
+           "--envs", "32", "--capacity", "4000", "--batch-size", "8", "--sync-interval", "4"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["config"]["actor_gpus"] == actor_gpus and d["rccl_ranks"] == 0 and d["config"]["envs_total"] == 32 * actor_gpus
+    per_step = inner * 32 * actor_gpus
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - per_step) < 1e-6 * per_step
+    assert d["final"]["train_count"] >= steps * inner and d["final"]["memory"] > 0
+
+
 def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     """`python bench.py --gpus 8` on a smaller node over RCCL must fail loudly instead of timing one GPU."""
     import subprocess

@@ -48,6 +48,7 @@ class RainbowDeviceConfig:
     memory_beta_initial: float = 0.4
     memory_beta_steps: int = 1_000_000
     memory_epsilon: float = 0.0001
+    memory_has_duplicate: bool = True  # False: a batch never holds an item twice (the uniform ReplayBuffer's random.sample; has_duplicate=False of the proportional memory)
     # --- model (set_dqn_block + dueling (512,))
     hidden_units: int = 512
     filters: int = 32
@@ -120,6 +121,7 @@ class RainbowEngine:
         self.replay = DeviceReplay(
             E, ring_len, H * W_, cfg.window_length, n, A, B, True, cfg.enable_reward_clip,
             cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
+            has_duplicate=cfg.memory_has_duplicate,
         )
         if env is None:
             self.env = SyntheticAtariVecEnv(self.replay, episode_len)

@@ -46,6 +46,7 @@ class DeviceReplay:
         seed: int = 0,
         device: int = 0,
         sample_slack: int = 8,
+        has_duplicate: bool = True,
     ):
         self.lib = N.lib()
         self.E, self.L, self.F, self.W, self.n, self.A, self.B = n_envs, ring_len, obs_elems, window, n_step, n_actions, batch_size
@@ -67,7 +68,7 @@ class DeviceReplay:
         self.capacity = int(self.lib.srlx_store_per_capacity(hs))
         hp = N.c_p()
         N.check(
-            self.lib.srlx_per_create(ctypes.byref(hp), self.capacity, float(alpha), float(beta_initial), float(beta_steps), 1, float(epsilon), self.device_index)
+            self.lib.srlx_per_create(ctypes.byref(hp), self.capacity, float(alpha), float(beta_initial), float(beta_steps), int(bool(has_duplicate)), float(epsilon), self.device_index)
         )
         self.h_per = hp
         d = self.dev
@@ -165,6 +166,33 @@ class DeviceReplay:
                 self.h_store, self.B, N.tptr(b.indices), N.tptr(b.obs), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st
             )
         )
+        return b
+
+    def draw_like_random_sample(self, population: int = None) -> torch.Tensor:
+        """The uniform ReplayBuffer's draw (srl/rl/memories/priority_memories/replay_buffer.py:33-34: `random.sample(self.memory, batch_size)`)
+        with the reference's own generator: `random.sample(range(len), B)` consumes Python's `random` stream exactly like sampling the list does (the
+        draws depend on the population SIZE only), so under `random.seed(s)` the device store hands out the items the reference's list would -- item j
+        of the list is leaf j of the store (insertion order, then ring order; one environment, or lane-major insertion with E lanes).  Without
+        replacement, every weight 1.0.  The indices land in `batch.indices` (tree indices, like a PER draw): follow with `gather_drawn()`.  Host-side
+        by nature (the generator is Python's); the engines' own draws stay on the device (`has_duplicate=False`: without replacement there too)."""
+        import random
+
+        n = self.length() if population is None else int(population)
+        slots = random.sample(range(n), self.B)
+        idx = torch.tensor(slots, dtype=torch.int64) + (self.capacity - 1)
+        self.batch.indices.copy_(idx.to(self.dev, non_blocking=False))
+        self.batch.weights.fill_(1.0)
+        return self.batch.indices
+
+    def gather_drawn(self, all_states: bool = True) -> ReplayBatch:
+        """n-step scalars and frame-offset tables (or float32 windows) of the items whose tree indices sit in `batch.indices`."""
+        st = N.torch_stream_ptr()
+        b = self.batch
+        if all_states:
+            N.check(self.lib.srlx_store_gather_train(self.h_store, self.B, N.tptr(b.indices), N.tptr(self.frame_off_all), N.tptr(self.frame_off_next), N.tptr(b.actions),
+                                                     N.tptr(b.rewards), N.tptr(b.terminated), st))
+        else:
+            N.check(self.lib.srlx_store_gather_nstep(self.h_store, self.B, N.tptr(b.indices), N.tptr(b.obs), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st))
         return b
 
     def frame_table_current(self) -> torch.Tensor:

@@ -239,8 +239,6 @@ def why_not_vector(context, env, rl_config) -> str:
     mem = rl_config.memory
     if mem.name not in ("Proportional", "Proportional_cpp", "ReplayBuffer"):
         return f"no device replay for memory '{mem.name}'"
-    if mem.name != "ReplayBuffer" and not mem.kwargs.get("has_duplicate", True):
-        return "has_duplicate=False is served by the plugin memory"
     if mem.enable_demo_memory:
         return "demo memory is served by the plugin memory"
     if kind == "agent57_light":  # torch networks: any DQN-image / dueling shape the plugin builds
@@ -300,7 +298,9 @@ def device_config_from(rl_config, env, n_envs: int, seed: int):
         multisteps=rl_config.multisteps, retrace_h=rl_config.retrace_h, window_length=rl_config.window_length,
         memory_capacity=mem.capacity, memory_warmup_size=mem.warmup_size,
         # the uniform ReplayBuffer (priority_memories/replay_buffer.py:10-55) is the alpha = 0 corner of the sum-tree: every leaf
-        # weighs 1, so every importance weight is 1 whatever beta is (draws are with replacement, unlike random.sample)
+        # weighs 1, so every importance weight is 1 whatever beta is; like random.sample its draws are WITHOUT replacement (a second hit
+        # of an item is rejected in draw order, proportional_memory.py:153-157 -- the has_duplicate=False rule of the proportional memory)
+        memory_has_duplicate=bool(kw.get("has_duplicate", True)) if prop else False,
         memory_alpha=float(kw.get("alpha", 0.0)), memory_beta_initial=float(kw.get("beta_initial", 0.4)),
         memory_beta_steps=int(kw.get("beta_steps", 1_000_000)), memory_epsilon=float(kw.get("epsilon", 1e-4)),
         hidden_units=int(hb.kwargs["layer_sizes"][0]), dueling_type=hb.kwargs.get("dueling_kwargs", {}).get("dueling_type", "average"),

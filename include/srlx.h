@@ -485,6 +485,14 @@ int srlx_qnet_fuse_adam_fc1(srlx_qnet_t *h, float *d_exp_avg, float *d_exp_avg_s
                             const int64_t *d_steps_taken);
 int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off,
                           const float *d_grad_q, float *const *d_grads, void *stream);
+/* The image block alone (networks whose dense part is not this handle's dueling head: Agent57_light's UVFA Q-networks, embedding and RND networks --
+ * srl/algorithms/agent57_light/model_torch.py:18-117): given d loss / d features f32 [batch][pixels * channels] (the layout srlx_qnet_forward_convs_u8
+ * returns; rows = the samples at rows 0, stride, 2*stride, ... of the LAST forward on this training-enabled handle), the ReLU mask of the kept
+ * activations is applied and the convolution part of loss.backward() (model_torch.py:437-439) runs: d_grads[0..5] = conv1 w, b, conv2 w, b, conv3 w, b in
+ * each parameter's own memory layout.  Same kernels, streams and fixed summation orders as the convolution half of srlx_qnet_backward_u8: run to run
+ * the gradients are bit-identical. */
+int srlx_qnet_backward_convs_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off,
+                                const float *d_grad_features, float *const *d_grads, void *stream);
 /* srlx_nstep_td_huber_priority_packed + srlx_qnet_backward_u8 in one call (one launch less on the learner's chain): the head kernel of
  * the backward pass evaluates the TD target / Huber loss / gradient seed / priorities itself (arguments and results as in
  * srlx_nstep_td_huber_priority_packed, bit-equal; d_q_on_all = the [batch][n_step+1][n_actions] output of the LAST forward on this handle,

@@ -567,6 +567,87 @@ int srlx_qnet_fuse_adam_fc1(srlx_qnet_t *h, float *d_exp_avg, float *d_exp_avg_s
     return SRLX_OK;
 }
 
+// Two branches (fork/join with events; capturable into a HIP graph): the data-gradient chain, then conv1's weight gradient (which needs the end of
+// it), stay on the caller's stream; the other weight gradients run on h->side as soon as the activation gradient each needs exists -- the first
+// dense layer's with Adam in its epilogue when the optimiser state is bound.
+static int chain_prologue(srlx_qnet_t *h, hipStream_t st) {
+    hipStream_t sd = h->side;
+    SRLX_HIP(hipEventRecord(h->ev_fork, st));
+    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
+    const int C2 = 2 * h->F1;
+    // the transposed filters of the two data-gradient GEMMs depend on the weights only: the fused forward of a training handle has
+    // built them already (k_pack_filters); otherwise they are built here, ahead of the chain that needs them
+    if (!h->wt_from_forward) {
+        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((C2 * 9 * C2 + 255) / 256)), dim3(256), 0, st, h->w3, C2, 3, 3, 1, C2, h->w_t);
+        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((C2 * 16 * h->F1 + 255) / 256)), dim3(256), 0, st, h->w2, C2, 4, 4, 2, h->F1, h->w_t2);
+    }
+    return SRLX_OK;
+}
+
+// From h->dact3 (the gradient at conv3's output, ReLU mask applied, rows 0..B-1) to the six convolution gradients g[0..5]; `with_fc1`: the first dense
+// layer's weight gradient rides on the side stream (the whole-network backward).
+static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *const *g, hipStream_t st, bool with_fc1) {
+    const int N1 = 2 * h->hidden, K = h->flat, C2 = 2 * h->F1;
+    float *g_w1 = g[0], *g_b1 = g[1], *g_w2 = g[2], *g_b2 = g[3], *g_w3 = g[4], *g_b3 = g[5], *g_wf = with_fc1 ? g[6] : nullptr;
+    float *bias_part = h->w_part + h->w_part_floats;  // [splits][CO] partial bias sums
+    const size_t c3 = (size_t)2 * h->F1 * 9 * 2 * h->F1, c2 = (size_t)2 * h->F1 * 16 * h->F1;
+    hipStream_t sd = h->side;
+    SRLX_HIP(hipEventRecord(h->ev_d3, st));  // dact3 exists; nothing reads the first dense layer's weights any more
+    {   // conv3 (3x3 stride 1 pad 1, act2 -> act3) data gradient on the padded grid (OH2 + 2)^2
+        const int HP = h->OH2 + 2, WP = h->OW2 + 2;
+        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st));
+        const i64 tot = (i64)B * h->OH2 * h->OW2 * C2;
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, 1, HP, WP, h->dxpad, h->act2, h->dact2);
+    }
+    SRLX_HIP(hipEventRecord(h->ev_d2, st));
+    {   // conv2 (4x4 stride 2 pad 2, act1 -> act2) data gradient on the padded grid (OH1 + 4)^2, four parity classes
+        const int HP = h->OH1 + 4, WP = h->OW1 + 4, QH = (HP + 1) / 2, QW = (WP + 1) / 2;
+        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact2, B, QH, QW, h->OH2, h->OW2, C2, 4, 4, 2, h->w_t2, h->F1, h->dxpad, st));
+        const i64 tot = (i64)B * h->OH1 * h->OW1 * h->F1;
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, 2, QH, QW, h->dxpad, h->act1, h->dact1);
+    }
+    SRLX_HIP(hipEventRecord(h->ev_d1, st));
+    // ---- weight gradients of conv3, conv2 and the first dense layer (side stream).  The dense layer's comes last: with Adam in its
+    // epilogue it streams 160 MB, and beside the data-gradient chain it tripled the duration of that chain's pad-fold kernels
+    const dim3 fg((unsigned)((K / 32 + 3) / 4), (unsigned)(N1 / 32));  // one wave per 32 x 32 tile of the weight
+    if (with_fc1 && !h->adam_m)
+        hipLaunchKernelGGL(k_fc1_wgrad<false>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr);
+    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
+    ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
+    hipLaunchKernelGGL(k_conv_wgrad_mfma<64>, dim3((9 * 2 * 2 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g3, ss, h->act2, h->dact3, h->w_part, bias_part);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
+    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
+    ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
+    hipLaunchKernelGGL(k_conv_wgrad_mfma<32>, dim3((16 * 2 * 1 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g2, ss, h->act1, h->dact2, h->w_part, bias_part);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2);
+    if (with_fc1 && h->adam_m)  // Adam in the epilogue updates the weights in place: (long) after ev_d3, when the data gradient has read them
+        hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
+                           h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
+    SRLX_HIP(hipEventRecord(h->ev_join, sd));
+    // conv1's weight gradient needs the END of the data-gradient chain: it follows it on the caller's stream instead of queueing behind
+    // the conv2 / conv3 weight gradients on the side stream
+    // output pixels per chunk, even (the MFMA consumes pixel pairs); four chunks keep the workgroup's LDS (31 KB for 84 x 84 frames) under the
+    // 33 KB a CU has left beside one of the actors' convolution workgroups -- with two (45 KB) the kernel took 65 us in the loop, 20 alone
+    const int per = ((h->OH1 * h->OW1 + kC1Chunks - 1) / kC1Chunks + 1) & ~1;
+    const size_t lds = (size_t)kC1Frame + (size_t)per * 4 + (size_t)per * 32 * sizeof(float) + 2 * 16 * 64 * sizeof(float);
+    SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
+    float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
+    hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(kC1Chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
+                       h->dact1, c1_part, c1_bias);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, st, c1_part, kC1Chunks * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
+    SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    return SRLX_OK;
+}
+
+// the incoming gradient at conv3's OUTPUT (after its ReLU), rows 0..B-1 compact -> h->dact3 with the ReLU mask of the kept activations (row b * ss)
+__global__ void __launch_bounds__(256) k_relu_mask_rows(const float *__restrict__ gy, const float *__restrict__ act, i64 ss, i64 row, i64 total, float *__restrict__ out) {
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= total) return;
+    const i64 b = (q * 4) / row, k = (q * 4) % row;
+    const float4 gv = *reinterpret_cast<const float4 *>(gy + q * 4), a = *reinterpret_cast<const float4 *>(act + b * ss * row + k);
+    *reinterpret_cast<float4 *>(out + q * 4) = make_float4(a.x > 0.f ? gv.x : 0.f, a.y > 0.f ? gv.y : 0.f, a.z > 0.f ? gv.z : 0.f, a.w > 0.f ? gv.w : 0.f);
+}
+
 // `td` != NULL: d loss / d Q is computed by the head kernel itself (srlx_qnet_backward_td_u8), d_grad_q is not read
 static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off, const float *d_grad_q,
                          const srlx::TdArgs *td, float *const *g, void *stream) {
@@ -579,10 +660,7 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
     hipStream_t st = (hipStream_t)stream;
     const int B = (int)batch, N1 = 2 * h->hidden, K = h->flat, A = h->A;
     const i64 ss = sample_stride;
-    float *g_w1 = g[0], *g_b1 = g[1], *g_w2 = g[2], *g_b2 = g[3], *g_w3 = g[4], *g_b3 = g[5], *g_wf = g[6], *g_bf = g[7], *g_v2w = g[8], *g_v2b = g[9], *g_a2w = g[10],
-          *g_a2b = g[11];
-    float *bias_part = h->w_part + h->w_part_floats;  // [splits][CO] partial bias sums
-    const size_t c3 = (size_t)2 * h->F1 * 9 * 2 * h->F1, c2 = (size_t)2 * h->F1 * 16 * h->F1;
+    float *g_bf = g[7], *g_v2w = g[8], *g_v2b = g[9], *g_a2w = g[10], *g_a2b = g[11];
 
     // head + second layers -> dh1 (masked by the first layer's ReLU), bias gradient of the first layer
     const bool mfma_dgrad = B <= 32;  // the batch fits one 32-row MFMA tile
@@ -602,19 +680,7 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
             hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, dh1t, g_bf, g_v2w, g_v2b, g_a2w,
                                g_a2b, tda, with_td);
     }
-    // Two branches from here (fork/join with events; capturable into a HIP graph): the data-gradient chain, then conv1's weight
-    // gradient (which needs the end of it), stay on the caller's stream; the other weight gradients run on h->side as soon as the
-    // activation gradient each needs exists -- the first dense layer's with Adam in its epilogue when the optimiser state is bound.
-    hipStream_t sd = h->side;
-    SRLX_HIP(hipEventRecord(h->ev_fork, st));
-    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
-    const int C2 = 2 * h->F1;
-    // the transposed filters of the two data-gradient GEMMs depend on the weights only: the fused forward of a training handle has
-    // built them already (k_pack_filters); otherwise they are built here, ahead of the chain that needs them
-    if (!h->wt_from_forward) {
-        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((C2 * 9 * C2 + 255) / 256)), dim3(256), 0, st, h->w3, C2, 3, 3, 1, C2, h->w_t);
-        hipLaunchKernelGGL(k_transpose_filter, dim3((unsigned)((C2 * 16 * h->F1 + 255) / 256)), dim3(256), 0, st, h->w2, C2, 4, 4, 2, h->F1, h->w_t2);
-    }
+    SRLX_TRY(chain_prologue(h, st));
     // ---- data-gradient chain (caller's stream)
     if (mfma_dgrad) {
         hipLaunchKernelGGL(k_fc1_dgrad_mfma, dim3((unsigned)(K / 32)), dim3(256), 0, st, B, ss, N1, K, h->dh1t, h->wf, h->act3, h->dact3);
@@ -622,50 +688,7 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
         hipLaunchKernelGGL(k_fc1_dgrad<64>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
         hipLaunchKernelGGL(k_fc1_dgrad_reduce, dim3((unsigned)(((i64)B * K + 255) / 256)), dim3(256), 0, st, B, ss, K, h->fc_part, h->act3, h->dact3);
     }
-    SRLX_HIP(hipEventRecord(h->ev_d3, st));  // dact3 exists; nothing reads the first dense layer's weights any more
-    {   // conv3 (3x3 stride 1 pad 1, act2 -> act3) data gradient on the padded grid (OH2 + 2)^2
-        const int HP = h->OH2 + 2, WP = h->OW2 + 2;
-        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st));
-        const i64 tot = (i64)B * h->OH2 * h->OW2 * C2;
-        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, 1, HP, WP, h->dxpad, h->act2, h->dact2);
-    }
-    SRLX_HIP(hipEventRecord(h->ev_d2, st));
-    {   // conv2 (4x4 stride 2 pad 2, act1 -> act2) data gradient on the padded grid (OH1 + 4)^2, four parity classes
-        const int HP = h->OH1 + 4, WP = h->OW1 + 4, QH = (HP + 1) / 2, QW = (WP + 1) / 2;
-        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact2, B, QH, QW, h->OH2, h->OW2, C2, 4, 4, 2, h->w_t2, h->F1, h->dxpad, st));
-        const i64 tot = (i64)B * h->OH1 * h->OW1 * h->F1;
-        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, 2, QH, QW, h->dxpad, h->act1, h->dact1);
-    }
-    SRLX_HIP(hipEventRecord(h->ev_d1, st));
-    // ---- weight gradients of conv3, conv2 and the first dense layer (side stream).  The dense layer's comes last: with Adam in its
-    // epilogue it streams 160 MB, and beside the data-gradient chain it tripled the duration of that chain's pad-fold kernels
-    const dim3 fg((unsigned)((K / 32 + 3) / 4), (unsigned)(N1 / 32));  // one wave per 32 x 32 tile of the weight
-    if (!h->adam_m)
-        hipLaunchKernelGGL(k_fc1_wgrad<false>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr);
-    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
-    ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
-    hipLaunchKernelGGL(k_conv_wgrad_mfma<64>, dim3((9 * 2 * 2 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g3, ss, h->act2, h->dact3, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
-    SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
-    ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
-    hipLaunchKernelGGL(k_conv_wgrad_mfma<32>, dim3((16 * 2 * 1 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g2, ss, h->act1, h->dact2, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2);
-    if (h->adam_m)  // Adam in the epilogue updates the weights in place: (long) after ev_d3, when the data gradient has read them
-        hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
-                           h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
-    SRLX_HIP(hipEventRecord(h->ev_join, sd));
-    // conv1's weight gradient needs the END of the data-gradient chain: it follows it on the caller's stream instead of queueing behind
-    // the conv2 / conv3 weight gradients on the side stream
-    // output pixels per chunk, even (the MFMA consumes pixel pairs); four chunks keep the workgroup's LDS (31 KB for 84 x 84 frames) under the
-    // 33 KB a CU has left beside one of the actors' convolution workgroups -- with two (45 KB) the kernel took 65 us in the loop, 20 alone
-    const int per = ((h->OH1 * h->OW1 + kC1Chunks - 1) / kC1Chunks + 1) & ~1;
-    const size_t lds = (size_t)kC1Frame + (size_t)per * 4 + (size_t)per * 32 * sizeof(float) + 2 * 16 * 64 * sizeof(float);
-    SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
-    float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
-    hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(kC1Chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
-                       h->dact1, c1_part, c1_bias);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, st, c1_part, kC1Chunks * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
-    SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    SRLX_TRY(conv_chain(h, B, ss, d_frame_base, d_frame_off, g, st, true));
     // NoisyLinear: d loss / d sigma = d loss / d W_effective * eps of the draw the forward used (regenerated, not stored)
     SRLX_TRY(srlx_qnet_noisy_sigma_grads(h, g, st));
     SRLX_HIP(hipGetLastError());
@@ -676,6 +699,23 @@ int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, 
                           const float *d_grad_q, float *const *g, void *stream) {
     SRLX_REQUIRE(d_grad_q, "qnet_backward_u8: NULL argument");
     return backward_impl(h, batch, sample_stride, d_frame_base, d_frame_off, d_grad_q, nullptr, g, stream);
+}
+
+int srlx_qnet_backward_convs_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off, const float *d_grad_features,
+                                float *const *g, void *stream) {
+    SRLX_REQUIRE(h && d_frame_base && d_frame_off && d_grad_features && g, "qnet_backward_convs_u8: NULL argument");
+    SRLX_REQUIRE(h->max_train > 0, "qnet_backward_convs_u8: call srlx_qnet_enable_training first");
+    SRLX_REQUIRE(batch > 0 && batch <= h->max_train && sample_stride >= 1 && batch * sample_stride <= h->max_batch, "qnet_backward_convs_u8: batch %lld x stride %lld out of range",
+                 (long long)batch, (long long)sample_stride);
+    for (int i = 0; i < 6; i++) SRLX_REQUIRE(g[i], "qnet_backward_convs_u8: gradient buffer %d is NULL", i);
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    SRLX_TRY(chain_prologue(h, st));
+    const i64 total = (i64)batch * h->flat;
+    hipLaunchKernelGGL(k_relu_mask_rows, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, d_grad_features, h->act3, (i64)sample_stride, (i64)h->flat, total, h->dact3);
+    SRLX_TRY(conv_chain(h, (int)batch, (i64)sample_stride, d_frame_base, d_frame_off, g, st, false));
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
 }
 
 int srlx_qnet_backward_td_u8(srlx_qnet_t *h, int64_t batch, int n_step, const uint8_t *d_frame_base, const int64_t *d_frame_off, const float *d_q_on_all,

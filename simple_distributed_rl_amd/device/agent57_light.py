@@ -106,19 +106,23 @@ class Agent57LightLearner:
         self.sync_count = 0
         self.info: dict = {}
 
-    def _q(self, net, inputs):
+    def _q(self, net, inputs, feat=None):
+        if feat is not None:  # the image block's output computed elsewhere (device/qnet.py:TrainableImageTrunk)
+            return q_values(net, None, *inputs[1:], features=feat)
         return q_values(net, *inputs) if self.cf else net(inputs)
 
-    def _update_q(self, online, target_net, optimizer, rewards, next_inputs, cur_inputs, undone, discount, inv, action, w):
-        """model_torch.py:384-443 with the arithmetic around the three forwards in libsrlx."""
+    def _update_q(self, online, target_net, optimizer, rewards, next_inputs, cur_inputs, undone, discount, inv, action, w, feats=None):
+        """model_torch.py:384-443 with the arithmetic around the three forwards in libsrlx.  feats = (features of the current states WITH gradient,
+        of the next states by the online network, of the next states by the target network) or None (the torch image blocks)."""
         cfg = self.config
+        f_cur, f_next_on, f_next_tg = feats if feats is not None else (None, None, None)
         with torch.no_grad():  # agent57_light.py:241-257
             online.eval()
-            q_tg_next = self._q(target_net, next_inputs)
-            q_on_next = self._q(online, next_inputs) if cfg.enable_double_dqn else None
+            q_tg_next = self._q(target_net, next_inputs, f_next_tg)
+            q_on_next = self._q(online, next_inputs, f_next_on) if cfg.enable_double_dqn else None
         target = self.ops.dqn_target(q_on_next, q_tg_next, rewards, undone, inv, 0.0, cfg.enable_double_dqn, cfg.enable_rescale, False, discount_per_sample=discount)
         online.train()
-        q = self._q(online, cur_inputs)
+        q = self._q(online, cur_inputs, f_cur)
         _, loss, grad, _ = self.ops.huber(target, q, action, w)
         optimizer.zero_grad()
         q.backward(grad)
@@ -143,9 +147,12 @@ class Agent57LightLearner:
             self.sync_count += 1
         self.train_count += 1
 
-    def update_networks(self, states, n_states, action, r_ext, r_int, undone, prev_action, prev_r_ext, prev_r_int, actor, weights, invalid=None):
-        """The device part of an update (everything of `update` but the target sync and the counters): only enqueues work, capturable."""
+    def update_networks(self, states, n_states, action, r_ext, r_int, undone, prev_action, prev_r_ext, prev_r_int, actor, weights, invalid=None, features=None):
+        """The device part of an update (everything of `update` but the target sync and the counters): only enqueues work, capturable.
+        features: the image blocks' outputs from hand-written trunks (Agent57LightEngine.learner_features; states / n_states are then unused) --
+        {"q_ext": (cur with grad, next online, next target), "q_int": ..., "emb": (cur, next: both with grad), "ll": (train with grad, target)}."""
         cfg, p = self.config, self.parameter
+        ft = features or {}
         B = action.shape[0]
         actor_onehot = self.actor_eye[actor.long()]
         discount = self.discount_list[actor.long()]  # model_torch.py:287
@@ -154,16 +161,19 @@ class Agent57LightLearner:
         cur_inputs = [states, prev_r_ext.view(B, 1), prev_r_int.view(B, 1), self.action_eye[prev_action.long()], actor_onehot]  # :427-433
         action32 = action.to(torch.int32)
         tgt_e, q_e, ext_loss = self._update_q(p.q_ext_online, p.q_ext_target, self.q_ext_optimizer, r_ext, next_inputs, cur_inputs, undone, discount, invalid,
-                                              action32, weights)
+                                              action32, weights, ft.get("q_ext"))
         self.ext_loss = ext_loss
         tgt_i = q_i = None
         if cfg.enable_intrinsic_reward:
             tgt_i, q_i, int_loss = self._update_q(p.q_int_online, p.q_int_target, self.q_int_optimizer, r_int, next_inputs, cur_inputs, undone, discount, invalid,
-                                                  action32, weights)
+                                                  action32, weights, ft.get("q_int"))
             self.int_loss = int_loss
             # inverse-dynamics embedding (:341-348)
             p.emb_network.train()
-            if self.cf:
+            if "emb" in ft:
+                h = torch.cat([embed(p.emb_network, None, ft["emb"][0]), embed(p.emb_network, None, ft["emb"][1])], dim=1)
+                probs = torch.softmax(p.emb_network.out_block_out1(p.emb_network.out_block_normalize(p.emb_network.out_block(h))), dim=1)
+            elif self.cf:
                 h = torch.cat([embed(p.emb_network, states), embed(p.emb_network, n_states)], dim=1)
                 probs = torch.softmax(p.emb_network.out_block_out1(p.emb_network.out_block_normalize(p.emb_network.out_block(h))), dim=1)
             else:
@@ -175,9 +185,16 @@ class Agent57LightLearner:
             self.emb_loss = emb_loss.detach()
             # RND (:353-362)
             with torch.no_grad():
-                lifelong_target_val = rnd(p.lifelong_target, states) if self.cf else p.lifelong_target(states)
+                if "ll" in ft:
+                    lifelong_target_val = rnd(p.lifelong_target, None, ft["ll"][1])
+                else:
+                    lifelong_target_val = rnd(p.lifelong_target, states) if self.cf else p.lifelong_target(states)
             p.lifelong_train.train()
-            lifelong_loss = torch.nn.functional.mse_loss(lifelong_target_val, rnd(p.lifelong_train, states) if self.cf else p.lifelong_train(states))
+            if "ll" in ft:
+                lifelong_train_val = rnd(p.lifelong_train, None, ft["ll"][0])
+            else:
+                lifelong_train_val = rnd(p.lifelong_train, states) if self.cf else p.lifelong_train(states)
+            lifelong_loss = torch.nn.functional.mse_loss(lifelong_target_val, lifelong_train_val)
             self.lifelong_optimizer.zero_grad()
             lifelong_loss.backward()
             self.lifelong_optimizer.step()
@@ -264,6 +281,21 @@ class Agent57LightEngine:
                 if blk is not None and getattr(net.in_block, "out_flatten", False) and ImageTrunk.supported(blk):
                     self._trunks[name] = ImageTrunk(blk, shape[:2], E, device)
         self._all_fused = len(self._trunks) == len(nets)
+        # The LEARNER's image blocks, forward and backward, hand-written too (device/qnet.py:TrainableImageTrunk): one handle per network that trains
+        # (its forward keeps the activations, its backward writes the six convolution gradients) and one per network that is only evaluated (targets).
+        # No MIOpen on the update path: its convolutions were 3.3 ms of the update and chose their solvers per engine instance by timing, so that one
+        # instance in four learned on a different trajectory.  SRLX_A57_TORCH_LEARNER=1: the torch image blocks (A/B, tests).
+        self._ltrunks = None
+        if self._all_fused and os.environ.get("SRLX_A57_TORCH_LEARNER", "0") != "1" and 2 * B <= 64 and nets["q_ext"].in_block.image_block.image_layers[0].out_channels == 32:
+            from simple_distributed_rl_amd.device.qnet import TrainableImageTrunk
+
+            blk = lambda net: net.in_block.image_block  # noqa: E731
+            lt = {"q_ext": TrainableImageTrunk(blk(p.q_ext_online), shape[:2], 2 * B, device, B), "q_ext_t": ImageTrunk(blk(p.q_ext_target), shape[:2], B, device),
+                  "q_int": TrainableImageTrunk(blk(p.q_int_online), shape[:2], 2 * B, device, B), "q_int_t": ImageTrunk(blk(p.q_int_target), shape[:2], B, device)}
+            if c.enable_intrinsic_reward:
+                lt.update(emb=TrainableImageTrunk(blk(p.emb_network), shape[:2], 2 * B, device, 2 * B), ll=TrainableImageTrunk(blk(p.lifelong_train), shape[:2], B, device, B),
+                          ll_t=ImageTrunk(blk(p.lifelong_target), shape[:2], B, device))
+            self._ltrunks = lt
         self.ngu = None
         if c.enable_intrinsic_reward:
             self.ngu = NguOps(d, E, p.emb_network.emb_block.out_size, c.episodic_memory_capacity, c.episodic_count_max, c.episodic_epsilon,
@@ -406,15 +438,35 @@ class Agent57LightEngine:
         self.total_env_steps += E
 
     # ---- learner --------------------------------------------------------------------------------
+    def learner_features(self, rp):
+        """The image blocks of one update through the hand-written trunks, straight from `rp`'s uint8 ring through the frame-offset table of the batch
+        just drawn (`rp.sample_items(all_states=True)`: rows [b][s_0, s_1][window]).  An online Q-network evaluates s_0 (with gradient) and s_1
+        (without: the double-DQN argmax, agent57_light.py:241-257) in ONE pass of 2 B rows whose backward touches rows 0, 2, 4, ... only."""
+        lt, B, W = self._ltrunks, rp.B, self.Wn
+        base = rp.obs_base
+        off01 = rp.frame_off_all.view(2 * B, W)
+        off0, off1 = rp.frame_off_all[:, 0].contiguous(), rp.frame_off_all[:, 1].contiguous()
+        ft = {}
+        for name in ("q_ext", "q_int"):
+            x = lt[name].features(base, off01, 2)
+            ft[name] = (x[0::2], x[1::2].detach(), lt[name + "_t"](base, off1))
+        if "emb" in lt:
+            x = lt["emb"].features(base, off01, 1)
+            ft["emb"] = (x[0::2], x[1::2])
+            ft["ll"] = (lt["ll"].features(base, off0, 1), lt["ll_t"](base, off0))
+        return ft
+
     def _learner_body(self):
         """PER sample -> gather (frames by the store, the other fields by (slot, env)) -> the five networks' update -> PER update: device work only."""
         r = self.replay
-        b = r.sample(self.train_count_dev)
+        hand = self._ltrunks is not None
+        b = r.sample_items(self.train_count_dev, all_states=True) if hand else r.sample(self.train_count_dev)
         N.check(self.lib.srlx_store_locate(r.h_store, r.B, N.tptr(b.indices), N.tptr(self.loc_env), N.tptr(self.loc_slot), None, N.torch_stream_ptr()))
         e, s = self.loc_env, self.loc_slot
-        obs = b.obs.view(r.B, 2, self.Wn, *self.hw)
-        pri = self.learner.update_networks(obs[:, 0], obs[:, 1], b.actions.view(-1), b.rewards.view(-1), self.x_r_int[s, e], 1.0 - b.terminated.view(-1),
-                                           self.x_prev_action[s, e], self.x_prev_r_ext[s, e], self.x_prev_r_int[s, e], self.x_actor[s, e], b.weights)
+        obs = None if hand else b.obs.view(r.B, 2, self.Wn, *self.hw)
+        pri = self.learner.update_networks(None if hand else obs[:, 0], None if hand else obs[:, 1], b.actions.view(-1), b.rewards.view(-1), self.x_r_int[s, e],
+                                           1.0 - b.terminated.view(-1), self.x_prev_action[s, e], self.x_prev_r_ext[s, e], self.x_prev_r_int[s, e], self.x_actor[s, e],
+                                           b.weights, features=self.learner_features(r) if hand else None)
         r.update(b.indices, pri)
         self.train_count_dev.add_(1)
 

@@ -484,12 +484,15 @@ class DistributedAgent57Light:
         rp, eng = self.replay, self.local
         if rp.is_warmup_needed():
             return False
-        b = rp.sample(self.train_count_dev)
+        hand = eng._ltrunks is not None  # the learner's image blocks through the hand-written trunks, straight from the global ring
+        b = rp.sample_items(self.train_count_dev, all_states=True) if hand else rp.sample(self.train_count_dev)
         N.check(rp.lib.srlx_store_locate(rp.h_store, rp.B, N.tptr(b.indices), N.tptr(self.loc_env), N.tptr(self.loc_slot), None, N.torch_stream_ptr()))
         x = self.x[self.loc_slot, self.loc_env]  # [B][5]
-        obs = b.obs.view(rp.B, 2, eng.Wn, *eng.hw)
-        pri = eng.learner.update(obs[:, 0], obs[:, 1], b.actions.view(-1), b.rewards.view(-1), x[:, 0].contiguous(), 1.0 - b.terminated.view(-1),
-                                 x[:, 2].long(), x[:, 3].contiguous(), x[:, 4].contiguous(), x[:, 1].long(), b.weights)
+        obs = None if hand else b.obs.view(rp.B, 2, eng.Wn, *eng.hw)
+        pri = eng.learner.update_networks(None if hand else obs[:, 0], None if hand else obs[:, 1], b.actions.view(-1), b.rewards.view(-1), x[:, 0].contiguous(),
+                                          1.0 - b.terminated.view(-1), x[:, 2].long(), x[:, 3].contiguous(), x[:, 4].contiguous(), x[:, 1].long(), b.weights,
+                                          features=eng.learner_features(rp) if hand else None)
+        eng.learner.after_update()
         rp.update(b.indices, pri)
         self.train_count_dev.add_(1)
         return True

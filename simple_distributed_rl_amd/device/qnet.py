@@ -392,6 +392,47 @@ class ImageTrunk:
         return self.out[:B].transpose(1, 2).reshape(B, self.channels * self.pixels)  # pixel-major -> torch's channel-major flatten
 
 
+class _TrunkFunction(torch.autograd.Function):
+    """features = image_block(frames) with the forward AND the backward in libsrlx.  The six convolution parameters are inputs only so that autograd
+    routes their gradients through `backward`; the kernels read them by address."""
+
+    @staticmethod
+    def forward(ctx, trunk, frame_base_ptr, frame_off, grad_stride, w1, b1, w2, b2, w3, b3):
+        ctx.trunk, ctx.base, ctx.off, ctx.stride = trunk, frame_base_ptr, frame_off, int(grad_stride)
+        return ImageTrunk.__call__(trunk, frame_base_ptr, frame_off)
+
+    @staticmethod
+    def backward(ctx, g):
+        t = ctx.trunk
+        R = g.shape[0]
+        ss = ctx.stride
+        rows = R // ss
+        # rows 0, ss, 2 ss, ... carry gradient (the others were used without one); channel-major flatten -> the kernels' pixel-major rows
+        gp = g.view(R, t.channels, t.pixels)[0::ss].transpose(1, 2).contiguous()
+        arr = (N.c_p * 6)(*[b.data_ptr() for b in t.grad_bufs])
+        N.check(t.lib.srlx_qnet_backward_convs_u8(t.h, rows, ss, N.c_p(ctx.base), N.tptr(ctx.off), N.tptr(gp), ctypes.cast(arr, N.c_p), N.torch_stream_ptr()))
+        return (None, None, None, None) + tuple(b.clone() for b in t.grad_bufs)
+
+
+class TrainableImageTrunk(ImageTrunk):
+    """An `ImageTrunk` whose features carry gradients: `features(base, off, grad_stride)` is differentiable with respect to the module's convolution
+    parameters, forward and backward both hand-written (srlx_qnet_forward_convs_u8 on a training-enabled handle, srlx_qnet_backward_convs_u8) -- the
+    image blocks of Agent57_light's learner (model_torch.py:18-117) without MIOpen: the convolutions' weight and data gradients use fixed summation
+    orders, so an update is reproducible run to run (MIOpen picks a solver per instance by timing, and its fp32 Winograd kernels round differently).
+    `grad_stride` = s: only rows 0, s, 2s, ... of the batch receive gradient (the others -- next states evaluated under no_grad -- share the forward)."""
+
+    def __init__(self, image_block, hw, max_batch: int, device: int = 0, max_grad_rows: int = 64):
+        super().__init__(image_block, hw, max_batch, device)
+        assert self.convs[0].out_channels == 32, "the backward kernels cover the 32 / 64 / 64-filter block"
+        N.check(self.lib.srlx_qnet_enable_training(self.h, int(max_grad_rows)))
+        ps = [t for c in self.convs for t in (c.weight, c.bias)]
+        self.grad_bufs = [torch.zeros_like(p) for p in ps]  # each in its parameter's own memory format (channels_last conv2 / conv3)
+
+    def features(self, frame_base_ptr: int, frame_off: torch.Tensor, grad_stride: int = 1) -> torch.Tensor:
+        ps = [t for c in self.convs for t in (c.weight, c.bias)]
+        return _TrunkFunction.apply(self, frame_base_ptr, frame_off, grad_stride, *ps)
+
+
 class DeviceAdam:
     """torch.optim.Adam(params, lr) for a fixed list of float32 device tensors as ONE libsrlx launch
     (`srlx_adam_step`; reference: `optim.Adam(self.q_online.parameters(), lr=...)`, model_torch.py:71, and

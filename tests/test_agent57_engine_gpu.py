@@ -200,3 +200,90 @@ def test_image_trunks_equal_the_torch_image_blocks(hw):
             torch.testing.assert_close(embed(p.emb_network, None, eng._trunks["emb"](eng.replay.obs_base, off)), embed(p.emb_network, stack), rtol=1e-4, atol=1e-5)
             torch.testing.assert_close(rnd(p.lifelong_train, None, eng._trunks["rnd_train"](eng.replay.obs_base, off)), rnd(p.lifelong_train, stack), rtol=1e-4, atol=1e-5)
     assert eng.train_count > 5
+
+
+def _engine84(batch=16, E=16, seed=3):
+    from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
+
+    cfg = agent57_light.Config(batch_size=batch, actor_num=4, target_model_update_interval=5, episodic_memory_capacity=64, ucb_window_size=6)
+    cfg.window_length = 4
+    cfg.memory.capacity, cfg.memory.warmup_size = E * 40, 64
+    cfg.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1000)
+    cfg.input_block.image.set_dqn_block()
+    cfg.hidden_block.set_dueling_network((64,))
+    env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(84, 84), n_actions=4, episode_len=11)))
+    cfg.setup(env)
+    return Agent57LightEngine(cfg, E, 0, episode_len=11, seed=seed), cfg
+
+
+def test_trainable_trunk_gradients_equal_autograd():
+    """device/qnet.py:TrainableImageTrunk -- the image block's forward AND backward in libsrlx (srlx_qnet_backward_convs_u8) -- against autograd through the
+    torch image block on the float32 stack of the same frames: features 1e-5, all six gradients 2e-4 relative to their largest element, with gradient on
+    every row (stride 1) and on every second row only (stride 2: the online Q-network's s_0 / s_1 pass)."""
+    eng, cfg = _engine84()
+    for _ in range(8):
+        eng.step(learner_updates=0)
+    assert eng._ltrunks is not None and set(eng._ltrunks) == {"q_ext", "q_ext_t", "q_int", "q_int_t", "emb", "ll", "ll_t"}
+    rp = eng.replay
+    rp.sample_items(eng.train_count_dev, all_states=True)
+    B, W = rp.B, eng.Wn
+    off01 = rp.frame_off_all.view(2 * B, W)
+    b = rp.sample(eng.train_count_dev.clone())  # the float32 windows of a second draw are not the same items: gather the drawn ones instead
+    N_ = rp.lib
+    from simple_distributed_rl_amd import _native as N
+
+    obs = torch.zeros((B, 2, W, 84 * 84), dtype=torch.float32, device="cuda")
+    rp.sample_items(eng.train_count_dev, all_states=True)
+    N.check(N_.srlx_store_gather_nstep(rp.h_store, B, N.tptr(rp.batch.indices), N.tptr(obs), N.tptr(rp.batch.actions), N.tptr(rp.batch.rewards), N.tptr(rp.batch.terminated),
+                                       N.torch_stream_ptr()))
+    stack = obs.view(2 * B, W, 84, 84)
+    net = eng.parameter.emb_network
+    trunk = eng._ltrunks["emb"]
+    params = [t for c in trunk.convs for t in (c.weight, c.bias)]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for stride in (1, 2):
+        R = torch.randn((2 * B, trunk.channels * trunk.pixels), device="cuda", generator=g)
+        if stride == 2:
+            R[1::2] = 0  # rows without gradient
+        for p in params:
+            p.grad = None
+        want_f = net.in_block(stack, channels_first=True)
+        (want_f * R).sum().backward()
+        want = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        got_f = trunk.features(rp.obs_base, off01, stride)
+        torch.testing.assert_close(got_f, want_f, rtol=1e-5, atol=1e-5 * float(want_f.abs().max()))
+        (got_f * R).sum().backward()
+        for p, w in zip(params, want):
+            torch.testing.assert_close(p.grad, w, rtol=2e-4, atol=2e-4 * float(w.abs().max()))
+
+
+def test_hand_written_learner_equals_the_torch_learner_and_is_reproducible():
+    """The update with the image blocks of all five networks in libsrlx (forward + backward; no MIOpen on the update path) against the same update through
+    torch's convolutions (SRLX_A57_TORCH_LEARNER=1) from the same seed: the four losses agree after 12 updates (1e-3: MIOpen's own fp32 solvers differ
+    more from each other than that); and two hand-written instances give the SAME losses bit for bit (with MIOpen one instance in
+    four landed on a different trajectory)."""
+    def run(torch_learner):
+        if torch_learner:
+            os.environ["SRLX_A57_TORCH_LEARNER"] = "1"
+        torch.manual_seed(11)  # the five networks are initialised from torch's global generator
+        random.seed(11)
+        np.random.seed(11)
+        try:
+            eng, _ = _engine84()
+        finally:
+            os.environ.pop("SRLX_A57_TORCH_LEARNER", None)
+        assert (eng._ltrunks is None) == torch_learner
+        for _ in range(20):
+            eng.step(learner_updates=1)
+        torch.cuda.synchronize()
+        assert eng.train_count >= 12
+        return eng.learner.losses(), eng.train_count
+
+    a, na = run(False)
+    b, nb = run(False)
+    t, nt = run(True)
+    assert na == nb == nt and a == b, (a, b)
+    for k in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"):
+        assert math.isfinite(a[k]) and abs(a[k] - t[k]) <= 1e-3 * max(abs(t[k]), 1e-3), (k, a[k], t[k])

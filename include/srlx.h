@@ -143,6 +143,9 @@ int srlx_per_refresh(srlx_per_t *h, void *stream);
  * afterwards *d_counter += 1.  Restated for tests in oracle/hot_path_oracle.py:rng_uniform.
  * ------------------------------------------------------------------------------------ */
 int srlx_rng_uniform(uint64_t seed, int64_t *d_counter, int64_t n, double *d_out, void *stream);
+/* A keyed pseudo-random permutation of 0..n-1 (int64), key = (seed, *d_counter); advances *d_counter by one.  Device state only: replayable inside a
+ * HIP graph (the PPO engine's minibatch shuffles -- the role of the reference's per-epoch shuffle of the collected batch, srl/algorithms/ppo/ppo.py). */
+int srlx_rng_permutation(uint64_t seed, int64_t *d_counter, int64_t n, int64_t *d_out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Device-resident transition store for E lock-stepped environments (uint8 or float32 frames).

@@ -63,6 +63,7 @@ SIGNATURES = {
     "srlx_per_state_ptr": (c_int, [c_p, ctypes.POINTER(c_p)]),
     "srlx_per_refresh": (c_int, [c_p, c_p]),
     "srlx_rng_uniform": (c_int, [ctypes.c_uint64, c_p, c_i64, c_p, c_p]),
+    "srlx_rng_permutation": (c_int, [ctypes.c_uint64, c_p, c_i64, c_p, c_p]),
     "srlx_store_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, c_int]),
     "srlx_store_destroy": (c_int, [c_p]),
     "srlx_store_item_len": (c_i64, [c_p]),

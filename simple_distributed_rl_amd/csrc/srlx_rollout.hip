@@ -676,6 +676,40 @@ int srlx_rng_uniform(uint64_t seed, int64_t *d_counter, int64_t n, double *d_out
     return SRLX_OK;
 }
 
+// A keyed pseudo-random PERMUTATION of 0..n-1 without a sort: a four-round Feistel network over the smallest even number of bits that holds n - 1,
+// walked until it lands below n (a bijection restricted to a subset by cycle walking stays a bijection; fewer than four rounds of walking on average).
+// Key = (seed, *counter): a captured graph draws a fresh permutation at every replay with nothing but device state -- the PPO engine's minibatch
+// shuffles (device/ppo.py; torch.randperm as a graph node, or eager between replays of its large graphs, did not replay reliably).
+__global__ void __launch_bounds__(256) k_rng_permutation(u64 seed, const i64 *counter, i64 n, int half_bits, i64 *out) {
+    const u64 c = (u64)counter[0];
+    const u64 mask = (1ull << half_bits) - 1;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        u64 x = (u64)i;
+        do {
+            u64 l = x >> half_bits, r = x & mask;
+#pragma unroll
+            for (int round = 0; round < 4; round++) {
+                const u64 f = rng_u64(seed + 0x9E3779B97F4A7C15ull * (u64)(round + 1), c, r) & mask;
+                const u64 nl = r;
+                r = l ^ f;
+                l = nl;
+            }
+            x = (l << half_bits) | r;
+        } while (x >= (u64)n);
+        out[i] = (i64)x;
+    }
+}
+
+int srlx_rng_permutation(uint64_t seed, int64_t *d_counter, int64_t n, int64_t *d_out, void *stream) {
+    SRLX_REQUIRE(d_counter && d_out && n > 0 && n < ((int64_t)1 << 40), "rng_permutation: bad argument");
+    int bits = 2;
+    while (((int64_t)1 << bits) < n) bits += 2;
+    hipLaunchKernelGGL(k_rng_permutation, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (u64)seed, d_counter, (i64)n, bits / 2, (i64 *)d_out);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, d_counter);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
 int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, float *d_rewards, uint8_t *d_terminated,
                         uint8_t *d_done, void *stream) {
     SRLX_REQUIRE(h && d_next_obs && d_rewards && d_terminated && d_done && episode_len > 0, "synth_env_step: bad argument");

@@ -18,6 +18,7 @@ every minibatch with one all-reduce of a flat ~40 KB buffer (latency-bound; RCCL
 """
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 from typing import Callable, Optional, Tuple
 
@@ -135,6 +136,17 @@ class PPOEngine:
         self._update_graph = None
         self.episode_return = torch.zeros(E, **f32)
         self.finished_returns = torch.zeros(2, **f32)  # sum, count of finished episodes since the last read
+        # One minibatch permutation per epoch from libsrlx's keyed permutation kernel (srlx_rng_permutation: device state only), INSIDE the captured
+        # update.  What round 2 hid behind a hipStreamSynchronize per iteration (tools/ppo_replay_bisect.py, ROCm 7.2 / torch 2.10, E = 4096): with NO
+        # eager launch between replays of the two large graphs (~700 / ~1000 nodes) -- fixed permutations, or this kernel -- 40 unsynchronised iterations
+        # equal the synchronised run to 1e-7; with torch.randperm as a graph node (torch refreshes the generator's offset tensors with eager launches before
+        # every replay) they turn non-finite, and with torch.randperm drawn eagerly between the replays they stay finite but train differently: eager
+        # kernels enqueued behind a large graph launch do not reliably wait for the graph's tail (an event recorded there does not either:
+        # event.synchronize() per iteration does not help, hipStreamSynchronize does).  A graph whose only node is randperm replays fine
+        # (tools/randperm_graph_repro.py).  SRLX_PPO_PERM = in_graph (torch.randperm as a node) / eager / fixed: the bisect's other arms.
+        self._perm_mode = os.environ.get("SRLX_PPO_PERM", "srlx")
+        self._perms = torch.stack([torch.randperm(T * E, device=d) for _ in range(cfg.epochs)])  # ("fixed": these stay)
+        self.perm_counter = torch.zeros(1, dtype=torch.int64, device=d)
 
     # --- rollout ---------------------------------------------------------------------------------------------------
     def act(self, obs: torch.Tensor, action_out: torch.Tensor, logp_out: torch.Tensor, deterministic: bool = False):
@@ -187,8 +199,10 @@ class PPOEngine:
         val = self.b_val.reshape(n)
         v_target = adv if cfg.v_target == "gae" else adv + val
         mb = n // cfg.minibatches
-        for _ in range(cfg.epochs):
-            perm = torch.randperm(n, device=self.dev)
+        for ep in range(cfg.epochs):
+            if self._perm_mode == "srlx":
+                N.check(self.lib.srlx_rng_permutation(cfg.seed ^ 0x7065726D, N.tptr(self.perm_counter), n, N.tptr(self._perms[ep]), N.torch_stream_ptr()))
+            perm = self._perms[ep] if self._perm_mode != "in_graph" else torch.randperm(n, device=self.dev)
             for k in range(cfg.minibatches):
                 idx = perm[k * mb : (k + 1) * mb]
                 outs, seeds = self.loss_and_seeds(obs[idx], act[idx].contiguous(), logp[idx].contiguous(), adv[idx].contiguous(), v_target[idx].contiguous(),
@@ -224,19 +238,28 @@ class PPOEngine:
         self._rollout_graph, self._update_graph = g1, g2
         torch.cuda.synchronize(self.dev)
 
+    def _draw_permutations(self):
+        if self._perm_mode == "eager":
+            for ep in range(self.cfg.epochs):
+                torch.randperm(self._perms.shape[1], device=self.dev, out=self._perms[ep])
+
     def step(self):
         """one PPO iteration: T x E environment steps + epochs x minibatches updates"""
+        self._draw_permutations()
         if self._rollout_graph is not None:
-            # One hipStreamSynchronize per iteration.  Measured on ROCm 7.2 / torch 2.10: with iterations of these two ~700 / ~1000-node
-            # graphs queued back to back the results depend on how far the host runs ahead and turn non-finite at E = 4096 within ten
-            # iterations; a stream (or device) synchronisation per iteration gives the eager results, waiting on an EVENT recorded after
-            # the iteration does not (so it is host-side bookkeeping of the runtime that the synchronisation advances, not a missing
-            # dependency on the GPU).  The Rainbow / Agent57_light graphs (~45 / ~400 nodes, eager launches between replays) are
-            # bit-stable over thousands of unsynchronised replays (tools/graph_replay_check.py).  Cost here: the host launches the next
-            # rollout graph with the GPU idle, ~1 ms of a 24 ms iteration.
+            # two graph launches per iteration, nothing waits on the host and nothing is launched eagerly between them (see __init__)
             self._rollout_graph.replay()
             self._update_graph.replay()
-            torch.cuda.current_stream(self.dev).synchronize()
+            mode = os.environ.get("SRLX_PPO_SYNC", "none")  # tools/ppo_replay_bisect.py: host-side waits as an experiment
+            if mode == "stream":
+                torch.cuda.current_stream(self.dev).synchronize()
+            elif mode == "event":
+                ev = torch.cuda.Event()
+                ev.record()
+                ev.synchronize()
+            elif mode.startswith("every"):
+                if (self.iterations + 1) % int(mode[5:]) == 0:
+                    torch.cuda.current_stream(self.dev).synchronize()
         else:
             self.rollout()
             self.update()

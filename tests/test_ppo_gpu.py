@@ -237,9 +237,9 @@ def test_bench_ppo_line():
 
 
 def test_graph_replays_do_not_depend_on_host_synchronisation():
-    """PPOEngine.step() with captured graphs, iterations queued back to back vs one host synchronisation per iteration: same training
-    (value loss within the run-to-run spread of the float atomics in torch's backward), finite at E = 4096 -- the engine
-    synchronises its stream once per iteration (device/ppo.py:step has the measurements)."""
+    """PPOEngine.step() with captured graphs, iterations queued back to back (nothing waits on the host) vs one host synchronisation per iteration: the
+    same training, finite at E = 4096.  The engine draws its minibatch permutations eagerly, outside the captured update: torch.randperm as a graph
+    node was what made unsynchronised replays diverge (tools/ppo_replay_bisect.py, tools/randperm_graph_repro.py; device/ppo.py:__init__)."""
     import torch
 
     from simple_distributed_rl_amd.device.ppo import PPODeviceConfig, PPOEngine
@@ -251,7 +251,7 @@ def test_graph_replays_do_not_depend_on_host_synchronisation():
         eng.capture_graphs()
         eng.step()
         torch.cuda.synchronize()
-        for _ in range(12):
+        for _ in range(40):
             eng.step()
             if sync:
                 torch.cuda.synchronize()
@@ -262,4 +262,38 @@ def test_graph_replays_do_not_depend_on_host_synchronisation():
     for E in (256, 4096):
         a, b = run(E, True), run(E, False)
         for k in a:
-            assert math.isfinite(b[k]) and abs(a[k] - b[k]) <= 1e-3 * abs(a[k]) + 1e-6, (E, k, a, b)
+            assert math.isfinite(b[k]) and abs(a[k] - b[k]) <= 1e-4 * abs(a[k]) + 1e-6, (E, k, a, b)
+
+
+def test_keyed_permutation_kernel():
+    """srlx_rng_permutation: a valid permutation of 0..n-1 for awkward n, a different one at every call (the device counter advances), the same one for
+    the same (seed, counter), and every position equally likely to receive any value (chi-square of one position over 4000 draws)."""
+    import torch
+
+    from simple_distributed_rl_amd import _native as N
+
+    lib = N.lib()
+    dev = torch.device("cuda:0")
+    for n in (1, 2, 5, 1000, 4097, 32 * 4096):
+        counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        out = torch.empty(n, dtype=torch.int64, device=dev)
+        seen = []
+        for k in range(3):
+            N.check(lib.srlx_rng_permutation(1234, N.tptr(counter), n, N.tptr(out), None))
+            torch.cuda.synchronize()
+            assert torch.equal(out.sort().values, torch.arange(n, device=dev)) and int(counter) == k + 1
+            seen.append(out.clone())
+        if n > 5:
+            assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+        counter.zero_()
+        N.check(lib.srlx_rng_permutation(1234, N.tptr(counter), n, N.tptr(out), None))
+        assert torch.equal(out, seen[0])
+    n, draws = 16, 4000
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    hist = np.zeros((n, n))
+    for _ in range(draws):
+        N.check(lib.srlx_rng_permutation(7, N.tptr(counter), n, N.tptr(out), None))
+        hist[np.arange(n), out.cpu().numpy()] += 1
+    chi2 = ((hist - draws / n) ** 2 / (draws / n)).sum(axis=1)  # 15 degrees of freedom per position: 99.99 % quantile = 44
+    assert chi2.max() < 60, chi2

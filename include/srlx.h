@@ -143,6 +143,10 @@ int srlx_per_refresh(srlx_per_t *h, void *stream);
  * afterwards *d_counter += 1.  Restated for tests in oracle/hot_path_oracle.py:rng_uniform.
  * ------------------------------------------------------------------------------------ */
 int srlx_rng_uniform(uint64_t seed, int64_t *d_counter, int64_t n, double *d_out, void *stream);
+/* rows frames of frame_bytes each, gathered through a frame-offset table (byte offsets from d_frame_base, -1 = none) into d_out[rows][frame_bytes], and the
+ * table re-based onto d_out (d_rel_off[row] = row * frame_bytes, or -1): a sampled batch as ONE message from a replay rank to a learner rank -- the
+ * device-path counterpart of the batches the reference's memory process puts on its queue (srl/base/run/play_mp_memory.py:253-351). */
+int srlx_pack_frames(const uint8_t *d_frame_base, const int64_t *d_frame_off, int64_t rows, int64_t frame_bytes, uint8_t *d_out, int64_t *d_rel_off, void *stream);
 /* A keyed pseudo-random permutation of 0..n-1 (int64), key = (seed, *d_counter); advances *d_counter by one.  Device state only: replayable inside a
  * HIP graph (the PPO engine's minibatch shuffles -- the role of the reference's per-epoch shuffle of the collected batch, srl/algorithms/ppo/ppo.py). */
 int srlx_rng_permutation(uint64_t seed, int64_t *d_counter, int64_t n, int64_t *d_out, void *stream);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "srlx_per_refresh": (c_int, [c_p, c_p]),
     "srlx_rng_uniform": (c_int, [ctypes.c_uint64, c_p, c_i64, c_p, c_p]),
     "srlx_rng_permutation": (c_int, [ctypes.c_uint64, c_p, c_i64, c_p, c_p]),
+    "srlx_pack_frames": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "srlx_store_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, c_int]),
     "srlx_store_destroy": (c_int, [c_p]),
     "srlx_store_item_len": (c_i64, [c_p]),

@@ -676,6 +676,26 @@ int srlx_rng_uniform(uint64_t seed, int64_t *d_counter, int64_t n, double *d_out
     return SRLX_OK;
 }
 
+// The frames a frame-offset table points at, packed row by row into one message buffer, and the table re-based onto that buffer (-1 = "no frame" stays):
+// what a replay rank ships to a learner rank instead of its ring (device/replay_role.py; the network kernels take a base pointer + offset table, so the
+// learner evaluates the packed frames exactly as it would the ring).
+__global__ void __launch_bounds__(256) k_pack_frames(const u8 *__restrict__ base, const i64 *__restrict__ off, i64 frame_bytes, u8 *__restrict__ out, i64 *__restrict__ rel) {
+    const i64 row = blockIdx.x;
+    const i64 o = off[row];
+    if (threadIdx.x == 0) rel[row] = o < 0 ? -1 : row * frame_bytes;
+    if (o < 0) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(base + o);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + row * frame_bytes);
+    for (i64 k = threadIdx.x; k < frame_bytes / 16; k += blockDim.x) dst[k] = src[k];
+}
+
+int srlx_pack_frames(const uint8_t *d_frame_base, const int64_t *d_frame_off, int64_t rows, int64_t frame_bytes, uint8_t *d_out, int64_t *d_rel_off, void *stream) {
+    SRLX_REQUIRE(d_frame_base && d_frame_off && d_out && d_rel_off && rows > 0 && frame_bytes > 0 && frame_bytes % 16 == 0, "pack_frames: bad argument (16-byte frames)");
+    hipLaunchKernelGGL(k_pack_frames, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, d_frame_base, (const i64 *)d_frame_off, (i64)frame_bytes, d_out, (i64 *)d_rel_off);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
 // A keyed pseudo-random PERMUTATION of 0..n-1 without a sort: a four-round Feistel network over the smallest even number of bits that holds n - 1,
 // walked until it lands below n (a bijection restricted to a subset by cycle walking stays a bijection; fewer than four rounds of walking on average).
 // Key = (seed, *counter): a captured graph draws a fresh permutation at every replay with nothing but device state -- the PPO engine's minibatch

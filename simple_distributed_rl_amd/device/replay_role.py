@@ -1,0 +1,270 @@
+"""The reference's THREE-role topology on the device path: actors -> replay -> learner, one process per GPU.
+
+Reference: srl/base/run/play_mp_memory.py -- a memory process between the actor processes and the trainer process (`_run_memory`, :253-351: it
+ingests the actors' items, samples batches ahead of the trainer into a bounded queue (`mem_to_train`, depth 5, :595-621) and applies the priority
+updates the trainer sends back through a second bounded queue (`train_to_mem`, :361-413)).  Here the memory process is a REPLAY GPU:
+
+    rank 0   learner   trains on served batches, never touches a ring or a tree; weights -> actors every `sync_interval` lock-steps (one flat broadcast)
+    rank 1   replay    owns the uint8 frame ring + the sum-tree for the environments of ALL actor ranks: ingests their slabs (grouped send / recv,
+                       device/dist.py:TransitionBus), commits, samples, and SERVES every batch as one message -- the frames its n-step windows point at
+                       packed by `srlx_pack_frames`, the frame-offset tables re-based onto the packed frames, indices / weights / n-step scalars
+    rank 2.. actors    E lock-stepped environments each, exactly the actor ranks of device/dist.py:DistributedRainbow
+
+The two bounded queues become a static software pipeline (deterministic, no polling): per lock-step the replay rank sends `updates` batch messages and
+the learner returns as many priority write-backs; the learner trains on the batch it received `prefetch` lock-steps earlier (so `prefetch` batches are
+always in flight: the reference's depth-5 prefetch queue), and the replay rank applies a write-back one lock-step after it was produced (its backlog is
+bounded by construction; the reference bounds it at 100).  A batch message whose header says "not warm yet" is skipped by the learner; every step moves
+the same number of messages, so the ranks need no other handshake.  The network kernels take (base pointer, offset table): the learner evaluates the
+packed frames exactly as it would a ring, through the same `RainbowEngine` update (online + target pass, fused TD / Huber / priorities, hand-written
+backward, Adam) with a served batch standing in for its replay.
+"""
+import dataclasses
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from simple_distributed_rl_amd import _native as N
+from simple_distributed_rl_amd.device.dist import TransitionBus, flatten_parameters
+from simple_distributed_rl_amd.device.qnet import DeviceAdam
+from simple_distributed_rl_amd.device.replay import ReplayBatch
+
+LEARNER, REPLAY, FIRST_ACTOR = 0, 1, 2
+
+
+class BatchCodec:
+    """Layout of one served batch as a flat uint8 message (both ends compute it from the configuration)."""
+
+    def __init__(self, B: int, n: int, W: int, F: int):
+        self.B, self.n, self.W, self.F = B, n, W, F
+        rows = B * (n + 1) * W
+        self.rows = rows
+        fields = [("header", 16), ("indices", 8 * B), ("weights", 4 * B), ("actions", 4 * B * n), ("rewards", 4 * B * n), ("terminated", 4 * B * n),
+                  ("rel_all", 8 * rows), ("rel_next", 8 * B * n * W), ("frames", rows * F)]
+        self.off, at = {}, 0
+        for name, nbytes in fields:
+            at = -(-at // 256) * 256  # every field on a 256-byte boundary (vector loads of the frames, aligned int64 views)
+            self.off[name] = (at, nbytes)
+            at += nbytes
+        self.nbytes = at
+
+    def view(self, buf: torch.Tensor, name: str, dtype: torch.dtype) -> torch.Tensor:
+        a, nb = self.off[name]
+        return buf[a : a + nb].view(dtype)
+
+
+class ServedBatch:
+    """What `RainbowEngine._learner_body` asks of a replay, answered from one received message (learner rank)."""
+
+    def __init__(self, codec: BatchCodec, device: torch.device, train_count_dev: torch.Tensor):
+        c = self.codec = codec
+        self.B = c.B
+        self.stage = torch.zeros(c.nbytes, dtype=torch.uint8, device=device)  # fixed address: a captured update could read it
+        v = lambda name, dt: c.view(self.stage, name, dt)  # noqa: E731
+        self.batch = ReplayBatch(indices=v("indices", torch.int64), weights=v("weights", torch.float32), obs=None, actions=v("actions", torch.int32).view(c.B, c.n),
+                                 rewards=v("rewards", torch.float32).view(c.B, c.n), terminated=v("terminated", torch.float32).view(c.B, c.n))
+        self.frame_off_all = v("rel_all", torch.int64).view(c.B, c.n + 1, c.W)
+        self.frame_off_next = v("rel_next", torch.int64).view(c.B, c.n, c.W)
+        self.obs_base = self.stage.data_ptr() + c.off["frames"][0]
+        self.out = torch.zeros(16 + 12 * c.B, dtype=torch.uint8, device=device)  # write-back: [valid int64 | pad | indices | priorities]
+        self._train_count_dev = train_count_dev
+
+    def sample_items(self, d_step, uniforms=None, all_states=False):
+        return self.batch
+
+    def update(self, indices, priorities):
+        B = self.B
+        self.out[16 : 16 + 8 * B].view(torch.int64).copy_(indices)
+        self.out[16 + 8 * B :].view(torch.float32).copy_(priorities)
+        self._train_count_dev.add_(1)
+
+    def is_warmup_needed(self) -> bool:
+        return False
+
+
+class ReplayRoleRainbow:
+    def __init__(self, cfg, device: int, episode_len: int = 200, sync_interval: int = 16, prefetch: int = 5, updates: int = 1, env=None):
+        from simple_distributed_rl_amd.device.rainbow import RainbowEngine
+        from simple_distributed_rl_amd.device.replay import DeviceReplay
+
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        assert self.world >= 3, "three roles: learner (rank 0), replay (rank 1), actors (ranks 2..)"
+        assert 0 <= prefetch <= 5, "the reference's prefetch queue holds 5 batches (play_mp_memory.py:595-621)"
+        self.cfg, self.dev = cfg, torch.device(f"cuda:{device}")
+        self.role = "learner" if self.rank == LEARNER else ("replay" if self.rank == REPLAY else "actor")
+        self.n_actor_ranks = self.world - FIRST_ACTOR
+        self.sync_interval, self.prefetch, self.updates = int(sync_interval), int(prefetch), int(updates)
+        self.staged = dist.get_backend() == "gloo"  # test rigs: ranks share one GPU, tensors travel through the host
+        E = cfg.n_envs
+        H, W_ = cfg.obs_hw
+        F, W, n, B = H * W_, cfg.window_length, cfg.multisteps, cfg.batch_size
+        self.codec = BatchCodec(B, n, W, F)
+        self.step_count, self._in_flight, self.env_steps_local, self.served, self.trained = 0, False, 0, 0, 0
+        self.weights_group = dist.new_group([LEARNER] + list(range(FIRST_ACTOR, self.world)))  # (every rank calls new_group)
+        self.bus = TransitionBus(E, F, torch.uint8, self.dev, learner_rank=REPLAY, actor_ranks=range(FIRST_ACTOR, self.world), p2p=True)
+        self.local = self.replay = None
+        if self.role != "replay":
+            pad = n + W
+            small = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62, seed=cfg.seed + 1_000_003 * self.rank,
+                                        n_envs=E if self.role == "actor" else 8)
+            self.local = RainbowEngine(small, device, episode_len, ring_len=pad + 4, env=env if self.role == "actor" else None, overlap=False)
+            self.flat = flatten_parameters(self.local.q_online)
+            self.local.inf_actor.bind()
+            self.local.inf_online.bind()
+            if isinstance(self.local.optimizer, DeviceAdam):
+                self.local.optimizer.bind()
+            self._broadcast_weights()
+        if self.role == "replay":
+            total = self.n_actor_ranks * E
+            self.replay = DeviceReplay(total, -(-cfg.memory_capacity // total) + n + W, F, W, n, cfg.n_actions, B, True, cfg.enable_reward_clip, cfg.memory_alpha,
+                                       cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
+                                       has_duplicate=cfg.memory_has_duplicate)
+            self.msg = [torch.zeros(self.codec.nbytes, dtype=torch.uint8, device=self.dev) for _ in range(2 * self.updates + 1)]  # send buffers, round robin
+            self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)  # the learner's train count as far as this rank knows (beta schedule)
+            self._wb_pending = []  # (work, host/device buffer) of write-backs posted and not yet applied
+            self._sends = []
+        if self.role == "learner":
+            self.served_batch = ServedBatch(self.codec, self.dev, self.local.train_count_dev)
+            self._rx = []  # (work, buffer) in arrival order
+            self._rx_bufs = [torch.zeros(self.codec.nbytes, dtype=torch.uint8, device="cpu" if self.staged else self.dev)
+                             for _ in range((self.prefetch + 1) * self.updates + 1)]
+            self._rx_n = 0
+            self._wb_sends = []
+        # first observations of every actor environment -> the replay rank's ring position 0
+        if self.role == "actor":
+            got = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, self.local.first_obs)
+        elif self.role == "replay":
+            z = torch.zeros(E, device=self.dev)
+            got = self.bus.push(z.int(), z, z.to(torch.uint8), z.to(torch.uint8), torch.zeros((E, F), dtype=torch.uint8, device=self.dev))
+            self.replay.reset_all(self._actor_rows(got)[4])
+
+    # ---- helpers --------------------------------------------------------------------------------------------------------------
+    def _actor_rows(self, gathered):
+        k = FIRST_ACTOR * self.cfg.n_envs
+        return tuple(t[k:] for t in gathered)
+
+    def _broadcast_weights(self):
+        if self.staged:
+            host = self.flat.cpu()
+            dist.broadcast(host, src=LEARNER, group=self.weights_group)
+            if self.role == "actor":
+                self.flat.copy_(host)
+        else:
+            dist.broadcast(self.flat, src=LEARNER, group=self.weights_group)
+
+    def _send(self, t: torch.Tensor, dst: int):
+        src = t.cpu() if self.staged else t
+        return dist.isend(src, dst), src
+
+    # ---- one lock-step ----------------------------------------------------------------------------------------------------------
+    def step(self):
+        getattr(self, "_step_" + self.role)()
+        self.step_count += 1
+        if self.step_count % self.sync_interval == 0 and self.role != "replay":
+            self._broadcast_weights()
+
+    def _step_actor(self):
+        eng = self.local
+        q = eng._actor_net(None, None)
+        if self._in_flight:
+            self.bus.push_end()
+        eng._actor_select(q)
+        eng.actor_commit()
+        self.env_steps_local += self.cfg.n_envs
+        env = eng.env
+        self.bus.push_begin(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
+        self._in_flight = True
+
+    def _step_replay(self):
+        rp, c = self.replay, self.codec
+        if self._in_flight:
+            rp.commit(*self._actor_rows(self.bus.push_end()))
+        z = torch.zeros(self.cfg.n_envs, device=self.dev)  # this rank contributes nothing: push_begin only posts the receives
+        self.bus.push_begin(z.int(), z, z.to(torch.uint8), z.to(torch.uint8), torch.zeros((1, 1), dtype=torch.uint8, device=self.dev))
+        self._in_flight = True
+        # the write-backs the learner produced during the PREVIOUS lock-step (posted then): apply, then post this lock-step's
+        for work, buf in self._wb_pending:
+            work.wait()
+            wb = buf.to(self.dev) if self.staged else buf
+            if int(wb[:8].view(torch.int64).item()) == 1:
+                B = c.B
+                rp.update(wb[16 : 16 + 8 * B].view(torch.int64), wb[16 + 8 * B :].view(torch.float32))
+                self.step_dev.add_(1)
+        self._wb_pending = []
+        for _ in range(self.updates):
+            buf = torch.zeros(16 + 12 * c.B, dtype=torch.uint8, device="cpu" if self.staged else self.dev)
+            self._wb_pending.append((dist.irecv(buf, LEARNER), buf))
+        # serve `updates` batches
+        for w, _ in self._sends:
+            w.wait()
+        self._sends = []
+        for u in range(self.updates):
+            m = self.msg[(self.served + u) % len(self.msg)]
+            warm = not rp.is_warmup_needed()
+            c.view(m, "header", torch.int64)[0] = 1 if warm else 0
+            if warm:
+                b = rp.sample_items(self.step_dev, all_states=True)
+                for name, src in (("indices", b.indices), ("weights", b.weights), ("actions", b.actions), ("rewards", b.rewards), ("terminated", b.terminated)):
+                    c.view(m, name, src.dtype).copy_(src.reshape(-1))
+                rel = c.view(m, "rel_all", torch.int64)
+                N.check(rp.lib.srlx_pack_frames(N.c_p(rp.obs_base), N.tptr(rp.frame_off_all), c.rows, c.F, N.c_p(m.data_ptr() + c.off["frames"][0]), N.tptr(rel),
+                                                N.torch_stream_ptr()))
+                c.view(m, "rel_next", torch.int64).copy_(rel.view(c.B, c.n + 1, c.W)[:, 1:].reshape(-1))  # s_1..s_n are rows 1.. of every item
+            self._sends.append(self._send(m, LEARNER))
+        self.served += self.updates
+
+    def _step_learner(self):
+        eng, c, sb = self.local, self.codec, self.served_batch
+        for w, _ in self._wb_sends:
+            w.wait()
+        self._wb_sends = []
+        for _ in range(self.updates):  # post this lock-step's receives
+            buf = self._rx_bufs[self._rx_n % len(self._rx_bufs)]
+            self._rx.append((dist.irecv(buf, REPLAY), buf))
+            self._rx_n += 1
+        for _ in range(self.updates):
+            valid = False
+            if len(self._rx) > self.prefetch * self.updates:  # train on the batch that arrived `prefetch` lock-steps ago
+                work, buf = self._rx.pop(0)
+                work.wait()
+                sb.stage.copy_(buf.to(self.dev) if self.staged else buf)
+                valid = int(c.view(sb.stage, "header", torch.int64)[0].item()) == 1
+                if valid:
+                    saved, eng.replay = eng.replay, sb
+                    try:
+                        eng._learner_body()
+                    finally:
+                        eng.replay = saved
+                    if eng.train_count % self.cfg.target_model_update_interval == 0:
+                        eng.sync_target()
+                    eng.train_count += 1
+                    self.trained += 1
+            sb.out[:8].view(torch.int64)[0] = 1 if valid else 0
+            self._wb_sends.append(self._send(sb.out.clone(), REPLAY))
+
+    def finish(self):
+        """Complete what is in flight: every message posted is matched (each lock-step moved the same number in both directions)."""
+        if self.role == "actor" and self._in_flight:
+            self.bus.push_end()
+        if self.role == "replay":
+            if self._in_flight:
+                self.replay.commit(*self._actor_rows(self.bus.push_end()))
+            for w, _ in self._sends:
+                w.wait()
+            for work, buf in self._wb_pending:
+                work.wait()
+        if self.role == "learner":
+            for w, _ in self._wb_sends:
+                w.wait()
+            for work, _ in self._rx:  # the prefetched batches nobody will train on any more
+                work.wait()
+        self._in_flight = False
+        torch.cuda.synchronize(self.dev)
+
+    def info(self) -> dict:
+        d = dict(role=self.role, steps=self.step_count, env_steps_local=self.env_steps_local)
+        if self.role == "replay":
+            d.update(memory=self.replay.length(), served=self.served, write_backs=int(self.step_dev.item()))
+        if self.role == "learner":
+            d.update(train_count=self.local.train_count, loss=float(self.local.loss.item()) if self.trained else None)
+        return d

@@ -709,6 +709,20 @@ def cpu_baseline(args, cfg):
             t = time.perf_counter() - t
         if best is None or t < best:
             best, cores = t, th
+    # ... and the one that makes the learner's batched passes (B n rows) fastest: the two phases get their own setting
+    probe_l = torch.rand(B * n, W, 84, 84)
+    best_l, cores_l = None, 1
+    for th in sorted({1, 4, 8, 16, 32, min(64, host_cores), host_cores}):
+        if th > host_cores:
+            continue
+        torch.set_num_threads(th)
+        with torch.no_grad():
+            q_on(probe_l, channels_first=True)
+            t = time.perf_counter()
+            q_on(probe_l, channels_first=True)
+            t = time.perf_counter() - t
+        if best_l is None or t < best_l:
+            best_l, cores_l = t, th
     torch.set_num_threads(cores)
     cap = args.capacity  # the stated workload: 1M leaves, depth 20
     per = OraclePER(cap, cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, True, cfg.memory_epsilon)
@@ -723,9 +737,12 @@ def cpu_baseline(args, cfg):
     store.reset_all(rng.integers(0, 256, (1, 84 * 84), dtype=np.uint8))
     ratio = max(1, args.envs // max(1, args.updates))  # env steps per learner update, same as the GPU run
     env_steps = updates = 0
+    t_actor = t_learner = 0.0
     t0 = time.perf_counter()
     deadline = t0 + args.cpu_seconds
     while time.perf_counter() < deadline:
+        ta = time.perf_counter()
+        torch.set_num_threads(cores)
         for _ in range(ratio):
             s = store.stack_current().reshape(1, W, 84, 84)
             with torch.no_grad():
@@ -737,7 +754,12 @@ def cpu_baseline(args, cfg):
             env_steps += 1
             if time.perf_counter() >= deadline:
                 break
-        # one learner update
+        t_actor += time.perf_counter() - ta
+        if updates >= 2 and time.perf_counter() >= deadline:
+            break
+        # one learner update (at least two are timed even when the actor phase used up the budget: the learner-only figure below needs them)
+        tl = time.perf_counter()
+        torch.set_num_threads(cores_l)
         _, idx, w, _ = per.sample(B, updates, rng.random(B + 8))
         valid_q = rng.integers(8, max(9, store.pos - n - 1), B)
         items = [store.gather_item(0, int(q_)) for q_ in valid_q]
@@ -760,12 +782,17 @@ def cpu_baseline(args, cfg):
         opt.step()
         per.update(idx, np.abs(target - qsel.detach().numpy()).astype(np.float32))
         updates += 1
+        t_learner += time.perf_counter() - tl
     el = time.perf_counter() - t0
     return {
         "value": env_steps / el,
         "unit": "env-steps/s",
         "learner_updates_per_s": updates / el,
-        "cores": cores,
+        "cores": max(cores, cores_l),
+        "threads": {"actor_batch1_inference": cores, "learner_batched_passes": cores_l, "host_cores": host_cores,
+                    "how": "torch intra-op threads, probed per phase (fastest of 1 / 4 / 8 / 16 / 32 / 64 / all)"},
+        "actor_only": {"env_steps_per_s": env_steps / t_actor if t_actor > 0 else None},
+        "learner_only": {"updates_per_s": updates / t_learner if t_learner > 0 else None, "ms_per_update": 1e3 * t_learner / updates if updates else None},
         "kind": "port",
         "sample": f"{env_steps} sequential env-steps (1 env, batch-1 inference) + {updates} learner updates (B={B}, n={n}) in {el:.1f}s, "
         f"{ratio} env-steps per update as in the GPU run; PER capacity {cap}",

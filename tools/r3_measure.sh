@@ -46,3 +46,12 @@ cd $R
 # the PMC file the bench line cites must be the one measured on THIS build
 mkdir -p profiles; cp gpurun_out/r3_pmc_traffic.json profiles/r3_pmc_traffic.json
 timeout 600 python bench.py > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.err; tail -c 1500 gpurun_out/r3_bench.json; echo
+# the other bench lines of the round and the replay-determinism check
+timeout 300 python bench.py --algo ppo --steps 20 > gpurun_out/r3_bench_ppo.json 2>/dev/null; python -c "import json;d=json.loads(open('gpurun_out/r3_bench_ppo.json').read().strip().splitlines()[-1]);print('ppo', round(d['value']), d['ms_per_step'], d['learner_updates_per_s'])"
+timeout 500 python bench.py --algo agent57_light --envs 1024 --capacity 200000 --steps 4 --inner 16 --warmup 1 > gpurun_out/r3_bench_agent57_light.json 2>/dev/null; python -c "import json;d=json.loads(open('gpurun_out/r3_bench_agent57_light.json').read().strip().splitlines()[-1]);print('agent57_light', round(d['value']), d['ms_per_lock_step'], d['learner_updates_per_s'])"
+timeout 400 python bench.py --noisy --no-cpu-baseline --no-per-micro > gpurun_out/r3_bench_noisy.json 2>/dev/null; python -c "import json;d=json.loads(open('gpurun_out/r3_bench_noisy.json').read().strip().splitlines()[-1]);print('noisy', round(d['value']), d['ms_per_lock_step'], d['learner_updates_per_s'])"
+timeout 900 python tools/graph_replay_check.py 2>&1 | grep -v "amdgpu\|Warning\|detach\|benchmark_limit" > gpurun_out/r3_graph_replay_check.txt; cat gpurun_out/r3_graph_replay_check.txt
+timeout 300 python tools/ppo_replay_bisect.py 2>&1 | grep -v amdgpu > gpurun_out/r3_ppo_replay_bisect.txt; cat gpurun_out/r3_ppo_replay_bisect.txt
+python tools/fused_phases.py 2>&1 | tail -10 > gpurun_out/r3_fused_phases.txt; cat gpurun_out/r3_fused_phases.txt
+(python tools/qnet_accuracy.py; SRLX_CONV1_F32=1 SRLX_CONV23_F32=1 SRLX_FC1_F32=1 python tools/qnet_accuracy.py) 2>&1 | grep -v amdgpu > gpurun_out/r3_qnet_accuracy.txt; cat gpurun_out/r3_qnet_accuracy.txt
+bash tools/_trace_loop.sh > gpurun_out/r3_loop_timeline.txt 2>&1; head -3 gpurun_out/r3_loop_timeline.txt

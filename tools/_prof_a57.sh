@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 E=${1:-16}
 rm -rf /tmp/profa
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profa -- python $R/bench.py --algo agent57_light --envs $E --capacity 20000 --steps 6 --inner 16 --warmup 1 > /tmp/a57.json 2>/dev/null
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profa -- python $R/bench.py --algo agent57_light --envs $E --capacity ${2:-20000} --steps 6 --inner 16 --warmup 1 > /tmp/a57.json 2>/dev/null
 python $R/tools/kstats.py /tmp/profa 40
 python - <<'PY'
 import csv, glob

@@ -560,7 +560,7 @@ def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0):
     pipe = lambda b16, k: ("bf16 pipe, %d exact partial products per multiply-add" % k) if b16 else "f32 pipe (v_mfma_f32_32x32x2_f32)"  # noqa: E731
     fc1_planes = bool(getattr(local.inf_actor, "_planes", False))
     fc1_alg_bytes = (E * flat * 6 + 2 * cfg.hidden_units * flat * 6 if fc1_planes else E * flat * 4 + 2 * cfg.hidden_units * flat * 4) + 4 * E * 2 * cfg.hidden_units * 4 if flat else None
-    fc1_traffic = _pmc_traffic("fc1")
+    fc1_traffic = _pmc_traffic("fc1" if fc1_planes else "k_gemm_s16")
     fc1 = None
     if fc1_ms > 0.0 and flat:
         fc1 = {

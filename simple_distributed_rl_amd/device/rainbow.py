@@ -156,9 +156,14 @@ class RainbowEngine:
             self.q_actor = self.q_online
         # one inference handle per concurrent user (each owns its activation buffers and, for noisy layers, its noise stream)
         self.inf_actor = QNetInference(self.q_actor, E, device, noise_seed=cfg.seed * 3 + 0xA11CE)
-        if not self.noisy and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0 and os.environ.get("SRLX_NO_FC1_PLANES", "0") != "1":
-            # chip-filling policy passes: the first dense layer on pre-split bf16 operand planes (srlx_fc1_planes.hip); with overlap the actor's
-            # private copy changes only in refresh_actor_copy, which also writes the planes (SRLX_NO_FC1_PLANES=1: A/B switch for measurements)
+        planes = os.environ.get("SRLX_FC1_PLANES", "auto")
+        if not self.noisy and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0 and (planes == "1" or (planes == "auto" and not overlap)):
+            # Chip-filling policy passes with the first dense layer on pre-split bf16 operand planes (srlx_fc1_planes.hip): the GEMM itself is 1.6x faster
+            # (85 against 137 us at 1024 rows), but beside a learner it LOSES: same-box A/B (tools/_ab_lockstep.sh) 0.565 against 0.511 ms per lock-step --
+            # the refresh of the actors' copy also has to split the 32 MB weight (22 us on the serial tail every lock-step) and the planes kernel's 144 KB /
+            # 512-thread workgroups keep the learner's dependent kernels waiting for compute units like the convolution kernel does.  So: on for an engine
+            # that only acts (no update shares the GPU: the actor ranks of device/dist.py), off when actors and learner overlap on one GPU.  SRLX_FC1_PLANES=1 / 0
+            # forces it.
             self.inf_actor.enable_fc1_planes(private_weights=self.q_actor is not self.q_online)
         self.inf_online = QNetInference(self.q_online, max(B * (n + 1), 64), device, noise_seed=cfg.seed * 3 + 0x0B0E)
         self.inf_target = QNetInference(self.q_target, B * n, device, noise_seed=cfg.seed * 3 + 0x7A26)

@@ -14,7 +14,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 torch.manual_seed(0)
 online, actor = EngineQNet(6).cuda(), EngineQNet(6).cuda()
 qn = QNetInference(actor, E)
-if os.environ.get("SRLX_NO_FC1_PLANES", "0") != "1":
+if os.environ.get("SRLX_FC1_PLANES", "0") == "1":  # default: the configuration the engine ships beside a learner (operands split while staging)
     qn.enable_fc1_planes(private_weights=True)
 F = 84 * 84
 g = torch.Generator(device="cuda").manual_seed(1)

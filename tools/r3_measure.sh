@@ -27,7 +27,7 @@ def mean_counter(d, counter, prefix):
                 vals.append(float(r["Counter_Value"]))
     vals = vals[len(vals) // 4:]  # drop the warm-up launches
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
-for key, prefix in (("k_convnet_fused", "k_convnet_fused<true"), ("fc1", "k_fc1_planes"), ("k_gemm_s16", "k_gemm_s16<"), ("k_split_planes", "k_split_planes"), ("k_head", "k_head")):
+for key, prefix in (("k_convnet_fused", "k_convnet_fused<true"), ("fc1", "k_fc1_planes"), ("k_gemm_s16", "k_gemm_s16<APlain"), ("k_split_planes", "k_split_planes"), ("k_head", "k_head")):
     fe, nf = mean_counter("/tmp/pmc_f", "FETCH_SIZE", prefix)
     wr, nw = mean_counter("/tmp/pmc_w", "WRITE_SIZE", prefix)
     if fe is None or wr is None:

@@ -243,8 +243,8 @@ def main():
             "actor_learner_overlap": (not args.no_overlap) if dist is None else True,
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "backend": "none" if dist is None else args.backend,
-            "topology": "1 GPU: actor+learner" if dist is None else (f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, RCCL gather/broadcast" if eng.learner_acts
-                         else f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology), RCCL gather/broadcast"),
+            "topology": "1 GPU: actor+learner" if dist is None else (f"{world} GPUs: rank0 learner+actor, {world - 1} actor ranks, grouped send/recv push + flat broadcast" if eng.learner_acts
+                         else f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology), grouped send/recv push + flat broadcast"),
             "actor_gpus": actor_ranks,
         },
         "roofline": roofline(eng, ev_ms, conv_ms, fc1_ms),

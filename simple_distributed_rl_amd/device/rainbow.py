@@ -149,7 +149,7 @@ class RainbowEngine:
             self.q_actor = make_net()
             self.q_actor.load_state_dict(self.q_online.state_dict())
             # high priority: the learner's many small kernels slot in between the actor's chip-filling GEMMs
-            self.s_learner = torch.cuda.Stream(device=self.dev, priority=-1)
+            self.s_learner = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("SRLX_LEARNER_PRIO", "-1")))
             self._ev_fork = torch.cuda.Event()
             self._ev_join = torch.cuda.Event()
         else:

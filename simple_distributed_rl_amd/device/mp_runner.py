@@ -38,9 +38,18 @@ def _device_index(name: str, default: int = 0) -> int:
     return default
 
 
-def plan_ranks(learner_device: str, actor_num: int, actor_devices) -> dict:
-    """Which GPU every rank drives.  rank 0 = learner.  Returns dict(devices=[gpu index per rank], learner_acts, backend)."""
+def plan_ranks(learner_device: str, actor_num: int, actor_devices, memory_device=None) -> dict:
+    """Which GPU every rank drives.  rank 0 = learner.  Returns dict(devices=[gpu index per rank], learner_acts, backend).
+    memory_device: the reference's THREE-role topology (play_mp_memory.py) -- rank 1 is a replay GPU, ranks 2.. act, nobody else does."""
     n_gpu = max(1, torch.cuda.device_count())
+    if memory_device is not None:
+        if isinstance(actor_devices, str):
+            used = {_device_index(learner_device), _device_index(memory_device)}
+            free = [g for g in range(n_gpu) if g not in used] or [_device_index(learner_device)]
+            actor_devices = [f"cuda:{free[i % len(free)]}" for i in range(actor_num)] if actor_devices.upper() in ("AUTO", "GPU", "CUDA") else [actor_devices] * actor_num
+        ranks = [_device_index(learner_device), _device_index(memory_device)] + [_device_index(d) for d in actor_devices]
+        assert len(ranks) == actor_num + 2, "one device per actor"
+        return dict(devices=ranks, learner_acts=False, backend="nccl" if len(set(ranks)) == len(ranks) else "gloo", replay_role=True)
     if isinstance(actor_devices, str):
         if actor_devices.upper() in ("AUTO", "GPU", "CUDA"):
             # spread the actors over the GPUs that are not the learner's; with a single GPU everybody shares it
@@ -111,6 +120,11 @@ def _make_engine(kind: str, cfg, device: int, plan: dict, env_spec: dict, opts: 
     """The rank's distributed engine: DistributedRainbow (cfg = RainbowDeviceConfig) or DistributedAgent57Light (cfg = the set-up rl_config)."""
     from simple_distributed_rl_amd.device import dist as D
 
+    if plan.get("replay_role"):
+        from simple_distributed_rl_amd.device.replay_role import ReplayRoleRainbow
+
+        assert kind == "rainbow", "the replay-GPU topology serves the Rainbow family"
+        return ReplayRoleRainbow(cfg, device, sync_interval=opts["sync_interval_steps"], prefetch=opts.get("prefetch", 5), updates=opts["updates_per_step"], env=_env_factory(env_spec))
     if kind == "agent57_light":
         if not cfg.is_setup():
             from simple_distributed_rl_amd.base.env.registration import make as make_env_run
@@ -126,7 +140,10 @@ def _actor_rank_main(rank: int, world: int, port: int, plan: dict, kind: str, cf
     dist = _init_group(rank, world, port, plan["backend"], plan["devices"][rank])
     try:
         eng = _make_engine(kind, cfg, plan["devices"][rank], plan, env_spec, opts)
-        eng.bus.broadcast_params(eng.flat)  # the weights the learner rank started from (runner.parameter)
+        if plan.get("replay_role"):
+            eng.broadcast_weights()
+        else:
+            eng.bus.broadcast_params(eng.flat)  # the weights the learner rank started from (runner.parameter)
         _JobLoop(eng, plan["backend"], opts["updates_per_step"], opts["check_every"]).run(lambda: False)
     finally:
         dist.destroy_process_group()
@@ -152,17 +169,19 @@ def _env_factory(env_spec: dict):
 
 
 def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, actor_devices, updates_per_step: int = 1,
-                       sync_interval_steps: int = 16, check_every: int = 16) -> RunStateTrainer:
+                       sync_interval_steps: int = 16, check_every: int = 16, memory_device=None, prefetch: int = 5) -> RunStateTrainer:
+    """memory_device (e.g. "cuda:1"): the reference's three-role topology with the replay on a GPU of its own (device/replay_role.py); default: the
+    learner rank owns the replay (device/dist.py)."""
     from simple_distributed_rl_amd.device import vector_runner as vr
 
     context.check_context_parameter()
-    plan = plan_ranks(context.used_device_torch, actor_num, actor_devices)
+    plan = plan_ranks(context.used_device_torch, actor_num, actor_devices, memory_device)
     world = len(plan["devices"])
     seed = 0 if context.seed is None else int(context.seed)
     kind = vr.engine_kind(runner.rl_config)
     cfg = runner.rl_config if kind == "agent57_light" else vr.device_config_from(runner.rl_config, runner.make_env(), lanes, seed)
     env_spec = dict(env_config=runner.env_config, seed=context.seed, processor=vr.frame_processor(runner.rl_config))
-    opts = dict(updates_per_step=updates_per_step, sync_interval_steps=sync_interval_steps, check_every=check_every, lanes=lanes)
+    opts = dict(updates_per_step=updates_per_step, sync_interval_steps=sync_interval_steps, check_every=check_every, lanes=lanes, prefetch=prefetch)
     port = _free_port()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = None
@@ -177,8 +196,11 @@ def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, 
         eng = _make_engine(kind, cfg, plan["devices"][0], plan, env_spec, opts, parameter=parameter)  # agent57_light trains `parameter` in place
         if kind == "rainbow":
             _load_reference_weights(eng, parameter)
-        eng.bus.broadcast_params(eng.flat)
-        state.parameter, state.memory, state.trainer = parameter, vr._ReplayFacade(eng.replay), eng
+        if plan.get("replay_role"):
+            eng.broadcast_weights()
+        else:
+            eng.bus.broadcast_params(eng.flat)
+        state.parameter, state.memory, state.trainer = parameter, (vr._ReplayFacade(eng.replay) if eng.replay is not None else None), eng
         hooks.fire("on_start")
         hooks.fire("on_trainer_start")
         state.elapsed_t0 = time.time()

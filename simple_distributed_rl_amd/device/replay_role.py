@@ -156,8 +156,21 @@ class ReplayRoleRainbow:
         src = t.cpu() if self.staged else t
         return dist.isend(src, dst), src
 
+    # ---- the driver interface of device/mp_runner.py (what DistributedRainbow offers) ------------------------------------------------------
+    @property
+    def global_envs(self) -> int:
+        return self.n_actor_ranks * self.cfg.n_envs
+
+    def broadcast_weights(self):
+        """learner -> actors now (mp_runner: after the learner rank has loaded the Runner's parameter)."""
+        if self.role != "replay":
+            self._broadcast_weights()
+
+    def flush(self):
+        self.finish()
+
     # ---- one lock-step ----------------------------------------------------------------------------------------------------------
-    def step(self):
+    def step(self, updates=None):
         getattr(self, "_step_" + self.role)()
         self.step_count += 1
         if self.step_count % self.sync_interval == 0 and self.role != "replay":

@@ -92,3 +92,42 @@ def test_three_roles_actors_replay_learner():
     # they moved away from the initialisation on every rank that acts or learns
     assert learner["weights_moved"] and all(a["weights_moved"] for a in actors)
     assert actors[0]["weights_sum"] == actors[1]["weights_sum"]
+
+
+def test_runner_train_mp_with_a_replay_gpu():
+    """`Runner.train_mp(actor_num, actor_devices=[...], memory_device="cuda:k")`: the reference's enable_mp_memory topology on the device path -- this
+    process is the learner rank, rank 1 the replay GPU, the actors ranks 2.. (here all four ranks time-share the test GPU over gloo).  Trainer-side
+    hooks fire, the stop rule is max_train_count, the trained weights come back into runner.parameter."""
+    import simple_distributed_rl_amd as srl
+    from simple_distributed_rl_amd.algorithms import rainbow
+    from simple_distributed_rl_amd.base.run.callback import RunCallback
+
+    cfg = rainbow.Config()
+    cfg.set_atari_config()
+    cfg.enable_noisy_dense = False
+    cfg.window_length = 4
+    cfg.memory.capacity, cfg.memory.warmup_size = 2 * 16 * 40, 64
+    cfg.hidden_block.set_dueling_network((32,))
+    cfg.batch_size = 8
+    runner = srl.Runner(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(84, 84), n_actions=4, episode_len=7)), cfg)
+    runner.set_vector_envs(16)
+    before = {k: v.detach().clone().cpu() for k, v in runner.parameter.q_online.state_dict().items()}
+    seen = []
+
+    class TCB(RunCallback):
+        def on_trainer_start(self, context, state, **kw):
+            seen.append("start")
+
+        def on_train_after(self, context, state, **kw):
+            seen.append(state.train_count)
+
+        def on_trainer_end(self, context, state, **kw):
+            seen.append("end")
+
+    st = runner.train_mp(actor_num=2, actor_devices=["cuda:0", "cuda:0"], memory_device="cuda:0", max_train_count=20, timeout=300, callbacks=[TCB()],
+                         sync_interval_steps=4, mem_to_train_queue_capacity=2)
+    assert runner.vector_reason == ""
+    assert st.end_reason == "max_train_count over." and 20 <= st.train_count < 20 + 16
+    assert seen[0] == "start" and seen[-1] == "end" and seen[-2] == st.train_count
+    after = runner.parameter.q_online.state_dict()
+    assert any(not torch.equal(before[k], after[k].cpu()) for k in before)

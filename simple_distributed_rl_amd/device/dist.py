@@ -21,6 +21,7 @@ step at E=1024, far below the ~153 GB/s per link), the broadcast is a 32 MB fan-
 `TransitionBus` only needs torch.distributed and tensors, so its protocol is tested on CPU with gloo
 (tests/test_dist_cpu.py); the kernels around it are tested on the GPU.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -51,7 +52,7 @@ class TransitionBus:
         self.is_learner = self.rank == learner_rank
         self.actor_ranks = list(range(self.world)) if actor_ranks is None else [int(r) for r in actor_ranks]
         self.contributes = self.rank in self.actor_ranks
-        self.p2p = (self.world > 1) if p2p is None else bool(p2p)
+        self.p2p = ((self.world > 1) and os.environ.get("SRLX_BUS_GATHER", "0") != "1") if p2p is None else bool(p2p)  # SRLX_BUS_GATHER=1: the gather collective (A/B, debugging)
         self.sent_bytes = self.recv_bytes = 0  # what this rank put on / took off the wire (tests: a learner-only rank sends nothing)
         self._pending, self._direct, self._keep, self._staged_in = [], None, None, []
         if self.is_learner:

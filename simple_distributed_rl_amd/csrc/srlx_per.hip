@@ -685,6 +685,7 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
     double *red = s_chg + n;                                    // blockDim doubles
     i64 *s_idx = reinterpret_cast<i64 *>(red + blockDim.x);     // n
     int *s_dep = reinterpret_cast<int *>(s_idx + n);            // n
+    int *s_shared = s_dep + n;                                  // n: depth of the deepest node index i shares with ANY other index of the call (-1: none)
     const int t = threadIdx.x, T = blockDim.x;
     const double maxp0 = state->max_priority;
 
@@ -699,7 +700,23 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
         s_p[i] = p;
         s_idx[i] = x;
         s_dep[i] = node_depth(x);
+        s_shared[i] = -1;
         pmax = fmax(pmax, p);
+    }
+    __syncthreads();
+    // Where do the indices' root paths meet?  Below the deepest node it shares with any other index, an index is the ONLY contributor of its ancestors
+    // (14 of the 20 levels of a 64-index call on a 1M-leaf tree), and an index that shares nothing at its own depth has no duplicate: those cases need
+    // neither the ownership scan nor the ordered replay below -- O(n) LDS look-ups per task, which is where a call's time went (ablation at 32 / 64 /
+    // 128 indices: 11.7 / 24.2 / 53.1 us with the scans, 7.9 / 11.6 / 16.8 us without).  n^2 / 2 pair tests, once: depth of the lowest common ancestor
+    // of (i, j) from the heap indices aligned to the shallower one.
+    for (i64 pair = t; pair < n * n; pair += T) {
+        const i64 i = pair / n, j = pair % n;
+        if (i >= j) continue;
+        const int di = s_dep[i], dj = s_dep[j], dm = di < dj ? di : dj;
+        const u64 u = (u64)(s_idx[i] + 1) >> (di - dm), v = (u64)(s_idx[j] + 1) >> (dj - dm);
+        const int lca = u == v ? dm : dm - (64 - __clzll(u ^ v));
+        atomicMax(&s_shared[i], lca);
+        atomicMax(&s_shared[j], lca);
     }
     __syncthreads();
 
@@ -708,14 +725,16 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
     for (i64 i = t; i < n; i += T, q++) {
         const i64 x = s_idx[i];
         i64 prev = -1;
-        for (i64 j = 0; j < i; j++)
-            if (s_idx[j] == x) prev = j;
         bool last = true;
-        for (i64 j = i + 1; j < n; j++)
-            if (s_idx[j] == x) {
-                last = false;
-                break;
-            }
+        if (s_shared[i] >= s_dep[i]) {  // somebody shares this very node: look for duplicates of the index
+            for (i64 j = 0; j < i; j++)
+                if (s_idx[j] == x) prev = j;
+            for (i64 j = i + 1; j < n; j++)
+                if (s_idx[j] == x) {
+                    last = false;
+                    break;
+                }
+        }
         const double before = prev >= 0 ? s_p[prev] : tr.get(x);
         s_chg[i] = s_p[i] - before;  // :83
         last_me[q] = last;
@@ -730,24 +749,29 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
     int maxd = tr.D;
     const i64 tasks = n * (i64)maxd;
     for (i64 task = t; task < tasks; task += T) {
-        const i64 i = task / maxd;
-        const int k = (int)(task % maxd) + 1;
+        const i64 i = task % n;  // level-major: a wave's lanes sit on the same few levels, so whole waves (the deep levels) skip the scans
+        const int k = (int)(task / n) + 1;
         const int dx = s_dep[i];
         if (k > dx) continue;
         const int da = dx - k;
         const i64 a = ((s_idx[i] + 1) >> k) - 1;
+        const bool alone = da > s_shared[i];  // nobody else's path passes through this node
         bool owner = true;
-        for (i64 j = 0; j < i; j++)
-            if (is_ancestor(a, da, s_idx[j], s_dep[j])) {
-                owner = false;
-                break;
-            }
+        if (!alone) {  // no early exit: with a `break` every iteration waits for its own LDS loads (~150 clocks each, serial); unrolled, eight travel together
+#pragma unroll 8
+            for (i64 j = 0; j < i; j++) owner &= !is_ancestor(a, da, s_idx[j], s_dep[j]);
+        }
         if (!owner) continue;
         const i64 pa = tr.phys(a);
         double v = tr.T[pa];
         v += s_chg[i];
-        for (i64 j = i + 1; j < n; j++)
-            if (is_ancestor(a, da, s_idx[j], s_dep[j])) v += s_chg[j];
+        if (!alone) {
+#pragma unroll 8
+            for (i64 j = i + 1; j < n; j++) {
+                const double c = s_chg[j];
+                if (is_ancestor(a, da, s_idx[j], s_dep[j])) v += c;
+            }
+        }
         tr.T[pa] = v;
     }
 
@@ -1004,7 +1028,7 @@ int launch_update(srlx_per *h, i64 n, const i64 *d_idx, const void *d_prio, int 
         const i64 m = (n - off < kUpdateChunk) ? n - off : kUpdateChunk;
         // one thread per (index, ancestor) task where that fits: the B = 32 learner call is 640 tasks, one round at 1024 threads
         const int threads = m * (i64)h->tree.D > kWgUpdate ? 1024 : kWgUpdate;
-        const size_t lds = (size_t)m * (8 + 8 + 8 + 4) + (size_t)threads * 8 + 16;
+        const size_t lds = (size_t)m * (8 + 8 + 8 + 4 + 4) + (size_t)threads * 8 + 16;
         hipLaunchKernelGGL(k_update_wg, dim3(1), dim3(threads), lds, st, h->tree, h->d_state, m,
                            d_idx + off, (const void *)((const char *)d_prio + (size_t)off * eb), kind, h->epsilon,
                            h->alpha, h->d_err, off + m >= n ? h->d_update_counter : nullptr);

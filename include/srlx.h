@@ -129,6 +129,9 @@ int srlx_per_restore_resized(srlx_per_t *h, int64_t old_capacity, int64_t old_si
  * csrc/srlx_per.hip struct Tree); n_doubles = allocated doubles.  Use backup() for heap order. */
 int srlx_per_tree_ptr(srlx_per_t *h, void **d_tree, int64_t *n_doubles);
 /* device struct { double max_priority; int64 size; int64 write; int64 pad; } */
+/* *d_out (device double) = max_priority as of this point of the stream: what `add(batch, None)` would use (proportional_memory.py:121-122) -- for callers that
+ * assemble final priorities themselves (the engines' actor-side initial priorities, rainbow.py:389-398) and add them as SRLX_PRIO_RAW. */
+int srlx_per_max_priority(srlx_per_t *h, double *d_out, void *stream);
 int srlx_per_state_ptr(srlx_per_t *h, void **d_state);
 /* re-read size/write from the device after HIP-graph replays that contained adds */
 int srlx_per_refresh(srlx_per_t *h, void *stream);

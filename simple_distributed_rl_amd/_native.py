@@ -60,6 +60,7 @@ SIGNATURES = {
     "srlx_per_restore": (c_int, [c_p, c_f64, c_i64, c_i64, c_p]),
     "srlx_per_restore_resized": (c_int, [c_p, c_i64, c_i64, c_p]),
     "srlx_per_tree_ptr": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_i64)]),
+    "srlx_per_max_priority": (c_int, [c_p, c_p, c_p]),
     "srlx_per_state_ptr": (c_int, [c_p, ctypes.POINTER(c_p)]),
     "srlx_per_refresh": (c_int, [c_p, c_p]),
     "srlx_rng_uniform": (c_int, [ctypes.c_uint64, c_p, c_i64, c_p, c_p]),

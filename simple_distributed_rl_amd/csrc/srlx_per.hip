@@ -1433,6 +1433,14 @@ int srlx_per_tree_ptr(srlx_per_t *h, void **d_tree, int64_t *tree_len) {
     return SRLX_OK;
 }
 
+int srlx_per_max_priority(srlx_per_t *h, double *d_out, void *stream) {
+    SRLX_REQUIRE(h && d_out, "per_max_priority: NULL argument");
+    srlx::DeviceGuard guard(h->device);
+    hipLaunchKernelGGL(k_snapshot_max, dim3(1), dim3(1), 0, pick_stream(h, stream), h->d_state, d_out);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
 int srlx_per_state_ptr(srlx_per_t *h, void **d_state) {
     SRLX_REQUIRE(h && d_state, "per_state_ptr: NULL argument");
     *d_state = h->d_state;

@@ -48,6 +48,7 @@ class RainbowDeviceConfig:
     memory_beta_initial: float = 0.4
     memory_beta_steps: int = 1_000_000
     memory_epsilon: float = 0.0001
+    actor_initial_priority: bool = False  # rainbow.py:389-398: new items enter the tree with |n-step target - Q(s_0, a_0)| estimated on the actor side instead of max_priority
     memory_has_duplicate: bool = True  # False: a batch never holds an item twice (the uniform ReplayBuffer's random.sample; has_duplicate=False of the proportional memory)
     # --- model (set_dqn_block + dueling (512,))
     hidden_units: int = 512
@@ -177,6 +178,27 @@ class RainbowEngine:
             self.optimizer = DeviceAdam(self.inf_online._params(), lr=cfg.lr)  # model_torch.py:71 as one libsrlx launch over all parameter tensors
         else:
             self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True, fused=True)
+        # ---- actor-side initial priorities (cfg.actor_initial_priority; the reference's distributed worker, rainbow.py:389-398) ----
+        # The Q rows of the last n + 1 acting passes are kept; one lock-step after an item was committed -- its last state s_n has then been evaluated by
+        # the pass that acts on it -- the existing fused TD kernel turns the cached rows + the item's stored actions / rewards into |target - Q(s_0, a_0)|,
+        # and the item's leaf is ADDED then (the add of a lock-step is deferred by one) with (|td| + eps)^alpha.  The cached online rows stand in for the
+        # target network too (an actor holds no target network here; equal right after a target sync) and are as old as the pass that produced them
+        # (the reference re-evaluates all n + 1 states under the current weights: identical while the weights stand still, tests/test_engine_gpu.py).
+        # Items whose window touches an episode end keep max_priority: the state after a terminal / truncated step is never evaluated by an actor.
+        self.actor_priority = bool(cfg.actor_initial_priority) and self.mfma
+        if self.actor_priority:
+            n1, W = cfg.multisteps + 1, cfg.window_length
+            d = self.dev
+            self.q_hist = torch.zeros((n1, E, cfg.n_actions), dtype=torch.float32, device=d)
+            self.done_hist = torch.ones((n1, E), dtype=torch.uint8, device=d)  # "an episode end" until n real commits have been seen
+            self._passes, self._ap_first_slot = 0, None
+            self._ap = dict(idx=torch.zeros(E, dtype=torch.int64, device=d), off_all=torch.zeros((E, n1, W), dtype=torch.int64, device=d),
+                            off_next=torch.zeros((E, n1 - 1, W), dtype=torch.int64, device=d), actions=torch.zeros((E, n1 - 1), dtype=torch.int32, device=d),
+                            rewards=torch.zeros((E, n1 - 1), dtype=torch.float32, device=d), terminated=torch.zeros((E, n1 - 1), dtype=torch.float32, device=d),
+                            target=torch.zeros(E, dtype=torch.float32, device=d), loss=torch.zeros(1, dtype=torch.float32, device=d),
+                            grad=torch.zeros((E, cfg.n_actions), dtype=torch.float32, device=d), pri=torch.zeros(E, dtype=torch.float32, device=d),
+                            ones=torch.ones(E, dtype=torch.float32, device=d), maxp=torch.zeros(1, dtype=torch.float64, device=d),
+                            mask=torch.zeros(E, dtype=torch.uint8, device=d), lanes=torch.arange(E, dtype=torch.int64, device=d))
         self._select_graph = None
         self._commit_graph = None
         d = self.dev
@@ -230,7 +252,33 @@ class RainbowEngine:
         e = self.env
         if self.ledger is not None:  # before the commit: the store's needs_reset view still marks the lanes that only received a first frame
             self.ledger.account(e.rewards, e.done, self.replay.needs_reset_ptr)
-        self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs)
+        self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs, defer_add=self.actor_priority)
+
+    def _add_with_actor_priorities(self):
+        """The deferred PER add of the PREVIOUS lock-step's items with actor-side initial priorities (see __init__).  Call after this lock-step's network pass
+        and after the learner has been joined (it writes the tree)."""
+        if self._ap_first_slot is None:
+            return
+        cfg, r, a = self.cfg, self.replay, self._ap
+        E, n, A = cfg.n_envs, cfg.multisteps, cfg.n_actions
+        n1, T = n + 1, self._passes  # pass T has just been stored; the items were committed at lock-step T - 1: states s_{T-n} .. s_T
+        order = [(T - n + k) % n1 for k in range(n1)]
+        q = self.q_hist[order].permute(1, 0, 2).contiguous()  # [E][n + 1][A]
+        q0, qn = q[:, 0].contiguous(), q[:, 1:].contiguous()
+        a["idx"].copy_((a["lanes"] + self._ap_first_slot) % r.capacity + (r.capacity - 1))
+        st = N.torch_stream_ptr()
+        N.check(self.lib.srlx_store_gather_train(r.h_store, E, N.tptr(a["idx"]), N.tptr(a["off_all"]), N.tptr(a["off_next"]), N.tptr(a["actions"]), N.tptr(a["rewards"]),
+                                                 N.tptr(a["terminated"]), st))
+        N.check(self.lib.srlx_nstep_td_huber_priority(E, n, A, N.tptr(qn), N.tptr(qn), N.tptr(q0), N.tptr(a["actions"]), N.tptr(a["rewards"]), N.tptr(a["terminated"]), None,
+                                                      N.tptr(a["ones"]), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
+                                                      N.tptr(a["target"]), N.tptr(a["loss"]), N.tptr(a["grad"]), N.tptr(a["pri"]), st))
+        r.max_priority_into(a["maxp"])
+        # commits T-n .. T-1 hold the item's n transitions (slots (T-n+k) % (n+1), k = 0..n-1 of done_hist); an episode end inside -> max_priority
+        inside = self.done_hist[[(T - n + k) % n1 for k in range(n)]].sum(dim=0) == 0
+        estimated = (a["pri"].double().abs() + float(cfg.memory_epsilon)) ** float(cfg.memory_alpha)  # the reference's transform on the widened value (:124)
+        raw = torch.where(a["mask"] != 0, torch.where(inside, estimated, a["maxp"].expand(E)), torch.zeros(E, dtype=torch.float64, device=self.dev))
+        r.add_raw(raw.contiguous())
+        self._ap_first_slot = None
 
     def actor_step(self):
         """One eager lock-step of the actors (no graphs, no learner)."""
@@ -394,6 +442,8 @@ class RainbowEngine:
     def actor_front(self, events=None):
         """Network pass + action selection + environments of one lock-step: reads the ring, writes nothing shared."""
         q = self._actor_net(None, events)  # eager launches, bracketed by the events
+        if self.actor_priority:
+            self.q_hist[self._passes % self.q_hist.shape[0]].copy_(q[: self.cfg.n_envs])
         if self._select_graph is not None:
             self._select_graph.replay()
         else:
@@ -406,6 +456,12 @@ class RainbowEngine:
             self.replay._steps_committed += 1
         else:
             self._actor_commit()
+        if self.actor_priority:  # what the deferred add of this lock-step will need
+            r = self.replay
+            self._ap["mask"].copy_(r.item_mask)
+            self.done_hist[self._passes % self.done_hist.shape[0]].copy_(self.env.done)
+            self._ap_first_slot = ((r._steps_committed - 1) * self.cfg.n_envs) % r.capacity
+            self._passes += 1
         self.total_env_steps += self.cfg.n_envs
 
     def step(self, learner_updates: int = 1, events=None):
@@ -417,6 +473,8 @@ class RainbowEngine:
         self.actor_front(events)
         if self.overlap:
             self.join_learner()
+        if self.actor_priority:
+            self._add_with_actor_priorities()
         self.actor_commit()
         if self.overlap:
             self.refresh_actor_copy()

@@ -123,17 +123,27 @@ class DeviceReplay:
         N.check(self.lib.srlx_store_stack_current(self.h_store, N.tptr(self.stacked), N.torch_stream_ptr()))
         return self.stacked
 
-    def commit(self, actions, rewards, terminated, done, next_obs):
+    def commit(self, actions, rewards, terminated, done, next_obs, defer_add: bool = False):
         """One lock-step transition of all E envs + the PER add of the items that became complete
-        (priority=None -> max_priority, proportional_memory.py:121-122; reset positions get 0)."""
+        (priority=None -> max_priority, proportional_memory.py:121-122; reset positions get 0).
+        defer_add: the ring commit only; the caller adds the E leaves later with priorities of its own (`add_raw`; `item_mask` says which lanes completed an item)."""
         st = N.torch_stream_ptr()
         N.check(
             self.lib.srlx_store_commit_step(
                 self.h_store, N.tptr(actions), N.tptr(rewards), N.tptr(terminated), N.tptr(done), N.tptr(next_obs), N.tptr(self.item_mask), st
             )
         )
-        N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(self.item_mask), N.PRIO_NONE_MASKED, 1, st))
+        if not defer_add:
+            N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(self.item_mask), N.PRIO_NONE_MASKED, 1, st))
         self._steps_committed += 1
+
+    def add_raw(self, priorities_f64: torch.Tensor):
+        """The deferred PER add of the last committed lock-step: E final leaf values (already transformed; 0 = no item), float64 on the device."""
+        assert priorities_f64.dtype == torch.float64 and priorities_f64.numel() == self.E
+        N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(priorities_f64), N.PRIO_RAW, 1, N.torch_stream_ptr()))
+
+    def max_priority_into(self, out: torch.Tensor):
+        N.check(self.lib.srlx_per_max_priority(self.h_per, N.tptr(out), N.torch_stream_ptr()))
 
     def length(self) -> int:
         """Items in the tree.  Counted from committed lock-steps (E adds each) rather than the library's

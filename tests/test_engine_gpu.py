@@ -253,3 +253,52 @@ def test_graph_replays_are_bit_stable_without_host_synchronisation():
     assert ca == cb and ca >= 300 and la == lb and torch.equal(ra, rb)
     for x, y in zip(pa, pb):
         assert torch.equal(x, y)
+
+
+def test_actor_side_initial_priorities():
+    """cfg.actor_initial_priority (the reference's distributed worker, rainbow.py:389-398: a new item enters the memory with |n-step target - Q(s_0, a_0)|
+    instead of max_priority).  With the weights standing still the cached Q rows ARE what the reference would re-evaluate, so every leaf added for an item
+    inside an episode equals (|td| + eps)^alpha with td from the oracle's n-step target on the network's own Q-values of the stored states (online rows in
+    both roles: an actor holds no target network); items whose window touches an episode end keep max_priority; positions without an item weigh 0."""
+    import ctypes
+
+    sys.path.insert(0, os.path.join(os.path.abspath(os.path.join(os.path.dirname(__file__), "..")), "oracle"))
+    import hot_path_oracle as H
+    from simple_distributed_rl_amd import _native as N
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+
+    E, n, A = 8, 3, 6
+    cfg = RainbowDeviceConfig(n_envs=E, batch_size=8, memory_capacity=E * 64, memory_warmup_size=1 << 40, actor_initial_priority=True, epsilon=0.3, seed=5)
+    eng = RainbowEngine(cfg, 0, episode_len=17)
+    steps = 50
+    for _ in range(steps):
+        eng.step(learner_updates=0)
+    torch.cuda.synchronize()
+    r = eng.replay
+    cap = r.capacity
+    mp, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+    tree = np.empty(2 * cap - 1)
+    N.check(r.lib.srlx_per_backup(r.h_per, ctypes.byref(mp), ctypes.byref(size), ctypes.byref(write), N.np_ptr(tree)))
+    leaves = tree[cap - 1:]
+    added = (steps - 1) * E  # the last lock-step's add is still deferred
+    assert write.value == added % cap and mp.value == 1.0  # nobody called update(): max_priority is the initial 1.0
+    slots = np.arange(added)
+    idx = torch.tensor(slots + cap - 1, dtype=torch.int64, device="cuda")
+    B = len(slots)
+    obs = torch.zeros((B, n + 1, cfg.window_length, 84 * 84), dtype=torch.float32, device="cuda")
+    act = torch.zeros((B, n), dtype=torch.int32, device="cuda")
+    rew = torch.zeros((B, n), dtype=torch.float32, device="cuda")
+    ter = torch.zeros((B, n), dtype=torch.float32, device="cuda")
+    N.check(r.lib.srlx_store_gather_nstep(r.h_store, B, N.tptr(idx), N.tptr(obs), N.tptr(act), N.tptr(rew), N.tptr(ter), None))
+    with torch.no_grad():
+        q = torch.cat([eng.q_online(obs[k:k + 64].view(-1, cfg.window_length, 84, 84), channels_first=True) for k in range(0, B, 64)]).view(B, n + 1, A).cpu().numpy()
+    want_target = H.nstep_target(q[:, 1:], q[:, 1:], act.cpu().numpy(), rew.cpu().numpy(), ter.cpu().numpy(), None, cfg.discount, cfg.retrace_h, True, False)
+    td = np.abs(want_target - q[np.arange(B), 0, act[:, 0].cpu().numpy()])
+    want = (td.astype(np.float64) + cfg.memory_epsilon) ** cfg.memory_alpha
+    got = leaves[slots]
+    estimated = (got != 0.0) & (got != 1.0)
+    # every lock-step adds E leaves: items inside an episode (estimated), items touching an episode end (max_priority = 1), positions without an item (0)
+    assert estimated.sum() > 0.5 * B and (got == 1.0).sum() > 0 and (got == 0.0).sum() > 0
+    np.testing.assert_allclose(got[estimated], want[estimated], rtol=2e-4, atol=1e-6)
+    # an estimated item never has an episode end inside its window
+    assert float(ter.cpu().numpy()[estimated].sum()) == 0.0

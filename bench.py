@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--learner-acts", choices=("auto", "yes", "no"), default="auto",
                     help="N>1: does the learner rank run actors too? auto = yes below 4 GPUs, no (dedicated learner GPU) from 4")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 code path with several ranks on ONE GPU)")
+    ap.add_argument("--actor-priority", action="store_true", help="actor-side initial priorities (rainbow.py:389-398) instead of max_priority for new items")
     ap.add_argument("--noisy", action="store_true", help="NoisyLinear dense layers (the reference's set_atari_config: enable_noisy_dense=True)")
     ap.add_argument("--algo", choices=("rainbow", "agent57_light", "ppo"), default="rainbow",
                     help="rainbow = BASELINE.json configs[2] (the headline metric); agent57_light = the configs[3] workload (two UVFA Q-networks, NGU "
@@ -125,7 +126,8 @@ def main():
         return bench_agent57_light(args, dev_index, rank, world, dist, envs_per_gpu, actor_ranks, learner_acts)
     if args.algo == "ppo":
         return bench_ppo(args, dev_index, rank, world, dist)
-    cfg = RainbowDeviceConfig(n_envs=envs_per_gpu, batch_size=args.batch_size, memory_capacity=args.capacity, seed=0, enable_noisy_dense=args.noisy)
+    cfg = RainbowDeviceConfig(n_envs=envs_per_gpu, batch_size=args.batch_size, memory_capacity=args.capacity, seed=0, enable_noisy_dense=args.noisy,
+                              actor_initial_priority=args.actor_priority)
 
     if dist is not None:
         from simple_distributed_rl_amd.device.dist import DistributedRainbow

@@ -225,7 +225,14 @@ class DistributedRainbow:
         self.local.inf_online.bind()
         if isinstance(self.local.optimizer, DeviceAdam):
             self.local.optimizer.bind()
-        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective, actor_ranks=range(self.first_actor_rank, self.world))
+        # cfg.actor_initial_priority (rainbow.py:389-398): every actor rank estimates |n-step target - Q(s_0, a_0)| of the items it committed one lock-step earlier from
+        # its cached Q rows (RainbowEngine.actor_td_estimates) and ships the E estimates (-1 = "use max_priority") as one more float field of the packed record;
+        # the learner rank's PER add runs one lock-step behind its ring commit and takes them
+        self.actor_priority = bool(cfg.actor_initial_priority)
+        self._minus_one = torch.full((E, 1), -1.0, dtype=torch.float32, device=self.dev)
+        self._est, self._pending_mask = self._minus_one, None
+        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective, actor_ranks=range(self.first_actor_rank, self.world),
+                                 extra_floats=1 if self.actor_priority else 0)
         self.step_count = 0
         self._in_flight = False  # an exchange started by push_begin and not yet finished
         self.env_steps_local = 0  # environment steps taken by THIS rank's actors
@@ -242,9 +249,11 @@ class DistributedRainbow:
         self.bus.broadcast_params(self.flat)
         # first observations of every env -> global ring position 0
         obs0 = self.local.first_obs  # the frames the local ring was reset with
-        gathered = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, obs0)
+        gathered = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, obs0, self._extra())
         if self.is_learner:
             self.replay.reset_all(self._actor_rows(gathered)[4])
+            if self.actor_priority:
+                self._maxp = torch.zeros(1, dtype=torch.float64, device=self.dev)
 
     def _actor_rows(self, gathered):
         """The staging rows of the actor ranks (a learner-only rank 0 owns row block 0 of the staging buffers and never fills it)."""
@@ -252,6 +261,24 @@ class DistributedRainbow:
             return gathered
         k = self.first_actor_rank * self.cfg.n_envs
         return tuple(t[k:] for t in gathered)
+
+    def _extra(self):
+        return self._est if self.actor_priority else None
+
+    def _commit_global(self, gathered):
+        """Learner rank: the gathered lock-step into the global ring + tree.  With actor-side initial priorities the tree add of the PREVIOUS ring commit happens
+        here (its estimates arrived with this slab), and this slab's add waits for the next one."""
+        rows = self._actor_rows(gathered)
+        if not self.actor_priority:
+            self.replay.commit(*rows[:5])
+            return
+        from simple_distributed_rl_amd.device.rainbow import RainbowEngine
+
+        if self._pending_mask is not None:
+            cfg = self.cfg
+            self.replay.add_raw(RainbowEngine.leaves_from_estimates(self.replay, rows[5].reshape(-1), self._pending_mask, cfg.memory_epsilon, cfg.memory_alpha, self._maxp))
+        self.replay.commit(*rows[:5], defer_add=True)
+        self._pending_mask = self.replay.item_mask.clone()
 
     # the learner's replay is the global one: swap it in around learner calls
     def _with_global_replay(self, fn):
@@ -277,7 +304,7 @@ class DistributedRainbow:
         env = eng.env
         if self.acts:
             self.env_steps_local += self.cfg.n_envs
-        return self.bus.push(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
+        return self.bus.push(eng.actions, env.rewards, env.terminated, env.done, env.next_obs, self._minus_one if self.actor_priority else None)
 
     def step(self, learner_updates: int = 1, events=None):
         """One lock-step of the whole job, software-pipelined over the exchange: the transitions of lock-step t travel
@@ -293,6 +320,9 @@ class DistributedRainbow:
             self._with_global_replay(lambda: eng.fork_learner(learner_updates))
         if self.acts:  # the network pass reads the local ring only: it does not depend on the exchange in flight
             q = eng._actor_net(None, events)
+            if self.actor_priority:  # estimates for the items this rank committed one lock-step ago (their last state has just been evaluated)
+                est = eng.actor_td_estimates()
+                self._est = self._minus_one if est is None else est.view(-1, 1)
         elif events is not None:
             events[0].record()
             events[1].record()
@@ -302,7 +332,7 @@ class DistributedRainbow:
             if self.overlap:
                 eng.join_learner()  # the updates read the replay: they finish before it changes
             if gathered is not None:
-                self.replay.commit(*self._actor_rows(gathered))
+                self._commit_global(gathered)
             if self.overlap:
                 if self.acts:  # this rank's actors act on a private copy of the network: refresh it between two updates
                     eng.refresh_actor_copy()
@@ -317,7 +347,7 @@ class DistributedRainbow:
             eng.actor_commit()  # the local ring (frame stacking of this rank's environments)
             self.env_steps_local += self.cfg.n_envs
         env = eng.env
-        self.bus.push_begin(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
+        self.bus.push_begin(eng.actions, env.rewards, env.terminated, env.done, env.next_obs, self._extra())
         self._in_flight = True
         self.step_count += 1
         if self.step_count % self.sync_interval == 0:
@@ -334,7 +364,7 @@ class DistributedRainbow:
                 if self.overlap:
                     self.local.join_learner()
                 if gathered is not None:
-                    self.replay.commit(*self._actor_rows(gathered))
+                    self._commit_global(gathered)
         if self.is_learner and self.overlap:
             self.local.join_learner()
         torch.cuda.synchronize(self.dev)
@@ -350,7 +380,7 @@ class DistributedRainbow:
         for _ in range(int(t.item())):
             gathered = self.actor_and_push(random_policy=True)
             if self.is_learner:
-                self.replay.commit(*self._actor_rows(gathered))
+                self.replay.commit(*self._actor_rows(gathered)[:5])  # (random-policy filling: no network pass, no estimates -- max_priority)
         if self.is_learner:
             g = torch.Generator(device=self.dev)
             g.manual_seed(self.cfg.seed + 1)

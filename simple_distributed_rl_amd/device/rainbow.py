@@ -237,6 +237,8 @@ class RainbowEngine:
         q = self.inf_actor.forward_u8(self.replay.obs_base, off)
         if events is not None:
             events[1].record()
+        if self.actor_priority:  # the rows the initial priorities are estimated from
+            self.q_hist[self._passes % self.q_hist.shape[0]].copy_(q[: self.cfg.n_envs])
         return q
 
     def _actor_select(self, q):
@@ -254,11 +256,11 @@ class RainbowEngine:
             self.ledger.account(e.rewards, e.done, self.replay.needs_reset_ptr)
         self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs, defer_add=self.actor_priority)
 
-    def _add_with_actor_priorities(self):
-        """The deferred PER add of the PREVIOUS lock-step's items with actor-side initial priorities (see __init__).  Call after this lock-step's network pass
-        and after the learner has been joined (it writes the tree)."""
+    def actor_td_estimates(self):
+        """|n-step target - Q(s_0, a_0)| of the items the PREVIOUS lock-step committed, float32 [E], from the cached Q rows (see __init__); -1 where the item's
+        window touches an episode end (the caller uses max_priority there).  Call after this lock-step's network pass.  None before the first commit."""
         if self._ap_first_slot is None:
-            return
+            return None
         cfg, r, a = self.cfg, self.replay, self._ap
         E, n, A = cfg.n_envs, cfg.multisteps, cfg.n_actions
         n1, T = n + 1, self._passes  # pass T has just been stored; the items were committed at lock-step T - 1: states s_{T-n} .. s_T
@@ -272,13 +274,27 @@ class RainbowEngine:
         N.check(self.lib.srlx_nstep_td_huber_priority(E, n, A, N.tptr(qn), N.tptr(qn), N.tptr(q0), N.tptr(a["actions"]), N.tptr(a["rewards"]), N.tptr(a["terminated"]), None,
                                                       N.tptr(a["ones"]), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
                                                       N.tptr(a["target"]), N.tptr(a["loss"]), N.tptr(a["grad"]), N.tptr(a["pri"]), st))
-        r.max_priority_into(a["maxp"])
-        # commits T-n .. T-1 hold the item's n transitions (slots (T-n+k) % (n+1), k = 0..n-1 of done_hist); an episode end inside -> max_priority
+        # commits T-n .. T-1 hold the item's n transitions (slots (T-n+k) % (n+1), k = 0..n-1 of done_hist); an episode end inside -> -1
         inside = self.done_hist[[(T - n + k) % n1 for k in range(n)]].sum(dim=0) == 0
-        estimated = (a["pri"].double().abs() + float(cfg.memory_epsilon)) ** float(cfg.memory_alpha)  # the reference's transform on the widened value (:124)
-        raw = torch.where(a["mask"] != 0, torch.where(inside, estimated, a["maxp"].expand(E)), torch.zeros(E, dtype=torch.float64, device=self.dev))
-        r.add_raw(raw.contiguous())
         self._ap_first_slot = None
+        return torch.where(inside, a["pri"].abs(), torch.full_like(a["pri"], -1.0))
+
+    @staticmethod
+    def leaves_from_estimates(replay, est: torch.Tensor, mask: torch.Tensor, epsilon: float, alpha: float, maxp_buf: torch.Tensor) -> torch.Tensor:
+        """Final leaf values of a deferred add: (|td| + eps)^alpha on the widened value (proportional_memory.py:124) where an estimate exists, max_priority where the
+        estimate is -1, 0 where the lock-step completed no item for the lane (`mask`)."""
+        replay.max_priority_into(maxp_buf)
+        estimated = (est.double().clamp_min(0.0) + float(epsilon)) ** float(alpha)
+        leaf = torch.where(est >= 0, estimated, maxp_buf.expand(est.numel()))
+        return torch.where(mask != 0, leaf, torch.zeros_like(leaf)).contiguous()
+
+    def _add_with_actor_priorities(self):
+        """The deferred PER add of the PREVIOUS lock-step's items with actor-side initial priorities.  Call after this lock-step's network pass and after the
+        learner has been joined (it writes the tree)."""
+        est = self.actor_td_estimates()
+        if est is not None:
+            cfg = self.cfg
+            self.replay.add_raw(self.leaves_from_estimates(self.replay, est, self._ap["mask"], cfg.memory_epsilon, cfg.memory_alpha, self._ap["maxp"]))
 
     def actor_step(self):
         """One eager lock-step of the actors (no graphs, no learner)."""
@@ -442,8 +458,6 @@ class RainbowEngine:
     def actor_front(self, events=None):
         """Network pass + action selection + environments of one lock-step: reads the ring, writes nothing shared."""
         q = self._actor_net(None, events)  # eager launches, bracketed by the events
-        if self.actor_priority:
-            self.q_hist[self._passes % self.q_hist.shape[0]].copy_(q[: self.cfg.n_envs])
         if self._select_graph is not None:
             self._select_graph.replay()
         else:

@@ -342,3 +342,81 @@ def test_distributed_agent57_light_world_one_equals_the_single_engine(backend, a
     r = ret[0]
     assert r["committed"][0] == r["committed"][1] == 17 and r["len"][0] == r["len"][1]
     assert r["same"] and r["r_int_nonzero"] > 0
+
+
+def _priority_worker(rank, world, port, ret, learner_acts):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes
+
+        import numpy as np
+
+        import hot_path_oracle as H
+        from simple_distributed_rl_amd import _native as N
+        from simple_distributed_rl_amd.device.dist import DistributedRainbow
+        from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig
+
+        n, A = 3, 4
+        cfg = RainbowDeviceConfig(n_envs=8, batch_size=8, memory_capacity=8 * 2 * 60, memory_warmup_size=1 << 40, n_actions=A, seed=3, epsilon=0.3,
+                                  actor_initial_priority=True)
+        eng = DistributedRainbow(cfg, 0, episode_len=19, sync_interval=4, learner_acts=learner_acts)
+        steps = 40
+        for _ in range(steps):
+            eng.step(learner_updates=0)  # the weights stand still: the actors' cached rows are what the learner's network gives on the stored states
+        eng.flush()
+        torch.cuda.synchronize()
+        out = {}
+        if rank == 0:
+            r = eng.replay
+            cap, E = r.capacity, r.E
+            mp_, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+            tree = np.empty(2 * cap - 1)
+            N.check(r.lib.srlx_per_backup(r.h_per, ctypes.byref(mp_), ctypes.byref(size), ctypes.byref(write), N.np_ptr(tree)))
+            added = write.value  # every add appends E leaves; the last commit's add is still deferred
+            slots = np.arange(added)
+            idx = torch.tensor(slots + cap - 1, dtype=torch.int64, device="cuda")
+            B = len(slots)
+            obs = torch.zeros((B, n + 1, cfg.window_length, 84 * 84), dtype=torch.float32, device="cuda")
+            act = torch.zeros((B, n), dtype=torch.int32, device="cuda")
+            rew = torch.zeros((B, n), dtype=torch.float32, device="cuda")
+            ter = torch.zeros((B, n), dtype=torch.float32, device="cuda")
+            N.check(r.lib.srlx_store_gather_nstep(r.h_store, B, N.tptr(idx), N.tptr(obs), N.tptr(act), N.tptr(rew), N.tptr(ter), None))
+            net = eng.local.q_online
+            with torch.no_grad():
+                q = torch.cat([net(obs[k:k + 64].view(-1, cfg.window_length, 84, 84), channels_first=True) for k in range(0, B, 64)]).view(B, n + 1, A).cpu().numpy()
+            tgt = H.nstep_target(q[:, 1:], q[:, 1:], act.cpu().numpy(), rew.cpu().numpy(), ter.cpu().numpy(), None, cfg.discount, cfg.retrace_h, True, False)
+            td = np.abs(tgt - q[np.arange(B), 0, act[:, 0].cpu().numpy()])
+            want = (td.astype(np.float64) + cfg.memory_epsilon) ** cfg.memory_alpha
+            got = tree[cap - 1:][slots]
+            est = (got != 0.0) & (got != 1.0)
+            out = dict(added=int(added), per_step=int(E), estimated=int(est.sum()), at_max=int((got == 1.0).sum()), empty=int((got == 0.0).sum()),
+                       max_rel=float(np.max(np.abs(got[est] - want[est]) / np.maximum(want[est], 1e-6))), max_priority=mp_.value)
+        ret[rank] = out
+    except Exception:
+        import traceback
+
+        ret[f"error{rank}"] = traceback.format_exc()
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("learner_acts", [True, False])
+def test_actor_ranks_ship_initial_priorities(learner_acts):
+    """cfg.actor_initial_priority over two ranks: every actor rank estimates |n-step target - Q(s_0, a_0)| of its items from its cached Q rows and ships the estimates
+    in the packed record one lock-step behind the frames; the learner rank's tree add (one lock-step behind its ring commit) takes them.  The leaves of the GLOBAL
+    tree equal the oracle's n-step arithmetic on the learner's own Q-values of the stored states (the weights stand still)."""
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    try:
+        mp.spawn(_priority_worker, args=(2, _free_port(), ret, learner_acts), nprocs=2, join=True)
+    except Exception:
+        errs = [v for k, v in sorted(ret.items(), key=lambda kv: str(kv[0])) if str(k).startswith("error")]
+        raise AssertionError("worker failed:\n" + "\n".join(errs))
+    d = ret[0]
+    assert d["per_step"] == (16 if learner_acts else 8) and d["added"] > 30 * d["per_step"] and d["max_priority"] == 1.0
+    assert d["estimated"] > 0.5 * d["added"] and d["at_max"] > 0 and d["empty"] > 0
+    assert d["max_rel"] < 2e-4, d

@@ -139,6 +139,9 @@ int srlx_per_refresh(srlx_per_t *h, void *stream);
 /* SRLX_PRIO_NONE with a validity mask (uint8[n]): p = mask ? max_priority : 0.  Used by the
  * vectorised actor, where the ring position holding an episode's terminal frame has no transition. */
 #define SRLX_PRIO_NONE_MASKED 4
+/* add only, float32[n] ESTIMATES of |td| made on the actor side (rainbow.py:389-398; srlx_store_actor_td): x >= 0 -> p = (|x| + eps)^alpha on the widened value
+ * (proportional_memory.py:124), x = -1 -> the current max_priority (priority = None), x = -2 -> 0 (the lock-step completed no item for the lane). */
+#define SRLX_PRIO_EST_F32 5
 
 /* ------------------------------------------------------------------------------------
  * Counter-based device RNG (the vectorised path has no reference stream to match; the
@@ -413,6 +416,14 @@ int srlx_store_gather_items(srlx_store_t *h, int64_t batch, const int64_t *d_tre
                             int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream);
 int srlx_store_gather_train(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int64_t *d_frame_off_all, int64_t *d_frame_off_next,
                             int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream);
+/* Actor-side initial priorities (rainbow.py:389-398: a distributed worker hands `abs(calc_target_q([batch]) - q[action])` to memory.add): for the E items the LAST
+ * commit completed -- PER slots first_slot .. first_slot + E - 1 (mod per_capacity), lane e's item in slot first_slot + e -- the n-step / retrace TD of
+ * rainbow.py:226-287 on CACHED Q rows: d_q_hist f32 [n_step + 1][E][n_actions] is a ring over the acting passes, row (base_slot + k) mod (n_step + 1) holds
+ * Q(s_k) of the item's k-th state (the online rows stand in for the target network's).  d_est[e] = |target - Q(s_0, a_0)|, or -1 when an episode ends inside
+ * the item's window (its last states were never evaluated by an actor: the caller uses max_priority), or -2 when d_item_mask[e] == 0 (no item).  Feeds
+ * srlx_per_add(..., SRLX_PRIO_EST_F32). */
+int srlx_store_actor_td(srlx_store_t *h, int64_t first_slot, int64_t per_capacity, const float *d_q_hist, int base_slot, const uint8_t *d_item_mask, double discount,
+                        double retrace_h, int enable_double_dqn, int enable_rescale, float *d_est, void *stream);
 int srlx_store_gather_obs(srlx_store_t *h, int64_t batch, int k_begin, int k_count, float *d_obs, void *stream);
 
 /* ------------------------------------------------------------------------------------

@@ -126,6 +126,10 @@ __device__ __forceinline__ double load_prio(const void *prio, int kind, i64 i, d
         case SRLX_PRIO_F64: return transform_f64(((const double *)prio)[i], eps, alpha);
         case SRLX_PRIO_F32: return transform_f32(((const float *)prio)[i], eps, alpha);
         case SRLX_PRIO_NONE_MASKED: return ((const unsigned char *)prio)[i] ? max_priority : 0.0;
+        case SRLX_PRIO_EST_F32: {
+            const float x = ((const float *)prio)[i];
+            return x < -1.5f ? 0.0 : (x < 0.f ? max_priority : transform_f64((double)x, eps, alpha));
+        }
         default: return ((const double *)prio)[i];
     }
 }
@@ -993,7 +997,7 @@ namespace {
 
 hipStream_t pick_stream(srlx_per *, void *stream) { return (hipStream_t)stream; }  // NULL = HIP's default stream
 
-size_t prio_elem_bytes(int kind) { return kind == SRLX_PRIO_F32 ? 4 : (kind == SRLX_PRIO_NONE_MASKED ? 1 : 8); }
+size_t prio_elem_bytes(int kind) { return (kind == SRLX_PRIO_F32 || kind == SRLX_PRIO_EST_F32) ? 4 : (kind == SRLX_PRIO_NONE_MASKED ? 1 : 8); }
 
 int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st, i64 start_slot = -1) {
     SRLX_TRY(h->scratch.reserve(srlx::Carver::padded((size_t)n * 8) + 256));
@@ -1250,7 +1254,7 @@ int srlx_per_add(srlx_per_t *h, int64_t n, const void *prio, int prio_kind, int 
     SRLX_REQUIRE(h, "per_add: NULL handle");
     SRLX_REQUIRE(n >= 0 && n <= h->capacity, "per_add: n=%lld must be in [0, capacity=%lld]", (long long)n,
                  (long long)h->capacity);
-    SRLX_REQUIRE(prio_kind >= SRLX_PRIO_NONE && prio_kind <= SRLX_PRIO_NONE_MASKED, "per_add: bad prio_kind %d", prio_kind);
+    SRLX_REQUIRE(prio_kind >= SRLX_PRIO_NONE && prio_kind <= SRLX_PRIO_EST_F32, "per_add: bad prio_kind %d", prio_kind);
     SRLX_REQUIRE(prio_kind == SRLX_PRIO_NONE || prio != nullptr, "per_add: prio is NULL");
     if (n == 0) return SRLX_OK;
     srlx::DeviceGuard guard(h->device);

@@ -16,6 +16,7 @@
 #include <new>
 
 #include "srlx_common.h"
+#include "srlx_td_math.h"
 
 namespace {
 
@@ -672,6 +673,62 @@ int srlx_rng_uniform(uint64_t seed, int64_t *d_counter, int64_t n, double *d_out
     }
     hipLaunchKernelGGL(k_rng_uniform, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (u64)seed, d_counter, (i64)n, d_out);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, d_counter);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+// Actor-side initial priorities (rainbow.py:389-398): one thread per lane -- the item the last commit completed for it (item_meta: scalars, terminal padding, where the
+// episode ends inside the window), then the n-step / retrace TD of srlx_td_math.h:td_rows on the lane's CACHED Q rows (a ring over the acting passes; the online rows in
+// both roles).  Replaces ~20 small torch launches on the serial tail of a lock-step.
+__global__ void __launch_bounds__(256) k_actor_td(StoreDev s, i64 first_slot, i64 cap, const float *__restrict__ q_hist, int base_slot, const u8 *__restrict__ mask,
+                                                  double discount, double retrace_h, int double_dqn, int rescale, float *__restrict__ est) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.E) return;
+    if (!mask[e]) {
+        est[e] = -2.f;
+        return;
+    }
+    const int n = s.n, A = s.A, n1 = n + 1;
+    i64 tidx = (first_slot + e) % cap + (cap - 1);
+    int32_t act[srlx::kTdMaxStep];
+    float rew[srlx::kTdMaxStep], ter[srlx::kTdMaxStep];
+    const ItemMeta m = item_meta(s, 0, &tidx, act, rew, ter);
+    if (m.jd < n || m.e != e) {  // an episode ends inside the window (or the slot is not this lane's: a caller error) -> max_priority
+        est[e] = -1.f;
+        return;
+    }
+    auto row = [&](int k) { return q_hist + (((i64)((base_slot + k) % n1)) * s.E + e) * A; };
+    const float disc_f = (float)discount;
+    float td[srlx::kTdMaxStep];
+    int nact[srlx::kTdMaxStep];
+    for (int k = 0; k < n; k++) {  // srlx_td_math.h:td_rows with q_on_next = q_tg_next = rows 1..n, q_on_0 = row 0
+        const float *nx = row(k + 1);
+        nact[k] = srlx::argmax_masked(nx, nullptr, A);
+        float maxq = nx[nact[k]];
+        if (rescale) maxq = srlx::inverse_rescaling(maxq);
+        float gain = rew[k] + ((1.0f - ter[k]) * disc_f) * maxq;
+        if (rescale) gain = srlx::rescaling(gain);
+        const float qsel = (k == 0) ? 0.f : row(k)[act[k]];
+        td[k] = gain - qsel;
+    }
+    (void)double_dqn;  // one set of rows: the greedy action and its value come from the same network
+    double c = 1.0;
+    float target = 0.f;
+    for (int k = 0; k < n; k++) {
+        if (k > 0) c *= retrace_h * ((act[k] == nact[k]) ? 1.0 : 0.0);  // td_rows: pi = (act[m] == nact[m])
+        const float dm = (float)pow(discount, (double)k);
+        target = target + (float)((double)(td[k] * dm) * c);
+    }
+    est[e] = fabsf(target - row(0)[act[0]]);
+}
+
+int srlx_store_actor_td(srlx_store_t *h, int64_t first_slot, int64_t per_capacity, const float *d_q_hist, int base_slot, const uint8_t *d_item_mask, double discount,
+                        double retrace_h, int enable_double_dqn, int enable_rescale, float *d_est, void *stream) {
+    SRLX_REQUIRE(h && d_q_hist && d_item_mask && d_est && per_capacity > 0 && first_slot >= 0 && base_slot >= 0, "store_actor_td: bad argument");
+    SRLX_REQUIRE(h->d.n <= srlx::kTdMaxStep, "store_actor_td: n_step <= %d", srlx::kTdMaxStep);
+    srlx::DeviceGuard guard(h->device);
+    hipLaunchKernelGGL(k_actor_td, dim3((unsigned)((h->d.E + 255) / 256)), dim3(256), 0, pick(h, stream), h->d, (i64)first_slot, (i64)per_capacity, d_q_hist, base_slot,
+                       d_item_mask, discount, retrace_h, enable_double_dqn, enable_rescale, d_est);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

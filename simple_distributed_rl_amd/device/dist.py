@@ -252,8 +252,7 @@ class DistributedRainbow:
         gathered = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, obs0, self._extra())
         if self.is_learner:
             self.replay.reset_all(self._actor_rows(gathered)[4])
-            if self.actor_priority:
-                self._maxp = torch.zeros(1, dtype=torch.float64, device=self.dev)
+
 
     def _actor_rows(self, gathered):
         """The staging rows of the actor ranks (a learner-only rank 0 owns row block 0 of the staging buffers and never fills it)."""
@@ -272,11 +271,9 @@ class DistributedRainbow:
         if not self.actor_priority:
             self.replay.commit(*rows[:5])
             return
-        from simple_distributed_rl_amd.device.rainbow import RainbowEngine
-
-        if self._pending_mask is not None:
-            cfg = self.cfg
-            self.replay.add_raw(RainbowEngine.leaves_from_estimates(self.replay, rows[5].reshape(-1), self._pending_mask, cfg.memory_epsilon, cfg.memory_alpha, self._maxp))
+        if self._pending_mask is not None:  # estimates of the previous ring commit's items; the learner's own mask decides where an item exists at all
+            est = torch.where(self._pending_mask != 0, rows[5].reshape(-1), torch.full_like(rows[5].reshape(-1), -2.0)).contiguous()
+            N.check(self.replay.lib.srlx_per_add(self.replay.h_per, self.replay.E, N.tptr(est), N.PRIO_EST_F32, 1, N.torch_stream_ptr()))
         self.replay.commit(*rows[:5], defer_add=True)
         self._pending_mask = self.replay.item_mask.clone()
 

@@ -170,7 +170,7 @@ def _env_factory(env_spec: dict):
 
 def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, actor_devices, updates_per_step: int = 1,
                        sync_interval_steps: int = 16, check_every: int = 16, memory_device=None, prefetch: int = 5,
-                       actor_initial_priority: bool = False) -> RunStateTrainer:
+                       actor_initial_priority: bool = True) -> RunStateTrainer:
     """memory_device (e.g. "cuda:1"): the reference's three-role topology with the replay on a GPU of its own (device/replay_role.py); default: the
     learner rank owns the replay (device/dist.py)."""
     from simple_distributed_rl_amd.device import vector_runner as vr
@@ -184,8 +184,8 @@ def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, 
     if actor_initial_priority and kind == "rainbow" and not plan.get("replay_role") and runner.rl_config.memory.name != "ReplayBuffer":
         import dataclasses
 
-        # the reference's DISTRIBUTED workers estimate an item's first priority themselves (rainbow.py:389-398, `memory.requires_priority()`); opt-in here: the
-        # estimate is ~20 small launches on the serial tail of every lock-step today (0.81 against 0.51 ms at 1024 environments)
+        # the reference's DISTRIBUTED workers estimate an item's first priority themselves (rainbow.py:389-398, `memory.requires_priority()`): so do the actor
+        # ranks (two launches per lock-step: +5 % at 1024 environments); train_mp(..., actor_initial_priority=False) keeps max_priority
         cfg = dataclasses.replace(cfg, actor_initial_priority=True)
     env_spec = dict(env_config=runner.env_config, seed=context.seed, processor=vr.frame_processor(runner.rl_config))
     opts = dict(updates_per_step=updates_per_step, sync_interval_steps=sync_interval_steps, check_every=check_every, lanes=lanes, prefetch=prefetch)

@@ -181,24 +181,17 @@ class RainbowEngine:
         # ---- actor-side initial priorities (cfg.actor_initial_priority; the reference's distributed worker, rainbow.py:389-398) ----
         # The Q rows of the last n + 1 acting passes are kept; one lock-step after an item was committed -- its last state s_n has then been evaluated by
         # the pass that acts on it -- the existing fused TD kernel turns the cached rows + the item's stored actions / rewards into |target - Q(s_0, a_0)|,
-        # and the item's leaf is ADDED then (the add of a lock-step is deferred by one) with (|td| + eps)^alpha.  The cached online rows stand in for the
+        # and the item's leaf is ADDED then (the add of a lock-step is deferred by one) with (|td| + eps)^alpha -- two launches per lock-step: srlx_store_actor_td and the add.  The cached online rows stand in for the
         # target network too (an actor holds no target network here; equal right after a target sync) and are as old as the pass that produced them
         # (the reference re-evaluates all n + 1 states under the current weights: identical while the weights stand still, tests/test_engine_gpu.py).
         # Items whose window touches an episode end keep max_priority: the state after a terminal / truncated step is never evaluated by an actor.
         self.actor_priority = bool(cfg.actor_initial_priority) and self.mfma
         if self.actor_priority:
-            n1, W = cfg.multisteps + 1, cfg.window_length
+            n1 = cfg.multisteps + 1
             d = self.dev
             self.q_hist = torch.zeros((n1, E, cfg.n_actions), dtype=torch.float32, device=d)
-            self.done_hist = torch.ones((n1, E), dtype=torch.uint8, device=d)  # "an episode end" until n real commits have been seen
             self._passes, self._ap_first_slot = 0, None
-            self._ap = dict(idx=torch.zeros(E, dtype=torch.int64, device=d), off_all=torch.zeros((E, n1, W), dtype=torch.int64, device=d),
-                            off_next=torch.zeros((E, n1 - 1, W), dtype=torch.int64, device=d), actions=torch.zeros((E, n1 - 1), dtype=torch.int32, device=d),
-                            rewards=torch.zeros((E, n1 - 1), dtype=torch.float32, device=d), terminated=torch.zeros((E, n1 - 1), dtype=torch.float32, device=d),
-                            target=torch.zeros(E, dtype=torch.float32, device=d), loss=torch.zeros(1, dtype=torch.float32, device=d),
-                            grad=torch.zeros((E, cfg.n_actions), dtype=torch.float32, device=d), pri=torch.zeros(E, dtype=torch.float32, device=d),
-                            ones=torch.ones(E, dtype=torch.float32, device=d), maxp=torch.zeros(1, dtype=torch.float64, device=d),
-                            mask=torch.zeros(E, dtype=torch.uint8, device=d), lanes=torch.arange(E, dtype=torch.int64, device=d))
+            self._ap = dict(pri=torch.zeros(E, dtype=torch.float32, device=d), mask=torch.zeros(E, dtype=torch.uint8, device=d))
         self._select_graph = None
         self._commit_graph = None
         d = self.dev
@@ -257,44 +250,29 @@ class RainbowEngine:
         self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs, defer_add=self.actor_priority)
 
     def actor_td_estimates(self):
-        """|n-step target - Q(s_0, a_0)| of the items the PREVIOUS lock-step committed, float32 [E], from the cached Q rows (see __init__); -1 where the item's
-        window touches an episode end (the caller uses max_priority there).  Call after this lock-step's network pass.  None before the first commit."""
+        """float32 [E] for the items the PREVIOUS lock-step committed, from the cached Q rows (see __init__; ONE launch, srlx_store_actor_td): |n-step target -
+        Q(s_0, a_0)|, or -1 where the item's window touches an episode end (the adder uses max_priority), or -2 where the lock-step completed no item for the lane.
+        Call after this lock-step's network pass.  None before the first commit."""
         if self._ap_first_slot is None:
             return None
         cfg, r, a = self.cfg, self.replay, self._ap
-        E, n, A = cfg.n_envs, cfg.multisteps, cfg.n_actions
-        n1, T = n + 1, self._passes  # pass T has just been stored; the items were committed at lock-step T - 1: states s_{T-n} .. s_T
-        order = [(T - n + k) % n1 for k in range(n1)]
-        q = self.q_hist[order].permute(1, 0, 2).contiguous()  # [E][n + 1][A]
-        q0, qn = q[:, 0].contiguous(), q[:, 1:].contiguous()
-        a["idx"].copy_((a["lanes"] + self._ap_first_slot) % r.capacity + (r.capacity - 1))
-        st = N.torch_stream_ptr()
-        N.check(self.lib.srlx_store_gather_train(r.h_store, E, N.tptr(a["idx"]), N.tptr(a["off_all"]), N.tptr(a["off_next"]), N.tptr(a["actions"]), N.tptr(a["rewards"]),
-                                                 N.tptr(a["terminated"]), st))
-        N.check(self.lib.srlx_nstep_td_huber_priority(E, n, A, N.tptr(qn), N.tptr(qn), N.tptr(q0), N.tptr(a["actions"]), N.tptr(a["rewards"]), N.tptr(a["terminated"]), None,
-                                                      N.tptr(a["ones"]), float(cfg.discount), float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale),
-                                                      N.tptr(a["target"]), N.tptr(a["loss"]), N.tptr(a["grad"]), N.tptr(a["pri"]), st))
-        # commits T-n .. T-1 hold the item's n transitions (slots (T-n+k) % (n+1), k = 0..n-1 of done_hist); an episode end inside -> -1
-        inside = self.done_hist[[(T - n + k) % n1 for k in range(n)]].sum(dim=0) == 0
+        n1, T = cfg.multisteps + 1, self._passes  # pass T has just been stored; the items were committed at lock-step T - 1: states s_{T-n} .. s_T
+        if T < cfg.multisteps:  # the first lock-steps: some of the window's states were never evaluated (random filling came before) -> max_priority
+            a["pri"].copy_(torch.where(a["mask"] != 0, -1.0, -2.0))
+            self._ap_first_slot = None
+            return a["pri"]
+        N.check(self.lib.srlx_store_actor_td(r.h_store, self._ap_first_slot, r.capacity, N.tptr(self.q_hist), (T - cfg.multisteps) % n1, N.tptr(a["mask"]), float(cfg.discount),
+                                             float(cfg.retrace_h), int(cfg.enable_double_dqn), int(cfg.enable_rescale), N.tptr(a["pri"]), N.torch_stream_ptr()))
         self._ap_first_slot = None
-        return torch.where(inside, a["pri"].abs(), torch.full_like(a["pri"], -1.0))
-
-    @staticmethod
-    def leaves_from_estimates(replay, est: torch.Tensor, mask: torch.Tensor, epsilon: float, alpha: float, maxp_buf: torch.Tensor) -> torch.Tensor:
-        """Final leaf values of a deferred add: (|td| + eps)^alpha on the widened value (proportional_memory.py:124) where an estimate exists, max_priority where the
-        estimate is -1, 0 where the lock-step completed no item for the lane (`mask`)."""
-        replay.max_priority_into(maxp_buf)
-        estimated = (est.double().clamp_min(0.0) + float(epsilon)) ** float(alpha)
-        leaf = torch.where(est >= 0, estimated, maxp_buf.expand(est.numel()))
-        return torch.where(mask != 0, leaf, torch.zeros_like(leaf)).contiguous()
+        return a["pri"]
 
     def _add_with_actor_priorities(self):
-        """The deferred PER add of the PREVIOUS lock-step's items with actor-side initial priorities.  Call after this lock-step's network pass and after the
-        learner has been joined (it writes the tree)."""
+        """The deferred PER add of the PREVIOUS lock-step's items with actor-side initial priorities (srlx_per_add, SRLX_PRIO_EST_F32).  Call after this lock-step's
+        network pass and after the learner has been joined (it writes the tree)."""
         est = self.actor_td_estimates()
         if est is not None:
-            cfg = self.cfg
-            self.replay.add_raw(self.leaves_from_estimates(self.replay, est, self._ap["mask"], cfg.memory_epsilon, cfg.memory_alpha, self._ap["maxp"]))
+            r = self.replay
+            N.check(self.lib.srlx_per_add(r.h_per, r.E, N.tptr(est), N.PRIO_EST_F32, 1, N.torch_stream_ptr()))
 
     def actor_step(self):
         """One eager lock-step of the actors (no graphs, no learner)."""
@@ -473,7 +451,6 @@ class RainbowEngine:
         if self.actor_priority:  # what the deferred add of this lock-step will need
             r = self.replay
             self._ap["mask"].copy_(r.item_mask)
-            self.done_hist[self._passes % self.done_hist.shape[0]].copy_(self.env.done)
             self._ap_first_slot = ((r._steps_committed - 1) * self.cfg.n_envs) % r.capacity
             self._passes += 1
         self.total_env_steps += self.cfg.n_envs

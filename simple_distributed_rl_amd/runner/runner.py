@@ -228,7 +228,7 @@ class Runner:
                     self.state = train_mp_on_engine(self, c, int(lanes), actor_num, actor_devices, updates_per_step=int(kwargs.get("updates_per_step", 1)),
                                                     sync_interval_steps=int(kwargs.get("sync_interval_steps", 16)), memory_device=kwargs.get("memory_device"),
                                                     prefetch=int(kwargs.get("mem_to_train_queue_capacity", 5)),
-                                                    actor_initial_priority=bool(kwargs.get("actor_initial_priority", False)))
+                                                    actor_initial_priority=bool(kwargs.get("actor_initial_priority", True)))
                     return self.state
             else:
                 self.vector_reason = "the run is not on a GPU device"

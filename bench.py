@@ -668,6 +668,7 @@ def per_micro(eng, draws=1 << 20, reps=20):
         ops[f"update_{B}"] = {"us_per_call": 1e3 * ms, "updates_per_s": B / (ms * 1e-3), "algorithmic_bytes_per_index": 16 + depth * 16}
     E = r.E
     mask = torch.ones(E, dtype=torch.uint8, device=d)
+    N.check(r.lib.srlx_per_set_add_counters(r.h_per, None, None))  # (the engine's adds also move its ring position: not these stand-alone ones -- the run is over)
     ms = timed(lambda: N.check(r.lib.srlx_per_add(r.h_per, E, N.tptr(mask), N.PRIO_NONE_MASKED, 1, N.torch_stream_ptr())), 100)
     ops[f"add_{E}"] = {"us_per_call": 1e3 * ms, "adds_per_s": E / (ms * 1e-3), "algorithmic_bytes_per_item": 16 + depth * 16 + 8}
     out["ops"] = ops

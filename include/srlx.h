@@ -76,6 +76,9 @@ int srlx_per_set_has_duplicate(srlx_per_t *h, int has_duplicate);
  * train_count (trainer.py: `self.train_count += 1` after the priority write-back, model_torch.py:113-122) kept on the device without
  * a launch of its own.  Launches queued after the update see the new value. */
 int srlx_per_set_update_counter(srlx_per_t *h, int64_t *d_counter);
+/* every later APPENDING srlx_per_add also adds 1 to these int64 device counters (either may be NULL), inside its own launch: an engine's ring position and the
+ * counter of its policy generator advance with the add that closes a lock-step instead of in launches of their own (readers ran in earlier launches). */
+int srlx_per_set_add_counters(srlx_per_t *h, int64_t *d_counter0, int64_t *d_counter1);
 int srlx_per_clear(srlx_per_t *h, void *stream);
 /* length() (:117-118).  Host mirror; exact as long as adds go through srlx_per_add. */
 int64_t srlx_per_length(const srlx_per_t *h);
@@ -191,6 +194,18 @@ int srlx_store_stack_current(srlx_store_t *h, float *d_out, void *stream);
  * (position p-(n_step-1)) for srlx_per_add(..., SRLX_PRIO_NONE_MASKED). */
 int srlx_store_commit_step(srlx_store_t *h, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated,
                            const uint8_t *d_done, const void *d_next_obs, uint8_t *d_item_mask, void *stream);
+/* The same commit as ONE launch with two options (the round-4 lock-step):
+ *   d_next_frame_table  int64 [E][window] or NULL: the frame-offset table of the NEXT policy pass (what srlx_store_frame_table_current would write after
+ *                       the position has advanced), so the next pass needs no launch of its own for it (uint8 stores)
+ *   advance             1: p advances inside the launch (srlx_store_commit_step = this with NULL, 1); 0: p stays and the caller advances it later --
+ *                       srlx_store_advance, or srlx_per_set_add_counters on the position view (srlx_store_views).  Ring slot p + 1 and the scalars of p are
+ *                       referenced by no stored item, so with advance = 0 the commit may run while a learner still reads the ring; p itself feeds the
+ *                       learner's item lookup and must not move under it.
+ *   d_bump              int64 device counter or NULL: advanced by one when the launch's last block is done (the counter of the policy generator that
+ *                       srlx_qnet_forward_u8_policy only reads) */
+int srlx_store_commit_step_ex(srlx_store_t *h, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated, const uint8_t *d_done,
+                              const void *d_next_obs, uint8_t *d_item_mask, int64_t *d_next_frame_table, int advance, int64_t *d_bump, void *stream);
+int srlx_store_advance(srlx_store_t *h, void *stream);
 /* device views: int64 position p; uint8 needs_reset[E]; int32 step_in_episode[E] (of position p) */
 int srlx_store_views(srlx_store_t *h, void **d_pos, void **d_needs_reset, void **d_step_in_ep);
 /* sampled PER tree indices -> training batch (rainbow.py:190-194 + terminal padding :354-372):
@@ -460,6 +475,34 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
 int srlx_qnet_destroy(srlx_qnet_t *h);
 int srlx_qnet_bind(srlx_qnet_t *h, const float *const *d_params);
 int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, void *stream);
+/* The batched Worker.policy step as one call (srl/algorithms/rainbow/rainbow.py:301-329 behind srl/base/rl/worker_run.py:316-322): srlx_qnet_forward_u8 whose head
+ * kernel also selects the actions -- epsilon-greedy exactly as srlx_policy_epsilon_greedy would on the Q rows with the uniforms srlx_rng_uniform(seed, d_counter,
+ * 2 * batch, u) would write (row e uses u[2 e], u[2 e + 1]).  *d_counter is READ only: advance it once per pass yourself (srlx_store_commit_step_ex's d_bump does).
+ *   d_eps float32 [batch], d_invalid uint8 [batch][n_actions] or NULL, d_actions int32 [batch], d_q_copy float32 [batch][n_actions] or NULL (a second copy of Q) */
+int srlx_qnet_forward_u8_policy(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, const float *d_eps, uint64_t seed,
+                                const int64_t *d_counter, const uint8_t *d_invalid, int32_t *d_actions, float *d_q_copy, void *stream);
+/* Weights handed from a learner to the actors that share its GPU without a copy on the lock-step's serial tail (the role of the parameter board the reference's
+ * trainer publishes and its actors poll, srl/base/run/play_mp.py:289-303,151-165; there a pickled state_dict, here two device-resident parameter sets):
+ *   srlx_qnet_actor_sets_enable   an actor handle gets two sets of everything a policy pass reads (packed convolution filters, the first dense layer as bf16
+ *                                 operand planes, biases and head vectors)
+ *   srlx_qnet_publish             packs h_src's convolution filters for its own next forwards (they then skip the packing launch until
+ *                                 srlx_qnet_weights_changed) and, with h_actor, writes set `set` in the same launch; with_fc1 != 0 also splits the first dense
+ *                                 layer's weight into the set's planes (the out-of-band publish: start-up, restore, a target sync)
+ *   srlx_qnet_fuse_adam_fc1_planes  the fused Adam epilogue of srlx_qnet_fuse_adam_fc1 ALSO writes the updated weight as planes to d_planes_out (an actor set's,
+ *                                 srlx_qnet_actor_set_planes); NULL switches it off
+ *   srlx_qnet_actor_set_select    the next forwards of the actor handle read set 0 / 1 (-1: its bound parameters again)
+ *   srlx_qnet_set_pack_sticky     a forward's packed filters stay valid until srlx_qnet_weights_changed (a target network: weights change at a sync only)
+ *   srlx_qnet_weights_changed     the bound tensors were written by somebody else: packed filters and operand planes derived from them are stale */
+int srlx_qnet_actor_sets_enable(srlx_qnet_t *h);
+int srlx_qnet_actor_set_planes(srlx_qnet_t *h, int set, void **d_planes);
+int srlx_qnet_actor_set_select(srlx_qnet_t *h, int set);
+int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int with_fc1, void *stream);
+int srlx_qnet_fuse_adam_fc1_planes(srlx_qnet_t *h, void *d_planes_out);
+int srlx_qnet_set_pack_sticky(srlx_qnet_t *h, int on);
+/* splits > 0: the chip-filling first-dense-layer launches of a handle with operand planes use half-CU workgroups (256 threads, 72 KB of LDS, `splits` K splits:
+ * a steady stream of short workgroups that leaves room for a learner's kernels on every compute unit); 0 (default): CU-filling workgroups, the fastest form alone. */
+int srlx_qnet_set_fc1_neighbour(srlx_qnet_t *h, int splits);
+int srlx_qnet_weights_changed(srlx_qnet_t *h);
 /* The image block alone (DQNImageBlock, srl/rl/torch_/blocks/dqn_image_block.py:29-54: three convolutions with replicate padding + ReLU) for
  * networks whose dense part is not the dueling head of this handle (Agent57_light's UVFA Q-networks, its embedding and RND networks,
  * agent57_light/model_torch.py:35-64,98-131,160-193): d_features = float32 [batch][OH3*OW3][2*filters] -- the post-ReLU conv3 output in

@@ -48,6 +48,7 @@ SIGNATURES = {
     "srlx_per_destroy": (c_int, [c_p]),
     "srlx_per_set_has_duplicate": (c_int, [c_p, c_int]),
     "srlx_per_set_update_counter": (c_int, [c_p, c_p]),
+    "srlx_per_set_add_counters": (c_int, [c_p, c_p, c_p]),
     "srlx_per_clear": (c_int, [c_p, c_p]),
     "srlx_per_length": (c_i64, [c_p]),
     "srlx_per_capacity": (c_i64, [c_p]),
@@ -74,6 +75,8 @@ SIGNATURES = {
     "srlx_store_reset_all": (c_int, [c_p, c_p, c_p]),
     "srlx_store_stack_current": (c_int, [c_p, c_p, c_p]),
     "srlx_store_commit_step": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_store_commit_step_ex": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p]),
+    "srlx_store_advance": (c_int, [c_p, c_p]),
     "srlx_store_views": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p)]),
     "srlx_store_gather_nstep": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_store_locate": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
@@ -88,6 +91,15 @@ SIGNATURES = {
     "srlx_qnet_bind": (c_int, [c_p, c_p]),
     "srlx_qnet_forward_u8": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     "srlx_qnet_forward_convs_u8": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "srlx_qnet_forward_u8_policy": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_u64, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_qnet_actor_sets_enable": (c_int, [c_p]),
+    "srlx_qnet_actor_set_planes": (c_int, [c_p, c_int, ctypes.POINTER(c_p)]),
+    "srlx_qnet_actor_set_select": (c_int, [c_p, c_int]),
+    "srlx_qnet_publish": (c_int, [c_p, c_p, c_int, c_int, c_p]),
+    "srlx_qnet_fuse_adam_fc1_planes": (c_int, [c_p, c_p]),
+    "srlx_qnet_set_pack_sticky": (c_int, [c_p, c_int]),
+    "srlx_qnet_set_fc1_neighbour": (c_int, [c_p, c_int]),
+    "srlx_qnet_weights_changed": (c_int, [c_p]),
     "srlx_qnet_enable_training": (c_int, [c_p, c_i64]),
     "srlx_qnet_set_probe": (c_int, [c_p, c_p, c_p]),
     "srlx_qnet_set_probe_fc1": (c_int, [c_p, c_p, c_p]),

@@ -7,7 +7,9 @@
 //   * the activations: the convolution kernel's conv3 epilogue writes act3 as planes (srlx_qnet_fused.hip, PLANES = true), and
 //   * the weight: the actors act on a private copy of the online network that is refreshed once per lock-step
 //     (device/rainbow.py:refresh_actor_copy) -- that copy now also emits the planes (k_split_planes, one pass over the 32 MB weight).
-// Plane layout (both operands): [K/32 slabs][rows][4 k-groups][3 parts][8 bf16] -- the 16-byte chunk (k-group g, part p) IS the fragment a lane
+// Plane layout: activations [K/32 slabs][rows][4 k-groups][3 parts][8 bf16], weight [K/32 slabs][rows][3 parts][4 k-groups][8 bf16] (a part's 32 k of a row are
+// 64 contiguous bytes: what a lane group of the weight-gradient kernel's Adam epilogue holds, srlx_qnet_bwd.hip: k_fc1_wgrad<.., PLANES>; the LDS image of a
+// tile is the same for both, only the SOURCE chunk index of the DMA differs) -- the 16-byte chunk (k-group g, part p) IS the fragment a lane
 // feeds v_mfma_f32_32x32x16_bf16 (row i, k = 8 g .. 8 g + 7); a row's 32-deep K-slab is 192 contiguous bytes (12 chunks), and the slab-major
 // order makes a whole 128-row operand tile of a K-slab ONE contiguous 24 KB run: every 128-byte line the LDS-DMA touches is used in full (with
 // row-major planes a row's slab straddles 2-3 lines of which 60 % is wanted, and the L2 -> CU path carries the rest for nothing).
@@ -37,6 +39,7 @@ constexpr size_t kLds = kStages * kBufBytes; // 144 KB
 
 // float32 [rows][K] -> planes [K/32][rows][4][3][8] bf16 (+ an optional float32 copy: the actors' private weight and its planes in one pass);
 // one thread per 8 consecutive k of a row
+template <bool WEIGHT>  // WEIGHT: the weight's chunk order [part][k-group], else the activations' [k-group][part]
 __global__ void __launch_bounds__(256) k_split_planes(const float *__restrict__ src, i64 rows, int K8, bf16x8 *__restrict__ planes, float *__restrict__ copy) {
     const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= rows * K8) return;
@@ -48,7 +51,7 @@ __global__ void __launch_bounds__(256) k_split_planes(const float *__restrict__ 
         reinterpret_cast<float4 *>(copy)[2 * q + 1] = x1;
     }
     float r[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    bf16x8 *dst = planes + (((i64)(k8 >> 2) * rows + row) * 4 + (k8 & 3)) * 3;
+    bf16x8 *dst = planes + ((i64)(k8 >> 2) * rows + row) * 12 + (WEIGHT ? (k8 & 3) : (k8 & 3) * 3);
 #pragma unroll
     for (int p = 0; p < 3; p++) {
         bf16x8 part;
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(256) k_split_planes(const float *__restrict__ 
             part[j] = b;
             r[j] -= (float)b;
         }
-        dst[p] = part;
+        dst[WEIGHT ? 4 * p : p] = part;
     }
 }
 
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(512) k_fc1_planes(const uint4 *__restrict__ A,
         int j = q - ((r >> 2) & 3);
         j += j < 0 ? 12 : 0;
         ga[u] = A + (((i64)s_beg * M + m0 + r) * 12 + j);
-        gb[u] = W + (((i64)s_beg * N + n0 + r) * 12 + j);
+        gb[u] = W + (((i64)s_beg * N + n0 + r) * 12 + (j % 3) * 4 + j / 3);  // chunk (k-group j / 3, part j % 3) in the weight's [part][k-group] order
     }
     // one piece (1 KB per wave) of the next slab: piece v = 0..5 -> (operand v & 1, instruction v >> 1)
     auto issue_piece = [&](int buf, int v) __attribute__((always_inline)) {
@@ -209,6 +212,157 @@ __global__ void __launch_bounds__(512) k_fc1_planes(const uint4 *__restrict__ A,
         }
 }
 
+// ---- the same GEMM as a GOOD NEIGHBOUR (round 4) ---------------------------------------------------------------------------------------------------------
+// k_fc1_planes above owns its CU: 512 threads whose registers fill the four SIMDs, 144 KB of LDS, one workgroup per CU for the whole launch (83 us).  Alone that
+// is the fastest form; beside a learner it is the slowest -- the update is a chain of ~22 short dependent kernels, each of which then waits for a compute unit
+// to come free (same-box A/B of the whole lock-step: 0.535 ms with it, 0.486 ms with the staging-split k_gemm_s16 that is 1.5x slower alone but leaves room).
+// This variant keeps the conversion-free operand planes and the LDS-DMA ring and gives up the CU: 256 threads (one wave per SIMD, a 64 x 64 block of the
+// 128 x 128 tile each: four accumulators, 12 fragment reads per 24 MFMAs instead of 18), stages of HALF a K-slab (16 k: 12 KB per operand tile), a
+// three-slot ring = 72 KB -- two workgroups share a CU, or one workgroup and whatever the learner wants to run; with 8 K splits the launch is 512 workgroups
+// that retire in a steady stream.  Same K order inside a split and the same order of the six partial products as k_fc1_planes / k_gemm_s16; the split-K
+// partial sums are added by k_head in split order, so the result depends on the NUMBER of splits only through float32 association (bit-identical at equal splits).
+// LDS image of a half-slab tile: row r = 6 chunk slots of 16 B (k-group hh = 0 / 1 of the half-slab x 3 parts: chunk c = hh * 3 + p), chunk c at slot
+// (c + ((r >> 4) & 1)) mod 6: the 16 rows of a ds_read_b128 lane group ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) then hit 16 different 16-byte bank groups
+// (6 r mod 16 takes the eight even values over r mod 8; the rotation moves rows 16-31 to the odd ones).
+constexpr int kHRow = 96;                      // bytes per row of a half-slab tile
+constexpr int kHTile = kTM * kHRow;            // 12 KB
+constexpr int kHBuf = 2 * kHTile;              // A + B
+constexpr int kHStages = 3;
+constexpr size_t kHLds = kHStages * kHBuf;     // 72 KB
+
+__global__ void __launch_bounds__(256, 2) k_fc1_planes_h(const uint4 *__restrict__ A, const uint4 *__restrict__ W, float *__restrict__ C, int M, int N, int K8,
+                                                      int slabs_per_split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {   // XCD-aware tile order (as k_fc1_planes)
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        if (total % 8 == 0) {
+            const unsigned lin = bx + gx * (by + gy * bz), tile = (lin % 8) * (total / 8) + lin / 8;
+            bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
+        }
+    }
+    const int m0 = bx * kTM, n0 = by * kTN;
+    const int nsl_total = K8 / 4;
+    const int s_beg = bz * slabs_per_split;
+    const int s_end = s_beg + slabs_per_split < nsl_total ? s_beg + slabs_per_split : nsl_total;
+    const int nst = 2 * (s_end - s_beg);  // half-slab stages of this split
+    const int wm = wave >> 1, wn = wave & 1;  // this wave's 64 x 64 block
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    // ---- LDS-DMA addressing: per operand tile 768 chunk slots = 12 wave-instructions, 3 per wave; instruction u of wave w fills slots (u * 4 + w) * 64 + lane
+    const uint4 *ga[3], *gb[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const int sl = (u * 4 + wave) * 64 + lane, r = sl / 6, q = sl % 6;
+        int c = q - ((r >> 4) & 1);
+        c += c < 0 ? 6 : 0;
+        const int hh = c / 3, p = c % 3;
+        // activations [slab][row][k-group 4][part 3]: half-slab ks starts at chunk 6 ks; weight [slab][row][part 3][k-group 4]: chunk 4 p + 2 ks + hh
+        ga[u] = A + (((i64)s_beg * M + m0 + r) * 12 + c);
+        gb[u] = W + (((i64)s_beg * N + n0 + r) * 12 + 4 * p + hh);
+    }
+    // stage st = 2 (slab - s_beg) + ks: piece v = 0..5 -> (operand v & 1, instruction v >> 1)
+    auto issue_piece = [&](int slot, int st, int v) __attribute__((always_inline)) {
+        unsigned char *base = smem + slot * kHBuf + wave * 1024 + (v >> 1) * 4096;
+        const int ks = st & 1;
+        const i64 slab = st >> 1;
+        if (v & 1)
+            __builtin_amdgcn_global_load_lds((gptr_t *)(gb[v >> 1] + slab * N * 12 + 2 * ks), (lptr_t *)(base + kHTile), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t *)(ga[v >> 1] + slab * M * 12 + 6 * ks), (lptr_t *)base, 16, 0, 0);
+    };
+    // fragment addresses: row r, chunk c = h * 3 + p at slot (c + rot) mod 6, rot = (r >> 4) & 1 = (i >> 4) & 1 (block row bases are multiples of 32)
+    const int rot = (i >> 4) & 1;
+    int fo[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        int c = h * 3 + p + rot;
+        c -= c >= 6 ? 6 : 0;
+        fo[p] = c * 16;
+    }
+    const int arow = (wm * 64 + i) * kHRow, brow = kHTile + (wn * 64 + i) * kHRow;
+    struct Frags {
+        bf16x8 a[2][3], b[2][3];
+    };
+    // 3 of a stage's 12 fragment reads: group g = 0..3 -> g < 2: the A parts of row tile g, else the B parts of column tile g - 2
+    auto read_group = [&](const unsigned char *buf, Frags &f, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            if (g < 2)
+                f.a[g][p] = *reinterpret_cast<const bf16x8 *>(buf + arow + g * 32 * kHRow + fo[p]);
+            else
+                f.b[g - 2][p] = *reinterpret_cast<const bf16x8 *>(buf + brow + (g - 2) * 32 * kHRow + fo[p]);
+        }
+    };
+    constexpr int pq[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};  // smallest partial products first (as k_gemm_s16)
+    auto body = [&](int st, int slot_next, int slot_free, const Frags &cur, Frags &nxt) __attribute__((always_inline)) {
+        if (st + 2 < nst)
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everybody's pieces of stage st + 1 have landed; every wave has finished READING stage st: its slot is free for stage st + 3
+        const bool rd = st + 1 < nst, dma = st + 3 < nst;
+        const unsigned char *buf = smem + slot_next * kHBuf;
+#pragma unroll
+        for (int x = 0; x < 6; x++) {  // six steps of four MFMAs (one partial product on the four accumulators); behind them two fragment-read groups or three DMA pieces
+#pragma unroll
+            for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+                for (int ns = 0; ns < 2; ns++) acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[ms][pq[x][0]], cur.b[ns][pq[x][1]], acc[ms][ns], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (x < 4) {
+                if (rd) read_group(buf, nxt, x);
+            } else if (dma) {
+#pragma unroll
+                for (int v = 0; v < 3; v++) issue_piece(slot_free, st + 3, (x - 4) * 3 + v);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (nst > 0) {
+        Frags f0, f1;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (k < nst)
+#pragma unroll
+                for (int v = 0; v < 6; v++) issue_piece(k, k, v);
+        if (nst >= 3)
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (nst == 2)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // stage 0 is in slot 0 for everybody
+#pragma unroll
+        for (int g = 0; g < 4; g++) read_group(smem, f0, g);
+        int slot = 0;  // slot of stage st
+        for (int st = 0; st < nst; st += 2) {
+            const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+            body(st, s1, slot, f0, f1);
+            if (st + 1 < nst) body(st + 1, s2, s1, f1, f0);
+            slot = s2;
+        }
+    }
+    float *Cz = C + (i64)bz * M * N;
+#pragma unroll
+    for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+        for (int ns = 0; ns < 2; ns++) {
+            const int n = n0 + wn * 64 + ns * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const i64 m = m0 + wm * 64 + ms * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Cz[m * N + n] = acc[ms][ns][r];
+            }
+        }
+}
+
 }  // namespace
 
 // operand planes of this handle: allocated by srlx_qnet_enable_fc1_planes
@@ -222,9 +376,12 @@ int srlx_fc1_planes_alloc(srlx_qnet *h) {
 }
 
 // float32 weight [2 hidden][flat] (src, or the handle's bound weight) -> the handle's planes; `copy_dst` (optional) also receives the float32 values
-int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst, hipStream_t st) {
+size_t srlx_fc1_planes_weight_bytes(const srlx_qnet *h) { return 2 * (size_t)h->hidden * h->flat * 6; }
+
+int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst, hipStream_t st, void *planes_dst) {
     const i64 rows = 2 * (i64)h->hidden, n8 = rows * h->flat / 8;
-    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, src, rows, h->flat / 8, (bf16x8 *)h->wf_planes, copy_dst);
+    hipLaunchKernelGGL(k_split_planes<true>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, src, rows, h->flat / 8,
+                       (bf16x8 *)(planes_dst ? planes_dst : h->wf_planes), copy_dst);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }
@@ -232,7 +389,7 @@ int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst
 // float32 activations act3 [rows][flat] -> a3_planes (the path for geometries whose convolution kernel does not write planes itself)
 int srlx_fc1_planes_split_act(srlx_qnet *h, int64_t rows, hipStream_t st) {
     const i64 n8 = rows * h->flat / 8;
-    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const float *)h->act3, (i64)rows, h->flat / 8, (bf16x8 *)h->a3_planes,
+    hipLaunchKernelGGL(k_split_planes<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const float *)h->act3, (i64)rows, h->flat / 8, (bf16x8 *)h->a3_planes,
                        (float *)nullptr);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
@@ -253,6 +410,16 @@ int srlx_fc1_planes_gemm(srlx_qnet *h, int64_t rows, int splits, int kps, hipStr
     }
     const int N1 = 2 * h->hidden;
     const dim3 grid((unsigned)(rows / kTM), (unsigned)(N1 / kTN), (unsigned)splits);
+    if (h->fc1_neighbour) {  // half-CU workgroups (srlx_qnet_set_fc1_neighbour): the handle's passes run beside a learner
+        static bool attr_h = false;
+        if (!attr_h) {
+            SRLX_HIP(hipFuncSetAttribute((const void *)k_fc1_planes_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHLds));
+            attr_h = true;
+        }
+        hipLaunchKernelGGL(k_fc1_planes_h, grid, dim3(256), kHLds, st, (const uint4 *)h->a3_planes, (const uint4 *)h->wf_planes, h->partial, (int)rows, N1, h->flat / 8, kps);
+        SRLX_HIP(hipGetLastError());
+        return SRLX_OK;
+    }
     static const int abl = getenv("SRLX_FC1_ABL") ? atoi(getenv("SRLX_FC1_ABL")) : 0;  // measurement only: results are garbage for abl != 0
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, (const uint4 *)h->a3_planes, (const uint4 *)h->wf_planes, h->partial, (int)rows, N1, h->flat / 8, kps);

@@ -884,6 +884,7 @@ struct AddArgs {
     int track_max;   // raise max_priority like update() does (:176-177)
     double maxp_snapshot;  // bulk path only: filled from *maxp_dev by the leaf kernel's caller
     const double *maxp_dev;
+    i64 *bump0, *bump1;  // srlx_per_set_add_counters: int64 device counters an appending add advances by one (NULL: none)
 };
 
 __device__ __forceinline__ i64 add_start(const AddArgs &a) { return a.start_slot >= 0 ? a.start_slot : a.state->write; }
@@ -908,6 +909,8 @@ __device__ __forceinline__ void add_commit(const AddArgs &a) {
     s->write = w;
     i64 z = s->size + a.n;
     s->size = z > a.cap ? a.cap : z;
+    if (a.bump0) *a.bump0 += 1;  // readers of these counters ran in earlier launches of the stream
+    if (a.bump1) *a.bump1 += 1;
 }
 
 // n <= kSmallAddMax: everything in one launch; the per-leaf changes live in LDS so that the root
@@ -987,6 +990,7 @@ struct srlx_per {
     PerState *d_state;
     int *d_err;
     i64 *d_update_counter;  // BORROWED (srlx_per_set_update_counter) or NULL
+    i64 *d_add_counter[2];  // BORROWED (srlx_per_set_add_counters) or NULL
     i64 size, write;  // host mirror
     srlx::Arena scratch;  // device
     srlx::Arena staging;  // device copies of host-mode arguments / results
@@ -1004,7 +1008,7 @@ int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st,
     const bool append = start_slot < 0;
     double *snap = (double *)((char *)h->scratch.ptr + srlx::Carver::padded((size_t)n * 8));
     AddArgs a{h->tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr,
-              start_slot, append ? 1 : 0, append ? 0 : 1, 0.0, snap};
+              start_slot, append ? 1 : 0, append ? 0 : 1, 0.0, snap, append ? h->d_add_counter[0] : nullptr, append ? h->d_add_counter[1] : nullptr};
     if (n <= kSmallAddMax) {
         hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(n <= 1024 ? kWgAdd : 1024), (size_t)n * sizeof(double), st, a);
     } else {
@@ -1216,6 +1220,13 @@ int srlx_per_set_has_duplicate(srlx_per_t *h, int has_duplicate) {
 int srlx_per_set_update_counter(srlx_per_t *h, int64_t *d_counter) {
     SRLX_REQUIRE(h, "per_set_update_counter: NULL handle");
     h->d_update_counter = d_counter;
+    return SRLX_OK;
+}
+
+int srlx_per_set_add_counters(srlx_per_t *h, int64_t *d_counter0, int64_t *d_counter1) {
+    SRLX_REQUIRE(h, "per_set_add_counters: NULL handle");
+    h->d_add_counter[0] = d_counter0;
+    h->d_add_counter[1] = d_counter1;
     return SRLX_OK;
 }
 

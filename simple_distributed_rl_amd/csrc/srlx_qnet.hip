@@ -477,7 +477,7 @@ constexpr int kMaxActions = 32;
 __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial, int splits, i64 M, int hidden, const float *__restrict__ b1,
                                               const float *__restrict__ v2w, const float *__restrict__ v2b, const float *__restrict__ a2w,
                                               const float *__restrict__ a2b, int A, int dueling, float *__restrict__ q, float *__restrict__ h1, i64 ostride,
-                                              i64 *__restrict__ draw) {
+                                              i64 *__restrict__ draw, srlx_qnet::Policy pol) {
     __shared__ float red[8][kMaxActions + 1];  // one row per wave (256 or 512 threads)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const i64 m = blockIdx.x;
@@ -550,7 +550,43 @@ __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial,
         const float sub = dueling == 0 ? mean : (dueling == 1 ? mx : 0.f);  // "average" / "max" / "" (dueling_network.py:49-56)
 #pragma unroll
         for (int j = 0; j < kMaxActions; j++)
-            if (j < A) q[mo * A + j] = v + out[j] - sub;
+            if (j < A) {
+                out[j] = v + out[j] - sub;
+                q[mo * A + j] = out[j];
+                if (pol.q_copy) pol.q_copy[mo * A + j] = out[j];
+            }
+        // ---- the batched Worker.policy step's selection (rainbow.py:301-329), fused: epsilon-greedy on the Q row this thread has just finished, with the two
+        //      uniforms srlx_rng_uniform(seed, counter, 2 E) would have written for the row (u[2 e], u[2 e + 1]); arithmetic = k_eps_greedy (srlx_rollout.hip).
+        //      The counter is only READ here (one workgroup per row): the caller advances it once per pass, in a later launch.
+        if (pol.actions) {
+            const unsigned long long c = (unsigned long long)pol.counter[0];
+            const unsigned char *inv = pol.invalid ? pol.invalid + m * A : nullptr;
+            int act = 0;
+            if (srlx::u53(srlx::rng_u64(pol.seed, c, (unsigned long long)(2 * m))) < (double)pol.eps[m]) {  // random.random() < epsilon (:317)
+                int nv = 0;
+                for (int a = 0; a < A; a++) nv += !(inv && inv[a]);
+                int pick = (int)(srlx::u53(srlx::rng_u64(pol.seed, c, (unsigned long long)(2 * m + 1))) * (double)nv);
+                if (pick >= nv) pick = nv - 1;
+                for (int a = 0; a < A; a++) {
+                    if (inv && inv[a]) continue;
+                    if (pick == 0) {
+                        act = a;
+                        break;
+                    }
+                    pick--;
+                }
+            } else {  // q[invalid] = -inf; first maximum, like np.argmax (:321-325)
+                float bv = -INFINITY;
+                bool have = false;
+#pragma unroll
+                for (int a = 0; a < kMaxActions; a++)
+                    if (a < A) {
+                        const float x = (inv && inv[a]) ? -INFINITY : out[a];
+                        if (!have || x > bv) act = a, bv = x, have = true;
+                    }
+            }
+            pol.actions[m] = act;
+        }
     }
 }
 
@@ -669,6 +705,9 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     const i64 tiles = ((B + BM - 1) / BM) * ((N1 + 63) / 64);
     int splits = (int)((512 + tiles - 1) / tiles);  // (1024 workgroups for the learner's 96 / 128 rows: measured no faster)
     const int ksteps = h->flat / BK;
+    static const int force_splits = getenv("SRLX_FC1_SPLITS") ? atoi(getenv("SRLX_FC1_SPLITS")) : 0;  // measurement: workgroup granularity of the chip-filling launches
+    if (force_splits > 0 && B >= 512) splits = force_splits;
+    if (h->fc1_neighbour > 0 && h->planes_valid && srlx_fc1_planes_applicable(h, B) && force_splits <= 0) splits = h->fc1_neighbour;
     if (splits > ksteps) splits = ksteps;
     if (splits > h->max_splits) splits = h->max_splits;
     if (splits < 1) splits = 1;
@@ -676,7 +715,8 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     const int used = (ksteps + kps - 1) / kps;  // splits that actually own a K range
     static const bool fc1_f32 = getenv("SRLX_FC1_F32") && getenv("SRLX_FC1_F32")[0] == '1';  // A/B switch: FC1 on the float32 matrix pipe
     // chip-filling launches of a handle with valid weight planes (the actors' pass): conversion-free GEMM on pre-split operands, bit-identical to k_gemm_s16
-    const bool planes = !fc1_f32 && stride == 1 && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, B);
+    static const bool no_planes_gemm = getenv("SRLX_NO_PLANES_GEMM") && getenv("SRLX_NO_PLANES_GEMM")[0] == '1';  // measurement only (a selected set's pass then reads the BOUND float32 weight)
+    const bool planes = !fc1_f32 && !no_planes_gemm && stride == 1 && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, B);
     if (planes && !h->a3_planes_fresh) SRLX_TRY(srlx_fc1_planes_split_act(h, B, st));  // (a convolution path that wrote float32 act3 only)
     h->a3_planes_fresh = false;
     if (h->probe_fc0) SRLX_HIP(hipEventRecord(h->probe_fc0, st));
@@ -694,7 +734,8 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     h->probe_fc0 = h->probe_fc1 = nullptr;  // one forward only
     // small launches (the learner's 128 / 96 rows) are one workgroup per row and far from filling the chip: twice the threads per row
     hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(B <= 256 && h->hidden > 256 ? 512 : 256), 0, st, h->partial, used, B, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
-                       h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, h->sig[0] ? h->d_draw : nullptr);
+                       h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, h->sig[0] ? h->d_draw : nullptr, h->pol);
+    h->pol = srlx_qnet::Policy{};  // one forward only
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }
@@ -751,6 +792,7 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
     h->flat = h->OH3 * h->OW3 * 2 * filters;
     h->max_batch = max_batch;
     h->max_splits = 64;
+    h->aset_cur = -1;
     SRLX_REQUIRE(h->flat % BK == 0, "qnet_create: flattened size %d must be a multiple of %d", h->flat, BK);
     const size_t f = sizeof(float);
     struct {
@@ -760,7 +802,8 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
                 {&h->act2, (size_t)max_batch * h->OH2 * h->OW2 * 2 * filters},
                 {&h->act3, (size_t)max_batch * h->flat},
                 // FC1 split-K partial sums: splits(B) * B <= 4096 + B for every batch B (see run_tail)
-                {&h->partial, (size_t)(4096 + 128 + max_batch) * 2 * hidden}};
+                {&h->partial, (size_t)(4096 + 128 + max_batch * (getenv("SRLX_FC1_SPLITS") ? atoi(getenv("SRLX_FC1_SPLITS")) : 1)) * 2 * hidden}};
+    h->partial_floats = bufs[3].n;
     for (auto &b : bufs) {
         hipError_t e = hipMalloc((void **)b.p, b.n * f);
         if (e != hipSuccess) {
@@ -783,6 +826,12 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     for (float *p : h->eff)
         if (p) (void)hipFree(p);
     if (h->d_draw) (void)hipFree(h->d_draw);
+    if (h->aset_cur >= 0) h->wpack = h->wpack_own, h->wf_planes = h->wf_planes_own;
+    for (auto &st_ : h->aset) {
+        if (st_.wpack) (void)hipFree(st_.wpack);
+        if (st_.wf_planes) (void)hipFree(st_.wf_planes);
+        if (st_.small) (void)hipFree(st_.small);
+    }
     if (h->wpack) (void)hipFree(h->wpack);
     if (h->wf_planes) (void)hipFree(h->wf_planes);
     if (h->a3_planes) (void)hipFree(h->a3_planes);
@@ -796,6 +845,13 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
 int srlx_qnet_bind(srlx_qnet_t *h, const float *const *p) {
     SRLX_REQUIRE(h && p, "qnet_bind: NULL argument");
     for (int i = 0; i < 12; i++) SRLX_REQUIRE(p[i], "qnet_bind: parameter %d is NULL", i);
+    for (int i = 0; i < 12; i++) h->bound[i] = p[i];
+    h->pack_valid = false;  // other weights: the packed filters are stale
+    if (h->aset_cur >= 0) {  // forwards keep reading the selected set; the filters / first dense layer it was made from are the bound ones
+        h->w1 = p[0], h->w2 = p[2], h->w3 = p[4], h->wf = p[6];
+        h->pack_valid = true;
+        return SRLX_OK;
+    }
     h->w1 = p[0], h->b1 = p[1], h->w2 = p[2], h->b2 = p[3], h->w3 = p[4], h->b3 = p[5];
     if (h->eff[0]) {  // NoisyLinear: the dense-layer entries are the mu tensors; the kernels keep reading the effective tensors
         for (int t = 0; t < 6; t++) h->mu[t] = p[6 + t];
@@ -856,6 +912,115 @@ int srlx_qnet_set_probe_fc1(srlx_qnet_t *h, void *ev_start, void *ev_end) {
     return SRLX_OK;
 }
 
+// ---- packed filters that outlive a forward, and the actors' published parameter sets (srlx_qnet_int.h) ----------------------------------------------------
+int srlx_qnet_weights_changed(srlx_qnet_t *h) {
+    SRLX_REQUIRE(h, "qnet_weights_changed: NULL handle");
+    h->pack_valid = h->aset_cur >= 0;  // (a selected set is what it is: republish it)
+    if (h->aset_cur < 0) h->planes_valid = false;
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_pack_sticky(srlx_qnet_t *h, int on) {
+    SRLX_REQUIRE(h, "qnet_set_pack_sticky: NULL handle");
+    h->pack_sticky = on != 0;
+    if (!on && h->aset_cur < 0) h->pack_valid = false;
+    return SRLX_OK;
+}
+
+int srlx_qnet_actor_sets_enable(srlx_qnet_t *h) {
+    SRLX_REQUIRE(h, "qnet_actor_sets_enable: NULL handle");
+    SRLX_REQUIRE(!h->eff[0], "qnet_actor_sets_enable: NoisyLinear layers draw new effective weights per forward: nothing to publish");
+    SRLX_REQUIRE(h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32, "qnet_actor_sets_enable: the published sets serve the fused convolution kernel's geometry (84 x 84 x 4, 32 filters)");
+    srlx::DeviceGuard guard(h->device);
+    SRLX_TRY(srlx_fc1_planes_alloc(h));
+    const srlx_small_layout L = srlx_small_offsets(h);
+    for (auto &st_ : h->aset) {
+        if (st_.wpack) continue;
+        SRLX_HIP(hipMalloc((void **)&st_.wpack, srlx_qnet_pack_bytes()));
+        SRLX_HIP(hipMalloc((void **)&st_.wf_planes, srlx_fc1_planes_weight_bytes(h)));
+        SRLX_HIP(hipMalloc((void **)&st_.small, (size_t)L.total * sizeof(float)));
+        SRLX_HIP(hipMemset(st_.small, 0, (size_t)L.total * sizeof(float)));
+    }
+    return SRLX_OK;
+}
+
+int srlx_qnet_actor_set_planes(srlx_qnet_t *h, int set, void **d_planes) {
+    SRLX_REQUIRE(h && d_planes && (set == 0 || set == 1) && h->aset[set].wf_planes, "qnet_actor_set_planes: bad argument (srlx_qnet_actor_sets_enable first)");
+    *d_planes = h->aset[set].wf_planes;
+    return SRLX_OK;
+}
+
+int srlx_qnet_actor_set_select(srlx_qnet_t *h, int set) {
+    SRLX_REQUIRE(h && set >= -1 && set <= 1, "qnet_actor_set_select: bad argument");
+    SRLX_REQUIRE(set < 0 || h->aset[set].wpack, "qnet_actor_set_select: srlx_qnet_actor_sets_enable first");
+    if (h->aset_cur < 0 && set >= 0) h->wpack_own = h->wpack, h->wf_planes_own = h->wf_planes;
+    if (set < 0) {
+        if (h->aset_cur >= 0) {
+            h->wpack = h->wpack_own, h->wf_planes = h->wf_planes_own;
+            h->b1 = h->bound[1], h->b2 = h->bound[3], h->b3 = h->bound[5];
+            h->bf = h->bound[7], h->v2w = h->bound[8], h->v2b = h->bound[9], h->a2w = h->bound[10], h->a2b = h->bound[11];
+            h->pack_valid = false, h->planes_valid = false;
+        }
+        h->aset_cur = -1;
+        return SRLX_OK;
+    }
+    const srlx_small_layout L = srlx_small_offsets(h);
+    const srlx_qnet::ActorSet &a = h->aset[set];
+    h->wpack = a.wpack, h->wf_planes = a.wf_planes;
+    h->b1 = a.small + L.b1, h->b2 = a.small + L.b2, h->b3 = a.small + L.b3;
+    h->bf = a.small + L.bf, h->v2w = a.small + L.v2w, h->v2b = a.small + L.v2b, h->a2w = a.small + L.a2w, h->a2b = a.small + L.a2b;
+    h->pack_valid = true, h->planes_valid = true;
+    h->aset_cur = set;
+    return SRLX_OK;
+}
+
+// Packs `h_src`'s convolution filters for ITS next forwards (they then skip k_pack_filters until srlx_qnet_weights_changed / the next publish) and, with `h_actor`,
+// publishes the network into that handle's set `set`: packed filters + small vectors in the same launch; `with_fc1`: also the first dense layer's weight as
+// operand planes (one splitting pass -- the initial / out-of-band publish; an update publishes them from the fused Adam's epilogue, srlx_qnet_fuse_adam_fc1_planes).
+int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int with_fc1, void *stream) {
+    SRLX_REQUIRE(h_src && h_src->bound[0], "qnet_publish: no parameters bound on the source handle");
+    SRLX_REQUIRE(!h_src->eff[0], "qnet_publish: NoisyLinear source");
+    SRLX_REQUIRE(h_src->H == 84 && h_src->W == 84 && h_src->Wn == 4 && h_src->F1 == 32, "qnet_publish: the fused convolution kernel's geometry only");
+    srlx::DeviceGuard guard(h_src->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (!h_actor) {
+        SRLX_TRY(srlx_qnet_pack_publish(h_src, nullptr, nullptr, st));
+        h_src->pack_valid = true;
+        return SRLX_OK;
+    }
+    SRLX_REQUIRE((set == 0 || set == 1) && h_actor->aset[set].wpack, "qnet_publish: srlx_qnet_actor_sets_enable on the actor handle first");
+    SRLX_REQUIRE(h_actor->hidden == h_src->hidden && h_actor->A == h_src->A && h_actor->flat == h_src->flat, "qnet_publish: the two handles describe different networks");
+    const srlx_small_layout L = srlx_small_offsets(h_actor);
+    SRLX_TRY(srlx_qnet_pack_publish(h_src, &h_actor->aset[set], &L, st));
+    if (h_src->aset_cur < 0) h_src->pack_valid = true;
+    if (with_fc1) SRLX_TRY(srlx_fc1_planes_split_weight(h_actor, h_src->bound[6], nullptr, st, h_actor->aset[set].wf_planes));
+    return SRLX_OK;
+}
+
+// splits > 0: the chip-filling first-dense-layer launches of this handle (operand planes) use half-CU workgroups (k_fc1_planes_h) with `splits` K splits -- for a
+// handle whose passes run BESIDE a learner; 0: the CU-filling k_fc1_planes (fastest alone).
+int srlx_qnet_set_fc1_neighbour(srlx_qnet_t *h, int splits) {
+    SRLX_REQUIRE(h && splits >= 0 && splits <= 64, "qnet_set_fc1_neighbour: bad argument");
+    srlx::DeviceGuard guard(h->device);
+    const size_t need = (size_t)splits * h->max_batch * 2 * h->hidden;
+    if (need > h->partial_floats) {  // split-K partial slabs of the chip-filling launch
+        SRLX_HIP(hipDeviceSynchronize());
+        if (h->partial) SRLX_HIP(hipFree(h->partial));
+        h->partial = nullptr;
+        SRLX_HIP(hipMalloc((void **)&h->partial, need * sizeof(float)));
+        h->partial_floats = need;
+    }
+    h->fc1_neighbour = splits;
+    return SRLX_OK;
+}
+
+int srlx_qnet_fuse_adam_fc1_planes(srlx_qnet_t *h, void *d_planes_out) {
+    SRLX_REQUIRE(h, "qnet_fuse_adam_fc1_planes: NULL handle");
+    SRLX_REQUIRE(!d_planes_out || h->adam_m, "qnet_fuse_adam_fc1_planes: srlx_qnet_fuse_adam_fc1 first (the planes ride on the fused Adam epilogue)");
+    h->adam_planes_out = d_planes_out;
+    return SRLX_OK;
+}
+
 // conv1 -> conv2 -> conv3 from the uint8 ring into h->act3, then (d_q != NULL) the dense layers
 static int forward_u8_impl(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, hipStream_t st) {
     static const bool no_fused = getenv("SRLX_NO_FUSED_CONV") && getenv("SRLX_NO_FUSED_CONV")[0] == '1';  // A/B switch for measurements
@@ -886,6 +1051,18 @@ int srlx_qnet_forward_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_b
     SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_u8: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
     srlx::DeviceGuard guard(h->device);
     return forward_u8_impl(h, batch, d_frame_base, d_frame_off, d_q, (hipStream_t)stream);
+}
+
+int srlx_qnet_forward_u8_policy(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_q, const float *d_eps, uint64_t seed,
+                                const int64_t *d_counter, const uint8_t *d_invalid, int32_t *d_actions, float *d_q_copy, void *stream) {
+    SRLX_REQUIRE(h && d_frame_base && d_frame_off && d_q && d_eps && d_counter && d_actions, "qnet_forward_u8_policy: NULL argument");
+    SRLX_REQUIRE(h->bound[0], "qnet_forward_u8_policy: no parameters bound (srlx_qnet_bind)");
+    SRLX_REQUIRE(batch > 0 && batch <= h->max_batch, "qnet_forward_u8_policy: batch %lld exceeds max_batch %lld", (long long)batch, (long long)h->max_batch);
+    srlx::DeviceGuard guard(h->device);
+    h->pol = srlx_qnet::Policy{d_eps, (unsigned long long)seed, d_counter, d_invalid, d_actions, d_q_copy};
+    const int rc = forward_u8_impl(h, batch, d_frame_base, d_frame_off, d_q, (hipStream_t)stream);
+    h->pol = srlx_qnet::Policy{};
+    return rc;
 }
 
 int srlx_qnet_forward_convs_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, float *d_features, void *stream) {

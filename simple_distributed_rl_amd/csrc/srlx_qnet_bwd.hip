@@ -146,10 +146,13 @@ __global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden
 // 16 weights and their two moment estimates in place (their loads are issued before the MFMAs): 226 MB of traffic for
 // "write g, then Adam" becomes 161 MB, and the update of 97 % of the parameters runs beside the convolution gradients instead
 // of after them.  Both variants run the same instruction sequence, so the fused update is bit-equal to the separate one.
-template <bool ADAM>
+// PLANES (with ADAM): the updated weight is ALSO written as the three bf16 part planes the actors' first dense layer multiplies (srlx_fc1_planes.hip, weight layout
+// [K/32 slabs][N1 rows][3 parts][4 k-groups][8 bf16]): a lane holds column k0 + i of sixteen rows, so part p of a row's 32 k is 64 contiguous bytes written by the
+// 32 lanes of a half-wave, two bytes each -- the actors' private copy of 97 % of the parameters needs neither a copy nor a splitting pass on the lock-step's tail.
+template <bool ADAM, bool PLANES = false>
 __global__ void __launch_bounds__(256) k_fc1_wgrad(int B, i64 sstride, int N1, int K, const float *__restrict__ dh1, const float *__restrict__ act3,
                                                    float *__restrict__ g_wf, float *__restrict__ wf, float *__restrict__ m, float *__restrict__ v, double lr, double beta1,
-                                                   double beta2, double eps, const i64 *__restrict__ d_step) {
+                                                   double beta2, double eps, const i64 *__restrict__ d_step, __bf16 *__restrict__ planes = nullptr) {
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32, n0 = blockIdx.y * 32;
     if (k0 >= K) return;  // (wave-uniform; no barriers in this kernel)
@@ -183,6 +186,16 @@ __global__ void __launch_bounds__(256) k_fc1_wgrad(int B, i64 sstride, int N1, i
             const i64 at = (i64)(n0 + (r & 3) + 8 * (r >> 2) + 4 * h) * K + k0 + i;
             srlx::adam_one(pp[r], acc[r], mm[r], vv[r], c);
             wf[at] = pp[r], m[at] = mm[r], v[at] = vv[r];
+            if (PLANES) {
+                __bf16 *row = planes + (((i64)(k0 >> 5) * N1 + n0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 96) + i;  // 96 bf16 per (slab, row); part p at + 32 p
+                float x = pp[r];
+#pragma unroll
+                for (int p = 0; p < 3; p++) {
+                    const __bf16 b = (__bf16)x;
+                    row[32 * p] = b;
+                    x -= (float)b;
+                }
+            }
         }
     } else {
 #pragma unroll
@@ -621,8 +634,14 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     hipLaunchKernelGGL(k_conv_wgrad_mfma<32>, dim3((16 * 2 * 1 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g2, ss, h->act1, h->dact2, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2);
     if (with_fc1 && h->adam_m)  // Adam in the epilogue updates the weights in place: (long) after ev_d3, when the data gradient has read them
-        hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
-                           h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
+    {
+        if (h->adam_planes_out)
+            hipLaunchKernelGGL((k_fc1_wgrad<true, true>), fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v,
+                               h->adam_lr, h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step, (__bf16 *)h->adam_planes_out);
+        else
+            hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
+                               h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
+    }
     SRLX_HIP(hipEventRecord(h->ev_join, sd));
     // conv1's weight gradient needs the END of the data-gradient chain: it follows it on the caller's stream instead of queueing behind
     // the conv2 / conv3 weight gradients on the side stream

@@ -56,11 +56,30 @@ constexpr int kPackFloats = kW1 + kW2 + kW3 + kW1B + kW2B + kW3B;
 // A training handle's launch also builds the transposed filters of the backward pass's two data-gradient GEMMs (wT3 / wT2: layout of
 // k_transpose_filter in srlx_qnet_bwd.hip) -- they depend on the weights only, and the weights do not change between this forward and
 // its backward, so two launches leave the learner's critical path.
+// `out2` (optional): a second copy of the packed buffer -- an actor handle's published set (srlx_qnet_publish) -- and `sm`: the network's small vectors
+// (biases, the head's second layers) copied element by element into that set's block by the threads behind the packing ranges.
+struct SmallCopy {
+    const float *src[8];
+    int off[9];  // destination offsets (floats); off[8] = total
+    int len[8];  // elements of each vector (the padding behind it is never read or written)
+    float *dst;  // NULL: nothing to copy
+    int first;   // first thread index of the copy range
+};
 __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
-                                                      float *__restrict__ out, float *__restrict__ wT3, float *__restrict__ wT2) {
+                                                      float *__restrict__ out, float *__restrict__ wT3, float *__restrict__ wT2, float *__restrict__ out2, SmallCopy sm) {
     // one thread per float4 of the packed float32 buffer, then one per (step, lane) of conv1's split-bf16 fragments
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = (kW1 + kW2 + kW3) / 4;
+    if (sm.dst && q >= sm.first) {
+        const int x = q - sm.first;
+        if (x >= sm.off[8]) return;
+        int v = 0;
+#pragma unroll
+        for (int k = 1; k < 8; k++) v += x >= sm.off[k] ? 1 : 0;
+        const int j = x - sm.off[v];
+        if (j < sm.len[v]) sm.dst[x] = sm.src[v][j];
+        return;
+    }
     if (q >= n4 && q < n4 + 16 * 64) {
         // conv1 on the bf16 matrix pipe, exactly: w / 255 (float32, as the float32 path folds it) = p0 + p1 + p2 with three bf16 parts (8 + 8 + 8
         // mantissa bits; each remainder is exact in float32), the pixel operand is a uint8 and exact in ONE bf16, every partial product is exact in
@@ -80,6 +99,11 @@ __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ 
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(out + kW1 + kW2 + kW3);
 #pragma unroll
         for (int t = 0; t < 3; t++) dst[(step * 3 + t) * 64 + lane] = part[t];
+        if (out2) {
+            bf16x8 *d2 = reinterpret_cast<bf16x8 *>(out2 + kW1 + kW2 + kW3);
+#pragma unroll
+            for (int t = 0; t < 3; t++) d2[(step * 3 + t) * 64 + lane] = part[t];
+        }
         return;
     }
     if (q >= n4 + 16 * 64 && q < n4 + 16 * 64 + (32 + 36) * 2 * 64) {
@@ -105,6 +129,11 @@ __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ 
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(out + kW1 + kW2 + kW3 + kW1B + (third ? kW2B : 0));
 #pragma unroll
         for (int t = 0; t < 3; t++) dst[((step * 2 + nt) * 3 + t) * 64 + lane] = part[t];
+        if (out2) {
+            bf16x8 *d2 = reinterpret_cast<bf16x8 *>(out2 + kW1 + kW2 + kW3 + kW1B + (third ? kW2B : 0));
+#pragma unroll
+            for (int t = 0; t < 3; t++) d2[((step * 2 + nt) * 3 + t) * 64 + lane] = part[t];
+        }
         return;
     }
     if (q >= n4) {
@@ -128,7 +157,9 @@ __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ 
     const int lane = local & 63, v = (local >> 6) & 3, rest = local >> 8;  // rest = slab * tiles + nt
     const int nt = rest % tiles, slab = rest / tiles;
     const int i = lane & 31, hh = lane >> 5;
-    reinterpret_cast<float4 *>(out)[q] = *reinterpret_cast<const float4 *>(src + (i64)(nt * 32 + i) * K + slab * 32 + 16 * hh + 4 * v);
+    const float4 val = *reinterpret_cast<const float4 *>(src + (i64)(nt * 32 + i) * K + slab * 32 + 16 * hh + 4 * v);
+    reinterpret_cast<float4 *>(out)[q] = val;
+    if (out2) reinterpret_cast<float4 *>(out2)[q] = val;
 }
 
 // one 32 (pixels) x 32 (channels) tile of a convolution whose input sits in LDS (pixel-major, `stride` floats per pixel):
@@ -655,6 +686,35 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
 
 }  // namespace
 
+size_t srlx_qnet_pack_bytes() { return (size_t)kPackFloats * sizeof(float); }
+
+// k_pack_filters over `src`'s bound filters into its own packed buffer (+ the transposed filters of a training handle) and, with `dst_set`, a second copy
+// into an actor set together with the small vectors (layout *L)
+int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st) {
+    float *&own = src->aset_cur >= 0 ? src->wpack_own : src->wpack;
+    if (!own) SRLX_HIP(hipMalloc((void **)&own, (size_t)kPackFloats * sizeof(float)));
+    const bool keep = src->max_train > 0;
+    const float *const *b = src->aset_cur >= 0 ? src->bound : nullptr;  // a handle reading a set still packs its BOUND weights
+    const float *w1 = b ? b[0] : src->w1, *w2 = b ? b[2] : src->w2, *w3 = b ? b[4] : src->w3;
+    int pack_threads = (kW1 + kW2 + kW3) / 4 + 16 * 64 + (32 + 36) * 2 * 64 + (keep ? kW3 + kW2 : 0);
+    SmallCopy sm{};
+    if (dst_set) {
+        const float *v[8] = {b ? b[1] : src->b1, b ? b[3] : src->b2, b ? b[5] : src->b3, b ? b[7] : src->bf, b ? b[8] : src->v2w, b ? b[9] : src->v2b,
+                             b ? b[10] : src->a2w, b ? b[11] : src->a2b};
+        const int off[9] = {L->b1, L->b2, L->b3, L->bf, L->v2w, L->v2b, L->a2w, L->a2b, L->total};
+        const int len[8] = {src->F1, 2 * src->F1, 2 * src->F1, 2 * src->hidden, src->hidden, 1, src->A * src->hidden, src->A};
+        for (int k = 0; k < 8; k++) sm.src[k] = v[k], sm.len[k] = len[k];
+        for (int k = 0; k < 9; k++) sm.off[k] = off[k];
+        sm.dst = dst_set->small;
+        sm.first = ((pack_threads + 255) / 256) * 256;
+        pack_threads = sm.first + L->total;
+    }
+    hipLaunchKernelGGL(k_pack_filters, dim3((pack_threads + 255) / 256), dim3(256), 0, st, w1, w2, w3, own, keep ? src->w_t : nullptr, keep ? src->w_t2 : nullptr,
+                       dst_set ? dst_set->wpack : nullptr, sm);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
 // Launcher: true when the fused kernel covers this handle's geometry (then act3 -- and act1 / act2 when training is enabled -- are valid).
 bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st) {
     if (!(h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32)) return false;
@@ -668,13 +728,11 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
             if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess) return false;
         attr_set = true;
     }
-    if (!h->wpack) {
-        if (hipMalloc((void **)&h->wpack, (size_t)kPackFloats * sizeof(float)) != hipSuccess) return false;
-    }
     const bool keep = h->max_train > 0;  // a training handle: the backward pass reads act1 / act2 and the transposed filters
-    const int pack_threads = (kW1 + kW2 + kW3) / 4 + 16 * 64 + (32 + 36) * 2 * 64 + (keep ? kW3 + kW2 : 0);
-    hipLaunchKernelGGL(k_pack_filters, dim3((pack_threads + 255) / 256), dim3(256), 0, st, h->w1, h->w2, h->w3, h->wpack, keep ? h->w_t : nullptr,
-                       keep ? h->w_t2 : nullptr);
+    if (!h->pack_valid) {  // (valid: packed right after the last optimiser step by srlx_qnet_publish, a selected actor set, or a sticky pack of unchanged weights)
+        if (srlx_qnet_pack_publish(h, nullptr, nullptr, st) != SRLX_OK) return false;
+        h->pack_valid = h->pack_sticky;
+    }
     h->wt_from_forward = keep;
     static const bool c1_f32 = getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1';  // A/B switch: conv1 on the float32 matrix pipe
     float *out3 = h->act3;
@@ -685,7 +743,8 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
     if (h->probe0 && hipEventRecord(h->probe0, st) != hipSuccess) return false;  // measurement hook: exactly this kernel, on its launch stream
     // the dense layers will run on operand planes (srlx_qnet_dense_rows's own condition): conv3 writes them itself, float32 act3 is not produced
-    static const bool no_planes_out = getenv("SRLX_NO_CONV_PLANES") && getenv("SRLX_NO_CONV_PLANES")[0] == '1';  // A/B switch: float32 act3 + a split pass
+    static const bool no_planes_out = (getenv("SRLX_NO_CONV_PLANES") && getenv("SRLX_NO_CONV_PLANES")[0] == '1') ||  // A/B switch: float32 act3 + a split pass
+                                      (getenv("SRLX_NO_PLANES_GEMM") && getenv("SRLX_NO_PLANES_GEMM")[0] == '1');
     h->a3_planes_fresh = false;
     if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && !keep && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch)) {
         out3 = reinterpret_cast<float *>(h->a3_planes);

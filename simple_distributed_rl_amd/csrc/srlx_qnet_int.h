@@ -47,7 +47,54 @@ struct srlx_qnet {
     bool planes_valid;                    // wf_planes holds the weight the next forward should use
     bool a3_planes_fresh;                 // the convolution kernel of THIS forward wrote a3_planes itself
     bool want_planes_out;                 // this forward continues into the dense layers (set by forward_u8_impl; a convs-only call needs float32 act3)
+    // ---- round 4: weights handed from the learner to the actors without a copy on the lock-step's serial tail ----
+    // packed filters that stay valid between forwards: srlx_qnet_publish packs them right after the optimiser step (the NEXT forward of this handle skips
+    // k_pack_filters); `pack_sticky`: a forward's own pack stays valid too (a target network: its weights change at a sync only).  srlx_qnet_weights_changed clears.
+    bool pack_valid, pack_sticky;
+    // an ACTOR handle's two published parameter sets (srlx_qnet_actor_sets_enable): everything a policy pass reads -- packed convolution filters, the first dense
+    // layer as bf16 operand planes, biases and the head's vectors -- written by the learner's update (srlx_qnet_publish + the fused Adam's plane epilogue) into the
+    // set the actors are NOT reading; srlx_qnet_actor_set_select flips which one the next forwards read.
+    struct ActorSet {
+        float *wpack;     // kPackFloats
+        void *wf_planes;  // [flat/32][2 hidden][3 parts][4 k-groups][8 bf16]
+        float *small;     // b1 | b2 | b3 | bf | v2w | v2b | a2w | a2b (each padded to 4 floats)
+    } aset[2];
+    int aset_cur;                         // -1: the bound parameters; 0 / 1: forwards read this set
+    float *wpack_own;                     // this handle's own packed-filter buffer while a set is selected
+    void *wf_planes_own;
+    const float *bound[12];               // what srlx_qnet_bind bound (restored by srlx_qnet_actor_set_select(h, -1))
+    int fc1_neighbour;                    // > 0: chip-filling first-dense-layer launches use k_fc1_planes_h (half-CU workgroups) with this many K splits
+    size_t partial_floats;                // allocation of `partial`
+    void *adam_planes_out;                // the fused Adam of the first dense layer ALSO writes the updated weight as operand planes here (NULL: off)
+    // epsilon-greedy fused into the head kernel of the NEXT forward (srlx_qnet_forward_u8_policy)
+    struct Policy {
+        const float *eps;
+        unsigned long long seed;
+        const int64_t *counter;
+        const unsigned char *invalid;
+        int32_t *actions;
+        float *q_copy;
+    } pol;
 };
+
+// offsets (floats) of the vectors inside ActorSet::small
+struct srlx_small_layout {
+    int b1, b2, b3, bf, v2w, v2b, a2w, a2b, total;
+};
+inline srlx_small_layout srlx_small_offsets(const srlx_qnet *h) {
+    auto pad = [](int n) { return (n + 3) & ~3; };
+    srlx_small_layout L;
+    L.b1 = 0;
+    L.b2 = L.b1 + pad(h->F1);
+    L.b3 = L.b2 + pad(2 * h->F1);
+    L.bf = L.b3 + pad(2 * h->F1);
+    L.v2w = L.bf + pad(2 * h->hidden);
+    L.v2b = L.v2w + pad(h->hidden);
+    L.a2w = L.v2b + 4;
+    L.a2b = L.a2w + pad(h->A * h->hidden);
+    L.total = L.a2b + pad(h->A);
+    return L;
+}
 
 // srlx_noisy.hip: (re)materialise the effective dense-layer tensors with a fresh draw (no-op for a plain network)
 int srlx_qnet_noisy_refresh(srlx_qnet *h, hipStream_t st);
@@ -61,7 +108,12 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
 
 // srlx_fc1_planes.hip: the first dense layer of chip-filling launches as a conversion-free GEMM on pre-split bf16 operand planes
 int srlx_fc1_planes_alloc(srlx_qnet *h);
-int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst, hipStream_t st);
+int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst, hipStream_t st, void *planes_dst = nullptr);
+size_t srlx_fc1_planes_weight_bytes(const srlx_qnet *h);
+// srlx_qnet_fused.hip: pack `src`'s convolution filters (its own wpack + transposed filters when it trains) and, with `dst_set`, also into an actor set together
+// with the small vectors
+int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st);
+size_t srlx_qnet_pack_bytes();
 int srlx_fc1_planes_split_act(srlx_qnet *h, int64_t rows, hipStream_t st);
 bool srlx_fc1_planes_applicable(const srlx_qnet *h, int64_t rows);
 int srlx_fc1_planes_gemm(srlx_qnet *h, int64_t rows, int splits, int kps, hipStream_t st);

@@ -167,41 +167,21 @@ __global__ void k_reset_all(StoreDev s, const void *first_obs) {
     if (blockIdx.x == 0 && threadIdx.x == 0) s.pos[0] = 0;
 }
 
-// scalar part of a commit, one thread per env
-__global__ void __launch_bounds__(256) k_commit_scalars(StoreDev s, const int32_t *actions, const float *rewards,
-                                                         const u8 *terminated, const u8 *done, u8 *item_mask) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= s.E) return;
+__global__ void k_advance(i64 *counter) { counter[0] += 1; }
+
+// ---- one lock-step commit as ONE launch (k_commit_frames + k_commit_scalars + k_advance + the next lock-step's k_frame_table_current) ----------
+// Every block copies its share of the frames (grid-stride, 16 B per lane); the first ceil(E / 256) blocks also do the per-environment scalars, the
+// item mask and -- a pure function of (environment, p + 1, the step_in_ep value this thread has just written) -- the frame-offset table of the NEXT
+// policy pass.  advance != 0: the ring position moves inside the launch.  Every block reads p when it starts and takes a ticket when it is done; the
+// block that draws the last ticket is the only one left running, moves p and rewinds the ticket counter (pos[4]) for the next launch.
+// advance == 0: p stays (an engine that overlaps a learner moves it after joining it: the learner's item lookup reads p; ring slot p + 1 itself is
+// referenced by no item, so frames and scalars may land while the learner still runs).  `bump`: one more int64 counter the launch advances (block 0).
+__global__ void __launch_bounds__(256) k_commit_step(StoreDev s, const int32_t *__restrict__ actions, const float *__restrict__ rewards, const u8 *__restrict__ terminated,
+                                                     const u8 *__restrict__ done, const void *__restrict__ next_obs, u8 *__restrict__ item_mask,
+                                                     i64 *__restrict__ next_table, int advance, i64 *__restrict__ bump) {
     const i64 p = s.pos[0];
     const i64 r = posmod(p, s.L), r1 = posmod(p + 1, s.L);
-    const i64 base = e * s.L;
-    if (s.needs_reset[e]) {
-        // position p holds the previous episode's terminal frame: no transition starts here
-        s.flags[base + r] = kInvalid;
-        s.action[base + r] = 0;
-        s.reward[base + r] = 0.f;
-        s.step_in_ep[base + r1] = 0;
-        s.needs_reset[e] = 0;
-    } else {
-        float rew = rewards[e];
-        if (s.reward_clip) rew = rew < 0.f ? -1.f : (rew > 0.f ? 1.f : 0.f);  // rainbow.py:337-343
-        const u8 d = done[e] ? 1 : 0, tm = terminated[e] ? 1 : 0;
-        s.flags[base + r] = (tm ? kTerm : 0) | (d ? kDone : 0);
-        s.action[base + r] = actions[e];
-        s.reward[base + r] = rew;
-        s.step_in_ep[base + r1] = s.step_in_ep[base + r] + 1;
-        s.needs_reset[e] = d;
-    }
-    if (item_mask) {
-        const i64 q = p - (s.n - 1);
-        item_mask[e] = (q >= 0 && !(s.flags[base + posmod(q, s.L)] & kInvalid)) ? 1 : 0;
-    }
-}
-
-// frame part of a commit: next_obs[e] -> ring position p+1 (16 B per lane when possible)
-__global__ void __launch_bounds__(256) k_commit_frames(StoreDev s, const void *next_obs) {
     const i64 fb = s.obs_dtype == SRLX_OBS_U8 ? s.F : s.F * 4;  // frame bytes
-    const i64 r1 = posmod(s.pos[0] + 1, s.L);
     if ((fb & 15) == 0) {
         const i64 cpf = fb / 16, total = s.E * cpf;
         for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
@@ -215,9 +195,50 @@ __global__ void __launch_bounds__(256) k_commit_frames(StoreDev s, const void *n
             ((u8 *)s.obs)[(e * s.L + r1) * fb + c] = ((const u8 *)next_obs)[t];
         }
     }
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < s.E) {  // the scalars of environment e (k_commit_scalars)
+        const i64 base = e * s.L;
+        int sie1;
+        if (s.needs_reset[e]) {
+            // position p holds the previous episode's terminal frame: no transition starts here
+            s.flags[base + r] = kInvalid;
+            s.action[base + r] = 0;
+            s.reward[base + r] = 0.f;
+            sie1 = 0;
+            s.needs_reset[e] = 0;
+        } else {
+            float rew = rewards[e];
+            if (s.reward_clip) rew = rew < 0.f ? -1.f : (rew > 0.f ? 1.f : 0.f);  // rainbow.py:337-343
+            const u8 d = done[e] ? 1 : 0, tm = terminated[e] ? 1 : 0;
+            s.flags[base + r] = (tm ? kTerm : 0) | (d ? kDone : 0);
+            s.action[base + r] = actions[e];
+            s.reward[base + r] = rew;
+            sie1 = s.step_in_ep[base + r] + 1;
+            s.needs_reset[e] = d;
+        }
+        s.step_in_ep[base + r1] = sie1;
+        if (item_mask) {
+            const i64 q = p - (s.n - 1);
+            item_mask[e] = (q >= 0 && !(s.flags[base + posmod(q, s.L)] & kInvalid)) ? 1 : 0;
+        }
+        if (next_table)  // frame_offset(s, e, p + 1, c) with step_in_ep[p + 1] = sie1
+            for (int c = 0; c < s.W; c++) {
+                const int back = s.W - 1 - c;
+                next_table[e * s.W + c] = back > sie1 ? -1 : (base + posmod(p + 1 - back, s.L)) * s.F;
+            }
+    }
+    if (bump && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;  // nobody in THIS launch reads it (the policy pass that did is an earlier launch): no ticket needed
+    if (advance) {  // p is read by every block: the block that draws the last ticket moves it (the launcher keeps the grid small: one atomic per block on one address)
+        __shared__ int last;
+        __syncthreads();  // this block's reads of p are done
+        if (threadIdx.x == 0) last = atomicAdd(reinterpret_cast<unsigned *>(s.pos + 4), 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (last && threadIdx.x == 0) {
+            s.pos[0] = p + 1;
+            *reinterpret_cast<unsigned *>(s.pos + 4) = 0u;
+        }
+    }
 }
-
-__global__ void k_advance(i64 *counter) { counter[0] += 1; }
 
 // ------------------------------------------------------------------------------------------
 // gather_nstep
@@ -467,9 +488,22 @@ __global__ void __launch_bounds__(256) k_synth_frames(StoreDev s, void *next_obs
         }
     }
 }
-__global__ void __launch_bounds__(256) k_synth_scalars(StoreDev s, i64 episode_len, float *rewards, u8 *terminated, u8 *done) {
+// frames AND scalars of one synthetic lock-step in one launch (the first ceil(E / 256) blocks also do the scalars)
+__device__ __forceinline__ void synth_scalars_one(const StoreDev &s, i64 e, i64 episode_len, float *rewards, u8 *terminated, u8 *done);
+__global__ void __launch_bounds__(256) k_synth_env(StoreDev s, i64 episode_len, void *next_obs, float *rewards, u8 *terminated, u8 *done) {
+    const i64 fb = s.F;  // uint8 frames of 16-byte multiples only (the launcher checks)
+    const i64 p1 = s.pos[0] + 1;
+    const i64 cpf = fb / 16, total = s.E * cpf;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        const i64 e = t / cpf, c = t % cpf;
+        const u64 key = (u64)(e * 0x100000000ll + (p1 & 0xffffffffll));
+        const u64 a = rng_u64(s.seed, key, (u64)(2 * c)), b = rng_u64(s.seed, key, (u64)(2 * c + 1));
+        reinterpret_cast<uint4 *>(next_obs)[t] = make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32));
+    }
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= s.E) return;
+    if (e < s.E) synth_scalars_one(s, e, episode_len, rewards, terminated, done);
+}
+__device__ __forceinline__ void synth_scalars_one(const StoreDev &s, i64 e, i64 episode_len, float *rewards, u8 *terminated, u8 *done) {
     const i64 p = s.pos[0];
     if (s.needs_reset[e]) {
         rewards[e] = 0.f;
@@ -483,6 +517,10 @@ __global__ void __launch_bounds__(256) k_synth_scalars(StoreDev s, i64 episode_l
     const u8 d = (sie + 1 >= episode_len) ? 1 : 0;
     terminated[e] = d;
     done[e] = d;
+}
+__global__ void __launch_bounds__(256) k_synth_scalars(StoreDev s, i64 episode_len, float *rewards, u8 *terminated, u8 *done) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < s.E) synth_scalars_one(s, e, episode_len, rewards, terminated, done);
 }
 
 }  // namespace
@@ -601,17 +639,32 @@ int srlx_store_stack_current(srlx_store_t *h, float *d_out, void *stream) {
     return SRLX_OK;
 }
 
-int srlx_store_commit_step(srlx_store_t *h, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated,
-                           const uint8_t *d_done, const void *d_next_obs, uint8_t *d_item_mask, void *stream) {
+int srlx_store_commit_step_ex(srlx_store_t *h, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated, const uint8_t *d_done,
+                              const void *d_next_obs, uint8_t *d_item_mask, int64_t *d_next_frame_table, int advance, int64_t *d_bump, void *stream) {
     SRLX_REQUIRE(h && d_actions && d_rewards && d_terminated && d_done && d_next_obs, "store_commit_step: NULL argument");
+    SRLX_REQUIRE(!d_next_frame_table || h->d.obs_dtype == SRLX_OBS_U8, "store_commit_step: frame tables exist for uint8 stores only");
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = pick(h, stream);
     const StoreDev &d = h->d;
     const i64 fb = d.F * (d.obs_dtype == SRLX_OBS_U8 ? 1 : 4);
-    hipLaunchKernelGGL(k_commit_frames, dim3(grid_for(d.E * (fb / 16 + 1))), dim3(256), 0, st, d, d_next_obs);
-    hipLaunchKernelGGL(k_commit_scalars, dim3((unsigned)((d.E + 255) / 256)), dim3(256), 0, st, d, d_actions, d_rewards,
-                       d_terminated, d_done, d_item_mask);
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, d.pos);
+    int grid = grid_for(d.E * (fb / 16 + 1), advance ? 256 : 2048);  // (advance: 256 tickets on one address cost ~3 us, 2048 cost 25)
+    const int need = (int)((d.E + 255) / 256);  // the scalar part needs one thread per environment
+    if (grid < need) grid = need;
+    hipLaunchKernelGGL(k_commit_step, dim3((unsigned)grid), dim3(256), 0, st, d, d_actions, d_rewards, d_terminated, d_done, d_next_obs, d_item_mask,
+                       (i64 *)d_next_frame_table, advance, (i64 *)d_bump);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_commit_step(srlx_store_t *h, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated,
+                           const uint8_t *d_done, const void *d_next_obs, uint8_t *d_item_mask, void *stream) {
+    return srlx_store_commit_step_ex(h, d_actions, d_rewards, d_terminated, d_done, d_next_obs, d_item_mask, nullptr, 1, nullptr, stream);
+}
+
+int srlx_store_advance(srlx_store_t *h, void *stream) {
+    SRLX_REQUIRE(h, "store_advance: NULL handle");
+    srlx::DeviceGuard guard(h->device);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, pick(h, stream), h->d.pos);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }
@@ -794,9 +847,16 @@ int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, 
     hipStream_t st = pick(h, stream);
     const StoreDev &d = h->d;
     const i64 fb = d.F * (d.obs_dtype == SRLX_OBS_U8 ? 1 : 4);
-    hipLaunchKernelGGL(k_synth_frames, dim3(grid_for(d.E * (fb / 16 + 1))), dim3(256), 0, st, d, d_next_obs);
-    hipLaunchKernelGGL(k_synth_scalars, dim3((unsigned)((d.E + 255) / 256)), dim3(256), 0, st, d, (i64)episode_len, d_rewards,
-                       d_terminated, d_done);
+    if (d.obs_dtype == SRLX_OBS_U8 && (fb & 15) == 0) {  // frames and scalars in one launch
+        int grid = grid_for(d.E * (fb / 16 + 1), 2048);
+        const int need = (int)((d.E + 255) / 256);
+        if (grid < need) grid = need;
+        hipLaunchKernelGGL(k_synth_env, dim3((unsigned)grid), dim3(256), 0, st, d, (i64)episode_len, d_next_obs, d_rewards, d_terminated, d_done);
+    } else {
+        hipLaunchKernelGGL(k_synth_frames, dim3(grid_for(d.E * (fb / 16 + 1))), dim3(256), 0, st, d, d_next_obs);
+        hipLaunchKernelGGL(k_synth_scalars, dim3((unsigned)((d.E + 255) / 256)), dim3(256), 0, st, d, (i64)episode_len, d_rewards,
+                           d_terminated, d_done);
+    }
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

@@ -287,10 +287,55 @@ class QNetInference:
         self._planes, self._planes_private, self._planes_stale, self._planes_version = True, bool(private_weights), True, -1
 
     def weights_changed(self):
-        """The bound float32 weights were written by somebody else (load_state_dict, a broadcast): the planes are stale."""
+        """The bound float32 weights were written by somebody else (load_state_dict, a broadcast): planes and packed filters derived from them are stale."""
+        N.check(self.lib.srlx_qnet_weights_changed(self.h))
         if getattr(self, "_planes", False):
             self._planes_stale = True
             N.check(self.lib.srlx_qnet_invalidate_fc1_planes(self.h))
+
+    # ---- round 4: published parameter sets (an actor handle) / packed filters that outlive a forward -------------------------------------------
+    def enable_actor_sets(self):
+        """Two device-resident parameter sets for the policy pass (packed convolution filters, first dense layer as bf16 operand planes, small vectors): the learner
+        writes one while the actors read the other (`publish_to`, the fused Adam's plane epilogue), `select_set` flips."""
+        assert not self.net.noisy
+        N.check(self.lib.srlx_qnet_actor_sets_enable(self.h))
+        self._set = -1
+
+    def set_planes_ptr(self, k: int) -> int:
+        p = N.c_p()
+        N.check(self.lib.srlx_qnet_actor_set_planes(self.h, int(k), ctypes.byref(p)))
+        return p.value
+
+    def select_set(self, k: int):
+        N.check(self.lib.srlx_qnet_actor_set_select(self.h, int(k)))
+        self._set = int(k)
+
+    def publish_to(self, actor: "QNetInference" = None, k: int = 0, with_fc1: bool = False):
+        """Pack this handle's convolution filters for its own next forwards and (with `actor`) publish the network into that handle's set k in the same launch;
+        with_fc1: also split the first dense layer's weight into the set's planes (out-of-band publishes: start-up, restore)."""
+        N.check(self.lib.srlx_qnet_publish(self.h, actor.h if actor is not None else None, int(k), int(bool(with_fc1)), N.torch_stream_ptr()))
+
+    def fuse_adam_planes(self, planes_ptr):
+        """The fused first-dense-layer Adam of the next backward passes also writes the updated weight as operand planes at `planes_ptr` (None: off)."""
+        N.check(self.lib.srlx_qnet_fuse_adam_fc1_planes(self.h, N.c_p(planes_ptr) if planes_ptr else None))
+
+    def set_fc1_neighbour(self, splits: int):
+        """Chip-filling first-dense-layer launches on operand planes as half-CU workgroups with `splits` K splits (0: CU-filling workgroups, the fastest form alone)."""
+        N.check(self.lib.srlx_qnet_set_fc1_neighbour(self.h, int(splits)))
+
+    def set_pack_sticky(self, on: bool = True):
+        N.check(self.lib.srlx_qnet_set_pack_sticky(self.h, int(bool(on))))
+
+    def forward_u8_policy(self, frame_base_ptr: int, frame_off: torch.Tensor, eps: torch.Tensor, seed: int, counter: torch.Tensor, actions: torch.Tensor,
+                          invalid: torch.Tensor = None, q_copy: torch.Tensor = None, out: torch.Tensor = None) -> torch.Tensor:
+        """`forward_u8` whose head kernel also selects the actions (epsilon-greedy with the keyed uniforms of (seed, counter): what srlx_rng_uniform +
+        srlx_policy_epsilon_greedy would pick); the counter is only read."""
+        B = frame_off.numel() // self.window
+        q = self.q[:B] if out is None else out
+        self._planes_ready(B)
+        N.check(self.lib.srlx_qnet_forward_u8_policy(self.h, B, N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(q), N.tptr(eps), int(seed) & 0xFFFFFFFFFFFFFFFF, N.tptr(counter),
+                                                     N.tptr(invalid), N.tptr(actions), N.tptr(q_copy), N.torch_stream_ptr()))
+        return q
 
     def refresh_from(self, online: "EngineQNet"):
         """This network := `online` (all parameter tensors), the first dense layer's weight copied AND split into planes in one pass."""
@@ -306,7 +351,7 @@ class QNetInference:
                 torch._foreach_copy_(mine, theirs)
 
     def _planes_ready(self, B: int):
-        if not getattr(self, "_planes", False) or B < 512 or B % 128:
+        if not getattr(self, "_planes", False) or B < 512 or B % 128 or getattr(self, "_set", -1) >= 0:
             return
         if self._planes_stale or not self._planes_private or self._planes_version != self.net.weights_version:
             N.check(self.lib.srlx_qnet_refresh_fc1_planes(self.h, None, None, N.torch_stream_ptr()))

@@ -103,11 +103,21 @@ class RainbowEngine:
     kernels do not cover raise."""
 
     def __init__(self, cfg: RainbowDeviceConfig, device: int = 0, episode_len: int = 200, ring_len: Optional[int] = None, env=None,
-                 overlap: bool = False):
+                 overlap: bool = False, fast: Optional[bool] = None):
         """overlap=True runs the actor's network pass and the learner update concurrently on two HIP
         streams.  The actor then acts with its own copy of the online network, refreshed after every
         step (the reference's distributed actors do the same on a timer, play_mp.py:121-165), so no
-        kernel ever reads weights that another stream is updating."""
+        kernel ever reads weights that another stream is updating.
+
+        fast (None = wherever it applies, SRLX_FAST=0 switches it off; True raises where it does not): the round-4 lock-step for an overlapping engine with
+        chip-filling policy passes -- six launches on the actors' stream instead of fifteen and nothing but the PER add behind the join:
+          * the policy pass selects its actions in the head kernel (srlx_qnet_forward_u8_policy: `north_star`'s fused policy step);
+          * the environments' frames and scalars are one launch, the ring commit is one launch that also writes the next pass's frame-offset table, runs BEFORE
+            the join (ring slot p + 1 belongs to no stored item) and leaves the ring position to the PER add (srlx_per_set_add_counters);
+          * the actors' "private copy" is one of two published parameter sets (packed filters, first dense layer as bf16 operand planes, small vectors) that the
+            UPDATE writes -- the first dense layer from the fused Adam's epilogue, the rest with the filter packing of the learner's own next forward -- so the
+            32 MB per-lock-step weight copy and the splitting pass are gone; the actors flip to the new set after the join (a host-side pointer swap).
+        Actions, ring and tree are bit-identical to the fifteen-launch path (tests/test_fast_lockstep_gpu.py)."""
         self.cfg = cfg
         self.overlap = bool(overlap)
         self.dev = torch.device(f"cuda:{device}")
@@ -137,6 +147,13 @@ class RainbowEngine:
                              f"layer of <= 512 units (average / none) and batches <= 64; got filters={cfg.filters}, hidden={cfg.hidden_units}, batch={B}, "
                              f"frames={cfg.obs_hw}, dueling='{cfg.dueling_type}'.  There is no fallback network path.")
         self.mfma_train = covered and not self.autograd_yardstick
+        fused_adam = self.mfma_train and not self.noisy and os.environ.get("SRLX_NO_FUSED_ADAM", "0") != "1"
+        can_fast = (self.overlap and fused_adam and self.fused_convs and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0 and not cfg.actor_initial_priority
+                    and os.environ.get("SRLX_NO_FUSED_TD", "0") != "1")
+        if fast and not can_fast:
+            raise ValueError("RainbowEngine(fast=True): needs overlap, the 84 x 84 x 4 / 32-filter geometry, plain dense layers, >= 512 environments in multiples of 128, "
+                             "a hidden layer in multiples of 64 and max-priority adds")
+        self.fast = can_fast and (bool(fast) if fast is not None else os.environ.get("SRLX_FAST", "1") != "0")
 
         def make_net():
             return EngineQNet(A, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.filters, cfg.dueling_type, noisy=self.noisy).to(self.dev)
@@ -147,8 +164,11 @@ class RainbowEngine:
         self.q_target.load_state_dict(self.q_online.state_dict())  # model_torch.py:41-42
         self.q_online.train()
         if self.overlap:
-            self.q_actor = make_net()
-            self.q_actor.load_state_dict(self.q_online.state_dict())
+            if self.fast:  # the actors read a PUBLISHED set, never these tensors: no second module
+                self.q_actor = self.q_online
+            else:
+                self.q_actor = make_net()
+                self.q_actor.load_state_dict(self.q_online.state_dict())
             # high priority: the learner's many small kernels slot in between the actor's chip-filling GEMMs
             self.s_learner = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("SRLX_LEARNER_PRIO", "-1")))
             self._ev_fork = torch.cuda.Event()
@@ -158,7 +178,14 @@ class RainbowEngine:
         # one inference handle per concurrent user (each owns its activation buffers and, for noisy layers, its noise stream)
         self.inf_actor = QNetInference(self.q_actor, E, device, noise_seed=cfg.seed * 3 + 0xA11CE)
         planes = os.environ.get("SRLX_FC1_PLANES", "auto")
-        if not self.noisy and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0 and (planes == "1" or (planes == "auto" and not overlap)):
+        if self.fast:
+            self.inf_actor.enable_fc1_planes(private_weights=True)  # (the activation planes; the weight planes the passes read are the published sets')
+            self.inf_actor.enable_actor_sets()
+            # the passes run BESIDE the update: half-CU workgroups in a steady stream instead of one CU-filling workgroup per CU for the whole launch
+            # (same-box A/B of the lock-step, tools/_r4_probe3.sh: 0.508 ms with 4 K splits -- 256 workgroups that leave half of every CU to the update --, 0.515
+            # with 8, 0.528 with 16, 0.545 with the CU-filling kernel; SRLX_FC1_NEIGHBOUR=0 selects that one, = k the K splits)
+            self.inf_actor.set_fc1_neighbour(int(os.environ.get("SRLX_FC1_NEIGHBOUR", "4")))
+        elif not self.noisy and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0 and (planes == "1" or (planes == "auto" and not overlap)):
             # Chip-filling policy passes with the first dense layer on pre-split bf16 operand planes (srlx_fc1_planes.hip): the GEMM itself is 1.6x faster
             # (85 against 137 us at 1024 rows), but beside a learner it LOSES: same-box A/B (tools/_ab_lockstep.sh) 0.565 against 0.511 ms per lock-step --
             # the refresh of the actors' copy also has to split the 32 MB weight (22 us on the serial tail every lock-step) and the planes kernel's 144 KB /
@@ -198,9 +225,18 @@ class RainbowEngine:
         self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
         self._fused_td = os.environ.get("SRLX_NO_FUSED_TD", "0") != "1"  # TD / Huber / priorities inside the backward's head kernel (A/B switch)
         self.replay.count_updates_in(self.train_count_dev)  # train_count += 1 rides on the priority write-back's launch
-        if self.mfma_train and not self.noisy and os.environ.get("SRLX_NO_FUSED_ADAM", "0") != "1":
+        if fused_adam:
             # the 32 MB first dense layer takes its Adam step inside the backward pass, beside the convolution gradients (A/B switch for measurements)
             self.optimizer.fuse_first_dense(self.inf_online, self.train_count_dev)
+        self._learner_graphs = {}
+        if self.fast:
+            self._actor_first = os.environ.get("SRLX_ORDER", "learner_first") == "actor_first"
+            self._planes_ptr = [self.inf_actor.set_planes_ptr(0), self.inf_actor.set_planes_ptr(1)]
+            self._set, self._published = 0, None
+            self._seen_versions = None
+            self.inf_target.set_pack_sticky(True)  # the target network's packed filters change at a sync only
+            self.replay.enable_deferred_advance()
+            self._publish_out_of_band()
         self.train_count = 0
         self.sync_count = 0
         self.total_env_steps = 0
@@ -249,6 +285,36 @@ class RainbowEngine:
             self.ledger.account(e.rewards, e.done, self.replay.needs_reset_ptr)
         self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs, defer_add=self.actor_priority)
 
+    # ---- the round-4 lock-step (self.fast) -----------------------------------------------------------------------------------------------------
+    def _publish_out_of_band(self):
+        """Set `self._set` := the online network as it stands (packed filters, small vectors AND a splitting pass over the first dense layer): start-up and after
+        weights were loaded from outside; the target handle re-packs too.  Runs on the current stream, nothing of the engine in flight."""
+        self.inf_online.weights_changed()
+        self.inf_online.publish_to(self.inf_actor, self._set, with_fc1=True)
+        self.inf_actor.select_set(self._set)
+        self.inf_target.weights_changed()
+        self.inf_target.publish_to(None)
+        self._published = None
+        self._seen_versions = (self.q_online.weights_version, self.q_target.weights_version)
+
+    def _check_versions(self):
+        if self._seen_versions != (self.q_online.weights_version, self.q_target.weights_version):  # a state dict was loaded behind the engine's back
+            self.join_learner()
+            self._publish_out_of_band()
+
+    def actor_commit_ring(self):
+        """fast: the ring half of the commit -- one launch (frames, scalars, item mask, the NEXT pass's frame-offset table, the policy generator's counter); touches
+        nothing a running learner reads, so it goes BEFORE the join."""
+        e = self.env
+        if self.ledger is not None:
+            self.ledger.account(e.rewards, e.done, self.replay.needs_reset_ptr)
+        self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs, defer_add=True, next_table=True, bump=self.policy_counter)
+
+    def actor_commit_tree(self):
+        """fast: the tree half -- the PER add at max_priority, which also moves the ring position; behind the join (the learner writes the tree and reads the position)."""
+        self.replay.add_masked()
+        self.total_env_steps += self.cfg.n_envs
+
     def actor_td_estimates(self):
         """float32 [E] for the items the PREVIOUS lock-step committed, from the cached Q rows (see __init__; ONE launch, srlx_store_actor_td): |n-step target -
         Q(s_0, a_0)|, or -1 where the item's window touches an episode end (the adder uses max_priority), or -2 where the lock-step completed no item for the lane.
@@ -276,6 +342,11 @@ class RainbowEngine:
 
     def actor_step(self):
         """One eager lock-step of the actors (no graphs, no learner)."""
+        if self.fast:
+            self.actor_front()
+            self.actor_commit_ring()
+            self.replay.add_masked()
+            return
         self._actor_select(self._actor_net())
         self._actor_commit()
 
@@ -337,9 +408,14 @@ class RainbowEngine:
         return tuple(c.obs_hw) == (84, 84) and c.window_length == 4 and c.filters == 32 and os.environ.get("SRLX_NO_FUSED_CONV", "0") != "1"
 
     # ---- learner (model_torch.py:85-122) -----------------------------------------------------
-    def _learner_body(self):
+    def _learner_body(self, publish: Optional[int] = None):
+        """One Rainbow update.  fast engines: `publish` = the actor set (0 / 1) this update also writes -- the first dense layer as operand planes from the fused
+        Adam's epilogue, packed filters and small vectors with the packing launch that follows the optimiser step (None: that launch only packs for this handle's
+        own next forward)."""
         cfg, r = self.cfg, self.replay
         B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
+        if self.fast:
+            self.inf_online.fuse_adam_planes(self._planes_ptr[publish] if publish is not None else None)
         if self.mfma_train:
             b = r.sample_items(self.train_count_dev, all_states=True)
             cur = torch.cuda.current_stream(self.dev)
@@ -370,6 +446,8 @@ class RainbowEngine:
                 )
                 self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
             self.optimizer.step(self.train_count_dev)
+            if self.fast:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors)
+                self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0)
         else:  # SRLX_TORCH_BACKWARD=1: the test yardstick -- matrix-core evaluation of s_1..s_n, autograd for the gradient step
             b = r.sample_items(self.train_count_dev)
             foff = r.frame_off_next.view(B * n, cfg.window_length)
@@ -388,14 +466,15 @@ class RainbowEngine:
             self.optimizer.step()
         r.update(b.indices, self.priorities)  # model_torch.py:113-114; train_count_dev += 1 in the same launch (count_updates_in)
 
-    def learner_step(self) -> bool:
+    def learner_step(self, publish: Optional[int] = None) -> bool:
         """Returns False while the replay is below warm-up (priority_replay_buffer.py:228-230)."""
         if self.replay.is_warmup_needed():
             return False
-        if self._learner_graph is not None:
-            self._learner_graph.replay()
+        g = self._learner_graphs.get(publish) if self.fast else self._learner_graph
+        if g is not None:
+            g.replay()
         else:
-            self._learner_body()
+            self._learner_body(publish) if self.fast else self._learner_body()
         # model_torch.py:117-119 (fires at train_count 0 too)
         if self.train_count % self.cfg.target_model_update_interval == 0:
             self.sync_target()
@@ -405,22 +484,37 @@ class RainbowEngine:
     def sync_target(self):
         with torch.no_grad():
             torch._foreach_copy_(list(self.q_target.parameters()), list(self.q_online.parameters()))
+        if self.fast:  # the target handle keeps its packed filters between syncs: re-pack them now (current stream: the learner's)
+            self.inf_target.weights_changed()
+            self.inf_target.publish_to(None)
         self.sync_count += 1
 
     # ---- the pieces of a step (the Runner's vectorised loop drives them one by one: device/vector_runner.py) --------
     def fork_learner(self, updates: int) -> int:
         """overlap=True: enqueue `updates` learner updates on the learner's stream, ordered after everything enqueued on the
         current stream so far (they see the replay as of now).  Returns how many ran (0 below the warm-up)."""
+        if self.fast:
+            self._check_versions()
         main = torch.cuda.current_stream(self.dev)
         self._ev_fork.record(main)
-        self.s_learner.wait_event(self._ev_fork)
-        ran = 0
-        with torch.cuda.stream(self.s_learner):
-            for _ in range(updates):
-                ran += int(self.learner_step())
-            self._ev_join.record(self.s_learner)
+
+        def body():
+            self.s_learner.wait_event(self._ev_fork)
+            ran = 0
+            with torch.cuda.stream(self.s_learner):
+                for k in range(updates):
+                    if self.fast and k == updates - 1:  # the last update of the lock-step publishes into the set the actors are NOT reading
+                        ok = self.learner_step(1 - self._set)
+                        if ok:
+                            self._published = 1 - self._set
+                    else:
+                        ok = self.learner_step()
+                    ran += int(ok)
+                self._ev_join.record(self.s_learner)
+            return ran
+
         self._learner_pending = True
-        return ran
+        return body()
 
     def join_learner(self):
         """The current stream waits for the forked updates (before the next write to the replay)."""
@@ -430,11 +524,25 @@ class RainbowEngine:
 
     def refresh_actor_copy(self):
         """overlap=True: one multi-tensor copy online -> the actor's private network."""
-        if self.q_actor is not self.q_online:
+        if self.fast:  # the joined update wrote the other set: the next passes read it (a pointer swap on the host)
+            if self._published is not None:
+                self._set, self._published = self._published, None
+                self.inf_actor.select_set(self._set)
+        elif self.q_actor is not self.q_online:
             self.inf_actor.refresh_from(self.q_online)
 
     def actor_front(self, events=None):
         """Network pass + action selection + environments of one lock-step: reads the ring, writes nothing shared."""
+        if self.fast:  # network pass + selection in one call (3 launches), the environments in one
+            self._check_versions()
+            off = self.replay.frame_table_current()  # (no launch: the last commit wrote it)
+            if events is not None:
+                events[0].record()
+            self.inf_actor.forward_u8_policy(self.replay.obs_base, off, self.eps, self.cfg.seed ^ 0xAC7, self.policy_counter, self.actions)
+            if events is not None:
+                events[1].record()
+            self.env.step(self.actions)
+            return
         q = self._actor_net(None, events)  # eager launches, bracketed by the events
         if self._select_graph is not None:
             self._select_graph.replay()
@@ -443,6 +551,10 @@ class RainbowEngine:
 
     def actor_commit(self):
         """Ring commit + PER add of the lock-step `actor_front` produced: the only actor writes to the replay."""
+        if self.fast:
+            self.actor_commit_ring()
+            self.actor_commit_tree()
+            return
         if self._commit_graph is not None:
             self._commit_graph.replay()
             self.replay._steps_committed += 1
@@ -459,6 +571,18 @@ class RainbowEngine:
         """One engine step: E environment steps and `learner_updates` Rainbow updates.  `events` = (start, end)
         torch events recorded around the dominant hand-written kernel group of the actor on its launch
         stream: the matrix-core network pass (or, on the torch path, the frame-stack kernel)."""
+        if self.fast:
+            if self._actor_first:  # the host issues the actors' four launches BEFORE the update's graph (whose launch keeps the host busy for tens of microseconds)
+                self.actor_front(events)
+                self.fork_learner(learner_updates)
+            else:
+                self.fork_learner(learner_updates)
+                self.actor_front(events)
+            self.actor_commit_ring()  # before the join: nothing the learner reads
+            self.join_learner()
+            self.actor_commit_tree()
+            self.refresh_actor_copy()
+            return
         if self.overlap:  # the learner sees the replay as of the end of the previous step
             self.fork_learner(learner_updates)
         self.actor_front(events)
@@ -490,6 +614,16 @@ class RainbowEngine:
                 self.learner_step()  # a real update (eager: sizes the arenas), target sync and counters included
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
+        if self.fast:  # the actors' six launches stay eager; the update is captured three times: publishing into set 0 / set 1 / not at all
+            if learner and not self.replay.is_warmup_needed():
+                for key in (None, 0, 1):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._learner_body(key)
+                    self._learner_graphs[key] = g
+                self._learner_graph = self._learner_graphs[None]
+            torch.cuda.synchronize(self.dev)
+            return
         if actor:
             q = self._actor_net(None)
             g = torch.cuda.CUDAGraph()

@@ -100,6 +100,15 @@ class DeviceReplay:
         N.check(self.lib.srlx_store_views(hs, ctypes.byref(pos), ctypes.byref(nr), ctypes.byref(sie)))
         self._views = (pos, nr, sie)
         self.needs_reset_ptr = nr  # uint8 [E]: lanes whose next lock-step only delivers the first frame of a new episode
+        self.deferred_advance = False
+        self.table_fresh = False  # `frame_off_actor` holds the table of the CURRENT ring position (written by the last commit)
+
+    def enable_deferred_advance(self):
+        """The round-4 lock-step: a commit leaves the ring position where it is and the PER add that closes the lock-step advances it inside its own launch
+        (srlx_per_set_add_counters), so the ring commit may run while a learner still reads the replay (ring slot p + 1 and the scalars of p belong to no stored
+        item; p itself feeds the learner's item lookup) and the add is the only launch behind the join.  Every commit must then be followed by exactly one add."""
+        N.check(self.lib.srlx_per_set_add_counters(self.h_per, self._views[0], None))
+        self.deferred_advance = True
 
     def close(self):
         if getattr(self, "h_store", None):
@@ -117,25 +126,33 @@ class DeviceReplay:
     # ---- actor side ---------------------------------------------------------------------------
     def reset_all(self, first_obs: torch.Tensor):
         N.check(self.lib.srlx_store_reset_all(self.h_store, N.tptr(first_obs), N.torch_stream_ptr()))
+        self.table_fresh = False
 
     def stack_current(self) -> torch.Tensor:
         """float32 [E, W, F] policy input at the current ring position (oldest frame first)."""
         N.check(self.lib.srlx_store_stack_current(self.h_store, N.tptr(self.stacked), N.torch_stream_ptr()))
         return self.stacked
 
-    def commit(self, actions, rewards, terminated, done, next_obs, defer_add: bool = False):
-        """One lock-step transition of all E envs + the PER add of the items that became complete
+    def commit(self, actions, rewards, terminated, done, next_obs, defer_add: bool = False, next_table: bool = False, bump: Optional[torch.Tensor] = None):
+        """One lock-step transition of all E envs (ONE launch: frames, scalars, item mask, ring position) + the PER add of the items that became complete
         (priority=None -> max_priority, proportional_memory.py:121-122; reset positions get 0).
-        defer_add: the ring commit only; the caller adds the E leaves later with priorities of its own (`add_raw`; `item_mask` says which lanes completed an item)."""
+        defer_add: the ring commit only; the caller adds the E leaves later with priorities of its own (`add_raw` / `add_masked`; `item_mask` says which lanes
+        completed an item).  next_table: the commit also writes `frame_off_actor` for the NEXT policy pass.  bump: an int64 device counter advanced by the launch."""
         st = N.torch_stream_ptr()
         N.check(
-            self.lib.srlx_store_commit_step(
-                self.h_store, N.tptr(actions), N.tptr(rewards), N.tptr(terminated), N.tptr(done), N.tptr(next_obs), N.tptr(self.item_mask), st
+            self.lib.srlx_store_commit_step_ex(
+                self.h_store, N.tptr(actions), N.tptr(rewards), N.tptr(terminated), N.tptr(done), N.tptr(next_obs), N.tptr(self.item_mask),
+                N.tptr(self.frame_off_actor) if next_table else None, 0 if self.deferred_advance else 1, N.tptr(bump), st
             )
         )
+        self.table_fresh = bool(next_table)
         if not defer_add:
-            N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(self.item_mask), N.PRIO_NONE_MASKED, 1, st))
+            self.add_masked()
         self._steps_committed += 1
+
+    def add_masked(self):
+        """The PER add of the last committed lock-step at max_priority (0 where `item_mask` says the lock-step completed no item for the lane)."""
+        N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(self.item_mask), N.PRIO_NONE_MASKED, 1, N.torch_stream_ptr()))
 
     def add_raw(self, priorities_f64: torch.Tensor):
         """The deferred PER add of the last committed lock-step: E final leaf values (already transformed; 0 = no item), float64 on the device."""
@@ -206,8 +223,9 @@ class DeviceReplay:
         return b
 
     def frame_table_current(self) -> torch.Tensor:
-        """int64 [E, W] byte offsets of the frames that form every env's current stacked observation."""
-        N.check(self.lib.srlx_store_frame_table_current(self.h_store, N.tptr(self.frame_off_actor), N.torch_stream_ptr()))
+        """int64 [E, W] byte offsets of the frames that form every env's current stacked observation (no launch when the last commit wrote it)."""
+        if not self.table_fresh:
+            N.check(self.lib.srlx_store_frame_table_current(self.h_store, N.tptr(self.frame_off_actor), N.torch_stream_ptr()))
         return self.frame_off_actor
 
     def sample_items(self, d_step: torch.Tensor, uniforms: torch.Tensor = None, all_states: bool = False) -> ReplayBatch:

@@ -21,6 +21,30 @@ for _ in range(50):
 torch.cuda.synchronize()
 n = 300
 E = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+if eng.fast:  # the round-4 lock-step: network pass + selection | environments | ring commit (before the join) | join + PER add
+    ev = [[E() for _ in range(7)] for _ in range(n)]
+    main = torch.cuda.current_stream()
+    for k in range(n):
+        e = ev[k]
+        e[0].record(main)
+        eng.fork_learner(1)
+        e[5].record(eng.s_learner)
+        off = eng.replay.frame_table_current()
+        eng.inf_actor.forward_u8_policy(eng.replay.obs_base, off, eng.eps, cfg.seed ^ 0xAC7, eng.policy_counter, eng.actions)
+        e[1].record(main)
+        eng.env.step(eng.actions)
+        e[2].record(main)
+        eng.actor_commit_ring()
+        e[3].record(main)
+        eng.join_learner()
+        eng.actor_commit_tree()
+        eng.refresh_actor_copy()
+        e[4].record(main)
+    torch.cuda.synchronize()
+    for nm, i in zip(["policy pass end", "environments end", "ring commit end", "add end (after join)", "learner end"], [1, 2, 3, 4, 5]):
+        v = sorted(ev[k][0].elapsed_time(ev[k][i]) for k in range(20, n))
+        print(f"{nm:26s} median {1e3 * v[len(v) // 2]:7.1f} us   (10 % {1e3 * v[len(v) // 10]:7.1f}, 90 % {1e3 * v[9 * len(v) // 10]:7.1f})")
+    sys.exit(0)
 ev = [[E() for _ in range(6)] for _ in range(n)]
 main = torch.cuda.current_stream()
 for k in range(n):

@@ -485,7 +485,8 @@ int srlx_qnet_forward_u8_policy(srlx_qnet_t *h, int64_t batch, const uint8_t *d_
  * trainer publishes and its actors poll, srl/base/run/play_mp.py:289-303,151-165; there a pickled state_dict, here two device-resident parameter sets):
  *   srlx_qnet_actor_sets_enable   an actor handle gets two sets of everything a policy pass reads (packed convolution filters, the first dense layer as bf16
  *                                 operand planes, biases and head vectors)
- *   srlx_qnet_publish             packs h_src's convolution filters for its own next forwards (they then skip the packing launch until
+ *   srlx_qnet_publish             (d_bump: an int64 device counter the launch advances by one, or NULL -- the update's step count, once every reader is done)
+ *                                 packs h_src's convolution filters for its own next forwards (they then skip the packing launch until
  *                                 srlx_qnet_weights_changed) and, with h_actor, writes set `set` in the same launch; with_fc1 != 0 also splits the first dense
  *                                 layer's weight into the set's planes (the out-of-band publish: start-up, restore, a target sync)
  *   srlx_qnet_fuse_adam_fc1_planes  the fused Adam epilogue of srlx_qnet_fuse_adam_fc1 ALSO writes the updated weight as planes to d_planes_out (an actor set's,
@@ -496,7 +497,10 @@ int srlx_qnet_forward_u8_policy(srlx_qnet_t *h, int64_t batch, const uint8_t *d_
 int srlx_qnet_actor_sets_enable(srlx_qnet_t *h);
 int srlx_qnet_actor_set_planes(srlx_qnet_t *h, int set, void **d_planes);
 int srlx_qnet_actor_set_select(srlx_qnet_t *h, int set);
-int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int with_fc1, void *stream);
+int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int with_fc1, int64_t *d_bump, void *stream);
+/* a caller-owned HIP event (hipEvent_t, NULL: none) recorded on the backward pass's stream right behind its head kernel: with srlx_qnet_backward_td_u8 the TD
+ * targets, loss and new priorities exist from there on, so the priority write-back (srlx_per_update) can run beside the gradient kernels on another stream */
+int srlx_qnet_set_td_event(srlx_qnet_t *h, void *event);
 int srlx_qnet_fuse_adam_fc1_planes(srlx_qnet_t *h, void *d_planes_out);
 int srlx_qnet_set_pack_sticky(srlx_qnet_t *h, int on);
 /* splits > 0: the chip-filling first-dense-layer launches of a handle with operand planes use half-CU workgroups (256 threads, 72 KB of LDS, `splits` K splits:

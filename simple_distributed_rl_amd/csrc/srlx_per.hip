@@ -74,6 +74,11 @@ struct Tree {
     int D, h0, G;
     i64 base[12];
 
+    // base[g] in closed form, g >= 1: 1 + 2^h0 (8^(g-1) - 1) / 7.  A lane-dependent index into the by-value array makes hipcc copy the array to scratch
+    // memory (every kernel that calls phys() then starts with scratch stores and pays scratch latency per look-up: the 1024-leaf add spent 11 of its 27 us
+    // there).  (8^j - 1) / 7 is taken as a bit pattern: written with the 64-bit division, the expression came out wrong inside the add kernels (ROCm 7.2 hipcc,
+    // gfx950: correct in a stand-alone probe, tools/README.md) -- tests/test_per_gpu.py::test_full_size_1M_bulk_paths caught it.
+    __device__ __forceinline__ i64 base_of(int g) const { return 1 + (i64)((0x1249249249249249ull & ((1ull << (3 * (g - 1))) - 1ull)) << h0); }  // (8^(g-1) - 1) / 7 = 0b...001001001
     __device__ __forceinline__ i64 phys(i64 i) const {
         if (i == 0) return kRootSlot;
         const int d = node_depth(i);
@@ -81,7 +86,7 @@ struct Tree {
         if (d <= h0) return slot_in_block(d, q);
         const int k = d - h0 - 1;
         const int g = 1 + k / 3, r = k % 3 + 1;
-        const i64 blk = base[g] + (q >> r);
+        const i64 blk = base_of(g) + (q >> r);
         return 16 * blk + slot_in_block(r, q & (((i64)1 << r) - 1));
     }
     __device__ __forceinline__ double get(i64 i) const { return T[phys(i)]; }
@@ -97,7 +102,7 @@ struct Tree {
     // block that holds the children of owner node `owner` on level `level` (level = 0, h0, h0+3, ...)
     __device__ __forceinline__ i64 block_of_owner(i64 owner, int level) const {
         if (level == 0) return 0;
-        return base[1 + (level - h0) / 3] + (owner + 1 - ((i64)1 << level));
+        return base_of(1 + (level - h0) / 3) + (owner + 1 - ((i64)1 << level));
     }
 };
 
@@ -724,7 +729,7 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
     }
     __syncthreads();
 
-    bool last_me[ (kUpdateChunk + kWgUpdate - 1) / kWgUpdate ];
+    unsigned last_me = 0u;  // bit q: this thread's q-th index is the last occurrence of its leaf (a register, not an indexed array: that would live in scratch memory)
     int q = 0;
     for (i64 i = t; i < n; i += T, q++) {
         const i64 x = s_idx[i];
@@ -741,12 +746,12 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
         }
         const double before = prev >= 0 ? s_p[prev] : tr.get(x);
         s_chg[i] = s_p[i] - before;  // :83
-        last_me[q] = last;
+        last_me |= (last ? 1u : 0u) << q;
     }
     __syncthreads();  // every old leaf value has been read
     q = 0;
     for (i64 i = t; i < n; i += T, q++)
-        if (last_me[q]) tr.set(s_idx[i], s_p[i]);  // :85
+        if ((last_me >> q) & 1u) tr.set(s_idx[i], s_p[i]);  // :85
 
     // ancestors (:49-54).  task (i, k): the k-th ancestor of index i; the first i that reaches a
     // node owns it.
@@ -796,32 +801,36 @@ struct Run {
     int dl;          // depth of the run's leaves
 };
 
-__device__ __forceinline__ int make_runs(i64 cap, i64 write, i64 n, Run runs[4]) {
+// run number `want` of the batch (false: there is none) -- make_runs without the array (a lane-uniform but run-time index would put it into scratch memory)
+__device__ __forceinline__ bool get_run(i64 cap, i64 write, i64 n, int want, Run &out) {
     const i64 tree_len = 2 * cap - 1;
     const int D = node_depth(tree_len - 1);
-    const i64 first_deep = ((i64)1 << D) - 1;  // first node on the deepest level
-    const i64 sb = first_deep - (cap - 1);     // slots [0,sb) are one level up, [sb,cap) on level D
+    const i64 first_deep = ((i64)1 << D) - 1;
+    const i64 sb = first_deep - (cap - 1);
     int nr = 0;
     i64 done = 0;
-    // ring pieces in batch order: [write, min(write+n,cap)) then [0, write+n-cap)
+#pragma unroll
     for (int piece = 0; piece < 2; piece++) {
-        i64 s_lo = piece == 0 ? write : 0;
-        i64 s_hi = piece == 0 ? (write + n < cap ? write + n : cap) : (write + n - cap);
+        const i64 s_lo = piece == 0 ? write : 0;
+        const i64 s_hi = piece == 0 ? (write + n < cap ? write + n : cap) : (write + n - cap);
         if (piece == 1 && write + n <= cap) break;
-        // split at sb
-        i64 cuts[3] = {s_lo, (sb > s_lo && sb < s_hi) ? sb : s_lo, s_hi};
+        const i64 mid = (sb > s_lo && sb < s_hi) ? sb : s_lo;
+#pragma unroll
         for (int c = 0; c < 2; c++) {
-            const i64 a = cuts[c], b = cuts[c + 1];
+            const i64 a = c == 0 ? s_lo : mid, b = c == 0 ? mid : s_hi;
             if (b <= a) continue;
-            runs[nr].i_lo = done;
-            runs[nr].i_hi = done + (b - a);
-            runs[nr].x_lo = a + cap - 1;
-            runs[nr].dl = (a < sb) ? D - 1 : D;
+            if (nr == want) {
+                out.i_lo = done;
+                out.i_hi = done + (b - a);
+                out.x_lo = a + cap - 1;
+                out.dl = (a < sb) ? D - 1 : D;
+                return true;
+            }
             done += b - a;
             nr++;
         }
     }
-    return nr;
+    return false;
 }
 
 // number of ancestor nodes of a run
@@ -833,7 +842,7 @@ __device__ __forceinline__ i64 run_tasks(const Run &r) {
 }
 
 // thread `tid` of `nthreads` processes its share of a run's ancestor nodes
-__device__ __forceinline__ void run_ancestors(const Tree &tr, const double *chg, const Run &r, i64 tid, i64 nthreads) {
+__device__ __forceinline__ void run_ancestors(const Tree &tr, const double *chg, const Run &r, i64 tid, i64 nthreads, int abl = 0) {
     const i64 cnt = r.i_hi - r.i_lo;
     const i64 x_hi = r.x_lo + cnt - 1;
     const i64 tasks = run_tasks(r);
@@ -856,17 +865,42 @@ __device__ __forceinline__ void run_ancestors(const Tree &tr, const double *chg,
         if (first < r.x_lo) first = r.x_lo;
         if (last > x_hi) last = x_hi;
         const double *c0 = chg + r.i_lo + (first - r.x_lo);
-        const i64 m = last - first + 1;
-        const i64 pa = tr.phys(a);
-        double v = tr.T[pa];
+        i64 m = last - first + 1;
+        if (abl == 2 && m > 64) m = 64;
+        const i64 pa = abl == 3 ? 0 : tr.phys(a);
+        double v = abl == 3 ? 0.0 : tr.T[pa];
+        // additions strictly in list order (the reference's propagate order).  The upper levels' owners add ALL n changes: one dependent fp64 add per change
+        // is the floor of the whole call, so the loads must not sit on that chain -- blocks of 16 changes, the next block requested before the current one is added
+        // (the scheduling barriers keep hipcc from sinking the loads to their uses: 8 loads then 8 dependent adds per trip cost 2.6x the adds alone)
         i64 k = 0;
-        for (; k + 8 <= m; k += 8) {  // loads issued together, additions strictly in list order
-            const double c[8] = {c0[k], c0[k + 1], c0[k + 2], c0[k + 3], c0[k + 4], c0[k + 5], c0[k + 6], c0[k + 7]};
+        if (m >= 32) {
+            double ca[16], cb[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v += c[u];
+            for (int u = 0; u < 16; u++) ca[u] = c0[u];
+            for (; k + 32 <= m; k += 32) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) cb[u] = c0[k + 16 + u];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 16; u++) v += ca[u];
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 48 <= m) {
+#pragma unroll
+                    for (int u = 0; u < 16; u++) ca[u] = c0[k + 32 + u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 16; u++) v += cb[u];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (k + 16 <= m) {  // (ca holds block k)
+#pragma unroll
+                for (int u = 0; u < 16; u++) v += ca[u];
+                k += 16;
+            }
         }
-        for (; k < m; k++) v += c0[k];  // list order: the reference's propagate order
-        tr.T[pa] = v;
+        for (; k < m; k++) v += c0[k];
+        if (abl != 3 || v == 1.2345) tr.T[pa] = v;
     }
 }
 
@@ -882,6 +916,7 @@ struct AddArgs {
     i64 start_slot;  // -1: append at state->write (add); >= 0: rewrite these ring slots in place (set_range)
     int commit;      // advance write/size (add) or not (set_range)
     int track_max;   // raise max_priority like update() does (:176-177)
+    int abl;               // measurement only (SRLX_ADD_ABL): 1 = leaves only, 2 = ancestor chains capped at 64 changes, 3 = no ancestor tree accesses
     double maxp_snapshot;  // bulk path only: filled from *maxp_dev by the leaf kernel's caller
     const double *maxp_dev;
     i64 *bump0, *bump1;  // srlx_per_set_add_counters: int64 device counters an appending add advances by one (NULL: none)
@@ -915,7 +950,7 @@ __device__ __forceinline__ void add_commit(const AddArgs &a) {
 
 // n <= kSmallAddMax: everything in one launch; the per-leaf changes live in LDS so that the root
 // owner's n dependent fp64 additions are fed from LDS, not from memory
-__global__ void __launch_bounds__(1024) k_add_wg(AddArgs a) {
+__global__ void __launch_bounds__(512) k_add_wg(AddArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_chg[];  // n doubles
     a.chg = s_chg;
     const int t = threadIdx.x, T = blockDim.x;
@@ -924,12 +959,13 @@ __global__ void __launch_bounds__(1024) k_add_wg(AddArgs a) {
     __syncthreads();  // every thread has read max_priority before anyone raises it
     for (i64 i = t; i < a.n; i += T) add_leaf(a, i, write, maxp);
     __syncthreads();
-    Run runs[4];
-    const int nr = make_runs(a.cap, write, a.n, runs);
-    for (int r = 0; r < nr; r++) {
-        run_ancestors(a.tree, a.chg, runs[r], t, T);
-        __syncthreads();
-    }
+    if (a.abl != 1)
+        for (int r = 0; r < 4; r++) {
+            Run run;
+            if (!get_run(a.cap, write, a.n, r, run)) break;
+            run_ancestors(a.tree, a.chg, run, t, T, a.abl);
+            __syncthreads();
+        }
     if (t == 0) add_commit(a);
 }
 
@@ -939,10 +975,9 @@ __global__ void __launch_bounds__(256) k_add_leaf_bulk(AddArgs a) {
     if (i < a.n) add_leaf(a, i, add_start(a), *a.maxp_dev);
 }
 __global__ void __launch_bounds__(256) k_add_anc_bulk(AddArgs a, int r) {
-    Run runs[4];
-    const int nr = make_runs(a.cap, add_start(a), a.n, runs);
-    if (r >= nr) return;
-    run_ancestors(a.tree, a.chg, runs[r], (i64)blockIdx.x * blockDim.x + threadIdx.x, (i64)gridDim.x * blockDim.x);
+    Run run;
+    if (!get_run(a.cap, add_start(a), a.n, r, run)) return;
+    run_ancestors(a.tree, a.chg, run, (i64)blockIdx.x * blockDim.x + threadIdx.x, (i64)gridDim.x * blockDim.x);
 }
 __global__ void k_add_commit(AddArgs a) { add_commit(a); }
 // max_priority as it was before this call (every add with priority=None uses that value, and
@@ -1008,9 +1043,9 @@ int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st,
     const bool append = start_slot < 0;
     double *snap = (double *)((char *)h->scratch.ptr + srlx::Carver::padded((size_t)n * 8));
     AddArgs a{h->tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr,
-              start_slot, append ? 1 : 0, append ? 0 : 1, 0.0, snap, append ? h->d_add_counter[0] : nullptr, append ? h->d_add_counter[1] : nullptr};
+              start_slot, append ? 1 : 0, append ? 0 : 1, getenv("SRLX_ADD_ABL") ? atoi(getenv("SRLX_ADD_ABL")) : 0, 0.0, snap, append ? h->d_add_counter[0] : nullptr, append ? h->d_add_counter[1] : nullptr};
     if (n <= kSmallAddMax) {
-        hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(n <= 1024 ? kWgAdd : 1024), (size_t)n * sizeof(double), st, a);
+        hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(n < 512 ? kWgAdd : 512), (size_t)n * sizeof(double), st, a);  // (512 threads: a 256-register budget keeps the pipelined chain blocks out of scratch)
     } else {
         const int blocks = (int)((n + 255) / 256);
         hipLaunchKernelGGL(k_snapshot_max, dim3(1), dim3(1), 0, st, h->d_state, snap);

@@ -977,21 +977,21 @@ int srlx_qnet_actor_set_select(srlx_qnet_t *h, int set) {
 // Packs `h_src`'s convolution filters for ITS next forwards (they then skip k_pack_filters until srlx_qnet_weights_changed / the next publish) and, with `h_actor`,
 // publishes the network into that handle's set `set`: packed filters + small vectors in the same launch; `with_fc1`: also the first dense layer's weight as
 // operand planes (one splitting pass -- the initial / out-of-band publish; an update publishes them from the fused Adam's epilogue, srlx_qnet_fuse_adam_fc1_planes).
-int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int with_fc1, void *stream) {
+int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int with_fc1, int64_t *d_bump, void *stream) {
     SRLX_REQUIRE(h_src && h_src->bound[0], "qnet_publish: no parameters bound on the source handle");
     SRLX_REQUIRE(!h_src->eff[0], "qnet_publish: NoisyLinear source");
     SRLX_REQUIRE(h_src->H == 84 && h_src->W == 84 && h_src->Wn == 4 && h_src->F1 == 32, "qnet_publish: the fused convolution kernel's geometry only");
     srlx::DeviceGuard guard(h_src->device);
     hipStream_t st = (hipStream_t)stream;
     if (!h_actor) {
-        SRLX_TRY(srlx_qnet_pack_publish(h_src, nullptr, nullptr, st));
+        SRLX_TRY(srlx_qnet_pack_publish(h_src, nullptr, nullptr, st, d_bump));
         h_src->pack_valid = true;
         return SRLX_OK;
     }
     SRLX_REQUIRE((set == 0 || set == 1) && h_actor->aset[set].wpack, "qnet_publish: srlx_qnet_actor_sets_enable on the actor handle first");
     SRLX_REQUIRE(h_actor->hidden == h_src->hidden && h_actor->A == h_src->A && h_actor->flat == h_src->flat, "qnet_publish: the two handles describe different networks");
     const srlx_small_layout L = srlx_small_offsets(h_actor);
-    SRLX_TRY(srlx_qnet_pack_publish(h_src, &h_actor->aset[set], &L, st));
+    SRLX_TRY(srlx_qnet_pack_publish(h_src, &h_actor->aset[set], &L, st, d_bump));
     if (h_src->aset_cur < 0) h_src->pack_valid = true;
     if (with_fc1) SRLX_TRY(srlx_fc1_planes_split_weight(h_actor, h_src->bound[6], nullptr, st, h_actor->aset[set].wf_planes));
     return SRLX_OK;
@@ -1011,6 +1011,12 @@ int srlx_qnet_set_fc1_neighbour(srlx_qnet_t *h, int splits) {
         h->partial_floats = need;
     }
     h->fc1_neighbour = splits;
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_td_event(srlx_qnet_t *h, void *event) {
+    SRLX_REQUIRE(h, "qnet_set_td_event: NULL handle");
+    h->ev_td = (hipEvent_t)event;
     return SRLX_OK;
 }
 

@@ -699,6 +699,7 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
             hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, dh1t, g_bf, g_v2w, g_v2b, g_a2w,
                                g_a2b, tda, with_td);
     }
+    if (h->ev_td) SRLX_HIP(hipEventRecord(h->ev_td, st));  // target / loss / priorities exist: the caller's priority write-back need not wait for the gradients
     SRLX_TRY(chain_prologue(h, st));
     // ---- data-gradient chain (caller's stream)
     if (mfma_dgrad) {

@@ -64,12 +64,14 @@ struct SmallCopy {
     int len[8];  // elements of each vector (the padding behind it is never read or written)
     float *dst;  // NULL: nothing to copy
     int first;   // first thread index of the copy range
+    long long *bump;  // int64 device counter advanced by the launch (NULL: none): the update's step count, whose readers all ran in earlier launches
 };
 __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
                                                       float *__restrict__ out, float *__restrict__ wT3, float *__restrict__ wT2, float *__restrict__ out2, SmallCopy sm) {
     // one thread per float4 of the packed float32 buffer, then one per (step, lane) of conv1's split-bf16 fragments
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = (kW1 + kW2 + kW3) / 4;
+    if (sm.bump && q == 0) *sm.bump += 1;
     if (sm.dst && q >= sm.first) {
         const int x = q - sm.first;
         if (x >= sm.off[8]) return;
@@ -690,7 +692,7 @@ size_t srlx_qnet_pack_bytes() { return (size_t)kPackFloats * sizeof(float); }
 
 // k_pack_filters over `src`'s bound filters into its own packed buffer (+ the transposed filters of a training handle) and, with `dst_set`, a second copy
 // into an actor set together with the small vectors (layout *L)
-int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st) {
+int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st, int64_t *bump) {
     float *&own = src->aset_cur >= 0 ? src->wpack_own : src->wpack;
     if (!own) SRLX_HIP(hipMalloc((void **)&own, (size_t)kPackFloats * sizeof(float)));
     const bool keep = src->max_train > 0;
@@ -698,6 +700,7 @@ int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const s
     const float *w1 = b ? b[0] : src->w1, *w2 = b ? b[2] : src->w2, *w3 = b ? b[4] : src->w3;
     int pack_threads = (kW1 + kW2 + kW3) / 4 + 16 * 64 + (32 + 36) * 2 * 64 + (keep ? kW3 + kW2 : 0);
     SmallCopy sm{};
+    sm.bump = (long long *)bump;
     if (dst_set) {
         const float *v[8] = {b ? b[1] : src->b1, b ? b[3] : src->b2, b ? b[5] : src->b3, b ? b[7] : src->bf, b ? b[8] : src->v2w, b ? b[9] : src->v2b,
                              b ? b[10] : src->a2w, b ? b[11] : src->a2b};

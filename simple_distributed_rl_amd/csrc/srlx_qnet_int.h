@@ -65,6 +65,7 @@ struct srlx_qnet {
     const float *bound[12];               // what srlx_qnet_bind bound (restored by srlx_qnet_actor_set_select(h, -1))
     int fc1_neighbour;                    // > 0: chip-filling first-dense-layer launches use k_fc1_planes_h (half-CU workgroups) with this many K splits
     size_t partial_floats;                // allocation of `partial`
+    hipEvent_t ev_td;                     // caller-owned or NULL: recorded right behind the head kernel of every backward pass (srlx_qnet_set_td_event)
     void *adam_planes_out;                // the fused Adam of the first dense layer ALSO writes the updated weight as operand planes here (NULL: off)
     // epsilon-greedy fused into the head kernel of the NEXT forward (srlx_qnet_forward_u8_policy)
     struct Policy {
@@ -112,7 +113,7 @@ int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst
 size_t srlx_fc1_planes_weight_bytes(const srlx_qnet *h);
 // srlx_qnet_fused.hip: pack `src`'s convolution filters (its own wpack + transposed filters when it trains) and, with `dst_set`, also into an actor set together
 // with the small vectors
-int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st);
+int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st, int64_t *bump = nullptr);
 size_t srlx_qnet_pack_bytes();
 int srlx_fc1_planes_split_act(srlx_qnet *h, int64_t rows, hipStream_t st);
 bool srlx_fc1_planes_applicable(const srlx_qnet *h, int64_t rows);

@@ -310,10 +310,15 @@ class QNetInference:
         N.check(self.lib.srlx_qnet_actor_set_select(self.h, int(k)))
         self._set = int(k)
 
-    def publish_to(self, actor: "QNetInference" = None, k: int = 0, with_fc1: bool = False):
+    def publish_to(self, actor: "QNetInference" = None, k: int = 0, with_fc1: bool = False, bump: torch.Tensor = None):
         """Pack this handle's convolution filters for its own next forwards and (with `actor`) publish the network into that handle's set k in the same launch;
         with_fc1: also split the first dense layer's weight into the set's planes (out-of-band publishes: start-up, restore)."""
-        N.check(self.lib.srlx_qnet_publish(self.h, actor.h if actor is not None else None, int(k), int(bool(with_fc1)), N.torch_stream_ptr()))
+        N.check(self.lib.srlx_qnet_publish(self.h, actor.h if actor is not None else None, int(k), int(bool(with_fc1)), N.tptr(bump), N.torch_stream_ptr()))
+
+    def set_td_event(self, ev: torch.cuda.Event):
+        """`ev` (already recorded once: torch creates the HIP event lazily) is recorded right behind the head kernel of every backward pass from now on."""
+        self._td_event = ev  # keeps it alive
+        N.check(self.lib.srlx_qnet_set_td_event(self.h, N.c_p(ev.cuda_event) if ev is not None else None))
 
     def fuse_adam_planes(self, planes_ptr):
         """The fused first-dense-layer Adam of the next backward passes also writes the updated weight as operand planes at `planes_ptr` (None: off)."""

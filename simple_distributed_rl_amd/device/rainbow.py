@@ -235,6 +235,14 @@ class RainbowEngine:
             self._set, self._published = 0, None
             self._seen_versions = None
             self.inf_target.set_pack_sticky(True)  # the target network's packed filters change at a sync only
+            # the priority write-back leaves the update's critical path: it needs the head kernel's priorities only, so it runs on the target network's (by then idle)
+            # stream beside the gradient kernels; the step count it used to advance moves to the update's LAST launch (the packing / publishing one)
+            self._update_branch = os.environ.get("SRLX_UPDATE_BRANCH", "0") == "1"
+            if self._update_branch:
+                self._ev_td, self._ev_upd = torch.cuda.Event(), torch.cuda.Event()
+                self._ev_td.record()
+                self.inf_online.set_td_event(self._ev_td)
+                N.check(self.lib.srlx_per_set_update_counter(self.replay.h_per, None))
             self.replay.enable_deferred_advance()
             self._publish_out_of_band()
         self.train_count = 0
@@ -445,9 +453,17 @@ class RainbowEngine:
                     )
                 )
                 self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
+            if self.fast and self._update_branch:  # priorities -> tree, beside the gradient kernels (srlx_qnet_set_td_event)
+                self.s_target.wait_event(self._ev_td)
+                with torch.cuda.stream(self.s_target):
+                    r.update(b.indices, self.priorities)  # model_torch.py:113-114
+                    self._ev_upd.record(self.s_target)
             self.optimizer.step(self.train_count_dev)
-            if self.fast:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors)
-                self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0)
+            if self.fast:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors); train_count_dev += 1
+                self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0, bump=self.train_count_dev if self._update_branch else None)
+                if self._update_branch:
+                    cur.wait_event(self._ev_upd)
+                    return
         else:  # SRLX_TORCH_BACKWARD=1: the test yardstick -- matrix-core evaluation of s_1..s_n, autograd for the gradient step
             b = r.sample_items(self.train_count_dev)
             foff = r.frame_off_next.view(B * n, cfg.window_length)

@@ -1,0 +1,13 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+{
+timeout 1200 python -m pytest tests/test_per_gpu.py tests/test_fast_lockstep_gpu.py tests/test_seams_gpu.py -x -q 2>&1 | tail -4
+for a in 0 1; do echo "ABL=$a"; SRLX_ADD_ABL=$a python tools/_ab_add.py 2>&1 | tail -1; done
+python tools/_ab_update.py 2>&1 | tail -2
+one() { env "$@" timeout 300 python $R/bench.py --no-cpu-baseline --steps 12 2>gpurun_out/bench_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; s=d.get('subfigures',{}); o=d['per_micro']['ops']; print('%-24s %8d env-steps/s  %.4f ms per lock-step  conv %.3f ms  fc1 %.3f ms  actors-only %.3f  update-only %.3f | sample32 %.1f update32 %.1f update64 %.1f add %.1f us | bulk frac %.3f' % ('$*', d['value'], d['ms_per_lock_step'], r['avg_launch_ms'], (r.get('fc1') or {}).get('avg_launch_ms', 0), s.get('actors_only',{}).get('ms_per_lock_step',0), s.get('learner_only',{}).get('ms_per_update',0), o['sample_32']['us_per_call'], o['update_32']['us_per_call'], o['update_64']['us_per_call'], o['add_1024']['us_per_call'], d['per_micro']['frac_of_hbm_peak']))" || tail -20 gpurun_out/bench_err.log; }
+for rep in 1 2; do
+one SRLX_FAST=1
+one SRLX_FAST=0
+done
+} 2>&1 | tee gpurun_out/r4_probe9.log

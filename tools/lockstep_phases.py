@@ -29,6 +29,7 @@ if eng.fast:  # the round-4 lock-step: network pass + selection | environments |
         e[0].record(main)
         eng.fork_learner(1)
         e[5].record(eng.s_learner)
+        e[6].record(main)  # reached as soon as the host is back from the graph launch (the main stream is idle here)
         off = eng.replay.frame_table_current()
         eng.inf_actor.forward_u8_policy(eng.replay.obs_base, off, eng.eps, cfg.seed ^ 0xAC7, eng.policy_counter, eng.actions)
         e[1].record(main)
@@ -41,7 +42,7 @@ if eng.fast:  # the round-4 lock-step: network pass + selection | environments |
         eng.refresh_actor_copy()
         e[4].record(main)
     torch.cuda.synchronize()
-    for nm, i in zip(["policy pass end", "environments end", "ring commit end", "add end (after join)", "learner end"], [1, 2, 3, 4, 5]):
+    for nm, i in zip(["policy pass START", "policy pass end", "environments end", "ring commit end", "add end (after join)", "learner end"], [6, 1, 2, 3, 4, 5]):
         v = sorted(ev[k][0].elapsed_time(ev[k][i]) for k in range(20, n))
         print(f"{nm:26s} median {1e3 * v[len(v) // 2]:7.1f} us   (10 % {1e3 * v[len(v) // 10]:7.1f}, 90 % {1e3 * v[9 * len(v) // 10]:7.1f})")
     sys.exit(0)

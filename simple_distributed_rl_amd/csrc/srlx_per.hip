@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
     }
     __syncthreads();
 
-    unsigned last_me = 0u;  // bit q: this thread's q-th index is the last occurrence of its leaf (a register, not an indexed array: that would live in scratch memory)
+    bool last_me[ (kUpdateChunk + kWgUpdate - 1) / kWgUpdate ];
     int q = 0;
     for (i64 i = t; i < n; i += T, q++) {
         const i64 x = s_idx[i];
@@ -746,12 +746,12 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
         }
         const double before = prev >= 0 ? s_p[prev] : tr.get(x);
         s_chg[i] = s_p[i] - before;  // :83
-        last_me |= (last ? 1u : 0u) << q;
+        last_me[q] = last;
     }
     __syncthreads();  // every old leaf value has been read
     q = 0;
     for (i64 i = t; i < n; i += T, q++)
-        if ((last_me >> q) & 1u) tr.set(s_idx[i], s_p[i]);  // :85
+        if (last_me[q]) tr.set(s_idx[i], s_p[i]);  // :85
 
     // ancestors (:49-54).  task (i, k): the k-th ancestor of index i; the first i that reaches a
     // node owns it.

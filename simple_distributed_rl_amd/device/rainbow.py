@@ -355,6 +355,12 @@ class RainbowEngine:
             self.actor_commit_ring()
             self.replay.add_masked()
             return
+        if self.actor_priority:  # the deferred add and its bookkeeping (mask, first slot, pass count) live in the piecewise calls: take exactly that path
+            self.actor_front()
+            self._add_with_actor_priorities()
+            self.actor_commit()
+            self.total_env_steps -= self.cfg.n_envs  # (actor_commit counted the lock-step; callers of actor_step count it themselves)
+            return
         self._actor_select(self._actor_net())
         self._actor_commit()
 

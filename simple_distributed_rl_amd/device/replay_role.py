@@ -13,8 +13,11 @@ updates the trainer sends back through a second bounded queue (`train_to_mem`, :
 The two bounded queues become a static software pipeline (deterministic, no polling): per lock-step the replay rank sends `updates` batch messages and
 the learner returns as many priority write-backs; the learner trains on the batch it received `prefetch` lock-steps earlier (so `prefetch` batches are
 always in flight: the reference's depth-5 prefetch queue), and the replay rank applies a write-back one lock-step after it was produced (its backlog is
-bounded by construction; the reference bounds it at 100).  A batch message whose header says "not warm yet" is skipped by the learner; every step moves
-the same number of messages, so the ranks need no other handshake.  The network kernels take (base pointer, offset table): the learner evaluates the
+bounded by construction; the reference bounds it at 100).  Per lock-step each of the two ranks issues ALL its transfers with the other as ONE group
+(`dist.batch_isend_irecv`: on RCCL every send / receive of a rank pair shares one communicator stream, and ungrouped non-blocking calls posted in opposite
+orders on the two sides wait for each other forever) and completes it at the start of its next lock-step.  Whether a batch is "warm" is a function of the
+lock-step it was served in (the replay's fill level is lock-steps x environments), so both ranks compute it on the host: no header is read back from the
+device, no `.item()` in the loop (the header still travels and SRLX_CHECK_HEADERS=1 compares it).  Every buffer is allocated once.  The network kernels take (base pointer, offset table): the learner evaluates the
 packed frames exactly as it would a ring, through the same `RainbowEngine` update (online + target pass, fused TD / Huber / priorities, hand-written
 backward, Adam) with a served batch standing in for its replay.
 """
@@ -119,17 +122,24 @@ class ReplayRoleRainbow:
             self.replay = DeviceReplay(total, -(-cfg.memory_capacity // total) + n + W, F, W, n, cfg.n_actions, B, True, cfg.enable_reward_clip, cfg.memory_alpha,
                                        cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
                                        has_duplicate=cfg.memory_has_duplicate)
-            self.msg = [torch.zeros(self.codec.nbytes, dtype=torch.uint8, device=self.dev) for _ in range(2 * self.updates + 1)]  # send buffers, round robin
+            xdev = "cpu" if self.staged else self.dev
+            self.msg = [torch.zeros(self.codec.nbytes, dtype=torch.uint8, device=self.dev) for _ in range(2 * self.updates)]  # batches: built here, two lock-steps deep
+            self.msg_tx = [torch.zeros(self.codec.nbytes, dtype=torch.uint8, device=xdev) for _ in range(2 * self.updates)] if self.staged else self.msg
+            self.wb_rx = [torch.zeros(16 + 12 * B, dtype=torch.uint8, device=xdev) for _ in range(2 * self.updates)]
+            self.wb_dev = torch.zeros(16 + 12 * B, dtype=torch.uint8, device=self.dev)
             self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)  # the learner's train count as far as this rank knows (beta schedule)
-            self._wb_pending = []  # (work, host/device buffer) of write-backs posted and not yet applied
-            self._sends = []
+            self._works = []  # the group posted in the previous lock-step
         if self.role == "learner":
             self.served_batch = ServedBatch(self.codec, self.dev, self.local.train_count_dev)
-            self._rx = []  # (work, buffer) in arrival order
-            self._rx_bufs = [torch.zeros(self.codec.nbytes, dtype=torch.uint8, device="cpu" if self.staged else self.dev)
-                             for _ in range((self.prefetch + 1) * self.updates + 1)]
+            xdev = "cpu" if self.staged else self.dev
+            self._rx = []  # (serve lock-step, buffer) of received batches, in arrival order
+            self._rx_bufs = [torch.zeros(self.codec.nbytes, dtype=torch.uint8, device=xdev) for _ in range((self.prefetch + 2) * self.updates)]
             self._rx_n = 0
-            self._wb_sends = []
+            self.wb_tx = [torch.zeros(16 + 12 * B, dtype=torch.uint8, device=xdev) for _ in range(2 * self.updates)]
+            self._posted = []  # (serve lock-step, buffer) of the receives in the group posted in the previous lock-step
+            self._works = []
+        self.check_headers = __import__("os").environ.get("SRLX_CHECK_HEADERS", "0") == "1"
+        self._total_envs = self.n_actor_ranks * E
         # first observations of every actor environment -> the replay rank's ring position 0
         if self.role == "actor":
             got = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, self.local.first_obs)
@@ -152,9 +162,18 @@ class ReplayRoleRainbow:
         else:
             dist.broadcast(self.flat, src=LEARNER, group=self.weights_group)
 
-    def _send(self, t: torch.Tensor, dst: int):
-        src = t.cpu() if self.staged else t
-        return dist.isend(src, dst), src
+    def _warm_at(self, serve_step: int) -> bool:
+        """Was the replay past its warm-up gate when it served the batches of lock-step `serve_step`?  (it has committed `serve_step` lock-steps by then)"""
+        return serve_step >= 0 and min(self.cfg.memory_capacity, serve_step * self._total_envs) >= self.cfg.memory_warmup_size
+
+    def _trained_from(self, learner_step: int) -> int:
+        """The serve lock-step of the batch the learner trains on in its lock-step `learner_step` (negative: nothing has arrived yet)."""
+        return learner_step - 1 - self.prefetch
+
+    @staticmethod
+    def _complete(works):
+        for w in works:
+            w.wait()
 
     # ---- the driver interface of device/mp_runner.py (what DistributedRainbow offers) ------------------------------------------------------
     @property
@@ -189,31 +208,33 @@ class ReplayRoleRainbow:
         self._in_flight = True
 
     def _step_replay(self):
-        rp, c = self.replay, self.codec
+        rp, c, U, s_now = self.replay, self.codec, self.updates, self.step_count
         if self._in_flight:
             rp.commit(*self._actor_rows(self.bus.push_end()))
-        z = torch.zeros(self.cfg.n_envs, device=self.dev)  # this rank contributes nothing: push_begin only posts the receives
-        self.bus.push_begin(z.int(), z, z.to(torch.uint8), z.to(torch.uint8), torch.zeros((1, 1), dtype=torch.uint8, device=self.dev))
+        if not hasattr(self, "_zeros"):
+            z = torch.zeros(self.cfg.n_envs, device=self.dev)  # this rank contributes nothing: push_begin only posts the receives
+            self._zeros = (z.int(), z, z.to(torch.uint8), z.to(torch.uint8), torch.zeros((1, 1), dtype=torch.uint8, device=self.dev))
+        self.bus.push_begin(*self._zeros)
         self._in_flight = True
-        # the write-backs the learner produced during the PREVIOUS lock-step (posted then): apply, then post this lock-step's
-        for work, buf in self._wb_pending:
-            work.wait()
-            wb = buf.to(self.dev) if self.staged else buf
-            if int(wb[:8].view(torch.int64).item()) == 1:
-                B = c.B
+        # the group of the previous lock-step: its batches are out, the write-backs the learner produced during that lock-step are in -- apply them
+        self._complete(self._works)
+        if s_now >= 1 and self._warm_at(self._trained_from(s_now - 1)):
+            B = c.B
+            for u in range(U):
+                buf = self.wb_rx[((s_now - 1) % 2) * U + u]
+                wb = self.wb_dev
+                wb.copy_(buf, non_blocking=True)
+                if self.check_headers:
+                    assert int(wb[:8].view(torch.int64).item()) == 1, "a write-back the schedule calls valid says it is not"
                 rp.update(wb[16 : 16 + 8 * B].view(torch.int64), wb[16 + 8 * B :].view(torch.float32))
                 self.step_dev.add_(1)
-        self._wb_pending = []
-        for _ in range(self.updates):
-            buf = torch.zeros(16 + 12 * c.B, dtype=torch.uint8, device="cpu" if self.staged else self.dev)
-            self._wb_pending.append((dist.irecv(buf, LEARNER), buf))
-        # serve `updates` batches
-        for w, _ in self._sends:
-            w.wait()
-        self._sends = []
-        for u in range(self.updates):
-            m = self.msg[(self.served + u) % len(self.msg)]
-            warm = not rp.is_warmup_needed()
+        # serve `updates` batches (built into this lock-step's half of the ring; the other half may still be read by the previous group's sends -- completed above)
+        warm = self._warm_at(s_now)
+        assert warm == (not rp.is_warmup_needed())
+        ops = []
+        for u in range(U):
+            k = (s_now % 2) * U + u
+            m = self.msg[k]
             c.view(m, "header", torch.int64)[0] = 1 if warm else 0
             if warm:
                 b = rp.sample_items(self.step_dev, all_states=True)
@@ -223,26 +244,39 @@ class ReplayRoleRainbow:
                 N.check(rp.lib.srlx_pack_frames(N.c_p(rp.obs_base), N.tptr(rp.frame_off_all), c.rows, c.F, N.c_p(m.data_ptr() + c.off["frames"][0]), N.tptr(rel),
                                                 N.torch_stream_ptr()))
                 c.view(m, "rel_next", torch.int64).copy_(rel.view(c.B, c.n + 1, c.W)[:, 1:].reshape(-1))  # s_1..s_n are rows 1.. of every item
-            self._sends.append(self._send(m, LEARNER))
-        self.served += self.updates
+            if self.staged:
+                self.msg_tx[k].copy_(m)
+            ops.append(dist.P2POp(dist.irecv, self.wb_rx[k], LEARNER))
+        for u in range(U):
+            ops.append(dist.P2POp(dist.isend, self.msg_tx[(s_now % 2) * U + u], LEARNER))
+        if not self.staged:
+            torch.cuda.current_stream(self.dev).synchronize()  # the messages are complete before the communicator's stream reads them (RCCL orders with the CURRENT stream: kept explicit)
+        self._works = dist.batch_isend_irecv(ops)
+        self.served += U
 
     def _step_learner(self):
-        eng, c, sb = self.local, self.codec, self.served_batch
-        for w, _ in self._wb_sends:
-            w.wait()
-        self._wb_sends = []
-        for _ in range(self.updates):  # post this lock-step's receives
+        eng, c, sb, U, s_now = self.local, self.codec, self.served_batch, self.updates, self.step_count
+        # the group of the previous lock-step: that lock-step's batches have arrived, its write-backs are out
+        self._complete(self._works)
+        self._rx.extend(self._posted)
+        ops, self._posted = [], []
+        for u in range(U):  # this lock-step's receives
             buf = self._rx_bufs[self._rx_n % len(self._rx_bufs)]
-            self._rx.append((dist.irecv(buf, REPLAY), buf))
             self._rx_n += 1
-        for _ in range(self.updates):
+            self._posted.append((s_now, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, REPLAY))
+        t_serve = self._trained_from(s_now)
+        for u in range(U):
+            out = self.wb_tx[(s_now % 2) * U + u]
             valid = False
-            if len(self._rx) > self.prefetch * self.updates:  # train on the batch that arrived `prefetch` lock-steps ago
-                work, buf = self._rx.pop(0)
-                work.wait()
-                sb.stage.copy_(buf.to(self.dev) if self.staged else buf)
-                valid = int(c.view(sb.stage, "header", torch.int64)[0].item()) == 1
+            if t_serve >= 0:  # train on the batch that arrived `prefetch` lock-steps ago
+                tag, buf = self._rx.pop(0)
+                assert tag == t_serve
+                valid = self._warm_at(t_serve)
                 if valid:
+                    sb.stage.copy_(buf, non_blocking=True)
+                    if self.check_headers:
+                        assert int(c.view(sb.stage, "header", torch.int64)[0].item()) == 1, "a batch the schedule calls warm says it is not"
                     saved, eng.replay = eng.replay, sb
                     try:
                         eng._learner_body()
@@ -253,7 +287,11 @@ class ReplayRoleRainbow:
                     eng.train_count += 1
                     self.trained += 1
             sb.out[:8].view(torch.int64)[0] = 1 if valid else 0
-            self._wb_sends.append(self._send(sb.out.clone(), REPLAY))
+            out.copy_(sb.out, non_blocking=not self.staged)
+            ops.append(dist.P2POp(dist.isend, out, REPLAY))
+        if not self.staged:
+            torch.cuda.current_stream(self.dev).synchronize()
+        self._works = dist.batch_isend_irecv(ops)
 
     def finish(self):
         """Complete what is in flight: every message posted is matched (each lock-step moved the same number in both directions)."""
@@ -262,15 +300,10 @@ class ReplayRoleRainbow:
         if self.role == "replay":
             if self._in_flight:
                 self.replay.commit(*self._actor_rows(self.bus.push_end()))
-            for w, _ in self._sends:
-                w.wait()
-            for work, buf in self._wb_pending:
-                work.wait()
+            self._complete(self._works)
         if self.role == "learner":
-            for w, _ in self._wb_sends:
-                w.wait()
-            for work, _ in self._rx:  # the prefetched batches nobody will train on any more
-                work.wait()
+            self._complete(self._works)  # (the batches received last are never trained on)
+        self._works = []
         self._in_flight = False
         torch.cuda.synchronize(self.dev)
 

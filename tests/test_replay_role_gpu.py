@@ -50,9 +50,9 @@ def test_a_served_batch_is_the_ring_batch():
     assert torch.equal(q_ring, q_msg)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, prefetch=2):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), SRLX_CHECK_HEADERS="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig
@@ -60,7 +60,7 @@ def _worker(rank, world, port, ret):
 
         torch.cuda.set_device(0)
         cfg = RainbowDeviceConfig(n_envs=16, batch_size=8, memory_capacity=2 * 16 * 40, memory_warmup_size=64, target_model_update_interval=5, seed=0)
-        top = ReplayRoleRainbow(cfg, 0, episode_len=9, sync_interval=4, prefetch=2, updates=1)
+        top = ReplayRoleRainbow(cfg, 0, episode_len=9, sync_interval=4, prefetch=prefetch, updates=1)
         w0 = float(top.flat.double().sum()) if top.role != "replay" else None
         T = 40
         for _ in range(T):
@@ -75,18 +75,21 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_three_roles_actors_replay_learner():
+@pytest.mark.parametrize("prefetch", [2, 5])  # 5 = the reference's queue depth (play_mp_memory.py:595-621)
+def test_three_roles_actors_replay_learner(prefetch):
+    """Every transfer between the replay and the learner rank of a lock-step is one dist.batch_isend_irecv group per side; whether a batch / write-back is valid
+    is computed on the host from the lock-step it belongs to, and SRLX_CHECK_HEADERS=1 (set in the workers) compares that with the header that travelled."""
     world = 4  # learner, replay, two actor ranks
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, prefetch), nprocs=world, join=True)
     r = dict(ret)
     learner, replay, actors = r[0], r[1], [r[2], r[3]]
     assert learner["role"] == "learner" and replay["role"] == "replay" and all(a["role"] == "actor" for a in actors)
     assert all(a["env_steps_local"] == 40 * 16 for a in actors) and learner["env_steps_local"] == 0 and replay["env_steps_local"] == 0
     assert replay["memory"] > 64 and replay["served"] == 40  # one batch message per lock-step, warm or not
     # the learner trained on every WARM batch that arrived `prefetch` lock-steps before the end, and every update came back as a priority write-back
-    assert learner["train_count"] >= 10 and np.isfinite(learner["loss"])
+    assert learner["train_count"] >= 40 - 3 - 1 - prefetch - 2 and np.isfinite(learner["loss"])  # warm from lock-step 2 on (64 / 32 environments), trained from prefetch + 1 lock-steps later
     assert learner["train_count"] - 1 <= replay["write_backs"] <= learner["train_count"]
     # the weights reached the actor ranks: after the broadcast of the last multiple of sync_interval all three hold the learner's parameters of that moment;
     # they moved away from the initialisation on every rank that acts or learns

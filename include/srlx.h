@@ -431,6 +431,12 @@ int srlx_store_gather_items(srlx_store_t *h, int64_t batch, const int64_t *d_tre
                             int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream);
 int srlx_store_gather_train(srlx_store_t *h, int64_t batch, const int64_t *d_tree_idx, int64_t *d_frame_off_all, int64_t *d_frame_off_next,
                             int32_t *d_actions, float *d_rewards, float *d_terminated, void *stream);
+/* srlx_per_sample_keyed + srlx_store_gather_train as ONE launch: the learner's draw (proportional_memory.py:131-169), then the location, n-step scalars
+ * (rainbow.py:190-194 with the terminal padding of :354-372) and frame-offset tables of the drawn items of `store`, whose leaf j is this tree's slot j.  Up to 64
+ * items; device pointers only; outputs as the two calls'. */
+int srlx_per_sample_gather_train(srlx_per_t *h, srlx_store_t *store, int64_t batch_size, const int64_t *d_step, uint64_t seed, int64_t *d_counter, int64_t n_uniforms,
+                                 int64_t *d_out_idx, float *d_out_w32, int64_t *d_out_used, int64_t *d_frame_off_all, int64_t *d_frame_off_next, int32_t *d_actions,
+                                 float *d_rewards, float *d_terminated, void *stream);
 /* Actor-side initial priorities (rainbow.py:389-398: a distributed worker hands `abs(calc_target_q([batch]) - q[action])` to memory.add): for the E items the LAST
  * commit completed -- PER slots first_slot .. first_slot + E - 1 (mod per_capacity), lane e's item in slot first_slot + e -- the n-step / retrace TD of
  * rainbow.py:226-287 on CACHED Q rows: d_q_hist f32 [n_step + 1][E][n_actions] is a ring over the acting passes, row (base_slot + k) mod (n_step + 1) holds

@@ -30,6 +30,7 @@
 #include <new>
 
 #include "srlx_common.h"
+#include "srlx_store_dev.h"
 
 namespace {
 
@@ -224,8 +225,7 @@ struct SampleArgs {
 // in-order acceptance (zero-priority and duplicate rejects consume a uniform each, :146-157),
 // prefix-sum compaction, IS weights and max-normalisation (:163-167) in ONE launch.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ bool sample_wg_body(const SampleArgs &a, unsigned char *smem) {
     double *red = reinterpret_cast<double *>(smem);                 // blockDim doubles
     int *ibuf = reinterpret_cast<int *>(red + blockDim.x);          // blockDim ints
     unsigned char *flags = reinterpret_cast<unsigned char *>(ibuf + blockDim.x);  // n_uniforms bytes
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
     }
     if (t == 0 && total_ok < B) *a.out_used = -1;
     __syncthreads();
-    if (total_ok < B) return;
+    if (total_ok < B) return false;
 
     // phase 4: importance weights (:163-167)
     const i64 step = a.d_step ? *a.d_step : a.step;
@@ -299,6 +299,29 @@ __global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
         if (a.out_w) a.out_w[i] = w;
         if (a.out_w32) a.out_w32[i] = (float)w;
     }
+    return true;
+}
+
+__global__ void __launch_bounds__(kWgSample) k_sample_wg(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    (void)sample_wg_body(a, smem);
+}
+
+// The learner's draw AND its gather as one launch (round 4): the single-workgroup sampler, then -- same workgroup, the indices it has just written -- item location,
+// n-step scalars and both frame-offset tables of the store (srlx_store_dev.h: what k_gather_train of srlx_rollout.hip does).  B <= 64 items.
+struct GatherArgs {
+    srlxs::StoreDev store;
+    srlxs::ItemMeta *meta;
+    int32_t *actions;
+    float *rewards, *terminated;
+    i64 *off_all, *off_next;
+};
+__global__ void __launch_bounds__(kWgSample) k_sample_gather_wg(SampleArgs a, GatherArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ srlxs::ItemMeta sm[srlxs::kTrainItems];
+    if (!sample_wg_body(a, smem)) return;  // (not enough accepted draws: out_used = -1, the batch is not touched)
+    __syncthreads();  // out_idx is complete (written by this workgroup: visible through the CU's own cache)
+    srlxs::gather_train_items(g.store, 0, (int)a.batch, a.out_idx, g.meta, g.actions, g.rewards, g.terminated, g.off_all, g.off_next, sm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1388,6 +1411,33 @@ int srlx_per_sample_keyed(srlx_per_t *h, int64_t batch_size, const int64_t *d_st
     SRLX_REQUIRE(d_step && d_counter && d_out_idx && d_out_used, "per_sample_keyed: NULL argument");
     srlx::DeviceGuard guard(h->device);
     return launch_sample(h, batch_size, 0, d_step, nullptr, n_uniforms, d_out_idx, d_out_w, d_out_w32, d_out_used, pick_stream(h, stream), seed, d_counter);
+}
+
+int srlx_per_sample_gather_train(srlx_per_t *h, srlx_store_t *store, int64_t batch_size, const int64_t *d_step, uint64_t seed, int64_t *d_counter, int64_t n_uniforms,
+                                 int64_t *d_out_idx, float *d_out_w32, int64_t *d_out_used, int64_t *d_frame_off_all, int64_t *d_frame_off_next, int32_t *d_actions,
+                                 float *d_rewards, float *d_terminated, void *stream) {
+    SRLX_REQUIRE(h && store, "per_sample_gather_train: NULL handle");
+    SRLX_REQUIRE(batch_size > 0 && batch_size <= srlxs::kTrainItems && n_uniforms >= batch_size && n_uniforms <= kSmallSampleMax,
+                 "per_sample_gather_train: 1..%d items, batch_size..%lld uniforms", srlxs::kTrainItems, (long long)kSmallSampleMax);
+    SRLX_REQUIRE(d_step && d_counter && d_out_idx && d_out_w32 && d_out_used && d_frame_off_all && d_actions && d_rewards && d_terminated, "per_sample_gather_train: NULL argument");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick_stream(h, stream);
+    GatherArgs g{};
+    SRLX_TRY(srlx_store_dev_view(store, batch_size, &g.store, &g.meta));
+    SRLX_REQUIRE(g.store.obs_dtype == SRLX_OBS_U8, "per_sample_gather_train: uint8 stores only");
+    g.actions = d_actions, g.rewards = d_rewards, g.terminated = d_terminated, g.off_all = (i64 *)d_frame_off_all, g.off_next = (i64 *)d_frame_off_next;
+    const i64 M = n_uniforms, B = batch_size;
+    SRLX_TRY(h->scratch.reserve(SampleScratch::bytes(M, B, false)));
+    srlx::Carver cv(h->scratch.ptr);
+    SampleArgs a{};
+    a.tr = h->tree, a.state = h->d_state, a.beta_initial = h->beta_initial, a.beta_steps = h->beta_steps, a.step = 0, a.d_step = d_step;
+    a.has_duplicate = h->has_duplicate, a.uniforms = nullptr, a.key_seed = seed, a.key_counter = d_counter, a.n_uniforms = M, a.batch = B;
+    a.out_idx = d_out_idx, a.out_w = nullptr, a.out_w32 = d_out_w32, a.out_used = d_out_used;
+    a.cand_idx = cv.take<i64>(M), a.cand_p = cv.take<double>(M), a.map = cv.take<i64>(B), a.wtmp = cv.take<double>(B);
+    const size_t lds = (size_t)kWgSample * (8 + 4) + (size_t)M + 16;
+    hipLaunchKernelGGL(k_sample_gather_wg, dim3(1), dim3(kWgSample), lds, st, a, g);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
 }
 
 int srlx_per_update(srlx_per_t *h, int64_t n, const int64_t *indices, const void *prio, int prio_kind, int on_device,

@@ -825,6 +825,8 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
         if (p) (void)hipFree(p);
     for (float *p : h->eff)
         if (p) (void)hipFree(p);
+    if (h->c1_gpart) (void)hipFree(h->c1_gpart);
+    if (h->c1_cnt) (void)hipFree(h->c1_cnt);
     if (h->d_draw) (void)hipFree(h->d_draw);
     if (h->aset_cur >= 0) h->wpack = h->wpack_own, h->wf_planes = h->wf_planes_own;
     for (auto &st_ : h->aset) {

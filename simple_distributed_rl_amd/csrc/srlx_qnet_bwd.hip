@@ -447,7 +447,8 @@ __global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int
 // one byte.  The two pixel interleaves are added through LDS (ph order): a sample leaves 4 partial tensors.
 __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, i64 sstride, int Wn, int H, int W,
                                                           int OH, int OW, int per, const float *__restrict__ dY1, float *__restrict__ part,
-                                                          float *__restrict__ bias_part) {
+                                                          float *__restrict__ bias_part, float *__restrict__ gpart, unsigned *__restrict__ tickets,
+                                                          float *__restrict__ g_w1, float *__restrict__ g_b1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u8 *fr = smem;                                                           // [88][88]
     int *poff = reinterpret_cast<int *>(smem + kC1Frame);                    // [per]
@@ -511,6 +512,66 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
             part[(((i64)b * kC1Chunks + half) * 32 + co) * K + c * 64 + tt * 32 + i] = acc[r] + red[(tt * 16 + r) * 64 + lane];
         }
     }
+    // ---- the reduction over (sample, pixel chunk) inside the launch (round 4: it was a launch of its own, k_reduce_parts -- 4 us of work that cost the update's
+    // critical path 17 us beside the actors).  Fixed summation order, the one k_reduce_parts used: the samples in four groups, a group's parts added in (sample,
+    // chunk) order by the LAST workgroup of the group to arrive (ticket per frame and group), the four group sums added in order by the last group to finish.
+    // Publication: plain stores -> barrier -> one lane's agent-scope fence -> ticket; the reducer: ticket -> agent-scope fence (this CU's L1 drops what it holds
+    // of other CUs' lines) -> barrier -> plain loads (MI355X_MICROARCH.md, inter-workgroup visibility).  Tickets rewind themselves.
+    const int B = gridDim.x, K = Wn * 64;
+    const int gs = (B + 3) / 4, g = (int)b / gs, ng = (B + gs - 1) / gs;
+    const int b_lo = g * gs, b_hi = b_lo + gs < B ? b_lo + gs : B;
+    __shared__ int s_last;
+    __syncthreads();
+    if (t == 0) {
+        __threadfence();
+        s_last = atomicAdd(&tickets[c * 5 + g], 1u) == (unsigned)((b_hi - b_lo) * kC1Chunks) - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (t == 0) __threadfence();
+    __syncthreads();
+    float4 *gp = reinterpret_cast<float4 *>(gpart + ((i64)c * 4 + g) * (32 * 64 + 32));
+    for (int q = t; q < 32 * 16; q += 256) {
+        const int co = q >> 4, tap4 = (q & 15) * 4;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int p = b_lo * kC1Chunks; p < b_hi * kC1Chunks; p++) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + ((i64)p * 32 + co) * K + c * 64 + tap4);
+            sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+        }
+        gp[q] = sum;
+    }
+    if (c == 0 && t < 32) {
+        float bs = 0.f;
+        for (int p = b_lo * kC1Chunks; p < b_hi * kC1Chunks; p++) bs += bias_part[(i64)p * 32 + t];
+        reinterpret_cast<float *>(gp)[32 * 64 + t] = bs;
+    }
+    __syncthreads();
+    if (t == 0) {
+        tickets[c * 5 + g] = 0u;
+        __threadfence();
+        s_last = atomicAdd(&tickets[c * 5 + 4], 1u) == (unsigned)ng - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (t == 0) __threadfence();
+    __syncthreads();
+    const float *g0 = gpart + (i64)c * 4 * (32 * 64 + 32);
+    for (int q = t; q < 32 * 16; q += 256) {
+        const int co = q >> 4, tap4 = (q & 15) * 4;
+        float4 sum = reinterpret_cast<const float4 *>(g0)[q];
+        for (int k = 1; k < ng; k++) {
+            const float4 v = reinterpret_cast<const float4 *>(g0 + (i64)k * (32 * 64 + 32))[q];
+            sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(g_w1 + (i64)co * K + c * 64 + tap4) = sum;
+    }
+    if (c == 0 && t < 32) {
+        float bs = g0[32 * 64 + t];
+        for (int k = 1; k < ng; k++) bs += g0[(i64)k * (32 * 64 + 32) + 32 * 64 + t];
+        g_b1[t] = bs;
+    }
+    if (t == 0) tickets[c * 5 + 4] = 0u;
 }
 
 }  // namespace
@@ -557,6 +618,9 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
     // (one side stream, created WITHOUT a priority: a second side stream, or hipStreamCreateWithPriority at either end of the range,
     // changes which hardware queues the learner's branches land on -- measured: the update then no longer overlaps the actors' pass
     // at all (0.84 instead of 0.755 ms per lock-step); GPU_MAX_HW_QUEUES above the default 4 triples the update's own time)
+    SRLX_HIP(hipMalloc((void **)&h->c1_gpart, (size_t)h->Wn * 4 * (32 * 64 + 32) * sizeof(float)));
+    SRLX_HIP(hipMalloc((void **)&h->c1_cnt, (size_t)h->Wn * 5 * sizeof(unsigned)));
+    SRLX_HIP(hipMemset(h->c1_cnt, 0, (size_t)h->Wn * 5 * sizeof(unsigned)));
     SRLX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     for (hipEvent_t *e : {&h->ev_fork, &h->ev_d3, &h->ev_d2, &h->ev_d1, &h->ev_join, &h->ev_wt})
         SRLX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -652,8 +716,7 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
     float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
     hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(kC1Chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
-                       h->dact1, c1_part, c1_bias);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, st, c1_part, kC1Chunks * B, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1);
+                       h->dact1, c1_part, c1_bias, h->c1_gpart, h->c1_cnt, g_w1, g_b1);  // (reduces its own partial sums: no k_reduce_parts launch behind it)
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     return SRLX_OK;
 }

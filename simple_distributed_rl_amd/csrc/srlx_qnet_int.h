@@ -65,6 +65,8 @@ struct srlx_qnet {
     const float *bound[12];               // what srlx_qnet_bind bound (restored by srlx_qnet_actor_set_select(h, -1))
     int fc1_neighbour;                    // > 0: chip-filling first-dense-layer launches use k_fc1_planes_h (half-CU workgroups) with this many K splits
     size_t partial_floats;                // allocation of `partial`
+    float *c1_gpart;                      // conv1 weight gradient: group partial sums [Wn][4][32 x 64 + 32] of the in-launch reduction
+    unsigned *c1_cnt;                     // ... and its arrival tickets [Wn][5] (zero between launches)
     hipEvent_t ev_td;                     // caller-owned or NULL: recorded right behind the head kernel of every backward pass (srlx_qnet_set_td_event)
     void *adam_planes_out;                // the fused Adam of the first dense layer ALSO writes the updated weight as operand planes here (NULL: off)
     // epsilon-greedy fused into the head kernel of the NEXT forward (srlx_qnet_forward_u8_policy)

@@ -16,38 +16,12 @@
 #include <new>
 
 #include "srlx_common.h"
+#include "srlx_store_dev.h"
 #include "srlx_td_math.h"
 
 namespace {
 
-using i64 = int64_t;
-using u64 = unsigned long long;
-using u8 = unsigned char;
-
-constexpr u8 kTerm = 1, kDone = 2, kInvalid = 4;
-
-using srlx::mix64;
-using srlx::rng_u64;
-using srlx::u53;
-
-__device__ __forceinline__ i64 posmod(i64 a, i64 m) {
-    i64 r = a % m;
-    return r < 0 ? r + m : r;
-}
-
-struct StoreDev {
-    i64 E, L, F;
-    int obs_dtype, W, n, A, reward_clip;
-    u64 seed;
-    i64 item_len;
-    void *obs;
-    int32_t *action;
-    float *reward;
-    u8 *flags;
-    int32_t *step_in_ep;
-    i64 *pos;  // [0] ring position p, [1] rng counter
-    u8 *needs_reset;
-};
+using namespace srlxs;
 
 // u8/255 in float32, correctly rounded (image_processor.py:140-142 `state.astype(float32); state /= 255`)
 __device__ __forceinline__ float norm_u8(unsigned b) { return __fdiv_rn((float)b, 255.0f); }
@@ -243,51 +217,6 @@ __global__ void __launch_bounds__(256) k_commit_step(StoreDev s, const int32_t *
 // ------------------------------------------------------------------------------------------
 // gather_nstep
 // ------------------------------------------------------------------------------------------
-struct ItemMeta {
-    i64 e, q;
-    int jd;  // first transition index that ended the episode (n if none)
-    int pad;
-};
-
-// per sampled item: locate (env, position), find the episode end inside the window, emit the scalars
-__device__ __forceinline__ ItemMeta item_meta(const StoreDev &s, i64 b, const i64 *tree_idx, int32_t *actions, float *rewards, float *terminated) {
-    ItemMeta out;
-    const i64 N = s.E * s.item_len;
-    i64 j = tree_idx[b] - (N - 1);
-    if (j < 0) j = 0;
-    if (j >= N) j = N - 1;
-    const i64 e = j % s.E, tau = j / s.E;
-    const i64 p_last = s.pos[0] - 1;
-    const i64 p_add = p_last - posmod(p_last - tau, s.item_len);
-    i64 q = p_add - (s.n - 1);
-    if (q < 0) q = 0;
-    const i64 base = e * s.L;
-    int jd = s.n;
-    for (int k = 0; k < s.n; k++)
-        if (s.flags[base + posmod(q + k, s.L)] & kDone) {
-            jd = k;
-            break;
-        }
-    out.e = e;
-    out.q = q;
-    out.jd = jd;
-    out.pad = 0;
-    for (int k = 0; k < s.n; k++) {
-        const i64 r = base + posmod(q + k, s.L);
-        if (k <= jd) {
-            actions[b * s.n + k] = s.action[r];
-            rewards[b * s.n + k] = s.reward[r];
-            terminated[b * s.n + k] = (s.flags[r] & kTerm) ? 1.f : 0.f;
-        } else {
-            // terminal padding (rainbow.py:354-372): random action, reward 0, terminated 1.  The action is
-            // a fixed function of the item so that re-sampling the item reproduces it.
-            actions[b * s.n + k] = (int32_t)(rng_u64(s.seed ^ 0x70616464ull, (u64)(e * 0x100000000ll + (q & 0xffffffffll)), (u64)k) % (u64)s.A);
-            rewards[b * s.n + k] = 0.f;
-            terminated[b * s.n + k] = 1.f;
-        }
-    }
-    return out;
-}
 __global__ void __launch_bounds__(256) k_gather_meta(StoreDev s, i64 B, const i64 *tree_idx, ItemMeta *meta,
                                                       int32_t *actions, float *rewards, float *terminated) {
     const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,11 +288,6 @@ __global__ void __launch_bounds__(256) k_gather_obs(StoreDev s, i64 B, const Ite
 // uint8 frame inside the ring (or -1 for the all-zero history before an episode start), so that the
 // first convolution can read the ring directly and the float32 stacked observation never exists.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ i64 frame_offset(const StoreDev &s, i64 e, i64 x, int c) {
-    const int back = s.W - 1 - c;
-    if (back > s.step_in_ep[e * s.L + posmod(x, s.L)]) return -1;
-    return (e * s.L + posmod(x - back, s.L)) * s.F;
-}
 __global__ void __launch_bounds__(256) k_frame_table_current(StoreDev s, i64 *out) {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= s.E * s.W) return;
@@ -382,27 +306,12 @@ __global__ void __launch_bounds__(256) k_frame_table_items(StoreDev s, i64 B, co
 
 // the learner's whole "gather" in one launch: item location + n-step scalars (k_gather_meta) and both offset tables
 // (s_0..s_n for the online network, s_1..s_n for the target network); 64 items per workgroup, their metadata in LDS
-constexpr int kTrainItems = 64;
 __global__ void __launch_bounds__(256) k_gather_train(StoreDev s, i64 B, const i64 *tree_idx, ItemMeta *meta, int32_t *actions, float *rewards,
                                                        float *terminated, i64 *off_all, i64 *off_next) {
     __shared__ ItemMeta sm[kTrainItems];
-    const int t = threadIdx.x;
     const i64 b0 = (i64)blockIdx.x * kTrainItems;
     const int cnt = (int)(B - b0 < kTrainItems ? B - b0 : kTrainItems);
-    if (t < cnt) {
-        sm[t] = item_meta(s, b0 + t, tree_idx, actions, rewards, terminated);
-        meta[b0 + t] = sm[t];
-    }
-    __syncthreads();
-    const int S = s.n + 1, W = s.W;
-    for (int x = t; x < cnt * S * W; x += 256) {
-        const int c = x % W, k = (x / W) % S, bl = x / (W * S);
-        const ItemMeta m = sm[bl];
-        const int kk = k < m.jd + 1 ? k : m.jd + 1;  // states after the terminal one repeat it (rainbow.py:358)
-        const i64 off = frame_offset(s, m.e, m.q + kk, c);
-        off_all[((b0 + bl) * S + k) * W + c] = off;
-        if (off_next && k >= 1) off_next[((b0 + bl) * s.n + (k - 1)) * W + c] = off;
-    }
+    gather_train_items(s, b0, cnt, tree_idx, meta, actions, rewards, terminated, off_all, off_next, sm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -926,3 +835,15 @@ int srlx_store_gather_obs(srlx_store_t *h, int64_t batch, int k_begin, int k_cou
 }
 
 }  // extern "C"
+
+// (C++ linkage: internal to the library, srlx_store_dev.h)
+int srlx_store_dev_view(srlx_store_t *h, int64_t batch, srlxs::StoreDev *out, srlxs::ItemMeta **meta) {
+    SRLX_REQUIRE(h && out && batch > 0, "store_dev_view: bad argument");
+    *out = h->d;
+    if (meta) {
+        SRLX_TRY(h->scratch.reserve((size_t)batch * sizeof(ItemMeta)));
+        *meta = (ItemMeta *)h->scratch.ptr;
+    }
+    return SRLX_OK;
+}
+

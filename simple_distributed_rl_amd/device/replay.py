@@ -101,6 +101,7 @@ class DeviceReplay:
         self._views = (pos, nr, sie)
         self.needs_reset_ptr = nr  # uint8 [E]: lanes whose next lock-step only delivers the first frame of a new episode
         self.deferred_advance = False
+        self._fused_draw = __import__("os").environ.get("SRLX_NO_SAMPLE_GATHER", "0") != "1"  # (A/B switch)
         self.table_fresh = False  # `frame_off_actor` holds the table of the CURRENT ring position (written by the last commit)
 
     def enable_deferred_advance(self):
@@ -234,6 +235,11 @@ class DeviceReplay:
         all_states=True (hand-written training pass): the table of s_0..s_n (`frame_off_all`) instead of the pixels."""
         st = N.torch_stream_ptr()
         b = self.batch
+        if all_states and uniforms is None and self.B <= 64 and self._fused_draw:  # the draw and the gather as ONE launch (srlx_per_sample_gather_train)
+            N.check(self.lib.srlx_per_sample_gather_train(self.h_per, self.h_store, self.B, N.tptr(d_step), self.seed ^ 0x5EED, N.tptr(self.rng_counter), self.u.numel(),
+                                                          N.tptr(b.indices), N.tptr(b.weights), N.tptr(self.used), N.tptr(self.frame_off_all), N.tptr(self.frame_off_next),
+                                                          N.tptr(b.actions), N.tptr(b.rewards), N.tptr(b.terminated), st))
+            return b
         self._draw(d_step, uniforms, st)
         if all_states:  # item location, n-step scalars and both offset tables (s_0..s_n, s_1..s_n) in one launch
             N.check(

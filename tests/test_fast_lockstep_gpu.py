@@ -282,3 +282,31 @@ def test_fast_lockstep_follows_a_loaded_state_dict():
         for eng in (fast, slow):
             eng.step(learner_updates=1)
         _same_state(fast, slow, ("after load", k))
+
+
+def test_draw_and_gather_in_one_launch_equals_the_two_calls():
+    """srlx_per_sample_gather_train against srlx_per_sample_keyed + srlx_store_gather_train: the same indices, weights, n-step scalars (terminal padding included)
+    and frame-offset tables, and the generator's counter advances alike -- on a ring with episode ends, zero-priority leaves and wrap-around."""
+    import copy
+
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+
+    cfg = RainbowDeviceConfig(n_envs=8, batch_size=32, memory_capacity=8 * 40, memory_warmup_size=16, seed=9)
+    eng = RainbowEngine(cfg, 0, episode_len=6)
+    for _ in range(70):
+        eng.step(learner_updates=0)
+    r = eng.replay
+    step = torch.tensor([123], dtype=torch.int64, device="cuda")
+    outs = []
+    for fused in (True, False):
+        r._fused_draw = fused
+        r.rng_counter.fill_(5)
+        r.batch.indices.fill_(-1)
+        r.frame_off_all.fill_(-7)
+        r.frame_off_next.fill_(-7)
+        b = r.sample_items(step, all_states=True)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (b.indices, b.weights, b.actions, b.rewards, b.terminated, r.frame_off_all, r.frame_off_next, r.used, r.rng_counter)])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert int(outs[0][7].item()) >= 32 and int(outs[0][8].item()) == 6 and float(outs[0][4].sum()) > 0 and int((outs[0][5] < 0).sum()) > 0

@@ -59,6 +59,10 @@ def parse_args():
                     help="rainbow = BASELINE.json configs[2] (the headline metric); agent57_light = the configs[3] workload (two UVFA Q-networks, NGU "
                          "intrinsic reward, per-environment UCB) on the E-environment engine")
     ap.add_argument("--dist-selftest", action="store_true", help="run the N>1 code path (DistributedRainbow, RCCL gathers/broadcasts) at world size 1")
+    ap.add_argument("--topology", choices=("default", "replay"), default="default",
+                    help="replay (N >= 3): the reference's enable_mp_memory topology on the device path -- rank 0 learner, rank 1 replay GPU, ranks 2.. actors "
+                         "(device/replay_role.py; srl/base/run/play_mp_memory.py:595-621)")
+    ap.add_argument("--no-strong-ref", action="store_true", help="N>1: skip the single-GPU engine at the job's total environment count that rank 0 times after the distributed region")
     return ap.parse_args()
 
 
@@ -122,6 +126,8 @@ def main():
     else:
         actor_ranks = world if (learner_acts if learner_acts is not None else world < 4) else world - 1
     envs_per_gpu = args.envs if args.scaling == "weak" else max(1, args.envs // actor_ranks)
+    if args.topology == "replay":
+        return bench_replay_role(args, dev_index, rank, world, dist)
     if args.algo == "agent57_light":
         return bench_agent57_light(args, dev_index, rank, world, dist, envs_per_gpu, actor_ranks, learner_acts)
     if args.algo == "ppo":
@@ -137,6 +143,7 @@ def main():
         assert eng.n_actor_ranks == actor_ranks
     else:
         eng = RainbowEngine(cfg, dev_index, args.episode_len, overlap=not args.no_overlap)
+    lockstep = "round-4 lock-step (6 launches on the actors' stream, published parameter sets)" if getattr(getattr(eng, "local", eng), "fast", False) else "fifteen-launch lock-step"
 
     # ---- fill the replay (untimed): random-policy rollout until the ring is full, then |delta| ~ U(0,1)
     #      priorities like tests/quick/rl/memories/speedtest.py:40-41
@@ -191,14 +198,52 @@ def main():
         elapsed = float(t.item())
         eng.flush()
 
+    def stats(events):
+        v = sorted(a_.elapsed_time(b_) for a_, b_ in events)
+        return {"min_ms": v[0], "median_ms": v[len(v) // 2], "mean_ms": sum(v) / len(v), "max_ms": v[-1], "probes": len(v)}
+
     ev_ms = sum(a_.elapsed_time(b_) for a_, b_ in ev) / len(ev)
     conv_ms = sum(a_.elapsed_time(b_) for a_, b_ in pr) / len(pr) if probing else 0.0
     fc1_ms = sum(a_.elapsed_time(b_) for a_, b_ in pf) / len(pf) if probing else 0.0
+    probe_stats = {"pass": stats(ev), "conv": stats(pr) if probing else None, "fc1": stats(pf) if probing else None}
     if dist is not None:  # a learner-only rank 0 runs no actor pass: report the slowest actor rank's
         t = torch.tensor([ev_ms, conv_ms, fc1_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ev_ms, conv_ms, fc1_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
     rccl_ranks = dist.get_world_size() if (dist is not None and args.backend == "nccl") else (1 if dist is None else 0)
+
+    # N > 1: the SAME number of environments on ONE GPU (rank 0, after the distributed region), so that the line carries its own strong-scaling ratio:
+    # value / strong_ref.value = what spreading E_total environments over the actor GPUs bought (north_star: >= 6x at 8 GPUs)
+    strong_ref = None
+    if dist is not None and world > 1 and not args.no_strong_ref:
+        if rank == 0:
+            try:
+                import dataclasses
+
+                e_total = envs_per_gpu * actor_ranks
+                ref = RainbowEngine(dataclasses.replace(cfg, n_envs=e_total), dev_index, args.episode_len, overlap=True)
+                ref.prefill()
+                for _ in range(8):
+                    ref.step(args.updates)
+                torch.cuda.synchronize()
+                if not args.no_graph:
+                    ref.capture_graphs()
+                n_ref = max(8, min(n_lock, 48))
+                for _ in range(4):
+                    ref.step(args.updates)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n_ref):
+                    ref.step(args.updates)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / n_ref
+                strong_ref = {"what": "the single-GPU engine (actors + learner on rank 0's GPU) at the job's total environment count, timed after the distributed region",
+                              "envs": e_total, "lock_steps": n_ref, "ms_per_lock_step": 1e3 * dt, "value": e_total / dt, "unit": "env-steps/s",
+                              "learner_updates_per_s": args.updates / dt}
+                del ref
+            except Exception as exc:  # the reference figure must never take the measured line down with it
+                strong_ref = {"error": repr(exc)}
+        dist.barrier()
 
     if rank != 0:
         if dist is not None:
@@ -239,6 +284,7 @@ def main():
             "noisy_dense": cfg.enable_noisy_dense,
             "epsilon": cfg.epsilon,
             "hip_graphs": not args.no_graph,
+            "lockstep": lockstep,
             "qnet": ("libsrlx: float32 results; forward = float32 products as exact split-bf16 partial products on v_mfma_f32_32x32x16_bf16 (conv1 3, conv2 / conv3 / "
                      "first dense layer 6 per multiply-add), float32 accumulate; " +
                      ("hand-written backward (no autograd)" if getattr(local, "mfma_train", False) else "torch autograd backward (SRLX_TORCH_BACKWARD=1 yardstick)")),
@@ -249,9 +295,13 @@ def main():
                          else f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology), grouped send/recv push + flat broadcast"),
             "actor_gpus": actor_ranks,
         },
-        "roofline": roofline(eng, ev_ms, conv_ms, fc1_ms),
+        "roofline": roofline(eng, ev_ms, conv_ms, fc1_ms, probe_stats),
         "final": {"loss": info["loss"], "train_count": info["train_count"], "memory": info["memory"]},
     }
+    if strong_ref is not None:
+        out["strong_ref"] = strong_ref
+        if "value" in strong_ref:
+            out["strong_ratio"] = out["value"] / strong_ref["value"]
     if dist is None and not args.no_subfigures:
         out["subfigures"] = subfigures(eng, args, inner)
     if not args.no_per_micro:
@@ -266,6 +316,52 @@ def main():
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(out), flush=True)
+
+
+def bench_replay_role(args, dev_index, rank, world, dist):
+    """f2 as a bench line: learner GPU <- replay GPU <- actor GPUs (device/replay_role.py: batches served as one packed message, `prefetch` in flight, priority
+    write-backs one lock-step behind; one dist.batch_isend_irecv group per lock-step and side).  value = env-steps/s of the actor ranks."""
+    import torch
+
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig
+    from simple_distributed_rl_amd.device.replay_role import ReplayRoleRainbow
+
+    assert dist is not None and world >= 3, "--topology replay needs --gpus >= 3 (learner, replay, actors)"
+    E = args.envs if args.scaling == "weak" else max(128, args.envs // (world - 2))
+    cfg = RainbowDeviceConfig(n_envs=E, batch_size=args.batch_size, memory_capacity=args.capacity, memory_warmup_size=min(80_000, args.capacity // 4), seed=0)
+    top = ReplayRoleRainbow(cfg, dev_index, args.episode_len, sync_interval=args.sync_interval, prefetch=5, updates=args.updates)
+    inner = max(1, args.inner)
+    warm_steps = -(-cfg.memory_warmup_size // (E * (world - 2))) + 8  # past the replay's warm-up gate + the prefetch pipeline
+    for _ in range(max(warm_steps, args.warmup * inner)):
+        top.step()
+    n_lock = args.steps * inner
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_lock):
+        top.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    dev = torch.device(f"cuda:{dev_index}")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    top.finish()
+    info = top.info()
+    if rank == 0:
+        out = {"metric": "env-steps/sec + learner updates/sec, Rainbow 84x84x4", "value": n_lock * E * (world - 2) / elapsed, "unit": "env-steps/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic", "learner_updates_per_s": n_lock * args.updates / elapsed, "ms_per_lock_step": 1e3 * elapsed / n_lock,
+               "rccl_ranks": world if args.backend == "nccl" else 0,
+               "config": {"workload": "Rainbow on synthetic 84x84x4 Atari frames, PER 1M transitions, n-step=3 (BASELINE.json configs[2] workload), three-role topology",
+                          "topology": f"{world} GPUs: rank0 learner, rank1 replay (ring + tree, serves packed batches, prefetch 5), {world - 2} actor ranks", "envs_per_gpu": E,
+                          "envs_total": E * (world - 2), "actor_gpus": world - 2, "learner_updates_per_lock_step": args.updates, "batch_size": args.batch_size,
+                          "per_capacity": args.capacity, "backend": args.backend},
+               "roofline": None, "final": {"train_count": info.get("train_count"), "loss": info.get("loss")}}
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
 
 
 def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=None, actor_ranks=1, learner_acts=None):
@@ -506,11 +602,11 @@ def _isolated_forward_ms(eng, reps=20):
     return a.elapsed_time(b) / reps
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
 
 
 def _pmc_traffic(kernel: str):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r3_pmc_traffic.json, written by tools/r3_measure.sh from two separate
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r4_pmc_traffic.json, written by tools/r4_measure.sh from two separate
     `rocprofv3 --pmc` runs of tools/actor_pass_probe.py -- FETCH_SIZE and WRITE_SIZE do not fit one pass; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for wide coalesced reads on gfx950).  None when no such profile has been recorded."""
     if not os.path.exists(PMC_FILE):
@@ -522,7 +618,7 @@ def _pmc_traffic(kernel: str):
         return None
 
 
-def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0):
+def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0, probe_stats=None):
     """The dominant hand-written kernel, timed live with HIP events on its launch stream: k_convnet_fused (conv1 -> conv2 -> conv3 of the actors' network
     pass in one launch).  It evaluates float32 products on the bf16 matrix pipe as exact split partial products, so its bound is the dense bf16 MFMA
     peak and its work is what it EXECUTES there: 3 MFMA flops per conv1 multiply-add flop, 6 per conv2 / conv3 one.
@@ -545,8 +641,8 @@ def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0):
     exe_conv = (3.0 if c1_bf16 else 1.0) * f_1 + (6.0 if c23_bf16 else 1.0) * f_23
     exe_fc1 = (6.0 if fc1_bf16 else 1.0) * f_fc1
     group = {
-        "kernel": "srlx_qnet_forward_u8 over E envs: " + ("k_pack_filters + k_convnet_fused (conv1..conv3 from the uint8 ring)" if fused else
-                  "k_conv1_u8 + k_gemm<AConv> x2") + " + first dense layer (k_fc1_planes on operand planes, or k_gemm_s16) + k_head",
+        "kernel": "srlx_qnet_forward_u8(_policy) over E envs: " + ("k_convnet_fused (conv1..conv3 from the uint8 ring; packed filters from the published set)" if fused else
+                  "k_conv1_u8 + k_gemm<AConv> x2") + " + first dense layer (k_fc1_planes_h / k_fc1_planes on operand planes, or k_gemm_s16) + k_head (+ epsilon-greedy in its epilogue)",
         "algorithmic_f32_flops_per_launch_group": flops,
         "executed_mfma_flops_per_launch_group": exe_conv + exe_fc1 + f_head,
         "avg_launch_group_ms": ev_ms,
@@ -561,12 +657,16 @@ def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0):
         return group
     pipe = lambda b16, k: ("bf16 pipe, %d exact partial products per multiply-add" % k) if b16 else "f32 pipe (v_mfma_f32_32x32x2_f32)"  # noqa: E731
     fc1_planes = bool(getattr(local.inf_actor, "_planes", False))
+    fast = bool(getattr(local, "fast", False))
+    neighbour = int(os.environ.get("SRLX_FC1_NEIGHBOUR", "4")) if fast else 0
     fc1_alg_bytes = (E * flat * 6 + 2 * cfg.hidden_units * flat * 6 if fc1_planes else E * flat * 4 + 2 * cfg.hidden_units * flat * 4) + 4 * E * 2 * cfg.hidden_units * 4 if flat else None
     fc1_traffic = _pmc_traffic("fc1" if fc1_planes else "k_gemm_s16")
     fc1 = None
     if fc1_ms > 0.0 and flat:
         fc1 = {
-            "kernel": ("k_fc1_planes: [E][7744] x [2 hidden][7744]^T on pre-split bf16 operand planes (LDS-DMA tiles, no conversions), split-K partials reduced by k_head"
+            "kernel": ((f"k_fc1_planes_h: [E][7744] x [2 hidden][7744]^T on pre-split bf16 operand planes (the weight planes written by the update's fused Adam epilogue), "
+                        f"half-CU workgroups (256 threads, 72 KB of LDS, {neighbour} K splits) beside the learner; split-K partials reduced by k_head" if neighbour else
+                        "k_fc1_planes: [E][7744] x [2 hidden][7744]^T on pre-split bf16 operand planes (LDS-DMA tiles, no conversions), split-K partials reduced by k_head")
                        if fc1_planes else "k_gemm_s16<APlain>: operands split into bf16 parts while staging"),
             "bound": "mfma", "achieved": exe_fc1 / (fc1_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS if fc1_bf16 else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": exe_fc1 / (fc1_ms * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS if fc1_bf16 else MFMA_F32_PEAK_TFLOPS),
@@ -595,8 +695,10 @@ def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0):
         "f32_equivalent": {"achieved": f_conv / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "frac": f_conv / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                            "note": "algorithmic float32 FLOP/s over the f32 MFMA peak (the `frac` of the round-1/2 lines); NOT this kernel's bound: it does not run on that pipe"},
         "note": "timed inside the lock-step loop (HIP events on the launch stream, right around this kernel), where the learner's streams share the chip; `frac` = "
-                "executed bf16-MFMA flops / time / 2.5 PFLOP/s dense; traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/r3_pmc_traffic.json (isolated "
-                "launches of tools/actor_pass_probe.py); rocprofv3 cross-check: this kernel's AverageNs in profiles/r3_kernel_stats.csv",
+                "executed bf16-MFMA flops / time / 2.5 PFLOP/s dense; traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/r4_pmc_traffic.json (isolated "
+                "launches of tools/actor_pass_probe.py); rocprofv3 cross-check: this kernel's AverageNs in profiles/r4_kernel_stats.csv; `probes` = min / median / "
+                "mean / max of the HIP-event brackets of this run (every 4th lock-step): the brackets include queue wait beside the learner's streams",
+        "probes": probe_stats,
         "fc1": fc1,
         "pass": group,
         "dtype": "f32 results (float32 products as exact split-bf16 partial products, f32 accumulate)" if c1_bf16 else "f32 in / f32 accumulate",

@@ -703,7 +703,8 @@ int run_dense(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
 int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hipStream_t st) {
     const int N1 = 2 * h->hidden;
     const i64 tiles = ((B + BM - 1) / BM) * ((N1 + 63) / 64);
-    int splits = (int)((512 + tiles - 1) / tiles);  // (1024 workgroups for the learner's 96 / 128 rows: measured no faster)
+    static const int target_wgs = getenv("SRLX_FC1_TARGET_WGS") ? atoi(getenv("SRLX_FC1_TARGET_WGS")) : 512;  // (measurement switch)
+    int splits = (int)((target_wgs + tiles - 1) / tiles);  // (1024 workgroups for the learner's 96 / 128 rows: measured no faster)
     const int ksteps = h->flat / BK;
     static const int force_splits = getenv("SRLX_FC1_SPLITS") ? atoi(getenv("SRLX_FC1_SPLITS")) : 0;  // measurement: workgroup granularity of the chip-filling launches
     if (force_splits > 0 && B >= 512) splits = force_splits;

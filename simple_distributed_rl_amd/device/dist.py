@@ -217,7 +217,9 @@ class DistributedRainbow:
         local_cfg = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62, seed=cfg.seed + 1_000_003 * self.rank)
         # the learner rank overlaps its update with its own actors (second stream, private actor copy of the network),
         # exactly like the single-GPU engine; the other ranks only act
-        self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, env=env, overlap=self.is_learner and overlap)
+        # (fast=False: this wrapper drives the engine's pieces in its own order around the transition exchange -- the one-launch commit / environment step, the
+        # draw + gather launch and the in-launch reductions still apply; the published parameter sets and the fused policy head belong to RainbowEngine.step)
+        self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, env=env, overlap=self.is_learner and overlap, fast=False)
         self.overlap = self.is_learner and overlap
         self.flat = flatten_parameters(self.local.q_online)
         # the parameters moved: point the inference kernels (and the fused Adam) at their new home

@@ -512,6 +512,10 @@ int srlx_qnet_set_pack_sticky(srlx_qnet_t *h, int on);
 /* splits > 0: the chip-filling first-dense-layer launches of a handle with operand planes use half-CU workgroups (256 threads, 72 KB of LDS, `splits` K splits:
  * a steady stream of short workgroups that leaves room for a learner's kernels on every compute unit); 0 (default): CU-filling workgroups, the fastest form alone. */
 int srlx_qnet_set_fc1_neighbour(srlx_qnet_t *h, int splits);
+/* a learner's handle: operand planes also for its 96 / 128-row passes (convolution kernel writes float32 act3 AND planes; first dense layer on the half-CU kernel
+ * with the staging-split GEMM's split-K shape: bit-identical results); d_weight_planes = BORROWED planes of the bound weight (an actor set's, srlx_qnet_actor_set_planes:
+ * the set the last update published holds the online network's current weight) or NULL for the handle's own (srlx_qnet_refresh_fc1_planes) */
+int srlx_qnet_set_planes_small(srlx_qnet_t *h, int on, const void *d_weight_planes);
 int srlx_qnet_weights_changed(srlx_qnet_t *h);
 /* The image block alone (DQNImageBlock, srl/rl/torch_/blocks/dqn_image_block.py:29-54: three convolutions with replicate padding + ReLU) for
  * networks whose dense part is not the dueling head of this handle (Agent57_light's UVFA Q-networks, its embedding and RND networks,

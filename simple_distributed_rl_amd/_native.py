@@ -101,6 +101,7 @@ SIGNATURES = {
     "srlx_qnet_fuse_adam_fc1_planes": (c_int, [c_p, c_p]),
     "srlx_qnet_set_pack_sticky": (c_int, [c_p, c_int]),
     "srlx_qnet_set_fc1_neighbour": (c_int, [c_p, c_int]),
+    "srlx_qnet_set_planes_small": (c_int, [c_p, c_int, c_p]),
     "srlx_qnet_weights_changed": (c_int, [c_p]),
     "srlx_qnet_enable_training": (c_int, [c_p, c_i64]),
     "srlx_qnet_set_probe": (c_int, [c_p, c_p, c_p]),

@@ -371,7 +371,7 @@ int srlx_fc1_planes_alloc(srlx_qnet *h) {
     const size_t N1 = 2 * (size_t)h->hidden;
     SRLX_REQUIRE(h->flat % 32 == 0 && N1 % kTN == 0, "fc1_planes: the layer must be a multiple of 32 wide (K) and of %d (units)", kTN);
     SRLX_HIP(hipMalloc((void **)&h->wf_planes, N1 * h->flat * 6));
-    SRLX_HIP(hipMalloc((void **)&h->a3_planes, (size_t)h->max_batch * h->flat * 6));
+    SRLX_HIP(hipMalloc((void **)&h->a3_planes, (size_t)((h->max_batch + 127) / 128 * 128) * h->flat * 6));
     return SRLX_OK;
 }
 
@@ -395,7 +395,13 @@ int srlx_fc1_planes_split_act(srlx_qnet *h, int64_t rows, hipStream_t st) {
     return SRLX_OK;
 }
 
-bool srlx_fc1_planes_applicable(const srlx_qnet *h, int64_t rows) { return h->wf_planes && rows % kTM == 0 && rows >= 512; }
+// chip-filling launches (>= 512 rows in multiples of the tile); with `planes_small` (srlx_qnet_set_planes_small: a learner's handle, half-CU kernel) any launch, rows
+// padded to the tile
+bool srlx_fc1_planes_applicable(const srlx_qnet *h, int64_t rows) {
+    if (!h->wf_planes) return false;
+    if (h->planes_small && h->fc1_neighbour > 0) return true;
+    return rows % kTM == 0 && rows >= 512;
+}
 
 // partial[split][rows][2 hidden] = a3_planes x wf_planes^T over the split's K range; `splits` / `kps` (32-deep K-slabs per split) as k_gemm_s16's launch
 int srlx_fc1_planes_gemm(srlx_qnet *h, int64_t rows, int splits, int kps, hipStream_t st) {
@@ -409,6 +415,7 @@ int srlx_fc1_planes_gemm(srlx_qnet *h, int64_t rows, int splits, int kps, hipStr
         attr_set = true;
     }
     const int N1 = 2 * h->hidden;
+    rows = (rows + kTM - 1) / kTM * kTM;  // (a small launch's pad rows multiply whatever the plane buffer holds: their partial sums are never read)
     const dim3 grid((unsigned)(rows / kTM), (unsigned)(N1 / kTN), (unsigned)splits);
     if (h->fc1_neighbour) {  // half-CU workgroups (srlx_qnet_set_fc1_neighbour): the handle's passes run beside a learner
         static bool attr_h = false;

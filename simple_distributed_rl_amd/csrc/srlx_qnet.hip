@@ -708,7 +708,7 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     const int ksteps = h->flat / BK;
     static const int force_splits = getenv("SRLX_FC1_SPLITS") ? atoi(getenv("SRLX_FC1_SPLITS")) : 0;  // measurement: workgroup granularity of the chip-filling launches
     if (force_splits > 0 && B >= 512) splits = force_splits;
-    if (h->fc1_neighbour > 0 && h->planes_valid && srlx_fc1_planes_applicable(h, B) && force_splits <= 0) splits = h->fc1_neighbour;
+    if (h->fc1_neighbour > 0 && h->planes_valid && srlx_fc1_planes_applicable(h, B) && force_splits <= 0 && B >= 512) splits = h->fc1_neighbour;
     if (splits > ksteps) splits = ksteps;
     if (splits > h->max_splits) splits = h->max_splits;
     if (splits < 1) splits = 1;
@@ -721,8 +721,14 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     if (planes && !h->a3_planes_fresh) SRLX_TRY(srlx_fc1_planes_split_act(h, B, st));  // (a convolution path that wrote float32 act3 only)
     h->a3_planes_fresh = false;
     if (h->probe_fc0) SRLX_HIP(hipEventRecord(h->probe_fc0, st));
+    const i64 Mp = planes ? (B + 127) / 128 * 128 : B;  // row stride of the split-K partial slabs (the planes GEMM pads small launches to its 128-row tile)
     if (planes) {
-        SRLX_TRY(srlx_fc1_planes_gemm(h, B, splits, kps, st));
+        SRLX_REQUIRE((size_t)used * Mp * N1 <= h->partial_floats, "qnet: split-K partial buffer too small for %d splits of %lld rows", used, (long long)Mp);
+        void *own = h->wf_planes;
+        if (h->wf_planes_ext) h->wf_planes = const_cast<void *>(h->wf_planes_ext);
+        const int rc = srlx_fc1_planes_gemm(h, B, splits, kps, st);
+        h->wf_planes = own;
+        SRLX_TRY(rc);
     } else if (!fc1_f32 && h->flat % BK == 0) {
         const dim3 grid((unsigned)((B + 127) / 128), (unsigned)((N1 + 63) / 64), (unsigned)splits);
         APlain fa{h->act3, (i64)h->flat * stride};
@@ -734,7 +740,7 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     if (h->probe_fc1) SRLX_HIP(hipEventRecord(h->probe_fc1, st));
     h->probe_fc0 = h->probe_fc1 = nullptr;  // one forward only
     // small launches (the learner's 128 / 96 rows) are one workgroup per row and far from filling the chip: twice the threads per row
-    hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(B <= 256 && h->hidden > 256 ? 512 : 256), 0, st, h->partial, used, B, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
+    hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(B <= 256 && h->hidden > 256 ? 512 : 256), 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
                        h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, h->sig[0] ? h->d_draw : nullptr, h->pol);
     h->pol = srlx_qnet::Policy{};  // one forward only
     SRLX_HIP(hipGetLastError());
@@ -1014,6 +1020,19 @@ int srlx_qnet_set_fc1_neighbour(srlx_qnet_t *h, int splits) {
         h->partial_floats = need;
     }
     h->fc1_neighbour = splits;
+    return SRLX_OK;
+}
+
+// A learner's handle on operand planes: `on` -- planes also for launches below 512 rows (its convolution kernel then writes float32 act3 AND planes, the first
+// dense layer runs on the half-CU planes kernel with the split-K shape of the staging-split GEMM: bit-identical); d_weight_planes -- BORROWED planes of the bound
+// weight for the next forwards (NULL: the handle's own, srlx_qnet_refresh_fc1_planes).  The caller vouches that the planes hold the bound weight.
+int srlx_qnet_set_planes_small(srlx_qnet_t *h, int on, const void *d_weight_planes) {
+    SRLX_REQUIRE(h, "qnet_set_planes_small: NULL handle");
+    SRLX_REQUIRE(!on || h->a3_planes, "qnet_set_planes_small: srlx_qnet_enable_fc1_planes first");
+    h->planes_small = on != 0;
+    h->wf_planes_ext = d_weight_planes;
+    if (on && h->fc1_neighbour <= 0) h->fc1_neighbour = 4;
+    if (d_weight_planes) h->planes_valid = true;
     return SRLX_OK;
 }
 

@@ -337,11 +337,14 @@ __device__ __forceinline__ f32x16 reduce_quarters(float *__restrict__ scratch, i
 // launches and the learner's 96 / 128-sample launches as separate kernels (same code).
 // PLANES (chip-filling launches of a handle with operand planes, srlx_fc1_planes.hip): act3 is written as the three bf16 part planes the first dense
 // layer's GEMM reads -- [K/32 slabs][batch rows][4 k-groups][3 parts][8 bf16], K = pixel * 64 + channel -- instead of float32; `act3` then points at them.
-template <bool BIG, bool C1B16, bool C23B16, bool PLANES = false>
+// PLANES = 2 (round 4, the learner's passes): BOTH -- float32 act3 for the backward pass and the planes (at `planes_out`, `plane_rows` rows per K-slab: the launch's
+// rows rounded up to the GEMM's 128-row tile) for the first dense layer.
+template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
                                                                 float *__restrict__ act3,
-                                                                float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg) {
+                                                                float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg,
+                                                                unsigned char *__restrict__ planes_out = nullptr, long long plane_rows = 0) {
     static_assert(!PLANES || C23B16, "operand planes come out of the split-bf16 conv3 only");
     static_assert(!C23B16 || C1B16, "the split-bf16 conv2 / conv3 read the part planes conv1's split-bf16 epilogue writes");
     constexpr bool PL = C23B16;  // act1 / act2 as bf16 part planes in LDS (kPB1 / kPB2 bytes per pixel) instead of float32
@@ -619,14 +622,16 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
         block_planes<3>(a2p, wf3, blk, kq, lane, acc4);
         const f32x16 sum = reduce_quarters(scratch, blk, kq, lane, acc4);
         if (pix < kM2) {
-            if constexpr (PLANES) {
+            if constexpr (PLANES != 0) {
                 // k-group g of K-slab (pixel * 2 + nt) = channels nt * 32 + 8 g .. + 7: this lane's four are the 8-byte half h of a 16-byte chunk per (g, part)
-                const i64 rows = gridDim.x;
-                unsigned char *dst = reinterpret_cast<unsigned char *>(act3) + (((i64)(pix * 2 + nt) * rows + b) * 4) * 48 + h * 8;
+                const i64 rows = PLANES == 2 ? (i64)plane_rows : (i64)gridDim.x;
+                unsigned char *dst = (PLANES == 2 ? planes_out : reinterpret_cast<unsigned char *>(act3)) + (((i64)(pix * 2 + nt) * rows + b) * 4) * 48 + h * 8;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
+                    const float4 v = bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b3 + nt * 32 + 8 * g + 4 * h));
+                    if constexpr (PLANES == 2) *reinterpret_cast<float4 *>(act3 + (b * kM2 + pix) * 64 + nt * 32 + 8 * g + 4 * h) = v;
                     bf16x4 part[3];
-                    split3(bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b3 + nt * 32 + 8 * g + 4 * h)), part);
+                    split3(v, part);
 #pragma unroll
                     for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(dst + g * 48 + q * 16) = part[q];
                 }
@@ -723,7 +728,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     if (!(h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32)) return false;
     static bool attr_set = false;
     if (!attr_set) {
-        const void *kerns[] = {(const void *)k_convnet_fused<true, true, true, true>,
+        const void *kerns[] = {(const void *)k_convnet_fused<true, true, true, 1>, (const void *)k_convnet_fused<false, true, true, 2>,
                                (const void *)k_convnet_fused<true, true, true>,  (const void *)k_convnet_fused<false, true, true>,
                                (const void *)k_convnet_fused<true, true, false>, (const void *)k_convnet_fused<false, true, false>,
                                (const void *)k_convnet_fused<true, false, false>, (const void *)k_convnet_fused<false, false, false>};
@@ -741,7 +746,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     float *out3 = h->act3;
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
-                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg);
+                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll);
     };
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
     if (h->probe0 && hipEventRecord(h->probe0, st) != hipSuccess) return false;  // measurement hook: exactly this kernel, on its launch stream
@@ -749,9 +754,15 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     static const bool no_planes_out = (getenv("SRLX_NO_CONV_PLANES") && getenv("SRLX_NO_CONV_PLANES")[0] == '1') ||  // A/B switch: float32 act3 + a split pass
                                       (getenv("SRLX_NO_PLANES_GEMM") && getenv("SRLX_NO_PLANES_GEMM")[0] == '1');
     h->a3_planes_fresh = false;
-    if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && !keep && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch)) {
+    if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && !keep && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch) && batch >= 512) {
         out3 = reinterpret_cast<float *>(h->a3_planes);
-        launch(k_convnet_fused<true, true, true, true>);
+        launch(k_convnet_fused<true, true, true, 1>);
+        h->a3_planes_fresh = true;
+    } else if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch)) {
+        // a learner's pass (96 / 128 rows; `planes_small`): float32 act3 for its backward pass AND the planes for the first dense layer, rows padded to the GEMM's tile
+        const long long prow = (batch + 127) / 128 * 128;
+        hipLaunchKernelGGL((k_convnet_fused<false, true, true, 2>), dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2,
+                           h->b3, out3, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)h->a3_planes, prow);
         h->a3_planes_fresh = true;
     } else if (batch >= 512)
         c1_f32 ? launch(k_convnet_fused<true, false, false>) : c23_f32 ? launch(k_convnet_fused<true, true, false>) : launch(k_convnet_fused<true, true, true>);

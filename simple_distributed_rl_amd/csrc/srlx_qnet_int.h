@@ -63,6 +63,8 @@ struct srlx_qnet {
     float *wpack_own;                     // this handle's own packed-filter buffer while a set is selected
     void *wf_planes_own;
     const float *bound[12];               // what srlx_qnet_bind bound (restored by srlx_qnet_actor_set_select(h, -1))
+    bool planes_small;                    // operand planes also for launches below 512 rows (a learner's 96 / 128-row passes: srlx_qnet_set_planes_small)
+    const void *wf_planes_ext;            // BORROWED weight planes for the next forwards (an actor set's: the learner's online network reads what it published)
     int fc1_neighbour;                    // > 0: chip-filling first-dense-layer launches use k_fc1_planes_h (half-CU workgroups) with this many K splits
     size_t partial_floats;                // allocation of `partial`
     float *c1_gpart;                      // conv1 weight gradient: group partial sums [Wn][4][32 x 64 + 32] of the in-launch reduction

@@ -328,6 +328,15 @@ class QNetInference:
         """Chip-filling first-dense-layer launches on operand planes as half-CU workgroups with `splits` K splits (0: CU-filling workgroups, the fastest form alone)."""
         N.check(self.lib.srlx_qnet_set_fc1_neighbour(self.h, int(splits)))
 
+    def set_planes_small(self, on: bool, weight_planes_ptr=None):
+        """A learner's handle: operand planes also for its 96 / 128-row passes; `weight_planes_ptr`: borrowed planes of the bound weight for the next forwards
+        (None: the handle's own, `refresh_own_planes`)."""
+        N.check(self.lib.srlx_qnet_set_planes_small(self.h, int(bool(on)), N.c_p(weight_planes_ptr) if weight_planes_ptr else None))
+
+    def refresh_own_planes(self):
+        """The bound first-dense-layer weight split into the handle's own operand planes (one pass over the weight, current stream)."""
+        N.check(self.lib.srlx_qnet_refresh_fc1_planes(self.h, None, None, N.torch_stream_ptr()))
+
     def set_pack_sticky(self, on: bool = True):
         N.check(self.lib.srlx_qnet_set_pack_sticky(self.h, int(bool(on))))
 

@@ -235,6 +235,17 @@ class RainbowEngine:
             self._set, self._published = 0, None
             self._seen_versions = None
             self.inf_target.set_pack_sticky(True)  # the target network's packed filters change at a sync only
+            # SRLX_LEARNER_PLANES=1 (measurement switch, off): the learner's own 128 / 96-row passes on operand planes too -- the online network reads the planes of the set
+            # its LAST update published (they hold exactly its current weight), the target network keeps planes of its own, split at every sync; bit-identical to the
+            # staging-split GEMM (tests/test_fast_lockstep_gpu.py) and SLOWER at these sizes: the planes GEMM streams 47.6 MB of weight planes instead of 32 MB of
+            # float32 (35 against 30 us per pass) and the convolution kernel writes both forms (36 against 29 us): update alone 0.384 against 0.344 ms, lock-step
+            # 0.535 against 0.526 ms on one box (tools/_r4_probe11.sh).
+            self._learner_planes = os.environ.get("SRLX_LEARNER_PLANES", "0") == "1"
+            self._fresh_set = None  # the set whose planes equal the online network's current weight (None: some update did not publish)
+            if self._learner_planes:
+                self.inf_online.enable_fc1_planes(private_weights=False)
+                self.inf_target.enable_fc1_planes(private_weights=True)
+                self.inf_target.set_planes_small(True, None)
             # the priority write-back leaves the update's critical path: it needs the head kernel's priorities only, so it runs on the target network's (by then idle)
             # stream beside the gradient kernels; the step count it used to advance moves to the update's LAST launch (the packing / publishing one)
             self._update_branch = os.environ.get("SRLX_UPDATE_BRANCH", "0") == "1"
@@ -302,6 +313,9 @@ class RainbowEngine:
         self.inf_actor.select_set(self._set)
         self.inf_target.weights_changed()
         self.inf_target.publish_to(None)
+        if self._learner_planes:
+            self.inf_target.refresh_own_planes()
+        self._fresh_set = self._set
         self._published = None
         self._seen_versions = (self.q_online.weights_version, self.q_target.weights_version)
 
@@ -422,7 +436,7 @@ class RainbowEngine:
         return tuple(c.obs_hw) == (84, 84) and c.window_length == 4 and c.filters == 32 and os.environ.get("SRLX_NO_FUSED_CONV", "0") != "1"
 
     # ---- learner (model_torch.py:85-122) -----------------------------------------------------
-    def _learner_body(self, publish: Optional[int] = None):
+    def _learner_body(self, publish: Optional[int] = None, planes_set: Optional[int] = None):
         """One Rainbow update.  fast engines: `publish` = the actor set (0 / 1) this update also writes -- the first dense layer as operand planes from the fused
         Adam's epilogue, packed filters and small vectors with the packing launch that follows the optimiser step (None: that launch only packs for this handle's
         own next forward)."""
@@ -430,6 +444,8 @@ class RainbowEngine:
         B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
         if self.fast:
             self.inf_online.fuse_adam_planes(self._planes_ptr[publish] if publish is not None else None)
+            if self._learner_planes:  # planes_set: the published set that holds the online network's current first-dense-layer weight (None: none does)
+                self.inf_online.set_planes_small(planes_set is not None, self._planes_ptr[planes_set] if planes_set is not None else None)
         if self.mfma_train:
             b = r.sample_items(self.train_count_dev, all_states=True)
             cur = torch.cuda.current_stream(self.dev)
@@ -488,15 +504,19 @@ class RainbowEngine:
             self.optimizer.step()
         r.update(b.indices, self.priorities)  # model_torch.py:113-114; train_count_dev += 1 in the same launch (count_updates_in)
 
-    def learner_step(self, publish: Optional[int] = None) -> bool:
+    def learner_step(self, publish: Optional[int] = None, planes_set: Optional[int] = None) -> bool:
         """Returns False while the replay is below warm-up (priority_replay_buffer.py:228-230)."""
         if self.replay.is_warmup_needed():
             return False
-        g = self._learner_graphs.get(publish) if self.fast else self._learner_graph
+        if self.fast and not self._learner_planes:
+            planes_set = None
+        g = self._learner_graphs.get((publish, planes_set)) if self.fast else self._learner_graph
         if g is not None:
             g.replay()
         else:
-            self._learner_body(publish) if self.fast else self._learner_body()
+            self._learner_body(publish, planes_set) if self.fast else self._learner_body()
+        if self.fast:
+            self._fresh_set = publish  # the planes of that set now hold the online weight (None: no set does)
         # model_torch.py:117-119 (fires at train_count 0 too)
         if self.train_count % self.cfg.target_model_update_interval == 0:
             self.sync_target()
@@ -509,6 +529,8 @@ class RainbowEngine:
         if self.fast:  # the target handle keeps its packed filters between syncs: re-pack them now (current stream: the learner's)
             self.inf_target.weights_changed()
             self.inf_target.publish_to(None)
+            if self._learner_planes:
+                self.inf_target.refresh_own_planes()
         self.sync_count += 1
 
     # ---- the pieces of a step (the Runner's vectorised loop drives them one by one: device/vector_runner.py) --------
@@ -525,10 +547,11 @@ class RainbowEngine:
             ran = 0
             with torch.cuda.stream(self.s_learner):
                 for k in range(updates):
-                    if self.fast and k == updates - 1:  # the last update of the lock-step publishes into the set the actors are NOT reading
-                        ok = self.learner_step(1 - self._set)
-                        if ok:
-                            self._published = 1 - self._set
+                    if self.fast:
+                        pub = 1 - self._set if k == updates - 1 else None  # the last update of the lock-step publishes into the set the actors are NOT reading
+                        ok = self.learner_step(pub, self._fresh_set)
+                        if ok and pub is not None:
+                            self._published = pub
                     else:
                         ok = self.learner_step()
                     ran += int(ok)
@@ -638,12 +661,15 @@ class RainbowEngine:
         torch.cuda.synchronize(self.dev)
         if self.fast:  # the actors' six launches stay eager; the update is captured three times: publishing into set 0 / set 1 / not at all
             if learner and not self.replay.is_warmup_needed():
-                for key in (None, 0, 1):
+                keys = [(None, None), (0, None), (1, None)]  # (set the update publishes into, set whose planes hold the online weight)
+                if self._learner_planes:
+                    keys += [(0, 1), (1, 0), (None, 0), (None, 1)]
+                for key in keys:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        self._learner_body(key)
+                        self._learner_body(*key)
                     self._learner_graphs[key] = g
-                self._learner_graph = self._learner_graphs[None]
+                self._learner_graph = self._learner_graphs[(None, None)]
             torch.cuda.synchronize(self.dev)
             return
         if actor:

@@ -310,3 +310,47 @@ def test_draw_and_gather_in_one_launch_equals_the_two_calls():
     for x, y in zip(*outs):
         assert torch.equal(x, y)
     assert int(outs[0][7].item()) >= 32 and int(outs[0][8].item()) == 6 and float(outs[0][4].sum()) > 0 and int((outs[0][5] < 0).sum()) > 0
+
+
+@pytest.mark.parametrize("rows", [128, 96])
+def test_learner_passes_on_operand_planes_equal_the_staging_split_gemm(rows):
+    """A learner's 128- / 96-row pass with srlx_qnet_set_planes_small (the convolution kernel writes float32 act3 AND operand planes, the first dense layer runs on
+    the half-CU planes kernel, rows padded to its tile) returns the Q rows of the staging-split GEMM bit for bit -- with borrowed weight planes (an actor set's)
+    and with the handle's own -- and leaves the float32 activations the backward pass reads untouched (same gradients)."""
+    from simple_distributed_rl_amd.device.qnet import QNetInference
+
+    net, ref = _qnet_pair(rows)
+    ring, off = _frames(rows)
+    want = ref.forward_u8(ring.data_ptr(), off).clone()
+    actor = QNetInference(net, 512, 0)
+    actor.enable_fc1_planes(private_weights=True)
+    actor.enable_actor_sets()
+    ref.publish_to(actor, 1, with_fc1=True)
+    pl = QNetInference(net, rows, 0)
+    pl.enable_fc1_planes(private_weights=False)
+    pl.set_planes_small(True, actor.set_planes_ptr(1))
+    assert torch.equal(pl.forward_u8(ring.data_ptr(), off), want)
+    own = QNetInference(net, rows, 0)
+    own.enable_fc1_planes(private_weights=True)
+    own.set_planes_small(True, None)
+    own.refresh_own_planes()
+    assert torch.equal(own.forward_u8(ring.data_ptr(), off), want)
+    pl.set_planes_small(False, None)
+    assert torch.equal(pl.forward_u8(ring.data_ptr(), off), want)
+    if rows == 128:  # the training pass: gradients from the float32 activations the planes pass also wrote
+        B = 32
+        g = torch.Generator(device="cuda").manual_seed(4)
+        gq = torch.randn((B, 6), device="cuda", generator=g)
+        grads = []
+        for use_planes in (False, True):
+            h = QNetInference(net, rows, 0)
+            h.enable_training(B)
+            if use_planes:
+                h.enable_fc1_planes(private_weights=False)
+                h.set_planes_small(True, actor.set_planes_ptr(1))
+            h.forward_u8(ring.data_ptr(), off)
+            h.backward_u8(ring.data_ptr(), off, gq, sample_stride=4)
+            torch.cuda.synchronize()
+            grads.append([p.grad.clone() for p in net.kernel_parameters()])
+        for a, b in zip(*grads):
+            assert torch.equal(a, b)

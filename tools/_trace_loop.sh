@@ -8,7 +8,7 @@ python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_sample_wg' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_sample_gather_wg' in r['Kernel_Name'] or 'k_sample_wg' in r['Kernel_Name']]
 a, b = idx[-4], idx[-3]
 t0 = int(rows[a]['Start_Timestamp'])
 print("kernels in window:", b - a, "span us: %.1f" % ((int(rows[b]['Start_Timestamp']) - t0) / 1e3))

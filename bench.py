@@ -399,7 +399,7 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
                 break
         stack_replay = eng.local.replay
     else:
-        eng = Agent57LightEngine(rl, E, dev_index, episode_len=args.episode_len, seed=0)
+        eng = Agent57LightEngine(rl, E, dev_index, episode_len=args.episode_len, seed=0, overlap=not args.no_overlap)
         eng.prefill()
         stack_replay = eng.replay
     inner = max(1, args.inner)

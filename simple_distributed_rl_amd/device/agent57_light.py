@@ -222,11 +222,50 @@ def _miopen_find(fn):
     return scoped
 
 
+class _GraphLauncher:
+    """A helper thread that enqueues the update (its HIP-graph launch keeps the calling thread inside hipGraphLaunch for milliseconds; torch releases the GIL there,
+    so the main thread goes on issuing the actors' launches).  One request at a time: submit, then wait."""
+
+    def __init__(self, device: torch.device):
+        import queue
+        import threading
+
+        self._q, self._done, self._err, self._dev = queue.SimpleQueue(), threading.Event(), None, device
+        self._done.set()
+        threading.Thread(target=self._run, name="srlx-a57-launcher", daemon=True).start()
+
+    def _run(self):
+        torch.cuda.set_device(self._dev)
+        while True:
+            fn = self._q.get()
+            try:
+                fn()
+            except BaseException as e:  # surfaces in wait()
+                self._err = e
+            self._done.set()
+
+    def submit(self, fn):
+        self.wait()
+        self._done.clear()
+        self._q.put(fn)
+
+    def wait(self):
+        self._done.wait()
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+
+
 class Agent57LightEngine:
     """E environments + learner on one GPU.  `rl_config`: a set-up algorithms.agent57_light.Config (image observations, window 4);
     `parameter`: its Parameter (the five networks), created here when not given."""
 
-    def __init__(self, rl_config, n_envs: int, device: int = 0, episode_len: int = 200, seed: int = 0, env=None, parameter=None, ring_len: Optional[int] = None):
+    def __init__(self, rl_config, n_envs: int, device: int = 0, episode_len: int = 200, seed: int = 0, env=None, parameter=None, ring_len: Optional[int] = None,
+                 overlap: bool = False):
+        """overlap=True (round 4): the update runs on its own stream BESIDE the actors' lock-step, forked before the policy pass and joined before the ring commit,
+        exactly like RainbowEngine's overlap: the actors act on private copies of the two Q-networks (refreshed after every join; the reference's distributed actors
+        poll the trainer's parameter board on a timer, play_mp.py:151-165).  The update's HIP graph is launched by a helper thread: hipGraphLaunch keeps its caller
+        busy for the whole ~2.4 ms of that graph (tools/_r4_a57.sh), during which the main thread issues the actors' launches."""
         from simple_distributed_rl_amd.device.rainbow import SyntheticAtariVecEnv
 
         c = self.cfg = rl_config
@@ -271,16 +310,37 @@ class Agent57LightEngine:
         # lock-step; the dense parts and the whole learner stay torch.  SRLX_A57_TORCH_TRUNKS=1: the all-torch pass (A/B, tests).
         from simple_distributed_rl_amd.device.qnet import ImageTrunk
 
-        self._trunks = {}
-        nets = {"q_ext": p.q_ext_online, "q_int": p.q_int_online}
+        self.overlap = bool(overlap)
+        self._act_q = {"q_ext": p.q_ext_online, "q_int": p.q_int_online}  # the networks the actors evaluate
         if c.enable_intrinsic_reward:
-            nets.update(emb=p.emb_network, rnd_target=p.lifelong_target, rnd_train=p.lifelong_train)
+            self._act_q.update(emb=p.emb_network, rnd_train=p.lifelong_train)
+        if self.overlap:
+            import copy
+
+            # private copies of everything the actors evaluate AND the update trains (the RND target network is never trained: shared)
+            self._act_src = dict(self._act_q)
+            self._act_q = {k: copy.deepcopy(v).to(self.dev) for k, v in self._act_q.items()}
+            for v in self._act_q.values():
+                v.eval()
+            self.s_learner = torch.cuda.Stream(device=self.dev, priority=-1)
+            self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+            self._learner_pending = False
+            self._launcher = _GraphLauncher(self.dev)
+        self._trunks = {}
+        nets = {"q_ext": self._act_q["q_ext"], "q_int": self._act_q["q_int"]}
+        if c.enable_intrinsic_reward:
+            nets.update(emb=self._act_q["emb"], rnd_target=p.lifelong_target, rnd_train=self._act_q["rnd_train"])
         if os.environ.get("SRLX_A57_TORCH_TRUNKS", "0") != "1":
             for name, net in nets.items():
                 blk = getattr(getattr(net, "in_block", None), "image_block", None)
                 if blk is not None and getattr(net.in_block, "out_flatten", False) and ImageTrunk.supported(blk):
                     self._trunks[name] = ImageTrunk(blk, shape[:2], E, device)
         self._all_fused = len(self._trunks) == len(nets)
+        if self.overlap:
+            assert self._all_fused, "Agent57LightEngine(overlap=True): every image block must run on the libsrlx trunks (the float32 stack kernel reads the ring position)"
+            # the ring commit leaves the ring position to the PER add (which follows the join): everything between the two -- next state's features, intrinsic
+            # reward, per-lane bookkeeping -- runs beside the update, off the frame-offset table the commit itself writes
+            self.replay.enable_deferred_advance()
         # The LEARNER's image blocks, forward and backward, hand-written too (device/qnet.py:TrainableImageTrunk): one handle per network that trains
         # (its forward keeps the activations, its backward writes the six convolution gradients) and one per network that is only evaluated (targets).
         # No MIOpen on the update path: its convolutions were 3.3 ms of the update and chose their solvers per engine instance by timing, so that one
@@ -324,7 +384,6 @@ class Agent57LightEngine:
         self.total_env_steps = 0
         self.ledger = None
         self._learner_graph = None
-        self.overlap = False  # the drivers of device/vector_runner.py: updates run on the caller's stream
         self.training = True
         self.first_obs = self.env.reset()
         self.replay.reset_all(self.first_obs)
@@ -378,9 +437,9 @@ class Agent57LightEngine:
         inputs = (self.state, self.prev_r_ext.view(-1, 1), self.prev_r_int.view(-1, 1), self.action_eye[self.prev_action], self.actor_eye[arm])
         with torch.no_grad():
             fe = self._trunks["q_ext"](self.replay.obs_base, self._frame_off) if "q_ext" in self._trunks else None
-            q_ext = q_values(p.q_ext_online, *inputs, features=fe)
+            q_ext = q_values(self._act_q["q_ext"], *inputs, features=fe)
             fi = self._trunks["q_int"](self.replay.obs_base, self._frame_off) if "q_int" in self._trunks else None
-            q_int = q_values(p.q_int_online, *inputs, features=fi)
+            q_int = q_values(self._act_q["q_int"], *inputs, features=fi)
         beta = self.beta_list[arm] if self.training else torch.full((self.E,), float(self.cfg.test_beta), device=self.dev)
         return q_ext, q_int, (q_ext + beta.view(-1, 1) * q_int).contiguous()
 
@@ -412,18 +471,22 @@ class Agent57LightEngine:
         self.x_prev_r_int[slot] = self.prev_r_int
         if self.ledger is not None:
             self.ledger.account(rewards, done, r.needs_reset_ptr)
-        r.commit(self.actions, rewards, terminated, done, next_obs)
+        if self.overlap:  # ring commit now (slot p + 1 and the scalars of p belong to no stored item), tree add + ring position after the join at the end
+            r.commit(self.actions, rewards, terminated, done, next_obs, defer_add=True, next_table=True)
+        else:
+            r.commit(self.actions, rewards, terminated, done, next_obs)
         self.state = self._stack()  # s_{t+1}: the next lock-step's policy input AND the intrinsic reward's argument
         live = (self.reset_lane == 0)
         r_int = torch.zeros(E, dtype=torch.float32, device=self.dev)
         if c.enable_intrinsic_reward:
             p = self.parameter
             with torch.no_grad():
-                p.emb_network.eval()
-                p.lifelong_train.eval()
+                emb_net, rnd_train = self._act_q["emb"], self._act_q["rnd_train"]
+                emb_net.eval()
+                rnd_train.eval()
                 f = self._feat
-                episodic = self.ngu.episodic(embed(p.emb_network, self.state, f.get("emb")), reset=self.reset_lane, active=live.to(torch.uint8))
-                lifelong = self.ngu.lifelong(rnd(p.lifelong_target, self.state, f.get("rnd_target")), rnd(p.lifelong_train, self.state, f.get("rnd_train")),
+                episodic = self.ngu.episodic(embed(emb_net, self.state, f.get("emb")), reset=self.reset_lane, active=live.to(torch.uint8))
+                lifelong = self.ngu.lifelong(rnd(p.lifelong_target, self.state, f.get("rnd_target")), rnd(rnd_train, self.state, f.get("rnd_train")),
                                              c.lifelong_max)
             r_int = torch.where(live, episodic * lifelong, r_int)  # :383-391
         self.x_r_int[slot] = r_int
@@ -436,6 +499,9 @@ class Agent57LightEngine:
             self._begin_episodes(done)  # lanes whose episode just ended: book it with their UCB controller, draw the next arm
         self.reset_lane = done.clone()
         self.total_env_steps += E
+        if self.overlap:  # the forked updates read the ring position and write the tree: they finish before the add (which moves the position)
+            self.join_learner()
+            r.add_masked()
 
     # ---- learner --------------------------------------------------------------------------------
     def learner_features(self, rp):
@@ -470,8 +536,7 @@ class Agent57LightEngine:
         r.update(b.indices, pri)
         self.train_count_dev.add_(1)
 
-    @_miopen_find
-    def learner_step(self) -> bool:
+    def _learner_step_raw(self) -> bool:
         if self.replay.is_warmup_needed():
             return False
         if self._learner_graph is not None:
@@ -480,6 +545,30 @@ class Agent57LightEngine:
             self._learner_body()
         self.learner.after_update()
         return True
+
+    @_miopen_find
+    def learner_step(self) -> bool:
+        return self._learner_step_raw()
+
+    def fork_learner(self, updates: int):
+        """overlap: `updates` updates on the learner's stream, ordered after everything enqueued on the current stream so far, launched by the helper thread."""
+        if updates <= 0 or self.replay.is_warmup_needed():
+            return
+        main = torch.cuda.current_stream(self.dev)
+        self._ev_fork.record(main)
+
+        def body():
+            self.s_learner.wait_event(self._ev_fork)
+            with torch.cuda.stream(self.s_learner):
+                for _ in range(updates):
+                    self._learner_step_raw()
+                self._ev_join.record(self.s_learner)
+
+        self._learner_pending = True
+        if self._learner_graph is not None:
+            self._launcher.submit(body)
+        else:  # (eager updates call MIOpen-free torch ops from this thread)
+            body()
 
     @_miopen_find
     def capture_graphs(self, warm_updates: int = 3):
@@ -503,16 +592,34 @@ class Agent57LightEngine:
         torch.cuda.synchronize(self.dev)
 
     def step(self, learner_updates: int = 1, events=None):
+        if self.overlap:
+            self.fork_learner(learner_updates)
         if events is not None:
             events[0].record()
-        self.actor_step()
+        self.actor_step()  # (joins the forked updates before its ring commit)
         if events is not None:
             events[1].record()
-        for _ in range(learner_updates):
-            self.learner_step()
+        if self.overlap:
+            self.refresh_actor_copy()
+        else:
+            for _ in range(learner_updates):
+                self.learner_step()
 
     def join_learner(self):
-        """(driver interface of device/vector_runner.py: updates run on the caller's stream, nothing to join)"""
+        """The current stream waits for the forked updates (overlap; otherwise updates run on the caller's stream and there is nothing to join)."""
+        if self.overlap and self._learner_pending:
+            self._launcher.wait()
+            torch.cuda.current_stream(self.dev).wait_event(self._ev_join)
+            self._learner_pending = False
+
+    def refresh_actor_copy(self):
+        """overlap: the actors' private Q-networks := the online ones (one multi-tensor copy each; call with the learner joined)."""
+        if self.overlap:
+            with torch.no_grad():
+                for k, src in self._act_src.items():
+                    torch._foreach_copy_(list(self._act_q[k].parameters()), list(src.parameters()))
+                    if list(src.buffers()):
+                        torch._foreach_copy_(list(self._act_q[k].buffers()), list(src.buffers()))
 
     def prefill(self, randomise_priorities: bool = True):
         """Random-policy rollout until every PER leaf holds an item (untimed benchmark set-up)."""

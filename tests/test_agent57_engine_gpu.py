@@ -287,3 +287,33 @@ def test_hand_written_learner_equals_the_torch_learner_and_is_reproducible():
     assert na == nb == nt and a == b, (a, b)
     for k in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"):
         assert math.isfinite(a[k]) and abs(a[k] - t[k]) <= 1e-3 * max(abs(t[k]), 1e-3), (k, a[k], t[k])
+
+
+def test_overlapped_update_runs_beside_the_actors():
+    """Agent57LightEngine(overlap=True): the update (one HIP graph, launched by the helper thread on the learner's stream) beside the actors' lock-step, joined
+    before the ring commit; the actors act on private copies of the two Q-networks that equal the online ones after every lock-step; the run trains (finite
+    losses, the expected number of updates) and two overlapped instances walk one trajectory."""
+    from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
+
+    def run():
+        torch.manual_seed(0)  # (the networks' initialisation draws from torch's global generator)
+        eng, cfg = _engine84(batch=16, E=16, seed=3)
+        del eng
+        eng = Agent57LightEngine(cfg, 16, 0, episode_len=11, seed=3, overlap=True)
+        for k in range(30):
+            if k == 12:
+                eng.join_learner()
+                eng.capture_graphs()
+            eng.step(learner_updates=1)
+        eng.join_learner()
+        torch.cuda.synchronize()
+        p = eng.parameter
+        for name, src in (("q_ext", p.q_ext_online), ("q_int", p.q_int_online), ("emb", p.emb_network), ("rnd_train", p.lifelong_train)):
+            for a, b in zip(eng._act_q[name].parameters(), src.parameters()):
+                assert torch.equal(a, b), name
+        info = eng.info()
+        assert eng.train_count >= 20 and all(np.isfinite(info[k]) for k in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss")), info
+        return info, float(sum(float(q.double().sum()) for q in p.q_ext_online.parameters()))
+
+    a, b = run(), run()
+    assert a == b

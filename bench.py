@@ -367,8 +367,8 @@ def bench_replay_role(args, dev_index, rank, world, dist):
 def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=None, actor_ranks=1, learner_acts=None):
     """The configs[3] workload: Agent57_light with 84x84x4 frames.  N = 1: E environments + learner on one GPU.  N > 1: `DistributedAgent57Light` --
     actor ranks x E environments, learner + global replay on rank 0 (from 4 ranks up rank 0 ONLY learns: "7 actor GPUs + 1 learner GPU"), the transition
-    push as grouped point-to-point transfers, the five online networks back as one flat broadcast.  `roofline` = the uint8 ring -> float32 stack kernel
-    (the engine's dominant hand-written HBM kernel), timed in isolation on rank 0."""
+    push as grouped point-to-point transfers, the five online networks back as one flat broadcast.  `roofline` = the fused convolution kernel of the
+    actors' image trunks (the dominant kernel by rocprofv3), timed in isolation on rank 0; `cpu_baseline` = the sequential CPU path (N = 1 only)."""
     import torch
 
     import simple_distributed_rl_amd as srl
@@ -429,19 +429,33 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
         if rank != 0:
             dist.destroy_process_group()
             return
-    # roofline of the stack kernel, isolated
-    reps = 50
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(3):
-        stack_replay.stack_current()
-    a.record()
-    for _ in range(reps):
-        stack_replay.stack_current()
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / reps
-    nbytes = E * 4 * 84 * 84 * (1 + 4)
+    # roofline of the dominant kernel (rocprofv3: k_convnet_fused<true, ...>, the actors' image trunks: five launches per lock-step), isolated launches
+    # of ONE trunk over the E current stacks, HIP events on the launch stream (libsrlx launches on torch's current stream here)
+    local = eng.local if dist is not None else eng
+    trunk = local._trunks.get("q_ext") if getattr(local, "_trunks", None) else None
+    roof = None
+    if trunk is not None:
+        reps = 30
+        base, off = stack_replay.obs_base, local._frame_off
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            trunk(base, off)
+        a.record()
+        for _ in range(reps):
+            trunk(base, off)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        ex = CONV_EXECUTED_FLOPS_PER_SAMPLE * E
+        roof = {"kernel": "k_convnet_fused<true, ...> (+ k_pack_filters): conv1 -> conv2 -> conv3 of ONE of the five image trunks of the actors' pass over E uint8 stacks "
+                          "(five such launches per lock-step; 24 % of the GPU time in profiles/r4_a57_kernel_stats.csv)",
+                "bound": "mfma", "achieved": ex / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": None, "executed_mfma_flops_per_launch": ex, "avg_launch_ms": ms, "launches_per_lock_step": len(local._trunks),
+                "note": "isolated launches (the update does not run beside them); executed flops = 3 x conv1 + 6 x conv2 / conv3 exact split-bf16 partial products"}
     info = eng.info()
+    cpu = None
+    if dist is None and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_agent57(args, rl, E)
     out = {
         "metric": "env-steps/sec + learner updates/sec, Agent57_light 84x84x4", "value": n_lock * E * actor_ranks / elapsed, "unit": "env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -452,11 +466,9 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
                                 f"{world} GPUs: rank0 learner + replay, {world - 1} actor ranks (BASELINE.json configs[3] topology)") + ", grouped send/recv push, flat broadcast",
                    "backend": "none" if dist is None else args.backend,
                    "learner_updates_per_lock_step": args.updates, "batch_size": args.batch_size, "per_capacity": eng.replay.capacity, "actor_num": rl.actor_num,
-                   "networks": "torch modules (MIOpen / hipBLASLt); libsrlx: frame ring + stack, epsilon-greedy, UCB, NGU kNN / RND reward, targets, losses, priorities, PER",
+                   "networks": "image blocks of all five networks forward AND backward in libsrlx (k_convnet_fused + the hand-written backward; no MIOpen on the path); dense tails + Adam: torch (hipBLASLt); libsrlx also: frame ring + stack, epsilon-greedy, UCB, NGU kNN / RND reward, targets, losses, priorities, PER",
                    "hip_graphs": "learner update" if (not args.no_graph and dist is None) else False},
-        "roofline": {"kernel": "k_stack_current_u8 (uint8 frame ring -> float32 [E,4,84,84] network input)", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes,
-                     "avg_launch_ms": ms, "note": "isolated launches"},
+        "roofline": roof, "cpu_baseline": cpu,
         "final": {"loss": info.get("loss"), "train_count": info["train_count"], "memory": info["memory"]},
     }
     if dist is not None:
@@ -580,6 +592,7 @@ def subfigures(eng, args, inner):
     }
 
 
+CONV_EXECUTED_FLOPS_PER_SAMPLE = 125728456704.0 / 1024  # 84x84x4 DQN image block: 3 x conv1's 7.23 MFLOP + 6 x conv2 / conv3's 16.85 MFLOP (exact split-bf16 partial products)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= the fp32 vector peak)
 
@@ -775,6 +788,149 @@ def per_micro(eng, draws=1 << 20, reps=20):
     ops[f"add_{E}"] = {"us_per_call": 1e3 * ms, "adds_per_s": E / (ms * 1e-3), "algorithmic_bytes_per_item": 16 + depth * 16 + 8}
     out["ops"] = ops
     return out
+
+
+def cpu_baseline_agent57(args, rl, E):
+    """The reference-shaped sequential CPU path of Agent57_light (agent57_light.py:271-529, model_torch.py:263-443): ONE environment, batch-1 inference of
+    the two UVFA Q-networks + embedding + RND pair on torch-CPU, episodic / lifelong novelty and targets in the numpy oracle, PER in the C oracle, one
+    update (four forward / backward passes at B = batch_size) per E env-steps as in the GPU run.  kind = "port"; bounded to --cpu-seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import torch
+
+    import hot_path_oracle as H
+    from oracle_bindings import OraclePER
+    from simple_distributed_rl_amd.device.agent57_light import embed, q_values, rnd
+    from simple_distributed_rl_amd.rl import functions as funcs
+
+    host_cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    c = rl
+    c._set_device("cpu")
+    p = c.make_parameter()
+    p.to_device("cpu")
+    A, Na, B, W = c.action_space.n, c.actor_num, c.batch_size, 4
+    beta_l = np.array(funcs.create_beta_list(Na), np.float32)
+    disc_l = np.array(funcs.create_discount_list(Na), np.float32)
+    eps_l = np.array(funcs.create_epsilon_list(Na), np.float32)
+    opts = [torch.optim.Adam(m.parameters(), lr=lr) for m, lr in ((p.q_ext_online, c.lr_ext), (p.q_int_online, c.lr_int), (p.emb_network, c.episodic_lr),
+                                                                  (p.lifelong_train, c.lifelong_lr))]
+    probe = torch.rand(1, W, 84, 84)
+    z1, zA, zN = torch.zeros(1, 1), torch.zeros(1, A), torch.zeros(1, Na)
+    zN[0, 0] = 1
+
+    def pick_threads(fn):
+        best, cores = None, 1
+        for th in sorted({1, 4, 8, 16, 32, min(64, host_cores)}):
+            if th > host_cores:
+                continue
+            torch.set_num_threads(th)
+            fn()
+            t = time.perf_counter()
+            fn()
+            fn()
+            t = time.perf_counter() - t
+            if best is None or t < best:
+                best, cores = t, th
+        return cores
+
+    with torch.no_grad():
+        cores = pick_threads(lambda: q_values(p.q_ext_online, probe, z1, z1, zA, zN))
+        big = torch.rand(B, W, 84, 84)
+        zB1, zBA, zBN = torch.zeros(B, 1), torch.zeros(B, A), torch.zeros(B, Na)
+        cores_l = pick_threads(lambda: q_values(p.q_ext_online, big, zB1, zB1, zBA, zBN))
+    cap = min(args.capacity, 200_000)
+    per = OraclePER(cap, 0.6, 0.4, 1_000_000, True, 0.0001)
+    store = H.StoreOracle(1, 4096, 84 * 84, W, 1, A, True, 0)
+    store.reset_all(rng.integers(0, 256, (1, 84 * 84), dtype=np.uint8))
+    epi = H.EpisodicMemoryOracle(c.episodic_memory_capacity, c.episodic_count_max, c.episodic_epsilon, c.episodic_cluster_distance, c.episodic_pseudo_counts)
+    for _ in range(512):
+        per.add(None)
+    eyeA, eyeN = np.eye(A, dtype=np.float32), np.eye(Na, dtype=np.float32)
+    arm, prev_a, prev_re, prev_ri = 0, 0, 0.0, 0.0
+    env_steps = updates = 0
+    t_actor = t_learner = 0.0
+    t0 = time.perf_counter()
+    deadline = t0 + args.cpu_seconds
+    T = torch.from_numpy
+    while time.perf_counter() < deadline:
+        ta = time.perf_counter()
+        torch.set_num_threads(cores)
+        for _ in range(E):
+            s = T(store.stack_current().reshape(1, W, 84, 84))
+            ins = (T(np.float32([[prev_re]])), T(np.float32([[prev_ri]])), T(eyeA[[prev_a]]), T(eyeN[[arm]]))
+            with torch.no_grad():
+                q = (q_values(p.q_ext_online, s, *ins) + float(beta_l[arm]) * q_values(p.q_int_online, s, *ins)).numpy()
+            a = H.epsilon_greedy(q, [float(eps_l[arm])], rng.random((1, 2)))
+            nxt, rew, term, done = H.synth_env_step(store, args.episode_len)
+            store.commit_step(a, rew, term, done, nxt)
+            s2 = T(store.stack_current().reshape(1, W, 84, 84))
+            with torch.no_grad():
+                e = embed(p.emb_network, s2).numpy()[0]
+                lt, lp = rnd(p.lifelong_target, s2).numpy(), rnd(p.lifelong_train, s2).numpy()
+            r_int = float(epi.step(e, exact_dot=False)) * float(H.ngu_lifelong_reward(lt, lp, c.lifelong_max)[0])
+            if bool(np.asarray(done).reshape(-1)[0]):
+                epi.reset()
+                arm = int(rng.integers(Na))
+            prev_a, prev_re, prev_ri = int(np.asarray(a).reshape(-1)[0]), float(np.asarray(rew).reshape(-1)[0]), r_int
+            per.add(None)
+            env_steps += 1
+            if time.perf_counter() >= deadline:
+                break
+        t_actor += time.perf_counter() - ta
+        if updates >= 2 and time.perf_counter() >= deadline:
+            break
+        tl = time.perf_counter()
+        torch.set_num_threads(cores_l)
+        _, idx, w, _ = per.sample(B, updates, rng.random(B + 8))
+        valid_q = rng.integers(8, max(9, store.pos - 3), B)
+        items = [store.gather_item(0, int(q_)) for q_ in valid_q]
+        obs = np.stack([it[0] for it in items]).reshape(B, 2, W, 84, 84)
+        act = np.stack([it[1] for it in items])[:, 0].astype(np.int64)
+        rew = np.stack([it[2] for it in items])[:, 0].astype(np.float32)
+        und = 1.0 - np.stack([it[3] for it in items])[:, 0].astype(np.float32)
+        actor = rng.integers(0, Na, B)
+        s0, s1 = T(obs[:, 0].copy()), T(obs[:, 1].copy())
+        r_i = rng.random(B).astype(np.float32)
+        nins = (T(rew[:, None]), T(r_i[:, None]), T(eyeA[act]), T(eyeN[actor]))
+        cins = (T(rew[:, None]), T(r_i[:, None]), T(eyeA[act]), T(eyeN[actor]))
+        wt = T(w.astype(np.float32))
+        tds = []
+        for (on, tg, opt, r) in ((p.q_ext_online, p.q_ext_target, opts[0], rew), (p.q_int_online, p.q_int_target, opts[1], r_i)):
+            with torch.no_grad():
+                qt, qo = q_values(tg, s1, *nins).numpy(), q_values(on, s1, *nins).numpy()
+            target = H.agent57_target(qo, qt, r, und, disc_l[actor], None, True, False)
+            q0 = q_values(on, s0, *cins)
+            qsel = q0[torch.arange(B), T(act)]
+            loss = torch.nn.functional.huber_loss(T(target) * wt, qsel * wt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            tds.append(target - qsel.detach().numpy())
+        h = torch.cat([embed(p.emb_network, s0), embed(p.emb_network, s1)], dim=1)
+        probs = torch.softmax(p.emb_network.out_block_out1(p.emb_network.out_block_normalize(p.emb_network.out_block(h))), dim=1)
+        loss = torch.nn.functional.mse_loss(probs, T(eyeA[act]))
+        opts[2].zero_grad()
+        loss.backward()
+        opts[2].step()
+        with torch.no_grad():
+            ltv = rnd(p.lifelong_target, s0)
+        loss = torch.nn.functional.mse_loss(ltv, rnd(p.lifelong_train, s0))
+        opts[3].zero_grad()
+        loss.backward()
+        opts[3].step()
+        per.update(idx, H.agent57_priority(tds[0], tds[1], beta_l[actor]))
+        updates += 1
+        t_learner += time.perf_counter() - tl
+    el = time.perf_counter() - t0
+    return {"value": env_steps / el, "unit": "env-steps/s", "learner_updates_per_s": updates / el, "cores": max(cores, cores_l),
+            "threads": {"actor_batch1_inference": cores, "learner_batched_passes": cores_l, "host_cores": host_cores},
+            "actor_only": {"env_steps_per_s": env_steps / t_actor if t_actor > 0 else None},
+            "learner_only": {"updates_per_s": updates / t_learner if t_learner > 0 else None, "ms_per_update": 1e3 * t_learner / updates if updates else None},
+            "kind": "port",
+            "sample": f"{env_steps} sequential env-steps (1 env, batch-1 inference of 5 networks, numpy NGU novelty) + {updates} learner updates (B={B}, four "
+                      f"forward/backward passes) in {el:.1f}s, {E} env-steps per update as in the GPU run; PER capacity {cap}"}
 
 
 def cpu_baseline(args, cfg):

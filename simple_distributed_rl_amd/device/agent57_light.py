@@ -16,9 +16,14 @@ array and every list comprehension a kernel:
                                                                                                 srlx_agent57_priority
     proportional replay                                                                         srlx_per_*
 
-The five networks (two UVFA Q-networks, the inverse-dynamics embedding, RND target / predictor) are the plugin's torch
-modules (algorithms/agent57_light.py: the reference's module trees, so parameters stay interchangeable); their convolutions
-and GEMMs run through MIOpen / hipBLASLt.  `Agent57LightLearner` is shared with the single-environment plugin trainer.
+The five networks (two UVFA Q-networks, the inverse-dynamics embedding, RND target / predictor) keep the plugin's torch
+module trees (algorithms/agent57_light.py: the reference's, so parameters stay interchangeable), but on this engine their
+IMAGE BLOCKS never run through torch: actors and learner evaluate them with libsrlx's fused convolution kernel straight from
+the uint8 ring (device/qnet.py:ImageTrunk / TrainableImageTrunk, weights bound by address) and the learner differentiates
+them with the hand-written backward (srlx_qnet_backward_convs_u8); only the dense tails and Adam are torch (hipBLASLt).
+SRLX_A57_TORCH_LEARNER=1 puts the learner back on torch's convolutions (a test yardstick).  `Agent57LightLearner` is shared
+with the single-environment plugin trainer.  With overlap=True the update runs on its own stream beside the next lock-step's
+actors, which act on copies of the networks they need (refreshed after the join), like the Rainbow engine.
 """
 import ctypes
 import functools

@@ -261,9 +261,17 @@ def test_trainable_trunk_gradients_equal_autograd():
 
 def test_hand_written_learner_equals_the_torch_learner_and_is_reproducible():
     """The update with the image blocks of all five networks in libsrlx (forward + backward; no MIOpen on the update path) against the same update through
-    torch's convolutions (SRLX_A57_TORCH_LEARNER=1) from the same seed: the four losses agree after 12 updates (1e-3: MIOpen's own fp32 solvers differ
-    more from each other than that); and two hand-written instances give the SAME losses bit for bit (with MIOpen one instance in
-    four landed on a different trajectory)."""
+    torch's convolutions (SRLX_A57_TORCH_LEARNER=1) from the same seed.  Two statements, two tolerances:
+    * the FIRST update's four losses -- same weights, same batch, only the forward arithmetic differs (split-bf16 products on the matrix pipe against
+      MIOpen's fp32 convolutions) -- agree to north_star's 1e-5;
+    * after 12 updates the losses agree to 1e-3.  That is a statement about two float32 Adam TRAJECTORIES, not about a kernel: Adam divides by
+      sqrt(v) + eps, so a parameter whose gradient is a cancellation residue moves by the full learning rate in a direction that the last bits of the
+      gradient sum decide; the two learners order their gradient sums differently (MIOpen's solver against ticketed MFMA partials), the differences
+      compound over the updates, and MIOpen's own fp32 solvers differ more from each other than 1e-3 over the same 12 updates (round 3: one instance
+      in four landed on a different trajectory).  A per-update bound is the first bullet; the single-update gradients are held to 2e-4 of max |g|
+      in test_trainable_trunk_gradients_equal_autograd above, the whole update against a recorded Trainer.train() of the reference in tests/test_agent57_cpu.py / test_agent57_gpu.py (golden
+      train_step_agent57_light.npz).
+    Two hand-written instances give the SAME losses bit for bit."""
     def run(torch_learner):
         if torch_learner:
             os.environ["SRLX_A57_TORCH_LEARNER"] = "1"
@@ -275,16 +283,22 @@ def test_hand_written_learner_equals_the_torch_learner_and_is_reproducible():
         finally:
             os.environ.pop("SRLX_A57_TORCH_LEARNER", None)
         assert (eng._ltrunks is None) == torch_learner
+        first = None
         for _ in range(20):
             eng.step(learner_updates=1)
+            if first is None and eng.train_count == 1:
+                torch.cuda.synchronize()
+                first = dict(eng.learner.losses())
         torch.cuda.synchronize()
-        assert eng.train_count >= 12
-        return eng.learner.losses(), eng.train_count
+        assert eng.train_count >= 12 and first is not None
+        return eng.learner.losses(), eng.train_count, first
 
-    a, na = run(False)
-    b, nb = run(False)
-    t, nt = run(True)
-    assert na == nb == nt and a == b, (a, b)
+    a, na, fa = run(False)
+    b, nb, fb = run(False)
+    t, nt, ft = run(True)
+    assert na == nb == nt and a == b and fa == fb, (a, b)
+    for k in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"):
+        assert abs(fa[k] - ft[k]) <= 1e-5 * max(abs(ft[k]), 1e-2), ("first update", k, fa[k], ft[k])
     for k in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss"):
         assert math.isfinite(a[k]) and abs(a[k] - t[k]) <= 1e-3 * max(abs(t[k]), 1e-3), (k, a[k], t[k])
 

@@ -40,6 +40,8 @@ extern "C" {
 
 const char *srlx_last_error(void);
 int srlx_version(void);
+/* Measurement aid: one-thread launch writing the device's constant-rate wall clock (wall_clock64: 100 MHz) into d_buf[index]; capturable into HIP graphs. */
+int srlx_debug_stamp(uint64_t *d_buf, int index, void *stream);
 int srlx_device_count(int *out_count);
 /* name (e.g. "gfx950"), CU count and total HBM bytes of a device */
 int srlx_device_info(int device, char *arch_name, int arch_name_len, int *cu_count, int64_t *hbm_bytes);
@@ -504,9 +506,20 @@ int srlx_qnet_actor_sets_enable(srlx_qnet_t *h);
 int srlx_qnet_actor_set_planes(srlx_qnet_t *h, int set, void **d_planes);
 int srlx_qnet_actor_set_select(srlx_qnet_t *h, int set);
 int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int with_fc1, int64_t *d_bump, void *stream);
+/* The replay's priority write-back (rainbow/model_torch.py:113-114: memory.update(batch, priorities)) as part of the backward pass: with a sink set, every
+ * srlx_qnet_backward_td_u8 / _backward_u8 launches srlx_per_update(per, n, d_indices, d_priorities, prio_kind, on_device = 1) first thing on its weight-gradient
+ * branch -- right behind the kernel that produced the priorities, beside the gradient kernels -- instead of the caller doing it after the optimiser step.
+ * The branch joins the caller's stream before the call's last launch, so the tree is updated when the backward returns to the caller's stream order.
+ * per = NULL removes the sink.  Pointers are device pointers that must stay valid (captured into HIP graphs with the pass). */
+int srlx_qnet_set_priority_sink(srlx_qnet_t *h, srlx_per_t *per, int64_t n, const int64_t *d_indices, const void *d_priorities, int prio_kind);
+
 /* a caller-owned HIP event (hipEvent_t, NULL: none) recorded on the backward pass's stream right behind its head kernel: with srlx_qnet_backward_td_u8 the TD
  * targets, loss and new priorities exist from there on, so the priority write-back (srlx_per_update) can run beside the gradient kernels on another stream */
 int srlx_qnet_set_td_event(srlx_qnet_t *h, void *event);
+/* Measurement aid (tools/lockstep_phases.py): with a buffer set, every backward pass launches srlx_debug_stamp at fixed points -- d_buf[16] head kernel done,
+ * [17] first dense layer's data gradient, [18] conv3's data gradient + fold, [19] conv2's data gradient + fold, [20] conv1's weight gradient (caller's stream);
+ * [21] priority sink, [22] conv3's weight gradient + reduction, [23] conv2's, [24] the first dense layer's (weight-gradient branch).  NULL: none (production). */
+int srlx_qnet_set_stamp_buffer(srlx_qnet_t *h, uint64_t *d_buf);
 int srlx_qnet_fuse_adam_fc1_planes(srlx_qnet_t *h, void *d_planes_out);
 int srlx_qnet_set_pack_sticky(srlx_qnet_t *h, int on);
 /* splits > 0: the chip-filling first-dense-layer launches of a handle with operand planes use half-CU workgroups (256 threads, 72 KB of LDS, `splits` K splits:

@@ -11,7 +11,20 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace srlx
 
+namespace {
+__global__ void k_stamp(unsigned long long *buf, int i) { buf[i] = wall_clock64(); }
+}  // namespace
+
 extern "C" {
+
+// Measurement aid (tools/lockstep_phases.py): a one-thread launch that writes the device's constant-rate wall clock (100 MHz on MI355X) into d_buf[index] --
+// a timestamp that survives capture into a HIP graph, where external event records are refused by this HIP runtime.
+int srlx_debug_stamp(uint64_t *d_buf, int index, void *stream) {
+    SRLX_REQUIRE(d_buf && index >= 0, "debug_stamp: bad argument");
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long *)d_buf, index);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
 
 const char *srlx_last_error(void) { return srlx::g_err; }
 int srlx_version(void) { return SRLX_VERSION; }

@@ -845,7 +845,8 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     if (h->wf_planes) (void)hipFree(h->wf_planes);
     if (h->a3_planes) (void)hipFree(h->a3_planes);
     if (h->side && !h->side_external) (void)hipStreamDestroy(h->side);
-    for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join, h->ev_wt})
+    if (h->side2) (void)hipStreamDestroy(h->side2);
+    for (hipEvent_t e : {h->ev_fork, h->ev_d3, h->ev_d2, h->ev_d1, h->ev_join, h->ev_wt, h->ev_join2})
         if (e) (void)hipEventDestroy(e);
     delete h;
     return SRLX_OK;
@@ -1033,6 +1034,19 @@ int srlx_qnet_set_planes_small(srlx_qnet_t *h, int on, const void *d_weight_plan
     h->wf_planes_ext = d_weight_planes;
     if (on && h->fc1_neighbour <= 0) h->fc1_neighbour = 4;
     if (d_weight_planes) h->planes_valid = true;
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_priority_sink(srlx_qnet_t *h, srlx_per_t *per, int64_t n, const int64_t *d_indices, const void *d_priorities, int prio_kind) {
+    SRLX_REQUIRE(h, "qnet_set_priority_sink: NULL handle");
+    SRLX_REQUIRE(!per || (h->max_train > 0 && n > 0 && d_indices && d_priorities), "qnet_set_priority_sink: enable training first; n > 0 and device pointers");
+    h->sink_per = per, h->sink_n = n, h->sink_idx = d_indices, h->sink_prio = d_priorities, h->sink_kind = prio_kind;
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_stamp_buffer(srlx_qnet_t *h, uint64_t *d_buf) {
+    SRLX_REQUIRE(h, "qnet_set_stamp_buffer: NULL handle");
+    h->stamp_buf = d_buf;
     return SRLX_OK;
 }
 

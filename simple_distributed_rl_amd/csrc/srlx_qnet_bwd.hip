@@ -622,7 +622,9 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
     SRLX_HIP(hipMalloc((void **)&h->c1_cnt, (size_t)h->Wn * 5 * sizeof(unsigned)));
     SRLX_HIP(hipMemset(h->c1_cnt, 0, (size_t)h->Wn * 5 * sizeof(unsigned)));
     SRLX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    for (hipEvent_t *e : {&h->ev_fork, &h->ev_d3, &h->ev_d2, &h->ev_d1, &h->ev_join, &h->ev_wt})
+    // (side2 -- SRLX_FC1_ORDER=2 -- is created on first use: one more stream in the process changes which hardware queues the others land on, and with two
+    //  queues that decides whether the update overlaps the actors' pass at all: measured 0.61 against 0.50 ms per lock-step with an UNUSED extra stream)
+    for (hipEvent_t *e : {&h->ev_fork, &h->ev_d3, &h->ev_d2, &h->ev_d1, &h->ev_join, &h->ev_wt, &h->ev_join2})
         SRLX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     h->max_train = max_train_batch;
     return SRLX_OK;
@@ -647,10 +649,17 @@ int srlx_qnet_fuse_adam_fc1(srlx_qnet_t *h, float *d_exp_avg, float *d_exp_avg_s
 // Two branches (fork/join with events; capturable into a HIP graph): the data-gradient chain, then conv1's weight gradient (which needs the end of
 // it), stay on the caller's stream; the other weight gradients run on h->side as soon as the activation gradient each needs exists -- the first
 // dense layer's with Adam in its epilogue when the optimiser state is bound.
+#define SRLX_STAMP(idx, stream) \
+    if (h->stamp_buf) SRLX_TRY(srlx_debug_stamp(h->stamp_buf, (idx), (stream)))
+
 static int chain_prologue(srlx_qnet_t *h, hipStream_t st) {
     hipStream_t sd = h->side;
     SRLX_HIP(hipEventRecord(h->ev_fork, st));
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
+    // the replay's priority write-back (model_torch.py:113-114) needs the TD kernel's output only: first thing on the weight-gradient branch instead of the
+    // last launch of the update (it was 9 us + a launch boundary at the very end of the learner's critical path)
+    if (h->sink_per) SRLX_TRY(srlx_per_update(h->sink_per, h->sink_n, h->sink_idx, h->sink_prio, h->sink_kind, 1, sd));
+    SRLX_STAMP(21, sd);
     const int C2 = 2 * h->F1;
     // the transposed filters of the two data-gradient GEMMs depend on the weights only: the fused forward of a training handle has
     // built them already (k_pack_filters); otherwise they are built here, ahead of the chain that needs them
@@ -676,6 +685,7 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
         const i64 tot = (i64)B * h->OH2 * h->OW2 * C2;
         hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, 1, HP, WP, h->dxpad, h->act2, h->dact2);
     }
+    SRLX_STAMP(18, st);
     SRLX_HIP(hipEventRecord(h->ev_d2, st));
     {   // conv2 (4x4 stride 2 pad 2, act1 -> act2) data gradient on the padded grid (OH1 + 4)^2, four parity classes
         const int HP = h->OH1 + 4, WP = h->OW1 + 4, QH = (HP + 1) / 2, QW = (WP + 1) / 2;
@@ -683,6 +693,7 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
         const i64 tot = (i64)B * h->OH1 * h->OW1 * h->F1;
         hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH1, h->OW1, h->F1, 2, HP, WP, 2, QH, QW, h->dxpad, h->act1, h->dact1);
     }
+    SRLX_STAMP(19, st);
     SRLX_HIP(hipEventRecord(h->ev_d1, st));
     // ---- weight gradients of conv3, conv2 and the first dense layer (side stream).  The dense layer's comes last: with Adam in its
     // epilogue it streams 160 MB, and beside the data-gradient chain it tripled the duration of that chain's pad-fold kernels
@@ -690,22 +701,36 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     if (with_fc1 && !h->adam_m)
         hipLaunchKernelGGL(k_fc1_wgrad<false>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
+    // where the Adam-fused first-dense-layer weight gradient goes (SRLX_FC1_ORDER): 0 = last on the side stream (rounds 2-3), 1 = first on the side stream (as soon
+    // as the data gradient has read the weights: ev_d3), 2 = a branch of its own (side2) from ev_d3
+    static const int fc1_order = getenv("SRLX_FC1_ORDER") ? atoi(getenv("SRLX_FC1_ORDER")) : 0;
+    auto launch_fc1_adam = [&](hipStream_t s2) {
+        if (h->adam_planes_out)
+            hipLaunchKernelGGL((k_fc1_wgrad<true, true>), fg, dim3(256), 0, s2, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v,
+                               h->adam_lr, h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step, (__bf16 *)h->adam_planes_out);
+        else
+            hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, s2, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
+                               h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
+    };
+    const bool fc1_adam = with_fc1 && h->adam_m;
+    if (fc1_adam && fc1_order == 1) launch_fc1_adam(sd);
+    if (fc1_adam && fc1_order == 2) {
+        if (!h->side2) SRLX_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+        SRLX_HIP(hipStreamWaitEvent(h->side2, h->ev_d3, 0));
+        launch_fc1_adam(h->side2);
+        SRLX_HIP(hipEventRecord(h->ev_join2, h->side2));
+    }
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
     hipLaunchKernelGGL(k_conv_wgrad_mfma<64>, dim3((9 * 2 * 2 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g3, ss, h->act2, h->dact3, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
+    SRLX_STAMP(22, sd);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
     hipLaunchKernelGGL(k_conv_wgrad_mfma<32>, dim3((16 * 2 * 1 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g2, ss, h->act1, h->dact2, h->w_part, bias_part);
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2);
-    if (with_fc1 && h->adam_m)  // Adam in the epilogue updates the weights in place: (long) after ev_d3, when the data gradient has read them
-    {
-        if (h->adam_planes_out)
-            hipLaunchKernelGGL((k_fc1_wgrad<true, true>), fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v,
-                               h->adam_lr, h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step, (__bf16 *)h->adam_planes_out);
-        else
-            hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
-                               h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);
-    }
+    SRLX_STAMP(23, sd);
+    if (fc1_adam && fc1_order != 1 && fc1_order != 2) launch_fc1_adam(sd);  // Adam in the epilogue updates the weights in place: after ev_d3, when the data gradient has read them
+    SRLX_STAMP(24, sd);
     SRLX_HIP(hipEventRecord(h->ev_join, sd));
     // conv1's weight gradient needs the END of the data-gradient chain: it follows it on the caller's stream instead of queueing behind
     // the conv2 / conv3 weight gradients on the side stream
@@ -717,7 +742,9 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
     hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(kC1Chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
                        h->dact1, c1_part, c1_bias, h->c1_gpart, h->c1_cnt, g_w1, g_b1);  // (reduces its own partial sums: no k_reduce_parts launch behind it)
+    SRLX_STAMP(20, st);
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    if (fc1_adam && fc1_order == 2) SRLX_HIP(hipStreamWaitEvent(st, h->ev_join2, 0));
     return SRLX_OK;
 }
 
@@ -762,6 +789,7 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
             hipLaunchKernelGGL(k_head_bwd<32>, hg, dim3(256), hl, st, B, ss, h->hidden, A, h->dueling, d_grad_q, h->h1, h->v2w, h->a2w, h->dh1, dh1t, g_bf, g_v2w, g_v2b, g_a2w,
                                g_a2b, tda, with_td);
     }
+    SRLX_STAMP(16, st);
     if (h->ev_td) SRLX_HIP(hipEventRecord(h->ev_td, st));  // target / loss / priorities exist: the caller's priority write-back need not wait for the gradients
     SRLX_TRY(chain_prologue(h, st));
     // ---- data-gradient chain (caller's stream)
@@ -771,6 +799,7 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
         hipLaunchKernelGGL(k_fc1_dgrad<64>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
         hipLaunchKernelGGL(k_fc1_dgrad_reduce, dim3((unsigned)(((i64)B * K + 255) / 256)), dim3(256), 0, st, B, ss, K, h->fc_part, h->act3, h->dact3);
     }
+    SRLX_STAMP(17, st);
     SRLX_TRY(conv_chain(h, B, ss, d_frame_base, d_frame_off, g, st, true));
     // NoisyLinear: d loss / d sigma = d loss / d W_effective * eps of the draw the forward used (regenerated, not stored)
     SRLX_TRY(srlx_qnet_noisy_sigma_grads(h, g, st));

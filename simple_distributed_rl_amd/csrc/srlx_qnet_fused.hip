@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
                                                                 float *__restrict__ act3,
                                                                 float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg,
-                                                                unsigned char *__restrict__ planes_out = nullptr, long long plane_rows = 0) {
+                                                                unsigned char *__restrict__ planes_out = nullptr, long long plane_rows = 0, long long n_samples = 0) {
     static_assert(!PLANES || C23B16, "operand planes come out of the split-bf16 conv3 only");
     static_assert(!C23B16 || C1B16, "the split-bf16 conv2 / conv3 read the part planes conv1's split-bf16 epilogue writes");
     constexpr bool PL = C23B16;  // act1 / act2 as bf16 part planes in LDS (kPB1 / kPB2 bytes per pixel) instead of float32
@@ -353,12 +353,23 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     float *a1 = reinterpret_cast<float *>(smem + 4 * kFrame);      // [441][36]            (float32 layout)
     float *a2 = a1 + kM1 * kS1;                                    // [121][68]
     unsigned char *a1p = smem + kOffA1P, *a2p = smem;              // [441][kPB1], [121][kPB2] (plane layout; act2 overlays the frames and conv1's filters)
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, h = lane >> 5, i = lane & 31;
-    const i64 b = blockIdx.x;
+    const int t0 = threadIdx.x, wave = t0 >> 6;
     constexpr int H = 84, W = 84, NT = 64 * kWaves;
     auto stamp = [&](int k) {  // phase timestamps of every wave of workgroup 0 (tools/fused_phases.py); dbg is NULL in production
-        if (dbg && blockIdx.x == 0 && lane == 0) dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (dbg && blockIdx.x == 0 && (t0 & 63) == 0) dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime();
     };
+    // A launch may bring FEWER workgroups than samples (round 4, the actors' chip-filling launches: srlx_qnet_fused_convs): a workgroup then walks samples
+    // blockIdx.x, + gridDim.x, ...  One of these workgroups owns a whole CU (155 KB of LDS, 8 waves x up to 256 registers), so a grid of G < 256 leaves
+    // 256 - G compute units to the learner's kernels for the whole launch instead of one when a 27 us workgroup happens to retire.
+    const float *wpk0 = wpk, *b10 = b1, *b20 = b2, *b30 = b3;
+    for (i64 b = blockIdx.x; b < n_samples; b += gridDim.x) {
+    // (opaque per-iteration copies of the parameter pointers: hoisted out of the sample loop, the filter fragments and biases -- 100+ registers -- would
+    //  stay live through conv2 / conv3 and spill)
+    const float *wpk = wpk0, *b1 = b10, *b2 = b20, *b3 = b30;
+    asm volatile("" : "+s"(wpk), "+s"(b1), "+s"(b2), "+s"(b3));
+    int t = t0;  // ... and of the thread index: the lane's im2col addresses of every unrolled K step are loop-invariant too
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63, h = lane >> 5, i = lane & 31;
     stamp(0);
 
     // ---- stage the four frames (uint8, replicate padding materialised): padded dword (row r, dword d) covers image columns
@@ -624,7 +635,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
         if (pix < kM2) {
             if constexpr (PLANES != 0) {
                 // k-group g of K-slab (pixel * 2 + nt) = channels nt * 32 + 8 g .. + 7: this lane's four are the 8-byte half h of a 16-byte chunk per (g, part)
-                const i64 rows = PLANES == 2 ? (i64)plane_rows : (i64)gridDim.x;
+                const i64 rows = PLANES == 2 ? (i64)plane_rows : (i64)n_samples;
                 unsigned char *dst = (PLANES == 2 ? planes_out : reinterpret_cast<unsigned char *>(act3)) + (((i64)(pix * 2 + nt) * rows + b) * 4) * 48 + h * 8;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
@@ -689,6 +700,8 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
         }
     }
     stamp(7);
+    __syncthreads();  // the next sample's frames / conv1 filter parts overwrite regions the slower waves may still be reading (act2 planes, reduction scratch)
+    }
 }
 
 }  // namespace
@@ -744,9 +757,12 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     h->wt_from_forward = keep;
     static const bool c1_f32 = getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1';  // A/B switch: conv1 on the float32 matrix pipe
     float *out3 = h->act3;
+    // chip-filling launches (>= 512 samples): at most SRLX_CONV_WGS workgroups (default: all samples = the round-3 launch), each walking several samples
+    static const long long conv_wgs = getenv("SRLX_CONV_WGS") ? atoll(getenv("SRLX_CONV_WGS")) : 0;
+    const unsigned grid = (unsigned)(batch >= 512 && conv_wgs > 0 && conv_wgs < batch ? conv_wgs : batch);
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
-                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
+                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch);
     };
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
     if (h->probe0 && hipEventRecord(h->probe0, st) != hipSuccess) return false;  // measurement hook: exactly this kernel, on its launch stream
@@ -762,7 +778,8 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
         // a learner's pass (96 / 128 rows; `planes_small`): float32 act3 for its backward pass AND the planes for the first dense layer, rows padded to the GEMM's tile
         const long long prow = (batch + 127) / 128 * 128;
         hipLaunchKernelGGL((k_convnet_fused<false, true, true, 2>), dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2,
-                           h->b3, out3, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)h->a3_planes, prow);
+                           h->b3, out3, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)h->a3_planes, prow,
+                           (long long)batch);
         h->a3_planes_fresh = true;
     } else if (batch >= 512)
         c1_f32 ? launch(k_convnet_fused<true, false, false>) : c23_f32 ? launch(k_convnet_fused<true, true, false>) : launch(k_convnet_fused<true, true, true>);

@@ -69,6 +69,16 @@ struct srlx_qnet {
     size_t partial_floats;                // allocation of `partial`
     float *c1_gpart;                      // conv1 weight gradient: group partial sums [Wn][4][32 x 64 + 32] of the in-launch reduction
     unsigned *c1_cnt;                     // ... and its arrival tickets [Wn][5] (zero between launches)
+    // round 4 (second half): the replay's priority write-back rides on the weight-gradient branch (srlx_qnet_set_priority_sink), and the first dense layer's
+    // weight gradient can take a branch of its own (side2; SRLX_FC1_ORDER)
+    struct srlx_per *sink_per;            // NULL: no sink
+    const int64_t *sink_idx;
+    const void *sink_prio;
+    int64_t sink_n;
+    int sink_kind;
+    hipStream_t side2;
+    hipEvent_t ev_join2;
+    uint64_t *stamp_buf;                  // measurement aid (srlx_qnet_set_stamp_buffer): srlx_debug_stamp launches at fixed points of the backward pass
     hipEvent_t ev_td;                     // caller-owned or NULL: recorded right behind the head kernel of every backward pass (srlx_qnet_set_td_event)
     void *adam_planes_out;                // the fused Adam of the first dense layer ALSO writes the updated weight as operand planes here (NULL: off)
     // epsilon-greedy fused into the head kernel of the NEXT forward (srlx_qnet_forward_u8_policy)

@@ -14,6 +14,7 @@ the actor's policy step and the learner's online/target evaluation of s_1..s_n, 
 straight from the ring.
 """
 import ctypes
+from typing import Optional
 
 import torch
 import torch.nn as nn
@@ -314,6 +315,14 @@ class QNetInference:
         """Pack this handle's convolution filters for its own next forwards and (with `actor`) publish the network into that handle's set k in the same launch;
         with_fc1: also split the first dense layer's weight into the set's planes (out-of-band publishes: start-up, restore)."""
         N.check(self.lib.srlx_qnet_publish(self.h, actor.h if actor is not None else None, int(k), int(bool(with_fc1)), N.tptr(bump), N.torch_stream_ptr()))
+
+    def set_priority_sink(self, replay, indices: Optional[torch.Tensor], priorities: Optional[torch.Tensor]):
+        """The replay's priority write-back (model_torch.py:113-114) as the first launch of the backward pass's weight-gradient branch (srlx_qnet_set_priority_sink);
+        replay = None removes it.  float32 |td| priorities, transformed on the device like DeviceReplay.update does."""
+        if replay is None:
+            N.check(self.lib.srlx_qnet_set_priority_sink(self.h, None, 0, None, None, 0))
+        else:
+            N.check(self.lib.srlx_qnet_set_priority_sink(self.h, replay.h_per, indices.numel(), N.tptr(indices), N.tptr(priorities), N.PRIO_F32))
 
     def set_td_event(self, ev: torch.cuda.Event):
         """`ev` (already recorded once: torch creates the HIP event lazily) is recorded right behind the head kernel of every backward pass from now on."""

@@ -249,6 +249,11 @@ class RainbowEngine:
             # the priority write-back leaves the update's critical path: it needs the head kernel's priorities only, so it runs on the target network's (by then idle)
             # stream beside the gradient kernels; the step count it used to advance moves to the update's LAST launch (the packing / publishing one)
             self._update_branch = os.environ.get("SRLX_UPDATE_BRANCH", "0") == "1"
+            # ... what ships instead: the write-back as the FIRST launch of the backward pass's own weight-gradient branch (no new branch in the graph:
+            # srlx_qnet_set_priority_sink); the step count moves to the packing launch as above.  SRLX_UPDATE_SIDE=0: the write-back as the update's last launch.
+            self._update_side = (not self._update_branch) and self._fused_td and os.environ.get("SRLX_UPDATE_SIDE", "1") != "0"
+            if self._update_side:
+                N.check(self.lib.srlx_per_set_update_counter(self.replay.h_per, None))
             if self._update_branch:
                 self._ev_td, self._ev_upd = torch.cuda.Event(), torch.cuda.Event()
                 self._ev_td.record()
@@ -442,12 +447,20 @@ class RainbowEngine:
         own next forward)."""
         cfg, r = self.cfg, self.replay
         B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
+        pe = getattr(self, "_phase_mark", None)  # tools/lockstep_phases.py: timing events recorded inside the (captured) update; None in production
+
+        def mark(i):
+            if pe is not None:
+                pe(i)
+
+        mark(0)
         if self.fast:
             self.inf_online.fuse_adam_planes(self._planes_ptr[publish] if publish is not None else None)
             if self._learner_planes:  # planes_set: the published set that holds the online network's current first-dense-layer weight (None: none does)
                 self.inf_online.set_planes_small(planes_set is not None, self._planes_ptr[planes_set] if planes_set is not None else None)
         if self.mfma_train:
             b = r.sample_items(self.train_count_dev, all_states=True)
+            mark(1)
             cur = torch.cuda.current_stream(self.dev)
             self._ev_t0.record(cur)
             self.s_target.wait_event(self._ev_t0)
@@ -460,9 +473,12 @@ class RainbowEngine:
                 # calls, i.e. under two noise draws: re-evaluate the dense layers of the s_0 rows under a fresh one
                 self.inf_online.redraw_rows(B, n + 1, out=q_all)
             q_all = q_all.view(B, n + 1, A)
+            mark(2)
             cur.wait_event(self._ev_t1)  # join before the TD kernel
             # rainbow.py:220 + model_torch.py:103: the TD arithmetic reads s_0 and s_1..s_n rows straight out of the one forward;
             # model_torch.py:107-109 without autograd: every p.grad is (over)written by the backward kernels
+            if self.fast and self._update_side:
+                self.inf_online.set_priority_sink(r, b.indices, self.priorities)
             if self._fused_td:  # ... in the prologue of the backward's first kernel
                 self.inf_online.backward_td_u8(r.obs_base, r.frame_off_all, n, q_all, q_tg_next, b.actions, b.rewards, b.terminated, b.weights, cfg.discount,
                                                cfg.retrace_h, cfg.enable_double_dqn, cfg.enable_rescale, self.target, self.loss, self.grad_q0, self.priorities)
@@ -480,11 +496,17 @@ class RainbowEngine:
                 with torch.cuda.stream(self.s_target):
                     r.update(b.indices, self.priorities)  # model_torch.py:113-114
                     self._ev_upd.record(self.s_target)
+            mark(4)
             self.optimizer.step(self.train_count_dev)
+            mark(5)
             if self.fast:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors); train_count_dev += 1
-                self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0, bump=self.train_count_dev if self._update_branch else None)
+                self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0,
+                                           bump=self.train_count_dev if (self._update_branch or self._update_side) else None)
                 if self._update_branch:
                     cur.wait_event(self._ev_upd)
+                    return
+                mark(6)
+                if self._update_side:
                     return
         else:  # SRLX_TORCH_BACKWARD=1: the test yardstick -- matrix-core evaluation of s_1..s_n, autograd for the gradient step
             b = r.sample_items(self.train_count_dev)
@@ -534,13 +556,18 @@ class RainbowEngine:
         self.sync_count += 1
 
     # ---- the pieces of a step (the Runner's vectorised loop drives them one by one: device/vector_runner.py) --------
-    def fork_learner(self, updates: int) -> int:
+    def fork_point(self):
+        """Marks the point of the current stream the next fork_learner(..., marked=True) is ordered after (the replay as of now): lets the host enqueue more work on
+        the current stream -- the actors' pass -- BEFORE it spends ~100 us inside the update graph's launch, without that work becoming a dependency of the update."""
+        self._ev_fork.record(torch.cuda.current_stream(self.dev))
+
+    def fork_learner(self, updates: int, marked: bool = False) -> int:
         """overlap=True: enqueue `updates` learner updates on the learner's stream, ordered after everything enqueued on the
-        current stream so far (they see the replay as of now).  Returns how many ran (0 below the warm-up)."""
+        current stream so far (they see the replay as of now; marked=True: as of the last fork_point()).  Returns how many ran (0 below the warm-up)."""
         if self.fast:
             self._check_versions()
-        main = torch.cuda.current_stream(self.dev)
-        self._ev_fork.record(main)
+        if not marked:
+            self.fork_point()
 
         def body():
             self.s_learner.wait_event(self._ev_fork)
@@ -618,8 +645,9 @@ class RainbowEngine:
         stream: the matrix-core network pass (or, on the torch path, the frame-stack kernel)."""
         if self.fast:
             if self._actor_first:  # the host issues the actors' four launches BEFORE the update's graph (whose launch keeps the host busy for tens of microseconds)
+                self.fork_point()
                 self.actor_front(events)
-                self.fork_learner(learner_updates)
+                self.fork_learner(learner_updates, marked=True)
             else:
                 self.fork_learner(learner_updates)
                 self.actor_front(events)

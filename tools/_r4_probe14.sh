@@ -1,0 +1,14 @@
+#!/bin/bash
+# same-box A/B: conv2's weight gradient behind conv1's on the caller's stream (SRLX_WGRAD_SPLIT=1) against the side stream
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+{
+SRLX_WGRAD_SPLIT=1 timeout 1200 python -m pytest tests/test_fast_lockstep_gpu.py tests/test_qnet_bwd_gpu.py -x -q 2>&1 | tail -2
+one() { env "$@" timeout 300 python $R/bench.py --no-cpu-baseline --no-per-micro --steps 12 2>gpurun_out/bench_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; s=d.get('subfigures',{}); print('%-64s %8d env-steps/s  %.4f ms per lock-step  conv %.3f ms  fc1 %.3f ms  actors-only %.3f  update-only %.3f' % ('$*', d['value'], d['ms_per_lock_step'], r['avg_launch_ms'], (r.get('fc1') or {}).get('avg_launch_ms', 0), s.get('actors_only',{}).get('ms_per_lock_step',0), s.get('learner_only',{}).get('ms_per_update',0)))" || tail -3 gpurun_out/bench_err.log; }
+for rep in 1 2; do
+one SRLX_UPDATE_SIDE=0 SRLX_WGRAD_SPLIT=0
+one SRLX_UPDATE_SIDE=1 SRLX_WGRAD_SPLIT=0
+one SRLX_UPDATE_SIDE=1 SRLX_WGRAD_SPLIT=1
+one SRLX_UPDATE_SIDE=1 SRLX_WGRAD_SPLIT=1 SRLX_FC1_ORDER=1
+done
+} 2>&1 | tee gpurun_out/r4_probe14.log

@@ -1,0 +1,18 @@
+#!/bin/bash
+# same-box A/B: the actors' convolution launch on G < 256 workgroups that walk the samples (SRLX_CONV_WGS), leaving 256 - G compute units to the learner's kernels
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+{
+timeout 1200 python -m pytest tests/test_qnet_gpu.py tests/test_qnet_pinned.py tests/test_fast_lockstep_gpu.py -x -q 2>&1 | tail -2
+SRLX_CONV_WGS=224 timeout 1200 python -m pytest tests/test_qnet_gpu.py tests/test_qnet_pinned.py tests/test_fast_lockstep_gpu.py -x -q 2>&1 | tail -2
+one() { env "$@" timeout 300 python $R/bench.py --no-cpu-baseline --no-per-micro --steps 12 2>gpurun_out/bench_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; s=d.get('subfigures',{}); print('%-34s %8d env-steps/s  %.4f ms per lock-step  conv %.3f ms  fc1 %.3f ms  actors-only %.3f  update-only %.3f' % ('$*', d['value'], d['ms_per_lock_step'], r['avg_launch_ms'], (r.get('fc1') or {}).get('avg_launch_ms', 0), s.get('actors_only',{}).get('ms_per_lock_step',0), s.get('learner_only',{}).get('ms_per_update',0)))" || tail -3 gpurun_out/bench_err.log; }
+for rep in 1 2; do
+one SRLX_CONV_WGS=0
+one SRLX_CONV_WGS=256
+one SRLX_CONV_WGS=240
+one SRLX_CONV_WGS=224
+one SRLX_CONV_WGS=205
+one SRLX_CONV_WGS=192
+done
+SRLX_CONV_WGS=224 SRLX_LEARNER_PHASES=1 python tools/lockstep_phases.py 2>&1 | tail -20
+} 2>&1 | tee gpurun_out/r4_probe15.log

@@ -9,7 +9,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # find the last k_sample_wg .. next k_sample_wg window
-idx = [i for i, r in enumerate(rows) if 'k_sample_wg' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_sample_gather_wg' in r['Kernel_Name'] or 'k_sample_wg' in r['Kernel_Name']]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]['Start_Timestamp'])
 prev_end = t0

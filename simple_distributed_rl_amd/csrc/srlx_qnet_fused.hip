@@ -339,7 +339,7 @@ __device__ __forceinline__ f32x16 reduce_quarters(float *__restrict__ scratch, i
 // layer's GEMM reads -- [K/32 slabs][batch rows][4 k-groups][3 parts][8 bf16], K = pixel * 64 + channel -- instead of float32; `act3` then points at them.
 // PLANES = 2 (round 4, the learner's passes): BOTH -- float32 act3 for the backward pass and the planes (at `planes_out`, `plane_rows` rows per K-slab: the launch's
 // rows rounded up to the GEMM's 128-row tile) for the first dense layer.
-template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0>
+template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0, bool WALK = false>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
                                                                 float *__restrict__ act3,
@@ -353,22 +353,23 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     float *a1 = reinterpret_cast<float *>(smem + 4 * kFrame);      // [441][36]            (float32 layout)
     float *a2 = a1 + kM1 * kS1;                                    // [121][68]
     unsigned char *a1p = smem + kOffA1P, *a2p = smem;              // [441][kPB1], [121][kPB2] (plane layout; act2 overlays the frames and conv1's filters)
-    const int t0 = threadIdx.x, wave = t0 >> 6;
+    int t = threadIdx.x;
+    const int wave = t >> 6;
+    i64 b = blockIdx.x;
     constexpr int H = 84, W = 84, NT = 64 * kWaves;
     auto stamp = [&](int k) {  // phase timestamps of every wave of workgroup 0 (tools/fused_phases.py); dbg is NULL in production
-        if (dbg && blockIdx.x == 0 && (t0 & 63) == 0) dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime();
     };
-    // A launch may bring FEWER workgroups than samples (round 4, the actors' chip-filling launches: srlx_qnet_fused_convs): a workgroup then walks samples
-    // blockIdx.x, + gridDim.x, ...  One of these workgroups owns a whole CU (155 KB of LDS, 8 waves x up to 256 registers), so a grid of G < 256 leaves
-    // 256 - G compute units to the learner's kernels for the whole launch instead of one when a 27 us workgroup happens to retire.
-    const float *wpk0 = wpk, *b10 = b1, *b20 = b2, *b30 = b3;
-    for (i64 b = blockIdx.x; b < n_samples; b += gridDim.x) {
-    // (opaque per-iteration copies of the parameter pointers: hoisted out of the sample loop, the filter fragments and biases -- 100+ registers -- would
-    //  stay live through conv2 / conv3 and spill)
-    const float *wpk = wpk0, *b1 = b10, *b2 = b20, *b3 = b30;
-    asm volatile("" : "+s"(wpk), "+s"(b1), "+s"(b2), "+s"(b3));
-    int t = t0;  // ... and of the thread index: the lane's im2col addresses of every unrolled K step are loop-invariant too
-    asm volatile("" : "+v"(t));
+    // WALK (round 4, a measurement variant: SRLX_CONV_WGS): the launch brings FEWER workgroups than samples and a workgroup walks samples blockIdx.x,
+    // + gridDim.x, ...  One of these workgroups owns a whole CU (155 KB of LDS, 8 waves x up to 256 registers), so a grid of G < 256 leaves 256 - G compute
+    // units to the learner's kernels for the whole launch.  Measured slower in the lock-step (profiles/r4_probe15.log), and the loop form costs the
+    // single-sample kernel 20 % (244 instead of 193 registers, a worse schedule of conv2 / conv3): its own instantiation, the default launch stays loop-free.
+next_sample:
+    if constexpr (WALK) {  // opaque per-sample copies of the parameter pointers and the thread index: hoisted out of the sample loop, the filter fragments, biases
+        // and the lane's im2col addresses of every unrolled K step would stay live through conv2 / conv3 and spill
+        asm volatile("" : "+s"(wpk), "+s"(b1), "+s"(b2), "+s"(b3));
+        asm volatile("" : "+v"(t));
+    }
     const int lane = t & 63, h = lane >> 5, i = lane & 31;
     stamp(0);
 
@@ -700,7 +701,10 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
         }
     }
     stamp(7);
-    __syncthreads();  // the next sample's frames / conv1 filter parts overwrite regions the slower waves may still be reading (act2 planes, reduction scratch)
+    if constexpr (WALK) {
+        __syncthreads();  // the next sample's frames / conv1 filter parts overwrite regions the slower waves may still be reading (act2 planes, reduction scratch)
+        b += gridDim.x;
+        if (b < (i64)n_samples) goto next_sample;
     }
 }
 
@@ -742,6 +746,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     static bool attr_set = false;
     if (!attr_set) {
         const void *kerns[] = {(const void *)k_convnet_fused<true, true, true, 1>, (const void *)k_convnet_fused<false, true, true, 2>,
+                               (const void *)k_convnet_fused<true, true, true, 1, true>, (const void *)k_convnet_fused<true, true, true, 0, true>,
                                (const void *)k_convnet_fused<true, true, true>,  (const void *)k_convnet_fused<false, true, true>,
                                (const void *)k_convnet_fused<true, true, false>, (const void *)k_convnet_fused<false, true, false>,
                                (const void *)k_convnet_fused<true, false, false>, (const void *)k_convnet_fused<false, false, false>};
@@ -759,7 +764,8 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     float *out3 = h->act3;
     // chip-filling launches (>= 512 samples): at most SRLX_CONV_WGS workgroups (default: all samples = the round-3 launch), each walking several samples
     static const long long conv_wgs = getenv("SRLX_CONV_WGS") ? atoll(getenv("SRLX_CONV_WGS")) : 0;
-    const unsigned grid = (unsigned)(batch >= 512 && conv_wgs > 0 && conv_wgs < batch ? conv_wgs : batch);
+    static const bool f32_variants = (getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1') || (getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1');
+    const unsigned grid = (unsigned)(batch >= 512 && conv_wgs > 0 && conv_wgs < batch && !f32_variants ? conv_wgs : batch);
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
                            keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch);
@@ -772,7 +778,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     h->a3_planes_fresh = false;
     if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && !keep && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch) && batch >= 512) {
         out3 = reinterpret_cast<float *>(h->a3_planes);
-        launch(k_convnet_fused<true, true, true, 1>);
+        grid < batch ? launch(k_convnet_fused<true, true, true, 1, true>) : launch(k_convnet_fused<true, true, true, 1>);
         h->a3_planes_fresh = true;
     } else if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch)) {
         // a learner's pass (96 / 128 rows; `planes_small`): float32 act3 for its backward pass AND the planes for the first dense layer, rows padded to the GEMM's tile
@@ -782,7 +788,8 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
                            (long long)batch);
         h->a3_planes_fresh = true;
     } else if (batch >= 512)
-        c1_f32 ? launch(k_convnet_fused<true, false, false>) : c23_f32 ? launch(k_convnet_fused<true, true, false>) : launch(k_convnet_fused<true, true, true>);
+        c1_f32 ? launch(k_convnet_fused<true, false, false>) : c23_f32 ? launch(k_convnet_fused<true, true, false>)
+               : grid < batch ? launch(k_convnet_fused<true, true, true, 0, true>) : launch(k_convnet_fused<true, true, true>);
     else
         c1_f32 ? launch(k_convnet_fused<false, false, false>) : c23_f32 ? launch(k_convnet_fused<false, true, false>) : launch(k_convnet_fused<false, true, true>);
     if (h->probe1 && hipEventRecord(h->probe1, st) != hipSuccess) return false;

@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graphs")
     ap.add_argument("--no-overlap", action="store_true", help="run actor and learner back to back on one stream (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--actor-stream", default="low", choices=["low", "normal", "high", "default"],
+                    help="priority level of the stream the actors' side runs on (its own pool of hardware queues); default: torch's current stream")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
     ap.add_argument("--no-per-micro", action="store_true", help="skip the PER micro-benchmark (sample / update / add ops/s, bulk-sample HBM fraction)")
@@ -142,7 +144,7 @@ def main():
                                  learner_acts=learner_acts)
         assert eng.n_actor_ranks == actor_ranks
     else:
-        eng = RainbowEngine(cfg, dev_index, args.episode_len, overlap=not args.no_overlap)
+        eng = RainbowEngine(cfg, dev_index, args.episode_len, overlap=not args.no_overlap, actor_stream=None if args.actor_stream == "default" else args.actor_stream)
     lockstep = "round-4 lock-step (6 launches on the actors' stream, published parameter sets)" if getattr(getattr(eng, "local", eng), "fast", False) else "fifteen-launch lock-step"
 
     # ---- fill the replay (untimed): random-policy rollout until the ring is full, then |delta| ~ U(0,1)
@@ -284,7 +286,7 @@ def main():
             "noisy_dense": cfg.enable_noisy_dense,
             "epsilon": cfg.epsilon,
             "hip_graphs": not args.no_graph,
-            "lockstep": lockstep,
+            "lockstep": lockstep, "actor_stream": (args.actor_stream + "-priority HIP stream (a hardware-queue pool of its own); update graph three branches wide") if getattr(eng, "actor_stream", None) is not None else "torch's current stream",
             "qnet": ("libsrlx: float32 results; forward = float32 products as exact split-bf16 partial products on v_mfma_f32_32x32x16_bf16 (conv1 3, conv2 / conv3 / "
                      "first dense layer 6 per multiply-add), float32 accumulate; " +
                      ("hand-written backward (no autograd)" if getattr(local, "mfma_train", False) else "torch autograd backward (SRLX_TORCH_BACKWARD=1 yardstick)")),

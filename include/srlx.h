@@ -40,6 +40,11 @@ extern "C" {
 
 const char *srlx_last_error(void);
 int srlx_version(void);
+/* A HIP stream of priority level -1 (high) / 0 (normal) / 1 (low), non-blocking.  The device engines run the ACTORS' side on a low-priority stream: HIP keeps
+ * one pool of hardware queues per level, and a HIP graph replays its branches on normal-priority internal streams -- on a pool of its own the actors' stream
+ * never queues behind an update's branch (what the reference's actor / trainer PROCESSES get for free: play_mp.py:471-642). */
+int srlx_stream_create(int priority_level, void **out_stream);
+int srlx_stream_destroy(void *stream);
 /* Measurement aid: one-thread launch writing the device's constant-rate wall clock (wall_clock64: 100 MHz) into d_buf[index]; capturable into HIP graphs. */
 int srlx_debug_stamp(uint64_t *d_buf, int index, void *stream);
 int srlx_device_count(int *out_count);
@@ -520,6 +525,10 @@ int srlx_qnet_set_td_event(srlx_qnet_t *h, void *event);
  * [17] first dense layer's data gradient, [18] conv3's data gradient + fold, [19] conv2's data gradient + fold, [20] conv1's weight gradient (caller's stream);
  * [21] priority sink, [22] conv3's weight gradient + reduction, [23] conv2's, [24] the first dense layer's (weight-gradient branch).  NULL: none (production). */
 int srlx_qnet_set_stamp_buffer(srlx_qnet_t *h, uint64_t *d_buf);
+/* Where a backward pass launches the first dense layer's Adam-fused weight gradient (the update's largest kernel: 240 MB): 0 = last on the weight-gradient
+ * branch (default), 1 = first on it, 2 = on a branch of its own as soon as the data gradient has read the weights.  2 makes a captured update three
+ * branches wide: use it only with the actors on a stream of another priority level (srlx_stream_create). */
+int srlx_qnet_set_fc1_branch(srlx_qnet_t *h, int order);
 int srlx_qnet_fuse_adam_fc1_planes(srlx_qnet_t *h, void *d_planes_out);
 int srlx_qnet_set_pack_sticky(srlx_qnet_t *h, int on);
 /* splits > 0: the chip-filling first-dense-layer launches of a handle with operand planes use half-CU workgroups (256 threads, 72 KB of LDS, `splits` K splits:

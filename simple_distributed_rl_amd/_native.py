@@ -98,6 +98,9 @@ SIGNATURES = {
     "srlx_qnet_actor_set_select": (c_int, [c_p, c_int]),
     "srlx_qnet_publish": (c_int, [c_p, c_p, c_int, c_int, c_p, c_p]),
     "srlx_debug_stamp": (c_int, [c_p, c_int, c_p]),
+    "srlx_stream_create": (c_int, [c_int, ctypes.POINTER(c_p)]),
+    "srlx_stream_destroy": (c_int, [c_p]),
+    "srlx_qnet_set_fc1_branch": (c_int, [c_p, c_int]),
     "srlx_qnet_set_stamp_buffer": (c_int, [c_p, c_p]),
     "srlx_qnet_set_td_event": (c_int, [c_p, c_p]),
     "srlx_qnet_set_priority_sink": (c_int, [c_p, c_p, c_i64, c_p, c_p, c_int]),

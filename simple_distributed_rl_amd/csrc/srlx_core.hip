@@ -26,6 +26,21 @@ int srlx_debug_stamp(uint64_t *d_buf, int index, void *stream) {
     return SRLX_OK;
 }
 
+// A HIP stream of a given priority LEVEL (-1 high, 0 normal, 1 low; hipStreamNonBlocking).  HIP keeps one pool of hardware queues per level: a stream of its
+// own level never shares a hardware queue with the normal-priority internal streams a HIP graph replays its branches on (tools/README.md, finding 5).
+int srlx_stream_create(int priority_level, void **out_stream) {
+    SRLX_REQUIRE(out_stream && priority_level >= -1 && priority_level <= 1, "stream_create: level -1 / 0 / 1");
+    hipStream_t s = nullptr;
+    SRLX_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority_level));
+    *out_stream = (void *)s;
+    return SRLX_OK;
+}
+
+int srlx_stream_destroy(void *stream) {
+    if (stream) SRLX_HIP(hipStreamDestroy((hipStream_t)stream));
+    return SRLX_OK;
+}
+
 const char *srlx_last_error(void) { return srlx::g_err; }
 int srlx_version(void) { return SRLX_VERSION; }
 

@@ -701,9 +701,11 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     if (with_fc1 && !h->adam_m)
         hipLaunchKernelGGL(k_fc1_wgrad<false>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
-    // where the Adam-fused first-dense-layer weight gradient goes (SRLX_FC1_ORDER): 0 = last on the side stream (rounds 2-3), 1 = first on the side stream (as soon
-    // as the data gradient has read the weights: ev_d3), 2 = a branch of its own (side2) from ev_d3
-    static const int fc1_order = getenv("SRLX_FC1_ORDER") ? atoi(getenv("SRLX_FC1_ORDER")) : 0;
+    // where the Adam-fused first-dense-layer weight gradient goes (srlx_qnet_set_fc1_branch; SRLX_FC1_ORDER overrides): 0 = last on the side stream (rounds 2-3),
+    // 1 = first on the side stream (as soon as the data gradient has read the weights: ev_d3), 2 = a branch of its own (side2) from ev_d3 -- a THIRD concurrent
+    // branch of a captured update: only where the actors' stream does not share a hardware-queue pool with the graph's internal streams (tools/README.md, 5)
+    static const int fc1_order_env = getenv("SRLX_FC1_ORDER") ? atoi(getenv("SRLX_FC1_ORDER")) : -1;  // (measurement: overrides the handle's setting)
+    const int fc1_order = fc1_order_env >= 0 ? fc1_order_env : h->fc1_order;
     auto launch_fc1_adam = [&](hipStream_t s2) {
         if (h->adam_planes_out)
             hipLaunchKernelGGL((k_fc1_wgrad<true, true>), fg, dim3(256), 0, s2, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v,

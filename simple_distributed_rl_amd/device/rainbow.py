@@ -103,11 +103,17 @@ class RainbowEngine:
     kernels do not cover raise."""
 
     def __init__(self, cfg: RainbowDeviceConfig, device: int = 0, episode_len: int = 200, ring_len: Optional[int] = None, env=None,
-                 overlap: bool = False, fast: Optional[bool] = None):
+                 overlap: bool = False, fast: Optional[bool] = None, actor_stream: Optional[str] = None):
         """overlap=True runs the actor's network pass and the learner update concurrently on two HIP
         streams.  The actor then acts with its own copy of the online network, refreshed after every
         step (the reference's distributed actors do the same on a timer, play_mp.py:121-165), so no
         kernel ever reads weights that another stream is updating.
+
+        actor_stream="low" (the round-4 lock-step only; SRLX_ACTOR_STREAM overrides): the engine creates a LOW-priority HIP stream and makes it the calling thread's
+        current stream (torch.cuda.set_stream) -- everything the caller enqueues from now on, the actors' side of the engine included, runs on it.  HIP keeps one
+        pool of hardware queues per priority level and replays a graph's branches on normal-priority internal streams, so on a pool of their own the actors never
+        queue behind a branch of the update; the update may then run THREE branches wide (the first dense layer's Adam-fused weight gradient on a branch of its own:
+        srlx_qnet_set_fc1_branch).  Same kernels, same results; None: the current stream stays what it is and the update stays two branches wide.
 
         fast (None = wherever it applies, SRLX_FAST=0 switches it off; True raises where it does not): the round-4 lock-step for an overlapping engine with
         chip-filling policy passes -- six launches on the actors' stream instead of fifteen and nothing but the PER add behind the join:
@@ -154,6 +160,18 @@ class RainbowEngine:
             raise ValueError("RainbowEngine(fast=True): needs overlap, the 84 x 84 x 4 / 32-filter geometry, plain dense layers, >= 512 environments in multiples of 128, "
                              "a hidden layer in multiples of 64 and max-priority adds")
         self.fast = can_fast and (bool(fast) if fast is not None else os.environ.get("SRLX_FAST", "1") != "0")
+
+        self.actor_stream = None
+        want = os.environ.get("SRLX_ACTOR_STREAM") or actor_stream
+        if self.fast and want and want != "default":
+            import ctypes
+
+            raw = ctypes.c_void_p()
+            N.check(self.lib.srlx_stream_create({"high": -1, "normal": 0, "low": 1}[want], ctypes.byref(raw)))
+            self._actor_stream_raw = raw  # (kept for the life of the process: graphs captured on the stream outlive the engine object in some callers)
+            self.actor_stream = torch.cuda.ExternalStream(raw.value, device=self.dev)
+            self.actor_stream.wait_stream(torch.cuda.current_stream(self.dev))
+            torch.cuda.set_stream(self.actor_stream)
 
         def make_net():
             return EngineQNet(A, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.filters, cfg.dueling_type, noisy=self.noisy).to(self.dev)
@@ -252,6 +270,8 @@ class RainbowEngine:
             # ... what ships instead: the write-back as the FIRST launch of the backward pass's own weight-gradient branch (no new branch in the graph:
             # srlx_qnet_set_priority_sink); the step count moves to the packing launch as above.  SRLX_UPDATE_SIDE=0: the write-back as the update's last launch.
             self._update_side = (not self._update_branch) and self._fused_td and os.environ.get("SRLX_UPDATE_SIDE", "1") != "0"
+            if self.actor_stream is not None and want == "low":  # the actors cannot queue behind a branch of the update: it may run three wide
+                N.check(self.lib.srlx_qnet_set_fc1_branch(self.inf_online.h, 2))
             if self._update_side:
                 N.check(self.lib.srlx_per_set_update_counter(self.replay.h_per, None))
             if self._update_branch:

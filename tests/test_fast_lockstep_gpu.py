@@ -190,7 +190,7 @@ def test_half_cu_first_dense_layer_equals_the_other_forms():
     assert torch.equal(pl.forward_u8(ring.data_ptr(), off), want)
 
 
-def _engines(E=512, **cfgkw):
+def _engines(E=512, actor_stream=None, **cfgkw):
     from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
 
     kw = dict(n_envs=E, batch_size=32, memory_capacity=E * 12, memory_warmup_size=E * 4, target_model_update_interval=5, lr=1e-4, seed=3)
@@ -198,7 +198,7 @@ def _engines(E=512, **cfgkw):
     cfg = RainbowDeviceConfig(**kw)
     os.environ["SRLX_FC1_NEIGHBOUR"] = "4"  # the K splits of the fifteen-launch engine's first dense layer: split-K partial sums associate alike, Q-values bit-equal
     try:
-        fast = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=True)
+        fast = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=True, actor_stream=actor_stream)
     finally:
         os.environ.pop("SRLX_FC1_NEIGHBOUR", None)
     slow = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=False)
@@ -230,10 +230,21 @@ def _tree(eng):
     return tree
 
 
-def test_fast_lockstep_equals_the_fifteen_launch_lockstep():
+@pytest.fixture
+def _restore_stream():
+    yield
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+@pytest.mark.parametrize("actor_stream", [None, "low"])
+def test_fast_lockstep_equals_the_fifteen_launch_lockstep(actor_stream, _restore_stream):
     """Two overlapping engines on one seed, one with the round-4 lock-step: identical actions, sampled indices, losses, priorities, weights, ring and tree at
-    every lock-step -- through the warm-up gate, target syncs, episode ends, eager steps, graph capture and replays."""
-    fast, slow = _engines()
+    every lock-step -- through the warm-up gate, target syncs, episode ends, eager steps, graph capture and replays.  actor_stream="low": the actors' side on a
+    low-priority stream of its own (it becomes the thread's current stream) and the update three branches wide (the first dense layer's Adam-fused weight gradient
+    on a branch of its own): the same bits."""
+    fast, slow = _engines(actor_stream=actor_stream)
+    assert (fast.actor_stream is not None) == (actor_stream is not None)
     for eng in (fast, slow):
         for _ in range(6):
             eng._random_rest()

@@ -1,0 +1,16 @@
+#!/bin/bash
+# same-box A/B: the actors on a stream of another priority level (its own pool of hardware queues) x the first dense layer's weight gradient on a third branch of the update graph
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+{
+one() { env "$@" timeout 300 python $R/bench.py --no-cpu-baseline --no-per-micro --steps 12 2>gpurun_out/bench_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; s=d.get('subfigures',{}); print('%-74s %8d env-steps/s  %.4f ms per lock-step  conv %.3f ms  fc1 %.3f ms  actors-only %.3f  update-only %.3f' % ('$*', d['value'], d['ms_per_lock_step'], r['avg_launch_ms'], (r.get('fc1') or {}).get('avg_launch_ms', 0), s.get('actors_only',{}).get('ms_per_lock_step',0), s.get('learner_only',{}).get('ms_per_update',0)))" || tail -3 gpurun_out/bench_err.log; }
+for rep in 1 2; do
+one X=base
+one SRLX_ACTOR_STREAM=high
+one SRLX_ACTOR_STREAM=low
+one SRLX_ACTOR_STREAM=high SRLX_FC1_ORDER=2
+one SRLX_ACTOR_STREAM=low SRLX_FC1_ORDER=2
+one SRLX_ACTOR_STREAM=high SRLX_LEARNER_PRIO=0 SRLX_FC1_ORDER=2
+one SRLX_ACTOR_STREAM=high SRLX_LEARNER_PRIO=0
+done
+} 2>&1 | tee gpurun_out/r4_probe21.log

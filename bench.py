@@ -387,6 +387,14 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
     env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(episode_len=args.episode_len)))
     rl.setup(env)
     dev = torch.device(f"cuda:{dev_index}")
+    if dist is None and args.actor_stream != "default":  # as the Rainbow line: the actors' side on a stream of its own priority level (its own hardware-queue pool)
+        import ctypes
+
+        from simple_distributed_rl_amd import _native as N
+
+        raw = ctypes.c_void_p()
+        N.check(N.lib().srlx_stream_create({"high": -1, "normal": 0, "low": 1}[args.actor_stream], ctypes.byref(raw)))
+        torch.cuda.set_stream(torch.cuda.ExternalStream(raw.value, device=dev))
     if dist is not None:
         from simple_distributed_rl_amd.device.dist import DistributedAgent57Light
 

@@ -28,7 +28,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kFcSplits = 16;   // splits of the hidden dimension in the dense data-gradient
 constexpr int kWgSplits = 64;   // partial tensors of a conv weight gradient: one per sample (max_train <= 64)
-constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad, kC1Chunks = 4;  // conv1 weight gradient: pixel chunks per (sample, frame)
+constexpr int kC1Pad = 88, kC1Frame = kC1Pad * kC1Pad, kC1Chunks = 4;  // conv1 weight gradient: pixel chunks per (sample, frame) the scratch is sized for; the launch uses c1_chunks() of them
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float byte_to_unit(unsigned b) {  // u8 / 255, correctly rounded (see srlx_qnet.hip)
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int
 __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, i64 sstride, int Wn, int H, int W,
                                                           int OH, int OW, int per, const float *__restrict__ dY1, float *__restrict__ part,
                                                           float *__restrict__ bias_part, float *__restrict__ gpart, unsigned *__restrict__ tickets,
-                                                          float *__restrict__ g_w1, float *__restrict__ g_b1) {
+                                                          float *__restrict__ g_w1, float *__restrict__ g_b1, int nch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u8 *fr = smem;                                                           // [88][88]
     int *poff = reinterpret_cast<int *>(smem + kC1Frame);                    // [per]
@@ -456,11 +456,24 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
     float *red = sy + (size_t)per * 32;                                      // [2][16][64]
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
     const i64 b = blockIdx.x;
-    const int c = blockIdx.y / kC1Chunks, half = blockIdx.y % kC1Chunks;  // (`half`: the pixel chunk)
+    const int c = blockIdx.y / nch, half = blockIdx.y % nch;  // (`half`: the pixel chunk)
     const int M = OH * OW, p_lo = half * per, cnt = (p_lo + per < M ? p_lo + per : M) - p_lo;
     {
         const i64 off = frame_off[b * sstride * Wn + c];
         unsigned *dst = reinterpret_cast<unsigned *>(fr);
+        if (W == kC1Pad - 4) {  // the Atari geometry: one (unaligned) dword load per padded dword, the border bytes placed by v_perm_b32 (as k_convnet_fused stages its frames)
+            constexpr int kCols = kC1Pad / 4;
+            for (int idx = t; idx < kC1Pad * kCols; idx += 256) {
+                unsigned o = 0u;
+                if (off >= 0) {
+                    const int r = idx / kCols, d = idx % kCols;
+                    unsigned v;
+                    __builtin_memcpy(&v, base + off + (i64)clampi(r - 3, 0, H - 1) * W + clampi(4 * d - 3, 0, W - 4), 4);
+                    o = __builtin_amdgcn_perm(0u, v, d == 0 ? 0x00000000u : (d == kCols - 1 ? 0x03030201u : 0x03020100u));
+                }
+                dst[idx] = o;
+            }
+        } else
         for (int idx = t; idx < kC1Pad * (kC1Pad / 4); idx += 256) {
             unsigned o = 0u;
             if (off >= 0) {
@@ -486,7 +499,7 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
         if (t < 32) {
             float tot = red[t];
             for (int q = 1; q < 8; q++) tot += red[q * 32 + t];
-            bias_part[((i64)b * kC1Chunks + half) * 32 + t] = tot;
+            __hip_atomic_store(&bias_part[((i64)b * nch + half) * 32 + t], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (write-through: see below)
         }
         __syncthreads();
     }
@@ -509,52 +522,55 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int co = (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout: row = output channel, column = tap
-            part[(((i64)b * kC1Chunks + half) * 32 + co) * K + c * 64 + tt * 32 + i] = acc[r] + red[(tt * 16 + r) * 64 + lane];
+            __hip_atomic_store(&part[(((i64)b * nch + half) * 32 + co) * K + c * 64 + tt * 32 + i], acc[r] + red[(tt * 16 + r) * 64 + lane], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // ---- the reduction over (sample, pixel chunk) inside the launch (round 4: it was a launch of its own, k_reduce_parts -- 4 us of work that cost the update's
     // critical path 17 us beside the actors).  Fixed summation order, the one k_reduce_parts used: the samples in four groups, a group's parts added in (sample,
     // chunk) order by the LAST workgroup of the group to arrive (ticket per frame and group), the four group sums added in order by the last group to finish.
-    // Publication: plain stores -> barrier -> one lane's agent-scope fence -> ticket; the reducer: ticket -> agent-scope fence (this CU's L1 drops what it holds
-    // of other CUs' lines) -> barrier -> plain loads (MI355X_MICROARCH.md, inter-workgroup visibility).  Tickets rewind themselves.
+    // Publication (round 4, second half): the partials are stored WRITE-THROUGH (relaxed agent-scope atomic stores = sc1 stores) -> every wave drains its stores
+    // (s_waitcnt vmcnt(0)) -> barrier -> one lane's relaxed ticket.  No release fence: __threadfence() in each of the 512 workgroups wrote back its XCD's whole L2
+    // and invalidated the CU's L1 every time -- the kernel took 46 us with nothing beside it.  The reducer: ticket -> ONE agent-scope acquire fence (this CU's L1
+    // drops what it holds of other CUs' lines) -> barrier -> plain loads (cdna_hip_programming.md, in-launch split-K reduction).  Tickets rewind themselves.
     const int B = gridDim.x, K = Wn * 64;
     const int gs = (B + 3) / 4, g = (int)b / gs, ng = (B + gs - 1) / gs;
     const int b_lo = g * gs, b_hi = b_lo + gs < B ? b_lo + gs : B;
     __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) {
-        __threadfence();
-        s_last = atomicAdd(&tickets[c * 5 + g], 1u) == (unsigned)((b_hi - b_lo) * kC1Chunks) - 1u;
-    }
+    if (t == 0) s_last = __hip_atomic_fetch_add(&tickets[c * 5 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)((b_hi - b_lo) * nch) - 1u;
     __syncthreads();
     if (!s_last) return;
-    if (t == 0) __threadfence();
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     float4 *gp = reinterpret_cast<float4 *>(gpart + ((i64)c * 4 + g) * (32 * 64 + 32));
     for (int q = t; q < 32 * 16; q += 256) {
         const int co = q >> 4, tap4 = (q & 15) * 4;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-        for (int p = b_lo * kC1Chunks; p < b_hi * kC1Chunks; p++) {
+        for (int p = b_lo * nch; p < b_hi * nch; p++) {
             const float4 v = *reinterpret_cast<const float4 *>(part + ((i64)p * 32 + co) * K + c * 64 + tap4);
             sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
         }
-        gp[q] = sum;
+        float *gq = reinterpret_cast<float *>(gp + q);
+        __hip_atomic_store(gq, sum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(gq + 1, sum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gq + 2, sum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(gq + 3, sum.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (c == 0 && t < 32) {
         float bs = 0.f;
-        for (int p = b_lo * kC1Chunks; p < b_hi * kC1Chunks; p++) bs += bias_part[(i64)p * 32 + t];
-        reinterpret_cast<float *>(gp)[32 * 64 + t] = bs;
+        for (int p = b_lo * nch; p < b_hi * nch; p++) bs += bias_part[(i64)p * 32 + t];
+        __hip_atomic_store(reinterpret_cast<float *>(gp) + 32 * 64 + t, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
-        tickets[c * 5 + g] = 0u;
-        __threadfence();
-        s_last = atomicAdd(&tickets[c * 5 + 4], 1u) == (unsigned)ng - 1u;
+        __hip_atomic_store(&tickets[c * 5 + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = __hip_atomic_fetch_add(&tickets[c * 5 + 4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ng - 1u;
     }
     __syncthreads();
     if (!s_last) return;
-    if (t == 0) __threadfence();
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     const float *g0 = gpart + (i64)c * 4 * (32 * 64 + 32);
     for (int q = t; q < 32 * 16; q += 256) {
@@ -571,7 +587,7 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
         for (int k = 1; k < ng; k++) bs += g0[(i64)k * (32 * 64 + 32) + 32 * 64 + t];
         g_b1[t] = bs;
     }
-    if (t == 0) tickets[c * 5 + 4] = 0u;
+    if (t == 0) __hip_atomic_store(&tickets[c * 5 + 4], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -736,14 +752,16 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     SRLX_HIP(hipEventRecord(h->ev_join, sd));
     // conv1's weight gradient needs the END of the data-gradient chain: it follows it on the caller's stream instead of queueing behind
     // the conv2 / conv3 weight gradients on the side stream
-    // output pixels per chunk, even (the MFMA consumes pixel pairs); four chunks keep the workgroup's LDS (31 KB for 84 x 84 frames) under the
-    // 33 KB a CU has left beside one of the actors' convolution workgroups -- with two (45 KB) the kernel took 65 us in the loop, 20 alone
-    const int per = ((h->OH1 * h->OW1 + kC1Chunks - 1) / kC1Chunks + 1) & ~1;
+    // output pixels per chunk, even (the MFMA consumes pixel pairs).  Two chunks per (sample, frame) (45 KB of LDS; SRLX_C1_CHUNKS): in round 2 four kept the
+    // workgroup under the 33 KB a CU had left beside one of the actors' convolution workgroups; those now leave 4 KB, so neither co-resides, and two halve the
+    // partial tensors the in-launch reduction reads
+    static const int c1_chunks = getenv("SRLX_C1_CHUNKS") && atoi(getenv("SRLX_C1_CHUNKS")) >= 1 && atoi(getenv("SRLX_C1_CHUNKS")) <= kC1Chunks ? atoi(getenv("SRLX_C1_CHUNKS")) : 2;
+    const int per = ((h->OH1 * h->OW1 + c1_chunks - 1) / c1_chunks + 1) & ~1;
     const size_t lds = (size_t)kC1Frame + (size_t)per * 4 + (size_t)per * 32 * sizeof(float) + 2 * 16 * 64 * sizeof(float);
     SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
     float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
-    hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(kC1Chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
-                       h->dact1, c1_part, c1_bias, h->c1_gpart, h->c1_cnt, g_w1, g_b1);  // (reduces its own partial sums: no k_reduce_parts launch behind it)
+    hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(c1_chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
+                       h->dact1, c1_part, c1_bias, h->c1_gpart, h->c1_cnt, g_w1, g_b1, c1_chunks);  // (reduces its own partial sums: no k_reduce_parts launch behind it)
     SRLX_STAMP(20, st);
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     if (fc1_adam && fc1_order == 2) SRLX_HIP(hipStreamWaitEvent(st, h->ev_join2, 0));

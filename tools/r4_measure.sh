@@ -4,7 +4,8 @@
 #   2. FETCH_SIZE / WRITE_SIZE (two SEPARATE --pmc passes, kernel-trace only) of tools/actor_pass_probe.py:
 #      the actors' policy pass exactly as the engine launches it     -> r4_pmc_traffic.json (keys: k_convnet_fused, fc1 = k_fc1_planes_h, k_head)
 #   3. kernel-trace + stats of the bulk PER probe                    -> r4_per_kernel_stats.csv
-#   4. the plain bench line (no profiler), LAST so that it reads the PMC file of step 2 -> r4_bench.json
+#   4. the plain bench line (no profiler), after step 2 so that it reads that PMC file -> r4_bench.json
+#   5. the other bench lines, replay-determinism checks, phase clocks, free-running lock-step phases, the update's timeline alone, SQ counters, PER counters, A57 kernel stats
 # Kernels are matched by PREFIX (k_convnet_fused<true = the chip-filling instantiation whatever its further template arguments).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
@@ -55,7 +56,11 @@ timeout 300 python tools/ppo_replay_bisect.py 2>&1 | grep -v amdgpu > gpurun_out
 python tools/fused_phases.py 2>&1 | tail -10 > gpurun_out/r4_fused_phases.txt; cat gpurun_out/r4_fused_phases.txt
 (python tools/qnet_accuracy.py; SRLX_CONV1_F32=1 SRLX_CONV23_F32=1 SRLX_FC1_F32=1 python tools/qnet_accuracy.py) 2>&1 | grep -v amdgpu > gpurun_out/r4_qnet_accuracy.txt; cat gpurun_out/r4_qnet_accuracy.txt
 bash tools/_trace_loop.sh > gpurun_out/r4_loop_timeline.txt 2>&1; head -3 gpurun_out/r4_loop_timeline.txt
-python tools/lockstep_phases.py 2>&1 | grep -v amdgpu | tail -7 > gpurun_out/r4_lockstep_phases.txt; cat gpurun_out/r4_lockstep_phases.txt
+# where a lock-step's time goes in the FREE-RUNNING loop (stamp kernels on the actors' stream; with SRLX_BACKWARD_STAMPS=1 also inside the update's graph), as bench.py runs it
+SRLX_ACTOR_STREAM=low python tools/freerun_phases.py 2>&1 | grep -v amdgpu | tail -6 > gpurun_out/r4_freerun_phases.txt; cat gpurun_out/r4_freerun_phases.txt
+SRLX_ACTOR_STREAM=low SRLX_BACKWARD_STAMPS=1 python tools/freerun_phases.py 2>&1 | grep "free-running" > gpurun_out/r4_freerun_update_phases.txt; cat gpurun_out/r4_freerun_update_phases.txt
+bash tools/_trace_learner_fast.sh > gpurun_out/r4_learner_alone_timeline.txt 2>&1; head -2 gpurun_out/r4_learner_alone_timeline.txt
+bash tools/_pmc_conv.sh 2>&1 | grep "^conv\|^fc1\|^head" > gpurun_out/r4_pmc_sq_counters.txt; head -2 gpurun_out/r4_pmc_sq_counters.txt
 bash tools/_pmc_per.sh > gpurun_out/r4_per_pmc.txt 2>&1; tail -6 gpurun_out/r4_per_pmc.txt
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/profa
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profa -- python $R/bench.py --algo agent57_light --envs 1024 --capacity 200000 --steps 4 --inner 16 --warmup 1 > /dev/null 2>&1

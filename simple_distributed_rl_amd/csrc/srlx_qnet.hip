@@ -494,6 +494,26 @@ __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial,
         const float *p = partial + m * N1 + u;
         const i64 ss = M * N1;
         int s = 0;
+        if (splits > 8 && splits <= 32) {
+            // the learner's 96 / 128-row launches (31 splits): all 62 loads in flight at once instead of four dependent rounds of sixteen; the same sums in the same
+            // order (chain q takes splits q, q + 8, q + 16, q + 24; an absent split adds +0.f, which changes no float that came out of an addition with +0.f)
+            float pv[32], pa[32];
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                pv[q] = q < splits ? p[q * ss] : 0.f;
+                pa[q] = q < splits ? p[q * ss + hidden] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    if (8 * r + q < splits) {
+                        v8[q] += pv[8 * r + q];
+                        a8[q] += pa[8 * r + q];
+                    }
+                }
+            s = splits;
+        }
         for (; s + 8 <= splits; s += 8)
 #pragma unroll
             for (int q = 0; q < 8; q++) {

@@ -523,7 +523,8 @@ int srlx_qnet_set_priority_sink(srlx_qnet_t *h, srlx_per_t *per, int64_t n, cons
 int srlx_qnet_set_td_event(srlx_qnet_t *h, void *event);
 /* Measurement aid (tools/lockstep_phases.py): with a buffer set, every backward pass launches srlx_debug_stamp at fixed points -- d_buf[16] head kernel done,
  * [17] first dense layer's data gradient, [18] conv3's data gradient + fold, [19] conv2's data gradient + fold, [20] conv1's weight gradient (caller's stream);
- * [21] priority sink, [22] conv3's weight gradient + reduction, [23] conv2's, [24] the first dense layer's (weight-gradient branch).  NULL: none (production). */
+ * [21] priority sink, [22] conv3's weight gradient + reduction, [23] conv2's, [24] the first dense layer's (weight-gradient branch); every forward pass of the
+ * handle: [10] convolutions, [11] first dense layer, [12] head.  NULL: none (production). */
 int srlx_qnet_set_stamp_buffer(srlx_qnet_t *h, uint64_t *d_buf);
 /* Where a backward pass launches the first dense layer's Adam-fused weight gradient (the update's largest kernel: 240 MB): 0 = last on the weight-gradient
  * branch (default), 1 = first on it, 2 = on a branch of its own as soon as the data gradient has read the weights.  2 makes a captured update three

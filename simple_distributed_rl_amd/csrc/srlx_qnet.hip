@@ -759,10 +759,12 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     }
     if (h->probe_fc1) SRLX_HIP(hipEventRecord(h->probe_fc1, st));
     h->probe_fc0 = h->probe_fc1 = nullptr;  // one forward only
+    if (h->stamp_buf) SRLX_TRY(srlx_debug_stamp(h->stamp_buf, 11, st));  // (measurement aid: the first dense layer's launch is done)
     // small launches (the learner's 128 / 96 rows) are one workgroup per row and far from filling the chip: twice the threads per row
     hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(B <= 256 && h->hidden > 256 ? 512 : 256), 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
                        h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, h->sig[0] ? h->d_draw : nullptr, h->pol);
     h->pol = srlx_qnet::Policy{};  // one forward only
+    if (h->stamp_buf) SRLX_TRY(srlx_debug_stamp(h->stamp_buf, 12, st));  // (... and the head)
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

@@ -344,7 +344,8 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
                                                                 float *__restrict__ act3,
                                                                 float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg,
-                                                                unsigned char *__restrict__ planes_out = nullptr, long long plane_rows = 0, long long n_samples = 0) {
+                                                                unsigned char *__restrict__ planes_out = nullptr, long long plane_rows = 0, long long n_samples = 0,
+                                                                long long first_sample = 0) {
     static_assert(!PLANES || C23B16, "operand planes come out of the split-bf16 conv3 only");
     static_assert(!C23B16 || C1B16, "the split-bf16 conv2 / conv3 read the part planes conv1's split-bf16 epilogue writes");
     constexpr bool PL = C23B16;  // act1 / act2 as bf16 part planes in LDS (kPB1 / kPB2 bytes per pixel) instead of float32
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     unsigned char *a1p = smem + kOffA1P, *a2p = smem;              // [441][kPB1], [121][kPB2] (plane layout; act2 overlays the frames and conv1's filters)
     int t = threadIdx.x;
     const int wave = t >> 6;
-    i64 b = blockIdx.x;
+    i64 b = (i64)blockIdx.x + first_sample;  // (a chip-filling pass may come as several launches of consecutive samples: srlx_qnet_fused_convs)
     constexpr int H = 84, W = 84, NT = 64 * kWaves;
     auto stamp = [&](int k) {  // phase timestamps of every wave of workgroup 0 (tools/fused_phases.py); dbg is NULL in production
         if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime();
@@ -766,9 +767,20 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     static const long long conv_wgs = getenv("SRLX_CONV_WGS") ? atoll(getenv("SRLX_CONV_WGS")) : 0;
     static const bool f32_variants = (getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1') || (getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1');
     const unsigned grid = (unsigned)(batch >= 512 && conv_wgs > 0 && conv_wgs < batch && !f32_variants ? conv_wgs : batch);
+    // (measurement: SRLX_CONV_CHUNKS = n launches of consecutive samples instead of one.  The workgroup dispatcher keeps feeding a RUNNING kernel's pending
+    // workgroups before it looks at another queue, whatever the queues' priorities: the update's first kernels -- one workgroup for the draw, then a convolution
+    // pass that needs whole CUs -- get their first CU when the actors' 1024-workgroup launch, issued 20 us earlier, has dispatched its last round: 137 us instead
+    // of 55 to the end of the update's convolutions (profiles/r4_freerun_update_phases.txt).  Chunking moves that to 117 us and the lock-step by -1.1 % / +0.4 %
+    // on two boxes (2 chunks), worse from 4 up: the chunk boundaries cost the actors what the update gains -- profiles/r4_probe30.log, r4_probe31.log.)
+    static const int conv_chunks = getenv("SRLX_CONV_CHUNKS") && atoi(getenv("SRLX_CONV_CHUNKS")) >= 1 ? atoi(getenv("SRLX_CONV_CHUNKS")) : 1;
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
-                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch);
+        const int nch = (batch >= 512 && grid == (unsigned)batch && conv_chunks > 1) ? conv_chunks : 1;
+        const long long per = (((long long)batch + nch - 1) / nch + 7) / 8 * 8;  // (multiples of 8: the kernel rotates its tile split with the sample index)
+        for (long long f = 0; f < (long long)batch; f += (nch == 1 ? (long long)batch : per)) {
+            const unsigned g = nch == 1 ? grid : (unsigned)((long long)batch - f < per ? (long long)batch - f : per);
+            hipLaunchKernelGGL(kern, dim3(g), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
+                               keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch, f);
+        }
     };
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
     if (h->probe0 && hipEventRecord(h->probe0, st) != hipSuccess) return false;  // measurement hook: exactly this kernel, on its launch stream
@@ -793,5 +805,6 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     else
         c1_f32 ? launch(k_convnet_fused<false, false, false>) : c23_f32 ? launch(k_convnet_fused<false, true, false>) : launch(k_convnet_fused<false, true, true>);
     if (h->probe1 && hipEventRecord(h->probe1, st) != hipSuccess) return false;
+    if (h->stamp_buf && srlx_debug_stamp(h->stamp_buf, 10, st) != SRLX_OK) return false;  // (measurement aid: the convolution launch of a forward pass is done)
     return hipGetLastError() == hipSuccess;
 }

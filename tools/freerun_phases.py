@@ -36,7 +36,7 @@ for k in range(n):
         torch.cuda.synchronize()
         g_ = GST.cpu().tolist()
         t0_ = int(ST[(k - 1) * P].item())
-        bw_rows.append([(g_[i] - t0_) / 100.0 for i in range(16, 25)] + [(int(ST[(k - 1) * P + j].item()) - t0_) / 100.0 for j in (1, 2, 3, 4)])
+        bw_rows.append([(g_[i] - t0_) / 100.0 for i in range(16, 25)] + [(int(ST[(k - 1) * P + j].item()) - t0_) / 100.0 for j in (1, 2, 3, 4)] + [(g_[i] - t0_) / 100.0 for i in (10, 11, 12)])
     mark(b)
     if first:
         eng.fork_point()
@@ -68,7 +68,8 @@ print(f"{'lock-step period':40s} median {per[len(per) // 2]:7.1f} us   (10 % {pe
 if BW:
     nm = ["head backward (TD) end", "fc1 data gradient end", "conv3 data gradient + fold end", "conv2 data gradient + fold end", "conv1 weight gradient end",
           "[branch] priority write-back end", "[branch] conv3 weight gradient end", "[branch] conv2 weight gradient end", "[branch] fc1 weight gradient + Adam end",
-          "ACTORS policy pass + environments end", "ACTORS ring commit end", "ACTORS join passed", "ACTORS add end"]
+          "ACTORS policy pass + environments end", "ACTORS ring commit end", "ACTORS join passed", "ACTORS add end",
+          "online pass: convolutions end", "online pass: first dense layer end", "online pass: head end"]
     for j, x in enumerate(nm):
         v = sorted(r[j] for r in bw_rows)
         print(f"  in the free-running loop: {x:44s} median {v[len(v) // 2]:7.1f} us  ({v[0]:7.1f} .. {v[-1]:7.1f})")

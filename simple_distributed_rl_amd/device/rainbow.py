@@ -264,20 +264,14 @@ class RainbowEngine:
                 self.inf_online.enable_fc1_planes(private_weights=False)
                 self.inf_target.enable_fc1_planes(private_weights=True)
                 self.inf_target.set_planes_small(True, None)
-            # the priority write-back leaves the update's critical path: it needs the head kernel's priorities only, so it runs on the target network's (by then idle)
-            # stream beside the gradient kernels; the step count it used to advance moves to the update's LAST launch (the packing / publishing one)
-            self._update_branch = os.environ.get("SRLX_UPDATE_BRANCH", "0") == "1"
-            # ... what ships instead: the write-back as the FIRST launch of the backward pass's own weight-gradient branch (no new branch in the graph:
-            # srlx_qnet_set_priority_sink); the step count moves to the packing launch as above.  SRLX_UPDATE_SIDE=0: the write-back as the update's last launch.
-            self._update_side = (not self._update_branch) and self._fused_td and os.environ.get("SRLX_UPDATE_SIDE", "1") != "0"
+            # the priority write-back leaves the update's critical path: it needs the head kernel's priorities only, so it is the FIRST launch of the backward pass's
+            # weight-gradient branch (srlx_qnet_set_priority_sink; no new branch in the graph -- as a branch of its own it put the update on the actors' hardware queue:
+            # tools/README.md findings 3, 5); the step count it used to advance moves to the update's LAST launch (the packing / publishing one).
+            # SRLX_UPDATE_SIDE=0: the write-back as the update's last launch.
+            self._update_side = self._fused_td and os.environ.get("SRLX_UPDATE_SIDE", "1") != "0"
             if self.actor_stream is not None and want == "low":  # the actors cannot queue behind a branch of the update: it may run three wide
                 N.check(self.lib.srlx_qnet_set_fc1_branch(self.inf_online.h, 2))
             if self._update_side:
-                N.check(self.lib.srlx_per_set_update_counter(self.replay.h_per, None))
-            if self._update_branch:
-                self._ev_td, self._ev_upd = torch.cuda.Event(), torch.cuda.Event()
-                self._ev_td.record()
-                self.inf_online.set_td_event(self._ev_td)
                 N.check(self.lib.srlx_per_set_update_counter(self.replay.h_per, None))
             self.replay.enable_deferred_advance()
             self._publish_out_of_band()
@@ -511,20 +505,12 @@ class RainbowEngine:
                     )
                 )
                 self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
-            if self.fast and self._update_branch:  # priorities -> tree, beside the gradient kernels (srlx_qnet_set_td_event)
-                self.s_target.wait_event(self._ev_td)
-                with torch.cuda.stream(self.s_target):
-                    r.update(b.indices, self.priorities)  # model_torch.py:113-114
-                    self._ev_upd.record(self.s_target)
             mark(4)
             self.optimizer.step(self.train_count_dev)
             mark(5)
             if self.fast:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors); train_count_dev += 1
                 self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0,
-                                           bump=self.train_count_dev if (self._update_branch or self._update_side) else None)
-                if self._update_branch:
-                    cur.wait_event(self._ev_upd)
-                    return
+                                           bump=self.train_count_dev if self._update_side else None)
                 mark(6)
                 if self._update_side:
                     return

@@ -12,6 +12,5 @@ one SRLX_FC1_NEIGHBOUR=8
 one SRLX_FC1_NEIGHBOUR=2
 one GPU_MAX_HW_QUEUES=4
 one GPU_MAX_HW_QUEUES=1
-one SRLX_UPDATE_BRANCH=1
 done
 } 2>&1 | tee gpurun_out/r4_probe23.log

@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int
 __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, i64 sstride, int Wn, int H, int W,
                                                           int OH, int OW, int per, const float *__restrict__ dY1, float *__restrict__ part,
                                                           float *__restrict__ bias_part, float *__restrict__ gpart, unsigned *__restrict__ tickets,
-                                                          float *__restrict__ g_w1, float *__restrict__ g_b1, int nch) {
+                                                          float *__restrict__ g_w1, float *__restrict__ g_b1, int nch, int in_launch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u8 *fr = smem;                                                           // [88][88]
     int *poff = reinterpret_cast<int *>(smem + kC1Frame);                    // [per]
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
         if (t < 32) {
             float tot = red[t];
             for (int q = 1; q < 8; q++) tot += red[q * 32 + t];
-            __hip_atomic_store(&bias_part[((i64)b * nch + half) * 32 + t], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (write-through: see below)
+            bias_part[((i64)b * nch + half) * 32 + t] = tot;
         }
         __syncthreads();
     }
@@ -522,24 +522,29 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int co = (r & 3) + 8 * (r >> 2) + 4 * h;  // C/D layout: row = output channel, column = tap
-            __hip_atomic_store(&part[(((i64)b * nch + half) * 32 + co) * K + c * 64 + tt * 32 + i], acc[r] + red[(tt * 16 + r) * 64 + lane], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            part[(((i64)b * nch + half) * 32 + co) * K + c * 64 + tt * 32 + i] = acc[r] + red[(tt * 16 + r) * 64 + lane];
         }
     }
     // ---- the reduction over (sample, pixel chunk) inside the launch (round 4: it was a launch of its own, k_reduce_parts -- 4 us of work that cost the update's
     // critical path 17 us beside the actors).  Fixed summation order, the one k_reduce_parts used: the samples in four groups, a group's parts added in (sample,
     // chunk) order by the LAST workgroup of the group to arrive (ticket per frame and group), the four group sums added in order by the last group to finish.
-    // Publication (round 4, second half): the partials are stored WRITE-THROUGH (relaxed agent-scope atomic stores = sc1 stores) -> every wave drains its stores
-    // (s_waitcnt vmcnt(0)) -> barrier -> one lane's relaxed ticket.  No release fence: __threadfence() in each of the 512 workgroups wrote back its XCD's whole L2
-    // and invalidated the CU's L1 every time -- the kernel took 46 us with nothing beside it.  The reducer: ticket -> ONE agent-scope acquire fence (this CU's L1
+    // Publication (cdna_hip_programming.md, in-launch split-K reduction): plain stores -> every wave drains its stores (s_waitcnt vmcnt(0)) -> barrier -> ONE lane's
+    // agent-scope RELEASE fence (+ the restated wait) -> relaxed ticket; the reducer: ticket -> one agent-scope ACQUIRE fence -> barrier -> plain loads.  (Round 4
+    // tried write-through sc1 stores without a release: 16 us faster and stale partial sums in about one run of six -- the write-throughs are not what a later
+    // buffer_wbl2 waits for; __threadfence(), release AND acquire in every workgroup, is what the first version used.)  The reducer: ticket -> ONE agent-scope acquire fence (this CU's L1
     // drops what it holds of other CUs' lines) -> barrier -> plain loads (cdna_hip_programming.md, in-launch split-K reduction).  Tickets rewind themselves.
+    if (!in_launch) return;  // the partial sums are added up by a k_reduce_parts launch behind this one (conv_chain)
     const int B = gridDim.x, K = Wn * 64;
     const int gs = (B + 3) / 4, g = (int)b / gs, ng = (B + gs - 1) / gs;
     const int b_lo = g * gs, b_hi = b_lo + gs < B ? b_lo + gs : B;
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) s_last = __hip_atomic_fetch_add(&tickets[c * 5 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)((b_hi - b_lo) * nch) - 1u;
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(&tickets[c * 5 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)((b_hi - b_lo) * nch) - 1u;
+    }
     __syncthreads();
     if (!s_last) return;
     if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -553,19 +558,19 @@ __global__ void __launch_bounds__(256) k_conv1_wgrad_mfma(const u8 *__restrict__
             const float4 v = *reinterpret_cast<const float4 *>(part + ((i64)p * 32 + co) * K + c * 64 + tap4);
             sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
         }
-        float *gq = reinterpret_cast<float *>(gp + q);
-        __hip_atomic_store(gq, sum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(gq + 1, sum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(gq + 2, sum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(gq + 3, sum.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gp[q] = sum;
     }
     if (c == 0 && t < 32) {
         float bs = 0.f;
         for (int p = b_lo * nch; p < b_hi * nch; p++) bs += bias_part[(i64)p * 32 + t];
-        __hip_atomic_store(reinterpret_cast<float *>(gp) + 32 * 64 + t, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<float *>(gp)[32 * 64 + t] = bs;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
         __hip_atomic_store(&tickets[c * 5 + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s_last = __hip_atomic_fetch_add(&tickets[c * 5 + 4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ng - 1u;
     }
     __syncthreads();
@@ -756,12 +761,19 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     // workgroup under the 33 KB a CU had left beside one of the actors' convolution workgroups; those now leave 4 KB, so neither co-resides, and two halve the
     // partial tensors the in-launch reduction reads
     static const int c1_chunks = getenv("SRLX_C1_CHUNKS") && atoi(getenv("SRLX_C1_CHUNKS")) >= 1 && atoi(getenv("SRLX_C1_CHUNKS")) <= kC1Chunks ? atoi(getenv("SRLX_C1_CHUNKS")) : 2;
+    // conv1's partial sums are added up by a k_reduce_parts launch behind the kernel; SRLX_C1_REDUCE=in_launch: by its last workgroups (tickets) -- the same sums
+    // in the same order.  The in-launch form was this round's first version (-1 launch); with two chunks per (sample, frame) the separate launch is 1.6 % faster
+    // per lock-step (profiles/r4_probe32.log): 64 partial tensors per frame are more than a last-arriver should read alone.
+    static const bool c1_in_launch = getenv("SRLX_C1_REDUCE") && !strcmp(getenv("SRLX_C1_REDUCE"), "in_launch");
     const int per = ((h->OH1 * h->OW1 + c1_chunks - 1) / c1_chunks + 1) & ~1;
     const size_t lds = (size_t)kC1Frame + (size_t)per * 4 + (size_t)per * 32 * sizeof(float) + 2 * 16 * 64 * sizeof(float);
     SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);
     float *c1_part = h->w_part + kWgSplits * (c3 > c2 ? c3 : c2), *c1_bias = bias_part + 2 * kWgSplits * 64;  // its own scratch: runs beside conv2's reduction
     hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(c1_chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
-                       h->dact1, c1_part, c1_bias, h->c1_gpart, h->c1_cnt, g_w1, g_b1, c1_chunks);  // (reduces its own partial sums: no k_reduce_parts launch behind it)
+                       h->dact1, c1_part, c1_bias, h->c1_gpart, h->c1_cnt, g_w1, g_b1, c1_chunks, c1_in_launch ? 1 : 0);
+    if (!c1_in_launch)  // the same sums in the same order (four slices of consecutive partial tensors, then ((s0 + s1) + s2) + s3), behind a kernel boundary
+        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, st, c1_part, B * c1_chunks, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32,
+                           g_b1);  // (reduces its own partial sums: no k_reduce_parts launch behind it)
     SRLX_STAMP(20, st);
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     if (fc1_adam && fc1_order == 2) SRLX_HIP(hipStreamWaitEvent(st, h->ev_join2, 0));

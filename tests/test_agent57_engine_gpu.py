@@ -218,8 +218,17 @@ def _engine84(batch=16, E=16, seed=3):
 
 def test_trainable_trunk_gradients_equal_autograd():
     """device/qnet.py:TrainableImageTrunk -- the image block's forward AND backward in libsrlx (srlx_qnet_backward_convs_u8) -- against autograd through the
-    torch image block on the float32 stack of the same frames: features 1e-5, all six gradients 2e-4 relative to their largest element, with gradient on
-    every row (stride 1) and on every second row only (stride 2: the online Q-network's s_0 / s_1 pass)."""
+    SAME torch image block evaluated in float64 on the CPU, on the float32 stack of the same frames: features and all six gradients 1e-5 relative to their
+    largest element, with gradient on every row (stride 1) and on every second row only (stride 2: the online Q-network's s_0 / s_1 pass).
+    (The yardstick used to be autograd on the GPU, i.e. MIOpen's float32 convolution backward, at 2e-4: in about one fresh process of eight MIOpen's own
+    gradients were off by 4e-4 .. 1.4e-2 of their largest element against float64 while libsrlx's stayed at 3e-7 .. 9e-7 -- tools/_flaky_trunk.py.)
+    The networks are initialised from torch's global generator: seeded here, because a comparison of ReLU networks across precisions is only as tight as
+    its closest-to-zero activation -- about one random initialisation in fifty puts a conv3 output within float32 rounding of zero, the two evaluations
+    then disagree on that element's mask and every gradient moves by ~1e-3 of its largest element (reproducibly for that network; features still 3e-7)."""
+    import copy
+
+    torch.manual_seed(7)
+
     eng, cfg = _engine84()
     for _ in range(8):
         eng.step(learner_updates=0)
@@ -245,18 +254,20 @@ def test_trainable_trunk_gradients_equal_autograd():
         R = torch.randn((2 * B, trunk.channels * trunk.pixels), device="cuda", generator=g)
         if stride == 2:
             R[1::2] = 0  # rows without gradient
-        for p in params:
-            p.grad = None
-        want_f = net.in_block(stack, channels_first=True)
-        (want_f * R).sum().backward()
-        want = [p.grad.clone() for p in params]
+        blk64 = copy.deepcopy(net.in_block).double().cpu()
+        for q in blk64.parameters():
+            q.grad = None
+        want_f = blk64(stack.double().cpu(), channels_first=True)
+        (want_f * R.double().cpu()).sum().backward()
+        want = [t for c in [m for m in blk64.modules() if isinstance(m, torch.nn.Conv2d)] for t in (c.weight.grad, c.bias.grad)]
+        assert len(want) == len(params) and all(w.shape == p.shape for w, p in zip(want, params))
         for p in params:
             p.grad = None
         got_f = trunk.features(rp.obs_base, off01, stride)
-        torch.testing.assert_close(got_f, want_f, rtol=1e-5, atol=1e-5 * float(want_f.abs().max()))
+        torch.testing.assert_close(got_f.double().cpu(), want_f.detach(), rtol=1e-5, atol=1e-5 * float(want_f.abs().max()))
         (got_f * R).sum().backward()
         for p, w in zip(params, want):
-            torch.testing.assert_close(p.grad, w, rtol=2e-4, atol=2e-4 * float(w.abs().max()))
+            torch.testing.assert_close(p.grad.double().cpu(), w, rtol=1e-5, atol=1e-5 * float(w.abs().max()))
 
 
 def test_hand_written_learner_equals_the_torch_learner_and_is_reproducible():

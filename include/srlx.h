@@ -526,14 +526,6 @@ int srlx_qnet_set_td_event(srlx_qnet_t *h, void *event);
  * [21] priority sink, [22] conv3's weight gradient + reduction, [23] conv2's, [24] the first dense layer's (weight-gradient branch); every forward pass of the
  * handle: [10] convolutions, [11] first dense layer, [12] head.  NULL: none (production). */
 int srlx_qnet_set_stamp_buffer(srlx_qnet_t *h, uint64_t *d_buf);
-/* optimizer.step() (model_torch.py:109) for the tensors of h_src's network given here (every bound parameter but the first dense layer's weight when that is
- * fused into the backward pass: srlx_qnet_fuse_adam_fc1) AND srlx_qnet_publish(h_src, h_actor, set, with_fc1 = 0, d_bump) with the NEW values, as ONE launch:
- * the thread that updates a parameter also writes its places in the packed filter layouts, the transposed filters and the actors' small-vector block.
- * Same arguments as srlx_adam_step / srlx_qnet_publish; the three convolution filters must be among the tensors; d_bump (may equal d_step) is advanced by
- * the launch's last block.  Results are bit-identical to srlx_adam_step followed by srlx_qnet_publish. */
-int srlx_qnet_adam_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int n_tensors, float *const *d_params, const float *const *d_grads, float *const *d_exp_avg,
-                           float *const *d_exp_avg_sq, const int64_t *numels, double lr, double beta1, double beta2, double eps, const int64_t *d_step, int64_t *d_bump,
-                           void *stream);
 /* Where a backward pass launches the first dense layer's Adam-fused weight gradient (the update's largest kernel: 240 MB): 0 = last on the weight-gradient
  * branch (default), 1 = first on it, 2 = on a branch of its own as soon as the data gradient has read the weights.  2 makes a captured update three
  * branches wide: use it only with the actors on a stream of another priority level (srlx_stream_create). */

@@ -101,7 +101,6 @@ SIGNATURES = {
     "srlx_stream_create": (c_int, [c_int, ctypes.POINTER(c_p)]),
     "srlx_stream_destroy": (c_int, [c_p]),
     "srlx_qnet_set_fc1_branch": (c_int, [c_p, c_int]),
-    "srlx_qnet_adam_publish": (c_int, [c_p, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p]),
     "srlx_qnet_set_stamp_buffer": (c_int, [c_p, c_p]),
     "srlx_qnet_set_td_event": (c_int, [c_p, c_p]),
     "srlx_qnet_set_priority_sink": (c_int, [c_p, c_p, c_i64, c_p, c_p, c_int]),

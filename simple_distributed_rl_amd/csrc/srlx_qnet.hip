@@ -1029,28 +1029,6 @@ int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int wit
     return SRLX_OK;
 }
 
-int srlx_qnet_adam_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int n_tensors, float *const *d_params, const float *const *d_grads, float *const *d_exp_avg,
-                           float *const *d_exp_avg_sq, const int64_t *numels, double lr, double beta1, double beta2, double eps, const int64_t *d_step, int64_t *d_bump,
-                           void *stream) {
-    SRLX_REQUIRE(h_src && h_src->bound[0], "qnet_adam_publish: no parameters bound on the source handle");
-    SRLX_REQUIRE(!h_src->eff[0], "qnet_adam_publish: NoisyLinear source");
-    SRLX_REQUIRE(h_src->H == 84 && h_src->W == 84 && h_src->Wn == 4 && h_src->F1 == 32, "qnet_adam_publish: the fused convolution kernel's geometry only");
-    SRLX_REQUIRE(d_params && d_grads && d_exp_avg && d_exp_avg_sq && numels && d_step, "qnet_adam_publish: NULL argument");
-    srlx::DeviceGuard guard(h_src->device);
-    hipStream_t st = (hipStream_t)stream;
-    if (!h_actor) {
-        SRLX_TRY(srlx_qnet_adam_pack_publish(h_src, nullptr, nullptr, n_tensors, d_params, d_grads, d_exp_avg, d_exp_avg_sq, numels, lr, beta1, beta2, eps, d_step, d_bump, st));
-        h_src->pack_valid = true;
-        return SRLX_OK;
-    }
-    SRLX_REQUIRE((set == 0 || set == 1) && h_actor->aset[set].wpack, "qnet_adam_publish: srlx_qnet_actor_sets_enable on the actor handle first");
-    SRLX_REQUIRE(h_actor->hidden == h_src->hidden && h_actor->A == h_src->A && h_actor->flat == h_src->flat, "qnet_adam_publish: the two handles describe different networks");
-    const srlx_small_layout L = srlx_small_offsets(h_actor);
-    SRLX_TRY(srlx_qnet_adam_pack_publish(h_src, &h_actor->aset[set], &L, n_tensors, d_params, d_grads, d_exp_avg, d_exp_avg_sq, numels, lr, beta1, beta2, eps, d_step, d_bump, st));
-    if (h_src->aset_cur < 0) h_src->pack_valid = true;
-    return SRLX_OK;
-}
-
 // splits > 0: the chip-filling first-dense-layer launches of this handle (operand planes) use half-CU workgroups (k_fc1_planes_h) with `splits` K splits -- for a
 // handle whose passes run BESIDE a learner; 0: the CU-filling k_fc1_planes (fastest alone).
 int srlx_qnet_set_fc1_neighbour(srlx_qnet_t *h, int splits) {

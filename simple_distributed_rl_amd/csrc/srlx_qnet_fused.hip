@@ -15,7 +15,6 @@
 // tile per wave, conv1 14 pixel tiles over the 8 waves.  Pixel strides 36 / 68 floats spread the 16-lane groups of a
 // ds_read_b128 over the 64 banks.  With `act1_out` / `act2_out` the activations are ALSO written to HBM for the backward
 // pass of a training forward.
-#include "srlx_adam_math.h"
 #include "srlx_qnet_int.h"
 
 namespace {
@@ -163,104 +162,6 @@ __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ 
     const float4 val = *reinterpret_cast<const float4 *>(src + (i64)(nt * 32 + i) * K + slab * 32 + 16 * hh + 4 * v);
     reinterpret_cast<float4 *>(out)[q] = val;
     if (out2) reinterpret_cast<float4 *>(out2)[q] = val;
-}
-
-// ---- Adam + packing + publishing in ONE launch (round 4) ---------------------------------------------------------------------------------
-// The update's last two launches were k_adam (the eleven small tensors) and k_pack_filters (the new convolution filters in the three layouts of the fused
-// kernel, the transposed filters of the next backward pass, the actors' copy of all of it and of the small vectors): two launches + a boundary on a tail
-// nothing else runs beside.  Every packed value depends on exactly ONE parameter, so the thread that updates a parameter also writes its packed places
-// (the inverse of k_pack_filters' index maps; the same splitting arithmetic): same bits, one launch.
-constexpr int kApMax = 16, kApChunk = 4096;
-struct AdamPackTable {
-    float *p[kApMax];
-    const float *g[kApMax];
-    float *m[kApMax];
-    float *v[kApMax];
-    i64 n[kApMax];
-    int chunk_start[kApMax + 1];
-    int kind[kApMax];  // 0: plain Adam; 1 / 2 / 3: conv1 / conv2 / conv3 filters; 4 + k: small vector k (b1 b2 b3 bf v2w v2b a2w a2b)
-    int n_tensors;
-};
-struct PackDst {
-    float *out, *out2;   // packed buffers (own / the actors' set or NULL)
-    float *wT3, *wT2;    // transposed filters of the data-gradient GEMMs (training handles) or NULL
-    float *small;        // the actors' small-vector block or NULL
-    int small_off[8];
-    long long *bump;     // int64 device counter advanced by the launch (the update's step count -- the SAME scalar every block reads for its Adam coefficients:
-    unsigned *ticket;    // it is advanced by the LAST block to finish, found through this self-resetting ticket)
-};
-__device__ __forceinline__ void pack_scatter(int kind, i64 e, float pnew, const PackDst &d) {
-    if (kind >= 4) {
-        if (d.small) d.small[d.small_off[kind - 4] + e] = pnew;
-        return;
-    }
-    const int K = kind == 1 ? 256 : (kind == 2 ? 512 : 576), tiles = kind == 1 ? 1 : 2;
-    const int base_f = kind == 1 ? 0 : (kind == 2 ? kW1 : kW1 + kW2);
-    const int n = (int)(e / K), k = (int)(e % K), nt = n >> 5, i = n & 31;
-    {   // float32 fragment order (k_pack_filters' last branch): [slab * tiles + nt][v][lane][4]
-        const int slab = k >> 5, hh = (k >> 4) & 1, vv = (k >> 2) & 3, ee = k & 3;
-        const int idx = base_f + ((((slab * tiles + nt) << 2 | vv) << 6) | (hh << 5 | i)) * 4 + ee;
-        d.out[idx] = pnew;
-        if (d.out2) d.out2[idx] = pnew;
-    }
-    {   // split-bf16 fragments: [step][(n-tile)][part][lane] x 8 bf16; conv1's filters carry the 1 / 255 of the pixel scale
-        float r = kind == 1 ? pnew * (1.0f / 255.0f) : pnew;
-        const int step = k >> 4, h8 = (k >> 3) & 1, j = k & 7, lane = h8 * 32 + i;
-        const int vbase = kind == 1 ? step * 3 : (step * 2 + nt) * 3;
-        const int fbase = kW1 + kW2 + kW3 + (kind == 1 ? 0 : (kind == 2 ? kW1B : kW1B + kW2B));
-        __bf16 *o1 = reinterpret_cast<__bf16 *>(d.out + fbase), *o2 = d.out2 ? reinterpret_cast<__bf16 *>(d.out2 + fbase) : nullptr;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const __bf16 b = (__bf16)r;
-            r -= (float)b;
-            const int at = ((vbase + t) * 64 + lane) * 8 + j;
-            o1[at] = b;
-            if (o2) o2[at] = b;
-        }
-    }
-    if (kind == 3 && d.wT3) {  // wT[ci][tap * 64 + co] = W[co][tap][ci]
-        const int ci = (int)(e % 64), tap = (int)((e / 64) % 9), co = (int)(e / (64 * 9));
-        d.wT3[ci * 576 + tap * 64 + co] = pnew;
-    } else if (kind == 2 && d.wT2) {  // four parity classes: wT[cls][ci][((ky/2) * 2 + kx/2) * 64 + co]
-        const int ci = (int)(e % 32), tap = (int)((e / 32) % 16), co = (int)(e / (32 * 16));
-        const int ky = tap / 4, kx = tap % 4, cls = (ky % 2) * 2 + (kx % 2);
-        d.wT2[(cls * 32 + ci) * 256 + ((ky / 2) * 2 + kx / 2) * 64 + co] = pnew;
-    }
-}
-__global__ void __launch_bounds__(256) k_adam_pack(AdamPackTable tb, PackDst d, double lr, double beta1, double beta2, double eps, const i64 *d_step) {
-    int ti = 0;
-    while (ti + 1 < tb.n_tensors && (int)blockIdx.x >= tb.chunk_start[ti + 1]) ti++;
-    const i64 off = (i64)((int)blockIdx.x - tb.chunk_start[ti]) * kApChunk;
-    const i64 n = tb.n[ti];
-    float *p = tb.p[ti] + off, *m = tb.m[ti] + off, *v = tb.v[ti] + off;
-    const float *g = tb.g[ti] + off;
-    const i64 left = n - off;
-    const int cnt = left < kApChunk ? (int)left : kApChunk;
-    const int t = threadIdx.x, kind = tb.kind[ti];
-    constexpr int R = kApChunk / 256;
-    float pp[R], mm[R], vv[R], gg[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int k = r * 256 + t;
-        if (k < cnt) pp[r] = p[k], mm[r] = m[k], vv[r] = v[k], gg[r] = g[k];
-    }
-    const srlx::AdamCoef c = srlx::adam_coef(lr, beta1, beta2, eps, *d_step);  // (read BEFORE the bump below could land: the bump is this launch's last store of thread 0)
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int k = r * 256 + t;
-        if (k < cnt) {
-            srlx::adam_one(pp[r], gg[r], mm[r], vv[r], c);
-            p[k] = pp[r], m[k] = mm[r], v[k] = vv[r];
-            if (kind) pack_scatter(kind, off + k, pp[r], d);
-        }
-    }
-    if (d.bump) {
-        __syncthreads();  // every thread of the block has its coefficients
-        if (t == 0 && atomicAdd(d.ticket, 1u) == gridDim.x - 1u) {
-            *d.ticket = 0u;
-            *d.bump += 1;
-        }
-    }
 }
 
 // one 32 (pixels) x 32 (channels) tile of a convolution whose input sits in LDS (pixel-major, `stride` floats per pixel):
@@ -836,57 +737,6 @@ int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const s
     }
     hipLaunchKernelGGL(k_pack_filters, dim3((pack_threads + 255) / 256), dim3(256), 0, st, w1, w2, w3, own, keep ? src->w_t : nullptr, keep ? src->w_t2 : nullptr,
                        dst_set ? dst_set->wpack : nullptr, sm);
-    SRLX_HIP(hipGetLastError());
-    return SRLX_OK;
-}
-
-// Adam step of `n` tensors of `src`'s network (every bound parameter but the first dense layer's weight, which the backward pass updates itself) + what
-// srlx_qnet_pack_publish does with the NEW values, in one launch.  Tensors are recognised by address (src->bound[]); others get a plain Adam step.
-int srlx_qnet_adam_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, int n, float *const *params, const float *const *grads,
-                                float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numels, double lr, double beta1, double beta2, double eps,
-                                const int64_t *d_step, int64_t *bump, hipStream_t st) {
-    SRLX_REQUIRE(n > 0 && n <= kApMax, "qnet_adam_publish: 1..%d tensors", kApMax);
-    float *&own = src->aset_cur >= 0 ? src->wpack_own : src->wpack;
-    if (!own) SRLX_HIP(hipMalloc((void **)&own, (size_t)kPackFloats * sizeof(float)));
-    if (!src->ap_ticket) {
-        SRLX_HIP(hipMalloc((void **)&src->ap_ticket, sizeof(unsigned)));
-        SRLX_HIP(hipMemset(src->ap_ticket, 0, sizeof(unsigned)));
-    }
-    const bool keep = src->max_train > 0;
-    const float *const *b = src->bound;
-    AdamPackTable tb{};
-    tb.n_tensors = n;
-    int chunks = 0, seen = 0;
-    for (int i = 0; i < n; i++) {
-        SRLX_REQUIRE(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i] && numels[i] > 0, "qnet_adam_publish: tensor %d is NULL or empty", i);
-        tb.p[i] = params[i], tb.g[i] = grads[i], tb.m[i] = exp_avg[i], tb.v[i] = exp_avg_sq[i], tb.n[i] = numels[i];
-        const float *q = params[i];
-        int kind = 0;
-        if (q == b[0]) kind = 1;
-        else if (q == b[2]) kind = 2;
-        else if (q == b[4]) kind = 3;
-        else {
-            const int small_of[8] = {1, 3, 5, 7, 8, 9, 10, 11};
-            for (int k = 0; k < 8; k++)
-                if (q == b[small_of[k]]) kind = 4 + k;
-        }
-        if (kind >= 1 && kind <= 3) seen |= 1 << kind;
-        tb.kind[i] = kind;
-        tb.chunk_start[i] = chunks;
-        chunks += (int)((numels[i] + kApChunk - 1) / kApChunk);
-    }
-    tb.chunk_start[n] = chunks;
-    SRLX_REQUIRE(seen == 0xE, "qnet_adam_publish: the table must hold the three convolution filters of the source handle");  // all three convolution filters must be in the table: the packed buffer is rewritten as a whole
-    PackDst d{};
-    d.out = own, d.out2 = dst_set ? dst_set->wpack : nullptr;
-    d.wT3 = keep ? src->w_t : nullptr, d.wT2 = keep ? src->w_t2 : nullptr;
-    d.small = dst_set ? dst_set->small : nullptr;
-    if (dst_set) {
-        const int off[8] = {L->b1, L->b2, L->b3, L->bf, L->v2w, L->v2b, L->a2w, L->a2b};
-        for (int k = 0; k < 8; k++) d.small_off[k] = off[k];
-    }
-    d.bump = (long long *)bump, d.ticket = src->ap_ticket;
-    hipLaunchKernelGGL(k_adam_pack, dim3((unsigned)chunks), dim3(256), 0, st, tb, d, lr, beta1, beta2, eps, (const i64 *)d_step);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

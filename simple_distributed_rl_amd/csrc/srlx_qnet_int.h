@@ -79,7 +79,6 @@ struct srlx_qnet {
     int fc1_order;                        // -1: SRLX_FC1_ORDER decides (default 0); 0 / 1 / 2: srlx_qnet_set_fc1_branch
     hipStream_t side2;
     hipEvent_t ev_join2;
-    unsigned *ap_ticket;                  // self-resetting ticket of the fused Adam + pack launch (srlx_qnet_adam_publish)
     uint64_t *stamp_buf;                  // measurement aid (srlx_qnet_set_stamp_buffer): srlx_debug_stamp launches at fixed points of the backward pass
     hipEvent_t ev_td;                     // caller-owned or NULL: recorded right behind the head kernel of every backward pass (srlx_qnet_set_td_event)
     void *adam_planes_out;                // the fused Adam of the first dense layer ALSO writes the updated weight as operand planes here (NULL: off)
@@ -129,9 +128,6 @@ int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst
 size_t srlx_fc1_planes_weight_bytes(const srlx_qnet *h);
 // srlx_qnet_fused.hip: pack `src`'s convolution filters (its own wpack + transposed filters when it trains) and, with `dst_set`, also into an actor set together
 // with the small vectors
-int srlx_qnet_adam_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, int n, float *const *params, const float *const *grads,
-                                float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numels, double lr, double beta1, double beta2, double eps,
-                                const int64_t *d_step, int64_t *bump, hipStream_t st);
 int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st, int64_t *bump = nullptr);
 size_t srlx_qnet_pack_bytes();
 int srlx_fc1_planes_split_act(srlx_qnet *h, int64_t rows, hipStream_t st);

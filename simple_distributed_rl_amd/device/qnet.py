@@ -553,15 +553,6 @@ class DeviceAdam:
         N.check(self.lib.srlx_adam_step(k, ctypes.cast(self._p, N.c_p), ctypes.cast(self._g, N.c_p), ctypes.cast(self._m, N.c_p), ctypes.cast(self._v, N.c_p),
                                         ctypes.cast(self._n, N.c_p), self.lr, self.betas[0], self.betas[1], self.eps, N.tptr(steps_taken_dev), N.torch_stream_ptr()))
 
-    def step_publish(self, steps_taken_dev: torch.Tensor, src: "QNetInference", actor: "QNetInference" = None, k: int = 0, bump: torch.Tensor = None):
-        """step() AND src.publish_to(actor, k, bump=bump) as ONE launch (srlx_qnet_adam_publish): the thread that updates a parameter also writes its places in
-        the packed filter layouts / the actors' set.  Bit-identical to the two calls."""
-        assert self._fused is None or steps_taken_dev.data_ptr() == self._fused_steps.data_ptr()
-        n = len(self._idx)
-        N.check(self.lib.srlx_qnet_adam_publish(src.h, actor.h if actor is not None else None, int(k), n, ctypes.cast(self._p, N.c_p), ctypes.cast(self._g, N.c_p),
-                                                ctypes.cast(self._m, N.c_p), ctypes.cast(self._v, N.c_p), ctypes.cast(self._n, N.c_p), self.lr, self.betas[0], self.betas[1],
-                                                self.eps, N.tptr(steps_taken_dev), N.tptr(bump), N.torch_stream_ptr()))
-
     def state_dict(self):
         return {"exp_avg": [t.clone() for t in self.exp_avg], "exp_avg_sq": [t.clone() for t in self.exp_avg_sq]}
 

@@ -275,7 +275,6 @@ class RainbowEngine:
                 N.check(self.lib.srlx_per_set_update_counter(self.replay.h_per, None))
             self.replay.enable_deferred_advance()
             self._publish_out_of_band()
-            self._adam_pack = os.environ.get("SRLX_ADAM_PACK", "1") != "0"  # (A/B switch: 0 = optimiser step and packing launch separately)
         self.train_count = 0
         self.sync_count = 0
         self.total_env_steps = 0
@@ -507,17 +506,9 @@ class RainbowEngine:
                 )
                 self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
             mark(4)
-            if self.fast and self._adam_pack:  # the optimiser step and the packing / publishing launch as ONE launch (srlx_qnet_adam_publish)
-                self.optimizer.step_publish(self.train_count_dev, self.inf_online, self.inf_actor if publish is not None else None, publish or 0,
-                                            bump=self.train_count_dev if self._update_side else None)
-                mark(5)
-                mark(6)
-                if self._update_side:
-                    return
-            else:
-                self.optimizer.step(self.train_count_dev)
+            self.optimizer.step(self.train_count_dev)
             mark(5)
-            if self.fast and not self._adam_pack:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors); train_count_dev += 1
+            if self.fast:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors); train_count_dev += 1
                 self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0,
                                            bump=self.train_count_dev if self._update_side else None)
                 mark(6)

@@ -237,43 +237,6 @@ def _restore_stream():
     torch.cuda.set_stream(torch.cuda.default_stream())
 
 
-def test_adam_and_publish_as_one_launch_equal_the_two_launches():
-    """srlx_qnet_adam_publish (the optimiser step of the eleven small tensors + packed filters, transposed filters and the actors' set written by the thread that
-    updates the parameter) against srlx_adam_step followed by srlx_qnet_publish: the same weights, Adam state, actions and replay after every lock-step, eager and
-    captured -- i.e. every packed place the next passes read holds the same bits."""
-    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
-
-    cfg = RainbowDeviceConfig(n_envs=512, batch_size=32, memory_capacity=512 * 12, memory_warmup_size=512 * 4, target_model_update_interval=5, lr=1e-4, seed=3)
-    engs = []
-    for flag in ("1", "0"):
-        os.environ["SRLX_ADAM_PACK"] = flag
-        try:
-            engs.append(RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=True))
-        finally:
-            os.environ.pop("SRLX_ADAM_PACK", None)
-    one, two = engs
-    assert one._adam_pack and not two._adam_pack
-    two.q_online.load_state_dict(one.q_online.state_dict())
-    two.q_target.load_state_dict(one.q_target.state_dict())
-    for eng in engs:
-        eng._publish_out_of_band()
-        for _ in range(6):
-            eng._random_rest()
-    for k in range(8):
-        for eng in engs:
-            eng.step(learner_updates=1)
-        _same_state(one, two, ("eager", k))
-    for eng in engs:
-        eng.capture_graphs()
-    for k in range(10):
-        for eng in engs:
-            eng.step(learner_updates=2 if k == 4 else 1)
-        _same_state(one, two, ("graphs", k))
-    for a, b in zip(one.optimizer.exp_avg + one.optimizer.exp_avg_sq, two.optimizer.exp_avg + two.optimizer.exp_avg_sq):
-        assert torch.equal(a, b)
-    assert one.train_count >= 10
-
-
 @pytest.mark.parametrize("actor_stream", [None, "low"])
 def test_fast_lockstep_equals_the_fifteen_launch_lockstep(actor_stream, _restore_stream):
     """Two overlapping engines on one seed, one with the round-4 lock-step: identical actions, sampled indices, losses, priorities, weights, ring and tree at

@@ -445,16 +445,42 @@ __device__ __forceinline__ void step_free(double l, double &val, unsigned &pos) 
 }
 
 constexpr int kIlp = 2;
+// Control words of the bulk sampler (handle-owned, 32 x u64).  [0] epoch, written by k_compact_bulk only; [1] the epoch the running call uses, written by
+// k_descend_bulk only (kernels of one call and of successive calls are stream-ordered, so neither word is ever written by the kernel that reads it);
+// [2 + 2 s], [3 + 2 s] for s = epoch & 1: zero-priority draws seen by the walk / max weight of the draws < B (bits) -- a call accumulates into set s and clears
+// set 1 - s, so nothing has to be re-armed behind it (round 5: the third launch, k_finish_slow, is gone); [6] max weight of the compacted draws (bits),
+// [7] tile tickets, [8] workgroups that left the compaction: re-armed by the compaction's last workgroup.
+constexpr int kCtlEpoch = 0, kCtlUse = 1, kCtlSets = 2, kCtlSlowMax = 6, kCtlTickets = 7, kCtlDone = 8, kCtlWords = 32;
 template <int kThreads>
-__global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int lds_blocks, int free_groups, u64 *zero_count, u64 *wmax_bits) {
+__global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int lds_blocks, int free_groups, u64 *ctl) {
     extern __shared__ __attribute__((aligned(16))) double bulk_smem[];
     double *top = bulk_smem;                      // block b, left slot s (0..7) at top[8 * b + s]
     double *red = bulk_smem + (size_t)lds_blocks * 8;
     const Tree tr = a.tr;
-    for (int k = threadIdx.x; k < lds_blocks * 4; k += blockDim.x)
-        reinterpret_cast<double2 *>(top)[k] = reinterpret_cast<const double2 *>(tr.T)[(k >> 2) * 8 + (k & 3)];
+    {   // staging: eight loads of a thread in flight before its first LDS store (a rolled loop is one dependent memory round trip per 16 KB: 3 us of the call)
+        constexpr int kStage = 8;
+        const int pieces = lds_blocks * 4;
+        int k0 = threadIdx.x;
+        for (; k0 + (kStage - 1) * kThreads < pieces; k0 += kStage * kThreads) {
+            double2 v[kStage];
+#pragma unroll
+            for (int u = 0; u < kStage; u++) {
+                const int k = k0 + u * kThreads;
+                v[u] = reinterpret_cast<const double2 *>(tr.T)[(k >> 2) * 8 + (k & 3)];
+            }
+#pragma unroll
+            for (int u = 0; u < kStage; u++) reinterpret_cast<double2 *>(top)[k0 + u * kThreads] = v[u];
+        }
+        for (; k0 < pieces; k0 += kThreads) reinterpret_cast<double2 *>(top)[k0] = reinterpret_cast<const double2 *>(tr.T)[(k0 >> 2) * 8 + (k0 & 3)];
+    }
+    const u64 epoch = ctl[kCtlEpoch];
+    u64 *zero_count = ctl + kCtlSets + 2 * (epoch & 1), *wmax_bits = zero_count + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[kCtlUse] = epoch;
+        ctl[kCtlSets + 2 * (1 - (epoch & 1))] = 0;  // the other set: the next call's, untouched by this one
+        ctl[kCtlSets + 2 * (1 - (epoch & 1)) + 1] = 0;
+    }
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) zero_count[3] = 0;  // re-arm the rejecting path's max weight: nothing in this kernel reads it
     const double total = top[kRootSlot];
     const i64 M = a.n_uniforms, B = a.batch, len = tr.len;
     const i64 step = a.d_step ? *a.d_step : a.step;
@@ -559,9 +585,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int 
             const double p = w[d].wl ? w[d].pl : pr[d];
             const double wi = p == 0.0 ? 0.0 : is_weight_call(size, p, total, beta);  // :163-164, computed once per draw
             // scratch for the rejecting path (struct of arrays) + the speculative output: with nothing rejected draw j IS output j
-            a.cand_idx[j] = w[d].idx;
+            (j < B ? a.out_idx : a.cand_idx)[j] = w[d].idx;  // (the compaction reads draw j's leaf from where it was written: tile sources are in registers before a tile publishes)
             a.cand_p[j] = wi;
-            if (j < B) a.out_idx[j] = w[d].idx;
             if (p == 0.0) {
                 zeros++;
             } else if (j < B) {  // fast path: with no rejection output i is draw i
@@ -575,35 +600,34 @@ __global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// After the walk.  Counters (handle-owned, zero between calls): [0] zero-priority draws seen by the walk,
-// [1] max weight of draws < B (bits), [2] "some draw was rejected" (rewritten by every call), [3] max weight of the
-// compacted draws (bits), [4] tile tickets.  Each counter is re-armed by a kernel that does not read it.
-//   k_compact_bulk  nothing was rejected (the common case): output i is draw i, the walk already wrote the indices, one
-//                   pass writes the normalised weights (:163-167); else the ORDERED compaction of the
-//                   accepted draws (in-order rejection, :146-157) over the whole device: one 2048-draw tile per
-//                   workgroup, tile offsets by a decoupled look-back scan (a tile publishes its count, then its
-//                   first wave sums 64 predecessors per step until it meets a resolved prefix)
-//   k_finish_slow   normalises the compacted weights (no per-call memset anywhere: safe under HIP-graph replay)
+// After the walk: ONE launch (round 5; the control words are described at k_descend_bulk).
+//   nothing was rejected (the common case): output i is draw i, the walk already wrote the indices, one pass writes the
+//                   normalised weights (:163-167);
+//   else            the ORDERED compaction of the accepted draws (in-order rejection, :146-157) over the whole device: one
+//                   2048-draw tile per workgroup, tile offsets by a decoupled look-back scan (a tile publishes its count, then
+//                   its first wave sums 64 predecessors per step until it meets a resolved prefix); the LAST workgroup to leave
+//                   normalises the compacted weights and re-arms tickets and look-back state (rare path: a draw is rejected only
+//                   when it lands exactly on a zero-priority leaf's boundary).  No per-call memset anywhere: safe under HIP-graph replay.
 // (A counting-sorted "binned" walk -- sort the draws by the subtree they reach so that every walk finishes in
-// LDS -- was measured at 100 us against 81 us per 2^20 draws and removed; DESIGN.md section 4 keeps the numbers.)
+// LDS -- was measured at 100 us against 81 us per 2^20 draws and removed; profiles/NOTES.md keeps the numbers.)
 // ------------------------------------------------------------------------------------------
 constexpr int kTileThreads = 256, kTilePer = 8, kTile = kTileThreads * kTilePer;
 constexpr u64 kStAggregate = 1ull << 62, kStPrefix = 2ull << 62, kStMask = 3ull << 62;
 
-__global__ void __launch_bounds__(kTileThreads) k_compact_bulk(SampleArgs a, u64 *counters, u64 *tile_state, i64 ntiles, int slow_workgroups) {
+__global__ void __launch_bounds__(kTileThreads) k_compact_bulk(SampleArgs a, u64 *ctl, u64 *tile_state, i64 ntiles, int slow_workgroups) {
     __shared__ int ibuf[kTileThreads];
     __shared__ double dred[kTileThreads];
     __shared__ i64 s_prefix;
     __shared__ unsigned s_tile;
     const i64 M = a.n_uniforms, B = a.batch;
     const int t = threadIdx.x;
-    if (counters[0] == 0) {  // nothing was rejected (the common case): output i is draw i, the walk already wrote the indices
-        if (blockIdx.x == 0 && t == 0) {
-            counters[2] = 0;
-            *a.out_used = (M >= B) ? B : -1;
-        }
+    const u64 epoch = ctl[kCtlUse];
+    const u64 *set = ctl + kCtlSets + 2 * (epoch & 1);
+    if (blockIdx.x == 0 && t == 0) ctl[kCtlEpoch] = epoch + 1;  // (read by the NEXT call's walk only)
+    if (set[0] == 0) {  // nothing was rejected: output i is draw i, the walk already wrote the indices
+        if (blockIdx.x == 0 && t == 0) *a.out_used = (M >= B) ? B : -1;
         if (M < B) return;
-        const double wmax = __longlong_as_double((long long)counters[1]);
+        const double wmax = __longlong_as_double((long long)set[1]);
         for (i64 i = (i64)blockIdx.x * blockDim.x + t; i < B; i += (i64)gridDim.x * blockDim.x) {
             const double w = a.cand_p[i] / wmax;  // :167
             if (a.out_w) a.out_w[i] = w;
@@ -612,86 +636,99 @@ __global__ void __launch_bounds__(kTileThreads) k_compact_bulk(SampleArgs a, u64
         return;
     }
     if ((int)blockIdx.x >= slow_workgroups) return;  // the grid is sized for the normalising pass; the compaction wants fewer, persistent workgroups
+    const int participants = (int)gridDim.x < slow_workgroups ? (int)gridDim.x : slow_workgroups;
     // tiles are handed out in scheduling order, so every predecessor a tile waits for has been taken by a running workgroup
-  for (;;) {
-    __syncthreads();
-    if (t == 0) s_tile = (unsigned)atomicAdd(&counters[4], 1ull);
-    __syncthreads();
-    const i64 tile = s_tile;
-    if (tile >= ntiles) return;
-    if (tile == 0 && t == 0) counters[2] = 1;
-    const i64 j0 = tile * kTile + (i64)t * kTilePer;
-    double w[kTilePer];
-    int cnt = 0;
+    for (;;) {
+        __syncthreads();
+        if (t == 0) s_tile = (unsigned)atomicAdd(&ctl[kCtlTickets], 1ull);
+        __syncthreads();
+        const i64 tile = s_tile;
+        if (tile >= ntiles) break;
+        const i64 j0 = tile * kTile + (i64)t * kTilePer;
+        double w[kTilePer];
+        i64 src[kTilePer];  // the draws' leaves, in registers BEFORE this tile publishes anything: a later tile may then overwrite out_idx[j < B] in place
+        int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < kTilePer; k++) {
-        w[k] = j0 + k < M ? a.cand_p[j0 + k] : 0.0;
-        cnt += w[k] != 0.0 ? 1 : 0;
-    }
-    int tot;
-    const int local = block_exscan(cnt, ibuf, &tot);
-    if (t < 64) {  // first wave: decoupled look-back
-        if (t == 0)
-            __hip_atomic_store(&tile_state[tile], (tile == 0 ? kStPrefix : kStAggregate) | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        i64 excl = 0, hi = tile - 1;
-        bool done = tile == 0;
-        while (!done) {
-            const i64 p = hi - t;
-            u64 v = kStPrefix;  // "tiles" before the first: resolved, nothing accepted
-            if (p >= 0) {
-                do {
-                    v = __hip_atomic_load(&tile_state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((v & kStMask) == 0);
+        for (int k = 0; k < kTilePer; k++) {
+            const i64 j = j0 + k;
+            w[k] = j < M ? a.cand_p[j] : 0.0;
+            src[k] = j < M ? (j < B ? a.out_idx : a.cand_idx)[j] : 0;
+            cnt += w[k] != 0.0 ? 1 : 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loads have RETURNED (a published count must not overtake them)
+        int tot;
+        const int local = block_exscan(cnt, ibuf, &tot);
+        if (t < 64) {  // first wave: decoupled look-back
+            if (t == 0)
+                __hip_atomic_store(&tile_state[tile], (tile == 0 ? kStPrefix : kStAggregate) | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            i64 excl = 0, hi = tile - 1;
+            bool done = tile == 0;
+            while (!done) {
+                const i64 p = hi - t;
+                u64 v = kStPrefix;  // "tiles" before the first: resolved, nothing accepted
+                if (p >= 0) {
+                    do {
+                        v = __hip_atomic_load(&tile_state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((v & kStMask) == 0);
+                }
+                const u64 resolved = __ballot((v & kStMask) == kStPrefix);
+                const int first = resolved ? __ffsll((unsigned long long)resolved) - 1 : 64;
+                i64 part = t <= first ? (i64)(v & ~kStMask) : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+                excl += part;
+                done = resolved != 0;
+                hi -= 64;
             }
-            const u64 resolved = __ballot((v & kStMask) == kStPrefix);
-            const int first = resolved ? __ffsll((unsigned long long)resolved) - 1 : 64;
-            i64 part = t <= first ? (i64)(v & ~kStMask) : 0;
+            if (t == 0) {
+                if (tile != 0) __hip_atomic_store(&tile_state[tile], kStPrefix | (u64)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_prefix = excl;
+            }
+        }
+        __syncthreads();
+        const i64 prefix = s_prefix;
+        i64 pos = prefix + local;
+        double wm = 0.0;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            excl += part;
-            done = resolved != 0;
-            hi -= 64;
+        for (int k = 0; k < kTilePer; k++) {
+            if (w[k] == 0.0) continue;
+            if (pos < B) {
+                a.out_idx[pos] = src[k];
+                a.wtmp[pos] = w[k];
+                wm = fmax(wm, w[k]);
+                if (pos == B - 1) *a.out_used = j0 + k + 1;  // uniforms consumed = index of the B-th accept + 1
+            }
+            pos++;
         }
+        wm = block_max(wm, dred);
         if (t == 0) {
-            if (tile != 0) __hip_atomic_store(&tile_state[tile], kStPrefix | (u64)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix = excl;
+            if (wm > 0.0) atomicMax(&ctl[kCtlSlowMax], (u64)__double_as_longlong(wm));  // positive doubles order like their bits
+            if (tile == ntiles - 1 && prefix + tot < B) *a.out_used = -1;
         }
+    }
+    // leave: the last workgroup out normalises and re-arms (release of this workgroup's writes, ticket, acquire by the last one)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_tile = (unsigned)__hip_atomic_fetch_add(&ctl[kCtlDone], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const i64 prefix = s_prefix;
-    i64 pos = prefix + local;
-    double wm = 0.0;
-#pragma unroll
-    for (int k = 0; k < kTilePer; k++) {
-        if (w[k] == 0.0) continue;
-        if (pos < B) {
-            a.out_idx[pos] = a.cand_idx[j0 + k];
-            a.wtmp[pos] = w[k];
-            wm = fmax(wm, w[k]);
-            if (pos == B - 1) *a.out_used = j0 + k + 1;  // uniforms consumed = index of the B-th accept + 1
+    if ((int)s_tile != participants - 1) return;
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    for (i64 i = t; i < ntiles; i += kTileThreads) tile_state[i] = 0;
+    const i64 used = __hip_atomic_load(a.out_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double wmax = __longlong_as_double((long long)__hip_atomic_load(&ctl[kCtlSlowMax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (used >= 0)
+        for (i64 i = t; i < B; i += kTileThreads) {
+            const double w = a.wtmp[i] / wmax;  // :167
+            if (a.out_w) a.out_w[i] = w;
+            if (a.out_w32) a.out_w32[i] = (float)w;
         }
-        pos++;
-    }
-    wm = block_max(wm, dred);
-    if (t == 0) {
-        if (wm > 0.0) atomicMax(&counters[3], (u64)__double_as_longlong(wm));  // positive doubles order like their bits
-        if (tile == ntiles - 1 && prefix + tot < B) *a.out_used = -1;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) k_finish_slow(SampleArgs a, u64 *counters, u64 *tile_state, i64 ntiles) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[0] = counters[1] = counters[4] = 0;  // re-arm: nothing in this kernel reads them
-    if (counters[2] == 0) return;
-    const i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x, gsz = (i64)gridDim.x * blockDim.x;
-    for (i64 i = gid; i < ntiles; i += gsz) tile_state[i] = 0;
-    if (*a.out_used < 0) return;
-    const double wmax = __longlong_as_double((long long)counters[3]);
-    for (i64 i = gid; i < a.batch; i += gsz) {
-        const double w = a.wtmp[i] / wmax;  // :167
-        if (a.out_w) a.out_w[i] = w;
-        if (a.out_w32) a.out_w32[i] = (float)w;
-    }
+    __syncthreads();
+    if (t == 0) ctl[kCtlSlowMax] = ctl[kCtlTickets] = ctl[kCtlDone] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1042,7 +1079,7 @@ struct srlx_per {
     int lds_blocks_big;  // ... by its one-workgroup-per-CU configuration
     int n_cu;
     int free_groups;  // leading groups of the blocked layout that cannot contain a leaf (walked without end-of-tree tests)
-    u64 *d_ctl;       // 8 counters of the bulk sampler (zero between calls)
+    u64 *d_ctl;       // control words of the bulk sampler (kCtl*: epochs, two counter sets, compaction tickets)
     u64 *d_tiles;     // look-back state of the bulk compaction (zero between calls)
     i64 tiles_cap;
     PerState *d_state;
@@ -1150,7 +1187,7 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
         a.wtmp = cv.take<double>(B);
         a.cand_idx = cv.take<i64>(M);
         a.cand_p = cv.take<double>(M);  // un-normalised IS weight of the draw (0 = zero-priority leaf, rejected)
-        u64 *counters = h->d_ctl;
+        u64 *ctl = h->d_ctl;
         const i64 ntiles = (M + kTile - 1) / kTile;
         if (ntiles > h->tiles_cap) {  // look-back state of the compaction, zero between calls
             if (h->d_tiles) SRLX_HIP(hipFree(h->d_tiles));
@@ -1169,15 +1206,13 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
         const int blocks = (int)(want < resident ? want : resident);
         const size_t lds = (size_t)top_blocks * 64 + (size_t)threads * 8;
         if (big)
-            hipLaunchKernelGGL((k_descend_bulk<1024>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, counters, counters + 1);
+            hipLaunchKernelGGL((k_descend_bulk<1024>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, ctl);
         else
-            hipLaunchKernelGGL((k_descend_bulk<256>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, counters, counters + 1);
+            hipLaunchKernelGGL((k_descend_bulk<256>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, ctl);
         // one launch finishes either path: the normalising pass when nothing was rejected, else the ordered compaction
         const i64 fw = (B + 256 * 4 - 1) / (256 * 4);
         const i64 cw = 8 * (i64)h->n_cu, need = ntiles > fw ? ntiles : fw;
-        hipLaunchKernelGGL(k_compact_bulk, dim3((unsigned)(need < cw ? need : cw)), dim3(kTileThreads), 0, st, a, counters, h->d_tiles, ntiles,
-                           2 * h->n_cu);
-        hipLaunchKernelGGL(k_finish_slow, dim3((unsigned)(fw < h->n_cu ? fw : h->n_cu)), dim3(256), 0, st, a, counters, h->d_tiles, ntiles);
+        hipLaunchKernelGGL(k_compact_bulk, dim3((unsigned)(need < cw ? need : cw)), dim3(kTileThreads), 0, st, a, ctl, h->d_tiles, ntiles, 2 * h->n_cu);
     }
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
@@ -1252,8 +1287,8 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
     hipError_t e = hipMalloc((void **)&h->tree.T, 128 * (size_t)h->n_blocks);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_state, sizeof(PerState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_err, sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_ctl, 64);
-    if (e == hipSuccess) e = hipMemset(h->d_ctl, 0, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_ctl, kCtlWords * 8);
+    if (e == hipSuccess) e = hipMemset(h->d_ctl, 0, kCtlWords * 8);
     if (e != hipSuccess) {
         srlx::set_error("per_create: %s", hipGetErrorString(e));
         srlx_per_destroy(h);

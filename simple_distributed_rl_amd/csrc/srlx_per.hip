@@ -63,12 +63,20 @@ __host__ __device__ __forceinline__ int node_depth(i64 x) {
 // the deepest level D: the top group has h0 = ((D-1) % 3) + 1 levels (1..h0), then G groups of 3.  The
 // nodes of a group that descend from the same "owner" (the ancestor on the level just above the
 // group) share one 16-double block.  A node at relative depth r (1..3) with in-block offset m (0..2^r-1)
-// sits in slot (m&1)*8 + {0,1,3}[r-1] + (m>>1): left children in slots 0..6, their right siblings 8 slots
-// further (8..14); block 0 slot 7 is the root.  base[g] = index of the first block of group g.
+// with even m (a left child) sits in slot {0,1,3}[r-1] + (m>>1) (slots 0..6: the line's first half); the right children fill the second half DEEPEST FIRST --
+// relative depth 3 in slots 8..11, depth 2 in 12..13, depth 1 in 14 -- so that the bulk walk's last group gets every value it can need (7 left children to
+// compare against, 4 right leaves) from the first 96 bytes of the line; block 0 slot 7 is the root.  base[g] = index of the first block of group g.
+// A LEAF on depth D-1 (capacities that are not powers of two) is also MIRRORED into the slot its left child would have (`Tree::mirror`): the walk reads such a
+// leaf's priority from the left half it fetched anyway, whichever side of its parent the leaf hangs on (round 5: the dependent read of the right sibling after
+// the walk cost 4.5 of the 48 us of a 2^20-draw call).
 constexpr int kRootSlot = 7;
 __host__ __device__ __forceinline__ int slot_in_block(int r, int64_t m) {
-    return (int)(m & 1) * 8 + (r == 1 ? 0 : (r == 2 ? 1 : 3)) + (int)(m >> 1);
+    const int h = (int)(m >> 1);
+    if (m & 1) return r == 1 ? 14 : (r == 2 ? 12 + h : 8 + h);
+    return (r == 1 ? 0 : (r == 2 ? 1 : 3)) + h;
 }
+// slot of the right sibling of the left child in slot s
+__host__ __device__ __forceinline__ int right_of_left_slot(int s) { return s == 0 ? 14 : (s < 3 ? s + 11 : s + 5); }
 struct Tree {
     double *T;
     i64 len;  // 2 * capacity - 1 logical nodes
@@ -91,14 +99,13 @@ struct Tree {
         return 16 * blk + slot_in_block(r, q & (((i64)1 << r) - 1));
     }
     __device__ __forceinline__ double get(i64 i) const { return T[phys(i)]; }
-    __device__ __forceinline__ void set(i64 i, double v) const { T[phys(i)] = v; }
-    // (left, right) children values: two independent 8-byte loads from one line; `left` must be odd (a left child)
-    __device__ __forceinline__ double2 pair(i64 left) const {
-        const double *s = T + phys(left);
-        double2 v;
-        v.x = s[0];
-        v.y = s[8];
-        return v;
+    __device__ __forceinline__ void set(i64 i, double v) const {
+        T[phys(i)] = v;
+        mirror(i, v);
+    }
+    // every store to a LEAF goes through here (or through set): a leaf on depth D-1 also lives where its left child would
+    __device__ __forceinline__ void mirror(i64 i, double v) const {
+        if (2 * i + 1 >= len && D >= 1 && node_depth(i) == D - 1) T[phys(2 * i + 1)] = v;
     }
     // block that holds the children of owner node `owner` on level `level` (level = 0, h0, h0+3, ...)
     __device__ __forceinline__ i64 block_of_owner(i64 owner, int level) const {
@@ -361,7 +368,7 @@ __device__ __forceinline__ void walk_block_regs(const double (&L)[8], i64 blockp
     const int s1 = go ? 0 : 1;
     w.val = go ? w.val : w.val - l;
     w.idx = left + s1;
-    w.pl = l; w.wl = go; w.rpos = blockpos + 8;
+    w.pl = l; w.wl = go; w.rpos = blockpos + 14;
     if (levels < 2) return;
     left = 2 * w.idx + 1;
     if (left >= len) { w.live = false; return; }
@@ -370,7 +377,7 @@ __device__ __forceinline__ void walk_block_regs(const double (&L)[8], i64 blockp
     const int s2 = 2 * s1 + (go ? 0 : 1);
     w.val = go ? w.val : w.val - l;
     w.idx = left + (go ? 0 : 1);
-    w.pl = l; w.wl = go; w.rpos = blockpos + 9 + s1;
+    w.pl = l; w.wl = go; w.rpos = blockpos + 12 + s1;
     if (levels < 3) return;
     left = 2 * w.idx + 1;
     if (left >= len) { w.live = false; return; }
@@ -379,7 +386,35 @@ __device__ __forceinline__ void walk_block_regs(const double (&L)[8], i64 blockp
     go = w.val <= l;
     w.val = go ? w.val : w.val - l;
     w.idx = left + (go ? 0 : 1);
-    w.pl = l; w.wl = go; w.rpos = blockpos + 11 + s2;
+    w.pl = l; w.wl = go; w.rpos = blockpos + 8 + s2;
+}
+
+// The LAST group's block out of registers (bulk walk; the group spans the depths D-2 .. D, so every live draw ends in it): left half L[0..7] and the four deepest
+// right children R4[0..3] (slots 8..11).  Ends the walk: pl = the priority of the leaf reached, wl = true (nothing is left to read).
+__device__ __forceinline__ void walk_last_regs(const double (&L)[8], const double (&R4)[4], i64 len, Draw &w) {
+    i64 left = 2 * w.idx + 1;  // (a node on depth D-2 has children)
+    double l = L[0];
+    bool go = w.val <= l;  // :61
+    const int s1 = go ? 0 : 1;
+    w.val = go ? w.val : w.val - l;
+    w.idx = left + s1;
+    left = 2 * w.idx + 1;
+    l = s1 ? L[2] : L[1];
+    go = w.val <= l;
+    const int s2 = 2 * s1 + (go ? 0 : 1);
+    w.val = go ? w.val : w.val - l;
+    w.idx = left + (go ? 0 : 1);
+    left = 2 * w.idx + 1;
+    const double la = (s2 & 1) ? L[4] : L[3], lb = (s2 & 1) ? L[6] : L[5];
+    l = (s2 >> 1) ? lb : la;  // the left child -- or, for a leaf on depth D-1, the leaf's own mirror
+    const double ra = (s2 & 1) ? R4[1] : R4[0], rb = (s2 & 1) ? R4[3] : R4[2];
+    const double r = (s2 >> 1) ? rb : ra;
+    const bool leaf = left >= len;
+    go = leaf || w.val <= l;
+    w.idx = leaf ? w.idx : left + (go ? 0 : 1);
+    w.pl = go ? l : r;
+    w.wl = true;
+    w.live = false;
 }
 
 // one draw of the small (single-workgroup) sampler: block by block out of memory
@@ -423,7 +458,7 @@ __device__ __forceinline__ void walk_block_lds(const double *blk, i64 blockpos, 
         const bool go = w.val <= l;  // :61
         w.val = go ? w.val : w.val - l;
         w.idx = left + (go ? 0 : 1);
-        w.pl = l; w.wl = go; w.rpos = blockpos + 8 + slot;
+        w.pl = l; w.wl = go; w.rpos = blockpos + right_of_left_slot(slot);
         pos = 2 * pos + (go ? 0 : 1);
     }
 }
@@ -451,8 +486,11 @@ constexpr int kIlp = 2;
 // set 1 - s, so nothing has to be re-armed behind it (round 5: the third launch, k_finish_slow, is gone); [6] max weight of the compacted draws (bits),
 // [7] tile tickets, [8] workgroups that left the compaction: re-armed by the compaction's last workgroup.
 constexpr int kCtlEpoch = 0, kCtlUse = 1, kCtlSets = 2, kCtlSlowMax = 6, kCtlTickets = 7, kCtlDone = 8, kCtlWords = 32;
-template <int kThreads>
-__global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int lds_blocks, int free_groups, u64 *ctl) {
+// kAllStaged: every block of the tree is staged in LDS (small trees); else the last group -- and for deep trees the groups just above it -- is fetched.
+// Every group but the last lies above the shallowest leaf (the last group spans the depths D-2 .. D), so all of them are walked branch-free on 32-bit in-level
+// offsets, out of LDS or out of the four 16-byte pieces of a fetched line's left half; only the last group can end a walk.
+template <int kThreads, bool kAllStaged>
+__global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int lds_blocks, u64 *ctl) {
     extern __shared__ __attribute__((aligned(16))) double bulk_smem[];
     double *top = bulk_smem;                      // block b, left slot s (0..7) at top[8 * b + s]
     double *red = bulk_smem + (size_t)lds_blocks * 8;
@@ -499,12 +537,11 @@ __global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int 
             q[d] = 0;
         }
         int level = 0;  // level of the current owner nodes (same for every draw)
-        int g = 0;
-        for (; g < free_groups && (g == 0 || tr.base[g + 1] <= lds_blocks); g++) {
+        for (int g = 0; g < tr.G; g++) {  // the groups above the last
             const int levels = g == 0 ? tr.h0 : 3;
             const unsigned gbase = (unsigned)tr.base[g];
             unsigned pos[kIlp];
-            {
+            if (kAllStaged || g == 0 || tr.base[g + 1] <= lds_blocks) {  // staged: one dependent 8-byte LDS read per level, the draws of a lane interleaved
                 const double *blk[kIlp];
                 double l[kIlp];
 #pragma unroll
@@ -528,11 +565,30 @@ __global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int 
 #pragma unroll
                     for (int d = 0; d < kIlp; d++) step_free(l[d], val[d], pos[d]);
                 }
+            } else {  // fetched (three levels): the left half of one line per draw, the decisions are register selects
+                double2 P[kIlp][4];
+#pragma unroll
+                for (int d = 0; d < kIlp; d++) {
+                    const double2 *src = reinterpret_cast<const double2 *>(tr.T + (size_t)(gbase + q[d]) * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) P[d][k] = src[k];
+                }
+#pragma unroll
+                for (int d = 0; d < kIlp; d++) {
+                    pos[d] = 0;
+                    step_free(P[d][0].x, val[d], pos[d]);
+                    const unsigned s1 = pos[d];
+                    step_free(s1 ? P[d][1].x : P[d][0].y, val[d], pos[d]);
+                    const unsigned s2 = pos[d];
+                    const double la = (s2 & 1) ? P[d][2].x : P[d][1].y, lb = (s2 & 1) ? P[d][3].x : P[d][2].y;
+                    step_free((s2 >> 1) ? lb : la, val[d], pos[d]);
+                }
             }
 #pragma unroll
             for (int d = 0; d < kIlp; d++) q[d] = (q[d] << levels) + pos[d];
             level += levels;
         }
+        // the last group
         Draw w[kIlp];
 #pragma unroll
         for (int d = 0; d < kIlp; d++) {
@@ -544,40 +600,41 @@ __global__ void __launch_bounds__(kThreads, 4) k_descend_bulk(SampleArgs a, int 
             w[d].wl = true;
             w[d].rpos = 0;
         }
-        for (; g <= tr.G; g++) {
-            const int levels = g == 0 ? tr.h0 : 3;
-            if (tr.base[g + 1] <= lds_blocks || g == 0) {
-                // group staged in LDS: one dependent 8-byte read per level
+        double pr[kIlp];
+        if (kAllStaged || tr.G == 0) {  // out of LDS, with end-of-tree tests; then the one read of a right child: the leaf's own priority
 #pragma unroll
-                for (int d = 0; d < kIlp; d++)
-                    if (w[d].live) {
-                        const i64 blk = tr.block_of_owner(w[d].idx, level);
-                        walk_block_lds(top + blk * 8, blk * 16, levels, len, w[d]);
-                    }
-            } else {
-                double L[kIlp][8];
-                i64 bp[kIlp];
-#pragma unroll
-                for (int d = 0; d < kIlp; d++) {
-                    if (!w[d].live) continue;
-                    bp[d] = tr.block_of_owner(w[d].idx, level) * 16;
-                    const double2 *src = reinterpret_cast<const double2 *>(tr.T + bp[d]);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const double2 v = src[k];
-                        L[d][2 * k] = v.x;
-                        L[d][2 * k + 1] = v.y;
-                    }
+            for (int d = 0; d < kIlp; d++)
+                if (w[d].live) {
+                    const i64 blk = tr.block_of_owner(w[d].idx, level);
+                    walk_block_lds(top + blk * 8, blk * 16, tr.G == 0 ? tr.h0 : 3, len, w[d]);
                 }
 #pragma unroll
-                for (int d = 0; d < kIlp; d++)
-                    if (w[d].live) walk_block_regs(L[d], bp[d], levels, len, w[d]);
-            }
-            level += levels;
-        }
-        double pr[kIlp];
+            for (int d = 0; d < kIlp; d++) pr[d] = w[d].wl ? 0.0 : tr.T[w[d].rpos];
+        } else {  // fetched: 96 bytes per draw, and the leaf's priority comes out of them (no dependent read behind the walk)
+            double L[kIlp][8], R4[kIlp][4];
+            const unsigned gbase = (unsigned)tr.base[tr.G];
 #pragma unroll
-        for (int d = 0; d < kIlp; d++) pr[d] = w[d].wl ? 0.0 : tr.T[w[d].rpos];  // the one read of a right child: the leaf's own priority
+            for (int d = 0; d < kIlp; d++) {
+                const double2 *src = reinterpret_cast<const double2 *>(tr.T + (size_t)(gbase + q[d]) * 16);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double2 v = src[k];
+                    L[d][2 * k] = v.x;
+                    L[d][2 * k + 1] = v.y;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const double2 v = src[4 + k];
+                    R4[d][2 * k] = v.x;
+                    R4[d][2 * k + 1] = v.y;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < kIlp; d++) {
+                if (w[d].live) walk_last_regs(L[d], R4[d], len, w[d]);
+                pr[d] = 0.0;
+            }
+        }
 #pragma unroll
         for (int d = 0; d < kIlp; d++) {
             const i64 j = base + d * stride;
@@ -902,7 +959,7 @@ __device__ __forceinline__ i64 run_tasks(const Run &r) {
 }
 
 // thread `tid` of `nthreads` processes its share of a run's ancestor nodes
-__device__ __forceinline__ void run_ancestors(const Tree &tr, const double *chg, const Run &r, i64 tid, i64 nthreads, int abl = 0) {
+__device__ __forceinline__ void run_ancestors(const Tree &tr, const double *chg, const Run &r, i64 tid, i64 nthreads) {
     const i64 cnt = r.i_hi - r.i_lo;
     const i64 x_hi = r.x_lo + cnt - 1;
     const i64 tasks = run_tasks(r);
@@ -925,10 +982,9 @@ __device__ __forceinline__ void run_ancestors(const Tree &tr, const double *chg,
         if (first < r.x_lo) first = r.x_lo;
         if (last > x_hi) last = x_hi;
         const double *c0 = chg + r.i_lo + (first - r.x_lo);
-        i64 m = last - first + 1;
-        if (abl == 2 && m > 64) m = 64;
-        const i64 pa = abl == 3 ? 0 : tr.phys(a);
-        double v = abl == 3 ? 0.0 : tr.T[pa];
+        const i64 m = last - first + 1;
+        const i64 pa = tr.phys(a);
+        double v = tr.T[pa];
         // additions strictly in list order (the reference's propagate order).  The upper levels' owners add ALL n changes: one dependent fp64 add per change
         // is the floor of the whole call, so the loads must not sit on that chain -- blocks of 16 changes, the next block requested before the current one is added
         // (the scheduling barriers keep hipcc from sinking the loads to their uses: 8 loads then 8 dependent adds per trip cost 2.6x the adds alone)
@@ -960,7 +1016,7 @@ __device__ __forceinline__ void run_ancestors(const Tree &tr, const double *chg,
             }
         }
         for (; k < m; k++) v += c0[k];
-        if (abl != 3 || v == 1.2345) tr.T[pa] = v;
+        tr.T[pa] = v;
     }
 }
 
@@ -976,7 +1032,6 @@ struct AddArgs {
     i64 start_slot;  // -1: append at state->write (add); >= 0: rewrite these ring slots in place (set_range)
     int commit;      // advance write/size (add) or not (set_range)
     int track_max;   // raise max_priority like update() does (:176-177)
-    int abl;               // measurement only (SRLX_ADD_ABL): 1 = leaves only, 2 = ancestor chains capped at 64 changes, 3 = no ancestor tree accesses
     double maxp_snapshot;  // bulk path only: filled from *maxp_dev by the leaf kernel's caller
     const double *maxp_dev;
     i64 *bump0, *bump1;  // srlx_per_set_add_counters: int64 device counters an appending add advances by one (NULL: none)
@@ -992,6 +1047,7 @@ __device__ __forceinline__ void add_leaf(const AddArgs &a, i64 i, i64 write, dou
     const i64 px = a.tree.phys(x);
     a.chg[i] = p - a.tree.T[px];
     a.tree.T[px] = p;
+    a.tree.mirror(x, p);
     // priorities are >= 0, so their bit patterns order like the values
     if (a.track_max && p > maxp) atomicMax((u64 *)&a.state->max_priority, (u64)__double_as_longlong(p));
 }
@@ -1019,13 +1075,12 @@ __global__ void __launch_bounds__(512) k_add_wg(AddArgs a) {
     __syncthreads();  // every thread has read max_priority before anyone raises it
     for (i64 i = t; i < a.n; i += T) add_leaf(a, i, write, maxp);
     __syncthreads();
-    if (a.abl != 1)
-        for (int r = 0; r < 4; r++) {
-            Run run;
-            if (!get_run(a.cap, write, a.n, r, run)) break;
-            run_ancestors(a.tree, a.chg, run, t, T, a.abl);
-            __syncthreads();
-        }
+    for (int r = 0; r < 4; r++) {
+        Run run;
+        if (!get_run(a.cap, write, a.n, r, run)) break;
+        run_ancestors(a.tree, a.chg, run, t, T);
+        __syncthreads();
+    }
     if (t == 0) add_commit(a);
 }
 
@@ -1078,7 +1133,6 @@ struct srlx_per {
     int lds_blocks;   // leading blocks the bulk sampler stages in LDS
     int lds_blocks_big;  // ... by its one-workgroup-per-CU configuration
     int n_cu;
-    int free_groups;  // leading groups of the blocked layout that cannot contain a leaf (walked without end-of-tree tests)
     u64 *d_ctl;       // control words of the bulk sampler (kCtl*: epochs, two counter sets, compaction tickets)
     u64 *d_tiles;     // look-back state of the bulk compaction (zero between calls)
     i64 tiles_cap;
@@ -1103,7 +1157,7 @@ int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st,
     const bool append = start_slot < 0;
     double *snap = (double *)((char *)h->scratch.ptr + srlx::Carver::padded((size_t)n * 8));
     AddArgs a{h->tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr,
-              start_slot, append ? 1 : 0, append ? 0 : 1, getenv("SRLX_ADD_ABL") ? atoi(getenv("SRLX_ADD_ABL")) : 0, 0.0, snap, append ? h->d_add_counter[0] : nullptr, append ? h->d_add_counter[1] : nullptr};
+              start_slot, append ? 1 : 0, append ? 0 : 1, 0.0, snap, append ? h->d_add_counter[0] : nullptr, append ? h->d_add_counter[1] : nullptr};
     if (n <= kSmallAddMax) {
         hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(n < 512 ? kWgAdd : 512), (size_t)n * sizeof(double), st, a);  // (512 threads: a 256-register budget keeps the pipelined chain blocks out of scratch)
     } else {
@@ -1205,10 +1259,15 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
         const i64 want = (M + threads * kIlp - 1) / (threads * kIlp);
         const int blocks = (int)(want < resident ? want : resident);
         const size_t lds = (size_t)top_blocks * 64 + (size_t)threads * 8;
-        if (big)
-            hipLaunchKernelGGL((k_descend_bulk<1024>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, ctl);
+        const bool all_staged = h->n_blocks <= top_blocks;
+        if (big && all_staged)
+            hipLaunchKernelGGL((k_descend_bulk<1024, true>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, ctl);
+        else if (big)
+            hipLaunchKernelGGL((k_descend_bulk<1024, false>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, ctl);
+        else if (all_staged)
+            hipLaunchKernelGGL((k_descend_bulk<256, true>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, ctl);
         else
-            hipLaunchKernelGGL((k_descend_bulk<256>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, h->free_groups, ctl);
+            hipLaunchKernelGGL((k_descend_bulk<256, false>), dim3(blocks), dim3(threads), lds, st, a, top_blocks, ctl);
         // one launch finishes either path: the normalising pass when nothing was rejected, else the ordered compaction
         const i64 fw = (B + 256 * 4 - 1) / (256 * 4);
         const i64 cw = 8 * (i64)h->n_cu, need = ntiles > fw ? ntiles : fw;
@@ -1267,11 +1326,6 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
         }
         h->lds_blocks = 1;
         h->lds_blocks_big = 1;
-        h->free_groups = 0;
-        if (t.D > 0) {
-            const int shallowest_leaf = node_depth(capacity - 1);  // node N-1 is the first leaf
-            for (int g = 0; g <= t.G && t.h0 + 3 * g < shallowest_leaf; g++) h->free_groups = g + 1;
-        }
         for (int g = 1; g <= t.G; g++) {
             if (t.base[g + 1] <= kBulkTopSmall) h->lds_blocks = (int)t.base[g + 1];
             if (t.base[g + 1] <= kBulkTopBig) h->lds_blocks_big = (int)t.base[g + 1];
@@ -1281,7 +1335,9 @@ int srlx_per_create(srlx_per_t **out, int64_t capacity, double alpha, double bet
         hipDeviceProp_t prop;
         SRLX_HIP(hipGetDeviceProperties(&prop, device));
         h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        SRLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend_bulk<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        SRLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend_bulk<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kBulkTopBig * 64 + 1024 * 8));
+        SRLX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend_bulk<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kBulkTopBig * 64 + 1024 * 8));
     }
     hipError_t e = hipMalloc((void **)&h->tree.T, 128 * (size_t)h->n_blocks);

@@ -212,6 +212,14 @@ int srlx_store_commit_step(srlx_store_t *h, const int32_t *d_actions, const floa
  *                       srlx_qnet_forward_u8_policy only reads) */
 int srlx_store_commit_step_ex(srlx_store_t *h, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated, const uint8_t *d_done,
                               const void *d_next_obs, uint8_t *d_item_mask, int64_t *d_next_frame_table, int advance, int64_t *d_bump, void *stream);
+/* The commit of a lock-step that arrived as PACKED RECORDS (what actor ranks ship to a learner rank; replaces the unpickling of queued items in the reference's
+ * trainer-side drain thread, srl/base/run/play_mp.py:248-286): environment e is lane e % envs_per_record of record e / envs_per_record; a record =
+ * [action int32 x per | reward float32 x per | terminated uint8 x per | done uint8 x per | extra float32 x per x extra_floats], records record_stride bytes apart;
+ * d_next_obs is the frames of all E environments in environment order.  d_est_records (or NULL): a packed buffer of the same shape whose FIRST extra field holds
+ * actor-side initial-priority estimates (srl/algorithms/rainbow/rainbow.py:389-398) for the items THIS commit completes; d_est_out float32 [E] receives them, -2
+ * where the commit completed no item, -1 (= "use max_priority") without d_est_records -- the array srlx_per_add(SRLX_PRIO_EST_F32) takes. */
+int srlx_store_commit_step_packed(srlx_store_t *h, const uint8_t *d_records, int64_t record_stride, int64_t envs_per_record, int extra_floats, const void *d_next_obs,
+                                  uint8_t *d_item_mask, const uint8_t *d_est_records, float *d_est_out, int advance, void *stream);
 int srlx_store_advance(srlx_store_t *h, void *stream);
 /* device views: int64 position p; uint8 needs_reset[E]; int32 step_in_episode[E] (of position p) */
 int srlx_store_views(srlx_store_t *h, void **d_pos, void **d_needs_reset, void **d_step_in_ep);
@@ -517,6 +525,10 @@ int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int wit
  * The branch joins the caller's stream before the call's last launch, so the tree is updated when the backward returns to the caller's stream order.
  * per = NULL removes the sink.  Pointers are device pointers that must stay valid (captured into HIP graphs with the pass). */
 int srlx_qnet_set_priority_sink(srlx_qnet_t *h, srlx_per_t *per, int64_t n, const int64_t *d_indices, const void *d_priorities, int prio_kind);
+/* a caller-owned HIP event (hipEvent_t, NULL: none) the priority sink's branch waits for before its write-back: a learner rank that commits incoming
+ * transitions BESIDE its update (device/dist.py: tree add on a side stream between the update's draw and its write-back) records it behind the add, so the
+ * tree sees draw -> add -> write-back in that order whatever the streams do */
+int srlx_qnet_set_sink_wait(srlx_qnet_t *h, void *event);
 
 /* a caller-owned HIP event (hipEvent_t, NULL: none) recorded on the backward pass's stream right behind its head kernel: with srlx_qnet_backward_td_u8 the TD
  * targets, loss and new priorities exist from there on, so the priority write-back (srlx_per_update) can run beside the gradient kernels on another stream */

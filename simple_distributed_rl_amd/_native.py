@@ -77,6 +77,7 @@ SIGNATURES = {
     "srlx_store_stack_current": (c_int, [c_p, c_p, c_p]),
     "srlx_store_commit_step": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_store_commit_step_ex": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p]),
+    "srlx_store_commit_step_packed": (c_int, [c_p, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_int, c_p]),
     "srlx_store_advance": (c_int, [c_p, c_p]),
     "srlx_store_views": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p)]),
     "srlx_store_gather_nstep": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "srlx_qnet_set_stamp_buffer": (c_int, [c_p, c_p]),
     "srlx_qnet_set_td_event": (c_int, [c_p, c_p]),
     "srlx_qnet_set_priority_sink": (c_int, [c_p, c_p, c_i64, c_p, c_p, c_int]),
+    "srlx_qnet_set_sink_wait": (c_int, [c_p, c_p]),
     "srlx_qnet_fuse_adam_fc1_planes": (c_int, [c_p, c_p]),
     "srlx_qnet_set_pack_sticky": (c_int, [c_p, c_int]),
     "srlx_qnet_set_fc1_neighbour": (c_int, [c_p, c_int]),

@@ -679,6 +679,7 @@ static int chain_prologue(srlx_qnet_t *h, hipStream_t st) {
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
     // the replay's priority write-back (model_torch.py:113-114) needs the TD kernel's output only: first thing on the weight-gradient branch instead of the
     // last launch of the update (it was 9 us + a launch boundary at the very end of the learner's critical path)
+    if (h->sink_per && h->sink_wait) SRLX_HIP(hipStreamWaitEvent(sd, h->sink_wait, 0));
     if (h->sink_per) SRLX_TRY(srlx_per_update(h->sink_per, h->sink_n, h->sink_idx, h->sink_prio, h->sink_kind, 1, sd));
     SRLX_STAMP(21, sd);
     const int C2 = 2 * h->F1;

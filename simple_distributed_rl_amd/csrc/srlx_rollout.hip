@@ -150,9 +150,21 @@ __global__ void k_advance(i64 *counter) { counter[0] += 1; }
 // block that draws the last ticket is the only one left running, moves p and rewinds the ticket counter (pos[4]) for the next launch.
 // advance == 0: p stays (an engine that overlaps a learner moves it after joining it: the learner's item lookup reads p; ring slot p + 1 itself is
 // referenced by no item, so frames and scalars may land while the learner still runs).  `bump`: one more int64 counter the launch advances (block 0).
+// Packed source (srlx_store_commit_step_packed: the slabs actor ranks ship to a learner rank, device/dist.py): environment e = (rank block e / per, lane e % per);
+// a block's record = [action int32 x per | reward float32 x per | terminated u8 x per | done u8 x per | extra float32 x per x k].  est / est_out: the first
+// extra field of ANOTHER packed buffer of the same shape (the actor-side initial-priority estimates, which travel one slab behind the items they belong to)
+// written as one float per environment, -2 where this commit completed no item for the lane (what srlx_per_add(SRLX_PRIO_EST_F32) expects).
+struct PackedSrc {
+    const u8 *base;  // NULL: separate arrays
+    i64 stride;      // bytes between rank blocks
+    i64 per;         // environments per rank block
+    int k;           // extra float32 fields per environment
+    const u8 *est;   // packed buffer carrying the estimates, or NULL
+    float *est_out;  // [E]
+};
 __global__ void __launch_bounds__(256) k_commit_step(StoreDev s, const int32_t *__restrict__ actions, const float *__restrict__ rewards, const u8 *__restrict__ terminated,
                                                      const u8 *__restrict__ done, const void *__restrict__ next_obs, u8 *__restrict__ item_mask,
-                                                     i64 *__restrict__ next_table, int advance, i64 *__restrict__ bump) {
+                                                     i64 *__restrict__ next_table, int advance, i64 *__restrict__ bump, PackedSrc pk) {
     const i64 p = s.pos[0];
     const i64 r = posmod(p, s.L), r1 = posmod(p + 1, s.L);
     const i64 fb = s.obs_dtype == SRLX_OBS_U8 ? s.F : s.F * 4;  // frame bytes
@@ -181,11 +193,24 @@ __global__ void __launch_bounds__(256) k_commit_step(StoreDev s, const int32_t *
             sie1 = 0;
             s.needs_reset[e] = 0;
         } else {
-            float rew = rewards[e];
+            float rew;
+            int32_t act;
+            u8 d, tm;
+            if (pk.base) {
+                const u8 *rec = pk.base + (e / pk.per) * pk.stride;
+                const i64 i = e % pk.per;
+                act = reinterpret_cast<const int32_t *>(rec)[i];
+                rew = reinterpret_cast<const float *>(rec + 4 * pk.per)[i];
+                tm = rec[8 * pk.per + i] ? 1 : 0;
+                d = rec[9 * pk.per + i] ? 1 : 0;
+            } else {
+                act = actions[e];
+                rew = rewards[e];
+                d = done[e] ? 1 : 0, tm = terminated[e] ? 1 : 0;
+            }
             if (s.reward_clip) rew = rew < 0.f ? -1.f : (rew > 0.f ? 1.f : 0.f);  // rainbow.py:337-343
-            const u8 d = done[e] ? 1 : 0, tm = terminated[e] ? 1 : 0;
             s.flags[base + r] = (tm ? kTerm : 0) | (d ? kDone : 0);
-            s.action[base + r] = actions[e];
+            s.action[base + r] = act;
             s.reward[base + r] = rew;
             sie1 = s.step_in_ep[base + r] + 1;
             s.needs_reset[e] = d;
@@ -193,7 +218,10 @@ __global__ void __launch_bounds__(256) k_commit_step(StoreDev s, const int32_t *
         s.step_in_ep[base + r1] = sie1;
         if (item_mask) {
             const i64 q = p - (s.n - 1);
-            item_mask[e] = (q >= 0 && !(s.flags[base + posmod(q, s.L)] & kInvalid)) ? 1 : 0;
+            const u8 has = (q >= 0 && !(s.flags[base + posmod(q, s.L)] & kInvalid)) ? 1 : 0;
+            item_mask[e] = has;
+            if (pk.est_out)
+                pk.est_out[e] = !has ? -2.f : (pk.est ? reinterpret_cast<const float *>(pk.est + (e / pk.per) * pk.stride + 10 * pk.per)[(e % pk.per) * pk.k] : -1.f);
         }
         if (next_table)  // frame_offset(s, e, p + 1, c) with step_in_ep[p + 1] = sie1
             for (int c = 0; c < s.W; c++) {
@@ -560,7 +588,28 @@ int srlx_store_commit_step_ex(srlx_store_t *h, const int32_t *d_actions, const f
     const int need = (int)((d.E + 255) / 256);  // the scalar part needs one thread per environment
     if (grid < need) grid = need;
     hipLaunchKernelGGL(k_commit_step, dim3((unsigned)grid), dim3(256), 0, st, d, d_actions, d_rewards, d_terminated, d_done, d_next_obs, d_item_mask,
-                       (i64 *)d_next_frame_table, advance, (i64 *)d_bump);
+                       (i64 *)d_next_frame_table, advance, (i64 *)d_bump, PackedSrc{});
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_commit_step_packed(srlx_store_t *h, const uint8_t *d_records, int64_t record_stride, int64_t envs_per_record, int extra_floats, const void *d_next_obs,
+                                  uint8_t *d_item_mask, const uint8_t *d_est_records, float *d_est_out, int advance, void *stream) {
+    SRLX_REQUIRE(h && d_records && d_next_obs && d_item_mask, "store_commit_step_packed: NULL argument");
+    SRLX_REQUIRE(envs_per_record > 0 && h->d.E % envs_per_record == 0 && extra_floats >= 0 && record_stride >= (10 + 4 * (int64_t)extra_floats) * envs_per_record &&
+                     record_stride % 4 == 0 && envs_per_record % 4 == 0,
+                 "store_commit_step_packed: %lld environments do not split into records of %lld (stride %lld bytes, %d extra fields; multiples of 4)", (long long)h->d.E,
+                 (long long)envs_per_record, (long long)record_stride, extra_floats);
+    SRLX_REQUIRE(!d_est_records || (extra_floats >= 1 && d_est_out), "store_commit_step_packed: estimates ride in the first extra field and need d_est_out");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick(h, stream);
+    const StoreDev &d = h->d;
+    const i64 fb = d.F * (d.obs_dtype == SRLX_OBS_U8 ? 1 : 4);
+    int grid = grid_for(d.E * (fb / 16 + 1), advance ? 256 : 2048);
+    const int need = (int)((d.E + 255) / 256);
+    if (grid < need) grid = need;
+    hipLaunchKernelGGL(k_commit_step, dim3((unsigned)grid), dim3(256), 0, st, d, nullptr, nullptr, nullptr, nullptr, d_next_obs, d_item_mask, nullptr, advance, nullptr,
+                       PackedSrc{d_records, (i64)record_stride, (i64)envs_per_record, extra_floats, d_est_records, d_est_out});
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

@@ -157,6 +157,77 @@ class TransitionBus:
         self.push_begin(actions, rewards, terminated, done, next_obs, extra)
         return self.push_end()
 
+    # ---- slot API (DistributedRainbow): packed records + frames, the learner's staging buffers rotate so that a slab can be committed a lock-step or two after it
+    #      arrived while the next one is being received ----------------------------------------------------------------------------------------------------------
+    def enable_slots(self, slots: int):
+        """Learner rank: `slots` staging buffers of (packed records uint8 [actor ranks][record bytes], frames [actor ranks x E][F]); only actor ranks have rows."""
+        self.rec_bytes = (10 + 4 * self.K) * self.E
+        self.row_of = {r: i for i, r in enumerate(self.actor_ranks)}
+        if self.is_learner:
+            R = len(self.actor_ranks)
+            dt = self.g_next_obs.dtype if hasattr(self, "g_next_obs") else torch.uint8
+            self.slot_scal = [torch.zeros((R, self.rec_bytes), dtype=torch.uint8, device=self.device) for _ in range(slots)]
+            self.slot_obs = [torch.zeros((R * self.E, self.F), dtype=dt, device=self.device) for _ in range(slots)]
+        self._staged = dist.is_initialized() and self.world > 1 and dist.get_backend(self.group) == "gloo" and self.device.type == "cuda"  # test rigs: ranks sharing one GPU
+
+    def pack(self, actions, rewards, terminated, done, extra=None) -> torch.Tensor:
+        """One rank's record: [action int32 x E | reward float32 x E | terminated u8 x E | done u8 x E | extra float32 x E x K] as uint8 (a fresh tensor: ONE launch)."""
+        assert (extra is not None) == (self.K > 0)
+        fields = [actions.view(torch.uint8), rewards.view(torch.uint8), terminated.view(torch.uint8), done.view(torch.uint8)]
+        if self.K:
+            fields.append(extra.to(torch.float32).contiguous().view(-1).view(torch.uint8))  # [E][K] row-major
+        return torch.cat(fields)
+
+    def send_begin(self, scal: torch.Tensor, next_obs: torch.Tensor):
+        """Actor rank that is not the learner: ONE group of two sends (record, frames) to the learner rank; nothing may overwrite `next_obs` before `send_end`."""
+        if self.world == 1 or self.is_learner or not self.contributes:
+            return
+        src = [scal, next_obs.contiguous()]
+        if self._staged:
+            src = [t.cpu() for t in src]
+        self._keep = src
+        ops = [dist.P2POp(dist.isend, t, self.learner_rank, self.group) for t in src]
+        self.sent_bytes += sum(t.numel() * t.element_size() for t in src)
+        self._pending = list(dist.batch_isend_irecv(ops))
+
+    def send_end(self):
+        """The current stream waits for the sends `send_begin` started (a stream-level wait on RCCL)."""
+        for work in self._pending:
+            work.wait()
+        self._pending, self._keep = [], None
+
+    def recv_begin(self, slot: int):
+        """Learner rank: ONE group of receives, two per other actor rank, straight into staging slot `slot`."""
+        self._staged_in = []
+        if self.world == 1 or not self.is_learner:
+            return
+        ops = []
+        for r in self.actor_ranks:
+            if r == self.rank:
+                continue
+            i = self.row_of[r]
+            for view in (self.slot_scal[slot][i], self.slot_obs[slot][i * self.E : (i + 1) * self.E]):
+                dst = torch.empty(view.shape, dtype=view.dtype, device="cpu") if self._staged else view
+                if self._staged:
+                    self._staged_in.append((dst, view))
+                ops.append(dist.P2POp(dist.irecv, dst, r, self.group))
+                self.recv_bytes += dst.numel() * dst.element_size()
+        self._pending = list(dist.batch_isend_irecv(ops)) if ops else []
+
+    def recv_end(self):
+        for work in self._pending:
+            work.wait()
+        self._pending = []
+        for host, view in self._staged_in:
+            view.copy_(host.to(self.device))
+        self._staged_in = []
+
+    def put_own(self, slot: int, scal: torch.Tensor, next_obs: torch.Tensor):
+        """Learner rank that also acts: its own transitions never leave its HBM (two device copies into its rows of the slot)."""
+        i = self.row_of[self.rank]
+        self.slot_scal[slot][i].copy_(scal)
+        self.slot_obs[slot][i * self.E : (i + 1) * self.E].copy_(next_obs.view(self.E, self.F))
+
     def broadcast_params(self, flat: torch.Tensor):
         if self.world <= 1 and not self.always_collective:
             return
@@ -187,13 +258,28 @@ def flatten_parameters(module: torch.nn.Module) -> torch.Tensor:
 
 
 class DistributedRainbow:
-    """world ranks x E actors, learner + replay on rank 0 (BASELINE.json config 4 topology applied to Rainbow)."""
+    """world ranks x E actors, learner + replay on rank 0 (BASELINE.json config 4 topology applied to Rainbow; the reference: srl/base/run/play_mp.py:121-165 actor
+    loop, :248-318 trainer + drain thread, :540-571 process layout).
+
+    Roles.  An ACTOR rank runs `RainbowEngine(role="actor")`: the round-4 policy pass (fused policy head, parameter sets published out of band after every
+    weight broadcast, CU-filling first dense layer), one-launch environments, one-launch commit into a short local ring that only stacks frames; per lock-step it
+    ships ONE packed record + its frames to the learner rank (a group of two sends) while its next pass runs.  The LEARNER rank owns ring + tree for the actor
+    ranks' environments.  With `learner_acts` it runs the single-GPU lock-step (update graph beside its own actors' pass) on top; without, only updates.
+
+    The exchange is one lock-step late by construction (slab t arrives while the learner works on t - 1), and the learner commits a slab INSIDE its update: the
+    update's draw samples the tree first (one add older than a commit-first order would show it), the ring commit + tree add of the arrived slab run on a side
+    stream beside the update's network passes, and the priority write-back waits for them -- the tree sees draw, add, write-back in that order
+    (tests/test_dist_gpu.py replays it against the oracle), and the learner rank's period is max(update, receive) instead of update + commit + add.
+    With actor-side initial priorities (cfg.actor_initial_priority, rainbow.py:389-398) the estimates of the items a slab completes travel in the NEXT slab (their last
+    state is evaluated by the next pass); the learner then holds a slab back one more lock-step and commits ring and tree together, so no leaf ever carries the
+    priority of the item it replaced.
+    """
 
     def __init__(self, cfg, device: int, episode_len: int = 200, sync_interval: int = 16, overlap: bool = True, always_collective: bool = False,
-                 learner_acts: Optional[bool] = None, env=None):
+                 learner_acts: Optional[bool] = None, env=None, actor_stream: Optional[str] = None):
         import dataclasses
 
-        from simple_distributed_rl_amd.device.rainbow import RainbowEngine, SyntheticAtariVecEnv
+        from simple_distributed_rl_amd.device.rainbow import RainbowEngine
         from simple_distributed_rl_amd.device.replay import DeviceReplay
 
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -208,164 +294,165 @@ class DistributedRainbow:
         self.acts = self.learner_acts or not self.is_learner  # this rank runs actors
         self.first_actor_rank = 0 if self.learner_acts else 1
         self.n_actor_ranks = self.world - self.first_actor_rank
-        E = cfg.n_envs
+        E = self.E = cfg.n_envs
         H, W_ = cfg.obs_hw
         pad = cfg.multisteps + cfg.window_length
-        # every rank: a short local ring, only for frame stacking of its own envs (no PER use)
-        # every rank draws its environments, its exploration and its padding actions from its OWN stream: ranks acting on the
-        # same broadcast weights must not produce byte-identical transitions (the learner's replay seed stays cfg.seed)
-        local_cfg = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62, seed=cfg.seed + 1_000_003 * self.rank)
-        # the learner rank overlaps its update with its own actors (second stream, private actor copy of the network),
-        # exactly like the single-GPU engine; the other ranks only act
-        # (fast=False: this wrapper drives the engine's pieces in its own order around the transition exchange -- the one-launch commit / environment step, the
-        # draw + gather launch and the in-launch reductions still apply; the published parameter sets and the fused policy head belong to RainbowEngine.step)
-        self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, env=env, overlap=self.is_learner and overlap, fast=False)
-        self.overlap = self.is_learner and overlap
-        self.flat = flatten_parameters(self.local.q_online)
-        # the parameters moved: point the inference kernels (and the fused Adam) at their new home
-        self.local.inf_actor.bind()
-        self.local.inf_online.bind()
-        if isinstance(self.local.optimizer, DeviceAdam):
-            self.local.optimizer.bind()
-        # cfg.actor_initial_priority (rainbow.py:389-398): every actor rank estimates |n-step target - Q(s_0, a_0)| of the items it committed one lock-step earlier from
-        # its cached Q rows (RainbowEngine.actor_td_estimates) and ships the E estimates (-1 = "use max_priority") as one more float field of the packed record;
-        # the learner rank's PER add runs one lock-step behind its ring commit and takes them
         self.actor_priority = bool(cfg.actor_initial_priority)
-        self._minus_one = torch.full((E, 1), -1.0, dtype=torch.float32, device=self.dev)
-        self._est, self._pending_mask = self._minus_one, None
+        self.K = 1 if self.actor_priority else 0
+        self.slots = 3 if self.actor_priority else 2
+        # every rank: a short local ring, only for frame stacking of its own envs (no PER use); every rank draws its environments, its exploration and its padding
+        # actions from its OWN stream: ranks acting on the same broadcast weights must not produce byte-identical transitions (the learner's replay seed stays cfg.seed)
+        local_cfg = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62, seed=cfg.seed + 1_000_003 * self.rank)
         self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective, actor_ranks=range(self.first_actor_rank, self.world),
-                                 extra_floats=1 if self.actor_priority else 0)
-        self.step_count = 0
-        self._in_flight = False  # an exchange started by push_begin and not yet finished
-        self.env_steps_local = 0  # environment steps taken by THIS rank's actors
+                                 extra_floats=self.K)
+        self.bus.enable_slots(self.slots)
         if self.is_learner:
             total = self.n_actor_ranks * E
             ring_len = -(-cfg.memory_capacity // total) + pad
             self.replay = DeviceReplay(
                 total, ring_len, H * W_, cfg.window_length, cfg.multisteps, cfg.n_actions, cfg.batch_size, True, cfg.enable_reward_clip,
                 cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
+                has_duplicate=cfg.memory_has_duplicate,
             )
-            # the learner trains the SAME network object the local actors use; its replay is the global one
+            self.est_buf = torch.full((total,), -1.0, dtype=torch.float32, device=self.dev)
+            role = "both" if self.acts else "learner"
+            self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, env=env, overlap=overlap and self.acts, role=role, learner_replay=self.replay,
+                                       actor_stream=actor_stream if self.acts else None)
         else:
+            self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, env=env, role="actor")
             self.replay = self.local.replay
+            self.local.before_env = self.bus.send_end  # the previous slab's frames must have left before the environments overwrite them
+        self.overlap = self.local.overlap
+        self.flat = flatten_parameters(self.local.q_online)
+        # the parameters moved: point the kernels (and the fused Adam) at their new home
+        for inf in (self.local.inf_actor, self.local.inf_online, self.local.inf_target):
+            if inf is not None and (inf.net is self.local.q_online):
+                inf.bind()
+        if isinstance(self.local.optimizer, DeviceAdam):
+            self.local.optimizer.bind()
+        self._minus_one = torch.full((E, 1), -1.0, dtype=torch.float32, device=self.dev)
+        self.step_count = 0
+        self._next_ingest = 0  # the next slab (= lock-step index) the learner rank has not committed yet
+        self.env_steps_local = 0  # environment steps taken by THIS rank's actors
         self.bus.broadcast_params(self.flat)
-        # first observations of every env -> global ring position 0
-        obs0 = self.local.first_obs  # the frames the local ring was reset with
-        gathered = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, obs0, self._extra())
+        if self.local.fast:
+            self.local._publish_out_of_band()
+        elif self.acts:
+            self.local.inf_actor.weights_changed()
+        # first observations of every env -> global ring position 0 (a one-off synchronous exchange through slot 0; the records are not used)
+        eng = self.local
+        scal = self.bus.pack(eng.actions, eng.env.rewards, eng.env.terminated, eng.env.done, self._minus_one if self.K else None)
         if self.is_learner:
-            self.replay.reset_all(self._actor_rows(gathered)[4])
+            self.bus.recv_begin(0)
+            if self.acts:
+                self.bus.put_own(0, scal, eng.first_obs)
+            self.bus.recv_end()
+            self.replay.reset_all(self.bus.slot_obs[0])
+        else:
+            self.bus.send_begin(scal, eng.first_obs)
+            self.bus.send_end()
+        torch.cuda.synchronize(self.dev)
 
-
-    def _actor_rows(self, gathered):
-        """The staging rows of the actor ranks (a learner-only rank 0 owns row block 0 of the staging buffers and never fills it)."""
-        if self.first_actor_rank == 0:
-            return gathered
-        k = self.first_actor_rank * self.cfg.n_envs
-        return tuple(t[k:] for t in gathered)
-
-    def _extra(self):
-        return self._est if self.actor_priority else None
-
-    def _commit_global(self, gathered):
-        """Learner rank: the gathered lock-step into the global ring + tree.  With actor-side initial priorities the tree add of the PREVIOUS ring commit happens
-        here (its estimates arrived with this slab), and this slab's add waits for the next one."""
-        rows = self._actor_rows(gathered)
+    # ---- learner rank: committing arrived slabs -----------------------------------------------------------------------------------------------------------------
+    def _ingest_fn(self, j: int, with_est: bool):
+        """The launches that commit slab j (ring + tree): staging slot j % slots, estimates (if any) out of the slab behind it."""
+        rp, bus, E, K = self.replay, self.bus, self.E, self.K
+        a = j % self.slots
         if not self.actor_priority:
-            self.replay.commit(*rows[:5])
-            return
-        if self._pending_mask is not None:  # estimates of the previous ring commit's items; the learner's own mask decides where an item exists at all
-            est = torch.where(self._pending_mask != 0, rows[5].reshape(-1), torch.full_like(rows[5].reshape(-1), -2.0)).contiguous()
-            N.check(self.replay.lib.srlx_per_add(self.replay.h_per, self.replay.E, N.tptr(est), N.PRIO_EST_F32, 1, N.torch_stream_ptr()))
-        self.replay.commit(*rows[:5], defer_add=True)
-        self._pending_mask = self.replay.item_mask.clone()
+            def fn():
+                rp.commit_packed(bus.slot_scal[a], E, K, bus.slot_obs[a])
+                rp.add_masked()
+        else:
+            est_src = bus.slot_scal[(j + 1) % self.slots] if with_est else None
 
-    # the learner's replay is the global one: swap it in around learner calls
-    def _with_global_replay(self, fn):
-        eng = self.local
-        saved = eng.replay
-        eng.replay = self.replay
-        try:
-            return fn()
-        finally:
-            eng.replay = saved
+            def fn():
+                rp.commit_packed(bus.slot_scal[a], E, K, bus.slot_obs[a], est_records=est_src, est_out=self.est_buf)
+                rp.add_estimates(self.est_buf)
+        return (a, with_est), fn
 
-    def actor_and_push(self, events=None, random_policy=False):
+    def _ingest_ready(self, k: int):
+        """Slab to commit during lock-step k, or None: slab j has arrived when lock-step j is over; with estimates it also needs slab j + 1."""
+        j = self._next_ingest
+        return j if j <= k - (2 if self.actor_priority else 1) else None
+
+    def _extra(self, random_policy: bool):
+        if not self.actor_priority:
+            return None
+        est = None if random_policy else self.local.actor_td_estimates()
+        return self._minus_one if est is None else est.view(-1, 1)
+
+    def _act(self, events, random_policy: bool):
         eng = self.local
-        if not self.acts:  # learner-only rank: nothing to step, nothing to send (the bus only posts its receives)
-            if events is not None:
-                events[0].record()
-                events[1].record()
-        elif random_policy:
-            eng._random_rest()
+        if random_policy:
+            eng.random_front()
+            extra = self._extra(True)
         else:
             eng.actor_front(events)
-            eng.actor_commit()
+            extra = self._extra(False)  # estimates for the items this rank committed one lock-step ago (their last state has just been evaluated)
+        eng.actor_commit()  # the local ring (frame stacking of this rank's environments)
+        self.env_steps_local += self.E
         env = eng.env
-        if self.acts:
-            self.env_steps_local += self.cfg.n_envs
-        return self.bus.push(eng.actions, env.rewards, env.terminated, env.done, env.next_obs, self._minus_one if self.actor_priority else None)
+        return self.bus.pack(eng.actions, env.rewards, env.terminated, env.done, extra), env.next_obs
 
-    def step(self, learner_updates: int = 1, events=None):
-        """One lock-step of the whole job, software-pipelined over the exchange: the transitions of lock-step t travel
-        (push_begin) while every actor rank already runs the network pass of lock-step t+1, and are committed to the global
-        replay at the start of the learner rank's next call.  Order on every rank (collectives are issued in the same order
-        everywhere): [learner: fork updates] -> network pass -> push_end(t-1) -> [learner: join updates, commit t-1] -> action selection +
-        environments + local ring -> push_begin(t) -> parameter broadcast every `sync_interval` steps."""
-        eng = self.local
-        q = None
-        if self.is_learner and self.overlap:
-            # the updates run beside this lock-step's network pass, on the replay as of the last commit (the exchange in flight is one
-            # lock-step younger: it is committed below, after they have been joined)
-            self._with_global_replay(lambda: eng.fork_learner(learner_updates))
-        if self.acts:  # the network pass reads the local ring only: it does not depend on the exchange in flight
-            q = eng._actor_net(None, events)
-            if self.actor_priority:  # estimates for the items this rank committed one lock-step ago (their last state has just been evaluated)
-                est = eng.actor_td_estimates()
-                self._est = self._minus_one if est is None else est.view(-1, 1)
-        elif events is not None:
-            events[0].record()
-            events[1].record()
-        gathered = self.bus.push_end() if self._in_flight else None
-        self._in_flight = False
+    def step(self, learner_updates: int = 1, events=None, random_policy: bool = False):
+        """One lock-step of the whole job.  Every rank issues exactly one group of point-to-point transfers per lock-step (and every `sync_interval` lock-steps the
+        parameter broadcast behind it), in the same order everywhere."""
+        eng, bus, k = self.local, self.bus, self.step_count
+        U = 0 if random_policy else learner_updates
         if self.is_learner:
-            if self.overlap:
-                eng.join_learner()  # the updates read the replay: they finish before it changes
-            if gathered is not None:
-                self._commit_global(gathered)
-            if self.overlap:
-                if self.acts:  # this rank's actors act on a private copy of the network: refresh it between two updates
+            bus.recv_begin(k % self.slots)  # slab k lands while this lock-step runs
+            j = self._ingest_ready(k)
+            if j is not None:
+                eng.ingest = self._ingest_fn(j, with_est=True)
+            if self.acts:
+                if eng.overlap:
+                    eng.fork_learner(U)  # the update (and the slab's commit inside it) beside this rank's own actors
+                scal, obs = self._act(events, random_policy)
+                bus.put_own(k % self.slots, scal, obs)
+                if eng.overlap:
+                    eng.join_learner()
+                else:
+                    self._learn_inline(U)
+                bus.recv_end()
+                if eng.overlap:
                     eng.refresh_actor_copy()
             else:
-                for _ in range(learner_updates):
-                    self._with_global_replay(eng.learner_step)
-        if self.acts:
-            if eng._select_graph is not None:
-                eng._select_graph.replay()
-            else:
-                eng._actor_select(q)
-            eng.actor_commit()  # the local ring (frame stacking of this rank's environments)
-            self.env_steps_local += self.cfg.n_envs
-        env = eng.env
-        self.bus.push_begin(eng.actions, env.rewards, env.terminated, env.done, env.next_obs, self._extra())
-        self._in_flight = True
+                if events is not None:
+                    events[0].record()
+                    events[1].record()
+                self._learn_inline(U)
+                bus.recv_end()
+            if j is not None:  # (after the updates: their warm-up gate saw the replay as the draw did)
+                self.replay.note_commit()
+                self._next_ingest = j + 1
+        else:
+            scal, obs = self._act(events, random_policy)  # (bus.send_end() of the previous slab sits between the policy pass and the environments)
+            bus.send_begin(scal, obs)
         self.step_count += 1
         if self.step_count % self.sync_interval == 0:
-            if self.is_learner and self.overlap:
+            if self.is_learner:
                 eng.join_learner()  # broadcast consistent weights: not while Adam is writing them
-            self.bus.broadcast_params(self.flat)
+            bus.broadcast_params(self.flat)
+            if not self.is_learner:
+                eng.on_weights_broadcast()
+
+    def _learn_inline(self, updates: int):
+        """Updates that do not run beside this rank's own actors (a learner-only rank; a learner rank without overlap)."""
+        self.local.run_updates(updates)
 
     def flush(self):
-        """Commit the exchange still in flight (end of a run, before the process group goes away)."""
-        if self._in_flight:
-            gathered = self.bus.push_end()
-            self._in_flight = False
-            if self.is_learner:
-                if self.overlap:
-                    self.local.join_learner()
-                if gathered is not None:
-                    self._commit_global(gathered)
-        if self.is_learner and self.overlap:
-            self.local.join_learner()
+        """Commit the slabs that have arrived and are still staged (end of a run / of the filling phase); the last one of a run with actor-side priorities has no
+        estimates behind it and enters at max_priority."""
+        if not self.is_learner:
+            self.bus.send_end()
+            torch.cuda.synchronize(self.dev)
+            return
+        self.local.join_learner()
+        while self._next_ingest < self.step_count:
+            j = self._next_ingest
+            self._ingest_fn(j, with_est=j + 1 < self.step_count)[1]()
+            self.replay.note_commit()
+            self._next_ingest = j + 1
         torch.cuda.synchronize(self.dev)
 
     def prefill(self):
@@ -377,9 +464,8 @@ class DistributedRainbow:
             t = t.to(self.dev)
         dist.broadcast(t, src=0)
         for _ in range(int(t.item())):
-            gathered = self.actor_and_push(random_policy=True)
-            if self.is_learner:
-                self.replay.commit(*self._actor_rows(gathered)[:5])  # (random-policy filling: no network pass, no estimates -- max_priority)
+            self.step(0, random_policy=True)
+        self.flush()
         if self.is_learner:
             g = torch.Generator(device=self.dev)
             g.manual_seed(self.cfg.seed + 1)
@@ -388,11 +474,10 @@ class DistributedRainbow:
         torch.cuda.synchronize(self.dev)
 
     def capture_graphs(self):
-        # actor step: local graph on every rank; learner: graph over the global replay on rank 0
-        if self.acts:
-            self.local.capture_graphs(actor=True, learner=False, warm_actor=False)
+        """The actors' launches stay eager; the learner rank's update is captured per variant (set it publishes into x staging slot it commits) the first time
+        each runs."""
         if self.is_learner:
-            self._with_global_replay(lambda: self.local.capture_graphs(actor=False, learner=True))
+            self.local.enable_lazy_capture()
 
     def actor_forward_flops(self):
         return self.local.actor_forward_flops()
@@ -414,9 +499,9 @@ class DistributedRainbow:
         return self.n_actor_ranks * self.cfg.n_envs
 
     def info(self):
-        d = self.local.info()
-        d["memory"] = self.replay.length()
-        return d
+        if self.is_learner:
+            return self.local.info()
+        return dict(loss=float("nan"), train_count=0, sync=0, memory=0)
 
 
 class DistributedAgent57Light:

@@ -324,6 +324,11 @@ class QNetInference:
         else:
             N.check(self.lib.srlx_qnet_set_priority_sink(self.h, replay.h_per, indices.numel(), N.tptr(indices), N.tptr(priorities), N.PRIO_F32))
 
+    def set_sink_wait(self, ev: Optional[torch.cuda.Event]):
+        """The priority sink's write-back waits for `ev` first (recorded at least once already: torch creates the HIP event lazily); None: no wait."""
+        self._sink_wait = ev  # keeps it alive
+        N.check(self.lib.srlx_qnet_set_sink_wait(self.h, N.c_p(ev.cuda_event) if ev is not None else None))
+
     def set_td_event(self, ev: torch.cuda.Event):
         """`ev` (already recorded once: torch creates the HIP event lazily) is recorded right behind the head kernel of every backward pass from now on."""
         self._td_event = ev  # keeps it alive

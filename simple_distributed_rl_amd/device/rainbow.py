@@ -103,8 +103,13 @@ class RainbowEngine:
     kernels do not cover raise."""
 
     def __init__(self, cfg: RainbowDeviceConfig, device: int = 0, episode_len: int = 200, ring_len: Optional[int] = None, env=None,
-                 overlap: bool = False, fast: Optional[bool] = None, actor_stream: Optional[str] = None):
-        """overlap=True runs the actor's network pass and the learner update concurrently on two HIP
+                 overlap: bool = False, fast: Optional[bool] = None, actor_stream: Optional[str] = None, role: str = "both", learner_replay: Optional[DeviceReplay] = None):
+        """role (device/dist.py): "both" = actors and learner on this GPU; "actor" = a rank that only acts (no target network, no optimiser; its policy passes read
+        parameter sets published out of band after every weight broadcast, `on_weights_broadcast`); "learner" = a rank that only learns (never call the actor pieces).
+        learner_replay: the replay the LEARNER samples and writes back to when it is not this engine's own ring (a learner rank's global replay); the engine's own ring
+        then only stacks frames for its actors: its commits advance the ring position themselves and it gets no tree add.
+
+        overlap=True runs the actor's network pass and the learner update concurrently on two HIP
         streams.  The actor then acts with its own copy of the online network, refreshed after every
         step (the reference's distributed actors do the same on a timer, play_mp.py:121-165), so no
         kernel ever reads weights that another stream is updating.
@@ -124,8 +129,11 @@ class RainbowEngine:
             UPDATE writes -- the first dense layer from the fused Adam's epilogue, the rest with the filter packing of the learner's own next forward -- so the
             32 MB per-lock-step weight copy and the splitting pass are gone; the actors flip to the new set after the join (a host-side pointer swap).
         Actions, ring and tree are bit-identical to the fifteen-launch path (tests/test_fast_lockstep_gpu.py)."""
+        assert role in ("both", "actor", "learner")
         self.cfg = cfg
-        self.overlap = bool(overlap)
+        self.role = role
+        self.learner_replay = learner_replay
+        self.overlap = bool(overlap) and role == "both"
         self.dev = torch.device(f"cuda:{device}")
         self.lib = N.lib()
         torch.manual_seed(cfg.seed)
@@ -153,9 +161,13 @@ class RainbowEngine:
                              f"layer of <= 512 units (average / none) and batches <= 64; got filters={cfg.filters}, hidden={cfg.hidden_units}, batch={B}, "
                              f"frames={cfg.obs_hw}, dueling='{cfg.dueling_type}'.  There is no fallback network path.")
         self.mfma_train = covered and not self.autograd_yardstick
-        fused_adam = self.mfma_train and not self.noisy and os.environ.get("SRLX_NO_FUSED_ADAM", "0") != "1"
-        can_fast = (self.overlap and fused_adam and self.fused_convs and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0 and not cfg.actor_initial_priority
-                    and os.environ.get("SRLX_NO_FUSED_TD", "0") != "1")
+        fused_adam = self.mfma_train and not self.noisy and os.environ.get("SRLX_NO_FUSED_ADAM", "0") != "1" and role != "actor"
+        fast_actor = self.fused_convs and not self.noisy and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0
+        fast_learner = fused_adam and self.fused_convs and os.environ.get("SRLX_NO_FUSED_TD", "0") != "1"
+        # (actor-side initial priorities on one GPU keep the fifteen-launch lock-step: their tree add runs one lock-step behind the ring commit, which the
+        #  deferred-advance commit does not model; a distributed learner -- learner_replay -- commits ring and tree together, two slabs behind: device/dist.py)
+        can_fast = {"both": self.overlap and fast_actor and fast_learner and (not cfg.actor_initial_priority or learner_replay is not None),
+                    "actor": fast_actor, "learner": fast_learner}[role]
         if fast and not can_fast:
             raise ValueError("RainbowEngine(fast=True): needs overlap, the 84 x 84 x 4 / 32-filter geometry, plain dense layers, >= 512 environments in multiples of 128, "
                              "a hidden layer in multiples of 64 and max-priority adds")
@@ -168,15 +180,36 @@ class RainbowEngine:
 
             raw = ctypes.c_void_p()
             N.check(self.lib.srlx_stream_create({"high": -1, "normal": 0, "low": 1}[want], ctypes.byref(raw)))
-            self._actor_stream_raw = raw  # (kept for the life of the process: graphs captured on the stream outlive the engine object in some callers)
+            self._actor_stream_raw = raw
+            self._stream_before = torch.cuda.current_stream(self.dev)  # `close()` hands the thread back to it
             self.actor_stream = torch.cuda.ExternalStream(raw.value, device=self.dev)
-            self.actor_stream.wait_stream(torch.cuda.current_stream(self.dev))
+            self.actor_stream.wait_stream(self._stream_before)
             torch.cuda.set_stream(self.actor_stream)
 
         def make_net():
             return EngineQNet(A, cfg.obs_hw, cfg.window_length, cfg.hidden_units, cfg.filters, cfg.dueling_type, noisy=self.noisy).to(self.dev)
 
         self.q_online = make_net()
+        if role == "actor":  # an actor rank: the online network is the broadcast's landing place, nothing trains here
+            self.q_target = self.q_actor = self.q_online
+            self.inf_actor = QNetInference(self.q_online, E, device, noise_seed=cfg.seed * 3 + 0xA11CE)
+            self.inf_online = self.inf_target = None
+            if self.fast:
+                self.inf_online = QNetInference(self.q_online, 64, device)  # (packs the filters a publish writes: srlx_qnet_publish is a call on the source handle)
+                self.inf_actor.enable_fc1_planes(private_weights=True)
+                self.inf_actor.enable_actor_sets()
+                self.inf_actor.set_fc1_neighbour(0)  # nobody shares the GPU: CU-filling workgroups (83 against 97-130 us at 1024 rows)
+                self._planes_ptr = [self.inf_actor.set_planes_ptr(0), self.inf_actor.set_planes_ptr(1)]
+                self._set, self._published, self._seen_versions, self._fresh_set, self._learner_planes = 0, None, None, None, False
+            elif not self.noisy and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0:
+                self.inf_actor.enable_fc1_planes(private_weights=True)  # (re-split by `on_weights_broadcast`)
+            self.mfma_train = False
+            self.optimizer = None
+            self.actor_priority = bool(cfg.actor_initial_priority)
+            self._init_common(cfg, E, B, A, H, W_)
+            if self.fast:
+                self._publish_out_of_band()
+            return
         self.q_target = make_net()
         self.q_target.eval()
         self.q_target.load_state_dict(self.q_online.state_dict())  # model_torch.py:41-42
@@ -193,10 +226,14 @@ class RainbowEngine:
             self._ev_join = torch.cuda.Event()
         else:
             self.q_actor = self.q_online
+            if learner_replay is not None:  # `run_updates`: a graph three branches wide (online | target | ingest) must be launched from a high-priority stream (tools/README.md, 9)
+                self.s_learner = torch.cuda.Stream(device=self.dev, priority=-1)
         # one inference handle per concurrent user (each owns its activation buffers and, for noisy layers, its noise stream)
         self.inf_actor = QNetInference(self.q_actor, E, device, noise_seed=cfg.seed * 3 + 0xA11CE)
         planes = os.environ.get("SRLX_FC1_PLANES", "auto")
-        if self.fast:
+        if role == "learner":
+            pass  # (never acts: no operand planes, no parameter sets)
+        elif self.fast:
             self.inf_actor.enable_fc1_planes(private_weights=True)  # (the activation planes; the weight planes the passes read are the published sets')
             self.inf_actor.enable_actor_sets()
             # the passes run BESIDE the update: half-CU workgroups in a steady stream instead of one CU-filling workgroup per CU for the whole launch
@@ -223,58 +260,72 @@ class RainbowEngine:
             self.optimizer = DeviceAdam(self.inf_online._params(), lr=cfg.lr)  # model_torch.py:71 as one libsrlx launch over all parameter tensors
         else:
             self.optimizer = torch.optim.Adam(self.q_online.parameters(), lr=cfg.lr, capturable=True, fused=True)
+        self.actor_priority = bool(cfg.actor_initial_priority) and self.mfma
+        self._init_common(cfg, E, B, A, H, W_)
+        d = self.dev
+        self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
+        self._fused_td = os.environ.get("SRLX_NO_FUSED_TD", "0") != "1"  # TD / Huber / priorities inside the backward's head kernel (A/B switch)
+        self.lreplay.count_updates_in(self.train_count_dev)  # train_count += 1 rides on the priority write-back's launch
+        if fused_adam:
+            # the 32 MB first dense layer takes its Adam step inside the backward pass, beside the convolution gradients (A/B switch for measurements)
+            self.optimizer.fuse_first_dense(self.inf_online, self.train_count_dev)
+        if self.fast:
+            if role == "both":
+                self._planes_ptr = [self.inf_actor.set_planes_ptr(0), self.inf_actor.set_planes_ptr(1)]
+            self._set, self._published = 0, None
+            self._seen_versions = None
+            self.inf_target.set_pack_sticky(True)  # the target network's packed filters change at a sync only
+            self._learner_planes = False
+            self._fresh_set = None  # the set whose planes equal the online network's current weight (None: some update did not publish)
+            # the priority write-back leaves the update's critical path: it needs the head kernel's priorities only, so it is the FIRST launch of the backward pass's
+            # weight-gradient branch (srlx_qnet_set_priority_sink; no new branch in the graph -- as a branch of its own it put the update on the actors' hardware queue:
+            # tools/README.md findings 3, 5); the step count it used to advance moves to the update's LAST launch (the packing / publishing one).
+            self._update_side = self._fused_td
+            if (self.actor_stream is not None and want == "low") or role == "learner":  # the actors cannot queue behind a branch of the update: it may run three wide
+                N.check(self.lib.srlx_qnet_set_fc1_branch(self.inf_online.h, 2))
+            if self._update_side:
+                N.check(self.lib.srlx_per_set_update_counter(self.lreplay.h_per, None))
+            if role == "both" and learner_replay is None:
+                self.replay.enable_deferred_advance()
+            self._publish_out_of_band()
+        self.target = torch.zeros(B, dtype=torch.float32, device=d)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=d)
+        self.grad_q0 = torch.zeros((B, A), dtype=torch.float32, device=d)
+        self.priorities = torch.zeros(B, dtype=torch.float32, device=d)
+        self._learner_graph = None
+        self._learner_graphs = {}
+        self._learner_pending = False
+        self._capturing = self._in_capture = False
+        # a learner rank's ingest (device/dist.py): the commit of transitions that arrived from other ranks runs on a side stream between the update's draw and
+        # its priority write-back -- `ingest` = (key, callable issuing the launches) for the NEXT update only
+        self.ingest = None
+        self.s_ingest = torch.cuda.Stream(device=self.dev, priority=-1) if learner_replay is not None else None
+        self._ev_drawn, self._ev_ingested = torch.cuda.Event(), torch.cuda.Event()
+
+    @property
+    def lreplay(self) -> DeviceReplay:
+        """The replay the learner samples and writes back to."""
+        return self.learner_replay if self.learner_replay is not None else self.replay
+
+    def _init_common(self, cfg, E, B, A, H, W_):
+        """What every role needs: the actors' buffers and the first observations."""
+        d = self.dev
         # ---- actor-side initial priorities (cfg.actor_initial_priority; the reference's distributed worker, rainbow.py:389-398) ----
         # The Q rows of the last n + 1 acting passes are kept; one lock-step after an item was committed -- its last state s_n has then been evaluated by
-        # the pass that acts on it -- the existing fused TD kernel turns the cached rows + the item's stored actions / rewards into |target - Q(s_0, a_0)|,
-        # and the item's leaf is ADDED then (the add of a lock-step is deferred by one) with (|td| + eps)^alpha -- two launches per lock-step: srlx_store_actor_td and the add.  The cached online rows stand in for the
-        # target network too (an actor holds no target network here; equal right after a target sync) and are as old as the pass that produced them
-        # (the reference re-evaluates all n + 1 states under the current weights: identical while the weights stand still, tests/test_engine_gpu.py).
+        # the pass that acts on it -- the existing fused TD kernel turns the cached rows + the item's stored actions / rewards into |target - Q(s_0, a_0)|
+        # (ONE launch: srlx_store_actor_td).  On one GPU the item's leaf is ADDED then (the add of a lock-step is deferred by one) with (|td| + eps)^alpha; an
+        # actor rank ships the estimates with its next slab and the learner rank commits ring and tree together, two slabs behind (device/dist.py).  The cached online
+        # rows stand in for the target network too (an actor holds no target network here; equal right after a target sync) and are as old as the pass that
+        # produced them (the reference re-evaluates all n + 1 states under the current weights: identical while the weights stand still, tests/test_engine_gpu.py).
         # Items whose window touches an episode end keep max_priority: the state after a terminal / truncated step is never evaluated by an actor.
-        self.actor_priority = bool(cfg.actor_initial_priority) and self.mfma
         if self.actor_priority:
             n1 = cfg.multisteps + 1
-            d = self.dev
             self.q_hist = torch.zeros((n1, E, cfg.n_actions), dtype=torch.float32, device=d)
             self._passes, self._ap_first_slot = 0, None
             self._ap = dict(pri=torch.zeros(E, dtype=torch.float32, device=d), mask=torch.zeros(E, dtype=torch.uint8, device=d))
         self._select_graph = None
         self._commit_graph = None
-        d = self.dev
-        self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
-        self._fused_td = os.environ.get("SRLX_NO_FUSED_TD", "0") != "1"  # TD / Huber / priorities inside the backward's head kernel (A/B switch)
-        self.replay.count_updates_in(self.train_count_dev)  # train_count += 1 rides on the priority write-back's launch
-        if fused_adam:
-            # the 32 MB first dense layer takes its Adam step inside the backward pass, beside the convolution gradients (A/B switch for measurements)
-            self.optimizer.fuse_first_dense(self.inf_online, self.train_count_dev)
-        self._learner_graphs = {}
-        if self.fast:
-            self._actor_first = os.environ.get("SRLX_ORDER", "learner_first") == "actor_first"
-            self._planes_ptr = [self.inf_actor.set_planes_ptr(0), self.inf_actor.set_planes_ptr(1)]
-            self._set, self._published = 0, None
-            self._seen_versions = None
-            self.inf_target.set_pack_sticky(True)  # the target network's packed filters change at a sync only
-            # SRLX_LEARNER_PLANES=1 (measurement switch, off): the learner's own 128 / 96-row passes on operand planes too -- the online network reads the planes of the set
-            # its LAST update published (they hold exactly its current weight), the target network keeps planes of its own, split at every sync; bit-identical to the
-            # staging-split GEMM (tests/test_fast_lockstep_gpu.py) and SLOWER at these sizes: the planes GEMM streams 47.6 MB of weight planes instead of 32 MB of
-            # float32 (35 against 30 us per pass) and the convolution kernel writes both forms (36 against 29 us): update alone 0.384 against 0.344 ms, lock-step
-            # 0.535 against 0.526 ms on one box (tools/_r4_probe11.sh).
-            self._learner_planes = os.environ.get("SRLX_LEARNER_PLANES", "0") == "1"
-            self._fresh_set = None  # the set whose planes equal the online network's current weight (None: some update did not publish)
-            if self._learner_planes:
-                self.inf_online.enable_fc1_planes(private_weights=False)
-                self.inf_target.enable_fc1_planes(private_weights=True)
-                self.inf_target.set_planes_small(True, None)
-            # the priority write-back leaves the update's critical path: it needs the head kernel's priorities only, so it is the FIRST launch of the backward pass's
-            # weight-gradient branch (srlx_qnet_set_priority_sink; no new branch in the graph -- as a branch of its own it put the update on the actors' hardware queue:
-            # tools/README.md findings 3, 5); the step count it used to advance moves to the update's LAST launch (the packing / publishing one).
-            # SRLX_UPDATE_SIDE=0: the write-back as the update's last launch.
-            self._update_side = self._fused_td and os.environ.get("SRLX_UPDATE_SIDE", "1") != "0"
-            if self.actor_stream is not None and want == "low":  # the actors cannot queue behind a branch of the update: it may run three wide
-                N.check(self.lib.srlx_qnet_set_fc1_branch(self.inf_online.h, 2))
-            if self._update_side:
-                N.check(self.lib.srlx_per_set_update_counter(self.replay.h_per, None))
-            self.replay.enable_deferred_advance()
-            self._publish_out_of_band()
+        self._learner_pending = False
         self.train_count = 0
         self.sync_count = 0
         self.total_env_steps = 0
@@ -283,16 +334,20 @@ class RainbowEngine:
         self.actions = torch.zeros(E, dtype=torch.int32, device=d)
         self.u_policy = torch.zeros(2 * E, dtype=torch.float64, device=d)
         self.policy_counter = torch.zeros(1, dtype=torch.int64, device=d)
-        self.target = torch.zeros(B, dtype=torch.float32, device=d)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=d)
-        self.grad_q0 = torch.zeros((B, A), dtype=torch.float32, device=d)
-        self.priorities = torch.zeros(B, dtype=torch.float32, device=d)
         self._img = (cfg.window_length, H, W_)
-        self._learner_graph = None
-        self._learner_pending = False
+        self.before_env = None  # optional hook between the policy pass and the environments' step
         self.ledger = None  # optional EpisodeLedger (device/vector_runner.py): per-episode returns without leaving HBM
+        self._own_ring_only = self.learner_replay is not None or self.role == "actor"  # the engine's ring only stacks frames: no tree add, the commit moves the position
         self.first_obs = self.env.reset()
         self.replay.reset_all(self.first_obs)
+
+    def close(self):
+        """Hands the calling thread back to the stream it was on before the engine took it to its actors' stream (`actor_stream=`), and destroys that stream."""
+        if getattr(self, "actor_stream", None) is not None:
+            torch.cuda.synchronize(self.dev)
+            torch.cuda.set_stream(self._stream_before)
+            self.actor_stream = None
+            N.check(self.lib.srlx_stream_destroy(self._actor_stream_raw))
 
     # ---- actor (rainbow.py:301-329 + 331-400 for E envs) --------------------------------------
     def _actor_net(self, obs=None, events=None):
@@ -326,17 +381,29 @@ class RainbowEngine:
     # ---- the round-4 lock-step (self.fast) -----------------------------------------------------------------------------------------------------
     def _publish_out_of_band(self):
         """Set `self._set` := the online network as it stands (packed filters, small vectors AND a splitting pass over the first dense layer): start-up and after
-        weights were loaded from outside; the target handle re-packs too.  Runs on the current stream, nothing of the engine in flight."""
+        weights were loaded from outside (a state dict, a broadcast); the target handle re-packs too.  Runs on the current stream, nothing of the engine in flight."""
         self.inf_online.weights_changed()
-        self.inf_online.publish_to(self.inf_actor, self._set, with_fc1=True)
-        self.inf_actor.select_set(self._set)
-        self.inf_target.weights_changed()
-        self.inf_target.publish_to(None)
-        if self._learner_planes:
-            self.inf_target.refresh_own_planes()
+        if self.role == "learner":
+            self.inf_online.publish_to(None)
+        else:
+            self.inf_online.publish_to(self.inf_actor, self._set, with_fc1=True)
+            self.inf_actor.select_set(self._set)
+        if self.inf_target is not None:
+            self.inf_target.weights_changed()
+            self.inf_target.publish_to(None)
         self._fresh_set = self._set
         self._published = None
         self._seen_versions = (self.q_online.weights_version, self.q_target.weights_version)
+
+    def on_weights_broadcast(self):
+        """A broadcast (device/dist.py) has just overwritten the parameters in place: whatever was derived from them is rebuilt (fast: the published set; else
+        the actor handle's operand planes and packed filters)."""
+        if self.fast:
+            if self.role != "actor":
+                self.join_learner()
+            self._publish_out_of_band()
+        else:
+            self.inf_actor.weights_changed()
 
     def _check_versions(self):
         if self._seen_versions != (self.q_online.weights_version, self.q_target.weights_version):  # a state dict was loaded behind the engine's back
@@ -350,10 +417,17 @@ class RainbowEngine:
         if self.ledger is not None:
             self.ledger.account(e.rewards, e.done, self.replay.needs_reset_ptr)
         self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs, defer_add=True, next_table=True, bump=self.policy_counter)
+        if self.actor_priority:  # what the estimates of the NEXT pass will need (the items this commit completed)
+            r = self.replay
+            self._ap["mask"].copy_(r.item_mask)
+            self._ap_first_slot = ((r._steps_committed - 1) * self.cfg.n_envs) % r.capacity
+            self._passes += 1
 
     def actor_commit_tree(self):
-        """fast: the tree half -- the PER add at max_priority, which also moves the ring position; behind the join (the learner writes the tree and reads the position)."""
-        self.replay.add_masked()
+        """fast: the tree half -- the PER add at max_priority, which also moves the ring position; behind the join (the learner writes the tree and reads the position).
+        Nothing where the engine's ring only stacks frames (an actor rank; a learner rank's own actors): that ring's commit has moved the position itself."""
+        if not self._own_ring_only:
+            self.replay.add_masked()
         self.total_env_steps += self.cfg.n_envs
 
     def actor_td_estimates(self):
@@ -386,7 +460,8 @@ class RainbowEngine:
         if self.fast:
             self.actor_front()
             self.actor_commit_ring()
-            self.replay.add_masked()
+            if not self._own_ring_only:
+                self.replay.add_masked()
             return
         if self.actor_priority:  # the deferred add and its bookkeeping (mask, first slot, pass count) live in the piecewise calls: take exactly that path
             self.actor_front()
@@ -397,9 +472,9 @@ class RainbowEngine:
         self._actor_select(self._actor_net())
         self._actor_commit()
 
-    def _random_rest(self):
-        """One lock-step with uniformly random actions (epsilon = 1, no network): used to fill the replay."""
-        r, cfg = self.replay, self.cfg
+    def random_front(self):
+        """Uniformly random actions (epsilon = 1, no network) + the environments' step: the front of a lock-step that fills the replay."""
+        cfg = self.cfg
         E = cfg.n_envs
         st = N.torch_stream_ptr()
         if not hasattr(self, "_ones"):
@@ -407,8 +482,18 @@ class RainbowEngine:
             self._zq = torch.zeros((E, cfg.n_actions), dtype=torch.float32, device=self.dev)
         N.check(self.lib.srlx_rng_uniform(cfg.seed ^ 0xF111, N.tptr(self.policy_counter), self.u_policy.numel(), N.tptr(self.u_policy), st))
         N.check(self.lib.srlx_policy_epsilon_greedy(E, cfg.n_actions, N.tptr(self._zq), N.tptr(self._ones), N.tptr(self.u_policy), None, N.tptr(self.actions), st))
-        next_obs, rewards, terminated, done = self.env.step(self.actions)
-        r.commit(self.actions, rewards, terminated, done, next_obs)
+        if self.before_env is not None:
+            self.before_env()
+        return self.env.step(self.actions)
+
+    def _random_rest(self):
+        """One lock-step with uniformly random actions: used to fill the replay."""
+        next_obs, rewards, terminated, done = self.random_front()
+        self.replay.commit(self.actions, rewards, terminated, done, next_obs)
+
+    def enable_lazy_capture(self):
+        """From now on every update variant (published set x ingest key) is captured into a HIP graph the first time it runs and replayed afterwards."""
+        self._capturing = True
 
     def prefill(self, randomise_priorities: bool = True):
         """Untimed set-up of the benchmark state: a random-policy rollout until every PER leaf holds an
@@ -455,11 +540,12 @@ class RainbowEngine:
         return tuple(c.obs_hw) == (84, 84) and c.window_length == 4 and c.filters == 32 and os.environ.get("SRLX_NO_FUSED_CONV", "0") != "1"
 
     # ---- learner (model_torch.py:85-122) -----------------------------------------------------
-    def _learner_body(self, publish: Optional[int] = None, planes_set: Optional[int] = None):
+    def _learner_body(self, publish: Optional[int] = None, ingest=None):
         """One Rainbow update.  fast engines: `publish` = the actor set (0 / 1) this update also writes -- the first dense layer as operand planes from the fused
         Adam's epilogue, packed filters and small vectors with the packing launch that follows the optimiser step (None: that launch only packs for this handle's
-        own next forward)."""
-        cfg, r = self.cfg, self.replay
+        own next forward).  `ingest` (a learner rank, device/dist.py): a callable issuing the launches that commit transitions from other ranks; they run on a side
+        stream behind the draw (the update samples the tree one add older) and the priority write-back waits for them: the tree sees draw -> add -> write-back."""
+        cfg, r = self.cfg, self.lreplay
         B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
         pe = getattr(self, "_phase_mark", None)  # tools/lockstep_phases.py: timing events recorded inside the (captured) update; None in production
 
@@ -467,15 +553,23 @@ class RainbowEngine:
             if pe is not None:
                 pe(i)
 
+        def fork_ingest(cur):
+            if ingest is None:
+                return
+            self._ev_drawn.record(cur)
+            self.s_ingest.wait_event(self._ev_drawn)
+            with torch.cuda.stream(self.s_ingest):
+                ingest()
+                self._ev_ingested.record(self.s_ingest)
+
         mark(0)
         if self.fast:
             self.inf_online.fuse_adam_planes(self._planes_ptr[publish] if publish is not None else None)
-            if self._learner_planes:  # planes_set: the published set that holds the online network's current first-dense-layer weight (None: none does)
-                self.inf_online.set_planes_small(planes_set is not None, self._planes_ptr[planes_set] if planes_set is not None else None)
         if self.mfma_train:
             b = r.sample_items(self.train_count_dev, all_states=True)
             mark(1)
             cur = torch.cuda.current_stream(self.dev)
+            fork_ingest(cur)
             self._ev_t0.record(cur)
             self.s_target.wait_event(self._ev_t0)
             with torch.cuda.stream(self.s_target):  # fork: target network (rainbow.py:221) alongside the online network
@@ -493,6 +587,7 @@ class RainbowEngine:
             # model_torch.py:107-109 without autograd: every p.grad is (over)written by the backward kernels
             if self.fast and self._update_side:
                 self.inf_online.set_priority_sink(r, b.indices, self.priorities)
+                self.inf_online.set_sink_wait(self._ev_ingested if ingest is not None else None)
             if self._fused_td:  # ... in the prologue of the backward's first kernel
                 self.inf_online.backward_td_u8(r.obs_base, r.frame_off_all, n, q_all, q_tg_next, b.actions, b.rewards, b.terminated, b.weights, cfg.discount,
                                                cfg.retrace_h, cfg.enable_double_dqn, cfg.enable_rescale, self.target, self.loss, self.grad_q0, self.priorities)
@@ -508,6 +603,8 @@ class RainbowEngine:
             mark(4)
             self.optimizer.step(self.train_count_dev)
             mark(5)
+            if ingest is not None:
+                cur.wait_event(self._ev_ingested)  # (the side stream joins: a capture must see it come back; a write-back on this stream must follow the add)
             if self.fast:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors); train_count_dev += 1
                 self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0,
                                            bump=self.train_count_dev if self._update_side else None)
@@ -516,6 +613,8 @@ class RainbowEngine:
                     return
         else:  # SRLX_TORCH_BACKWARD=1: the test yardstick -- matrix-core evaluation of s_1..s_n, autograd for the gradient step
             b = r.sample_items(self.train_count_dev)
+            cur = torch.cuda.current_stream(self.dev)
+            fork_ingest(cur)
             foff = r.frame_off_next.view(B * n, cfg.window_length)
             q_on_next = self.inf_online.forward_u8(r.obs_base, foff)  # rainbow.py:220
             q_tg_next = self.inf_target.forward_u8(r.obs_base, foff)  # rainbow.py:221
@@ -530,19 +629,26 @@ class RainbowEngine:
             self.optimizer.zero_grad(set_to_none=False)
             q0.backward(self.grad_q0)  # model_torch.py:107-109: d loss / d q seeds autograd
             self.optimizer.step()
+            if ingest is not None:
+                cur.wait_event(self._ev_ingested)
         r.update(b.indices, self.priorities)  # model_torch.py:113-114; train_count_dev += 1 in the same launch (count_updates_in)
 
-    def learner_step(self, publish: Optional[int] = None, planes_set: Optional[int] = None) -> bool:
-        """Returns False while the replay is below warm-up (priority_replay_buffer.py:228-230)."""
-        if self.replay.is_warmup_needed():
+    def learner_step(self, publish: Optional[int] = None) -> bool:
+        """Returns False while the replay is below warm-up (priority_replay_buffer.py:228-230).  A pending `self.ingest` rides on this update."""
+        if self.lreplay.is_warmup_needed():
             return False
-        if self.fast and not self._learner_planes:
-            planes_set = None
-        g = self._learner_graphs.get((publish, planes_set)) if self.fast else self._learner_graph
+        if self.fast:
+            self._check_versions()  # (a state dict loaded behind the engine's back: re-pack before anything trains on stale filters)
+        ing, self.ingest = self.ingest, None
+        key = (publish, ing[0] if ing is not None else None)
+        g = self._learner_graphs.get(key)
+        if g is None and self._capturing and not self._in_capture:  # a combination first seen after `capture_graphs`: captured now, replayed from then on
+            torch.cuda.current_stream(self.dev).synchronize()
+            g = self._capture_learner(key, ing[1] if ing is not None else None)
         if g is not None:
             g.replay()
         else:
-            self._learner_body(publish, planes_set) if self.fast else self._learner_body()
+            self._learner_body(publish, ing[1] if ing is not None else None)
         if self.fast:
             self._fresh_set = publish  # the planes of that set now hold the online weight (None: no set does)
         # model_torch.py:117-119 (fires at train_count 0 too)
@@ -551,14 +657,23 @@ class RainbowEngine:
         self.train_count += 1
         return True
 
+    def _capture_learner(self, key, ingest_fn):
+        g = torch.cuda.CUDAGraph()
+        self._in_capture = True
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
+                self._learner_body(key[0], ingest_fn)
+        finally:
+            self._in_capture = False
+        self._learner_graphs[key] = g
+        return g
+
     def sync_target(self):
         with torch.no_grad():
             torch._foreach_copy_(list(self.q_target.parameters()), list(self.q_online.parameters()))
         if self.fast:  # the target handle keeps its packed filters between syncs: re-pack them now (current stream: the learner's)
             self.inf_target.weights_changed()
             self.inf_target.publish_to(None)
-            if self._learner_planes:
-                self.inf_target.refresh_own_planes()
         self.sync_count += 1
 
     # ---- the pieces of a step (the Runner's vectorised loop drives them one by one: device/vector_runner.py) --------
@@ -574,25 +689,39 @@ class RainbowEngine:
             self._check_versions()
         if not marked:
             self.fork_point()
-
-        def body():
-            self.s_learner.wait_event(self._ev_fork)
-            ran = 0
-            with torch.cuda.stream(self.s_learner):
-                for k in range(updates):
-                    if self.fast:
-                        pub = 1 - self._set if k == updates - 1 else None  # the last update of the lock-step publishes into the set the actors are NOT reading
-                        ok = self.learner_step(pub, self._fresh_set)
-                        if ok and pub is not None:
-                            self._published = pub
-                    else:
-                        ok = self.learner_step()
-                    ran += int(ok)
-                self._ev_join.record(self.s_learner)
-            return ran
-
+        self.s_learner.wait_event(self._ev_fork)
+        ran = 0
+        with torch.cuda.stream(self.s_learner):
+            for k in range(updates):
+                if self.fast:
+                    pub = 1 - self._set if k == updates - 1 else None  # the last update of the lock-step publishes into the set the actors are NOT reading
+                    ok = self.learner_step(pub)
+                    if ok and pub is not None:
+                        self._published = pub
+                else:
+                    ok = self.learner_step()
+                ran += int(ok)
+            if self.ingest is not None:  # no update took the pending ingest with it (warm-up, or none asked for): commit it here, in stream order
+                ing, self.ingest = self.ingest, None
+                ing[1]()
+            self._ev_join.record(self.s_learner)
         self._learner_pending = True
-        return body()
+        return ran
+
+    def run_updates(self, updates: int) -> int:
+        """`updates` learner updates NOT beside this engine's actors (a learner-only rank; a learner rank without overlap): on the learner's launch stream, ordered
+        after the current stream and joined back to it.  A pending `ingest` rides on the first update or runs by itself."""
+        cur = torch.cuda.current_stream(self.dev)
+        self.s_learner.wait_stream(cur)
+        ran = 0
+        with torch.cuda.stream(self.s_learner):
+            for _ in range(updates):
+                ran += int(self.learner_step())
+            if self.ingest is not None:
+                ing, self.ingest = self.ingest, None
+                ing[1]()
+        cur.wait_stream(self.s_learner)
+        return ran
 
     def join_learner(self):
         """The current stream waits for the forked updates (before the next write to the replay)."""
@@ -616,12 +745,17 @@ class RainbowEngine:
             off = self.replay.frame_table_current()  # (no launch: the last commit wrote it)
             if events is not None:
                 events[0].record()
-            self.inf_actor.forward_u8_policy(self.replay.obs_base, off, self.eps, self.cfg.seed ^ 0xAC7, self.policy_counter, self.actions)
+            self.inf_actor.forward_u8_policy(self.replay.obs_base, off, self.eps, self.cfg.seed ^ 0xAC7, self.policy_counter, self.actions,
+                                             q_copy=self.q_hist[self._passes % self.q_hist.shape[0]] if self.actor_priority else None)
             if events is not None:
                 events[1].record()
+            if self.before_env is not None:  # (device/dist.py: the exchange of the previous lock-step must be over before the environments overwrite what it ships)
+                self.before_env()
             self.env.step(self.actions)
             return
         q = self._actor_net(None, events)  # eager launches, bracketed by the events
+        if self.before_env is not None:
+            self.before_env()
         if self._select_graph is not None:
             self._select_graph.replay()
         else:
@@ -633,7 +767,12 @@ class RainbowEngine:
             self.actor_commit_ring()
             self.actor_commit_tree()
             return
-        if self._commit_graph is not None:
+        if self._own_ring_only:  # the ring only stacks frames for this engine's actors
+            e = self.env
+            if self.ledger is not None:
+                self.ledger.account(e.rewards, e.done, self.replay.needs_reset_ptr)
+            self.replay.commit(self.actions, e.rewards, e.terminated, e.done, e.next_obs, defer_add=True)
+        elif self._commit_graph is not None:
             self._commit_graph.replay()
             self.replay._steps_committed += 1
         else:
@@ -650,13 +789,8 @@ class RainbowEngine:
         torch events recorded around the dominant hand-written kernel group of the actor on its launch
         stream: the matrix-core network pass (or, on the torch path, the frame-stack kernel)."""
         if self.fast:
-            if self._actor_first:  # the host issues the actors' four launches BEFORE the update's graph (whose launch keeps the host busy for tens of microseconds)
-                self.fork_point()
-                self.actor_front(events)
-                self.fork_learner(learner_updates, marked=True)
-            else:
-                self.fork_learner(learner_updates)
-                self.actor_front(events)
+            self.fork_learner(learner_updates)
+            self.actor_front(events)
             self.actor_commit_ring()  # before the join: nothing the learner reads
             self.join_learner()
             self.actor_commit_tree()
@@ -680,33 +814,30 @@ class RainbowEngine:
     def capture_graphs(self, actor: bool = True, learner: bool = True, warm_actor: bool = True, warm_learner: bool = True):
         """Captures the actor step and the learner step into HIP graphs (launch-bound inner loops).
         Call after warm-up: arenas are sized and the replay is past its warm-up gate.  `warm_actor=False` skips the
-        extra eager actor step (the distributed wrapper has already stepped, and an un-pushed step would desynchronise
-        the learner's global ring from this rank's environments)."""
+        extra eager actor step (a distributed wrapper has already stepped, and an un-pushed step would desynchronise
+        the learner's global ring from this rank's environments).  Update variants that were not captured here (a learner rank's ingest keys) are captured the
+        first time they run."""
         torch.cuda.synchronize(self.dev)
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
-            if actor and warm_actor:
+            if actor and warm_actor and self.role != "learner":
                 self.actor_step()
                 self.total_env_steps += self.cfg.n_envs
-            if learner and warm_learner and not self.replay.is_warmup_needed():
+            if learner and warm_learner and self.role != "actor" and not self.lreplay.is_warmup_needed() and self.ingest is None:
                 self.learner_step()  # a real update (eager: sizes the arenas), target sync and counters included
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
-        if self.fast:  # the actors' six launches stay eager; the update is captured three times: publishing into set 0 / set 1 / not at all
-            if learner and not self.replay.is_warmup_needed():
-                keys = [(None, None), (0, None), (1, None)]  # (set the update publishes into, set whose planes hold the online weight)
-                if self._learner_planes:
-                    keys += [(0, 1), (1, 0), (None, 0), (None, 1)]
-                for key in keys:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        self._learner_body(*key)
-                    self._learner_graphs[key] = g
+        if learner and self.role != "actor":
+            self._capturing = True
+        if self.fast:  # the actors' launches stay eager; the update is captured per variant: publishing into set 0 / set 1 / not at all
+            if learner and self.role != "actor" and not self.lreplay.is_warmup_needed() and self.learner_replay is None:
+                for key in ([(None, None), (0, None), (1, None)] if self.role == "both" else [(None, None)]):
+                    self._capture_learner(key, None)
                 self._learner_graph = self._learner_graphs[(None, None)]
             torch.cuda.synchronize(self.dev)
             return
-        if actor:
+        if actor and self.role != "learner" and not self._own_ring_only:
             q = self._actor_net(None)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
@@ -717,15 +848,13 @@ class RainbowEngine:
                 self._actor_commit()
             self.replay._steps_committed -= 1  # capture does not execute
             self._commit_graph = g
-        if learner and not self.replay.is_warmup_needed():
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
-                self._learner_body()
-            self._learner_graph = g
+        if learner and self.role != "actor" and not self.lreplay.is_warmup_needed() and self.learner_replay is None:
+            self._learner_graph = self._capture_learner((None, None), None)
         torch.cuda.synchronize(self.dev)
 
     def refresh_host_mirrors(self):
         N.check(self.lib.srlx_per_refresh(self.replay.h_per, N.torch_stream_ptr()))
 
     def info(self):
-        return dict(loss=float(self.loss.item()), train_count=self.train_count, sync=self.sync_count, memory=self.replay.length())
+        self.lreplay.check_draws()
+        return dict(loss=float(self.loss.item()), train_count=self.train_count, sync=self.sync_count, memory=self.lreplay.length())

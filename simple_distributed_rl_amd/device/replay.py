@@ -103,6 +103,8 @@ class DeviceReplay:
         self.deferred_advance = False
         self._fused_draw = __import__("os").environ.get("SRLX_NO_SAMPLE_GATHER", "0") != "1"  # (A/B switch)
         self.table_fresh = False  # `frame_off_actor` holds the table of the CURRENT ring position (written by the last commit)
+        self.has_duplicate = bool(has_duplicate)
+        self._drew = False
 
     def enable_deferred_advance(self):
         """The round-4 lock-step: a commit leaves the ring position where it is and the PER add that closes the lock-step advances it inside its own launch
@@ -151,6 +153,35 @@ class DeviceReplay:
             self.add_masked()
         self._steps_committed += 1
 
+    def commit_packed(self, records: torch.Tensor, envs_per_record: int, extra_floats: int, next_obs: torch.Tensor, est_records: Optional[torch.Tensor] = None,
+                      est_out: Optional[torch.Tensor] = None):
+        """The ring commit of a lock-step that arrived as packed records (uint8 [ranks][record bytes], device/dist.py) -- LAUNCH ONLY: no host bookkeeping, so the call
+        may sit inside a captured graph; the caller reports every execution with `note_commit()`.  The ring position advances inside the launch.  est_records /
+        est_out: srlx_store_commit_step_packed."""
+        assert records.dtype == torch.uint8 and records.dim() == 2 and records.is_contiguous()
+        N.check(self.lib.srlx_store_commit_step_packed(self.h_store, N.tptr(records), records.shape[1], int(envs_per_record), int(extra_floats), N.tptr(next_obs),
+                                                       N.tptr(self.item_mask), N.tptr(est_records), N.tptr(est_out), 1, N.torch_stream_ptr()))
+
+    def note_commit(self):
+        """One `commit_packed` launch has been enqueued for execution (eagerly or by a graph replay)."""
+        self._steps_committed += 1
+        self.table_fresh = False
+
+    def add_estimates(self, est: torch.Tensor):
+        """The PER add of the last committed lock-step with actor-side estimates: float32 [E], >= 0 an |td| estimate, -1 max_priority, -2 no item (SRLX_PRIO_EST_F32)."""
+        assert est.dtype == torch.float32 and est.numel() == self.E
+        N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(est), N.PRIO_EST_F32, 1, N.torch_stream_ptr()))
+
+    def check_draws(self):
+        """Host-side check of the last draw (synchronises): a draw without duplicates that ran out of uniforms left the batch untouched (`used` = -1) -- silently
+        training on the previous batch would be the alternative.  Called where the host synchronises anyway (engine.info())."""
+        if not self._drew:
+            return
+        used = int(self.used.item())
+        if used < 0:
+            raise RuntimeError(f"DeviceReplay: the last draw of {self.B} items (has_duplicate={self.has_duplicate}) ran out of uniforms ({self.u.numel()} supplied): "
+                               "fewer distinct non-zero leaves than the batch needs, or raise sample_slack")
+
     def add_masked(self):
         """The PER add of the last committed lock-step at max_priority (0 where `item_mask` says the lock-step completed no item for the lane)."""
         N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(self.item_mask), N.PRIO_NONE_MASKED, 1, N.torch_stream_ptr()))
@@ -176,6 +207,7 @@ class DeviceReplay:
         """B indices + IS weights into `self.batch`.  Without explicit uniforms the sampler generates them itself from the keyed counter
         generator (srlx_per_sample_keyed: the values srlx_rng_uniform would have written for this seed and counter, one launch less)."""
         b = self.batch
+        self._drew = True
         if uniforms is None:
             N.check(self.lib.srlx_per_sample_keyed(self.h_per, self.B, N.tptr(d_step), self.seed ^ 0x5EED, N.tptr(self.rng_counter), self.u.numel(), N.tptr(b.indices),
                                                    None, N.tptr(b.weights), N.tptr(self.used), st))
@@ -235,6 +267,7 @@ class DeviceReplay:
         all_states=True (hand-written training pass): the table of s_0..s_n (`frame_off_all`) instead of the pixels."""
         st = N.torch_stream_ptr()
         b = self.batch
+        self._drew = True
         if all_states and uniforms is None and self.B <= 64 and self._fused_draw:  # the draw and the gather as ONE launch (srlx_per_sample_gather_train)
             N.check(self.lib.srlx_per_sample_gather_train(self.h_per, self.h_store, self.B, N.tptr(d_step), self.seed ^ 0x5EED, N.tptr(self.rng_counter), self.u.numel(),
                                                           N.tptr(b.indices), N.tptr(b.weights), N.tptr(self.used), N.tptr(self.frame_off_all), N.tptr(self.frame_off_next),

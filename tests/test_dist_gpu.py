@@ -169,8 +169,8 @@ def test_bench_multi_rank_rehearsal(n, actor_gpus, launcher):
     per_step = inner * 128 * actor_gpus
     assert d["config"]["transitions_per_step"] == per_step
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - per_step) < 1e-6 * per_step  # value = all actor ranks' env-steps / time
-    # one update per lock-step: eager warm-up (warmup x min(inner, 8)), graph capture (1), 2 after it, warm-up, timed region
-    assert d["final"]["train_count"] == warmup * min(inner, 8) + 1 + 2 + warmup * inner + steps * inner
+    # one update per lock-step: eager warm-up (warmup x min(inner, 8)), 2 after the switch to graphs (captured lazily: no extra update), warm-up, timed region
+    assert d["final"]["train_count"] == warmup * min(inner, 8) + 2 + warmup * inner + steps * inner
     assert "cpu_baseline" not in d and d["roofline"]["avg_launch_ms"] > 0 and d["roofline"]["pass"]["avg_launch_group_ms"] > 0
 
 
@@ -420,3 +420,152 @@ def test_actor_ranks_ship_initial_priorities(learner_acts):
     assert d["per_step"] == (16 if learner_acts else 8) and d["added"] > 30 * d["per_step"] and d["max_priority"] == 1.0
     assert d["estimated"] > 0.5 * d["added"] and d["at_max"] > 0 and d["empty"] > 0
     assert d["max_rel"] < 2e-4, d
+
+
+# ---- round 5: the distributed job on the round-4 lock-step; the learner rank commits arrived slabs INSIDE its update -------------------------------------------------
+def _fast_worker(rank, world, port, ret, learner_acts, actor_priority):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_distributed_rl_amd.device.dist import DistributedRainbow
+        from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig
+
+        E = 512
+        n_act = world if learner_acts else world - 1
+        cfg = RainbowDeviceConfig(n_envs=E, batch_size=32, memory_capacity=E * n_act * 12, memory_warmup_size=E * n_act * 2, seed=5, target_model_update_interval=4,
+                                  actor_initial_priority=actor_priority)
+        eng = DistributedRainbow(cfg, 0, episode_len=9, sync_interval=3, learner_acts=learner_acts)
+        assert eng.local.fast, "every rank of the job runs the round-4 lock-step"
+        steps = 12
+        for k in range(steps):
+            if k == 6:
+                eng.capture_graphs()
+            eng.step(learner_updates=1)
+        eng.flush()
+        torch.cuda.synchronize()
+        out = {"flat_sum": float(eng.flat.double().sum().item()), "role": eng.local.role, "env_steps_local": int(eng.env_steps_local)}
+        if rank == 0:
+            out.update(eng.info())
+            out["per"] = eng.replay.per_state()
+            out["graphs"] = sorted(str(k) for k in eng.local._learner_graphs)
+            out["global_envs"] = eng.replay.E
+        else:
+            out["set_reads"] = int(eng.local._set)
+        ret[rank] = out
+    except Exception:
+        import traceback
+
+        ret[f"error{rank}"] = traceback.format_exc()
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("learner_acts,actor_priority", [(True, False), (False, False), (False, True)])
+def test_distributed_rainbow_on_the_fast_lockstep(learner_acts, actor_priority):
+    """Two ranks, 512 environments each at the benchmark geometry: every rank runs the round-4 lock-step (`fast`) -- an actor rank the fused policy pass on
+    parameter sets it republishes after each broadcast, the learner rank its update with the arrived slab's ring commit + tree add on a side branch of the update
+    (captured per staging slot once graphs are switched on).  The global replay ends up with every lock-step of every actor rank; the actor rank holds the
+    learner's weights after the last broadcast."""
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    try:
+        mp.spawn(_fast_worker, args=(2, _free_port(), ret, learner_acts, actor_priority), nprocs=2, join=True)
+    except Exception:
+        errs = [v for k, v in sorted(ret.items(), key=lambda kv: str(kv[0])) if str(k).startswith("error")]
+        raise AssertionError("worker failed:\n" + "\n".join(errs))
+    r0, r1 = ret[0], ret[1]
+    n_act = 2 if learner_acts else 1
+    assert r0["role"] == ("both" if learner_acts else "learner") and r1["role"] == "actor"
+    assert r0["global_envs"] == 512 * n_act
+    assert r0["memory"] == min(12 * 512 * n_act, r0["per"]["size"]) and r0["per"]["size"] == 12 * 512 * n_act  # every slab of every actor rank was committed
+    assert r0["train_count"] >= 8 and r0["loss"] == r0["loss"]
+    assert len(r0["graphs"]) >= 2  # one captured update per staging slot (x published set where the learner rank acts)
+    assert r0["flat_sum"] == r1["flat_sum"]  # lock-step 12 ended with a broadcast (sync_interval 3)
+    assert r1["env_steps_local"] == 12 * 512 and r0["env_steps_local"] == (12 * 512 if learner_acts else 0)
+
+
+def _order_worker(rank, world, port, ret, fast):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes
+
+        import numpy as np
+
+        import hot_path_oracle as H
+        from oracle_bindings import ADD_RAW, OraclePER
+        from simple_distributed_rl_amd import _native as N
+        from simple_distributed_rl_amd.device.dist import DistributedRainbow
+        from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig
+
+        if fast:
+            cfg = RainbowDeviceConfig(n_envs=512, batch_size=32, memory_capacity=512 * 9, memory_warmup_size=512 * 4, seed=11, target_model_update_interval=5)
+        else:
+            cfg = RainbowDeviceConfig(n_envs=16, batch_size=8, memory_capacity=16 * 2 * 20, memory_warmup_size=48, obs_hw=(20, 20), hidden_units=32, n_actions=4, seed=11,
+                                      target_model_update_interval=5)
+        eng = DistributedRainbow(cfg, 0, episode_len=7, sync_interval=4)
+        assert eng.local.fast == fast
+        rp = eng.replay
+        E, B = rp.E, cfg.batch_size
+        o = OraclePER(rp.capacity, cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, True, cfg.memory_epsilon)
+        checked = 0
+        for k in range(26):
+            if k == 14:
+                eng.capture_graphs()
+            counter0, trained0, ingested0 = int(rp.rng_counter.item()), eng.local.train_count, eng._next_ingest
+            eng.step(learner_updates=1)
+            torch.cuda.synchronize()
+            # the learner's side of this lock-step, replayed on the oracle in the order the tree must have seen: draw -> add (the slab committed inside the update) -> write-back
+            if eng.local.train_count > trained0:
+                u = H.rng_uniform(cfg.seed ^ 0x5EED, counter0, rp.u.numel())
+                used, idx, w, _ = o.sample(B, trained0, u)
+                assert used == int(rp.used.item()) and used > 0
+                np.testing.assert_array_equal(rp.batch.indices.cpu().numpy(), idx)
+                np.testing.assert_allclose(rp.batch.weights.cpu().numpy(), (w / 1.0).astype(np.float32), rtol=1e-6)
+                checked += 1
+            if eng._next_ingest > ingested0:
+                for m in rp.item_mask.cpu().numpy():
+                    if m:
+                        o.add(None)
+                    else:
+                        o.add(0.0, mode=ADD_RAW)
+            if eng.local.train_count > trained0:
+                o.update(idx, eng.local.priorities.cpu().numpy())
+        eng.flush()
+        torch.cuda.synchronize()
+        for m in rp.item_mask.cpu().numpy():  # (the flush committed the last slab)
+            o.add(None) if m else o.add(0.0, mode=ADD_RAW)
+        mp_, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+        tree = np.empty(2 * rp.capacity - 1)
+        N.check(rp.lib.srlx_per_backup(rp.h_per, ctypes.byref(mp_), ctypes.byref(size), ctypes.byref(write), N.np_ptr(tree)))
+        ret[rank] = dict(checked=checked, tree_equal=bool((tree == o.tree()).all()), max_priority=(mp_.value, o.max_priority), write=(write.value, o.write),
+                         graphs=len(eng.local._learner_graphs))
+    except Exception:
+        import traceback
+
+        ret[f"error{rank}"] = traceback.format_exc()
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_learner_rank_tree_order_is_draw_add_writeback(fast):
+    """The learner rank commits a slab on a side branch of its update: the update's draw samples the tree BEFORE that slab's add, the priority write-back lands AFTER
+    it.  Replayed on the CPU oracle in exactly that order (draw with the keyed uniforms, E adds at max_priority / 0, update with the priorities the update produced):
+    every sampled index and the final tree are bit-equal -- eagerly and from the captured graphs."""
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    try:
+        mp.spawn(_order_worker, args=(1, _free_port(), ret, fast), nprocs=1, join=True)
+    except Exception:
+        errs = [v for k, v in sorted(ret.items(), key=lambda kv: str(kv[0])) if str(k).startswith("error")]
+        raise AssertionError("worker failed:\n" + "\n".join(errs))
+    d = ret[0]
+    assert d["checked"] >= 15 and d["graphs"] >= 2, d
+    assert d["tree_equal"] and d["max_priority"][0] == d["max_priority"][1] and d["write"][0] == d["write"][1], d

@@ -141,7 +141,7 @@ def main():
         from simple_distributed_rl_amd.device.dist import DistributedRainbow
 
         eng = DistributedRainbow(cfg, dev_index, args.episode_len, sync_interval=args.sync_interval, always_collective=args.dist_selftest,
-                                 learner_acts=learner_acts)
+                                 learner_acts=learner_acts, actor_stream=None if args.actor_stream == "default" else args.actor_stream)
         assert eng.n_actor_ranks == actor_ranks
     else:
         eng = RainbowEngine(cfg, dev_index, args.episode_len, overlap=not args.no_overlap, actor_stream=None if args.actor_stream == "default" else args.actor_stream)
@@ -223,7 +223,9 @@ def main():
                 import dataclasses
 
                 e_total = envs_per_gpu * actor_ranks
-                ref = RainbowEngine(dataclasses.replace(cfg, n_envs=e_total), dev_index, args.episode_len, overlap=True)
+                eng.local.close()  # (hands the thread's stream back before another engine takes it)
+                ref = RainbowEngine(dataclasses.replace(cfg, n_envs=e_total, actor_initial_priority=False), dev_index, args.episode_len, overlap=True,
+                                    actor_stream=None if args.actor_stream == "default" else args.actor_stream)
                 ref.prefill()
                 for _ in range(8):
                     ref.step(args.updates)
@@ -242,6 +244,7 @@ def main():
                 strong_ref = {"what": "the single-GPU engine (actors + learner on rank 0's GPU) at the job's total environment count, timed after the distributed region",
                               "envs": e_total, "lock_steps": n_ref, "ms_per_lock_step": 1e3 * dt, "value": e_total / dt, "unit": "env-steps/s",
                               "learner_updates_per_s": args.updates / dt}
+                ref.close()
                 del ref
             except Exception as exc:  # the reference figure must never take the measured line down with it
                 strong_ref = {"error": repr(exc)}
@@ -286,7 +289,7 @@ def main():
             "noisy_dense": cfg.enable_noisy_dense,
             "epsilon": cfg.epsilon,
             "hip_graphs": not args.no_graph,
-            "lockstep": lockstep, "actor_stream": (args.actor_stream + "-priority HIP stream (a hardware-queue pool of its own); update graph three branches wide") if getattr(eng, "actor_stream", None) is not None else "torch's current stream",
+            "lockstep": lockstep, "actor_stream": (args.actor_stream + "-priority HIP stream (a hardware-queue pool of its own); update graph three branches wide") if getattr(getattr(eng, "local", eng), "actor_stream", None) is not None else "torch's current stream",
             "qnet": ("libsrlx: float32 results; forward = float32 products as exact split-bf16 partial products on v_mfma_f32_32x32x16_bf16 (conv1 3, conv2 / conv3 / "
                      "first dense layer 6 per multiply-add), float32 accumulate; " +
                      ("hand-written backward (no autograd)" if getattr(local, "mfma_train", False) else "torch autograd backward (SRLX_TORCH_BACKWARD=1 yardstick)")),
@@ -306,6 +309,11 @@ def main():
             out["strong_ratio"] = out["value"] / strong_ref["value"]
     if dist is None and not args.no_subfigures:
         out["subfigures"] = subfigures(eng, args, inner)
+        if args.algo == "rainbow" and not args.noisy and args.envs >= 512 and args.envs % 128 == 0:
+            try:
+                out["subfigures"]["roles"] = role_timings(args, dev_index)
+            except Exception as exc:  # a side figure must never take the measured line down with it
+                out["subfigures"]["roles"] = {"error": repr(exc)}
     if not args.no_per_micro:
         out["per_micro"] = per_micro(eng)
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other runs would only repeat it
@@ -600,6 +608,123 @@ def subfigures(eng, args, inner):
         "learner_only": {"ms_per_update": 1e3 * t_upd, "updates_per_s": 1.0 / t_upd},
         "note": "the timed region runs both concurrently (actor pass on the main stream, updates on the learner's streams)",
     }
+
+
+def role_timings(args, dev_index, actor_ranks=7):
+    """The two roles of the multi-GPU job, each ALONE on this GPU (their maximum is the job's lock-step period when the links keep up):
+    an actor rank's lock-step (fused policy pass on a published set, environments, local ring commit, record packing; no exchange) and a learner-only rank's
+    period (one captured update with the ring commit + tree add of a slab of `actor_ranks` x E environments on its side branch)."""
+    import dataclasses
+
+    import torch
+
+    from simple_distributed_rl_amd import _native as N
+    from simple_distributed_rl_amd.device.dist import TransitionBus
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+    from simple_distributed_rl_amd.device.replay import DeviceReplay
+
+    def timed(fn, reps):
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    dev = torch.device(f"cuda:{dev_index}")
+    E = args.envs
+    cfg = RainbowDeviceConfig(n_envs=E, batch_size=args.batch_size, memory_capacity=args.capacity, seed=0)
+    pad = cfg.multisteps + cfg.window_length
+    local_cfg = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62)
+    out = {}
+    # ---- actor rank
+    eng = RainbowEngine(local_cfg, dev_index, args.episode_len, ring_len=pad + 4, role="actor")
+    bus = TransitionBus(E, 84 * 84, torch.uint8, dev)
+    bus.enable_slots(2)
+
+    def actor_step():
+        eng.actor_front()
+        eng.actor_commit()
+        bus.pack(eng.actions, eng.env.rewards, eng.env.terminated, eng.env.done)
+
+    t = timed(actor_step, 256)
+    out["actor_rank"] = {"ms_per_lock_step": 1e3 * t, "envs": E, "env_steps_per_s": E / t, "fast": bool(eng.fast)}
+    del eng, bus
+    # ---- learner-only rank
+    total = actor_ranks * E
+    ring_len = -(-cfg.memory_capacity // total) + pad
+    replay = DeviceReplay(total, ring_len, 84 * 84, cfg.window_length, cfg.multisteps, cfg.n_actions, cfg.batch_size, True, cfg.enable_reward_clip, cfg.memory_alpha,
+                          cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, dev_index)
+    eng = RainbowEngine(local_cfg, dev_index, args.episode_len, ring_len=pad + 4, role="learner", learner_replay=replay)
+    g = torch.Generator(device=dev).manual_seed(1)
+    rec = (10) * E
+    slabs = []
+    for _ in range(2):
+        scal = torch.zeros((actor_ranks, rec), dtype=torch.uint8, device=dev)
+        scal[:, : 4 * E].view(torch.int32).copy_(torch.randint(0, cfg.n_actions, (actor_ranks, E), dtype=torch.int32, device=dev, generator=g))
+        scal[:, 4 * E : 8 * E].view(torch.float32).copy_(torch.randint(-1, 2, (actor_ranks, E), device=dev, generator=g).float())
+        flags = (torch.rand((actor_ranks, E), device=dev, generator=g) < 1.0 / args.episode_len).to(torch.uint8)
+        scal[:, 8 * E : 9 * E] = flags
+        scal[:, 9 * E : 10 * E] = flags
+        slabs.append((scal, torch.randint(0, 256, (total, 84 * 84), dtype=torch.uint8, device=dev, generator=g)))
+    replay.reset_all(slabs[0][1])
+
+    def ingest_fn(k):
+        scal, obs = slabs[k % 2]
+
+        def fn():
+            replay.commit_packed(scal, E, 0, obs)
+            replay.add_masked()
+        return (k % 2, True), fn
+
+    for k in range(replay.item_len + cfg.multisteps - 1):
+        ingest_fn(k)[1]()
+        replay.note_commit()
+    pri = torch.rand(replay.capacity, dtype=torch.float32, device=dev, generator=g)
+    N.check(replay.lib.srlx_per_set_range(replay.h_per, 0, replay.capacity, N.tptr(pri), N.PRIO_F32, 1, N.torch_stream_ptr()))
+    torch.cuda.synchronize()
+    state = {"k": 0}
+
+    def learner_period():
+        eng.ingest = ingest_fn(state["k"])
+        eng.run_updates(1)
+        replay.note_commit()
+        state["k"] += 1
+
+    for _ in range(4):
+        learner_period()
+    if not args.no_graph:
+        eng.enable_lazy_capture()
+    t = timed(learner_period, 256)
+    out["learner_rank"] = {"ms_per_period": 1e3 * t, "updates_per_s": 1.0 / t, "slab_envs": total, "fast": bool(eng.fast), "graphs": len(eng._learner_graphs)}
+
+    def add_only():
+        ingest_fn(state["k"])[1]()
+        replay.note_commit()
+        state["k"] += 1
+
+    out["learner_rank"]["ingest_alone_ms"] = 1e3 * timed(add_only, 64)
+    out["learner_rank"]["update_alone_ms"] = 1e3 * timed(lambda: eng.run_updates(1), 128)
+    if os.environ.get("SRLX_ROLE_PROBE"):  # host time of one period, and the period with the host synchronising (is the host the bound?)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(64):
+            learner_period()
+        out["learner_rank"]["host_ms_per_period"] = 1e3 * (time.perf_counter() - t0) / 64
+        torch.cuda.synchronize()
+
+        def synced():
+            learner_period()
+            torch.cuda.synchronize()
+        out["learner_rank"]["synchronised_ms_per_period"] = 1e3 * timed(synced, 64)
+    period = max(out["actor_rank"]["ms_per_lock_step"], out["learner_rank"]["ms_per_period"])
+    out["predicted"] = {"actor_ranks": actor_ranks, "ms_per_lock_step": period, "env_steps_per_s": total / (period * 1e-3),
+                        "note": "max of the two roles' periods (links keep up: 7.2 MB per actor rank per lock-step over its own xGMI link); unmeasured on more than one GPU"}
+    del eng, replay
+    torch.cuda.empty_cache()
+    return out
 
 
 CONV_EXECUTED_FLOPS_PER_SAMPLE = 125728456704.0 / 1024  # 84x84x4 DQN image block: 3 x conv1's 7.23 MFLOP + 6 x conv2 / conv3's 16.85 MFLOP (exact split-bf16 partial products)

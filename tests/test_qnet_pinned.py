@@ -124,3 +124,111 @@ def test_split_products_on_a_trained_network_against_float64():
     scale = np.abs(q64).max()
     err, err_ref = np.abs(q - q64).max(), np.abs(q32 - q64).max()
     assert err <= 2.0 * err_ref + 2.0 ** -23 * scale, (err, err_ref, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("neighbour", [4, 0])
+def test_the_shipped_policy_pass_against_the_reference_network(kind, neighbour):
+    """The combination bench.py and the actor ranks run (round-4 lock-step): a PUBLISHED parameter set (packed filters, first dense layer as bf16 operand planes, small
+    vectors: srlx_qnet_publish) read by srlx_qnet_forward_u8_policy -- fused convolutions writing operand planes, the planes GEMM as half-CU workgroups with 4 K splits
+    (`neighbour` 4: beside a learner) or CU-filling workgroups (0: an actor rank), the head kernel that also selects the actions -- against the reference's recorded
+    Q-values, directly (not through the equivalence with the round-3 path)."""
+    from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference
+
+    z, sd = _golden(kind)
+    net = EngineQNet(6).cuda().load_reference_state_dict(sd)
+    B, E = z["frames"].shape[0], 1024
+    actor = QNetInference(net, max_batch=E)
+    actor.enable_fc1_planes(private_weights=True)
+    actor.enable_actor_sets()
+    actor.set_fc1_neighbour(neighbour)
+    source = QNetInference(net, max_batch=64)
+    source.weights_changed()
+    source.publish_to(actor, 1, with_fc1=True)
+    actor.select_set(1)
+    ring = torch.tensor(z["frames"]).permute(0, 3, 1, 2).contiguous().view(B * 4, 84 * 84).cuda()
+    off = (torch.arange(B * 4, device="cuda", dtype=torch.int64) * (84 * 84)).view(B, 4).clone()
+    off[5, :2] = -1
+    off_big = off.repeat((E + B - 1) // B, 1)[:E].contiguous()
+    eps = torch.zeros(E, dtype=torch.float32, device="cuda")  # greedy: the selected action is the first argmax of the row
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    actions = torch.full((E,), -1, dtype=torch.int32, device="cuda")
+    q = actor.forward_u8_policy(ring.data_ptr(), off_big, eps, 1234, counter, actions).cpu().numpy()
+    for r in range(0, E - B + 1, B * 29):
+        _check(q[r:r + B], z, f"forward_u8_policy rows {r}.. ({'half-CU' if neighbour else 'CU-filling'} planes kernel)")
+    assert np.array_equal(actions.cpu().numpy(), q.argmax(axis=1).astype(np.int32))
+    assert np.array_equal(q[:B], q[B * 7:B * 8]), "the same sample gives the same bits wherever it sits in the batch"
+
+
+@pytest.mark.gpu
+def test_fast_engine_learner_step_against_the_reference_trainer():
+    """One update of `RainbowEngine(fast=True)` -- the shipped learner path: fused draw + gather tables, split-bf16 forward of s_0..s_n and the target pass, TD / Huber /
+    priorities in the head kernel of the hand-written backward, Adam fused into the first dense layer's weight gradient (writing the next published set), k_adam for
+    the rest -- against ONE Trainer.train() of the reference at the benchmark geometry (tests/golden/train_step_rainbow84.npz, oracle/gen_golden_train84.py): the same
+    weights (numpy recipe), the same 16 items (7 frames each, written into the engine's ring by ordinary commits), the same importance weights."""
+    import ast
+
+    from gen_golden_qnet84 import recipe_state_dict
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+
+    z = np.load(os.path.join(GOLDEN, "train_step_rainbow84.npz"))
+    keys_shapes = [(str(k), ast.literal_eval(str(s))) for k, s in zip(z["keys"], z["shapes"])]
+    sd_on = {k: torch.tensor(v) for k, v in recipe_state_dict(keys_shapes, "init", int(z["seed_online"])).items()}
+    sd_tg = {k: torch.tensor(v) for k, v in recipe_state_dict(keys_shapes, "init", int(z["seed_target"])).items()}
+    frames, actions, reward, done = z["frames"], z["actions"], z["reward"], z["done"]
+    B, n, E = frames.shape[0], 3, 512
+    cfg = RainbowDeviceConfig(n_envs=E, batch_size=B, memory_capacity=E * 8, memory_warmup_size=E, lr=float(z["lr"]), discount=float(z["discount"]),
+                              target_model_update_interval=1000, enable_reward_clip=False)
+    eng = RainbowEngine(cfg, 0, episode_len=1000, overlap=True, fast=True)
+    assert eng.fast
+    eng.q_online.load_reference_state_dict(sd_on)
+    eng.q_target.load_reference_state_dict(sd_tg)
+    rp = eng.replay
+    dev = eng.dev
+
+    def lanes(x, dtype, fill=0):  # the 16 items are environments 0..15; the other lanes idle on black frames
+        t = torch.full((E,) + tuple(x.shape[1:]), fill, dtype=dtype, device=dev)
+        t[:B] = torch.tensor(x).to(dev).to(dtype)
+        return t
+
+    rp.reset_all(lanes(frames[:, 0].reshape(B, -1), torch.uint8))
+    for i in range(1, n + 4):  # frame i arrives with the transition (frame i - 1 -> i); the item's transitions are commits 4, 5, 6
+        k = i - 4
+        a = lanes(actions[:, k] if k >= 0 else np.zeros(B, np.int32), torch.int32)
+        r = lanes(reward[:, k] if k >= 0 else np.zeros(B, np.float32), torch.float32)
+        d = lanes(done[:, k] if k >= 0 else np.zeros(B, np.float32), torch.uint8)
+        rp.commit(a, r, d, d, lanes(frames[:, i].reshape(B, -1), torch.uint8))
+    # the item of environment e that starts at ring time 3 was completed -- and its leaf appended -- by commit number 3 + n - 1 = 5 (leaf slot = commit * E + e)
+    idx = ((3 + n - 1) * E + torch.arange(B, device=dev, dtype=torch.int64)) + rp.capacity - 1
+    w = torch.tensor(z["weights"]).to(dev)
+
+    def fixed_batch(*a, **k):
+        rp.batch.indices.copy_(idx)
+        rp.batch.weights.copy_(w)
+        return rp.gather_drawn(all_states=True)
+
+    rp.sample_items = fixed_batch
+    eng._check_versions()  # (the loaded weights: packed filters and published set follow)
+    before = {k: v.clone() for k, v in eng.q_online.reference_state_dict().items()}
+    eng._learner_body(publish=1)
+    torch.cuda.synchronize()
+    q0 = eng.inf_online.q[: B * (n + 1)].view(B, n + 1, -1)[:, 0].cpu().numpy()
+    np.testing.assert_allclose(q0, z["q0"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(eng.target.cpu().numpy(), z["target_q"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(float(eng.loss.item()), float(z["loss"]), rtol=1e-5)
+    # |target - q| is a difference of O(1) numbers: 1e-5 of their size is the bar for the residue
+    np.testing.assert_allclose(eng.priorities.cpu().numpy(), z["priorities"], rtol=1e-5, atol=1e-5 * float(np.abs(z["target_q"]).max()))
+    after = eng.q_online.reference_state_dict()
+    lr = float(z["lr"])
+    for k, _ in keys_shapes:
+        pos = torch.tensor(z["pos." + k])
+        got = (after[k].double().cpu().reshape(-1)[pos] - before[k].double().cpu().reshape(-1)[pos]).numpy()
+        want = z["upd." + k].astype(np.float64)
+        # Adam's first step moves a weight by lr * g / (|g| + eps): compare the UPDATE; where |g| ~ eps (1e-8) the direction amplifies last-ulp differences of the
+        # gradient, so up to 2 % of the sampled entries may sit anywhere within one lr-sized step -- the rest agree to 1 % of a step
+        bad = np.abs(got - want) > 1e-2 * lr
+        assert bad.mean() <= 0.02, (k, float(bad.mean()))
+        assert np.abs(got - want).max() <= 2.0 * lr * (1 + 1e-3), (k, float(np.abs(got - want).max()))
+        total = float((after[k].double() - before[k].double()).sum().item())
+        assert abs(total - float(z["sum." + k])) <= 2e-2 * float(z["abs." + k]) + 1e-12, (k, total, float(z["sum." + k]))

@@ -65,7 +65,6 @@ __global__ void __launch_bounds__(256) k_split_planes(const float *__restrict__ 
     }
 }
 
-template <int ABL>  // ablation switch for measurements (SRLX_FC1_ABL): 0 = the kernel; 1 = no LDS-DMA in the loop; 2 = no MFMAs; 3 = no DMA, no barrier; 4 = no DMA, no fragment reads
 __global__ void __launch_bounds__(512) k_fc1_planes(const uint4 *__restrict__ A, const uint4 *__restrict__ W, float *__restrict__ C, int M, int N, int K8,
                                                     int slabs_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -158,16 +157,14 @@ __global__ void __launch_bounds__(512) k_fc1_planes(const uint4 *__restrict__ A,
             asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (ABL != 3) __builtin_amdgcn_s_barrier();  // ... everybody's pieces; and every wave has finished READING slab s: its slot is free for slab s + 3
-        const bool rd = ABL != 4 && s + 1 < s_end, dma = (ABL == 0 || ABL == 2) && s + 3 < s_end;
+        __builtin_amdgcn_s_barrier();  // ... everybody's pieces; and every wave has finished READING slab s: its slot is free for slab s + 3
+        const bool rd = s + 1 < s_end, dma = s + 3 < s_end;
         const unsigned char *buf = smem + slot_next * kBufBytes;
 #pragma unroll
         for (int t = 0; t < 12; t++) {  // 12 steps of two MFMAs; behind them alternately three fragment reads / one DMA piece
             const int ks = t / 6, c = t % 6;
-            if (ABL != 2) {
 #pragma unroll
-                for (int ms = 0; ms < 2; ms++) acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[ks][ms][pq[c][0]], cur.b[ks][pq[c][1]], acc[ms], 0, 0, 0);
-            }
+            for (int ms = 0; ms < 2; ms++) acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[ks][ms][pq[c][0]], cur.b[ks][pq[c][1]], acc[ms], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (t & 1) {
                 if (dma) issue_piece(slot_free, t >> 1);
@@ -407,11 +404,7 @@ bool srlx_fc1_planes_applicable(const srlx_qnet *h, int64_t rows) {
 int srlx_fc1_planes_gemm(srlx_qnet *h, int64_t rows, int splits, int kps, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        SRLX_HIP(hipFuncSetAttribute((const void *)k_fc1_planes<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-        SRLX_HIP(hipFuncSetAttribute((const void *)k_fc1_planes<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-        SRLX_HIP(hipFuncSetAttribute((const void *)k_fc1_planes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-        SRLX_HIP(hipFuncSetAttribute((const void *)k_fc1_planes<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-        SRLX_HIP(hipFuncSetAttribute((const void *)k_fc1_planes<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        SRLX_HIP(hipFuncSetAttribute((const void *)k_fc1_planes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
         attr_set = true;
     }
     const int N1 = 2 * h->hidden;
@@ -427,11 +420,7 @@ int srlx_fc1_planes_gemm(srlx_qnet *h, int64_t rows, int splits, int kps, hipStr
         SRLX_HIP(hipGetLastError());
         return SRLX_OK;
     }
-    static const int abl = getenv("SRLX_FC1_ABL") ? atoi(getenv("SRLX_FC1_ABL")) : 0;  // measurement only: results are garbage for abl != 0
-    auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, (const uint4 *)h->a3_planes, (const uint4 *)h->wf_planes, h->partial, (int)rows, N1, h->flat / 8, kps);
-    };
-    abl == 1 ? launch(k_fc1_planes<1>) : abl == 2 ? launch(k_fc1_planes<2>) : abl == 3 ? launch(k_fc1_planes<3>) : abl == 4 ? launch(k_fc1_planes<4>) : launch(k_fc1_planes<0>);
+    hipLaunchKernelGGL(k_fc1_planes, grid, dim3(512), kLds, st, (const uint4 *)h->a3_planes, (const uint4 *)h->wf_planes, h->partial, (int)rows, N1, h->flat / 8, kps);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

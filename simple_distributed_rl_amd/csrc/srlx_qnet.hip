@@ -722,13 +722,11 @@ int run_dense(srlx_qnet *h, i64 B, float *d_q, hipStream_t st) {
 // the batch, then the head (split reduction + bias + ReLU, second layers, dueling combine) writing q / h1 rows i * stride.
 int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hipStream_t st) {
     const int N1 = 2 * h->hidden;
+    h->partial_used = true;
     const i64 tiles = ((B + BM - 1) / BM) * ((N1 + 63) / 64);
-    static const int target_wgs = getenv("SRLX_FC1_TARGET_WGS") ? atoi(getenv("SRLX_FC1_TARGET_WGS")) : 512;  // (measurement switch)
-    int splits = (int)((target_wgs + tiles - 1) / tiles);  // (1024 workgroups for the learner's 96 / 128 rows: measured no faster)
+    int splits = (int)((512 + tiles - 1) / tiles);  // ~512 workgroups (1024 for the learner's 96 / 128 rows: measured no faster)
     const int ksteps = h->flat / BK;
-    static const int force_splits = getenv("SRLX_FC1_SPLITS") ? atoi(getenv("SRLX_FC1_SPLITS")) : 0;  // measurement: workgroup granularity of the chip-filling launches
-    if (force_splits > 0 && B >= 512) splits = force_splits;
-    if (h->fc1_neighbour > 0 && h->planes_valid && srlx_fc1_planes_applicable(h, B) && force_splits <= 0 && B >= 512) splits = h->fc1_neighbour;
+    if (h->fc1_neighbour > 0 && h->planes_valid && srlx_fc1_planes_applicable(h, B) && B >= 512) splits = h->fc1_neighbour;
     if (splits > ksteps) splits = ksteps;
     if (splits > h->max_splits) splits = h->max_splits;
     if (splits < 1) splits = 1;
@@ -831,7 +829,7 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
                 {&h->act2, (size_t)max_batch * h->OH2 * h->OW2 * 2 * filters},
                 {&h->act3, (size_t)max_batch * h->flat},
                 // FC1 split-K partial sums: splits(B) * B <= 4096 + B for every batch B (see run_tail)
-                {&h->partial, (size_t)(4096 + 128 + max_batch * (getenv("SRLX_FC1_SPLITS") ? atoi(getenv("SRLX_FC1_SPLITS")) : 1)) * 2 * hidden}};
+                {&h->partial, (size_t)(4096 + 128 + max_batch) * 2 * hidden}};
     h->partial_floats = bufs[3].n;
     for (auto &b : bufs) {
         hipError_t e = hipMalloc((void **)b.p, b.n * f);
@@ -1036,6 +1034,8 @@ int srlx_qnet_set_fc1_neighbour(srlx_qnet_t *h, int splits) {
     srlx::DeviceGuard guard(h->device);
     const size_t need = (size_t)splits * h->max_batch * 2 * h->hidden;
     if (need > h->partial_floats) {  // split-K partial slabs of the chip-filling launch
+        SRLX_REQUIRE(!h->partial_used, "qnet_set_fc1_neighbour: %d splits need a larger partial-sum buffer, and a forward (possibly captured in a graph) already uses the "
+                                       "current one: choose the split count before the first forward", splits);
         SRLX_HIP(hipDeviceSynchronize());
         if (h->partial) SRLX_HIP(hipFree(h->partial));
         h->partial = nullptr;

@@ -723,11 +723,10 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     if (with_fc1 && !h->adam_m)
         hipLaunchKernelGGL(k_fc1_wgrad<false>, fg, dim3(256), 0, sd, B, ss, N1, K, h->dh1, h->act3, g_wf, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d3, 0));
-    // where the Adam-fused first-dense-layer weight gradient goes (srlx_qnet_set_fc1_branch; SRLX_FC1_ORDER overrides): 0 = last on the side stream (rounds 2-3),
+    // where the Adam-fused first-dense-layer weight gradient goes (srlx_qnet_set_fc1_branch): 0 = last on the side stream (rounds 2-3),
     // 1 = first on the side stream (as soon as the data gradient has read the weights: ev_d3), 2 = a branch of its own (side2) from ev_d3 -- a THIRD concurrent
     // branch of a captured update: only where the actors' stream does not share a hardware-queue pool with the graph's internal streams (tools/README.md, 5)
-    static const int fc1_order_env = getenv("SRLX_FC1_ORDER") ? atoi(getenv("SRLX_FC1_ORDER")) : -1;  // (measurement: overrides the handle's setting)
-    const int fc1_order = fc1_order_env >= 0 ? fc1_order_env : h->fc1_order;
+    const int fc1_order = h->fc1_order;
     auto launch_fc1_adam = [&](hipStream_t s2) {
         if (h->adam_planes_out)
             hipLaunchKernelGGL((k_fc1_wgrad<true, true>), fg, dim3(256), 0, s2, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v,
@@ -758,14 +757,10 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     SRLX_HIP(hipEventRecord(h->ev_join, sd));
     // conv1's weight gradient needs the END of the data-gradient chain: it follows it on the caller's stream instead of queueing behind
     // the conv2 / conv3 weight gradients on the side stream
-    // output pixels per chunk, even (the MFMA consumes pixel pairs).  Two chunks per (sample, frame) (45 KB of LDS; SRLX_C1_CHUNKS): in round 2 four kept the
-    // workgroup under the 33 KB a CU had left beside one of the actors' convolution workgroups; those now leave 4 KB, so neither co-resides, and two halve the
-    // partial tensors the in-launch reduction reads
-    static const int c1_chunks = getenv("SRLX_C1_CHUNKS") && atoi(getenv("SRLX_C1_CHUNKS")) >= 1 && atoi(getenv("SRLX_C1_CHUNKS")) <= kC1Chunks ? atoi(getenv("SRLX_C1_CHUNKS")) : 2;
-    // conv1's partial sums are added up by a k_reduce_parts launch behind the kernel; SRLX_C1_REDUCE=in_launch: by its last workgroups (tickets) -- the same sums
-    // in the same order.  The in-launch form was this round's first version (-1 launch); with two chunks per (sample, frame) the separate launch is 1.6 % faster
-    // per lock-step (profiles/r4_probe32.log): 64 partial tensors per frame are more than a last-arriver should read alone.
-    static const bool c1_in_launch = getenv("SRLX_C1_REDUCE") && !strcmp(getenv("SRLX_C1_REDUCE"), "in_launch");
+    // output pixels per chunk, even (the MFMA consumes pixel pairs).  Two chunks per (sample, frame) (45 KB of LDS); the partial sums are added up by a
+    // k_reduce_parts launch behind the kernel (an in-launch ticket reduction saved the launch and cost 1.6 % per lock-step: `__threadfence()` in 512 workgroups).
+    constexpr int c1_chunks = 2;
+    constexpr bool c1_in_launch = false;
     const int per = ((h->OH1 * h->OW1 + c1_chunks - 1) / c1_chunks + 1) & ~1;
     const size_t lds = (size_t)kC1Frame + (size_t)per * 4 + (size_t)per * 32 * sizeof(float) + 2 * 16 * 64 * sizeof(float);
     SRLX_REQUIRE(lds <= 64 * 1024, "qnet_backward_u8: conv1 staging needs %zu bytes of LDS", lds);

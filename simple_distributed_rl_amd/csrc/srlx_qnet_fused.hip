@@ -339,7 +339,7 @@ __device__ __forceinline__ f32x16 reduce_quarters(float *__restrict__ scratch, i
 // layer's GEMM reads -- [K/32 slabs][batch rows][4 k-groups][3 parts][8 bf16], K = pixel * 64 + channel -- instead of float32; `act3` then points at them.
 // PLANES = 2 (round 4, the learner's passes): BOTH -- float32 act3 for the backward pass and the planes (at `planes_out`, `plane_rows` rows per K-slab: the launch's
 // rows rounded up to the GEMM's 128-row tile) for the first dense layer.
-template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0, bool WALK = false>
+template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
                                                                 float *__restrict__ act3,
@@ -361,16 +361,6 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     auto stamp = [&](int k) {  // phase timestamps of every wave of workgroup 0 (tools/fused_phases.py); dbg is NULL in production
         if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime();
     };
-    // WALK (round 4, a measurement variant: SRLX_CONV_WGS): the launch brings FEWER workgroups than samples and a workgroup walks samples blockIdx.x,
-    // + gridDim.x, ...  One of these workgroups owns a whole CU (155 KB of LDS, 8 waves x up to 256 registers), so a grid of G < 256 leaves 256 - G compute
-    // units to the learner's kernels for the whole launch.  Measured slower in the lock-step (profiles/r4_probe15.log), and the loop form costs the
-    // single-sample kernel 20 % (244 instead of 193 registers, a worse schedule of conv2 / conv3): its own instantiation, the default launch stays loop-free.
-next_sample:
-    if constexpr (WALK) {  // opaque per-sample copies of the parameter pointers and the thread index: hoisted out of the sample loop, the filter fragments, biases
-        // and the lane's im2col addresses of every unrolled K step would stay live through conv2 / conv3 and spill
-        asm volatile("" : "+s"(wpk), "+s"(b1), "+s"(b2), "+s"(b3));
-        asm volatile("" : "+v"(t));
-    }
     const int lane = t & 63, h = lane >> 5, i = lane & 31;
     stamp(0);
 
@@ -702,11 +692,6 @@ next_sample:
         }
     }
     stamp(7);
-    if constexpr (WALK) {
-        __syncthreads();  // the next sample's frames / conv1 filter parts overwrite regions the slower waves may still be reading (act2 planes, reduction scratch)
-        b += gridDim.x;
-        if (b < (i64)n_samples) goto next_sample;
-    }
 }
 
 }  // namespace
@@ -747,7 +732,6 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     static bool attr_set = false;
     if (!attr_set) {
         const void *kerns[] = {(const void *)k_convnet_fused<true, true, true, 1>, (const void *)k_convnet_fused<false, true, true, 2>,
-                               (const void *)k_convnet_fused<true, true, true, 1, true>, (const void *)k_convnet_fused<true, true, true, 0, true>,
                                (const void *)k_convnet_fused<true, true, true>,  (const void *)k_convnet_fused<false, true, true>,
                                (const void *)k_convnet_fused<true, true, false>, (const void *)k_convnet_fused<false, true, false>,
                                (const void *)k_convnet_fused<true, false, false>, (const void *)k_convnet_fused<false, false, false>};
@@ -763,24 +747,11 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     h->wt_from_forward = keep;
     static const bool c1_f32 = getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1';  // A/B switch: conv1 on the float32 matrix pipe
     float *out3 = h->act3;
-    // chip-filling launches (>= 512 samples): at most SRLX_CONV_WGS workgroups (default: all samples = the round-3 launch), each walking several samples
-    static const long long conv_wgs = getenv("SRLX_CONV_WGS") ? atoll(getenv("SRLX_CONV_WGS")) : 0;
-    static const bool f32_variants = (getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1') || (getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1');
-    const unsigned grid = (unsigned)(batch >= 512 && conv_wgs > 0 && conv_wgs < batch && !f32_variants ? conv_wgs : batch);
-    // (measurement: SRLX_CONV_CHUNKS = n launches of consecutive samples instead of one.  The workgroup dispatcher keeps feeding a RUNNING kernel's pending
-    // workgroups before it looks at another queue, whatever the queues' priorities: the update's first kernels -- one workgroup for the draw, then a convolution
-    // pass that needs whole CUs -- get their first CU when the actors' 1024-workgroup launch, issued 20 us earlier, has dispatched its last round: 137 us instead
-    // of 55 to the end of the update's convolutions (profiles/r4_freerun_update_phases.txt).  Chunking moves that to 117 us and the lock-step by -1.1 % / +0.4 %
-    // on two boxes (2 chunks), worse from 4 up: the chunk boundaries cost the actors what the update gains -- profiles/r4_probe30.log, r4_probe31.log.)
-    static const int conv_chunks = getenv("SRLX_CONV_CHUNKS") && atoi(getenv("SRLX_CONV_CHUNKS")) >= 1 ? atoi(getenv("SRLX_CONV_CHUNKS")) : 1;
+    // one workgroup per sample.  (Measured and dropped in round 4: fewer, sample-walking workgroups -- the loop form cost 20 % in code generation -- and the launch
+    // cut into chunks of consecutive samples so that the update's kernels get compute units earlier: -1.1 % / +0.4 % per lock-step on two boxes; profiles/NOTES.md.)
     auto launch = [&](auto kern) {
-        const int nch = (batch >= 512 && grid == (unsigned)batch && conv_chunks > 1) ? conv_chunks : 1;
-        const long long per = (((long long)batch + nch - 1) / nch + 7) / 8 * 8;  // (multiples of 8: the kernel rotates its tile split with the sample index)
-        for (long long f = 0; f < (long long)batch; f += (nch == 1 ? (long long)batch : per)) {
-            const unsigned g = nch == 1 ? grid : (unsigned)((long long)batch - f < per ? (long long)batch - f : per);
-            hipLaunchKernelGGL(kern, dim3(g), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
-                               keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch, f);
-        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
+                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch, 0ll);
     };
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
     if (h->probe0 && hipEventRecord(h->probe0, st) != hipSuccess) return false;  // measurement hook: exactly this kernel, on its launch stream
@@ -790,7 +761,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     h->a3_planes_fresh = false;
     if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && !keep && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch) && batch >= 512) {
         out3 = reinterpret_cast<float *>(h->a3_planes);
-        grid < batch ? launch(k_convnet_fused<true, true, true, 1, true>) : launch(k_convnet_fused<true, true, true, 1>);
+        launch(k_convnet_fused<true, true, true, 1>);
         h->a3_planes_fresh = true;
     } else if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch)) {
         // a learner's pass (96 / 128 rows; `planes_small`): float32 act3 for its backward pass AND the planes for the first dense layer, rows padded to the GEMM's tile
@@ -801,7 +772,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
         h->a3_planes_fresh = true;
     } else if (batch >= 512)
         c1_f32 ? launch(k_convnet_fused<true, false, false>) : c23_f32 ? launch(k_convnet_fused<true, true, false>)
-               : grid < batch ? launch(k_convnet_fused<true, true, true, 0, true>) : launch(k_convnet_fused<true, true, true>);
+               : launch(k_convnet_fused<true, true, true>);
     else
         c1_f32 ? launch(k_convnet_fused<false, false, false>) : c23_f32 ? launch(k_convnet_fused<false, true, false>) : launch(k_convnet_fused<false, true, true>);
     if (h->probe1 && hipEventRecord(h->probe1, st) != hipSuccess) return false;

@@ -76,8 +76,9 @@ struct srlx_qnet {
     const void *sink_prio;
     int64_t sink_n;
     int sink_kind;
+    bool partial_used;                    // a forward has used `partial` (srlx_qnet_set_fc1_neighbour may no longer move it)
     hipEvent_t sink_wait;                 // caller-owned or NULL: the sink's branch waits for it first (srlx_qnet_set_sink_wait)
-    int fc1_order;                        // -1: SRLX_FC1_ORDER decides (default 0); 0 / 1 / 2: srlx_qnet_set_fc1_branch
+    int fc1_order;                        // 0 (default) / 1 / 2: srlx_qnet_set_fc1_branch
     hipStream_t side2;
     hipEvent_t ev_join2;
     uint64_t *stamp_buf;                  // measurement aid (srlx_qnet_set_stamp_buffer): srlx_debug_stamp launches at fixed points of the backward pass

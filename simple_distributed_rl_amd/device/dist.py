@@ -81,7 +81,7 @@ class TransitionBus:
         self._direct = None
         assert (extra is not None) == (self.K > 0)
         if self.world == 1 and not self.always_collective:
-            self._direct = (actions, rewards, terminated, done, next_obs) + ((extra,) if self.K else ())
+            self._direct = (actions, rewards, terminated, done, next_obs) + ((extra.clone(),) if self.K else ())  # (`extra` is assembled per call by the caller: keep a copy)
             return
         # two collectives per step: the frames, and ONE packed record buffer for the four scalar fields
         # ([actions 4E | rewards 4E | terminated E | done E] bytes per rank) that the learner unpacks with strided copies

@@ -782,6 +782,12 @@ class RainbowEngine:
             self._ap["mask"].copy_(r.item_mask)
             self._ap_first_slot = ((r._steps_committed - 1) * self.cfg.n_envs) % r.capacity
             self._passes += 1
+            if not self._own_ring_only:
+                # the commit has just replaced the items these E leaves stood for, and their successors are added one lock-step from now: until then the leaves
+                # hold NOTHING (priority 0: never drawn) instead of the old items' priorities on the new items' data
+                if not hasattr(self, "_zero_leaves"):
+                    self._zero_leaves = torch.zeros(self.cfg.n_envs, dtype=torch.float64, device=self.dev)
+                N.check(self.lib.srlx_per_set_range(r.h_per, self._ap_first_slot, self.cfg.n_envs, N.tptr(self._zero_leaves), N.PRIO_RAW, 1, N.torch_stream_ptr()))
         self.total_env_steps += self.cfg.n_envs
 
     def step(self, learner_updates: int = 1, events=None):

@@ -142,7 +142,7 @@ def test_rccl_transport_calls_at_world_size_one():
     assert ret[0] == {"push_ok": True, "bcast_ok": True, "max": 1.25, "n": 7, "backend": "nccl"}
 
 
-@pytest.mark.parametrize("n,actor_gpus,launcher", [(2, 2, True), (4, 3, True), (2, 2, False)])
+@pytest.mark.parametrize("n,actor_gpus,launcher", [pytest.param(2, 2, True, marks=pytest.mark.slow), (4, 3, True), pytest.param(2, 2, False, marks=pytest.mark.slow)])
 def test_bench_multi_rank_rehearsal(n, actor_gpus, launcher):
     """`bench.py --gpus N` with N ranks sharing the test GPU (`--backend gloo`), under the driver's launcher and WITHOUT one
     (bench.py then starts the ranks itself): the whole N>1 bench path -- rendezvous, prefill, warm-up, graph capture, timed loop,
@@ -174,7 +174,7 @@ def test_bench_multi_rank_rehearsal(n, actor_gpus, launcher):
     assert "cpu_baseline" not in d and d["roofline"]["avg_launch_ms"] > 0 and d["roofline"]["pass"]["avg_launch_group_ms"] > 0
 
 
-@pytest.mark.parametrize("n,actor_gpus", [(2, 2), (4, 3)])
+@pytest.mark.parametrize("n,actor_gpus", [pytest.param(2, 2, marks=pytest.mark.slow), (4, 3)])
 def test_bench_agent57_light_multi_rank_rehearsal(n, actor_gpus):
     """BASELINE configs[3] as a bench line: `bench.py --algo agent57_light --gpus N` (here N ranks sharing the test GPU over gloo): DistributedAgent57Light,
     the grouped send/recv transition push, the flat five-network broadcast, barriers and MAX all-reduce, env-step accounting over the ACTOR ranks."""

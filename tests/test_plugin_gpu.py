@@ -215,6 +215,7 @@ def test_train_mp_dqn_cartpole_on_gpu():
     assert np.mean(rewards) > 50, rewards
 
 
+@pytest.mark.slow
 def test_ppo_plugin_continuous_pendulum():
     """"PPO:torch" with a continuous action space (BASELINE.json configs[4] shapes through the plugin surface): the space
     negotiation hands the algorithm an NpArraySpace with the environment's bounds, the Normal-policy loss of the trainer
@@ -312,6 +313,13 @@ def test_distributed_actor_initial_priorities_match_the_reference(name):
     parameter.q_online.load_state_dict(sd)
     parameter.q_target.load_state_dict(sd)
     worker = runner.make_worker(parameter, memory)
+    qmax = [0.0]
+    for fn_name in ("pred_q", "pred_target_q"):  # the largest |Q| the worker ever sees: the scale of what its priorities are residues of
+        def wrapped(state, _f=getattr(parameter, fn_name)):
+            out = _f(state)
+            qmax[0] = max(qmax[0], float(np.abs(np.asarray(out)).max()))
+            return out
+        setattr(parameter, fn_name, wrapped)
     got = []
     worker.worker.memory = type("Rec", (), {"add": staticmethod(lambda batch, priority=None, **kw: got.append(priority)), "config": memory.config})()
     ctx = RunContext(runner.env_config, rl)
@@ -330,4 +338,7 @@ def test_distributed_actor_initial_priorities_match_the_reference(name):
     log = env.unwrapped.log
     np.testing.assert_array_equal(np.array([l[1] for l in log], np.int32), z["actions"])  # the same trajectory (epsilon draws, argmax, padding draws)
     assert len(got) == len(z["priorities"]) and all(p is not None for p in got)
-    np.testing.assert_allclose(np.array(got), z["priorities"], rtol=2e-4, atol=2e-5)
+    # a priority |n-step target - Q(s_0, a_0)| is a residue of up to 2 (n + 1) Q-values (rewards are exact small integers): with every Q-value within 1e-5 of the
+    # reference's (`north_star`; here torch's GPU kernels against the reference's CPU run) it is within 1e-5 x 2 (n + 1) x max |Q| of the recorded one
+    n = int(z["multisteps"])
+    np.testing.assert_allclose(np.array(got), z["priorities"], rtol=1e-5, atol=1e-5 * 2 * (n + 1) * qmax[0])

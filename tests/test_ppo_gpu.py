@@ -142,6 +142,7 @@ def test_pendulum_step_vs_oracle():
         np.testing.assert_allclose(obs.cpu().numpy(), np.stack([np.cos(got_state[:, 0]), np.sin(got_state[:, 0]), got_state[:, 1]], 1), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.slow
 def test_ppo_engine_learns_pendulum():
     """The engine with the reference's default hyper-parameters (ppo/config.py:43-110: gamma = lambda = 0.9, the GAE
     value as v_target AND advantage, value clipping) improves the mean episode return of 1024 Pendulum environments:

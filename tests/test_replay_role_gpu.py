@@ -75,7 +75,7 @@ def _worker(rank, world, port, ret, prefetch=2):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("prefetch", [2, 5])  # 5 = the reference's queue depth (play_mp_memory.py:595-621)
+@pytest.mark.parametrize("prefetch", [pytest.param(2, marks=pytest.mark.slow), 5])  # 5 = the reference's queue depth (play_mp_memory.py:595-621)
 def test_three_roles_actors_replay_learner(prefetch):
     """Every transfer between the replay and the learner rank of a lock-step is one dist.batch_isend_irecv group per side; whether a batch / write-back is valid
     is computed on the host from the lock-step it belongs to, and SRLX_CHECK_HEADERS=1 (set in the workers) compares that with the header that travelled."""

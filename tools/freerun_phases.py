@@ -28,7 +28,7 @@ n, P = 400, 6
 ST = torch.zeros(n * P, dtype=torch.int64, device="cuda")
 lib = N.lib()
 mark = lambda i: N.check(lib.srlx_debug_stamp(N.tptr(ST), i, N.torch_stream_ptr()))  # noqa: E731
-first = os.environ.get("SRLX_ORDER", "learner_first") == "actor_first"
+first = False  # (the "actors first" issue order was measured and dropped in round 4)
 bw_rows = []
 for k in range(n):
     b = k * P

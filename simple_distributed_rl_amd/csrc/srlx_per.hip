@@ -808,12 +808,13 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
     if (bump && threadIdx.x == 0) *bump += 1;  // srlx_per_set_update_counter: the caller's count of priority write-backs (read by later launches only)
     double *s_p = reinterpret_cast<double *>(smem);
     double *s_chg = s_p + n;
-    double *red = s_chg + n;                                    // blockDim doubles
+    double *red = s_chg + n;                                    // blockDim doubles (only [0] is used: the maximum as a bit pattern)
     i64 *s_idx = reinterpret_cast<i64 *>(red + blockDim.x);     // n
     int *s_dep = reinterpret_cast<int *>(s_idx + n);            // n
     int *s_shared = s_dep + n;                                  // n: depth of the deepest node index i shares with ANY other index of the call (-1: none)
     const int t = threadIdx.x, T = blockDim.x;
     const double maxp0 = state->max_priority;
+    if (t == 0) reinterpret_cast<u64 *>(red)[0] = 0ull;
 
     double pmax = 0.0;
     for (i64 i = t; i < n; i += T) {
@@ -830,13 +831,37 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
         pmax = fmax(pmax, p);
     }
     __syncthreads();
+    // The learner's call (n * depth <= 2 x the workgroup: 32 / 64 indices of a 1M-leaf tree): every value the call will read from the tree -- the old leaf of index
+    // t, the old value of the <= 2 ancestors a thread owns a task for -- is REQUESTED here, before the pair pass and the scans below, which then run while the loads
+    // travel (round 5: the leaf read and the ancestor read were two dependent memory round trips behind them).  A load of a node that turns out to be somebody
+    // else's is dropped.
+    const int maxd = tr.D;
+    const i64 tasks = n * (i64)maxd;
+    const bool pre = tasks <= 2 * (i64)T && n <= T;
+    double pre_v[2] = {0.0, 0.0}, pre_leaf = 0.0;
+    i64 pre_pa[2] = {0, 0};
+    if (pre) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const i64 task = t + (i64)r * T;
+            if (task >= tasks) continue;
+            const i64 i = task % n;
+            const int k = (int)(task / n) + 1;
+            if (k > s_dep[i]) continue;
+            pre_pa[r] = tr.phys(((s_idx[i] + 1) >> k) - 1);
+            pre_v[r] = tr.T[pre_pa[r]];
+        }
+        if (t < n) pre_leaf = tr.get(s_idx[t]);
+    }
     // Where do the indices' root paths meet?  Below the deepest node it shares with any other index, an index is the ONLY contributor of its ancestors
     // (14 of the 20 levels of a 64-index call on a 1M-leaf tree), and an index that shares nothing at its own depth has no duplicate: those cases need
     // neither the ownership scan nor the ordered replay below -- O(n) LDS look-ups per task, which is where a call's time went (ablation at 32 / 64 /
-    // 128 indices: 11.7 / 24.2 / 53.1 us with the scans, 7.9 / 11.6 / 16.8 us without).  n^2 / 2 pair tests, once: depth of the lowest common ancestor
-    // of (i, j) from the heap indices aligned to the shallower one.
-    for (i64 pair = t; pair < n * n; pair += T) {
-        const i64 i = pair / n, j = pair % n;
+    // 128 indices: 11.7 / 24.2 / 53.1 us with the scans, 7.9 / 11.6 / 16.8 us without).  n (n - 1) / 2 pair tests, once: depth of the lowest common ancestor
+    // of (i, j) from the heap indices aligned to the shallower one.  (Even n: slot (i, j <= i) of the half square stands for the pair (n-1-i, n-1-j).)
+    const bool even = (n & 1) == 0;
+    for (i64 pair = t; pair < (even ? n * n / 2 : n * n); pair += T) {
+        i64 i = pair / n, j = pair % n;
+        if (even && j <= i) i = n - 1 - i, j = n - 1 - j;
         if (i >= j) continue;
         const int di = s_dep[i], dj = s_dep[j], dm = di < dj ? di : dj;
         const u64 u = (u64)(s_idx[i] + 1) >> (di - dm), v = (u64)(s_idx[j] + 1) >> (dj - dm);
@@ -861,7 +886,7 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
                     break;
                 }
         }
-        const double before = prev >= 0 ? s_p[prev] : tr.get(x);
+        const double before = prev >= 0 ? s_p[prev] : (pre ? pre_leaf : tr.get(x));
         s_chg[i] = s_p[i] - before;  // :83
         last_me[q] = last;
     }
@@ -872,8 +897,6 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
 
     // ancestors (:49-54).  task (i, k): the k-th ancestor of index i; the first i that reaches a
     // node owns it.
-    int maxd = tr.D;
-    const i64 tasks = n * (i64)maxd;
     for (i64 task = t; task < tasks; task += T) {
         const i64 i = task % n;  // level-major: a wave's lanes sit on the same few levels, so whole waves (the deep levels) skip the scans
         const int k = (int)(task / n) + 1;
@@ -888,8 +911,9 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
             for (i64 j = 0; j < i; j++) owner &= !is_ancestor(a, da, s_idx[j], s_dep[j]);
         }
         if (!owner) continue;
-        const i64 pa = tr.phys(a);
-        double v = tr.T[pa];
+        const int r = (int)(task / T);
+        const i64 pa = pre ? pre_pa[r & 1] : tr.phys(a);
+        double v = pre ? pre_v[r & 1] : tr.T[pa];
         v += s_chg[i];
         if (!alone) {
 #pragma unroll 8
@@ -901,7 +925,12 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
         tr.T[pa] = v;
     }
 
-    const double m = block_max(pmax, red);
+    // max_priority (:176-177): wave maxima, then one LDS atomic per wave (priorities are >= 0: their bit patterns order like the values)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pmax = fmax(pmax, __shfl_xor(pmax, off));
+    if ((t & 63) == 0 && pmax > 0.0) atomicMax(reinterpret_cast<u64 *>(red), (u64)__double_as_longlong(pmax));
+    __syncthreads();
+    const double m = __longlong_as_double((long long)reinterpret_cast<u64 *>(red)[0]);
     if (t == 0 && kind != SRLX_PRIO_NONE && maxp0 < m) state->max_priority = m;
 }
 

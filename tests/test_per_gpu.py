@@ -584,3 +584,34 @@ def test_keyed_sample_and_update_counter_equal_the_separate_launches(has_duplica
     N.check(lib.srlx_per_update(per.h, B, N.tptr(ib), N.tptr(pri), N.PRIO_F32, 1, None))
     torch.cuda.synchronize()
     assert int(count) == 43
+
+
+@pytest.mark.parametrize("capacity,n", [(1_000_000, 64), (1_000_000, 32), (300_001, 64), (5000, 48)])
+def test_learner_sized_updates_200_repeats_vs_oracle(capacity, n):
+    """The learner's priority write-back (k_update_wg at 32 / 64 indices: tree values prefetched ahead of the ownership scans -- round 5) 200 times over on one
+    tree, against the oracle call by call: random leaves with clustered neighbours (shared ancestors far down) and repeated indices, the final tree bit-equal and
+    max_priority equal after every 50th call.  (Round 4's first rewrite of this kernel raced once in ~100 calls; hence the repeats.)"""
+    N = _N()
+    rng = np.random.default_rng(capacity + n)
+    g = AbiPER(capacity, 0.5, 0.4, 5000, True, 1e-4)
+    o = OraclePER(capacity, 0.5, 0.4, 5000, True, 1e-4)
+    v = rng.random(capacity) * 2
+    g.add(v, N.PRIO_F64)
+    for x in np.sqrt(np.abs(v) + 1e-4):
+        o.add(float(x), mode=2)
+    for rep in range(200):
+        base = rng.integers(0, capacity, n)
+        k = rep % 4
+        if k == 1:  # neighbours: paths that part only in the last levels
+            base[n // 2:] = np.minimum(base[: n - n // 2] + rng.integers(0, 3, n - n // 2), capacity - 1)
+        elif k == 2:  # repeated indices (the later occurrence sees the earlier one's write)
+            base[n // 3:] = base[rng.integers(0, n // 3, n - n // 3)]
+        idx = base + capacity - 1
+        pri = (np.abs(rng.standard_normal(n)) * (3.0 if rep % 17 == 0 else 1.0)).astype(np.float32)
+        g.update(idx, pri, N.PRIO_F32)
+        o.update(idx, pri)
+        if rep % 50 == 49:
+            mp, size, write, tree = g.state()
+            omp, osize, owrite, otree = o.get_state()
+            np.testing.assert_array_equal(tree, otree)
+            assert (mp, size, write) == (omp, osize, owrite)

@@ -309,6 +309,7 @@ def main():
             out["strong_ratio"] = out["value"] / strong_ref["value"]
     if dist is None and not args.no_subfigures:
         out["subfigures"] = subfigures(eng, args, inner)
+        eng.close()  # (the engine took the thread to its actors' low-priority stream: hand it back before other engines are built and timed)
         if args.algo == "rainbow" and not args.noisy and args.envs >= 512 and args.envs % 128 == 0:
             try:
                 out["subfigures"]["roles"] = role_timings(args, dev_index)
@@ -466,7 +467,7 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
         ms = a.elapsed_time(b) / reps
         ex = CONV_EXECUTED_FLOPS_PER_SAMPLE * E
         roof = {"kernel": "k_convnet_fused<true, ...> (+ k_pack_filters): conv1 -> conv2 -> conv3 of ONE of the five image trunks of the actors' pass over E uint8 stacks "
-                          "(five such launches per lock-step; 24 % of the GPU time in profiles/r4_a57_kernel_stats.csv)",
+                          "(five such launches per lock-step; 24 % of the GPU time in profiles/r5_a57_kernel_stats.csv)",
                 "bound": "mfma", "achieved": ex / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": None, "executed_mfma_flops_per_launch": ex, "avg_launch_ms": ms, "launches_per_lock_step": len(local._trunks),
                 "note": "isolated launches (the update does not run beside them); executed flops = 3 x conv1 + 6 x conv2 / conv3 exact split-bf16 partial products"}
@@ -750,11 +751,11 @@ def _isolated_forward_ms(eng, reps=20):
     return a.elapsed_time(b) / reps
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")
 
 
 def _pmc_traffic(kernel: str):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r4_pmc_traffic.json, written by tools/r4_measure.sh from two separate
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r5_pmc_traffic.json, written by tools/r5_measure.sh from two separate
     `rocprofv3 --pmc` runs of tools/actor_pass_probe.py -- FETCH_SIZE and WRITE_SIZE do not fit one pass; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for wide coalesced reads on gfx950).  None when no such profile has been recorded."""
     if not os.path.exists(PMC_FILE):
@@ -843,8 +844,8 @@ def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0, probe_stats=None):
         "f32_equivalent": {"achieved": f_conv / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "frac": f_conv / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                            "note": "algorithmic float32 FLOP/s over the f32 MFMA peak (the `frac` of the round-1/2 lines); NOT this kernel's bound: it does not run on that pipe"},
         "note": "timed inside the lock-step loop (HIP events on the launch stream, right around this kernel), where the learner's streams share the chip; `frac` = "
-                "executed bf16-MFMA flops / time / 2.5 PFLOP/s dense; traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/r4_pmc_traffic.json (isolated "
-                "launches of tools/actor_pass_probe.py); rocprofv3 cross-check: this kernel's AverageNs in profiles/r4_kernel_stats.csv; `probes` = min / median / "
+                "executed bf16-MFMA flops / time / 2.5 PFLOP/s dense; traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/r5_pmc_traffic.json (isolated "
+                "launches of tools/actor_pass_probe.py); rocprofv3 cross-check: this kernel's AverageNs in profiles/r5_kernel_stats.csv; `probes` = min / median / "
                 "mean / max of the HIP-event brackets of this run (every 4th lock-step): the brackets include queue wait beside the learner's streams",
         "probes": probe_stats,
         "fc1": fc1,
@@ -922,6 +923,57 @@ def per_micro(eng, draws=1 << 20, reps=20):
     ms = timed(lambda: N.check(r.lib.srlx_per_add(r.h_per, E, N.tptr(mask), N.PRIO_NONE_MASKED, 1, N.torch_stream_ptr())), 100)
     ops[f"add_{E}"] = {"us_per_call": 1e3 * ms, "adds_per_s": E / (ms * 1e-3), "algorithmic_bytes_per_item": 16 + depth * 16 + 8}
     out["ops"] = ops
+    try:
+        out["shim"] = per_shim_timing()
+    except Exception as exc:  # a side figure must never take the measured line down with it
+        out["shim"] = {"error": repr(exc)}
+    return out
+
+
+def per_shim_timing(rounds=1500, warm=20_000):
+    """The b1 seam as the reference calls it (srl/rl/memories/priority_replay_buffer.py:149-152 -> the `set_custom` drop-in class): the loop of the reference's own
+    tests/quick/rl/memories/speedtest.py:30-58 -- add one item, sample 64, update 64 with Python floats -- through
+    simple_distributed_rl_amd.rl.memories.priority_memories.proportional_memory:ProportionalMemory, HOST arrays in and out (every call is a PCIe round trip and a
+    stream synchronisation), each operation timed on its own; beside it the reference's own C++ sum-tree (oracle/_ref) in the same loop when that build is present."""
+    import importlib.util
+    import random
+
+    from simple_distributed_rl_amd.rl.memories.priority_memories.proportional_memory import ProportionalMemory
+
+    def loop(mem, rounds):
+        random.seed(0)
+        step = 0
+        for _ in range(warm):  # speedtest.py:38-42 (20 000 instead of 100 000 adds: the tree's depth is what an operation's cost depends on, not its fill)
+            mem.add((step, step, step, step), random.random())
+            step += 1
+        t_add = t_s = t_u = 0.0
+        B = 64
+        for _ in range(rounds):
+            r = random.random()
+            t = time.perf_counter()
+            mem.add((step, step, step, step), r)
+            t_add += time.perf_counter() - t
+            step += 1
+            t = time.perf_counter()
+            batches, weights, update_args = mem.sample(B, step)
+            t_s += time.perf_counter() - t
+            pri = [random.random() for _ in range(B)]
+            t = time.perf_counter()
+            mem.update(update_args, pri)
+            t_u += time.perf_counter() - t
+        return {"add_us": 1e6 * t_add / rounds, "sample_64_us": 1e6 * t_s / rounds, "update_64_us": 1e6 * t_u / rounds,
+                "sample_idx_per_s": rounds * B / t_s, "update_per_s": rounds * B / t_u, "add_per_s": rounds / t_add}
+
+    out = {"what": f"speedtest.py loop: {rounds} x (add 1, sample 64, update 64) on a 1 000 000-leaf memory after {warm} adds, host arrays through the Python class",
+           "device_shim": loop(ProportionalMemory(1_000_000, 0.8, 0.4, 1000, has_duplicate=True), rounds)}
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    so = [f for f in (os.listdir(ref_dir) if os.path.isdir(ref_dir) else []) if f.startswith("proportional_memory_cpp") and f.endswith(".so")]
+    if so:
+        spec = importlib.util.spec_from_file_location("proportional_memory_cpp", os.path.join(ref_dir, so[0]))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out["reference_cpp"] = loop(mod.ProportionalMemory(1_000_000, 0.8, 0.4, 1000, True, 0.0001), rounds)
+        out["reference_cpp"]["kind"] = "reference (oracle/_ref: the reference's pybind11 sum-tree, one host thread)"
     return out
 
 

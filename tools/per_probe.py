@@ -6,7 +6,8 @@ import torch
 from simple_distributed_rl_amd import _native as N
 lib = N.lib()
 dev = torch.device("cuda:0")
-QUICK = len(sys.argv) > 1 and sys.argv[1] == "quick"
+QUICK = len(sys.argv) > 1 and sys.argv[1] in ("quick", "one20")
+ONE20 = len(sys.argv) > 1 and sys.argv[1] == "one20"  # 2^20 draws only (the PMC passes of tools/_pmc_per.sh)
 CAPS = [(int(c), 0.0) for c in sys.argv[2:]]
 for cap, zero_frac in (CAPS if CAPS else ((1_000_000, 0.0),) if QUICK else ((1_000_000, 0.0), (1_000_000, 0.01), (300_001, 0.0))):
     h = N.c_p(); N.check(lib.srlx_per_create(ctypes.byref(h), cap, 0.5, 0.4, 1e6, 1, 1e-4, 0))
@@ -20,7 +21,7 @@ for cap, zero_frac in (CAPS if CAPS else ((1_000_000, 0.0),) if QUICK else ((1_0
         N.check(lib.srlx_per_add(h, cap, N.tptr(pri), N.PRIO_RAW if hasattr(N, "PRIO_RAW") else 3, 1, None))
     else:
         N.check(lib.srlx_per_add(h, cap, N.tptr(pri), N.PRIO_F64, 1, None))
-    for draws in ((1 << 20, 1 << 22) if QUICK else (1 << 20, 1 << 22, 1 << 24)):
+    for draws in ((1 << 20,) if ONE20 else (1 << 20, 1 << 22) if QUICK else (1 << 20, 1 << 22, 1 << 24)):
         u = torch.rand(draws, dtype=torch.float64, device=dev, generator=g)
         B = draws if not zero_frac else draws // 2
         if zero_frac: u[torch.rand(draws, device=dev, generator=g) < zero_frac] = 0.0  # forces the in-order rejection path

@@ -220,6 +220,14 @@ int srlx_store_commit_step_ex(srlx_store_t *h, const int32_t *d_actions, const f
  * where the commit completed no item, -1 (= "use max_priority") without d_est_records -- the array srlx_per_add(SRLX_PRIO_EST_F32) takes. */
 int srlx_store_commit_step_packed(srlx_store_t *h, const uint8_t *d_records, int64_t record_stride, int64_t envs_per_record, int extra_floats, const void *d_next_obs,
                                   uint8_t *d_item_mask, const uint8_t *d_est_records, float *d_est_out, int advance, void *stream);
+/* The commit at an EXPLICIT ring position (the host's count of commits) that leaves the device-resident position alone: a store whose tree add runs one lock-step
+ * behind its ring commit (device/rainbow.py: the add of lock-step t rides on a side branch of update t + 1, off the lock-step's serial tail) keeps the device
+ * position as the LEARNER's view -- it advances with the tree add (srlx_per_set_add_counters), so sampled leaves always resolve against the ring the tree
+ * describes -- while the actors' commits run ahead of it by one.  Such a store needs one spare ring slot: srlx_store_set_item_slack(h, 1) right after
+ * srlx_store_create (item_len = ring_len - (n_step + window) - slack; the slot a commit overwrites then belongs to no item even of the older view). */
+int srlx_store_commit_step_at(srlx_store_t *h, int64_t position, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated, const uint8_t *d_done,
+                              const void *d_next_obs, uint8_t *d_item_mask, int64_t *d_next_frame_table, int64_t *d_bump, void *stream);
+int srlx_store_set_item_slack(srlx_store_t *h, int slack);
 int srlx_store_advance(srlx_store_t *h, void *stream);
 /* device views: int64 position p; uint8 needs_reset[E]; int32 step_in_episode[E] (of position p) */
 int srlx_store_views(srlx_store_t *h, void **d_pos, void **d_needs_reset, void **d_step_in_ep);

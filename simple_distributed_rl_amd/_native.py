@@ -77,6 +77,8 @@ SIGNATURES = {
     "srlx_store_stack_current": (c_int, [c_p, c_p, c_p]),
     "srlx_store_commit_step": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_store_commit_step_ex": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_p, c_p]),
+    "srlx_store_commit_step_at": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_store_set_item_slack": (c_int, [c_p, c_int]),
     "srlx_store_commit_step_packed": (c_int, [c_p, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_int, c_p]),
     "srlx_store_advance": (c_int, [c_p, c_p]),
     "srlx_store_views": (c_int, [c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p)]),

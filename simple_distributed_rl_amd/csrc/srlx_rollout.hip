@@ -164,8 +164,8 @@ struct PackedSrc {
 };
 __global__ void __launch_bounds__(256) k_commit_step(StoreDev s, const int32_t *__restrict__ actions, const float *__restrict__ rewards, const u8 *__restrict__ terminated,
                                                      const u8 *__restrict__ done, const void *__restrict__ next_obs, u8 *__restrict__ item_mask,
-                                                     i64 *__restrict__ next_table, int advance, i64 *__restrict__ bump, PackedSrc pk) {
-    const i64 p = s.pos[0];
+                                                     i64 *__restrict__ next_table, int advance, i64 *__restrict__ bump, PackedSrc pk, i64 host_pos) {
+    const i64 p = host_pos >= 0 ? host_pos : s.pos[0];  // (host_pos: srlx_store_commit_step_at -- the device position then belongs to the learner's view alone)
     const i64 r = posmod(p, s.L), r1 = posmod(p + 1, s.L);
     const i64 fb = s.obs_dtype == SRLX_OBS_U8 ? s.F : s.F * 4;  // frame bytes
     if ((fb & 15) == 0) {
@@ -588,8 +588,31 @@ int srlx_store_commit_step_ex(srlx_store_t *h, const int32_t *d_actions, const f
     const int need = (int)((d.E + 255) / 256);  // the scalar part needs one thread per environment
     if (grid < need) grid = need;
     hipLaunchKernelGGL(k_commit_step, dim3((unsigned)grid), dim3(256), 0, st, d, d_actions, d_rewards, d_terminated, d_done, d_next_obs, d_item_mask,
-                       (i64 *)d_next_frame_table, advance, (i64 *)d_bump, PackedSrc{});
+                       (i64 *)d_next_frame_table, advance, (i64 *)d_bump, PackedSrc{}, (i64)-1);
     SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_commit_step_at(srlx_store_t *h, int64_t position, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated, const uint8_t *d_done,
+                              const void *d_next_obs, uint8_t *d_item_mask, int64_t *d_next_frame_table, int64_t *d_bump, void *stream) {
+    SRLX_REQUIRE(h && d_actions && d_rewards && d_terminated && d_done && d_next_obs && position >= 0, "store_commit_step_at: bad argument");
+    SRLX_REQUIRE(!d_next_frame_table || h->d.obs_dtype == SRLX_OBS_U8, "store_commit_step_at: frame tables exist for uint8 stores only");
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick(h, stream);
+    const StoreDev &d = h->d;
+    const i64 fb = d.F * (d.obs_dtype == SRLX_OBS_U8 ? 1 : 4);
+    int grid = grid_for(d.E * (fb / 16 + 1), 2048);
+    const int need = (int)((d.E + 255) / 256);
+    if (grid < need) grid = need;
+    hipLaunchKernelGGL(k_commit_step, dim3((unsigned)grid), dim3(256), 0, st, d, d_actions, d_rewards, d_terminated, d_done, d_next_obs, d_item_mask,
+                       (i64 *)d_next_frame_table, 0, (i64 *)d_bump, PackedSrc{}, (i64)position);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_store_set_item_slack(srlx_store_t *h, int slack) {
+    SRLX_REQUIRE(h && slack >= 0 && h->d.L - (h->d.n + h->d.W) - slack >= 1, "store_set_item_slack: bad slack");
+    h->d.item_len = h->d.L - (h->d.n + h->d.W) - slack;
     return SRLX_OK;
 }
 
@@ -609,7 +632,7 @@ int srlx_store_commit_step_packed(srlx_store_t *h, const uint8_t *d_records, int
     const int need = (int)((d.E + 255) / 256);
     if (grid < need) grid = need;
     hipLaunchKernelGGL(k_commit_step, dim3((unsigned)grid), dim3(256), 0, st, d, nullptr, nullptr, nullptr, nullptr, d_next_obs, d_item_mask, nullptr, advance, nullptr,
-                       PackedSrc{d_records, (i64)record_stride, (i64)envs_per_record, extra_floats, d_est_records, d_est_out});
+                       PackedSrc{d_records, (i64)record_stride, (i64)envs_per_record, extra_floats, d_est_records, d_est_out}, (i64)-1);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

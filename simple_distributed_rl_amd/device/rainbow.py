@@ -143,15 +143,6 @@ class RainbowEngine:
         pad = n + cfg.window_length
         if ring_len is None:
             ring_len = -(-cfg.memory_capacity // E) + pad  # item_len * E >= capacity
-        self.replay = DeviceReplay(
-            E, ring_len, H * W_, cfg.window_length, n, A, B, True, cfg.enable_reward_clip,
-            cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
-            has_duplicate=cfg.memory_has_duplicate,
-        )
-        if env is None:
-            self.env = SyntheticAtariVecEnv(self.replay, episode_len)
-        else:  # a ready batch environment, or a factory that needs this engine's replay (device/vector_runner.py)
-            self.env = env(self.replay) if callable(env) else env
         self.noisy = bool(cfg.enable_noisy_dense)
         self.mfma = True  # (kept for callers that used to branch on it: there is no other network path)
         self.autograd_yardstick = os.environ.get("SRLX_TORCH_BACKWARD", "0") == "1"
@@ -172,6 +163,18 @@ class RainbowEngine:
             raise ValueError("RainbowEngine(fast=True): needs overlap, the 84 x 84 x 4 / 32-filter geometry, plain dense layers, >= 512 environments in multiples of 128, "
                              "a hidden layer in multiples of 64 and max-priority adds")
         self.fast = can_fast and (bool(fast) if fast is not None else os.environ.get("SRLX_FAST", "1") != "0")
+        # the single-GPU round-5 lock-step (actors + learner here, the learner's replay = this ring): the tree add of a lock-step runs one lock-step behind its ring
+        # commit, on a side branch of the next update -- the ring gets one spare slot (DeviceReplay(lagged_add=True)).  SRLX_LAGGED_ADD=0: the add behind the join.
+        lag = self.fast and role == "both" and learner_replay is None and os.environ.get("SRLX_LAGGED_ADD", "1") != "0"
+        self.replay = DeviceReplay(
+            E, ring_len + (1 if lag else 0), H * W_, cfg.window_length, n, A, B, True, cfg.enable_reward_clip,
+            cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
+            has_duplicate=cfg.memory_has_duplicate, lagged_add=lag,
+        )
+        if env is None:
+            self.env = SyntheticAtariVecEnv(self.replay, episode_len)
+        else:  # a ready batch environment, or a factory that needs this engine's replay (device/vector_runner.py)
+            self.env = env(self.replay) if callable(env) else env
 
         self.actor_stream = None
         want = os.environ.get("SRLX_ACTOR_STREAM") or actor_stream
@@ -299,7 +302,7 @@ class RainbowEngine:
         # a learner rank's ingest (device/dist.py): the commit of transitions that arrived from other ranks runs on a side stream between the update's draw and
         # its priority write-back -- `ingest` = (key, callable issuing the launches) for the NEXT update only
         self.ingest = None
-        self.s_ingest = torch.cuda.Stream(device=self.dev, priority=-1) if learner_replay is not None else None
+        self.s_ingest = torch.cuda.Stream(device=self.dev, priority=-1) if (learner_replay is not None or self.replay.lagged) else None
         self._ev_drawn, self._ev_ingested = torch.cuda.Event(), torch.cuda.Event()
 
     @property
@@ -426,7 +429,7 @@ class RainbowEngine:
     def actor_commit_tree(self):
         """fast: the tree half -- the PER add at max_priority, which also moves the ring position; behind the join (the learner writes the tree and reads the position).
         Nothing where the engine's ring only stacks frames (an actor rank; a learner rank's own actors): that ring's commit has moved the position itself."""
-        if not self._own_ring_only:
+        if not self._own_ring_only and not self.replay.lagged:  # (lagged: the next fork takes the add with it)
             self.replay.add_masked()
         self.total_env_steps += self.cfg.n_envs
 
@@ -461,7 +464,7 @@ class RainbowEngine:
             self.actor_front()
             self.actor_commit_ring()
             if not self._own_ring_only:
-                self.replay.add_masked()
+                self.replay.add_masked()  # (lagged: launches the pending add now)
             return
         if self.actor_priority:  # the deferred add and its bookkeeping (mask, first slot, pass count) live in the piecewise calls: take exactly that path
             self.actor_front()
@@ -689,6 +692,8 @@ class RainbowEngine:
             self._check_versions()
         if not marked:
             self.fork_point()
+        if self.ingest is None and self.replay.lagged:  # the tree add of the previous lock-step rides on this fork's first update (or runs alone below)
+            self.ingest = self.replay.take_pending_add()
         self.s_learner.wait_event(self._ev_fork)
         ran = 0
         with torch.cuda.stream(self.s_learner):
@@ -837,7 +842,7 @@ class RainbowEngine:
         if learner and self.role != "actor":
             self._capturing = True
         if self.fast:  # the actors' launches stay eager; the update is captured per variant: publishing into set 0 / set 1 / not at all
-            if learner and self.role != "actor" and not self.lreplay.is_warmup_needed() and self.learner_replay is None:
+            if learner and self.role != "actor" and not self.lreplay.is_warmup_needed() and self.learner_replay is None and not self.replay.lagged:
                 for key in ([(None, None), (0, None), (1, None)] if self.role == "both" else [(None, None)]):
                     self._capture_learner(key, None)
                 self._learner_graph = self._learner_graphs[(None, None)]
@@ -859,8 +864,12 @@ class RainbowEngine:
         torch.cuda.synchronize(self.dev)
 
     def refresh_host_mirrors(self):
+        self.join_learner()
+        self.replay.flush_pending_add()
         N.check(self.lib.srlx_per_refresh(self.replay.h_per, N.torch_stream_ptr()))
 
     def info(self):
+        self.join_learner()
+        self.replay.flush_pending_add()
         self.lreplay.check_draws()
         return dict(loss=float(self.loss.item()), train_count=self.train_count, sync=self.sync_count, memory=self.lreplay.length())

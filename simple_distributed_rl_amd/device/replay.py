@@ -47,7 +47,13 @@ class DeviceReplay:
         device: int = 0,
         sample_slack: int = 8,
         has_duplicate: bool = True,
+        lagged_add: bool = False,
     ):
+        """lagged_add (the single-GPU round-5 lock-step): the tree add of a lock-step is not launched behind its ring commit but handed to the NEXT update
+        (`take_pending_add`), which runs it on a side branch between its draw and its priority write-back -- off the lock-step's serial tail.  Commits then carry
+        their ring position as a launch argument (the host's count), the device-resident position is the learner's view and advances with the add; `ring_len` must
+        include ONE spare slot (srlx_store_set_item_slack), and the item masks alternate between two buffers (the add of lock-step t reads its mask while the
+        commit of t + 1 writes the other)."""
         self.lib = N.lib()
         self.E, self.L, self.F, self.W, self.n, self.A, self.B = n_envs, ring_len, obs_elems, window, n_step, n_actions, batch_size
         self.obs_uint8 = obs_uint8
@@ -64,6 +70,9 @@ class DeviceReplay:
             )
         )
         self.h_store = hs
+        self.lagged = bool(lagged_add)
+        if self.lagged:
+            N.check(self.lib.srlx_store_set_item_slack(hs, 1))
         self.item_len = int(self.lib.srlx_store_item_len(hs))
         self.capacity = int(self.lib.srlx_store_per_capacity(hs))
         hp = N.c_p()
@@ -74,7 +83,9 @@ class DeviceReplay:
         d = self.dev
         B, n = batch_size, n_step
         # preallocated device buffers (stable addresses: required for HIP-graph capture)
-        self.item_mask = torch.zeros(n_envs, dtype=torch.uint8, device=d)
+        self.item_masks = [torch.zeros(n_envs, dtype=torch.uint8, device=d) for _ in range(2 if self.lagged else 1)]
+        self.item_mask = self.item_masks[0]  # (the mask the LAST commit wrote)
+        self._pending_add = None  # lagged: parity of the commit whose tree add has not been launched yet
         self.u = torch.zeros(B + self.slack, dtype=torch.float64, device=d)
         self.rng_counter = torch.zeros(1, dtype=torch.int64, device=d)
         self.used = torch.zeros(1, dtype=torch.int64, device=d)
@@ -142,6 +153,18 @@ class DeviceReplay:
         defer_add: the ring commit only; the caller adds the E leaves later with priorities of its own (`add_raw` / `add_masked`; `item_mask` says which lanes
         completed an item).  next_table: the commit also writes `frame_off_actor` for the NEXT policy pass.  bump: an int64 device counter advanced by the launch."""
         st = N.torch_stream_ptr()
+        if self.lagged:
+            self.flush_pending_add()  # (a commit whose add nobody took: the adds stay in commit order)
+            par = self._steps_committed & 1
+            self.item_mask = self.item_masks[par]
+            N.check(self.lib.srlx_store_commit_step_at(self.h_store, self._steps_committed, N.tptr(actions), N.tptr(rewards), N.tptr(terminated), N.tptr(done),
+                                                       N.tptr(next_obs), N.tptr(self.item_mask), N.tptr(self.frame_off_actor) if next_table else None, N.tptr(bump), st))
+            self.table_fresh = bool(next_table)
+            self._steps_committed += 1
+            self._pending_add = par
+            if not defer_add:
+                self.flush_pending_add()
+            return
         N.check(
             self.lib.srlx_store_commit_step_ex(
                 self.h_store, N.tptr(actions), N.tptr(rewards), N.tptr(terminated), N.tptr(done), N.tptr(next_obs), N.tptr(self.item_mask),
@@ -182,9 +205,25 @@ class DeviceReplay:
             raise RuntimeError(f"DeviceReplay: the last draw of {self.B} items (has_duplicate={self.has_duplicate}) ran out of uniforms ({self.u.numel()} supplied): "
                                "fewer distinct non-zero leaves than the batch needs, or raise sample_slack")
 
-    def add_masked(self):
+    def add_masked(self, mask: Optional[torch.Tensor] = None):
         """The PER add of the last committed lock-step at max_priority (0 where `item_mask` says the lock-step completed no item for the lane)."""
-        N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(self.item_mask), N.PRIO_NONE_MASKED, 1, N.torch_stream_ptr()))
+        if self.lagged and mask is None:
+            return self.flush_pending_add()
+        N.check(self.lib.srlx_per_add(self.h_per, self.E, N.tptr(self.item_mask if mask is None else mask), N.PRIO_NONE_MASKED, 1, N.torch_stream_ptr()))
+
+    def take_pending_add(self):
+        """lagged: (key, callable) for the add of the last commit -- the caller runs the callable exactly once (inside an update: RainbowEngine.ingest) --, or None."""
+        if self._pending_add is None:
+            return None
+        par, self._pending_add = self._pending_add, None
+        mask = self.item_masks[par]
+        return ("add", par), (lambda: self.add_masked(mask))
+
+    def flush_pending_add(self):
+        """lagged: launch the pending add now, on the current stream (nothing of the learner in flight)."""
+        pend = self.take_pending_add() if self.lagged else None
+        if pend is not None:
+            pend[1]()
 
     def add_raw(self, priorities_f64: torch.Tensor):
         """The deferred PER add of the last committed lock-step: E final leaf values (already transformed; 0 = no item), float64 on the device."""
@@ -258,6 +297,7 @@ class DeviceReplay:
     def frame_table_current(self) -> torch.Tensor:
         """int64 [E, W] byte offsets of the frames that form every env's current stacked observation (no launch when the last commit wrote it)."""
         if not self.table_fresh:
+            self.flush_pending_add()  # (the kernel reads the device position: it must have caught up with the commits)
             N.check(self.lib.srlx_store_frame_table_current(self.h_store, N.tptr(self.frame_off_actor), N.torch_stream_ptr()))
         return self.frame_off_actor
 

@@ -198,10 +198,13 @@ def _engines(E=512, actor_stream=None, **cfgkw):
     kw.update(cfgkw)
     cfg = RainbowDeviceConfig(**kw)
     os.environ["SRLX_FC1_NEIGHBOUR"] = "4"  # the K splits of the fifteen-launch engine's first dense layer: split-K partial sums associate alike, Q-values bit-equal
+    os.environ["SRLX_LAGGED_ADD"] = "0"  # the tree add behind the join, as the fifteen-launch lock-step orders it (round 5's default runs it inside the NEXT update:
+    #                                      the update then samples the tree one add older -- pinned against the oracle in test_lagged_add_tree_order_against_the_oracle)
     try:
         fast = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=True, actor_stream=actor_stream)
     finally:
         os.environ.pop("SRLX_FC1_NEIGHBOUR", None)
+        os.environ.pop("SRLX_LAGGED_ADD", None)
     slow = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=False)
     assert fast.fast and not slow.fast
     slow.q_online.load_state_dict(fast.q_online.state_dict())
@@ -366,3 +369,60 @@ def test_learner_passes_on_operand_planes_equal_the_staging_split_gemm(rows):
             grads.append([p.grad.clone() for p in net.kernel_parameters()])
         for a, b in zip(*grads):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("actor_stream", [None, "low"])
+def test_lagged_add_tree_order_against_the_oracle(actor_stream):
+    """The shipped single-GPU lock-step (round 5): the tree add of lock-step t is not launched behind the join but rides on a side branch of update t + 1, between
+    that update's draw and its priority write-back (the ring commit carries its position as a launch argument, the device position is the learner's view and moves
+    with the add, the ring has one spare slot).  Replayed on the CPU oracle in the order the tree must have seen -- draw (keyed uniforms), E adds at max_priority / 0,
+    write-back with the priorities the update produced -- every sampled index and the final tree are bit-equal, eagerly and from the lazily captured graphs."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
+    import hot_path_oracle as H
+    from oracle_bindings import ADD_RAW, OraclePER
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+
+    cfg = RainbowDeviceConfig(n_envs=512, batch_size=32, memory_capacity=512 * 9, memory_warmup_size=512 * 4, seed=7, target_model_update_interval=5)
+    eng = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=True, actor_stream=actor_stream)
+    try:
+        rp = eng.replay
+        assert eng.fast and rp.lagged and rp.capacity == 512 * 9
+        o = OraclePER(rp.capacity, cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, True, cfg.memory_epsilon)
+        B, checked = cfg.batch_size, 0
+
+        def oracle_add(mask):
+            for m in mask.cpu().numpy():
+                o.add(None) if m else o.add(0.0, mode=ADD_RAW)
+
+        for T in range(30):
+            if T == 16:
+                eng.enable_lazy_capture()  # (capture_graphs() would also take a warm-up actor step: one more commit + add than this replay counts)
+            counter0, trained0 = int(rp.rng_counter.item()), eng.train_count
+            eng.step(learner_updates=1)
+            torch.cuda.synchronize()
+            trained = eng.train_count > trained0
+            if trained:
+                used, idx, w, _ = o.sample(B, trained0, H.rng_uniform(cfg.seed ^ 0x5EED, counter0, rp.u.numel()))
+                assert used == int(rp.used.item()) and used > 0
+                np.testing.assert_array_equal(rp.batch.indices.cpu().numpy(), idx)
+                checked += 1
+            if T >= 1:  # the add of lock-step T - 1 ran inside this lock-step's update (or alone, below the warm-up); its mask buffer is the one commit T left alone
+                oracle_add(rp.item_masks[(T - 1) & 1])
+            if trained:
+                o.update(idx, eng.priorities.cpu().numpy())
+        info = eng.info()  # (launches the last commit's add)
+        torch.cuda.synchronize()
+        oracle_add(rp.item_masks[(rp._steps_committed - 1) & 1])
+        st = rp.per_state()
+        import ctypes
+
+        from simple_distributed_rl_amd import _native as N
+        tree = np.empty(2 * rp.capacity - 1)
+        mp_, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+        N.check(rp.lib.srlx_per_backup(rp.h_per, ctypes.byref(mp_), ctypes.byref(size), ctypes.byref(write), N.np_ptr(tree)))
+        assert checked >= 20 and info["train_count"] == eng.train_count and len(eng._learner_graphs) >= 2
+        assert (tree == o.tree()).all() and mp_.value == o.max_priority and write.value == o.write and st["size"] == min(rp.capacity, rp._steps_committed * 512)
+    finally:
+        eng.close()

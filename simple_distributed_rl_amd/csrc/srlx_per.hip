@@ -1545,6 +1545,8 @@ int srlx_per_sample_gather_train(srlx_per_t *h, srlx_store_t *store, int64_t bat
     GatherArgs g{};
     SRLX_TRY(srlx_store_dev_view(store, batch_size, &g.store, &g.meta));
     SRLX_REQUIRE(g.store.obs_dtype == SRLX_OBS_U8, "per_sample_gather_train: uint8 stores only");
+    SRLX_REQUIRE(h->capacity == g.store.E * g.store.item_len, "per_sample_gather_train: the tree has %lld leaves, the store %lld items (leaf j <-> environment j %% E, ring time j / E)",
+                 (long long)h->capacity, (long long)(g.store.E * g.store.item_len));
     g.actions = d_actions, g.rewards = d_rewards, g.terminated = d_terminated, g.off_all = (i64 *)d_frame_off_all, g.off_next = (i64 *)d_frame_off_next;
     const i64 M = n_uniforms, B = batch_size;
     SRLX_TRY(h->scratch.reserve(SampleScratch::bytes(M, B, false)));

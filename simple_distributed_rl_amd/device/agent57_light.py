@@ -237,12 +237,23 @@ class _GraphLauncher:
 
         self._q, self._done, self._err, self._dev = queue.SimpleQueue(), threading.Event(), None, device
         self._done.set()
-        threading.Thread(target=self._run, name="srlx-a57-launcher", daemon=True).start()
+        self._thread = threading.Thread(target=self._run, name="srlx-a57-launcher", daemon=True)
+        self._thread.start()
+
+    def close(self):
+        """Ends the helper thread (a sentinel request); the launcher cannot be used afterwards."""
+        if self._thread is not None:
+            self.wait()
+            self._q.put(None)
+            self._thread.join(timeout=5)
+            self._thread = None
 
     def _run(self):
         torch.cuda.set_device(self._dev)
         while True:
             fn = self._q.get()
+            if fn is None:
+                return
             try:
                 fn()
             except BaseException as e:  # surfaces in wait()
@@ -558,7 +569,7 @@ class Agent57LightEngine:
     def fork_learner(self, updates: int):
         """overlap: `updates` updates on the learner's stream, ordered after everything enqueued on the current stream so far, launched by the helper thread."""
         if updates <= 0 or self.replay.is_warmup_needed():
-            return
+            return 0
         main = torch.cuda.current_stream(self.dev)
         self._ev_fork.record(main)
 
@@ -574,6 +585,15 @@ class Agent57LightEngine:
             self._launcher.submit(body)
         else:  # (eager updates call MIOpen-free torch ops from this thread)
             body()
+        return updates  # (as RainbowEngine.fork_learner: how many updates were enqueued)
+
+    def close(self):
+        """Joins a pending update and ends the launcher thread."""
+        if self.overlap and getattr(self, "_launcher", None) is not None:
+            self.join_learner()
+            torch.cuda.synchronize(self.dev)
+            self._launcher.close()
+            self._launcher = None
 
     @_miopen_find
     def capture_graphs(self, warm_updates: int = 3):

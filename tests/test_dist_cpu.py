@@ -140,6 +140,67 @@ def test_a_learner_only_rank_sends_nothing_gloo_world3():
     assert dict(ret) == {0: True, 1: True, 2: True}
 
 
+def _slot_worker(rank, world, port, ret, learner_acts):
+    """The slot form of the exchange (device/dist.py:DistributedRainbow): packed records + frames, staging slots that rotate on the learner rank, one group of
+    point-to-point transfers per lock-step; the learner's own transitions (when it acts) are copied, never sent."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_distributed_rl_amd.device.dist import TransitionBus
+
+        E, F, K, S = 8, 16, 1, 3
+        first = 0 if learner_acts else 1
+        bus = TransitionBus(E, F, torch.uint8, torch.device("cpu"), extra_floats=K, actor_ranks=range(first, world))
+        bus.enable_slots(S)
+        ok = True
+
+        def slab(r, step):
+            rng = np.random.default_rng(1000 * step + r)
+            return (torch.tensor(rng.integers(0, 6, E), dtype=torch.int32), torch.tensor(rng.standard_normal(E), dtype=torch.float32),
+                    torch.tensor(rng.integers(0, 2, E), dtype=torch.uint8), torch.tensor(rng.integers(0, 2, E), dtype=torch.uint8),
+                    torch.tensor(rng.integers(0, 256, (E, F)), dtype=torch.uint8), torch.tensor(rng.standard_normal((E, K)), dtype=torch.float32))
+
+        for step in range(5):
+            a, r, t, d, o, x = slab(rank, step)
+            if rank == 0:
+                bus.recv_begin(step % S)
+                if learner_acts:
+                    bus.put_own(step % S, bus.pack(a, r, t, d, x), o)
+                bus.recv_end()
+                scal, obs = bus.slot_scal[step % S], bus.slot_obs[step % S]
+                for src in range(first, world):  # row block of actor rank `src`: exactly what that rank packed this lock-step
+                    i = bus.row_of[src]
+                    wa, wr, wt, wd, wo, wx = slab(src, step)
+                    ok &= bool(torch.equal(scal[i], bus.pack(wa, wr, wt, wd, wx))) and bool(torch.equal(obs[i * E:(i + 1) * E], wo))
+                    rec = scal[i]
+                    ok &= bool(torch.equal(rec[: 4 * E].view(torch.int32), wa)) and bool(torch.equal(rec[10 * E:].view(torch.float32).view(E, K), wx))
+                if step >= 1:  # the slot of the previous lock-step still holds that slab (it is committed one or two lock-steps after it arrived)
+                    i = bus.row_of[world - 1]
+                    ok &= bool(torch.equal(bus.slot_obs[(step - 1) % S][i * E:(i + 1) * E], slab(world - 1, step - 1)[4]))
+            else:
+                bus.send_end()  # (the previous slab has left)
+                bus.send_begin(bus.pack(a, r, t, d, x), o)
+        bus.send_end()
+        per_step = (10 + 4 * K) * E + E * F
+        if rank == 0:
+            ok &= bus.sent_bytes == 0 and bus.recv_bytes == 5 * per_step * (world - 1)
+        else:
+            ok &= bus.sent_bytes == 5 * per_step and bus.recv_bytes == 0
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,learner_acts", [(2, True), (3, False)])
+def test_slot_exchange_gloo(world, learner_acts):
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_slot_worker, args=(world, port, ret, learner_acts), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
 def _grad_avg_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

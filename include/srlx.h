@@ -537,6 +537,9 @@ int srlx_qnet_set_priority_sink(srlx_qnet_t *h, srlx_per_t *per, int64_t n, cons
  * transitions BESIDE its update (device/dist.py: tree add on a side stream between the update's draw and its write-back) records it behind the add, so the
  * tree sees draw -> add -> write-back in that order whatever the streams do */
 int srlx_qnet_set_sink_wait(srlx_qnet_t *h, void *event);
+/* ... and one recorded on that branch right BEHIND the write-back: whatever must see the written-back priorities -- the NEXT update's draw, which an engine runs
+ * here, beside the rest of the backward pass, instead of at the head of the next update (device/rainbow.py) -- waits for it */
+int srlx_qnet_set_sink_done(srlx_qnet_t *h, void *event);
 
 /* a caller-owned HIP event (hipEvent_t, NULL: none) recorded on the backward pass's stream right behind its head kernel: with srlx_qnet_backward_td_u8 the TD
  * targets, loss and new priorities exist from there on, so the priority write-back (srlx_per_update) can run beside the gradient kernels on another stream */

@@ -289,7 +289,8 @@ __device__ __forceinline__ bool sample_wg_body(const SampleArgs &a, unsigned cha
     if (total_ok < B) return false;
 
     // phase 4: importance weights (:163-167)
-    const i64 step = a.d_step ? *a.d_step : a.step;
+    // (d_step == key_counter: the call's own draw number is the step -- an engine whose every draw feeds exactly one update; the counter itself has moved on by now)
+    const i64 step = a.d_step ? (a.d_step == a.key_counter ? (i64)kc : *a.d_step) : a.step;
     const double beta = beta_of(a.beta_initial, a.beta_steps, step);
     const double size = (double)a.state->size;
     double wmax_local = 0.0;

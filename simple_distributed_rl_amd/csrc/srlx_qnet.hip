@@ -1066,6 +1066,12 @@ int srlx_qnet_set_priority_sink(srlx_qnet_t *h, srlx_per_t *per, int64_t n, cons
     return SRLX_OK;
 }
 
+int srlx_qnet_set_sink_done(srlx_qnet_t *h, void *event) {
+    SRLX_REQUIRE(h, "qnet_set_sink_done: NULL handle");
+    h->sink_done = (hipEvent_t)event;
+    return SRLX_OK;
+}
+
 int srlx_qnet_set_sink_wait(srlx_qnet_t *h, void *event) {
     SRLX_REQUIRE(h, "qnet_set_sink_wait: NULL handle");
     h->sink_wait = (hipEvent_t)event;

@@ -681,6 +681,7 @@ static int chain_prologue(srlx_qnet_t *h, hipStream_t st) {
     // last launch of the update (it was 9 us + a launch boundary at the very end of the learner's critical path)
     if (h->sink_per && h->sink_wait) SRLX_HIP(hipStreamWaitEvent(sd, h->sink_wait, 0));
     if (h->sink_per) SRLX_TRY(srlx_per_update(h->sink_per, h->sink_n, h->sink_idx, h->sink_prio, h->sink_kind, 1, sd));
+    if (h->sink_per && h->sink_done) SRLX_HIP(hipEventRecord(h->sink_done, sd));
     SRLX_STAMP(21, sd);
     const int C2 = 2 * h->F1;
     // the transposed filters of the two data-gradient GEMMs depend on the weights only: the fused forward of a training handle has

@@ -77,6 +77,7 @@ struct srlx_qnet {
     int64_t sink_n;
     int sink_kind;
     bool partial_used;                    // a forward has used `partial` (srlx_qnet_set_fc1_neighbour may no longer move it)
+    hipEvent_t sink_done;                 // caller-owned or NULL: recorded on the sink's branch right behind the write-back (srlx_qnet_set_sink_done)
     hipEvent_t sink_wait;                 // caller-owned or NULL: the sink's branch waits for it first (srlx_qnet_set_sink_wait)
     int fc1_order;                        // 0 (default) / 1 / 2: srlx_qnet_set_fc1_branch
     hipStream_t side2;

@@ -329,6 +329,11 @@ class QNetInference:
         self._sink_wait = ev  # keeps it alive
         N.check(self.lib.srlx_qnet_set_sink_wait(self.h, N.c_p(ev.cuda_event) if ev is not None else None))
 
+    def set_sink_done(self, ev: Optional[torch.cuda.Event]):
+        """`ev` (recorded at least once already) is recorded on the sink's branch right behind every write-back from now on; None: off."""
+        self._sink_done = ev
+        N.check(self.lib.srlx_qnet_set_sink_done(self.h, N.c_p(ev.cuda_event) if ev is not None else None))
+
     def set_td_event(self, ev: torch.cuda.Event):
         """`ev` (already recorded once: torch creates the HIP event lazily) is recorded right behind the head kernel of every backward pass from now on."""
         self._td_event = ev  # keeps it alive

@@ -303,7 +303,16 @@ class RainbowEngine:
         # its priority write-back -- `ingest` = (key, callable issuing the launches) for the NEXT update only
         self.ingest = None
         self.s_ingest = torch.cuda.Stream(device=self.dev, priority=-1) if (learner_replay is not None or self.replay.lagged) else None
-        self._ev_drawn, self._ev_ingested = torch.cuda.Event(), torch.cuda.Event()
+        self._ev_drawn, self._ev_ingested, self._ev_sunk, self._ev_predrawn = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        for ev in (self._ev_drawn, self._ev_ingested, self._ev_sunk, self._ev_predrawn):
+            ev.record()  # (torch creates the HIP event at the first record: the library keeps raw handles of two of them)
+        # pre-draw: the NEXT update's batch is drawn right behind this update's write-back, into the replay's other buffer set, instead of at the head of the next
+        # update's chain.  On for a learner rank's replay, where the update's own chain is the period (0.338 -> 0.323 ms per period alone on a GPU, same box); beside
+        # this GPU's own actors the period is contention-bound and the move changed nothing (0.457 against 0.454 ms, same box): off there unless SRLX_PREDRAW=1.
+        self._predraw = bool(self.fast and self._update_side and self.s_ingest is not None and getattr(self.lreplay, "two_sets", False)
+                             and os.environ.get("SRLX_PREDRAW", "1" if learner_replay is not None else "0") == "1")
+        self._bset, self._drawn, self._drawn_at = 0, None, 0
+        self.s_predraw = torch.cuda.Stream(device=self.dev, priority=-1) if self._predraw else None
 
     @property
     def lreplay(self) -> DeviceReplay:
@@ -543,11 +552,14 @@ class RainbowEngine:
         return tuple(c.obs_hw) == (84, 84) and c.window_length == 4 and c.filters == 32 and os.environ.get("SRLX_NO_FUSED_CONV", "0") != "1"
 
     # ---- learner (model_torch.py:85-122) -----------------------------------------------------
-    def _learner_body(self, publish: Optional[int] = None, ingest=None):
+    def _learner_body(self, publish: Optional[int] = None, ingest=None, bset: Optional[int] = None, have_batch: bool = False, predraw: bool = False):
         """One Rainbow update.  fast engines: `publish` = the actor set (0 / 1) this update also writes -- the first dense layer as operand planes from the fused
         Adam's epilogue, packed filters and small vectors with the packing launch that follows the optimiser step (None: that launch only packs for this handle's
-        own next forward).  `ingest` (a learner rank, device/dist.py): a callable issuing the launches that commit transitions from other ranks; they run on a side
-        stream behind the draw (the update samples the tree one add older) and the priority write-back waits for them: the tree sees draw -> add -> write-back."""
+        own next forward).  `ingest`: a callable issuing the launches that add committed transitions to the tree (a learner rank's arrived slab, device/dist.py; the
+        single-GPU engine's previous lock-step); they run on a side stream and the priority write-back waits for them.
+        Pre-draw (round 5): `bset` = the replay's buffer set this update trains on, `have_batch` = the PREVIOUS update drew it already (no draw at the head of this
+        update's chain), `predraw` = this update draws the next one's batch into the other set right behind its priority write-back, beside the rest of its backward
+        pass.  The tree sees the same sequence of operations either way: ... add, write-back(u), draw(u + 1), add, write-back(u + 1), draw(u + 2) ..."""
         cfg, r = self.cfg, self.lreplay
         B, n, A = cfg.batch_size, cfg.multisteps, cfg.n_actions
         pe = getattr(self, "_phase_mark", None)  # tools/lockstep_phases.py: timing events recorded inside the (captured) update; None in production
@@ -566,10 +578,13 @@ class RainbowEngine:
                 self._ev_ingested.record(self.s_ingest)
 
         mark(0)
+        if bset is not None:
+            r.use_set(bset)
+        step_dev = r.rng_counter if self._predraw else self.train_count_dev  # (pre-draw: the draw's own number is the update's number; srlx_per.hip:sample_wg_body)
         if self.fast:
             self.inf_online.fuse_adam_planes(self._planes_ptr[publish] if publish is not None else None)
         if self.mfma_train:
-            b = r.sample_items(self.train_count_dev, all_states=True)
+            b = r.batch if have_batch else r.sample_items(step_dev, all_states=True)
             mark(1)
             cur = torch.cuda.current_stream(self.dev)
             fork_ingest(cur)
@@ -591,6 +606,7 @@ class RainbowEngine:
             if self.fast and self._update_side:
                 self.inf_online.set_priority_sink(r, b.indices, self.priorities)
                 self.inf_online.set_sink_wait(self._ev_ingested if ingest is not None else None)
+                self.inf_online.set_sink_done(self._ev_sunk if predraw else None)
             if self._fused_td:  # ... in the prologue of the backward's first kernel
                 self.inf_online.backward_td_u8(r.obs_base, r.frame_off_all, n, q_all, q_tg_next, b.actions, b.rewards, b.terminated, b.weights, cfg.discount,
                                                cfg.retrace_h, cfg.enable_double_dqn, cfg.enable_rescale, self.target, self.loss, self.grad_q0, self.priorities)
@@ -603,11 +619,20 @@ class RainbowEngine:
                     )
                 )
                 self.inf_online.backward_u8(r.obs_base, r.frame_off_all, self.grad_q0, sample_stride=n + 1)
+            if predraw:  # the NEXT update's batch: behind this update's write-back (and the add it waited for), beside the rest of this backward pass
+                self.s_predraw.wait_event(self._ev_sunk)
+                with torch.cuda.stream(self.s_predraw):
+                    r.use_set(1 - bset)
+                    r.sample_items(step_dev, all_states=True)
+                    r.use_set(bset)
+                    self._ev_predrawn.record(self.s_predraw)
             mark(4)
             self.optimizer.step(self.train_count_dev)
             mark(5)
             if ingest is not None:
                 cur.wait_event(self._ev_ingested)  # (the side stream joins: a capture must see it come back; a write-back on this stream must follow the add)
+            if predraw:
+                cur.wait_event(self._ev_predrawn)
             if self.fast:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors); train_count_dev += 1
                 self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0,
                                            bump=self.train_count_dev if self._update_side else None)
@@ -638,20 +663,32 @@ class RainbowEngine:
 
     def learner_step(self, publish: Optional[int] = None) -> bool:
         """Returns False while the replay is below warm-up (priority_replay_buffer.py:228-230).  A pending `self.ingest` rides on this update."""
-        if self.lreplay.is_warmup_needed():
+        r = self.lreplay
+        if r.is_warmup_needed():
             return False
         if self.fast:
             self._check_versions()  # (a state dict loaded behind the engine's back: re-pack before anything trains on stale filters)
         ing, self.ingest = self.ingest, None
-        key = (publish, ing[0] if ing is not None else None)
+        ing_key, ing_fn = (ing[0], ing[1]) if ing is not None else (None, None)
+        bset, have, pre = None, False, False
+        if self._predraw:
+            bset, pre = self._bset, True
+            # the set holds a batch the previous update drew -- unless more than one ring commit has passed since (updates paused): its frames may be gone
+            have = self._drawn == bset and r._steps_committed - self._drawn_at <= 1
+            if self._drawn is not None and not have:
+                r.rng_counter.sub_(1)  # the stale draw is dropped: this update draws under the same number (the draw's number is the update's number)
+        key = (publish, ing_key, bset, have)
         g = self._learner_graphs.get(key)
         if g is None and self._capturing and not self._in_capture:  # a combination first seen after `capture_graphs`: captured now, replayed from then on
             torch.cuda.current_stream(self.dev).synchronize()
-            g = self._capture_learner(key, ing[1] if ing is not None else None)
+            g = self._capture_learner(key, ing_fn, pre)
         if g is not None:
             g.replay()
         else:
-            self._learner_body(publish, ing[1] if ing is not None else None)
+            self._learner_body(publish, ing_fn, bset, have, pre)
+        if self._predraw:
+            r.use_set(bset)  # (host view: `batch`, `used`, ... name what THIS update trained on)
+            self._drawn, self._drawn_at, self._bset = 1 - bset, r._steps_committed, 1 - bset
         if self.fast:
             self._fresh_set = publish  # the planes of that set now hold the online weight (None: no set does)
         # model_torch.py:117-119 (fires at train_count 0 too)
@@ -660,12 +697,12 @@ class RainbowEngine:
         self.train_count += 1
         return True
 
-    def _capture_learner(self, key, ingest_fn):
+    def _capture_learner(self, key, ingest_fn, predraw: bool = False):
         g = torch.cuda.CUDAGraph()
         self._in_capture = True
         try:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime meanwhile
-                self._learner_body(key[0], ingest_fn)
+                self._learner_body(key[0], ingest_fn, key[2] if len(key) > 2 else None, key[3] if len(key) > 3 else False, predraw)
         finally:
             self._in_capture = False
         self._learner_graphs[key] = g
@@ -843,9 +880,9 @@ class RainbowEngine:
             self._capturing = True
         if self.fast:  # the actors' launches stay eager; the update is captured per variant: publishing into set 0 / set 1 / not at all
             if learner and self.role != "actor" and not self.lreplay.is_warmup_needed() and self.learner_replay is None and not self.replay.lagged:
-                for key in ([(None, None), (0, None), (1, None)] if self.role == "both" else [(None, None)]):
+                for key in ([(None, None, None, False), (0, None, None, False), (1, None, None, False)] if self.role == "both" else [(None, None, None, False)]):
                     self._capture_learner(key, None)
-                self._learner_graph = self._learner_graphs[(None, None)]
+                self._learner_graph = self._learner_graphs[(None, None, None, False)]
             torch.cuda.synchronize(self.dev)
             return
         if actor and self.role != "learner" and not self._own_ring_only:
@@ -860,7 +897,7 @@ class RainbowEngine:
             self.replay._steps_committed -= 1  # capture does not execute
             self._commit_graph = g
         if learner and self.role != "actor" and not self.lreplay.is_warmup_needed() and self.learner_replay is None:
-            self._learner_graph = self._capture_learner((None, None), None)
+            self._learner_graph = self._capture_learner((None, None, None, False), None)
         torch.cuda.synchronize(self.dev)
 
     def refresh_host_mirrors(self):

@@ -88,20 +88,23 @@ class DeviceReplay:
         self._pending_add = None  # lagged: parity of the commit whose tree add has not been launched yet
         self.u = torch.zeros(B + self.slack, dtype=torch.float64, device=d)
         self.rng_counter = torch.zeros(1, dtype=torch.int64, device=d)
-        self.used = torch.zeros(1, dtype=torch.int64, device=d)
-        self.batch = ReplayBatch(
-            indices=torch.zeros(B, dtype=torch.int64, device=d),
-            weights=torch.zeros(B, dtype=torch.float32, device=d),
-            obs=torch.zeros((B, n + 1, window, obs_elems), dtype=torch.float32, device=d),
-            actions=torch.zeros((B, n), dtype=torch.int32, device=d),
-            rewards=torch.zeros((B, n), dtype=torch.float32, device=d),
-            terminated=torch.zeros((B, n), dtype=torch.float32, device=d),
-        )
+        obs = torch.zeros((B, n + 1, window, obs_elems), dtype=torch.float32, device=d)  # (the float32 windows of the autograd yardstick: shared by both sets)
+        # TWO sets of everything a draw writes (batch, frame-offset tables, consumed-uniform count): an engine draws the batch of update u + 1 while update u's
+        # backward pass still reads its own (RainbowEngine: pre-draw); `use_set(k)` points the plain attribute names at one of them
+        self.two_sets = True
+        self._sets = []
+        for _ in range(2):
+            self._sets.append(dict(
+                batch=ReplayBatch(indices=torch.zeros(B, dtype=torch.int64, device=d), weights=torch.zeros(B, dtype=torch.float32, device=d), obs=obs,
+                                  actions=torch.zeros((B, n), dtype=torch.int32, device=d), rewards=torch.zeros((B, n), dtype=torch.float32, device=d),
+                                  terminated=torch.zeros((B, n), dtype=torch.float32, device=d)),
+                used=torch.zeros(1, dtype=torch.int64, device=d),
+                frame_off_next=torch.zeros((B, n, window), dtype=torch.int64, device=d),
+                frame_off_all=torch.zeros((B, n + 1, window), dtype=torch.int64, device=d)))
+        self.use_set(0)
         self.stacked = torch.zeros((n_envs, window, obs_elems), dtype=torch.float32, device=d)
         # frame-offset tables for the matrix-core network (conv1 reads the uint8 ring directly)
         self.frame_off_actor = torch.zeros((n_envs, window), dtype=torch.int64, device=d)
-        self.frame_off_next = torch.zeros((B, n, window), dtype=torch.int64, device=d)
-        self.frame_off_all = torch.zeros((B, n + 1, window), dtype=torch.int64, device=d)
         self.obs0 = torch.zeros((B, 1, window, obs_elems), dtype=torch.float32, device=d)
         base, fb = N.c_p(), N.c_i64()
         N.check(self.lib.srlx_store_obs_base(hs, ctypes.byref(base), ctypes.byref(fb)))
@@ -116,6 +119,12 @@ class DeviceReplay:
         self.table_fresh = False  # `frame_off_actor` holds the table of the CURRENT ring position (written by the last commit)
         self.has_duplicate = bool(has_duplicate)
         self._drew = False
+
+    def use_set(self, k: int):
+        """`batch`, `used`, `frame_off_all`, `frame_off_next` := buffer set k (0 / 1): what the next draw writes and what readers of these names see."""
+        st = self._sets[k]
+        self.set_index = k
+        self.batch, self.used, self.frame_off_next, self.frame_off_all = st["batch"], st["used"], st["frame_off_next"], st["frame_off_all"]
 
     def enable_deferred_advance(self):
         """The round-4 lock-step: a commit leaves the ring position where it is and the PER add that closes the lock-step advances it inside its own launch

@@ -522,7 +522,7 @@ def _order_worker(rank, world, port, ret, fast):
             torch.cuda.synchronize()
             # the learner's side of this lock-step, replayed on the oracle in the order the tree must have seen: draw -> add (the slab committed inside the update) -> write-back
             if eng.local.train_count > trained0:
-                u = H.rng_uniform(cfg.seed ^ 0x5EED, counter0, rp.u.numel())
+                u = H.rng_uniform(cfg.seed ^ 0x5EED, trained0, rp.u.numel())
                 used, idx, w, _ = o.sample(B, trained0, u)
                 assert used == int(rp.used.item()) and used > 0
                 np.testing.assert_array_equal(rp.batch.indices.cpu().numpy(), idx)

@@ -404,7 +404,7 @@ def test_lagged_add_tree_order_against_the_oracle(actor_stream):
             torch.cuda.synchronize()
             trained = eng.train_count > trained0
             if trained:
-                used, idx, w, _ = o.sample(B, trained0, H.rng_uniform(cfg.seed ^ 0x5EED, counter0, rp.u.numel()))
+                used, idx, w, _ = o.sample(B, trained0, H.rng_uniform(cfg.seed ^ 0x5EED, trained0, rp.u.numel()))
                 assert used == int(rp.used.item()) and used > 0
                 np.testing.assert_array_equal(rp.batch.indices.cpu().numpy(), idx)
                 checked += 1

@@ -310,7 +310,7 @@ def main():
     if dist is None and not args.no_subfigures:
         out["subfigures"] = subfigures(eng, args, inner)
         eng.close()  # (the engine took the thread to its actors' low-priority stream: hand it back before other engines are built and timed)
-        if args.algo == "rainbow" and not args.noisy and args.envs >= 512 and args.envs % 128 == 0:
+        if args.algo == "rainbow" and not args.noisy and args.envs >= 512 and args.envs % 128 == 0 and os.environ.get("SRLX_NO_ROLES", "0") != "1":
             try:
                 out["subfigures"]["roles"] = role_timings(args, dev_index)
             except Exception as exc:  # a side figure must never take the measured line down with it

@@ -587,13 +587,20 @@ class RainbowEngine:
             b = r.batch if have_batch else r.sample_items(step_dev, all_states=True)
             mark(1)
             cur = torch.cuda.current_stream(self.dev)
-            fork_ingest(cur)
+            # where the ingest is enqueued decides which hardware queue gets its first kernel when: a learner rank's ingest (ring commit + 7168-leaf add: 150 us, the
+            # write-back waits for it) goes FIRST (period alone 0.322 against 0.458 ms); the single-GPU engine's (one 16 us add) goes behind the two network passes,
+            # which then start together (0.4466 against 0.4555 ms per lock-step; both same-box)
+            early = self.learner_replay is not None
+            if early:
+                fork_ingest(cur)
             self._ev_t0.record(cur)
             self.s_target.wait_event(self._ev_t0)
             with torch.cuda.stream(self.s_target):  # fork: target network (rainbow.py:221) alongside the online network
                 q_tg_next = self.inf_target.forward_u8(r.obs_base, r.frame_off_next.view(B * n, cfg.window_length))
                 self._ev_t1.record(self.s_target)
             q_all = self.inf_online.forward_u8(r.obs_base, r.frame_off_all.view(B * (n + 1), cfg.window_length))
+            if not early:
+                fork_ingest(cur)
             if self.noisy:
                 # the reference evaluates q_online(s_1..s_n) (rainbow.py:220) and q_online(s_0) (model_torch.py:103) in two forward
                 # calls, i.e. under two noise draws: re-evaluate the dense layers of the s_0 rows under a fresh one

@@ -2,7 +2,7 @@
 # kernel timeline of one learner update ALONE on the round-4 lock-step's engine (E = 1024): the last updates of the bench command are its `subfigures.learner_only` loop
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trf
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trf -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --inner 20 --no-cpu-baseline --no-per-micro > /tmp/trf.log 2>&1
+SRLX_NO_ROLES=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trf -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --inner 20 --no-cpu-baseline --no-per-micro > /tmp/trf.log 2>&1
 f=$(find /tmp/trf -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys

@@ -587,9 +587,10 @@ class RainbowEngine:
             b = r.batch if have_batch else r.sample_items(step_dev, all_states=True)
             mark(1)
             cur = torch.cuda.current_stream(self.dev)
-            # where the ingest is enqueued decides which hardware queue gets its first kernel when: a learner rank's ingest (ring commit + 7168-leaf add: 150 us, the
-            # write-back waits for it) goes FIRST (period alone 0.322 against 0.458 ms); the single-GPU engine's (one 16 us add) goes behind the two network passes,
-            # which then start together (0.4466 against 0.4555 ms per lock-step; both same-box)
+            # Where the ingest is enqueued decides which hardware queue gets its first kernel when (same-box A/B, profiles/r5_ab_ingest_order.txt): a learner rank's
+            # ingest (ring commit + 7168-leaf add: 150 us, the write-back waits for it) goes FIRST -- period alone 0.326 ms against 0.427 behind the target fork and
+            # 0.467 behind both passes' launches; the single-GPU engine's (one 16 us add) goes behind the online PASS ITSELF (dependent on it): 0.432 ms per lock-step
+            # against 0.454 first, 0.444 behind the target fork, 0.493 behind the launches but independent of them
             early = self.learner_replay is not None
             if early:
                 fork_ingest(cur)

@@ -596,11 +596,15 @@ class RainbowEngine:
                 fork_ingest(cur)
             self._ev_t0.record(cur)
             self.s_target.wait_event(self._ev_t0)
+            on_target = (not early) and ingest is not None  # (... and on the target pass's own stream, behind that pass: -0.5 % against a stream of its own behind the online pass)
             with torch.cuda.stream(self.s_target):  # fork: target network (rainbow.py:221) alongside the online network
                 q_tg_next = self.inf_target.forward_u8(r.obs_base, r.frame_off_next.view(B * n, cfg.window_length))
                 self._ev_t1.record(self.s_target)
+                if on_target:
+                    ingest()
+                    self._ev_ingested.record(self.s_target)
             q_all = self.inf_online.forward_u8(r.obs_base, r.frame_off_all.view(B * (n + 1), cfg.window_length))
-            if not early:
+            if not early and not on_target:
                 fork_ingest(cur)
             if self.noisy:
                 # the reference evaluates q_online(s_1..s_n) (rainbow.py:220) and q_online(s_0) (model_torch.py:103) in two forward

@@ -658,6 +658,7 @@ def role_timings(args, dev_index, actor_ranks=7):
     ring_len = -(-cfg.memory_capacity // total) + pad
     replay = DeviceReplay(total, ring_len, 84 * 84, cfg.window_length, cfg.multisteps, cfg.n_actions, cfg.batch_size, True, cfg.enable_reward_clip, cfg.memory_alpha,
                           cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, dev_index)
+    replay.enable_deferred_advance()
     eng = RainbowEngine(local_cfg, dev_index, args.episode_len, ring_len=pad + 4, role="learner", learner_replay=replay)
     g = torch.Generator(device=dev).manual_seed(1)
     rec = (10) * E

@@ -314,6 +314,7 @@ class DistributedRainbow:
                 cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
                 has_duplicate=cfg.memory_has_duplicate,
             )
+            self.replay.enable_deferred_advance()  # every ring commit of the global replay is followed by its tree add (`_ingest_fn`): the add moves the position
             self.est_buf = torch.full((total,), -1.0, dtype=torch.float32, device=self.dev)
             role = "both" if self.acts else "learner"
             self.local = RainbowEngine(local_cfg, device, episode_len, ring_len=pad + 4, env=env, overlap=overlap and self.acts, role=role, learner_replay=self.replay,

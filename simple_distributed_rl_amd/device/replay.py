@@ -188,11 +188,12 @@ class DeviceReplay:
     def commit_packed(self, records: torch.Tensor, envs_per_record: int, extra_floats: int, next_obs: torch.Tensor, est_records: Optional[torch.Tensor] = None,
                       est_out: Optional[torch.Tensor] = None):
         """The ring commit of a lock-step that arrived as packed records (uint8 [ranks][record bytes], device/dist.py) -- LAUNCH ONLY: no host bookkeeping, so the call
-        may sit inside a captured graph; the caller reports every execution with `note_commit()`.  The ring position advances inside the launch.  est_records /
-        est_out: srlx_store_commit_step_packed."""
+        may sit inside a captured graph; the caller reports every execution with `note_commit()`.  The ring position advances inside the launch -- or, after
+        `enable_deferred_advance()`, with the tree add that must follow (the launch then spreads over eight times as many workgroups: no arrival tickets).
+        est_records / est_out: srlx_store_commit_step_packed."""
         assert records.dtype == torch.uint8 and records.dim() == 2 and records.is_contiguous()
         N.check(self.lib.srlx_store_commit_step_packed(self.h_store, N.tptr(records), records.shape[1], int(envs_per_record), int(extra_floats), N.tptr(next_obs),
-                                                       N.tptr(self.item_mask), N.tptr(est_records), N.tptr(est_out), 1, N.torch_stream_ptr()))
+                                                       N.tptr(self.item_mask), N.tptr(est_records), N.tptr(est_out), 0 if self.deferred_advance else 1, N.torch_stream_ptr()))
 
     def note_commit(self):
         """One `commit_packed` launch has been enqueued for execution (eagerly or by a graph replay)."""

@@ -145,7 +145,7 @@ def main():
         assert eng.n_actor_ranks == actor_ranks
     else:
         eng = RainbowEngine(cfg, dev_index, args.episode_len, overlap=not args.no_overlap, actor_stream=None if args.actor_stream == "default" else args.actor_stream)
-    lockstep = "round-4 lock-step (6 launches on the actors' stream, published parameter sets)" if getattr(getattr(eng, "local", eng), "fast", False) else "fifteen-launch lock-step"
+    lockstep = "fast lock-step (6 launches on the actors' stream, published parameter sets; round 5: the tree add rides on a side branch of the next update)" if getattr(getattr(eng, "local", eng), "fast", False) else "fifteen-launch lock-step"
 
     # ---- fill the replay (untimed): random-policy rollout until the ring is full, then |delta| ~ U(0,1)
     #      priorities like tests/quick/rl/memories/speedtest.py:40-41

@@ -838,9 +838,26 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
     // else's is dropped.
     const int maxd = tr.D;
     const i64 tasks = n * (i64)maxd;
-    const bool pre = tasks <= 2 * (i64)T && n <= T;
+    // n <= 64 (the learner's calls): the WAVE FORM of the ancestor pass below -- lane i of every wave holds index i, wave w owns the tree depths w and w + 16
+    const bool wave_form = n <= 64 && T == 1024 && maxd <= 32;
+    const bool pre = !wave_form && tasks <= 2 * (i64)T && n <= T;
     double pre_v[2] = {0.0, 0.0}, pre_leaf = 0.0;
     i64 pre_pa[2] = {0, 0};
+    unsigned wf_key[2] = {~0u, ~0u};  // position of lane i's ancestor within depth w + 16 r (~0: index i has no ancestor there)
+    if (wave_form) {
+        const int lane = t & 63, w = t >> 6;
+        const i64 x = lane < n ? s_idx[lane] : 0;
+        const int dep = lane < n ? s_dep[lane] : 0;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int d = w + 16 * r;
+            if (d >= dep) continue;
+            wf_key[r] = (unsigned)(((x + 1) >> (dep - d)) - ((i64)1 << d));
+            pre_pa[r] = tr.phys((((i64)1 << d) - 1) + wf_key[r]);
+            pre_v[r] = tr.T[pre_pa[r]];
+        }
+        if (t < n) pre_leaf = tr.get(x);
+    }
     if (pre) {
 #pragma unroll
         for (int r = 0; r < 2; r++) {
@@ -872,7 +889,7 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
     }
     __syncthreads();
 
-    bool last_me[ (kUpdateChunk + kWgUpdate - 1) / kWgUpdate ];
+    unsigned last_me = 0u;  // bit q: this thread's q-th index is the last occurrence of its leaf (kUpdateChunk / kWgUpdate <= 32 rounds)
     int q = 0;
     for (i64 i = t; i < n; i += T, q++) {
         const i64 x = s_idx[i];
@@ -887,18 +904,46 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
                     break;
                 }
         }
-        const double before = prev >= 0 ? s_p[prev] : (pre ? pre_leaf : tr.get(x));
+        const double before = prev >= 0 ? s_p[prev] : (pre || wave_form ? pre_leaf : tr.get(x));
         s_chg[i] = s_p[i] - before;  // :83
-        last_me[q] = last;
+        last_me |= (last ? 1u : 0u) << q;
     }
     __syncthreads();  // every old leaf value has been read
     q = 0;
     for (i64 i = t; i < n; i += T, q++)
-        if (last_me[q]) tr.set(s_idx[i], s_p[i]);  // :85
+        if ((last_me >> q) & 1u) tr.set(s_idx[i], s_p[i]);  // :85
 
     // ancestors (:49-54).  task (i, k): the k-th ancestor of index i; the first i that reaches a
     // node owns it.
-    for (i64 task = t; task < tasks; task += T) {
+    if (wave_form) {
+        // Every lane with an ancestor on this depth replays `node += change_j` over the call's indices in list order (the reference's order for that node): the other
+        // indices' node positions and changes come out of the wave's own registers (v_readlane: no LDS round trips, no ownership scan -- lanes under the same node
+        // compute the same sum and store the same value).  A depth on which no index of the wave shares a node (the pair pass above) skips the replay.  Round 5:
+        // the LDS scans this replaces were 6.7 of a 64-index call's 14.0 us (tools/_upd_abl.sh).
+        const int lane = t & 63, w = t >> 6;
+        const double chg = lane < n ? s_chg[lane] : 0.0;
+        const int sh = lane < n ? s_shared[lane] : -1;
+        const int clo = __double2loint(chg), chi = __double2hiint(chg);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int d = w + 16 * r;
+            const unsigned key = wf_key[r];
+            const bool valid = key != ~0u;
+            double v = pre_v[r];
+            if (__any(valid && d <= sh)) {
+#pragma unroll 8
+                for (int j = 0; j < (int)n; j++) {
+                    const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
+                    const double sum = v + __hiloint2double(__builtin_amdgcn_readlane(chi, j), __builtin_amdgcn_readlane(clo, j));
+                    v = kj == key ? sum : v;
+                }
+            } else {
+                v += chg;
+            }
+            if (valid) tr.T[pre_pa[r]] = v;
+        }
+    }
+    for (i64 task = t; !wave_form && task < tasks; task += T) {
         const i64 i = task % n;  // level-major: a wave's lanes sit on the same few levels, so whole waves (the deep levels) skip the scans
         const int k = (int)(task / n) + 1;
         const int dx = s_dep[i];
@@ -913,8 +958,8 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
         }
         if (!owner) continue;
         const int r = (int)(task / T);
-        const i64 pa = pre ? pre_pa[r & 1] : tr.phys(a);
-        double v = pre ? pre_v[r & 1] : tr.T[pa];
+        const i64 pa = pre ? ((r & 1) ? pre_pa[1] : pre_pa[0]) : tr.phys(a);  // (selects, not a run-time index: that would put the arrays into scratch memory)
+        double v = pre ? ((r & 1) ? pre_v[1] : pre_v[0]) : tr.T[pa];
         v += s_chg[i];
         if (!alone) {
 #pragma unroll 8
@@ -1214,7 +1259,7 @@ int launch_update(srlx_per *h, i64 n, const i64 *d_idx, const void *d_prio, int 
     for (i64 off = 0; off < n; off += kUpdateChunk) {
         const i64 m = (n - off < kUpdateChunk) ? n - off : kUpdateChunk;
         // one thread per (index, ancestor) task where that fits: the B = 32 learner call is 640 tasks, one round at 1024 threads
-        const int threads = m * (i64)h->tree.D > kWgUpdate ? 1024 : kWgUpdate;
+        const int threads = (m <= 64 || m * (i64)h->tree.D > kWgUpdate) ? 1024 : kWgUpdate;  // (m <= 64: the kernel's wave form wants its 16 waves)
         const size_t lds = (size_t)m * (8 + 8 + 8 + 4 + 4) + (size_t)threads * 8 + 16;
         hipLaunchKernelGGL(k_update_wg, dim3(1), dim3(threads), lds, st, h->tree, h->d_state, m,
                            d_idx + off, (const void *)((const char *)d_prio + (size_t)off * eb), kind, h->epsilon,

@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
     ap.add_argument("--no-per-micro", action="store_true", help="skip the PER micro-benchmark (sample / update / add ops/s, bulk-sample HBM fraction)")
     ap.add_argument("--no-subfigures", action="store_true", help="skip the actor-only / learner-only timings")
+    ap.add_argument("--roles-only", action="store_true", help="only time the two roles of the multi-GPU job, each alone on this GPU (bench.py runs this in a process of its own)")
     ap.add_argument("--learner-acts", choices=("auto", "yes", "no"), default="auto",
                     help="N>1: does the learner rank run actors too? auto = yes below 4 GPUs, no (dedicated learner GPU) from 4")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 code path with several ranks on ONE GPU)")
@@ -90,8 +91,42 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def roles_only(args):
+    """`python bench.py --roles-only`: role_timings in this (fresh) process, with a one-rank RCCL process group initialised and used first -- a rank of the
+    multi-GPU job has RCCL's streams and helper threads beside its own."""
+    import torch
+
+    dev_index = int(os.environ.get("SRLX_ROLE_DEVICE", "0"))
+    torch.cuda.set_device(dev_index)
+    rccl = False
+    if os.environ.get("SRLX_ROLE_RCCL", "1") != "0":
+        try:
+            import socket
+
+            import torch.distributed as dist
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(f"cuda:{dev_index}"))
+            t = torch.ones(1 << 20, device=f"cuda:{dev_index}")
+            dist.broadcast(t, src=0)
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            rccl = True
+        except Exception:
+            rccl = False
+    out = role_timings(args, dev_index)
+    out["rccl_initialised"] = rccl
+    print(json.dumps(out), flush=True)
+    if rccl:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    if args.roles_only:
+        return roles_only(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -220,32 +255,28 @@ def main():
     if dist is not None and world > 1 and not args.no_strong_ref:
         if rank == 0:
             try:
-                import dataclasses
+                # in a process of its own (one process per GPU is how the N = 1 line is measured too; and what a process's earlier streams do to a later
+                # engine's hardware queues is not something a reference figure should depend on: roles_in_own_process), on rank 0's GPU, the other ranks idle
+                import subprocess
 
                 e_total = envs_per_gpu * actor_ranks
-                eng.local.close()  # (hands the thread's stream back before another engine takes it)
-                ref = RainbowEngine(dataclasses.replace(cfg, n_envs=e_total, actor_initial_priority=False), dev_index, args.episode_len, overlap=True,
-                                    actor_stream=None if args.actor_stream == "default" else args.actor_stream)
-                ref.prefill()
-                for _ in range(8):
-                    ref.step(args.updates)
-                torch.cuda.synchronize()
-                if not args.no_graph:
-                    ref.capture_graphs()
-                n_ref = max(8, min(n_lock, 48))
-                for _ in range(4):
-                    ref.step(args.updates)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(n_ref):
-                    ref.step(args.updates)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / n_ref
-                strong_ref = {"what": "the single-GPU engine (actors + learner on rank 0's GPU) at the job's total environment count, timed after the distributed region",
-                              "envs": e_total, "lock_steps": n_ref, "ms_per_lock_step": 1e3 * dt, "value": e_total / dt, "unit": "env-steps/s",
-                              "learner_updates_per_s": args.updates / dt}
-                ref.close()
-                del ref
+                inner_ref = max(4, min(args.inner, 16))
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--envs", str(e_total), "--steps", "3", "--warmup", "1", "--inner", str(inner_ref),
+                       "--updates", str(args.updates), "--batch-size", str(args.batch_size), "--capacity", str(args.capacity), "--episode-len", str(args.episode_len),
+                       "--actor-stream", args.actor_stream, "--no-cpu-baseline", "--no-per-micro", "--no-subfigures"] + (["--no-graph"] if args.no_graph else [])
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT")}
+                vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+                env["HIP_VISIBLE_DEVICES"] = vis.split(",")[dev_index] if vis else str(dev_index)  # rank 0's GPU is the child's device 0
+                env.pop("CUDA_VISIBLE_DEVICES", None)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode != 0 or not lines:
+                    raise RuntimeError((r.stderr or r.stdout)[-400:])
+                d = json.loads(lines[-1])
+                strong_ref = {"what": "the single-GPU engine (actors + learner on ONE GPU: rank 0's, the other ranks idle) at the job's total environment count, "
+                                      "timed after the distributed region in a process of its own (python bench.py --gpus 1 --envs <total>)",
+                              "envs": e_total, "lock_steps": 3 * inner_ref, "ms_per_lock_step": d["ms_per_lock_step"], "value": d["value"], "unit": "env-steps/s",
+                              "learner_updates_per_s": d["learner_updates_per_s"]}
             except Exception as exc:  # the reference figure must never take the measured line down with it
                 strong_ref = {"error": repr(exc)}
         dist.barrier()
@@ -311,10 +342,7 @@ def main():
         out["subfigures"] = subfigures(eng, args, inner)
         eng.close()  # (the engine took the thread to its actors' low-priority stream: hand it back before other engines are built and timed)
         if args.algo == "rainbow" and not args.noisy and args.envs >= 512 and args.envs % 128 == 0 and os.environ.get("SRLX_NO_ROLES", "0") != "1":
-            try:
-                out["subfigures"]["roles"] = role_timings(args, dev_index)
-            except Exception as exc:  # a side figure must never take the measured line down with it
-                out["subfigures"]["roles"] = {"error": repr(exc)}
+            out["subfigures"]["roles"] = roles_in_own_process(args, dev_index)
     if not args.no_per_micro:
         out["per_micro"] = per_micro(eng)
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other runs would only repeat it
@@ -609,6 +637,29 @@ def subfigures(eng, args, inner):
         "learner_only": {"ms_per_update": 1e3 * t_upd, "updates_per_s": 1.0 / t_upd},
         "note": "the timed region runs both concurrently (actor pass on the main stream, updates on the learner's streams)",
     }
+
+
+def roles_in_own_process(args, dev_index):
+    """`role_timings` in a FRESH process, as the roles run in the multi-GPU job (one process per GPU).  Not in this one: a process that has ever created a
+    low-priority HIP stream (this one's actors ran on one) replays a learner-only rank's update graph three times slower (0.95 against 0.32 ms per period,
+    same box, engine closed and dropped: tools/README.md finding 15) -- where the HIP runtime puts a graph's internal streams depends on the process's queue
+    history, and a learner-only rank never creates such a stream."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--roles-only", "--envs", str(args.envs), "--batch-size", str(args.batch_size), "--capacity", str(args.capacity),
+           "--episode-len", str(args.episode_len)] + (["--no-graph"] if args.no_graph else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env["SRLX_ROLE_DEVICE"] = str(dev_index)
+    try:  # a side figure must never take the measured line down with it
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        out = json.loads(lines[-1])
+        out["how"] = "each role alone on this GPU, in a process of its own (python bench.py --roles-only)"
+        return out
+    except Exception as exc:
+        return {"error": repr(exc)}
 
 
 def role_timings(args, dev_index, actor_ranks=7):

@@ -172,6 +172,8 @@ def test_bench_multi_rank_rehearsal(n, actor_gpus, launcher):
     # one update per lock-step: eager warm-up (warmup x min(inner, 8)), 2 after the switch to graphs (captured lazily: no extra update), warm-up, timed region
     assert d["final"]["train_count"] == warmup * min(inner, 8) + 2 + warmup * inner + steps * inner
     assert "cpu_baseline" not in d and d["roofline"]["avg_launch_ms"] > 0 and d["roofline"]["pass"]["avg_launch_group_ms"] > 0
+    # the same total environment count on ONE GPU, timed by rank 0 in a process of its own behind the distributed region: the line's own strong-scaling ratio
+    assert d["strong_ref"]["envs"] == 128 * actor_gpus and d["strong_ref"]["value"] > 0 and abs(d["strong_ratio"] - d["value"] / d["strong_ref"]["value"]) < 1e-9
 
 
 @pytest.mark.parametrize("n,actor_gpus", [pytest.param(2, 2, marks=pytest.mark.slow), (4, 3)])

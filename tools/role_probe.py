@@ -5,4 +5,4 @@ os.environ["SRLX_ROLE_PROBE"] = "1"
 import bench
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 args = bench.parse_args()
-print(json.dumps(bench.role_timings(args, 0), indent=1))
+print(json.dumps(bench.role_timings(args, 0), indent=1))  # (no RCCL in this process; `python bench.py --roles-only` initialises a one-rank group first)

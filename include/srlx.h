@@ -607,6 +607,13 @@ int srlx_qnet_set_debug(srlx_qnet_t *h, void *d_phase_stamps);
 int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch);
 int srlx_qnet_fuse_adam_fc1(srlx_qnet_t *h, float *d_exp_avg, float *d_exp_avg_sq, double lr, double beta1, double beta2, double eps,
                             const int64_t *d_steps_taken);
+/* srlx_qnet_fuse_adam_rest (round 5; after srlx_qnet_fuse_adam_fc1, whose hyper-parameters and step count it uses): `optimizer.step()` (model_torch.py:109) for
+ * EVERY OTHER tensor inside the launch that finishes its gradient -- the convolution weights and biases in the epilogue of their gradient reductions, the first
+ * dense layer's bias and the head's second layers in the small-vector range of the packing launch of srlx_qnet_publish -- so that no optimiser launch is left on
+ * the update's tail (srlx_adam_step is then not called at all).  The three arrays are indexed like the gradient list of srlx_qnet_backward_u8 (entry 6 ignored);
+ * every later backward pass must be handed the same gradient buffers, and EVERY backward pass must be followed by srlx_qnet_publish(h, ...) (which completes the
+ * step; the next backward pass fails loudly otherwise).  The arithmetic is srlx_adam_step's, element by element: bit-equal results.  d_grads == NULL: off. */
+int srlx_qnet_fuse_adam_rest(srlx_qnet_t *h, const float *const *d_grads, float *const *d_exp_avg, float *const *d_exp_avg_sq);
 int srlx_qnet_backward_u8(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, const uint8_t *d_frame_base, const int64_t *d_frame_off,
                           const float *d_grad_q, float *const *d_grads, void *stream);
 /* The image block alone (networks whose dense part is not this handle's dueling head: Agent57_light's UVFA Q-networks, embedding and RND networks --

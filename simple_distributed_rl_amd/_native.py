@@ -123,6 +123,7 @@ SIGNATURES = {
     "srlx_qnet_set_debug": (c_int, [c_p, c_p]),
     "srlx_qnet_set_side_stream": (c_int, [c_p, c_p]),
     "srlx_qnet_fuse_adam_fc1": (c_int, [c_p, c_p, c_p, c_f64, c_f64, c_f64, c_f64, c_p]),
+    "srlx_qnet_fuse_adam_rest": (c_int, [c_p, c_p, c_p, c_p]),
     "srlx_qnet_backward_u8": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_qnet_backward_convs_u8": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_qnet_backward_td_u8": (c_int, [c_p, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),

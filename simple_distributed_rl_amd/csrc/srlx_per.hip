@@ -28,6 +28,7 @@
 //   per_update : 16 B leaf R/W + depth*16 B ancestor RMW per index           -> latency bound at B=32
 //   per_add    : same as update + 8 B priority                               -> root chain (n fp64 adds)
 #include <new>
+#include <type_traits>
 
 #include "srlx_common.h"
 #include "srlx_store_dev.h"
@@ -931,12 +932,19 @@ __global__ void __launch_bounds__(1024) k_update_wg(Tree tr, PerState *state, i6
             const bool valid = key != ~0u;
             double v = pre_v[r];
             if (__any(valid && d <= sh)) {
-#pragma unroll 8
-                for (int j = 0; j < (int)n; j++) {
-                    const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
-                    const double sum = v + __hiloint2double(__builtin_amdgcn_readlane(chi, j), __builtin_amdgcn_readlane(clo, j));
-                    v = kj == key ? sum : v;
-                }
+                // (fully unrolled over constant lane numbers; lanes past n hold no index: their position never equals a valid one)
+                auto replay = [&](auto cnt) {
+#pragma unroll
+                    for (int j = 0; j < decltype(cnt)::value; j++) {
+                        const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
+                        const double sum = v + __hiloint2double(__builtin_amdgcn_readlane(chi, j), __builtin_amdgcn_readlane(clo, j));
+                        v = kj == key ? sum : v;
+                    }
+                };
+                if (n <= 32)
+                    replay(std::integral_constant<int, 32>{});
+                else
+                    replay(std::integral_constant<int, 64>{});
             } else {
                 v += chg;
             }

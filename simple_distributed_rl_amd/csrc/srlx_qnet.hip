@@ -855,6 +855,7 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
     if (h->c1_gpart) (void)hipFree(h->c1_gpart);
     if (h->c1_cnt) (void)hipFree(h->c1_cnt);
     if (h->d_draw) (void)hipFree(h->d_draw);
+    if (h->step_snap) (void)hipFree(h->step_snap);
     if (h->aset_cur >= 0) h->wpack = h->wpack_own, h->wf_planes = h->wf_planes_own;
     for (auto &st_ : h->aset) {
         if (st_.wpack) (void)hipFree(st_.wpack);
@@ -1014,14 +1015,14 @@ int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int wit
     srlx::DeviceGuard guard(h_src->device);
     hipStream_t st = (hipStream_t)stream;
     if (!h_actor) {
-        SRLX_TRY(srlx_qnet_pack_publish(h_src, nullptr, nullptr, st, d_bump));
+        SRLX_TRY(srlx_qnet_pack_publish(h_src, nullptr, nullptr, st, d_bump, true));
         h_src->pack_valid = true;
         return SRLX_OK;
     }
     SRLX_REQUIRE((set == 0 || set == 1) && h_actor->aset[set].wpack, "qnet_publish: srlx_qnet_actor_sets_enable on the actor handle first");
     SRLX_REQUIRE(h_actor->hidden == h_src->hidden && h_actor->A == h_src->A && h_actor->flat == h_src->flat, "qnet_publish: the two handles describe different networks");
     const srlx_small_layout L = srlx_small_offsets(h_actor);
-    SRLX_TRY(srlx_qnet_pack_publish(h_src, &h_actor->aset[set], &L, st, d_bump));
+    SRLX_TRY(srlx_qnet_pack_publish(h_src, &h_actor->aset[set], &L, st, d_bump, true));
     if (h_src->aset_cur < 0) h_src->pack_valid = true;
     if (with_fc1) SRLX_TRY(srlx_fc1_planes_split_weight(h_actor, h_src->bound[6], nullptr, st, h_actor->aset[set].wf_planes));
     return SRLX_OK;

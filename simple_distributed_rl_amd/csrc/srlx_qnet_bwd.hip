@@ -372,17 +372,34 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_mfma(ConvGeo g, i64 sstride,
 // 256 outputs (64 lanes x float4) x 4 slices per workgroup: slice s adds its run of parts in order (the loads of a run are independent: up to 16 in
 // flight), the slices are then added in order -- a fixed summation order.  (256 threads, not more: a 1024-thread workgroup waits
 // for sixteen free wave slots on one CU, which beside the actors' convolution workgroups took 25 us per launch.)
+struct AdamArgs {
+    double lr, beta1, beta2, eps;
+    const i64 *d_step;
+};
+// ADAM (srlx_qnet_fuse_adam_rest): the optimiser step of the weight / bias right behind the sum, in place -- the arithmetic and the operand order of k_adam
+// (srlx_adam_math.h), so the fused update is bit-equal to the separate launch.  `snap` (one launch per update): the step count is copied for the packing launch.
+template <bool ADAM>
 __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, int P, i64 n, float *__restrict__ out, const float *__restrict__ bpart, int nb,
-                                                      float *__restrict__ bout) {
+                                                      float *__restrict__ bout, float *__restrict__ pw = nullptr, float *__restrict__ mw = nullptr,
+                                                      float *__restrict__ vw = nullptr, float *__restrict__ pb = nullptr, float *__restrict__ mb = nullptr,
+                                                      float *__restrict__ vb = nullptr, AdamArgs ad = AdamArgs{}, i64 *__restrict__ snap = nullptr) {
     __shared__ float4 sm[4][64];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     i64 i = ((i64)blockIdx.x * 64 + lane) * 4;  // four consecutive outputs per lane (n and nb are multiples of 4)
     const bool live = i < n + nb;
+    if (ADAM && snap && blockIdx.x == 0 && threadIdx.x == 0) *snap = *ad.d_step;
     if (i >= n) {
         i -= n;
         part = bpart;
         n = nb;
         out = bout;
+        pw = pb, mw = mb, vw = vb;
+    }
+    float4 pp, mm, vv;
+    i64 step = 0;
+    if (ADAM && sl == 0 && live) {  // requested ahead of the partial sums: one memory round trip for the launch
+        pp = *reinterpret_cast<const float4 *>(pw + i), mm = *reinterpret_cast<const float4 *>(mw + i), vv = *reinterpret_cast<const float4 *>(vw + i);
+        step = *ad.d_step;
     }
     const int per = (P + 3) / 4, p_lo = sl * per, p_hi = p_lo + per < P ? p_lo + per : P;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -396,7 +413,18 @@ __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ 
     __syncthreads();
     if (sl == 0 && live) {
         const float4 a = sm[1][lane], b = sm[2][lane], c = sm[3][lane];
-        *reinterpret_cast<float4 *>(out + i) = make_float4(((s.x + a.x) + b.x) + c.x, ((s.y + a.y) + b.y) + c.y, ((s.z + a.z) + b.z) + c.z, ((s.w + a.w) + b.w) + c.w);
+        const float4 g = make_float4(((s.x + a.x) + b.x) + c.x, ((s.y + a.y) + b.y) + c.y, ((s.z + a.z) + b.z) + c.z, ((s.w + a.w) + b.w) + c.w);
+        *reinterpret_cast<float4 *>(out + i) = g;
+        if (ADAM) {
+            const srlx::AdamCoef cf = srlx::adam_coef(ad.lr, ad.beta1, ad.beta2, ad.eps, step);
+            srlx::adam_one(pp.x, g.x, mm.x, vv.x, cf);
+            srlx::adam_one(pp.y, g.y, mm.y, vv.y, cf);
+            srlx::adam_one(pp.z, g.z, mm.z, vv.z, cf);
+            srlx::adam_one(pp.w, g.w, mm.w, vv.w, cf);
+            *reinterpret_cast<float4 *>(pw + i) = pp;
+            *reinterpret_cast<float4 *>(mw + i) = mm;
+            *reinterpret_cast<float4 *>(vw + i) = vv;
+        }
     }
 }
 
@@ -667,6 +695,26 @@ int srlx_qnet_fuse_adam_fc1(srlx_qnet_t *h, float *d_exp_avg, float *d_exp_avg_s
     return SRLX_OK;
 }
 
+int srlx_qnet_fuse_adam_rest(srlx_qnet_t *h, const float *const *d_grads, float *const *d_exp_avg, float *const *d_exp_avg_sq) {
+    SRLX_REQUIRE(h, "qnet_fuse_adam_rest: NULL handle");
+    if (!d_grads) {
+        h->rest_on = h->rest_armed = false;
+        return SRLX_OK;
+    }
+    SRLX_REQUIRE(h->adam_m && h->adam_step, "qnet_fuse_adam_rest: call srlx_qnet_fuse_adam_fc1 first (its hyper-parameters and step count are used)");
+    SRLX_REQUIRE(d_exp_avg && d_exp_avg_sq && !h->sig[0] && h->bound[0], "qnet_fuse_adam_rest: bad argument (NoisyLinear networks are not fusable; parameters must be bound)");
+    for (int k = 0; k < 12; k++) {
+        if (k == 6) continue;
+        SRLX_REQUIRE(d_grads[k] && d_exp_avg[k] && d_exp_avg_sq[k], "qnet_fuse_adam_rest: tensor %d has a NULL buffer", k);
+        h->rest_g[k] = d_grads[k], h->rest_m[k] = d_exp_avg[k], h->rest_v[k] = d_exp_avg_sq[k];
+    }
+    srlx::DeviceGuard guard(h->device);
+    if (!h->step_snap) SRLX_HIP(hipMalloc((void **)&h->step_snap, sizeof(int64_t)));
+    h->rest_on = true;
+    h->rest_armed = false;
+    return SRLX_OK;
+}
+
 // Two branches (fork/join with events; capturable into a HIP graph): the data-gradient chain, then conv1's weight gradient (which needs the end of
 // it), stay on the caller's stream; the other weight gradients run on h->side as soon as the activation gradient each needs exists -- the first
 // dense layer's with Adam in its epilogue when the optimiser state is bound.
@@ -746,12 +794,24 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     }
     ConvGeo g3{h->OH2, h->OW2, C2, h->OH3, h->OW3, C2, 3, 3, 1, 1};
     hipLaunchKernelGGL(k_conv_wgrad_mfma<64>, dim3((9 * 2 * 2 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g3, ss, h->act2, h->dact3, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 9 * C2 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3);
+    // the convolution tensors' optimiser steps ride on their reductions (srlx_qnet_fuse_adam_rest); a tensor's raw weights have no reader left in this update:
+    // the data-gradient GEMMs read transposed copies, the forwards packed ones, and the packing launch that rebuilds both runs behind the join
+    const bool rest = h->rest_on && with_fc1;
+    const AdamArgs ad{h->adam_lr, h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step};
+    auto reduce = [&](hipStream_t s_, const float *part_, int P_, i64 n_, float *gw_, const float *bp_, int nb_, float *gb_, int wi, i64 *snap_) {
+        const dim3 grid((unsigned)((n_ + nb_ + 255) / 256));
+        if (rest)
+            hipLaunchKernelGGL(k_reduce_parts<true>, grid, dim3(256), 0, s_, part_, P_, n_, gw_, bp_, nb_, gb_, const_cast<float *>(h->bound[wi]), h->rest_m[wi], h->rest_v[wi],
+                               const_cast<float *>(h->bound[wi + 1]), h->rest_m[wi + 1], h->rest_v[wi + 1], ad, snap_);
+        else
+            hipLaunchKernelGGL(k_reduce_parts<false>, grid, dim3(256), 0, s_, part_, P_, n_, gw_, bp_, nb_, gb_);
+    };
+    reduce(sd, h->w_part, B, (i64)C2 * 9 * C2, g_w3, bias_part, C2, g_b3, 4, nullptr);
     SRLX_STAMP(22, sd);
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_d2, 0));
     ConvGeo g2{h->OH1, h->OW1, h->F1, h->OH2, h->OW2, C2, 4, 4, 2, 2};
     hipLaunchKernelGGL(k_conv_wgrad_mfma<32>, dim3((16 * 2 * 1 + 3) / 4, (unsigned)B), dim3(256), 0, sd, g2, ss, h->act1, h->dact2, h->w_part, bias_part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((C2 * 16 * h->F1 + C2 + 255) / 256)), dim3(256), 0, sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2);
+    reduce(sd, h->w_part, B, (i64)C2 * 16 * h->F1, g_w2, bias_part, C2, g_b2, 2, nullptr);
     SRLX_STAMP(23, sd);
     if (fc1_adam && fc1_order != 1 && fc1_order != 2) launch_fc1_adam(sd);  // Adam in the epilogue updates the weights in place: after ev_d3, when the data gradient has read them
     SRLX_STAMP(24, sd);
@@ -769,8 +829,7 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3((unsigned)B, (unsigned)(c1_chunks * h->Wn)), dim3(256), lds, st, d_frame_base, d_frame_off, ss, h->Wn, h->H, h->W, h->OH1, h->OW1, per,
                        h->dact1, c1_part, c1_bias, h->c1_gpart, h->c1_cnt, g_w1, g_b1, c1_chunks, c1_in_launch ? 1 : 0);
     if (!c1_in_launch)  // the same sums in the same order (four slices of consecutive partial tensors, then ((s0 + s1) + s2) + s3), behind a kernel boundary
-        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((32 * h->Wn * 64 + 32 + 255) / 256)), dim3(256), 0, st, c1_part, B * c1_chunks, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32,
-                           g_b1);  // (reduces its own partial sums: no k_reduce_parts launch behind it)
+        reduce(st, c1_part, B * c1_chunks, (i64)32 * h->Wn * 64, g_w1, c1_bias, 32, g_b1, 0, h->step_snap);
     SRLX_STAMP(20, st);
     SRLX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     if (fc1_adam && fc1_order == 2) SRLX_HIP(hipStreamWaitEvent(st, h->ev_join2, 0));
@@ -794,6 +853,11 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
     SRLX_REQUIRE(batch > 0 && batch <= h->max_train && sample_stride >= 1 && batch * sample_stride <= h->max_batch, "qnet_backward_u8: batch %lld x stride %lld out of range",
                  (long long)batch, (long long)sample_stride);
     for (int i = 0; i < 12; i++) SRLX_REQUIRE(g[i], "qnet_backward_u8: gradient buffer %d is NULL", i);
+    if (h->rest_on) {  // srlx_qnet_fuse_adam_rest: this pass applies the convolution tensors' optimiser steps itself and leaves the small vectors' to the packing launch
+        SRLX_REQUIRE(!h->rest_armed, "qnet_backward_u8: the previous pass's optimiser step was never completed (srlx_qnet_publish must follow every backward pass "
+                                     "of a handle with srlx_qnet_fuse_adam_rest)");
+        for (int i = 7; i < 12; i++) SRLX_REQUIRE(g[i] == h->rest_g[i], "qnet_backward_u8: gradient buffer %d is not the one srlx_qnet_fuse_adam_rest was given", i);
+    }
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     const int B = (int)batch, N1 = 2 * h->hidden, K = h->flat, A = h->A;
@@ -833,6 +897,7 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
     // NoisyLinear: d loss / d sigma = d loss / d W_effective * eps of the draw the forward used (regenerated, not stored)
     SRLX_TRY(srlx_qnet_noisy_sigma_grads(h, g, st));
     SRLX_HIP(hipGetLastError());
+    h->rest_armed = h->rest_on;
     return SRLX_OK;
 }
 

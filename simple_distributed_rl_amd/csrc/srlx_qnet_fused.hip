@@ -15,6 +15,7 @@
 // tile per wave, conv1 14 pixel tiles over the 8 waves.  Pixel strides 36 / 68 floats spread the 16-lane groups of a
 // ds_read_b128 over the 64 banks.  With `act1_out` / `act2_out` the activations are ALSO written to HBM for the backward
 // pass of a training forward.
+#include "srlx_adam_math.h"
 #include "srlx_qnet_int.h"
 
 namespace {
@@ -65,6 +66,12 @@ struct SmallCopy {
     float *dst;  // NULL: nothing to copy
     int first;   // first thread index of the copy range
     long long *bump;  // int64 device counter advanced by the launch (NULL: none): the update's step count, whose readers all ran in earlier launches
+    // srlx_qnet_fuse_adam_rest: the optimiser step of vector k right here (g[k] != NULL), in place, before it is copied -- every element has exactly one thread.
+    // The step count comes from `snap` (copied by an earlier launch of the update): thread 0 of this launch advances the count itself.
+    const float *g[8];
+    float *m[8], *v[8];
+    double lr, beta1, beta2, eps;
+    const long long *snap;
 };
 __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
                                                       float *__restrict__ out, float *__restrict__ wT3, float *__restrict__ wT2, float *__restrict__ out2, SmallCopy sm) {
@@ -72,14 +79,30 @@ __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ 
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = (kW1 + kW2 + kW3) / 4;
     if (sm.bump && q == 0) *sm.bump += 1;
-    if (sm.dst && q >= sm.first) {
+    if (sm.first > 0 && q >= sm.first) {
         const int x = q - sm.first;
         if (x >= sm.off[8]) return;
         int v = 0;
 #pragma unroll
         for (int k = 1; k < 8; k++) v += x >= sm.off[k] ? 1 : 0;
         const int j = x - sm.off[v];
-        if (j < sm.len[v]) sm.dst[x] = sm.src[v][j];
+        if (j >= sm.len[v]) return;
+        // (selects over the by-value tables: a lane-dependent index would send them to scratch memory)
+        const float *src = sm.src[0], *gp = sm.g[0];
+        float *mp = sm.m[0], *vp = sm.v[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++)
+            if (v == k) src = sm.src[k], gp = sm.g[k], mp = sm.m[k], vp = sm.v[k];
+        float pv = src[j];
+        if (gp) {
+            float mv = mp[j], vv = vp[j];
+            const srlx::AdamCoef cf = srlx::adam_coef(sm.lr, sm.beta1, sm.beta2, sm.eps, (int64_t)*sm.snap);
+            srlx::adam_one(pv, gp[j], mv, vv, cf);
+            const_cast<float *>(src)[j] = pv;
+            mp[j] = mv;
+            vp[j] = vv;
+        }
+        if (sm.dst) sm.dst[x] = pv;
         return;
     }
     if (q >= n4 && q < n4 + 16 * 64) {
@@ -700,7 +723,7 @@ size_t srlx_qnet_pack_bytes() { return (size_t)kPackFloats * sizeof(float); }
 
 // k_pack_filters over `src`'s bound filters into its own packed buffer (+ the transposed filters of a training handle) and, with `dst_set`, a second copy
 // into an actor set together with the small vectors (layout *L)
-int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st, int64_t *bump) {
+int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st, int64_t *bump, bool adam_small) {
     float *&own = src->aset_cur >= 0 ? src->wpack_own : src->wpack;
     if (!own) SRLX_HIP(hipMalloc((void **)&own, (size_t)kPackFloats * sizeof(float)));
     const bool keep = src->max_train > 0;
@@ -709,16 +732,28 @@ int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const s
     int pack_threads = (kW1 + kW2 + kW3) / 4 + 16 * 64 + (32 + 36) * 2 * 64 + (keep ? kW3 + kW2 : 0);
     SmallCopy sm{};
     sm.bump = (long long *)bump;
-    if (dst_set) {
+    const bool adam = adam_small && src->rest_on && src->rest_armed;
+    srlx_small_layout own_layout;
+    if (adam && !L) {  // no set to publish into: the small vectors still get their optimiser step (any dense layout of the eight will do)
+        own_layout = srlx_small_offsets(src);
+        L = &own_layout;
+    }
+    if (dst_set || adam) {
         const float *v[8] = {b ? b[1] : src->b1, b ? b[3] : src->b2, b ? b[5] : src->b3, b ? b[7] : src->bf, b ? b[8] : src->v2w, b ? b[9] : src->v2b,
                              b ? b[10] : src->a2w, b ? b[11] : src->a2b};
         const int off[9] = {L->b1, L->b2, L->b3, L->bf, L->v2w, L->v2b, L->a2w, L->a2b, L->total};
         const int len[8] = {src->F1, 2 * src->F1, 2 * src->F1, 2 * src->hidden, src->hidden, 1, src->A * src->hidden, src->A};
         for (int k = 0; k < 8; k++) sm.src[k] = v[k], sm.len[k] = len[k];
         for (int k = 0; k < 9; k++) sm.off[k] = off[k];
-        sm.dst = dst_set->small;
+        sm.dst = dst_set ? dst_set->small : nullptr;
         sm.first = ((pack_threads + 255) / 256) * 256;
         pack_threads = sm.first + L->total;
+        if (adam) {  // the convolution biases (vectors 0..2) took their step in k_reduce_parts; 3..7 = gradient list entries 7..11
+            for (int k = 3; k < 8; k++) sm.g[k] = src->rest_g[k + 4], sm.m[k] = src->rest_m[k + 4], sm.v[k] = src->rest_v[k + 4], sm.src[k] = src->bound[k + 4];
+            sm.lr = src->adam_lr, sm.beta1 = src->adam_b1, sm.beta2 = src->adam_b2, sm.eps = src->adam_eps;
+            sm.snap = (const long long *)src->step_snap;
+            src->rest_armed = false;
+        }
     }
     hipLaunchKernelGGL(k_pack_filters, dim3((pack_threads + 255) / 256), dim3(256), 0, st, w1, w2, w3, own, keep ? src->w_t : nullptr, keep ? src->w_t2 : nullptr,
                        dst_set ? dst_set->wpack : nullptr, sm);

@@ -27,6 +27,13 @@ struct srlx_qnet {
     float *adam_m, *adam_v;               // BORROWED optimiser state of wf (NULL: the gradient is written out instead)
     double adam_lr, adam_b1, adam_b2, adam_eps;
     const int64_t *adam_step;             // BORROWED device scalar: optimiser steps already taken
+    // Adam for every OTHER tensor inside the launch that finishes its gradient (srlx_qnet_fuse_adam_rest; round 5: k_adam was a launch + a dependent-launch gap on the
+    // update's tail): convolution weights and biases in k_reduce_parts' epilogue, the first dense layer's bias and the head's second layers in the small-vector range
+    // of the packing launch (srlx_qnet_publish).  Indexed like the gradient list of srlx_qnet_backward_u8 (entry 6 = the first dense layer's weight: unused here).
+    const float *rest_g[12];              // BORROWED gradient buffers (the ones every backward call is handed)
+    float *rest_m[12], *rest_v[12];       // BORROWED optimiser state
+    bool rest_on, rest_armed;             // armed: a backward pass has run and the packing launch that completes its optimiser step has not
+    int64_t *step_snap;                   // owned device scalar: the step count as this update's Adam launches see it (the packing launch itself advances the count)
     hipEvent_t probe0, probe1;            // optional, caller-owned: recorded right around the convolution kernel launch(es) of the next forward (srlx_qnet_set_probe)
     hipEvent_t probe_fc0, probe_fc1;      // the same around the first dense layer's GEMM launch (srlx_qnet_set_probe_fc1)
     // NoisyLinear dense layers (srlx_qnet_bind_noisy, srlx_noisy.hip): wf..a2b above then point at `eff`, the effective tensors
@@ -131,7 +138,7 @@ int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst
 size_t srlx_fc1_planes_weight_bytes(const srlx_qnet *h);
 // srlx_qnet_fused.hip: pack `src`'s convolution filters (its own wpack + transposed filters when it trains) and, with `dst_set`, also into an actor set together
 // with the small vectors
-int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st, int64_t *bump = nullptr);
+int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const srlx_small_layout *L, hipStream_t st, int64_t *bump = nullptr, bool adam_small = false);
 size_t srlx_qnet_pack_bytes();
 int srlx_fc1_planes_split_act(srlx_qnet *h, int64_t rows, hipStream_t st);
 bool srlx_fc1_planes_applicable(const srlx_qnet *h, int64_t rows);

@@ -223,6 +223,10 @@ class QNetInference:
     def _params(self):
         return self.net.kernel_parameters()
 
+    def grad_params(self):
+        """The 12 parameters in the order of the gradient list handed to the backward entry points."""
+        return list(self._params())[:12]
+
     def enable_training(self, max_train_batch: int):
         """Allocates the backward scratch and static gradient tensors (`p.grad`, in each parameter's own memory format,
         so that the fused Adam reads what `backward_u8` writes and both can live in one HIP graph)."""
@@ -528,6 +532,7 @@ class DeviceAdam:
         for p, m in zip(self.params, self.exp_avg):
             assert p.stride() == m.stride() == p.grad.stride(), "parameter, gradient and Adam state must share one memory format"
         self._fused = None  # index of the tensor the network's backward pass updates itself (fuse_first_dense)
+        self._rest = False  # fuse_rest: every other tensor too
         self._tables()
 
     def _tables(self):
@@ -556,9 +561,23 @@ class DeviceAdam:
                                                  self.eps, N.tptr(steps_taken_dev)))
         self._tables()
 
+    def fuse_rest(self, inf: "QNetInference"):
+        """After `fuse_first_dense`: every other tensor takes its step inside the launch that finishes its gradient (srlx_qnet_fuse_adam_rest: the convolution
+        tensors in their gradient reductions, the small vectors in the packing launch of `inf.publish_to`) -- `step()` then launches nothing, and every
+        `inf.backward*_u8` must be followed by `inf.publish_to(...)`.  Only for a handle whose parameter order is the gradient list's (QNetInference.grad_list)."""
+        assert self._fused is not None and not self._rest
+        order = inf.grad_params()  # the 12 parameters in the gradient list's order
+        pos = [next(i for i, q in enumerate(self.params) if q is p_) for p_ in order]
+        self._rest_tables = ((N.c_p * 12)(*[self.params[i].grad.data_ptr() for i in pos]), (N.c_p * 12)(*[self.exp_avg[i].data_ptr() for i in pos]),
+                             (N.c_p * 12)(*[self.exp_avg_sq[i].data_ptr() for i in pos]))
+        N.check(self.lib.srlx_qnet_fuse_adam_rest(inf.h, *[ctypes.cast(t, N.c_p) for t in self._rest_tables]))
+        self._rest = True
+
     def step(self, steps_taken_dev: torch.Tensor):
         """One Adam step; `steps_taken_dev` (int64 device scalar) = steps already taken (the caller increments it)."""
         assert self._fused is None or steps_taken_dev.data_ptr() == self._fused_steps.data_ptr()
+        if self._rest:  # nothing left for a launch of its own
+            return
         k = len(self._idx)
         N.check(self.lib.srlx_adam_step(k, ctypes.cast(self._p, N.c_p), ctypes.cast(self._g, N.c_p), ctypes.cast(self._m, N.c_p), ctypes.cast(self._v, N.c_p),
                                         ctypes.cast(self._n, N.c_p), self.lr, self.betas[0], self.betas[1], self.eps, N.tptr(steps_taken_dev), N.torch_stream_ptr()))

@@ -288,6 +288,10 @@ class RainbowEngine:
                 N.check(self.lib.srlx_qnet_set_fc1_branch(self.inf_online.h, 2))
             if self._update_side:
                 N.check(self.lib.srlx_per_set_update_counter(self.lreplay.h_per, None))
+            if fused_adam and not self.noisy and os.environ.get("SRLX_ADAM_REST", "1") != "0":
+                # no optimiser launch on the update's tail: the remaining eleven tensors take their steps in the launches that finish their gradients and in the
+                # packing launch (`publish_to` follows every backward pass of a fast engine)
+                self.optimizer.fuse_rest(self.inf_online)
             if role == "both" and learner_replay is None:
                 self.replay.enable_deferred_advance()
             self._publish_out_of_band()

@@ -540,6 +540,14 @@ int srlx_qnet_set_sink_wait(srlx_qnet_t *h, void *event);
 /* ... and one recorded on that branch right BEHIND the write-back: whatever must see the written-back priorities -- the NEXT update's draw, which an engine runs
  * here, beside the rest of the backward pass, instead of at the head of the next update (device/rainbow.py) -- waits for it */
 int srlx_qnet_set_sink_done(srlx_qnet_t *h, void *event);
+/* ... and a caller-owned stream (hipStream_t, NULL: none) the write-back is launched on instead of the weight-gradient branch, behind the kernel that produced the
+ * priorities (and the wait event, if any).  For a learner rank whose write-back waits for a long ingest: the weight gradients then do not queue behind that wait.
+ * The CALLER joins that stream (the event of srlx_qnet_set_sink_done is recorded behind the write-back). */
+int srlx_qnet_set_sink_stream(srlx_qnet_t *h, void *stream);
+/* on != 0: a backward pass enqueues the first kernel of its data-gradient chain BEFORE the launches of its weight-gradient branch (default: behind them).  No
+ * effect on results or on eager execution order constraints; under stream capture it decides which of the graph's internal streams the critical chain stays on
+ * (finding 14). */
+int srlx_qnet_set_main_first(srlx_qnet_t *h, int on);
 
 /* a caller-owned HIP event (hipEvent_t, NULL: none) recorded on the backward pass's stream right behind its head kernel: with srlx_qnet_backward_td_u8 the TD
  * targets, loss and new priorities exist from there on, so the priority write-back (srlx_per_update) can run beside the gradient kernels on another stream */

@@ -1073,6 +1073,18 @@ int srlx_qnet_set_sink_done(srlx_qnet_t *h, void *event) {
     return SRLX_OK;
 }
 
+int srlx_qnet_set_main_first(srlx_qnet_t *h, int on) {
+    SRLX_REQUIRE(h, "qnet_set_main_first: NULL handle");
+    h->main_first = on != 0;
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_sink_stream(srlx_qnet_t *h, void *stream) {
+    SRLX_REQUIRE(h, "qnet_set_sink_stream: NULL handle");
+    h->sink_stream = (hipStream_t)stream;
+    return SRLX_OK;
+}
+
 int srlx_qnet_set_sink_wait(srlx_qnet_t *h, void *event) {
     SRLX_REQUIRE(h, "qnet_set_sink_wait: NULL handle");
     h->sink_wait = (hipEvent_t)event;

@@ -721,15 +721,19 @@ int srlx_qnet_fuse_adam_rest(srlx_qnet_t *h, const float *const *d_grads, float 
 #define SRLX_STAMP(idx, stream) \
     if (h->stamp_buf) SRLX_TRY(srlx_debug_stamp(h->stamp_buf, (idx), (stream)))
 
-static int chain_prologue(srlx_qnet_t *h, hipStream_t st) {
+static int chain_prologue(srlx_qnet_t *h, hipStream_t st, int part = 3) {  // part 1: the fork point on `st`; part 2: the side branch's first launches; 3: both
     hipStream_t sd = h->side;
-    SRLX_HIP(hipEventRecord(h->ev_fork, st));
+    if (part & 1) SRLX_HIP(hipEventRecord(h->ev_fork, st));
+    if (!(part & 2)) return SRLX_OK;
     SRLX_HIP(hipStreamWaitEvent(sd, h->ev_fork, 0));
     // the replay's priority write-back (model_torch.py:113-114) needs the TD kernel's output only: first thing on the weight-gradient branch instead of the
-    // last launch of the update (it was 9 us + a launch boundary at the very end of the learner's critical path)
-    if (h->sink_per && h->sink_wait) SRLX_HIP(hipStreamWaitEvent(sd, h->sink_wait, 0));
-    if (h->sink_per) SRLX_TRY(srlx_per_update(h->sink_per, h->sink_n, h->sink_idx, h->sink_prio, h->sink_kind, 1, sd));
-    if (h->sink_per && h->sink_done) SRLX_HIP(hipEventRecord(h->sink_done, sd));
+    // last launch of the update (it was 9 us + a launch boundary at the very end of the learner's critical path) -- or, with a sink stream (a learner rank: the
+    // write-back waits for the slab's 150 us ingest, and the weight gradients must not queue behind that wait), on the caller's stream, which joins it itself
+    hipStream_t sk = h->sink_per && h->sink_stream ? h->sink_stream : sd;
+    if (sk != sd) SRLX_HIP(hipStreamWaitEvent(sk, h->ev_fork, 0));
+    if (h->sink_per && h->sink_wait) SRLX_HIP(hipStreamWaitEvent(sk, h->sink_wait, 0));
+    if (h->sink_per) SRLX_TRY(srlx_per_update(h->sink_per, h->sink_n, h->sink_idx, h->sink_prio, h->sink_kind, 1, sk));
+    if (h->sink_per && h->sink_done) SRLX_HIP(hipEventRecord(h->sink_done, sk));
     SRLX_STAMP(21, sd);
     const int C2 = 2 * h->F1;
     // the transposed filters of the two data-gradient GEMMs depend on the weights only: the fused forward of a training handle has
@@ -884,10 +888,16 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
     }
     SRLX_STAMP(16, st);
     if (h->ev_td) SRLX_HIP(hipEventRecord(h->ev_td, st));  // target / loss / priorities exist: the caller's priority write-back need not wait for the gradients
-    SRLX_TRY(chain_prologue(h, st));
+    // srlx_qnet_set_main_first: the data-gradient chain's first kernel is RECORDED ahead of the side branch's launches.  A captured graph's concurrent branches
+    // land on streams in recording order (the chain a node's first-recorded successor starts stays on its stream): with the critical chain recorded first it keeps
+    // one hardware queue from the head kernel to the packing launch instead of hopping queues at the fork (-1.2 % per single-GPU lock-step, -4 % per period of a
+    // learner rank, update alone 0.313 -> 0.273 ms; profiles/r5_ab_ingest_order.txt)
+    const bool main_first = h->main_first;
+    SRLX_TRY(chain_prologue(h, st, main_first && mfma_dgrad ? 1 : 3));
     // ---- data-gradient chain (caller's stream)
     if (mfma_dgrad) {
         hipLaunchKernelGGL(k_fc1_dgrad_mfma, dim3((unsigned)(K / 32)), dim3(256), 0, st, B, ss, N1, K, h->dh1t, h->wf, h->act3, h->dact3);
+        if (main_first) SRLX_TRY(chain_prologue(h, st, 2));
     } else {
         hipLaunchKernelGGL(k_fc1_dgrad<64>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
         hipLaunchKernelGGL(k_fc1_dgrad_reduce, dim3((unsigned)(((i64)B * K + 255) / 256)), dim3(256), 0, st, B, ss, K, h->fc_part, h->act3, h->dact3);

@@ -86,6 +86,8 @@ struct srlx_qnet {
     bool partial_used;                    // a forward has used `partial` (srlx_qnet_set_fc1_neighbour may no longer move it)
     hipEvent_t sink_done;                 // caller-owned or NULL: recorded on the sink's branch right behind the write-back (srlx_qnet_set_sink_done)
     hipEvent_t sink_wait;                 // caller-owned or NULL: the sink's branch waits for it first (srlx_qnet_set_sink_wait)
+    bool main_first;                      // srlx_qnet_set_main_first
+    hipStream_t sink_stream;              // caller-owned or NULL: the write-back runs there (behind the fork point) instead of first on the weight-gradient branch (srlx_qnet_set_sink_stream)
     int fc1_order;                        // 0 (default) / 1 / 2: srlx_qnet_set_fc1_branch
     hipStream_t side2;
     hipEvent_t ev_join2;

@@ -338,6 +338,11 @@ class QNetInference:
         self._sink_done = ev
         N.check(self.lib.srlx_qnet_set_sink_done(self.h, N.c_p(ev.cuda_event) if ev is not None else None))
 
+    def set_sink_stream(self, stream: Optional[torch.cuda.Stream]):
+        """The write-back runs on `stream` (which the caller joins: `set_sink_done`) instead of first on the weight-gradient branch; None: back there."""
+        self._sink_stream = stream
+        N.check(self.lib.srlx_qnet_set_sink_stream(self.h, N.c_p(stream.cuda_stream) if stream is not None else None))
+
     def set_td_event(self, ev: torch.cuda.Event):
         """`ev` (already recorded once: torch creates the HIP event lazily) is recorded right behind the head kernel of every backward pass from now on."""
         self._td_event = ev  # keeps it alive

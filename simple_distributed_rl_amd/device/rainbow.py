@@ -284,8 +284,11 @@ class RainbowEngine:
             # weight-gradient branch (srlx_qnet_set_priority_sink; no new branch in the graph -- as a branch of its own it put the update on the actors' hardware queue:
             # tools/README.md findings 3, 5); the step count it used to advance moves to the update's LAST launch (the packing / publishing one).
             self._update_side = self._fused_td
-            if (self.actor_stream is not None and want == "low") or role == "learner":  # the actors cannot queue behind a branch of the update: it may run three wide
+            if self.actor_stream is not None and want == "low":  # the actors cannot queue behind a branch of the update: it may run three wide
                 N.check(self.lib.srlx_qnet_set_fc1_branch(self.inf_online.h, 2))
+            # (a learner-only rank: the first dense layer's weight gradient LAST on the weight-gradient branch, order 0 -- with the critical chain recorded first,
+            # 0.300 ms per period against 0.343 on a branch of its own; same box, profiles/r5_ab_ingest_order.txt)
+            N.check(self.lib.srlx_qnet_set_main_first(self.inf_online.h, 1))
             if self._update_side:
                 N.check(self.lib.srlx_per_set_update_counter(self.lreplay.h_per, None))
             if fused_adam and not self.noisy and os.environ.get("SRLX_ADAM_REST", "1") != "0":
@@ -621,8 +624,12 @@ class RainbowEngine:
             # model_torch.py:107-109 without autograd: every p.grad is (over)written by the backward kernels
             if self.fast and self._update_side:
                 self.inf_online.set_priority_sink(r, b.indices, self.priorities)
-                self.inf_online.set_sink_wait(self._ev_ingested if ingest is not None else None)
-                self.inf_online.set_sink_done(self._ev_sunk if predraw else None)
+                # a learner rank's write-back follows the slab's ingest on the ingest's own stream: on the weight-gradient branch it would hold that branch back
+                # until the 150 us ingest is through
+                sink_on_ingest = early and ingest is not None
+                self.inf_online.set_sink_stream(self.s_ingest if sink_on_ingest else None)
+                self.inf_online.set_sink_wait(self._ev_ingested if ingest is not None and not sink_on_ingest else None)
+                self.inf_online.set_sink_done(self._ev_sunk if predraw or sink_on_ingest else None)
             if self._fused_td:  # ... in the prologue of the backward's first kernel
                 self.inf_online.backward_td_u8(r.obs_base, r.frame_off_all, n, q_all, q_tg_next, b.actions, b.rewards, b.terminated, b.weights, cfg.discount,
                                                cfg.retrace_h, cfg.enable_double_dqn, cfg.enable_rescale, self.target, self.loss, self.grad_q0, self.priorities)
@@ -649,6 +656,8 @@ class RainbowEngine:
                 cur.wait_event(self._ev_ingested)  # (the side stream joins: a capture must see it come back; a write-back on this stream must follow the add)
             if predraw:
                 cur.wait_event(self._ev_predrawn)
+            elif self.fast and self._update_side and early and ingest is not None:
+                cur.wait_event(self._ev_sunk)  # (the ingest stream carries the write-back behind the add: it joins here)
             if self.fast:  # the new weights' packed filters: for the next online forward and, with `publish`, for the actors (+ the small vectors); train_count_dev += 1
                 self.inf_online.publish_to(self.inf_actor if publish is not None else None, publish or 0,
                                            bump=self.train_count_dev if self._update_side else None)

@@ -724,7 +724,7 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     const int N1 = 2 * h->hidden;
     h->partial_used = true;
     const i64 tiles = ((B + BM - 1) / BM) * ((N1 + 63) / 64);
-    int splits = (int)((512 + tiles - 1) / tiles);  // ~512 workgroups (1024 for the learner's 96 / 128 rows: measured no faster)
+    int splits = (int)((512 + tiles - 1) / tiles);  // ~512 workgroups (the learner's 96 / 128 rows at 1024: no faster; at 384 / 256 / 192: +2 / +7 / +9 % per period of a learner rank)
     const int ksteps = h->flat / BK;
     if (h->fc1_neighbour > 0 && h->planes_valid && srlx_fc1_planes_applicable(h, B) && B >= 512) splits = h->fc1_neighbour;
     if (splits > ksteps) splits = ksteps;

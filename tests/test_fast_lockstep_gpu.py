@@ -222,6 +222,12 @@ def _same_state(fast, slow, tag):
     assert torch.equal(fast.priorities, slow.priorities) and torch.equal(fast.loss, slow.loss), tag
     for (name, p), q in zip(fast.q_online.named_parameters(), slow.q_online.parameters()):
         assert torch.equal(p, q), (tag, name)
+    # the optimiser state too: the fast engine takes every tensor's Adam step inside the launch that finishes its gradient (srlx_qnet_fuse_adam_fc1 / _rest:
+    # no optimiser launch at all), the fifteen-launch engine all but the first dense layer's in srlx_adam_step
+    if hasattr(fast.optimizer, "exp_avg") and hasattr(slow.optimizer, "exp_avg"):
+        assert fast.optimizer._rest and not slow.optimizer._rest
+        for k, (m1, m2, v1, v2) in enumerate(zip(fast.optimizer.exp_avg, slow.optimizer.exp_avg, fast.optimizer.exp_avg_sq, slow.optimizer.exp_avg_sq)):
+            assert torch.equal(m1, m2) and torch.equal(v1, v2), (tag, "adam state", k)
     assert torch.equal(fast.replay.stack_current(), slow.replay.stack_current()), tag
 
 

@@ -249,3 +249,52 @@ def test_fc1_operand_planes_path_is_bit_identical():
     for rows in (640, 96):  # 5 row tiles (another K split than 1024 rows); small launches keep the staging-split kernel
         o = off[:rows].contiguous()
         assert torch.equal(priv.forward_u8(ring.data_ptr(), o), plain_other.forward_u8(ring.data_ptr(), o))
+
+
+def test_adam_inside_the_gradient_launches_equals_the_optimiser_launch():
+    """srlx_qnet_fuse_adam_rest (round 5): Adam for the eleven tensors besides the first dense layer's weight inside the launches that finish their gradients
+    (convolution tensors: the gradient reductions' epilogues; small vectors: the packing launch of srlx_qnet_publish) against srlx_adam_step over the same
+    gradients -- parameters and both moment estimates bit-equal after three steps (model_torch.py:71,109: torch.optim.Adam, one step per train()); and a backward
+    pass whose optimiser step was never completed by a publish must make the next one fail loudly."""
+    from simple_distributed_rl_amd import _native as N
+    from simple_distributed_rl_amd.device.qnet import DeviceAdam, EngineQNet, QNetInference
+
+    def build():
+        torch.manual_seed(11)
+        net = EngineQNet(6, (84, 84), 4, 512, 32, "average").cuda()
+        qn = QNetInference(net, max_batch=128).enable_training(32)
+        opt = DeviceAdam(qn._params(), lr=2.5e-4)
+        steps = torch.zeros(1, dtype=torch.int64, device="cuda")
+        opt.fuse_first_dense(qn, steps)
+        return net, qn, opt, steps
+
+    F, n_frames, B, stride = 84 * 84, 200, 32, 4
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ring = torch.randint(0, 256, (n_frames * F,), dtype=torch.uint8, device="cuda", generator=g)
+    off = torch.randint(0, n_frames, (B * stride, 4), device="cuda", generator=g) * F
+    grads = [torch.randn((B, 6), device="cuda", generator=g) for _ in range(3)]
+    (net_a, qa, opt_a, steps_a), (net_b, qb, opt_b, steps_b) = build(), build()
+    opt_b.fuse_rest(qb)
+    w0 = [p_.detach().clone() for p_ in net_b.parameters()]
+    for k in range(3):
+        qa.forward_u8(ring.data_ptr(), off)
+        qa.backward_u8(ring.data_ptr(), off, grads[k], sample_stride=stride)
+        opt_a.step(steps_a)
+        qa.publish_to(None, 0, bump=steps_a)
+        qb.forward_u8(ring.data_ptr(), off)
+        qb.backward_u8(ring.data_ptr(), off, grads[k], sample_stride=stride)
+        opt_b.step(steps_b)  # (launches nothing)
+        qb.publish_to(None, 0, bump=steps_b)
+    torch.cuda.synchronize()
+    assert int(steps_a.item()) == int(steps_b.item()) == 3
+    for (name, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+        assert torch.equal(pa, pb), name
+    for k, (m1, m2, v1, v2) in enumerate(zip(opt_a.exp_avg, opt_b.exp_avg, opt_a.exp_avg_sq, opt_b.exp_avg_sq)):
+        assert torch.equal(m1, m2) and torch.equal(v1, v2), k
+    assert all(float((p_.detach() - q_).abs().max()) > 0 for p_, q_ in zip(net_b.parameters(), w0))  # (every tensor did take its steps)
+    qb.forward_u8(ring.data_ptr(), off)
+    qb.backward_u8(ring.data_ptr(), off, grads[0], sample_stride=stride)
+    with pytest.raises(Exception, match="never completed"):
+        qb.backward_u8(ring.data_ptr(), off, grads[0], sample_stride=stride)
+    qb.publish_to(None, 0, bump=steps_b)
+    torch.cuda.synchronize()

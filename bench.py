@@ -213,6 +213,12 @@ def main():
     for a_, b_ in pr + pf:  # torch creates the underlying hipEvent_t at the first record
         a_.record()
         b_.record()
+    # the first dense layer's OWN span per probed launch (first workgroup in .. last workgroup out on the device's 100 MHz wall clock, written by the kernel itself:
+    # srlx_qnet_set_fc1_span) -- what rocprofv3 reports as its duration; the event bracket beside it also holds the wait for compute units the learner's streams hold
+    spans = None
+    if probing and getattr(local.inf_actor, "_planes", False):
+        spans = torch.zeros((n_probe, 2), dtype=torch.int64, device=dev)
+        spans[:, 0] = -1
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -222,6 +228,8 @@ def main():
             if probing:
                 local.inf_actor.set_probe(*pr[k // probe_every])
                 local.inf_actor.set_probe_fc1(*pf[k // probe_every])
+                if spans is not None:
+                    local.inf_actor.set_fc1_span(spans[k // probe_every])
             eng.step(args.updates, events=ev[k // probe_every])
         else:
             eng.step(args.updates)
@@ -243,6 +251,11 @@ def main():
     conv_ms = sum(a_.elapsed_time(b_) for a_, b_ in pr) / len(pr) if probing else 0.0
     fc1_ms = sum(a_.elapsed_time(b_) for a_, b_ in pf) / len(pf) if probing else 0.0
     probe_stats = {"pass": stats(ev), "conv": stats(pr) if probing else None, "fc1": stats(pf) if probing else None}
+    if spans is not None:
+        sp = spans.cpu()
+        v = sorted(float(b_ - a_) * 1e-5 for a_, b_ in sp.tolist() if a_ != -1 and b_ > a_)  # 100 MHz ticks -> ms
+        if v:
+            probe_stats["fc1_kernel_span"] = {"min_ms": v[0], "median_ms": v[len(v) // 2], "mean_ms": sum(v) / len(v), "max_ms": v[-1], "probes": len(v)}
     if dist is not None:  # a learner-only rank 0 runs no actor pass: report the slowest actor rank's
         t = torch.tensor([ev_ms, conv_ms, fc1_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -876,6 +889,13 @@ def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0, probe_stats=None):
             "traffic_over_algorithmic": (fc1_traffic / fc1_alg_bytes) if (fc1_traffic and fc1_alg_bytes) else None,
             "note": "algorithmic bytes = both operands once (planes: 6 B per element) + the four split-K partial slabs written",
         }
+        span = (probe_stats or {}).get("fc1_kernel_span")
+        if span:  # the kernel's own first-in .. last-out span (rocprofv3's notion of its duration) beside the event bracket, which also holds the queue wait
+            fc1["kernel_span_ms"] = span["mean_ms"]
+            fc1["frac_on_kernel_span"] = exe_fc1 / (span["mean_ms"] * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS if fc1_bf16 else MFMA_F32_PEAK_TFLOPS)
+            fc1["note"] += ("; avg_launch_ms = HIP events around the launch on the actors' stream (includes waiting for compute units the update's kernels hold); "
+                            "kernel_span_ms = min(first workgroup in) .. max(last workgroup out) stamped by the kernel itself on the device's wall clock, same launches: "
+                            "compare THIS with the kernel's AverageNs in profiles/r5_kernel_stats.csv")
     conv_alg_bytes = E * (4 * 7056 + (121 * 64 * 6 if fc1_planes else 121 * 64 * 4)) + 466944 if fused else None  # 4 frames in + act3 out per sample + the split-bf16 packed filters once
     conv_traffic = _pmc_traffic("k_convnet_fused") if fused else None
     return {

@@ -584,6 +584,10 @@ int srlx_qnet_forward_convs_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_f
 int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end);
 /* the same for the first dense layer's GEMM launch (FC1: the second-largest kernel of a lock-step) */
 int srlx_qnet_set_probe_fc1(srlx_qnet_t *h, void *ev_start, void *ev_end);
+/* ... and the KERNEL's own span (round 5): d_span[0] / d_span[1] (pre-set by the caller to UINT64_MAX / 0) receive min(first workgroup in) / max(last workgroup out)
+ * of the device's 100 MHz wall clock for the NEXT operand-planes first-dense-layer launch -- what rocprofv3's kernel trace reports as that kernel's duration, without
+ * the queue wait an event bracket on the launch stream includes when other streams hold the compute units. */
+int srlx_qnet_set_fc1_span(srlx_qnet_t *h, uint64_t *d_span);
 /* The first dense layer of chip-filling launches (>= 512 rows, a multiple of 128: the actors' policy pass) on PRE-SPLIT operands.  The layer evaluates
  * float32 x float32 as six exact bf16 partial products; by default both operands are split while staging, in every workgroup, every K-slab.  A handle
  * with planes enabled keeps its weight as three bf16 parts ([unit][K/8][3][8 bf16], 1.5x the float32 bytes), the convolution kernel writes its output

@@ -119,6 +119,7 @@ SIGNATURES = {
     "srlx_qnet_enable_training": (c_int, [c_p, c_i64]),
     "srlx_qnet_set_probe": (c_int, [c_p, c_p, c_p]),
     "srlx_qnet_set_probe_fc1": (c_int, [c_p, c_p, c_p]),
+    "srlx_qnet_set_fc1_span": (c_int, [c_p, c_p]),
     "srlx_qnet_enable_fc1_planes": (c_int, [c_p]),
     "srlx_qnet_refresh_fc1_planes": (c_int, [c_p, c_p, c_p, c_p]),
     "srlx_qnet_invalidate_fc1_planes": (c_int, [c_p]),

@@ -66,8 +66,9 @@ __global__ void __launch_bounds__(256) k_split_planes(const float *__restrict__ 
 }
 
 __global__ void __launch_bounds__(512) k_fc1_planes(const uint4 *__restrict__ A, const uint4 *__restrict__ W, float *__restrict__ C, int M, int N, int K8,
-                                                    int slabs_per_split) {
+                                                    int slabs_per_split, unsigned long long *__restrict__ span) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (span && threadIdx.x == 0) atomicMin(&span[0], (unsigned long long)wall_clock64());  // srlx_qnet_set_fc1_span: first workgroup in
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
     // XCD-aware tile order (as k_gemm): XCD x = linear id % 8 gets the x-th contiguous eighth of the (split, N tile, M tile) space -- one K range x
     // a share of the N tiles x all M tiles -- so that a weight tile is fetched by one XCD's L2 and an activation K-slice by as few as possible
@@ -207,6 +208,7 @@ __global__ void __launch_bounds__(512) k_fc1_planes(const uint4 *__restrict__ A,
             const i64 m = m0 + wm * 64 + ms * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             Cz[m * N + n] = acc[ms][r];
         }
+    if (span && threadIdx.x == 0) atomicMax(&span[1], (unsigned long long)wall_clock64());  // (last workgroup out; its stores are in flight, as at a kernel's end)
 }
 
 // ---- the same GEMM as a GOOD NEIGHBOUR (round 4) ---------------------------------------------------------------------------------------------------------
@@ -228,8 +230,9 @@ constexpr int kHStages = 3;
 constexpr size_t kHLds = kHStages * kHBuf;     // 72 KB
 
 __global__ void __launch_bounds__(256, 2) k_fc1_planes_h(const uint4 *__restrict__ A, const uint4 *__restrict__ W, float *__restrict__ C, int M, int N, int K8,
-                                                      int slabs_per_split) {
+                                                      int slabs_per_split, unsigned long long *__restrict__ span) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (span && threadIdx.x == 0) atomicMin(&span[0], (unsigned long long)wall_clock64());  // srlx_qnet_set_fc1_span: first workgroup in
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     {   // XCD-aware tile order (as k_fc1_planes)
@@ -358,6 +361,7 @@ __global__ void __launch_bounds__(256, 2) k_fc1_planes_h(const uint4 *__restrict
                 Cz[m * N + n] = acc[ms][ns][r];
             }
         }
+    if (span && threadIdx.x == 0) atomicMax(&span[1], (unsigned long long)wall_clock64());
 }
 
 }  // namespace
@@ -416,11 +420,15 @@ int srlx_fc1_planes_gemm(srlx_qnet *h, int64_t rows, int splits, int kps, hipStr
             SRLX_HIP(hipFuncSetAttribute((const void *)k_fc1_planes_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHLds));
             attr_h = true;
         }
-        hipLaunchKernelGGL(k_fc1_planes_h, grid, dim3(256), kHLds, st, (const uint4 *)h->a3_planes, (const uint4 *)h->wf_planes, h->partial, (int)rows, N1, h->flat / 8, kps);
+        hipLaunchKernelGGL(k_fc1_planes_h, grid, dim3(256), kHLds, st, (const uint4 *)h->a3_planes, (const uint4 *)h->wf_planes, h->partial, (int)rows, N1, h->flat / 8, kps,
+                           (unsigned long long *)h->fc1_span);
+        h->fc1_span = nullptr;  // one launch only
         SRLX_HIP(hipGetLastError());
         return SRLX_OK;
     }
-    hipLaunchKernelGGL(k_fc1_planes, grid, dim3(512), kLds, st, (const uint4 *)h->a3_planes, (const uint4 *)h->wf_planes, h->partial, (int)rows, N1, h->flat / 8, kps);
+    hipLaunchKernelGGL(k_fc1_planes, grid, dim3(512), kLds, st, (const uint4 *)h->a3_planes, (const uint4 *)h->wf_planes, h->partial, (int)rows, N1, h->flat / 8, kps,
+                       (unsigned long long *)h->fc1_span);
+    h->fc1_span = nullptr;
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

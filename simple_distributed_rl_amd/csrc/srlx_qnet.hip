@@ -936,6 +936,12 @@ int srlx_qnet_set_probe(srlx_qnet_t *h, void *ev_start, void *ev_end) {
     return SRLX_OK;
 }
 
+int srlx_qnet_set_fc1_span(srlx_qnet_t *h, uint64_t *d_span) {
+    SRLX_REQUIRE(h, "qnet_set_fc1_span: NULL handle");
+    h->fc1_span = d_span;
+    return SRLX_OK;
+}
+
 int srlx_qnet_set_probe_fc1(srlx_qnet_t *h, void *ev_start, void *ev_end) {
     SRLX_REQUIRE(h, "qnet_set_probe_fc1: NULL handle");
     h->probe_fc0 = (hipEvent_t)ev_start;

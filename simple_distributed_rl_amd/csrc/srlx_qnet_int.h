@@ -36,6 +36,7 @@ struct srlx_qnet {
     int64_t *step_snap;                   // owned device scalar: the step count as this update's Adam launches see it (the packing launch itself advances the count)
     hipEvent_t probe0, probe1;            // optional, caller-owned: recorded right around the convolution kernel launch(es) of the next forward (srlx_qnet_set_probe)
     hipEvent_t probe_fc0, probe_fc1;      // the same around the first dense layer's GEMM launch (srlx_qnet_set_probe_fc1)
+    uint64_t *fc1_span;                   // caller-owned or NULL: the NEXT operand-planes first-dense-layer launch leaves min(first workgroup in), max(last workgroup out) of the device wall clock there (srlx_qnet_set_fc1_span)
     // NoisyLinear dense layers (srlx_qnet_bind_noisy, srlx_noisy.hip): wf..a2b above then point at `eff`, the effective tensors
     // mu + sigma * eps of the current noise draw; order of the six: wf, bf, v2w, v2b, a2w, a2b
     const float *mu[6], *sig[6];          // BORROWED torch parameters

@@ -277,6 +277,12 @@ class QNetInference:
         """The next forward records the two (timing-enabled, already created) events right around its convolution kernel launch(es)."""
         N.check(self.lib.srlx_qnet_set_probe(self.h, N.c_p(ev_start.cuda_event), N.c_p(ev_end.cuda_event)))
 
+    def set_fc1_span(self, span: torch.Tensor):
+        """int64 [2] device tensor pre-set to (-1, 0): the next operand-planes first-dense-layer launch leaves its own first-in / last-out wall-clock stamps there
+        (100 MHz ticks; srlx_qnet_set_fc1_span)."""
+        assert span.dtype == torch.int64 and span.numel() == 2 and span.is_contiguous()
+        N.check(self.lib.srlx_qnet_set_fc1_span(self.h, N.tptr(span)))
+
     def set_probe_fc1(self, ev_start: torch.cuda.Event, ev_end: torch.cuda.Event):
         """The same around the first dense layer's GEMM launch."""
         N.check(self.lib.srlx_qnet_set_probe_fc1(self.h, N.c_p(ev_start.cuda_event), N.c_p(ev_end.cuda_event)))

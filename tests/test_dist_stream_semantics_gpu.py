@@ -1,0 +1,299 @@
+"""The multi-GPU exchange under RCCL's STREAM semantics, on one GPU.
+
+`torch.distributed` over RCCL returns from `batch_isend_irecv` / `broadcast` at once: the transfer runs on the communicator's own stream, behind what the caller
+had enqueued on its current stream, and `work.wait()` is a stream-level wait -- the host never blocks.  gloo (every other N > 1 test of this repository) blocks the
+host until the data has arrived, which hides a missing dependency between a transfer and the kernels around it; and RCCL refuses two ranks on one GPU
+("Duplicate GPU detected"), so the real transport cannot be exercised on a one-GPU box either.
+
+This test puts a fabric with exactly those semantics under `device/dist.py`: two ranks as two THREADS of one process (a learner-only rank and an actor rank, the
+BASELINE configs[3] topology), point-to-point transfers and the parameter broadcast as device copies on a communicator stream of their own, issued when both sides
+have posted, behind events of both posters' streams -- and DELAYED there by a multi-millisecond spin kernel, an order of magnitude longer than a lock-step, so
+that any consumer that does not wait for its transfer reads stale staging buffers and any producer that overwrites a buffer before its send has left corrupts the
+slab.  The learner's replay (ring, tree), its weights and its counters after 30 lock-steps must equal, bit for bit, those of the same job on a fabric whose every
+transfer is synchronous (device idle before and after the copy).  What it covers: `TransitionBus.send_begin / send_end / recv_begin / recv_end / put_own`,
+`DistributedRainbow.step / prefill / flush`, the engine's `before_env` hook, the captured update's ingest of staging slots, the broadcast / republish order
+(reference: the queue / board hand-over of srl/base/run/play_mp.py:76-118,121-165,248-318)."""
+import collections
+import os
+import sys
+import threading
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+TIMEOUT = 120.0
+
+
+class _Work:
+    def __init__(self, fabric, slot):
+        self.fabric, self.slot = fabric, slot
+
+    def wait(self):
+        if not self.slot["matched"].wait(TIMEOUT):
+            raise RuntimeError("fabric: a transfer was waited for and its peer never posted")
+        if self.fabric.sync:
+            return
+        torch.cuda.current_stream().wait_event(self.slot["done"])  # what ProcessGroupNCCL's work.wait() is: the host goes on
+
+
+class _Fabric:
+    """Matches sends and receives per (source, destination) in posting order and runs each transfer on `comm`."""
+
+    def __init__(self, dev, sync: bool, delay_cycles: int):
+        self.dev, self.sync, self.delay = dev, sync, delay_cycles
+        self.comm = torch.cuda.Stream(device=dev)
+        self.lock = threading.Lock()
+        self.sends = collections.defaultdict(collections.deque)
+        self.recvs = collections.defaultdict(collections.deque)
+        self.bcast = collections.defaultdict(collections.deque)  # per receiving rank: posted sources
+        self.bcast_cv = threading.Condition(self.lock)
+        self.bytes = 0
+        self.source_posted = threading.Event()  # rank 0 has built its networks (the first thing a job does on the fabric is its parameter broadcast)
+
+    def _posted(self, tensor):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        if self.sync:  # (event / stream waits only: a device-wide synchronise from this thread would invalidate a stream capture running in the other rank's)
+            ev.synchronize()
+        return {"tensor": tensor, "posted": ev, "matched": threading.Event(), "done": torch.cuda.Event()}
+
+    def _copy(self, src, dst):
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(src["posted"])
+            self.comm.wait_event(dst["posted"])
+            if self.delay and not self.sync:
+                torch.cuda._sleep(self.delay)
+            dst["tensor"].copy_(src["tensor"].view(dst["tensor"].dtype).view(dst["tensor"].shape))
+            src["done"].record(self.comm)
+            dst["done"].record(self.comm)
+        self.bytes += dst["tensor"].numel() * dst["tensor"].element_size()
+        if self.sync:
+            dst["done"].synchronize()
+        src["matched"].set()
+        dst["matched"].set()
+
+    def post(self, kind, me, peer, tensor):
+        slot = self._posted(tensor)
+        with self.lock:
+            key = (me, peer) if kind == "send" else (peer, me)
+            mine, theirs = (self.sends, self.recvs) if kind == "send" else (self.recvs, self.sends)
+            if theirs[key]:
+                other = theirs[key].popleft()
+                self._copy(slot, other) if kind == "send" else self._copy(other, slot)
+            else:
+                mine[key].append(slot)
+        return _Work(self, slot)
+
+    def broadcast(self, me, src_rank, world, tensor):
+        slot = self._posted(tensor)
+        with self.bcast_cv:
+            if me == src_rank:  # the source's stream, too, waits for the collective: its buffer is read until the last receiver has its copy
+                slot["served"] = []
+                for r in range(world):
+                    if r != me:
+                        self.bcast[r].append(slot)
+                self.bcast_cv.notify_all()
+                self.source_posted.set()
+                if not self.bcast_cv.wait_for(lambda: len(slot["served"]) == world - 1, TIMEOUT):
+                    raise RuntimeError("fabric: a broadcast's receivers never posted")
+                served = list(slot["served"])
+            else:
+                if not self.bcast_cv.wait_for(lambda: len(self.bcast[me]) > 0, TIMEOUT):
+                    raise RuntimeError("fabric: a broadcast's source never posted")
+                src = self.bcast[me].popleft()
+                self._copy({"tensor": src["tensor"], "posted": src["posted"], "matched": threading.Event(), "done": torch.cuda.Event()}, slot)
+                src["served"].append(slot["done"])
+                self.bcast_cv.notify_all()
+                served = [slot["done"]]
+        if not self.sync:
+            for ev in served:
+                torch.cuda.current_stream(self.dev).wait_event(ev)  # (a non-async collective: the caller's stream waits for it)
+
+
+class _P2POp:
+    def __init__(self, op, tensor, peer, group=None, tag=0):
+        self.op, self.tensor, self.peer = op, tensor, peer
+
+
+class _FakeDist:
+    """The part of torch.distributed that device/dist.py uses, for ONE rank of the fabric."""
+
+    P2POp = _P2POp
+
+    def __init__(self, fabric, rank, world):
+        self.fabric, self.rank, self.world = fabric, rank, world
+
+    @staticmethod
+    def isend(*a, **k):
+        raise AssertionError("only through batch_isend_irecv")
+
+    irecv = isend
+
+    def is_initialized(self):
+        return True
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_backend(self, group=None):
+        return "nccl"
+
+    def batch_isend_irecv(self, ops):
+        return [self.fabric.post("send" if op.op is _Switch.isend else "recv", self.rank, op.peer, op.tensor) for op in ops]
+
+    def broadcast(self, tensor, src=0, group=None):
+        self.fabric.broadcast(self.rank, src, self.world, tensor)
+
+    def gather(self, *a, **k):
+        raise AssertionError("the slot exchange does not gather")
+
+
+class _Switch:
+    """What `device.dist.dist` is replaced with: every thread sees its own rank's facade."""
+
+    local = threading.local()
+
+    @staticmethod
+    def isend(*a, **k):
+        raise AssertionError("only through batch_isend_irecv")
+
+    @staticmethod
+    def irecv(*a, **k):
+        raise AssertionError("only through batch_isend_irecv")
+
+    P2POp = _P2POp
+
+    def __getattr__(self, name):
+        return getattr(_Switch.local.facade, name)
+
+
+class _DeviceBytes:
+    """Zero-copy uint8 view of device memory for torch.as_tensor (the frame ring lives in libsrlx, not in a torch tensor)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _replay_snapshot(rp, batch: int):
+    """Everything the exchange wrote into the learner's replay: the whole frame ring, the whole tree, and the scalars of a fixed spread of items."""
+    import ctypes
+
+    import numpy as np
+
+    from simple_distributed_rl_amd import _native as N
+
+    frames = torch.as_tensor(_DeviceBytes(rp.obs_base, rp.E * rp.L * rp.F), device="cuda").clone()
+    tree = np.empty(2 * rp.capacity - 1)
+    N.check(rp.lib.srlx_per_backup(rp.h_per, ctypes.byref(N.c_f64(0)), ctypes.byref(N.c_i64(0)), ctypes.byref(N.c_i64(0)), N.np_ptr(tree)))
+    items = []
+    for first in range(0, rp.capacity - batch, max(batch, (rp.capacity - batch) // 24)):
+        rp.batch.indices.copy_(torch.arange(first, first + batch, dtype=torch.int64, device="cuda") + rp.capacity - 1)
+        b = rp.gather_drawn(all_states=False)
+        items += [b.actions.clone(), b.rewards.clone(), b.terminated.clone()]
+    torch.cuda.synchronize()
+    return [frames, torch.tensor(tree)] + items
+
+
+def _job(sync: bool, delay_cycles: int, steps: int, actor_priority: bool):
+    import simple_distributed_rl_amd.device.dist as dmod
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig
+
+    dev = torch.device("cuda:0")
+    fabric = _Fabric(dev, sync, delay_cycles)
+    out, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            # (two ranks in ONE process: neither may sit on the legacy default stream, whose launches synchronise implicitly with the other rank's streams and
+            # would invalidate a stream capture running there -- a rank of a real job has its process, and its default stream, to itself)
+            torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+            _Switch.local.facade = _FakeDist(fabric, rank, 2)
+            E = 512
+            cfg = RainbowDeviceConfig(n_envs=E, batch_size=32, memory_capacity=E * 10, memory_warmup_size=E * 3, seed=23, target_model_update_interval=4,
+                                      actor_initial_priority=actor_priority)
+            job = dmod.DistributedRainbow(cfg, 0, episode_len=6, sync_interval=5, learner_acts=False)
+            assert job.local.fast and job.local.role == ("learner" if rank == 0 else "actor")
+            # (eager launches throughout: the update's captured graph is recorded from exactly these streams and events, and its launch is ordered behind the same
+            # `wait_stream`; a stream capture in one thread while the other rank's thread drives the runtime is not something this HIP runtime survives reliably)
+            for k in range(steps):
+                job.step(learner_updates=1)
+            job.flush()
+            torch.cuda.synchronize()
+            if rank == 0:
+                rp = job.replay
+                out["per"] = rp.per_state()
+                out["info"] = {k_: v for k_, v in job.info().items() if k_ in ("train_count", "memory", "loss")}
+                out["flat"] = job.flat.detach().clone()
+                out["ring"] = _replay_snapshot(rp, cfg.batch_size)
+                out["graphs"] = len(job.local._learner_graphs)
+            else:
+                out["actor_flat"] = job.flat.detach().clone()
+                out["actor_steps"] = int(job.env_steps_local)
+            job.local.close()
+        except Exception:
+            import traceback
+
+            errors.append(f"rank {rank}:\n{traceback.format_exc()}")
+
+    saved = dmod.dist
+    dmod.dist = _Switch()
+    try:
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in (0, 1)]
+        # (two ranks of a real job are two processes with a random generator each; here they share torch's: rank 1 starts once rank 0 has initialised its networks --
+        # rank 1's own initial weights are overwritten by the first broadcast)
+        threads[0].start()
+        assert fabric.source_posted.wait(TIMEOUT) or errors, "rank 0 never reached its first broadcast"
+        threads[1].start()
+        for t in threads:
+            t.join(4 * TIMEOUT)
+        assert not any(t.is_alive() for t in threads), "a rank hung"
+        assert not errors, "\n".join(errors)
+    finally:
+        dmod.dist = saved
+    out["bytes"] = fabric.bytes
+    return out
+
+
+@pytest.mark.parametrize("actor_priority", [False, True])
+def test_exchange_under_stream_ordered_transfers_equals_synchronous_transfers(actor_priority):
+    steps = 30
+    want = _job(sync=True, delay_cycles=0, steps=steps, actor_priority=actor_priority)
+    got = _job(sync=False, delay_cycles=6_000_000, steps=steps, actor_priority=actor_priority)  # ~2.5-3 ms per transfer at 2.1-2.4 GHz: ten lock-steps' worth
+    assert want["info"]["train_count"] >= 15 and want["actor_steps"] == steps * 512
+    assert got["info"] == want["info"] and got["per"] == want["per"] and got["graphs"] == want["graphs"] and got["bytes"] == want["bytes"]
+    for k, (a, b) in enumerate(zip(got["ring"], want["ring"])):
+        assert torch.equal(a, b), f"ring tensor {k} differs: a consumer ran ahead of its transfer, or a producer overwrote a buffer in flight"
+    assert torch.equal(got["flat"], want["flat"]), "the learner's weights differ"
+    assert torch.equal(got["actor_flat"], want["actor_flat"]) and torch.equal(got["actor_flat"], got["flat"])  # lock-step 30 ended with a broadcast (interval 5)
+
+
+@pytest.mark.parametrize("broken", ["recv_end", "send_end"])
+def test_the_fabric_exposes_a_missing_stream_wait(broken, monkeypatch):
+    """The test above has teeth: with the stream-level wait of `TransitionBus.recv_end` (the learner's staging slot is read by the next update's ingest) or of
+    `send_end` (the actor's environments overwrite the frames a send is still reading) taken out -- the host still learns that the peer has posted, as it would
+    over RCCL -- the delayed fabric produces a different replay."""
+    import simple_distributed_rl_amd.device.dist as dmod
+
+    steps = 20
+    want = _job(sync=True, delay_cycles=0, steps=steps, actor_priority=False)
+
+    def no_stream_wait(self):
+        for w in self._pending:
+            assert w.slot["matched"].wait(TIMEOUT)
+        self._pending = []
+        if broken == "send_end":
+            self._keep = None
+        else:
+            for host, view in self._staged_in:
+                view.copy_(host.to(self.device))
+            self._staged_in = []
+
+    monkeypatch.setattr(dmod.TransitionBus, broken, no_stream_wait)
+    got = _job(sync=False, delay_cycles=6_000_000, steps=steps, actor_priority=False)
+    assert any(not torch.equal(a, b) for a, b in zip(got["ring"], want["ring"])) or not torch.equal(got["flat"], want["flat"])

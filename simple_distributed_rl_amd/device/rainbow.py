@@ -315,9 +315,10 @@ class RainbowEngine:
             ev.record()  # (torch creates the HIP event at the first record: the library keeps raw handles of two of them)
         # pre-draw: the NEXT update's batch is drawn right behind this update's write-back, into the replay's other buffer set, instead of at the head of the next
         # update's chain.  On for a learner rank's replay, where the update's own chain is the period (0.338 -> 0.323 ms per period alone on a GPU, same box); beside
-        # this GPU's own actors the period is contention-bound and the move changed nothing (0.457 against 0.454 ms, same box): off there unless SRLX_PREDRAW=1.
+        # this GPU's own actors the period is contention-bound and the move changed nothing (0.457 against 0.454 ms, same box; 0.441 against 0.434 for the 2-GPU
+        # topology's acting learner rank): on for learner-ONLY ranks unless SRLX_PREDRAW says otherwise.
         self._predraw = bool(self.fast and self._update_side and self.s_ingest is not None and getattr(self.lreplay, "two_sets", False)
-                             and os.environ.get("SRLX_PREDRAW", "1" if learner_replay is not None else "0") == "1")
+                             and os.environ.get("SRLX_PREDRAW", "1" if (learner_replay is not None and role == "learner") else "0") == "1")
         self._bset, self._drawn, self._drawn_at = 0, None, 0
         self.s_predraw = torch.cuda.Stream(device=self.dev, priority=-1) if self._predraw else None
 
@@ -598,7 +599,9 @@ class RainbowEngine:
             # ingest (ring commit + 7168-leaf add: 150 us, the write-back waits for it) goes FIRST -- period alone 0.326 ms against 0.427 behind the target fork and
             # 0.467 behind both passes' launches; the single-GPU engine's (one 16 us add) goes behind the online PASS ITSELF (dependent on it): 0.432 ms per lock-step
             # against 0.454 first, 0.444 behind the target fork, 0.493 behind the launches but independent of them
-            early = self.learner_replay is not None
+            # (a rank that acts AND ingests other ranks' slabs -- the 2-GPU topology's rank 0 -- keeps the single-GPU placement: 0.429 against 0.455 ms per lock-step
+            # with the ingest first, tools/dist_one_rank_probe.py)
+            early = self.learner_replay is not None and self.role == "learner"
             if early:
                 fork_ingest(cur)
             self._ev_t0.record(cur)

@@ -618,6 +618,10 @@ def bench_ppo(args, dev_index, rank, world, dist):
                      "note": "isolated launches; 2.7 MB per launch at E = 4096, T = 32: latency-bound (the kernel is one dependent chain of T steps per environment)"},
         "final": {k: info.get(k) for k in ("policy_loss", "value_loss", "entropy_loss")},
     }
+    out["roofline"]["note"] += ("; NOT where this line's time goes: the iteration is dominated by the torch MLPs' forward / backward (hipBLASLt GEMMs at 64-wide "
+                                "layers, inside two HIP graphs) -- libsrlx owns the environments, the sampling, this scan and the loss")
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_ppo(args, cfg)
     print(json.dumps(out), flush=True)
 
 
@@ -1047,6 +1051,102 @@ def per_shim_timing(rounds=1500, warm=20_000):
         out["reference_cpp"] = loop(mod.ProportionalMemory(1_000_000, 0.8, 0.4, 1000, True, 0.0001), rounds)
         out["reference_cpp"]["kind"] = "reference (oracle/_ref: the reference's pybind11 sum-tree, one host thread)"
     return out
+
+
+def cpu_baseline_ppo(args, cfg):
+    """The reference-shaped sequential CPU path of PPO (srl/algorithms/ppo/ppo.py:102-169 trainer, :316-404 worker -- restated, the module itself needs
+    TensorFlow): ONE environment, batch-1 policy / value inference on torch-CPU, Normal sampling, the numpy Pendulum-shaped dynamics and GAE of the oracle, and
+    the clipped-surrogate update (autograd on torch-CPU) at the GPU run's minibatch size, at the GPU run's ratio of environment steps to updates.  kind = "port"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import torch
+
+    import hot_path_oracle as H
+    from simple_distributed_rl_amd.device.ppo import ActorCritic
+
+    host_cores = os.cpu_count() or 1
+    torch.manual_seed(0)
+    net = ActorCritic(cfg)
+    opt = torch.optim.Adam(net.parameters(), lr=cfg.lr)
+    rng = np.random.default_rng(0)
+
+    def pick_threads(fn):
+        best, cores = None, 1
+        for th in sorted({1, 4, 8, 16, 32, min(64, host_cores)}):
+            if th > host_cores:
+                continue
+            torch.set_num_threads(th)
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            dt = (time.perf_counter() - t0) / 3
+            if best is None or dt < best:
+                best, cores = dt, th
+        return cores
+
+    # ---- actor: one environment, one step at a time
+    state, t_ep = np.array([[0.5, 0.1]], np.float32), np.zeros(1, np.int64)
+    obs = np.array([[np.cos(0.5), np.sin(0.5), 0.1]], np.float32)
+    torch.set_num_threads(1)  # (a 3 -> 64 -> 64 MLP at batch 1: threads only cost)
+    budget = max(2.0, 0.5 * args.cpu_seconds)
+    T = cfg.horizon
+    steps, roll = 0, []
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        with torch.no_grad():
+            v, loc, log_scale = net(torch.from_numpy(obs))
+        a = loc.numpy() + np.exp(log_scale.numpy()) * rng.standard_normal(loc.shape).astype(np.float32)
+        state, t_ep, nobs, rew, done = H.pendulum_step(state, t_ep, a[:, 0], cfg.episode_len)
+        roll.append((float(rew[0]), float(v[0]), bool(done[0])))
+        if done[0]:
+            state, t_ep = np.array([[rng.uniform(-np.pi, np.pi), rng.uniform(-1, 1)]], np.float32), np.zeros(1, np.int64)
+            nobs = np.array([[np.cos(state[0, 0]), np.sin(state[0, 0]), state[0, 1]]], np.float32)
+        obs = nobs
+        steps += 1
+        if len(roll) == T:  # the worker's GAE over the horizon (ppo.py:389-404)
+            r_, v_, d_ = (np.array(x, np.float32).reshape(T, 1) for x in zip(*roll))
+            H.gae(r_, v_, d_.astype(bool), np.zeros(1, np.float32), cfg.discount, cfg.gae_discount)
+            roll = []
+    t_actor = time.perf_counter() - t0
+    # ---- learner: clipped-surrogate updates at the GPU run's minibatch size
+    M = cfg.horizon * cfg.n_envs // cfg.minibatches
+    g = torch.Generator().manual_seed(1)
+    ob = torch.randn(M, cfg.obs_dim, generator=g)
+    act = torch.randn(M, cfg.action_dim, generator=g)
+    old_lp, adv, vt, ov = -torch.rand(M, 1, generator=g), torch.randn(M, generator=g), torch.randn(M, generator=g), torch.randn(M, generator=g)
+
+    def update():
+        v, loc, log_scale = net(ob)
+        lp = (-0.5 * ((act - loc) / log_scale.exp()) ** 2 - log_scale - 0.9189385332).sum(-1, keepdim=True)
+        a2 = adv.view(-1, 1) - (v.detach().view(-1, 1) if cfg.baseline_type == "advantage" else 0.0)
+        ratio = torch.exp(lp - old_lp)
+        pol = -torch.minimum(ratio * a2, torch.clamp(ratio, 1 - cfg.policy_clip_range, 1 + cfg.policy_clip_range) * a2).mean()
+        vc = torch.maximum(torch.minimum(v, ov + cfg.value_clip_range), ov - cfg.value_clip_range)
+        val = cfg.value_loss_weight * torch.maximum((v - vt) ** 2, (vc - vt) ** 2).mean()
+        ent = cfg.entropy_weight * -(-(torch.exp(lp) * lp).sum(-1)).mean()
+        opt.zero_grad()
+        (pol + val + ent).backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), cfg.global_gradient_clip_norm)
+        opt.step()
+
+    th_l = pick_threads(update)
+    torch.set_num_threads(th_l)
+    n_upd = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < max(2.0, 0.3 * args.cpu_seconds):
+        update()
+        n_upd += 1
+    t_upd = (time.perf_counter() - t0) / n_upd
+    # the GPU run's schedule: horizon x envs environment steps, then epochs x minibatches updates
+    per_iter_steps, per_iter_updates = cfg.horizon * cfg.n_envs, cfg.epochs * cfg.minibatches
+    t_iter = per_iter_steps / (steps / t_actor) + per_iter_updates * t_upd
+    return {"value": per_iter_steps / t_iter, "unit": "env-steps/s", "learner_updates_per_s": per_iter_updates / t_iter, "cores": th_l,
+            "threads": {"actor_batch1_inference": 1, "learner_updates": th_l, "host_cores": host_cores},
+            "actor_only": {"env_steps_per_s": steps / t_actor}, "learner_only": {"updates_per_s": 1.0 / t_upd, "ms_per_update": 1e3 * t_upd, "minibatch": M},
+            "kind": "port",
+            "sample": f"{steps} sequential env-steps (1 env, batch-1 inference, numpy dynamics + GAE) in {t_actor:.1f}s + {n_upd} updates at minibatch {M}; combined at the GPU "
+                      f"run's schedule ({per_iter_steps} env-steps then {per_iter_updates} updates per iteration)"}
 
 
 def cpu_baseline_agent57(args, rl, E):

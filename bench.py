@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
     ap.add_argument("--no-per-micro", action="store_true", help="skip the PER micro-benchmark (sample / update / add ops/s, bulk-sample HBM fraction)")
     ap.add_argument("--no-subfigures", action="store_true", help="skip the actor-only / learner-only timings")
+    ap.add_argument("--actor-ranks", type=int, default=7, help="--roles-only: actor GPUs whose slab the learner-only rank ingests per period (7 = the 8-GPU job, 3 = the 4-GPU job)")
     ap.add_argument("--roles-only", action="store_true", help="only time the two roles of the multi-GPU job, each alone on this GPU (bench.py runs this in a process of its own)")
     ap.add_argument("--learner-acts", choices=("auto", "yes", "no"), default="auto",
                     help="N>1: does the learner rank run actors too? auto = yes below 4 GPUs, no (dedicated learner GPU) from 4")
@@ -116,7 +117,7 @@ def roles_only(args):
             rccl = True
         except Exception:
             rccl = False
-    out = role_timings(args, dev_index)
+    out = role_timings(args, dev_index, actor_ranks=args.actor_ranks)
     out["rccl_initialised"] = rccl
     print(json.dumps(out), flush=True)
     if rccl:

@@ -671,7 +671,7 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
     SRLX_HIP(hipMalloc((void **)&h->c1_cnt, (size_t)h->Wn * 5 * sizeof(unsigned)));
     SRLX_HIP(hipMemset(h->c1_cnt, 0, (size_t)h->Wn * 5 * sizeof(unsigned)));
     SRLX_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    // (side2 -- SRLX_FC1_ORDER=2 -- is created on first use: one more stream in the process changes which hardware queues the others land on, and with two
+    // (side2 -- srlx_qnet_set_fc1_branch(h, 2) -- is created on first use: one more stream in the process changes which hardware queues the others land on, and with two
     //  queues that decides whether the update overlaps the actors' pass at all: measured 0.61 against 0.50 ms per lock-step with an UNUSED extra stream)
     for (hipEvent_t *e : {&h->ev_fork, &h->ev_d3, &h->ev_d2, &h->ev_d1, &h->ev_join, &h->ev_wt, &h->ev_join2})
         SRLX_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));

@@ -78,7 +78,7 @@ struct srlx_qnet {
     float *c1_gpart;                      // conv1 weight gradient: group partial sums [Wn][4][32 x 64 + 32] of the in-launch reduction
     unsigned *c1_cnt;                     // ... and its arrival tickets [Wn][5] (zero between launches)
     // round 4 (second half): the replay's priority write-back rides on the weight-gradient branch (srlx_qnet_set_priority_sink), and the first dense layer's
-    // weight gradient can take a branch of its own (side2; SRLX_FC1_ORDER)
+    // weight gradient can take a branch of its own (side2; srlx_qnet_set_fc1_branch)
     struct srlx_per *sink_per;            // NULL: no sink
     const int64_t *sink_idx;
     const void *sink_prio;

@@ -944,8 +944,9 @@ int srlx_qnet_backward_td_u8(srlx_qnet_t *h, int64_t batch, int n_step, const ui
     SRLX_REQUIRE(d_target && d_loss && d_grad_q0 && d_priorities, "qnet_backward_td_u8: NULL output");
     const int A = h->A;
     const int64_t row = (int64_t)(n_step + 1) * A;
-    const srlx::TdArgs td{batch, n_step, A, d_q_on_all + A, d_q_tg_next, d_q_on_all, d_actions, d_rewards, d_terminated, d_invalid_next, d_weights, discount, retrace_h,
+    srlx::TdArgs td{batch, n_step, A, d_q_on_all + A, d_q_tg_next, d_q_on_all, d_actions, d_rewards, d_terminated, d_invalid_next, d_weights, discount, retrace_h,
                           enable_double_dqn, enable_rescale, d_target, d_loss, d_grad_q0, d_priorities, row, row};
+    srlx::td_fill_discounts(td);
     return backward_impl(h, batch, n_step + 1, d_frame_base, d_frame_off, nullptr, &td, g, stream);
 }
 

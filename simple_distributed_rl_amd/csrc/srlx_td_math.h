@@ -5,6 +5,8 @@
 //   srl/algorithms/rainbow/model_torch.py:103-105,113 (selected Q, HuberLoss(target*w, q*w), |target-q|)
 // float32 arithmetic follows numpy's evaluation order of the cited lines.
 #pragma once
+#include <math.h>
+
 #include "srlx_common.h"
 
 namespace srlx {
@@ -52,7 +54,14 @@ struct TdArgs {
     int double_dqn, rescale;
     float *target, *loss, *grad_q0, *priorities;
     i64 on_next_stride, on_0_stride;  // floats between consecutive items (dense: n*A and A; packed [B][n+1][A]: (n+1)*A for both)
+    // multi_discounts (rainbow.py:182): float32(discount ** m), evaluated ON THE HOST by td_fill_discounts -- the C library's pow(), which is what Python's `**`
+    // calls -- instead of three device pow() calls per item in the head kernel's prologue (round 5: ~1000 instructions each on the update's critical chain)
+    float dm[kTdMaxStep];
 };
+
+inline void td_fill_discounts(TdArgs &a) {
+    for (int m = 0; m < kTdMaxStep; m++) a.dm[m] = m < a.n ? (float)pow(a.discount, (double)m) : 0.f;
+}
 
 // rows t, t + T, ... of the batch: target / gradient seed / priority of each; returns this thread's sum of Huber terms (float64).
 // `grad_out` [B][A] may be LDS; `write_global`: also store target, priorities (and grad_q0 when grad_out is elsewhere).
@@ -87,8 +96,7 @@ __device__ __forceinline__ double td_rows(const TdArgs &a, int t, int T, float *
                 const bool pi = (act[m] == nact[m]);  // argmax(n_action)[m-1] == n_act_idx[:,1:][m-1]
                 c *= a.retrace_h * (pi ? 1.0 : 0.0);
             }
-            // multi_discounts is float32(discount**m) (:182); python evaluates discount**m with pow()
-            const float dm = (float)pow(a.discount, (double)m);
+            const float dm = a.dm[m];  // float32(discount ** m) (:182), from the host
             const float term = (float)((double)(td[m] * dm) * c);
             target = target + term;
         }

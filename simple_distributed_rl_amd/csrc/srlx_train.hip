@@ -205,6 +205,7 @@ int srlx_nstep_td_huber_priority(int64_t batch, int n_step, int n_actions, const
     TdArgs a{batch, n_step, n_actions, d_q_on_next, d_q_tg_next, d_q_on_0, d_actions, d_rewards, d_terminated,
              d_invalid_next, d_weights, discount, retrace_h, enable_double_dqn, enable_rescale, d_target, d_loss,
              d_grad_q0, d_priorities, (i64)n_step * n_actions, (i64)n_actions};
+    srlx::td_fill_discounts(a);
     hipLaunchKernelGGL(k_nstep_td_huber_priority, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
@@ -222,6 +223,7 @@ int srlx_nstep_td_huber_priority_packed(int64_t batch, int n_step, int n_actions
     TdArgs a{batch, n_step, n_actions, d_q_on_all + n_actions, d_q_tg_next, d_q_on_all, d_actions, d_rewards, d_terminated,
              d_invalid_next, d_weights, discount, retrace_h, enable_double_dqn, enable_rescale, d_target, d_loss,
              d_grad_q0, d_priorities, row, row};
+    srlx::td_fill_discounts(a);
     hipLaunchKernelGGL(k_nstep_td_huber_priority, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

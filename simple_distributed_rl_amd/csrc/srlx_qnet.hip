@@ -474,6 +474,9 @@ __global__ void __launch_bounds__(256) k_gemm_s16(AL al, const float *__restrict
 
 // ---- head: reduce FC1 splits (+bias, ReLU), second layers, dueling combine; one workgroup per sample ----
 constexpr int kMaxActions = 32;
+// AMAX = 8 / 16 / 32 >= A (round 5: with the loops over kMaxActions = 32 and a run-time A, every one of the accumulate / shuffle / store loops carried 32 uniform
+// branches for 6 live actions, and thread 0 summed the waves' partial rows with 56 dependent LDS reads: 16.5 us for the learner's 128 rows, of which the loads were 7)
+template <int AMAX>
 __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial, int splits, i64 M, int hidden, const float *__restrict__ b1,
                                               const float *__restrict__ v2w, const float *__restrict__ v2b, const float *__restrict__ a2w,
                                               const float *__restrict__ a2b, int A, int dueling, float *__restrict__ q, float *__restrict__ h1, i64 ostride,
@@ -484,9 +487,9 @@ __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial,
     const i64 mo = m * ostride;  // row of q / h1 this sample's results go to (the partial sums are dense over the launch's rows)
     const int N1 = 2 * hidden;
     if (draw && blockIdx.x == 0 && t == 0) draw[0] += 1;  // NoisyLinear: the draw this pass used is spent (every reader of draw[0] ran in an earlier launch)
-    float v = 0.f, adv[kMaxActions];
+    float v = 0.f, adv[AMAX];
 #pragma unroll
-    for (int j = 0; j < kMaxActions; j++) adv[j] = 0.f;
+    for (int j = 0; j < AMAX; j++) adv[j] = 0.f;
     const int nwaves = blockDim.x >> 6;
     for (int u = t; u < hidden; u += blockDim.x) {
         // split sums in a fixed order with eight independent chains (sixteen loads in flight per iteration)
@@ -534,42 +537,50 @@ __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial,
         }
         v += hv * v2w[u];
 #pragma unroll
-        for (int j = 0; j < kMaxActions; j++)
+        for (int j = 0; j < AMAX; j++)
             if (j < A) adv[j] += ha * a2w[j * hidden + u];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         v += __shfl_xor(v, off);
 #pragma unroll
-        for (int j = 0; j < kMaxActions; j++)
+        for (int j = 0; j < AMAX; j++)
             if (j < A) adv[j] += __shfl_xor(adv[j], off);
     }
     if (lane == 0) {
         red[wave][kMaxActions] = v;
 #pragma unroll
-        for (int j = 0; j < kMaxActions; j++)
+        for (int j = 0; j < AMAX; j++)
             if (j < A) red[wave][j] = adv[j];
     }
     __syncthreads();
+    if (wave != 0) return;
+    // the waves' partial rows: lane j < A sums column j, lane A the value stream's, each over the waves in wave order (what thread 0 did alone: the same sums);
+    // thread 0 then collects them through the wave's registers
+    float colsum = 0.f;
+    {
+        const int col = lane < A ? lane : kMaxActions;
+        if (lane <= A)
+            for (int w = 0; w < nwaves; w++) colsum += red[w][col];
+    }
+    float out[AMAX];
+#pragma unroll
+    for (int j = 0; j < AMAX; j++) out[j] = j < A ? __shfl(colsum, j) : 0.f;
+    v = __shfl(colsum, A);
     if (t == 0) {
-        v = 0.f;
-        for (int w = 0; w < nwaves; w++) v += red[w][kMaxActions];
         v += v2b[0];
         float mean = 0.f, mx = -INFINITY;
-        float out[kMaxActions];
 #pragma unroll
-        for (int j = 0; j < kMaxActions; j++)
+        for (int j = 0; j < AMAX; j++)
             if (j < A) {
-                float o = 0.f;
-                for (int w = 0; w < nwaves; w++) o += red[w][j];
-                out[j] = o + a2b[j];
+                out[j] = out[j] + a2b[j];
                 mean += out[j];
                 mx = out[j] > mx ? out[j] : mx;
             }
         mean /= (float)A;
         const float sub = dueling == 0 ? mean : (dueling == 1 ? mx : 0.f);  // "average" / "max" / "" (dueling_network.py:49-56)
 #pragma unroll
-        for (int j = 0; j < kMaxActions; j++)
+        for (int j = 0; j < AMAX; j++)
             if (j < A) {
                 out[j] = v + out[j] - sub;
                 q[mo * A + j] = out[j];
@@ -599,7 +610,7 @@ __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial,
                 float bv = -INFINITY;
                 bool have = false;
 #pragma unroll
-                for (int a = 0; a < kMaxActions; a++)
+                for (int a = 0; a < AMAX; a++)
                     if (a < A) {
                         const float x = (inv && inv[a]) ? -INFINITY : out[a];
                         if (!have || x > bv) act = a, bv = x, have = true;
@@ -759,8 +770,14 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     h->probe_fc0 = h->probe_fc1 = nullptr;  // one forward only
     if (h->stamp_buf) SRLX_TRY(srlx_debug_stamp(h->stamp_buf, 11, st));  // (measurement aid: the first dense layer's launch is done)
     // small launches (the learner's 128 / 96 rows) are one workgroup per row and far from filling the chip: twice the threads per row
-    hipLaunchKernelGGL(k_head, dim3((unsigned)B), dim3(B <= 256 && h->hidden > 256 ? 512 : 256), 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w,
-                       h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, h->sig[0] ? h->d_draw : nullptr, h->pol);
+    const dim3 hgrid((unsigned)B), hblock(B <= 256 && h->hidden > 256 ? 512 : 256);
+    i64 *const hdraw = h->sig[0] ? h->d_draw : nullptr;
+    if (h->A <= 8)
+        hipLaunchKernelGGL(k_head<8>, hgrid, hblock, 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w, h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, hdraw, h->pol);
+    else if (h->A <= 16)
+        hipLaunchKernelGGL(k_head<16>, hgrid, hblock, 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w, h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, hdraw, h->pol);
+    else
+        hipLaunchKernelGGL(k_head<32>, hgrid, hblock, 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w, h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, hdraw, h->pol);
     h->pol = srlx_qnet::Policy{};  // one forward only
     if (h->stamp_buf) SRLX_TRY(srlx_debug_stamp(h->stamp_buf, 12, st));  // (... and the head)
     SRLX_HIP(hipGetLastError());

@@ -548,6 +548,10 @@ int srlx_qnet_set_sink_stream(srlx_qnet_t *h, void *stream);
  * effect on results or on eager execution order constraints; under stream capture it decides which of the graph's internal streams the critical chain stays on
  * (finding 14). */
 int srlx_qnet_set_main_first(srlx_qnet_t *h, int on);
+/* splits = 2: conv3's data-gradient GEMM of the backward pass is split over K in two (twice the workgroups, each half as long; the pad fold adds the two partial
+ * slabs) -- for a handle that has the GPU to itself (a learner-only rank), where one workgroup per CU is a serial chain; 1: one pass over K (default).  The sum over K
+ * associates differently: results agree to float32 rounding, not bit for bit, with the unsplit pass. */
+int srlx_qnet_set_dgrad_split(srlx_qnet_t *h, int splits);
 
 /* a caller-owned HIP event (hipEvent_t, NULL: none) recorded on the backward pass's stream right behind its head kernel: with srlx_qnet_backward_td_u8 the TD
  * targets, loss and new priorities exist from there on, so the priority write-back (srlx_per_update) can run beside the gradient kernels on another stream */

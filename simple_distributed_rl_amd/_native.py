@@ -111,6 +111,7 @@ SIGNATURES = {
     "srlx_qnet_set_sink_done": (c_int, [c_p, c_p]),
     "srlx_qnet_set_sink_stream": (c_int, [c_p, c_p]),
     "srlx_qnet_set_main_first": (c_int, [c_p, c_int]),
+    "srlx_qnet_set_dgrad_split": (c_int, [c_p, c_int]),
     "srlx_qnet_fuse_adam_fc1_planes": (c_int, [c_p, c_p]),
     "srlx_qnet_set_pack_sticky": (c_int, [c_p, c_int]),
     "srlx_qnet_set_fc1_neighbour": (c_int, [c_p, c_int]),

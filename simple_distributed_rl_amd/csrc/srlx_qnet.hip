@@ -786,7 +786,7 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
 
 // per parity class z: dXq[z][M = B*QH*QW][CI] = ADgrad(dY) x WT[z][CI][K]^T, K = (KH/S)(KW/S) CO  (srlx_qnet_bwd.hip)
 int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,
-                         hipStream_t st) {
+                         hipStream_t st, int ksplits) {
     SRLX_REQUIRE(KH % S == 0 && KW % S == 0, "dgrad_gemm: the kernel size must be a multiple of the stride");
     ADgrad a{dY, QH, QW, OH, OW, CO, {}};
     const int K = (KH / S) * (KW / S) * CO;
@@ -795,7 +795,11 @@ int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW,
     const i64 M = (i64)B * QH * QW;
     const unsigned Z = (unsigned)(S * S);
     static const bool dgrad_f32 = getenv("SRLX_DGRAD_F32") && getenv("SRLX_DGRAD_F32")[0] == '1';  // A/B switch: the data-gradient GEMMs on the float32 matrix pipe
-    if (CI == 64) {
+    if (CI == 64 && ksplits > 1) {  // stride 1 only (blockIdx.z is the K split here, the parity class otherwise): ksplits partial slabs of M x CI floats
+        SRLX_REQUIRE(S == 1 && (K / BK) % ksplits == 0 && !dgrad_f32, "dgrad_gemm: K splits need stride 1 and a K that divides");
+        dim3 grid((unsigned)((M + 63) / 64), 1, (unsigned)ksplits);
+        hipLaunchKernelGGL((k_gemm_s16<ADgrad, 64, true, 64>), grid, dim3(256), 0, st, a, wT, dXq, M, CI, K, K / ksplits);
+    } else if (CI == 64) {
         dim3 grid((unsigned)((M + 63) / 64), 1, Z);
         if (dgrad_f32)
             hipLaunchKernelGGL((k_gemm<ADgrad, 64, false, false, 64>), grid, dim3(256), 0, st, a, wT, nullptr, dXq, M, CI, K, K, (i64)CI * K, M * CI);
@@ -1099,6 +1103,12 @@ int srlx_qnet_set_sink_done(srlx_qnet_t *h, void *event) {
 int srlx_qnet_set_main_first(srlx_qnet_t *h, int on) {
     SRLX_REQUIRE(h, "qnet_set_main_first: NULL handle");
     h->main_first = on != 0;
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_dgrad_split(srlx_qnet_t *h, int splits) {
+    SRLX_REQUIRE(h && (splits == 1 || splits == 2), "qnet_set_dgrad_split: 1 or 2");
+    h->dgrad_split = splits;
     return SRLX_OK;
 }
 

@@ -446,8 +446,9 @@ __global__ void __launch_bounds__(256) k_transpose_filter(const float *__restric
 
 // dX[b][iy][ix][ci] = [X > 0] * sum over the padded positions that replicate (iy, ix) of dXq[class][b][py / S][px / S][ci]
 // one thread per four channels (float4 loads / stores; CI is a multiple of 32)
+// nsplit > 1: dxq is nsplit split-K partial slabs (split_stride floats apart), added per position in split order
 __global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int W, int CI, int P, int HP, int WP, int S, int QH, int QW,
-                                                  const float *__restrict__ dxq, const float *__restrict__ X, float *__restrict__ dX) {
+                                                  const float *__restrict__ dxq, const float *__restrict__ X, float *__restrict__ dX, int nsplit = 1, i64 split_stride = 0) {
     // 32-bit index arithmetic: B <= 64 samples of at most 21 x 21 x 64 values (64-bit divisions cost more than the kernel's traffic)
     const unsigned i4 = blockIdx.x * 256u + threadIdx.x;
     const unsigned c4n = (unsigned)CI / 4u;
@@ -460,7 +461,12 @@ __global__ void __launch_bounds__(256) k_fold_pad(int B, i64 sstride, int H, int
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int py = y0; py <= y1; py++)
         for (int px = x0; px <= x1; px++) {
-            const float4 v = *reinterpret_cast<const float4 *>(dxq + ((py % S) * S + px % S) * cls_stride + (((i64)b * QH + py / S) * QW + px / S) * CI + ci);
+            const float *src = dxq + ((py % S) * S + px % S) * cls_stride + (((i64)b * QH + py / S) * QW + px / S) * CI + ci;
+            float4 v = *reinterpret_cast<const float4 *>(src);
+            for (int sp = 1; sp < nsplit; sp++) {
+                const float4 w = *reinterpret_cast<const float4 *>(src + sp * split_stride);
+                v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+            }
             s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
         }
     const float4 x = *reinterpret_cast<const float4 *>(X + (((i64)b * sstride * H + iy) * W + ix) * CI + ci);
@@ -650,9 +656,9 @@ int srlx_qnet_enable_training(srlx_qnet_t *h, int64_t max_train_batch) {
                 {&h->dact2, (size_t)max_train_batch * h->OH2 * h->OW2 * 2 * h->F1},
                 {&h->dact1, (size_t)max_train_batch * h->OH1 * h->OW1 * h->F1},
                 {&h->fc_part, (size_t)kFcSplits * max_train_batch * h->flat},
-                {&h->dxpad, (size_t)max_train_batch * (4 * (size_t)((h->OH1 + 5) / 2) * ((h->OW1 + 5) / 2) * h->F1 > (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1
+                {&h->dxpad, (size_t)max_train_batch * (4 * (size_t)((h->OH1 + 5) / 2) * ((h->OW1 + 5) / 2) * h->F1 > 2 * (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1
                                                              ? 4 * (size_t)((h->OH1 + 5) / 2) * ((h->OW1 + 5) / 2) * h->F1
-                                                             : (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1) + 128 * 64},
+                                                             : 2 * (size_t)(h->OH2 + 2) * (h->OW2 + 2) * 2 * h->F1) + 128 * 64},
                 {&h->w_t, c3},
                 {&h->w_t2, c2},
                 {&h->w_part, wp + 64 + 2 * kWgSplits * 64 + 64 * kC1Chunks * 32}};  // + bias partials: [sample][64] conv2/conv3 (x2), [sample, chunk][32] conv1
@@ -756,9 +762,15 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     SRLX_HIP(hipEventRecord(h->ev_d3, st));  // dact3 exists; nothing reads the first dense layer's weights any more
     {   // conv3 (3x3 stride 1 pad 1, act2 -> act3) data gradient on the padded grid (OH2 + 2)^2
         const int HP = h->OH2 + 2, WP = h->OW2 + 2;
-        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st));
+        // split over K in two (round 5): 254 workgroups of 18 K-slabs -- one per CU, each a serial chain of stage / barrier / multiply -- become 508 of 9 that
+        // overlap two to a CU; the fold adds the two partial slabs per padded position
+        // (srlx_qnet_set_dgrad_split: for a handle that has the GPU to itself -- learner rank 0.293 -> 0.287 ms per period, the GEMM 21.2 -> 12.2 us; beside a GPU's own
+        // actors the chip is full either way: 0.4184 against 0.4173 ms per lock-step)
+        const int nsplit = (C2 == 64 && h->dgrad_split == 2) ? 2 : 1;
+        SRLX_TRY(srlx_qnet_dgrad_gemm(h->dact3, B, HP, WP, h->OH3, h->OW3, C2, 3, 3, 1, h->w_t, C2, h->dxpad, st, nsplit));
         const i64 tot = (i64)B * h->OH2 * h->OW2 * C2;
-        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, 1, HP, WP, h->dxpad, h->act2, h->dact2);
+        hipLaunchKernelGGL(k_fold_pad, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, B, ss, h->OH2, h->OW2, C2, 1, HP, WP, 1, HP, WP, h->dxpad, h->act2, h->dact2, nsplit,
+                           (i64)B * HP * WP * C2);
     }
     SRLX_STAMP(18, st);
     SRLX_HIP(hipEventRecord(h->ev_d2, st));

@@ -88,6 +88,7 @@ struct srlx_qnet {
     hipEvent_t sink_done;                 // caller-owned or NULL: recorded on the sink's branch right behind the write-back (srlx_qnet_set_sink_done)
     hipEvent_t sink_wait;                 // caller-owned or NULL: the sink's branch waits for it first (srlx_qnet_set_sink_wait)
     bool main_first;                      // srlx_qnet_set_main_first
+    int dgrad_split;                      // srlx_qnet_set_dgrad_split: K splits of conv3's data-gradient GEMM (0 / 1: none, 2)
     hipStream_t sink_stream;              // caller-owned or NULL: the write-back runs there (behind the fork point) instead of first on the weight-gradient branch (srlx_qnet_set_sink_stream)
     int fc1_order;                        // 0 (default) / 1 / 2: srlx_qnet_set_fc1_branch
     hipStream_t side2;
@@ -149,4 +150,4 @@ int srlx_fc1_planes_gemm(srlx_qnet *h, int64_t rows, int splits, int kps, hipStr
 
 // implicit-GEMM data gradient on the matrix cores (defined next to k_gemm in srlx_qnet.hip)
 int srlx_qnet_dgrad_gemm(const float *dY, int B, int QH, int QW, int OH, int OW, int CO, int KH, int KW, int S, const float *wT, int CI, float *dXq,
-                         hipStream_t st);
+                         hipStream_t st, int ksplits = 1);

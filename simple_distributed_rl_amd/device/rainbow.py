@@ -289,6 +289,8 @@ class RainbowEngine:
             # (a learner-only rank: the first dense layer's weight gradient LAST on the weight-gradient branch, order 0 -- with the critical chain recorded first,
             # 0.300 ms per period against 0.343 on a branch of its own; same box, profiles/r5_ab_ingest_order.txt)
             N.check(self.lib.srlx_qnet_set_main_first(self.inf_online.h, 1))
+            if role == "learner":  # the GPU to itself: conv3's data-gradient GEMM as twice the workgroups, each half as long (-2 % per period)
+                N.check(self.lib.srlx_qnet_set_dgrad_split(self.inf_online.h, 2))
             if self._update_side:
                 N.check(self.lib.srlx_per_set_update_counter(self.lreplay.h_per, None))
             if fused_adam and not self.noisy and os.environ.get("SRLX_ADAM_REST", "1") != "0":

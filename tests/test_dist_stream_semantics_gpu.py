@@ -298,3 +298,74 @@ def test_the_fabric_exposes_a_missing_stream_wait(broken, monkeypatch):
     monkeypatch.setattr(dmod.TransitionBus, broken, no_stream_wait)
     got = _job(sync=False, delay_cycles=6_000_000, steps=steps, actor_priority=False)
     assert any(not torch.equal(a, b) for a, b in zip(got["ring"], want["ring"])) or not torch.equal(got["flat"], want["flat"])
+
+
+def _job_a57(sync: bool, delay_cycles: int, steps: int):
+    """BASELINE configs[3] (DistributedAgent57Light: dedicated learner rank + one actor rank) on the fabric.  No parameter broadcast after the first one
+    (sync_interval beyond the run): what the actor rank plays then depends on the initial weights only, so the learner's replay is reproducible whatever torch's
+    convolution backward does between runs -- the comparison isolates the TRANSITION exchange (`TransitionBus.push_begin / push_end`: live tensors in flight)."""
+    import simple_distributed_rl_amd as srl
+    import simple_distributed_rl_amd.device.dist as dmod
+    from simple_distributed_rl_amd.algorithms import agent57_light
+
+    dev = torch.device("cuda:0")
+    fabric = _Fabric(dev, sync, delay_cycles)
+    out, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+            _Switch.local.facade = _FakeDist(fabric, rank, 2)
+            cfg = agent57_light.Config(batch_size=8, actor_num=4, target_model_update_interval=5, episodic_memory_capacity=64, ucb_window_size=6)
+            cfg.window_length = 4
+            cfg.memory.capacity, cfg.memory.warmup_size = 8 * 30, 32
+            cfg.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1000)
+            cfg.hidden_block.set_dueling_network((32,))
+            env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(20, 20), n_actions=3, episode_len=7)))
+            cfg.setup(env)
+            if rank == 0:
+                torch.manual_seed(100)
+            job = dmod.DistributedAgent57Light(cfg, 8, 0, episode_len=7, sync_interval=10**6, learner_acts=False, seed=5)
+            for _ in range(steps):
+                job.step(learner_updates=1)
+            job.flush()
+            torch.cuda.synchronize()
+            if rank == 0:
+                rp = job.replay
+                out["x"] = job.x.detach().clone()
+                out["frames"] = torch.as_tensor(_DeviceBytes(rp.obs_base, rp.E * rp.L * rp.F), device="cuda").clone()
+                out["size"] = rp.per_state()["size"]
+                out["train_count"] = job.train_count
+            else:
+                out["actor_steps"] = int(job.env_steps_local)
+        except Exception:
+            import traceback
+
+            errors.append(f"rank {rank}:\n{traceback.format_exc()}")
+
+    saved = dmod.dist
+    dmod.dist = _Switch()
+    try:
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in (0, 1)]
+        threads[0].start()
+        assert fabric.source_posted.wait(TIMEOUT) or errors, "rank 0 never reached its first broadcast"
+        threads[1].start()
+        for t in threads:
+            t.join(4 * TIMEOUT)
+        assert not any(t.is_alive() for t in threads), "a rank hung"
+        assert not errors, "\n".join(errors)
+    finally:
+        dmod.dist = saved
+    return out
+
+
+def test_agent57_light_exchange_under_stream_ordered_transfers():
+    """The same check for the configs[3] job's exchange (the older `push_begin / push_end` protocol: the tensors of lock-step t are in flight, uncopied, while the
+    actor rank's next network pass runs): frames and the five UVFA / intrinsic fields in the learner's global replay, bit for bit."""
+    steps = 16
+    want = _job_a57(sync=True, delay_cycles=0, steps=steps)
+    got = _job_a57(sync=False, delay_cycles=6_000_000, steps=steps)
+    assert want["actor_steps"] == steps * 8 and want["size"] == got["size"] > 0 and want["train_count"] > 0
+    assert torch.equal(got["frames"], want["frames"]), "frames differ: a transfer was overtaken by the kernels around it"
+    assert torch.equal(got["x"], want["x"]), "UVFA / intrinsic fields differ"

@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256) k_frame_table_items(StoreDev s, i64 B, co
     const int k = k_begin + (int)(bk % k_count);
     const ItemMeta m = meta[bk / k_count];
     const int kk = k < m.jd + 1 ? k : m.jd + 1;
-    out[t] = frame_offset(s, m.e, m.q + kk, c);
+    out[t] = frame_offset_q(s, m.e, m.pad, kk, c);
 }
 
 // the learner's whole "gather" in one launch: item location + n-step scalars (k_gather_meta) and both offset tables

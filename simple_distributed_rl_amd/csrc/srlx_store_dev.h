@@ -40,31 +40,41 @@ struct ItemMeta {
     int pad;
 };
 
-// per sampled item: locate (env, position), find the episode end inside the window, emit the scalars
+// per sampled item: locate (env, position), find the episode end inside the window, emit the scalars.
+// (Round 5: the ring position is a 64-bit count, and every posmod() of it was a 64-bit software division -- ten per item, ~2.5 us of the learner's draw + gather launch.
+// Two are left, of the position itself; everything relative to them is 32-bit wrap-around arithmetic.  The episode-end scan loads its n flags without a break: the loads
+// no longer wait for one another.)
+__device__ __forceinline__ int wrap32(int r, int m) { return r >= m ? r - m : (r < 0 ? r + m : r); }  // r in (-m, 2m)
 __device__ __forceinline__ ItemMeta item_meta(const StoreDev &s, i64 b, const i64 *tree_idx, int32_t *actions, float *rewards, float *terminated) {
     ItemMeta out;
     const i64 N = s.E * s.item_len;
     i64 j = tree_idx[b] - (N - 1);
     if (j < 0) j = 0;
     if (j >= N) j = N - 1;
-    const i64 e = j % s.E, tau = j / s.E;
+    i64 e, tau;
+    if (N < ((i64)1 << 31)) {  // (32-bit division: every store of this build)
+        const unsigned uj = (unsigned)j, uE = (unsigned)s.E;
+        e = uj % uE, tau = uj / uE;
+    } else {
+        e = j % s.E, tau = j / s.E;
+    }
     const i64 p_last = s.pos[0] - 1;
-    const i64 p_add = p_last - posmod(p_last - tau, s.item_len);
+    const int il = (int)s.item_len, L = (int)s.L;
+    const int d = wrap32((int)posmod(p_last, s.item_len) - (int)tau, il);  // posmod(p_last - tau, item_len): tau < item_len
+    const i64 p_add = p_last - d;
     i64 q = p_add - (s.n - 1);
     if (q < 0) q = 0;
+    const int qm = (int)posmod(q, s.L);
     const i64 base = e * s.L;
     int jd = s.n;
-    for (int k = 0; k < s.n; k++)
-        if (s.flags[base + posmod(q + k, s.L)] & kDone) {
-            jd = k;
-            break;
-        }
+    for (int k = s.n - 1; k >= 0; k--)
+        if (s.flags[base + wrap32(qm + k, L)] & kDone) jd = k;  // (the first transition that ended the episode)
     out.e = e;
     out.q = q;
     out.jd = jd;
-    out.pad = 0;
+    out.pad = qm;  // q mod L, for frame_offset_q
     for (int k = 0; k < s.n; k++) {
-        const i64 r = base + posmod(q + k, s.L);
+        const i64 r = base + wrap32(qm + k, L);
         if (k <= jd) {
             actions[b * s.n + k] = s.action[r];
             rewards[b * s.n + k] = s.reward[r];
@@ -78,6 +88,12 @@ __device__ __forceinline__ ItemMeta item_meta(const StoreDev &s, i64 b, const i6
         }
     }
     return out;
+}
+// frame c of the stack at position q + kk of environment e, given qm = q mod L (ItemMeta.pad): frame_offset(s, e, q + kk, c) without the 64-bit divisions
+__device__ __forceinline__ i64 frame_offset_q(const StoreDev &s, i64 e, int qm, int kk, int c) {
+    const int back = s.W - 1 - c, L = (int)s.L;
+    if (back > s.step_in_ep[e * s.L + wrap32(qm + kk, L)]) return -1;
+    return (e * s.L + wrap32(qm + kk - back, L)) * s.F;  // (kk <= n, back < W, n + W <= L)
 }
 __device__ __forceinline__ i64 frame_offset(const StoreDev &s, i64 e, i64 x, int c) {
     const int back = s.W - 1 - c;
@@ -101,7 +117,7 @@ __device__ __forceinline__ void gather_train_items(const StoreDev &s, i64 b0, in
         const int c = x % W, k = (x / W) % S, bl = x / (W * S);
         const ItemMeta m = sm[bl];
         const int kk = k < m.jd + 1 ? k : m.jd + 1;  // states after the terminal one repeat it (rainbow.py:358)
-        const i64 off = frame_offset(s, m.e, m.q + kk, c);
+        const i64 off = frame_offset_q(s, m.e, m.pad, kk, c);
         off_all[((b0 + bl) * S + k) * W + c] = off;
         if (off_next && k >= 1) off_next[((b0 + bl) * s.n + (k - 1)) * W + c] = off;
     }

@@ -274,14 +274,17 @@ def test_exchange_under_stream_ordered_transfers_equals_synchronous_transfers(ac
     assert torch.equal(got["actor_flat"], want["actor_flat"]) and torch.equal(got["actor_flat"], got["flat"])  # lock-step 30 ended with a broadcast (interval 5)
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("broken", ["recv_end", "send_end"])
 def test_the_fabric_exposes_a_missing_stream_wait(broken, monkeypatch):
-    """The test above has teeth: with the stream-level wait of `TransitionBus.recv_end` (the learner's staging slot is read by the next update's ingest) or of
+    """(`slow`: opt-in with SRLX_RUN_SLOW=1 -- a check OF the check, and not a deterministic one: with GPU_MAX_HW_QUEUES = 2 the communicator stream's spin kernel
+    sometimes shares an in-order hardware queue with the very stream that should have waited for it, which then waits anyway; 8 of 10 runs detect `recv_end`, all
+    detected `send_end`.)  The test above has teeth: with the stream-level wait of `TransitionBus.recv_end` (the learner's staging slot is read by the next update's ingest) or of
     `send_end` (the actor's environments overwrite the frames a send is still reading) taken out -- the host still learns that the peer has posted, as it would
     over RCCL -- the delayed fabric produces a different replay."""
     import simple_distributed_rl_amd.device.dist as dmod
 
-    steps = 20
+    steps = 14
     want = _job(sync=True, delay_cycles=0, steps=steps, actor_priority=False)
 
     def no_stream_wait(self):
@@ -296,7 +299,8 @@ def test_the_fabric_exposes_a_missing_stream_wait(broken, monkeypatch):
             self._staged_in = []
 
     monkeypatch.setattr(dmod.TransitionBus, broken, no_stream_wait)
-    got = _job(sync=False, delay_cycles=6_000_000, steps=steps, actor_priority=False)
+    # (every transfer ~25-30 ms late: several eager lock-steps of host time, so that the unguarded consumer / producer is certain to run first)
+    got = _job(sync=False, delay_cycles=60_000_000, steps=steps, actor_priority=False)
     assert any(not torch.equal(a, b) for a, b in zip(got["ring"], want["ring"])) or not torch.equal(got["flat"], want["flat"])
 
 

@@ -10,6 +10,10 @@
  *     pinned memory, runs on `stream` and returns after the results are in the host arrays.
  *     `on_device` = 1: array arguments are DEVICE pointers on the handle's device; the call
  *     only enqueues work on `stream` (no host synchronisation, HIP-graph capturable).
+ *     `on_device` = 2 (srlx_per_add / _sample / _update; round 6): HOST pointers, asynchronous -- the arguments are copied
+ *     into a device-visible pinned slot that the kernel reads over the link: add / update return without synchronising (later
+ *     calls on the stream are ordered behind them), sample synchronises once and has no copy commands.  Arguments that do not
+ *     fit a 16 KB slot take the synchronous path.
  *   - `stream` is a hipStream_t passed as void* (NULL = HIP's default stream, which is also
  *     PyTorch's default stream).
  *   - calls on one handle must be serialised by the caller (the Python shim holds a lock),
@@ -247,6 +251,10 @@ int srlx_policy_epsilon_greedy(int64_t n_envs, int n_actions, const float *d_q, 
  * {-1,0,1}, episodes of episode_len steps ending `terminated`. Reads the store's reset/step state. */
 int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, float *d_rewards, uint8_t *d_terminated,
                         uint8_t *d_done, void *stream);
+/* The same at an EXPLICIT ring position (the host's count of commits; < 0: the device-resident position): for a store whose device position is the learner's view
+ * and trails the actors' commits by one lock-step (srlx_store_commit_step_at) -- the environments belong to the actors' side and must see the actors' position. */
+int srlx_synth_env_step_at(srlx_store_t *h, int64_t position, int64_t episode_len, void *d_next_obs, float *d_rewards, uint8_t *d_terminated, uint8_t *d_done,
+                           void *stream);
 
 /* Episode ledger of E device-resident environments, one call per lock-step BEFORE the commit.
  * Replaces the per-step host bookkeeping of srl/base/env/env_run.py:334-352 (step counter, episode reward sums) and
@@ -649,6 +657,66 @@ int srlx_qnet_backward_td_u8(srlx_qnet_t *h, int64_t batch, int n_step, const ui
                              const uint8_t *d_invalid_next, const float *d_weights, double discount, double retrace_h, int enable_double_dqn,
                              int enable_rescale, float *d_target, float *d_loss, float *d_grad_q0, float *d_priorities, float *const *d_grads, void *stream);
 int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Agent57_light's five networks on srlx_qnet handles (round 6; SURVEY 8 a18, BASELINE configs[3]).
+ * Replaces srl/algorithms/agent57_light/model_torch.py:18-117 (QNetwork with UVFA inputs, _EmbeddingNetwork, _LifelongNetwork), :244-255 (four Adams) and
+ * :384-443 (_update_q) -- through round 5 the dense parts ran in torch (hipBLASLt + ATen elementwise).
+ *   srlx_qnet_bind_uvfa       : a Q-network's UVFA inputs (:35-64: previous extrinsic reward, previous intrinsic reward, one-hot previous action, one-hot actor,
+ *       concatenated BEHIND the image features).  Their columns of the dueling block's two first layers are kept apart from the image columns as
+ *       d_wx float32 [n_cols][2 * hidden] (COLUMN-major: unit u of column c at c * 2 * hidden + u; units 0..hidden-1 = value stream, the rest = advantage stream) and
+ *       enter the layer as rank-1 terms in the head kernel: reward * column, one column per one-hot.  col_* = first column of an input or -1 (input absent).
+ *       Before srlx_qnet_actor_sets_enable: a published set carries a copy of the columns.
+ *   srlx_qnet_set_uvfa_inputs : the per-row inputs of the next forward / backward passes, device arrays indexed by the forward's row (float32 rewards, int32 indices;
+ *       NULL where the input is absent).  BORROWED until replaced (captured into HIP graphs with the passes).
+ *   srlx_qnet_fuse_adam_uvfa  : gradient buffer of the columns (same layout; every backward pass writes it, beside the data-gradient chain) and, with Adam state
+ *       (after srlx_qnet_fuse_adam_rest), their optimiser step in the packing launch of srlx_qnet_publish.
+ *   srlx_qnet_set_td_extras   : the TD prologue of srlx_qnet_backward_td_u8 with a per-sample discount float32 [batch] (the sampled actor's gamma,
+ *       agent57_light.py:263; n_step = 1 makes the prologue exactly calc_target_q :218-268) and the SIGNED TD error target - q float32 [batch] (:442).
+ *   srlx_qnet_set_head_mode   : mode 1 = the handle ends behind the first dense layer (the embedding block :78 and the lifelong networks' hidden block :111): `d_q` of
+ *       the forward entry points is float32 [batch][out_cols], the first out_cols post-ReLU units (a layer narrower than the GEMM's tile is padded with zero rows);
+ *       d_ln_w / d_ln_b != NULL: nn.LayerNorm over all 2 * hidden units first (:112, inference only).  srlx_qnet_backward_u8 then takes d loss / d that output
+ *       [batch][out_cols]; d_grads[8..11] are ignored (bind small dummies).  mode 0 = the dueling head.
+ * ------------------------------------------------------------------------------------------------ */
+int srlx_qnet_bind_uvfa(srlx_qnet_t *h, const float *d_wx, int n_cols, int col_ext, int col_int, int col_action, int n_action_in, int col_actor, int n_actor);
+int srlx_qnet_set_uvfa_inputs(srlx_qnet_t *h, const float *d_r_ext, const float *d_r_int, const int32_t *d_action, const int32_t *d_actor);
+int srlx_qnet_fuse_adam_uvfa(srlx_qnet_t *h, float *d_grad_wx, float *d_exp_avg, float *d_exp_avg_sq);
+int srlx_qnet_set_td_extras(srlx_qnet_t *h, const float *d_discount_per_sample, float *d_td_signed);
+int srlx_qnet_set_head_mode(srlx_qnet_t *h, int mode, int out_cols, const float *d_ln_w, const float *d_ln_b, double ln_eps);
+/* Agent57_light around its networks, one launch each (csrc/srlx_agent57.hip):
+ *   srlx_agent57_policy         : Worker.policy (agent57_light.py:355-375) for E environments: q = q_ext + beta[arm] * q_int, epsilon[arm]-greedy with the keyed uniforms
+ *       (seed, *d_counter, 2 e / 2 e + 1) like srlx_qnet_forward_u8_policy (the counter is only read).  d_arm = NULL: evaluation (test_beta / test_epsilon, :294-297).
+ *   srlx_agent57_post_step      : Worker.on_step's bookkeeping (:377-432): the item fields the frame store does not keep (rows of the caller's [ring slot][env] arrays:
+ *       actor, previous action, previous rewards, intrinsic reward = episodic * lifelong :383-391), then previous action / rewards and the episode reward of the lanes
+ *       that took a step (d_reset_lane == 0).
+ *   srlx_agent57_begin_episodes : Worker.on_reset (:288-311) for the lanes in d_done (NULL: all): random previous action (keyed: seed, *d_counter, lane), zero previous
+ *       rewards and episode reward; d_reset_lane (or NULL) := d_done, d_live_lane (or NULL) := !d_done.
+ *   srlx_agent57_gather_inputs  : change_batches_format (:165-216) for a drawn batch located by srlx_store_locate: the online network's rows interleaved (2 b = s_0 with the
+ *       inputs of model_torch.py:427-433, 2 b + 1 = s_1 with :294-299), the target network's rows (s_1), discount[b] = discount_list[actor] (:287), r_int[b].
+ *   srlx_agent57_emb_tail       : the embedding network behind its two embeddings (model_torch.py:87-95) + MSE against the one-hot action (:343) + backward + Adam (:345-347)
+ *       in ONE single-workgroup launch.  d_emb float32 [2 batch][emb_dim] (rows 2 b = f(s), 2 b + 1 = f(s')); the four pointer tables are HOST arrays of 6 device
+ *       pointers: out_block weight [hidden][2 emb_dim], its bias, LayerNorm weight, bias, out_block_out1 weight [n_actions][hidden], its bias; d_exp_avg = NULL:
+ *       gradients only.  d_steps_taken = optimiser steps already applied (device scalar).  Out: d_loss [1], d_grad_emb [2 batch][emb_dim].
+ *   srlx_agent57_rnd_tail       : the predictor's LayerNorm (:112,116) + MSE against the target network's output (:357) + backward + Adam for the LayerNorm parameters;
+ *       d_hidden / d_target = the predictor's post-ReLU hidden layer / the target network's output, `batch` rows of `dim` floats row_stride floats apart; d_mirror_* (or NULL) receive the updated LayerNorm parameters once more (the copy the actors
+ *       read next). */
+int srlx_agent57_policy(int64_t n_envs, int n_actions, const float *d_q_ext, const float *d_q_int, const int32_t *d_arm, const float *d_beta_list, const float *d_eps_list,
+                        double test_beta, double test_epsilon, uint64_t seed, const int64_t *d_counter, int32_t *d_actions, float *d_q_out, void *stream);
+int srlx_agent57_post_step(int64_t n_envs, const int32_t *d_actions, const int32_t *d_arm, const float *d_rewards, const uint8_t *d_reset_lane, const float *d_episodic,
+                           const float *d_lifelong, int32_t *d_prev_action, float *d_prev_r_ext, float *d_prev_r_int, float *d_episode_reward, float *d_x_r_int,
+                           float *d_x_prev_r_ext, float *d_x_prev_r_int, int32_t *d_x_actor, int32_t *d_x_prev_action, void *stream);
+int srlx_agent57_begin_episodes(int64_t n_envs, int n_actions, const uint8_t *d_done, uint64_t seed, const int64_t *d_counter, int32_t *d_prev_action, float *d_prev_r_ext,
+                                float *d_prev_r_int, float *d_episode_reward, uint8_t *d_reset_lane, uint8_t *d_live_lane, void *stream);
+int srlx_agent57_gather_inputs(int64_t batch, int64_t n_envs, const int64_t *d_loc_env, const int64_t *d_loc_slot, const int32_t *d_actions, const float *d_rewards,
+                               const float *d_x_r_int, const float *d_x_prev_r_ext, const float *d_x_prev_r_int, const int32_t *d_x_actor, const int32_t *d_x_prev_action,
+                               const float *d_discount_list, float *d_on_r_ext, float *d_on_r_int, int32_t *d_on_action, int32_t *d_on_actor, float *d_tg_r_ext,
+                               float *d_tg_r_int, int32_t *d_tg_action, int32_t *d_tg_actor, float *d_discount, float *d_r_int, void *stream);
+int srlx_agent57_emb_tail(int64_t batch, int emb_dim, int hidden, int n_actions, const float *d_emb, const int32_t *d_actions, float *const *d_params, float *const *d_grads,
+                          float *const *d_exp_avg, float *const *d_exp_avg_sq, double ln_eps, double lr, double beta1, double beta2, double eps, const int64_t *d_steps_taken,
+                          float *d_loss, float *d_grad_emb, void *stream);
+int srlx_agent57_rnd_tail(int64_t batch, int dim, int64_t row_stride, const float *d_hidden, const float *d_target, float *d_ln_w, float *d_ln_b, float *d_grad_ln_w, float *d_grad_ln_b,
+                          float *d_exp_avg_w, float *d_exp_avg_sq_w, float *d_exp_avg_b, float *d_exp_avg_sq_b, float *d_mirror_w, float *d_mirror_b, double ln_eps, double lr,
+                          double beta1, double beta2, double eps, const int64_t *d_steps_taken, float *d_loss, float *d_grad_hidden, void *stream);
 
 /* NoisyLinear dense layers (replaces srl/rl/torch_/modules/noisy_linear.py:26-52, the dense layers of the reference's
  * rainbow.Config.set_atari_config(), rainbow.py:116-148): W = w_mu + w_sigma * eps, b = b_mu + b_sigma * eps, eps ~ N(0,1)

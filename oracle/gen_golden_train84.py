@@ -10,6 +10,7 @@ Only data travels (tests/golden/train_step_rainbow84.npz):
   actions / reward / done [B][3], weights [B] (importance weights handed to the trainer)
   outputs of the reference: target_q [B], q0 [B][6] (online Q of s_0), loss, priorities [B]
   the Adam step: for every parameter tensor 2048 sampled entries of (after - before) (`upd.<key>`, positions `pos.<key>`), and float64 sums of after - before
+  the gradients (round 6): the same positions of every `p.grad` as loss.backward() left it (`grad.<key>`), its largest magnitude and its float64 sum (`gmax.`, `gsum.`)
 The 8.0 M weights of the online and the target network are NOT stored: gen_golden_qnet84.recipe_state_dict regenerates them (kind "init", seeds 20260929 / 20260930).
 """
 import os
@@ -104,8 +105,23 @@ def main():
         return y
 
     parameter.q_online.forward = fwd
+    # p.grad as `loss.backward()` left it (model_torch.py:107-108), caught at `optimizer.step()` (:109): Adam's FIRST step is lr * g / (|g| + eps) ~ lr * sign(g),
+    # so the step alone pins signs -- the gradient entries themselves pin the hand-written backward's magnitudes on the reference
+    names = {id(p): k for k, p in parameter.q_online.named_parameters()}
+    grads = {}
+    _step = torch.optim.Adam.step
+
+    def step(self, *a, **k):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None and id(p) in names:
+                    grads[names[id(p)]] = p.grad.detach().clone().numpy()
+        return _step(self, *a, **k)
+
+    torch.optim.Adam.step = step
     trainer.train_count = 1  # not a sync step
     trainer.train()
+    torch.optim.Adam.step = _step
     parameter.q_online.forward = orig_forward
     after = {k: v.detach().numpy() for k, v in parameter.q_online.state_dict().items()}
     save = dict(frames=frames, actions=actions, reward=reward, done=done, weights=weights, target_q=rec["target_q"].astype(np.float32), q0=holder["q"].numpy(),
@@ -120,6 +136,10 @@ def main():
         save["upd." + k] = d[pos].astype(np.float32)
         save["sum." + k] = np.float64(d.sum())
         save["abs." + k] = np.float64(np.abs(d).sum())
+        g = grads[k].astype(np.float64).reshape(-1)
+        save["grad." + k] = g[pos].astype(np.float32)
+        save["gmax." + k] = np.float64(np.abs(g).max())
+        save["gsum." + k] = np.float64(g.sum())
     np.savez_compressed(os.path.join(OUT, "train_step_rainbow84.npz"), **save)
     print(f"train_step_rainbow84: loss={float(trainer.info['loss']):.6f} target range [{rec['target_q'].min():.4f}, {rec['target_q'].max():.4f}]")
 

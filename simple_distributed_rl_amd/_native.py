@@ -140,6 +140,7 @@ SIGNATURES = {
     "srlx_image_preprocess": (c_int, [c_i64, c_int, c_int, c_int, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_int, c_f64, c_p]),
     "srlx_episode_account": (c_int, [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "srlx_synth_env_step": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_synth_env_step_at": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_nstep_td_huber_priority": (
         c_int,
         [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_int, c_int, c_p, c_p, c_p, c_p, c_p],
@@ -168,6 +169,17 @@ SIGNATURES = {
     "srlx_ngu_episodic_reward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_ngu_lifelong_reward": (c_int, [c_i64, c_int, c_p, c_p, c_f64, c_p, c_p]),
     "srlx_agent57_seq_td": (c_int, [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_qnet_bind_uvfa": (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "srlx_qnet_set_uvfa_inputs": (c_int, [c_p, c_p, c_p, c_p, c_p]),
+    "srlx_qnet_fuse_adam_uvfa": (c_int, [c_p, c_p, c_p, c_p]),
+    "srlx_qnet_set_td_extras": (c_int, [c_p, c_p, c_p]),
+    "srlx_qnet_set_head_mode": (c_int, [c_p, c_int, c_int, c_p, c_p, c_f64]),
+    "srlx_agent57_policy": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_u64, c_p, c_p, c_p, c_p]),
+    "srlx_agent57_post_step": (c_int, [c_i64] + [c_p] * 16),
+    "srlx_agent57_begin_episodes": (c_int, [c_i64, c_int, c_p, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_agent57_gather_inputs": (c_int, [c_i64, c_i64] + [c_p] * 21),
+    "srlx_agent57_emb_tail": (c_int, [c_i64, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p, c_p]),
+    "srlx_agent57_rnd_tail": (c_int, [c_i64, c_int, c_i64] + [c_p] * 12 + [c_f64] * 5 + [c_p, c_p, c_p, c_p]),
     "srlx_agent57_priority": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
 }
 OBS_U8, OBS_F32 = 0, 1

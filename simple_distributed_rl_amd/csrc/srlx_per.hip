@@ -1227,6 +1227,15 @@ struct srlx_per {
     srlx::Arena scratch;  // device
     srlx::Arena staging;  // device copies of host-mode arguments / results
     srlx::Arena pinned;   // pinned host
+    // on_device = 2 (round 6: the b1 shim's asynchronous host mode): a ring of device-visible pinned slots; add / update copy their host arguments into a slot and
+    // launch kernels that read it over the link -- no staging copy, no stream synchronisation -- and sample reads its uniforms from and writes its results to one
+    // (ONE synchronisation per call).  ring_ev[k] is recorded behind the launch that reads slot k; a slot is reused only once its event has completed.
+    static constexpr int kRingSlots = 16;
+    static constexpr size_t kRingSlotBytes = 16 * 1024;
+    char *ring;
+    hipEvent_t ring_ev[kRingSlots];
+    bool ring_busy[kRingSlots];
+    int ring_next;
 };
 
 namespace {
@@ -1234,6 +1243,28 @@ namespace {
 hipStream_t pick_stream(srlx_per *, void *stream) { return (hipStream_t)stream; }  // NULL = HIP's default stream
 
 size_t prio_elem_bytes(int kind) { return (kind == SRLX_PRIO_F32 || kind == SRLX_PRIO_EST_F32) ? 4 : (kind == SRLX_PRIO_NONE_MASKED ? 1 : 8); }
+
+// a free slot of the asynchronous host mode's pinned ring (NULL: the arguments do not fit one slot -- the caller takes the synchronous path)
+int ring_acquire(srlx_per *h, size_t bytes, char **out, int *slot) {
+    *out = nullptr;
+    if (bytes > srlx_per::kRingSlotBytes) return SRLX_OK;
+    if (!h->ring) {
+        SRLX_HIP(hipHostMalloc((void **)&h->ring, srlx_per::kRingSlots * srlx_per::kRingSlotBytes, hipHostMallocDefault));
+        for (auto &e : h->ring_ev) SRLX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int k = h->ring_next;
+    h->ring_next = (k + 1) % srlx_per::kRingSlots;
+    if (h->ring_busy[k]) SRLX_HIP(hipEventSynchronize(h->ring_ev[k]));
+    h->ring_busy[k] = false;
+    *out = h->ring + (size_t)k * srlx_per::kRingSlotBytes;
+    *slot = k;
+    return SRLX_OK;
+}
+int ring_release(srlx_per *h, int slot, hipStream_t st) {
+    SRLX_HIP(hipEventRecord(h->ring_ev[slot], st));
+    h->ring_busy[slot] = true;
+    return SRLX_OK;
+}
 
 int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st, i64 start_slot = -1) {
     SRLX_TRY(h->scratch.reserve(srlx::Carver::padded((size_t)n * 8) + 256));
@@ -1474,6 +1505,10 @@ int srlx_per_destroy(srlx_per_t *h) {
     h->scratch.release();
     h->staging.release();
     h->pinned.release();
+    if (h->ring) {
+        (void)hipHostFree(h->ring);
+        for (auto &e : h->ring_ev) (void)hipEventDestroy(e);
+    }
     delete h;
     return SRLX_OK;
 }
@@ -1502,8 +1537,18 @@ int srlx_per_add(srlx_per_t *h, int64_t n, const void *prio, int prio_kind, int 
     if (n == 0) return SRLX_OK;
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = pick_stream(h, stream);
-    if (on_device || prio_kind == SRLX_PRIO_NONE) return launch_add(h, n, prio, prio_kind, st);
+    if (on_device == 1 || prio_kind == SRLX_PRIO_NONE) return launch_add(h, n, prio, prio_kind, st);
     const size_t bytes = (size_t)n * prio_elem_bytes(prio_kind);
+    if (on_device == 2) {  // host arrays, asynchronous: the kernel reads a device-visible pinned slot
+        char *slot_ptr;
+        int slot = 0;
+        SRLX_TRY(ring_acquire(h, bytes, &slot_ptr, &slot));
+        if (slot_ptr) {
+            memcpy(slot_ptr, prio, bytes);
+            SRLX_TRY(launch_add(h, n, slot_ptr, prio_kind, st));
+            return ring_release(h, slot, st);
+        }
+    }
     SRLX_TRY(h->pinned.reserve(bytes));
     SRLX_TRY(h->staging.reserve(bytes));
     memcpy(h->pinned.ptr, prio, bytes);
@@ -1542,11 +1587,37 @@ int srlx_per_sample(srlx_per_t *h, int64_t batch_size, int64_t step, const int64
     SRLX_REQUIRE(out_idx && out_used, "per_sample: out_idx/out_used are NULL");
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = pick_stream(h, stream);
-    if (on_device)
+    if (on_device == 1)
         return launch_sample(h, batch_size, step, d_step, uniforms, n_uniforms, out_idx, out_w, out_w32, out_used, st);
 
     SRLX_REQUIRE(d_step == nullptr, "per_sample: d_step needs on_device=1");
     using C = srlx::Carver;
+    if (on_device == 2) {  // host arrays through ONE device-visible pinned slot: uniforms in, results out, one synchronisation, no copy commands
+        const size_t need = C::padded((size_t)n_uniforms * 8) + C::padded((size_t)batch_size * 8) * 2 + C::padded((size_t)batch_size * 4) + C::padded(8);
+        char *slot_ptr;
+        int slot = 0;
+        SRLX_TRY(ring_acquire(h, need, &slot_ptr, &slot));
+        if (slot_ptr) {
+            C sp(slot_ptr);
+            double *m_u = sp.take<double>(n_uniforms);
+            i64 *m_idx = sp.take<i64>(batch_size);
+            double *m_w = sp.take<double>(batch_size);
+            float *m_w32 = sp.take<float>(batch_size);
+            i64 *m_used = sp.take<i64>(1);
+            memcpy(m_u, uniforms, (size_t)n_uniforms * 8);
+            SRLX_TRY(launch_sample(h, batch_size, step, nullptr, m_u, n_uniforms, m_idx, m_w, m_w32, m_used, st));
+            SRLX_HIP(hipStreamSynchronize(st));
+            *out_used = *m_used;
+            if (*m_used < 0) {
+                srlx::set_error("per_sample: %lld uniforms were not enough for %lld accepted draws", (long long)n_uniforms, (long long)batch_size);
+                return SRLX_ERR_UNIFORMS_EXHAUSTED;
+            }
+            memcpy(out_idx, m_idx, (size_t)batch_size * 8);
+            if (out_w) memcpy(out_w, m_w, (size_t)batch_size * 8);
+            if (out_w32) memcpy(out_w32, m_w32, (size_t)batch_size * 4);
+            return SRLX_OK;
+        }
+    }
     const size_t in_bytes = C::padded((size_t)n_uniforms * 8);
     const size_t out_bytes = C::padded((size_t)batch_size * 8) * 2 + C::padded((size_t)batch_size * 4) + C::padded(8);
     SRLX_TRY(h->pinned.reserve(in_bytes + out_bytes));
@@ -1625,13 +1696,24 @@ int srlx_per_update(srlx_per_t *h, int64_t n, const int64_t *indices, const void
     SRLX_REQUIRE(indices && prio, "per_update: NULL array");
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = pick_stream(h, stream);
-    if (on_device) return launch_update(h, n, indices, prio, prio_kind, st);
+    if (on_device == 1) return launch_update(h, n, indices, prio, prio_kind, st);
 
     for (i64 i = 0; i < n; i++)
         SRLX_REQUIRE(indices[i] >= 0 && indices[i] < h->tree_len, "per_update: index %lld out of range [0,%lld)",
                      (long long)indices[i], (long long)h->tree_len);
     using C = srlx::Carver;
     const size_t ib = C::padded((size_t)n * 8), pb = C::padded((size_t)n * prio_elem_bytes(prio_kind));
+    if (on_device == 2) {  // host arrays, asynchronous (see srlx_per_add)
+        char *slot_ptr;
+        int slot = 0;
+        SRLX_TRY(ring_acquire(h, ib + pb, &slot_ptr, &slot));
+        if (slot_ptr) {
+            memcpy(slot_ptr, indices, (size_t)n * 8);
+            memcpy(slot_ptr + ib, prio, (size_t)n * prio_elem_bytes(prio_kind));
+            SRLX_TRY(launch_update(h, n, (const i64 *)slot_ptr, slot_ptr + ib, prio_kind, st));
+            return ring_release(h, slot, st);
+        }
+    }
     SRLX_TRY(h->pinned.reserve(ib + pb));
     SRLX_TRY(h->staging.reserve(ib + pb));
     C hp(h->pinned.ptr), dp(h->staging.ptr);

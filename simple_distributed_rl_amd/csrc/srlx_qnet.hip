@@ -480,10 +480,20 @@ template <int AMAX>
 __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial, int splits, i64 M, int hidden, const float *__restrict__ b1,
                                               const float *__restrict__ v2w, const float *__restrict__ v2b, const float *__restrict__ a2w,
                                               const float *__restrict__ a2b, int A, int dueling, float *__restrict__ q, float *__restrict__ h1, i64 ostride,
-                                              i64 *__restrict__ draw, srlx_qnet::Policy pol) {
+                                              i64 *__restrict__ draw, srlx_qnet::Policy pol, srlx_uvfa_dev uv) {
     __shared__ float red[8][kMaxActions + 1];  // one row per wave (256 or 512 threads)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const i64 m = blockIdx.x;
+    // UVFA inputs of this row (agent57_light/model_torch.py:52-62): the rewards scale their columns of the first dense layer, each one-hot selects one
+    float x_ext = 0.f, x_int = 0.f;
+    const float *col_act = nullptr, *col_actor = nullptr, *col_ext = nullptr, *col_int = nullptr;
+    if (uv.wx) {
+        const int n1 = 2 * hidden;
+        if (uv.c_ext >= 0) x_ext = uv.r_ext[m], col_ext = uv.wx + (i64)uv.c_ext * n1;
+        if (uv.c_int >= 0) x_int = uv.r_int[m], col_int = uv.wx + (i64)uv.c_int * n1;
+        if (uv.c_act >= 0) col_act = uv.wx + (i64)(uv.c_act + uv.action[m]) * n1;
+        if (uv.c_actor >= 0) col_actor = uv.wx + (i64)(uv.c_actor + uv.actor[m]) * n1;
+    }
     const i64 mo = m * ostride;  // row of q / h1 this sample's results go to (the partial sums are dense over the launch's rows)
     const int N1 = 2 * hidden;
     if (draw && blockIdx.x == 0 && t == 0) draw[0] += 1;  // NoisyLinear: the draw this pass used is spent (every reader of draw[0] ran in an earlier launch)
@@ -529,6 +539,14 @@ __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial,
         }
         float hv = b1[u] + (((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7])));
         float ha = b1[hidden + u] + (((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7])));
+        if (uv.wx) {  // the UVFA columns' share of the pre-activation, in the reference's column order
+            float xv = 0.f, xa = 0.f;
+            if (col_ext) xv += x_ext * col_ext[u], xa += x_ext * col_ext[hidden + u];
+            if (col_int) xv += x_int * col_int[u], xa += x_int * col_int[hidden + u];
+            if (col_act) xv += col_act[u], xa += col_act[hidden + u];
+            if (col_actor) xv += col_actor[u], xa += col_actor[hidden + u];
+            hv += xv, ha += xa;
+        }
         hv = hv > 0.f ? hv : 0.f;
         ha = ha > 0.f ? ha : 0.f;
         if (h1) {  // training: the backward pass needs the hidden layer
@@ -618,6 +636,65 @@ __global__ void __launch_bounds__(512) k_head(const float *__restrict__ partial,
             }
             pol.actions[m] = act;
         }
+    }
+}
+
+// ---- head_mode 1: the handle ends behind the first dense layer (the embedding / RND networks of Agent57_light, model_torch.py:70-117) ----
+// one workgroup per row: split sums in split order + bias + ReLU -> h1 (training) and out[row][0..out_cols); ln_w != NULL: LayerNorm over all N1 units first
+// (nn.LayerNorm: biased variance, eps inside the root, :112,116), the lifelong networks' last layer.
+__global__ void __launch_bounds__(256) k_hidden_out(const float *__restrict__ partial, int splits, i64 M, int N1, const float *__restrict__ b1, float *__restrict__ out,
+                                                    int out_cols, float *__restrict__ h1, i64 ostride, const float *__restrict__ ln_w, const float *__restrict__ ln_b,
+                                                    float ln_eps) {
+    __shared__ float red[2][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const i64 m = blockIdx.x, mo = m * ostride;
+    constexpr int kPer = 4;  // N1 <= 1024
+    float hv[kPer];
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        const int u = t + 256 * j;
+        hv[j] = 0.f;
+        if (u < N1) {
+            const float *p = partial + m * N1 + u;
+            const i64 ss = M * N1;
+            float c4[4] = {0.f, 0.f, 0.f, 0.f};
+            int s = 0;
+            for (; s + 4 <= splits; s += 4)
+#pragma unroll
+                for (int q = 0; q < 4; q++) c4[q] += p[(s + q) * ss];
+            for (; s < splits; s++) c4[s & 3] += p[s * ss];
+            float v = b1[u] + ((c4[0] + c4[1]) + (c4[2] + c4[3]));
+            v = v > 0.f ? v : 0.f;
+            hv[j] = v;
+            if (h1) h1[mo * N1 + u] = v;
+            s1 += v;
+        }
+    }
+    if (ln_w) {
+        for (int off = 32; off > 0; off >>= 1) s1 += __shfl_xor(s1, off);
+        if (lane == 0) red[0][wave] = s1;
+        __syncthreads();
+        const float mean = (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) / (float)N1;
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kPer; j++)
+            if (t + 256 * j < N1) s2 += (hv[j] - mean) * (hv[j] - mean);
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+        if (lane == 0) red[1][wave] = s2;
+        __syncthreads();
+        const float var = (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) / (float)N1;
+        const float rstd = 1.0f / sqrtf(var + ln_eps);
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int u = t + 256 * j;
+            if (u < N1) hv[j] = ((hv[j] - mean) * rstd) * ln_w[u] + ln_b[u];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        const int u = t + 256 * j;
+        if (u < out_cols) out[mo * out_cols + u] = hv[j];
     }
 }
 
@@ -740,6 +817,10 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     if (h->fc1_neighbour > 0 && h->planes_valid && srlx_fc1_planes_applicable(h, B) && B >= 512) splits = h->fc1_neighbour;
     if (splits > ksteps) splits = ksteps;
     if (splits > h->max_splits) splits = h->max_splits;
+    {   // (a narrow layer has few column tiles and would ask for more K splits than the partial-sum buffer holds rows for: srlx_qnet_set_fc1_neighbour sizes it for more)
+        const size_t fit = h->partial_floats / ((size_t)((B + 127) / 128 * 128) * N1);
+        if ((size_t)splits > fit) splits = (int)fit;
+    }
     if (splits < 1) splits = 1;
     const int kps = ((ksteps + splits - 1) / splits);
     const int used = (ksteps + kps - 1) / kps;  // splits that actually own a K range
@@ -772,12 +853,17 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     // small launches (the learner's 128 / 96 rows) are one workgroup per row and far from filling the chip: twice the threads per row
     const dim3 hgrid((unsigned)B), hblock(B <= 256 && h->hidden > 256 ? 512 : 256);
     i64 *const hdraw = h->sig[0] ? h->d_draw : nullptr;
-    if (h->A <= 8)
-        hipLaunchKernelGGL(k_head<8>, hgrid, hblock, 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w, h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, hdraw, h->pol);
+    const srlx_uvfa_dev uv = srlx_uvfa_args(h);
+    SRLX_REQUIRE(!uv.wx || ((uv.c_ext < 0 || uv.r_ext) && (uv.c_int < 0 || uv.r_int) && (uv.c_act < 0 || uv.action) && (uv.c_actor < 0 || uv.actor)),
+                 "qnet_forward: a UVFA network needs its per-row inputs (srlx_qnet_set_uvfa_inputs)");
+    if (h->head_mode == 1)  // the handle ends behind the first dense layer: d_q is the hidden layer's first out_cols units (+ LayerNorm)
+        hipLaunchKernelGGL(k_hidden_out, hgrid, dim3(256), 0, st, h->partial, used, Mp, N1, h->bf, d_q, h->out_cols, h->h1, (i64)stride, h->ln_w, h->ln_b, h->ln_eps);
+    else if (h->A <= 8)
+        hipLaunchKernelGGL(k_head<8>, hgrid, hblock, 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w, h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, hdraw, h->pol, uv);
     else if (h->A <= 16)
-        hipLaunchKernelGGL(k_head<16>, hgrid, hblock, 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w, h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, hdraw, h->pol);
+        hipLaunchKernelGGL(k_head<16>, hgrid, hblock, 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w, h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, hdraw, h->pol, uv);
     else
-        hipLaunchKernelGGL(k_head<32>, hgrid, hblock, 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w, h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, hdraw, h->pol);
+        hipLaunchKernelGGL(k_head<32>, hgrid, hblock, 0, st, h->partial, used, Mp, h->hidden, h->bf, h->v2w, h->v2b, h->a2w, h->a2b, h->A, h->dueling, d_q, h->h1, (i64)stride, hdraw, h->pol, uv);
     h->pol = srlx_qnet::Policy{};  // one forward only
     if (h->stamp_buf) SRLX_TRY(srlx_debug_stamp(h->stamp_buf, 12, st));  // (... and the head)
     SRLX_HIP(hipGetLastError());
@@ -1017,6 +1103,7 @@ int srlx_qnet_actor_set_select(srlx_qnet_t *h, int set) {
             h->wpack = h->wpack_own, h->wf_planes = h->wf_planes_own;
             h->b1 = h->bound[1], h->b2 = h->bound[3], h->b3 = h->bound[5];
             h->bf = h->bound[7], h->v2w = h->bound[8], h->v2b = h->bound[9], h->a2w = h->bound[10], h->a2b = h->bound[11];
+            h->uvfa.wx = h->uvfa.wx_bound;
             h->pack_valid = false, h->planes_valid = false;
         }
         h->aset_cur = -1;
@@ -1027,6 +1114,7 @@ int srlx_qnet_actor_set_select(srlx_qnet_t *h, int set) {
     h->wpack = a.wpack, h->wf_planes = a.wf_planes;
     h->b1 = a.small + L.b1, h->b2 = a.small + L.b2, h->b3 = a.small + L.b3;
     h->bf = a.small + L.bf, h->v2w = a.small + L.v2w, h->v2b = a.small + L.v2b, h->a2w = a.small + L.a2w, h->a2b = a.small + L.a2b;
+    if (h->uvfa.X > 0) h->uvfa.wx = a.small + L.wx;
     h->pack_valid = true, h->planes_valid = true;
     h->aset_cur = set;
     return SRLX_OK;
@@ -1047,7 +1135,8 @@ int srlx_qnet_publish(srlx_qnet_t *h_src, srlx_qnet_t *h_actor, int set, int wit
         return SRLX_OK;
     }
     SRLX_REQUIRE((set == 0 || set == 1) && h_actor->aset[set].wpack, "qnet_publish: srlx_qnet_actor_sets_enable on the actor handle first");
-    SRLX_REQUIRE(h_actor->hidden == h_src->hidden && h_actor->A == h_src->A && h_actor->flat == h_src->flat, "qnet_publish: the two handles describe different networks");
+    SRLX_REQUIRE(h_actor->hidden == h_src->hidden && h_actor->A == h_src->A && h_actor->flat == h_src->flat && h_actor->uvfa.X == h_src->uvfa.X,
+                 "qnet_publish: the two handles describe different networks");
     const srlx_small_layout L = srlx_small_offsets(h_actor);
     SRLX_TRY(srlx_qnet_pack_publish(h_src, &h_actor->aset[set], &L, st, d_bump, true));
     if (h_src->aset_cur < 0) h_src->pack_valid = true;
@@ -1146,6 +1235,49 @@ int srlx_qnet_fuse_adam_fc1_planes(srlx_qnet_t *h, void *d_planes_out) {
     SRLX_REQUIRE(h, "qnet_fuse_adam_fc1_planes: NULL handle");
     SRLX_REQUIRE(!d_planes_out || h->adam_m, "qnet_fuse_adam_fc1_planes: srlx_qnet_fuse_adam_fc1 first (the planes ride on the fused Adam epilogue)");
     h->adam_planes_out = d_planes_out;
+    return SRLX_OK;
+}
+
+// ---- round 6: Agent57(_light)'s networks on the handle (srlx_qnet_int.h) ------------------------------------------------------------------------------------
+int srlx_qnet_bind_uvfa(srlx_qnet_t *h, const float *d_wx, int n_cols, int col_ext, int col_int, int col_action, int n_action_in, int col_actor, int n_actor) {
+    SRLX_REQUIRE(h && d_wx && n_cols > 0 && n_cols <= 256, "qnet_bind_uvfa: bad argument");
+    SRLX_REQUIRE(h->uvfa.X == 0 || h->uvfa.X == n_cols, "qnet_bind_uvfa: the column count of a handle is fixed by its first binding");
+    SRLX_REQUIRE(h->uvfa.X == n_cols || !h->aset[0].small, "qnet_bind_uvfa: bind before srlx_qnet_actor_sets_enable (the sets hold a copy of the columns)");
+    SRLX_REQUIRE(!h->eff[0] && h->head_mode == 0, "qnet_bind_uvfa: plain dueling handles only");
+    auto ok = [&](int c, int n) { return c < 0 || (n > 0 && c + n <= n_cols); };
+    SRLX_REQUIRE(ok(col_ext, 1) && ok(col_int, 1) && ok(col_action, n_action_in) && ok(col_actor, n_actor), "qnet_bind_uvfa: a column range leaves the matrix");
+    srlx_qnet::Uvfa &u = h->uvfa;
+    u.wx_bound = d_wx;
+    if (h->aset_cur < 0) u.wx = d_wx;
+    u.X = n_cols, u.c_ext = col_ext, u.c_int = col_int, u.c_act = col_action, u.n_act_in = n_action_in, u.c_actor = col_actor, u.n_actor = n_actor;
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_uvfa_inputs(srlx_qnet_t *h, const float *d_r_ext, const float *d_r_int, const int32_t *d_action, const int32_t *d_actor) {
+    SRLX_REQUIRE(h && h->uvfa.X > 0, "qnet_set_uvfa_inputs: srlx_qnet_bind_uvfa first");
+    h->uvfa.r_ext = d_r_ext, h->uvfa.r_int = d_r_int, h->uvfa.action = d_action, h->uvfa.actor = d_actor;
+    return SRLX_OK;
+}
+
+int srlx_qnet_fuse_adam_uvfa(srlx_qnet_t *h, float *d_grad_wx, float *d_exp_avg, float *d_exp_avg_sq) {
+    SRLX_REQUIRE(h && h->uvfa.X > 0 && h->max_train > 0, "qnet_fuse_adam_uvfa: a training handle with UVFA columns");
+    SRLX_REQUIRE(d_grad_wx && (!d_exp_avg || (d_exp_avg_sq && h->rest_on)), "qnet_fuse_adam_uvfa: the optimiser step rides on srlx_qnet_fuse_adam_rest's packing launch");
+    h->uvfa.g_wx = d_grad_wx, h->uvfa.m_wx = d_exp_avg, h->uvfa.v_wx = d_exp_avg_sq;
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_td_extras(srlx_qnet_t *h, const float *d_discount_per_sample, float *d_td_signed) {
+    SRLX_REQUIRE(h, "qnet_set_td_extras: NULL handle");
+    h->td_disc_ps = d_discount_per_sample, h->td_signed = d_td_signed;
+    return SRLX_OK;
+}
+
+int srlx_qnet_set_head_mode(srlx_qnet_t *h, int mode, int out_cols, const float *d_ln_w, const float *d_ln_b, double ln_eps) {
+    SRLX_REQUIRE(h && (mode == 0 || mode == 1), "qnet_set_head_mode: mode 0 (dueling head) or 1 (hidden layer out)");
+    SRLX_REQUIRE(mode == 0 || (out_cols > 0 && out_cols <= 2 * h->hidden && 2 * h->hidden <= 1024 && !h->eff[0] && h->uvfa.X == 0),
+                 "qnet_set_head_mode: 1 <= out_cols <= 2 * hidden <= 1024, plain layers");
+    SRLX_REQUIRE(!d_ln_w == !d_ln_b, "qnet_set_head_mode: LayerNorm needs weight and bias");
+    h->head_mode = mode, h->out_cols = out_cols, h->ln_w = d_ln_w, h->ln_b = d_ln_b, h->ln_eps = (float)ln_eps;
     return SRLX_OK;
 }
 

@@ -139,6 +139,50 @@ __global__ void __launch_bounds__(256) k_head_bwd(int B, i64 sstride, int hidden
     }
 }
 
+// ---- UVFA columns of an Agent57(_light) Q-network (srlx_qnet_int.h): g_wx[c][u] = sum_b dh1[b][u] * x[b][c], x = (previous rewards, one-hot previous action,
+// one-hot actor) of the rows that carry gradient (b * sstride of the forward); one thread per (column, unit), the batch in order ------------------------------
+__global__ void __launch_bounds__(256) k_uvfa_wgrad(int B, i64 sstride, int N1, int X, srlx_uvfa_dev uv, const float *__restrict__ dh1, float *__restrict__ g_wx) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= X * N1) return;
+    const int c = id / N1, u = id % N1;
+    float s = 0.f;
+    for (int b = 0; b < B; b++) {
+        const i64 row = (i64)b * sstride;
+        float x;
+        if (c == uv.c_ext) x = uv.r_ext[row];
+        else if (c == uv.c_int) x = uv.r_int[row];
+        else if (uv.c_act >= 0 && c >= uv.c_act && c < uv.c_act + uv.n_act_in) x = uv.action[row] == c - uv.c_act ? 1.f : 0.f;
+        else x = (uv.c_actor >= 0 && uv.actor[row] == c - uv.c_actor) ? 1.f : 0.f;
+        s += dh1[(i64)b * N1 + u] * x;
+    }
+    g_wx[id] = s;
+}
+
+// ---- head_mode 1: the gradient arrives at the post-ReLU hidden layer's first out_cols units, g [B][out_cols] (the other units of a padded layer get none):
+// dh1 = g masked by the ReLU, its transpose for the matrix-core data gradient, and the bias gradient (batch in slice order, as k_head_bwd) -------------------
+__global__ void __launch_bounds__(256) k_hidden_bwd(int B, i64 sstride, int N1, int out_cols, const float *__restrict__ g, const float *__restrict__ h1,
+                                                    float *__restrict__ dh1, float *__restrict__ dh1t, float *__restrict__ g_bf) {
+    __shared__ float part[256];
+    const int ul = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int u = blockIdx.x * 64 + ul;
+    float gb = 0.f;
+    if (u < N1) {
+        for (int b = slice; b < B; b += 4) {
+            const float hv = h1[(i64)b * sstride * N1 + u];
+            const float d = (u < out_cols && hv > 0.f) ? g[(i64)b * out_cols + u] : 0.f;
+            dh1[(i64)b * N1 + u] = d;
+            if (dh1t) dh1t[u * 32 + b] = d;
+            gb += d;
+        }
+        if (dh1t)
+            for (int b = slice; b < 32; b += 4)
+                if (b >= B) dh1t[u * 32 + b] = 0.f;
+    }
+    part[threadIdx.x] = gb;
+    __syncthreads();
+    if (slice == 0 && u < N1) g_bf[u] = ((part[ul] + part[64 + ul]) + part[128 + ul]) + part[192 + ul];
+}
+
 // ---- first dense layer: weight gradient  g_wf[n][k] = sum_b dh1[b][n] * act3[b][k]  on the matrix cores -------------------------
 // One wave per 32 x 32 tile of the 32 MB matrix: the batch is the K dimension of v_mfma_f32_32x32x2_f32 (two samples per
 // instruction), both operands come straight from global memory as coalesced 128-byte rows (dh1[b][n0 + i], act3[b][k0 + i]), no
@@ -727,7 +771,7 @@ int srlx_qnet_fuse_adam_rest(srlx_qnet_t *h, const float *const *d_grads, float 
 #define SRLX_STAMP(idx, stream) \
     if (h->stamp_buf) SRLX_TRY(srlx_debug_stamp(h->stamp_buf, (idx), (stream)))
 
-static int chain_prologue(srlx_qnet_t *h, hipStream_t st, int part = 3) {  // part 1: the fork point on `st`; part 2: the side branch's first launches; 3: both
+static int chain_prologue(srlx_qnet_t *h, hipStream_t st, int part = 3, bool with_uvfa = false, int uvfa_B = 0, i64 uvfa_ss = 1) {  // part 1: the fork point on `st`; part 2: the side branch's first launches; 3: both
     hipStream_t sd = h->side;
     if (part & 1) SRLX_HIP(hipEventRecord(h->ev_fork, st));
     if (!(part & 2)) return SRLX_OK;
@@ -741,6 +785,10 @@ static int chain_prologue(srlx_qnet_t *h, hipStream_t st, int part = 3) {  // pa
     if (h->sink_per) SRLX_TRY(srlx_per_update(h->sink_per, h->sink_n, h->sink_idx, h->sink_prio, h->sink_kind, 1, sk));
     if (h->sink_per && h->sink_done) SRLX_HIP(hipEventRecord(h->sink_done, sk));
     SRLX_STAMP(21, sd);
+    if (h->uvfa.X > 0 && h->uvfa.g_wx && with_uvfa) {  // the UVFA columns' gradient needs dh1 only: beside the data-gradient chain
+        const int N1 = 2 * h->hidden;
+        hipLaunchKernelGGL(k_uvfa_wgrad, dim3((unsigned)((h->uvfa.X * N1 + 255) / 256)), dim3(256), 0, sd, uvfa_B, uvfa_ss, N1, h->uvfa.X, srlx_uvfa_args(h), h->dh1, h->uvfa.g_wx);
+    }
     const int C2 = 2 * h->F1;
     // the transposed filters of the two data-gradient GEMMs depend on the weights only: the fused forward of a training handle has
     // built them already (k_pack_filters); otherwise they are built here, ahead of the chain that needs them
@@ -882,7 +930,10 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
 
     // head + second layers -> dh1 (masked by the first layer's ReLU), bias gradient of the first layer
     const bool mfma_dgrad = B <= 32;  // the batch fits one 32-row MFMA tile
-    {
+    if (h->head_mode == 1) {  // the handle ends behind the first dense layer: d_grad_q is the gradient at its first out_cols post-ReLU units
+        SRLX_REQUIRE(!td && !h->ln_w, "qnet_backward_u8: a hidden-layer handle takes the gradient of its output (no TD prologue, no LayerNorm inside)");
+        hipLaunchKernelGGL(k_hidden_bwd, dim3((unsigned)((N1 + 63) / 64)), dim3(256), 0, st, B, ss, N1, h->out_cols, d_grad_q, h->h1, h->dh1, mfma_dgrad ? h->dh1t : nullptr, g_bf);
+    } else {
         const dim3 hg((unsigned)((h->hidden + 63) / 64));
         const size_t hl = (size_t)(B + B * A + (3 + (A <= 8 ? 8 : (A <= 16 ? 16 : 32))) * 256 + (td ? B * A + 2 + 512 : 0)) * sizeof(float);
         float *dh1t = mfma_dgrad ? h->dh1t : nullptr;
@@ -905,11 +956,13 @@ static int backward_impl(srlx_qnet_t *h, int64_t batch, int64_t sample_stride, c
     // one hardware queue from the head kernel to the packing launch instead of hopping queues at the fork (-1.2 % per single-GPU lock-step, -4 % per period of a
     // learner rank, update alone 0.313 -> 0.273 ms; profiles/r5_ab_ingest_order.txt)
     const bool main_first = h->main_first;
-    SRLX_TRY(chain_prologue(h, st, main_first && mfma_dgrad ? 1 : 3));
+    const bool uvfa = h->uvfa.X > 0;
+    SRLX_REQUIRE(!uvfa || h->uvfa.g_wx, "qnet_backward_u8: a UVFA network needs a gradient buffer for its columns (srlx_qnet_fuse_adam_uvfa)");
+    SRLX_TRY(chain_prologue(h, st, main_first && mfma_dgrad ? 1 : 3, uvfa, B, ss));
     // ---- data-gradient chain (caller's stream)
     if (mfma_dgrad) {
         hipLaunchKernelGGL(k_fc1_dgrad_mfma, dim3((unsigned)(K / 32)), dim3(256), 0, st, B, ss, N1, K, h->dh1t, h->wf, h->act3, h->dact3);
-        if (main_first) SRLX_TRY(chain_prologue(h, st, 2));
+        if (main_first) SRLX_TRY(chain_prologue(h, st, 2, uvfa, B, ss));
     } else {
         hipLaunchKernelGGL(k_fc1_dgrad<64>, dim3((unsigned)((K + 255) / 256), kFcSplits), dim3(256), 0, st, B, N1, K, h->dh1, h->wf, h->fc_part);
         hipLaunchKernelGGL(k_fc1_dgrad_reduce, dim3((unsigned)(((i64)B * K + 255) / 256)), dim3(256), 0, st, B, ss, K, h->fc_part, h->act3, h->dact3);
@@ -959,6 +1012,7 @@ int srlx_qnet_backward_td_u8(srlx_qnet_t *h, int64_t batch, int n_step, const ui
     srlx::TdArgs td{batch, n_step, A, d_q_on_all + A, d_q_tg_next, d_q_on_all, d_actions, d_rewards, d_terminated, d_invalid_next, d_weights, discount, retrace_h,
                           enable_double_dqn, enable_rescale, d_target, d_loss, d_grad_q0, d_priorities, row, row};
     srlx::td_fill_discounts(td);
+    td.disc_ps = h->td_disc_ps, td.td_signed = h->td_signed;  // (srlx_qnet_set_td_extras; NULL: Rainbow's scalar discount, priorities only)
     return backward_impl(h, batch, n_step + 1, d_frame_base, d_frame_off, nullptr, &td, g, stream);
 }
 

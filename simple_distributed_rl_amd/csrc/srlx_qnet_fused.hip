@@ -59,17 +59,18 @@ constexpr int kPackFloats = kW1 + kW2 + kW3 + kW1B + kW2B + kW3B;
 // its backward, so two launches leave the learner's critical path.
 // `out2` (optional): a second copy of the packed buffer -- an actor handle's published set (srlx_qnet_publish) -- and `sm`: the network's small vectors
 // (biases, the head's second layers) copied element by element into that set's block by the threads behind the packing ranges.
+constexpr int kSmallVecs = 9;  // b1 b2 b3 bf v2w v2b a2w a2b + the UVFA columns of an Agent57(_light) Q-network (round 6; length 0 elsewhere)
 struct SmallCopy {
-    const float *src[8];
-    int off[9];  // destination offsets (floats); off[8] = total
-    int len[8];  // elements of each vector (the padding behind it is never read or written)
+    const float *src[kSmallVecs];
+    int off[kSmallVecs + 1];  // destination offsets (floats); off[kSmallVecs] = total
+    int len[kSmallVecs];  // elements of each vector (the padding behind it is never read or written)
     float *dst;  // NULL: nothing to copy
     int first;   // first thread index of the copy range
     long long *bump;  // int64 device counter advanced by the launch (NULL: none): the update's step count, whose readers all ran in earlier launches
     // srlx_qnet_fuse_adam_rest: the optimiser step of vector k right here (g[k] != NULL), in place, before it is copied -- every element has exactly one thread.
     // The step count comes from `snap` (copied by an earlier launch of the update): thread 0 of this launch advances the count itself.
-    const float *g[8];
-    float *m[8], *v[8];
+    const float *g[kSmallVecs];
+    float *m[kSmallVecs], *v[kSmallVecs];
     double lr, beta1, beta2, eps;
     const long long *snap;
 };
@@ -81,17 +82,17 @@ __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ 
     if (sm.bump && q == 0) *sm.bump += 1;
     if (sm.first > 0 && q >= sm.first) {
         const int x = q - sm.first;
-        if (x >= sm.off[8]) return;
+        if (x >= sm.off[kSmallVecs]) return;
         int v = 0;
 #pragma unroll
-        for (int k = 1; k < 8; k++) v += x >= sm.off[k] ? 1 : 0;
+        for (int k = 1; k < kSmallVecs; k++) v += x >= sm.off[k] ? 1 : 0;
         const int j = x - sm.off[v];
         if (j >= sm.len[v]) return;
         // (selects over the by-value tables: a lane-dependent index would send them to scratch memory)
         const float *src = sm.src[0], *gp = sm.g[0];
         float *mp = sm.m[0], *vp = sm.v[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++)
+        for (int k = 1; k < kSmallVecs; k++)
             if (v == k) src = sm.src[k], gp = sm.g[k], mp = sm.m[k], vp = sm.v[k];
         float pv = src[j];
         if (gp) {
@@ -739,17 +740,18 @@ int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const s
         L = &own_layout;
     }
     if (dst_set || adam) {
-        const float *v[8] = {b ? b[1] : src->b1, b ? b[3] : src->b2, b ? b[5] : src->b3, b ? b[7] : src->bf, b ? b[8] : src->v2w, b ? b[9] : src->v2b,
-                             b ? b[10] : src->a2w, b ? b[11] : src->a2b};
-        const int off[9] = {L->b1, L->b2, L->b3, L->bf, L->v2w, L->v2b, L->a2w, L->a2b, L->total};
-        const int len[8] = {src->F1, 2 * src->F1, 2 * src->F1, 2 * src->hidden, src->hidden, 1, src->A * src->hidden, src->A};
-        for (int k = 0; k < 8; k++) sm.src[k] = v[k], sm.len[k] = len[k];
-        for (int k = 0; k < 9; k++) sm.off[k] = off[k];
+        const float *v[kSmallVecs] = {b ? b[1] : src->b1, b ? b[3] : src->b2, b ? b[5] : src->b3, b ? b[7] : src->bf, b ? b[8] : src->v2w, b ? b[9] : src->v2b,
+                                      b ? b[10] : src->a2w, b ? b[11] : src->a2b, src->uvfa.wx_bound};
+        const int off[kSmallVecs + 1] = {L->b1, L->b2, L->b3, L->bf, L->v2w, L->v2b, L->a2w, L->a2b, L->wx, L->total};
+        const int len[kSmallVecs] = {src->F1, 2 * src->F1, 2 * src->F1, 2 * src->hidden, src->hidden, 1, src->A * src->hidden, src->A, src->uvfa.X * 2 * src->hidden};
+        for (int k = 0; k < kSmallVecs; k++) sm.src[k] = v[k], sm.len[k] = len[k];
+        for (int k = 0; k <= kSmallVecs; k++) sm.off[k] = off[k];
         sm.dst = dst_set ? dst_set->small : nullptr;
         sm.first = ((pack_threads + 255) / 256) * 256;
         pack_threads = sm.first + L->total;
         if (adam) {  // the convolution biases (vectors 0..2) took their step in k_reduce_parts; 3..7 = gradient list entries 7..11
             for (int k = 3; k < 8; k++) sm.g[k] = src->rest_g[k + 4], sm.m[k] = src->rest_m[k + 4], sm.v[k] = src->rest_v[k + 4], sm.src[k] = src->bound[k + 4];
+            if (src->uvfa.X > 0 && src->uvfa.m_wx) sm.g[8] = src->uvfa.g_wx, sm.m[8] = src->uvfa.m_wx, sm.v[8] = src->uvfa.v_wx;  // the UVFA columns' step (srlx_qnet_fuse_adam_uvfa)
             sm.lr = src->adam_lr, sm.beta1 = src->adam_b1, sm.beta2 = src->adam_b2, sm.eps = src->adam_eps;
             sm.snap = (const long long *)src->step_snap;
             src->rest_armed = false;

@@ -105,11 +105,43 @@ struct srlx_qnet {
         int32_t *actions;
         float *q_copy;
     } pol;
+    // ---- round 6: Agent57(_light)'s networks on this handle (srl/algorithms/agent57_light/model_torch.py:18-117) ----
+    // UVFA inputs of a Q-network (:35-64: previous extrinsic / intrinsic reward, one-hot previous action, one-hot actor, concatenated behind the image features): their
+    // columns of the first dense layer are kept apart as wx [X][2 hidden] (column-major: unit u of column c at c * 2 hidden + u) and enter the layer as rank-1 terms
+    // in the head kernel -- scalar * column for the rewards, one column gather for each one-hot -- instead of K columns of the GEMM; no concatenated input exists.
+    struct Uvfa {
+        const float *wx;                  // what the next forwards read: the bound tensor, or a selected actor set's copy
+        const float *wx_bound;            // BORROWED master (srlx_qnet_bind_uvfa)
+        int X, c_ext, c_int, c_act, n_act_in, c_actor, n_actor;  // columns; c_* = first column of the input or -1 (absent)
+        const float *r_ext, *r_int;       // per-row inputs of the next forwards / backward passes (srlx_qnet_set_uvfa_inputs; device, BORROWED)
+        const int32_t *action, *actor;
+        float *g_wx, *m_wx, *v_wx;        // gradient buffer and optimiser state (srlx_qnet_fuse_adam_uvfa): the step rides on the packing launch
+    } uvfa;
+    // per-sample discount and signed TD error for the fused TD prologue of srlx_qnet_backward_td_u8 (srlx_qnet_set_td_extras)
+    const float *td_disc_ps;
+    float *td_signed;
+    // head_mode 1 (srlx_qnet_set_head_mode): the handle ends behind the first dense layer -- q / grad_q of the forward / backward entry points are the post-ReLU
+    // hidden layer's first out_cols units [rows][out_cols] (the embedding and RND networks, model_torch.py:70-117); ln_w != NULL: a LayerNorm over all 2 hidden
+    // units follows in the forward (inference handles only)
+    int head_mode, out_cols;
+    const float *ln_w, *ln_b;
+    float ln_eps;
 };
+
+// what the head kernels need of srlx_qnet::Uvfa, by value
+struct srlx_uvfa_dev {
+    const float *wx, *r_ext, *r_int;
+    const int32_t *action, *actor;
+    int c_ext, c_int, c_act, c_actor, n_act_in, n_actor;
+};
+inline srlx_uvfa_dev srlx_uvfa_args(const srlx_qnet *h) {
+    const srlx_qnet::Uvfa &u = h->uvfa;
+    return srlx_uvfa_dev{u.wx, u.r_ext, u.r_int, u.action, u.actor, u.c_ext, u.c_int, u.c_act, u.c_actor, u.n_act_in, u.n_actor};
+}
 
 // offsets (floats) of the vectors inside ActorSet::small
 struct srlx_small_layout {
-    int b1, b2, b3, bf, v2w, v2b, a2w, a2b, total;
+    int b1, b2, b3, bf, v2w, v2b, a2w, a2b, wx, total;  // wx: the UVFA columns (round 6; empty without them)
 };
 inline srlx_small_layout srlx_small_offsets(const srlx_qnet *h) {
     auto pad = [](int n) { return (n + 3) & ~3; };
@@ -122,7 +154,8 @@ inline srlx_small_layout srlx_small_offsets(const srlx_qnet *h) {
     L.v2b = L.v2w + pad(h->hidden);
     L.a2w = L.v2b + 4;
     L.a2b = L.a2w + pad(h->A * h->hidden);
-    L.total = L.a2b + pad(h->A);
+    L.wx = L.a2b + pad(h->A);
+    L.total = L.wx + pad(h->uvfa.X * 2 * h->hidden);
     return L;
 }
 

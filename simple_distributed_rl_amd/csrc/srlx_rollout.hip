@@ -398,9 +398,10 @@ __global__ void __launch_bounds__(1024) k_rng_uniform_wg(u64 seed, i64 *counter,
 // ------------------------------------------------------------------------------------------
 // synthetic environment batch
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_synth_frames(StoreDev s, void *next_obs) {
+// `pos_arg` >= 0: the ring position as a launch argument (srlx_synth_env_step_at: a store whose device-resident position trails its commits); < 0: the device's
+__global__ void __launch_bounds__(256) k_synth_frames(StoreDev s, void *next_obs, i64 pos_arg) {
     const i64 fb = s.obs_dtype == SRLX_OBS_U8 ? s.F : s.F * 4;
-    const i64 p1 = s.pos[0] + 1;
+    const i64 p1 = (pos_arg >= 0 ? pos_arg : s.pos[0]) + 1;
     if (s.obs_dtype == SRLX_OBS_U8 && (fb & 15) == 0) {
         const i64 cpf = fb / 16, total = s.E * cpf;
         for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
@@ -426,10 +427,10 @@ __global__ void __launch_bounds__(256) k_synth_frames(StoreDev s, void *next_obs
     }
 }
 // frames AND scalars of one synthetic lock-step in one launch (the first ceil(E / 256) blocks also do the scalars)
-__device__ __forceinline__ void synth_scalars_one(const StoreDev &s, i64 e, i64 episode_len, float *rewards, u8 *terminated, u8 *done);
-__global__ void __launch_bounds__(256) k_synth_env(StoreDev s, i64 episode_len, void *next_obs, float *rewards, u8 *terminated, u8 *done) {
+__device__ __forceinline__ void synth_scalars_one(const StoreDev &s, i64 e, i64 episode_len, float *rewards, u8 *terminated, u8 *done, i64 pos_arg);
+__global__ void __launch_bounds__(256) k_synth_env(StoreDev s, i64 episode_len, void *next_obs, float *rewards, u8 *terminated, u8 *done, i64 pos_arg) {
     const i64 fb = s.F;  // uint8 frames of 16-byte multiples only (the launcher checks)
-    const i64 p1 = s.pos[0] + 1;
+    const i64 p1 = (pos_arg >= 0 ? pos_arg : s.pos[0]) + 1;
     const i64 cpf = fb / 16, total = s.E * cpf;
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
         const i64 e = t / cpf, c = t % cpf;
@@ -438,10 +439,10 @@ __global__ void __launch_bounds__(256) k_synth_env(StoreDev s, i64 episode_len, 
         reinterpret_cast<uint4 *>(next_obs)[t] = make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32));
     }
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < s.E) synth_scalars_one(s, e, episode_len, rewards, terminated, done);
+    if (e < s.E) synth_scalars_one(s, e, episode_len, rewards, terminated, done, pos_arg);
 }
-__device__ __forceinline__ void synth_scalars_one(const StoreDev &s, i64 e, i64 episode_len, float *rewards, u8 *terminated, u8 *done) {
-    const i64 p = s.pos[0];
+__device__ __forceinline__ void synth_scalars_one(const StoreDev &s, i64 e, i64 episode_len, float *rewards, u8 *terminated, u8 *done, i64 pos_arg) {
+    const i64 p = pos_arg >= 0 ? pos_arg : s.pos[0];
     if (s.needs_reset[e]) {
         rewards[e] = 0.f;
         terminated[e] = 0;
@@ -455,9 +456,9 @@ __device__ __forceinline__ void synth_scalars_one(const StoreDev &s, i64 e, i64 
     terminated[e] = d;
     done[e] = d;
 }
-__global__ void __launch_bounds__(256) k_synth_scalars(StoreDev s, i64 episode_len, float *rewards, u8 *terminated, u8 *done) {
+__global__ void __launch_bounds__(256) k_synth_scalars(StoreDev s, i64 episode_len, float *rewards, u8 *terminated, u8 *done, i64 pos_arg) {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < s.E) synth_scalars_one(s, e, episode_len, rewards, terminated, done);
+    if (e < s.E) synth_scalars_one(s, e, episode_len, rewards, terminated, done, pos_arg);
 }
 
 }  // namespace
@@ -823,7 +824,13 @@ int srlx_rng_permutation(uint64_t seed, int64_t *d_counter, int64_t n, int64_t *
 
 int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, float *d_rewards, uint8_t *d_terminated,
                         uint8_t *d_done, void *stream) {
+    return srlx_synth_env_step_at(h, -1, episode_len, d_next_obs, d_rewards, d_terminated, d_done, stream);
+}
+
+int srlx_synth_env_step_at(srlx_store_t *h, int64_t position, int64_t episode_len, void *d_next_obs, float *d_rewards, uint8_t *d_terminated, uint8_t *d_done,
+                           void *stream) {
     SRLX_REQUIRE(h && d_next_obs && d_rewards && d_terminated && d_done && episode_len > 0, "synth_env_step: bad argument");
+    const i64 pos_arg = position;
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = pick(h, stream);
     const StoreDev &d = h->d;
@@ -832,11 +839,11 @@ int srlx_synth_env_step(srlx_store_t *h, int64_t episode_len, void *d_next_obs, 
         int grid = grid_for(d.E * (fb / 16 + 1), 2048);
         const int need = (int)((d.E + 255) / 256);
         if (grid < need) grid = need;
-        hipLaunchKernelGGL(k_synth_env, dim3((unsigned)grid), dim3(256), 0, st, d, (i64)episode_len, d_next_obs, d_rewards, d_terminated, d_done);
+        hipLaunchKernelGGL(k_synth_env, dim3((unsigned)grid), dim3(256), 0, st, d, (i64)episode_len, d_next_obs, d_rewards, d_terminated, d_done, pos_arg);
     } else {
-        hipLaunchKernelGGL(k_synth_frames, dim3(grid_for(d.E * (fb / 16 + 1))), dim3(256), 0, st, d, d_next_obs);
+        hipLaunchKernelGGL(k_synth_frames, dim3(grid_for(d.E * (fb / 16 + 1))), dim3(256), 0, st, d, d_next_obs, pos_arg);
         hipLaunchKernelGGL(k_synth_scalars, dim3((unsigned)((d.E + 255) / 256)), dim3(256), 0, st, d, (i64)episode_len, d_rewards,
-                           d_terminated, d_done);
+                           d_terminated, d_done, pos_arg);
     }
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

@@ -57,6 +57,10 @@ struct TdArgs {
     // multi_discounts (rainbow.py:182): float32(discount ** m), evaluated ON THE HOST by td_fill_discounts -- the C library's pow(), which is what Python's `**`
     // calls -- instead of three device pow() calls per item in the head kernel's prologue (round 5: ~1000 instructions each on the update's critical chain)
     float dm[kTdMaxStep];
+    // round 6 (Agent57_light's 1-step targets, agent57_light.py:218-268 + model_torch.py:384-443; srlx_qnet_set_td_extras): a per-sample discount (the sampled
+    // actor's gamma, float32 [B]; NULL: `discount`) and the SIGNED TD error target - q (NULL: not stored; the priorities are mixed from both networks' errors)
+    const float *disc_ps;
+    float *td_signed;
 };
 
 inline void td_fill_discounts(TdArgs &a) {
@@ -67,9 +71,9 @@ inline void td_fill_discounts(TdArgs &a) {
 // `grad_out` [B][A] may be LDS; `write_global`: also store target, priorities (and grad_q0 when grad_out is elsewhere).
 __device__ __forceinline__ double td_rows(const TdArgs &a, int t, int T, float *grad_out, bool write_global) {
     const int n = a.n, A = a.A;
-    const float disc_f = (float)a.discount;
     double loss_acc = 0.0;
     for (i64 b = t; b < a.B; b += T) {
+        const float disc_f = a.disc_ps ? a.disc_ps[b] : (float)a.discount;
         const float *qon = a.q_on_next + b * a.on_next_stride;
         const float *qtg = a.q_tg_next + b * n * A;
         const int32_t *act = a.actions + b * n;
@@ -117,6 +121,7 @@ __device__ __forceinline__ double td_rows(const TdArgs &a, int t, int T, float *
             if (grad_out != a.grad_q0)
                 for (int k = 0; k < A; k++) a.grad_q0[b * A + k] = k == a0 ? gsel : 0.f;
             a.priorities[b] = fabsf(target - q0);
+            if (a.td_signed) a.td_signed[b] = target - q0;  // model_torch.py:442
         }
     }
     return loss_acc;

@@ -26,12 +26,18 @@ _DUELING = {"average": 0, "max": 1, "": 2}
 
 
 class EngineQNet(nn.Module):
-    def __init__(self, n_actions: int, hw=(84, 84), window: int = 4, hidden: int = 512, filters: int = 32, dueling_type: str = "average", noisy: bool = False):
+    def __init__(self, n_actions: int, hw=(84, 84), window: int = 4, hidden: int = 512, filters: int = 32, dueling_type: str = "average", noisy: bool = False,
+                 uvfa_cols: int = 0):
         """noisy=True: the dense layers are NoisyLinear (srl/rl/torch_/modules/noisy_linear.py:8-52): `fc1`/`v2`/`a2` hold the mu
-        tensors, `fc1_sigma_w` ... `a2_sigma_b` the sigmas, in the same (fused, NHWC-column) layouts."""
+        tensors, `fc1_sigma_w` ... `a2_sigma_b` the sigmas, in the same (fused, NHWC-column) layouts.
+        uvfa_cols = X > 0 (round 6): Agent57(_light)'s Q-network (agent57_light/model_torch.py:18-64) -- X further input columns behind the image features (previous
+        rewards, one-hot previous action, one-hot actor).  They are kept apart as `fcx` [X][2*hidden] (column-major: what srlx_qnet_bind_uvfa reads); such a
+        network is initialised by `load_reference_state_dict` (the reference's He-normal scale depends on the fan-in of the 7744 + X wide layer)."""
         super().__init__()
         self.hw, self.window, self.hidden, self.filters, self.n_actions, self.dueling_type = tuple(hw), window, hidden, filters, n_actions, dueling_type
         self.noisy = bool(noisy)
+        self.uvfa_cols = int(uvfa_cols)
+        assert not (self.noisy and self.uvfa_cols)
         Fi = filters
         self.conv1 = nn.Conv2d(window, Fi, 8, 4, padding=3, padding_mode="replicate")
         self.conv2 = nn.Conv2d(Fi, 2 * Fi, 4, 2, padding=2, padding_mode="replicate")
@@ -43,6 +49,8 @@ class EngineQNet(nn.Module):
         self.fc1 = nn.Linear(self.flat, 2 * hidden)
         self.v2 = nn.Linear(hidden, 1)
         self.a2 = nn.Linear(hidden, n_actions)
+        if self.uvfa_cols:
+            self.fcx = nn.Parameter(torch.zeros(self.uvfa_cols, 2 * hidden))
         if self.noisy:
             for name, lin in (("fc1", self.fc1), ("v2", self.v2), ("a2", self.a2)):
                 setattr(self, name + "_sigma_w", nn.Parameter(torch.zeros_like(lin.weight)))
@@ -53,7 +61,8 @@ class EngineQNet(nn.Module):
         self.weights_version = 0  # bumped by every state-dict load: caches derived from the weights (QNetInference's operand planes) compare it
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._bump_version())
         self.fix_formats()
-        self.load_reference_state_dict(atari_qnetwork(n_actions, hw, window, hidden, self.noisy, filters, dueling_type).state_dict())
+        if not self.uvfa_cols:
+            self.load_reference_state_dict(atari_qnetwork(n_actions, hw, window, hidden, self.noisy, filters, dueling_type).state_dict())
 
     def fix_formats(self):
         """conv2/conv3 weights in channels_last memory = [Cout][ky][kx][Cin], the K order of an NHWC implicit GEMM."""
@@ -66,7 +75,8 @@ class EngineQNet(nn.Module):
         self.fix_formats()
         return out
 
-    def forward(self, x, channels_first: bool = True):
+    def forward(self, x, channels_first: bool = True, extras: torch.Tensor = None):
+        """extras [B][uvfa_cols]: the dense UVFA inputs of a uvfa network (test yardstick; the kernels take them as scalars / indices)."""
         if not channels_first:
             x = x.permute(0, 3, 1, 2)
         x = F.relu(self.conv1(x))
@@ -84,7 +94,10 @@ class EngineQNet(nn.Module):
             v = lin("v2", h[:, : self.hidden])
             adv = lin("a2", h[:, self.hidden :])
         else:
-            h = F.relu(self.fc1(x))
+            pre = self.fc1(x)
+            if self.uvfa_cols:
+                pre = pre + extras @ self.fcx
+            h = F.relu(pre)
             v = self.v2(h[:, : self.hidden])
             adv = self.a2(h[:, self.hidden :])
         if self.dueling_type == "average":
@@ -98,14 +111,20 @@ class EngineQNet(nn.Module):
     _HEAD = "hidden_block.hidden_layers.0"
 
     def _fuse_fc1(self, v1, a1):
-        """[H, C*P] x 2 (columns c*P+p) -> [2H, P*C] (NHWC columns)"""
+        """[H, C*P (+ X)] x 2 (columns c*P+p, then the UVFA columns) -> [2H, P*C] (NHWC columns); the UVFA columns go to `fcx` (transposed)"""
         C, P, H = self.out_c, self.out_p, self.hidden
         w = torch.cat([v1, a1], dim=0)
-        return w.view(2 * H, C, P).permute(0, 2, 1).reshape(2 * H, P * C)
+        if self.uvfa_cols:
+            with torch.no_grad():
+                self.fcx.copy_(w[:, C * P :].t())
+            w = w[:, : C * P]
+        return w.reshape(2 * H, C, P).permute(0, 2, 1).reshape(2 * H, P * C)
 
     def _split_fc1(self, w):
         C, P, H = self.out_c, self.out_p, self.hidden
         w = w.detach().view(2 * H, P, C).permute(0, 2, 1).reshape(2 * H, C * P)
+        if self.uvfa_cols:
+            w = torch.cat([w, self.fcx.detach().t()], dim=1)
         return w[:H].clone(), w[H:].clone()
 
     def _bump_version(self):
@@ -177,12 +196,93 @@ class EngineQNet(nn.Module):
         return ps
 
 
+class EngineHiddenNet(nn.Module):
+    """DQN image block + ONE dense layer with ReLU, in the kernels' layouts -- the trunk of Agent57_light's embedding network (`emb_block`,
+    agent57_light/model_torch.py:76-78,96-97) and of its lifelong networks (`hidden_block`, :109-111); what follows (the embedding network's classifier, the
+    lifelong networks' LayerNorm) are `tail` tensors in the reference's own layouts (csrc/srlx_agent57.hip).  The dense layer is padded with zero rows to the
+    first-dense-layer GEMM's 128-unit tile (`units_padded`; the pad units have zero weight and bias, produce 0 and receive no gradient), and the handle
+    (QNetInference + srlx_qnet_set_head_mode) needs a dueling head's tensors to exist: four zero dummies."""
+
+    def __init__(self, units: int, hw=(84, 84), window: int = 4, filters: int = 32, tail_shapes=()):
+        super().__init__()
+        self.units = int(units)
+        self.units_padded = -(-self.units // 128) * 128
+        self.hw, self.window, self.filters = tuple(hw), window, filters
+        self.hidden, self.n_actions, self.dueling_type, self.noisy, self.uvfa_cols = self.units_padded // 2, 1, "average", False, 0
+        Fi = filters
+        self.conv1 = nn.Conv2d(window, Fi, 8, 4, padding=3, padding_mode="replicate")
+        self.conv2 = nn.Conv2d(Fi, 2 * Fi, 4, 2, padding=2, padding_mode="replicate")
+        self.conv3 = nn.Conv2d(2 * Fi, 2 * Fi, 3, 1, padding=1, padding_mode="replicate")
+        with torch.no_grad():
+            y = self.conv3(self.conv2(self.conv1(torch.zeros(1, window, hw[0], hw[1]))))
+        self.out_c, self.out_p = y.shape[1], y.shape[2] * y.shape[3]
+        self.flat = self.out_c * self.out_p
+        self.fc1 = nn.Linear(self.flat, self.units_padded)
+        self.v2 = nn.Linear(self.hidden, 1)
+        self.a2 = nn.Linear(self.hidden, 1)
+        self.tail = nn.ParameterList([nn.Parameter(torch.zeros(sh)) for sh in tail_shapes])
+        with torch.no_grad():
+            for p in (self.fc1.weight, self.fc1.bias, self.v2.weight, self.v2.bias, self.a2.weight, self.a2.bias):
+                p.zero_()
+        self.weights_version = 0
+        for conv in (self.conv2, self.conv3):
+            conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        for conv in (self.conv2, self.conv3):
+            conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+        return out
+
+    _CONV_KEYS = EngineQNet._CONV_KEYS
+
+    def load_reference(self, sd, dense_key: str, tail_keys=()):
+        """sd: the reference network's state_dict; dense_key e.g. "emb_block.hidden_layers.0"; tail_keys: the tail tensors' keys in `tail` order."""
+        self.weights_version += 1
+        C, P, U = self.out_c, self.out_p, self.units
+        with torch.no_grad():
+            for mine, ref in self._CONV_KEYS.items():
+                getattr(self, mine).weight.copy_(sd[ref + ".weight"])
+                getattr(self, mine).bias.copy_(sd[ref + ".bias"])
+            w = sd[dense_key + ".weight"].to(self.fc1.weight.device)
+            self.fc1.weight.zero_()
+            self.fc1.bias.zero_()
+            self.fc1.weight[:U].copy_(w.reshape(U, C, P).permute(0, 2, 1).reshape(U, P * C))  # channel-major columns -> NHWC
+            self.fc1.bias[:U].copy_(sd[dense_key + ".bias"])
+            for t, k in zip(self.tail, tail_keys):
+                t.copy_(sd[k])
+        return self
+
+    def reference_tensors(self, dense_key: str, tail_keys=()):
+        C, P, U = self.out_c, self.out_p, self.units
+        sd = {}
+        for mine, ref in self._CONV_KEYS.items():
+            sd[ref + ".weight"] = getattr(self, mine).weight.detach().contiguous().clone()
+            sd[ref + ".bias"] = getattr(self, mine).bias.detach().clone()
+        sd[dense_key + ".weight"] = self.fc1.weight.detach()[:U].reshape(U, P, C).permute(0, 2, 1).reshape(U, C * P).clone()
+        sd[dense_key + ".bias"] = self.fc1.bias.detach()[:U].clone()
+        for t, k in zip(self.tail, tail_keys):
+            sd[k] = t.detach().clone()
+        return sd
+
+    def kernel_parameters(self):
+        n = self
+        return [n.conv1.weight, n.conv1.bias, n.conv2.weight, n.conv2.bias, n.conv3.weight, n.conv3.bias, n.fc1.weight, n.fc1.bias, n.v2.weight, n.v2.bias,
+                n.a2.weight, n.a2.bias]
+
+    def forward(self, x):
+        """float32 channels-first stack -> the dense layer's post-ReLU units [B][units] (test yardstick)."""
+        x = F.relu(self.conv3(F.relu(self.conv2(F.relu(self.conv1(x))))))
+        return F.relu(self.fc1(x.permute(0, 2, 3, 1).flatten(1)))[:, : self.units]
+
+
 class QNetInference:
     """Matrix-core forward over the live parameters of an EngineQNet (zero copy)."""
 
-    def __init__(self, net: EngineQNet, max_batch: int, device: int = 0, noise_seed: int = 0):
+    def __init__(self, net: EngineQNet, max_batch: int, device: int = 0, noise_seed: int = 0, uvfa_layout=None):
         self.lib = N.lib()
         self.net = net
+        self._uvfa_layout = uvfa_layout
         self.noise_seed = int(noise_seed)
         self.window, self.n_actions = net.window, net.n_actions
         self.max_batch = int(max_batch)
@@ -219,9 +319,32 @@ class QNetInference:
             sig = (N.c_p * 6)(*[p.data_ptr() for p in params[12:]])
             N.check(self.lib.srlx_qnet_bind_noisy(self.h, ctypes.cast(sig, N.c_p), self.noise_seed))
         self._bound = [p.data_ptr() for p in params]
+        if getattr(n, "uvfa_cols", 0):
+            assert self._uvfa_layout is not None, "a UVFA network: QNetInference(..., uvfa_layout=(col_ext, col_int, col_action, n_action_in, col_actor, n_actor))"
+            ce, ci, ca, na, ck, nk = self._uvfa_layout
+            N.check(self.lib.srlx_qnet_bind_uvfa(self.h, N.tptr(n.fcx), n.uvfa_cols, ce, ci, ca, na, ck, nk))
 
     def _params(self):
-        return self.net.kernel_parameters()
+        ps = list(self.net.kernel_parameters())
+        if getattr(self.net, "uvfa_cols", 0):
+            ps.append(self.net.fcx)
+        return ps
+
+    # ---- round 6: Agent57(_light)'s networks (srlx.h: srlx_qnet_bind_uvfa ..) -------------------------------------------------------------------------------
+    def set_uvfa_inputs(self, r_ext, r_int, action, actor):
+        """Per-row UVFA inputs of the next passes: float32 rewards, int32 indices (device tensors the handle keeps reading; None where the input is absent)."""
+        self._uvfa_in = (r_ext, r_int, action, actor)
+        for t, dt in zip(self._uvfa_in, (torch.float32, torch.float32, torch.int32, torch.int32)):
+            assert t is None or (t.dtype == dt and t.is_contiguous())
+        N.check(self.lib.srlx_qnet_set_uvfa_inputs(self.h, N.tptr(r_ext), N.tptr(r_int), N.tptr(action), N.tptr(actor)))
+
+    def set_td_extras(self, discount_per_sample, td_signed):
+        self._td_extras = (discount_per_sample, td_signed)
+        N.check(self.lib.srlx_qnet_set_td_extras(self.h, N.tptr(discount_per_sample), N.tptr(td_signed)))
+
+    def set_head_mode(self, mode: int, out_cols: int = 0, ln_w=None, ln_b=None, ln_eps: float = 1e-5):
+        self._ln = (ln_w, ln_b)
+        N.check(self.lib.srlx_qnet_set_head_mode(self.h, int(mode), int(out_cols), N.tptr(ln_w), N.tptr(ln_b), float(ln_eps)))
 
     def grad_params(self):
         """The 12 parameters in the order of the gradient list handed to the backward entry points."""
@@ -235,6 +358,8 @@ class QNetInference:
             p.grad = torch.zeros_like(p)  # preserve_format: conv2/conv3 stay channels_last
         self._grads = [p.grad for p in self._params()]
         self._grad_arr = (N.c_p * 12)(*[g.data_ptr() for g in self._grads[:12]])
+        if getattr(self.net, "uvfa_cols", 0):  # the columns' gradient buffer (their optimiser step: DeviceAdam.fuse_rest)
+            N.check(self.lib.srlx_qnet_fuse_adam_uvfa(self.h, N.tptr(self.net.fcx.grad), None, None))
         if self.net.noisy:
             self._sig_grad_arr = (N.c_p * 6)(*[g.data_ptr() for g in self._grads[12:]])
             N.check(self.lib.srlx_qnet_bind_noisy_grads(self.h, ctypes.cast(self._sig_grad_arr, N.c_p)))
@@ -259,7 +384,7 @@ class QNetInference:
         """Parameter gradients of sum(q * grad_q) for the samples at rows 0, stride, 2*stride, ... of the last forward_u8
         (for a noisy net: of the draw the dense layers of those rows were last evaluated under; sigma gradients included)."""
         B = grad_q.shape[0]
-        assert grad_q.is_contiguous() and grad_q.shape[1] == self.n_actions
+        assert grad_q.is_contiguous() and (hasattr(self.net, "units") or grad_q.shape[1] == self.n_actions)  # (a hidden-layer handle takes d loss / d its output)
         N.check(self.lib.srlx_qnet_backward_u8(self.h, B, int(sample_stride), N.c_p(frame_base_ptr), N.tptr(frame_off), N.tptr(grad_q),
                                                ctypes.cast(self._grad_arr, N.c_p), N.torch_stream_ptr()))
 
@@ -582,6 +707,9 @@ class DeviceAdam:
         self._rest_tables = ((N.c_p * 12)(*[self.params[i].grad.data_ptr() for i in pos]), (N.c_p * 12)(*[self.exp_avg[i].data_ptr() for i in pos]),
                              (N.c_p * 12)(*[self.exp_avg_sq[i].data_ptr() for i in pos]))
         N.check(self.lib.srlx_qnet_fuse_adam_rest(inf.h, *[ctypes.cast(t, N.c_p) for t in self._rest_tables]))
+        if getattr(inf.net, "uvfa_cols", 0):  # the UVFA columns step in the packing launch too
+            k = next(i for i, q in enumerate(self.params) if q is inf.net.fcx)
+            N.check(self.lib.srlx_qnet_fuse_adam_uvfa(inf.h, N.tptr(inf.net.fcx.grad), N.tptr(self.exp_avg[k]), N.tptr(self.exp_avg_sq[k])))
         self._rest = True
 
     def step(self, steps_taken_dev: torch.Tensor):

@@ -84,9 +84,12 @@ class SyntheticAtariVecEnv:
 
     def step(self, actions: torch.Tensor):
         r = self.replay
+        # a ring whose tree add lags its commit keeps the device-resident position as the LEARNER's view (it moves with the add, on the learner's stream): the
+        # environments belong to the actors' side and take the actors' position -- the host's count of commits -- as a launch argument
+        pos = r._steps_committed if r.lagged else -1
         N.check(
-            r.lib.srlx_synth_env_step(
-                r.h_store, self.episode_len, N.tptr(self.next_obs), N.tptr(self.rewards), N.tptr(self.terminated), N.tptr(self.done), N.torch_stream_ptr()
+            r.lib.srlx_synth_env_step_at(
+                r.h_store, pos, self.episode_len, N.tptr(self.next_obs), N.tptr(self.rewards), N.tptr(self.terminated), N.tptr(self.done), N.torch_stream_ptr()
             )
         )
         return self.next_obs, self.rewards, self.terminated, self.done

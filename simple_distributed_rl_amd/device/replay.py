@@ -246,7 +246,9 @@ class DeviceReplay:
     def length(self) -> int:
         """Items in the tree.  Counted from committed lock-steps (E adds each) rather than the library's
         host mirror, so it stays exact when commits are replayed from a HIP graph."""
-        return min(self.capacity, self._steps_committed * self.E)
+        # (lagged: the tree -- what a draw sees -- trails the commits by the one pending add; the warm-up gate must not open on leaves that are not there yet)
+        pending = 1 if (self.lagged and self._pending_add is not None) else 0
+        return min(self.capacity, (self._steps_committed - pending) * self.E)
 
     def is_warmup_needed(self) -> bool:
         return self.length() < self.warmup_size

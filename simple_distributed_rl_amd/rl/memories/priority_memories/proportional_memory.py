@@ -13,6 +13,13 @@ priorities.  Random numbers: the reference calls `random.random()` once per desc
 (:147); this class draws the same stream from Python's `random` and leaves the generator in
 exactly the state the reference would (rejected draws included), so a seeded run interleaves
 with other `random` users identically.
+
+Round 6 (the seam at the speed of what it replaces; reference loop: tests/quick/rl/memories/speedtest.py:15-58): `add` only queues -- the tree is observed by
+`sample / update / backup / restore / max_priority` alone, where the queue is flushed as ONE `srlx_per_add(n)` (consecutive adds of one priority kind; `add` does
+not move `max_priority` in the reference, proportional_memory.py:120-129, so a queued `priority=None` add resolves to the same value as an immediate one: the
+class mirrors `max_priority` on the host when it transforms priorities itself); `update` copies its arguments into a device-visible pinned slot and returns
+without synchronising; `sample` reads its uniforms from and writes its results to such a slot (one synchronisation, no copy commands) -- `on_device = 2` of
+include/srlx.h.
 """
 import ctypes
 import random
@@ -67,6 +74,9 @@ class ProportionalMemory(IPriorityMemory):
         self._h = h
         self.data: List[Any] = [None] * self.capacity
         self._write = 0
+        self._queue: List[float] = []  # values of queued adds (one priority kind per run)
+        self._queue_kind = None
+        self._max_host = 1.0  # mirror of max_priority (exact while host_transform: every value that can raise it passes through `update` here)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -77,30 +87,53 @@ class ProportionalMemory(IPriorityMemory):
     # ---- IPriorityMemory -----------------------------------------------------------------
     def clear(self) -> None:
         with self._lock:
+            self._queue, self._queue_kind = [], None
             N.check(self._lib.srlx_per_clear(self._h, None))
             self.data = [None] * self.capacity
             self._write = 0
+            self._max_host = 1.0
 
     def length(self) -> int:
-        return int(self._lib.srlx_per_length(self._h))
+        return min(self.capacity, int(self._lib.srlx_per_length(self._h)) + len(self._queue))
+
+    def _flush(self) -> None:
+        """The queued adds as ONE launch (call with the lock held)."""
+        q, kind = self._queue, self._queue_kind
+        if not q:
+            return
+        self._queue, self._queue_kind = [], None
+        for i in range(0, len(q), self.capacity):  # (srlx_per_add takes at most `capacity` items per call)
+            part = q[i : i + self.capacity]
+            if kind == N.PRIO_NONE:
+                N.check(self._lib.srlx_per_add(self._h, len(part), None, N.PRIO_NONE, 0, None))
+            else:
+                v = np.asarray(part, np.float64)
+                N.check(self._lib.srlx_per_add(self._h, len(part), N.np_ptr(v), kind, 2, None))
 
     def add(self, batch: Any, priority: Optional[float] = None, _restore_skip: bool = False) -> None:
         with self._lock:
             self.data[self._write] = batch
             self._write = (self._write + 1) % self.capacity
             if priority is None:
-                N.check(self._lib.srlx_per_add(self._h, 1, None, N.PRIO_NONE, 0, None))
-                return
-            priority = float(priority)  # see oracle/gen_golden.py trace (4): numpy scalars are widened
-            if _restore_skip:
-                kind = N.PRIO_RAW
-            elif self.host_transform:
-                priority = (abs(priority) + self.epsilon) ** self.alpha  # proportional_memory.py:124
-                kind = N.PRIO_RAW
+                if self.host_transform:  # max_priority is mirrored here: the add is a plain value
+                    kind, priority = N.PRIO_RAW, self._max_host
+                else:
+                    kind, priority = N.PRIO_NONE, 0.0
             else:
-                kind = N.PRIO_F64
-            v = N.c_f64(priority)
-            N.check(self._lib.srlx_per_add(self._h, 1, ctypes.byref(v), kind, 0, None))
+                priority = float(priority)  # see oracle/gen_golden.py trace (4): numpy scalars are widened
+                if _restore_skip:
+                    kind = N.PRIO_RAW
+                elif self.host_transform:
+                    priority = (abs(priority) + self.epsilon) ** self.alpha  # proportional_memory.py:124
+                    kind = N.PRIO_RAW
+                else:
+                    kind = N.PRIO_F64
+            if self._queue and kind != self._queue_kind:
+                self._flush()
+            self._queue_kind = kind
+            self._queue.append(priority)
+            if len(self._queue) >= 2048:  # (a pinned slot holds 2048 float64 values)
+                self._flush()
 
     def sample(self, batch_size: int, step: int):
         batch_size = int(batch_size)
@@ -108,6 +141,7 @@ class ProportionalMemory(IPriorityMemory):
         w = np.empty(batch_size, np.float64)
         used = N.c_i64(0)
         with self._lock:
+            self._flush()
             state = random.getstate()
             m = batch_size if self.has_duplicate else 4 * batch_size
             cap = 8192 if not self.has_duplicate else 9999 * batch_size  # without duplicates one call walks at most 8192 uniforms
@@ -116,7 +150,7 @@ class ProportionalMemory(IPriorityMemory):
                 m = min(m, cap)
                 u = np.fromiter((random.random() for _ in range(m)), np.float64, m)
                 st = self._lib.srlx_per_sample(
-                    self._h, batch_size, int(step), None, N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), 0, None
+                    self._h, batch_size, int(step), None, N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), 2, None
                 )
                 if st == N.ERR_UNIFORMS_EXHAUSTED and m < cap:  # rejected draws ate the uniforms: again with more
                     random.setstate(state)
@@ -151,6 +185,9 @@ class ProportionalMemory(IPriorityMemory):
         if self.host_transform:
             pr = np.ascontiguousarray((np.abs(pr) + self.epsilon) ** self.alpha, dtype=np.float64)  # :172
             kind = N.PRIO_RAW
+            mx = float(pr[:n].max())  # :176-177 (the device raises its own copy the same way)
+            if self._max_host < mx:
+                self._max_host = mx
         elif pr.dtype == np.float32:
             pr = np.ascontiguousarray(pr)
             kind = N.PRIO_F32
@@ -160,11 +197,13 @@ class ProportionalMemory(IPriorityMemory):
         if pr.shape[0] < n:
             raise IndexError("priorities shorter than indices")
         with self._lock:
-            N.check(self._lib.srlx_per_update(self._h, n, N.np_ptr(idx), N.np_ptr(pr), kind, 0, None))
+            self._flush()
+            N.check(self._lib.srlx_per_update(self._h, n, N.np_ptr(idx), N.np_ptr(pr), kind, 2, None))  # asynchronous: ordered before every later call
 
     def backup(self):
         """Same list layout as proportional_memory.py:179-187."""
         with self._lock:
+            self._flush()
             mp, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
             tree = np.empty(2 * self.capacity - 1, np.float64)
             N.check(self._lib.srlx_per_backup(self._h, ctypes.byref(mp), ctypes.byref(size), ctypes.byref(write), N.np_ptr(tree)))
@@ -172,7 +211,9 @@ class ProportionalMemory(IPriorityMemory):
 
     def restore(self, data) -> None:
         with self._lock:
+            self._queue, self._queue_kind = [], None  # (restore replaces the tree: :189-205)
             if self.capacity == data[0]:  # :190-194
+                self._max_host = float(data[1])
                 tree = np.ascontiguousarray(data[4], dtype=np.float64)
                 N.check(self._lib.srlx_per_restore(self._h, float(data[1]), int(data[2]), int(data[3]), N.np_ptr(tree)))
                 self.data = list(data[5][:])
@@ -181,6 +222,7 @@ class ProportionalMemory(IPriorityMemory):
                 old_cap, old_size = int(data[0]), int(data[2])
                 tree = np.ascontiguousarray(data[4], dtype=np.float64)
                 N.check(self._lib.srlx_per_restore_resized(self._h, old_cap, old_size, N.np_ptr(tree)))
+                self._max_host = 1.0  # (clear() of :196; the re-adds use _restore_skip and leave it alone)
                 self.data = [None] * self.capacity
                 self._write = 0
                 for i in range(old_size):
@@ -190,6 +232,8 @@ class ProportionalMemory(IPriorityMemory):
     # ---- extras (not in the reference interface) --------------------------------------------
     @property
     def max_priority(self) -> float:
+        with self._lock:
+            self._flush()
         mp, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
         N.check(self._lib.srlx_per_backup(self._h, ctypes.byref(mp), ctypes.byref(size), ctypes.byref(write), None))
         return mp.value

@@ -432,3 +432,102 @@ def test_lagged_add_tree_order_against_the_oracle(actor_stream):
         assert (tree == o.tree()).all() and mp_.value == o.max_priority and write.value == o.write and st["size"] == min(rp.capacity, rp._steps_committed * 512)
     finally:
         eng.close()
+
+
+def test_full_size_engine_tree_order_against_the_oracle():
+    """BASELINE.json configs[2] at its full size -- E = 1024 environments, 1 000 448 PER leaves (977 ring slots), batch 32, n = 3 -- on the shipped lock-step
+    (`bench.py`'s engine: fast, lagged add, actors on a low-priority stream, lazily captured update graphs): after `prefill()` the C oracle takes over the device
+    tree (its fill is what tests/test_per_gpu.py checks at this size), then 20 lock-steps are replayed on it in the order the tree must have seen -- draw (keyed
+    uniforms), 1024 adds at max_priority / 0, write-back of the priorities the update produced: every drawn index, the uniform consumption and the final tree
+    (2 000 895 nodes), max_priority and write position are bit-equal."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ctypes
+
+    import numpy as np
+
+    import hot_path_oracle as H
+    from oracle_bindings import ADD_RAW, OraclePER
+    from simple_distributed_rl_amd import _native as N
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+
+    cfg = RainbowDeviceConfig()
+    assert cfg.n_envs == 1024 and cfg.memory_capacity == 1_000_000 and cfg.batch_size == 32 and cfg.multisteps == 3
+    eng = RainbowEngine(cfg, 0, episode_len=200, overlap=True, fast=True, actor_stream="low")
+    try:
+        rp = eng.replay
+        assert eng.fast and rp.lagged and rp.capacity == 1024 * 977
+        eng.prefill()
+        eng.refresh_host_mirrors()
+        torch.cuda.synchronize()
+
+        def backup():
+            tree = np.empty(2 * rp.capacity - 1)
+            mp_, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+            N.check(rp.lib.srlx_per_backup(rp.h_per, ctypes.byref(mp_), ctypes.byref(size), ctypes.byref(write), N.np_ptr(tree)))
+            return mp_.value, size.value, write.value, tree
+
+        mp0, size0, write0, tree0 = backup()
+        assert size0 == rp.capacity
+        o = OraclePER(rp.capacity, cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, True, cfg.memory_epsilon)
+        o.set_state(mp0, size0, write0, tree0)
+        B, checked = cfg.batch_size, 0
+
+        def oracle_add(mask):
+            for m in mask.cpu().numpy():
+                o.add(None) if m else o.add(0.0, mode=ADD_RAW)
+
+        for T in range(20):
+            if T == 6:
+                eng.enable_lazy_capture()
+            trained0 = eng.train_count
+            assert int(rp.rng_counter.item()) == trained0
+            eng.step(learner_updates=1)
+            torch.cuda.synchronize()
+            assert eng.train_count == trained0 + 1
+            used, idx, w, _ = o.sample(B, trained0, H.rng_uniform(cfg.seed ^ 0x5EED, trained0, rp.u.numel()))
+            assert used == int(rp.used.item()) and used > 0
+            np.testing.assert_array_equal(rp.batch.indices.cpu().numpy(), idx)
+            np.testing.assert_allclose(rp.batch.weights.cpu().numpy(), np.asarray(w, np.float32), rtol=1e-6)
+            checked += 1
+            if T >= 1:  # the add of lock-step T - 1 ran inside this lock-step's update
+                oracle_add(rp.item_masks[(T - 1) & 1])
+            o.update(idx, eng.priorities.cpu().numpy())
+        eng.info()  # (launches the last commit's add)
+        torch.cuda.synchronize()
+        oracle_add(rp.item_masks[(rp._steps_committed - 1) & 1])
+        mp1, size1, write1, tree1 = backup()
+        assert checked == 20 and len(eng._learner_graphs) >= 2
+        assert (tree1 == o.tree()).all() and mp1 == o.max_priority and write1 == o.write and size1 == rp.capacity
+    finally:
+        eng.close()
+
+
+def test_synthetic_environments_do_not_depend_on_the_lagged_add(monkeypatch):
+    """The synthetic environments key frames, rewards and episode ends by the ring position.  With the lagged add the device-resident position is the learner's view
+    (it moves with the tree add, on the learner's stream), so the environments take the ACTORS' position as a launch argument (srlx_synth_env_step_at): rewards, episode
+    ends and frames of 40 lock-steps with updates equal those of the engine whose add follows the join (SRLX_LAGGED_ADD=0), whatever the streams do."""
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+
+    def run(lagged):
+        monkeypatch.setenv("SRLX_LAGGED_ADD", "1" if lagged else "0")
+        cfg = RainbowDeviceConfig(n_envs=512, batch_size=32, memory_capacity=512 * 9, memory_warmup_size=512 * 4, seed=7, target_model_update_interval=5)
+        eng = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=True, actor_stream="low")
+        try:
+            assert eng.replay.lagged == lagged
+            out = []
+            for T in range(40):
+                if T == 12:
+                    eng.enable_lazy_capture()
+                eng.step(learner_updates=1)
+                e = eng.env
+                out.append((e.rewards.clone(), e.done.clone(), e.terminated.clone(), e.next_obs[:, ::97].clone()))
+            torch.cuda.synchronize()
+            return out
+        finally:
+            eng.close()
+
+    a, b = run(True), run(False)
+    for T, (x, y) in enumerate(zip(a, b)):
+        for k, (u, v) in enumerate(zip(x, y)):
+            assert torch.equal(u, v), (T, k)
+    assert any(int(x[1].sum()) > 0 for x in a)  # episodes ended

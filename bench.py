@@ -426,7 +426,6 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
 
     import simple_distributed_rl_amd as srl
     from simple_distributed_rl_amd.algorithms import agent57_light
-    from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
 
     E = envs_per_gpu or args.envs
     rl = agent57_light.Config(batch_size=args.batch_size)
@@ -458,7 +457,6 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             if int(t.item()) == 0:
                 break
-        stack_replay = eng.local.replay
     else:
         # round 6: every network pass, optimiser step and array operation in libsrlx (device/agent57_fast.py); the round-5 engine with torch dense tails
         # (device/agent57_light.py) is a test yardstick now
@@ -466,14 +464,13 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
 
         eng = Agent57LightFastEngine(rl, E, dev_index, episode_len=args.episode_len, seed=0, overlap=None if not args.no_overlap else False)
         eng.prefill()
-        stack_replay = eng.replay
-    fast_engine = dist is None
+    fast_engine = True
     inner = max(1, args.inner)
     for _ in range(max(1, args.warmup) * inner):
         eng.step(args.updates)
     torch.cuda.synchronize()
-    if not args.no_graph and dist is None:
-        eng.capture_graphs()  # the update (five networks, their optimiser steps) as one HIP graph per published set
+    if not args.no_graph:
+        eng.capture_graphs()  # the update (five networks, their optimiser steps) as one HIP graph per published set (/ staging slot on a learner rank)
         for _ in range(4):  # (each variant is captured the first time it runs, and a fresh graph's first replay instantiates it)
             eng.step(args.updates)
         torch.cuda.synchronize()
@@ -481,7 +478,8 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
     # HIP events right around k_convnet_fused of the q_ext actor handle (one of the five trunk launches of a lock-step), recorded by the library on the kernel's own
     # launch stream, every 4th lock-step INSIDE the timed loop
     probe_every, pr = 4, []
-    if fast_engine:
+    probe_handle = (eng.local if dist is not None else eng).nets["q_ext"].actor  # (None on a rank that only learns)
+    if probe_handle is not None:
         pr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((n_lock + probe_every - 1) // probe_every)]
         for a_, b_ in pr:
             a_.record()
@@ -492,7 +490,7 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
     t0 = time.perf_counter()
     for k in range(n_lock):
         if pr and k % probe_every == 0:
-            eng.nets["q_ext"].actor.set_probe(*pr[k // probe_every])
+            probe_handle.set_probe(*pr[k // probe_every])
         eng.step(args.updates)
     torch.cuda.synchronize()
     if dist is not None:
@@ -511,13 +509,12 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
     # roofline of the dominant kernel (rocprofv3: k_convnet_fused<true, ...>, the actors' image trunks: five launches per lock-step), isolated launches
     # of ONE trunk over the E current stacks, HIP events on the launch stream (libsrlx launches on torch's current stream here)
     local = eng.local if dist is not None else eng
-    trunk = local._trunks.get("q_ext") if getattr(local, "_trunks", None) else None
     roof = None
     if fast_engine and pr:
         v = sorted(a_.elapsed_time(b_) for a_, b_ in pr)
         ms = sum(v) / len(v)
         ex = CONV_EXECUTED_FLOPS_PER_SAMPLE * E
-        n_trunks = 5 if eng.intrinsic else 2
+        n_trunks = 5 if local.intrinsic else 2
         roof = {"kernel": "k_convnet_fused<true, ..., PLANES> : conv1 -> conv2 -> conv3 of ONE of the five image trunks of the actors' pass over E uint8 stacks, writing the "
                           "first dense layer's A operand planes (five such launches per lock-step; the dominant kernel of profiles/r6_a57_kernel_stats.csv)",
                 "bound": "mfma", "achieved": ex / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
@@ -526,24 +523,6 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
                 "note": "HIP events recorded by the library around exactly this kernel on its launch stream, every 4th lock-step inside the timed loop (the update runs "
                         "beside it); executed flops = 3 x conv1 + 6 x conv2 / conv3 exact split-bf16 partial products; traffic: the same kernel's PMC figure of the "
                         "Rainbow policy pass (profiles/r5_pmc_traffic.json: the kernel and its launch geometry are identical)"}
-    elif trunk is not None:
-        reps = 30
-        base, off = stack_replay.obs_base, local._frame_off
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            trunk(base, off)
-        a.record()
-        for _ in range(reps):
-            trunk(base, off)
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / reps
-        ex = CONV_EXECUTED_FLOPS_PER_SAMPLE * E
-        roof = {"kernel": "k_convnet_fused<true, ...> (+ k_pack_filters): conv1 -> conv2 -> conv3 of ONE of the five image trunks of the actors' pass over E uint8 stacks "
-                          "(five such launches per lock-step; 24 % of the GPU time in profiles/r5_a57_kernel_stats.csv)",
-                "bound": "mfma", "achieved": ex / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": None, "executed_mfma_flops_per_launch": ex, "avg_launch_ms": ms, "launches_per_lock_step": len(local._trunks),
-                "note": "isolated launches (the update does not run beside them); executed flops = 3 x conv1 + 6 x conv2 / conv3 exact split-bf16 partial products"}
     info = eng.info()
     cpu = None
     if dist is None and rank == 0 and not args.no_cpu_baseline:
@@ -561,9 +540,9 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
                    "networks": ("all five networks forward AND backward, their optimiser steps and every per-lane / per-batch array operation in libsrlx (no torch network, "
                                 "no hipBLASLt, no ATen elementwise launch on the lock-step): UVFA Q-networks as rank-1 terms of the head kernel, embedding / RND tails as "
                                 "single-workgroup kernels, Adam fused into the gradient launches; actors read published parameter sets") if fast_engine else
-                               "image blocks in libsrlx, dense tails + Adam in torch (the round-3 exchange's engine, device/agent57_light.py)",
+                               "-",
                    "overlap": bool(getattr(eng, "overlap", False)),
-                   "hip_graphs": "learner update (one graph per published set)" if (not args.no_graph and dist is None) else False},
+                   "hip_graphs": "learner update (one graph per published set / staging slot)" if not args.no_graph else False},
         "roofline": roof, "cpu_baseline": cpu,
         "final": {"loss": info.get("loss"), "train_count": info["train_count"], "memory": info["memory"]},
     }

@@ -711,6 +711,17 @@ int srlx_agent57_gather_inputs(int64_t batch, int64_t n_envs, const int64_t *d_l
                                const float *d_x_r_int, const float *d_x_prev_r_ext, const float *d_x_prev_r_int, const int32_t *d_x_actor, const int32_t *d_x_prev_action,
                                const float *d_discount_list, float *d_on_r_ext, float *d_on_r_int, int32_t *d_on_action, int32_t *d_on_actor, float *d_tg_r_ext,
                                float *d_tg_r_int, int32_t *d_tg_action, int32_t *d_tg_actor, float *d_discount, float *d_r_int, void *stream);
+/* Multi-GPU (BASELINE configs[3]: 7 actor GPUs + 1 learner GPU; replaces the pickled 11-field items of srl/base/run/play_mp.py:76-118 and their unpickling in the
+ * trainer's drain thread, :248-286):
+ *   srlx_agent57_pack_record   : an actor rank's lock-step as ONE packed record uint8 [(10 + 4 * 5) * n_envs] in the layout srlx_store_commit_step_packed takes with
+ *       extra_floats = 5: [action | reward | terminated | done | (intrinsic reward, arm, previous action, previous extrinsic reward, previous intrinsic reward) per lane].
+ *   srlx_agent57_unpack_fields : the learner rank's inverse for the five fields: environment g = lane g % envs_per_record of record g / envs_per_record; they land
+ *       in row (*d_position mod ring_len) of the learner's [ring slot][environment] arrays -- the slot the ring commit of the same slab writes; the position is read
+ *       on the device (srlx_store_views), so the launch replays inside a captured update. */
+int srlx_agent57_pack_record(int64_t n_envs, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated, const uint8_t *d_done, const float *d_x_r_int,
+                             const int32_t *d_x_actor, const int32_t *d_x_prev_action, const float *d_x_prev_r_ext, const float *d_x_prev_r_int, uint8_t *d_record, void *stream);
+int srlx_agent57_unpack_fields(int64_t n_records, int64_t envs_per_record, const uint8_t *d_records, int64_t record_stride, const int64_t *d_position, int64_t ring_len,
+                               float *d_x_r_int, int32_t *d_x_actor, int32_t *d_x_prev_action, float *d_x_prev_r_ext, float *d_x_prev_r_int, void *stream);
 int srlx_agent57_emb_tail(int64_t batch, int emb_dim, int hidden, int n_actions, const float *d_emb, const int32_t *d_actions, float *const *d_params, float *const *d_grads,
                           float *const *d_exp_avg, float *const *d_exp_avg_sq, double ln_eps, double lr, double beta1, double beta2, double eps, const int64_t *d_steps_taken,
                           float *d_loss, float *d_grad_emb, void *stream);

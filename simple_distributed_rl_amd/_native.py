@@ -178,6 +178,8 @@ SIGNATURES = {
     "srlx_agent57_post_step": (c_int, [c_i64] + [c_p] * 16),
     "srlx_agent57_begin_episodes": (c_int, [c_i64, c_int, c_p, c_u64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_agent57_gather_inputs": (c_int, [c_i64, c_i64] + [c_p] * 21),
+    "srlx_agent57_pack_record": (c_int, [c_i64] + [c_p] * 11),
+    "srlx_agent57_unpack_fields": (c_int, [c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_agent57_emb_tail": (c_int, [c_i64, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p, c_p]),
     "srlx_agent57_rnd_tail": (c_int, [c_i64, c_int, c_i64] + [c_p] * 12 + [c_f64] * 5 + [c_p, c_p, c_p, c_p]),
     "srlx_agent57_priority": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -138,6 +138,33 @@ __global__ void __launch_bounds__(64) k_a57_gather(GatherArgs a) {
     a.r_int[b] = ri;
 }
 
+// ---- multi-GPU: one rank's lock-step as a packed record (the layout srlx_store_commit_step_packed takes, with Agent57_light's five further item fields as extra
+// floats: intrinsic reward, arm, previous action, previous extrinsic / intrinsic reward), and its inverse on the learner rank -----------------------------------
+constexpr int kA57Fields = 5;
+__global__ void __launch_bounds__(256) k_a57_pack(i64 E, const int32_t *actions, const float *rewards, const u8 *terminated, const u8 *done, const float *x_r_int,
+                                                  const int32_t *x_actor, const int32_t *x_prev_action, const float *x_prev_r_ext, const float *x_prev_r_int, u8 *rec) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    reinterpret_cast<int32_t *>(rec)[e] = actions[e];
+    reinterpret_cast<float *>(rec + 4 * E)[e] = rewards[e];
+    rec[8 * E + e] = terminated[e];
+    rec[9 * E + e] = done[e];
+    float *x = reinterpret_cast<float *>(rec + 10 * E) + e * kA57Fields;
+    x[0] = x_r_int[e], x[1] = (float)x_actor[e], x[2] = (float)x_prev_action[e], x[3] = x_prev_r_ext[e], x[4] = x_prev_r_int[e];
+}
+
+// environment g of the learner's replay = lane g % per of record g / per; the fields land in row (*pos % L) of the learner's [ring slot][environment] arrays -- the
+// slot the ring commit of the same slab writes (the position is read on the device: the launch replays inside a captured update)
+__global__ void __launch_bounds__(256) k_a57_unpack(i64 total, i64 per, const u8 *rec, i64 stride, const i64 *pos, i64 L, float *x_r_int, int32_t *x_actor,
+                                                    int32_t *x_prev_action, float *x_prev_r_ext, float *x_prev_r_int) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const i64 slot = ((pos[0] % L) + L) % L;
+    const float *x = reinterpret_cast<const float *>(rec + (g / per) * stride + 10 * per) + (g % per) * kA57Fields;
+    const i64 at = slot * total + g;
+    x_r_int[at] = x[0], x_actor[at] = (int32_t)x[1], x_prev_action[at] = (int32_t)x[2], x_prev_r_ext[at] = x[3], x_prev_r_int[at] = x[4];
+}
+
 // ---- learner: the two small tails -----------------------------------------------------------------------------------------------------------------------
 struct AdamHyper {
     double lr, beta1, beta2, eps;
@@ -428,6 +455,27 @@ int srlx_agent57_gather_inputs(int64_t batch, int64_t n_envs, const int64_t *d_l
     GatherArgs a{(int)batch, n_envs, d_loc_env, d_loc_slot, d_actions, d_rewards, d_x_r_int, d_x_prev_r_ext, d_x_prev_r_int, d_x_actor, d_x_prev_action, d_discount_list,
                  d_on_r_ext, d_on_r_int, d_on_action, d_on_actor, d_tg_r_ext, d_tg_r_int, d_tg_action, d_tg_actor, d_discount, d_r_int};
     hipLaunchKernelGGL(k_a57_gather, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_agent57_pack_record(int64_t n_envs, const int32_t *d_actions, const float *d_rewards, const uint8_t *d_terminated, const uint8_t *d_done, const float *d_x_r_int,
+                             const int32_t *d_x_actor, const int32_t *d_x_prev_action, const float *d_x_prev_r_ext, const float *d_x_prev_r_int, uint8_t *d_record, void *stream) {
+    SRLX_REQUIRE(n_envs > 0 && n_envs % 4 == 0 && d_actions && d_rewards && d_terminated && d_done && d_x_r_int && d_x_actor && d_x_prev_action && d_x_prev_r_ext && d_x_prev_r_int &&
+                     d_record, "agent57_pack_record: bad argument (n_envs in multiples of 4: the float fields sit behind 10 * n_envs bytes)");
+    hipLaunchKernelGGL(k_a57_pack, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (i64)n_envs, d_actions, d_rewards, d_terminated, d_done, d_x_r_int,
+                       d_x_actor, d_x_prev_action, d_x_prev_r_ext, d_x_prev_r_int, d_record);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+int srlx_agent57_unpack_fields(int64_t n_records, int64_t envs_per_record, const uint8_t *d_records, int64_t record_stride, const int64_t *d_position, int64_t ring_len,
+                               float *d_x_r_int, int32_t *d_x_actor, int32_t *d_x_prev_action, float *d_x_prev_r_ext, float *d_x_prev_r_int, void *stream) {
+    SRLX_REQUIRE(n_records > 0 && envs_per_record > 0 && envs_per_record % 4 == 0 && d_records && record_stride >= (10 + 4 * kA57Fields) * envs_per_record && d_position &&
+                     ring_len > 0 && d_x_r_int && d_x_actor && d_x_prev_action && d_x_prev_r_ext && d_x_prev_r_int, "agent57_unpack_fields: bad argument");
+    const i64 total = n_records * envs_per_record;
+    hipLaunchKernelGGL(k_a57_unpack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total, (i64)envs_per_record, d_records, (i64)record_stride, d_position,
+                       (i64)ring_len, d_x_r_int, d_x_actor, d_x_prev_action, d_x_prev_r_ext, d_x_prev_r_int);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

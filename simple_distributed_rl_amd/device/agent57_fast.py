@@ -52,6 +52,35 @@ def _single(block_cfg, what):
     return int(sizes[0])
 
 
+def why_not_fast(rl_config) -> str:
+    """Empty string when `Agent57LightFastEngine` covers this (set-up) config; otherwise the reason (the Runner then takes the round-5 engine with torch tails,
+    device/agent57_light.py, which serves every DQN-image / dueling shape the plugin builds)."""
+    c = rl_config
+    shape = tuple(int(x) for x in c.observation_space.shape)
+    if len(shape) != 3 or shape != (84, 84, 4):
+        return "observations are not 84 x 84 x 4 frame stacks"
+    if c.input_block.image.name != "DQN" or c.input_block.image.kwargs.get("filters", 32) != 32:
+        return "input block is not the DQN image block with 32 filters"
+    dk = c.hidden_block.kwargs
+    sizes = tuple(dk.get("layer_sizes", ()))
+    if c.hidden_block.name != "DuelingNetwork" or len(sizes) != 1 or sizes[0] % 64 or sizes[0] > 512:
+        return "hidden block is not one dueling layer of a multiple of 64 (<= 512) units"
+    if dk.get("dueling_kwargs", {}).get("dueling_type", "average") not in ("average", ""):
+        return "dueling type is neither 'average' nor ''"
+    if c.batch_size > 32:
+        return "batch size above 32"
+    if c.enable_intrinsic_reward:
+        for blk in (c.episodic_emb_block, c.episodic_out_block, c.lifelong_hidden_block):
+            if len(tuple(blk.kwargs.get("layer_sizes", ()))) != 1 or str(blk.kwargs.get("activation", "relu")).lower() != "relu":
+                return "an embedding / lifelong block is not ONE ReLU layer"
+        D, Hd, A = int(c.episodic_emb_block.kwargs["layer_sizes"][0]), int(c.episodic_out_block.kwargs["layer_sizes"][0]), int(c.action_space.n)
+        if D > 128 or c.batch_size * (2 * D + 3 * Hd + A + 1) + 256 > 16384:
+            return "the embedding network's tail does not fit one workgroup's 64 KB of LDS (batch x (2 x embedding + 3 x classifier layer))"
+        if int(c.lifelong_hidden_block.kwargs["layer_sizes"][0]) != 128:
+            return "the lifelong networks' layer is not 128 units wide (its LayerNorm is fused into a 128-unit tile)"
+    return ""
+
+
 class _Net:
     """One trained network: master module (kernel layouts), learner handle, optimiser, the actors' handle; for a Q-network also its target."""
 
@@ -63,15 +92,22 @@ class _Net:
 
 class Agent57LightFastEngine:
     def __init__(self, rl_config, n_envs: int, device: int = 0, episode_len: int = 200, seed: int = 0, env=None, parameter=None, ring_len: Optional[int] = None,
-                 overlap: Optional[bool] = None, fc1_neighbour: int = 4, fused_adam: bool = True):
+                 overlap: Optional[bool] = None, fc1_neighbour: int = 4, fused_adam: bool = True, role: str = "both", learner_replay: Optional[DeviceReplay] = None):
         """rl_config: a set-up algorithms.agent57_light.Config (84 x 84 x window-4 image observations); parameter: its Parameter (the five torch networks: the
         initial weights are taken from it, `export_parameter()` writes the trained ones back).  overlap (None = wherever it applies): the update beside the
         actors on published parameter sets; needs n_envs >= 512 in multiples of 128.  fused_adam=False (tests): every gradient is written to `p.grad` and the
-        optimiser steps are launches of their own (srlx_adam_step) -- the same arithmetic, with the gradients left to look at."""
+        optimiser steps are launches of their own (srlx_adam_step) -- the same arithmetic, with the gradients left to look at.
+        role (device/dist.py): "both" = actors and learner on this GPU; "actor" = a rank that only acts (no target networks, no optimisers; its passes read the
+        master parameters a weight broadcast lands in, through sets published out of band: `on_weights_broadcast`); "learner" = a rank that only learns.
+        learner_replay: the replay the LEARNER samples when it is not this engine's own ring (a learner rank's global replay over every actor rank's environments);
+        the engine's own ring then only stacks frames for its actors."""
         from simple_distributed_rl_amd.device.rainbow import SyntheticAtariVecEnv
 
         c = self.cfg = rl_config
         assert c.is_setup(), "rl_config.setup(env) first: the networks are built from the negotiated spaces"
+        assert role in ("both", "actor", "learner")
+        self.role, self.acts, self.learns = role, role != "learner", role != "actor"
+        self.learner_replay = learner_replay
         self.dev = torch.device(f"cuda:{device}")
         self.device_index = int(device)
         self.lib = N.lib()
@@ -86,25 +122,32 @@ class Agent57LightFastEngine:
         if not ok:
             raise ValueError("Agent57LightFastEngine covers 84 x 84 x 4 frames, the DQN image block with 32 filters, ONE dueling layer (average / none) and batches "
                              "<= 32; there is no fallback network path (the round-5 engine with torch tails is device/agent57_light.py, a test yardstick)")
+        why = why_not_fast(c)
+        if why:
+            raise ValueError(f"Agent57LightFastEngine: {why}; there is no fallback network path")
         self.hidden = int(tuple(dk["layer_sizes"])[0])
         self.dueling = dk.get("dueling_kwargs", {}).get("dueling_type", "average")
-        if self.hidden % 64 or self.hidden > 512:
-            raise ValueError("Agent57LightFastEngine: the dueling layer must be a multiple of 64 units, at most 512")
         self.intrinsic = bool(c.enable_intrinsic_reward)
         self.fused_adam = bool(fused_adam)
-        can_overlap = E >= 512 and E % 128 == 0 and self.fused_adam
+        chip_filling = E >= 512 and E % 128 == 0
+        can_overlap = chip_filling and self.fused_adam and role == "both"
         if overlap and not can_overlap:
             raise ValueError("Agent57LightFastEngine(overlap=True): needs >= 512 environments in multiples of 128 (the published sets feed the chip-filling kernels)")
         self.overlap = can_overlap if overlap is None else bool(overlap)
-        self.sets = self.overlap
+        self.sets = self.overlap or (role == "actor" and chip_filling)  # an actor rank's passes read sets published out of band after every weight broadcast
+        self._own_ring_only = role == "actor" or learner_replay is not None  # the engine's own ring only stacks frames: no tree add, the commit moves the position
         mem = c.memory
         kw = mem.kwargs if mem.name != "ReplayBuffer" else {}
         if ring_len is None:
             ring_len = -(-mem.capacity // E) + 1 + Wn
-        self.replay = DeviceReplay(E, ring_len, H * W_, Wn, 1, A, B, True, False, float(kw.get("alpha", 0.0)), float(kw.get("beta_initial", 0.4)),
-                                   int(kw.get("beta_steps", 1_000_000)), float(kw.get("epsilon", 1e-4)), mem.warmup_size, self.seed, device)
+        if self.acts:
+            self.replay = DeviceReplay(E, ring_len, H * W_, Wn, 1, A, B, True, False, float(kw.get("alpha", 0.0)), float(kw.get("beta_initial", 0.4)),
+                                       int(kw.get("beta_steps", 1_000_000)), float(kw.get("epsilon", 1e-4)), mem.warmup_size, self.seed, device)
+            self.env = SyntheticAtariVecEnv(self.replay, episode_len) if env is None else (env(self.replay) if callable(env) else env)
+        else:
+            assert learner_replay is not None, "role='learner' needs the replay it learns from"
+            self.replay, self.env = learner_replay, None
         self.L = self.replay.L
-        self.env = SyntheticAtariVecEnv(self.replay, episode_len) if env is None else (env(self.replay) if callable(env) else env)
         c._set_device(str(self.dev))
         if parameter is None:
             parameter = c.make_parameter()
@@ -132,8 +175,25 @@ class Agent57LightFastEngine:
         self.eps_list = torch.tensor(np.array(funcs.create_epsilon_list(Na), np.float32), device=d)
         self._build_networks(B, fc1_neighbour)
         self.load_parameter(parameter)
-        # ---- per-environment actor state (the reference keeps these on the worker object, :288-311) ----
         z = lambda dt, *sh: torch.zeros(sh, dtype=dt, device=d)  # noqa: E731
+        self._graphs, self._capturing, self._in_capture = {}, False, False
+        self._set, self._published = 0, None
+        self._learner_pending = False
+        self.train_count = self.sync_count = self.total_env_steps = 0
+        self.ledger, self.training, self.ingest, self.before_env = None, True, None, None
+        if self.learns:
+            self._init_learner(B, A, z)
+        if self.acts:
+            self._init_actors(E, A, Na, z)
+            self.first_obs = self.env.reset()
+            self.replay.reset_all(self.first_obs)
+        self._publish_out_of_band()
+        if self.acts:
+            self._begin_all()
+
+    def _init_actors(self, E, A, Na, z):
+        """Per-environment actor state (the reference keeps these on the worker object, :288-311)."""
+        c, d = self.cfg, self.dev
         self.ucb = UcbBank(E, Na, c.ucb_window_size, c.ucb_epsilon, c.ucb_beta, d, self.seed)
         self.episode_reward, self.prev_r_ext, self.prev_r_int = z(torch.float32, E), z(torch.float32, E), z(torch.float32, E)
         self.prev_action, self.actions, self.zero_arm = z(torch.int32, E), z(torch.int32, E), z(torch.int32, E)
@@ -148,7 +208,19 @@ class Agent57LightFastEngine:
             self.ngu = NguOps(d, E, self.D_emb, c.episodic_memory_capacity, c.episodic_count_max, c.episodic_epsilon, c.episodic_cluster_distance, c.episodic_pseudo_counts)
             self.emb_out, self.rnd_t_out, self.rnd_p_out = z(torch.float32, E, self.D_emb), z(torch.float32, E, self.D_rnd), z(torch.float32, E, self.D_rnd)
             self.episodic, self.lifelong = z(torch.float32, E), z(torch.float32, E)
-        # ---- learner buffers ----
+        self.record = z(torch.uint8, (10 + 4 * 5) * E)  # this lock-step as one packed record (srlx_agent57_pack_record: what an actor rank ships)
+
+    @property
+    def lreplay(self) -> DeviceReplay:
+        """The replay the learner samples and writes back to."""
+        return self.learner_replay if self.learner_replay is not None else self.replay
+
+    def _init_learner(self, B, A, z):
+        d = self.dev
+        if self.learner_replay is not None:  # the item fields of the global replay's environments, [ring slot][environment] (filled by `ingest_fields`)
+            Lg, Eg = self.learner_replay.L, self.learner_replay.E
+            self.lx = dict(r_int=z(torch.float32, Lg, Eg), prev_r_ext=z(torch.float32, Lg, Eg), prev_r_int=z(torch.float32, Lg, Eg), actor=z(torch.int32, Lg, Eg),
+                           prev_action=z(torch.int32, Lg, Eg))
         self.loc_env, self.loc_slot = z(torch.int64, B), z(torch.int64, B)
         self.on_r_ext, self.on_r_int, self.on_action, self.on_actor = z(torch.float32, 2 * B), z(torch.float32, 2 * B), z(torch.int32, 2 * B), z(torch.int32, 2 * B)
         self.tg_r_ext, self.tg_r_int, self.tg_action, self.tg_actor = z(torch.float32, B), z(torch.float32, B), z(torch.int32, B), z(torch.int32, B)
@@ -161,20 +233,15 @@ class Agent57LightFastEngine:
             self.l_rnd_p, self.l_rnd_t, self.g_rnd, self.rnd_loss = z(torch.float32, 2 * B, self.D_rnd), z(torch.float32, 2 * B, self.D_rnd), z(torch.float32, B, self.D_rnd), z(torch.float32, 1)
         self.s_target = torch.cuda.Stream(device=d, priority=-1)
         self._ev_t = {k: (torch.cuda.Event(), torch.cuda.Event()) for k in ("q_ext", "q_int")}
-        if self.overlap:
-            self.s_learner = torch.cuda.Stream(device=d, priority=-1)
-            self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        self.s_learner = torch.cuda.Stream(device=d, priority=-1)
+        self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        # a learner rank's ingest (device/dist.py): the commit of a slab that arrived from the actor ranks runs on a side stream between the update's draw and its
+        # priority write-back -- `self.ingest` = (key, callable issuing the launches) for the NEXT update only
+        self.s_ingest = torch.cuda.Stream(device=d, priority=-1) if self.learner_replay is not None else None  # (no stream the single-GPU engine does not use: one
+        # more stream in the process changes which hardware queues the others land on)
+        self._ev_drawn, self._ev_ingested = torch.cuda.Event(), torch.cuda.Event()
+        if self.overlap and not self._own_ring_only:
             self.replay.enable_deferred_advance()
-        self._learner_pending = False
-        self._graphs, self._capturing, self._in_capture = {}, False, False
-        self._set, self._published = 0, None
-        self.train_count = self.sync_count = self.total_env_steps = 0
-        self.ledger = None
-        self.training = True
-        self.first_obs = self.env.reset()
-        self.replay.reset_all(self.first_obs)
-        self._publish_out_of_band()
-        self._begin_all()
 
     # ---- networks ----------------------------------------------------------------------------------------------------------------------------------------------
     def _build_networks(self, B, fc1_neighbour):
@@ -183,23 +250,26 @@ class Agent57LightFastEngine:
         lrs = dict(q_ext=c.lr_ext, q_int=c.lr_int, emb=c.episodic_lr, rnd=c.lifelong_lr)
 
         def actor_handle(module, uv=None):
+            if not self.acts:
+                return None
             h = QNetInference(module, E, dev, uvfa_layout=uv)
             if self.sets:
                 h.enable_fc1_planes(private_weights=True)
                 h.enable_actor_sets()
-                # half-CU workgroups beside the update; a 128-unit layer is ONE column tile: 32 K splits make 256 short workgroups of it (4 would be E / 128 x 4
-                # serial chains of 60 K-slabs: the latency of the 1024-unit layer for an eighth of its work)
-                h.set_fc1_neighbour(fc1_neighbour if uv is not None else 32)
+                # beside an update: half-CU workgroups (an actor rank has the GPU to itself: CU-filling ones); a 128-unit layer is ONE column tile: 32 K splits make
+                # 256 short workgroups of it (4 would be E / 128 x 4 serial chains of 60 K-slabs: the latency of the 1024-unit layer for an eighth of its work)
+                h.set_fc1_neighbour((fc1_neighbour if self.role == "both" else 0) if uv is not None else 32)
             return h
 
         def trainable(net, max_train, max_rows, uv=None):
-            net.inf = QNetInference(net.module, max_rows, dev, uvfa_layout=uv)
-            net.inf.enable_training(max_train)
-            net.opt = DeviceAdam(net.inf._params(), lr=lrs[net.name])
-            if self.fused_adam:
-                net.opt.fuse_first_dense(net.inf, self.train_count_dev)
-                net.opt.fuse_rest(net.inf)
-            N.check(self.lib.srlx_qnet_set_main_first(net.inf.h, 1))
+            net.inf = QNetInference(net.module, max_rows, dev, uvfa_layout=uv)  # (an actor rank: only packs / publishes what a broadcast brought)
+            if self.learns:
+                net.inf.enable_training(max_train)
+                net.opt = DeviceAdam(net.inf._params(), lr=lrs[net.name])
+                if self.fused_adam:
+                    net.opt.fuse_first_dense(net.inf, self.train_count_dev)
+                    net.opt.fuse_rest(net.inf)
+                N.check(self.lib.srlx_qnet_set_main_first(net.inf.h, 1))
             net.actor = actor_handle(net.module, uv)
             if self.sets:
                 net.planes_ptr = [net.actor.set_planes_ptr(0), net.actor.set_planes_ptr(1)]
@@ -207,10 +277,12 @@ class Agent57LightFastEngine:
         for name in ("q_ext", "q_int"):
             n = self.nets[name] = _Net(name)
             mk = lambda: EngineQNet(self.A, self.hw, self.Wn, self.hidden, 32, self.dueling, uvfa_cols=self.X).to(d)  # noqa: E731
-            n.module, n.target = mk(), mk()
+            n.module = mk()
             trainable(n, B, 2 * B, self.uvfa_layout)
-            n.inf_target = QNetInference(n.target, B, dev, uvfa_layout=self.uvfa_layout)
-            n.inf_target.set_pack_sticky(True)
+            if self.learns:
+                n.target = mk()
+                n.inf_target = QNetInference(n.target, B, dev, uvfa_layout=self.uvfa_layout)
+                n.inf_target.set_pack_sticky(True)
         if not self.intrinsic:
             return
         n = self.nets["emb"] = _Net("emb")
@@ -218,12 +290,11 @@ class Agent57LightFastEngine:
         n.module = EngineHiddenNet(De, self.hw, self.Wn, 32, tail_shapes=[(Hd, 2 * De), (Hd,), (Hd,), (Hd,), (A, Hd), (A,)]).to(d)
         trainable(n, 2 * B, 2 * B)
         n.inf.set_head_mode(1, De)
-        n.actor.set_head_mode(1, De)
+        if n.actor is not None:
+            n.actor.set_head_mode(1, De)
         n.tail_g = [torch.zeros_like(t) for t in n.module.tail]
         n.tail_m = [torch.zeros_like(t) for t in n.module.tail]
         n.tail_v = [torch.zeros_like(t) for t in n.module.tail]
-        tab = lambda ts: (N.c_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
-        n.tail_tabs = (tab(list(n.module.tail)), tab(n.tail_g), tab(n.tail_m), tab(n.tail_v))
         n = self.nets["rnd"] = _Net("rnd")
         Dr = self.D_rnd
         n.module = EngineHiddenNet(Dr, self.hw, self.Wn, 32, tail_shapes=[(Dr,), (Dr,)]).to(d)
@@ -235,15 +306,52 @@ class Agent57LightFastEngine:
         n.tail_v = [torch.zeros_like(t) for t in n.module.tail]
         # the actors' copies of the predictor's LayerNorm parameters, one pair per published set (the RND tail writes the pair of the set the update publishes into)
         n.ln_sets = [[torch.ones(Dr, device=d), torch.zeros(Dr, device=d)] for _ in range(2)]
-        n.inf_target = QNetInference(n.target, 2 * B, dev)
-        n.inf_target.set_pack_sticky(True)
-        n.inf_target.set_head_mode(1, Dr, n.target.tail[0], n.target.tail[1])
-        n.actor_target = QNetInference(n.target, E, dev)
-        n.actor_target.set_pack_sticky(True)
-        if self.sets:
-            n.actor_target.enable_fc1_planes(private_weights=True)
-            n.actor_target.set_fc1_neighbour(32)
-        n.actor_target.set_head_mode(1, Dr, n.target.tail[0], n.target.tail[1])
+        n.actor_target = None
+        if self.learns:
+            n.inf_target = QNetInference(n.target, 2 * B, dev)
+            n.inf_target.set_pack_sticky(True)
+        if self.acts:
+            n.actor_target = QNetInference(n.target, E, dev)
+            n.actor_target.set_pack_sticky(True)
+            if self.sets:
+                n.actor_target.enable_fc1_planes(private_weights=True)
+                n.actor_target.set_fc1_neighbour(32)
+        self._set_tail_pointers()
+
+    def _set_tail_pointers(self):
+        """Everything that holds the ADDRESS of a tail tensor (the embedding tail's pointer tables, the LayerNorm pointers of the RND target handles): again after the
+        parameters were re-homed (`rebind`)."""
+        if not self.intrinsic:
+            return
+        e, n, Dr = self.nets["emb"], self.nets["rnd"], self.D_rnd
+        tab = lambda ts: (N.c_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+        e.tail_tabs = (tab(list(e.module.tail)), tab(e.tail_g), tab(e.tail_m), tab(e.tail_v))
+        for h in (n.inf_target, n.actor_target):
+            if h is not None:
+                h.set_head_mode(1, Dr, n.target.tail[0], n.target.tail[1])
+
+    def modules(self):
+        """The five networks a weight broadcast carries (model_torch.py:148-156: both online Q-networks, the embedding network, the RND target and predictor)."""
+        ms = [self.nets["q_ext"].module, self.nets["q_int"].module]
+        if self.intrinsic:
+            ms += [self.nets["emb"].module, self.nets["rnd"].target, self.nets["rnd"].module]
+        return ms
+
+    def rebind(self):
+        """The parameters were re-homed (device/dist.py:flatten_parameters): every handle, optimiser and pointer table reads their addresses again."""
+        for n in self.nets.values():
+            for h in (n.inf, n.actor, n.inf_target, getattr(n, "actor_target", None)):
+                if h is not None:
+                    h.bind()
+            if n.opt is not None:
+                n.opt.bind()
+        self._set_tail_pointers()
+        self._publish_out_of_band()
+
+    def on_weights_broadcast(self):
+        """A broadcast has just overwritten the master parameters in place: whatever was derived from them is rebuilt."""
+        self.join_learner()
+        self._publish_out_of_band()
 
     def load_parameter(self, p):
         """The five networks := the plugin Parameter's torch modules (the reference's state_dict keys)."""
@@ -251,12 +359,13 @@ class Agent57LightFastEngine:
         for name, src in (("q_ext", p.q_ext_online), ("q_int", p.q_int_online)):
             n = self.nets[name]
             n.module.load_reference_state_dict(src.state_dict())
-            n.target.load_reference_state_dict(getattr(p, name + "_target").state_dict())
+            if n.target is not None:
+                n.target.load_reference_state_dict(getattr(p, name + "_target").state_dict())
         if self.intrinsic:
             self.nets["emb"].module.load_reference(p.emb_network.state_dict(), "emb_block.hidden_layers.0", _EMB_TAIL_KEYS)
             self.nets["rnd"].module.load_reference(p.lifelong_train.state_dict(), "hidden_block.hidden_layers.0", _RND_TAIL_KEYS)
             self.nets["rnd"].target.load_reference(p.lifelong_target.state_dict(), "hidden_block.hidden_layers.0", _RND_TAIL_KEYS)
-        if hasattr(self, "first_obs"):
+        if hasattr(self, "_published"):
             self._publish_out_of_band()
 
     def export_parameter(self, p=None):
@@ -267,7 +376,8 @@ class Agent57LightFastEngine:
         for name, dst in (("q_ext", p.q_ext_online), ("q_int", p.q_int_online)):
             n = self.nets[name]
             dst.load_state_dict({k: v.to(next(dst.parameters()).device) for k, v in n.module.reference_state_dict().items()})
-            getattr(p, name + "_target").load_state_dict({k: v.to(next(dst.parameters()).device) for k, v in n.target.reference_state_dict().items()})
+            if n.target is not None:
+                getattr(p, name + "_target").load_state_dict({k: v.to(next(dst.parameters()).device) for k, v in n.target.reference_state_dict().items()})
         if self.intrinsic:
             to = lambda sd, m: m.load_state_dict({k: v.to(next(m.parameters()).device) for k, v in sd.items()})  # noqa: E731
             to(self.nets["emb"].module.reference_tensors("emb_block.hidden_layers.0", _EMB_TAIL_KEYS), p.emb_network)
@@ -285,11 +395,12 @@ class Agent57LightFastEngine:
                 n.actor.select_set(self._set)
             else:
                 n.inf.publish_to(None)
-                n.actor.weights_changed()
+                if n.actor is not None:
+                    n.actor.weights_changed()
             if n.inf_target is not None:
                 n.inf_target.weights_changed()
                 n.inf_target.publish_to(None)
-        if self.intrinsic:
+        if self.intrinsic and self.acts:
             r = self.nets["rnd"]
             r.actor_target.weights_changed()
             if self.sets:
@@ -335,6 +446,8 @@ class Agent57LightFastEngine:
         E = self.E
         arm = self.arm()
         self.policy_q()
+        if self.before_env is not None:  # (device/dist.py: the previous slab's frames must have left before the environments overwrite them)
+            self.before_env()
         next_obs, rewards, terminated, done = self.env.step(self.actions)
         slot = r._steps_committed % self.L
         if self.ledger is not None:
@@ -352,6 +465,7 @@ class Agent57LightFastEngine:
             N.check(self.lib.srlx_ngu_lifelong_reward(E, self.D_rnd, N.tptr(self.rnd_t_out), N.tptr(self.rnd_p_out), float(c.lifelong_max), N.tptr(self.lifelong), st))
             epi, lif = self.episodic, self.lifelong
         row = lambda t: N.c_p(t.data_ptr() + slot * E * t.element_size())  # noqa: E731
+        self._last_slot = slot
         N.check(self.lib.srlx_agent57_post_step(E, N.tptr(self.actions), N.tptr(arm), N.tptr(rewards), N.tptr(self.reset_lane), N.tptr(epi), N.tptr(lif), N.tptr(self.prev_action),
                                                 N.tptr(self.prev_r_ext), N.tptr(self.prev_r_int), N.tptr(self.episode_reward), row(self.x_r_int), row(self.x_prev_r_ext),
                                                 row(self.x_prev_r_int), row(self.x_actor), row(self.x_prev_action), st))
@@ -363,13 +477,24 @@ class Agent57LightFastEngine:
             self.reset_lane.copy_(done)
             torch.bitwise_xor(done, 1, out=self.live_lane)
         self.total_env_steps += E
+        if self._own_ring_only:  # the ring only stacks frames for this engine's actors: its commit moved the position itself, there is no tree here
+            return
         self.join_learner()
         r.add_masked()
         self._flip()
 
+    def pack_record(self) -> torch.Tensor:
+        """The lock-step `actor_step` has just taken as ONE packed record (uint8: action, reward, flags and the five item fields of every lane): what an actor rank
+        ships to the learner rank beside its frames (`env.next_obs`)."""
+        e, E, slot = self.env, self.E, self._last_slot
+        row = lambda t: N.c_p(t.data_ptr() + slot * E * t.element_size())  # noqa: E731
+        N.check(self.lib.srlx_agent57_pack_record(E, N.tptr(self.actions), N.tptr(e.rewards), N.tptr(e.terminated), N.tptr(e.done), row(self.x_r_int), row(self.x_actor),
+                                                  row(self.x_prev_action), row(self.x_prev_r_ext), row(self.x_prev_r_int), N.tptr(self.record), N.torch_stream_ptr()))
+        return self.record
+
     def _flip(self):
         """The joined update wrote the other set of every network: the next passes read it (host-side pointer swaps)."""
-        if self.sets and self._published is not None:
+        if self.sets and self._published is not None and self.acts:
             self._set, self._published = self._published, None
             for n in self.nets.values():
                 n.actor.select_set(self._set)
@@ -380,7 +505,7 @@ class Agent57LightFastEngine:
     def _update_q(self, n: _Net, rewards, publish, bump):
         """model_torch.py:384-443 for one Q-network: ONE online pass over the interleaved [s_0, s_1] rows, the target network on s_1 beside it, TD target (per-actor
         discount) / Huber / gradient seed in the backward pass's head kernel, Adam inside the gradient launches, publish."""
-        c, r = self.cfg, self.replay
+        c, r = self.cfg, self.lreplay
         B, W = r.B, self.Wn
         o = self.out[n.name]
         cur = torch.cuda.current_stream(self.dev)
@@ -403,27 +528,51 @@ class Agent57LightFastEngine:
         n.opt.step(self.train_count_dev)  # (fused: nothing left to launch)
         n.inf.publish_to(n.actor if publish is not None else None, publish or 0, bump=bump)
 
-    def _learner_body(self, publish: Optional[int] = None, drawn: bool = False):
+    def _learner_body(self, publish: Optional[int] = None, drawn: bool = False, ingest=None):
         """One update of the four trained networks (model_torch.py:263-381) -- device work only, capturable.  publish: the actor set (0 / 1) it also writes.
-        drawn=True (tests): the batch, its frame tables and its UVFA inputs are already in the engine's buffers."""
-        c, r, st = self.cfg, self.replay, N.torch_stream_ptr()
-        B, W = r.B, self.Wn
+        drawn=True (tests): the batch, its frame tables and its UVFA inputs are already in the engine's buffers.  ingest: a callable issuing the launches that commit
+        a slab of arrived transitions (ring + item fields + tree; device/dist.py): they run on a side stream BEHIND the draw, and the priority write-back waits for
+        them -- the tree sees draw, add, write-back in that order, and the commit hides beside the networks' passes."""
+        c, r, st = self.cfg, self.lreplay, N.torch_stream_ptr()
         b = r.batch if drawn else r.sample_items(self.train_count_dev, all_states=True)
         st = N.torch_stream_ptr()
         if not drawn:
             self._gather_inputs(b, st)
-        self._update_networks(b, publish, st)
+        if ingest is not None:  # behind the draw AND the gather of the drawn items' fields (the ingest overwrites a ring slot's fields: one no stored item points at)
+            cur = torch.cuda.current_stream(self.dev)
+            self._ev_drawn.record(cur)
+            self.s_ingest.wait_event(self._ev_drawn)
+            with torch.cuda.stream(self.s_ingest):
+                ingest()
+                self._ev_ingested.record(self.s_ingest)
+        self._update_networks(b, publish, st, wait=self._ev_ingested if ingest is not None else None)
+
+    def _lx(self):
+        """The learner's view of the item fields: the global replay's arrays on a learner rank, this engine's own otherwise."""
+        if self.learner_replay is not None:
+            x = self.lx
+            return x["r_int"], x["prev_r_ext"], x["prev_r_int"], x["actor"], x["prev_action"]
+        return self.x_r_int, self.x_prev_r_ext, self.x_prev_r_int, self.x_actor, self.x_prev_action
+
+    def ingest_fields(self, records: torch.Tensor, envs_per_record: int):
+        """Learner rank: the five item fields of a slab of packed records -> row (ring position mod L) of the global replay's field arrays.  Launch BETWEEN the ring
+        commit of the same slab (deferred advance) and the tree add that moves the position."""
+        rp = self.learner_replay
+        xr, xpe, xpi, xa, xpa = self._lx()
+        N.check(self.lib.srlx_agent57_unpack_fields(records.shape[0], int(envs_per_record), N.tptr(records), records.shape[1], rp._views[0], rp.L, N.tptr(xr), N.tptr(xa),
+                                                    N.tptr(xpa), N.tptr(xpe), N.tptr(xpi), N.torch_stream_ptr()))
 
     def _gather_inputs(self, b, st):
-        r, B = self.replay, self.replay.B
+        r, B = self.lreplay, self.lreplay.B
+        xr, xpe, xpi, xa, xpa = self._lx()
         N.check(self.lib.srlx_store_locate(r.h_store, B, N.tptr(b.indices), N.tptr(self.loc_env), N.tptr(self.loc_slot), None, st))
-        N.check(self.lib.srlx_agent57_gather_inputs(B, self.E, N.tptr(self.loc_env), N.tptr(self.loc_slot), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(self.x_r_int),
-                                                    N.tptr(self.x_prev_r_ext), N.tptr(self.x_prev_r_int), N.tptr(self.x_actor), N.tptr(self.x_prev_action), N.tptr(self.discount_list),
+        N.check(self.lib.srlx_agent57_gather_inputs(B, r.E, N.tptr(self.loc_env), N.tptr(self.loc_slot), N.tptr(b.actions), N.tptr(b.rewards), N.tptr(xr),
+                                                    N.tptr(xpe), N.tptr(xpi), N.tptr(xa), N.tptr(xpa), N.tptr(self.discount_list),
                                                     N.tptr(self.on_r_ext), N.tptr(self.on_r_int), N.tptr(self.on_action), N.tptr(self.on_actor), N.tptr(self.tg_r_ext),
                                                     N.tptr(self.tg_r_int), N.tptr(self.tg_action), N.tptr(self.tg_actor), N.tptr(self.b_discount), N.tptr(self.b_r_int), st))
 
-    def _update_networks(self, b, publish, st):
-        c, r = self.cfg, self.replay
+    def _update_networks(self, b, publish, st, wait=None):
+        c, r = self.cfg, self.lreplay
         B, W = r.B, self.Wn
         last = "rnd" if self.intrinsic else "q_ext"
         self._update_q(self.nets["q_ext"], b.rewards, publish, self.train_count_dev if last == "q_ext" else None)
@@ -461,6 +610,8 @@ class Agent57LightFastEngine:
         N.check(self.lib.srlx_agent57_priority(B, self.A, N.tptr(self.out["q_ext"]["td"]), None, N.tptr(self.out["q_int"]["td"]) if use_int else None, None, None,
                                                N.tptr(self.tg_actor), N.tptr(self.beta_list), None, None,
                                                N.tptr(self.priorities), st))
+        if wait is not None:
+            torch.cuda.current_stream(self.dev).wait_event(wait)
         r.update(b.indices, self.priorities)
 
     def _after_update(self):
@@ -476,29 +627,48 @@ class Agent57LightFastEngine:
         self.train_count += 1
 
     def learner_step(self, publish: Optional[int] = None) -> bool:
-        if self.replay.is_warmup_needed():
+        """Returns False while the replay is below warm-up.  A pending `self.ingest` rides on this update."""
+        if self.lreplay.is_warmup_needed():
             return False
-        g = self._graphs.get(publish)
+        ing, self.ingest = self.ingest, None
+        ing_key, ing_fn = (ing[0], ing[1]) if ing is not None else (None, None)
+        key = (publish, ing_key)
+        g = self._graphs.get(key)
         if g is None and self._capturing and not self._in_capture:
             torch.cuda.current_stream(self.dev).synchronize()
             g = torch.cuda.CUDAGraph()
             self._in_capture = True
             try:
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._learner_body(publish)
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (other threads -- the RCCL watchdog -- may touch the runtime meanwhile)
+                    self._learner_body(publish, ingest=ing_fn)
             finally:
                 self._in_capture = False
-            self._graphs[publish] = g
+            self._graphs[key] = g
         if g is not None:
             g.replay()
         else:
-            self._learner_body(publish)
+            self._learner_body(publish, ingest=ing_fn)
         self._after_update()
         return True
 
+    def run_updates(self, updates: int) -> int:
+        """`updates` updates NOT beside this engine's actors (a learner-only rank): on the learner's stream, ordered after the current stream and joined back to it.  A
+        pending `ingest` rides on the first update or runs by itself."""
+        cur = torch.cuda.current_stream(self.dev)
+        self.s_learner.wait_stream(cur)
+        ran = 0
+        with torch.cuda.stream(self.s_learner):
+            for _ in range(updates):
+                ran += int(self.learner_step(None))
+            if self.ingest is not None:
+                ing, self.ingest = self.ingest, None
+                ing[1]()
+        cur.wait_stream(self.s_learner)
+        return ran
+
     def fork_learner(self, updates: int) -> int:
         """overlap: `updates` updates on the learner's stream, ordered after everything enqueued on the current stream so far; the last one publishes."""
-        if updates <= 0 or self.replay.is_warmup_needed():
+        if (updates <= 0 or self.lreplay.is_warmup_needed()) and self.ingest is None:
             return 0
         self._ev_fork.record(torch.cuda.current_stream(self.dev))
         self.s_learner.wait_event(self._ev_fork)
@@ -510,6 +680,9 @@ class Agent57LightFastEngine:
                     ran += 1
                     if pub is not None:
                         self._published = pub
+            if self.ingest is not None:  # no update took the pending ingest with it (warm-up, or none asked for): commit it here, in stream order
+                ing, self.ingest = self.ingest, None
+                ing[1]()
             self._ev_join.record(self.s_learner)
         self._learner_pending = True
         return ran
@@ -522,7 +695,7 @@ class Agent57LightFastEngine:
     def capture_graphs(self, warm_updates: int = 1):
         """From now on every update variant (publishing into set 0 / 1 / none) is captured into a HIP graph the first time it runs.  Call once the replay is warm:
         `warm_updates` eager updates run first (library scratch, event creation)."""
-        if self._capturing or self.replay.is_warmup_needed():
+        if self._capturing or self.lreplay.is_warmup_needed():
             return
         self.join_learner()
         torch.cuda.synchronize(self.dev)
@@ -571,7 +744,7 @@ class Agent57LightFastEngine:
 
     def info(self) -> dict:
         self.join_learner()
-        d = dict(train_count=self.train_count, memory=self.replay.length())
+        d = dict(train_count=self.train_count, memory=self.lreplay.length())
         if self.train_count > 0:
             d.update(self.losses())
             d["loss"] = d["ext_loss"]

@@ -505,8 +505,11 @@ class DistributedRainbow:
         return dict(loss=float("nan"), train_count=0, sync=0, memory=0)
 
 
-class DistributedAgent57Light:
-    """BASELINE.json configs[3]: Agent57_light on `world` ranks -- actor ranks x E environments, learner + global replay on rank 0 (7 actor
+class DistributedAgent57LightGeneral:
+    """The round-3 form of the configs[3] job, kept for the geometries the all-libsrlx engine does not cover (`DistributedAgent57Light` below the class is what
+    84 x 84 x 4 configs get: mp_runner picks): image trunks in libsrlx, dense tails and optimisers in torch (device/agent57_light.py), live tensors exchanged with
+    `TransitionBus.push_begin / push_end`.
+    Agent57_light on `world` ranks -- actor ranks x E environments, learner + global replay on rank 0 (7 actor
     GPUs + 1 learner GPU from 4 ranks up; with fewer ranks rank 0 also acts).  Every rank runs an `Agent57LightEngine` on a short local ring
     (frame stacking, its environments' episodic memories and UCB controllers: the intrinsic reward is an ACTOR-side quantity in the
     reference too, agent57_light.py:383-391).  Per lock-step an actor rank ships next frame, action, reward, flags and the five UVFA /
@@ -656,4 +659,190 @@ class DistributedAgent57Light:
         d = dict(train_count=self.train_count, memory=self.replay.length())
         if self.is_learner and self.train_count > 0:
             d.update(self.local.learner.losses())
+        return d
+
+
+class DistributedAgent57Light:
+    """BASELINE.json configs[3]: Agent57_light on `world` ranks -- actor ranks x E environments, learner + global replay on rank 0 (7 actor GPUs + 1 learner GPU from
+    4 ranks up; with fewer ranks rank 0 also acts) -- on the all-libsrlx engine (device/agent57_fast.py) and the slot exchange of `DistributedRainbow` (round 6; the
+    reference: srl/base/run/play_mp.py:121-165 actor loop, :248-318 trainer + drain thread, :540-571 process layout; the actor-side intrinsic reward of
+    agent57_light.py:383-391).
+
+    An ACTOR rank runs `Agent57LightFastEngine(role="actor")`: its five networks' passes read parameter sets published out of band after every weight broadcast, its
+    environments' episodic memories and UCB controllers live on it; per lock-step it ships ONE packed record (srlx_agent57_pack_record: action, reward, flags and the
+    five item fields -- intrinsic reward, arm, previous action, previous rewards -- of its E lanes) + its frames to the learner rank as a group of two sends, waited
+    for between its NEXT policy passes and its environments.  The LEARNER rank owns ring + tree + field arrays for all actor ranks' environments: it posts one group
+    of receives per lock-step into staging slot t mod 2 and commits the slab that arrived during the PREVIOUS lock-step INSIDE its update -- ring commit
+    (srlx_store_commit_step_packed), item fields (srlx_agent57_unpack_fields), tree add on a side stream behind the update's draw, the priority write-back behind
+    them: the tree sees draw, add, write-back in that order and the learner rank's period is max(update, receive).  The reference moves the same information as
+    pickled 11-field items on a queue and a pickled list of five state_dicts on a timer (play_mp.py:76-118,289-318; model_torch.py:148-156)."""
+
+    FIELDS = 5  # r_int, arm, prev_action, prev_r_ext, prev_r_int (csrc/srlx_agent57.hip: kA57Fields)
+    SLOTS = 2
+
+    def __init__(self, rl_config, n_envs: int, device: int, episode_len: int = 200, sync_interval: int = 16, learner_acts: Optional[bool] = None, seed: int = 0,
+                 env=None, parameter=None, always_collective: bool = False, overlap: Optional[bool] = None):
+        import copy
+
+        from simple_distributed_rl_amd.device.agent57_fast import Agent57LightFastEngine
+        from simple_distributed_rl_amd.device.replay import DeviceReplay
+
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.dev = torch.device(f"cuda:{device}")
+        self.sync_interval = int(sync_interval)
+        self.is_learner = self.rank == 0
+        self.learner_acts = (self.world < 4) if learner_acts is None else bool(learner_acts)
+        if self.world == 1:
+            self.learner_acts = True
+        self.acts = self.learner_acts or not self.is_learner
+        self.first_actor_rank = 0 if self.learner_acts else 1
+        self.n_actor_ranks = self.world - self.first_actor_rank
+        E = self.E = int(n_envs)
+        self.cfg = rl_config
+        W = rl_config.window_length
+        H, W_ = int(rl_config.observation_space.shape[0]), int(rl_config.observation_space.shape[1])
+        local_cfg = copy.deepcopy(rl_config)
+        local_cfg.memory.capacity, local_cfg.memory.warmup_size = E * 4, 1 << 60  # the local ring only stacks frames; nobody samples it
+        self.bus = TransitionBus(E, H * W_, torch.uint8, self.dev, always_collective=always_collective, extra_floats=self.FIELDS,
+                                 actor_ranks=range(self.first_actor_rank, self.world))
+        self.bus.enable_slots(self.SLOTS)
+        # every rank draws its environments, its exploration and its arms from its OWN stream (ranks acting on the same broadcast weights must not produce
+        # byte-identical transitions); the learner's replay seed stays `seed`
+        kw = dict(episode_len=episode_len, seed=seed + 1_000_003 * self.rank, env=env, parameter=parameter, ring_len=1 + W + 4)
+        if self.is_learner:
+            total = self.n_actor_ranks * E
+            mem = rl_config.memory
+            mk = mem.kwargs if mem.name != "ReplayBuffer" else {}
+            ring_len = -(-mem.capacity // total) + 1 + W
+            self.replay = DeviceReplay(total, ring_len, H * W_, W, 1, int(rl_config.action_space.n), rl_config.batch_size, True, False, float(mk.get("alpha", 0.0)),
+                                       float(mk.get("beta_initial", 0.4)), int(mk.get("beta_steps", 1_000_000)), float(mk.get("epsilon", 1e-4)), mem.warmup_size, seed,
+                                       device)
+            self.replay.enable_deferred_advance()  # every ring commit of the global replay is followed by its tree add (`_ingest_fn`): the add moves the position
+            self.local = Agent57LightFastEngine(local_cfg, E, device, role="both" if self.acts else "learner", learner_replay=self.replay, overlap=overlap, **kw)
+        else:
+            self.local = Agent57LightFastEngine(local_cfg, E, device, role="actor", **kw)
+            self.replay = self.local.replay
+            self.local.before_env = self.bus.send_end  # the previous slab's frames must have left before the environments overwrite them
+        eng = self.local
+        self.flat = flatten_parameters(torch.nn.ModuleList(eng.modules()))  # model_torch.py:148-156: the five networks as ONE buffer
+        eng.rebind()  # the parameters moved: handles, optimisers and pointer tables read their new addresses
+        self.step_count, self._next_ingest, self.env_steps_local = 0, 0, 0
+        self.bus.broadcast_params(self.flat)
+        eng.on_weights_broadcast()
+        # first observations of every environment -> global ring position 0 (a one-off synchronous exchange through slot 0; the records are not used)
+        if self.is_learner:
+            self.bus.recv_begin(0)
+            if self.acts:
+                self.bus.put_own(0, eng.record, eng.first_obs)
+            self.bus.recv_end()
+            self.replay.reset_all(self.bus.slot_obs[0])
+        else:
+            self.bus.send_begin(eng.record, eng.first_obs)
+            self.bus.send_end()
+        torch.cuda.synchronize(self.dev)
+
+    @property
+    def global_envs(self) -> int:
+        return self.n_actor_ranks * self.E
+
+    @property
+    def train_count(self) -> int:
+        return self.local.train_count
+
+    @property
+    def overlap(self) -> bool:
+        return self.local.overlap
+
+    def _ingest_fn(self, j: int):
+        """The launches that commit slab j: ring (frames, scalars, item masks), item fields, tree add -- out of staging slot j % SLOTS."""
+        rp, bus, eng, E = self.replay, self.bus, self.local, self.E
+        a = j % self.SLOTS
+
+        def fn():
+            rp.commit_packed(bus.slot_scal[a], E, self.FIELDS, bus.slot_obs[a])
+            eng.ingest_fields(bus.slot_scal[a], E)  # (reads the ring position the add below moves)
+            rp.add_masked()
+
+        return (a,), fn
+
+    def _ingest_ready(self, k: int):
+        """Slab to commit during lock-step k, or None: slab j has arrived when lock-step j is over."""
+        j = self._next_ingest
+        return j if j <= k - 1 else None
+
+    def _act(self, events):
+        eng = self.local
+        if events is not None:
+            events[0].record()
+        eng.actor_step()  # (an actor rank: bus.send_end() of the previous slab sits between the policy passes and the environments)
+        if events is not None:
+            events[1].record()
+        self.env_steps_local += self.E
+        return eng.pack_record(), eng.env.next_obs
+
+    def step(self, learner_updates: int = 1, events=None):
+        """One lock-step of the whole job.  Every rank issues exactly one group of point-to-point transfers per lock-step (and every `sync_interval` lock-steps the
+        parameter broadcast behind it), in the same order everywhere."""
+        eng, bus, k = self.local, self.bus, self.step_count
+        if self.is_learner:
+            bus.recv_begin(k % self.SLOTS)  # slab k lands while this lock-step runs
+            j = self._ingest_ready(k)
+            if j is not None:
+                eng.ingest = self._ingest_fn(j)
+            if self.acts:
+                if eng.overlap:
+                    eng.fork_learner(learner_updates)  # the update (and the slab's commit inside it) beside this rank's own actors
+                rec, obs = self._act(events)
+                bus.put_own(k % self.SLOTS, rec, obs)
+                if eng.overlap:
+                    eng.join_learner()
+                else:
+                    eng.run_updates(learner_updates)
+                bus.recv_end()
+                eng._flip()
+            else:
+                if events is not None:
+                    events[0].record()
+                    events[1].record()
+                eng.run_updates(learner_updates)
+                bus.recv_end()
+            if j is not None:  # (after the updates: their warm-up gate saw the replay as the draw did)
+                self.replay.note_commit()
+                self._next_ingest = j + 1
+        else:
+            rec, obs = self._act(events)
+            bus.send_begin(rec, obs)
+        self.step_count += 1
+        if self.step_count % self.sync_interval == 0:
+            if self.is_learner:
+                eng.join_learner()  # broadcast consistent weights: not while Adam is writing them
+            bus.broadcast_params(self.flat)
+            if not self.is_learner:
+                eng.on_weights_broadcast()
+
+    def flush(self):
+        """Commit the slabs that have arrived and are still staged (end of a run)."""
+        if not self.is_learner:
+            self.bus.send_end()
+            torch.cuda.synchronize(self.dev)
+            return
+        self.local.join_learner()
+        while self._next_ingest < self.step_count:
+            j = self._next_ingest
+            self._ingest_fn(j)[1]()
+            self.replay.note_commit()
+            self._next_ingest = j + 1
+        torch.cuda.synchronize(self.dev)
+
+    def capture_graphs(self):
+        """The actors' launches stay eager; the learner rank's update is captured per variant (set it publishes into x staging slot it commits) the first time each
+        runs -- after at least one eager update (library scratch, event creation)."""
+        if self.is_learner and not self.replay.is_warmup_needed():
+            self.local.capture_graphs(warm_updates=1 if self.local.train_count == 0 else 0)
+
+    def info(self):
+        d = dict(train_count=self.train_count, memory=self.replay.length() if self.is_learner else 0)
+        if self.is_learner and self.train_count > 0:
+            d.update(self.local.losses())
+            d["loss"] = d["ext_loss"]
         return d

@@ -130,8 +130,11 @@ def _make_engine(kind: str, cfg, device: int, plan: dict, env_spec: dict, opts: 
             from simple_distributed_rl_amd.base.env.registration import make as make_env_run
 
             cfg.setup(make_env_run(env_spec["env_config"]))
-        return D.DistributedAgent57Light(cfg, opts["lanes"], device, sync_interval=opts["sync_interval_steps"], learner_acts=plan["learner_acts"],
-                                         seed=int(env_spec.get("seed") or 0), env=_env_factory(env_spec), parameter=parameter)
+        from simple_distributed_rl_amd.device.agent57_fast import why_not_fast
+
+        cls = D.DistributedAgent57Light if not why_not_fast(cfg) else D.DistributedAgent57LightGeneral  # (84 x 84 x 4: all-libsrlx engine + slot exchange)
+        return cls(cfg, opts["lanes"], device, sync_interval=opts["sync_interval_steps"], learner_acts=plan["learner_acts"],
+                   seed=int(env_spec.get("seed") or 0), env=_env_factory(env_spec), parameter=parameter)
     return D.DistributedRainbow(cfg, device, sync_interval=opts["sync_interval_steps"], learner_acts=plan["learner_acts"], env=_env_factory(env_spec))
 
 
@@ -238,6 +241,8 @@ def train_mp_on_engine(runner, context: RunContext, lanes: int, actor_num: int, 
         _JobLoop(eng, plan["backend"], updates_per_step, check_every).run(should_stop, before=lambda: hooks.fire("on_train_before"), after=after)
         if kind == "rainbow":
             _store_reference_weights(eng, parameter)
+        elif hasattr(eng.local, "export_parameter"):  # the all-libsrlx Agent57_light engine trains masters of its own
+            eng.local.export_parameter(parameter)
         state.shared_vars["actor_env_steps"] = eng.step_count * E_total
     finally:
         try:

@@ -523,13 +523,16 @@ class VectorAgent57Actor(VectorActor):
     Runner's own Parameter object (the five torch networks), so nothing has to be copied back."""
 
     def attach(self, context, state):
+        from simple_distributed_rl_amd.device.agent57_fast import Agent57LightFastEngine, why_not_fast
         from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
 
         dev = torch.device(context.used_device_torch)
         if self.engine is None:
             seed = 0 if context.seed is None else int(context.seed)
-            self.engine = Agent57LightEngine(self.rl_config, self.lanes, dev.index or 0, seed=seed, env=lambda replay: self._make_batch_env(replay, context),
-                                             parameter=self.parameter)
+            # 84 x 84 x 4 configs: every network pass and optimiser step in libsrlx (round 6; the trained networks are written back into the Runner's Parameter at
+            # `close`); other geometries: the round-5 engine (image trunks in libsrlx, dense tails in torch), which trains the Parameter's modules in place
+            cls = Agent57LightFastEngine if not why_not_fast(self.rl_config) else Agent57LightEngine
+            self.engine = cls(self.rl_config, self.lanes, dev.index or 0, seed=seed, env=lambda replay: self._make_batch_env(replay, context), parameter=self.parameter)
         eng = self.engine
         if eng.ledger is None:
             eng.ledger = EpisodeLedger(self.lanes, dev)
@@ -563,6 +566,8 @@ class VectorAgent57Actor(VectorActor):
         self._book(state, records, None, fire=False)
         state.episode_count = total[0]
         state.shared_vars["env_steps_exact"] = total[1]
+        if hasattr(eng, "export_parameter"):  # the all-libsrlx engine trains masters of its own: the Runner's Parameter gets the result
+            eng.export_parameter(self.parameter)
 
     def ensure_graphs(self):
         """The whole update as one HIP graph once the replay is warm (its warm-up updates are real ones and are counted by the caller)."""

@@ -548,3 +548,29 @@ def test_update_on_the_reference_trainer_step_at_84(fused):
             off = np.abs(upd - want) > 0.02 * lrs[net]
             assert off.mean() <= 0.03, (net, key, float(off.mean()))
             assert np.abs(upd - want).max() <= 2.001 * lrs[net], (net, key)
+
+
+def test_runner_train_and_train_mp_reach_the_fast_engine():
+    """`srl.Runner(env, agent57_light.Config()).train()` / `.train_mp()` with 84 x 84 x 4 frames run on the all-libsrlx engine (device/vector_runner.py picks it by
+    `why_not_fast`) and on `DistributedAgent57Light` (2 ranks time-sharing the test GPU over gloo); the trained networks come back in the Runner's own Parameter."""
+    N, lib, torch, dev = _env()
+    import simple_distributed_rl_amd as srl
+    from simple_distributed_rl_amd.algorithms import agent57_light
+    from simple_distributed_rl_amd.device.agent57_fast import Agent57LightFastEngine
+
+    cfg = agent57_light.Config(batch_size=8, actor_num=4, target_model_update_interval=5, episodic_memory_capacity=64, ucb_window_size=6)
+    cfg.window_length = 4
+    cfg.memory.capacity, cfg.memory.warmup_size = 2 * 8 * 30, 32
+    cfg.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1000)
+    cfg.hidden_block.set_dueling_network((64,))
+    runner = srl.Runner(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(84, 84), n_actions=3, episode_len=7)), cfg)
+    runner.set_vector_envs(8)
+    before = {k: v.detach().clone() for k, v in runner.parameter.q_ext_online.state_dict().items()}
+    st = runner.train(max_train_count=10, train_interval=8)
+    assert runner.vector_reason == "" and st.end_reason == "max_train_count over." and st.train_count >= 10
+    assert st.episode_count > 0 and st.memory.length() > 32
+    after = runner.parameter.q_ext_online.state_dict()
+    assert any(not torch.equal(before[k], after[k].to(before[k].device)) for k in before)  # the Runner's own parameter object carries the trained networks
+    st = runner.train_mp(actor_num=2, actor_devices=["cuda:0", "cuda:0"], max_train_count=12, timeout=300, sync_interval_steps=4)
+    assert runner.vector_reason == "" and st.end_reason == "max_train_count over." and st.train_count >= 12 and st.trainer_recv_q > 0
+    assert isinstance(Agent57LightFastEngine, type)

@@ -222,20 +222,26 @@ def _a57_worker(rank, world, port, ret, learner_acts):
         cfg.window_length = 4
         cfg.memory.capacity, cfg.memory.warmup_size = 2 * 8 * 30, 32
         cfg.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1000)
-        cfg.hidden_block.set_dueling_network((32,))
-        env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(20, 20), n_actions=3, episode_len=7)))
+        cfg.hidden_block.set_dueling_network((64,))
+        env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(84, 84), n_actions=3, episode_len=7)))
         cfg.setup(env)
         torch.manual_seed(100 + rank)  # ranks start from DIFFERENT weights: the first broadcast must make them equal
         eng = DistributedAgent57Light(cfg, 8, 0, episode_len=7, sync_interval=2, learner_acts=learner_acts, seed=5)
-        for _ in range(12):
+        for k in range(12):
+            if k == 8:
+                eng.capture_graphs()  # (the learner rank's update variants, captured the first time each runs)
             eng.step(learner_updates=1)
         eng.flush()
-        out = {"flat_sum": float(eng.flat.double().sum().item()), "env_steps_local": eng.env_steps_local, "arm_max": int(eng.local.ucb.arm.max().item())}
+        out = {"flat_sum": float(eng.flat.double().sum().item()), "env_steps_local": eng.env_steps_local}
+        if eng.acts:
+            out["arm_max"] = int(eng.local.ucb.arm.max().item())
         if rank == 0:
             out.update(eng.info())
             out["global_envs"] = eng.replay.E
-            out["x_nonzero"] = float(eng.x[..., 0].abs().sum().item())
-            out["arms_seen"] = sorted(set(eng.x[: eng.replay._steps_committed % eng.replay.L, :, 1].flatten().long().tolist()))
+            lx = eng.local.lx
+            out["x_nonzero"] = float(lx["r_int"].abs().sum().item())
+            out["arms_seen"] = sorted(set(lx["actor"][: eng.replay._steps_committed % eng.replay.L].flatten().long().tolist()))
+            out["graphs"] = len(eng.local._graphs)
         ret[rank] = out
     except Exception:
         import traceback
@@ -249,8 +255,9 @@ def _a57_worker(rank, world, port, ret, learner_acts):
 @pytest.mark.parametrize("learner_acts", [True, False])
 def test_distributed_agent57_light_two_ranks_one_gpu(learner_acts):
     """BASELINE.json configs[3] topology with Agent57_light (dedicated learner rank for learner_acts=False), two ranks time-sharing the
-    test GPU: transitions AND the five UVFA / intrinsic fields reach the learner's global replay, it trains all five networks, and the
-    flat broadcast leaves the actor rank with the learner's weights."""
+    test GPU, every rank on the all-libsrlx engine and the slot exchange (round 6): transitions AND the five UVFA / intrinsic fields reach the learner's global
+    replay as packed records committed inside its update (eagerly, then from lazily captured graphs), it trains all five networks, and the flat broadcast leaves
+    the actor rank with the learner's weights."""
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     try:
@@ -265,6 +272,7 @@ def test_distributed_agent57_light_two_ranks_one_gpu(learner_acts):
     assert r0["x_nonzero"] > 0 and set(r0["arms_seen"]) <= {0, 1, 2, 3} and len(r0["arms_seen"]) > 1  # intrinsic rewards and arms arrived
     assert (r0["env_steps_local"] > 0) == learner_acts and r1["env_steps_local"] == 12 * 8
     assert r0["flat_sum"] == r1["flat_sum"]  # step 12 ended with a broadcast (sync_interval = 2)
+    assert r0["graphs"] >= 2  # one captured update per staging slot
 
 
 def _a57_world1_worker(rank, world, port, ret, backend, always_collective):
@@ -281,18 +289,18 @@ def _a57_world1_worker(rank, world, port, ret, backend, always_collective):
         import simple_distributed_rl_amd as srl
         from simple_distributed_rl_amd import _native as N
         from simple_distributed_rl_amd.algorithms import agent57_light
-        from simple_distributed_rl_amd.device.agent57_light import Agent57LightEngine
+        from simple_distributed_rl_amd.device.agent57_fast import Agent57LightFastEngine
         from simple_distributed_rl_amd.device.dist import DistributedAgent57Light
 
         cfg = agent57_light.Config(batch_size=16, actor_num=4, target_model_update_interval=5, episodic_memory_capacity=64, ucb_window_size=6)
         cfg.window_length = 4
         cfg.memory.capacity, cfg.memory.warmup_size = 8 * 30, 32
         cfg.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1000)
-        cfg.hidden_block.set_dueling_network((32,))
-        env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(20, 20), n_actions=3, episode_len=7)))
+        cfg.hidden_block.set_dueling_network((64,))
+        env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(84, 84), n_actions=3, episode_len=7)))
         cfg.setup(env)
         torch.manual_seed(7)
-        ref = Agent57LightEngine(copy.deepcopy(cfg), 8, 0, episode_len=7, seed=5)
+        ref = Agent57LightFastEngine(copy.deepcopy(cfg), 8, 0, episode_len=7, seed=5)
         torch.manual_seed(7)
         eng = DistributedAgent57Light(copy.deepcopy(cfg), 8, 0, episode_len=7, sync_interval=4, seed=5, always_collective=always_collective)
         steps = 17
@@ -314,11 +322,11 @@ def _a57_world1_worker(rank, world, port, ret, backend, always_collective):
                 loc.append((e, s))
             (e1, s1), (e2, s2) = loc
             same = same and torch.equal(e1, e2) and torch.equal(s1, s2)
-            x2 = eng.x[s2, e2]
-            for k, t in enumerate((ref.x_r_int, ref.x_actor, ref.x_prev_action, ref.x_prev_r_ext, ref.x_prev_r_int)):
-                same = same and torch.equal(t[s1, e1].float(), x2[:, k])
+            lx = eng.local.lx
+            for t, k in ((ref.x_r_int, "r_int"), (ref.x_actor, "actor"), (ref.x_prev_action, "prev_action"), (ref.x_prev_r_ext, "prev_r_ext"), (ref.x_prev_r_int, "prev_r_int")):
+                same = same and torch.equal(t[s1, e1], lx[k][s2, e2])
         out["same"] = bool(same)
-        out["r_int_nonzero"] = float(eng.x[..., 0].abs().sum().item())
+        out["r_int_nonzero"] = float(eng.local.lx["r_int"].abs().sum().item())
         ret[rank] = out
     except Exception:
         import traceback
@@ -331,9 +339,9 @@ def _a57_world1_worker(rank, world, port, ret, backend, always_collective):
 
 @pytest.mark.parametrize("backend,always_collective", [("gloo", False), ("nccl", True)])
 def test_distributed_agent57_light_world_one_equals_the_single_engine(backend, always_collective):
-    """The pipelined exchange must hand the learner the transition of lock-step t with the UVFA / intrinsic fields of lock-step t: at world size 1
-    (the direct path that returns the live tensors, and RCCL's asynchronous gather into the staging buffers) the global replay + field arrays equal,
-    item by item, what a plain Agent57LightEngine with the same seed stored -- nothing torn, nothing shifted by one slot, the first lock-step there."""
+    """The slot exchange must hand the learner the transition of lock-step t with the UVFA / intrinsic fields of lock-step t: at world size 1 (the rank's own
+    rows are device copies into the staging slot; with RCCL initialised the group calls run too) the global replay + field arrays equal, item by item, what a plain
+    Agent57LightFastEngine with the same seed stored -- packed, staged, committed one lock-step late and unpacked: nothing torn, nothing shifted by one slot."""
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     try:

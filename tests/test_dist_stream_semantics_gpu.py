@@ -305,9 +305,10 @@ def test_the_fabric_exposes_a_missing_stream_wait(broken, monkeypatch):
 
 
 def _job_a57(sync: bool, delay_cycles: int, steps: int):
-    """BASELINE configs[3] (DistributedAgent57Light: dedicated learner rank + one actor rank) on the fabric.  No parameter broadcast after the first one
-    (sync_interval beyond the run): what the actor rank plays then depends on the initial weights only, so the learner's replay is reproducible whatever torch's
-    convolution backward does between runs -- the comparison isolates the TRANSITION exchange (`TransitionBus.push_begin / push_end`: live tensors in flight)."""
+    """BASELINE configs[3] (DistributedAgent57Light: dedicated learner rank + one actor rank) on the fabric, every rank on the all-libsrlx engine and the slot
+    exchange (round 6: packed records + frames into rotating staging slots, the slab's commit -- ring, item fields, tree add -- inside the learner's update behind its
+    draw, the priority write-back behind the add).  No parameter broadcast after the first one (sync_interval beyond the run): what the actor rank plays depends on the
+    initial weights only."""
     import simple_distributed_rl_amd as srl
     import simple_distributed_rl_amd.device.dist as dmod
     from simple_distributed_rl_amd.algorithms import agent57_light
@@ -325,22 +326,24 @@ def _job_a57(sync: bool, delay_cycles: int, steps: int):
             cfg.window_length = 4
             cfg.memory.capacity, cfg.memory.warmup_size = 8 * 12, 32  # (a 17-slot ring: the run below writes every slot, so the whole ring can be compared)
             cfg.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1000)
-            cfg.hidden_block.set_dueling_network((32,))
-            # 84 x 84 frames: every image block, the actors' and the learner's, then runs on the libsrlx trunks -- at other geometries they are torch convolutions,
-            # whose MIOpen solvers are picked by timing (and whose find-mode flag is process-global, shared here by the two rank threads): not reproducible
+            cfg.hidden_block.set_dueling_network((64,))
             env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(hw=(84, 84), n_actions=3, episode_len=7)))
             cfg.setup(env)
             if rank == 0:
                 torch.manual_seed(100)
             job = dmod.DistributedAgent57Light(cfg, 8, 0, episode_len=7, sync_interval=10**6, learner_acts=False, seed=5)
-            assert job.local._all_fused
-            for _ in range(steps):
+            for k in range(steps):
+                if k == steps // 2:
+                    job.capture_graphs()  # (the second half replays the lazily captured update variants: one per staging slot)
                 job.step(learner_updates=1)
             job.flush()
             torch.cuda.synchronize()
             if rank == 0:
                 rp = job.replay
-                out["x"] = job.x.detach().clone()
+                lx = job.local.lx
+                out["x"] = torch.stack([lx[k].float() for k in ("r_int", "actor", "prev_action", "prev_r_ext", "prev_r_int")]).clone()
+                out["flat"] = job.flat.detach().clone()
+                out["losses"] = job.local.losses()
                 out["frames"] = torch.as_tensor(_DeviceBytes(rp.obs_base, rp.E * rp.L * rp.F), device="cuda").clone()
                 out["size"] = rp.per_state()["size"]
                 out["train_count"] = job.train_count
@@ -368,11 +371,13 @@ def _job_a57(sync: bool, delay_cycles: int, steps: int):
 
 
 def test_agent57_light_exchange_under_stream_ordered_transfers():
-    """The same check for the configs[3] job's exchange (the older `push_begin / push_end` protocol: the tensors of lock-step t are in flight, uncopied, while the
-    actor rank's next network pass runs): frames and the five UVFA / intrinsic fields in the learner's global replay, bit for bit."""
+    """The same check for the configs[3] job (round 6: on the slot exchange with the in-update ingest, like the Rainbow job above): frames and the five UVFA /
+    intrinsic fields in the learner's global replay, the learner's weights (all five networks, one flat buffer) and its four losses -- bit for bit between
+    synchronous transfers and asynchronous ones delayed by ~3 ms on a communicator stream of their own."""
     steps = 22
     want = _job_a57(sync=True, delay_cycles=0, steps=steps)
     got = _job_a57(sync=False, delay_cycles=6_000_000, steps=steps)
     assert want["actor_steps"] == steps * 8 and want["size"] == got["size"] > 0 and want["train_count"] > 0
     assert torch.equal(got["frames"], want["frames"]), "frames differ: a transfer was overtaken by the kernels around it"
     assert torch.equal(got["x"], want["x"]), "UVFA / intrinsic fields differ"
+    assert torch.equal(got["flat"], want["flat"]) and got["losses"] == want["losses"], "the learner trained on something else"

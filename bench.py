@@ -337,7 +337,7 @@ def main():
             "lockstep": lockstep, "actor_stream": (args.actor_stream + "-priority HIP stream (a hardware-queue pool of its own); update graph three branches wide") if getattr(getattr(eng, "local", eng), "actor_stream", None) is not None else "torch's current stream",
             "qnet": ("libsrlx: float32 results; forward = float32 products as exact split-bf16 partial products on v_mfma_f32_32x32x16_bf16 (conv1 3, conv2 / conv3 / "
                      "first dense layer 6 per multiply-add), float32 accumulate; " +
-                     ("hand-written backward (no autograd)" if getattr(local, "mfma_train", False) else "torch autograd backward (SRLX_TORCH_BACKWARD=1 yardstick)")),
+                     ("hand-written backward (no autograd)" if getattr(local, "mfma_train", False) else "torch autograd backward (EngineSchedule.autograd_yardstick)")),
             "actor_learner_overlap": (not args.no_overlap) if dist is None else True,
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "backend": "none" if dist is None else args.backend,
@@ -891,7 +891,7 @@ def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0, probe_stats=None):
     pipe = lambda b16, k: ("bf16 pipe, %d exact partial products per multiply-add" % k) if b16 else "f32 pipe (v_mfma_f32_32x32x2_f32)"  # noqa: E731
     fc1_planes = bool(getattr(local.inf_actor, "_planes", False))
     fast = bool(getattr(local, "fast", False))
-    neighbour = int(os.environ.get("SRLX_FC1_NEIGHBOUR", "4")) if fast else 0
+    neighbour = int(cfg.schedule.fc1_neighbour) if fast else 0
     fc1_alg_bytes = (E * flat * 6 + 2 * cfg.hidden_units * flat * 6 if fc1_planes else E * flat * 4 + 2 * cfg.hidden_units * flat * 4) + 4 * E * 2 * cfg.hidden_units * 4 if flat else None
     fc1_traffic = _pmc_traffic("fc1" if fc1_planes else "k_gemm_s16")
     fc1 = None

@@ -52,7 +52,7 @@ class TransitionBus:
         self.is_learner = self.rank == learner_rank
         self.actor_ranks = list(range(self.world)) if actor_ranks is None else [int(r) for r in actor_ranks]
         self.contributes = self.rank in self.actor_ranks
-        self.p2p = ((self.world > 1) and os.environ.get("SRLX_BUS_GATHER", "0") != "1") if p2p is None else bool(p2p)  # SRLX_BUS_GATHER=1: the gather collective (A/B, debugging)
+        self.p2p = (self.world > 1) if p2p is None else bool(p2p)  # (p2p=False: the gather collective)
         self.sent_bytes = self.recv_bytes = 0  # what this rank put on / took off the wire (tests: a learner-only rank sends nothing)
         self._pending, self._direct, self._keep, self._staged_in = [], None, None, []
         if self.is_learner:

@@ -26,6 +26,24 @@ from simple_distributed_rl_amd.device.qnet import DeviceAdam, EngineQNet, QNetIn
 
 
 @dataclass
+class EngineSchedule:
+    """How the engine arranges its launches -- nothing here changes a result beyond float32 summation order (the tests compare the variants).  These were
+    SRLX_* environment switches through round 5; a schedule is part of the configuration of a run, not of the process environment."""
+    fast: Optional[bool] = None  # the round-4/5 lock-step wherever it applies (None), never (False), or raise where it does not (True: as RainbowEngine(fast=True))
+    lagged_add: bool = True  # single-GPU fast lock-step: the tree add of lock-step t rides on a side branch of update t + 1 (False: the add behind the join, round 4's order)
+    predraw: Optional[bool] = None  # the next update's batch drawn behind this update's write-back (None: on learner-only ranks)
+    fc1_neighbour: int = 4  # K splits of the actors' half-CU first-dense-layer kernel beside an update (0: the CU-filling kernel)
+    fc1_planes: str = "auto"  # engines off the fast path: operand planes for chip-filling policy passes ("auto": only where no learner shares the GPU; "1" / "0")
+    actor_stream: Optional[str] = None  # "low" / "normal" / "high": the actors' side on a stream of that priority level (None: the caller's current stream)
+    learner_priority: int = -1  # priority of the learner's launch stream
+    fused_adam: bool = True  # Adam inside the launches that finish each gradient (False: gradients written out, srlx_adam_step as a launch -- tests read p.grad)
+    fused_adam_rest: bool = True  # ... for the eleven tensors behind the first dense layer's weight too
+    fused_td: bool = True  # TD target / Huber / priorities in the backward pass's head kernel (False: a launch of their own)
+    autograd_yardstick: bool = False  # the gradient step through torch autograd on float32 pixels: a TEST yardstick, never a fallback
+    fused_draw: bool = True  # PER draw + item gather as one launch
+
+
+@dataclass
 class RainbowDeviceConfig:
     # --- rainbow.Config fields (rainbow.py:57-114); defaults = set_atari_config (rainbow.py:116-148)
     batch_size: int = 32
@@ -59,6 +77,7 @@ class RainbowDeviceConfig:
     n_actions: int = 6
     n_envs: int = 1024
     seed: int = 0
+    schedule: EngineSchedule = field(default_factory=EngineSchedule)
 
 
 class SyntheticAtariVecEnv:
@@ -101,7 +120,7 @@ class RainbowEngine:
 
     Every network pass is hand-written HIP (libsrlx `srlx_qnet_*`): the actors' policy pass, the learner's online /
     target evaluation and the gradient step's forward + backward, with plain dense layers or NoisyLinear ones
-    (`enable_noisy_dense`, the reference's own Atari configuration).  `SRLX_TORCH_BACKWARD=1` swaps the gradient step for
+    (`enable_noisy_dense`, the reference's own Atari configuration).  `EngineSchedule(autograd_yardstick=True)` swaps the gradient step for
     torch autograd on float32 pixels: a test-only yardstick (tests/test_engine_gpu.py), never a fallback -- shapes the
     kernels do not cover raise."""
 
@@ -117,13 +136,13 @@ class RainbowEngine:
         step (the reference's distributed actors do the same on a timer, play_mp.py:121-165), so no
         kernel ever reads weights that another stream is updating.
 
-        actor_stream="low" (the round-4 lock-step only; SRLX_ACTOR_STREAM overrides): the engine creates a LOW-priority HIP stream and makes it the calling thread's
+        actor_stream="low" (the round-4 lock-step only; default: cfg.schedule.actor_stream): the engine creates a LOW-priority HIP stream and makes it the calling thread's
         current stream (torch.cuda.set_stream) -- everything the caller enqueues from now on, the actors' side of the engine included, runs on it.  HIP keeps one
         pool of hardware queues per priority level and replays a graph's branches on normal-priority internal streams, so on a pool of their own the actors never
         queue behind a branch of the update; the update may then run THREE branches wide (the first dense layer's Adam-fused weight gradient on a branch of its own:
         srlx_qnet_set_fc1_branch).  Same kernels, same results; None: the current stream stays what it is and the update stays two branches wide.
 
-        fast (None = wherever it applies, SRLX_FAST=0 switches it off; True raises where it does not): the round-4 lock-step for an overlapping engine with
+        fast (None = cfg.schedule.fast, whose None = wherever it applies; True raises where it does not): the round-4 lock-step for an overlapping engine with
         chip-filling policy passes -- six launches on the actors' stream instead of fifteen and nothing but the PER add behind the join:
           * the policy pass selects its actions in the head kernel (srlx_qnet_forward_u8_policy: `north_star`'s fused policy step);
           * the environments' frames and scalars are one launch, the ring commit is one launch that also writes the next pass's frame-offset table, runs BEFORE
@@ -148,16 +167,17 @@ class RainbowEngine:
             ring_len = -(-cfg.memory_capacity // E) + pad  # item_len * E >= capacity
         self.noisy = bool(cfg.enable_noisy_dense)
         self.mfma = True  # (kept for callers that used to branch on it: there is no other network path)
-        self.autograd_yardstick = os.environ.get("SRLX_TORCH_BACKWARD", "0") == "1"
+        sch = self.schedule = cfg.schedule
+        self.autograd_yardstick = bool(sch.autograd_yardstick)
         covered = cfg.filters == 32 and cfg.hidden_units <= 512 and cfg.hidden_units % 32 == 0 and B <= 64 and H == W_ and W_ % 4 == 0 and cfg.dueling_type != "max"
         if not covered and not self.autograd_yardstick:
             raise ValueError("RainbowEngine: the hand-written gradient step covers the DQN image block with 32 filters on square frames (side % 4 == 0), one dueling "
                              f"layer of <= 512 units (average / none) and batches <= 64; got filters={cfg.filters}, hidden={cfg.hidden_units}, batch={B}, "
                              f"frames={cfg.obs_hw}, dueling='{cfg.dueling_type}'.  There is no fallback network path.")
         self.mfma_train = covered and not self.autograd_yardstick
-        fused_adam = self.mfma_train and not self.noisy and os.environ.get("SRLX_NO_FUSED_ADAM", "0") != "1" and role != "actor"
+        fused_adam = self.mfma_train and not self.noisy and sch.fused_adam and role != "actor"
         fast_actor = self.fused_convs and not self.noisy and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0
-        fast_learner = fused_adam and self.fused_convs and os.environ.get("SRLX_NO_FUSED_TD", "0") != "1"
+        fast_learner = fused_adam and self.fused_convs and sch.fused_td
         # (actor-side initial priorities on one GPU keep the fifteen-launch lock-step: their tree add runs one lock-step behind the ring commit, which the
         #  deferred-advance commit does not model; a distributed learner -- learner_replay -- commits ring and tree together, two slabs behind: device/dist.py)
         can_fast = {"both": self.overlap and fast_actor and fast_learner and (not cfg.actor_initial_priority or learner_replay is not None),
@@ -165,14 +185,18 @@ class RainbowEngine:
         if fast and not can_fast:
             raise ValueError("RainbowEngine(fast=True): needs overlap, the 84 x 84 x 4 / 32-filter geometry, plain dense layers, >= 512 environments in multiples of 128, "
                              "a hidden layer in multiples of 64 and max-priority adds")
-        self.fast = can_fast and (bool(fast) if fast is not None else os.environ.get("SRLX_FAST", "1") != "0")
+        if fast is None:
+            fast = sch.fast
+        if fast and not can_fast:
+            raise ValueError("RainbowEngine: schedule.fast=True where the fast lock-step does not apply")
+        self.fast = can_fast and (bool(fast) if fast is not None else True)
         # the single-GPU round-5 lock-step (actors + learner here, the learner's replay = this ring): the tree add of a lock-step runs one lock-step behind its ring
         # commit, on a side branch of the next update -- the ring gets one spare slot (DeviceReplay(lagged_add=True)).  SRLX_LAGGED_ADD=0: the add behind the join.
-        lag = self.fast and role == "both" and learner_replay is None and os.environ.get("SRLX_LAGGED_ADD", "1") != "0"
+        lag = self.fast and role == "both" and learner_replay is None and sch.lagged_add
         self.replay = DeviceReplay(
             E, ring_len + (1 if lag else 0), H * W_, cfg.window_length, n, A, B, True, cfg.enable_reward_clip,
             cfg.memory_alpha, cfg.memory_beta_initial, cfg.memory_beta_steps, cfg.memory_epsilon, cfg.memory_warmup_size, cfg.seed, device,
-            has_duplicate=cfg.memory_has_duplicate, lagged_add=lag,
+            has_duplicate=cfg.memory_has_duplicate, lagged_add=lag, fused_draw=sch.fused_draw,
         )
         if env is None:
             self.env = SyntheticAtariVecEnv(self.replay, episode_len)
@@ -180,7 +204,7 @@ class RainbowEngine:
             self.env = env(self.replay) if callable(env) else env
 
         self.actor_stream = None
-        want = os.environ.get("SRLX_ACTOR_STREAM") or actor_stream
+        want = actor_stream or sch.actor_stream
         if self.fast and want and want != "default":
             import ctypes
 
@@ -227,7 +251,7 @@ class RainbowEngine:
                 self.q_actor = make_net()
                 self.q_actor.load_state_dict(self.q_online.state_dict())
             # high priority: the learner's many small kernels slot in between the actor's chip-filling GEMMs
-            self.s_learner = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("SRLX_LEARNER_PRIO", "-1")))
+            self.s_learner = torch.cuda.Stream(device=self.dev, priority=int(sch.learner_priority))
             self._ev_fork = torch.cuda.Event()
             self._ev_join = torch.cuda.Event()
         else:
@@ -236,7 +260,7 @@ class RainbowEngine:
                 self.s_learner = torch.cuda.Stream(device=self.dev, priority=-1)
         # one inference handle per concurrent user (each owns its activation buffers and, for noisy layers, its noise stream)
         self.inf_actor = QNetInference(self.q_actor, E, device, noise_seed=cfg.seed * 3 + 0xA11CE)
-        planes = os.environ.get("SRLX_FC1_PLANES", "auto")
+        planes = str(sch.fc1_planes)
         if role == "learner":
             pass  # (never acts: no operand planes, no parameter sets)
         elif self.fast:
@@ -245,7 +269,7 @@ class RainbowEngine:
             # the passes run BESIDE the update: half-CU workgroups in a steady stream instead of one CU-filling workgroup per CU for the whole launch
             # (same-box A/B of the lock-step, tools/_r4_probe3.sh: 0.508 ms with 4 K splits -- 256 workgroups that leave half of every CU to the update --, 0.515
             # with 8, 0.528 with 16, 0.545 with the CU-filling kernel; SRLX_FC1_NEIGHBOUR=0 selects that one, = k the K splits)
-            self.inf_actor.set_fc1_neighbour(int(os.environ.get("SRLX_FC1_NEIGHBOUR", "4")))
+            self.inf_actor.set_fc1_neighbour(int(sch.fc1_neighbour))
         elif not self.noisy and E >= 512 and E % 128 == 0 and (2 * cfg.hidden_units) % 128 == 0 and (planes == "1" or (planes == "auto" and not overlap)):
             # Chip-filling policy passes with the first dense layer on pre-split bf16 operand planes (srlx_fc1_planes.hip): the GEMM itself is 1.6x faster
             # (85 against 137 us at 1024 rows), but beside a learner it LOSES: same-box A/B (tools/_ab_lockstep.sh) 0.565 against 0.511 ms per lock-step --
@@ -270,7 +294,7 @@ class RainbowEngine:
         self._init_common(cfg, E, B, A, H, W_)
         d = self.dev
         self.train_count_dev = torch.zeros(1, dtype=torch.int64, device=d)
-        self._fused_td = os.environ.get("SRLX_NO_FUSED_TD", "0") != "1"  # TD / Huber / priorities inside the backward's head kernel (A/B switch)
+        self._fused_td = bool(sch.fused_td)  # TD / Huber / priorities inside the backward's head kernel
         self.lreplay.count_updates_in(self.train_count_dev)  # train_count += 1 rides on the priority write-back's launch
         if fused_adam:
             # the 32 MB first dense layer takes its Adam step inside the backward pass, beside the convolution gradients (A/B switch for measurements)
@@ -296,7 +320,7 @@ class RainbowEngine:
                 N.check(self.lib.srlx_qnet_set_dgrad_split(self.inf_online.h, 2))
             if self._update_side:
                 N.check(self.lib.srlx_per_set_update_counter(self.lreplay.h_per, None))
-            if fused_adam and not self.noisy and os.environ.get("SRLX_ADAM_REST", "1") != "0":
+            if fused_adam and not self.noisy and sch.fused_adam_rest:
                 # no optimiser launch on the update's tail: the remaining eleven tensors take their steps in the launches that finish their gradients and in the
                 # packing launch (`publish_to` follows every backward pass of a fast engine)
                 self.optimizer.fuse_rest(self.inf_online)
@@ -323,7 +347,7 @@ class RainbowEngine:
         # this GPU's own actors the period is contention-bound and the move changed nothing (0.457 against 0.454 ms, same box; 0.441 against 0.434 for the 2-GPU
         # topology's acting learner rank): on for learner-ONLY ranks unless SRLX_PREDRAW says otherwise.
         self._predraw = bool(self.fast and self._update_side and self.s_ingest is not None and getattr(self.lreplay, "two_sets", False)
-                             and os.environ.get("SRLX_PREDRAW", "1" if (learner_replay is not None and role == "learner") else "0") == "1")
+                             and (sch.predraw if sch.predraw is not None else (learner_replay is not None and role == "learner")))
         self._bset, self._drawn, self._drawn_at = 0, None, 0
         self.s_predraw = torch.cuda.Stream(device=self.dev, priority=-1) if self._predraw else None
 

@@ -48,6 +48,7 @@ class DeviceReplay:
         sample_slack: int = 8,
         has_duplicate: bool = True,
         lagged_add: bool = False,
+        fused_draw: bool = True,
     ):
         """lagged_add (the single-GPU round-5 lock-step): the tree add of a lock-step is not launched behind its ring commit but handed to the NEXT update
         (`take_pending_add`), which runs it on a side branch between its draw and its priority write-back -- off the lock-step's serial tail.  Commits then carry
@@ -115,7 +116,7 @@ class DeviceReplay:
         self._views = (pos, nr, sie)
         self.needs_reset_ptr = nr  # uint8 [E]: lanes whose next lock-step only delivers the first frame of a new episode
         self.deferred_advance = False
-        self._fused_draw = __import__("os").environ.get("SRLX_NO_SAMPLE_GATHER", "0") != "1"  # (A/B switch)
+        self._fused_draw = bool(fused_draw)  # the draw and the item gather as ONE launch (srlx_per_sample_gather_train)
         self.table_fresh = False  # `frame_off_actor` holds the table of the CURRENT ring position (written by the last commit)
         self.has_duplicate = bool(has_duplicate)
         self._drew = False

@@ -12,18 +12,11 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 def _engine(torch_backward: bool, fused_adam: bool = True, fused_td: bool = True, **kw):
-    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+    from simple_distributed_rl_amd.device.rainbow import EngineSchedule, RainbowDeviceConfig, RainbowEngine
 
-    os.environ["SRLX_TORCH_BACKWARD"] = "1" if torch_backward else "0"
-    os.environ["SRLX_NO_FUSED_ADAM"] = "0" if fused_adam else "1"
-    os.environ["SRLX_NO_FUSED_TD"] = "0" if fused_td else "1"
-    try:
-        cfg = RainbowDeviceConfig(n_envs=8, batch_size=8, memory_capacity=8 * 64, memory_warmup_size=32, target_model_update_interval=4, lr=1e-4, seed=3)
-        return RainbowEngine(cfg, 0, episode_len=9, **kw)
-    finally:
-        os.environ.pop("SRLX_TORCH_BACKWARD", None)
-        os.environ.pop("SRLX_NO_FUSED_ADAM", None)
-        os.environ.pop("SRLX_NO_FUSED_TD", None)
+    cfg = RainbowDeviceConfig(n_envs=8, batch_size=8, memory_capacity=8 * 64, memory_warmup_size=32, target_model_update_interval=4, lr=1e-4, seed=3,
+                              schedule=EngineSchedule(autograd_yardstick=torch_backward, fused_adam=fused_adam, fused_td=fused_td))
+    return RainbowEngine(cfg, 0, episode_len=9, **kw)
 
 
 def test_training_pass_equals_autograd_path():

@@ -192,19 +192,17 @@ def test_half_cu_first_dense_layer_equals_the_other_forms():
 
 
 def _engines(E=512, actor_stream=None, **cfgkw):
-    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+    import dataclasses
+
+    from simple_distributed_rl_amd.device.rainbow import EngineSchedule, RainbowDeviceConfig, RainbowEngine
 
     kw = dict(n_envs=E, batch_size=32, memory_capacity=E * 12, memory_warmup_size=E * 4, target_model_update_interval=5, lr=1e-4, seed=3)
     kw.update(cfgkw)
     cfg = RainbowDeviceConfig(**kw)
-    os.environ["SRLX_FC1_NEIGHBOUR"] = "4"  # the K splits of the fifteen-launch engine's first dense layer: split-K partial sums associate alike, Q-values bit-equal
-    os.environ["SRLX_LAGGED_ADD"] = "0"  # the tree add behind the join, as the fifteen-launch lock-step orders it (round 5's default runs it inside the NEXT update:
-    #                                      the update then samples the tree one add older -- pinned against the oracle in test_lagged_add_tree_order_against_the_oracle)
-    try:
-        fast = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=True, actor_stream=actor_stream)
-    finally:
-        os.environ.pop("SRLX_FC1_NEIGHBOUR", None)
-        os.environ.pop("SRLX_LAGGED_ADD", None)
+    # fc1_neighbour = 4: the K splits of the fifteen-launch engine's first dense layer (split-K partial sums associate alike, Q-values bit-equal); lagged_add off: the
+    # tree add behind the join, as the fifteen-launch lock-step orders it (round 5's default runs it inside the NEXT update: the update then samples the tree one add
+    # older -- pinned against the oracle in test_lagged_add_tree_order_against_the_oracle)
+    fast = RainbowEngine(dataclasses.replace(cfg, schedule=EngineSchedule(fc1_neighbour=4, lagged_add=False)), 0, episode_len=7, overlap=True, fast=True, actor_stream=actor_stream)
     slow = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=False)
     assert fast.fast and not slow.fast
     slow.q_online.load_state_dict(fast.q_online.state_dict())
@@ -502,15 +500,15 @@ def test_full_size_engine_tree_order_against_the_oracle():
         eng.close()
 
 
-def test_synthetic_environments_do_not_depend_on_the_lagged_add(monkeypatch):
+def test_synthetic_environments_do_not_depend_on_the_lagged_add():
     """The synthetic environments key frames, rewards and episode ends by the ring position.  With the lagged add the device-resident position is the learner's view
     (it moves with the tree add, on the learner's stream), so the environments take the ACTORS' position as a launch argument (srlx_synth_env_step_at): rewards, episode
-    ends and frames of 40 lock-steps with updates equal those of the engine whose add follows the join (SRLX_LAGGED_ADD=0), whatever the streams do."""
-    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
+    ends and frames of 40 lock-steps with updates equal those of the engine whose add follows the join (EngineSchedule(lagged_add=False)), whatever the streams do."""
+    from simple_distributed_rl_amd.device.rainbow import EngineSchedule, RainbowDeviceConfig, RainbowEngine
 
     def run(lagged):
-        monkeypatch.setenv("SRLX_LAGGED_ADD", "1" if lagged else "0")
-        cfg = RainbowDeviceConfig(n_envs=512, batch_size=32, memory_capacity=512 * 9, memory_warmup_size=512 * 4, seed=7, target_model_update_interval=5)
+        cfg = RainbowDeviceConfig(n_envs=512, batch_size=32, memory_capacity=512 * 9, memory_warmup_size=512 * 4, seed=7, target_model_update_interval=5,
+                                  schedule=EngineSchedule(lagged_add=lagged))
         eng = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=True, actor_stream="low")
         try:
             assert eng.replay.lagged == lagged

@@ -161,7 +161,7 @@ def test_the_shipped_policy_pass_against_the_reference_network(kind, neighbour):
     assert np.array_equal(q[:B], q[B * 7:B * 8]), "the same sample gives the same bits wherever it sits in the batch"
 
 
-def _golden84_engine(fast: bool):
+def _golden84_engine(fast: bool, schedule=None):
     """A RainbowEngine carrying the golden's recipe weights whose next `_learner_body` trains on the golden's 16 items (7 frames each, written into the engine's ring
     by ordinary commits), with the golden's importance weights."""
     import ast
@@ -177,6 +177,8 @@ def _golden84_engine(fast: bool):
     B, n, E = frames.shape[0], 3, 512
     cfg = RainbowDeviceConfig(n_envs=E, batch_size=B, memory_capacity=E * 8, memory_warmup_size=E, lr=float(z["lr"]), discount=float(z["discount"]),
                               target_model_update_interval=1000, enable_reward_clip=False)
+    if schedule is not None:
+        cfg.schedule = schedule
     eng = RainbowEngine(cfg, 0, episode_len=1000, overlap=fast, fast=fast)
     assert eng.fast == fast
     eng.q_online.load_reference_state_dict(sd_on)
@@ -249,14 +251,15 @@ def test_fast_engine_learner_step_against_the_reference_trainer():
 
 
 @pytest.mark.gpu
-def test_learner_gradients_against_the_reference_trainer(monkeypatch):
+def test_learner_gradients_against_the_reference_trainer():
     """The hand-written backward pass at 84 x 84 against the reference's own gradients: 2048 sampled entries of EVERY `p.grad` that `loss.backward()` left in the
     reference's Trainer.train() (`grad.<key>` of the golden, caught at `optimizer.step()`: model_torch.py:107-109), with the optimiser as a launch of its own
-    (SRLX_NO_FUSED_ADAM=1: the same kernels write the gradients out instead of consuming them in their epilogues).  Bar: rel 1e-5 of the tensor's largest gradient
+    (EngineSchedule(fused_adam=False): the same kernels write the gradients out instead of consuming them in their epilogues).  Bar: rel 1e-5 of the tensor's largest gradient
     entry + rel 1e-4 per entry -- a gradient entry is a float32 sum of up to 16 x 441 products whose partial sums cancel (MIOpen-free CPU torch on the reference's
     side, ticketed MFMA partial sums here): the documented cancellation slack."""
-    monkeypatch.setenv("SRLX_NO_FUSED_ADAM", "1")
-    eng, z, keys_shapes = _golden84_engine(False)
+    from simple_distributed_rl_amd.device.rainbow import EngineSchedule
+
+    eng, z, keys_shapes = _golden84_engine(False, EngineSchedule(fused_adam=False))
     assert not eng.fast and eng.mfma_train
     eng._learner_body()
     torch.cuda.synchronize()

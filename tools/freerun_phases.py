@@ -10,7 +10,7 @@ from simple_distributed_rl_amd import _native as N
 from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig, RainbowEngine
 
 cfg = RainbowDeviceConfig(n_envs=1024, batch_size=32, memory_capacity=200_000, seed=0)
-eng = RainbowEngine(cfg, 0, 200, overlap=True)
+eng = RainbowEngine(cfg, 0, 200, overlap=True, actor_stream=os.environ.get("SRLX_ACTOR_STREAM") or None)  # (the tool's own command-line knob)
 assert eng.fast
 eng.prefill()
 for _ in range(8):

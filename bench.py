@@ -664,9 +664,22 @@ def subfigures(eng, args, inner):
     else:
         upd = eng.learner_step
     t_upd = timed(upd, reps)
+    # the reference's default operating point (srl/base/run/core_play.py:187-194: train_interval = 1 -- ONE update per environment step): a lock-step of E environment
+    # steps then carries E updates; the engine is bound by its update rate there
+    E = eng.cfg.n_envs
+    eng.step(E)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(E)
+    torch.cuda.synchronize()
+    t_ref = time.perf_counter() - t0
     return {
         "actors_only": {"ms_per_lock_step": 1e3 * t_act, "env_steps_per_s": eng.cfg.n_envs / t_act},
         "learner_only": {"ms_per_update": 1e3 * t_upd, "updates_per_s": 1.0 / t_upd},
+        "reference_ratio": {"what": "train_interval = 1 (the reference's default: one update per environment step, core_play.py:187-194): one lock-step of E environment "
+                                    "steps with E updates forked beside it", "updates_per_env_step": 1, "env_steps_per_s": E / t_ref, "updates_per_s": E / t_ref,
+                            "ms_per_lock_step": 1e3 * t_ref,
+                            "note": "the headline line runs 1 update per E = 1024 environment steps; at the reference's ratio the update rate is the bound"},
         "note": "the timed region runs both concurrently (actor pass on the main stream, updates on the learner's streams)",
     }
 
@@ -792,6 +805,39 @@ def role_timings(args, dev_index, actor_ranks=7):
 
     out["learner_rank"]["ingest_alone_ms"] = 1e3 * timed(add_only, 64)
     out["learner_rank"]["update_alone_ms"] = 1e3 * timed(lambda: eng.run_updates(1), 128)
+    # ---- the same period UNDER THE TRANSFERS' stream semantics (round 6): what RCCL brings to the learner rank besides the bytes -- a communicator stream of normal
+    # priority (ProcessGroupNCCL's default) that must find a hardware queue next to the update's branches, 2 x actor_ranks posted receives per period whose data lands
+    # in the staging slot the NEXT period's ingest reads, the host cost of posting them, and a stream-level wait at `recv_end`.  The transfers are device copies from
+    # "remote" buffers on this GPU (7.2 MB of frames + a 10 KB record per actor rank: the write traffic of the real thing, plus a read it would not have).
+    comm = torch.cuda.Stream(device=dev)
+    remote = [(torch.randint(0, 256, (rec,), dtype=torch.uint8, device=dev, generator=g), torch.randint(0, 256, (E, 84 * 84), dtype=torch.uint8, device=dev, generator=g))
+              for _ in range(actor_ranks)]
+    for r in range(actor_ranks):  # (valid records: the commit reads actions / flags out of them)
+        remote[r][0].copy_(slabs[0][0][r])
+    ev_post, ev_done = torch.cuda.Event(), torch.cuda.Event()
+
+    def learner_period_fabric():
+        k = state["k"]
+        scal, obs = slabs[k % 2]  # staging slot k % 2 receives; the ingest below commits the other one
+        cur = torch.cuda.current_stream(dev)
+        ev_post.record(cur)
+        comm.wait_event(ev_post)
+        with torch.cuda.stream(comm):
+            for r in range(actor_ranks):
+                scal[r].copy_(remote[r][0], non_blocking=True)
+                obs[r * E : (r + 1) * E].copy_(remote[r][1], non_blocking=True)
+            ev_done.record(comm)
+        eng.ingest = ingest_fn(k + 1)
+        eng.run_updates(1)
+        cur.wait_event(ev_done)  # recv_end
+        replay.note_commit()
+        state["k"] += 1
+
+    t_f = timed(learner_period_fabric, 256)
+    out["learner_rank"]["fabric_ms_per_period"] = 1e3 * t_f
+    out["learner_rank"]["fabric_over_bare"] = t_f / t
+    out["learner_rank"]["fabric_note"] = ("the period with 2 x %d receives per period posted on a communicator stream (device copies standing in for the xGMI transfers: "
+                                          "%.1f MB per period), a stream-level wait at recv_end and their host cost" % (actor_ranks, actor_ranks * (rec + E * 84 * 84) / 1e6))
     if os.environ.get("SRLX_ROLE_PROBE"):  # host time of one period, and the period with the host synchronising (is the host the bound?)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -805,8 +851,11 @@ def role_timings(args, dev_index, actor_ranks=7):
             torch.cuda.synchronize()
         out["learner_rank"]["synchronised_ms_per_period"] = 1e3 * timed(synced, 64)
     period = max(out["actor_rank"]["ms_per_lock_step"], out["learner_rank"]["ms_per_period"])
+    period_f = max(out["actor_rank"]["ms_per_lock_step"], out["learner_rank"]["fabric_ms_per_period"])
     out["predicted"] = {"actor_ranks": actor_ranks, "ms_per_lock_step": period, "env_steps_per_s": total / (period * 1e-3),
-                        "note": "max of the two roles' periods (links keep up: 7.2 MB per actor rank per lock-step over its own xGMI link); unmeasured on more than one GPU"}
+                        "with_fabric": {"ms_per_lock_step": period_f, "env_steps_per_s": total / (period_f * 1e-3)},
+                        "note": "max of the two roles' periods (links keep up: 7.2 MB per actor rank per lock-step over its own xGMI link); `with_fabric`: the learner "
+                                "rank's period rehearsed under the transfers' stream semantics; unmeasured on more than one GPU"}
     del eng, replay
     torch.cuda.empty_cache()
     return out
@@ -1014,6 +1063,9 @@ def per_micro(eng, draws=1 << 20, reps=20):
     ms = timed(lambda: N.check(r.lib.srlx_per_add(r.h_per, E, N.tptr(mask), N.PRIO_NONE_MASKED, 1, N.torch_stream_ptr())), 100)
     ops[f"add_{E}"] = {"us_per_call": 1e3 * ms, "adds_per_s": E / (ms * 1e-3), "algorithmic_bytes_per_item": 16 + depth * 16 + 8}
     out["ops"] = ops
+    out["regimes"] = ("frac_of_hbm_peak >= 0.5 (north_star's PER target) holds in the BULK regime only -- 2^20 draws per call and up, a regime no BASELINE config invokes; "
+                      "at training sizes the tree is latency-bound: ops.sample_32 / sample_64 / update_* are single-workgroup launches of a few KB whose cost is ~7 "
+                      "dependent cache-line fetches per draw plus the launch, ~1e-4 of the HBM roofline -- their figure of merit is us_per_call, not a bandwidth fraction")
     try:
         out["shim"] = per_shim_timing()
     except Exception as exc:  # a side figure must never take the measured line down with it

@@ -115,6 +115,12 @@ int srlx_per_add(srlx_per_t *h, int64_t n, const void *prio, int prio_kind, int 
 int srlx_per_sample(srlx_per_t *h, int64_t batch_size, int64_t step, const int64_t *d_step, const double *uniforms,
                     int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used,
                     int on_device, void *stream);
+/* The host loop of the reference's memory -- add one item, sample, update (srl/rl/memories/priority_replay_buffer.py:205-258; tests/quick/rl/memories/speedtest.py:15-58)
+ * -- as ONE launch per sample: `n_add` <= 16 adds queued since the tree was last observed (host values: final leaf priorities with SRLX_PRIO_RAW, or add_values = NULL
+ * with SRLX_PRIO_NONE) are applied inside the sampling launch, in order, exactly like srlx_per_add would; uniforms in and results out travel through a device-visible
+ * pinned slot and the host spins on a completion flag the kernel stores last (no stream synchronisation).  Host pointers; results as srlx_per_sample(on_device = 0). */
+int srlx_per_sample_after_adds(srlx_per_t *h, int64_t n_add, const double *add_values, int add_kind, int64_t batch_size, int64_t step, const double *uniforms,
+                               int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used, void *stream);
 /* The learner's call without the launch that draws its uniforms: uniform j is what srlx_rng_uniform(seed, d_counter, n_uniforms, u)
  * would have put into u[j], and *d_counter advances the same way -- results identical to that call followed by
  * srlx_per_sample(..., u, n_uniforms, ..., on_device = 1).  Device pointers only; n_uniforms within the single-workgroup sampler's range. */

@@ -1167,6 +1167,65 @@ __global__ void __launch_bounds__(512) k_add_wg(AddArgs a) {
     if (t == 0) add_commit(a);
 }
 
+// ---- n <= kTinyAddMax appending adds by ONE wave (round 6: the b1 shim's host loop adds one item between two samples, srl/rl/memories/priority_replay_buffer.py
+// :205-217; the 256-thread machinery above costs ~10 us for that).  The adds are applied one after the other like the reference's loop (proportional_memory.py:120-129):
+// leaf write, then lane d adds the change to the ancestor on depth d -- a node is always touched by the same lane, in add order: the fp64 sums of k_add_wg, bit for bit.
+constexpr int kTinyAddMax = 16;
+__device__ __forceinline__ void add_tiny_body(const AddArgs &a, int lane) {
+    const i64 write = add_start(a);
+    const double maxp = a.state->max_priority;
+    double seen_max = maxp;
+    for (i64 i = 0; i < a.n; i++) {
+        i64 slot = write + i;
+        if (slot >= a.cap) slot -= a.cap;
+        const i64 x = slot + a.cap - 1;
+        const double p = load_prio(a.prio, a.kind, i, a.eps, a.alpha, maxp);
+        const i64 px = a.tree.phys(x);
+        const double change = p - a.tree.T[px];  // (every lane reads the leaf before lane 0 overwrites it: the wave runs in lock-step and the load is waited for below)
+        const int dx = node_depth(x);
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) {
+            a.tree.T[px] = p;
+            a.tree.mirror(x, p);
+        }
+        if (lane < dx) {
+            const i64 node = ((x + 1) >> (dx - lane)) - 1;  // the ancestor on depth `lane`
+            const i64 pn = a.tree.phys(node);
+            a.tree.T[pn] = a.tree.T[pn] + change;
+        }
+        if (p > seen_max) seen_max = p;
+    }
+    if (lane == 0) {
+        if (a.track_max && seen_max > maxp) a.state->max_priority = seen_max;
+        add_commit(a);
+    }
+}
+__global__ void __launch_bounds__(64) k_add_tiny(AddArgs a) { add_tiny_body(a, threadIdx.x); }
+
+// The shim's `sample` with the adds queued since the last observation of the tree INSIDE the launch (values by value in the kernel arguments: no staging at all),
+// and a completion flag in host-visible memory for the caller to spin on (a stream synchronisation costs the host more than the kernel runs).
+struct TinyVals {
+    double v[kTinyAddMax];
+};
+__global__ void __launch_bounds__(kWgSample) k_add_sample_wg(AddArgs add, TinyVals vals, SampleArgs a, unsigned long long *done_flag, unsigned long long ticket) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double s_vals[kTinyAddMax];
+    if (add.n > 0) {
+        if (threadIdx.x < kTinyAddMax) s_vals[threadIdx.x] = vals.v[threadIdx.x];
+        __syncthreads();
+        add.prio = s_vals;
+        if (threadIdx.x < 64) add_tiny_body(add, threadIdx.x);
+        __threadfence();
+        __syncthreads();  // the tree the draw walks includes the adds
+    }
+    (void)sample_wg_body(a, smem);
+    if (done_flag) {  // results first (they may live in host memory), then the flag
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done_flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // bulk: leaf pass, then one ancestor launch per run (empty runs exit), then commit
 __global__ void __launch_bounds__(256) k_add_leaf_bulk(AddArgs a) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1272,7 +1331,9 @@ int launch_add(srlx_per *h, i64 n, const void *d_prio, int kind, hipStream_t st,
     double *snap = (double *)((char *)h->scratch.ptr + srlx::Carver::padded((size_t)n * 8));
     AddArgs a{h->tree, h->capacity, h->d_state, n, d_prio, kind, h->epsilon, h->alpha, (double *)h->scratch.ptr,
               start_slot, append ? 1 : 0, append ? 0 : 1, 0.0, snap, append ? h->d_add_counter[0] : nullptr, append ? h->d_add_counter[1] : nullptr};
-    if (n <= kSmallAddMax) {
+    if (n <= kTinyAddMax && append) {
+        hipLaunchKernelGGL(k_add_tiny, dim3(1), dim3(64), 0, st, a);
+    } else if (n <= kSmallAddMax) {
         hipLaunchKernelGGL(k_add_wg, dim3(1), dim3(n < 512 ? kWgAdd : 512), (size_t)n * sizeof(double), st, a);  // (512 threads: a 256-register budget keeps the pipelined chain blocks out of scratch)
     } else {
         const int blocks = (int)((n + 255) / 256);
@@ -1644,6 +1705,78 @@ int srlx_per_sample(srlx_per_t *h, int64_t batch_size, int64_t step, const int64
     memcpy(out_idx, h_idx, (size_t)batch_size * 8);
     if (out_w) memcpy(out_w, h_w, (size_t)batch_size * 8);
     if (out_w32) memcpy(out_w32, h_w32, (size_t)batch_size * 4);
+    return SRLX_OK;
+}
+
+// The b1 shim's `sample` (round 6): `n_add` <= 16 adds queued since the tree was last observed (HOST values: final leaf priorities, SRLX_PRIO_RAW, or NULL with
+// SRLX_PRIO_NONE) and the draw as ONE launch -- the add values travel in the kernel arguments, the uniforms and the results through a device-visible pinned slot --
+// and the host spins on a completion flag in that slot instead of synchronising the stream.  Results as srlx_per_sample(on_device = 0).
+int srlx_per_sample_after_adds(srlx_per_t *h, int64_t n_add, const double *add_values, int add_kind, int64_t batch_size, int64_t step, const double *uniforms,
+                               int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used, void *stream) {
+    SRLX_REQUIRE(h, "per_sample_after_adds: NULL handle");
+    SRLX_REQUIRE(n_add >= 0 && n_add <= kTinyAddMax && (n_add == 0 || add_kind == SRLX_PRIO_NONE || (add_kind == SRLX_PRIO_RAW && add_values)),
+                 "per_sample_after_adds: at most %d adds, SRLX_PRIO_RAW values or SRLX_PRIO_NONE", kTinyAddMax);
+    SRLX_REQUIRE(batch_size > 0 && uniforms && n_uniforms >= batch_size && n_uniforms <= kSmallSampleMax && out_idx && out_used,
+                 "per_sample_after_adds: batch_size <= n_uniforms <= %lld", (long long)kSmallSampleMax);
+    srlx::DeviceGuard guard(h->device);
+    hipStream_t st = pick_stream(h, stream);
+    using C = srlx::Carver;
+    const size_t need = C::padded((size_t)n_uniforms * 8) + C::padded((size_t)batch_size * 8) * 2 + C::padded((size_t)batch_size * 4) + C::padded(8) + C::padded(8);
+    char *slot_ptr;
+    int slot = 0;
+    SRLX_TRY(ring_acquire(h, need, &slot_ptr, &slot));
+    if (!slot_ptr) {  // does not fit a slot: the plain calls
+        if (n_add > 0) SRLX_TRY(srlx_per_add(h, n_add, add_values, add_kind, 0, stream));
+        return srlx_per_sample(h, batch_size, step, nullptr, uniforms, n_uniforms, out_idx, out_w, out_w32, out_used, 0, stream);
+    }
+    C sp(slot_ptr);
+    double *m_u = sp.take<double>(n_uniforms);
+    i64 *m_idx = sp.take<i64>(batch_size);
+    double *m_w = sp.take<double>(batch_size);
+    float *m_w32 = sp.take<float>(batch_size);
+    i64 *m_used = sp.take<i64>(1);
+    volatile unsigned long long *m_flag = (volatile unsigned long long *)sp.take<unsigned long long>(1);
+    memcpy(m_u, uniforms, (size_t)n_uniforms * 8);
+    static unsigned long long ticket = 0;
+    const unsigned long long want = ++ticket;
+    *m_flag = 0;
+    const i64 M = n_uniforms, B = batch_size;
+    SRLX_TRY(h->scratch.reserve(SampleScratch::bytes(M, B, false)));
+    srlx::Carver cv(h->scratch.ptr);
+    SampleArgs a{};
+    a.tr = h->tree, a.state = h->d_state, a.beta_initial = h->beta_initial, a.beta_steps = h->beta_steps, a.step = step, a.d_step = nullptr;
+    a.has_duplicate = h->has_duplicate, a.uniforms = m_u, a.key_seed = 0, a.key_counter = nullptr, a.n_uniforms = M, a.batch = B;
+    a.out_idx = m_idx, a.out_w = m_w, a.out_w32 = m_w32, a.out_used = m_used;
+    a.cand_idx = cv.take<i64>(M), a.cand_p = cv.take<double>(M), a.map = cv.take<i64>(B), a.wtmp = cv.take<double>(B);
+    AddArgs add{h->tree, h->capacity, h->d_state, n_add, nullptr, add_kind, h->epsilon, h->alpha, nullptr, -1, 1, 0, 0.0, nullptr, h->d_add_counter[0], h->d_add_counter[1]};
+    TinyVals vals{};
+    for (int k = 0; k < n_add && add_values; k++) vals.v[k] = add_values[k];
+    const size_t lds = (size_t)kWgSample * (8 + 4) + (size_t)M + 16;
+    hipLaunchKernelGGL(k_add_sample_wg, dim3(1), dim3(kWgSample), lds, st, add, vals, a, (unsigned long long *)m_flag, want);
+    SRLX_HIP(hipGetLastError());
+    if (n_add > 0) {  // host mirror
+        h->write = (h->write + n_add) % h->capacity;
+        h->size = (h->size + n_add > h->capacity) ? h->capacity : h->size + n_add;
+    }
+    // spin on the flag (the kernel's last store, system scope, behind its results); a stream synchronisation as the fallback after ~2 ms
+    bool done = false;
+    for (long spins = 0; spins < 2000000; spins++) {
+        if (*m_flag == want) {
+            done = true;
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    if (!done) SRLX_HIP(hipStreamSynchronize(st));
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    *out_used = *m_used;
+    if (*m_used < 0) {
+        srlx::set_error("per_sample: %lld uniforms were not enough for %lld accepted draws", (long long)n_uniforms, (long long)batch_size);
+        return SRLX_ERR_UNIFORMS_EXHAUSTED;
+    }
+    memcpy(out_idx, m_idx, (size_t)batch_size * 8);
+    if (out_w) memcpy(out_w, m_w, (size_t)batch_size * 8);
+    if (out_w32) memcpy(out_w32, m_w32, (size_t)batch_size * 4);
     return SRLX_OK;
 }
 

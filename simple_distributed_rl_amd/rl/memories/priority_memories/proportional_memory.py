@@ -141,35 +141,50 @@ class ProportionalMemory(IPriorityMemory):
         w = np.empty(batch_size, np.float64)
         used = N.c_i64(0)
         with self._lock:
-            self._flush()
-            state = random.getstate()
-            m = batch_size if self.has_duplicate else 4 * batch_size
+            # up to 16 queued adds of one kind ride INSIDE the sampling launch (srlx_per_sample_after_adds); a longer queue is flushed by a launch of its own first
+            q_kind = self._queue_kind
+            if len(self._queue) > 16 or (self._queue and q_kind not in (N.PRIO_RAW, N.PRIO_NONE)):
+                self._flush()
+            adds, self._queue, self._queue_kind = self._queue, [], None
+            add_arr = np.asarray(adds, np.float64) if (adds and q_kind == N.PRIO_RAW) else None
+            # Uniforms: the reference calls random.random() once per descent attempt (:147).  Without rejected draws a batch consumes exactly `batch_size` of them, so the
+            # first attempt draws exactly that many and needs no snapshot of the generator (random.getstate() copies 625 words: more host time than the kernel runs);
+            # only when the kernel reports that rejections ate the uniforms is the state captured -- AFTER the ones consumed so far -- before more are drawn, so that an
+            # over-provisioned retry can be rolled back to exactly what the reference would have consumed.
             cap = 8192 if not self.has_duplicate else 9999 * batch_size  # without duplicates one call walks at most 8192 uniforms
-            forced = False
+            drawn = [random.random() for _ in range(batch_size)]
+            state, base, forced = None, 0, False  # state: the generator AFTER `base` of the drawn uniforms
             while True:
-                m = min(m, cap)
-                u = np.fromiter((random.random() for _ in range(m)), np.float64, m)
-                st = self._lib.srlx_per_sample(
-                    self._h, batch_size, int(step), None, N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), 2, None
-                )
-                if st == N.ERR_UNIFORMS_EXHAUSTED and m < cap:  # rejected draws ate the uniforms: again with more
-                    random.setstate(state)
-                    m = 2 * m + 16
+                m = len(drawn)
+                u = np.asarray(drawn, np.float64)
+                if m <= 8192:
+                    st = self._lib.srlx_per_sample_after_adds(self._h, len(adds), N.np_ptr(add_arr) if add_arr is not None else None, q_kind if adds else N.PRIO_NONE,
+                                                              batch_size, int(step), N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), None)
+                    adds = []  # (applied by the first attempt, whatever the draw's outcome)
+                else:
+                    if adds:
+                        N.check(self._lib.srlx_per_add(self._h, len(adds), N.np_ptr(add_arr) if add_arr is not None else None, q_kind, 2, None))
+                        adds = []
+                    st = self._lib.srlx_per_sample(
+                        self._h, batch_size, int(step), None, N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), 2, None
+                    )
+                if st == N.ERR_UNIFORMS_EXHAUSTED and m < cap:  # rejected draws ate the uniforms: again with more (the same prefix: the same walk up to there)
+                    state, base = random.getstate(), m
+                    drawn.extend(random.random() for _ in range(min(m + 16, cap - m)))
                     continue
                 if st == N.ERR_UNIFORMS_EXHAUSTED and not self.has_duplicate and not forced:
                     # fewer distinct non-zero leaves than the batch needs: the reference gives up on a draw after 9999 tries and takes
                     # it, duplicate or not (:146-158); here the batch is completed with duplicates from the same uniforms
                     N.check(self._lib.srlx_per_set_has_duplicate(self._h, 1))
                     forced = True
-                    random.setstate(state)
                     continue
                 if forced:
                     N.check(self._lib.srlx_per_set_has_duplicate(self._h, 0))
                 N.check(st)
                 break
-            if used.value != m:  # rejected draws: leave `random` where the reference would
+            if used.value != len(drawn):  # the retry drew more than the walk consumed: leave `random` where the reference would
                 random.setstate(state)
-                for _ in range(used.value):
+                for _ in range(used.value - base):
                     random.random()
             cap1 = self.capacity - 1
             indices = idx.tolist()

@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graphs")
     ap.add_argument("--no-overlap", action="store_true", help="run actor and learner back to back on one stream (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi-trunk", action="store_true", help="agent57_light: ONE convolution launch for the five networks' image blocks instead of one per network (A/B: faster alone, slower beside the update)")
     ap.add_argument("--actor-stream", default="low", choices=["low", "normal", "high", "default"],
                     help="priority level of the stream the actors' side runs on (its own pool of hardware queues); default: torch's current stream")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
@@ -437,14 +438,6 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
     env = srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(episode_len=args.episode_len)))
     rl.setup(env)
     dev = torch.device(f"cuda:{dev_index}")
-    if dist is None and args.actor_stream != "default":  # as the Rainbow line: the actors' side on a stream of its own priority level (its own hardware-queue pool)
-        import ctypes
-
-        from simple_distributed_rl_amd import _native as N
-
-        raw = ctypes.c_void_p()
-        N.check(N.lib().srlx_stream_create({"high": -1, "normal": 0, "low": 1}[args.actor_stream], ctypes.byref(raw)))
-        torch.cuda.set_stream(torch.cuda.ExternalStream(raw.value, device=dev))
     if dist is not None:
         from simple_distributed_rl_amd.device.dist import DistributedAgent57Light
 
@@ -462,7 +455,8 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
         # (device/agent57_light.py) is a test yardstick now
         from simple_distributed_rl_amd.device.agent57_fast import Agent57LightFastEngine
 
-        eng = Agent57LightFastEngine(rl, E, dev_index, episode_len=args.episode_len, seed=0, overlap=None if not args.no_overlap else False)
+        eng = Agent57LightFastEngine(rl, E, dev_index, episode_len=args.episode_len, seed=0, overlap=None if not args.no_overlap else False, actor_stream=args.actor_stream)
+        eng.multi_trunk = bool(args.multi_trunk)
         eng.prefill()
     fast_engine = True
     inner = max(1, args.inner)
@@ -478,7 +472,9 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
     # HIP events right around k_convnet_fused of the q_ext actor handle (one of the five trunk launches of a lock-step), recorded by the library on the kernel's own
     # launch stream, every 4th lock-step INSIDE the timed loop
     probe_every, pr = 4, []
-    probe_handle = (eng.local if dist is not None else eng).nets["q_ext"].actor  # (None on a rank that only learns)
+    _loc = eng.local if dist is not None else eng
+    multi = bool(getattr(_loc, "multi_trunk", False) and _loc.sets and _loc.intrinsic)  # the five image blocks as ONE launch (the probe brackets the first handle's)
+    probe_handle = _loc.nets["emb" if multi else "q_ext"].actor  # (None on a rank that only learns)
     if probe_handle is not None:
         pr = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((n_lock + probe_every - 1) // probe_every)]
         for a_, b_ in pr:
@@ -513,12 +509,15 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
     if fast_engine and pr:
         v = sorted(a_.elapsed_time(b_) for a_, b_ in pr)
         ms = sum(v) / len(v)
-        ex = CONV_EXECUTED_FLOPS_PER_SAMPLE * E
         n_trunks = 5 if local.intrinsic else 2
-        roof = {"kernel": "k_convnet_fused<true, ..., PLANES> : conv1 -> conv2 -> conv3 of ONE of the five image trunks of the actors' pass over E uint8 stacks, writing the "
-                          "first dense layer's A operand planes (five such launches per lock-step; the dominant kernel of profiles/r6_a57_kernel_stats.csv)",
+        ex = CONV_EXECUTED_FLOPS_PER_SAMPLE * E * (n_trunks if multi else 1)
+        roof = {"kernel": ("k_convnet_fused_multi: conv1 -> conv2 -> conv3 of ALL FIVE image trunks of the actors' pass over the same E uint8 stacks as one launch of 5 E "
+                           "workgroups, each writing its network's first-dense-layer A operand planes (the dominant kernel of profiles/r6_a57_kernel_stats.csv)") if multi else
+                          ("k_convnet_fused<true, ..., PLANES> : conv1 -> conv2 -> conv3 of ONE of the image trunks of the actors' pass over E uint8 stacks, writing the "
+                           "first dense layer's A operand planes (one such launch per network and lock-step)"),
                 "bound": "mfma", "achieved": ex / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": _pmc_traffic("k_convnet_fused"), "executed_mfma_flops_per_launch": ex, "avg_launch_ms": ms, "launches_per_lock_step": n_trunks,
+                "traffic": (_pmc_traffic("k_convnet_fused") or 0) * (n_trunks if multi else 1) or None, "executed_mfma_flops_per_launch": ex, "avg_launch_ms": ms,
+                "launches_per_lock_step": 1 if multi else n_trunks,
                 "probes": {"min_ms": v[0], "median_ms": v[len(v) // 2], "mean_ms": ms, "max_ms": v[-1], "probes": len(v)},
                 "note": "HIP events recorded by the library around exactly this kernel on its launch stream, every 4th lock-step inside the timed loop (the update runs "
                         "beside it); executed flops = 3 x conv1 + 6 x conv2 / conv3 exact split-bf16 partial products; traffic: the same kernel's PMC figure of the "

@@ -663,6 +663,14 @@ int srlx_qnet_backward_td_u8(srlx_qnet_t *h, int64_t batch, int n_step, const ui
                              const uint8_t *d_invalid_next, const float *d_weights, double discount, double retrace_h, int enable_double_dqn,
                              int enable_rescale, float *d_target, float *d_loss, float *d_grad_q0, float *d_priorities, float *const *d_grads, void *stream);
 int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream);
+/* Several networks over the SAME frames (round 6; Agent57_light evaluates five networks on the state a lock-step has just produced: the two UVFA Q-networks of the next
+ * Worker.policy, agent57_light.py:355-363, and the embedding / RND networks of the intrinsic reward, :383-391):
+ *   srlx_qnet_forward_convs_multi_u8 : the image blocks of `n` <= 8 inference handles (84 x 84 x 4, operand planes valid, batch >= 512 in multiples of 128) as ONE
+ *       launch of n x batch workgroups -- one ramp and one tail instead of n; each handle is left with fresh operand planes;
+ *   srlx_qnet_forward_dense_planes   : a handle's dense layers (first dense layer on the planes + its head: dueling / hidden-layer mode, UVFA terms) on those planes --
+ *       together the two calls give what srlx_qnet_forward_u8 gives, bit for bit. */
+int srlx_qnet_forward_convs_multi_u8(srlx_qnet_t *const *hs, int n, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, void *stream);
+int srlx_qnet_forward_dense_planes(srlx_qnet_t *h, int64_t batch, float *d_q, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Agent57_light's five networks on srlx_qnet handles (round 6; SURVEY 8 a18, BASELINE configs[3]).

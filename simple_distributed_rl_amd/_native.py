@@ -95,6 +95,8 @@ SIGNATURES = {
     "srlx_qnet_destroy": (c_int, [c_p]),
     "srlx_qnet_bind": (c_int, [c_p, c_p]),
     "srlx_qnet_forward_u8": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "srlx_qnet_forward_convs_multi_u8": (c_int, [c_p, c_int, c_i64, c_p, c_p, c_p]),
+    "srlx_qnet_forward_dense_planes": (c_int, [c_p, c_i64, c_p, c_p]),
     "srlx_qnet_forward_convs_u8": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     "srlx_qnet_forward_u8_policy": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_u64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_qnet_actor_sets_enable": (c_int, [c_p]),

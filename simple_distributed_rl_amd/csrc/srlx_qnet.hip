@@ -1336,6 +1336,19 @@ int srlx_qnet_forward_convs_u8(srlx_qnet_t *h, int64_t batch, const uint8_t *d_f
     return SRLX_OK;
 }
 
+int srlx_qnet_forward_convs_multi_u8(srlx_qnet_t *const *hs, int n, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, void *stream) {
+    SRLX_REQUIRE(hs && d_frame_base && d_frame_off, "qnet_forward_convs_multi_u8: NULL argument");
+    srlx::DeviceGuard guard(hs[0]->device);
+    return srlx_qnet_fused_convs_multi(hs, n, batch, d_frame_base, d_frame_off, (hipStream_t)stream);
+}
+
+int srlx_qnet_forward_dense_planes(srlx_qnet_t *h, int64_t batch, float *d_q, void *stream) {
+    SRLX_REQUIRE(h && d_q, "qnet_forward_dense_planes: NULL argument");
+    SRLX_REQUIRE(h->a3_planes_fresh && batch > 0 && batch <= h->max_batch, "qnet_forward_dense_planes: no fresh operand planes (srlx_qnet_forward_convs_multi_u8 first)");
+    srlx::DeviceGuard guard(h->device);
+    return run_dense(h, batch, d_q, (hipStream_t)stream);
+}
+
 int srlx_qnet_forward_f32(srlx_qnet_t *h, int64_t batch, const float *d_obs_nchw, float *d_q, void *stream) {
     SRLX_REQUIRE(h && d_obs_nchw && d_q, "qnet_forward_f32: NULL argument");
     SRLX_REQUIRE(h->w1, "qnet_forward_f32: no parameters bound (srlx_qnet_bind)");

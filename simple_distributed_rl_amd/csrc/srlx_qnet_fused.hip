@@ -364,12 +364,10 @@ __device__ __forceinline__ f32x16 reduce_quarters(float *__restrict__ scratch, i
 // PLANES = 2 (round 4, the learner's passes): BOTH -- float32 act3 for the backward pass and the planes (at `planes_out`, `plane_rows` rows per K-slab: the launch's
 // rows rounded up to the GEMM's 128-row tile) for the first dense layer.
 template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0>
-__global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
-                                                                const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
-                                                                float *__restrict__ act3,
-                                                                float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg,
-                                                                unsigned char *__restrict__ planes_out = nullptr, long long plane_rows = 0, long long n_samples = 0,
-                                                                long long first_sample = 0) {
+__device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
+                                                   const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3, float *__restrict__ act3,
+                                                   float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg,
+                                                   unsigned char *__restrict__ planes_out, long long plane_rows, long long n_samples, i64 b, bool stamp_wg) {
     static_assert(!PLANES || C23B16, "operand planes come out of the split-bf16 conv3 only");
     static_assert(!C23B16 || C1B16, "the split-bf16 conv2 / conv3 read the part planes conv1's split-bf16 epilogue writes");
     constexpr bool PL = C23B16;  // act1 / act2 as bf16 part planes in LDS (kPB1 / kPB2 bytes per pixel) instead of float32
@@ -380,10 +378,9 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     unsigned char *a1p = smem + kOffA1P, *a2p = smem;              // [441][kPB1], [121][kPB2] (plane layout; act2 overlays the frames and conv1's filters)
     int t = threadIdx.x;
     const int wave = t >> 6;
-    i64 b = (i64)blockIdx.x + first_sample;  // (a chip-filling pass may come as several launches of consecutive samples: srlx_qnet_fused_convs)
     constexpr int H = 84, W = 84, NT = 64 * kWaves;
     auto stamp = [&](int k) {  // phase timestamps of every wave of workgroup 0 (tools/fused_phases.py); dbg is NULL in production
-        if (dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (dbg && stamp_wg && (threadIdx.x & 63) == 0) dbg[wave * 8 + k] = __builtin_amdgcn_s_memtime();
     };
     const int lane = t & 63, h = lane >> 5, i = lane & 31;
     stamp(0);
@@ -718,6 +715,34 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
     stamp(7);
 }
 
+template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0>
+__global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
+                                                                const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
+                                                                float *__restrict__ act3,
+                                                                float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg,
+                                                                unsigned char *__restrict__ planes_out = nullptr, long long plane_rows = 0, long long n_samples = 0,
+                                                                long long first_sample = 0) {
+    // (a chip-filling pass may come as several launches of consecutive samples: first_sample)
+    convnet_fused_body<BIG, C1B16, C23B16, PLANES>(base, frame_off, wpk, b1, b2, b3, act3, act1_out, act2_out, dbg, planes_out, plane_rows, n_samples,
+                                                   (i64)blockIdx.x + first_sample, blockIdx.x == 0);
+}
+
+// Several networks' image blocks over the SAME frames as ONE launch (round 6: Agent57_light's five networks all evaluate the state the ring commit has just made
+// current -- two UVFA Q-networks for the next policy step, the embedding network and the two RND networks for the intrinsic reward, agent57_light.py:355-391): workgroup
+// (net, sample) = (blockIdx.x / n_samples, blockIdx.x % n_samples) runs the chip-filling PLANES body on net's packed filters and writes net's operand planes.  Five
+// launches of 4 workgroup rounds each pay five ramps and five tails (a third of their time at E = 1024); one launch of 20 rounds pays one.
+constexpr int kMultiMax = 8;
+struct MultiNets {
+    const float *wpk[kMultiMax], *b1[kMultiMax], *b2[kMultiMax], *b3[kMultiMax];
+    float *act3[kMultiMax];
+};
+__global__ void __launch_bounds__(64 * kWaves) k_convnet_fused_multi(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, MultiNets nets, long long n_samples) {
+    const int net = (int)(blockIdx.x / (unsigned)n_samples);
+    const i64 b = (i64)(blockIdx.x % (unsigned)n_samples);
+    convnet_fused_body<true, true, true, 1>(base, frame_off, nets.wpk[net], nets.b1[net], nets.b2[net], nets.b3[net], nets.act3[net], nullptr, nullptr, nullptr, nullptr, 0,
+                                            n_samples, b, false);
+}
+
 }  // namespace
 
 size_t srlx_qnet_pack_bytes() { return (size_t)kPackFloats * sizeof(float); }
@@ -815,4 +840,35 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     if (h->probe1 && hipEventRecord(h->probe1, st) != hipSuccess) return false;
     if (h->stamp_buf && srlx_debug_stamp(h->stamp_buf, 10, st) != SRLX_OK) return false;  // (measurement aid: the convolution launch of a forward pass is done)
     return hipGetLastError() == hipSuccess;
+}
+
+// conv1 -> conv2 -> conv3 of `n` handles over the same `batch` frame stacks as one launch; every handle is left as after its own chip-filling forward's convolution
+// kernel (operand planes fresh): srlx_qnet_forward_dense_planes continues each.
+int srlx_qnet_fused_convs_multi(srlx_qnet *const *hs, int n, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st) {
+    SRLX_REQUIRE(n >= 1 && n <= kMultiMax && batch >= 512, "qnet_forward_convs_multi: 1..%d handles, chip-filling batches", kMultiMax);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SRLX_HIP(hipFuncSetAttribute((const void *)k_convnet_fused_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        attr_set = true;
+    }
+    MultiNets nets{};
+    for (int k = 0; k < n; k++) {
+        srlx_qnet *h = hs[k];
+        SRLX_REQUIRE(h && h->H == 84 && h->W == 84 && h->Wn == 4 && h->F1 == 32, "qnet_forward_convs_multi: handle %d is not the 84 x 84 x 4 / 32-filter geometry", k);
+        SRLX_REQUIRE(h->max_train == 0 && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch) && batch <= h->max_batch,
+                     "qnet_forward_convs_multi: handle %d must be an inference handle with valid operand planes for %lld rows", k, (long long)batch);
+        if (!h->pack_valid) {
+            SRLX_TRY(srlx_qnet_pack_publish(h, nullptr, nullptr, st));
+            h->pack_valid = h->pack_sticky;
+        }
+        h->wt_from_forward = false;
+        nets.wpk[k] = h->wpack, nets.b1[k] = h->b1, nets.b2[k] = h->b2, nets.b3[k] = h->b3, nets.act3[k] = reinterpret_cast<float *>(h->a3_planes);
+    }
+    if (hs[0]->probe0) SRLX_HIP(hipEventRecord(hs[0]->probe0, st));
+    hipLaunchKernelGGL(k_convnet_fused_multi, dim3((unsigned)(n * batch)), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, nets, (long long)batch);
+    if (hs[0]->probe1) SRLX_HIP(hipEventRecord(hs[0]->probe1, st));
+    hs[0]->probe0 = hs[0]->probe1 = nullptr;
+    for (int k = 0; k < n; k++) hs[k]->a3_planes_fresh = true, hs[k]->want_planes_out = true;
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
 }

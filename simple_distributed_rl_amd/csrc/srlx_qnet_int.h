@@ -169,6 +169,8 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t rows, int64_t stride, float *d_q,
 // srlx_qnet_fused.hip: conv1 -> conv2 -> conv3 in one kernel (activations in LDS); false when the geometry is not the Atari one
 bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st);
 
+int srlx_qnet_fused_convs_multi(srlx_qnet *const *hs, int n, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st);
+
 // srlx_fc1_planes.hip: the first dense layer of chip-filling launches as a conversion-free GEMM on pre-split bf16 operand planes
 int srlx_fc1_planes_alloc(srlx_qnet *h);
 int srlx_fc1_planes_split_weight(srlx_qnet *h, const float *src, float *copy_dst, hipStream_t st, void *planes_dst = nullptr);

@@ -92,7 +92,8 @@ class _Net:
 
 class Agent57LightFastEngine:
     def __init__(self, rl_config, n_envs: int, device: int = 0, episode_len: int = 200, seed: int = 0, env=None, parameter=None, ring_len: Optional[int] = None,
-                 overlap: Optional[bool] = None, fc1_neighbour: int = 4, fused_adam: bool = True, role: str = "both", learner_replay: Optional[DeviceReplay] = None):
+                 overlap: Optional[bool] = None, fc1_neighbour: int = 4, fused_adam: bool = True, role: str = "both", learner_replay: Optional[DeviceReplay] = None,
+                 actor_stream: Optional[str] = None):
         """rl_config: a set-up algorithms.agent57_light.Config (84 x 84 x window-4 image observations); parameter: its Parameter (the five torch networks: the
         initial weights are taken from it, `export_parameter()` writes the trained ones back).  overlap (None = wherever it applies): the update beside the
         actors on published parameter sets; needs n_envs >= 512 in multiples of 128.  fused_adam=False (tests): every gradient is written to `p.grad` and the
@@ -173,6 +174,19 @@ class Agent57LightFastEngine:
         self.beta_list = torch.tensor(np.array(funcs.create_beta_list(Na), np.float32), device=d)
         self.discount_list = torch.tensor(np.array(funcs.create_discount_list(Na), np.float32), device=d)
         self.eps_list = torch.tensor(np.array(funcs.create_epsilon_list(Na), np.float32), device=d)
+        # the actors' side on a stream of its own priority level: HIP keeps one pool of hardware queues per level and runs a graph's internal branches on
+        # normal-priority streams -- on the caller's (normal) stream the actors' chip-filling launches share a hardware queue with a branch of the update, which then
+        # runs BEHIND them instead of beside them (tools/a57_trace.py: no overlap at all).  Default: "low" for an overlapped engine; `close()` hands the thread back
+        self.actor_stream = None
+        want = actor_stream if actor_stream is not None else ("low" if (self.overlap and role == "both" and learner_replay is None) else "default")
+        if want != "default":
+            raw = ctypes.c_void_p()
+            N.check(self.lib.srlx_stream_create({"high": -1, "normal": 0, "low": 1}[want], ctypes.byref(raw)))
+            self._actor_stream_raw = raw
+            self._stream_before = torch.cuda.current_stream(self.dev)
+            self.actor_stream = torch.cuda.ExternalStream(raw.value, device=self.dev)
+            self.actor_stream.wait_stream(self._stream_before)
+            torch.cuda.set_stream(self.actor_stream)
         self._build_networks(B, fc1_neighbour)
         self.load_parameter(parameter)
         z = lambda dt, *sh: torch.zeros(sh, dtype=dt, device=d)  # noqa: E731
@@ -181,6 +195,10 @@ class Agent57LightFastEngine:
         self._learner_pending = False
         self.train_count = self.sync_count = self.total_env_steps = 0
         self.ledger, self.training, self.ingest, self.before_env = None, True, None, None
+        self._trunks_fresh, self._q_ready = False, False
+        # the five image blocks of a lock-step as ONE launch (srlx_qnet_forward_convs_multi_u8): 6-15 % faster for the blocks alone, 3-4 % SLOWER per lock-step beside
+        # the update (a 0.6 ms launch leaves the update's small kernels no launch boundary to slot into) -- off unless asked for
+        self.multi_trunk = False
         if self.learns:
             self._init_learner(B, A, z)
         if self.acts:
@@ -430,10 +448,12 @@ class Agent57LightFastEngine:
         r, st = self.replay, N.torch_stream_ptr()
         off = r.frame_table_current()
         arm = self.arm()
-        for name, out in (("q_ext", self.q_ext), ("q_int", self.q_int)):
-            h = self.nets[name].actor
-            h.set_uvfa_inputs(self.prev_r_ext, self.prev_r_int, self.prev_action, arm)
-            h.forward_u8(r.obs_base, off, out=out)
+        ready, self._q_ready = self._q_ready, False  # the last lock-step evaluated both Q-networks on this state already (`_next_q`)
+        if not ready:
+            for name, out in (("q_ext", self.q_ext), ("q_int", self.q_int)):
+                h = self.nets[name].actor
+                h.set_uvfa_inputs(self.prev_r_ext, self.prev_r_int, self.prev_action, arm)
+                h.forward_u8(r.obs_base, off, out=out)
         c = self.cfg
         N.check(self.lib.srlx_agent57_policy(self.E, self.A, N.tptr(self.q_ext), N.tptr(self.q_int), N.tptr(arm) if self.training else None, N.tptr(self.beta_list),
                                              N.tptr(self.eps_list), float(c.test_beta), float(c.test_epsilon), self.seed ^ 0xAC7, N.tptr(self.policy_counter),
@@ -458,9 +478,19 @@ class Agent57LightFastEngine:
         if self.intrinsic:  # :383-391 on s_{t+1}, the state the commit has just made current
             off = r.frame_table_current()
             e, rn = self.nets["emb"], self.nets["rnd"]
-            e.actor.forward_u8(r.obs_base, off, out=self.emb_out)
-            rn.actor_target.forward_u8(r.obs_base, off, out=self.rnd_t_out)
-            rn.actor.forward_u8(r.obs_base, off, out=self.rnd_p_out)
+            if self.sets and self.multi_trunk:
+                # ALL FIVE networks evaluate this state -- the embedding / RND networks now, the two Q-networks at the next policy step (their UVFA inputs enter in
+                # the head kernel, behind the image block): their image blocks as ONE launch of 5 E workgroups (one ramp and one tail instead of five)
+                hs = [e.actor, rn.actor_target, rn.actor, self.nets["q_ext"].actor, self.nets["q_int"].actor]
+                QNetInference.forward_convs_multi(hs, r.obs_base, off)
+                e.actor.forward_dense(E, out=self.emb_out)
+                rn.actor_target.forward_dense(E, out=self.rnd_t_out)
+                rn.actor.forward_dense(E, out=self.rnd_p_out)
+                self._trunks_fresh = True
+            else:
+                e.actor.forward_u8(r.obs_base, off, out=self.emb_out)
+                rn.actor_target.forward_u8(r.obs_base, off, out=self.rnd_t_out)
+                rn.actor.forward_u8(r.obs_base, off, out=self.rnd_p_out)
             N.check(self.lib.srlx_ngu_episodic_reward(self.ngu.h, N.tptr(self.emb_out), N.tptr(self.reset_lane), N.tptr(self.live_lane), N.tptr(self.episodic), st))
             N.check(self.lib.srlx_ngu_lifelong_reward(E, self.D_rnd, N.tptr(self.rnd_t_out), N.tptr(self.rnd_p_out), float(c.lifelong_max), N.tptr(self.lifelong), st))
             epi, lif = self.episodic, self.lifelong
@@ -477,11 +507,26 @@ class Agent57LightFastEngine:
             self.reset_lane.copy_(done)
             torch.bitwise_xor(done, 1, out=self.live_lane)
         self.total_env_steps += E
+        self._next_q()
         if self._own_ring_only:  # the ring only stacks frames for this engine's actors: its commit moved the position itself, there is no tree here
             return
         self.join_learner()
         r.add_masked()
         self._flip()
+
+    def _next_q(self):
+        """The Q-networks' dense layers for the NEXT policy step, on the operand planes the multi-network launch of this lock-step left: everything they need exists once
+        the lock-step's bookkeeping is done (the state, the previous action / rewards, the arm).  Run here -- before the join -- they use the same parameter set as
+        their image blocks (the flip to the set the joined update wrote comes behind them), and they are more work beside the update."""
+        if not self._trunks_fresh:
+            return
+        self._trunks_fresh = False
+        arm = self.arm()
+        for name, out in (("q_ext", self.q_ext), ("q_int", self.q_int)):
+            h = self.nets[name].actor
+            h.set_uvfa_inputs(self.prev_r_ext, self.prev_r_int, self.prev_action, arm)
+            h.forward_dense(self.E, out=out)
+        self._q_ready = True
 
     def pack_record(self) -> torch.Tensor:
         """The lock-step `actor_step` has just taken as ONE packed record (uint8: action, reward, flags and the five item fields of every lane): what an actor rank
@@ -533,19 +578,22 @@ class Agent57LightFastEngine:
         drawn=True (tests): the batch, its frame tables and its UVFA inputs are already in the engine's buffers.  ingest: a callable issuing the launches that commit
         a slab of arrived transitions (ring + item fields + tree; device/dist.py): they run on a side stream BEHIND the draw, and the priority write-back waits for
         them -- the tree sees draw, add, write-back in that order, and the commit hides beside the networks' passes."""
-        c, r, st = self.cfg, self.lreplay, N.torch_stream_ptr()
-        b = r.batch if drawn else r.sample_items(self.train_count_dev, all_states=True)
-        st = N.torch_stream_ptr()
+        r = self.lreplay
+        cur = torch.cuda.current_stream(self.dev)
+
+        def pre():
+            b = r.sample_items(self.train_count_dev, all_states=True)
+            self._gather_inputs(b, N.torch_stream_ptr())
+
         if not drawn:
-            self._gather_inputs(b, st)
+            pre()
         if ingest is not None:  # behind the draw AND the gather of the drawn items' fields (the ingest overwrites a ring slot's fields: one no stored item points at)
-            cur = torch.cuda.current_stream(self.dev)
             self._ev_drawn.record(cur)
             self.s_ingest.wait_event(self._ev_drawn)
             with torch.cuda.stream(self.s_ingest):
                 ingest()
                 self._ev_ingested.record(self.s_ingest)
-        self._update_networks(b, publish, st, wait=self._ev_ingested if ingest is not None else None)
+        self._update_networks(r.batch, publish, wait=self._ev_ingested if ingest is not None else None)
 
     def _lx(self):
         """The learner's view of the item fields: the global replay's arrays on a learner rank, this engine's own otherwise."""
@@ -571,47 +619,58 @@ class Agent57LightFastEngine:
                                                     N.tptr(self.on_r_ext), N.tptr(self.on_r_int), N.tptr(self.on_action), N.tptr(self.on_actor), N.tptr(self.tg_r_ext),
                                                     N.tptr(self.tg_r_int), N.tptr(self.tg_action), N.tptr(self.tg_actor), N.tptr(self.b_discount), N.tptr(self.b_r_int), st))
 
-    def _update_networks(self, b, publish, st, wait=None):
+    def _update_emb(self, publish):
+        """The inverse-dynamics embedding (:341-348): rows 2 b = f(s), 2 b + 1 = f(s'), all with gradient."""
+        c, r, e = self.cfg, self.lreplay, self.nets["emb"]
+        B, b = r.B, r.batch
+        off2 = r.frame_off_all.view(2 * B, self.Wn)
+        if self.sets:
+            e.inf.fuse_adam_planes(e.planes_ptr[publish] if publish is not None else None)
+        e.inf.forward_u8(r.obs_base, off2, out=self.l_emb)
+        tp, tg, tm, tv = e.tail_tabs
+        N.check(self.lib.srlx_agent57_emb_tail(B, self.D_emb, self.H_emb, self.A, N.tptr(self.l_emb), N.tptr(b.actions), ctypes.cast(tp, N.c_p), ctypes.cast(tg, N.c_p),
+                                               ctypes.cast(tm, N.c_p), ctypes.cast(tv, N.c_p), 1e-5, float(c.episodic_lr), 0.9, 0.999, 1e-8, N.tptr(self.train_count_dev),
+                                               N.tptr(self.emb_loss), N.tptr(self.g_emb), N.torch_stream_ptr()))
+        e.inf.backward_u8(r.obs_base, off2, self.g_emb, sample_stride=1)
+        e.opt.step(self.train_count_dev)
+        e.inf.publish_to(e.actor if publish is not None else None, publish or 0)
+
+    def _update_rnd(self, publish, bump=None):
+        """RND (:353-362): the predictor against the fixed target network on s_0 (rows 0, 2, ... of the interleaved pass)."""
+        c, r, rn = self.cfg, self.lreplay, self.nets["rnd"]
+        B = r.B
+        off2 = r.frame_off_all.view(2 * B, self.Wn)
+        if self.sets:
+            rn.inf.fuse_adam_planes(rn.planes_ptr[publish] if publish is not None else None)
+        rn.inf_target.forward_u8(r.obs_base, off2, out=self.l_rnd_t)
+        rn.inf.forward_u8(r.obs_base, off2, out=self.l_rnd_p)
+        mw, mb = (rn.ln_sets[publish] if (self.sets and publish is not None) else (None, None))
+        N.check(self.lib.srlx_agent57_rnd_tail(B, self.D_rnd, 2 * self.D_rnd, N.tptr(self.l_rnd_p), N.tptr(self.l_rnd_t), N.tptr(rn.module.tail[0]), N.tptr(rn.module.tail[1]),
+                                               N.tptr(rn.tail_g[0]), N.tptr(rn.tail_g[1]), N.tptr(rn.tail_m[0]), N.tptr(rn.tail_v[0]), N.tptr(rn.tail_m[1]),
+                                               N.tptr(rn.tail_v[1]), N.tptr(mw), N.tptr(mb), 1e-5, float(c.lifelong_lr), 0.9, 0.999, 1e-8, N.tptr(self.train_count_dev),
+                                               N.tptr(self.rnd_loss), N.tptr(self.g_rnd), N.torch_stream_ptr()))
+        rn.inf.backward_u8(r.obs_base, off2, self.g_rnd, sample_stride=2)
+        rn.opt.step(self.train_count_dev)
+        rn.inf.publish_to(rn.actor if publish is not None else None, publish or 0, bump=bump)
+
+    def _update_networks(self, b, publish, wait=None):
+        """The four networks' updates, then the mixed priorities and their write-back.  (The updates are independent of each other, but HIP graphs do not let them run
+        side by side: a captured stream that forks again faults in hipStreamEndCapture -- tools/capture_probe.py --, and a graph per network on streams of their own
+        runs 2.5 ms instead of 1.1 once the process owns a low-priority stream, which the actors need: profiles/NOTES.md, round 6.)"""
         c, r = self.cfg, self.lreplay
-        B, W = r.B, self.Wn
+        cur = torch.cuda.current_stream(self.dev)
         last = "rnd" if self.intrinsic else "q_ext"
         self._update_q(self.nets["q_ext"], b.rewards, publish, self.train_count_dev if last == "q_ext" else None)
         if self.intrinsic:
             self._update_q(self.nets["q_int"], self.b_r_int, publish, None)
-            off2 = r.frame_off_all.view(2 * B, W)
-            # ---- inverse-dynamics embedding (:341-348): rows 2 b = f(s), 2 b + 1 = f(s'), all with gradient ----
-            e = self.nets["emb"]
-            if self.sets:
-                e.inf.fuse_adam_planes(e.planes_ptr[publish] if publish is not None else None)
-            e.inf.forward_u8(r.obs_base, off2, out=self.l_emb)
-            tp, tg, tm, tv = e.tail_tabs
-            N.check(self.lib.srlx_agent57_emb_tail(B, self.D_emb, self.H_emb, self.A, N.tptr(self.l_emb), N.tptr(b.actions), ctypes.cast(tp, N.c_p), ctypes.cast(tg, N.c_p),
-                                                   ctypes.cast(tm, N.c_p), ctypes.cast(tv, N.c_p), 1e-5, float(c.episodic_lr), 0.9, 0.999, 1e-8, N.tptr(self.train_count_dev),
-                                                   N.tptr(self.emb_loss), N.tptr(self.g_emb), st))
-            e.inf.backward_u8(r.obs_base, off2, self.g_emb, sample_stride=1)
-            e.opt.step(self.train_count_dev)
-            e.inf.publish_to(e.actor if publish is not None else None, publish or 0)
-            # ---- RND (:353-362): predictor against the fixed target network on s_0 (rows 0, 2, ... of the interleaved pass) ----
-            rn = self.nets["rnd"]
-            if self.sets:
-                rn.inf.fuse_adam_planes(rn.planes_ptr[publish] if publish is not None else None)
-            rn.inf_target.forward_u8(r.obs_base, off2, out=self.l_rnd_t)
-            rn.inf.forward_u8(r.obs_base, off2, out=self.l_rnd_p)
-            mw, mb = (rn.ln_sets[publish] if (self.sets and publish is not None) else (None, None))
-            N.check(self.lib.srlx_agent57_rnd_tail(B, self.D_rnd, 2 * self.D_rnd, N.tptr(self.l_rnd_p), N.tptr(self.l_rnd_t), N.tptr(rn.module.tail[0]), N.tptr(rn.module.tail[1]),
-                                                   N.tptr(rn.tail_g[0]), N.tptr(rn.tail_g[1]), N.tptr(rn.tail_m[0]), N.tptr(rn.tail_v[0]), N.tptr(rn.tail_m[1]),
-                                                   N.tptr(rn.tail_v[1]), N.tptr(mw), N.tptr(mb), 1e-5, float(c.lifelong_lr), 0.9, 0.999, 1e-8, N.tptr(self.train_count_dev),
-                                                   N.tptr(self.rnd_loss), N.tptr(self.g_rnd), st))
-            rn.inf.backward_u8(r.obs_base, off2, self.g_rnd, sample_stride=2)
-            rn.opt.step(self.train_count_dev)
-            rn.inf.publish_to(rn.actor if publish is not None else None, publish or 0, bump=self.train_count_dev)
+            self._update_emb(publish)
+            self._update_rnd(publish, bump=self.train_count_dev)
         # ---- mixed priorities (:367-373) and their write-back ----
         use_int = self.intrinsic and not c.disable_int_priority
-        N.check(self.lib.srlx_agent57_priority(B, self.A, N.tptr(self.out["q_ext"]["td"]), None, N.tptr(self.out["q_int"]["td"]) if use_int else None, None, None,
-                                               N.tptr(self.tg_actor), N.tptr(self.beta_list), None, None,
-                                               N.tptr(self.priorities), st))
+        N.check(self.lib.srlx_agent57_priority(r.B, self.A, N.tptr(self.out["q_ext"]["td"]), None, N.tptr(self.out["q_int"]["td"]) if use_int else None, None, None,
+                                               N.tptr(self.tg_actor), N.tptr(self.beta_list), None, None, N.tptr(self.priorities), N.torch_stream_ptr()))
         if wait is not None:
-            torch.cuda.current_stream(self.dev).wait_event(wait)
+            cur.wait_event(wait)
         r.update(b.indices, self.priorities)
 
     def _after_update(self):
@@ -751,5 +810,10 @@ class Agent57LightFastEngine:
         return d
 
     def close(self):
+        """Joins the learner; hands the calling thread back to the stream it was on before the engine took it to its actors' stream."""
         self.join_learner()
         torch.cuda.synchronize(self.dev)
+        if getattr(self, "actor_stream", None) is not None:
+            torch.cuda.set_stream(self._stream_before)
+            self.actor_stream = None
+            N.check(self.lib.srlx_stream_destroy(self._actor_stream_raw))

@@ -530,6 +530,23 @@ class QNetInference:
             N.check(self.lib.srlx_qnet_refresh_fc1_planes(self.h, None, None, N.torch_stream_ptr()))
             self._planes_stale, self._planes_version = False, self.net.weights_version
 
+    @staticmethod
+    def forward_convs_multi(handles, frame_base_ptr: int, frame_off: torch.Tensor):
+        """The image blocks of several inference handles over the SAME frame stacks as one launch (srlx_qnet_forward_convs_multi_u8); `forward_dense` continues each."""
+        h0 = handles[0]
+        B = frame_off.numel() // h0.window
+        for h in handles:
+            h._planes_ready(B)
+        arr = (N.c_p * len(handles))(*[h.h for h in handles])
+        N.check(h0.lib.srlx_qnet_forward_convs_multi_u8(ctypes.cast(arr, N.c_p), len(handles), B, N.c_p(frame_base_ptr), N.tptr(frame_off), N.torch_stream_ptr()))
+        return B
+
+    def forward_dense(self, B: int, out: torch.Tensor = None) -> torch.Tensor:
+        """The dense layers on the operand planes the last `forward_convs_multi` left for this handle."""
+        q = self.q[:B] if out is None else out
+        N.check(self.lib.srlx_qnet_forward_dense_planes(self.h, int(B), N.tptr(q), N.torch_stream_ptr()))
+        return q
+
     def forward_f32(self, obs_nchw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         B = obs_nchw.shape[0]
         q = self.q[:B] if out is None else out

@@ -373,15 +373,17 @@ def test_small_engine_trains_items_consistent_and_reproducible():
 def test_overlapped_engine_on_published_sets(graphs):
     """512 lanes: the update beside the actors on published parameter sets (captured graphs or eager).  After every join the set the actors read equals the master
     parameters (packed first dense layer planes = the float32 weight split into three bf16 parts; UVFA columns; the RND LayerNorm mirror), the run trains, and
-    two instances walk one trajectory."""
+    two instances walk one trajectory -- the second with the five image blocks of a lock-step as ONE launch (`multi_trunk`: the same kernel body per sample, so the
+    same bits)."""
     N, lib, torch, dev = _env()
     from simple_distributed_rl_amd.device.agent57_fast import Agent57LightFastEngine
 
-    def run():
+    def run(multi_trunk=False):
         torch.manual_seed(1)
         cfg = _cfg84(batch=16, E=512, capacity=512 * 12, warmup=512 * 4)
         eng = Agent57LightFastEngine(cfg, 512, 0, episode_len=11, seed=5)
-        assert eng.overlap and eng.sets
+        eng.multi_trunk = multi_trunk
+        assert eng.overlap and eng.sets and eng.actor_stream is not None  # (the actors on the engine's low-priority stream)
         for k in range(14):
             if k == 8 and graphs:
                 eng.capture_graphs()
@@ -394,6 +396,7 @@ def test_overlapped_engine_on_published_sets(graphs):
     info = eng.info()
     assert eng.train_count >= 8 and all(np.isfinite(info[k]) for k in ("ext_loss", "int_loss", "emb_loss", "lifelong_loss")), info
     # what the actors read now is the master: evaluate the policy pass on the set and on the master (deselect) -- bit-identical Q rows
+    eng._q_ready = False  # (the Q rows cached for the next policy step were evaluated on the set BEFORE the last flip)
     q_set = [t.clone() for t in eng.policy_q()]
     for n in eng.nets.values():
         n.actor.select_set(-1)
@@ -404,11 +407,13 @@ def test_overlapped_engine_on_published_sets(graphs):
     q_master = eng.policy_q()
     for a, b in zip(q_set, q_master):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
-    eng2 = run()
+    eng2 = run(multi_trunk=True)
     assert eng2.info() == info
     for n1, n2 in zip(eng.nets.values(), eng2.nets.values()):
         for p, q in zip(n1.module.parameters(), n2.module.parameters()):
             assert torch.equal(p, q), n1.name
+    eng2.close()  # (in reverse order of construction: each hands the thread back to the stream it found)
+    eng.close()
 
 
 def _golden84_engine(z, fused_adam):

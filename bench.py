@@ -575,8 +575,11 @@ def bench_ppo(args, dev_index, rank, world, dist):
         step = eng.step
     for _ in range(max(2, args.warmup)):
         step()
-    if not args.no_graph and world == 1:  # (the data-parallel update calls the collective from Python between minibatches: eager)
-        eng.capture_graphs()
+    if not args.no_graph:
+        if world == 1:
+            eng.capture_graphs()
+        else:  # (RCCL + the libsrlx network: the all-reduces are nodes of the update graph; a host-staged gloo exchange stays eager)
+            wrap.capture_graphs()
         step()
     if dist is not None:
         dist.barrier()
@@ -599,24 +602,62 @@ def bench_ppo(args, dev_index, rank, world, dist):
         elapsed = float(t.item())
     if rank != 0:
         return
-    # the GAE scan in isolation: 16 B read + 8 B written per (environment, step)
     T = cfg.horizon
     dev = torch.device(f"cuda:{dev_index}")
-    r, v, d, lv, adv = (torch.rand(T, E, device=dev), torch.rand(T, E, device=dev), (torch.rand(T, E, device=dev) < 0.01).to(torch.uint8), torch.rand(E, device=dev),
-                        torch.zeros(T, E, device=dev))
     lib = N.lib()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 200
-    for k in range(reps + 5):
-        if k == 5:
-            a.record()
-        N.check(lib.srlx_gae_scan(E, T, N.tptr(r), N.tptr(v), N.tptr(d), N.tptr(lv), cfg.discount, cfg.gae_discount, N.tptr(adv), N.torch_stream_ptr()))
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / reps
-    nbytes = T * E * 13 + 4 * E  # rewards, values (f32), done (u8) read + advantage written, + the bootstrap values
     updates = args.steps * cfg.epochs * cfg.minibatches
     info = eng.info()
+    if eng.fused:
+        # the dominant kernel: one minibatch's forward + loss + backward (k_ppo_minibatch, + the 6 us gradient reduction the same C call launches), timed live on
+        # the engine's own buffers with HIP events on the launch stream
+        n, mb = T * E, T * E // cfg.minibatches
+        rows = eng._perms[0][:mb]
+        v_target = eng.b_adv.reshape(n)
+        grad = torch.zeros_like(eng.flat_grad)
+        reps = 200
+        for k in range(reps + 5):
+            if k == 5:
+                a.record()
+            N.check(lib.srlx_ppo_net_minibatch(mb, N.tptr(rows), cfg.obs_dim, cfg.action_dim, N.tptr(eng.flat), N.tptr(eng.b_obs), N.tptr(eng.b_act), N.tptr(eng.b_logp),
+                                               N.tptr(eng.b_adv), N.tptr(v_target), N.tptr(eng.b_val), eng.ls_range[0], eng.ls_range[1], 1, 1, cfg.policy_clip_range, 1,
+                                               cfg.value_clip_range, cfg.value_loss_weight, cfg.entropy_weight, N.tptr(eng.partials), N.tptr(grad), None, N.torch_stream_ptr()))
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        tiles = (mb + 63) // 64
+        mfma_flops = tiles * 9 * 2.0 * 64 * 64 * 64  # three 64 x 64 layers: forward, data gradient, weight gradient, on 64-sample tiles
+        small_flops = mb * 2.0 * (3 * cfg.obs_dim * 64 + 3 * 64 * (1 + 2 * cfg.action_dim))  # first layer and heads: forward + both gradients, vector units
+        roofline = {"kernel": "k_ppo_minibatch (srlx_ppo_net_minibatch: gather + forward + compute_train_loss + backward of one minibatch; the three 64 x 64 layers on "
+                              "v_mfma_f32_32x32x2_f32, per-workgroup gradient sums in registers) + k_ppo_reduce",
+                    "bound": "mfma", "achieved": (mfma_flops + small_flops) / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": (mfma_flops + small_flops) / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+                    "executed_mfma_flops_per_launch": mfma_flops, "algorithmic_f32_flops_per_launch": mfma_flops + small_flops, "samples_per_launch": mb,
+                    "algorithmic_bytes_per_launch": mb * 4 * (cfg.obs_dim + 2 * cfg.action_dim + 3 + 2) + 2 * 256 * 4 * eng.flat.numel(),
+                    "share_of_iteration": cfg.epochs * cfg.minibatches * ms / (1e3 * elapsed / args.steps),
+                    "note": "float32 in, float32 accumulate (the f32 MFMA peak equals the vector peak: the matrix cores are used for operand reuse, not for rate); "
+                            "isolated launches on the engine's buffers, HIP events on the launch stream (they bracket the launch PAIR: the reduction is ~6 us of it); "
+                            "per 64-sample tile the kernel measures ~3.2 k clocks per 32-MFMA product against the pipe's 2.0 k, plus ~20 k clocks of vector phases "
+                            "(first layer, heads, loss, head gradients) and barriers per 30 k of MFMA; rocprofv3 cross-check: profiles/r6_ppo_kernel_stats.csv; HBM "
+                            "traffic is the gathered samples (~50 B each) and the 13 MB of per-workgroup partial gradients: far from the bound"}
+    else:
+        # the GAE scan in isolation: 16 B read + 8 B written per (environment, step)
+        r, v, d, lv, adv = (torch.rand(T, E, device=dev), torch.rand(T, E, device=dev), (torch.rand(T, E, device=dev) < 0.01).to(torch.uint8), torch.rand(E, device=dev),
+                            torch.zeros(T, E, device=dev))
+        reps = 200
+        for k in range(reps + 5):
+            if k == 5:
+                a.record()
+            N.check(lib.srlx_gae_scan(E, T, N.tptr(r), N.tptr(v), N.tptr(d), N.tptr(lv), cfg.discount, cfg.gae_discount, N.tptr(adv), N.torch_stream_ptr()))
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        nbytes = T * E * 13 + 4 * E  # rewards, values (f32), done (u8) read + advantage written, + the bootstrap values
+        roofline = {"kernel": "k_gae_scan (srlx_gae_scan: the whole [T][E] rollout in one launch)", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes, "avg_launch_ms": ms,
+                    "note": "isolated launches; latency-bound; NOT where this line's time goes: with other network blocks than the reference's defaults the iteration is "
+                            "dominated by the torch modules' forward / backward"}
+    graphs = eng._update_graph is not None
     out = {
         "metric": "env-steps/sec + learner updates/sec, PPO continuous (Pendulum-shaped)", "value": args.steps * T * E * world / elapsed, "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
@@ -624,16 +665,15 @@ def bench_ppo(args, dev_index, rank, world, dist):
         "rccl_ranks": (dist.get_world_size() if dist is not None and args.backend == "nccl" else 1),
         "config": {"workload": "PPO continuous actions on Pendulum-shaped vectorised environments (BASELINE.json configs[4]); one step = one iteration: horizon x envs "
                                "environment steps + epochs x minibatches updates per GPU", "envs_per_gpu": E, "horizon": T, "epochs": cfg.epochs, "minibatches": cfg.minibatches,
-                   "parallelism": f"dp{world}: identical networks, disjoint environments, one flat gradient all-reduce per minibatch" if world > 1 else "single GPU",
-                   "networks": "torch MLPs (64-64 trunk, 64 value, 64 policy); libsrlx: environments, normal-policy sampling, GAE scan, PPO loss + gradient seeds",
-                   "hip_graphs": (not args.no_graph) and world == 1},
-        "roofline": {"kernel": "k_gae_scan (srlx_gae_scan: the whole [T][E] rollout in one launch)", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes, "avg_launch_ms": ms,
-                     "note": "isolated launches; 2.7 MB per launch at E = 4096, T = 32: latency-bound (the kernel is one dependent chain of T steps per environment)"},
+                   "parallelism": (f"dp{world}: identical networks, disjoint environments, one all-reduce of the flat 52 KB gradient per minibatch"
+                                   + (" inside the captured update graph" if graphs else "")) if world > 1 else "single GPU",
+                   "networks": ("libsrlx (csrc/srlx_ppo_net.hip): the whole rollout (T network passes, policy samples, environment steps, GAE) is one launch, a minibatch "
+                                "update three (forward + loss + backward; gradient reduction; clip + Adam)") if eng.fused else
+                               "torch MLPs (64-64 trunk, 64 value, 64 policy); libsrlx: environments, normal-policy sampling, GAE scan, PPO loss + gradient seeds",
+                   "hip_graphs": graphs},
+        "roofline": roofline,
         "final": {k: info.get(k) for k in ("policy_loss", "value_loss", "entropy_loss")},
     }
-    out["roofline"]["note"] += ("; NOT where this line's time goes: the iteration is dominated by the torch MLPs' forward / backward (hipBLASLt GEMMs at 64-wide "
-                                "layers, inside two HIP graphs) -- libsrlx owns the environments, the sampling, this scan and the loss")
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_ppo(args, cfg)
     print(json.dumps(out), flush=True)

@@ -393,6 +393,46 @@ int srlx_pendulum_step(int64_t n_envs, float *d_state, int32_t *d_step_in_episod
                        uint64_t seed, int64_t *d_counter, float *d_obs, float *d_reward, uint8_t *d_done, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * PPO's actor-critic in libsrlx (round 6): the network of srl/algorithms/ppo/ppo.py:55-99 with the reference's default blocks
+ * (config.py:47: hidden (64, 64), value (64,), policy (64,); Normal head: loc + log_scale layers) -- forward, loss, backward, clip and
+ * Adam -- so that an iteration is ~50 launches instead of ~1700 framework kernels.  Parameters: ONE float32 vector in the order of
+ * `ActorCritic.parameters()` (weights [out][in]): w1 [64][obs], b1, w2 [64][64], b2, wv [64][64], bv, wvo [1][64], bvo, wp [64][64], bp,
+ * wloc [A][64], bloc, wls [A][64], bls; obs_dim <= 8, action_dim <= 4.  float32, fmaf accumulation in ascending input order.
+ *   srlx_ppo_net_param_count    : length of that vector (-1: geometry not covered).
+ *   srlx_ppo_net_forward        : v f32 [n], loc / log_scale f32 [n][A] of obs f32 [n][obs_dim] (evaluation, tests, environments
+ *       stepped by the host side).
+ *   srlx_ppo_net_rollout        : ppo.py:316-339 (policy) + the environment + :389-404 (GAE) for `horizon` steps of `n_envs`
+ *       (a multiple of 16) Pendulum-shaped environments in ONE launch: the arithmetic of srlx_ppo_normal_act (key: act_seed,
+ *       *d_act_counter + t, 2 (env x A + dim)), srlx_pendulum_step (env_seed, *d_env_counter + t) and srlx_gae_scan; both counters
+ *       advance by `horizon`.  env_obs f32 [E][3] = the observation it starts from and (afterwards) ends at; b_obs f32 [T+1][E][3],
+ *       b_act / b_logp f32 [T][E][A], b_val / b_rew / b_adv f32 [T][E], b_done u8 [T][E], last_v f32 [E] = V(s_T),
+ *       episode_return f32 [E] (running), finished f32 [2] += (sum of finished episodes' returns, their count).
+ *   srlx_ppo_net_minibatch      : one minibatch of compute_train_loss (:102-169) + backward: rows i64 [minibatch] index the flattened
+ *       [T x E] buffers (b_val = the rollout's values = old_v); partials f32 [srlx_ppo_net_partials_floats]: scratch; grad f32
+ *       [param_count] = d loss / d parameters (sums in a fixed order: deterministic); losses f32 [3] or NULL.
+ *   srlx_ppo_net_adam           : grad *= grad_scale (1 / world size behind a data-parallel all-reduce); global-norm clip
+ *       (max_grad_norm, 0 = off: torch.nn.utils.clip_grad_norm_, ppo.py:240-241); torch.optim.Adam step; *d_step += 1.
+ * ------------------------------------------------------------------------------------------------ */
+int srlx_ppo_net_param_count(int obs_dim, int action_dim);
+int srlx_ppo_net_partials_floats(int obs_dim, int action_dim);
+int srlx_ppo_net_forward(int64_t n, int obs_dim, int action_dim, const float *d_params, const float *d_obs, float *d_v, float *d_loc,
+                         float *d_log_scale, void *stream);
+int srlx_ppo_net_rollout(int64_t n_envs, int64_t horizon, int action_dim, const float *d_params, float *d_env_state,
+                         int32_t *d_step_in_episode, float *d_env_obs, int64_t episode_len, uint64_t env_seed, int64_t *d_env_counter,
+                         uint64_t act_seed, int64_t *d_act_counter, double log_scale_min, double log_scale_max, double discount,
+                         double gae_lambda, float *d_b_obs, float *d_b_act, float *d_b_logp, float *d_b_val, float *d_b_rew,
+                         uint8_t *d_b_done, float *d_b_adv, float *d_last_v, float *d_episode_return, float *d_finished, void *stream);
+int srlx_ppo_net_minibatch(int64_t minibatch, const int64_t *d_rows, int obs_dim, int action_dim, const float *d_params,
+                           const float *d_b_obs, const float *d_b_act, const float *d_b_logp, const float *d_b_adv,
+                           const float *d_b_v_target, const float *d_b_val, double log_scale_min, double log_scale_max,
+                           int baseline_advantage, int surrogate_clip, double policy_clip_range, int enable_value_clip,
+                           double value_clip_range, double value_loss_weight, double entropy_weight, float *d_partials, float *d_grad,
+                           float *d_losses, void *stream);
+int srlx_ppo_net_adam(int obs_dim, int action_dim, float *d_params, float *d_grad, float *d_exp_avg, float *d_exp_avg_sq,
+                      int64_t *d_step, double lr, double beta1, double beta2, double eps, double max_grad_norm, double grad_scale,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Never-Give-Up intrinsic reward + Agent57_light priorities
  *
  * srlx_ngu_t: one bounded episodic memory per environment, [E][emb_dim][capacity] float32 in HBM

@@ -165,6 +165,14 @@ SIGNATURES = {
                                      c_p, c_p, c_p, c_p, c_p]),
     "srlx_ppo_loss_logpi": (c_int, [c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_f64, c_int, c_f64, c_f64, c_f64, c_p, c_p, c_p, c_p]),
     "srlx_pendulum_step": (c_int, [c_i64, c_p, c_p, c_p, c_i64, c_u64, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_ppo_net_param_count": (c_int, [c_int, c_int]),
+    "srlx_ppo_net_partials_floats": (c_int, [c_int, c_int]),
+    "srlx_ppo_net_forward": (c_int, [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_ppo_net_rollout": (c_int, [c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_i64, c_u64, c_p, c_u64, c_p, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                     c_p, c_p, c_p]),
+    "srlx_ppo_net_minibatch": (c_int, [c_i64, c_p, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_int, c_int, c_f64, c_int, c_f64, c_f64, c_f64, c_p, c_p, c_p,
+                                       c_p]),
+    "srlx_ppo_net_adam": (c_int, [c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_f64, c_f64, c_f64, c_f64, c_f64, c_f64, c_p]),
     "srlx_ngu_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_int, c_i64, c_int, c_f64, c_f64, c_f64, c_int]),
     "srlx_ngu_destroy": (c_int, [c_p]),
     "srlx_ngu_reset": (c_int, [c_p, c_p]),

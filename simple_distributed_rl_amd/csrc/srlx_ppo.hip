@@ -14,18 +14,13 @@
 // All of them are tiny elementwise/reduction kernels (B x action_dim floats): their point is launch count --
 // one launch instead of ~40 framework kernels per minibatch.
 #include "srlx_common.h"
+#include "srlx_ppo_math.h"
 
 namespace {
 
 using i64 = int64_t;
 using u8 = unsigned char;
-using srlx::rng_u64;
-using srlx::u53;
-
-constexpr float kHalfLog2Pi = 0.91893853320467274178f;  // 0.5 * log(2 pi)
-constexpr float kLogFloor = -13.815510557964274f;      // math.log(1e-6), ppo.py:322
-
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+using srlxp::LossCfg;
 
 __device__ __forceinline__ float block_sum(float v, float *red) {
     const int t = threadIdx.x;
@@ -40,24 +35,11 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return r;
 }
 
-// action = loc + exp(log_scale) * N(0,1) (Box-Muller on two keyed uniforms); log_prob per dimension, floored at log(1e-6)
 __global__ void __launch_bounds__(256) k_normal_act(i64 n, const float *loc, const float *log_scale, float ls_lo, float ls_hi, unsigned long long seed,
                                                     const i64 *counter, int deterministic, float *action, float *logprob) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float ls = clampf(log_scale[i], ls_lo, ls_hi);  // enable_stable_gradients clip, normal_dist_block.py:144-149
-    const float sd = expf(ls);
-    float a = loc[i];
-    if (!deterministic) {
-        const unsigned long long c = (unsigned long long)counter[0];
-        const double u1 = 1.0 - u53(rng_u64(seed, c, (unsigned long long)(2 * i)));  // (0, 1]
-        const double u2 = u53(rng_u64(seed, c, (unsigned long long)(2 * i + 1)));
-        const float z = (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
-        a = loc[i] + sd * z;
-    }
-    const float q = (a - loc[i]) / sd;
-    action[i] = a;
-    logprob[i] = fmaxf(-kHalfLog2Pi - ls - 0.5f * (q * q), kLogFloor);
+    srlxp::normal_act_one(loc[i], log_scale[i], ls_lo, ls_hi, seed, deterministic ? 0ull : (unsigned long long)counter[0], i, deterministic, action[i], logprob[i]);
 }
 
 struct PpoArgs {
@@ -78,7 +60,8 @@ struct PpoArgs {
 template <bool NORMAL>
 __global__ void __launch_bounds__(256) k_ppo_loss(PpoArgs a) {
     __shared__ float red[256];
-    const float inv_b = 1.0f / (float)a.B, inv_bk = 1.0f / (float)(a.B * a.K);
+    LossCfg c{a.ls_lo, a.ls_hi, a.baseline_advantage, a.surrogate_clip, a.value_clip, a.policy_clip, a.value_clip_range, a.value_w, a.entropy_w,
+              1.0f / (float)a.B, 1.0f / (float)(a.B * a.K)};
     float s_pol = 0.f, s_val = 0.f, s_ent = 0.f;
     for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += (i64)gridDim.x * blockDim.x) {
         const float v = a.v[b], vt = a.v_target[b];
@@ -86,96 +69,37 @@ __global__ void __launch_bounds__(256) k_ppo_loss(PpoArgs a) {
         float ent = 0.f;
         for (int k = 0; k < a.K; k++) {
             const i64 i = b * a.K + k;
-            float lp, q = 0.f, ls_raw = 0.f;
-            if (NORMAL) {
-                ls_raw = a.log_scale[i];
-                const float ls = clampf(ls_raw, a.ls_lo, a.ls_hi);
-                q = (a.action[i] - a.loc[i]) / expf(ls);
-                lp = -kHalfLog2Pi - ls - 0.5f * (q * q);  // normal_dist_block.py:13-20
-            } else {
-                lp = a.new_logpi[i];
-            }
-            const float ratio = expf(lp - a.old_logpi[i]);  // :126
-            float g_ratio;                                    // d policy_term / d ratio
-            float term;
-            if (a.surrogate_clip) {  // :127-137
-                const float rc = clampf(ratio, 1.0f - a.policy_clip, 1.0f + a.policy_clip);
-                const float lu = ratio * adv, lc = rc * adv;
-                term = fminf(lu, lc);
-                g_ratio = lu <= lc ? adv : 0.f;  // tf.minimum routes the gradient to its first argument on ties
-            } else {  // surrogate_type == "" (:148-149)
-                term = ratio * adv;
-                g_ratio = adv;
-            }
+            float term, e1;
+            if (NORMAL)
+                srlxp::policy_normal(c, a.loc[i], a.log_scale[i], a.action[i], a.old_logpi[i], adv, term, e1, a.d_loc[i], a.d_log_scale[i]);
+            else
+                a.d_logpi[i] = srlxp::policy_lp_terms(c, a.new_logpi[i], a.old_logpi[i], adv, term, e1);
             s_pol += term;
-            const float elp = expf(lp);
-            ent += -elp * lp;  // :166
-            // d loss / d lp: policy (-mean over B*K), entropy (weight * -mean over B of the per-sample sum)
-            const float g_lp = -inv_bk * g_ratio * ratio + a.entropy_w * inv_b * (elp * lp + elp);
-            if (NORMAL) {
-                const bool pass = ls_raw >= a.ls_lo && ls_raw <= a.ls_hi;  // clip_by_value passes the gradient inside the range
-                a.d_loc[i] = g_lp * (q / expf(clampf(ls_raw, a.ls_lo, a.ls_hi)));
-                a.d_log_scale[i] = pass ? g_lp * (q * q - 1.0f) : 0.f;
-            } else {
-                a.d_logpi[i] = g_lp;
-            }
+            ent += e1;
         }
         s_ent += ent;
-        // value loss :152-158
-        const float e1 = v - vt;
         float g_v;
-        if (a.value_clip) {
-            const float ov = a.old_v[b];
-            const float vc = clampf(v, ov - a.value_clip_range, ov + a.value_clip_range);
-            const float e2 = vc - vt;
-            const float l1 = e1 * e1, l2 = e2 * e2;
-            s_val += fmaxf(l1, l2);
-            // tf.maximum routes the gradient to its first argument on ties; the clipped branch only inside the range
-            g_v = l1 >= l2 ? 2.0f * e1 : ((v >= ov - a.value_clip_range && v <= ov + a.value_clip_range) ? 2.0f * e2 : 0.f);
-        } else {
-            s_val += e1 * e1;
-            g_v = 2.0f * e1;
-        }
-        a.d_v[b] = a.value_w * inv_b * g_v;
+        s_val += srlxp::value_term(c, v, vt, a.value_clip ? a.old_v[b] : 0.f, g_v);
+        a.d_v[b] = g_v;
     }
     const float p = block_sum(s_pol, red), vl = block_sum(s_val, red), en = block_sum(s_ent, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&a.losses[0], -inv_bk * p);
-        atomicAdd(&a.losses[1], a.value_w * inv_b * vl);
-        atomicAdd(&a.losses[2], a.entropy_w * -inv_b * en);
+        atomicAdd(&a.losses[0], -c.inv_bk * p);
+        atomicAdd(&a.losses[1], a.value_w * c.inv_b * vl);
+        atomicAdd(&a.losses[2], a.entropy_w * -c.inv_b * en);
     }
 }
 
-// Pendulum dynamics (the classic-control task config 5 is shaped on): th'' = 3g/(2l) sin th + 3/(m l^2) u
 __global__ void __launch_bounds__(256) k_pendulum(i64 E, float *state /*[E][2] th, thdot*/, int32_t *t_in_ep, const float *action, i64 episode_len,
                                                   unsigned long long seed, const i64 *counter, float *obs /*[E][3]*/, float *reward, u8 *done) {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
-    const float g = 10.0f, m = 1.0f, l = 1.0f, dt = 0.05f, max_speed = 8.0f, max_torque = 2.0f;
     float th = state[2 * e], thd = state[2 * e + 1];
-    const float u = clampf(action[e], -max_torque, max_torque);
-    const float pi = 3.14159265358979323846f;
-    float an = fmodf(th + pi, 2.0f * pi);
-    if (an < 0.f) an += 2.0f * pi;
-    an -= pi;  // angle_normalize
-    reward[e] = -(an * an + 0.1f * thd * thd + 0.001f * u * u);
-    thd = clampf(thd + (3.0f * g / (2.0f * l) * sinf(th) + 3.0f / (m * l * l) * u) * dt, -max_speed, max_speed);
-    th = th + thd * dt;
-    int t = t_in_ep[e] + 1;
-    const bool end = t >= episode_len;  // a time limit: truncation, not termination
-    done[e] = end ? 1 : 0;
-    if (end) {  // auto-reset: th ~ U(-pi, pi), thdot ~ U(-1, 1)
-        const unsigned long long c = (unsigned long long)counter[0];
-        th = (float)((2.0 * u53(rng_u64(seed ^ 0x70656e64ull, c, (unsigned long long)(2 * e))) - 1.0) * 3.14159265358979323846);
-        thd = (float)(2.0 * u53(rng_u64(seed ^ 0x70656e64ull, c, (unsigned long long)(2 * e + 1))) - 1.0);
-        t = 0;
-    }
+    int t = t_in_ep[e];
+    srlxp::pendulum_one(th, thd, t, action[e], episode_len, seed, (unsigned long long)counter[0], e, obs[3 * e], obs[3 * e + 1], obs[3 * e + 2], reward[e], done[e]);
     state[2 * e] = th;
     state[2 * e + 1] = thd;
     t_in_ep[e] = t;
-    obs[3 * e] = cosf(th);
-    obs[3 * e + 1] = sinf(th);
-    obs[3 * e + 2] = thd;
 }
 
 __global__ void k_advance1(i64 *c) { c[0] += 1; }

@@ -13,8 +13,15 @@ GAE value used as v_target and as advantage with `baseline_type="advantage"` sub
 -- `v_target="return"` selects the textbook target (advantage + V) instead --, clipped surrogate, value clipping,
 entropy bonus on the taken action's log-prob (:166), global gradient clipping (:240-241).
 
+Round 6: with the reference's default blocks (hidden (64, 64), value (64,), policy (64,)) the network itself is libsrlx code too (`fused`, the default then;
+csrc/srlx_ppo_net.hip): the WHOLE rollout of an iteration -- T network passes, policy samples, environment steps, the buffers, V(s_T), the GAE scan -- is one
+launch, a minibatch update is three (forward + loss + backward; gradient reduction; clip + Adam), and an iteration is ~55 launches instead of ~1700 framework
+kernels.  The parameters are one flat float32 vector; the `ActorCritic` module's tensors are views of it.  `fused=False` keeps the torch-autograd path as the
+yardstick the fused one is tested against.
+
 Data parallel (config 5): `DistributedPPO` gives every rank its own E environments and averages the gradients of
-every minibatch with one all-reduce of a flat ~40 KB buffer (latency-bound; RCCL over xGMI) -- the only exchange.
+every minibatch with one all-reduce of the flat ~52 KB gradient vector (latency-bound; RCCL over xGMI) -- the only exchange; with the fused network and RCCL
+it sits INSIDE the captured update graph, between the gradient reduction and the clip + Adam launch.
 """
 import ctypes
 import math
@@ -106,7 +113,11 @@ class PendulumVecEnv:
 
 
 class PPOEngine:
-    def __init__(self, cfg: PPODeviceConfig, device: int = 0, grad_sync: Optional[Callable[[nn.Module], None]] = None):
+    def __init__(self, cfg: PPODeviceConfig, device: int = 0, grad_sync: Optional[Callable[[nn.Module], None]] = None, fused: Optional[bool] = None,
+                 flat_grad_sync: Optional[Callable[[torch.Tensor], float]] = None):
+        """fused: the network in libsrlx (None: whenever the geometry is the reference's default blocks; True: required; False: torch modules + autograd, the test
+        yardstick).  grad_sync(module): the torch path's gradient exchange; flat_grad_sync(flat_grad) -> scale: the fused path's (all-reduces the flat gradient in
+        place, returns the factor the optimiser launch applies: 1 / world size)."""
         if not torch.cuda.is_available():
             raise RuntimeError("simple_distributed_rl_amd.device.ppo needs an MI355X: its rollout / GAE / loss arithmetic is libsrlx HIP code (no CPU fallback)")
         if cfg.surrogate_type not in ("clip", ""):
@@ -115,8 +126,29 @@ class PPOEngine:
         self.dev = torch.device(f"cuda:{device}")
         torch.manual_seed(cfg.seed)
         self.net = ActorCritic(cfg).to(self.dev)
-        self.opt = torch.optim.Adam(self.net.parameters(), lr=cfg.lr, capturable=True)
-        self.grad_sync = grad_sync
+        can_fuse = (tuple(cfg.hidden_sizes) == (64, 64) and tuple(cfg.value_sizes) == (64,) and tuple(cfg.policy_sizes) == (64,) and 1 <= cfg.obs_dim <= 8
+                    and 1 <= cfg.action_dim <= 4)
+        if fused and not can_fuse:
+            raise ValueError("PPOEngine(fused=True): the libsrlx network covers hidden (64, 64), value (64,), policy (64,), obs_dim <= 8, action_dim <= 4")
+        self.fused = can_fuse if fused is None else bool(fused)
+        self.grad_sync, self.flat_grad_sync = grad_sync, flat_grad_sync
+        if self.fused:
+            # one flat parameter vector in `parameters()` order; the module's tensors become views of it (state_dict / export keep working, always current)
+            P = self.lib.srlx_ppo_net_param_count(cfg.obs_dim, cfg.action_dim)
+            ps = list(self.net.parameters())
+            assert sum(p.numel() for p in ps) == P
+            self.flat = torch.cat([p.detach().reshape(-1) for p in ps]).contiguous()
+            off = 0
+            for p in ps:
+                p.data = self.flat[off : off + p.numel()].view_as(p)
+                off += p.numel()
+            self.flat_grad = torch.zeros(P, dtype=torch.float32, device=self.dev)
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+            self.opt_step = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.partials = torch.zeros(self.lib.srlx_ppo_net_partials_floats(cfg.obs_dim, cfg.action_dim), dtype=torch.float32, device=self.dev)
+            self.opt = None
+        else:
+            self.opt = torch.optim.Adam(self.net.parameters(), lr=cfg.lr, capturable=True)
         self.env = PendulumVecEnv(cfg.n_envs, cfg.episode_len, cfg.seed, self.dev)
         self.ls_range = (math.log(cfg.stable_gradients_scale_range[0]), math.log(cfg.stable_gradients_scale_range[1]))
         E, T, A, d = cfg.n_envs, cfg.horizon, cfg.action_dim, self.dev
@@ -134,6 +166,7 @@ class PPOEngine:
         self.iterations = 0
         self._rollout_graph = None
         self._update_graph = None
+        self._last_v = torch.zeros(E, **f32)
         self.episode_return = torch.zeros(E, **f32)
         self.finished_returns = torch.zeros(2, **f32)  # sum, count of finished episodes since the last read
         # One minibatch permutation per epoch from libsrlx's keyed permutation kernel (srlx_rng_permutation: device state only), INSIDE the captured
@@ -150,15 +183,36 @@ class PPOEngine:
 
     # --- rollout ---------------------------------------------------------------------------------------------------
     def act(self, obs: torch.Tensor, action_out: torch.Tensor, logp_out: torch.Tensor, deterministic: bool = False):
-        with torch.no_grad():
-            v, loc, ls = self.net(obs)
+        v, loc, ls = self.forward(obs)
         self._keep = (loc, ls)
         N.check(self.lib.srlx_ppo_normal_act(loc.numel(), N.tptr(loc), N.tptr(ls), self.ls_range[0], self.ls_range[1], self.cfg.seed ^ 0x61637400,
                                              N.tptr(self.act_counter), int(deterministic), N.tptr(action_out), N.tptr(logp_out), N.torch_stream_ptr()))
         return v
 
+    def forward(self, obs: torch.Tensor):
+        """(v [n], loc [n][A], log_scale [n][A]) of obs [n][obs_dim]: the libsrlx network when fused, the torch modules otherwise."""
+        if not self.fused:
+            with torch.no_grad():
+                return self.net(obs)
+        n, A = obs.shape[0], self.cfg.action_dim
+        v, loc, ls = (torch.empty(n, dtype=torch.float32, device=self.dev), torch.empty((n, A), dtype=torch.float32, device=self.dev),
+                      torch.empty((n, A), dtype=torch.float32, device=self.dev))
+        N.check(self.lib.srlx_ppo_net_forward(n, self.cfg.obs_dim, A, N.tptr(self.flat), N.tptr(obs.contiguous()), N.tptr(v), N.tptr(loc), N.tptr(ls), N.torch_stream_ptr()))
+        return v, loc, ls
+
+    def _fused_rollout_ok(self) -> bool:
+        return self.fused and isinstance(self.env, PendulumVecEnv) and self.cfg.obs_dim == 3 and self.cfg.n_envs % 16 == 0 and self.cfg.horizon <= 1024
+
     def rollout(self):
         cfg = self.cfg
+        if self._fused_rollout_ok():  # T steps of everything in ONE launch (csrc/srlx_ppo_net.hip: k_ppo_rollout)
+            env = self.env
+            N.check(self.lib.srlx_ppo_net_rollout(cfg.n_envs, cfg.horizon, cfg.action_dim, N.tptr(self.flat), N.tptr(env.state), N.tptr(env.t), N.tptr(env.obs), env.episode_len,
+                                                  env.seed, N.tptr(env.counter), cfg.seed ^ 0x61637400, N.tptr(self.act_counter), self.ls_range[0], self.ls_range[1],
+                                                  cfg.discount, cfg.gae_discount, N.tptr(self.b_obs), N.tptr(self.b_act), N.tptr(self.b_logp), N.tptr(self.b_val),
+                                                  N.tptr(self.b_rew), N.tptr(self.b_done), N.tptr(self.b_adv), N.tptr(self._last_v), N.tptr(self.episode_return),
+                                                  N.tptr(self.finished_returns), N.torch_stream_ptr()))
+            return
         for t in range(cfg.horizon):
             self.b_val[t].copy_(self.act(self.b_obs[t], self.b_act[t], self.b_logp[t]))
             self.env.step(self.b_act[t, :, 0].contiguous() if cfg.action_dim > 1 else self.b_act[t].view(-1), self.b_obs[t + 1], self.b_rew[t], self.b_done[t])
@@ -167,8 +221,7 @@ class PPOEngine:
             self.finished_returns[0] += (self.episode_return * d).sum()
             self.finished_returns[1] += d.sum()
             self.episode_return.masked_fill_(d, 0.0)
-        with torch.no_grad():
-            last_v, _, _ = self.net(self.b_obs[cfg.horizon])
+        last_v, _, _ = self.forward(self.b_obs[cfg.horizon])
         # episode ends are never bootstrapped (ppo.py:396-397); a horizon cut inside an episode bootstraps from V(s_T)
         N.check(self.lib.srlx_gae_scan(cfg.n_envs, cfg.horizon, N.tptr(self.b_rew), N.tptr(self.b_val), N.tptr(self.b_done), N.tptr(last_v.contiguous()),
                                        cfg.discount, cfg.gae_discount, N.tptr(self.b_adv), N.torch_stream_ptr()))
@@ -199,6 +252,8 @@ class PPOEngine:
         val = self.b_val.reshape(n)
         v_target = adv if cfg.v_target == "gae" else adv + val
         mb = n // cfg.minibatches
+        if self.fused:
+            return self._update_fused(n, mb, obs, act, logp, adv, val, v_target)
         for ep in range(cfg.epochs):
             if self._perm_mode == "srlx":
                 N.check(self.lib.srlx_rng_permutation(cfg.seed ^ 0x7065726D, N.tptr(self.perm_counter), n, N.tptr(self._perms[ep]), N.torch_stream_ptr()))
@@ -214,6 +269,24 @@ class PPOEngine:
                 if cfg.global_gradient_clip_norm != 0:
                     torch.nn.utils.clip_grad_norm_(self.net.parameters(), cfg.global_gradient_clip_norm)
                 self.opt.step()
+
+    def _update_fused(self, n, mb, obs, act, logp, adv, val, v_target):
+        """epochs x minibatches of (k_ppo_minibatch + k_ppo_reduce) -> [all-reduce of the flat gradient] -> k_ppo_adam; the buffers are read in place through the
+        permutation's rows."""
+        cfg = self.cfg
+        st = N.torch_stream_ptr()
+        for ep in range(cfg.epochs):
+            if self._perm_mode == "srlx":
+                N.check(self.lib.srlx_rng_permutation(cfg.seed ^ 0x7065726D, N.tptr(self.perm_counter), n, N.tptr(self._perms[ep]), st))
+            for k in range(cfg.minibatches):
+                rows = self._perms[ep][k * mb : (k + 1) * mb]
+                N.check(self.lib.srlx_ppo_net_minibatch(mb, N.tptr(rows), cfg.obs_dim, cfg.action_dim, N.tptr(self.flat), N.tptr(obs), N.tptr(act), N.tptr(logp), N.tptr(adv),
+                                                        N.tptr(v_target), N.tptr(val), self.ls_range[0], self.ls_range[1], int(cfg.baseline_type == "advantage"),
+                                                        int(cfg.surrogate_type == "clip"), cfg.policy_clip_range, int(cfg.enable_value_clip), cfg.value_clip_range,
+                                                        cfg.value_loss_weight, cfg.entropy_weight, N.tptr(self.partials), N.tptr(self.flat_grad), N.tptr(self.losses), st))
+                scale = self.flat_grad_sync(self.flat_grad) if self.flat_grad_sync is not None else 1.0
+                N.check(self.lib.srlx_ppo_net_adam(cfg.obs_dim, cfg.action_dim, N.tptr(self.flat), N.tptr(self.flat_grad), N.tptr(self.exp_avg), N.tptr(self.exp_avg_sq),
+                                                   N.tptr(self.opt_step), cfg.lr, 0.9, 0.999, 1e-8, cfg.global_gradient_clip_norm, scale, st))
 
     def capture_graphs(self):
         """Captures the T-step rollout (+ GAE) and the whole update phase into two HIP graphs: an iteration becomes two
@@ -292,28 +365,51 @@ def flat_grad_all_reduce(net: nn.Module, group=None):
         off += g.numel()
 
 
+def flat_vector_all_reduce(flat: torch.Tensor, group=None) -> float:
+    """The fused network's exchange: ONE in-place all-reduce (sum) of the flat gradient vector; returns 1 / world size, which the clip + Adam launch applies.  With
+    RCCL the collective is captured into the update graph like any other node; gloo (test rigs: ranks sharing one GPU) stages through the host and runs eagerly."""
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "gloo" and flat.is_cuda:
+        h = flat.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(h)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / dist.get_world_size(group)
+
+
 class DistributedPPO:
     """Data-parallel PPO (BASELINE config 5): identical networks, disjoint environments, averaged gradients."""
 
-    def __init__(self, cfg: PPODeviceConfig, device: int):
+    def __init__(self, cfg: PPODeviceConfig, device: int, fused: Optional[bool] = None):
         import dataclasses
 
         import torch.distributed as dist
 
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         local = dataclasses.replace(cfg, seed=cfg.seed)  # same seed -> same initial network on every rank
-        self.engine = PPOEngine(local, device, grad_sync=flat_grad_all_reduce)
+        self.engine = PPOEngine(local, device, grad_sync=flat_grad_all_reduce, flat_grad_sync=flat_vector_all_reduce, fused=fused)
         # decorrelate environments and sampling noise across ranks
         self.engine.env = PendulumVecEnv(cfg.n_envs, cfg.episode_len, cfg.seed + 7919 * (self.rank + 1), self.engine.dev)
         self.engine.b_obs[0].copy_(self.engine.env.obs)
         self.engine.act_counter.fill_(self.rank << 40)
-        for p in self.engine.net.parameters():  # belt and braces: one broadcast of the initial parameters
-            if dist.get_backend() == "gloo" and p.is_cuda:
-                h = p.data.cpu()
+        tensors = [self.engine.flat] if self.engine.fused else [p.data for p in self.engine.net.parameters()]
+        for t in tensors:  # belt and braces: one broadcast of the initial parameters
+            if dist.get_backend() == "gloo" and t.is_cuda:
+                h = t.cpu()
                 dist.broadcast(h, src=0)
-                p.data.copy_(h)
+                t.copy_(h)
             else:
-                dist.broadcast(p.data, src=0)
+                dist.broadcast(t, src=0)
+
+    def capture_graphs(self):
+        """The rollout and the update as HIP graphs; with the fused network over RCCL the update's graph holds its 16 all-reduces of the flat gradient (every rank
+        replays the same graph, so the collectives stay matched).  Other set-ups keep the update eager (a host-staged gloo all-reduce cannot be captured)."""
+        import torch.distributed as dist
+
+        if self.engine.fused and dist.get_backend() == "nccl":
+            self.engine.capture_graphs()
 
     def step(self):
         self.engine.step()

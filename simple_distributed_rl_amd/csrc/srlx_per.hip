@@ -1381,6 +1381,9 @@ struct SampleScratch {
 int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double *d_u, i64 M, i64 *d_idx, double *d_w,
                   float *d_w32, i64 *d_used, hipStream_t st, u64 key_seed = 0, i64 *key_counter = nullptr) {
     const bool bulk = M > kSmallSampleMax;
+    // "d_step == key_counter" (the call's own draw number is the beta step; sample_wg_body) exists on the one-workgroup path only: the bulk sampler reads *d_step
+    // in later launches, when the counter has already moved -- refuse instead of annealing beta a step off, depending on launch order
+    SRLX_REQUIRE(!(bulk && d_step && (const void *)d_step == (const void *)key_counter), "per_sample: d_step == the draw counter needs the one-workgroup sampler (at most 8192 uniforms)");
     SRLX_TRY(h->scratch.reserve(SampleScratch::bytes(M, B, bulk)));
     srlx::Carver cv(h->scratch.ptr);
     SampleArgs a{};

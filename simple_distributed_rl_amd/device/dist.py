@@ -426,6 +426,10 @@ class DistributedRainbow:
             if j is not None:  # (after the updates: their warm-up gate saw the replay as the draw did)
                 self.replay.note_commit()
                 self._next_ingest = j + 1
+            if getattr(self, "_capture_pending", False) and eng.train_count > 0:
+                self._capture_pending = False
+                eng.join_learner()
+                eng.enable_lazy_capture()
         else:
             scal, obs = self._act(events, random_policy)  # (bus.send_end() of the previous slab sits between the policy pass and the environments)
             bus.send_begin(scal, obs)
@@ -478,7 +482,12 @@ class DistributedRainbow:
         """The actors' launches stay eager; the learner rank's update is captured per variant (set it publishes into x staging slot it commits) the first time
         each runs."""
         if self.is_learner:
-            self.local.enable_lazy_capture()
+            # a variant's first run allocates inside the library (packed filters, scratch, a side stream, event records): that must not happen inside a capture --
+            # before the learner's first (eager) update the switch waits for it (`step`)
+            if self.local.train_count > 0:
+                self.local.enable_lazy_capture()
+            else:
+                self._capture_pending = True
 
     def actor_forward_flops(self):
         return self.local.actor_forward_flops()

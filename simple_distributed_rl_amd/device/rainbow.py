@@ -349,6 +349,7 @@ class RainbowEngine:
         self._predraw = bool(self.fast and self._update_side and self.s_ingest is not None and getattr(self.lreplay, "two_sets", False)
                              and (sch.predraw if sch.predraw is not None else (learner_replay is not None and role == "learner")))
         self._bset, self._drawn, self._drawn_at = 0, None, 0
+        self._seen_commits, self._unnoted = 0, 0  # ring commits issued on the device that the host's count (`note_commit`) has not caught up with
         self.s_predraw = torch.cuda.Stream(device=self.dev, priority=-1) if self._predraw else None
 
     @property
@@ -730,8 +731,9 @@ class RainbowEngine:
         bset, have, pre = None, False, False
         if self._predraw:
             bset, pre = self._bset, True
-            # the set holds a batch the previous update drew -- unless more than one ring commit has passed since (updates paused): its frames may be gone
-            have = self._drawn == bset and r._steps_committed - self._drawn_at <= 1
+            # the set holds a batch the previous update drew -- unless a ring commit has run on the device since that draw (updates paused while slabs kept
+            # arriving): this update's own ingest is then the SECOND commit between the draw and its frame reads, and the margin is one slot
+            have = self._drawn == bset and self._device_commits() == self._drawn_at
             if self._drawn is not None and not have:
                 r.rng_counter.sub_(1)  # the stale draw is dropped: this update draws under the same number (the draw's number is the update's number)
         key = (publish, ing_key, bset, have)
@@ -743,9 +745,11 @@ class RainbowEngine:
             g.replay()
         else:
             self._learner_body(publish, ing_fn, bset, have, pre)
+        if ing is not None:
+            self._note_issued_commit()
         if self._predraw:
             r.use_set(bset)  # (host view: `batch`, `used`, ... name what THIS update trained on)
-            self._drawn, self._drawn_at, self._bset = 1 - bset, r._steps_committed, 1 - bset
+            self._drawn, self._drawn_at, self._bset = 1 - bset, self._device_commits(), 1 - bset  # (the pre-draw ran behind this update's own ingest)
         if self.fast:
             self._fresh_set = publish  # the planes of that set now hold the online weight (None: no set does)
         # model_torch.py:117-119 (fires at train_count 0 too)
@@ -753,6 +757,17 @@ class RainbowEngine:
             self.sync_target()
         self.train_count += 1
         return True
+
+    def _device_commits(self) -> int:
+        """Ring commits the device has been handed: the host's count plus the ingests issued since it last moved (a slab's `note_commit` follows the updates)."""
+        r = self.lreplay
+        if r._steps_committed != self._seen_commits:
+            self._seen_commits, self._unnoted = r._steps_committed, 0
+        return r._steps_committed + self._unnoted
+
+    def _note_issued_commit(self):
+        self._device_commits()
+        self._unnoted += 1
 
     def _capture_learner(self, key, ingest_fn, predraw: bool = False):
         g = torch.cuda.CUDAGraph()
@@ -803,6 +818,7 @@ class RainbowEngine:
             if self.ingest is not None:  # no update took the pending ingest with it (warm-up, or none asked for): commit it here, in stream order
                 ing, self.ingest = self.ingest, None
                 ing[1]()
+                self._note_issued_commit()
             self._ev_join.record(self.s_learner)
         self._learner_pending = True
         return ran
@@ -819,6 +835,7 @@ class RainbowEngine:
             if self.ingest is not None:
                 ing, self.ingest = self.ingest, None
                 ing[1]()
+                self._note_issued_commit()
         cur.wait_stream(self.s_learner)
         return ran
 

@@ -218,15 +218,26 @@ __global__ void __launch_bounds__(256) k_a57_emb_tail(EmbTailArgs a) {
     float *pr = dz + B * Hd;       // [B][A]   probabilities, then d logits
     float *rs = pr + B * A;        // [B]      1 / std
     float *red = rs + B;           // [256]
+    // the tail's own parameters in LDS (a row of w1 padded by one float: "lane j reads row j" and "lane k reads column k" are both conflict-free) -- read from
+    // global memory inside the loops below, the [Hd][2 D] weight cost a strided load per multiply-add and the launch 140 us; staged once it costs ~25
+    const int W1 = D2 + 1;
+    float *w1s = red + 256;        // [Hd][D2 + 1]
+    float *w2s = w1s + Hd * W1;    // [A][Hd]
+    float *gms = w2s + A * Hd;     // [Hd] LayerNorm weight
+    float *bts = gms + Hd;         // [Hd] LayerNorm bias
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool adam = a.ad.d_step != nullptr;
     const srlx::AdamCoef cf = adam ? srlx::adam_coef(a.ad.lr, a.ad.beta1, a.ad.beta2, a.ad.eps, *a.ad.d_step) : srlx::AdamCoef{};
+    for (int i = t; i < Hd * D2; i += 256) w1s[(i / D2) * W1 + i % D2] = a.w1.p[i];
+    for (int i = t; i < A * Hd; i += 256) w2s[i] = a.w2.p[i];
+    for (int i = t; i < Hd; i += 256) gms[i] = a.lnw.p[i], bts[i] = a.lnb.p[i];
     for (int i = t; i < B * D2; i += 256) x[i] = a.emb[i];  // (row b of x = rows 2 b, 2 b + 1 of emb back to back: torch.cat([f(s), f(s')], dim=1), model_torch.py:90)
     __syncthreads();
     for (int i = t; i < B * Hd; i += 256) {  // out_block: Linear + ReLU
         const int b = i / Hd, j = i % Hd;
         float s = a.b1.p[j];
-        const float *w = a.w1.p + (i64)j * D2, *xb = x + b * D2;
+        const float *w = w1s + j * W1, *xb = x + b * D2;
+#pragma unroll 8
         for (int k = 0; k < D2; k++) s += w[k] * xb[k];
         a1[i] = s > 0.f ? s : 0.f;
     }
@@ -241,8 +252,9 @@ __global__ void __launch_bounds__(256) k_a57_emb_tail(EmbTailArgs a) {
     for (int i = t; i < B * A; i += 256) {  // out_block_out1
         const int b = i / A, k = i % A;
         float s = a.b2.p[k];
-        const float *w = a.w2.p + (i64)k * Hd;
-        for (int j = 0; j < Hd; j++) s += w[j] * (xh[b * Hd + j] * a.lnw.p[j] + a.lnb.p[j]);
+        const float *w = w2s + k * Hd;
+#pragma unroll 8
+        for (int j = 0; j < Hd; j++) s += w[j] * (xh[b * Hd + j] * gms[j] + bts[j]);
         pr[i] = s;
     }
     __syncthreads();
@@ -277,15 +289,16 @@ __global__ void __launch_bounds__(256) k_a57_emb_tail(EmbTailArgs a) {
     for (int i = t; i < B * Hd; i += 256) {
         const int b = i / Hd, j = i % Hd;
         float s = 0.f;
-        for (int k = 0; k < A; k++) s += pr[b * A + k] * a.w2.p[(i64)k * Hd + j];
+        for (int k = 0; k < A; k++) s += pr[b * A + k] * w2s[k * Hd + j];
         dz[i] = s;
     }
     __syncthreads();
     // gradients of out_block_out1 (y = xh * gamma + beta with the gamma / beta of this forward)
     for (int i = t; i < A * Hd; i += 256) {
         const int k = i / Hd, j = i % Hd;
-        const float gm = a.lnw.p[j], bt = a.lnb.p[j];
+        const float gm = gms[j], bt = bts[j];
         float s = 0.f;
+#pragma unroll 8
         for (int b = 0; b < B; b++) s += pr[b * A + k] * (xh[b * Hd + j] * gm + bt);
         a.w2.g[i] = s;  // (the step is applied below, once every reader of w2 / gamma / beta is through)
     }
@@ -297,6 +310,7 @@ __global__ void __launch_bounds__(256) k_a57_emb_tail(EmbTailArgs a) {
     // LayerNorm backward: d gamma / d beta over the batch, dx per row
     for (int j = t; j < Hd; j += 256) {
         float sg = 0.f, sb = 0.f;
+#pragma unroll 8
         for (int b = 0; b < B; b++) sg += dz[b * Hd + j] * xh[b * Hd + j], sb += dz[b * Hd + j];
         a.lnw.g[j] = sg, a.lnb.g[j] = sb;
     }
@@ -304,14 +318,14 @@ __global__ void __launch_bounds__(256) k_a57_emb_tail(EmbTailArgs a) {
     for (int b = wave; b < B; b += 4) {
         float m1 = 0.f, m2 = 0.f;
         for (int j = lane; j < Hd; j += 64) {
-            const float dxh = dz[b * Hd + j] * a.lnw.p[j];
+            const float dxh = dz[b * Hd + j] * gms[j];
             m1 += dxh, m2 += dxh * xh[b * Hd + j];
         }
         for (int off = 32; off > 0; off >>= 1) m1 += __shfl_xor(m1, off), m2 += __shfl_xor(m2, off);
         m1 /= (float)Hd, m2 /= (float)Hd;
         const float rstd = rs[b];
         for (int j = lane; j < Hd; j += 64) {
-            const float dxh = dz[b * Hd + j] * a.lnw.p[j];
+            const float dxh = dz[b * Hd + j] * gms[j];
             const float dx = rstd * ((dxh - m1) - xh[b * Hd + j] * m2);
             dz[b * Hd + j] = a1[b * Hd + j] > 0.f ? dx : 0.f;  // ReLU of out_block
         }
@@ -327,18 +341,46 @@ __global__ void __launch_bounds__(256) k_a57_emb_tail(EmbTailArgs a) {
     for (int i = t; i < B * D2; i += 256) {
         const int b = i / D2, k = i % D2;
         float s = 0.f;
-        for (int j = 0; j < Hd; j++) s += dz[b * Hd + j] * a.w1.p[(i64)j * D2 + k];
+#pragma unroll 8
+        for (int j = 0; j < Hd; j++) s += dz[b * Hd + j] * w1s[j * W1 + k];
         a.d_emb[i] = s;
     }
     __syncthreads();
-    for (int i = t; i < Hd * D2; i += 256) {
-        const int j = i / D2, k = i % D2;
-        float s = 0.f;
-        for (int b = 0; b < B; b++) s += dz[b * Hd + j] * x[b * D2 + k];
-        finish(a.w1, i, s, cf, adam);
+    // w1: eight elements per thread and pass -- their parameter / moment loads are issued BEFORE the sums (one element at a time, every optimiser step waited for
+    // its own three loads behind the previous element's stores: 44 of the launch's 122 us)
+    for (int i0 = t; i0 < Hd * D2; i0 += 8 * 256) {
+        float pp[8], mm[8], vv[8], gs[8];
+        const bool step = adam && a.w1.m;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = i0 + 256 * q;
+            const bool in = i < Hd * D2 && step;
+            pp[q] = in ? a.w1.p[i] : 0.f, mm[q] = in ? a.w1.m[i] : 0.f, vv[q] = in ? a.w1.v[i] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = i0 + 256 * q, j = i / D2, k = i % D2;
+            float s = 0.f;
+            if (i < Hd * D2) {
+#pragma unroll 8
+                for (int b = 0; b < B; b++) s += dz[b * Hd + j] * x[b * D2 + k];
+            }
+            gs[q] = s;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = i0 + 256 * q;
+            if (i >= Hd * D2) continue;
+            if (a.w1.g) a.w1.g[i] = gs[q];
+            if (step) {
+                srlx::adam_one(pp[q], gs[q], mm[q], vv[q], cf);
+                a.w1.p[i] = pp[q], a.w1.m[i] = mm[q], a.w1.v[i] = vv[q];
+            }
+        }
     }
     for (int j = t; j < Hd; j += 256) {
         float s = 0.f;
+#pragma unroll 8
         for (int b = 0; b < B; b++) s += dz[b * Hd + j];
         finish(a.b1, j, s, cf, adam);
     }
@@ -493,8 +535,14 @@ int srlx_agent57_emb_tail(int64_t batch, int emb_dim, int hidden, int n_actions,
     for (int k = 0; k < 6; k++) t[k] = Tensor3{d_params[k], d_grads[k], adam ? d_exp_avg[k] : nullptr, adam ? d_exp_avg_sq[k] : nullptr};
     EmbTailArgs a{(int)batch, emb_dim, hidden, n_actions, d_emb, d_actions, t[0], t[1], t[2], t[3], t[4], t[5], (float)ln_eps, d_loss, d_grad_emb,
                   AdamHyper{lr, beta1, beta2, eps, adam ? d_steps_taken : nullptr}};
-    const size_t lds = ((size_t)batch * 2 * emb_dim + 3 * (size_t)batch * hidden + (size_t)batch * n_actions + batch + 256) * sizeof(float);
-    SRLX_REQUIRE(lds <= 64 * 1024, "agent57_emb_tail: %zu bytes of LDS (batch x hidden too large)", lds);
+    const size_t lds = ((size_t)batch * 2 * emb_dim + 3 * (size_t)batch * hidden + (size_t)batch * n_actions + batch + 256 + (size_t)hidden * (2 * emb_dim + 1) +
+                        (size_t)n_actions * hidden + 2 * (size_t)hidden) * sizeof(float);
+    SRLX_REQUIRE(lds <= 160 * 1024, "agent57_emb_tail: %zu bytes of LDS (batch x hidden too large)", lds);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        SRLX_HIP(hipFuncSetAttribute((const void *)k_a57_emb_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
     hipLaunchKernelGGL(k_a57_emb_tail, dim3(1), dim3(256), lds, (hipStream_t)stream, a);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

@@ -110,7 +110,9 @@ def roles_only(args):
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(f"cuda:{dev_index}"))
+            from simple_distributed_rl_amd.device.dist import rccl_options
+
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(f"cuda:{dev_index}"), pg_options=rccl_options())
             t = torch.ones(1 << 20, device=f"cuda:{dev_index}")
             dist.broadcast(t, src=0)
             dist.all_reduce(t)
@@ -151,7 +153,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+            from simple_distributed_rl_amd.device.dist import rccl_options
+
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=rccl_options())  # nccl == RCCL on ROCm; high-priority communicator streams
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
@@ -844,11 +848,14 @@ def role_timings(args, dev_index, actor_ranks=7):
 
     out["learner_rank"]["ingest_alone_ms"] = 1e3 * timed(add_only, 64)
     out["learner_rank"]["update_alone_ms"] = 1e3 * timed(lambda: eng.run_updates(1), 128)
-    # ---- the same period UNDER THE TRANSFERS' stream semantics (round 6): what RCCL brings to the learner rank besides the bytes -- a communicator stream of normal
-    # priority (ProcessGroupNCCL's default) that must find a hardware queue next to the update's branches, 2 x actor_ranks posted receives per period whose data lands
+    # ---- the same period UNDER THE TRANSFERS' stream semantics (round 6): what RCCL brings to the learner rank besides the bytes -- a communicator stream (HIGH
+    # priority: device/dist.py:rccl_options, which bench.py and the Runner pass to init_process_group; at ProcessGroupNCCL's default, normal, the same rehearsal
+    # costs 1.35 x the bare period instead of 1.12 x) that must find a hardware queue next to the update's branches, 2 x actor_ranks posted receives per period whose data lands
     # in the staging slot the NEXT period's ingest reads, the host cost of posting them, and a stream-level wait at `recv_end`.  The transfers are device copies from
     # "remote" buffers on this GPU (7.2 MB of frames + a 10 KB record per actor rank: the write traffic of the real thing, plus a read it would not have).
-    comm = torch.cuda.Stream(device=dev)
+    comm = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SRLX_FABRIC_COMM_PRIO", "-1")))  # (what `rccl_options()` gives the job's communicator)
+    fused_copy = os.environ.get("SRLX_FABRIC_FUSED", "0") == "1"
+    post_after = os.environ.get("SRLX_FABRIC_ORDER", "before") == "after"
     remote = [(torch.randint(0, 256, (rec,), dtype=torch.uint8, device=dev, generator=g), torch.randint(0, 256, (E, 84 * 84), dtype=torch.uint8, device=dev, generator=g))
               for _ in range(actor_ranks)]
     for r in range(actor_ranks):  # (valid records: the commit reads actions / flags out of them)
@@ -859,24 +866,35 @@ def role_timings(args, dev_index, actor_ranks=7):
         k = state["k"]
         scal, obs = slabs[k % 2]  # staging slot k % 2 receives; the ingest below commits the other one
         cur = torch.cuda.current_stream(dev)
+        if post_after:
+            eng.ingest = ingest_fn(k + 1)
+            eng.run_updates(1)
         ev_post.record(cur)
         comm.wait_event(ev_post)
         with torch.cuda.stream(comm):
-            for r in range(actor_ranks):
-                scal[r].copy_(remote[r][0], non_blocking=True)
-                obs[r * E : (r + 1) * E].copy_(remote[r][1], non_blocking=True)
+            if fused_copy:
+                torch._foreach_copy_([scal[r] for r in range(actor_ranks)] + [obs[r * E : (r + 1) * E] for r in range(actor_ranks)],
+                                     [remote[r][0] for r in range(actor_ranks)] + [remote[r][1] for r in range(actor_ranks)])
+            else:
+                for r in range(actor_ranks):
+                    scal[r].copy_(remote[r][0], non_blocking=True)
+                    obs[r * E : (r + 1) * E].copy_(remote[r][1], non_blocking=True)
             ev_done.record(comm)
-        eng.ingest = ingest_fn(k + 1)
-        eng.run_updates(1)
+        if not post_after:
+            eng.ingest = ingest_fn(k + 1)
+            eng.run_updates(1)
         cur.wait_event(ev_done)  # recv_end
         replay.note_commit()
         state["k"] += 1
 
     t_f = timed(learner_period_fabric, 256)
     out["learner_rank"]["fabric_ms_per_period"] = 1e3 * t_f
+    out["learner_rank_fabric_ms"] = 1e3 * t_f  # (the same figure under the name VERDICT round 5 asked for)
     out["learner_rank"]["fabric_over_bare"] = t_f / t
-    out["learner_rank"]["fabric_note"] = ("the period with 2 x %d receives per period posted on a communicator stream (device copies standing in for the xGMI transfers: "
-                                          "%.1f MB per period), a stream-level wait at recv_end and their host cost" % (actor_ranks, actor_ranks * (rec + E * 84 * 84) / 1e6))
+    out["learner_rank"]["fabric_note"] = ("the period with 2 x %d receives per period posted on a high-priority communicator stream (ProcessGroupNCCL.Options.is_high_priority_stream, "
+                                          "device/dist.py:rccl_options; device copies standing in for the xGMI transfers: %.1f MB per period -- they also READ that much and "
+                                          "run on compute units, which the real receives do not), a stream-level wait at recv_end and their host cost; normal-priority "
+                                          "communicator: 1.35 x the bare period, receives posted behind the update instead of before it: 1.38 x (same box)" % (actor_ranks, actor_ranks * (rec + E * 84 * 84) / 1e6))
     if os.environ.get("SRLX_ROLE_PROBE"):  # host time of one period, and the period with the host synchronising (is the host the bound?)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

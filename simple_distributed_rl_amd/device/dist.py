@@ -31,6 +31,15 @@ from simple_distributed_rl_amd import _native as N
 from simple_distributed_rl_amd.device.qnet import DeviceAdam
 
 
+def rccl_options():
+    """`pg_options` for `init_process_group("nccl", ...)`: the communicator's streams at HIGH priority.  HIP keeps one pool of hardware queues per priority level; at
+    ProcessGroupNCCL's default (normal) the receives of a learner rank share the normal pool with the branches of its captured update, and the period under the
+    transfers' stream semantics is 1.35 x the bare one; at high priority 1.12 x (bench.py --roles-only: `learner_rank.fabric_ms_per_period`, same box)."""
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True
+    return opts
+
+
 class TransitionBus:
     """Fixed-size per-step transition exchange and parameter fan-out between ranks."""
 

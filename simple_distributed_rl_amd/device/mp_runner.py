@@ -80,7 +80,9 @@ def _init_group(rank: int, world: int, port: int, backend: str, device: int):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(device)
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{device}"))
+        from simple_distributed_rl_amd.device.dist import rccl_options
+
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{device}"), pg_options=rccl_options())
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     return dist

@@ -121,6 +121,12 @@ int srlx_per_sample(srlx_per_t *h, int64_t batch_size, int64_t step, const int64
  * pinned slot and the host spins on a completion flag the kernel stores last (no stream synchronisation).  Host pointers; results as srlx_per_sample(on_device = 0). */
 int srlx_per_sample_after_adds(srlx_per_t *h, int64_t n_add, const double *add_values, int add_kind, int64_t batch_size, int64_t step, const double *uniforms,
                                int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used, void *stream);
+/* The same with the uniforms given as consecutive MT19937 outputs, two 32-bit words per uniform -- what `random.getrandbits(64 * n).to_bytes(8 * n, "little")` yields
+ * and `random.random()` would have consumed (CPython: (a >> 5) * 2^26 + (b >> 6)) / 2^53 of consecutive outputs a, b): the host shim hands the generator's raw
+ * words over instead of building n Python floats.  out_slots (or NULL): the data slot of every index (tree index - (capacity - 1)). */
+int srlx_per_sample_after_adds_mt(srlx_per_t *h, int64_t n_add, const double *add_values, int add_kind, int64_t batch_size, int64_t step,
+                                  const uint32_t *mt_words, int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32,
+                                  int64_t *out_used, int64_t *out_slots, void *stream);
 /* The learner's call without the launch that draws its uniforms: uniform j is what srlx_rng_uniform(seed, d_counter, n_uniforms, u)
  * would have put into u[j], and *d_counter advances the same way -- results identical to that call followed by
  * srlx_per_sample(..., u, n_uniforms, ..., on_device = 1).  Device pointers only; n_uniforms within the single-workgroup sampler's range. */

@@ -55,6 +55,7 @@ SIGNATURES = {
     "srlx_per_add": (c_int, [c_p, c_i64, c_p, c_int, c_int, c_p]),
     "srlx_per_sample": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_int, c_p]),
     "srlx_per_sample_after_adds": (c_int, [c_p, c_i64, c_p, c_int, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "srlx_per_sample_after_adds_mt": (c_int, [c_p, c_i64, c_p, c_int, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_per_sample_keyed": (c_int, [c_p, c_i64, c_p, c_u64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_per_sample_gather_train": (c_int, [c_p, c_p, c_i64, c_p, c_u64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_per_update": (c_int, [c_p, c_i64, c_p, c_p, c_int, c_int, c_p]),

@@ -233,6 +233,8 @@ struct SampleArgs {
 // in-order acceptance (zero-priority and duplicate rejects consume a uniform each, :146-157),
 // prefix-sum compaction, IS weights and max-normalisation (:163-167) in ONE launch.
 // ------------------------------------------------------------------------------------------
+static inline size_t sample_wg_lds(i64 M) { return (size_t)kWgSample * (8 + 4) + (size_t)((M + 15) & ~(i64)15) + 16 + (M <= kWgSample ? (size_t)kWgSample * 32 : 0); }
+
 __device__ __forceinline__ bool sample_wg_body(const SampleArgs &a, unsigned char *smem) {
     double *red = reinterpret_cast<double *>(smem);                 // blockDim doubles
     int *ibuf = reinterpret_cast<int *>(red + blockDim.x);          // blockDim ints
@@ -240,6 +242,16 @@ __device__ __forceinline__ bool sample_wg_body(const SampleArgs &a, unsigned cha
 
     const int t = threadIdx.x, T = blockDim.x;
     const i64 M = a.n_uniforms, B = a.batch;
+    // the candidates, the compaction map and the raw weights: in LDS when one uniform per thread is all there is (the learner's B = 32 / 64 draw, the host shim's
+    // first attempt) -- through the global scratch every phase boundary was a write -> barrier -> read round trip to L2 (sample_wg_lds() sizes the launch)
+    i64 *cand_idx = a.cand_idx, *map = a.map;
+    double *cand_p = a.cand_p, *wtmp = a.wtmp;
+    if (M <= T) {
+        cand_idx = reinterpret_cast<i64 *>(flags + ((M + 15) & ~(i64)15));
+        cand_p = reinterpret_cast<double *>(cand_idx + T);
+        map = reinterpret_cast<i64 *>(cand_p + T);
+        wtmp = reinterpret_cast<double *>(map + T);
+    }
     const double total = a.tr.T[kRootSlot];  // :135 (root)
 
     // phase 1: one descent per uniform (coalesced uniform reads, strided assignment)
@@ -249,8 +261,8 @@ __device__ __forceinline__ bool sample_wg_body(const SampleArgs &a, unsigned cha
         double p;
         const double u = a.uniforms ? a.uniforms[j] : srlx::u53(srlx::rng_u64(a.key_seed, kc, (u64)j));
         descend(a.tr, u * total, idx, p);  // :147-148
-        a.cand_idx[j] = idx;
-        a.cand_p[j] = p;
+        cand_idx[j] = idx;
+        cand_p[j] = p;
     }
     __syncthreads();
     if (!a.uniforms && t == 0) a.key_counter[0] = (i64)kc + 1;  // like srlx_rng_uniform: one counter value per call (every thread has read it)
@@ -258,11 +270,11 @@ __device__ __forceinline__ bool sample_wg_body(const SampleArgs &a, unsigned cha
     // phase 2: acceptance.  A draw is rejected if its leaf priority is 0 (:150-152) or, without
     // duplicates, if an earlier non-zero draw already produced the same leaf (:155-156).
     for (i64 j = t; j < M; j += T) {
-        bool ok = a.cand_p[j] != 0.0;
+        bool ok = cand_p[j] != 0.0;
         if (ok && !a.has_duplicate) {
-            const i64 me = a.cand_idx[j];
+            const i64 me = cand_idx[j];
             for (i64 k = 0; k < j; k++)
-                if (a.cand_idx[k] == me && a.cand_p[k] != 0.0) {
+                if (cand_idx[k] == me && cand_p[k] != 0.0) {
                     ok = false;
                     break;
                 }
@@ -280,7 +292,7 @@ __device__ __forceinline__ bool sample_wg_body(const SampleArgs &a, unsigned cha
     int pos = block_exscan(cnt, ibuf, &total_ok);
     for (i64 j = lo; j < hi; j++) {
         if (flags[j]) {
-            if (pos < B) a.map[pos] = j;
+            if (pos < B) map[pos] = j;
             if (pos == B - 1) *a.out_used = j + 1;  // uniforms consumed = index of the B-th accept + 1
             pos++;
         }
@@ -296,15 +308,15 @@ __device__ __forceinline__ bool sample_wg_body(const SampleArgs &a, unsigned cha
     const double size = (double)a.state->size;
     double wmax_local = 0.0;
     for (i64 i = t; i < B; i += T) {
-        const i64 j = a.map[i];
-        const double w = is_weight(size, a.cand_p[j], total, beta);
-        a.wtmp[i] = w;
-        a.out_idx[i] = a.cand_idx[j];
+        const i64 j = map[i];
+        const double w = is_weight(size, cand_p[j], total, beta);
+        wtmp[i] = w;
+        a.out_idx[i] = cand_idx[j];
         wmax_local = fmax(wmax_local, w);
     }
     const double wmax = block_max(wmax_local, red);
     for (i64 i = t; i < B; i += T) {
-        const double w = a.wtmp[i] / wmax;
+        const double w = wtmp[i] / wmax;
         if (a.out_w) a.out_w[i] = w;
         if (a.out_w32) a.out_w32[i] = (float)w;
     }
@@ -1409,7 +1421,7 @@ int launch_sample(srlx_per *h, i64 B, i64 step, const i64 *d_step, const double 
         a.cand_p = cv.take<double>(M);
         a.map = cv.take<i64>(B);
         a.wtmp = cv.take<double>(B);
-        const size_t lds = (size_t)kWgSample * (8 + 4) + (size_t)M + 16;
+        const size_t lds = sample_wg_lds(M);
         hipLaunchKernelGGL(k_sample_wg, dim3(1), dim3(kWgSample), lds, st, a);
     } else {
         if (!h->has_duplicate) {
@@ -1714,12 +1726,13 @@ int srlx_per_sample(srlx_per_t *h, int64_t batch_size, int64_t step, const int64
 // The b1 shim's `sample` (round 6): `n_add` <= 16 adds queued since the tree was last observed (HOST values: final leaf priorities, SRLX_PRIO_RAW, or NULL with
 // SRLX_PRIO_NONE) and the draw as ONE launch -- the add values travel in the kernel arguments, the uniforms and the results through a device-visible pinned slot --
 // and the host spins on a completion flag in that slot instead of synchronising the stream.  Results as srlx_per_sample(on_device = 0).
-int srlx_per_sample_after_adds(srlx_per_t *h, int64_t n_add, const double *add_values, int add_kind, int64_t batch_size, int64_t step, const double *uniforms,
-                               int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used, void *stream) {
+static int sample_after_adds_impl(srlx_per_t *h, int64_t n_add, const double *add_values, int add_kind, int64_t batch_size, int64_t step, const double *uniforms,
+                                  const uint32_t *mt_words, int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used, int64_t *out_slots,
+                                  void *stream) {
     SRLX_REQUIRE(h, "per_sample_after_adds: NULL handle");
     SRLX_REQUIRE(n_add >= 0 && n_add <= kTinyAddMax && (n_add == 0 || add_kind == SRLX_PRIO_NONE || (add_kind == SRLX_PRIO_RAW && add_values)),
                  "per_sample_after_adds: at most %d adds, SRLX_PRIO_RAW values or SRLX_PRIO_NONE", kTinyAddMax);
-    SRLX_REQUIRE(batch_size > 0 && uniforms && n_uniforms >= batch_size && n_uniforms <= kSmallSampleMax && out_idx && out_used,
+    SRLX_REQUIRE(batch_size > 0 && (uniforms || mt_words) && n_uniforms >= batch_size && n_uniforms <= kSmallSampleMax && out_idx && out_used,
                  "per_sample_after_adds: batch_size <= n_uniforms <= %lld", (long long)kSmallSampleMax);
     srlx::DeviceGuard guard(h->device);
     hipStream_t st = pick_stream(h, stream);
@@ -1729,6 +1742,7 @@ int srlx_per_sample_after_adds(srlx_per_t *h, int64_t n_add, const double *add_v
     int slot = 0;
     SRLX_TRY(ring_acquire(h, need, &slot_ptr, &slot));
     if (!slot_ptr) {  // does not fit a slot: the plain calls
+        SRLX_REQUIRE(uniforms && !out_slots, "per_sample_after_adds_mt: the draw does not fit a pinned slot");
         if (n_add > 0) SRLX_TRY(srlx_per_add(h, n_add, add_values, add_kind, 0, stream));
         return srlx_per_sample(h, batch_size, step, nullptr, uniforms, n_uniforms, out_idx, out_w, out_w32, out_used, 0, stream);
     }
@@ -1739,7 +1753,10 @@ int srlx_per_sample_after_adds(srlx_per_t *h, int64_t n_add, const double *add_v
     float *m_w32 = sp.take<float>(batch_size);
     i64 *m_used = sp.take<i64>(1);
     volatile unsigned long long *m_flag = (volatile unsigned long long *)sp.take<unsigned long long>(1);
-    memcpy(m_u, uniforms, (size_t)n_uniforms * 8);
+    if (uniforms)
+        memcpy(m_u, uniforms, (size_t)n_uniforms * 8);
+    else  // CPython's random.random() (Modules/_randommodule.c: random_random) on consecutive MT19937 outputs
+        for (i64 j = 0; j < n_uniforms; j++) m_u[j] = ((double)(mt_words[2 * j] >> 5) * 67108864.0 + (double)(mt_words[2 * j + 1] >> 6)) * (1.0 / 9007199254740992.0);
     static unsigned long long ticket = 0;
     const unsigned long long want = ++ticket;
     *m_flag = 0;
@@ -1754,7 +1771,7 @@ int srlx_per_sample_after_adds(srlx_per_t *h, int64_t n_add, const double *add_v
     AddArgs add{h->tree, h->capacity, h->d_state, n_add, nullptr, add_kind, h->epsilon, h->alpha, nullptr, -1, 1, 0, 0.0, nullptr, h->d_add_counter[0], h->d_add_counter[1]};
     TinyVals vals{};
     for (int k = 0; k < n_add && add_values; k++) vals.v[k] = add_values[k];
-    const size_t lds = (size_t)kWgSample * (8 + 4) + (size_t)M + 16;
+    const size_t lds = sample_wg_lds(M);
     hipLaunchKernelGGL(k_add_sample_wg, dim3(1), dim3(kWgSample), lds, st, add, vals, a, (unsigned long long *)m_flag, want);
     SRLX_HIP(hipGetLastError());
     if (n_add > 0) {  // host mirror
@@ -1780,7 +1797,21 @@ int srlx_per_sample_after_adds(srlx_per_t *h, int64_t n_add, const double *add_v
     memcpy(out_idx, m_idx, (size_t)batch_size * 8);
     if (out_w) memcpy(out_w, m_w, (size_t)batch_size * 8);
     if (out_w32) memcpy(out_w32, m_w32, (size_t)batch_size * 4);
+    if (out_slots)
+        for (i64 j = 0; j < batch_size; j++) out_slots[j] = m_idx[j] - (h->capacity - 1);  // tree index -> data slot (leaf j <-> node j + N - 1)
     return SRLX_OK;
+}
+
+int srlx_per_sample_after_adds(srlx_per_t *h, int64_t n_add, const double *add_values, int add_kind, int64_t batch_size, int64_t step, const double *uniforms,
+                               int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used, void *stream) {
+    SRLX_REQUIRE(uniforms, "per_sample_after_adds: NULL uniforms");
+    return sample_after_adds_impl(h, n_add, add_values, add_kind, batch_size, step, uniforms, nullptr, n_uniforms, out_idx, out_w, out_w32, out_used, nullptr, stream);
+}
+
+int srlx_per_sample_after_adds_mt(srlx_per_t *h, int64_t n_add, const double *add_values, int add_kind, int64_t batch_size, int64_t step, const uint32_t *mt_words,
+                                  int64_t n_uniforms, int64_t *out_idx, double *out_w, float *out_w32, int64_t *out_used, int64_t *out_slots, void *stream) {
+    SRLX_REQUIRE(mt_words, "per_sample_after_adds_mt: NULL words");
+    return sample_after_adds_impl(h, n_add, add_values, add_kind, batch_size, step, nullptr, mt_words, n_uniforms, out_idx, out_w, out_w32, out_used, out_slots, stream);
 }
 
 int srlx_per_sample_keyed(srlx_per_t *h, int64_t batch_size, const int64_t *d_step, uint64_t seed, int64_t *d_counter, int64_t n_uniforms,
@@ -1817,7 +1848,7 @@ int srlx_per_sample_gather_train(srlx_per_t *h, srlx_store_t *store, int64_t bat
     a.has_duplicate = h->has_duplicate, a.uniforms = nullptr, a.key_seed = seed, a.key_counter = d_counter, a.n_uniforms = M, a.batch = B;
     a.out_idx = d_out_idx, a.out_w = nullptr, a.out_w32 = d_out_w32, a.out_used = d_out_used;
     a.cand_idx = cv.take<i64>(M), a.cand_p = cv.take<double>(M), a.map = cv.take<i64>(B), a.wtmp = cv.take<double>(B);
-    const size_t lds = (size_t)kWgSample * (8 + 4) + (size_t)M + 16;
+    const size_t lds = sample_wg_lds(M);
     hipLaunchKernelGGL(k_sample_gather_wg, dim3(1), dim3(kWgSample), lds, st, a, g);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

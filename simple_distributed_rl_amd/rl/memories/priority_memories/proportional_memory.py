@@ -24,6 +24,7 @@ include/srlx.h.
 import ctypes
 import random
 import threading
+from array import array
 from typing import Any, List, Optional
 
 import numpy as np
@@ -57,6 +58,7 @@ class ProportionalMemory(IPriorityMemory):
         self.device = int(device)
         self.host_transform = host_transform
         self._lock = threading.Lock()  # play_mp.py:248-286 calls add() and sample() from two threads
+        self._bufs = {}
         self._lib = N.lib()
         h = N.c_p()
         N.check(
@@ -135,68 +137,96 @@ class ProportionalMemory(IPriorityMemory):
             if len(self._queue) >= 2048:  # (a pinned slot holds 2048 float64 values)
                 self._flush()
 
+    def _buffers(self, batch_size: int):
+        """Per batch size: the result arrays and their ctypes pointers (building a pointer object costs a microsecond; a call needs six)."""
+        b = self._bufs.get(batch_size)
+        if b is None:
+            idx, w, slots, used = np.empty(batch_size, np.int64), np.empty(batch_size, np.float64), np.empty(batch_size, np.int64), N.c_i64(0)
+            b = self._bufs[batch_size] = (idx, w, slots, used, N.np_ptr(idx), N.np_ptr(w), N.np_ptr(slots), ctypes.byref(used))
+        return b
+
     def sample(self, batch_size: int, step: int):
         batch_size = int(batch_size)
-        idx = np.empty(batch_size, np.int64)
-        w = np.empty(batch_size, np.float64)
-        used = N.c_i64(0)
+        idx, w, slots, used, p_idx, p_w, p_slots, p_used = self._buffers(batch_size)
         with self._lock:
             # up to 16 queued adds of one kind ride INSIDE the sampling launch (srlx_per_sample_after_adds); a longer queue is flushed by a launch of its own first
             q_kind = self._queue_kind
             if len(self._queue) > 16 or (self._queue and q_kind not in (N.PRIO_RAW, N.PRIO_NONE)):
                 self._flush()
             adds, self._queue, self._queue_kind = self._queue, [], None
-            add_arr = np.asarray(adds, np.float64) if (adds and q_kind == N.PRIO_RAW) else None
-            # Uniforms: the reference calls random.random() once per descent attempt (:147).  Without rejected draws a batch consumes exactly `batch_size` of them, so the
-            # first attempt draws exactly that many and needs no snapshot of the generator (random.getstate() copies 625 words: more host time than the kernel runs);
-            # only when the kernel reports that rejections ate the uniforms is the state captured -- AFTER the ones consumed so far -- before more are drawn, so that an
-            # over-provisioned retry can be rolled back to exactly what the reference would have consumed.
-            cap = 8192 if not self.has_duplicate else 9999 * batch_size  # without duplicates one call walks at most 8192 uniforms
-            drawn = [random.random() for _ in range(batch_size)]
-            state, base, forced = None, 0, False  # state: the generator AFTER `base` of the drawn uniforms
-            while True:
-                m = len(drawn)
-                u = np.asarray(drawn, np.float64)
-                if m <= 8192:
-                    st = self._lib.srlx_per_sample_after_adds(self._h, len(adds), N.np_ptr(add_arr) if add_arr is not None else None, q_kind if adds else N.PRIO_NONE,
-                                                              batch_size, int(step), N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), None)
-                    adds = []  # (applied by the first attempt, whatever the draw's outcome)
-                else:
-                    if adds:
-                        N.check(self._lib.srlx_per_add(self._h, len(adds), N.np_ptr(add_arr) if add_arr is not None else None, q_kind, 2, None))
-                        adds = []
-                    st = self._lib.srlx_per_sample(
-                        self._h, batch_size, int(step), None, N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), 2, None
-                    )
-                if st == N.ERR_UNIFORMS_EXHAUSTED and m < cap:  # rejected draws ate the uniforms: again with more (the same prefix: the same walk up to there)
-                    state, base = random.getstate(), m
-                    drawn.extend(random.random() for _ in range(min(m + 16, cap - m)))
-                    continue
-                if st == N.ERR_UNIFORMS_EXHAUSTED and not self.has_duplicate and not forced:
-                    # fewer distinct non-zero leaves than the batch needs: the reference gives up on a draw after 9999 tries and takes
-                    # it, duplicate or not (:146-158); here the batch is completed with duplicates from the same uniforms
-                    N.check(self._lib.srlx_per_set_has_duplicate(self._h, 1))
-                    forced = True
-                    continue
-                if forced:
-                    N.check(self._lib.srlx_per_set_has_duplicate(self._h, 0))
-                N.check(st)
-                break
-            if used.value != len(drawn):  # the retry drew more than the walk consumed: leave `random` where the reference would
-                random.setstate(state)
-                for _ in range(used.value - base):
-                    random.random()
-            cap1 = self.capacity - 1
+            add_arr = array("d", adds) if (adds and q_kind == N.PRIO_RAW) else None
+            add_ptr = add_arr.buffer_info()[0] if add_arr is not None else None
+            # Uniforms: the reference calls random.random() once per descent attempt (:147).  Without rejected draws a batch consumes exactly `batch_size` of them: the
+            # first attempt takes the generator's raw output -- 2 x 32 bits per uniform, what `batch_size` calls of random.random() would have consumed, in one
+            # getrandbits() -- and libsrlx turns the words into the same doubles (srlx_per_sample_after_adds_mt).  No snapshot of the generator either
+            # (random.getstate() copies 625 words: more host time than the kernel runs); only when the kernel reports that rejections ate the uniforms is the state
+            # captured -- AFTER the ones consumed so far -- before more are drawn, so that an over-provisioned retry can be rolled back to what the reference consumes.
+            st = N.ERR_UNIFORMS_EXHAUSTED
+            raw = None
+            if batch_size <= 8192:
+                raw = random.getrandbits(64 * batch_size).to_bytes(8 * batch_size, "little")
+                st = self._lib.srlx_per_sample_after_adds_mt(self._h, len(adds), add_ptr, q_kind if adds else N.PRIO_NONE, batch_size, int(step), raw, batch_size, p_idx, p_w,
+                                                             None, p_used, p_slots, None)
+                adds = []  # (applied by the first attempt, whatever the draw's outcome)
+            if st != N.OK:
+                self._sample_slow(batch_size, step, raw, adds, add_arr, q_kind, idx, w, used)
+                np.subtract(idx, self.capacity - 1, out=slots)
+            data = self.data
             indices = idx.tolist()
-            batches = [self.data[i - cap1] for i in indices]
-        return batches, w, indices
+            batches = [data[i] for i in slots.tolist()]
+        return batches, w.copy(), indices
+
+    def _sample_slow(self, batch_size, step, raw, adds, add_arr, q_kind, idx, w, used):
+        """Rejected draws ate the first attempt's uniforms (or the batch is larger than one sampling launch takes): the list-based loop (lock held)."""
+        cap = 8192 if not self.has_duplicate else 9999 * batch_size  # without duplicates one call walks at most 8192 uniforms
+        if raw is not None:  # the uniforms the first attempt consumed: random.random() of consecutive generator outputs (a >> 5, b >> 6)
+            wd = np.frombuffer(raw, dtype="<u4")
+            drawn = (((wd[0::2] >> 5).astype(np.float64) * 67108864.0 + (wd[1::2] >> 6).astype(np.float64)) * (1.0 / 9007199254740992.0)).tolist()
+            state, base = random.getstate(), len(drawn)
+            drawn.extend(random.random() for _ in range(min(len(drawn) + 16, cap - len(drawn))))
+        else:
+            drawn = [random.random() for _ in range(batch_size)]
+            state, base = None, 0  # state: the generator AFTER `base` of the drawn uniforms
+        forced = False
+        add_np = np.asarray(add_arr, np.float64) if add_arr is not None else None
+        while True:
+            m = len(drawn)
+            u = np.asarray(drawn, np.float64)
+            if m <= 8192:
+                st = self._lib.srlx_per_sample_after_adds(self._h, len(adds), N.np_ptr(add_np) if (adds and add_np is not None) else None, q_kind if adds else N.PRIO_NONE,
+                                                          batch_size, int(step), N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), None)
+                adds = []
+            else:
+                if adds:
+                    N.check(self._lib.srlx_per_add(self._h, len(adds), N.np_ptr(add_np) if add_np is not None else None, q_kind, 2, None))
+                    adds = []
+                st = self._lib.srlx_per_sample(self._h, batch_size, int(step), None, N.np_ptr(u), m, N.np_ptr(idx), N.np_ptr(w), None, ctypes.byref(used), 2, None)
+            if st == N.ERR_UNIFORMS_EXHAUSTED and m < cap:  # rejected draws ate the uniforms: again with more (the same prefix: the same walk up to there)
+                state, base = random.getstate(), m
+                drawn.extend(random.random() for _ in range(min(m + 16, cap - m)))
+                continue
+            if st == N.ERR_UNIFORMS_EXHAUSTED and not self.has_duplicate and not forced:
+                # fewer distinct non-zero leaves than the batch needs: the reference gives up on a draw after 9999 tries and takes
+                # it, duplicate or not (:146-158); here the batch is completed with duplicates from the same uniforms
+                N.check(self._lib.srlx_per_set_has_duplicate(self._h, 1))
+                forced = True
+                continue
+            if forced:
+                N.check(self._lib.srlx_per_set_has_duplicate(self._h, 0))
+            N.check(st)
+            break
+        if used.value != len(drawn):  # the retry drew more than the walk consumed: leave `random` where the reference would
+            random.setstate(state)
+            for _ in range(used.value - base):
+                random.random()
 
     def update(self, indices: List[Any], priorities: np.ndarray) -> None:
         n = len(indices)
         if n == 0:
             return
-        idx = np.ascontiguousarray(indices, dtype=np.int64)
-        pr = np.asarray(priorities)
+        idx = array("q", indices)  # (a C loop over the list: a third of np.ascontiguousarray's time at 64 entries)
+        # (a list of Python floats -- the reference's speedtest -- through array('d'): a C loop, a third of np.asarray's time; same float64 values)
+        pr = np.frombuffer(array("d", priorities), np.float64) if type(priorities) is list else np.asarray(priorities)
         if self.host_transform:
             pr = np.ascontiguousarray((np.abs(pr) + self.epsilon) ** self.alpha, dtype=np.float64)  # :172
             kind = N.PRIO_RAW
@@ -213,7 +243,7 @@ class ProportionalMemory(IPriorityMemory):
             raise IndexError("priorities shorter than indices")
         with self._lock:
             self._flush()
-            N.check(self._lib.srlx_per_update(self._h, n, N.np_ptr(idx), N.np_ptr(pr), kind, 2, None))  # asynchronous: ordered before every later call
+            N.check(self._lib.srlx_per_update(self._h, n, idx.buffer_info()[0], pr.ctypes.data, kind, 2, None))  # asynchronous: ordered before every later call
 
     def backup(self):
         """Same list layout as proportional_memory.py:179-187."""

@@ -525,7 +525,7 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
                 "probes": {"min_ms": v[0], "median_ms": v[len(v) // 2], "mean_ms": ms, "max_ms": v[-1], "probes": len(v)},
                 "note": "HIP events recorded by the library around exactly this kernel on its launch stream, every 4th lock-step inside the timed loop (the update runs "
                         "beside it); executed flops = 3 x conv1 + 6 x conv2 / conv3 exact split-bf16 partial products; traffic: the same kernel's PMC figure of the "
-                        "Rainbow policy pass (profiles/r5_pmc_traffic.json: the kernel and its launch geometry are identical)"}
+                        "Rainbow policy pass (profiles/r6_pmc_traffic.json: the kernel and its launch geometry are identical)"}
     info = eng.info()
     cpu = None
     if dist is None and rank == 0 and not args.no_cpu_baseline:
@@ -941,11 +941,11 @@ def _isolated_forward_ms(eng, reps=20):
     return a.elapsed_time(b) / reps
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r6_pmc_traffic.json")
 
 
 def _pmc_traffic(kernel: str):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r5_pmc_traffic.json, written by tools/r5_measure.sh from two separate
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/r6_pmc_traffic.json, written by tools/r6_measure.sh from two separate
     `rocprofv3 --pmc` runs of tools/actor_pass_probe.py -- FETCH_SIZE and WRITE_SIZE do not fit one pass; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for wide coalesced reads on gfx950).  None when no such profile has been recorded."""
     if not os.path.exists(PMC_FILE):
@@ -1020,7 +1020,7 @@ def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0, probe_stats=None):
             fc1["frac_on_kernel_span"] = exe_fc1 / (span["mean_ms"] * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS if fc1_bf16 else MFMA_F32_PEAK_TFLOPS)
             fc1["note"] += ("; avg_launch_ms = HIP events around the launch on the actors' stream (includes waiting for compute units the update's kernels hold); "
                             "kernel_span_ms = min(first workgroup in) .. max(last workgroup out) stamped by the kernel itself on the device's wall clock, same launches: "
-                            "compare THIS with the kernel's AverageNs in profiles/r5_kernel_stats.csv")
+                            "compare THIS with the kernel's AverageNs in profiles/r6_kernel_stats.csv")
     conv_alg_bytes = E * (4 * 7056 + (121 * 64 * 6 if fc1_planes else 121 * 64 * 4)) + 466944 if fused else None  # 4 frames in + act3 out per sample + the split-bf16 packed filters once
     conv_traffic = _pmc_traffic("k_convnet_fused") if fused else None
     return {
@@ -1041,8 +1041,8 @@ def roofline(eng, ev_ms, conv_ms=0.0, fc1_ms=0.0, probe_stats=None):
         "f32_equivalent": {"achieved": f_conv / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "frac": f_conv / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                            "note": "algorithmic float32 FLOP/s over the f32 MFMA peak (the `frac` of the round-1/2 lines); NOT this kernel's bound: it does not run on that pipe"},
         "note": "timed inside the lock-step loop (HIP events on the launch stream, right around this kernel), where the learner's streams share the chip; `frac` = "
-                "executed bf16-MFMA flops / time / 2.5 PFLOP/s dense; traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/r5_pmc_traffic.json (isolated "
-                "launches of tools/actor_pass_probe.py); rocprofv3 cross-check: this kernel's AverageNs in profiles/r5_kernel_stats.csv; `probes` = min / median / "
+                "executed bf16-MFMA flops / time / 2.5 PFLOP/s dense; traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/r6_pmc_traffic.json (isolated "
+                "launches of tools/actor_pass_probe.py); rocprofv3 cross-check: this kernel's AverageNs in profiles/r6_kernel_stats.csv; `probes` = min / median / "
                 "mean / max of the HIP-event brackets of this run (every 4th lock-step): the brackets include queue wait beside the learner's streams",
         "probes": probe_stats,
         "fc1": fc1,

@@ -250,7 +250,9 @@ class Agent57LightFastEngine:
             self.l_emb, self.g_emb, self.emb_loss = z(torch.float32, 2 * B, self.D_emb), z(torch.float32, 2 * B, self.D_emb), z(torch.float32, 1)
             self.l_rnd_p, self.l_rnd_t, self.g_rnd, self.rnd_loss = z(torch.float32, 2 * B, self.D_rnd), z(torch.float32, 2 * B, self.D_rnd), z(torch.float32, B, self.D_rnd), z(torch.float32, 1)
         self.s_target = torch.cuda.Stream(device=d, priority=-1)
-        self._ev_t = {k: (torch.cuda.Event(), torch.cuda.Event()) for k in ("q_ext", "q_int")}
+        self._ev_fwd = {k: torch.cuda.Event() for k in ("q_ext", "q_int", "emb", "rnd")}  # a network's forward passes (on s_target) are through
+        self._ev_fork_fwd = torch.cuda.Event()
+        self.hoist_forwards = True  # every network's forward on the side stream, beside the previous network's backward (False: one network after the other)
         self.s_learner = torch.cuda.Stream(device=d, priority=-1)
         self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
         # a learner rank's ingest (device/dist.py): the commit of a slab that arrived from the actor ranks runs on a side stream between the update's draw and its
@@ -547,23 +549,24 @@ class Agent57LightFastEngine:
                 self._select_rnd_ln()
 
     # ---- learner -----------------------------------------------------------------------------------------------------------------------------------------------
-    def _update_q(self, n: _Net, rewards, publish, bump):
-        """model_torch.py:384-443 for one Q-network: ONE online pass over the interleaved [s_0, s_1] rows, the target network on s_1 beside it, TD target (per-actor
-        discount) / Huber / gradient seed in the backward pass's head kernel, Adam inside the gradient launches, publish."""
-        c, r = self.cfg, self.lreplay
+    def _forward_q(self, n: _Net, target_only: bool = False, online_only: bool = False):
+        """The passes of one Q-network's update (model_torch.py:384-443) on the CURRENT stream: the target network on s_1, the online network over the interleaved
+        [s_0, s_1] rows."""
+        r = self.lreplay
         B, W = r.B, self.Wn
         o = self.out[n.name]
-        cur = torch.cuda.current_stream(self.dev)
-        ev0, ev1 = self._ev_t[n.name]
-        ev0.record(cur)
-        self.s_target.wait_event(ev0)
-        with torch.cuda.stream(self.s_target):
+        if not online_only:
             n.inf_target.set_uvfa_inputs(self.tg_r_ext, self.tg_r_int, self.tg_action, self.tg_actor)
             n.inf_target.forward_u8(r.obs_base, r.frame_off_next.view(B, W), out=o["q_tg"])
-            ev1.record(self.s_target)
-        n.inf.set_uvfa_inputs(self.on_r_ext, self.on_r_int, self.on_action, self.on_actor)
-        n.inf.forward_u8(r.obs_base, r.frame_off_all.view(2 * B, W), out=o["q_all"])
-        cur.wait_event(ev1)
+        if not target_only:
+            n.inf.set_uvfa_inputs(self.on_r_ext, self.on_r_int, self.on_action, self.on_actor)
+            n.inf.forward_u8(r.obs_base, r.frame_off_all.view(2 * B, W), out=o["q_all"])
+
+    def _backward_q(self, n: _Net, rewards, publish, bump):
+        """TD target (per-actor discount) / Huber / gradient seed in the backward pass's head kernel, Adam inside the gradient launches, publish."""
+        c, r = self.cfg, self.lreplay
+        B = r.B
+        o = self.out[n.name]
         n.inf.set_td_extras(self.b_discount, o["td"])
         if self.sets:
             n.inf.fuse_adam_planes(n.planes_ptr[publish] if publish is not None else None)
@@ -619,29 +622,31 @@ class Agent57LightFastEngine:
                                                     N.tptr(self.on_r_ext), N.tptr(self.on_r_int), N.tptr(self.on_action), N.tptr(self.on_actor), N.tptr(self.tg_r_ext),
                                                     N.tptr(self.tg_r_int), N.tptr(self.tg_action), N.tptr(self.tg_actor), N.tptr(self.b_discount), N.tptr(self.b_r_int), st))
 
-    def _update_emb(self, publish):
-        """The inverse-dynamics embedding (:341-348): rows 2 b = f(s), 2 b + 1 = f(s'), all with gradient."""
+    def _forward_emb(self):
+        """The inverse-dynamics embedding (:341-348): rows 2 b = f(s), 2 b + 1 = f(s'), all with gradient; its dense tail (forward, loss, backward to the
+        embeddings, the tail's own Adam steps) in one launch behind the pass."""
         c, r, e = self.cfg, self.lreplay, self.nets["emb"]
         B, b = r.B, r.batch
-        off2 = r.frame_off_all.view(2 * B, self.Wn)
-        if self.sets:
-            e.inf.fuse_adam_planes(e.planes_ptr[publish] if publish is not None else None)
-        e.inf.forward_u8(r.obs_base, off2, out=self.l_emb)
+        e.inf.forward_u8(r.obs_base, r.frame_off_all.view(2 * B, self.Wn), out=self.l_emb)
         tp, tg, tm, tv = e.tail_tabs
         N.check(self.lib.srlx_agent57_emb_tail(B, self.D_emb, self.H_emb, self.A, N.tptr(self.l_emb), N.tptr(b.actions), ctypes.cast(tp, N.c_p), ctypes.cast(tg, N.c_p),
                                                ctypes.cast(tm, N.c_p), ctypes.cast(tv, N.c_p), 1e-5, float(c.episodic_lr), 0.9, 0.999, 1e-8, N.tptr(self.train_count_dev),
                                                N.tptr(self.emb_loss), N.tptr(self.g_emb), N.torch_stream_ptr()))
-        e.inf.backward_u8(r.obs_base, off2, self.g_emb, sample_stride=1)
+
+    def _backward_emb(self, publish):
+        r, e = self.lreplay, self.nets["emb"]
+        if self.sets:
+            e.inf.fuse_adam_planes(e.planes_ptr[publish] if publish is not None else None)
+        e.inf.backward_u8(r.obs_base, r.frame_off_all.view(2 * r.B, self.Wn), self.g_emb, sample_stride=1)
         e.opt.step(self.train_count_dev)
         e.inf.publish_to(e.actor if publish is not None else None, publish or 0)
 
-    def _update_rnd(self, publish, bump=None):
-        """RND (:353-362): the predictor against the fixed target network on s_0 (rows 0, 2, ... of the interleaved pass)."""
+    def _forward_rnd(self, publish):
+        """RND (:353-362): the predictor and the fixed target network (its rows 0, 2, ... = s_0 are what the loss reads), and the predictor's LayerNorm tail
+        (forward, loss, backward, its Adam steps, the published set's copy of its parameters) in one launch behind them."""
         c, r, rn = self.cfg, self.lreplay, self.nets["rnd"]
         B = r.B
         off2 = r.frame_off_all.view(2 * B, self.Wn)
-        if self.sets:
-            rn.inf.fuse_adam_planes(rn.planes_ptr[publish] if publish is not None else None)
         rn.inf_target.forward_u8(r.obs_base, off2, out=self.l_rnd_t)
         rn.inf.forward_u8(r.obs_base, off2, out=self.l_rnd_p)
         mw, mb = (rn.ln_sets[publish] if (self.sets and publish is not None) else (None, None))
@@ -649,22 +654,49 @@ class Agent57LightFastEngine:
                                                N.tptr(rn.tail_g[0]), N.tptr(rn.tail_g[1]), N.tptr(rn.tail_m[0]), N.tptr(rn.tail_v[0]), N.tptr(rn.tail_m[1]),
                                                N.tptr(rn.tail_v[1]), N.tptr(mw), N.tptr(mb), 1e-5, float(c.lifelong_lr), 0.9, 0.999, 1e-8, N.tptr(self.train_count_dev),
                                                N.tptr(self.rnd_loss), N.tptr(self.g_rnd), N.torch_stream_ptr()))
-        rn.inf.backward_u8(r.obs_base, off2, self.g_rnd, sample_stride=2)
+
+    def _backward_rnd(self, publish, bump=None):
+        r, rn = self.lreplay, self.nets["rnd"]
+        if self.sets:
+            rn.inf.fuse_adam_planes(rn.planes_ptr[publish] if publish is not None else None)
+        rn.inf.backward_u8(r.obs_base, r.frame_off_all.view(2 * r.B, self.Wn), self.g_rnd, sample_stride=2)
         rn.opt.step(self.train_count_dev)
         rn.inf.publish_to(rn.actor if publish is not None else None, publish or 0, bump=bump)
 
     def _update_networks(self, b, publish, wait=None):
-        """The four networks' updates, then the mixed priorities and their write-back.  (The updates are independent of each other, but HIP graphs do not let them run
-        side by side: a captured stream that forks again faults in hipStreamEndCapture -- tools/capture_probe.py --, and a graph per network on streams of their own
-        runs 2.5 ms instead of 1.1 once the process owns a low-priority stream, which the actors need: profiles/NOTES.md, round 6.)"""
+        """The four networks' updates, then the mixed priorities and their write-back.  A network's FORWARD passes do not depend on the other networks' updates:
+        they (and the embedding / RND tails behind them) all run on one side stream (`s_target`, forked once from the update's own stream), the backward passes -- each forks its weight-gradient stream -- one
+        after the other on the update's stream, each behind its forward's event: the forward of network k + 1 runs beside the backward of network k.  (A BACKWARD pass on the side stream -- RND's, with its weight-gradient launches in line -- made the update 2.24 ms instead of 0.81; a whole
+        update per branch is not possible either: a captured stream that forks again faults in hipStreamEndCapture -- tools/capture_probe.py --, and a graph per network
+        on streams of their own runs 2.5 ms instead of 1.1 once the process owns a low-priority stream, which the actors need: profiles/NOTES.md, round 6.)"""
         c, r = self.cfg, self.lreplay
-        cur = torch.cuda.current_stream(self.dev)
+        cur, sf = torch.cuda.current_stream(self.dev), self.s_target
         last = "rnd" if self.intrinsic else "q_ext"
-        self._update_q(self.nets["q_ext"], b.rewards, publish, self.train_count_dev if last == "q_ext" else None)
+        q_ext = self.nets["q_ext"]
+        ev = self._ev_fwd
+        self._ev_fork_fwd.record(cur)
+        sf.wait_event(self._ev_fork_fwd)
+        with torch.cuda.stream(sf):
+            self._forward_q(q_ext, target_only=True)
+            ev["q_ext"].record(sf)
+            if self.intrinsic and self.hoist_forwards:
+                self._forward_q(self.nets["q_int"])
+                ev["q_int"].record(sf)
+                self._forward_emb()
+                ev["emb"].record(sf)
+                self._forward_rnd(publish)
+                ev["rnd"].record(sf)
+        self._forward_q(q_ext, online_only=True)
+        cur.wait_event(ev["q_ext"])
+        self._backward_q(q_ext, b.rewards, publish, self.train_count_dev if last == "q_ext" else None)
         if self.intrinsic:
-            self._update_q(self.nets["q_int"], self.b_r_int, publish, None)
-            self._update_emb(publish)
-            self._update_rnd(publish, bump=self.train_count_dev)
+            hoist = self.hoist_forwards
+            cur.wait_event(ev["q_int"]) if hoist else self._forward_q(self.nets["q_int"])
+            self._backward_q(self.nets["q_int"], self.b_r_int, publish, None)
+            cur.wait_event(ev["emb"]) if hoist else self._forward_emb()
+            self._backward_emb(publish)
+            cur.wait_event(ev["rnd"]) if hoist else self._forward_rnd(publish)
+            self._backward_rnd(publish, bump=self.train_count_dev)
         # ---- mixed priorities (:367-373) and their write-back ----
         use_int = self.intrinsic and not c.disable_int_priority
         N.check(self.lib.srlx_agent57_priority(r.B, self.A, N.tptr(self.out["q_ext"]["td"]), None, N.tptr(self.out["q_int"]["td"]) if use_int else None, None, None,

@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graphs")
     ap.add_argument("--no-overlap", action="store_true", help="run actor and learner back to back on one stream (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--multi-trunk", action="store_true", help="agent57_light: ONE convolution launch for the five networks' image blocks instead of one per network (A/B: faster alone, slower beside the update)")
+    ap.add_argument("--no-multi-trunk", action="store_true", help="agent57_light: one convolution launch per network instead of ONE for the five networks' image blocks (A/B)")
     ap.add_argument("--actor-stream", default="low", choices=["low", "normal", "high", "default"],
                     help="priority level of the stream the actors' side runs on (its own pool of hardware queues); default: torch's current stream")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
@@ -460,7 +460,7 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
         from simple_distributed_rl_amd.device.agent57_fast import Agent57LightFastEngine
 
         eng = Agent57LightFastEngine(rl, E, dev_index, episode_len=args.episode_len, seed=0, overlap=None if not args.no_overlap else False, actor_stream=args.actor_stream)
-        eng.multi_trunk = bool(args.multi_trunk)
+        eng.multi_trunk = not args.no_multi_trunk
         eng.prefill()
     fast_engine = True
     inner = max(1, args.inner)

@@ -196,9 +196,10 @@ class Agent57LightFastEngine:
         self.train_count = self.sync_count = self.total_env_steps = 0
         self.ledger, self.training, self.ingest, self.before_env = None, True, None, None
         self._trunks_fresh, self._q_ready = False, False
-        # the five image blocks of a lock-step as ONE launch (srlx_qnet_forward_convs_multi_u8): 6-15 % faster for the blocks alone, 3-4 % SLOWER per lock-step beside
-        # the update (a 0.6 ms launch leaves the update's small kernels no launch boundary to slot into) -- off unless asked for
-        self.multi_trunk = False
+        # the five image blocks of a lock-step as ONE launch (srlx_qnet_forward_convs_multi_u8): 3 % faster for the actors alone and -4 % per lock-step beside the
+        # update (1.41 against 1.47 ms, three interleaved repetitions) since the update's forward passes left its critical chain; beside the round's earlier
+        # 1.1 ms update chain the single launch LOST 3-4 % (it leaves the update's small kernels no launch boundary to slot into)
+        self.multi_trunk = True
         if self.learns:
             self._init_learner(B, A, z)
         if self.acts:

@@ -1,4 +1,4 @@
-for v in "" "--multi-trunk" "--updates 0" "--updates 0 --no-multi-trunk"; do
+for v in "" "--no-multi-trunk" "--updates 0" "--updates 0 --no-multi-trunk"; do
 python bench.py --algo agent57_light --steps 6 --warmup 1 --inner 16 --no-cpu-baseline $v 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])

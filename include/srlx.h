@@ -416,8 +416,9 @@ int srlx_pendulum_step(int64_t n_envs, float *d_state, int32_t *d_step_in_episod
  *   srlx_ppo_net_minibatch      : one minibatch of compute_train_loss (:102-169) + backward: rows i64 [minibatch] index the flattened
  *       [T x E] buffers (b_val = the rollout's values = old_v); partials f32 [srlx_ppo_net_partials_floats]: scratch; grad f32
  *       [param_count] = d loss / d parameters (sums in a fixed order: deterministic); losses f32 [3] or NULL.
- *   srlx_ppo_net_adam           : grad *= grad_scale (1 / world size behind a data-parallel all-reduce); global-norm clip
- *       (max_grad_norm, 0 = off: torch.nn.utils.clip_grad_norm_, ppo.py:240-241); torch.optim.Adam step; *d_step += 1.
+ *   srlx_ppo_net_adam           : the gradient (read only) scaled by grad_scale (1 / world size behind a data-parallel all-reduce); global-norm clip
+ *       (max_grad_norm, 0 = off: torch.nn.utils.clip_grad_norm_, ppo.py:240-241); torch.optim.Adam step; d_step int64 [2]: [0] += 1 (steps
+ *       taken), [1] = the launch's arrival counter (zero it once; it is zero again behind every call).
  * ------------------------------------------------------------------------------------------------ */
 int srlx_ppo_net_param_count(int obs_dim, int action_dim);
 int srlx_ppo_net_partials_floats(int obs_dim, int action_dim);

@@ -15,20 +15,27 @@ constexpr float kLogFloor = -13.815510557964274f;      // math.log(1e-6), ppo.py
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-// action = loc + exp(log_scale) * N(0,1) (Box-Muller on two keyed uniforms); log_prob per dimension, floored at log(1e-6).  i = flat index of (environment, dimension)
-__device__ __forceinline__ void normal_act_one(float loc, float log_scale, float ls_lo, float ls_hi, u64 seed, u64 c, i64 i, int deterministic, float &action, float &logprob) {
+// action = loc + exp(log_scale) * N(0,1) (Box-Muller on two keyed uniforms); log_prob per dimension, floored at log(1e-6).  i = flat index of (environment, dimension).
+// The standard-normal draw depends on (seed, counter, index) only -- a rollout kernel draws all T steps' values up front (normal_z) and applies them per step
+// (normal_act_from_z): the same expression, the same bits as normal_act_one.
+__device__ __forceinline__ float normal_z(u64 seed, u64 c, i64 i) {
+    const double u1 = 1.0 - srlx::u53(srlx::rng_u64(seed, c, (u64)(2 * i)));  // (0, 1]
+    const double u2 = srlx::u53(srlx::rng_u64(seed, c, (u64)(2 * i + 1)));
+    return (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
+}
+
+__device__ __forceinline__ void normal_act_from_z(float loc, float log_scale, float ls_lo, float ls_hi, float z, int deterministic, float &action, float &logprob) {
     const float ls = clampf(log_scale, ls_lo, ls_hi);  // enable_stable_gradients clip, normal_dist_block.py:144-149
     const float sd = expf(ls);
     float a = loc;
-    if (!deterministic) {
-        const double u1 = 1.0 - srlx::u53(srlx::rng_u64(seed, c, (u64)(2 * i)));  // (0, 1]
-        const double u2 = srlx::u53(srlx::rng_u64(seed, c, (u64)(2 * i + 1)));
-        const float z = (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
-        a = loc + sd * z;
-    }
+    if (!deterministic) a = loc + sd * z;
     const float q = (a - loc) / sd;
     action = a;
     logprob = fmaxf(-kHalfLog2Pi - ls - 0.5f * (q * q), kLogFloor);
+}
+
+__device__ __forceinline__ void normal_act_one(float loc, float log_scale, float ls_lo, float ls_hi, u64 seed, u64 c, i64 i, int deterministic, float &action, float &logprob) {
+    normal_act_from_z(loc, log_scale, ls_lo, ls_hi, deterministic ? 0.f : normal_z(seed, c, i), deterministic, action, logprob);
 }
 
 struct LossCfg {

@@ -2,7 +2,7 @@
 //   k_ppo_rollout   : the WHOLE rollout of an iteration in one launch -- T steps of E Pendulum-shaped environments: network forward, Normal policy sample +
 //                     log-probability (ppo.py:316-339), environment step with auto-reset, the [T][E] buffers, episode returns, V(s_T) and the GAE scan (:389-404).
 //                     One workgroup owns 16 environments for all T steps (an environment's steps depend on each other, the environments do not): weights and
-//                     activations live in LDS, nothing but the buffers goes to HBM.
+//                     activations live in LDS (the 64 x 64 layers as v_mfma_f32_16x16x4_f32 tiles), nothing but the buffers goes to HBM.
 //   k_ppo_minibatch : one minibatch of the update in one launch -- gather of the permuted samples, forward, compute_train_loss + gradient seeds (:102-169), the whole
 //                     backward pass; every workgroup walks tiles of 64 samples (the three 64 x 64 layers on v_mfma_f32_32x32x2_f32) and keeps ITS sum of the
 //                     12 931 parameter gradients in registers; per-workgroup partial gradients go to HBM once.
@@ -92,20 +92,6 @@ __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
 __device__ __forceinline__ float4 fma4(float s, float4 w, float4 a) { return make_float4(fmaf(s, w.x, a.x), fmaf(s, w.y, a.y), fmaf(s, w.z, a.z), fmaf(s, w.w, a.w)); }
 
-// out[j0 .. j0 + 3] = bias + sum_k in[k] * Wt[k][j0 ..]   (k ascending, fmaf)
-__device__ __forceinline__ float4 dense_row(const float *__restrict__ in, const float *__restrict__ wt, const float *__restrict__ bias, int j0) {
-    float4 acc = ld4(bias + j0);
-#pragma unroll 4
-    for (int k = 0; k < H; k += 4) {
-        const float4 h = ld4(in + k);
-        acc = fma4(h.x, ld4(wt + (k + 0) * H + j0), acc);
-        acc = fma4(h.y, ld4(wt + (k + 1) * H + j0), acc);
-        acc = fma4(h.z, ld4(wt + (k + 2) * H + j0), acc);
-        acc = fma4(h.w, ld4(wt + (k + 3) * H + j0), acc);
-    }
-    return acc;
-}
-
 // first layer: out[j0 .. j0 + 3] = b1 + sum_o x[o] * w1[j][o]
 __device__ __forceinline__ float4 first_row(const float *__restrict__ x, const Small &sm, int obs, int j0) {
     float acc[4];
@@ -125,35 +111,57 @@ __device__ __forceinline__ float dot64(const float *__restrict__ a, const float 
     return acc;
 }
 
-// The forward of RE rows held in LDS (x [RE][OBS_MAX]) by 256 threads: thread (e = tid / 16, units 4 (tid % 16) ..) per layer.  heads [RE][1 + 2 A]: v, loc, log_scale.
-// value_only: the policy branch is skipped (V(s_T)).  Ends behind a barrier.
+// The forward of RE = 16 rows held in LDS (x [RE][OBS_MAX]) by 256 threads.  The first layer and the heads on the vector pipe; the three 64 x 64 layers as
+// v_mfma_f32_16x16x4_f32 tiles: wave w owns units 16 w .. 16 w + 15 of all 16 rows, 16 chained MFMAs per layer (lane l supplies in[row l & 15][k] and
+// Wt[k][unit l & 15] for k = (l >> 4) + 4 q; D[4 (l >> 4) + i][l & 15] = acc[i]) -- a layer is 0.5 k clocks of matrix pipe instead of ~3 k clocks of LDS-latency-
+// bound FMAs (one workgroup per CU, one wave per SIMD).  Activation rows are 65 floats long ("lane i reads row i" without bank conflicts).
+// heads [RE][1 + 2 A]: v, loc, log_scale.  value_only: the policy branch is skipped (V(s_T)).  Ends behind a barrier.
+constexpr int LDF = 65;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct FwdLds {
     float wt2[H * H], wtv[H * H], wtp[H * H];
     Small sm;
-    float x[RE * OBS_MAX], h1[RE * H], h2[RE * H], hv[RE * H], hp[RE * H], heads[RE * (1 + 2 * A_MAX)];
+    float x[RE * OBS_MAX], h1[RE * LDF], h2[RE * LDF], hv[RE * LDF], hp[RE * LDF], heads[RE * (1 + 2 * A_MAX)];
 };
+
+__device__ __forceinline__ void mfma16_dense(const float *__restrict__ in, const float *__restrict__ wt, const float *__restrict__ bias, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, n0 = (threadIdx.x >> 6) * 16, c = lane & 15, g = lane >> 4;
+    const float b = bias[n0 + c];
+    f32x4 acc = {b, b, b, b};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int k = g + 4 * q;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(in[c * LDF + k], wt[k * H + n0 + c], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[(4 * g + i) * LDF + n0 + c] = fmaxf(acc[i], 0.f);
+}
 
 __device__ __forceinline__ void forward_rows(FwdLds &L, int obs, int A, bool value_only) {
     const int tid = threadIdx.x, e = tid >> 4, j0 = (tid & 15) * 4;
-    st4(L.h1 + e * H + j0, relu4(first_row(L.x + e * OBS_MAX, L.sm, obs, j0)));
+    {
+        const float4 h = relu4(first_row(L.x + e * OBS_MAX, L.sm, obs, j0));
+        float *o = L.h1 + e * LDF + j0;
+        o[0] = h.x, o[1] = h.y, o[2] = h.z, o[3] = h.w;
+    }
     __syncthreads();
-    st4(L.h2 + e * H + j0, relu4(dense_row(L.h1 + e * H, L.wt2, L.sm.b2, j0)));
+    mfma16_dense(L.h1, L.wt2, L.sm.b2, L.h2);
     __syncthreads();
-    st4(L.hv + e * H + j0, relu4(dense_row(L.h2 + e * H, L.wtv, L.sm.bv, j0)));
-    if (!value_only) st4(L.hp + e * H + j0, relu4(dense_row(L.h2 + e * H, L.wtp, L.sm.bp, j0)));
+    mfma16_dense(L.h2, L.wtv, L.sm.bv, L.hv);
+    if (!value_only) mfma16_dense(L.h2, L.wtp, L.sm.bp, L.hp);
     __syncthreads();
     const int n_out = 1 + 2 * A;
     if (tid < RE * n_out) {
-        const int r = tid / n_out, o = tid % n_out;
+        const int r = tid % RE, o = tid / RE;  // (consecutive lanes: consecutive rows)
         float v;
         if (o == 0)
-            v = dot64(L.hv + r * H, L.sm.wvo, L.sm.bvo[0]);
+            v = dot64(L.hv + r * LDF, L.sm.wvo, L.sm.bvo[0]);
         else if (value_only)
             v = 0.f;
         else if (o <= A)
-            v = dot64(L.hp + r * H, L.sm.wloc + (o - 1) * H, L.sm.bloc[o - 1]);
+            v = dot64(L.hp + r * LDF, L.sm.wloc + (o - 1) * H, L.sm.bloc[o - 1]);
         else
-            v = dot64(L.hp + r * H, L.sm.wls + (o - 1 - A) * H, L.sm.bls[o - 1 - A]);
+            v = dot64(L.hp + r * LDF, L.sm.wls + (o - 1 - A) * H, L.sm.bls[o - 1 - A]);
         L.heads[r * (1 + 2 * A_MAX) + o] = v;
     }
     __syncthreads();
@@ -217,6 +225,7 @@ __global__ void __launch_bounds__(256) k_ppo_rollout(RolloutArgs a) {
     float *t_rew = reinterpret_cast<float *>(lds_raw + sizeof(FwdLds));  // [T][RE]
     float *t_val = t_rew + a.T * RE;
     float *t_done = t_val + a.T * RE;
+    float *zbuf = t_done + a.T * RE;  // [T][RE][A]: the policy's standard-normal draws of the whole rollout, made up front by all threads (double-precision log / cos off the step loop)
     const int obs = 3, A = a.A, tid = threadIdx.x;
     const NetOff o = net_off(obs, A);
     load_forward_weights(L, a.params, o, obs, A);
@@ -232,6 +241,11 @@ __global__ void __launch_bounds__(256) k_ppo_rollout(RolloutArgs a) {
         }
     }
     const u64 c_act = (u64)a.act_counter[0], c_env = (u64)a.env_counter[0];
+    for (i64 w = tid; w < a.T * RE * A; w += 256) {
+        const i64 t = w / (RE * A);
+        const int rem = (int)(w % (RE * A)), e = rem / A, d = rem % A;
+        zbuf[w] = srlxp::normal_z(a.act_seed, c_act + (u64)t, (e0 + e) * A + d);
+    }
     __syncthreads();
     for (i64 t = 0; t < a.T; t++) {
         forward_rows(L, obs, A, false);
@@ -240,7 +254,7 @@ __global__ void __launch_bounds__(256) k_ppo_rollout(RolloutArgs a) {
             float act0 = 0.f;
             for (int d = 0; d < A; d++) {
                 float ac, lp;
-                srlxp::normal_act_one(hd[1 + d], hd[1 + A + d], a.ls_lo, a.ls_hi, a.act_seed, c_act + (u64)t, eg * A + d, 0, ac, lp);
+                srlxp::normal_act_from_z(hd[1 + d], hd[1 + A + d], a.ls_lo, a.ls_hi, zbuf[(t * RE + tid) * A + d], 0, ac, lp);
                 a.b_act[(t * a.E + eg) * A + d] = ac;
                 a.b_logp[(t * a.E + eg) * A + d] = lp;
                 if (d == 0) act0 = ac;
@@ -313,7 +327,7 @@ struct MbArgs {
 // gradient: [sample][input], weight gradient: [unit][input] with the SAMPLES as the K dimension -- accumulated in registers across the workgroup's tiles).
 // LDS rows are 65 floats long: "lane i reads row i" and "lane i reads column i" are both conflict-free, so no matrix is kept twice.
 constexpr int LD = 65;
-static_assert(S == 64 && H == 64, "mfma_block: K = 64 for every product");
+static_assert(S == 64 && H == 64 && RE == 16, "mfma_block: K = 64 for every product; mfma16_dense: 16 rows");
 constexpr int HS = 12;  // floats per row of the heads / seeds tables (16-byte rows)
 constexpr int kVecs = 6 + 2 * A_MAX + OBS_MAX;  // vectors of 64 partial sums a thread row keeps (b1, b2, bv, bp, wvo, head biases, wloc[], wls[], w1[][c])
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -574,20 +588,24 @@ __global__ void __launch_bounds__(256) k_ppo_reduce(int n_wg, int P, int stride,
         losses[p - P] = p - P == 0 ? -cfg.inv_bk * acc : (p - P == 1 ? cfg.value_w * cfg.inv_b * acc : cfg.entropy_w * -cfg.inv_b * acc);
 }
 
-// grad *= grad_scale (1 / world size behind the data-parallel all-reduce); global-norm clip; Adam.  One workgroup: the vector is 13 K floats.
-__global__ void __launch_bounds__(1024) k_ppo_adam(int P, float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, i64 *__restrict__ step,
+// The gradient scaled by grad_scale (1 / world size behind the data-parallel all-reduce); global-norm clip; Adam.
+__global__ void __launch_bounds__(1024) k_ppo_adam(int P, float *__restrict__ params, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, i64 *__restrict__ step,
                                                     double lr, double b1, double b2, double eps, float max_norm, float grad_scale) {
+    // ceil(P / 1024) workgroups: every one computes the WHOLE vector's norm (52 KB out of L2, the same sums in the same order everywhere), then steps its own 1 024
+    // parameters -- no grid-wide exchange for the clip factor; the last workgroup out (step[1]: an arrival counter) advances the step count.
     __shared__ float red[1024];
-    constexpr int kPer = 16;  // elements per thread (>= the largest geometry's 14.3 K / 1024), fully unrolled: every load of the pass is in flight at once
-    const int tid = threadIdx.x;
-    float g[kPer], pp[kPer], mm[kPer], vv[kPer];
+    constexpr int kPer = 16;  // elements per thread of the norm pass (>= the largest geometry's 14.3 K / 1024), fully unrolled: every load in flight at once
+    const int tid = threadIdx.x, mine = blockIdx.x * 1024 + tid;
+    const i64 steps_taken = step[0];
+    const bool in_mine = mine < P;
+    float pp = 0.f, mm = 0.f, vv = 0.f;
+    if (in_mine) pp = params[mine], mm = m[mine], vv = v[mine];
+    float g[kPer];
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
         const int p = tid + 1024 * k;
-        const bool in = p < P;
-        g[k] = in ? grad[p] * grad_scale : 0.f;
-        pp[k] = in ? params[p] : 0.f, mm[k] = in ? m[p] : 0.f, vv[k] = in ? v[p] : 0.f;
+        g[k] = p < P ? grad[p] * grad_scale : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < kPer; k++) ss = fmaf(g[k], g[k], ss);
@@ -598,19 +616,24 @@ __global__ void __launch_bounds__(1024) k_ppo_adam(int P, float *__restrict__ pa
         __syncthreads();
     }
     const float clip = max_norm > 0.f ? fminf(max_norm / (sqrtf(red[0]) + 1e-6f), 1.0f) : 1.0f;  // torch.nn.utils.clip_grad_norm_
-    const srlx::AdamCoef c = srlx::adam_coef(lr, b1, b2, eps, step[0]);
+    if (in_mine) {
+        const srlx::AdamCoef c = srlx::adam_coef(lr, b1, b2, eps, steps_taken);
+        float gc = 0.f;
 #pragma unroll
-    for (int k = 0; k < kPer; k++) {
-        const int p = tid + 1024 * k;
-        if (p < P) {
-            const float gc = g[k] * clip;
-            grad[p] = gc;  // (what the optimiser saw: tests read it)
-            srlx::adam_one(pp[k], gc, mm[k], vv[k], c);
-            params[p] = pp[k], m[p] = mm[k], v[p] = vv[k];
-        }
+        for (int k = 0; k < kPer; k++)
+            if (k == (int)blockIdx.x) gc = g[k] * clip;  // (this thread's own element is g[blockIdx.x]: selected without a run-time register index)
+        srlx::adam_one(pp, gc, mm, vv, c);  // (`grad` itself stays as it is: every workgroup reads all of it for the norm)
+        params[mine] = pp, m[mine] = mm, v[mine] = vv;
     }
     __syncthreads();
-    if (tid == 0) step[0] += 1;
+    if (tid == 0) {
+        __threadfence();
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(step + 1), 1ull);
+        if (old == gridDim.x - 1) {  // every workgroup has read step[0] (it arrives behind that read)
+            step[1] = 0;
+            step[0] = steps_taken + 1;
+        }
+    }
 }
 
 static_assert(H * OBS_MAX + 3 * H * H + 2 * A_MAX * H + 5 * H + 1 + 2 * A_MAX <= 16 * 1024, "k_ppo_adam: sixteen elements per thread");
@@ -645,7 +668,7 @@ int srlx_ppo_net_rollout(int64_t n_envs, int64_t horizon, int action_dim, const 
     SRLX_REQUIRE(d_params && d_env_state && d_step_in_episode && d_env_obs && d_env_counter && d_act_counter && d_b_obs && d_b_act && d_b_logp && d_b_val && d_b_rew && d_b_done &&
                      d_b_adv && d_last_v && d_episode_return && d_finished,
                  "ppo_net_rollout: NULL argument");
-    const size_t lds = sizeof(FwdLds) + (size_t)horizon * RE * 3 * sizeof(float);
+    const size_t lds = sizeof(FwdLds) + (size_t)horizon * RE * (3 + action_dim) * sizeof(float);
     SRLX_REQUIRE(lds <= 160 * 1024, "ppo_net_rollout: horizon too long for the workgroup's LDS");
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -700,7 +723,7 @@ int srlx_ppo_net_partials_floats(int obs_dim, int action_dim) {
 int srlx_ppo_net_adam(int obs_dim, int action_dim, float *d_params, float *d_grad, float *d_exp_avg, float *d_exp_avg_sq, int64_t *d_step, double lr, double beta1, double beta2,
                       double eps, double max_grad_norm, double grad_scale, void *stream) {
     SRLX_REQUIRE(geometry_ok(obs_dim, action_dim) && d_params && d_grad && d_exp_avg && d_exp_avg_sq && d_step, "ppo_net_adam: bad argument");
-    hipLaunchKernelGGL(k_ppo_adam, dim3(1), dim3(1024), 0, (hipStream_t)stream, net_off(obs_dim, action_dim).total, d_params, d_grad, d_exp_avg, d_exp_avg_sq, (i64 *)d_step, lr, beta1,
+    hipLaunchKernelGGL(k_ppo_adam, dim3((unsigned)((net_off(obs_dim, action_dim).total + 1023) / 1024)), dim3(1024), 0, (hipStream_t)stream, net_off(obs_dim, action_dim).total, d_params, d_grad, d_exp_avg, d_exp_avg_sq, (i64 *)d_step, lr, beta1,
                        beta2, eps, (float)max_grad_norm, (float)grad_scale);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;

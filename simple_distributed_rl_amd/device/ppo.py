@@ -144,7 +144,7 @@ class PPOEngine:
                 off += p.numel()
             self.flat_grad = torch.zeros(P, dtype=torch.float32, device=self.dev)
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
-            self.opt_step = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.opt_step = torch.zeros(2, dtype=torch.int64, device=self.dev)  # [steps taken, the optimiser launch's arrival counter]
             self.partials = torch.zeros(self.lib.srlx_ppo_net_partials_floats(cfg.obs_dim, cfg.action_dim), dtype=torch.float32, device=self.dev)
             self.opt = None
         else:

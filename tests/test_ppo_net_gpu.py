@@ -107,7 +107,7 @@ def test_minibatch_gradients_against_autograd_in_float64(base, clip, vclip, obs,
     # ---- clip + Adam ----
     ref = flat.clone().requires_grad_()
     opt = torch.optim.Adam([ref], lr=3e-4)
-    m, v2, step = torch.zeros(P, device=dev), torch.zeros(P, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    m, v2, step = torch.zeros(P, device=dev), torch.zeros(P, device=dev), torch.zeros(2, dtype=torch.int64, device=dev)
     mine = flat.clone()
     for k in range(2):
         gk = grad.clone() * (1.0 + k)
@@ -117,9 +117,8 @@ def test_minibatch_gradients_against_autograd_in_float64(base, clip, vclip, obs,
         N.check(lib.srlx_ppo_net_adam(obs, A, N.tptr(mine), N.tptr(gk), N.tptr(m), N.tptr(v2), N.tptr(step), 3e-4, 0.9, 0.999, 1e-8, 0.01, 0.5, None))
         torch.cuda.synchronize()
         assert float(norm) > 0.01  # (the clip is active)
-        torch.testing.assert_close(gk, ref.grad, rtol=2e-6, atol=1e-9)  # what the optimiser saw
         torch.testing.assert_close(mine, ref.detach(), rtol=3e-7, atol=3e-4 * 2e-5)  # (an ulp of the parameter, or 2e-5 of the step)
-    assert int(step.item()) == 2
+    assert step.tolist() == [2, 0]
 
 
 def _engines(torch, E, T, seed, **kw):
@@ -183,7 +182,7 @@ def test_fused_engine_against_the_autograd_engine(v_target):
     diff = (a.flat - flat_b).abs()  # (Adam divides by sqrt(v): an entry whose gradients are rounding residue may step differently -- bounded by a few % of the movement)
     assert float(diff.max()) < 0.03 * moved and float(diff.mean()) < 2e-4 * moved, (float(diff.max()), float(diff.mean()), moved)
     torch.testing.assert_close(a.losses, b.losses, rtol=1e-3, atol=1e-5)
-    assert int(a.opt_step.item()) == cfg.epochs * cfg.minibatches
+    assert a.opt_step.tolist() == [cfg.epochs * cfg.minibatches, 0]
 
 
 def test_fused_engine_graphs_and_geometry_gate():

@@ -19,8 +19,8 @@ rl.memory.set_proportional(alpha=0.6, beta_initial=0.4, beta_steps=1_000_000)
 rl.input_block.image.set_dqn_block()
 rl.hidden_block.set_dueling_network((512,))
 rl.setup(srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(episode_len=200))))
-eng = Agent57LightFastEngine(rl, E, 0, episode_len=200, seed=0)
-eng.multi_trunk = os.environ.get("MULTI", "0") == "1"
+eng = Agent57LightFastEngine(rl, E, 0, episode_len=200, seed=0, fc1_neighbour=int(os.environ.get("FC1N", "4")))
+eng.multi_trunk = os.environ.get("MULTI", "1") == "1"
 eng.prefill()
 for _ in range(16):
     eng.step(1)

@@ -18,7 +18,7 @@ rl.input_block.image.set_dqn_block()
 rl.hidden_block.set_dueling_network((512,))
 rl.setup(srl.make_env(srl.EnvConfig("SyntheticAtari-v0", kwargs=dict(episode_len=200))))
 eng = Agent57LightFastEngine(rl, 1024, 0, episode_len=200, seed=0)
-eng.multi_trunk = os.environ.get("MULTI", "0") == "1"
+eng.multi_trunk = os.environ.get("MULTI", "1") == "1"
 eng.prefill()
 for _ in range(4):
     eng.step(1)

@@ -324,6 +324,35 @@ def test_one_update_equals_the_round5_learner_with_torch_tails():
             assert np.mean(np.abs(x - y) > 5e-6 * (5 if "emb" in name or "lifelong" in name else 1)) < 3e-2, (name, k)
 
 
+def test_forwards_beside_the_previous_backward_change_no_bit():
+    """The update with every network's forward passes (and the dense tails) on the side stream beside the previous network's backward pass (`hoist_forwards`, the
+    default) against the same update with one network after the other: the same launches on the same data in another stream order -- every parameter, every
+    optimiser moment, losses and priorities bit for bit, over several updates."""
+    N, lib, torch, dev = _env()
+    from simple_distributed_rl_amd.device.agent57_fast import Agent57LightFastEngine
+
+    def run(hoist):
+        torch.manual_seed(4)
+        eng = Agent57LightFastEngine(_cfg84(), 16, 0, episode_len=11, seed=3)
+        eng.hoist_forwards = hoist
+        for _ in range(12):
+            eng.step(learner_updates=0)
+        for _ in range(3):
+            eng._learner_body(None)
+            eng._after_update()
+        torch.cuda.synchronize()
+        return eng
+
+    a, b = run(True), run(False)
+    assert a.losses() == b.losses()
+    assert torch.equal(a.priorities, b.priorities)
+    for n1, n2 in zip(a.nets.values(), b.nets.values()):
+        for p, q in zip(n1.module.parameters(), n2.module.parameters()):
+            assert torch.equal(p, q), n1.name
+        for x, y in zip(n1.opt.exp_avg + n1.opt.exp_avg_sq, n2.opt.exp_avg + n2.opt.exp_avg_sq):
+            assert torch.equal(x, y), n1.name
+
+
 def test_small_engine_trains_items_consistent_and_reproducible():
     """The engine without overlap (16 lanes): 30 lock-steps with updates; the per-slot item fields are what the lanes held when they acted; finite losses; two
     instances from one seed walk one trajectory bit for bit; evaluation mode uses arm 0 / test_beta."""

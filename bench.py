@@ -93,6 +93,19 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def _emit(out):
+    """The line of the contract, as the LAST thing on stdout: RCCL prints a version banner through C stdio at communicator creation, which would otherwise be flushed
+    at exit, behind a line Python has already written."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def roles_only(args):
     """`python bench.py --roles-only`: role_timings in this (fresh) process, with a one-rank RCCL process group initialised and used first -- a rank of the
     multi-GPU job has RCCL's streams and helper threads beside its own."""
@@ -122,7 +135,7 @@ def roles_only(args):
             rccl = False
     out = role_timings(args, dev_index, actor_ranks=args.actor_ranks)
     out["rccl_initialised"] = rccl
-    print(json.dumps(out), flush=True)
+    _emit(out)
     if rccl:
         dist.destroy_process_group()
 
@@ -373,7 +386,7 @@ def main():
 
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
-    print(json.dumps(out), flush=True)
+    _emit(out)
 
 
 def bench_replay_role(args, dev_index, rank, world, dist):
@@ -418,7 +431,7 @@ def bench_replay_role(args, dev_index, rank, world, dist):
                           "per_capacity": args.capacity, "backend": args.backend},
                "roofline": None, "final": {"train_count": info.get("train_count"), "loss": info.get("loss")}}
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        _emit(out)
     dist.destroy_process_group()
 
 
@@ -555,7 +568,7 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
 
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
-    print(json.dumps(out), flush=True)
+    _emit(out)
 
 
 def bench_ppo(args, dev_index, rank, world, dist):
@@ -680,7 +693,7 @@ def bench_ppo(args, dev_index, rank, world, dist):
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_ppo(args, cfg)
-    print(json.dumps(out), flush=True)
+    _emit(out)
 
 
 def subfigures(eng, args, inner):

@@ -44,6 +44,26 @@ def test_no_gpu_calls_fail_cleanly():
 
     with pytest.raises(N.SrlxError):
         ProportionalMemory(100)
+    # the engines refuse to start as well (their arithmetic is libsrlx HIP code: there is nothing to fall back to)
+    from simple_distributed_rl_amd.device.ppo import PPODeviceConfig, PPOEngine
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PPOEngine(PPODeviceConfig(n_envs=16))
+
+
+def test_ppo_network_layout_is_host_arithmetic():
+    """The flat parameter vector of PPO's actor-critic (srlx_ppo_net_param_count: no device needed): the reference's default blocks at the geometries the kernels
+    cover, -1 outside them; the scratch size the minibatch launch asks for."""
+    from simple_distributed_rl_amd import _native as N
+
+    lib = N.lib()
+    count = lambda obs, A: 64 * obs + 64 + 3 * (64 * 64 + 64) + 64 + 1 + 2 * (A * 64 + A)  # noqa: E731
+    for obs, A in ((3, 1), (5, 3), (8, 4), (1, 1)):
+        assert lib.srlx_ppo_net_param_count(obs, A) == count(obs, A)
+        assert lib.srlx_ppo_net_partials_floats(obs, A) == 256 * ((count(obs, A) + 3 + 3) // 4 * 4)
+    assert lib.srlx_ppo_net_param_count(3, 1) == 12931
+    for obs, A in ((0, 1), (9, 1), (3, 0), (3, 5)):
+        assert lib.srlx_ppo_net_param_count(obs, A) == -1 and lib.srlx_ppo_net_partials_floats(obs, A) == -1
 
 
 def test_hardware_queue_default_is_set_before_the_runtime_starts():

@@ -234,3 +234,27 @@ def test_ppo_gradient_average_world2():
     for x0, x1, y0, y1 in zip(g0, g1, a0, a1):
         np.testing.assert_allclose(y0, (x0 + x1) / 2, rtol=1e-6)
         np.testing.assert_array_equal(y0, y1)
+
+
+def _ppo_grad_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simple_distributed_rl_amd.device.ppo import flat_vector_all_reduce
+
+        flat = torch.arange(12931, dtype=torch.float32) * (rank + 1)
+        scale = flat_vector_all_reduce(flat)
+        want = torch.arange(12931, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        ret[rank] = bool(scale == 1.0 / world and torch.equal(flat, want))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ppo_flat_gradient_all_reduce_gloo_world2():
+    """DistributedPPO's exchange (device/ppo.py:flat_vector_all_reduce): ONE in-place sum of the flat gradient vector; the factor the optimiser launch applies is
+    1 / world size (the mean of the ranks' gradients, as the reference's data-parallel learner would average them)."""
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_ppo_grad_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)

@@ -182,6 +182,8 @@ int srlx_pack_frames(const uint8_t *d_frame_base, const int64_t *d_frame_off, in
 /* A keyed pseudo-random permutation of 0..n-1 (int64), key = (seed, *d_counter); advances *d_counter by one.  Device state only: replayable inside a
  * HIP graph (the PPO engine's minibatch shuffles -- the role of the reference's per-epoch shuffle of the collected batch, srl/algorithms/ppo/ppo.py). */
 int srlx_rng_permutation(uint64_t seed, int64_t *d_counter, int64_t n, int64_t *d_out, void *stream);
+/* `count` permutations [count][n] in one launch: what `count` successive calls would have written (*d_counter + 0 .. count - 1); *d_counter += count. */
+int srlx_rng_permutations(uint64_t seed, int64_t *d_counter, int64_t n, int count, int64_t *d_out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Device-resident transition store for E lock-stepped environments (uint8 or float32 frames).

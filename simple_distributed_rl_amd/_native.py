@@ -69,6 +69,7 @@ SIGNATURES = {
     "srlx_per_refresh": (c_int, [c_p, c_p]),
     "srlx_rng_uniform": (c_int, [ctypes.c_uint64, c_p, c_i64, c_p, c_p]),
     "srlx_rng_permutation": (c_int, [ctypes.c_uint64, c_p, c_i64, c_p, c_p]),
+    "srlx_rng_permutations": (c_int, [ctypes.c_uint64, c_p, c_i64, c_int, c_p, c_p]),
     "srlx_store_actor_td": (c_int, [c_p, c_i64, c_i64, c_p, c_int, c_p, c_f64, c_f64, c_int, c_int, c_p, c_p]),
     "srlx_pack_frames": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "srlx_store_create": (c_int, [ctypes.POINTER(c_p), c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, c_int]),

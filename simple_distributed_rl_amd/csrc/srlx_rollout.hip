@@ -793,7 +793,8 @@ int srlx_pack_frames(const uint8_t *d_frame_base, const int64_t *d_frame_off, in
 // Key = (seed, *counter): a captured graph draws a fresh permutation at every replay with nothing but device state -- the PPO engine's minibatch
 // shuffles (device/ppo.py; torch.randperm as a graph node, or eager between replays of its large graphs, did not replay reliably).
 __global__ void __launch_bounds__(256) k_rng_permutation(u64 seed, const i64 *counter, i64 n, int half_bits, i64 *out) {
-    const u64 c = (u64)counter[0];
+    const u64 c = (u64)counter[0] + blockIdx.y;  // (blockIdx.y: the y-th of several permutations drawn in one launch, under the counter values successive calls would see)
+    out += (i64)blockIdx.y * n;
     const u64 mask = (1ull << half_bits) - 1;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
         u64 x = (u64)i;
@@ -818,6 +819,18 @@ int srlx_rng_permutation(uint64_t seed, int64_t *d_counter, int64_t n, int64_t *
     while (((int64_t)1 << bits) < n) bits += 2;
     hipLaunchKernelGGL(k_rng_permutation, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (u64)seed, d_counter, (i64)n, bits / 2, (i64 *)d_out);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, d_counter);
+    SRLX_HIP(hipGetLastError());
+    return SRLX_OK;
+}
+
+__global__ void k_advance_by(i64 *c, i64 k) { c[0] += k; }
+
+int srlx_rng_permutations(uint64_t seed, int64_t *d_counter, int64_t n, int count, int64_t *d_out, void *stream) {
+    SRLX_REQUIRE(d_counter && d_out && n > 0 && n < ((int64_t)1 << 40) && count >= 1 && count <= 65535, "rng_permutations: bad argument");
+    int bits = 2;
+    while (((int64_t)1 << bits) < n) bits += 2;
+    hipLaunchKernelGGL(k_rng_permutation, dim3(grid_for(n), (unsigned)count), dim3(256), 0, (hipStream_t)stream, (u64)seed, d_counter, (i64)n, bits / 2, (i64 *)d_out);
+    hipLaunchKernelGGL(k_advance_by, dim3(1), dim3(1), 0, (hipStream_t)stream, d_counter, (i64)count);
     SRLX_HIP(hipGetLastError());
     return SRLX_OK;
 }

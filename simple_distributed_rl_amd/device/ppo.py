@@ -275,9 +275,9 @@ class PPOEngine:
         permutation's rows."""
         cfg = self.cfg
         st = N.torch_stream_ptr()
+        if self._perm_mode == "srlx":  # the epochs' shuffles in one launch (the values `epochs` successive srlx_rng_permutation calls would write)
+            N.check(self.lib.srlx_rng_permutations(cfg.seed ^ 0x7065726D, N.tptr(self.perm_counter), n, cfg.epochs, N.tptr(self._perms), st))
         for ep in range(cfg.epochs):
-            if self._perm_mode == "srlx":
-                N.check(self.lib.srlx_rng_permutation(cfg.seed ^ 0x7065726D, N.tptr(self.perm_counter), n, N.tptr(self._perms[ep]), st))
             for k in range(cfg.minibatches):
                 rows = self._perms[ep][k * mb : (k + 1) * mb]
                 N.check(self.lib.srlx_ppo_net_minibatch(mb, N.tptr(rows), cfg.obs_dim, cfg.action_dim, N.tptr(self.flat), N.tptr(obs), N.tptr(act), N.tptr(logp), N.tptr(adv),

@@ -290,6 +290,10 @@ def test_keyed_permutation_kernel():
         counter.zero_()
         N.check(lib.srlx_rng_permutation(1234, N.tptr(counter), n, N.tptr(out), None))
         assert torch.equal(out, seen[0])
+        counter.zero_()  # the three of them in one launch (srlx_rng_permutations): the same values, the counter advanced by three
+        out3 = torch.empty((3, n), dtype=torch.int64, device=dev)
+        N.check(lib.srlx_rng_permutations(1234, N.tptr(counter), n, 3, N.tptr(out3), None))
+        assert all(torch.equal(out3[k], seen[k]) for k in range(3)) and int(counter) == 3
     n, draws = 16, 4000
     counter = torch.zeros(1, dtype=torch.int64, device=dev)
     out = torch.empty(n, dtype=torch.int64, device=dev)

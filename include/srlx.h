@@ -424,6 +424,7 @@ int srlx_pendulum_step(int64_t n_envs, float *d_state, int32_t *d_step_in_episod
  * ------------------------------------------------------------------------------------------------ */
 int srlx_ppo_net_param_count(int obs_dim, int action_dim);
 int srlx_ppo_net_partials_floats(int obs_dim, int action_dim);
+int srlx_ppo_net_rollout_max_horizon(int action_dim); /* longest horizon srlx_ppo_net_rollout takes (its per-step records live in the workgroup's LDS) */
 int srlx_ppo_net_forward(int64_t n, int obs_dim, int action_dim, const float *d_params, const float *d_obs, float *d_v, float *d_loc,
                          float *d_log_scale, void *stream);
 int srlx_ppo_net_rollout(int64_t n_envs, int64_t horizon, int action_dim, const float *d_params, float *d_env_state,

@@ -169,6 +169,7 @@ SIGNATURES = {
     "srlx_pendulum_step": (c_int, [c_i64, c_p, c_p, c_p, c_i64, c_u64, c_p, c_p, c_p, c_p, c_p]),
     "srlx_ppo_net_param_count": (c_int, [c_int, c_int]),
     "srlx_ppo_net_partials_floats": (c_int, [c_int, c_int]),
+    "srlx_ppo_net_rollout_max_horizon": (c_int, [c_int]),
     "srlx_ppo_net_forward": (c_int, [c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
     "srlx_ppo_net_rollout": (c_int, [c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_i64, c_u64, c_p, c_u64, c_p, c_f64, c_f64, c_f64, c_f64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                      c_p, c_p, c_p]),

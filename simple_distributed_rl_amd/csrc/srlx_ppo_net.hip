@@ -659,12 +659,19 @@ int srlx_ppo_net_forward(int64_t n, int obs_dim, int action_dim, const float *d_
     return SRLX_OK;
 }
 
+int srlx_ppo_net_rollout_max_horizon(int action_dim) {  // what fits the workgroup's LDS beside weights and activations
+    if (!geometry_ok(3, action_dim)) return -1;
+    const long long t = ((long long)160 * 1024 - (long long)sizeof(FwdLds)) / ((long long)RE * (3 + action_dim) * (long long)sizeof(float));
+    return (int)(t < 1024 ? t : 1024);
+}
+
 int srlx_ppo_net_rollout(int64_t n_envs, int64_t horizon, int action_dim, const float *d_params, float *d_env_state, int32_t *d_step_in_episode, float *d_env_obs,
                          int64_t episode_len, uint64_t env_seed, int64_t *d_env_counter, uint64_t act_seed, int64_t *d_act_counter, double log_scale_min,
                          double log_scale_max, double discount, double gae_lambda, float *d_b_obs, float *d_b_act, float *d_b_logp, float *d_b_val, float *d_b_rew,
                          uint8_t *d_b_done, float *d_b_adv, float *d_last_v, float *d_episode_return, float *d_finished, void *stream) {
     SRLX_REQUIRE(n_envs > 0 && n_envs % RE == 0, "ppo_net_rollout: the environment count must be a multiple of 16");
-    SRLX_REQUIRE(horizon > 0 && horizon <= 1024 && geometry_ok(3, action_dim) && episode_len > 0, "ppo_net_rollout: bad geometry");
+    SRLX_REQUIRE(horizon > 0 && geometry_ok(3, action_dim) && horizon <= srlx_ppo_net_rollout_max_horizon(action_dim) && episode_len > 0,
+                 "ppo_net_rollout: bad geometry (horizon <= srlx_ppo_net_rollout_max_horizon)");
     SRLX_REQUIRE(d_params && d_env_state && d_step_in_episode && d_env_obs && d_env_counter && d_act_counter && d_b_obs && d_b_act && d_b_logp && d_b_val && d_b_rew && d_b_done &&
                      d_b_adv && d_last_v && d_episode_return && d_finished,
                  "ppo_net_rollout: NULL argument");

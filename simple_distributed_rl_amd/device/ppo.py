@@ -201,7 +201,8 @@ class PPOEngine:
         return v, loc, ls
 
     def _fused_rollout_ok(self) -> bool:
-        return self.fused and isinstance(self.env, PendulumVecEnv) and self.cfg.obs_dim == 3 and self.cfg.n_envs % 16 == 0 and self.cfg.horizon <= 1024
+        return (self.fused and isinstance(self.env, PendulumVecEnv) and self.cfg.obs_dim == 3 and self.cfg.n_envs % 16 == 0
+                and self.cfg.horizon <= self.lib.srlx_ppo_net_rollout_max_horizon(self.cfg.action_dim))  # (longer horizons: the step-wise kernels)
 
     def rollout(self):
         cfg = self.cfg

@@ -62,6 +62,8 @@ def test_ppo_network_layout_is_host_arithmetic():
         assert lib.srlx_ppo_net_param_count(obs, A) == count(obs, A)
         assert lib.srlx_ppo_net_partials_floats(obs, A) == 256 * ((count(obs, A) + 3 + 3) // 4 * 4)
     assert lib.srlx_ppo_net_param_count(3, 1) == 12931
+    assert 256 <= lib.srlx_ppo_net_rollout_max_horizon(1) <= 1024 and lib.srlx_ppo_net_rollout_max_horizon(4) < lib.srlx_ppo_net_rollout_max_horizon(1)
+    assert lib.srlx_ppo_net_rollout_max_horizon(5) == -1
     for obs, A in ((0, 1), (9, 1), (3, 0), (3, 5)):
         assert lib.srlx_ppo_net_param_count(obs, A) == -1 and lib.srlx_ppo_net_partials_floats(obs, A) == -1
 

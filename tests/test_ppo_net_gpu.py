@@ -191,6 +191,11 @@ def test_fused_engine_graphs_and_geometry_gate():
 
     with pytest.raises(ValueError):
         PPOEngine(PPODeviceConfig(n_envs=64, hidden_sizes=(32, 32)), 0, fused=True)
+    long = PPOEngine(PPODeviceConfig(n_envs=32, horizon=400, epochs=1, minibatches=2), 0)  # a horizon whose per-step records do not fit the rollout kernel's LDS
+    assert long.fused and not long._fused_rollout_ok() and lib.srlx_ppo_net_rollout_max_horizon(1) < 400
+    long.step()  # (the step-wise kernels on the libsrlx network)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(long.flat).all()) and int(long.act_counter.item()) == 400
     assert not PPOEngine(PPODeviceConfig(n_envs=64, hidden_sizes=(32, 32)), 0).fused  # (other blocks: the torch modules)
 
     def run(graphs):

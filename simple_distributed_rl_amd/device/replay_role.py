@@ -139,6 +139,9 @@ class ReplayRoleRainbow:
             self._posted = []  # (serve lock-step, buffer) of the receives in the group posted in the previous lock-step
             self._works = []
         self.check_headers = __import__("os").environ.get("SRLX_CHECK_HEADERS", "0") == "1"
+        # a host synchronisation in front of every posted group (replay and learner rank).  Not needed: RCCL runs a group behind everything enqueued on the posting
+        # thread's current stream, and tests/test_dist_stream_semantics_gpu.py::test_replay_gpu_role_under_stream_ordered_transfers runs the role without it
+        self.host_sync = False
         self._total_envs = self.n_actor_ranks * E
         # first observations of every actor environment -> the replay rank's ring position 0
         if self.role == "actor":
@@ -249,8 +252,8 @@ class ReplayRoleRainbow:
             ops.append(dist.P2POp(dist.irecv, self.wb_rx[k], LEARNER))
         for u in range(U):
             ops.append(dist.P2POp(dist.isend, self.msg_tx[(s_now % 2) * U + u], LEARNER))
-        if not self.staged:
-            torch.cuda.current_stream(self.dev).synchronize()  # the messages are complete before the communicator's stream reads them (RCCL orders with the CURRENT stream: kept explicit)
+        if not self.staged and self.host_sync:
+            torch.cuda.current_stream(self.dev).synchronize()  # (RCCL orders a group behind everything on the CURRENT stream: the wait is optional, `host_sync`)
         self._works = dist.batch_isend_irecv(ops)
         self.served += U
 
@@ -289,7 +292,7 @@ class ReplayRoleRainbow:
             sb.out[:8].view(torch.int64)[0] = 1 if valid else 0
             out.copy_(sb.out, non_blocking=not self.staged)
             ops.append(dist.P2POp(dist.isend, out, REPLAY))
-        if not self.staged:
+        if not self.staged and self.host_sync:
             torch.cuda.current_stream(self.dev).synchronize()
         self._works = dist.batch_isend_irecv(ops)
 

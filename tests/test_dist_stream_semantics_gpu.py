@@ -96,12 +96,14 @@ class _Fabric:
                 mine[key].append(slot)
         return _Work(self, slot)
 
-    def broadcast(self, me, src_rank, world, tensor):
+    def broadcast(self, me, src_rank, world, tensor, members=None):
         slot = self._posted(tensor)
+        members = list(range(world)) if members is None else list(members)
+        world = len(members)
         with self.bcast_cv:
             if me == src_rank:  # the source's stream, too, waits for the collective: its buffer is read until the last receiver has its copy
                 slot["served"] = []
-                for r in range(world):
+                for r in members:
                     if r != me:
                         self.bcast[r].append(slot)
                 self.bcast_cv.notify_all()
@@ -157,7 +159,10 @@ class _FakeDist:
         return [self.fabric.post("send" if op.op is _Switch.isend else "recv", self.rank, op.peer, op.tensor) for op in ops]
 
     def broadcast(self, tensor, src=0, group=None):
-        self.fabric.broadcast(self.rank, src, self.world, tensor)
+        self.fabric.broadcast(self.rank, src, self.world, tensor, members=group)
+
+    def new_group(self, ranks):
+        return list(ranks)  # (a group is its member list: only `broadcast` takes one here)
 
     def gather(self, *a, **k):
         raise AssertionError("the slot exchange does not gather")
@@ -392,3 +397,87 @@ def test_agent57_light_exchange_under_stream_ordered_transfers():
     assert torch.equal(got["frames"], want["frames"]), "frames differ: a transfer was overtaken by the kernels around it"
     assert torch.equal(got["x"], want["x"]), "UVFA / intrinsic fields differ"
     assert torch.equal(got["flat"], want["flat"]) and got["losses"] == want["losses"], "the learner trained on something else"
+
+
+def _job_replay_role(sync: bool, delay_cycles: int, steps: int, host_sync: bool):
+    """The three-role topology (device/replay_role.py: learner <- replay GPU <- actor) as three threads over the fabric."""
+    import simple_distributed_rl_amd.device.dist as dmod
+    import simple_distributed_rl_amd.device.replay_role as rmod
+    from simple_distributed_rl_amd.device.rainbow import RainbowDeviceConfig
+
+    dev = torch.device("cuda:0")
+    fabric = _Fabric(dev, sync, delay_cycles)
+    out, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+            _Switch.local.facade = _FakeDist(fabric, rank, 3)
+            cfg = RainbowDeviceConfig(n_envs=64, batch_size=8, memory_capacity=64 * 40, memory_warmup_size=128, target_model_update_interval=5, seed=11)
+            top = rmod.ReplayRoleRainbow(cfg, 0, episode_len=9, sync_interval=4, prefetch=2, updates=1)
+            top.host_sync = host_sync
+            for _ in range(steps):
+                top.step()
+            top.finish()
+            if top.role == "learner":
+                out["flat"], out["loss"], out["train_count"] = top.flat.detach().clone(), float(top.local.loss.item()), top.local.train_count
+            elif top.role == "replay":
+                import ctypes
+
+                import numpy as np
+
+                from simple_distributed_rl_amd import _native as N
+
+                rp = top.replay
+                tree = np.empty(2 * rp.capacity - 1, np.float64)
+                mp_, size, write = N.c_f64(0), N.c_i64(0), N.c_i64(0)
+                N.check(rp.lib.srlx_per_backup(rp.h_per, ctypes.byref(mp_), ctypes.byref(size), ctypes.byref(write), N.np_ptr(tree)))
+                out["per"] = (mp_.value, size.value, write.value, torch.tensor(tree))
+                out["served"], out["write_backs"] = top.served, int(top.step_dev.item())
+            else:
+                out["actor_flat"] = top.flat.detach().clone()
+        except Exception:
+            import traceback
+
+            errors.append(f"rank {rank}:\n{traceback.format_exc()}")
+
+    saved = dmod.dist, rmod.dist
+    dmod.dist = rmod.dist = _Switch()
+    try:
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in (0, 1, 2)]
+        threads[0].start()  # (the ranks share torch's generator: the others start once the learner has built its networks and posted its first broadcast)
+        assert fabric.source_posted.wait(TIMEOUT) or errors, "the learner rank never reached its first broadcast"
+        for t in threads[1:]:
+            t.start()
+        for t in threads:
+            t.join(4 * TIMEOUT)
+        assert not any(t.is_alive() for t in threads), "a rank hung"
+        assert not errors, "\n".join(errors)
+    finally:
+        dmod.dist, rmod.dist = saved
+    return out
+
+
+def test_replay_gpu_role_under_stream_ordered_transfers():
+    """The replay-GPU topology (device/replay_role.py) under RCCL's stream semantics: batch messages, priority write-backs and the actors' slabs as
+    asynchronous, DELAYED transfers on the fabric's communicator stream, WITHOUT the per-lock-step host synchronisation the role used to put in front of its
+    posts -- the learner's weights, loss and update count and the replay rank's tree (every leaf, max_priority, size, write position) equal those of the same job
+    over synchronous transfers, bit for bit."""
+    steps = 30
+    a = _job_replay_role(sync=True, delay_cycles=0, steps=steps, host_sync=True)
+    b = _job_replay_role(sync=False, delay_cycles=6_000_000, steps=steps, host_sync=False)
+    assert a["train_count"] == b["train_count"] > 10 and a["served"] == b["served"] == steps and a["write_backs"] == b["write_backs"]
+    assert a["loss"] == b["loss"] and torch.equal(a["flat"], b["flat"]) and torch.equal(a["actor_flat"], b["actor_flat"])
+    for x, y in zip(a["per"], b["per"]):
+        assert (torch.equal(x, y) if torch.is_tensor(x) else x == y)
+    # the check has teeth: with the stream-level waits for the posted groups taken out, the same delayed fabric trains on batches that have not arrived
+    import simple_distributed_rl_amd.device.replay_role as rmod
+
+    orig = rmod.ReplayRoleRainbow.__dict__["_complete"]  # (the staticmethod object itself: the attribute access would hand back the bare function)
+    rmod.ReplayRoleRainbow._complete = staticmethod(lambda works: None)
+    try:
+        c = _job_replay_role(sync=False, delay_cycles=6_000_000, steps=steps, host_sync=False)
+    finally:
+        rmod.ReplayRoleRainbow._complete = orig
+    assert not torch.equal(a["flat"], c["flat"])

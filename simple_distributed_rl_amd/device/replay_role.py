@@ -5,8 +5,8 @@ ingests the actors' items, samples batches ahead of the trainer into a bounded q
 updates the trainer sends back through a second bounded queue (`train_to_mem`, :361-413)).  Here the memory process is a REPLAY GPU:
 
     rank 0   learner   trains on served batches, never touches a ring or a tree; weights -> actors every `sync_interval` lock-steps (one flat broadcast)
-    rank 1   replay    owns the uint8 frame ring + the sum-tree for the environments of ALL actor ranks: ingests their slabs (grouped send / recv,
-                       device/dist.py:TransitionBus), commits, samples, and SERVES every batch as one message -- the frames its n-step windows point at
+    rank 1   replay    owns the uint8 frame ring + the sum-tree for the environments of ALL actor ranks: ingests their slabs (round 6: the slot exchange of
+                       device/dist.py:TransitionBus -- packed records + frames straight into rotating staging slots, one unpack-and-commit launch), samples, and SERVES every batch as one message -- the frames its n-step windows point at
                        packed by `srlx_pack_frames`, the frame-offset tables re-based onto the packed frames, indices / weights / n-step scalars
     rank 2.. actors    E lock-stepped environments each, exactly the actor ranks of device/dist.py:DistributedRainbow
 
@@ -143,19 +143,19 @@ class ReplayRoleRainbow:
         # thread's current stream, and tests/test_dist_stream_semantics_gpu.py::test_replay_gpu_role_under_stream_ordered_transfers runs the role without it
         self.host_sync = False
         self._total_envs = self.n_actor_ranks * E
-        # first observations of every actor environment -> the replay rank's ring position 0
+        # first observations of every actor environment -> the replay rank's ring position 0 (a one-off exchange through staging slot 0; the records are not used)
+        self.bus.enable_slots(2)
         if self.role == "actor":
-            got = self.bus.push(self.local.actions, self.local.env.rewards, self.local.env.terminated, self.local.env.done, self.local.first_obs)
+            eng = self.local
+            self.bus.send_begin(self.bus.pack(eng.actions, eng.env.rewards, eng.env.terminated, eng.env.done), eng.first_obs)
+            self.bus.send_end()
         elif self.role == "replay":
-            z = torch.zeros(E, device=self.dev)
-            got = self.bus.push(z.int(), z, z.to(torch.uint8), z.to(torch.uint8), torch.zeros((E, F), dtype=torch.uint8, device=self.dev))
-            self.replay.reset_all(self._actor_rows(got)[4])
+            self.bus.recv_begin(0)
+            self.bus.recv_end()
+            self.replay.reset_all(self.bus.slot_obs[0])
+        torch.cuda.synchronize(self.dev)
 
     # ---- helpers --------------------------------------------------------------------------------------------------------------
-    def _actor_rows(self, gathered):
-        k = FIRST_ACTOR * self.cfg.n_envs
-        return tuple(t[k:] for t in gathered)
-
     def _broadcast_weights(self):
         if self.staged:
             host = self.flat.cpu()
@@ -202,22 +202,27 @@ class ReplayRoleRainbow:
         eng = self.local
         q = eng._actor_net(None, None)
         if self._in_flight:
-            self.bus.push_end()
+            self.bus.send_end()  # the previous slab's frames have left before the environments overwrite them
         eng._actor_select(q)
         eng.actor_commit()
         self.env_steps_local += self.cfg.n_envs
         env = eng.env
-        self.bus.push_begin(eng.actions, env.rewards, env.terminated, env.done, env.next_obs)
+        self.bus.send_begin(self.bus.pack(eng.actions, env.rewards, env.terminated, env.done), env.next_obs)  # one record + the frames: ONE group of two sends
         self._in_flight = True
+
+    def _commit_slab(self, slot: int):
+        """The slab in staging slot `slot` -> ring + tree: one launch unpacks the actor ranks' records and commits their environments, one adds the new leaves."""
+        rp, bus = self.replay, self.bus
+        rp.commit_packed(bus.slot_scal[slot], self.cfg.n_envs, 0, bus.slot_obs[slot])
+        rp.add_masked()
+        rp.note_commit()
 
     def _step_replay(self):
         rp, c, U, s_now = self.replay, self.codec, self.updates, self.step_count
-        if self._in_flight:
-            rp.commit(*self._actor_rows(self.bus.push_end()))
-        if not hasattr(self, "_zeros"):
-            z = torch.zeros(self.cfg.n_envs, device=self.dev)  # this rank contributes nothing: push_begin only posts the receives
-            self._zeros = (z.int(), z, z.to(torch.uint8), z.to(torch.uint8), torch.zeros((1, 1), dtype=torch.uint8, device=self.dev))
-        self.bus.push_begin(*self._zeros)
+        if self._in_flight:  # the slab that travelled during the previous lock-step (straight into staging slot (s_now - 1) % 2)
+            self.bus.recv_end()
+            self._commit_slab((s_now - 1) % 2)
+        self.bus.recv_begin(s_now % 2)
         self._in_flight = True
         # the group of the previous lock-step: its batches are out, the write-backs the learner produced during that lock-step are in -- apply them
         self._complete(self._works)
@@ -299,10 +304,11 @@ class ReplayRoleRainbow:
     def finish(self):
         """Complete what is in flight: every message posted is matched (each lock-step moved the same number in both directions)."""
         if self.role == "actor" and self._in_flight:
-            self.bus.push_end()
+            self.bus.send_end()
         if self.role == "replay":
             if self._in_flight:
-                self.replay.commit(*self._actor_rows(self.bus.push_end()))
+                self.bus.recv_end()
+                self._commit_slab((self.step_count - 1) % 2)
             self._complete(self._works)
         if self.role == "learner":
             self._complete(self._works)  # (the batches received last are never trained on)

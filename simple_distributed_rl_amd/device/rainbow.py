@@ -310,7 +310,8 @@ class RainbowEngine:
             # the priority write-back leaves the update's critical path: it needs the head kernel's priorities only, so it is the FIRST launch of the backward pass's
             # weight-gradient branch (srlx_qnet_set_priority_sink; no new branch in the graph -- as a branch of its own it put the update on the actors' hardware queue:
             # tools/README.md findings 3, 5); the step count it used to advance moves to the update's LAST launch (the packing / publishing one).
-            self._update_side = self._fused_td
+            # (a learner whose batches are SERVED by a replay GPU -- device/replay_role.py -- has no tree to write into: its priorities leave in a message, behind the update)
+            self._update_side = self._fused_td and getattr(self.lreplay, "h_per", None) is not None
             if self.actor_stream is not None and want == "low":  # the actors cannot queue behind a branch of the update: it may run three wide
                 N.check(self.lib.srlx_qnet_set_fc1_branch(self.inf_online.h, 2))
             # (a learner-only rank: the first dense layer's weight gradient LAST on the weight-gradient branch, order 0 -- with the critical chain recorded first,

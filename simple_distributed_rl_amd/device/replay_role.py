@@ -59,7 +59,9 @@ class BatchCodec:
 class ServedBatch:
     """What `RainbowEngine._learner_body` asks of a replay, answered from one received message (learner rank)."""
 
-    def __init__(self, codec: BatchCodec, device: torch.device, train_count_dev: torch.Tensor):
+    lagged = False
+
+    def __init__(self, codec: BatchCodec, device: torch.device, train_count_dev: Optional[torch.Tensor] = None):
         c = self.codec = codec
         self.B = c.B
         self.stage = torch.zeros(c.nbytes, dtype=torch.uint8, device=device)  # fixed address: a captured update could read it
@@ -84,6 +86,16 @@ class ServedBatch:
     def is_warmup_needed(self) -> bool:
         return False
 
+    # ---- what RainbowEngine(role="learner", learner_replay=...) asks of its replay besides the batch ----
+    def count_updates_in(self, counter: torch.Tensor):
+        self._train_count_dev = counter  # (`update` advances it: the write-back is this replay's last word on an update)
+
+    def check_draws(self):
+        pass
+
+    def length(self) -> int:
+        return 0
+
 
 class ReplayRoleRainbow:
     def __init__(self, cfg, device: int, episode_len: int = 200, sync_interval: int = 16, prefetch: int = 5, updates: int = 1, env=None):
@@ -103,6 +115,7 @@ class ReplayRoleRainbow:
         F, W, n, B = H * W_, cfg.window_length, cfg.multisteps, cfg.batch_size
         self.codec = BatchCodec(B, n, W, F)
         self.step_count, self._in_flight, self.env_steps_local, self.served, self.trained = 0, False, 0, 0, 0
+        self._graphs = False
         self.weights_group = dist.new_group([LEARNER] + list(range(FIRST_ACTOR, self.world)))  # (every rank calls new_group)
         self.bus = TransitionBus(E, F, torch.uint8, self.dev, learner_rank=REPLAY, actor_ranks=range(FIRST_ACTOR, self.world), p2p=True)
         self.local = self.replay = None
@@ -110,13 +123,22 @@ class ReplayRoleRainbow:
             pad = n + W
             small = dataclasses.replace(cfg, memory_capacity=E * 4, memory_warmup_size=1 << 62, seed=cfg.seed + 1_000_003 * self.rank,
                                         n_envs=E if self.role == "actor" else 8)
-            self.local = RainbowEngine(small, device, episode_len, ring_len=pad + 4, env=env if self.role == "actor" else None, overlap=False)
+            if self.role == "learner":
+                # the fast learner (round 6): one captured update per served batch -- online | target pass, TD / Huber / priorities in the backward's head kernel, Adam
+                # inside the gradient launches -- on a replay that is a received message (`ServedBatch`); its priorities leave in the write-back message
+                self.served_batch = ServedBatch(self.codec, self.dev)
+                self.local = RainbowEngine(small, device, episode_len, ring_len=pad + 4, role="learner", learner_replay=self.served_batch, overlap=False)
+            else:
+                self.local = RainbowEngine(small, device, episode_len, ring_len=pad + 4, env=env, overlap=False)
             self.flat = flatten_parameters(self.local.q_online)
-            self.local.inf_actor.bind()
-            self.local.inf_online.bind()
+            for inf in (self.local.inf_actor, self.local.inf_online, self.local.inf_target):
+                if inf is not None and inf.net is self.local.q_online:
+                    inf.bind()
             if isinstance(self.local.optimizer, DeviceAdam):
                 self.local.optimizer.bind()
             self._broadcast_weights()
+            if self.local.fast:
+                self.local._publish_out_of_band()  # packed filters / operand planes of the parameters' new home
         if self.role == "replay":
             total = self.n_actor_ranks * E
             self.replay = DeviceReplay(total, -(-cfg.memory_capacity // total) + n + W, F, W, n, cfg.n_actions, B, True, cfg.enable_reward_clip, cfg.memory_alpha,
@@ -130,7 +152,6 @@ class ReplayRoleRainbow:
             self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)  # the learner's train count as far as this rank knows (beta schedule)
             self._works = []  # the group posted in the previous lock-step
         if self.role == "learner":
-            self.served_batch = ServedBatch(self.codec, self.dev, self.local.train_count_dev)
             xdev = "cpu" if self.staged else self.dev
             self._rx = []  # (serve lock-step, buffer) of received batches, in arrival order
             self._rx_bufs = [torch.zeros(self.codec.nbytes, dtype=torch.uint8, device=xdev) for _ in range((self.prefetch + 2) * self.updates)]
@@ -285,14 +306,10 @@ class ReplayRoleRainbow:
                     sb.stage.copy_(buf, non_blocking=True)
                     if self.check_headers:
                         assert int(c.view(sb.stage, "header", torch.int64)[0].item()) == 1, "a batch the schedule calls warm says it is not"
-                    saved, eng.replay = eng.replay, sb
-                    try:
-                        eng._learner_body()
-                    finally:
-                        eng.replay = saved
-                    if eng.train_count % self.cfg.target_model_update_interval == 0:
-                        eng.sync_target()
-                    eng.train_count += 1
+                    eng.run_updates(1)  # (target sync and the update count inside: RainbowEngine.learner_step)
+                    if not self._graphs and eng.fast:
+                        eng.enable_lazy_capture()  # from the second update on: one graph (the staging buffer's address is fixed)
+                        self._graphs = True
                     self.trained += 1
             sb.out[:8].view(torch.int64)[0] = 1 if valid else 0
             out.copy_(sb.out, non_blocking=not self.staged)

@@ -24,6 +24,8 @@ using i64 = int64_t;
 using u8 = unsigned char;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
 constexpr int kPad = 88, kFrame = kPad * kPad;     // staged frame side / bytes
 constexpr int kP1 = 21, kM1 = kP1 * kP1;           // conv1 output side / pixels
@@ -36,6 +38,14 @@ constexpr size_t kLdsF32 = 4 * kFrame + (size_t)kM1 * kS1 * 4 + (size_t)kM2 * kS
 //   [frames 31.0 KB | conv1's shared filter parts 32.1 KB] -> later act2 planes (121 x 400 B = 47.3 KB) | act1 planes 441 x 208 B = 89.6 KB
 // the K-quarter reductions park their partials in the act1 region once its readers are done.
 constexpr int kPB1 = 3 * 32 * 2 + 16, kPB2 = 3 * 64 * 2 + 16;
+// Round 6, the TWO-PART FLOAT16 SPLIT (H16; the default): x = hi + lo / 2048 with hi = f16(x), lo = f16((x - hi) * 2048) -- 22 significand bits (the residual is exact in
+// float32, and scaled by 2^11 it is a NORMAL f16 wherever hi is: nothing is lost to f16's short exponent range below |x| = 2^-14, where the absolute error is 2^-36) --
+// and x * w = hi * hi' + (hi * lo' + lo * hi') / 2048 with the lo * lo' term (<= 2^-24 |x w|) dropped: THREE exact products per 16 K instead of six, into two
+// accumulators (the unscaled and the 2^11-scaled sums, joined once per K quarter).  Error per product <= 3 * 2^-24: float32 round-off.  Two parts of two bytes = the
+// float32's own four bytes: pixel strides 144 / 272 bytes (odd multiples of 16).  Range: an activation above 65 504 would overflow hi; `srlx_qnet` refuses nothing
+// silently -- see the range flag in the epilogues.
+constexpr int kPB1h = 2 * 32 * 2 + 16, kPB2h = 2 * 64 * 2 + 16;
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 constexpr size_t kOffA1P = 4 * kFrame + (size_t)kM2 * kS2 * 4;
 constexpr size_t kLdsPlanes = kOffA1P + (size_t)kM1 * kPB1;
 constexpr size_t kLdsBytes = kLdsPlanes > kLdsF32 ? kLdsPlanes : kLdsF32;
@@ -73,6 +83,7 @@ struct SmallCopy {
     float *m[kSmallVecs], *v[kSmallVecs];
     double lr, beta1, beta2, eps;
     const long long *snap;
+    int h16;  // the matrix-pipe fragments as two float16 parts (the default) instead of three bf16 parts
 };
 __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ w3,
                                                       float *__restrict__ out, float *__restrict__ wT3, float *__restrict__ wT2, float *__restrict__ out2, SmallCopy sm) {
@@ -111,6 +122,22 @@ __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ 
         // mantissa bits; each remainder is exact in float32), the pixel operand is a uint8 and exact in ONE bf16, every partial product is exact in
         // the float32 accumulator.  Fragment of v_mfma_f32_32x32x16_bf16: lane (i, h) holds k = 16 step + 8 h + 0..7 of filter row i.
         const int idx = q - n4, lane = idx & 63, step = idx >> 6, i = lane & 31, hh = lane >> 5;
+        if (sm.h16) {  // w * 256 / 255 = hi + lo / 2048 (times 256: the parts of a small filter stay normal float16s; the kernel's epilogue divides)
+            f16x8 hp[2];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float r = w1[i * 256 + step * 16 + hh * 8 + j] * (1.0f / 255.0f) * 256.0f;
+                const _Float16 hi = (_Float16)r;
+                hp[0][j] = hi, hp[1][j] = (_Float16)((r - (float)hi) * kLoScale);
+            }
+            f16x8 *dst = reinterpret_cast<f16x8 *>(out + kW1 + kW2 + kW3), *d2 = out2 ? reinterpret_cast<f16x8 *>(out2 + kW1 + kW2 + kW3) : nullptr;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                dst[(step * 2 + t) * 64 + lane] = hp[t];
+                if (d2) d2[(step * 2 + t) * 64 + lane] = hp[t];
+            }
+            return;
+        }
         bf16x8 part[3];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -141,6 +168,23 @@ __global__ void __launch_bounds__(256) k_pack_filters(const float *__restrict__ 
         const int lane = idx & 63, nt = (idx >> 6) & 1, step = idx >> 7, i = lane & 31, hh = lane >> 5;
         const float *src = third ? w3 : w2;
         const int K = third ? 576 : 512;
+        if (sm.h16) {
+            f16x8 hp[2];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float r = src[(nt * 32 + i) * K + step * 16 + hh * 8 + j];
+                const _Float16 hi = (_Float16)r;
+                hp[0][j] = hi, hp[1][j] = (_Float16)((r - (float)hi) * kLoScale);
+            }
+            const size_t o = kW1 + kW2 + kW3 + kW1B + (third ? kW2B : 0);
+            f16x8 *dst = reinterpret_cast<f16x8 *>(out + o), *d2 = out2 ? reinterpret_cast<f16x8 *>(out2 + o) : nullptr;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                dst[((step * 2 + nt) * 2 + t) * 64 + lane] = hp[t];
+                if (d2) d2[((step * 2 + nt) * 2 + t) * 64 + lane] = hp[t];
+            }
+            return;
+        }
         bf16x8 part[3];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -242,10 +286,11 @@ __device__ __forceinline__ void tile_from_lds(const float *__restrict__ lds_in, 
 //   LAYER 2: 4 x 4 stride 2 pad 2 over act1 (21 x 21 x 32), K = 16 taps x 32 = 32 steps of 16;  LAYER 3: 3 x 3 stride 1 pad 1 over act2 (11 x 11 x 64), 36 steps
 // The MFMA operands are SWAPPED (filters as the A operand), so each accumulator tile comes out transposed -- rows = channels, columns = pixels: a lane
 // holds runs of four consecutive channels of ONE pixel, i.e. 8-byte pieces of the next layer's part planes (and float4s of the float32 tensors).
-template <int LAYER>
+template <int LAYER, bool H16>
 __device__ __forceinline__ void block_planes(const unsigned char *__restrict__ lds_in, const bf16x8 *__restrict__ wfrag, int blk, int kq, int lane, f32x16 (&acc)[2][2]) {
     constexpr int S = LAYER == 2 ? 32 : 36, SPT = LAYER == 2 ? 2 : 4, KW = LAYER == 2 ? 4 : 3, STR = LAYER == 2 ? 2 : 1, PAD = LAYER == 2 ? 2 : 1;
-    constexpr int IN = LAYER == 2 ? kP1 : kP2, PB = LAYER == 2 ? kPB1 : kPB2, CB = LAYER == 2 ? 64 : 128, QS = S / 4;
+    constexpr int IN = LAYER == 2 ? kP1 : kP2, PB = LAYER == 2 ? (H16 ? kPB1h : kPB1) : (H16 ? kPB2h : kPB2), CB = LAYER == 2 ? 64 : 128, QS = S / 4;
+    constexpr int NP = H16 ? 2 : 3;  // parts per value
     const int i = lane & 31, h = lane >> 5;
     int oy[2], ox[2];
 #pragma unroll
@@ -253,50 +298,76 @@ __device__ __forceinline__ void block_planes(const unsigned char *__restrict__ l
         const int m = (2 * blk + a) * 32 + i < kM2 ? (2 * blk + a) * 32 + i : kM2 - 1;
         oy[a] = m / kP2, ox[a] = m % kP2;
     }
+    f32x16 lo[H16 ? 2 : 1][H16 ? 2 : 1];  // H16: the 2^11-scaled sums (hi * lo' + lo * hi')
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][n][r] = 0.f;
-    bf16x8 fa0[2][3], fa1[2][3];  // [pixel tile][part]
-    bf16x8 fb0[2][3], fb1[2][3];  // [channel tile][part]
-    auto load = [&](int sl, bf16x8(&fa)[2][3], bf16x8(&fb)[2][3]) __attribute__((always_inline)) {
+            for (int r = 0; r < 16; r++) {
+                acc[a][n][r] = 0.f;
+                if constexpr (H16) lo[a][n][r] = 0.f;
+            }
+    bf16x8 fa0[2][NP], fa1[2][NP];  // [pixel tile][part]  (H16: sixteen bytes of f16 in the same carrier type)
+    bf16x8 fb0[2][NP], fb1[2][NP];  // [channel tile][part]
+    auto load = [&](int sl, bf16x8(&fa)[2][NP], bf16x8(&fb)[2][NP]) __attribute__((always_inline)) {
         // which K steps a quarter owns: conv2 -- kernel row kq (8 consecutive steps); conv3 -- the 16-channel group kq of every tap, so that the tap of
         // step sl is a compile-time constant and the clamped pixel address costs a handful of instructions (a quarter of consecutive steps: 355 VALU per pass)
         const int sp = LAYER == 2 ? kq * QS + sl : sl * SPT + kq, tap = LAYER == 2 ? sp / SPT : sl, cg = LAYER == 2 ? sp % SPT : kq, ky = tap / KW, kx = tap % KW;
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int q = 0; q < 3; q++) fb[n][q] = wfrag[((sp * 2 + n) * 3 + q) * 64 + lane];  // filters: L2 -> registers (the long latency first)
+            for (int q = 0; q < NP; q++) fb[n][q] = wfrag[((sp * 2 + n) * NP + q) * 64 + lane];  // filters: L2 -> registers (the long latency first)
 #pragma unroll
         for (int a = 0; a < 2; a++) {
             const int iy = clampi(oy[a] * STR + ky - PAD, 0, IN - 1), ix = clampi(ox[a] * STR + kx - PAD, 0, IN - 1);
             const unsigned char *pa = lds_in + (iy * IN + ix) * PB + cg * 32 + 16 * h;
 #pragma unroll
-            for (int q = 0; q < 3; q++) fa[a][q] = *reinterpret_cast<const bf16x8 *>(pa + q * CB);
+            for (int q = 0; q < NP; q++) fa[a][q] = *reinterpret_cast<const bf16x8 *>(pa + q * CB);
         }
     };
-    auto mfma24 = [&](const bf16x8(&fa)[2][3], const bf16x8(&fb)[2][3]) __attribute__((always_inline)) {
-        constexpr int pq[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};  // smallest partial products first
+    auto mfma_step = [&](const bf16x8(&fa)[2][NP], const bf16x8(&fb)[2][NP]) __attribute__((always_inline)) {
+        if constexpr (H16) {
+            constexpr int pq[3][2] = {{1, 0}, {0, 1}, {0, 0}};  // (activation part, filter part): the two cross terms into `lo`, hi * hi' into `acc`
 #pragma unroll
-        for (int c = 0; c < 6; c++)
+            for (int c = 0; c < 3; c++)
 #pragma unroll
-            for (int a = 0; a < 2; a++)
+                for (int a = 0; a < 2; a++)
 #pragma unroll
-                for (int n = 0; n < 2; n++) acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][pq[c][1]], fa[a][pq[c][0]], acc[a][n], 0, 0, 0);
+                    for (int n = 0; n < 2; n++) {
+                        f32x16 &d = c < 2 ? lo[a][n] : acc[a][n];
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[n][pq[c][1]]), __builtin_bit_cast(f16x8, fa[a][pq[c][0]]), d, 0, 0, 0);
+                    }
+        } else {
+            constexpr int pq[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};  // smallest partial products first
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int n = 0; n < 2; n++)
+                        acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n][pq[c][1]], fa[a][pq[c][0]], acc[a][n], 0, 0, 0);
+        }
     };
     load(0, fa0, fb0);
 #pragma unroll
     for (int sl = 0; sl < QS; sl += 2) {
         if (sl + 1 < QS) load(sl + 1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        mfma24(fa0, fb0);
+        mfma_step(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         if (sl + 2 < QS) load(sl + 2, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        if (sl + 1 < QS) mfma24(fa1, fb1);
+        if (sl + 1 < QS) mfma_step(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (H16) {  // this K quarter's sum = the unscaled part + the scaled part / 2048
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][n][r] = __builtin_fmaf(lo[a][n][r], kLoInv, acc[a][n][r]);
     }
 }
 
@@ -317,6 +388,17 @@ __device__ __forceinline__ void split3(const float4 &x, bf16x4 (&part)[3]) {
             part[p][e] = q;
             v[e] -= (float)q;
         }
+}
+
+// the two-part float16 split of four values: hi = f16(x), lo = f16((x - hi) * 2048)
+__device__ __forceinline__ void split2(const float4 &x, f16x4 (&part)[2]) {
+    const float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const _Float16 hi = (_Float16)v[e];
+        part[0][e] = hi;
+        part[1][e] = (_Float16)((v[e] - (float)hi) * kLoScale);
+    }
 }
 
 // Sums the four K-quarter partial blocks of every output tile through `scratch` (96 KB of LDS nobody else uses meanwhile).  Wave (blk, kq) ends up
@@ -363,13 +445,15 @@ __device__ __forceinline__ f32x16 reduce_quarters(float *__restrict__ scratch, i
 // layer's GEMM reads -- [K/32 slabs][batch rows][4 k-groups][3 parts][8 bf16], K = pixel * 64 + channel -- instead of float32; `act3` then points at them.
 // PLANES = 2 (round 4, the learner's passes): BOTH -- float32 act3 for the backward pass and the planes (at `planes_out`, `plane_rows` rows per K-slab: the launch's
 // rows rounded up to the GEMM's 128-row tile) for the first dense layer.
-template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0>
+template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0, bool H16 = false>
 __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                    const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3, float *__restrict__ act3,
                                                    float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg,
                                                    unsigned char *__restrict__ planes_out, long long plane_rows, long long n_samples, i64 b, bool stamp_wg) {
     static_assert(!PLANES || C23B16, "operand planes come out of the split-bf16 conv3 only");
     static_assert(!C23B16 || C1B16, "the split-bf16 conv2 / conv3 read the part planes conv1's split-bf16 epilogue writes");
+    static_assert(!H16 || C23B16, "the float16 split is a variant of the part-plane kernel");
+    constexpr int PB1 = H16 ? kPB1h : kPB1, PB2 = H16 ? kPB2h : kPB2;
     constexpr bool PL = C23B16;  // act1 / act2 as bf16 part planes in LDS (kPB1 / kPB2 bytes per pixel) instead of float32
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u8 *fr = smem;                                                 // [4][88][88]
@@ -391,16 +475,18 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
     //      once per lane and dword -- the address arithmetic used to be 1000 VALU instructions per wave (8 k of the kernel's 70 k clocks per sample:
     //      vector instructions take their issue slots from the matrix pipe on gfx950); (row, dword) advance by 512 = 23 x 22 + 6 per j.
     // conv1's filter fragments do not depend on the sample: requested first, they travel during the frame-offset round trip (see the conv1 section)
-    bf16x8 bw2[C1B16 ? 16 : 1], wtmp[C1B16 ? 4 : 1];
+    bf16x8 bw2[C1B16 && !H16 ? 16 : 1], wtmp[C1B16 ? 4 : 1];
     if constexpr (C1B16) {
         const bf16x8 *wsrc = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int e = t + NT * j, l = e & 63, sp2 = e >> 6;  // sp2 = step * 2 + part
-            wtmp[j] = wsrc[((sp2 >> 1) * 3 + (sp2 & 1)) * 64 + l];
+            wtmp[j] = H16 ? wsrc[e] : wsrc[((sp2 >> 1) * 3 + (sp2 & 1)) * 64 + l];  // (H16: [step][2 parts][lane], both parts go to LDS)
         }
+        if constexpr (!H16) {
 #pragma unroll
-        for (int sp = 0; sp < 16; sp++) bw2[sp] = wsrc[(sp * 3 + 2) * 64 + lane];
+            for (int sp = 0; sp < 16; sp++) bw2[sp] = wsrc[(sp * 3 + 2) * 64 + lane];
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     {
@@ -460,9 +546,9 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
             const int m = tile * 32 + i < kM1 ? tile * 32 + i : kM1 - 1;
             const int oy = m / kP1, ox = m % kP1;
             const u8 *win = fr + (4 * oy + h) * kPad + 4 * ox;
-            f32x16 acc;
+            f32x16 acc, acl;  // (H16: acl = the 2^11-scaled sum of pixel * filter lo part)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            for (int r = 0; r < 16; r++) acc[r] = 0.f, acl[r] = 0.f;
             struct Step {
                 unsigned x, y;   // the lane's 8 pixels
                 bf16x8 f0, f1;   // filter parts 0 / 1 of the step (LDS)
@@ -475,6 +561,17 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
                 w.f1 = wl[(sp * 2 + 1) * 64 + lane];
             };
             auto mfma3 = [&](int sp, const Step &w) __attribute__((always_inline)) {
+                if constexpr (H16) {  // the pixel is exact in ONE f16 as well; filter * 256 / 255 = hi + lo / 2048: two products per step
+                    // a pixel byte n zero-extended to sixteen bits IS the float16 denormal n * 2^-24, and the matrix pipe keeps denormal inputs (tools/mfma_f16_denorm.hip):
+                    // one v_perm_b32 per two pixels instead of two conversions per pixel; the epilogue's scale carries the 2^24
+                    const unsigned pk[4] = {__builtin_amdgcn_perm(0u, w.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, w.x, 0x0c030c02u),
+                                            __builtin_amdgcn_perm(0u, w.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, w.y, 0x0c030c02u)};
+                    f16x8 a;
+                    __builtin_memcpy(&a, pk, 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.f0), a, acc, 0, 0, 0);
+                    acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.f1), a, acl, 0, 0, 0);
+                    return;
+                }
                 bf16x8 a;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -507,15 +604,26 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
                 // transposed C/D layout: col = lane & 31 = pixel, row = (r & 3) + 8 (r >> 2) + 4 h = channel: four consecutive channels of one pixel per quarter
                 // g = r >> 2 -> bias, ReLU, the exact three-way bf16 split ONCE per activation, 8-byte pieces of the pixel's three part planes
                 const int mm = tile * 32 + i;
+                if constexpr (H16) {  // filters packed times 2^8 (their f16 parts stay normal), pixels times 2^-24: sum = (acc + acl / 2048) * 2^16, every factor a power of two
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = __builtin_fmaf(acl[r], 32.0f, acc[r] * 65536.0f);
+                }
                 if (mm < kM1) {
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const float4 v = bias_relu4(acc, g, bias4[g]);
                         if (act1_out) *reinterpret_cast<float4 *>(act1_out + (b * kM1 + mm) * 32 + 8 * g + 4 * h) = v;
-                        bf16x4 part[3];
-                        split3(v, part);
+                        if constexpr (H16) {
+                            f16x4 part[2];
+                            split2(v, part);
 #pragma unroll
-                        for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(a1p + mm * kPB1 + q * 64 + (8 * g + 4 * h) * 2) = part[q];
+                            for (int q = 0; q < 2; q++) *reinterpret_cast<f16x4 *>(a1p + mm * PB1 + q * 64 + (8 * g + 4 * h) * 2) = part[q];
+                        } else {
+                            bf16x4 part[3];
+                            split3(v, part);
+#pragma unroll
+                            for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(a1p + mm * kPB1 + q * 64 + (8 * g + 4 * h) * 2) = part[q];
+                        }
                     }
                 }
             } else {
@@ -618,11 +726,11 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
         const int blk = wave & 1, kq = wave >> 1;  // 64 x 64 output block (pixel tiles 2 blk, 2 blk + 1; both channel tiles) x K quarter
         f32x16 acc4[2][2];
         // the K-quarter partials park in the 96 KB behind the act2 planes: act1 (and the tail of conv1's filter region) is dead once conv2's block loops are done
-        constexpr size_t kOffScratch = ((size_t)kM2 * kPB2 + 1023) / 1024 * 1024;
+        constexpr size_t kOffScratch = ((size_t)kM2 * PB2 + 1023) / 1024 * 1024;
         static_assert(kOffScratch + kScratchBytes <= kLdsBytes, "reduction scratch");
         float *scratch = reinterpret_cast<float *>(smem + kOffScratch);
         const bf16x8 *wf2 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B), *wf3 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B + kW2B);
-        block_planes<2>(a1p, wf2, blk, kq, lane, acc4);
+        block_planes<2, H16>(a1p, wf2, blk, kq, lane, acc4);
         stamp(5);
         __syncthreads();  // every wave has read its last act1 fragment
         const int mt = 2 * blk + (kq >> 1), nt = kq & 1;  // the tile this wave owns after the reduction: channels nt * 32 + 8 g + 4 h + e of pixel mt * 32 + i
@@ -634,22 +742,35 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
                 for (int g = 0; g < 4; g++) {
                     const float4 v = bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b2 + nt * 32 + 8 * g + 4 * h));
                     if (act2_out) *reinterpret_cast<float4 *>(act2_out + (b * kM2 + pix) * 64 + nt * 32 + 8 * g + 4 * h) = v;
-                    bf16x4 part[3];
-                    split3(v, part);
+                    if constexpr (H16) {
+                        f16x4 part[2];
+                        split2(v, part);
 #pragma unroll
-                    for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(a2p + pix * kPB2 + q * 128 + (nt * 32 + 8 * g + 4 * h) * 2) = part[q];
+                        for (int q = 0; q < 2; q++) *reinterpret_cast<f16x4 *>(a2p + pix * PB2 + q * 128 + (nt * 32 + 8 * g + 4 * h) * 2) = part[q];
+                    } else {
+                        bf16x4 part[3];
+                        split3(v, part);
+#pragma unroll
+                        for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(a2p + pix * kPB2 + q * 128 + (nt * 32 + 8 * g + 4 * h) * 2) = part[q];
+                    }
                 }
             }
         }
         __syncthreads();  // act2 is complete
         stamp(6);
-        block_planes<3>(a2p, wf3, blk, kq, lane, acc4);
+        block_planes<3, H16>(a2p, wf3, blk, kq, lane, acc4);
         const f32x16 sum = reduce_quarters(scratch, blk, kq, lane, acc4);
-        if (pix < kM2) {
-            if constexpr (PLANES != 0) {
-                // k-group g of K-slab (pixel * 2 + nt) = channels nt * 32 + 8 g .. + 7: this lane's four are the 8-byte half h of a 16-byte chunk per (g, part)
-                const i64 rows = PLANES == 2 ? (i64)plane_rows : (i64)n_samples;
-                unsigned char *dst = (PLANES == 2 ? planes_out : reinterpret_cast<unsigned char *>(act3)) + (((i64)(pix * 2 + nt) * rows + b) * 4) * 48 + h * 8;
+        if constexpr (PLANES != 0) {
+            // The operand planes of one sample are 242 chunks of 192 bytes (K-slab = (pixel, channel half): [4 k-groups][3 parts][8 bf16]) at a stride of rows * 192 bytes.
+            // Written from the accumulator layout they were 8-byte pieces, every lane of a store instruction in a line of its own: 12 instructions x 64 lines per wave,
+            // ~6 k clocks of the CU's store path per sample (a seventh of the kernel).  Now the tile's parts are parked in LDS ([channel half][k-group][part][pixel] x 16
+            // bytes: conflict-free for the writers; 129-pixel stride: at most three-way conflicts for the readers) and leave as 16-byte pieces, twelve consecutive lanes
+            // per chunk: 2 lines per chunk instead of 24 line visits.
+            constexpr int kStg = 129 * 16;
+            static_assert(24 * kStg <= kOffScratch + kScratchBytes, "plane staging");
+            unsigned char *stg = smem;
+            __syncthreads();  // every owner has read its partial sums: the scratch (and the act2 planes in front of it) may be overwritten
+            if (pix < kM2) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const float4 v = bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b3 + nt * 32 + 8 * g + 4 * h));
@@ -657,14 +778,28 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
                     bf16x4 part[3];
                     split3(v, part);
 #pragma unroll
-                    for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(dst + g * 48 + q * 16) = part[q];
+                    for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(stg + ((nt * 4 + g) * 3 + q) * kStg + pix * 16 + h * 8) = part[q];
                 }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    *reinterpret_cast<float4 *>(act3 + (b * kM2 + pix) * 64 + nt * 32 + 8 * g + 4 * h) =
-                        bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b3 + nt * 32 + 8 * g + 4 * h));
             }
+            __syncthreads();
+            // chunk piece c = slab * 12 + (k-group * 3 + part), slab = pixel * 2 + channel half: destination ((slab * rows + b) * 4 + k-group) * 48 + part * 16
+            const i64 rows = PLANES == 2 ? (i64)plane_rows : (i64)n_samples;
+            unsigned char *dst = (PLANES == 2 ? planes_out : reinterpret_cast<unsigned char *>(act3)) + b * 192;
+            constexpr int kPieces = 2 * kM2 * 12;
+#pragma unroll
+            for (int k = 0; k < (kPieces + NT - 1) / NT; k++) {
+                const int c = t + NT * k;
+                if (c < kPieces) {
+                    const int sl = c / 12, w = c - sl * 12;
+                    const uint4 val = *reinterpret_cast<const uint4 *>(stg + ((sl & 1) * 12 + w) * kStg + (sl >> 1) * 16);
+                    *reinterpret_cast<uint4 *>(dst + (i64)sl * rows * 192 + w * 16) = val;
+                }
+            }
+        } else if (pix < kM2) {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                *reinterpret_cast<float4 *>(act3 + (b * kM2 + pix) * 64 + nt * 32 + 8 * g + 4 * h) =
+                    bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b3 + nt * 32 + 8 * g + 4 * h));
         }
     } else {
         const int mt = wave >> 1, nt = wave & 1;  // conv2 / conv3: one 32 x 32 output tile per wave
@@ -715,7 +850,7 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
     stamp(7);
 }
 
-template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0>
+template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0, bool H16 = false>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3,
                                                                 float *__restrict__ act3,
@@ -723,7 +858,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
                                                                 unsigned char *__restrict__ planes_out = nullptr, long long plane_rows = 0, long long n_samples = 0,
                                                                 long long first_sample = 0) {
     // (a chip-filling pass may come as several launches of consecutive samples: first_sample)
-    convnet_fused_body<BIG, C1B16, C23B16, PLANES>(base, frame_off, wpk, b1, b2, b3, act3, act1_out, act2_out, dbg, planes_out, plane_rows, n_samples,
+    convnet_fused_body<BIG, C1B16, C23B16, PLANES, H16>(base, frame_off, wpk, b1, b2, b3, act3, act1_out, act2_out, dbg, planes_out, plane_rows, n_samples,
                                                    (i64)blockIdx.x + first_sample, blockIdx.x == 0);
 }
 
@@ -736,14 +871,23 @@ struct MultiNets {
     const float *wpk[kMultiMax], *b1[kMultiMax], *b2[kMultiMax], *b3[kMultiMax];
     float *act3[kMultiMax];
 };
+template <bool H16>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused_multi(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, MultiNets nets, long long n_samples) {
     const int net = (int)(blockIdx.x / (unsigned)n_samples);
     const i64 b = (i64)(blockIdx.x % (unsigned)n_samples);
-    convnet_fused_body<true, true, true, 1>(base, frame_off, nets.wpk[net], nets.b1[net], nets.b2[net], nets.b3[net], nets.act3[net], nullptr, nullptr, nullptr, nullptr, 0,
+    convnet_fused_body<true, true, true, 1, H16>(base, frame_off, nets.wpk[net], nets.b1[net], nets.b2[net], nets.b3[net], nets.act3[net], nullptr, nullptr, nullptr, nullptr, 0,
                                             n_samples, b, false);
 }
 
 }  // namespace
+
+// SRLX_CONV_BF16X3=1: the convolutions' matrix-pipe products as six of the nine products of three bf16 parts (rounds 3-5) instead of three products of two float16
+// parts (A/B switch, and the path for networks whose activations leave float16's range); read once per process
+bool srlx_conv_h16() {
+    static const bool bf16x3 = (getenv("SRLX_CONV_BF16X3") && getenv("SRLX_CONV_BF16X3")[0] == '1') ||
+                               (getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1');  // (that A/B variant's conv1 reads the bf16 fragments)
+    return !bf16x3;
+}
 
 size_t srlx_qnet_pack_bytes() { return (size_t)kPackFloats * sizeof(float); }
 
@@ -757,6 +901,7 @@ int srlx_qnet_pack_publish(srlx_qnet *src, srlx_qnet::ActorSet *dst_set, const s
     const float *w1 = b ? b[0] : src->w1, *w2 = b ? b[2] : src->w2, *w3 = b ? b[4] : src->w3;
     int pack_threads = (kW1 + kW2 + kW3) / 4 + 16 * 64 + (32 + 36) * 2 * 64 + (keep ? kW3 + kW2 : 0);
     SmallCopy sm{};
+    sm.h16 = srlx_conv_h16() ? 1 : 0;
     sm.bump = (long long *)bump;
     const bool adam = adam_small && src->rest_on && src->rest_armed;
     srlx_small_layout own_layout;
@@ -795,6 +940,8 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     if (!attr_set) {
         const void *kerns[] = {(const void *)k_convnet_fused<true, true, true, 1>, (const void *)k_convnet_fused<false, true, true, 2>,
                                (const void *)k_convnet_fused<true, true, true>,  (const void *)k_convnet_fused<false, true, true>,
+                               (const void *)k_convnet_fused<true, true, true, 1, true>, (const void *)k_convnet_fused<false, true, true, 2, true>,
+                               (const void *)k_convnet_fused<true, true, true, 0, true>,  (const void *)k_convnet_fused<false, true, true, 0, true>,
                                (const void *)k_convnet_fused<true, true, false>, (const void *)k_convnet_fused<false, true, false>,
                                (const void *)k_convnet_fused<true, false, false>, (const void *)k_convnet_fused<false, false, false>};
         for (const void *kp : kerns)
@@ -816,6 +963,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
                            keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch, 0ll);
     };
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
+    const bool h16 = srlx_conv_h16();
     if (h->probe0 && hipEventRecord(h->probe0, st) != hipSuccess) return false;  // measurement hook: exactly this kernel, on its launch stream
     // the dense layers will run on operand planes (srlx_qnet_dense_rows's own condition): conv3 writes them itself, float32 act3 is not produced
     static const bool no_planes_out = (getenv("SRLX_NO_CONV_PLANES") && getenv("SRLX_NO_CONV_PLANES")[0] == '1') ||  // A/B switch: float32 act3 + a split pass
@@ -823,20 +971,23 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     h->a3_planes_fresh = false;
     if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && !keep && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch) && batch >= 512) {
         out3 = reinterpret_cast<float *>(h->a3_planes);
-        launch(k_convnet_fused<true, true, true, 1>);
+        h16 ? launch(k_convnet_fused<true, true, true, 1, true>) : launch(k_convnet_fused<true, true, true, 1>);
         h->a3_planes_fresh = true;
     } else if (h->want_planes_out && !no_planes_out && !c1_f32 && !c23_f32 && h->planes_valid && !h->eff[0] && srlx_fc1_planes_applicable(h, batch)) {
         // a learner's pass (96 / 128 rows; `planes_small`): float32 act3 for its backward pass AND the planes for the first dense layer, rows padded to the GEMM's tile
         const long long prow = (batch + 127) / 128 * 128;
-        hipLaunchKernelGGL((k_convnet_fused<false, true, true, 2>), dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2,
-                           h->b3, out3, keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)h->a3_planes, prow,
-                           (long long)batch);
+        auto launch2 = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
+                               keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)h->a3_planes, prow, (long long)batch, 0ll);
+        };
+        h16 ? launch2(k_convnet_fused<false, true, true, 2, true>) : launch2(k_convnet_fused<false, true, true, 2>);
         h->a3_planes_fresh = true;
     } else if (batch >= 512)
         c1_f32 ? launch(k_convnet_fused<true, false, false>) : c23_f32 ? launch(k_convnet_fused<true, true, false>)
-               : launch(k_convnet_fused<true, true, true>);
+               : h16 ? launch(k_convnet_fused<true, true, true, 0, true>) : launch(k_convnet_fused<true, true, true>);
     else
-        c1_f32 ? launch(k_convnet_fused<false, false, false>) : c23_f32 ? launch(k_convnet_fused<false, true, false>) : launch(k_convnet_fused<false, true, true>);
+        c1_f32 ? launch(k_convnet_fused<false, false, false>) : c23_f32 ? launch(k_convnet_fused<false, true, false>)
+               : h16 ? launch(k_convnet_fused<false, true, true, 0, true>) : launch(k_convnet_fused<false, true, true>);
     if (h->probe1 && hipEventRecord(h->probe1, st) != hipSuccess) return false;
     if (h->stamp_buf && srlx_debug_stamp(h->stamp_buf, 10, st) != SRLX_OK) return false;  // (measurement aid: the convolution launch of a forward pass is done)
     return hipGetLastError() == hipSuccess;
@@ -848,7 +999,8 @@ int srlx_qnet_fused_convs_multi(srlx_qnet *const *hs, int n, int64_t batch, cons
     SRLX_REQUIRE(n >= 1 && n <= kMultiMax && batch >= 512, "qnet_forward_convs_multi: 1..%d handles, chip-filling batches", kMultiMax);
     static bool attr_set = false;
     if (!attr_set) {
-        SRLX_HIP(hipFuncSetAttribute((const void *)k_convnet_fused_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        SRLX_HIP(hipFuncSetAttribute((const void *)k_convnet_fused_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        SRLX_HIP(hipFuncSetAttribute((const void *)k_convnet_fused_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
         attr_set = true;
     }
     MultiNets nets{};
@@ -865,7 +1017,10 @@ int srlx_qnet_fused_convs_multi(srlx_qnet *const *hs, int n, int64_t batch, cons
         nets.wpk[k] = h->wpack, nets.b1[k] = h->b1, nets.b2[k] = h->b2, nets.b3[k] = h->b3, nets.act3[k] = reinterpret_cast<float *>(h->a3_planes);
     }
     if (hs[0]->probe0) SRLX_HIP(hipEventRecord(hs[0]->probe0, st));
-    hipLaunchKernelGGL(k_convnet_fused_multi, dim3((unsigned)(n * batch)), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, nets, (long long)batch);
+    if (srlx_conv_h16())
+        hipLaunchKernelGGL(k_convnet_fused_multi<true>, dim3((unsigned)(n * batch)), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, nets, (long long)batch);
+    else
+        hipLaunchKernelGGL(k_convnet_fused_multi<false>, dim3((unsigned)(n * batch)), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, nets, (long long)batch);
     if (hs[0]->probe1) SRLX_HIP(hipEventRecord(hs[0]->probe1, st));
     hs[0]->probe0 = hs[0]->probe1 = nullptr;
     for (int k = 0; k < n; k++) hs[k]->a3_planes_fresh = true, hs[k]->want_planes_out = true;

@@ -167,6 +167,7 @@ int srlx_qnet_noisy_sigma_grads(srlx_qnet *h, float *const *g, hipStream_t st);
 int srlx_qnet_dense_rows(srlx_qnet *h, int64_t rows, int64_t stride, float *d_q, hipStream_t st);
 
 // srlx_qnet_fused.hip: conv1 -> conv2 -> conv3 in one kernel (activations in LDS); false when the geometry is not the Atari one
+bool srlx_conv_h16();  // the convolutions' split: two float16 parts (default) or three bf16 parts (SRLX_CONV_BF16X3=1)
 bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st);
 
 int srlx_qnet_fused_convs_multi(srlx_qnet *const *hs, int n, int64_t batch, const uint8_t *d_frame_base, const int64_t *d_frame_off, hipStream_t st);

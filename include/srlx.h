@@ -672,6 +672,11 @@ int srlx_qnet_set_side_stream(srlx_qnet_t *h, void *stream);
 /* measurement aid: d_phase_stamps = device uint64 [8 waves][8] (or NULL to switch off): the fused convolution kernel's workgroup 0
  * records its shader clock at the phase boundaries (start, frames issued, staged, conv1 done, barrier, conv2 done, barrier, end) */
 int srlx_qnet_set_debug(srlx_qnet_t *h, void *d_phase_stamps);
+/* Round 6: the fused convolution kernel evaluates its float32 products as three exact products of two float16 parts per operand (x = hi + lo / 2048).  An
+ * activation above 65 504 does not fit; the kernel then sets bit (layer - 1) of a device word of the handle instead of failing silently.  *out_bits = that word
+ * (blocking device-to-host copy: call where the host has synchronised; the host side raises, device/qnet.py:check_ranges).  SRLX_CONV_BF16X3=1 selects the
+ * three-part bf16 split of rounds 3-5, whose range is float32's. */
+int srlx_qnet_range_flags(srlx_qnet_t *h, int *out_bits);
 /* Training on the vectorised path (replaces `loss.backward()` + the framework forward it needs,
  * srl/algorithms/rainbow/model_torch.py:103-109):
  *   srlx_qnet_enable_training : from now on every forward keeps its post-ReLU hidden layer, and gradient scratch for up

@@ -130,6 +130,7 @@ SIGNATURES = {
     "srlx_qnet_refresh_fc1_planes": (c_int, [c_p, c_p, c_p, c_p]),
     "srlx_qnet_invalidate_fc1_planes": (c_int, [c_p]),
     "srlx_qnet_set_debug": (c_int, [c_p, c_p]),
+    "srlx_qnet_range_flags": (c_int, [c_p, c_p]),
     "srlx_qnet_set_side_stream": (c_int, [c_p, c_p]),
     "srlx_qnet_fuse_adam_fc1": (c_int, [c_p, c_p, c_p, c_f64, c_f64, c_f64, c_f64, c_p]),
     "srlx_qnet_fuse_adam_rest": (c_int, [c_p, c_p, c_p, c_p]),

@@ -946,7 +946,21 @@ int srlx_qnet_create(srlx_qnet_t **out, int in_h, int in_w, int window, int filt
             return e == hipErrorOutOfMemory ? SRLX_ERR_NOMEM : SRLX_ERR_HIP;
         }
     }
+    if (hipMalloc((void **)&h->range_flag, sizeof(int)) != hipSuccess || hipMemset(h->range_flag, 0, sizeof(int)) != hipSuccess) {
+        srlx::set_error("qnet_create: the range flag");
+        srlx_qnet_destroy(h);
+        return SRLX_ERR_HIP;
+    }
     *out = h;
+    return SRLX_OK;
+}
+
+// Bit l of *out: an activation of convolution l + 1 exceeded 65 504 in some forward pass since the handle was created -- the two-part float16 split of the fused
+// convolution kernel cannot hold it (its result is then meaningless: run the process with SRLX_CONV_BF16X3=1).  Blocking copy: call where the host has synchronised.
+int srlx_qnet_range_flags(srlx_qnet_t *h, int *out) {
+    SRLX_REQUIRE(h && out, "qnet_range_flags: NULL argument");
+    srlx::DeviceGuard guard(h->device);
+    SRLX_HIP(hipMemcpy(out, h->range_flag, sizeof(int), hipMemcpyDeviceToHost));
     return SRLX_OK;
 }
 
@@ -959,6 +973,7 @@ int srlx_qnet_destroy(srlx_qnet_t *h) {
         if (p) (void)hipFree(p);
     for (float *p : h->eff)
         if (p) (void)hipFree(p);
+    if (h->range_flag) (void)hipFree(h->range_flag);
     if (h->c1_gpart) (void)hipFree(h->c1_gpart);
     if (h->c1_cnt) (void)hipFree(h->c1_cnt);
     if (h->d_draw) (void)hipFree(h->d_draw);

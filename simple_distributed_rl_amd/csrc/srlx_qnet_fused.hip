@@ -42,8 +42,8 @@ constexpr int kPB1 = 3 * 32 * 2 + 16, kPB2 = 3 * 64 * 2 + 16;
 // float32, and scaled by 2^11 it is a NORMAL f16 wherever hi is: nothing is lost to f16's short exponent range below |x| = 2^-14, where the absolute error is 2^-36) --
 // and x * w = hi * hi' + (hi * lo' + lo * hi') / 2048 with the lo * lo' term (<= 2^-24 |x w|) dropped: THREE exact products per 16 K instead of six, into two
 // accumulators (the unscaled and the 2^11-scaled sums, joined once per K quarter).  Error per product <= 3 * 2^-24: float32 round-off.  Two parts of two bytes = the
-// float32's own four bytes: pixel strides 144 / 272 bytes (odd multiples of 16).  Range: an activation above 65 504 would overflow hi; `srlx_qnet` refuses nothing
-// silently -- see the range flag in the epilogues.
+// float32's own four bytes: pixel strides 144 / 272 bytes (odd multiples of 16).  Range: an activation above 65 504 would overflow hi; the epilogues
+// then set a bit of the handle's range word (srlx_qnet_range_flags; the host side raises where it synchronises anyway) -- SRLX_CONV_BF16X3=1 is the path for such a network.
 constexpr int kPB1h = 2 * 32 * 2 + 16, kPB2h = 2 * 64 * 2 + 16;
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 constexpr size_t kOffA1P = 4 * kFrame + (size_t)kM2 * kS2 * 4;
@@ -449,7 +449,8 @@ template <bool BIG, bool C1B16, bool C23B16, int PLANES = 0, bool H16 = false>
 __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, const float *__restrict__ wpk,
                                                    const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ b3, float *__restrict__ act3,
                                                    float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg,
-                                                   unsigned char *__restrict__ planes_out, long long plane_rows, long long n_samples, i64 b, bool stamp_wg) {
+                                                   unsigned char *__restrict__ planes_out, long long plane_rows, long long n_samples, i64 b, bool stamp_wg,
+                                                   int *__restrict__ range_flag) {
     static_assert(!PLANES || C23B16, "operand planes come out of the split-bf16 conv3 only");
     static_assert(!C23B16 || C1B16, "the split-bf16 conv2 / conv3 read the part planes conv1's split-bf16 epilogue writes");
     static_assert(!H16 || C23B16, "the float16 split is a variant of the part-plane kernel");
@@ -609,11 +610,13 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
                     for (int r = 0; r < 16; r++) acc[r] = __builtin_fmaf(acl[r], 32.0f, acc[r] * 65536.0f);
                 }
                 if (mm < kM1) {
+                    float top = 0.f;
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const float4 v = bias_relu4(acc, g, bias4[g]);
                         if (act1_out) *reinterpret_cast<float4 *>(act1_out + (b * kM1 + mm) * 32 + 8 * g + 4 * h) = v;
                         if constexpr (H16) {
+                            top = fmaxf(fmaxf(top, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
                             f16x4 part[2];
                             split2(v, part);
 #pragma unroll
@@ -625,6 +628,7 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
                             for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(a1p + mm * kPB1 + q * 64 + (8 * g + 4 * h) * 2) = part[q];
                         }
                     }
+                    if (H16 && !(top <= 65504.0f)) atomicOr(range_flag, 1);  // outside float16: loud on the host side (srlx_qnet_range_flags), never silent
                 }
             } else {
                 // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 h (pixel)
@@ -738,11 +742,13 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
         {
             const f32x16 sum = reduce_quarters(scratch, blk, kq, lane, acc4);
             if (pix < kM2) {
+                float top = 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const float4 v = bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b2 + nt * 32 + 8 * g + 4 * h));
                     if (act2_out) *reinterpret_cast<float4 *>(act2_out + (b * kM2 + pix) * 64 + nt * 32 + 8 * g + 4 * h) = v;
                     if constexpr (H16) {
+                        top = fmaxf(fmaxf(top, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
                         f16x4 part[2];
                         split2(v, part);
 #pragma unroll
@@ -754,6 +760,7 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
                         for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(a2p + pix * kPB2 + q * 128 + (nt * 32 + 8 * g + 4 * h) * 2) = part[q];
                     }
                 }
+                if (H16 && !(top <= 65504.0f)) atomicOr(range_flag, 2);
             }
         }
         __syncthreads();  // act2 is complete
@@ -856,10 +863,10 @@ __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused(const u8 *__restr
                                                                 float *__restrict__ act3,
                                                                 float *__restrict__ act1_out, float *__restrict__ act2_out, unsigned long long *__restrict__ dbg,
                                                                 unsigned char *__restrict__ planes_out = nullptr, long long plane_rows = 0, long long n_samples = 0,
-                                                                long long first_sample = 0) {
+                                                                long long first_sample = 0, int *__restrict__ range_flag = nullptr) {
     // (a chip-filling pass may come as several launches of consecutive samples: first_sample)
     convnet_fused_body<BIG, C1B16, C23B16, PLANES, H16>(base, frame_off, wpk, b1, b2, b3, act3, act1_out, act2_out, dbg, planes_out, plane_rows, n_samples,
-                                                   (i64)blockIdx.x + first_sample, blockIdx.x == 0);
+                                                   (i64)blockIdx.x + first_sample, blockIdx.x == 0, range_flag);
 }
 
 // Several networks' image blocks over the SAME frames as ONE launch (round 6: Agent57_light's five networks all evaluate the state the ring commit has just made
@@ -870,13 +877,14 @@ constexpr int kMultiMax = 8;
 struct MultiNets {
     const float *wpk[kMultiMax], *b1[kMultiMax], *b2[kMultiMax], *b3[kMultiMax];
     float *act3[kMultiMax];
+    int *flag[kMultiMax];
 };
 template <bool H16>
 __global__ void __launch_bounds__(64 * kWaves) k_convnet_fused_multi(const u8 *__restrict__ base, const i64 *__restrict__ frame_off, MultiNets nets, long long n_samples) {
     const int net = (int)(blockIdx.x / (unsigned)n_samples);
     const i64 b = (i64)(blockIdx.x % (unsigned)n_samples);
     convnet_fused_body<true, true, true, 1, H16>(base, frame_off, nets.wpk[net], nets.b1[net], nets.b2[net], nets.b3[net], nets.act3[net], nullptr, nullptr, nullptr, nullptr, 0,
-                                            n_samples, b, false);
+                                                 n_samples, b, false, nets.flag[net]);
 }
 
 }  // namespace
@@ -960,7 +968,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     // cut into chunks of consecutive samples so that the update's kernels get compute units earlier: -1.1 % / +0.4 % per lock-step on two boxes; profiles/NOTES.md.)
     auto launch = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
-                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch, 0ll);
+                           keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch, 0ll, h->range_flag);
     };
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
     const bool h16 = srlx_conv_h16();
@@ -978,7 +986,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
         const long long prow = (batch + 127) / 128 * 128;
         auto launch2 = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
-                               keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)h->a3_planes, prow, (long long)batch, 0ll);
+                               keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)h->a3_planes, prow, (long long)batch, 0ll, h->range_flag);
         };
         h16 ? launch2(k_convnet_fused<false, true, true, 2, true>) : launch2(k_convnet_fused<false, true, true, 2>);
         h->a3_planes_fresh = true;
@@ -1014,7 +1022,7 @@ int srlx_qnet_fused_convs_multi(srlx_qnet *const *hs, int n, int64_t batch, cons
             h->pack_valid = h->pack_sticky;
         }
         h->wt_from_forward = false;
-        nets.wpk[k] = h->wpack, nets.b1[k] = h->b1, nets.b2[k] = h->b2, nets.b3[k] = h->b3, nets.act3[k] = reinterpret_cast<float *>(h->a3_planes);
+        nets.wpk[k] = h->wpack, nets.b1[k] = h->b1, nets.b2[k] = h->b2, nets.b3[k] = h->b3, nets.act3[k] = reinterpret_cast<float *>(h->a3_planes), nets.flag[k] = h->range_flag;
     }
     if (hs[0]->probe0) SRLX_HIP(hipEventRecord(hs[0]->probe0, st));
     if (srlx_conv_h16())

@@ -45,6 +45,7 @@ struct srlx_qnet {
     unsigned long long noisy_seed;
     int64_t *d_draw;                      // device: [0] id of the next draw, [1] id of the draw `eff` holds
     float *g_sig[6];                      // BORROWED gradient tensors of the sigmas (srlx_qnet_bind_noisy_grads)
+    int *range_flag;                      // device word: bit l set when an activation of layer l + 1 left float16's range in the two-part split (srlx_qnet_range_flags)
     void *fused_dbg;                      // optional device buffer [8 waves][8] of phase timestamps (srlx_qnet_set_debug; NULL in production)
     bool side_external;                   // h->side was handed in (srlx_qnet_set_side_stream): not ours to destroy
     bool wt_from_forward;                 // the last forward already built w_t / w_t2 (fused path of a training handle)

@@ -36,7 +36,7 @@ import torch
 from simple_distributed_rl_amd import _native as N
 from simple_distributed_rl_amd.algorithms._device_ops import NguOps
 from simple_distributed_rl_amd.device.agent57_light import UcbBank
-from simple_distributed_rl_amd.device.qnet import DeviceAdam, EngineHiddenNet, EngineQNet, QNetInference
+from simple_distributed_rl_amd.device.qnet import DeviceAdam, EngineHiddenNet, EngineQNet, QNetInference, check_ranges
 from simple_distributed_rl_amd.device.replay import DeviceReplay
 from simple_distributed_rl_amd.rl import functions as funcs
 
@@ -836,6 +836,7 @@ class Agent57LightFastEngine:
 
     def info(self) -> dict:
         self.join_learner()
+        check_ranges()
         d = dict(train_count=self.train_count, memory=self.lreplay.length())
         if self.train_count > 0:
             d.update(self.losses())

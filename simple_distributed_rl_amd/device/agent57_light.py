@@ -662,6 +662,9 @@ class Agent57LightEngine:
         torch.cuda.synchronize(self.dev)
 
     def info(self) -> dict:
+        from simple_distributed_rl_amd.device.qnet import check_ranges
+
+        check_ranges()
         d = dict(train_count=self.train_count, memory=self.replay.length())
         if self.train_count > 0:
             d.update(self.learner.losses())

@@ -22,7 +22,7 @@ import torch
 
 from simple_distributed_rl_amd import _native as N
 from simple_distributed_rl_amd.device.replay import DeviceReplay
-from simple_distributed_rl_amd.device.qnet import DeviceAdam, EngineQNet, QNetInference
+from simple_distributed_rl_amd.device.qnet import DeviceAdam, EngineQNet, QNetInference, check_ranges
 
 
 @dataclass
@@ -984,4 +984,5 @@ class RainbowEngine:
         self.join_learner()
         self.replay.flush_pending_add()
         self.lreplay.check_draws()
+        check_ranges()
         return dict(loss=float(self.loss.item()), train_count=self.train_count, sync=self.sync_count, memory=self.lreplay.length())

@@ -298,3 +298,48 @@ def test_adam_inside_the_gradient_launches_equals_the_optimiser_launch():
         qb.backward_u8(ring.data_ptr(), off, grads[0], sample_stride=stride)
     qb.publish_to(None, 0, bump=steps_b)
     torch.cuda.synchronize()
+
+
+def test_two_part_float16_split_error_and_its_range_flag():
+    """Round 6: the fused convolution kernel's products are three exact products of two float16 parts per operand (x = hi + lo / 2048).  (a) Against a float64
+    evaluation of the same network the Q-values are within 1e-6 of max |Q| (measured 2.9e-7: float32 accumulation round-off, the same as the three-part bf16 split
+    and the float32 pipe, tools/conv_split_error.py) -- also with filters 8 x larger and 20 x smaller than the initialisation's.  (b) An activation above 65 504 does
+    not fit float16: the kernel then sets a bit of the handle's range word and `check_ranges` (called by every engine's info()) raises -- never a silent wrong value."""
+    import copy
+
+    from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference, check_ranges
+
+    B, F = 96, 84 * 84
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ring = torch.randint(0, 256, (300 * F,), dtype=torch.uint8, device="cuda", generator=g)
+    idx = torch.randint(0, 300, (B, 4), device="cuda", generator=g)
+    frames = ring.view(300, 84, 84).cpu()[idx.cpu()].double() / 255.0
+    for scale in (1.0, 8.0, 0.05):
+        torch.manual_seed(0)
+        net = EngineQNet(6).cuda()
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if "conv" in name and p.dim() == 4:
+                    p.mul_(scale)
+        qn = QNetInference(net, B)
+        q = qn.forward_u8(ring.data_ptr(), idx * F).double().cpu()
+        with torch.no_grad():
+            q64 = copy.deepcopy(net).double().cpu()(frames)
+        assert float((q - q64).abs().max()) <= 1e-6 * float(q64.abs().max()), scale
+        check_ranges()
+        del qn
+    # (b) conv1 filters large enough that act1 passes 65 504
+    torch.manual_seed(0)
+    net = EngineQNet(6).cuda()
+    with torch.no_grad():
+        net.conv1.weight.fill_(600.0)  # 256 inputs x ~0.5 x 600 = 76 800
+    qn = QNetInference(net, B)
+    qn.forward_u8(ring.data_ptr(), idx * F)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="65504"):
+        check_ranges()
+    del qn
+    import gc
+
+    gc.collect()
+    check_ranges()  # the flagged handle is gone: nothing to report

@@ -179,8 +179,9 @@ def test_backward_u8_matches_autograd(A, dueling, B, stride, hw, hidden):
 
 
 def test_the_bf16_pipe_equals_the_float32_pipe(tmp_path):
-    """The forward pass evaluates its float32 products on v_mfma_f32_32x32x16_bf16 as exact partial products of bf16 parts (conv1: the pixel is ONE
-    bf16, the filter / 255 three parts; conv2 / conv3 and FC1: six of the nine products of three parts each), float32 accumulation.  Against the same
+    """The forward pass evaluates its float32 products on the 16-bit matrix pipe as exact partial products, float32 accumulation: the convolutions of TWO float16
+    parts per operand (round 6; conv1: the pixel is one f16, the filter two parts; conv2 / conv3: three of the four products), the first dense layer of three bf16
+    parts (six of the nine products); SRLX_CONV_BF16X3=1 = the convolutions of rounds 3-5 (three bf16 parts: 3 / 6 products).  Against the same
     kernels on the float32 pipe (SRLX_CONV1_F32=1 for the convolutions, SRLX_FC1_F32=1 for the dense layer; switches are read once per process, hence
     the subprocesses): Q-values within 2e-6 of max |Q| -- float32 round-off of different summation orders; and the float32-pipe fused kernel stays
     bit-identical to the three-launch path."""
@@ -200,16 +201,17 @@ def test_the_bf16_pipe_equals_the_float32_pipe(tmp_path):
     )
     outs = {}
     for name, env in (("bf16", {}), ("f32", {"SRLX_CONV1_F32": "1"}), ("three_launches", {"SRLX_NO_FUSED_CONV": "1"}),
-                      ("all_f32", {"SRLX_CONV1_F32": "1", "SRLX_FC1_F32": "1"}), ("convs_bf16_only", {"SRLX_FC1_F32": "1"})):
+                      ("all_f32", {"SRLX_CONV1_F32": "1", "SRLX_FC1_F32": "1"}), ("convs_bf16_only", {"SRLX_FC1_F32": "1"}),
+                      ("bf16x3", {"SRLX_CONV_BF16X3": "1"})):  # (round 6: "bf16" = the default = two float16 parts in the convolutions; bf16x3 = rounds 3-5's three bf16 parts)
         path = str(tmp_path / f"q_{name}.pt")
-        e = {k: v for k, v in os.environ.items() if k not in ("SRLX_CONV1_F32", "SRLX_CONV23_F32", "SRLX_FC1_F32", "SRLX_NO_FUSED_CONV")}
+        e = {k: v for k, v in os.environ.items() if k not in ("SRLX_CONV1_F32", "SRLX_CONV23_F32", "SRLX_FC1_F32", "SRLX_NO_FUSED_CONV", "SRLX_CONV_BF16X3")}
         e.update(env)
         r = subprocess.run([sys.executable, "-c", script, path], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = torch.load(path)
     assert torch.equal(outs["f32"], outs["three_launches"])
     scale = float(outs["all_f32"].abs().max())
-    for a, b in (("bf16", "f32"), ("bf16", "all_f32"), ("convs_bf16_only", "all_f32"), ("f32", "all_f32")):
+    for a, b in (("bf16", "f32"), ("bf16", "all_f32"), ("convs_bf16_only", "all_f32"), ("f32", "all_f32"), ("bf16x3", "all_f32"), ("bf16x3", "bf16")):
         diff = float((outs[a] - outs[b]).abs().max())
         assert 0 < scale and 0 < diff <= 2e-6 * scale, (a, b, diff, scale)
 

@@ -50,6 +50,10 @@ constexpr size_t kOffA1P = 4 * kFrame + (size_t)kM2 * kS2 * 4;
 constexpr size_t kLdsPlanes = kOffA1P + (size_t)kM1 * kPB1;
 constexpr size_t kLdsBytes = kLdsPlanes > kLdsF32 ? kLdsPlanes : kLdsF32;
 static_assert((size_t)kM2 * kPB2 <= kOffA1P && kOffA1P % 16 == 0 && kLdsBytes <= 160 * 1024, "LDS plan of the split-bf16 kernel");
+// what the float16 kernel asks for: act1 planes end at 127 392, the K-quarter scratch (96 KB behind the act2 planes) at 132 096 -- 28 KB of the CU's LDS stay free for a
+// neighbour's workgroup (the learner's small kernels run beside the actors' pass)
+constexpr size_t kLdsH16A = kOffA1P + (size_t)kM1 * kPB1h, kLdsH16B = ((size_t)kM2 * kPB2h + 1023) / 1024 * 1024 + 2 * 4 * 3 * 4 * 64 * 16;
+constexpr size_t kLdsH16 = kLdsH16A > kLdsH16B ? kLdsH16A : kLdsH16B;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -731,7 +735,7 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
         f32x16 acc4[2][2];
         // the K-quarter partials park in the 96 KB behind the act2 planes: act1 (and the tail of conv1's filter region) is dead once conv2's block loops are done
         constexpr size_t kOffScratch = ((size_t)kM2 * PB2 + 1023) / 1024 * 1024;
-        static_assert(kOffScratch + kScratchBytes <= kLdsBytes, "reduction scratch");
+        static_assert(kOffScratch + kScratchBytes <= (H16 ? kLdsH16 : kLdsBytes), "reduction scratch");
         float *scratch = reinterpret_cast<float *>(smem + kOffScratch);
         const bf16x8 *wf2 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B), *wf3 = reinterpret_cast<const bf16x8 *>(wpk + kW1 + kW2 + kW3 + kW1B + kW2B);
         block_planes<2, H16>(a1p, wf2, blk, kq, lane, acc4);
@@ -964,14 +968,15 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
     h->wt_from_forward = keep;
     static const bool c1_f32 = getenv("SRLX_CONV1_F32") && getenv("SRLX_CONV1_F32")[0] == '1';  // A/B switch: conv1 on the float32 matrix pipe
     float *out3 = h->act3;
+    const bool h16 = srlx_conv_h16();
+    const size_t lds = h16 && !c1_f32 ? kLdsH16 : kLdsBytes;
     // one workgroup per sample.  (Measured and dropped in round 4: fewer, sample-walking workgroups -- the loop form cost 20 % in code generation -- and the launch
     // cut into chunks of consecutive samples so that the update's kernels get compute units earlier: -1.1 % / +0.4 % per lock-step on two boxes; profiles/NOTES.md.)
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
+        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), lds, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
                            keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)nullptr, 0ll, (long long)batch, 0ll, h->range_flag);
     };
     static const bool c23_f32 = getenv("SRLX_CONV23_F32") && getenv("SRLX_CONV23_F32")[0] == '1';  // A/B switch: conv2 / conv3 on the float32 matrix pipe
-    const bool h16 = srlx_conv_h16();
     if (h->probe0 && hipEventRecord(h->probe0, st) != hipSuccess) return false;  // measurement hook: exactly this kernel, on its launch stream
     // the dense layers will run on operand planes (srlx_qnet_dense_rows's own condition): conv3 writes them itself, float32 act3 is not produced
     static const bool no_planes_out = (getenv("SRLX_NO_CONV_PLANES") && getenv("SRLX_NO_CONV_PLANES")[0] == '1') ||  // A/B switch: float32 act3 + a split pass
@@ -985,7 +990,7 @@ bool srlx_qnet_fused_convs(srlx_qnet *h, int64_t batch, const uint8_t *d_frame_b
         // a learner's pass (96 / 128 rows; `planes_small`): float32 act3 for its backward pass AND the planes for the first dense layer, rows padded to the GEMM's tile
         const long long prow = (batch + 127) / 128 * 128;
         auto launch2 = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
+            hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * kWaves), lds, st, d_frame_base, d_frame_off, h->wpack, h->b1, h->b2, h->b3, out3,
                                keep ? h->act1 : nullptr, keep ? h->act2 : nullptr, (unsigned long long *)h->fused_dbg, (unsigned char *)h->a3_planes, prow, (long long)batch, 0ll, h->range_flag);
         };
         h16 ? launch2(k_convnet_fused<false, true, true, 2, true>) : launch2(k_convnet_fused<false, true, true, 2>);
@@ -1026,7 +1031,7 @@ int srlx_qnet_fused_convs_multi(srlx_qnet *const *hs, int n, int64_t batch, cons
     }
     if (hs[0]->probe0) SRLX_HIP(hipEventRecord(hs[0]->probe0, st));
     if (srlx_conv_h16())
-        hipLaunchKernelGGL(k_convnet_fused_multi<true>, dim3((unsigned)(n * batch)), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, nets, (long long)batch);
+        hipLaunchKernelGGL(k_convnet_fused_multi<true>, dim3((unsigned)(n * batch)), dim3(64 * kWaves), kLdsH16, st, d_frame_base, d_frame_off, nets, (long long)batch);
     else
         hipLaunchKernelGGL(k_convnet_fused_multi<false>, dim3((unsigned)(n * batch)), dim3(64 * kWaves), kLdsBytes, st, d_frame_base, d_frame_off, nets, (long long)batch);
     if (hs[0]->probe1) SRLX_HIP(hipEventRecord(hs[0]->probe1, st));

@@ -376,7 +376,11 @@ __global__ void __launch_bounds__(256) k_gemm(AL al, const float *__restrict__ B
 // splitting pass over the 32 MB weight per forward, act3 written as planes by the convolution kernel -- were built first and measured slower inside
 // the lock-step loop: 0.573 against 0.545 ms.)  Tiles, split-K and XCD-aware order as k_gemm.
 constexpr int kRowB = 80;  // LDS bytes per tile row: 32 bf16 (64 B) + 16 B pad: the 16 lanes of a ds_read_b128 pass start 20 banks apart
-template <class AL, int BN, bool SPLITK, int TBM = 128>
+// H16 (round 6; the first dense layer's FORWARD only): two float16 parts per operand, hi = f16(x), lo = f16((x - hi) * 2048) -- three exact products per 16 K into an unscaled
+// and a 2^11-scaled accumulator, joined once per split (srlx_qnet_fused.hip has the derivation; forward error = float32 round-off) instead of six of three bf16 parts.
+// The data-gradient GEMMs stay on the three-part bf16 split: gradients live far below float16's normal range.  Per 16-k step, in this order: lo += a_lo b_hi,
+// lo += a_hi b_lo, acc += a_hi b_hi -- the order k_fc1_planes / k_fc1_planes_h keep (bit-identical results).
+template <class AL, int BN, bool SPLITK, int TBM = 128, bool H16 = false>
 __global__ void __launch_bounds__(256) k_gemm_s16(AL al, const float *__restrict__ Bw, float *__restrict__ C, i64 M, int N, int K, int k_per_split, i64 zstride_w = 0,
                                                   i64 zstride_c = 0) {
     if (!SPLITK) {  // batched GEMMs (blockIdx.z): same A loader, one weight matrix and one output per z
@@ -400,11 +404,14 @@ __global__ void __launch_bounds__(256) k_gemm_s16(AL al, const float *__restrict
     const int kbeg = SPLITK ? bz * k_per_split : 0;
     const int kend = SPLITK ? (kbeg + k_per_split < K ? kbeg + k_per_split : K) : K;
     const int wn = wave % WN, wm = wave / WN;
-    f32x16 acc[MT];
+    f32x16 acc[MT], lo[H16 ? MT : 1];
 #pragma unroll
     for (int a = 0; a < MT; a++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+        for (int r = 0; r < 16; r++) {
+            acc[a][r] = 0.f;
+            if constexpr (H16) lo[a][r] = 0.f;
+        }
     const int lrow = t >> 3, c4 = (t & 7) * 4;  // this lane stages rows lrow + 32 j, columns c4..c4+3 of a tile (as k_gemm)
     typename AL::Row rows[MR];
 #pragma unroll
@@ -421,6 +428,18 @@ __global__ void __launch_bounds__(256) k_gemm_s16(AL al, const float *__restrict
     };
     auto put = [&](unsigned char *tile, int rows_, int row, const float4 &x) __attribute__((always_inline)) {  // three bf16 parts of four floats -> the three plane tiles
         float r[4] = {x.x, x.y, x.z, x.w};
+        if constexpr (H16) {
+            typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+            f16x4 hp, lp;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const _Float16 hi = (_Float16)r[j];
+                hp[j] = hi, lp[j] = (_Float16)((r[j] - (float)hi) * 2048.0f);
+            }
+            *reinterpret_cast<f16x4 *>(&tile[row * kRowB + 2 * c4]) = hp;
+            *reinterpret_cast<f16x4 *>(&tile[(rows_ + row) * kRowB + 2 * c4]) = lp;
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -444,6 +463,23 @@ __global__ void __launch_bounds__(256) k_gemm_s16(AL al, const float *__restrict
         if (k0 + BK < kend) fetch(k0 + BK);  // overlaps with the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
+            if constexpr (H16) {
+                typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+                f16x8 bh[2], ah[MT][2];
+#pragma unroll
+                for (int p = 0; p < 2; p++) bh[p] = *reinterpret_cast<const f16x8 *>(&Bs[(p * BN + wn * 32 + i) * kRowB + (2 * ks + h) * 16]);
+#pragma unroll
+                for (int ms = 0; ms < MT; ms++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++) ah[ms][p] = *reinterpret_cast<const f16x8 *>(&As[(p * TBM + wm * 32 * MT + ms * 32 + i) * kRowB + (2 * ks + h) * 16]);
+#pragma unroll
+                for (int ms = 0; ms < MT; ms++) lo[ms] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ms][1], bh[0], lo[ms], 0, 0, 0);
+#pragma unroll
+                for (int ms = 0; ms < MT; ms++) lo[ms] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ms][0], bh[1], lo[ms], 0, 0, 0);
+#pragma unroll
+                for (int ms = 0; ms < MT; ms++) acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ms][0], bh[0], acc[ms], 0, 0, 0);
+                continue;
+            }
             bf16x8 bf[3];
 #pragma unroll
             for (int p = 0; p < 3; p++) bf[p] = *reinterpret_cast<const bf16x8 *>(&Bs[(p * BN + wn * 32 + i) * kRowB + (2 * ks + h) * 16]);
@@ -468,7 +504,9 @@ __global__ void __launch_bounds__(256) k_gemm_s16(AL al, const float *__restrict
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const i64 m = m0 + wm * 32 * MT + ms * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m < M && n < N) Cz[m * N + n] = acc[ms][r];
+            float out = acc[ms][r];
+            if constexpr (H16) out = __builtin_fmaf(lo[ms][r], 1.0f / 2048.0f, out);
+            if (m < M && n < N) Cz[m * N + n] = out;
         }
 }
 
@@ -842,7 +880,7 @@ int srlx_qnet_dense_rows(srlx_qnet *h, int64_t B, int64_t stride, float *d_q, hi
     } else if (!fc1_f32 && h->flat % BK == 0) {
         const dim3 grid((unsigned)((B + 127) / 128), (unsigned)((N1 + 63) / 64), (unsigned)splits);
         APlain fa{h->act3, (i64)h->flat * stride};
-        hipLaunchKernelGGL((k_gemm_s16<APlain, 64, true>), grid, dim3(256), 0, st, fa, h->wf, h->partial, B, N1, h->flat, kps * BK);
+        hipLaunchKernelGGL((k_gemm_s16<APlain, 64, true, 128, true>), grid, dim3(256), 0, st, fa, h->wf, h->partial, B, N1, h->flat, kps * BK);
     } else {
         APlain fa{h->act3, (i64)h->flat * stride};
         launch_gemm<APlain, 64, false, true>(fa, h->wf, nullptr, h->partial, B, N1, h->flat, splits, st);

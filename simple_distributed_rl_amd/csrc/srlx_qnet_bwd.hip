@@ -190,13 +190,13 @@ __global__ void __launch_bounds__(256) k_hidden_bwd(int B, i64 sstride, int N1, 
 // 16 weights and their two moment estimates in place (their loads are issued before the MFMAs): 226 MB of traffic for
 // "write g, then Adam" becomes 161 MB, and the update of 97 % of the parameters runs beside the convolution gradients instead
 // of after them.  Both variants run the same instruction sequence, so the fused update is bit-equal to the separate one.
-// PLANES (with ADAM): the updated weight is ALSO written as the three bf16 part planes the actors' first dense layer multiplies (srlx_fc1_planes.hip, weight layout
-// [K/32 slabs][N1 rows][3 parts][4 k-groups][8 bf16]): a lane holds column k0 + i of sixteen rows, so part p of a row's 32 k is 64 contiguous bytes written by the
+// PLANES (with ADAM): the updated weight is ALSO written as the two float16 part planes the actors' first dense layer multiplies (srlx_fc1_planes.hip, weight layout
+// [K/32 slabs][N1 rows][2 parts][4 k-groups][8 f16]; three bf16 parts in rounds 4-5): a lane holds column k0 + i of sixteen rows, so part p of a row's 32 k is 64 contiguous bytes written by the
 // 32 lanes of a half-wave, two bytes each -- the actors' private copy of 97 % of the parameters needs neither a copy nor a splitting pass on the lock-step's tail.
 template <bool ADAM, bool PLANES = false>
 __global__ void __launch_bounds__(256) k_fc1_wgrad(int B, i64 sstride, int N1, int K, const float *__restrict__ dh1, const float *__restrict__ act3,
                                                    float *__restrict__ g_wf, float *__restrict__ wf, float *__restrict__ m, float *__restrict__ v, double lr, double beta1,
-                                                   double beta2, double eps, const i64 *__restrict__ d_step, __bf16 *__restrict__ planes = nullptr) {
+                                                   double beta2, double eps, const i64 *__restrict__ d_step, _Float16 *__restrict__ planes = nullptr) {
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32, n0 = blockIdx.y * 32;
     if (k0 >= K) return;  // (wave-uniform; no barriers in this kernel)
@@ -231,14 +231,10 @@ __global__ void __launch_bounds__(256) k_fc1_wgrad(int B, i64 sstride, int N1, i
             srlx::adam_one(pp[r], acc[r], mm[r], vv[r], c);
             wf[at] = pp[r], m[at] = mm[r], v[at] = vv[r];
             if (PLANES) {
-                __bf16 *row = planes + (((i64)(k0 >> 5) * N1 + n0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 96) + i;  // 96 bf16 per (slab, row); part p at + 32 p
-                float x = pp[r];
-#pragma unroll
-                for (int p = 0; p < 3; p++) {
-                    const __bf16 b = (__bf16)x;
-                    row[32 * p] = b;
-                    x -= (float)b;
-                }
+                _Float16 *row = planes + (((i64)(k0 >> 5) * N1 + n0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64) + i;  // 64 f16 per (slab, row): hi at + 0, lo at + 32
+                const _Float16 hi = (_Float16)pp[r];
+                row[0] = hi;
+                row[32] = (_Float16)((pp[r] - (float)hi) * 2048.0f);
             }
         }
     } else {
@@ -843,7 +839,7 @@ static int conv_chain(srlx_qnet_t *h, int B, i64 ss, const uint8_t *d_frame_base
     auto launch_fc1_adam = [&](hipStream_t s2) {
         if (h->adam_planes_out)
             hipLaunchKernelGGL((k_fc1_wgrad<true, true>), fg, dim3(256), 0, s2, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v,
-                               h->adam_lr, h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step, (__bf16 *)h->adam_planes_out);
+                               h->adam_lr, h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step, (_Float16 *)h->adam_planes_out);
         else
             hipLaunchKernelGGL(k_fc1_wgrad<true>, fg, dim3(256), 0, s2, B, ss, N1, K, h->dh1, h->act3, nullptr, const_cast<float *>(h->wf), h->adam_m, h->adam_v, h->adam_lr,
                                h->adam_b1, h->adam_b2, h->adam_eps, h->adam_step);

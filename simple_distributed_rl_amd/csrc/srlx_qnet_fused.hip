@@ -772,38 +772,42 @@ __device__ __forceinline__ void convnet_fused_body(const u8 *__restrict__ base, 
         block_planes<3, H16>(a2p, wf3, blk, kq, lane, acc4);
         const f32x16 sum = reduce_quarters(scratch, blk, kq, lane, acc4);
         if constexpr (PLANES != 0) {
-            // The operand planes of one sample are 242 chunks of 192 bytes (K-slab = (pixel, channel half): [4 k-groups][3 parts][8 bf16]) at a stride of rows * 192 bytes.
-            // Written from the accumulator layout they were 8-byte pieces, every lane of a store instruction in a line of its own: 12 instructions x 64 lines per wave,
-            // ~6 k clocks of the CU's store path per sample (a seventh of the kernel).  Now the tile's parts are parked in LDS ([channel half][k-group][part][pixel] x 16
-            // bytes: conflict-free for the writers; 129-pixel stride: at most three-way conflicts for the readers) and leave as 16-byte pieces, twelve consecutive lanes
-            // per chunk: 2 lines per chunk instead of 24 line visits.
+            // The operand planes of one sample are 242 chunks of 128 bytes (K-slab = (pixel, channel half): [4 k-groups][2 float16 parts][8]; srlx_fc1_planes.hip) at a
+            // stride of rows * 128 bytes.  Written from the accumulator layout they would be 8-byte pieces, every lane of a store instruction in a line of its own (that
+            // cost ~6 k clocks of the CU's store path per sample with the three-part planes of rounds 3-5).  The tile's parts are parked in LDS ([channel half][k-group]
+            // [part][pixel] x 16 bytes: conflict-free for the writers; 129-pixel stride: at most three-way conflicts for the readers) and leave as 16-byte pieces, eight
+            // consecutive lanes per chunk = one full line.  These planes are ALWAYS the two-part float16 split (the first dense layer has no bf16 variant any more):
+            // an activation above 65 504 sets bit 2 of the handle's range word.
             constexpr int kStg = 129 * 16;
-            static_assert(24 * kStg <= kOffScratch + kScratchBytes, "plane staging");
+            static_assert(16 * kStg <= kOffScratch + kScratchBytes, "plane staging");
             unsigned char *stg = smem;
             __syncthreads();  // every owner has read its partial sums: the scratch (and the act2 planes in front of it) may be overwritten
             if (pix < kM2) {
+                float top = 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const float4 v = bias_relu4(sum, g, *reinterpret_cast<const float4 *>(b3 + nt * 32 + 8 * g + 4 * h));
                     if constexpr (PLANES == 2) *reinterpret_cast<float4 *>(act3 + (b * kM2 + pix) * 64 + nt * 32 + 8 * g + 4 * h) = v;
-                    bf16x4 part[3];
-                    split3(v, part);
+                    top = fmaxf(fmaxf(top, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                    f16x4 part[2];
+                    split2(v, part);
 #pragma unroll
-                    for (int q = 0; q < 3; q++) *reinterpret_cast<bf16x4 *>(stg + ((nt * 4 + g) * 3 + q) * kStg + pix * 16 + h * 8) = part[q];
+                    for (int q = 0; q < 2; q++) *reinterpret_cast<f16x4 *>(stg + ((nt * 4 + g) * 2 + q) * kStg + pix * 16 + h * 8) = part[q];
                 }
+                if (!(top <= 65504.0f)) atomicOr(range_flag, 4);
             }
             __syncthreads();
-            // chunk piece c = slab * 12 + (k-group * 3 + part), slab = pixel * 2 + channel half: destination ((slab * rows + b) * 4 + k-group) * 48 + part * 16
+            // chunk piece c = slab * 8 + (k-group * 2 + part), slab = pixel * 2 + channel half: destination ((slab * rows + b) * 8 + k-group * 2 + part) * 16
             const i64 rows = PLANES == 2 ? (i64)plane_rows : (i64)n_samples;
-            unsigned char *dst = (PLANES == 2 ? planes_out : reinterpret_cast<unsigned char *>(act3)) + b * 192;
-            constexpr int kPieces = 2 * kM2 * 12;
+            unsigned char *dst = (PLANES == 2 ? planes_out : reinterpret_cast<unsigned char *>(act3)) + b * 128;
+            constexpr int kPieces = 2 * kM2 * 8;
 #pragma unroll
             for (int k = 0; k < (kPieces + NT - 1) / NT; k++) {
                 const int c = t + NT * k;
                 if (c < kPieces) {
-                    const int sl = c / 12, w = c - sl * 12;
-                    const uint4 val = *reinterpret_cast<const uint4 *>(stg + ((sl & 1) * 12 + w) * kStg + (sl >> 1) * 16);
-                    *reinterpret_cast<uint4 *>(dst + (i64)sl * rows * 192 + w * 16) = val;
+                    const int sl = c >> 3, w = c & 7;
+                    const uint4 val = *reinterpret_cast<const uint4 *>(stg + ((sl & 1) * 8 + w) * kStg + (sl >> 1) * 16);
+                    *reinterpret_cast<uint4 *>(dst + (i64)sl * rows * 128 + w * 16) = val;
                 }
             }
         } else if (pix < kM2) {

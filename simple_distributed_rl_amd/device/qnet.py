@@ -14,6 +14,7 @@ the actor's policy step and the learner's online/target evaluation of s_1..s_n, 
 straight from the ring.
 """
 import ctypes
+import threading
 import weakref
 from typing import Optional
 
@@ -283,14 +284,17 @@ _LIVE_HANDLES = weakref.WeakSet()  # every wrapper of a srlx_qnet handle (check_
 def check_ranges():
     """Raises if a fused convolution pass of ANY live handle met an activation outside float16's range (the two-part split of round 6 cannot hold it: that pass's
     values are meaningless).  Reads one device word per handle: called where the host synchronises anyway (the engines' info())."""
+    me = threading.get_ident()  # (handles of the calling thread only: a rank-per-thread job's other threads create and destroy theirs concurrently)
     for w in list(_LIVE_HANDLES):
-        if getattr(w, "h", None):
+        if getattr(w, "h", None) and getattr(w, "_owner_thread", None) == me:
             bits = ctypes.c_int(0)
             N.check(w.lib.srlx_qnet_range_flags(w.h, ctypes.byref(bits)))
             if bits.value:
-                layers = " and ".join(f"conv{l + 1}" for l in range(2) if bits.value >> l & 1)
-                raise RuntimeError(f"srlx: an activation of {layers} exceeded 65504, the range of the fused convolution kernel's two-part float16 split -- its outputs since then "
-                                   "are not the network's.  Run the process with SRLX_CONV_BF16X3=1 (three-part bf16 split, float32's range).")
+                layers = " and ".join(f"conv{l + 1}" for l in range(3) if bits.value >> l & 1)
+                raise RuntimeError(f"srlx: an activation of {layers} exceeded 65504, the range of the two-part float16 split the fused convolution kernel and the first dense "
+                                   "layer evaluate their float32 products with -- the outputs since then are not the network's.  Run the process with SRLX_CONV_BF16X3=1 "
+                                   "(convolutions on the three-part bf16 split, float32's range) and, if conv3 is named, SRLX_FC1_F32=1 SRLX_NO_CONV_PLANES=1 (first dense layer "
+                                   "on the float32 matrix pipe).")
 
 
 class QNetInference:
@@ -310,6 +314,7 @@ class QNetInference:
                                       _DUELING[net.dueling_type], self.max_batch, int(device))
         )
         self.h = hh
+        self._owner_thread = threading.get_ident()
         _LIVE_HANDLES.add(self)
         self.q = torch.zeros((self.max_batch, self.n_actions), dtype=torch.float32, device=self.dev)
         self.bind()
@@ -611,6 +616,7 @@ class ImageTrunk:
         hh = N.c_p()
         N.check(self.lib.srlx_qnet_create(ctypes.byref(hh), int(hw[0]), int(hw[1]), c1.in_channels, c1.out_channels, 32, 1, 0, self.max_batch, int(device)))
         self.h = hh
+        self._owner_thread = threading.get_ident()
         _LIVE_HANDLES.add(self)
         self._unused = torch.zeros(64, dtype=torch.float32, device=self.dev)  # the dense-layer entries of srlx_qnet_bind (never read by forward_convs)
         with torch.no_grad():

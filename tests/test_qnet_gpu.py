@@ -345,3 +345,18 @@ def test_two_part_float16_split_error_and_its_range_flag():
 
     gc.collect()
     check_ranges()  # the flagged handle is gone: nothing to report
+    # conv3's output feeds the first dense layer as two-part float16 operand planes (chip-filling launches): the same flag, bit 2
+    torch.manual_seed(0)
+    net = EngineQNet(6).cuda()
+    with torch.no_grad():
+        net.conv3.weight.fill_(1.0e4)
+    qn = QNetInference(net, 512)
+    qn.enable_fc1_planes(private_weights=True)
+    idx = torch.randint(0, 300, (512, 4), device="cuda", generator=g)
+    qn.forward_u8(ring.data_ptr(), idx * F)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="conv3"):
+        check_ranges()
+    del qn
+    gc.collect()
+    check_ranges()

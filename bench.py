@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--actor-stream", default="low", choices=["low", "normal", "high", "default"],
                     help="priority level of the stream the actors' side runs on (its own pool of hardware queues); default: torch's current stream")
     ap.add_argument("--predraw", action="store_true", help="the single-GPU engine draws the next update's batch behind this update's write-back (A/B; the default on learner-only ranks)")
-    ap.add_argument("--fc1-neighbour", type=int, default=None, help="K splits of the actors' half-CU first-dense-layer kernel (A/B; default: the schedule's 4; 0: the CU-filling kernel)")
+    ap.add_argument("--fc1-neighbour", type=int, default=None, help="K splits of the actors' half-CU first-dense-layer kernel (A/B; default: the schedule's 2; 0: the generic split count)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
     ap.add_argument("--no-per-micro", action="store_true", help="skip the PER micro-benchmark (sample / update / add ops/s, bulk-sample HBM fraction)")
@@ -478,7 +478,8 @@ def bench_agent57_light(args, dev_index, rank, world, dist=None, envs_per_gpu=No
         # (device/agent57_light.py) is a test yardstick now
         from simple_distributed_rl_amd.device.agent57_fast import Agent57LightFastEngine
 
-        eng = Agent57LightFastEngine(rl, E, dev_index, episode_len=args.episode_len, seed=0, overlap=None if not args.no_overlap else False, actor_stream=args.actor_stream)
+        eng = Agent57LightFastEngine(rl, E, dev_index, episode_len=args.episode_len, seed=0, overlap=None if not args.no_overlap else False, actor_stream=args.actor_stream,
+                                     **({"fc1_neighbour": int(args.fc1_neighbour)} if args.fc1_neighbour is not None else {}))
         eng.multi_trunk = not args.no_multi_trunk
         eng.prefill()
     fast_engine = True

@@ -92,7 +92,7 @@ class _Net:
 
 class Agent57LightFastEngine:
     def __init__(self, rl_config, n_envs: int, device: int = 0, episode_len: int = 200, seed: int = 0, env=None, parameter=None, ring_len: Optional[int] = None,
-                 overlap: Optional[bool] = None, fc1_neighbour: int = 4, fused_adam: bool = True, role: str = "both", learner_replay: Optional[DeviceReplay] = None,
+                 overlap: Optional[bool] = None, fc1_neighbour: int = 3, fused_adam: bool = True, role: str = "both", learner_replay: Optional[DeviceReplay] = None,
                  actor_stream: Optional[str] = None):
         """rl_config: a set-up algorithms.agent57_light.Config (84 x 84 x window-4 image observations); parameter: its Parameter (the five torch networks: the
         initial weights are taken from it, `export_parameter()` writes the trained ones back).  overlap (None = wherever it applies): the update beside the

@@ -32,7 +32,8 @@ class EngineSchedule:
     fast: Optional[bool] = None  # the round-4/5 lock-step wherever it applies (None), never (False), or raise where it does not (True: as RainbowEngine(fast=True))
     lagged_add: bool = True  # single-GPU fast lock-step: the tree add of lock-step t rides on a side branch of update t + 1 (False: the add behind the join, round 4's order)
     predraw: Optional[bool] = None  # the next update's batch drawn behind this update's write-back (None: on learner-only ranks)
-    fc1_neighbour: int = 4  # K splits of the actors' half-CU first-dense-layer kernel beside an update (0: the CU-filling kernel)
+    fc1_neighbour: int = 2  # K splits of the actors' first-dense-layer kernel beside an update = how many CUs its 64 tiles x splits workgroups take (2: half the chip stays with the update,
+    # +12 % per lock-step over 4 since the layer's matrix work halved in round 6: profiles/r6_ab_lockstep2.txt; 0: the generic split count of a pass that has the GPU to itself)
     fc1_planes: str = "auto"  # engines off the fast path: operand planes for chip-filling policy passes ("auto": only where no learner shares the GPU; "1" / "0")
     actor_stream: Optional[str] = None  # "low" / "normal" / "high": the actors' side on a stream of that priority level (None: the caller's current stream)
     learner_priority: int = -1  # priority of the learner's launch stream

@@ -537,12 +537,15 @@ int srlx_store_gather_obs(srlx_store_t *h, int64_t batch, int k_begin, int k_cou
 /* ------------------------------------------------------------------------------------
  * Q-network inference on the matrix cores: float32 in, float32 out, float32 accumulation everywhere.
  * Arithmetic: v_mfma_f32_32x32x2_f32 (products of two float32 operands), except where a float32 product is evaluated
- * on the 16x faster bf16 pipe (v_mfma_f32_32x32x16_bf16) as a sum of EXACT partial products -- a float32 is the sum of three bf16
- * parts exactly, a product of two bf16 is exact in the float32 accumulator: conv1 of the 84x84x4 geometry (the uint8 pixel is one
- * bf16, the filter / 255 three parts: all three products kept), conv2 / conv3 of that geometry and the first dense layer
- * (six of the nine partial products; the dropped ones are below 2^-24 |a b|).  Q-values agree with the all-float32 pipe to float32 round-off (< 1e-6
- * relative; the tolerance promised against the reference is 1e-5).  Environment switches SRLX_CONV1_F32=1 (all convolutions) / SRLX_CONV23_F32=1 /
- * SRLX_FC1_F32=1 (read once per process) keep them on the float32 pipe.
+ * on the 16x faster 16-bit pipe as a sum of EXACT partial products, each exact in the float32 accumulator.  FORWARD passes of the 84x84x4 geometry
+ * (round 6): two float16 parts per operand, x = hi + lo / 2048 with hi = f16(x), lo = f16((x - hi) * 2048) -- 22 significand bits, lo a normal float16
+ * wherever hi is -- on v_mfma_f32_32x32x16_f16: conv1 (the uint8 pixel is one float16, the filter two parts: two products), conv2 / conv3 and the first
+ * dense layer (three of the four products, the cross terms in a 2^11-scaled accumulator; the dropped one is below 2^-24 |a b|).  BACKWARD GEMMs: three bf16
+ * parts per operand on v_mfma_f32_32x32x16_bf16, six of the nine products (gradients live below float16's normal range).  Q-values agree with the
+ * all-float32 pipe to float32 round-off (3e-7 of max |Q| against float64 for either; the tolerance promised against the reference is 1e-5).  The float16
+ * split holds activations up to 65 504: srlx_qnet_range_flags reports a pass that met a larger one.  Environment switches (read once per process):
+ * SRLX_CONV_BF16X3=1 (convolutions on three bf16 parts, float32's range), SRLX_CONV1_F32=1 (all convolutions) / SRLX_CONV23_F32=1 / SRLX_FC1_F32=1
+ * keep them on the float32 pipe.
  *
  * Replaces the no-grad forwards of the reference's torch modules -- DQNImageBlock
  * (srl/rl/torch_/blocks/dqn_image_block.py:10-67) + DuelingNetworkBlock
@@ -657,8 +660,8 @@ int srlx_qnet_set_probe_fc1(srlx_qnet_t *h, void *ev_start, void *ev_end);
  * the queue wait an event bracket on the launch stream includes when other streams hold the compute units. */
 int srlx_qnet_set_fc1_span(srlx_qnet_t *h, uint64_t *d_span);
 /* The first dense layer of chip-filling launches (>= 512 rows, a multiple of 128: the actors' policy pass) on PRE-SPLIT operands.  The layer evaluates
- * float32 x float32 as six exact bf16 partial products; by default both operands are split while staging, in every workgroup, every K-slab.  A handle
- * with planes enabled keeps its weight as three bf16 parts ([unit][K/8][3][8 bf16], 1.5x the float32 bytes), the convolution kernel writes its output
+ * float32 x float32 as three exact products of two float16 parts per operand; by default both operands are split while staging, in every workgroup, every
+ * K-slab.  A handle with planes enabled keeps its weight as the two parts ([K/32][unit][2][4][8 f16]: the float32's own 4 bytes per value), the convolution kernel writes its output
  * in the same form, and the GEMM runs without conversions (bit-identical results).  The planes are a CACHE of the float32 weight: after every change of
  * the weight call srlx_qnet_refresh_fc1_planes (d_src_wf = NULL: split the bound weight; otherwise split `d_src_wf`, and when d_copy_dst != NULL also
  * write the float32 values there -- the per-lock-step refresh of an actor's private copy of the online network, play_mp.py:121-165, and its planes in

@@ -34,6 +34,8 @@ class EngineSchedule:
     predraw: Optional[bool] = None  # the next update's batch drawn behind this update's write-back (None: on learner-only ranks)
     fc1_neighbour: int = 2  # K splits of the actors' first-dense-layer kernel beside an update = how many CUs its 64 tiles x splits workgroups take (2: half the chip stays with the update,
     # +12 % per lock-step over 4 since the layer's matrix work halved in round 6: profiles/r6_ab_lockstep2.txt; 0: the generic split count of a pass that has the GPU to itself)
+    dgrad_split: Optional[int] = None  # K splits (1 / 2) of conv3's data-gradient GEMM in the update (None: 2; 1 = the summation order of engines off the fast path.  Beside the actors
+    # 2 did nothing while their first dense layer filled the chip (0.4184 / 0.4173 ms, round 5) and is worth 2 % since that layer takes half of it)
     fc1_planes: str = "auto"  # engines off the fast path: operand planes for chip-filling policy passes ("auto": only where no learner shares the GPU; "1" / "0")
     actor_stream: Optional[str] = None  # "low" / "normal" / "high": the actors' side on a stream of that priority level (None: the caller's current stream)
     learner_priority: int = -1  # priority of the learner's launch stream
@@ -318,7 +320,7 @@ class RainbowEngine:
             # (a learner-only rank: the first dense layer's weight gradient LAST on the weight-gradient branch, order 0 -- with the critical chain recorded first,
             # 0.300 ms per period against 0.343 on a branch of its own; same box, profiles/r5_ab_ingest_order.txt)
             N.check(self.lib.srlx_qnet_set_main_first(self.inf_online.h, 1))
-            if role == "learner":  # the GPU to itself: conv3's data-gradient GEMM as twice the workgroups, each half as long (-2 % per period)
+            if sch.dgrad_split is None or int(sch.dgrad_split) == 2:  # conv3's data-gradient GEMM as twice the workgroups, each half as long (-2 % per period / per lock-step)
                 N.check(self.lib.srlx_qnet_set_dgrad_split(self.inf_online.h, 2))
             if self._update_side:
                 N.check(self.lib.srlx_per_set_update_counter(self.lreplay.h_per, None))

@@ -199,10 +199,11 @@ def _engines(E=512, actor_stream=None, **cfgkw):
     kw = dict(n_envs=E, batch_size=32, memory_capacity=E * 12, memory_warmup_size=E * 4, target_model_update_interval=5, lr=1e-4, seed=3)
     kw.update(cfgkw)
     cfg = RainbowDeviceConfig(**kw)
-    # fc1_neighbour = 4: the K splits of the fifteen-launch engine's first dense layer (split-K partial sums associate alike, Q-values bit-equal); lagged_add off: the
+    # fc1_neighbour = 4, dgrad_split = 1: the K splits of the fifteen-launch engine's first dense layer and of its conv3 data-gradient GEMM (split-K partial sums associate
+    # alike, Q-values and gradients bit-equal); lagged_add off: the
     # tree add behind the join, as the fifteen-launch lock-step orders it (round 5's default runs it inside the NEXT update: the update then samples the tree one add
     # older -- pinned against the oracle in test_lagged_add_tree_order_against_the_oracle)
-    fast = RainbowEngine(dataclasses.replace(cfg, schedule=EngineSchedule(fc1_neighbour=4, lagged_add=False)), 0, episode_len=7, overlap=True, fast=True, actor_stream=actor_stream)
+    fast = RainbowEngine(dataclasses.replace(cfg, schedule=EngineSchedule(fc1_neighbour=4, lagged_add=False, dgrad_split=1)), 0, episode_len=7, overlap=True, fast=True, actor_stream=actor_stream)
     slow = RainbowEngine(cfg, 0, episode_len=7, overlap=True, fast=False)
     assert fast.fast and not slow.fast
     slow.q_online.load_state_dict(fast.q_online.state_dict())

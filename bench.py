@@ -51,7 +51,7 @@ def parse_args():
                     help="priority level of the stream the actors' side runs on (its own pool of hardware queues); default: torch's current stream")
     ap.add_argument("--predraw", action="store_true", help="the single-GPU engine draws the next update's batch behind this update's write-back (A/B; the default on learner-only ranks)")
     ap.add_argument("--dgrad-split", type=int, default=None, help="K splits (1 / 2) of conv3's data-gradient GEMM in the update (A/B; default: the schedule's)")
-    ap.add_argument("--fc1-neighbour", type=int, default=None, help="K splits of the actors' half-CU first-dense-layer kernel (A/B; default: the schedule's 2; 0: the generic split count)")
+    ap.add_argument("--fc1-neighbour", type=int, default=None, help="K splits of the actors' half-CU first-dense-layer kernel (A/B; default: the schedule's 4; 0: the generic split count)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--sync-interval", type=int, default=16, help="learner->actor weight broadcast every k steps (N>1)")
     ap.add_argument("--no-per-micro", action="store_true", help="skip the PER micro-benchmark (sample / update / add ops/s, bulk-sample HBM fraction)")

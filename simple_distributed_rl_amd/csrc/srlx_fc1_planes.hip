@@ -122,47 +122,54 @@ __global__ void __launch_bounds__(256) k_fc1_planes_h(const uint4 *__restrict__ 
 #pragma unroll
         for (int p = 0; p < 2; p++) fo[ks][p] = ((((2 * ks + h) * 2 + p) + rot) & 7) * 16;
     const int arow = (wm * 64 + i) * kHRow, brow = kHTile + (wn * 64 + i) * kHRow;
+    // Fragments are double-buffered per K-STEP (16 k), not per stage: f0 always holds a stage's first k-step, f1 its second -- 64 registers instead of 128.  (With
+    // whole-stage sets the kernel needed 256 + registers; the compiler parked accumulators in AGPRs and moved them in and out around every stage: 320 v_accvgpr
+    // moves per two stages, and on gfx950 vector instructions take their issue slots from the matrix pipe: 8.5 VALU instructions per MFMA by the SQ counters.)
     struct Frags {
-        f16x8 a[2][2][2], b[2][2][2];  // [k-step][tile][part]
+        f16x8 a[2][2], b[2][2];  // [tile][part]
     };
-    // 4 of a stage's 16 fragment reads: group g = 0..3 -> k-step g >> 1; g & 1 = 0: the A parts of both row tiles, 1: the B parts of both column tiles
-    auto read_group = [&](const unsigned char *buf, Frags &f, int g) __attribute__((always_inline)) {
-        const int ks = g >> 1;
+    // 4 of a k-step's 8 fragment reads: g = 0: the A parts of both row tiles, 1: the B parts of both column tiles
+    auto read_half = [&](const unsigned char *buf, Frags &f, int ks, int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int x = 0; x < 2; x++)
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                if (g & 1)
-                    f.b[ks][x][p] = *reinterpret_cast<const f16x8 *>(buf + brow + x * 32 * kHRow + fo[ks][p]);
+                if (g)
+                    f.b[x][p] = *reinterpret_cast<const f16x8 *>(buf + brow + x * 32 * kHRow + fo[ks][p]);
                 else
-                    f.a[ks][x][p] = *reinterpret_cast<const f16x8 *>(buf + arow + x * 32 * kHRow + fo[ks][p]);
+                    f.a[x][p] = *reinterpret_cast<const f16x8 *>(buf + arow + x * 32 * kHRow + fo[ks][p]);
             }
     };
     constexpr int pq[3][2] = {{1, 0}, {0, 1}, {0, 0}};  // (a part, b part): the two cross terms into `lo`, then hi x hi into `acc` (as k_gemm_s16<.., H16>)
-    auto body = [&](int st, int slot_next, int slot_free, const Frags &cur, Frags &nxt) __attribute__((always_inline)) {
-        if (st + 2 < nst)
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everybody's pieces of stage st + 1 have landed; every wave has finished READING stage st: its slot is free for stage st + 3
-        const bool rd = st + 1 < nst, dma = st + 3 < nst;
-        const unsigned char *buf = smem + slot_next * kHBuf;
+    // k-step (st, ks): multiplies it out of `cur`; reads the NEXT k-step's fragments -- (st, 1) out of this stage's slot, or (st + 1, 0) out of the next one's -- into
+    // `nxt`; a stage's second k-step starts with the stage's one barrier (stage st + 1 has landed for everybody; everybody has finished reading stage st: its slot
+    // takes the DMA of stage st + 3, issued between this k-step's MFMAs)
+    auto kstep = [&](int st, int ks, int slot_cur, int slot_next, const Frags &cur, Frags &nxt) __attribute__((always_inline)) {
+        if (ks == 1) {
+            if (st + 2 < nst)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const bool rd = ks == 0 || st + 1 < nst, dma = ks == 1 && st + 3 < nst;
+        const unsigned char *buf = smem + (ks == 0 ? slot_cur : slot_next) * kHBuf;
 #pragma unroll
-        for (int x = 0; x < 6; x++) {  // six steps of four MFMAs (one partial product of one k-step on the four accumulators); behind them a fragment-read group or four DMA pieces
-            const int ks = x / 3, c = x % 3;
+        for (int c = 0; c < 3; c++) {  // three steps of four MFMAs (one partial product on the four accumulator pairs); behind them fragment reads / DMA pieces
 #pragma unroll
             for (int ms = 0; ms < 2; ms++)
 #pragma unroll
                 for (int ns = 0; ns < 2; ns++) {
-                    f32x16 &d = c < 2 ? lo[ms][ns] : acc[ms][ns];
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[ks][ms][pq[c][0]], cur.b[ks][ns][pq[c][1]], d, 0, 0, 0);
+                    if (c < 2)
+                        lo[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[ms][pq[c][0]], cur.b[ns][pq[c][1]], lo[ms][ns], 0, 0, 0);
+                    else
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[ms][pq[c][0]], cur.b[ns][pq[c][1]], acc[ms][ns], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (x < 4) {
-                if (rd) read_group(buf, nxt, x);
-            } else if (dma) {
+            if (c < 2 && rd) read_half(buf, nxt, 1 - ks, c);
+            if (dma) {
 #pragma unroll
-                for (int v = 0; v < 4; v++) issue_piece(slot_free, st + 3, (x - 4) * 4 + v);
+                for (int v = (c * 8) / 3; v < ((c + 1) * 8) / 3; v++) issue_piece(slot_cur, st + 3, v);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -181,14 +188,14 @@ __global__ void __launch_bounds__(256) k_fc1_planes_h(const uint4 *__restrict__ 
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage 0 is in slot 0 for everybody
-#pragma unroll
-        for (int g = 0; g < 4; g++) read_group(smem, f0, g);
+        read_half(smem, f0, 0, 0);
+        read_half(smem, f0, 0, 1);
         int slot = 0;  // slot of stage st
-        for (int st = 0; st < nst; st += 2) {
-            const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-            body(st, s1, slot, f0, f1);
-            if (st + 1 < nst) body(st + 1, s2, s1, f1, f0);
-            slot = s2;
+        for (int st = 0; st < nst; st++) {
+            const int s1 = slot == 2 ? 0 : slot + 1;
+            kstep(st, 0, slot, s1, f0, f1);
+            kstep(st, 1, slot, s1, f1, f0);
+            slot = s1;
         }
     }
     float *Cz = C + (i64)bz * M * N;

@@ -32,8 +32,9 @@ class EngineSchedule:
     fast: Optional[bool] = None  # the round-4/5 lock-step wherever it applies (None), never (False), or raise where it does not (True: as RainbowEngine(fast=True))
     lagged_add: bool = True  # single-GPU fast lock-step: the tree add of lock-step t rides on a side branch of update t + 1 (False: the add behind the join, round 4's order)
     predraw: Optional[bool] = None  # the next update's batch drawn behind this update's write-back (None: on learner-only ranks)
-    fc1_neighbour: int = 2  # K splits of the actors' first-dense-layer kernel beside an update = how many CUs its 64 tiles x splits workgroups take (2: half the chip stays with the update,
-    # +12 % per lock-step over 4 since the layer's matrix work halved in round 6: profiles/r6_ab_lockstep2.txt; 0: the generic split count of a pass that has the GPU to itself)
+    fc1_neighbour: int = 4  # K splits of the actors' first-dense-layer kernel beside an update = how many CUs its 64 tiles x splits workgroups take.  Re-measure after every change of
+    # that kernel: round 6's first float16 version (accumulators shuttled through AGPRs: 8.5 vector instructions per MFMA) was best at 2 (half the chip left to the update: +12 %
+    # over 4); once its loop was clean (fragments double-buffered per k-step) 4 is 3 % ahead of 2 and 3 again (profiles/r6_ab_lockstep2.txt, r6_ab_lockstep3.txt).  0: generic count
     dgrad_split: Optional[int] = None  # K splits (1 / 2) of conv3's data-gradient GEMM in the update (None: 2; 1 = the summation order of engines off the fast path.  Beside the actors
     # 2 did nothing while their first dense layer filled the chip (0.4184 / 0.4173 ms, round 5) and is worth 2 % since that layer takes half of it)
     fc1_planes: str = "auto"  # engines off the fast path: operand planes for chip-filling policy passes ("auto": only where no learner shares the GPU; "1" / "0")

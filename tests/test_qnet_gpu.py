@@ -178,6 +178,35 @@ def test_backward_u8_matches_autograd(A, dueling, B, stride, hw, hidden):
         np.testing.assert_allclose(p.grad.cpu().numpy(), w.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg=name)
 
 
+def test_data_gradient_gemm_split_over_k_equals_the_unsplit_one():
+    """srlx_qnet_set_dgrad_split(h, 2): conv3's data-gradient GEMM as twice the workgroups over half the K range each (the pad-fold kernel adds the two partial slabs)
+    -- the same gradients as unsplit up to float32 association: 1e-6 of each tensor's largest entry (the fast engines run split, the fifteen-launch engine unsplit)."""
+    from simple_distributed_rl_amd import _native as N
+    from simple_distributed_rl_amd.device.qnet import EngineQNet, QNetInference
+
+    B, F, n_frames = 32, 84 * 84, 200
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ring = torch.randint(0, 256, (n_frames * F,), dtype=torch.uint8, device="cuda", generator=g)
+    off = torch.randint(0, n_frames, (B, 4), device="cuda", generator=g) * F
+    grad_q = torch.randn((B, 6), device="cuda", generator=g)
+    grads = []
+    for split in (1, 2):
+        torch.manual_seed(3)
+        net = EngineQNet(6).cuda()
+        qn = QNetInference(net, max_batch=64).enable_training(64)
+        N.check(qn.lib.srlx_qnet_set_dgrad_split(qn.h, split))
+        qn.forward_u8(ring.data_ptr(), off)
+        qn.backward_u8(ring.data_ptr(), off, grad_q)
+        torch.cuda.synchronize()
+        grads.append([p.grad.detach().clone() for p in qn._params()])
+    moved = 0.0
+    for a, b in zip(*grads):
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 1e-6 * scale
+        moved += float((a - b).abs().max())
+    assert moved > 0  # (the split really ran: the sums associate differently)
+
+
 def test_the_bf16_pipe_equals_the_float32_pipe(tmp_path):
     """The forward pass evaluates its float32 products on the 16-bit matrix pipe as exact partial products, float32 accumulation: the convolutions of TWO float16
     parts per operand (round 6; conv1: the pixel is one f16, the filter two parts; conv2 / conv3: three of the four products), the first dense layer of three bf16
